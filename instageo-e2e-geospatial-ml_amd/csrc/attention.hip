@@ -1,0 +1,468 @@
+// Fused multi-head self-attention for the Prithvi ViT blocks on gfx950 (head_dim = 64, no mask, no dropout).
+// Replaces timm Attention's F.scaled_dot_product_attention called from pritvhi.py:446-456.
+//
+// Layout: qkv [B][N][3][H][64] bf16 (the timm reshape(B,N,3,H,hd) of the fused qkv Linear), out [B][N][H*64].
+// Structure (all three kernels): one workgroup = NW waves (<=16) of one (batch, head); every wave OWNS a 16-row
+// tile (queries in fwd / dQ, keys in dK/dV) whose operands live in registers, while the other side is STREAMED
+// through LDS in 32-row tiles shared by all waves.  All products are MFMA 16x16x32 bf16 with the streamed index
+// on the accumulator ROW, so the probability tile is directly the B operand of the next product (no LDS round
+// trip); the transposed operands (V^T, K^T, dO^T, Q^T) come from ds_read_b64_tr_b16 on the row-major LDS tile.
+// N = 197 / 589 tokens are handled by zero-filled tails and -inf / +inf masks.
+// SPLIT=true is the bf16x3 precision mode (hi*hi + hi*lo + lo*hi).
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 64;
+constexpr int KT = 32;                 // streamed rows per tile
+constexpr int TILE = KT * HD * 2;      // 4 KiB per bf16 tile
+
+__device__ __forceinline__ int lds_kc(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
+
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+
+// row fragment: lane holds T[row0 + (l&15)][32*s + 8*(l>>4) + j]
+__device__ __forceinline__ bf16x8_t frag_rows(const char* tile, int row0, int s, int lane) {
+    return *reinterpret_cast<const bf16x8_t*>(tile + lds_kc(row0 + (lane & 15), s * 4 + (lane >> 4)));
+}
+// transposed fragment for the "accumulator as operand" k order: lane (g=l>>4,i=l&15) holds
+// T[4g + j][col0 + i] (j<4) and T[16 + 4g + (j-4)][col0 + i] (j>=4)
+__device__ __forceinline__ bf16x8_t frag_tr(const char* tile, int col0, int lane) {
+    int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    int col = col0 + 4 * p;
+    int chunk = col >> 3, sub = (col & 7) * 2;
+    s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tile + lds_kc(4 * g + q, chunk) + sub));
+    s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tile + lds_kc(16 + 4 * g + q, chunk) + sub));
+    s16x8 r = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    return __builtin_bit_cast(bf16x8_t, r);
+}
+
+template <bool SPLIT>
+__device__ __forceinline__ f32x4 mma(bf16x8_t ah, bf16x8_t al, bf16x8_t bh, bf16x8_t bl, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+    if constexpr (SPLIT) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// pack two accumulator tiles (rows 4g+reg of sub-tile 0 and 1) into the next product's B operand (hi [+ lo])
+template <bool SPLIT>
+__device__ __forceinline__ void pack_acc(const f32x4& a0, const f32x4& a1, bf16x8_t& hi, bf16x8_t& lo) {
+    float f[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    uint4 u = pack8(f);
+    hi = __builtin_bit_cast(bf16x8_t, u);
+    if constexpr (SPLIT) {
+        float h[8], r[8];
+        unpack8(u, h);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = f[i] - h[i];
+        uint4 v = pack8(r);
+        lo = __builtin_bit_cast(bf16x8_t, v);
+    }
+}
+
+// cooperative load of one 32 x 64 tile: rows [r0, r0+32) of a (token-major) slice, zero beyond nrows
+__device__ __forceinline__ void load_tile(char* tile, const bf16_t* base, long row_stride, int r0, int nrows, int tid, int nthr) {
+    for (int u = tid; u < KT * 8; u += nthr) {
+        int r = u >> 3, c = u & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r0 + r < nrows) v = *reinterpret_cast<const uint4*>(base + (long)(r0 + r) * row_stride + c * 8);
+        *reinterpret_cast<uint4*>(tile + lds_kc(r, c)) = v;
+    }
+}
+
+// register fragment of the wave-owned 16-row tile straight from global memory (zero beyond nrows)
+__device__ __forceinline__ bf16x8_t load_own(const bf16_t* base, long row_stride, int row0, int nrows, int s, int lane) {
+    int r = row0 + (lane & 15);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r < nrows) v = *reinterpret_cast<const uint4*>(base + (long)r * row_stride + s * 32 + 8 * (lane >> 4));
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// forward: O = softmax(scale * Q K^T) V ; LSE saved for backward
+// ------------------------------------------------------------------------------------------------------
+template <bool SPLIT>
+__global__ __launch_bounds__(1024) void attn_fwd_kernel(const bf16_t* __restrict__ qkv_hi, const bf16_t* __restrict__ qkv_lo,
+                                                        bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo,
+                                                        float* __restrict__ lse, int N, int H, float scale) {
+    __shared__ __attribute__((aligned(16))) char smem[SPLIT ? 4 * TILE : 2 * TILE];
+    char* k_hi = smem;
+    char* v_hi = smem + TILE;
+    char* k_lo = smem + 2 * TILE;  // only SPLIT
+    char* v_lo = smem + 3 * TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const long RS = 3L * H * HD;
+    const bf16_t* base_hi = qkv_hi + (long)b * N * RS + h * HD;
+    const bf16_t* base_lo = SPLIT ? qkv_lo + (long)b * N * RS + h * HD : nullptr;
+    const int q0 = (blockIdx.x * nw + wave) * 16;
+    const int g = lane >> 4;
+
+    bf16x8_t qh[2], ql[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        qh[s] = load_own(base_hi, RS, q0, N, s, lane);
+        ql[s] = SPLIT ? load_own(base_lo, RS, q0, N, s, lane) : qh[s];
+    }
+    f32x4 o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles = (N + KT - 1) / KT;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();  // previous tile fully consumed
+        load_tile(k_hi, base_hi + H * HD, RS, kt * KT, N, tid, blockDim.x);
+        load_tile(v_hi, base_hi + 2 * H * HD, RS, kt * KT, N, tid, blockDim.x);
+        if constexpr (SPLIT) {
+            load_tile(k_lo, base_lo + H * HD, RS, kt * KT, N, tid, blockDim.x);
+            load_tile(v_lo, base_lo + 2 * H * HD, RS, kt * KT, N, tid, blockDim.x);
+        }
+        __syncthreads();
+        // S^T[key][q] for two 16-key sub-tiles
+        f32x4 st[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            st[sub] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8_t kh = frag_rows(k_hi, sub * 16, s, lane);
+                bf16x8_t kl = SPLIT ? frag_rows(k_lo, sub * 16, s, lane) : kh;
+                st[sub] = mma<SPLIT>(kh, kl, qh[s], ql[s], st[sub]);
+            }
+        }
+        // online softmax over this lane's query column (keys live in regs and in lanes l^16, l^32, l^48)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int key = kt * KT + sub * 16 + 4 * g + r;
+                float v = key < N ? st[sub][r] * scale : -INFINITY;
+                st[sub][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float m_new = fmaxf(m_run, mx);
+        float alpha = __expf(m_run - m_new);  // m_run=-inf on the first tile -> 0
+        float psum = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float p = __expf(st[sub][r] - m_new);
+                st[sub][r] = p;
+                psum += p;
+            }
+        l_run = l_run * alpha + psum;  // per-lane partial; alpha is uniform over the 4 lanes of a query
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] *= alpha;
+        bf16x8_t ph, pl;
+        pack_acc<SPLIT>(st[0], st[1], ph, pl);
+        if constexpr (!SPLIT) pl = ph;
+        // O^T[d][q] += V^T[d][key] P^T[key][q]
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            bf16x8_t vh = frag_tr(v_hi, dt * 16, lane);
+            bf16x8_t vl = SPLIT ? frag_tr(v_lo, dt * 16, lane) : vh;
+            o[dt] = mma<SPLIT>(vh, vl, ph, pl, o[dt]);
+        }
+    }
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    const int q = q0 + (lane & 15);
+    if (q < N) {
+        float inv = 1.f / l_run;
+        long orow = ((long)b * N + q) * ((long)H * HD) + h * HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            float f[4] = {o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv};
+            store4_split(out_hi, out_lo, (size_t)orow + dt * 16 + 4 * g, f);
+        }
+        if (lse && g == 0) lse[((long)b * H + h) * N + q] = m_run + __logf(l_run);
+    }
+}
+
+// delta[b][h][q] = sum_d dO[q][d] * O[q][d]
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o_hi, const bf16_t* __restrict__ o_lo,
+                                  const bf16_t* __restrict__ do_hi, const bf16_t* __restrict__ do_lo, float* __restrict__ delta,
+                                  int B, int N, int H) {
+    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;  // over B*N*H
+    if (i >= (long)B * N * H) return;
+    int h = (int)(i % H);
+    long bn = i / H;
+    int q = (int)(bn % N);
+    long b = bn / N;
+    size_t base = (size_t)bn * H * HD + h * HD;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float a[8], d[8];
+        load8_split(o_hi, o_lo, base + c * 8, a);
+        load8_split(do_hi, do_lo, base + c * 8, d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += a[j] * d[j];
+    }
+    delta[(b * H + h) * N + q] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward, query-owner pass: dQ = scale * dS K   (streams K,V tiles; recomputes P^T from LSE)
+// ------------------------------------------------------------------------------------------------------
+template <bool SPLIT>
+__global__ __launch_bounds__(1024) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv_hi, const bf16_t* __restrict__ qkv_lo,
+                                                           const bf16_t* __restrict__ do_hi, const bf16_t* __restrict__ do_lo,
+                                                           const float* __restrict__ lse, const float* __restrict__ delta,
+                                                           bf16_t* __restrict__ dqkv_hi, bf16_t* __restrict__ dqkv_lo, int N, int H,
+                                                           float scale) {
+    __shared__ __attribute__((aligned(16))) char smem[SPLIT ? 4 * TILE : 2 * TILE];
+    char* k_hi = smem;
+    char* v_hi = smem + TILE;
+    char* k_lo = smem + 2 * TILE;
+    char* v_lo = smem + 3 * TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const long RS = 3L * H * HD, OS = (long)H * HD;
+    const bf16_t* base_hi = qkv_hi + (long)b * N * RS + h * HD;
+    const bf16_t* base_lo = SPLIT ? qkv_lo + (long)b * N * RS + h * HD : nullptr;
+    const bf16_t* dob_hi = do_hi + (long)b * N * OS + h * HD;
+    const bf16_t* dob_lo = SPLIT ? do_lo + (long)b * N * OS + h * HD : nullptr;
+    const int q0 = (blockIdx.x * nw + wave) * 16;
+    const int g = lane >> 4;
+    const int q = q0 + (lane & 15);
+
+    bf16x8_t qh[2], ql[2], dh[2], dl[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        qh[s] = load_own(base_hi, RS, q0, N, s, lane);
+        dh[s] = load_own(dob_hi, OS, q0, N, s, lane);
+        ql[s] = SPLIT ? load_own(base_lo, RS, q0, N, s, lane) : qh[s];
+        dl[s] = SPLIT ? load_own(dob_lo, OS, q0, N, s, lane) : dh[s];
+    }
+    const float my_lse = q < N ? lse[((long)b * H + h) * N + q] : INFINITY;  // +inf -> P = 0 on padded queries
+    const float my_delta = q < N ? delta[((long)b * H + h) * N + q] : 0.f;
+    f32x4 dq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ntiles = (N + KT - 1) / KT;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();
+        load_tile(k_hi, base_hi + H * HD, RS, kt * KT, N, tid, blockDim.x);
+        load_tile(v_hi, base_hi + 2 * H * HD, RS, kt * KT, N, tid, blockDim.x);
+        if constexpr (SPLIT) {
+            load_tile(k_lo, base_lo + H * HD, RS, kt * KT, N, tid, blockDim.x);
+            load_tile(v_lo, base_lo + 2 * H * HD, RS, kt * KT, N, tid, blockDim.x);
+        }
+        __syncthreads();
+        f32x4 ds[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8_t kh = frag_rows(k_hi, sub * 16, s, lane);
+                bf16x8_t kl = SPLIT ? frag_rows(k_lo, sub * 16, s, lane) : kh;
+                st = mma<SPLIT>(kh, kl, qh[s], ql[s], st);
+                bf16x8_t vh = frag_rows(v_hi, sub * 16, s, lane);
+                bf16x8_t vl = SPLIT ? frag_rows(v_lo, sub * 16, s, lane) : vh;
+                dp = mma<SPLIT>(vh, vl, dh[s], dl[s], dp);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int key = kt * KT + sub * 16 + 4 * g + r;
+                float p = key < N ? __expf(st[r] * scale - my_lse) : 0.f;
+                ds[sub][r] = p * (dp[r] - my_delta) * scale;
+            }
+        }
+        bf16x8_t sh, sl;
+        pack_acc<SPLIT>(ds[0], ds[1], sh, sl);
+        if constexpr (!SPLIT) sl = sh;
+        // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            bf16x8_t kh = frag_tr(k_hi, dt * 16, lane);
+            bf16x8_t kl = SPLIT ? frag_tr(k_lo, dt * 16, lane) : kh;
+            dq[dt] = mma<SPLIT>(kh, kl, sh, sl, dq[dt]);
+        }
+    }
+    if (q < N) {
+        long orow = ((long)b * N + q) * RS + h * HD;  // q slot of dqkv
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            float f[4] = {dq[dt][0], dq[dt][1], dq[dt][2], dq[dt][3]};
+            store4_split(dqkv_hi, dqkv_lo, (size_t)orow + dt * 16 + 4 * g, f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward, key-owner pass: dV = P^T dO ; dK = scale * dS^T Q   (streams Q,dO tiles)
+// ------------------------------------------------------------------------------------------------------
+template <bool SPLIT>
+__global__ __launch_bounds__(1024) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv_hi, const bf16_t* __restrict__ qkv_lo,
+                                                            const bf16_t* __restrict__ do_hi, const bf16_t* __restrict__ do_lo,
+                                                            const float* __restrict__ lse, const float* __restrict__ delta,
+                                                            bf16_t* __restrict__ dqkv_hi, bf16_t* __restrict__ dqkv_lo, int N, int H,
+                                                            float scale) {
+    __shared__ __attribute__((aligned(16))) char smem[(SPLIT ? 4 * TILE : 2 * TILE) + 2 * KT * 4];
+    char* q_hi = smem;
+    char* d_hi = smem + TILE;
+    char* q_lo = smem + 2 * TILE;
+    char* d_lo = smem + 3 * TILE;
+    float* s_lse = reinterpret_cast<float*>(smem + (SPLIT ? 4 * TILE : 2 * TILE));
+    float* s_del = s_lse + KT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const long RS = 3L * H * HD, OS = (long)H * HD;
+    const bf16_t* base_hi = qkv_hi + (long)b * N * RS + h * HD;
+    const bf16_t* base_lo = SPLIT ? qkv_lo + (long)b * N * RS + h * HD : nullptr;
+    const bf16_t* dob_hi = do_hi + (long)b * N * OS + h * HD;
+    const bf16_t* dob_lo = SPLIT ? do_lo + (long)b * N * OS + h * HD : nullptr;
+    const int k0 = (blockIdx.x * nw + wave) * 16;
+    const int g = lane >> 4;
+
+    bf16x8_t kh[2], kl[2], vh[2], vl[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        kh[s] = load_own(base_hi + H * HD, RS, k0, N, s, lane);
+        vh[s] = load_own(base_hi + 2 * H * HD, RS, k0, N, s, lane);
+        kl[s] = SPLIT ? load_own(base_lo + H * HD, RS, k0, N, s, lane) : kh[s];
+        vl[s] = SPLIT ? load_own(base_lo + 2 * H * HD, RS, k0, N, s, lane) : vh[s];
+    }
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dk[i] = dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ntiles = (N + KT - 1) / KT;
+    for (int qt = 0; qt < ntiles; ++qt) {
+        __syncthreads();
+        load_tile(q_hi, base_hi, RS, qt * KT, N, tid, blockDim.x);
+        load_tile(d_hi, dob_hi, OS, qt * KT, N, tid, blockDim.x);
+        if constexpr (SPLIT) {
+            load_tile(q_lo, base_lo, RS, qt * KT, N, tid, blockDim.x);
+            load_tile(d_lo, dob_lo, OS, qt * KT, N, tid, blockDim.x);
+        }
+        if (tid < KT) {
+            int qq = qt * KT + tid;
+            s_lse[tid] = qq < N ? lse[((long)b * H + h) * N + qq] : INFINITY;
+            s_del[tid] = qq < N ? delta[((long)b * H + h) * N + qq] : 0.f;
+        }
+        __syncthreads();
+        f32x4 pp[2], ds[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8_t ah = frag_rows(q_hi, sub * 16, s, lane);
+                bf16x8_t al = SPLIT ? frag_rows(q_lo, sub * 16, s, lane) : ah;
+                st = mma<SPLIT>(ah, al, kh[s], kl[s], st);  // S[q][key]
+                bf16x8_t bh = frag_rows(d_hi, sub * 16, s, lane);
+                bf16x8_t bl = SPLIT ? frag_rows(d_lo, sub * 16, s, lane) : bh;
+                dp = mma<SPLIT>(bh, bl, vh[s], vl[s], dp);  // dP[q][key]
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int ql_ = sub * 16 + 4 * g + r;
+                float p = __expf(st[r] * scale - s_lse[ql_]);  // padded queries: lse=+inf -> 0
+                pp[sub][r] = p;
+                ds[sub][r] = p * (dp[r] - s_del[ql_]) * scale;
+            }
+        }
+        bf16x8_t ph, pl, sh, sl;
+        pack_acc<SPLIT>(pp[0], pp[1], ph, pl);
+        pack_acc<SPLIT>(ds[0], ds[1], sh, sl);
+        if constexpr (!SPLIT) pl = ph, sl = sh;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            bf16x8_t th = frag_tr(d_hi, dt * 16, lane);  // dO^T
+            bf16x8_t tl = SPLIT ? frag_tr(d_lo, dt * 16, lane) : th;
+            dv[dt] = mma<SPLIT>(th, tl, ph, pl, dv[dt]);
+            bf16x8_t uh = frag_tr(q_hi, dt * 16, lane);  // Q^T
+            bf16x8_t ul = SPLIT ? frag_tr(q_lo, dt * 16, lane) : uh;
+            dk[dt] = mma<SPLIT>(uh, ul, sh, sl, dk[dt]);
+        }
+    }
+    const int key = k0 + (lane & 15);
+    if (key < N) {
+        long orow = ((long)b * N + key) * RS + h * HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            float fk[4] = {dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]};
+            float fv[4] = {dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]};
+            store4_split(dqkv_hi, dqkv_lo, (size_t)orow + (long)H * HD + dt * 16 + 4 * g, fk);
+            store4_split(dqkv_hi, dqkv_lo, (size_t)orow + 2L * H * HD + dt * 16 + 4 * g, fv);
+        }
+    }
+}
+
+inline void wave_geometry(int N, int& nblk, int& nw) {
+    int tiles = (N + 15) / 16;
+    nblk = (tiles + 15) / 16;
+    nw = (tiles + nblk - 1) / nblk;
+}
+
+}  // namespace
+
+extern "C" {
+
+// out[B][N][H*64] = softmax(q k^T / sqrt(64)) v ; lse[B][H][N] (may be NULL for inference)
+int ig_attention_fwd(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, float* lse, int B, int N, int H,
+                     int head_dim, void* stream) {
+    IG_REQUIRE(qkv_hi && out_hi, "ig_attention_fwd: null pointer");
+    IG_REQUIRE(head_dim == HD, "ig_attention_fwd: head_dim must be 64 (got %d)", head_dim);
+    IG_REQUIRE((qkv_lo == nullptr) == (out_lo == nullptr), "ig_attention_fwd: split pointers must be given for all tensors or none");
+    if (B == 0 || N == 0) return IG_OK;
+    int nblk, nw;
+    wave_geometry(N, nblk, nw);
+    dim3 grid(nblk, H, B), block(nw * 64);
+    float scale = 1.0f / sqrtf((float)head_dim);
+    if (qkv_lo)
+        hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)qkv_hi, (const bf16_t*)qkv_lo,
+                           (bf16_t*)out_hi, (bf16_t*)out_lo, lse, N, H, scale);
+    else
+        hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)qkv_hi, nullptr,
+                           (bf16_t*)out_hi, nullptr, lse, N, H, scale);
+    return ig_check_launch("ig_attention_fwd");
+}
+
+// dqkv[B][N][3][H][64] from dout, qkv, out, lse ; delta: device scratch float[B*H*N]
+int ig_attention_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi, const void* out_lo, const void* dout_hi,
+                     const void* dout_lo, const float* lse, float* delta, void* dqkv_hi, void* dqkv_lo, int B, int N, int H,
+                     int head_dim, void* stream) {
+    IG_REQUIRE(qkv_hi && out_hi && dout_hi && lse && delta && dqkv_hi, "ig_attention_bwd: null pointer");
+    IG_REQUIRE(head_dim == HD, "ig_attention_bwd: head_dim must be 64 (got %d)", head_dim);
+    bool split = qkv_lo != nullptr;
+    IG_REQUIRE(split == (out_lo != nullptr) && split == (dout_lo != nullptr) && split == (dqkv_lo != nullptr),
+               "ig_attention_bwd: split pointers must be given for all tensors or none");
+    if (B == 0 || N == 0) return IG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    long rows = (long)B * N * H;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, (const bf16_t*)out_hi,
+                       (const bf16_t*)out_lo, (const bf16_t*)dout_hi, (const bf16_t*)dout_lo, delta, B, N, H);
+    int nblk, nw;
+    wave_geometry(N, nblk, nw);
+    dim3 grid(nblk, H, B), block(nw * 64);
+    float scale = 1.0f / sqrtf((float)head_dim);
+    if (split) {
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, grid, block, 0, st, (const bf16_t*)qkv_hi, (const bf16_t*)qkv_lo,
+                           (const bf16_t*)dout_hi, (const bf16_t*)dout_lo, lse, delta, (bf16_t*)dqkv_hi, (bf16_t*)dqkv_lo, N, H, scale);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, block, 0, st, (const bf16_t*)qkv_hi, (const bf16_t*)qkv_lo,
+                           (const bf16_t*)dout_hi, (const bf16_t*)dout_lo, lse, delta, (bf16_t*)dqkv_hi, (bf16_t*)dqkv_lo, N, H, scale);
+    } else {
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, block, 0, st, (const bf16_t*)qkv_hi, nullptr, (const bf16_t*)dout_hi,
+                           nullptr, lse, delta, (bf16_t*)dqkv_hi, nullptr, N, H, scale);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, block, 0, st, (const bf16_t*)qkv_hi, nullptr, (const bf16_t*)dout_hi,
+                           nullptr, lse, delta, (bf16_t*)dqkv_hi, nullptr, N, H, scale);
+    }
+    return ig_check_launch("ig_attention_bwd");
+}
+
+}  // extern "C"

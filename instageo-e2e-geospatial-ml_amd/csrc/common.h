@@ -1,0 +1,150 @@
+// Shared device/host helpers for the instageo MI355X (gfx950) hot-path library.
+// Wave = 64 lanes everywhere.  bf16 tensors are raw uint16_t in memory.
+//
+// "Split" tensors: in precision mode bf16x3 every bf16 activation/weight tensor is a pair
+// (hi, lo) of identically shaped bf16 arrays with value = hi + lo (~16 mantissa bits).  A NULL lo
+// pointer means plain bf16.  MFMA products are then formed as hi*hi + hi*lo + lo*hi (3 segments).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+#define IG_OK 0
+#define IG_ERR_ARG -1
+#define IG_ERR_HIP -2
+#define IG_ERR_UNSUPPORTED -3
+
+// host side ------------------------------------------------------------------------------------
+void ig_set_error(const char* fmt, ...);
+int ig_check_launch(const char* what);
+
+#define IG_REQUIRE(cond, ...)          \
+    do {                               \
+        if (!(cond)) {                 \
+            ig_set_error(__VA_ARGS__); \
+            return IG_ERR_ARG;         \
+        }                              \
+    } while (0)
+
+static inline int ig_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// device side ----------------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;  // round-to-nearest-even, NaN preserving (v_cvt_pk_bf16_f32)
+    return __builtin_bit_cast(bf16_t, b);
+}
+
+// pack two floats into one dword of 2 x bf16 (lo = a, hi = b)
+__device__ __forceinline__ uint32_t pack_bf2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+
+__device__ __forceinline__ void unpack8(const uint4& u, float* f) {
+    f[0] = __uint_as_float(u.x << 16);
+    f[1] = __uint_as_float(u.x & 0xffff0000u);
+    f[2] = __uint_as_float(u.y << 16);
+    f[3] = __uint_as_float(u.y & 0xffff0000u);
+    f[4] = __uint_as_float(u.z << 16);
+    f[5] = __uint_as_float(u.z & 0xffff0000u);
+    f[6] = __uint_as_float(u.w << 16);
+    f[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+
+__device__ __forceinline__ uint4 pack8(const float* f) {
+    uint4 u;
+    u.x = pack_bf2(f[0], f[1]);
+    u.y = pack_bf2(f[2], f[3]);
+    u.z = pack_bf2(f[4], f[5]);
+    u.w = pack_bf2(f[6], f[7]);
+    return u;
+}
+
+// Load 8 consecutive logical elements (16-byte aligned) of a possibly split tensor as floats.
+__device__ __forceinline__ void load8_split(const bf16_t* hi, const bf16_t* lo, size_t idx, float* f) {
+    uint4 u = *reinterpret_cast<const uint4*>(hi + idx);
+    unpack8(u, f);
+    if (lo) {
+        float g[8];
+        uint4 v = *reinterpret_cast<const uint4*>(lo + idx);
+        unpack8(v, g);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] += g[i];
+    }
+}
+
+// Store 8 consecutive logical elements to a possibly split tensor.
+__device__ __forceinline__ void store8_split(bf16_t* hi, bf16_t* lo, size_t idx, const float* f) {
+    uint4 u = pack8(f);
+    *reinterpret_cast<uint4*>(hi + idx) = u;
+    if (lo) {
+        float h[8], r[8];
+        unpack8(u, h);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = f[i] - h[i];
+        *reinterpret_cast<uint4*>(lo + idx) = pack8(r);
+    }
+}
+
+__device__ __forceinline__ void store4_split(bf16_t* hi, bf16_t* lo, size_t idx, const float* f) {
+    uint2 u;
+    u.x = pack_bf2(f[0], f[1]);
+    u.y = pack_bf2(f[2], f[3]);
+    *reinterpret_cast<uint2*>(hi + idx) = u;
+    if (lo) {
+        float r0 = f[0] - __uint_as_float(u.x << 16), r1 = f[1] - __uint_as_float(u.x & 0xffff0000u);
+        float r2 = f[2] - __uint_as_float(u.y << 16), r3 = f[3] - __uint_as_float(u.y & 0xffff0000u);
+        uint2 v;
+        v.x = pack_bf2(r0, r1);
+        v.y = pack_bf2(r2, r3);
+        *reinterpret_cast<uint2*>(lo + idx) = v;
+    }
+}
+
+__device__ __forceinline__ float load1_split(const bf16_t* hi, const bf16_t* lo, size_t idx) {
+    float v = bf2f(hi[idx]);
+    if (lo) v += bf2f(lo[idx]);
+    return v;
+}
+
+__device__ __forceinline__ void store1_split(bf16_t* hi, bf16_t* lo, size_t idx, float v) {
+    bf16_t h = f2bf(v);
+    hi[idx] = h;
+    if (lo) lo[idx] = f2bf(v - bf2f(h));
+}
+
+// wave-wide reductions (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Counter-based dropout mask: keep iff hash(seed, idx) >= p * 2^32.  Stateless so the backward pass
+// regenerates the same mask from the element index (no mask tensor in HBM).
+__device__ __forceinline__ uint32_t ig_hash(uint32_t seed, uint64_t idx) {
+    uint64_t z = idx + 0x9E3779B97F4A7C15ull * (uint64_t)(seed + 1u);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32);
+}
+// returns the multiplier (0 or 1/(1-p)) for element idx
+__device__ __forceinline__ float dropout_scale(uint32_t seed, uint64_t idx, uint32_t thresh, float inv_keep) {
+    return ig_hash(seed, idx) >= thresh ? inv_keep : 0.0f;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}

@@ -1,0 +1,710 @@
+// HBM-bound kernels of the Prithvi segmentation path (gfx950): chip normalisation, patch gather,
+// LayerNorm fwd/bwd, BatchNorm(+ReLU) fwd/bwd, column sums, bf16 splitting, AdamW.
+// All are streaming kernels: 16-byte accesses per lane, wave64 shuffles for row reductions, one
+// atomic per (block, column) for column reductions.  Reference call sites are cited per kernel.
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+inline int grid_for(long n, int per_block, int cap = 1 << 20) {
+    long g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+// ----------------------------------------------------------------------------------------------
+// K0: chip normalisation + layout  (instageo/model/dataloader.py:495-524, process_data :707-750)
+//   src (B, T*C, H, W) int16|f32, band index t*C+c  ->  dst (B, C, T, H, W) f32 = (src*mult - mean_c)/std_c
+// ----------------------------------------------------------------------------------------------
+template <typename SRC>
+__global__ void normalize_kernel(const SRC* __restrict__ src, float* __restrict__ dst, const float* __restrict__ mean,
+                                 const float* __restrict__ stdv, double mult, int use_mult, int T, int C, long HW, long total4) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        long e = i * 4;  // linear index in dst (B,C,T,HW)
+        long pix = e % HW;
+        long r = e / HW;
+        int t = (int)(r % T);
+        r /= T;
+        int c = (int)(r % C);
+        long b = r / C;
+        const SRC* s = src + ((b * T + t) * C + c) * HW + pix;
+        float m = mean[c], sd = stdv[c];
+        float4 o;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // reference: data * constant_multiplier in float64 (dataloader.py:737), then float32
+            float x = use_mult ? (float)((double)s[j] * mult) : (float)s[j];
+            v[j] = (x - m) / sd;
+        }
+        o = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(dst + e) = o;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// K1 gather: (B,C,T,H,W) f32 -> patches [B*T*gh*gw][C*p*p] bf16/split, k = c*p*p + iy*p + ix,
+// token order (t, row, col)  (pritvhi.py:266-268 flatten(2).transpose(1,2) of Conv3d k=s=(1,p,p))
+// ----------------------------------------------------------------------------------------------
+__global__ void patchify_kernel(const float* __restrict__ img, bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo,
+                                int C, int T, int H, int W, int p, int gh, int gw, long units) {
+    const int Kp = C * p * p;
+    const int upr = p / 8;  // 16-byte units per patch row
+    for (long u = blockIdx.x * (long)blockDim.x + threadIdx.x; u < units; u += (long)gridDim.x * blockDim.x) {
+        long e = u * 8;
+        long row = e / Kp;
+        int k = (int)(e - row * Kp);
+        int c = k / (p * p);
+        int rem = k - c * p * p;
+        int iy = rem / p, ix = rem - iy * p;
+        long tok = row;
+        int px = (int)(tok % gw);
+        tok /= gw;
+        int py = (int)(tok % gh);
+        tok /= gh;
+        int t = (int)(tok % T);
+        long b = tok / T;
+        const float* s = img + (((b * C + c) * T + t) * H + (py * p + iy)) * (long)W + px * p + ix;
+        float4 a = *reinterpret_cast<const float4*>(s);
+        float4 bq = *reinterpret_cast<const float4*>(s + 4);
+        float f[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
+        store8_split(out_hi, out_lo, (size_t)e, f);
+        (void)upr;
+    }
+}
+
+// cls rows: x[b][0][:] = cls + pos[0]   (pritvhi.py:520-522)
+__global__ void cls_rows_kernel(float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos, int B,
+                                long row_stride, int D) {
+    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)B * D) return;
+    int d = (int)(i % D);
+    long b = i / D;
+    x[b * row_stride + d] = cls[d] + pos[d];
+}
+
+// ----------------------------------------------------------------------------------------------
+// K3: LayerNorm forward (nn.LayerNorm eps=1e-5 inside timm Block and PrithviViT.norm, pritvhi.py:448-459,529)
+// one wave per row; fp32 in; bf16/split out; saves mean and rstd.  feat_T>0 selects the K9 layout
+// (model.py:406-413): token (b, 1+t*G+p) channel d -> out[(b*G+p)*(D*T) + d*T + t], cls row dropped.
+// ----------------------------------------------------------------------------------------------
+template <int MAXV>
+__global__ __launch_bounds__(TPB) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, bf16_t* __restrict__ out_hi,
+                                                            bf16_t* __restrict__ out_lo, float* __restrict__ mean_o,
+                                                            float* __restrict__ rstd_o, int M, int D, float eps, int feat_T,
+                                                            int feat_G, int ntok) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = D / 4;  // float4 chunks per row
+    const float* xr = x + (size_t)row * D;
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        int c = lane + i * 64;
+        if (c < nv) {
+            v[i] = *reinterpret_cast<const float4*>(xr + c * 4);
+            s += v[i].x + v[i].y + v[i].z + v[i].w;
+        }
+    }
+    float mu = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        int c = lane + i * 64;
+        if (c < nv) {
+            float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu;
+            q += a * a + b * b + cc * cc + d * d;
+        }
+    }
+    float rstd = rsqrtf(wave_sum(q) / D + eps);
+    if (lane == 0) {
+        if (mean_o) mean_o[row] = mu;
+        if (rstd_o) rstd_o[row] = rstd;
+    }
+    long obase;
+    int tfr = 0;
+    if (feat_T > 0) {
+        int b = row / ntok, tok = row - b * ntok;
+        if (tok == 0) return;  // cls token dropped
+        int tp = tok - 1;
+        tfr = tp / feat_G;
+        int p = tp - tfr * feat_G;
+        obase = ((long)b * feat_G + p) * ((long)D * feat_T);
+    } else {
+        obase = (long)row * D;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        int c = lane + i * 64;
+        if (c < nv) {
+            float4 g = *reinterpret_cast<const float4*>(gamma + c * 4);
+            float4 bb = *reinterpret_cast<const float4*>(beta + c * 4);
+            float o[4] = {(v[i].x - mu) * rstd * g.x + bb.x, (v[i].y - mu) * rstd * g.y + bb.y,
+                          (v[i].z - mu) * rstd * g.z + bb.z, (v[i].w - mu) * rstd * g.w + bb.w};
+            if (feat_T <= 1) {
+                store4_split(out_hi, out_lo, (size_t)obase + c * 4, o);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) store1_split(out_hi, out_lo, (size_t)obase + (long)(c * 4 + j) * feat_T + tfr, o[j]);
+            }
+        }
+    }
+}
+
+// LayerNorm backward.  dy: bf16/split [M][D] (or the K9 feature layout when feat_T>0, cls rows = 0).
+//   dx[row] = (accumulate ? dx[row] : 0) + rstd*(dy*g - mean(dy*g) - xhat*mean(dy*g*xhat))
+//   dgamma += sum_rows dy*xhat ; dbeta += sum_rows dy ; optional: dxb = bf16(dx), dcol += sum_rows dx
+// Each block owns ROWS_PER_BLOCK rows; each wave keeps its column partials in registers, then one
+// LDS reduction + one fp32 atomic per (block, column).
+template <int MAXV>
+__global__ __launch_bounds__(TPB) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy_hi, const bf16_t* __restrict__ dy_lo,
+                                                            const float* __restrict__ x, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                            float* __restrict__ dx, int accumulate, bf16_t* __restrict__ dxb_hi,
+                                                            bf16_t* __restrict__ dxb_lo, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, float* __restrict__ dcol, int M, int D,
+                                                            int rows_per_block, int feat_T, int feat_G, int ntok) {
+    extern __shared__ float red[];  // [3][D]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = D / 4;
+    float4 ag[MAXV], ab[MAXV], ac[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) ag[i] = ab[i] = ac[i] = make_float4(0, 0, 0, 0);
+    const int row0 = blockIdx.x * rows_per_block;
+    const int row1 = min(M, row0 + rows_per_block);
+    for (int row = row0 + wave; row < row1; row += TPB / 64) {
+        const float mu = mean[row], rs = rstd[row];
+        bool zero_dy = false;
+        long dbase = (long)row * D;
+        int tfr = 0;
+        if (feat_T > 0) {
+            int b = row / ntok, tok = row - b * ntok;
+            if (tok == 0) zero_dy = true;
+            else {
+                int tp = tok - 1;
+                tfr = tp / feat_G;
+                int p = tp - tfr * feat_G;
+                dbase = ((long)b * feat_G + p) * ((long)D * feat_T);
+            }
+        }
+        float4 xh[MAXV], dyv[MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            int c = lane + i * 64;
+            if (c < nv) {
+                float4 xv = *reinterpret_cast<const float4*>(x + (size_t)row * D + c * 4);
+                xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                float d[4] = {0.f, 0.f, 0.f, 0.f};
+                if (!zero_dy) {
+                    if (feat_T <= 1) {
+                        const bf16_t* ph = dy_hi + dbase + c * 4;
+                        uint2 u = *reinterpret_cast<const uint2*>(ph);
+                        d[0] = __uint_as_float(u.x << 16), d[1] = __uint_as_float(u.x & 0xffff0000u);
+                        d[2] = __uint_as_float(u.y << 16), d[3] = __uint_as_float(u.y & 0xffff0000u);
+                        if (dy_lo) {
+                            uint2 w = *reinterpret_cast<const uint2*>(dy_lo + dbase + c * 4);
+                            d[0] += __uint_as_float(w.x << 16), d[1] += __uint_as_float(w.x & 0xffff0000u);
+                            d[2] += __uint_as_float(w.y << 16), d[3] += __uint_as_float(w.y & 0xffff0000u);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) d[j] = load1_split(dy_hi, dy_lo, (size_t)dbase + (long)(c * 4 + j) * feat_T + tfr);
+                    }
+                }
+                dyv[i] = make_float4(d[0], d[1], d[2], d[3]);
+                float4 g = *reinterpret_cast<const float4*>(gamma + c * 4);
+                float a0 = d[0] * g.x, a1 = d[1] * g.y, a2 = d[2] * g.z, a3 = d[3] * g.w;
+                s1 += a0 + a1 + a2 + a3;
+                s2 += a0 * xh[i].x + a1 * xh[i].y + a2 * xh[i].z + a3 * xh[i].w;
+            }
+        }
+        s1 = wave_sum(s1) / D;
+        s2 = wave_sum(s2) / D;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            int c = lane + i * 64;
+            if (c < nv) {
+                float4 g = *reinterpret_cast<const float4*>(gamma + c * 4);
+                float4 r;
+                r.x = rs * (dyv[i].x * g.x - s1 - xh[i].x * s2);
+                r.y = rs * (dyv[i].y * g.y - s1 - xh[i].y * s2);
+                r.z = rs * (dyv[i].z * g.z - s1 - xh[i].z * s2);
+                r.w = rs * (dyv[i].w * g.w - s1 - xh[i].w * s2);
+                float* dp = dx + (size_t)row * D + c * 4;
+                if (accumulate) {
+                    float4 o = *reinterpret_cast<const float4*>(dp);
+                    r.x += o.x, r.y += o.y, r.z += o.z, r.w += o.w;
+                }
+                *reinterpret_cast<float4*>(dp) = r;
+                if (dxb_hi) {
+                    float f[4] = {r.x, r.y, r.z, r.w};
+                    store4_split(dxb_hi, dxb_lo, (size_t)row * D + c * 4, f);
+                }
+                ag[i].x += dyv[i].x * xh[i].x, ag[i].y += dyv[i].y * xh[i].y, ag[i].z += dyv[i].z * xh[i].z, ag[i].w += dyv[i].w * xh[i].w;
+                ab[i].x += dyv[i].x, ab[i].y += dyv[i].y, ab[i].z += dyv[i].z, ab[i].w += dyv[i].w;
+                ac[i].x += r.x, ac[i].y += r.y, ac[i].z += r.z, ac[i].w += r.w;
+            }
+        }
+    }
+    // cross-wave column reduction
+    for (int i = threadIdx.x; i < 3 * D; i += TPB) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        int c = lane + i * 64;
+        if (c < nv) {
+            float* r0 = red + c * 4;
+            atomicAdd(r0 + 0, ag[i].x), atomicAdd(r0 + 1, ag[i].y), atomicAdd(r0 + 2, ag[i].z), atomicAdd(r0 + 3, ag[i].w);
+            float* r1 = red + D + c * 4;
+            atomicAdd(r1 + 0, ab[i].x), atomicAdd(r1 + 1, ab[i].y), atomicAdd(r1 + 2, ab[i].z), atomicAdd(r1 + 3, ab[i].w);
+            float* r2 = red + 2 * D + c * 4;
+            atomicAdd(r2 + 0, ac[i].x), atomicAdd(r2 + 1, ac[i].y), atomicAdd(r2 + 2, ac[i].z), atomicAdd(r2 + 3, ac[i].w);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < D; i += TPB) {
+        if (dgamma) atomicAdd(dgamma + i, red[i]);
+        if (dbeta) atomicAdd(dbeta + i, red[D + i]);
+        if (dcol) atomicAdd(dcol + i, red[2 * D + i]);
+    }
+}
+
+// column sums of a bf16/split matrix: out[c] += sum_m x[m][c]   (bias gradients)
+// threads tile (row slice, 8-column unit); per-block LDS reduction, then one atomic per (block, column)
+__global__ __launch_bounds__(TPB) void colsum_kernel(const bf16_t* __restrict__ hi, const bf16_t* __restrict__ lo,
+                                                     float* __restrict__ out, long M, int C, int rows_per_block) {
+    extern __shared__ float red[];  // [C]
+    const int units = C / 8;
+    const int tu = min(units, TPB), nslice = TPB / tu;
+    const int u = threadIdx.x % tu, sl = threadIdx.x / tu;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(M, r0 + rows_per_block);
+    for (int i = threadIdx.x; i < C; i += TPB) red[i] = 0.f;
+    __syncthreads();
+    if (sl < nslice) {
+        for (int ub = u; ub < units; ub += tu) {
+            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (long r = r0 + sl; r < r1; r += nslice) {
+                float f[8];
+                load8_split(hi, lo, (size_t)r * C + ub * 8, f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += f[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) atomicAdd(red + ub * 8 + j, acc[j]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += TPB) atomicAdd(out + i, red[i]);
+}
+
+// f32 -> bf16 hi (+ lo)
+__global__ void split_kernel(const float* __restrict__ src, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        store1_split(hi, lo, (size_t)i, src[i]);
+    }
+}
+// bf16 hi (+ lo) -> f32
+__global__ void merge_kernel(const bf16_t* __restrict__ hi, const bf16_t* __restrict__ lo, float* __restrict__ dst, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        dst[i] = load1_split(hi, lo, (size_t)i);
+    }
+}
+
+// patch-embed gradient prep: dx f32 [B][ntok][D] -> dpe bf16/split [B*(ntok-1)][D] (cls row removed),
+// dcls[d] += sum_b dx[b][0][d], dbias[d] += sum over non-cls rows (cls_token / conv bias gradients)
+__global__ __launch_bounds__(TPB) void patch_grad_prep_kernel(const float* __restrict__ dx, bf16_t* __restrict__ hi,
+                                                              bf16_t* __restrict__ lo, float* __restrict__ dcls,
+                                                              float* __restrict__ dbias, int B, int ntok, int D) {
+    // one block per (b, chunk of 32 tokens); threads over D in float4
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * 32, t1 = min(ntok, t0 + 32);
+    for (int c = threadIdx.x; c < D / 4; c += TPB) {
+        float4 acc = make_float4(0, 0, 0, 0);
+        for (int t = t0; t < t1; ++t) {
+            float4 v = *reinterpret_cast<const float4*>(dx + ((size_t)b * ntok + t) * D + c * 4);
+            if (t == 0) {
+                atomicAdd(dcls + c * 4 + 0, v.x), atomicAdd(dcls + c * 4 + 1, v.y);
+                atomicAdd(dcls + c * 4 + 2, v.z), atomicAdd(dcls + c * 4 + 3, v.w);
+            } else {
+                float f[4] = {v.x, v.y, v.z, v.w};
+                store4_split(hi, lo, ((size_t)b * (ntok - 1) + (t - 1)) * D + c * 4, f);
+                acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+            }
+        }
+        atomicAdd(dbias + c * 4 + 0, acc.x), atomicAdd(dbias + c * 4 + 1, acc.y);
+        atomicAdd(dbias + c * 4 + 2, acc.z), atomicAdd(dbias + c * 4 + 3, acc.w);
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// K13: BatchNorm2d (+ReLU) on NHWC bf16/split tensors [M][C]   (model.py:376-377; eps 1e-5, momentum 0.1)
+// ----------------------------------------------------------------------------------------------
+// pass 1: per-channel sum / sum of squares: fp32 partials per thread, LDS reduction per block, one fp64
+// atomic per (block, channel, statistic)
+__global__ __launch_bounds__(TPB) void bn_stats_kernel(const bf16_t* __restrict__ hi, const bf16_t* __restrict__ lo,
+                                                       double* __restrict__ sums, long M, int C, int rows_per_block) {
+    extern __shared__ float red[];  // [2C]
+    const int units = C / 8;
+    const int tu = min(units, TPB), nslice = TPB / tu;
+    const int u = threadIdx.x % tu, sl = threadIdx.x / tu;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(M, r0 + rows_per_block);
+    for (int i = threadIdx.x; i < 2 * C; i += TPB) red[i] = 0.f;
+    __syncthreads();
+    if (sl < nslice) {
+        for (int ub = u; ub < units; ub += tu) {
+            float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (long r = r0 + sl; r < r1; r += nslice) {
+                float f[8];
+                load8_split(hi, lo, (size_t)r * C + ub * 8, f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[j] += f[j], q[j] += f[j] * f[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                atomicAdd(red + ub * 8 + j, s[j]);
+                atomicAdd(red + C + ub * 8 + j, q[j]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += TPB) atomicAdd(sums + i, (double)red[i]);
+}
+// finalize: train -> batch statistics (+ running update), eval -> running statistics
+//   scale = gamma*rstd ; shift = beta - mean*scale ; saves mean/rstd for backward
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ mean_o, float* __restrict__ rstd_o, double n, int C, float eps,
+                                   float momentum, int training, int update_running) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mu, var;
+    if (training) {
+        double m = sums[c] / n;
+        double v = sums[C + c] / n - m * m;
+        if (v < 0) v = 0;
+        mu = (float)m, var = (float)v;
+        if (update_running) {
+            double unbiased = n > 1 ? v * n / (n - 1) : v;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    } else {
+        mu = running_mean[c], var = running_var[c];
+    }
+    float rs = rsqrtf(var + eps);
+    float sc = gamma[c] * rs;
+    scale[c] = sc;
+    shift[c] = beta[c] - mu * sc;
+    if (mean_o) mean_o[c] = mu;
+    if (rstd_o) rstd_o[c] = rs;
+}
+// y = relu(x*scale + shift)
+__global__ void bn_relu_apply_kernel(const bf16_t* __restrict__ xh, const bf16_t* __restrict__ xl, const float* __restrict__ scale,
+                                     const float* __restrict__ shift, bf16_t* __restrict__ yh, bf16_t* __restrict__ yl, long units,
+                                     int C) {
+    for (long u = blockIdx.x * (long)blockDim.x + threadIdx.x; u < units; u += (long)gridDim.x * blockDim.x) {
+        int c = (int)((u * 8) % C);
+        float f[8];
+        load8_split(xh, xl, (size_t)u * 8, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * scale[c + j] + shift[c + j], 0.f);
+        store8_split(yh, yl, (size_t)u * 8, f);
+    }
+}
+// backward pass 1: sums[c] += dyr ; sums[C+c] += dyr*xhat   (dyr = dy * [bn(x) > 0])
+__global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const bf16_t* __restrict__ xh, const bf16_t* __restrict__ xl,
+                                                            const bf16_t* __restrict__ dyh, const bf16_t* __restrict__ dyl,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            double* __restrict__ sums, long M, int C, int rows_per_block) {
+    extern __shared__ float red[];  // [2C]
+    const int units = C / 8;
+    const int tu = min(units, TPB), nslice = TPB / tu;
+    const int u = threadIdx.x % tu, sl = threadIdx.x / tu;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(M, r0 + rows_per_block);
+    for (int i = threadIdx.x; i < 2 * C; i += TPB) red[i] = 0.f;
+    __syncthreads();
+    if (sl < nslice) {
+        for (int ub = u; ub < units; ub += tu) {
+            float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (long r = r0 + sl; r < r1; r += nslice) {
+                float x[8], d[8];
+                load8_split(xh, xl, (size_t)r * C + ub * 8, x);
+                load8_split(dyh, dyl, (size_t)r * C + ub * 8, d);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    int c = ub * 8 + j;
+                    float dyr = (x[j] * scale[c] + shift[c]) > 0.f ? d[j] : 0.f;
+                    s[j] += dyr;
+                    q[j] += dyr * (x[j] - mean[c]) * rstd[c];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                atomicAdd(red + ub * 8 + j, s[j]);
+                atomicAdd(red + C + ub * 8 + j, q[j]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += TPB) atomicAdd(sums + i, (double)red[i]);
+}
+// backward pass 2: dx = scale*(dyr - sum_dy/n - xhat*sum_dyxhat/n); also emits dgamma/dbeta once (block 0)
+__global__ void bn_bwd_apply_kernel(const bf16_t* __restrict__ xh, const bf16_t* __restrict__ xl, const bf16_t* __restrict__ dyh,
+                                    const bf16_t* __restrict__ dyl, const float* __restrict__ scale, const float* __restrict__ shift,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd, const double* __restrict__ sums,
+                                    bf16_t* __restrict__ dxh, bf16_t* __restrict__ dxl, float* __restrict__ dgamma,
+                                    float* __restrict__ dbeta, long units, int C, double n) {
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            if (dbeta) atomicAdd(dbeta + c, (float)sums[c]);
+            if (dgamma) atomicAdd(dgamma + c, (float)sums[C + c]);
+        }
+    }
+    const float inv_n = (float)(1.0 / n);
+    for (long u = blockIdx.x * (long)blockDim.x + threadIdx.x; u < units; u += (long)gridDim.x * blockDim.x) {
+        int c0 = (int)((u * 8) % C);
+        float x[8], d[8], o[8];
+        load8_split(xh, xl, (size_t)u * 8, x);
+        load8_split(dyh, dyl, (size_t)u * 8, d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int c = c0 + j;
+            float dyr = (x[j] * scale[c] + shift[c]) > 0.f ? d[j] : 0.f;
+            float xhat = (x[j] - mean[c]) * rstd[c];
+            o[j] = scale[c] * (dyr - (float)sums[c] * inv_n - xhat * (float)sums[C + c] * inv_n);
+        }
+        store8_split(dxh, dxl, (size_t)u * 8, o);
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// K18: AdamW (torch.optim.AdamW defaults, base.py:124-126) on the flat parameter buffer, fused with the
+// optional weight clamp (base.py:103-113) and the bf16 (hi/lo) shadow refresh used by the MFMA kernels.
+// hyper (device): [0]=lr [1]=beta1 [2]=beta2 [3]=eps [4]=weight_decay [5]=bias_corr1 [6]=sqrt(bias_corr2)
+//                 [7]=clip_lo [8]=clip_hi [9]=clip_enabled  [10]=step (as float)
+// ----------------------------------------------------------------------------------------------
+__global__ void adamw_advance_kernel(float* hyper) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float step = hyper[10] + 1.f;
+        hyper[10] = step;
+        hyper[5] = (float)(1.0 - pow((double)hyper[1], (double)step));
+        hyper[6] = (float)sqrt(1.0 - pow((double)hyper[2], (double)step));
+    }
+}
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             bf16_t* __restrict__ sh, bf16_t* __restrict__ sl, const float* __restrict__ hyper, long n4) {
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5], bc2s = hyper[6];
+    const float clo = hyper[7], chi = hyper[8];
+    const bool clip = hyper[9] != 0.f;
+    const float step_size = lr / bc1;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 P = reinterpret_cast<float4*>(p)[i];
+        float4 G = reinterpret_cast<const float4*>(g)[i];
+        float4 Mv = reinterpret_cast<float4*>(m)[i];
+        float4 V = reinterpret_cast<float4*>(v)[i];
+        float pp[4] = {P.x, P.y, P.z, P.w}, gg[4] = {G.x, G.y, G.z, G.w}, mm[4] = {Mv.x, Mv.y, Mv.z, Mv.w},
+              vv[4] = {V.x, V.y, V.z, V.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            pp[j] = pp[j] * (1.f - lr * wd);
+            mm[j] = mm[j] + (gg[j] - mm[j]) * (1.f - b1);  // lerp_
+            vv[j] = vv[j] * b2 + (1.f - b2) * gg[j] * gg[j];
+            float denom = sqrtf(vv[j]) / bc2s + eps;
+            pp[j] = pp[j] - step_size * (mm[j] / denom);
+            if (clip) pp[j] = fminf(fmaxf(pp[j], clo), chi);
+        }
+        reinterpret_cast<float4*>(p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+        reinterpret_cast<float4*>(m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+        reinterpret_cast<float4*>(v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        if (sh) store4_split(sh, sl, (size_t)i * 4, pp);
+    }
+}
+
+}  // namespace
+
+#define ST(s) ((hipStream_t)(s))
+
+extern "C" {
+
+// src_dtype: 0 = int16, 1 = float32.  mult_enabled=0 skips the constant multiplier.
+int ig_normalize_chips(const void* src, int src_dtype, const float* mean, const float* stdv, double mult, int mult_enabled,
+                       float* dst, int B, int T, int C, int H, int W, void* stream) {
+    IG_REQUIRE(src && mean && stdv && dst, "ig_normalize_chips: null pointer");
+    IG_REQUIRE(B >= 0 && T > 0 && C > 0 && H > 0 && W > 0, "ig_normalize_chips: bad dims");
+    long HW = (long)H * W;
+    IG_REQUIRE(HW % 4 == 0, "ig_normalize_chips: H*W must be a multiple of 4 (got %ld)", HW);
+    long total4 = (long)B * T * C * HW / 4;
+    if (total4 == 0) return IG_OK;
+    int grid = grid_for(total4, TPB, 8192);
+    if (src_dtype == 0)
+        hipLaunchKernelGGL(normalize_kernel<int16_t>, dim3(grid), dim3(TPB), 0, ST(stream), (const int16_t*)src, dst, mean, stdv,
+                           mult, mult_enabled, T, C, HW, total4);
+    else if (src_dtype == 1)
+        hipLaunchKernelGGL(normalize_kernel<float>, dim3(grid), dim3(TPB), 0, ST(stream), (const float*)src, dst, mean, stdv, mult,
+                           mult_enabled, T, C, HW, total4);
+    else {
+        ig_set_error("ig_normalize_chips: unsupported src_dtype %d", src_dtype);
+        return IG_ERR_UNSUPPORTED;
+    }
+    return ig_check_launch("ig_normalize_chips");
+}
+
+int ig_patchify(const float* img, void* out_hi, void* out_lo, int B, int C, int T, int H, int W, int p, void* stream) {
+    IG_REQUIRE(img && out_hi, "ig_patchify: null pointer");
+    IG_REQUIRE(p % 8 == 0 && W % 4 == 0, "ig_patchify: patch size must be a multiple of 8 and W of 4 (p=%d W=%d)", p, W);
+    int gh = H / p, gw = W / p;
+    long units = (long)B * T * gh * gw * C * p * p / 8;
+    if (units == 0) return IG_OK;
+    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(units, TPB, 16384)), dim3(TPB), 0, ST(stream), img, (bf16_t*)out_hi,
+                       (bf16_t*)out_lo, C, T, H, W, p, gh, gw, units);
+    return ig_check_launch("ig_patchify");
+}
+
+int ig_cls_rows(float* x, const float* cls, const float* pos, int B, int ntok, int D, void* stream) {
+    IG_REQUIRE(x && cls && pos, "ig_cls_rows: null pointer");
+    long n = (long)B * D;
+    if (n == 0) return IG_OK;
+    hipLaunchKernelGGL(cls_rows_kernel, dim3(grid_for(n, TPB)), dim3(TPB), 0, ST(stream), x, cls, pos, B, (long)ntok * D, D);
+    return ig_check_launch("ig_cls_rows");
+}
+
+// feat_T = 0: out[M][D]; feat_T >= 1: K9 feature-image layout [B][G][D*T] with the cls row dropped
+int ig_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* out_hi, void* out_lo, float* mean,
+                     float* rstd, int M, int D, float eps, int feat_T, int feat_G, int ntok, void* stream) {
+    IG_REQUIRE(x && gamma && beta && out_hi, "ig_layernorm_fwd: null pointer");
+    IG_REQUIRE(D % 4 == 0 && D <= 2048, "ig_layernorm_fwd: D must be a multiple of 4 and <= 2048 (got %d)", D);
+    if (M == 0) return IG_OK;
+    dim3 grid(ig_cdiv(M, TPB / 64));
+    if (D <= 1024)
+        hipLaunchKernelGGL(layernorm_fwd_kernel<4>, grid, dim3(TPB), 0, ST(stream), x, gamma, beta, (bf16_t*)out_hi, (bf16_t*)out_lo,
+                           mean, rstd, M, D, eps, feat_T, feat_G, ntok);
+    else
+        hipLaunchKernelGGL(layernorm_fwd_kernel<8>, grid, dim3(TPB), 0, ST(stream), x, gamma, beta, (bf16_t*)out_hi, (bf16_t*)out_lo,
+                           mean, rstd, M, D, eps, feat_T, feat_G, ntok);
+    return ig_check_launch("ig_layernorm_fwd");
+}
+
+int ig_layernorm_bwd(const void* dy_hi, const void* dy_lo, const float* x, const float* mean, const float* rstd,
+                     const float* gamma, float* dx, int accumulate, void* dxb_hi, void* dxb_lo, float* dgamma, float* dbeta,
+                     float* dcol, int M, int D, int feat_T, int feat_G, int ntok, void* stream) {
+    IG_REQUIRE(dy_hi && x && mean && rstd && gamma && dx, "ig_layernorm_bwd: null pointer");
+    IG_REQUIRE(D % 4 == 0 && D <= 2048, "ig_layernorm_bwd: D must be a multiple of 4 and <= 2048 (got %d)", D);
+    if (M == 0) return IG_OK;
+    const int rpb = 32;
+    dim3 grid(ig_cdiv(M, rpb));
+    size_t sm = 3 * (size_t)D * sizeof(float);
+    if (D <= 1024)
+        hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, dim3(TPB), sm, ST(stream), (const bf16_t*)dy_hi, (const bf16_t*)dy_lo, x,
+                           mean, rstd, gamma, dx, accumulate, (bf16_t*)dxb_hi, (bf16_t*)dxb_lo, dgamma, dbeta, dcol, M, D, rpb,
+                           feat_T, feat_G, ntok);
+    else
+        hipLaunchKernelGGL(layernorm_bwd_kernel<8>, grid, dim3(TPB), sm, ST(stream), (const bf16_t*)dy_hi, (const bf16_t*)dy_lo, x,
+                           mean, rstd, gamma, dx, accumulate, (bf16_t*)dxb_hi, (bf16_t*)dxb_lo, dgamma, dbeta, dcol, M, D, rpb,
+                           feat_T, feat_G, ntok);
+    return ig_check_launch("ig_layernorm_bwd");
+}
+
+int ig_colsum(const void* hi, const void* lo, float* out, long M, int C, void* stream) {
+    IG_REQUIRE(hi && out, "ig_colsum: null pointer");
+    IG_REQUIRE(C % 8 == 0, "ig_colsum: C must be a multiple of 8 (got %d)", C);
+    if (M == 0) return IG_OK;
+    const int rpb = M > 65536 ? 1024 : 128;
+    hipLaunchKernelGGL(colsum_kernel, dim3(ig_cdiv(M, rpb)), dim3(TPB), (size_t)C * sizeof(float), ST(stream), (const bf16_t*)hi, (const bf16_t*)lo, out, M,
+                       C, rpb);
+    return ig_check_launch("ig_colsum");
+}
+
+int ig_split_bf16(const float* src, void* hi, void* lo, long n, void* stream) {
+    IG_REQUIRE(src && hi, "ig_split_bf16: null pointer");
+    if (n == 0) return IG_OK;
+    hipLaunchKernelGGL(split_kernel, dim3(grid_for(n, TPB, 16384)), dim3(TPB), 0, ST(stream), src, (bf16_t*)hi, (bf16_t*)lo, n);
+    return ig_check_launch("ig_split_bf16");
+}
+
+int ig_merge_bf16(const void* hi, const void* lo, float* dst, long n, void* stream) {
+    IG_REQUIRE(hi && dst, "ig_merge_bf16: null pointer");
+    if (n == 0) return IG_OK;
+    hipLaunchKernelGGL(merge_kernel, dim3(grid_for(n, TPB, 16384)), dim3(TPB), 0, ST(stream), (const bf16_t*)hi, (const bf16_t*)lo,
+                       dst, n);
+    return ig_check_launch("ig_merge_bf16");
+}
+
+int ig_patch_grad_prep(const float* dx, void* hi, void* lo, float* dcls, float* dbias, int B, int ntok, int D, void* stream) {
+    IG_REQUIRE(dx && hi && dcls && dbias, "ig_patch_grad_prep: null pointer");
+    IG_REQUIRE(D % 4 == 0, "ig_patch_grad_prep: D must be a multiple of 4");
+    if (B == 0) return IG_OK;
+    hipLaunchKernelGGL(patch_grad_prep_kernel, dim3(ig_cdiv(ntok, 32), B), dim3(TPB), 0, ST(stream), dx, (bf16_t*)hi, (bf16_t*)lo,
+                       dcls, dbias, B, ntok, D);
+    return ig_check_launch("ig_patch_grad_prep");
+}
+
+// BatchNorm(+ReLU) forward.  sums: device scratch double[2*C] (zeroed here).  training=1: batch statistics
+// and (update_running=1) running-stat update; training=0: running statistics.
+int ig_bn_relu_fwd(const void* x_hi, const void* x_lo, const float* gamma, const float* beta, float* running_mean,
+                   float* running_var, void* y_hi, void* y_lo, float* scale, float* shift, float* mean, float* rstd,
+                   double* sums, long M, int C, float eps, float momentum, int training, int update_running, void* stream) {
+    IG_REQUIRE(x_hi && gamma && beta && running_mean && running_var && y_hi && scale && shift && sums, "ig_bn_relu_fwd: null pointer");
+    IG_REQUIRE(C % 8 == 0 && C <= 4096, "ig_bn_relu_fwd: C must be a multiple of 8 and <= 4096 (got %d)", C);
+    if (M == 0) return IG_OK;
+    if (training) {
+        (void)hipMemsetAsync(sums, 0, 2 * (size_t)C * sizeof(double), ST(stream));
+        const int rpb = M > 65536 ? 1024 : 128;
+        hipLaunchKernelGGL(bn_stats_kernel, dim3(ig_cdiv(M, rpb)), dim3(TPB), 2 * (size_t)C * sizeof(float), ST(stream), (const bf16_t*)x_hi, (const bf16_t*)x_lo,
+                           sums, M, C, rpb);
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ig_cdiv(C, TPB)), dim3(TPB), 0, ST(stream), sums, gamma, beta, running_mean,
+                       running_var, scale, shift, mean, rstd, (double)M, C, eps, momentum, training, update_running);
+    long units = M * C / 8;
+    hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(grid_for(units, TPB, 16384)), dim3(TPB), 0, ST(stream), (const bf16_t*)x_hi,
+                       (const bf16_t*)x_lo, scale, shift, (bf16_t*)y_hi, (bf16_t*)y_lo, units, C);
+    return ig_check_launch("ig_bn_relu_fwd");
+}
+
+// BatchNorm(+ReLU) backward (training statistics): x = saved conv output, dy = grad of the ReLU output
+int ig_bn_relu_bwd(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, const float* scale,
+                   const float* shift, const float* mean, const float* rstd, void* dx_hi, void* dx_lo, float* dgamma,
+                   float* dbeta, double* sums, long M, int C, void* stream) {
+    IG_REQUIRE(x_hi && dy_hi && scale && shift && mean && rstd && dx_hi && sums, "ig_bn_relu_bwd: null pointer");
+    IG_REQUIRE(C % 8 == 0 && C <= 4096, "ig_bn_relu_bwd: C must be a multiple of 8 and <= 4096 (got %d)", C);
+    if (M == 0) return IG_OK;
+    (void)hipMemsetAsync(sums, 0, 2 * (size_t)C * sizeof(double), ST(stream));
+    const int rpb = M > 65536 ? 1024 : 128;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ig_cdiv(M, rpb)), dim3(TPB), 2 * (size_t)C * sizeof(float), ST(stream), (const bf16_t*)x_hi, (const bf16_t*)x_lo,
+                       (const bf16_t*)dy_hi, (const bf16_t*)dy_lo, scale, shift, mean, rstd, sums, M, C, rpb);
+    long units = M * C / 8;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(units, TPB, 16384)), dim3(TPB), 0, ST(stream), (const bf16_t*)x_hi,
+                       (const bf16_t*)x_lo, (const bf16_t*)dy_hi, (const bf16_t*)dy_lo, scale, shift, mean, rstd, sums, (bf16_t*)dx_hi,
+                       (bf16_t*)dx_lo, dgamma, dbeta, units, C, (double)M);
+    return ig_check_launch("ig_bn_relu_bwd");
+}
+
+// hyper: device float[16] (layout above).  ig_adamw_advance increments the step and the bias corrections
+// on the device so that a captured graph can be replayed without host-side scalars.
+int ig_adamw_advance(float* hyper, void* stream) {
+    IG_REQUIRE(hyper, "ig_adamw_advance: null pointer");
+    hipLaunchKernelGGL(adamw_advance_kernel, dim3(1), dim3(64), 0, ST(stream), hyper);
+    return ig_check_launch("ig_adamw_advance");
+}
+int ig_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_hi, void* shadow_lo, const float* hyper, long n,
+                  void* stream) {
+    IG_REQUIRE(p && g && m && v && hyper, "ig_adamw_step: null pointer");
+    IG_REQUIRE(n % 4 == 0, "ig_adamw_step: n must be a multiple of 4 (pad the flat buffer)");
+    if (n == 0) return IG_OK;
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4, TPB, 8192)), dim3(TPB), 0, ST(stream), p, g, m, v, (bf16_t*)shadow_hi,
+                       (bf16_t*)shadow_lo, hyper, n / 4);
+    return ig_check_launch("ig_adamw_step");
+}
+
+}  // extern "C"

@@ -1,0 +1,639 @@
+// Generic bf16 MFMA "gather-GEMM" for gfx950 and every matmul-shaped op of the Prithvi path.
+//
+//   C[m][n] = sum_seg sum_k A_seg(m,k) * B_seg(n,k)           (fp32 accumulate)
+//
+// * 128x128 output tile, BK=64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16x32 bf16.
+// * Operands are fetched in 16-byte units (8 bf16) through *loader functors* that return a global
+//   pointer or NULL (zero fill): plain row-major matrices, NHWC convolution gathers (3x3 conv, stride-2
+//   transposed conv and their gradients) and weight views all go through the same kernel.
+// * Each operand is either K-contiguous (LDS image [row][64 k], ds_read_b128 fragments) or
+//   K-strided / "TR" (LDS image [64 k][128 rows], ds_read_b64_tr_b16 hardware-transposed fragments).
+//   NT = linear/conv forward, (A plain, B TR) = dgrad, (A TR, B TR) = wgrad.
+// * NSEG=3 runs the split-bf16 (hi*hi + hi*lo + lo*hi) precision mode through the same loop.
+// * The MFMA is issued as D = Bfrag x Afrag so that a lane owns 4 consecutive n of one row m:
+//   epilogues store 8-byte (bf16) / 16-byte (fp32) row-contiguous pieces.
+// * register-staged global->LDS double buffering: loads of tile t+1 are in flight during the MFMAs of
+//   tile t; one barrier per K-step.  XOR swizzles keep both fragment read kinds bank-conflict free.
+//
+// Reference ops replaced (file:line in /root/reference): nn.Conv3d patch embed pritvhi.py:243-268;
+// timm Block linears (qkv/proj/fc1/fc2) pritvhi.py:446-456; nn.ConvTranspose2d / nn.Conv2d of the
+// decode head model.py:361-375.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64, NTHR = 256;
+constexpr int TILE_BYTES = 16384;           // one operand tile
+constexpr int SMEM_BYTES = 4 * TILE_BYTES;  // 2 buffers x (A + B)
+
+// LDS images ------------------------------------------------------------------------------------
+// K-contiguous tile: 128 rows x 8 chunks(16 B); chunk ^= row&7  (ds_read_b128 conflict-free)
+__device__ __forceinline__ int lds_kc(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
+// TR tile: 64 k-rows x 16 chunks; chunk pair index ^= key(k) (ds_read_b64_tr_b16 conflict-free)
+__device__ __forceinline__ int lds_tr(int k, int c) {
+    int key = (k & 3) | (((k >> 3) & 1) << 2);
+    return k * 256 + ((c ^ (key << 1)) << 4);
+}
+
+template <bool TR>
+__device__ __forceinline__ bf16x8_t read_frag(const char* tile, int row0, int s, int lane) {
+    if constexpr (!TR) {
+        int r = row0 + (lane & 15);
+        int c = s * 4 + (lane >> 4);
+        return *reinterpret_cast<const bf16x8_t*>(tile + lds_kc(r, c));
+    } else {
+        int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+        int k0 = s * 32 + 8 * g + q;
+        int col = row0 + 4 * p;
+        int chunk = col >> 3, sub = (col & 7) * 2;
+        typedef __attribute__((address_space(3))) s16x4* lds_ptr;
+        s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(tile + lds_tr(k0, chunk) + sub));
+        s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(tile + lds_tr(k0 + 4, chunk) + sub));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        s16x8 r = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        return __builtin_bit_cast(bf16x8_t, r);
+    }
+}
+
+template <class AL, class BL, class EP, bool A_TR, bool B_TR, int NSEG>
+__global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, int N, int K, int tiles_n, int kchunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bm = blockIdx.x / tiles_n, bn = blockIdx.x - bm * tiles_n;
+    al.init(blockIdx.z);
+    bl.init(blockIdx.z);
+    ep.init(blockIdx.z);
+    if (al.kdim() >= 0) K = al.kdim();
+    // split-K (wgrad): blockIdx.y owns k-tiles [kt0, kt0+nk) of every segment
+    const int nk_all = (K + BK - 1) / BK;
+    const int kt0 = blockIdx.y * kchunk;
+    const int nk = min(kchunk, nk_all - kt0);
+    if (nk <= 0) return;
+    const int total = nk * NSEG;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[4], rb[4];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+    auto gload = [&](int it) {
+        int seg = (NSEG == 1) ? 0 : it / nk;
+        int kt = kt0 + it - seg * nk;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int u = tid + i * NTHR;
+            const bf16_t* p;
+            if constexpr (!A_TR) p = al.ptr(seg, bm * BM + (u >> 3), kt * 8 + (u & 7));
+            else p = al.ptr(seg, kt * BK + (u >> 4), bm * 16 + (u & 15));
+            ra[i] = p ? *reinterpret_cast<const uint4*>(p) : zero4;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int u = tid + i * NTHR;
+            const bf16_t* p;
+            if constexpr (!B_TR) p = bl.ptr(seg, bn * BN + (u >> 3), kt * 8 + (u & 7));
+            else p = bl.ptr(seg, kt * BK + (u >> 4), bn * 16 + (u & 15));
+            rb[i] = p ? *reinterpret_cast<const uint4*>(p) : zero4;
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* ta = smem + buf * 2 * TILE_BYTES;
+        char* tb = ta + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int u = tid + i * NTHR;
+            int oa = A_TR ? lds_tr(u >> 4, u & 15) : lds_kc(u >> 3, u & 7);
+            int ob = B_TR ? lds_tr(u >> 4, u & 15) : lds_kc(u >> 3, u & 7);
+            *reinterpret_cast<uint4*>(ta + oa) = ra[i];
+            *reinterpret_cast<uint4*>(tb + ob) = rb[i];
+        }
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int it = 0; it < total; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < total) gload(it + 1);
+        const char* ta = smem + cur * 2 * TILE_BYTES;
+        const char* tb = ta + TILE_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8_t af[4], bf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) af[t] = read_frag<A_TR>(ta, wm * 64 + t * 16, s, lane);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bf[t] = read_frag<B_TR>(tb, wn * 64 + t * 16, s, lane);
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[tn], af[tm], acc[tn][tm], 0, 0, 0);
+        }
+        if (it + 1 < total) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane owns C[m][n..n+3]
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+        int m = bm * BM + wm * 64 + tm * 16 + (lane & 15);
+        if (m >= M) continue;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            int n = bn * BN + wn * 64 + tn * 16 + 4 * (lane >> 4);
+            if (n < N) ep.store(m, n, acc[tn][tm]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ loaders
+struct PlainLoader {  // row-major [R][ld], logical width C (multiple of 8)
+    const bf16_t* base[3];
+    int R, C;
+    long ld;
+    __device__ void init(int) {}
+    __device__ int kdim() const { return -1; }
+    __device__ const bf16_t* ptr(int seg, int r, int c8) const {
+        int c = c8 * 8;
+        return (r < R && c < C) ? base[seg] + (long)r * ld + c : nullptr;
+    }
+};
+
+// NHWC 3x3 pad-1 gather: row r = pixel (b,y,x), column unit -> (tap, channel).  sign=+1 reads
+// (y+ky-1, x+kx-1) (conv forward / wgrad input side), sign=-1 reads (y+1-ky, x+1-kx) (dgrad).
+struct Conv3Loader {
+    const bf16_t* base[3];
+    int Mtot, H, W, C, sign;
+    __device__ void init(int) {}
+    __device__ int kdim() const { return -1; }
+    __device__ const bf16_t* ptr(int seg, int r, int c8) const {
+        int k = c8 * 8;
+        if (r >= Mtot || k >= 9 * C) return nullptr;
+        int tap = k / C, c = k - tap * C;
+        int ky = tap / 3, kx = tap - ky * 3;
+        int hw = H * W;
+        int b = r / hw, rem = r - b * hw;
+        int y = rem / W, x = rem - y * W;
+        int sy = y + sign * (ky - 1), sx = x + sign * (kx - 1);
+        if ((unsigned)sy >= (unsigned)H || (unsigned)sx >= (unsigned)W) return nullptr;
+        return base[seg] + ((long)(b * H + sy) * W + sx) * C + c;
+    }
+};
+
+// ConvTranspose2d(k3,s2,p1,op1) forward, sub-pixel phase z=(py,px): output (2iy+py, 2ix+px) reads taps
+// ky in {1} (py=0) or {0,2} (py=1); tap ky==0 reads input row iy+1, otherwise iy (same for x).
+struct ConvTFwdALoader {
+    const bf16_t* base[3];
+    int Mtot, H, W, C;
+    int nky, nkx, ky0, kx0, K;
+    __device__ void init(int z) {
+        int py = z >> 1, px = z & 1;
+        nky = py ? 2 : 1, nkx = px ? 2 : 1;
+        ky0 = py ? 0 : 1, kx0 = px ? 0 : 1;  // tap lists: {1} or {0,2}
+        K = nky * nkx * C;
+    }
+    __device__ int kdim() const { return K; }
+    __device__ const bf16_t* ptr(int seg, int r, int c8) const {
+        int k = c8 * 8;
+        if (r >= Mtot || k >= K) return nullptr;
+        int tl = k / C, c = k - tl * C;
+        int tyi = tl / nkx, txi = tl - tyi * nkx;
+        int ky = ky0 + 2 * tyi, kx = kx0 + 2 * txi;
+        int hw = H * W;
+        int b = r / hw, rem = r - b * hw;
+        int y = rem / W, x = rem - y * W;
+        int sy = y + (ky == 0), sx = x + (kx == 0);
+        if (sy >= H || sx >= W) return nullptr;
+        return base[seg] + ((long)(b * H + sy) * W + sx) * C + c;
+    }
+};
+// matching weight view: n = co, k = (local tap, ci) of storage Wc[co][tap][ci]
+struct ConvTFwdBLoader {
+    const bf16_t* base[3];
+    int Cout, C;
+    int nky, nkx, ky0, kx0, K;
+    __device__ void init(int z) {
+        int py = z >> 1, px = z & 1;
+        nky = py ? 2 : 1, nkx = px ? 2 : 1;
+        ky0 = py ? 0 : 1, kx0 = px ? 0 : 1;
+        K = nky * nkx * C;
+    }
+    __device__ int kdim() const { return K; }
+    __device__ const bf16_t* ptr(int seg, int r, int c8) const {
+        int k = c8 * 8;
+        if (r >= Cout || k >= K) return nullptr;
+        int tl = k / C, c = k - tl * C;
+        int tyi = tl / nkx, txi = tl - tyi * nkx;
+        int tap = (ky0 + 2 * tyi) * 3 + (kx0 + 2 * txi);
+        return base[seg] + ((long)r * 9 + tap) * C + c;
+    }
+};
+
+// dgrad weight view (TR operand): reduce row = (tap, co), contiguous columns = ci of Wc[co][tap][ci]
+struct ConvWgtTRLoader {
+    const bf16_t* base[3];
+    int Cout, Cin;
+    __device__ void init(int) {}
+    __device__ int kdim() const { return -1; }
+    __device__ const bf16_t* ptr(int seg, int r, int c8) const {
+        int c = c8 * 8;
+        int tap = r / Cout, co = r - tap * Cout;
+        if (tap >= 9 || c >= Cin) return nullptr;
+        return base[seg] + ((long)co * 9 + tap) * Cin + c;
+    }
+};
+
+// ConvTranspose dgrad A: row = input pixel (b,iy,ix), k = (tap, co): reads dOut(2iy-1+ky, 2ix-1+kx).
+// With fixed_tap >= 0 (wgrad, TR operand) the column unit is co only and the tap comes from init(z).
+struct ConvTGradLoader {
+    const bf16_t* base[3];
+    int Mtot, H, W, Cout;  // H,W = input resolution; dOut is (2H,2W)
+    int fixed_tap;         // -1: k=(tap,co); -2: take tap from blockIdx.z
+    int tapz;
+    __device__ void init(int z) { tapz = z; }
+    __device__ int kdim() const { return -1; }
+    __device__ const bf16_t* ptr(int seg, int r, int c8) const {
+        int k = c8 * 8;
+        int tap, c;
+        if (fixed_tap == -1) {
+            tap = k / Cout, c = k - tap * Cout;
+            if (tap >= 9) return nullptr;
+        } else {
+            tap = tapz, c = k;
+            if (c >= Cout) return nullptr;
+        }
+        if (r >= Mtot) return nullptr;
+        int ky = tap / 3, kx = tap - ky * 3;
+        int hw = H * W;
+        int b = r / hw, rem = r - b * hw;
+        int y = rem / W, x = rem - y * W;
+        int oy = 2 * y - 1 + ky, ox = 2 * x - 1 + kx;
+        if ((unsigned)oy >= (unsigned)(2 * H) || (unsigned)ox >= (unsigned)(2 * W)) return nullptr;
+        return base[seg] + ((long)(b * 2 * H + oy) * (2 * W) + ox) * Cout + c;
+    }
+};
+
+// ---------------------------------------------------------------------------------- epilogues
+// bf16/split store: out = drop(act(acc + bias)); optional pre-activation copy; optional ConvT phase row map
+struct EpStore {
+    bf16_t *out_hi, *out_lo;
+    bf16_t *pre_hi, *pre_lo;
+    const float* bias;
+    long ldo;
+    int act;  // 0 none, 1 exact GELU
+    uint32_t drop_seed, drop_thresh;
+    float drop_inv;
+    int phase_map, H, W;  // phase_map=1: row (b,iy,ix) -> (b, 2iy+py, 2ix+px) of a (2H,2W) image
+    int py, px;
+    __device__ void init(int z) { py = z >> 1, px = z & 1; }
+    __device__ void store(int m, int n, f32x4 a) const {
+        long row = m;
+        if (phase_map) {
+            int hw = H * W;
+            int b = m / hw, rem = m - b * hw;
+            int y = rem / W, x = rem - y * W;
+            row = ((long)(b * 2 * H + 2 * y + py)) * (2 * W) + 2 * x + px;
+        }
+        float v[4] = {a[0], a[1], a[2], a[3]};
+        if (bias) {
+            float4 bb = *reinterpret_cast<const float4*>(bias + n);
+            v[0] += bb.x, v[1] += bb.y, v[2] += bb.z, v[3] += bb.w;
+        }
+        size_t idx = (size_t)row * ldo + n;
+        if (act == 1) {
+            if (pre_hi) store4_split(pre_hi, pre_lo, idx, v);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
+        }
+        if (drop_thresh) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] *= dropout_scale(drop_seed, idx + i, drop_thresh, drop_inv);
+        }
+        store4_split(out_hi, out_lo, idx, v);
+    }
+};
+
+// dgrad store with an elementwise factor: mode 1: * gelu'(pre[m][n]); mode 2: * dropout mask(idx)
+struct EpGradStore {
+    bf16_t *out_hi, *out_lo;
+    const bf16_t *pre_hi, *pre_lo;
+    long ldo;
+    int mode;
+    uint32_t drop_seed, drop_thresh;
+    float drop_inv;
+    __device__ void init(int) {}
+    __device__ void store(int m, int n, f32x4 a) const {
+        size_t idx = (size_t)m * ldo + n;
+        float v[4] = {a[0], a[1], a[2], a[3]};
+        if (mode == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] *= gelu_erf_grad(load1_split(pre_hi, pre_lo, idx + i));
+        } else if (mode == 2 && drop_thresh) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] *= dropout_scale(drop_seed, idx + i, drop_thresh, drop_inv);
+        }
+        store4_split(out_hi, out_lo, idx, v);
+    }
+};
+
+// fp32 residual: out[m][n] = resid[m][n] + acc + bias[n]
+struct EpResidual {
+    float* out;
+    const float* resid;
+    const float* bias;
+    long ldo;
+    __device__ void init(int) {}
+    __device__ void store(int m, int n, f32x4 a) const {
+        size_t idx = (size_t)m * ldo + n;
+        float4 r = *reinterpret_cast<const float4*>(resid + idx);
+        float4 bb = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0, 0, 0, 0);
+        float4 o = make_float4(r.x + a[0] + bb.x, r.y + a[1] + bb.y, r.z + a[2] + bb.z, r.w + a[3] + bb.w);
+        *reinterpret_cast<float4*>(out + idx) = o;
+    }
+};
+
+// patch embed: token row m=(b, tp) -> x[b*Ntok + 1 + tp][n] = acc + bias[n] + pos[1+tp][n]   (pritvhi.py:513-517)
+struct EpPatchEmbed {
+    float* x;
+    const float* bias;
+    const float* pos;  // [Ntok][D]
+    int tokens_per_chip;  // T*g*g
+    long D;
+    __device__ void init(int) {}
+    __device__ void store(int m, int n, f32x4 a) const {
+        int b = m / tokens_per_chip, tp = m - b * tokens_per_chip;
+        size_t row = (size_t)b * (tokens_per_chip + 1) + 1 + tp;
+        float4 bb = *reinterpret_cast<const float4*>(bias + n);
+        float4 pp = *reinterpret_cast<const float4*>(pos + (size_t)(1 + tp) * D + n);
+        float4 o = make_float4(a[0] + bb.x + pp.x, a[1] + bb.y + pp.y, a[2] + bb.z + pp.z, a[3] + bb.w + pp.w);
+        *reinterpret_cast<float4*>(x + row * D + n) = o;
+    }
+};
+
+// wgrad: fp32 atomic accumulate into the gradient buffer; column offset z*zstride (ConvT taps)
+struct EpAtomic {
+    float* out;
+    long ldo;
+    long zstride;
+    long zoff;
+    __device__ void init(int z) { zoff = (long)z * zstride; }
+    __device__ void store(int m, int n, f32x4 a) const {
+        float* p = out + (size_t)m * ldo + zoff + n;
+        atomicAdd(p + 0, a[0]);
+        atomicAdd(p + 1, a[1]);
+        atomicAdd(p + 2, a[2]);
+        atomicAdd(p + 3, a[3]);
+    }
+};
+
+// ------------------------------------------------------------------------------------ launch
+template <class AL, class BL, class EP, bool A_TR, bool B_TR>
+int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int Z, bool split, hipStream_t st,
+                const char* what, bool allow_ksplit = false) {
+    if (M <= 0 || N <= 0 || K <= 0) return IG_OK;
+    int tm = ig_cdiv(M, BM), tn = ig_cdiv(N, BN);
+    int nk_all = ig_cdiv(K, BK);
+    int ksplit = 1;
+    if (allow_ksplit) {  // atomic epilogues only: aim for ~4 blocks per CU, at least 4 k-tiles per block
+        int tiles = tm * tn * Z;
+        ksplit = (1024 + tiles - 1) / tiles;
+        if (ksplit > nk_all / 4) ksplit = nk_all / 4;
+        if (ksplit < 1) ksplit = 1;
+    }
+    int kchunk = ig_cdiv(nk_all, ksplit);
+    ksplit = ig_cdiv(nk_all, kchunk);
+    dim3 grid(tm * tn, ksplit, Z), block(NTHR);
+    if (split) {
+        auto kern = gemm_kernel<AL, BL, EP, A_TR, B_TR, 3>;
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(kern, grid, block, SMEM_BYTES, st, al, bl, ep, M, N, K, tn, kchunk);
+    } else {
+        auto kern = gemm_kernel<AL, BL, EP, A_TR, B_TR, 1>;
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(kern, grid, block, SMEM_BYTES, st, al, bl, ep, M, N, K, tn, kchunk);
+    }
+    return ig_check_launch(what);
+}
+
+// segment pointer sets: A uses (hi,hi,lo), B uses (hi,lo,hi)
+inline void seg_a(const bf16_t* (&b)[3], const void* hi, const void* lo) {
+    b[0] = (const bf16_t*)hi, b[1] = (const bf16_t*)hi, b[2] = (const bf16_t*)(lo ? lo : hi);
+}
+inline void seg_b(const bf16_t* (&b)[3], const void* hi, const void* lo) {
+    b[0] = (const bf16_t*)hi, b[1] = (const bf16_t*)(lo ? lo : hi), b[2] = (const bf16_t*)hi;
+}
+inline PlainLoader plain_a(const void* hi, const void* lo, int R, int C, long ld) {
+    PlainLoader l;
+    seg_a(l.base, hi, lo);
+    l.R = R, l.C = C, l.ld = ld;
+    return l;
+}
+inline PlainLoader plain_b(const void* hi, const void* lo, int R, int C, long ld) {
+    PlainLoader l;
+    seg_b(l.base, hi, lo);
+    l.R = R, l.C = C, l.ld = ld;
+    return l;
+}
+inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace
+
+#define IG_SPLIT_CONSISTENT(a_lo, b_lo) \
+    IG_REQUIRE(((a_lo) == nullptr) == ((b_lo) == nullptr), "split (lo) pointers must be given for all bf16 operands or none")
+
+extern "C" {
+
+// y[M][N] = act(x[M][K] @ w[N][K]^T + bias)            act: 0 none, 1 GELU (pre-activation copy optional)
+int ig_linear_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
+                  void* y_hi, void* y_lo, void* pre_hi, void* pre_lo, int M, int N, int K, int act, void* stream) {
+    IG_REQUIRE(x_hi && w_hi && y_hi, "ig_linear_fwd: null pointer");
+    IG_REQUIRE(N % 8 == 0 && K % 8 == 0, "ig_linear_fwd: N and K must be multiples of 8 (got %d, %d)", N, K);
+    IG_REQUIRE(aligned16(x_hi) && aligned16(w_hi) && aligned16(y_hi), "ig_linear_fwd: pointers must be 16-byte aligned");
+    IG_SPLIT_CONSISTENT(x_lo, w_lo);
+    EpStore ep{};
+    ep.out_hi = (bf16_t*)y_hi, ep.out_lo = (bf16_t*)y_lo, ep.pre_hi = (bf16_t*)pre_hi, ep.pre_lo = (bf16_t*)pre_lo;
+    ep.bias = bias, ep.ldo = N, ep.act = act;
+    return launch_gemm<PlainLoader, PlainLoader, EpStore, false, false>(
+        plain_a(x_hi, x_lo, M, K, K), plain_b(w_hi, w_lo, N, K, K), ep, M, N, K, 1, x_lo != nullptr, (hipStream_t)stream,
+        "ig_linear_fwd");
+}
+
+// out_f32[M][N] = resid[M][N] + x @ w^T + bias      (residual-stream update; out may alias resid)
+int ig_linear_residual_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
+                           const float* resid, float* out, int M, int N, int K, void* stream) {
+    IG_REQUIRE(x_hi && w_hi && resid && out, "ig_linear_residual_fwd: null pointer");
+    IG_REQUIRE(N % 8 == 0 && K % 8 == 0, "ig_linear_residual_fwd: N and K must be multiples of 8");
+    IG_SPLIT_CONSISTENT(x_lo, w_lo);
+    EpResidual ep{out, resid, bias, (long)N};
+    return launch_gemm<PlainLoader, PlainLoader, EpResidual, false, false>(
+        plain_a(x_hi, x_lo, M, K, K), plain_b(w_hi, w_lo, N, K, K), ep, M, N, K, 1, x_lo != nullptr, (hipStream_t)stream,
+        "ig_linear_residual_fwd");
+}
+
+// dx[M][K] = dy[M][N] @ w[N][K]       mode 0: plain store, 1: * gelu'(pre[M][K])
+int ig_linear_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, const void* w_lo, void* dx_hi, void* dx_lo,
+                    const void* pre_hi, const void* pre_lo, int M, int N, int K, int mode, void* stream) {
+    IG_REQUIRE(dy_hi && w_hi && dx_hi, "ig_linear_dgrad: null pointer");
+    IG_REQUIRE(N % 8 == 0 && K % 8 == 0, "ig_linear_dgrad: N and K must be multiples of 8");
+    IG_REQUIRE(mode == 0 || (mode == 1 && pre_hi), "ig_linear_dgrad: mode 1 needs the pre-activation tensor");
+    IG_SPLIT_CONSISTENT(dy_lo, w_lo);
+    EpGradStore ep{};
+    ep.out_hi = (bf16_t*)dx_hi, ep.out_lo = (bf16_t*)dx_lo, ep.pre_hi = (const bf16_t*)pre_hi, ep.pre_lo = (const bf16_t*)pre_lo;
+    ep.ldo = K, ep.mode = mode;
+    // C[m][k] = sum_n dy[m][n] * w[n][k]: reduce dim = N; B operand is TR (rows n, contiguous k)
+    return launch_gemm<PlainLoader, PlainLoader, EpGradStore, false, true>(
+        plain_a(dy_hi, dy_lo, M, N, N), plain_b(w_hi, w_lo, N, K, K), ep, M, K, N, 1, dy_lo != nullptr, (hipStream_t)stream,
+        "ig_linear_dgrad");
+}
+
+// dw[N][K] += dy[M][N]^T @ x[M][K]   (fp32 atomic accumulate)
+int ig_linear_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const void* x_lo, float* dw, int M, int N,
+                    int K, void* stream) {
+    IG_REQUIRE(dy_hi && x_hi && dw, "ig_linear_wgrad: null pointer");
+    IG_REQUIRE(N % 8 == 0 && K % 8 == 0, "ig_linear_wgrad: N and K must be multiples of 8");
+    IG_SPLIT_CONSISTENT(dy_lo, x_lo);
+    EpAtomic ep{dw, (long)K, 0, 0};
+    return launch_gemm<PlainLoader, PlainLoader, EpAtomic, true, true>(
+        plain_a(dy_hi, dy_lo, M, N, N), plain_b(x_hi, x_lo, M, K, K), ep, N, K, M, 1, dy_lo != nullptr, (hipStream_t)stream,
+        "ig_linear_wgrad", true);
+}
+
+// Patch embedding (pritvhi.py:243-268,513-517): x[b][1+tp][:] = patches[b*TP+tp] @ w^T + bias + pos[1+tp]
+int ig_patch_embed_fwd(const void* p_hi, const void* p_lo, const void* w_hi, const void* w_lo, const float* bias,
+                       const float* pos, float* x, int batch, int tokens_per_chip, int D, int K, void* stream) {
+    IG_REQUIRE(p_hi && w_hi && bias && pos && x, "ig_patch_embed_fwd: null pointer");
+    IG_REQUIRE(D % 8 == 0 && K % 8 == 0, "ig_patch_embed_fwd: D and K must be multiples of 8");
+    IG_SPLIT_CONSISTENT(p_lo, w_lo);
+    int M = batch * tokens_per_chip;
+    EpPatchEmbed ep{x, bias, pos, tokens_per_chip, (long)D};
+    return launch_gemm<PlainLoader, PlainLoader, EpPatchEmbed, false, false>(
+        plain_a(p_hi, p_lo, M, K, K), plain_b(w_hi, w_lo, D, K, K), ep, M, D, K, 1, p_lo != nullptr, (hipStream_t)stream,
+        "ig_patch_embed_fwd");
+}
+
+// ---- 3x3 pad-1 convolution, NHWC activations, weight storage Wc[Cout][9][Cin] (tap = ky*3+kx) ----
+// model.py:370-375 (nn.Conv2d(k=3,padding=1))
+int ig_conv3x3_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias, void* y_hi,
+                   void* y_lo, int B, int H, int W, int Cin, int Cout, void* stream) {
+    IG_REQUIRE(x_hi && w_hi && y_hi, "ig_conv3x3_fwd: null pointer");
+    IG_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, "ig_conv3x3_fwd: channels must be multiples of 8");
+    IG_SPLIT_CONSISTENT(x_lo, w_lo);
+    Conv3Loader al{};
+    seg_a(al.base, x_hi, x_lo);
+    al.Mtot = B * H * W, al.H = H, al.W = W, al.C = Cin, al.sign = 1;
+    EpStore ep{};
+    ep.out_hi = (bf16_t*)y_hi, ep.out_lo = (bf16_t*)y_lo, ep.bias = bias, ep.ldo = Cout;
+    return launch_gemm<Conv3Loader, PlainLoader, EpStore, false, false>(
+        al, plain_b(w_hi, w_lo, Cout, 9 * Cin, 9L * Cin), ep, al.Mtot, Cout, 9 * Cin, 1, x_lo != nullptr,
+        (hipStream_t)stream, "ig_conv3x3_fwd");
+}
+
+// dx = conv_dgrad(dy, w) [* dropout mask of the conv input when drop_p > 0]
+int ig_conv3x3_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, const void* w_lo, void* dx_hi, void* dx_lo,
+                     int B, int H, int W, int Cin, int Cout, unsigned drop_seed, float drop_p, void* stream) {
+    IG_REQUIRE(dy_hi && w_hi && dx_hi, "ig_conv3x3_dgrad: null pointer");
+    IG_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, "ig_conv3x3_dgrad: channels must be multiples of 8");
+    IG_SPLIT_CONSISTENT(dy_lo, w_lo);
+    Conv3Loader al{};
+    seg_a(al.base, dy_hi, dy_lo);
+    al.Mtot = B * H * W, al.H = H, al.W = W, al.C = Cout, al.sign = -1;
+    ConvWgtTRLoader bl{};
+    seg_b(bl.base, w_hi, w_lo);
+    bl.Cout = Cout, bl.Cin = Cin;
+    EpGradStore ep{};
+    ep.out_hi = (bf16_t*)dx_hi, ep.out_lo = (bf16_t*)dx_lo, ep.ldo = Cin, ep.mode = 2;
+    ep.drop_seed = drop_seed;
+    ep.drop_thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    ep.drop_inv = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    return launch_gemm<Conv3Loader, ConvWgtTRLoader, EpGradStore, false, true>(
+        al, bl, ep, al.Mtot, Cin, 9 * Cout, 1, dy_lo != nullptr, (hipStream_t)stream, "ig_conv3x3_dgrad");
+}
+
+// dWc[Cout][9][Cin] += sum_pixels dy[p][co] * x[shift_tap(p)][ci]
+int ig_conv3x3_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const void* x_lo, float* dw, int B, int H,
+                     int W, int Cin, int Cout, void* stream) {
+    IG_REQUIRE(dy_hi && x_hi && dw, "ig_conv3x3_wgrad: null pointer");
+    IG_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, "ig_conv3x3_wgrad: channels must be multiples of 8");
+    IG_SPLIT_CONSISTENT(dy_lo, x_lo);
+    int Mtot = B * H * W;
+    Conv3Loader bl{};
+    seg_b(bl.base, x_hi, x_lo);
+    bl.Mtot = Mtot, bl.H = H, bl.W = W, bl.C = Cin, bl.sign = 1;
+    EpAtomic ep{dw, 9L * Cin, 0, 0};
+    return launch_gemm<PlainLoader, Conv3Loader, EpAtomic, true, true>(
+        plain_a(dy_hi, dy_lo, Mtot, Cout, Cout), bl, ep, Cout, 9 * Cin, Mtot, 1, dy_lo != nullptr, (hipStream_t)stream,
+        "ig_conv3x3_wgrad", true);
+}
+
+// ---- ConvTranspose2d(k=3,s=2,p=1,op=1), NHWC, weight storage Wc[Cout][9][Cin]  (model.py:361-368) ----
+// y (2H,2W) = drop(convT(x) + bias): four sub-pixel phase GEMMs in one launch (blockIdx.z = phase)
+int ig_convT_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias, void* y_hi,
+                 void* y_lo, int B, int H, int W, int Cin, int Cout, unsigned drop_seed, float drop_p, void* stream) {
+    IG_REQUIRE(x_hi && w_hi && y_hi, "ig_convT_fwd: null pointer");
+    IG_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, "ig_convT_fwd: channels must be multiples of 8");
+    IG_SPLIT_CONSISTENT(x_lo, w_lo);
+    ConvTFwdALoader al{};
+    seg_a(al.base, x_hi, x_lo);
+    al.Mtot = B * H * W, al.H = H, al.W = W, al.C = Cin;
+    ConvTFwdBLoader bl{};
+    seg_b(bl.base, w_hi, w_lo);
+    bl.Cout = Cout, bl.C = Cin;
+    EpStore ep{};
+    ep.out_hi = (bf16_t*)y_hi, ep.out_lo = (bf16_t*)y_lo, ep.bias = bias, ep.ldo = Cout;
+    ep.phase_map = 1, ep.H = H, ep.W = W;
+    ep.drop_seed = drop_seed;
+    ep.drop_thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    ep.drop_inv = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    return launch_gemm<ConvTFwdALoader, ConvTFwdBLoader, EpStore, false, false>(
+        al, bl, ep, al.Mtot, Cout, 4 * Cin, 4, x_lo != nullptr, (hipStream_t)stream, "ig_convT_fwd");
+}
+
+// dx (H,W,Cin) = stride-2 gather of dy (2H,2W,Cout) against Wc
+int ig_convT_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, const void* w_lo, void* dx_hi, void* dx_lo,
+                   int B, int H, int W, int Cin, int Cout, void* stream) {
+    IG_REQUIRE(dy_hi && w_hi && dx_hi, "ig_convT_dgrad: null pointer");
+    IG_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, "ig_convT_dgrad: channels must be multiples of 8");
+    IG_SPLIT_CONSISTENT(dy_lo, w_lo);
+    ConvTGradLoader al{};
+    seg_a(al.base, dy_hi, dy_lo);
+    al.Mtot = B * H * W, al.H = H, al.W = W, al.Cout = Cout, al.fixed_tap = -1;
+    ConvWgtTRLoader bl{};
+    seg_b(bl.base, w_hi, w_lo);
+    bl.Cout = Cout, bl.Cin = Cin;
+    EpGradStore ep{};
+    ep.out_hi = (bf16_t*)dx_hi, ep.out_lo = (bf16_t*)dx_lo, ep.ldo = Cin, ep.mode = 0;
+    return launch_gemm<ConvTGradLoader, ConvWgtTRLoader, EpGradStore, false, true>(
+        al, bl, ep, al.Mtot, Cin, 9 * Cout, 1, dy_lo != nullptr, (hipStream_t)stream, "ig_convT_dgrad");
+}
+
+// dWc[Cout][tap][Cin] += sum_{input pixels} dy[shift_tap(p)][co] * x[p][ci]     (blockIdx.z = tap)
+int ig_convT_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const void* x_lo, float* dw, int B, int H,
+                   int W, int Cin, int Cout, void* stream) {
+    IG_REQUIRE(dy_hi && x_hi && dw, "ig_convT_wgrad: null pointer");
+    IG_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, "ig_convT_wgrad: channels must be multiples of 8");
+    IG_SPLIT_CONSISTENT(dy_lo, x_lo);
+    int Mtot = B * H * W;
+    ConvTGradLoader al{};
+    seg_a(al.base, dy_hi, dy_lo);
+    al.Mtot = Mtot, al.H = H, al.W = W, al.Cout = Cout, al.fixed_tap = -2;
+    EpAtomic ep{dw, 9L * Cin, (long)Cin, 0};
+    return launch_gemm<ConvTGradLoader, PlainLoader, EpAtomic, true, true>(
+        al, plain_b(x_hi, x_lo, Mtot, Cin, Cin), ep, Cout, Cin, Mtot, 9, dy_lo != nullptr, (hipStream_t)stream,
+        "ig_convT_wgrad", true);
+}
+
+}  // extern "C"

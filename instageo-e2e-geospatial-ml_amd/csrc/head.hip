@@ -1,0 +1,297 @@
+// Classifier (1x1 conv), segmentation loss, argmax and streaming confusion matrix for gfx950.
+// HBM-bound per-pixel kernels: one thread per pixel, 16-byte NHWC reads, plane-coalesced NCHW logits.
+//   K14 nn.Conv2d(48T -> ncls, k=1) preceded by Dropout(0.1)      model.py:388-389
+//   K15 CrossEntropyLoss(weight, ignore_index, 'none') + loss[mask].mean()   segmentation.py:85-87,117-122
+//   K16 argmax / softmax                                              segmentation.py:125-126, infer_utils.py:99-101
+//   K17 np.bincount(y_true*k + y_pred) confusion matrix (int64)       metrics.py:86-108
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int MAXC = 16;  // max classes held in registers
+
+// logits[b][n][pix] = bias[n] + sum_c drop(f[b][pix][c]) * w[n][c]
+__global__ __launch_bounds__(TPB) void classifier_fwd_kernel(const bf16_t* __restrict__ f_hi, const bf16_t* __restrict__ f_lo,
+                                                             const float* __restrict__ w, const float* __restrict__ bias,
+                                                             float* __restrict__ logits, long M, long HW, int C, int ncls,
+                                                             uint32_t drop_seed, uint32_t drop_thresh, float drop_inv) {
+    extern __shared__ float sw[];  // [ncls][C] + [ncls]
+    for (int i = threadIdx.x; i < ncls * C; i += TPB) sw[i] = w[i];
+    for (int i = threadIdx.x; i < ncls; i += TPB) sw[ncls * C + i] = bias[i];
+    __syncthreads();
+    long m = blockIdx.x * (long)TPB + threadIdx.x;
+    if (m >= M) return;
+    float acc[MAXC];
+#pragma unroll
+    for (int n = 0; n < MAXC; ++n) acc[n] = n < ncls ? sw[ncls * C + n] : 0.f;
+    for (int c8 = 0; c8 < C / 8; ++c8) {
+        float f[8];
+        size_t idx = (size_t)m * C + c8 * 8;
+        load8_split(f_hi, f_lo, idx, f);
+        if (drop_thresh) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] *= dropout_scale(drop_seed, idx + j, drop_thresh, drop_inv);
+        }
+#pragma unroll
+        for (int n = 0; n < MAXC; ++n) {
+            if (n < ncls) {
+                const float* wr = sw + n * C + c8 * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[n] += f[j] * wr[j];
+            }
+        }
+    }
+    long b = m / HW, pix = m - b * HW;
+#pragma unroll
+    for (int n = 0; n < MAXC; ++n)
+        if (n < ncls) logits[(b * ncls + n) * HW + pix] = acc[n];
+}
+
+// df[m][c] = drop_mask * sum_n dl[b][n][pix] * w[n][c] * gscale ; dW[n][c] += sum_m dl*f_dropped ; db[n] += sum_m dl
+// gscale = 1/(*count) when count != NULL (fused trainer: dlogits left un-normalised by the loss kernel)
+__global__ __launch_bounds__(TPB) void classifier_bwd_kernel(const float* __restrict__ dl, const bf16_t* __restrict__ f_hi,
+                                                             const bf16_t* __restrict__ f_lo, const float* __restrict__ w,
+                                                             bf16_t* __restrict__ df_hi, bf16_t* __restrict__ df_lo,
+                                                             float* __restrict__ dw, float* __restrict__ db, const double* count,
+                                                             long M, long HW, int C, int ncls, uint32_t drop_seed,
+                                                             uint32_t drop_thresh, float drop_inv) {
+    extern __shared__ float sm[];  // w[ncls*C] | dwacc[ncls*C] | dbacc[ncls]
+    float* sw = sm;
+    float* sdw = sm + ncls * C;
+    float* sdb = sdw + ncls * C;
+    for (int i = threadIdx.x; i < ncls * C; i += TPB) sw[i] = w[i], sdw[i] = 0.f;
+    for (int i = threadIdx.x; i < ncls; i += TPB) sdb[i] = 0.f;
+    __syncthreads();
+    const float gscale = count ? (float)(1.0 / fmax(count[1], 1.0)) : 1.f;
+    long m = blockIdx.x * (long)TPB + threadIdx.x;
+    const bool act = m < M;
+    float g[MAXC];
+    long b = act ? m / HW : 0, pix = act ? m - b * HW : 0;
+#pragma unroll
+    for (int n = 0; n < MAXC; ++n) g[n] = (act && n < ncls) ? dl[(b * ncls + n) * HW + pix] * gscale : 0.f;
+    const int lane = threadIdx.x & 63;
+    for (int c8 = 0; c8 < C / 8; ++c8) {
+        float f[8], o[8];
+        size_t idx = (size_t)m * C + c8 * 8;
+        if (act) load8_split(f_hi, f_lo, idx, f);
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = 0.f;
+        }
+        float msk[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            msk[j] = (drop_thresh && act) ? dropout_scale(drop_seed, idx + j, drop_thresh, drop_inv) : 1.f;
+            f[j] *= msk[j];
+            o[j] = 0.f;
+        }
+#pragma unroll
+        for (int n = 0; n < MAXC; ++n) {
+            if (n < ncls) {
+                const float* wr = sw + n * C + c8 * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    o[j] += g[n] * wr[j];
+                    float t = wave_sum(g[n] * f[j]);  // wave-level partial of dW[n][c]
+                    if (lane == 0) atomicAdd(sdw + n * C + c8 * 8 + j, t);
+                }
+            }
+        }
+        if (act) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] *= msk[j];
+            store8_split(df_hi, df_lo, idx, o);
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < MAXC; ++n) {
+        if (n < ncls) {
+            float t = wave_sum(g[n]);
+            if (lane == 0) atomicAdd(sdb + n, t);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ncls * C; i += TPB) atomicAdd(dw + i, sdw[i]);
+    for (int i = threadIdx.x; i < ncls; i += TPB) atomicAdd(db + i, sdb[i]);
+}
+
+// stats[0] += sum w_y*nll over valid pixels ; stats[1] += #valid.  dlogits (optional) is left UN-normalised:
+// dl[n] = w_y*(softmax_n - [n==y]) (0 on ignored pixels); divide by stats[1] downstream.
+// preds (optional): int64 argmax (first maximal index, as torch.argmax); confusion (optional): int64 [k][k].
+template <typename LABEL>
+__global__ __launch_bounds__(TPB) void ce_loss_kernel(const float* __restrict__ logits, const LABEL* __restrict__ labels,
+                                                      const float* __restrict__ cw, long ignore_index, double* __restrict__ stats,
+                                                      float* __restrict__ dlogits, long long* __restrict__ preds,
+                                                      signed char* __restrict__ preds_i8, unsigned long long* __restrict__ confusion,
+                                                      long M, long HW, int ncls) {
+    extern __shared__ unsigned int hist[];  // [ncls*ncls] + 2 floats for loss/count
+    float* red = reinterpret_cast<float*>(hist + ncls * ncls);
+    for (int i = threadIdx.x; i < ncls * ncls; i += TPB) hist[i] = 0u;
+    if (threadIdx.x < 2) red[threadIdx.x] = 0.f;
+    __syncthreads();
+    long m = blockIdx.x * (long)TPB + threadIdx.x;
+    float my_loss = 0.f, my_cnt = 0.f;
+    if (m < M) {
+        long b = m / HW, pix = m - b * HW;
+        float z[MAXC];
+        float mx = -INFINITY;
+        int am = 0;
+#pragma unroll
+        for (int n = 0; n < MAXC; ++n) {
+            if (n < ncls) {
+                z[n] = logits[(b * ncls + n) * HW + pix];
+                if (z[n] > mx) mx = z[n], am = n;
+            }
+        }
+        float se = 0.f;
+#pragma unroll
+        for (int n = 0; n < MAXC; ++n)
+            if (n < ncls) se += __expf(z[n] - mx);
+        float lse = mx + __logf(se);
+        long y = (long)labels[m];
+        bool valid = (y != ignore_index) && y >= 0 && y < ncls;
+        float wy = valid ? (cw ? cw[y] : 1.f) : 0.f;
+        if (valid) {
+            float zy = 0.f;
+#pragma unroll
+            for (int n = 0; n < MAXC; ++n)
+                if (n == (int)y) zy = z[n];
+            my_loss = wy * (lse - zy);
+            my_cnt = 1.f;
+            if (confusion) atomicAdd(hist + (int)y * ncls + am, 1u);
+        }
+        if (dlogits) {
+#pragma unroll
+            for (int n = 0; n < MAXC; ++n)
+                if (n < ncls) dlogits[(b * ncls + n) * HW + pix] = wy * (__expf(z[n] - lse) - (n == (int)y ? 1.f : 0.f));
+        }
+        if (preds) preds[m] = am;
+        if (preds_i8) preds_i8[m] = (signed char)am;
+    }
+    my_loss = wave_sum(my_loss);
+    my_cnt = wave_sum(my_cnt);
+    if ((threadIdx.x & 63) == 0) atomicAdd(red, my_loss), atomicAdd(red + 1, my_cnt);
+    __syncthreads();
+    if (threadIdx.x == 0 && stats) atomicAdd(stats, (double)red[0]), atomicAdd(stats + 1, (double)red[1]);
+    if (confusion)
+        for (int i = threadIdx.x; i < ncls * ncls; i += TPB)
+            if (hist[i]) atomicAdd(confusion + i, (unsigned long long)hist[i]);
+}
+
+// argmax over classes -> int8 class map (infer_utils.py:99-101)
+__global__ void argmax_kernel(const float* __restrict__ logits, signed char* __restrict__ out, long M, long HW, int ncls) {
+    long m = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    long b = m / HW, pix = m - b * HW;
+    float mx = -INFINITY;
+    int am = 0;
+    for (int n = 0; n < ncls; ++n) {
+        float z = logits[(b * ncls + n) * HW + pix];
+        if (z > mx) mx = z, am = n;
+    }
+    out[m] = (signed char)am;
+}
+
+// confusion[y*k + p] += 1 over pixels with y != ignore  (metrics.py:86-108) for externally produced predictions
+__global__ __launch_bounds__(TPB) void confusion_kernel(const long long* __restrict__ y_true, const long long* __restrict__ y_pred,
+                                                        unsigned long long* __restrict__ confusion, long n, int k, long ignore_index,
+                                                        int has_ignore) {
+    extern __shared__ unsigned int hist[];
+    for (int i = threadIdx.x; i < k * k; i += TPB) hist[i] = 0u;
+    __syncthreads();
+    for (long i = blockIdx.x * (long)TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB) {
+        long long t = y_true[i], p = y_pred[i];
+        if (has_ignore && t == ignore_index) continue;
+        if (t < 0 || t >= k || p < 0 || p >= k) continue;
+        atomicAdd(hist + (int)t * k + (int)p, 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < k * k; i += TPB)
+        if (hist[i]) atomicAdd(confusion + i, (unsigned long long)hist[i]);
+}
+
+inline uint32_t thresh_of(float p) { return p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u; }
+
+}  // namespace
+
+extern "C" {
+
+int ig_classifier_fwd(const void* f_hi, const void* f_lo, const float* w, const float* bias, float* logits, int B, long HW, int C,
+                      int ncls, unsigned drop_seed, float drop_p, void* stream) {
+    IG_REQUIRE(f_hi && w && bias && logits, "ig_classifier_fwd: null pointer");
+    IG_REQUIRE(C % 8 == 0 && ncls >= 1 && ncls <= MAXC, "ig_classifier_fwd: need C %% 8 == 0 and 1 <= ncls <= %d (C=%d ncls=%d)", MAXC, C, ncls);
+    long M = (long)B * HW;
+    if (M == 0) return IG_OK;
+    size_t sm = ((size_t)ncls * C + ncls) * sizeof(float);
+    hipLaunchKernelGGL(classifier_fwd_kernel, dim3((unsigned)((M + TPB - 1) / TPB)), dim3(TPB), sm, (hipStream_t)stream,
+                       (const bf16_t*)f_hi, (const bf16_t*)f_lo, w, bias, logits, M, HW, C, ncls, drop_seed, thresh_of(drop_p),
+                       drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f);
+    return ig_check_launch("ig_classifier_fwd");
+}
+
+// count: NULL, or the loss kernel's stats buffer (uses stats[1] = #valid pixels to normalise dlogits)
+int ig_classifier_bwd(const float* dlogits, const void* f_hi, const void* f_lo, const float* w, void* df_hi, void* df_lo, float* dw,
+                      float* db, const double* count, int B, long HW, int C, int ncls, unsigned drop_seed, float drop_p,
+                      void* stream) {
+    IG_REQUIRE(dlogits && f_hi && w && df_hi && dw && db, "ig_classifier_bwd: null pointer");
+    IG_REQUIRE(C % 8 == 0 && ncls >= 1 && ncls <= MAXC, "ig_classifier_bwd: need C %% 8 == 0 and 1 <= ncls <= %d", MAXC);
+    long M = (long)B * HW;
+    if (M == 0) return IG_OK;
+    size_t sm = (2 * (size_t)ncls * C + ncls) * sizeof(float);
+    hipLaunchKernelGGL(classifier_bwd_kernel, dim3((unsigned)((M + TPB - 1) / TPB)), dim3(TPB), sm, (hipStream_t)stream, dlogits,
+                       (const bf16_t*)f_hi, (const bf16_t*)f_lo, w, (bf16_t*)df_hi, (bf16_t*)df_lo, dw, db, count, M, HW, C, ncls,
+                       drop_seed, thresh_of(drop_p), drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f);
+    return ig_check_launch("ig_classifier_bwd");
+}
+
+// label_dtype: 0 = int64, 1 = int32, 2 = float32 (reference labels are float tensors cast with .long())
+int ig_ce_loss(const float* logits, const void* labels, int label_dtype, const float* class_weights, long ignore_index,
+               double* stats, float* dlogits, long long* preds, signed char* preds_i8, unsigned long long* confusion, int B,
+               long HW, int ncls, void* stream) {
+    IG_REQUIRE(logits && labels, "ig_ce_loss: null pointer");
+    IG_REQUIRE(ncls >= 1 && ncls <= MAXC, "ig_ce_loss: 1 <= ncls <= %d (got %d)", MAXC, ncls);
+    long M = (long)B * HW;
+    if (M == 0) return IG_OK;
+    size_t sm = (size_t)ncls * ncls * sizeof(unsigned) + 2 * sizeof(float);
+    dim3 grid((unsigned)((M + TPB - 1) / TPB)), block(TPB);
+    hipStream_t st = (hipStream_t)stream;
+    if (label_dtype == 0)
+        hipLaunchKernelGGL(ce_loss_kernel<long long>, grid, block, sm, st, logits, (const long long*)labels, class_weights,
+                           ignore_index, stats, dlogits, preds, preds_i8, confusion, M, HW, ncls);
+    else if (label_dtype == 1)
+        hipLaunchKernelGGL(ce_loss_kernel<int>, grid, block, sm, st, logits, (const int*)labels, class_weights, ignore_index, stats,
+                           dlogits, preds, preds_i8, confusion, M, HW, ncls);
+    else if (label_dtype == 2)
+        hipLaunchKernelGGL(ce_loss_kernel<float>, grid, block, sm, st, logits, (const float*)labels, class_weights, ignore_index,
+                           stats, dlogits, preds, preds_i8, confusion, M, HW, ncls);
+    else {
+        ig_set_error("ig_ce_loss: unsupported label dtype %d", label_dtype);
+        return IG_ERR_UNSUPPORTED;
+    }
+    return ig_check_launch("ig_ce_loss");
+}
+
+int ig_argmax_i8(const float* logits, signed char* out, int B, long HW, int ncls, void* stream) {
+    IG_REQUIRE(logits && out, "ig_argmax_i8: null pointer");
+    IG_REQUIRE(ncls >= 1 && ncls <= 127, "ig_argmax_i8: 1 <= ncls <= 127");
+    long M = (long)B * HW;
+    if (M == 0) return IG_OK;
+    hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)((M + TPB - 1) / TPB)), dim3(TPB), 0, (hipStream_t)stream, logits, out, M, HW,
+                       ncls);
+    return ig_check_launch("ig_argmax_i8");
+}
+
+int ig_confusion_update(const long long* y_true, const long long* y_pred, unsigned long long* confusion, long n, int k,
+                        long ignore_index, int has_ignore, void* stream) {
+    IG_REQUIRE(y_true && y_pred && confusion, "ig_confusion_update: null pointer");
+    IG_REQUIRE(k >= 1 && k <= 64, "ig_confusion_update: 1 <= k <= 64");
+    if (n == 0) return IG_OK;
+    long g = (n + TPB - 1) / TPB;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(confusion_kernel, dim3((unsigned)g), dim3(TPB), (size_t)k * k * sizeof(unsigned), (hipStream_t)stream, y_true,
+                       y_pred, confusion, n, k, ignore_index, has_ignore);
+    return ig_check_launch("ig_confusion_update");
+}
+
+}  // extern "C"
