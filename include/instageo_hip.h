@@ -1,0 +1,121 @@
+/* instageo_hip.h -- C ABI of libinstageo_hip.so: the MI355X (gfx950) hot path of InstaGeo's Prithvi
+ * segmentation model (instageo/model).  Plain pointers and sizes only; every pointer is a DEVICE pointer
+ * unless stated otherwise; `stream` is a hipStream_t (NULL = default stream).  All functions return 0 on
+ * success or a negative IG_ERR_* code and set a thread-local message readable through ig_last_error().
+ *
+ * The reference has no native interface: the seam is the Python symbol instageo.model.base.PrithviSeg
+ * (base.py:28,69-77).  Each entry point below replaces the ATen op(s) that the reference module calls at the
+ * cited file:line (paths relative to the reference root); INTEGRATION.md shows the ctypes binding.
+ *
+ * bf16 tensors: raw uint16 storage.  Every bf16 tensor argument is a pair (x_hi, x_lo): x_lo == NULL selects
+ * plain bf16; non-NULL selects the split "bf16x3" precision mode (value = hi + lo, products hi*hi+hi*lo+lo*hi).
+ * Either all bf16 operands of a call are split or none.  Activations in the decode head are NHWC.
+ * Conv weights (3x3 and transposed) are stored Wc[Cout][9][Cin], tap = ky*3+kx.
+ */
+#ifndef INSTAGEO_HIP_H
+#define INSTAGEO_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IG_OK 0
+#define IG_ERR_ARG (-1)
+#define IG_ERR_HIP (-2)
+#define IG_ERR_UNSUPPORTED (-3)
+
+/* ---- runtime ---------------------------------------------------------------------------------------- */
+const char* ig_last_error(void);
+int ig_version(void);
+int ig_device_info(int device, char* name, int name_len, int* cu_count, int* lds_per_block, long* hbm_bytes);
+
+/* ---- dataset side: normalise + layout (instageo/model/dataloader.py:495-524, 707-750) ---------------- */
+/* src (B, T*C, H, W) band = t*C+c, src_dtype 0=int16 1=float32 -> dst (B, C, T, H, W) f32 = (src*mult-mean_c)/std_c */
+int ig_normalize_chips(const void* src, int src_dtype, const float* mean, const float* stdv, double mult, int mult_enabled,
+                       float* dst, int B, int T, int C, int H, int W, void* stream);
+
+/* ---- encoder (instageo/model/pritvhi.py) ------------------------------------------------------------- */
+/* Conv3d(k=s=(1,p,p)) im2col: img (B,C,T,H,W) f32 -> patches [B*T*gh*gw][C*p*p], token order (t,row,col)  :243-268 */
+int ig_patchify(const float* img, void* out_hi, void* out_lo, int B, int C, int T, int H, int W, int p, void* stream);
+/* x[b][0][:] = cls_token + pos_embed[0]                                                        :520-522 */
+int ig_cls_rows(float* x, const float* cls, const float* pos, int B, int ntok, int D, void* stream);
+/* x[b][1+tp][:] = patches[b*TP+tp] @ w^T + bias + pos_embed[1+tp]                               :266-268,513-517 */
+int ig_patch_embed_fwd(const void* p_hi, const void* p_lo, const void* w_hi, const void* w_lo, const float* bias,
+                       const float* pos, float* x, int batch, int tokens_per_chip, int D, int K, void* stream);
+/* nn.LayerNorm(eps) over D; feat_T>=1 writes the model.py:406-413 feature-image layout [B][G][D*T] (c = d*T+t) */
+int ig_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* out_hi, void* out_lo, float* mean,
+                     float* rstd, int M, int D, float eps, int feat_T, int feat_G, int ntok, void* stream);
+int ig_layernorm_bwd(const void* dy_hi, const void* dy_lo, const float* x, const float* mean, const float* rstd,
+                     const float* gamma, float* dx, int accumulate, void* dxb_hi, void* dxb_lo, float* dgamma, float* dbeta,
+                     float* dcol, int M, int D, int feat_T, int feat_G, int ntok, void* stream);
+/* timm Block linears (qkv / fc1 [+GELU]) : y = act(x @ w^T + b), act 0 none, 1 exact GELU            :446-456 */
+int ig_linear_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias, void* y_hi,
+                  void* y_lo, void* pre_hi, void* pre_lo, int M, int N, int K, int act, void* stream);
+/* timm Block residual linears (proj / fc2): out = resid + x @ w^T + b (fp32 residual stream)          :446-456 */
+int ig_linear_residual_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
+                           const float* resid, float* out, int M, int N, int K, void* stream);
+/* dx = dy @ w  (mode 1: * gelu'(pre)) ; dw += dy^T @ x (fp32 atomics) */
+int ig_linear_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, const void* w_lo, void* dx_hi, void* dx_lo,
+                    const void* pre_hi, const void* pre_lo, int M, int N, int K, int mode, void* stream);
+int ig_linear_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const void* x_lo, float* dw, int M, int N, int K,
+                    void* stream);
+/* F.scaled_dot_product_attention of timm Attention: qkv [B][N][3][H][64] -> out [B][N][H*64], lse [B][H][N] */
+int ig_attention_fwd(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, float* lse, int B, int N, int H,
+                     int head_dim, void* stream);
+int ig_attention_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi, const void* out_lo, const void* dout_hi,
+                     const void* dout_lo, const float* lse, float* delta, void* dqkv_hi, void* dqkv_lo, int B, int N, int H,
+                     int head_dim, void* stream);
+/* gradient plumbing: column sums (bias grads), patch-embed grad prep (cls_token / conv bias grads) */
+int ig_colsum(const void* hi, const void* lo, float* out, long M, int C, void* stream);
+int ig_patch_grad_prep(const float* dx, void* hi, void* lo, float* dcls, float* dbias, int B, int ntok, int D, void* stream);
+int ig_split_bf16(const float* src, void* hi, void* lo, long n, void* stream);
+int ig_merge_bf16(const void* hi, const void* lo, float* dst, long n, void* stream);
+
+/* ---- decode head (instageo/model/model.py:349-390) --------------------------------------------------- */
+/* nn.ConvTranspose2d(k=3,s=2,p=1,op=1) + nn.Dropout(p): x (B,H,W,Cin) -> y (B,2H,2W,Cout)             :361-369 */
+int ig_convT_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias, void* y_hi,
+                 void* y_lo, int B, int H, int W, int Cin, int Cout, unsigned drop_seed, float drop_p, void* stream);
+int ig_convT_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, const void* w_lo, void* dx_hi, void* dx_lo, int B,
+                   int H, int W, int Cin, int Cout, void* stream);
+int ig_convT_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const void* x_lo, float* dw, int B, int H, int W,
+                   int Cin, int Cout, void* stream);
+/* nn.Conv2d(k=3,padding=1)                                                                           :370-375 */
+int ig_conv3x3_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias, void* y_hi,
+                   void* y_lo, int B, int H, int W, int Cin, int Cout, void* stream);
+int ig_conv3x3_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, const void* w_lo, void* dx_hi, void* dx_lo, int B,
+                     int H, int W, int Cin, int Cout, unsigned drop_seed, float drop_p, void* stream);
+int ig_conv3x3_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const void* x_lo, float* dw, int B, int H, int W,
+                     int Cin, int Cout, void* stream);
+/* nn.BatchNorm2d + nn.ReLU on [M][C] (M = B*H*W)                                                      :376-377 */
+int ig_bn_relu_fwd(const void* x_hi, const void* x_lo, const float* gamma, const float* beta, float* running_mean,
+                   float* running_var, void* y_hi, void* y_lo, float* scale, float* shift, float* mean, float* rstd,
+                   double* sums, long M, int C, float eps, float momentum, int training, int update_running, void* stream);
+int ig_bn_relu_bwd(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, const float* scale,
+                   const float* shift, const float* mean, const float* rstd, void* dx_hi, void* dx_lo, float* dgamma,
+                   float* dbeta, double* sums, long M, int C, void* stream);
+/* nn.Dropout(p) + nn.Conv2d(k=1): f (B,HW,C) -> logits (B,ncls,HW) f32                                 :388-389 */
+int ig_classifier_fwd(const void* f_hi, const void* f_lo, const float* w, const float* bias, float* logits, int B, long HW, int C,
+                      int ncls, unsigned drop_seed, float drop_p, void* stream);
+int ig_classifier_bwd(const float* dlogits, const void* f_hi, const void* f_lo, const float* w, void* df_hi, void* df_lo,
+                      float* dw, float* db, const double* count, int B, long HW, int C, int ncls, unsigned drop_seed,
+                      float drop_p, void* stream);
+
+/* ---- task module (instageo/model/segmentation.py, metrics.py, infer_utils.py, base.py) --------------- */
+/* CE(weight, ignore_index,'none') + masked mean pieces, argmax, int64 confusion matrix   segmentation.py:85-87,117-151 */
+int ig_ce_loss(const float* logits, const void* labels, int label_dtype, const float* class_weights, long ignore_index,
+               double* stats, float* dlogits, long long* preds, signed char* preds_i8, unsigned long long* confusion, int B,
+               long HW, int ncls, void* stream);
+/* torch.argmax(dim=1) -> int8                                                           infer_utils.py:99-101 */
+int ig_argmax_i8(const float* logits, signed char* out, int B, long HW, int ncls, void* stream);
+/* RunningConfusionMatrix.update                                                         metrics.py:86-108 */
+int ig_confusion_update(const long long* y_true, const long long* y_pred, unsigned long long* confusion, long n, int k,
+                        long ignore_index, int has_ignore, void* stream);
+/* torch.optim.AdamW step on a flat buffer (+ clip_weights, + bf16 shadow refresh)        base.py:103-126 */
+int ig_adamw_advance(float* hyper, void* stream);
+int ig_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_hi, void* shadow_lo, const float* hyper, long n,
+                  void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INSTAGEO_HIP_H */

@@ -494,6 +494,7 @@ __global__ void bn_bwd_apply_kernel(const bf16_t* __restrict__ xh, const bf16_t*
 // optional weight clamp (base.py:103-113) and the bf16 (hi/lo) shadow refresh used by the MFMA kernels.
 // hyper (device): [0]=lr [1]=beta1 [2]=beta2 [3]=eps [4]=weight_decay [5]=bias_corr1 [6]=sqrt(bias_corr2)
 //                 [7]=clip_lo [8]=clip_hi [9]=clip_enabled  [10]=step (as float)
+//                 [11]=1-beta1 [12]=1-beta2 (host computes them in double like torch does)
 // ----------------------------------------------------------------------------------------------
 __global__ void adamw_advance_kernel(float* hyper) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -505,8 +506,9 @@ __global__ void adamw_advance_kernel(float* hyper) {
 }
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                              bf16_t* __restrict__ sh, bf16_t* __restrict__ sl, const float* __restrict__ hyper, long n4) {
-    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5], bc2s = hyper[6];
+    const float lr = hyper[0], b2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5], bc2s = hyper[6];
     const float clo = hyper[7], chi = hyper[8];
+    const float omb1 = hyper[11], omb2 = hyper[12];
     const bool clip = hyper[9] != 0.f;
     const float step_size = lr / bc1;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -519,8 +521,8 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             pp[j] = pp[j] * (1.f - lr * wd);
-            mm[j] = mm[j] + (gg[j] - mm[j]) * (1.f - b1);  // lerp_
-            vv[j] = vv[j] * b2 + (1.f - b2) * gg[j] * gg[j];
+            mm[j] = mm[j] + (gg[j] - mm[j]) * omb1;  // lerp_(grad, 1-beta1)
+            vv[j] = vv[j] * b2 + omb2 * gg[j] * gg[j];
             float denom = sqrtf(vv[j]) / bc2s + eps;
             pp[j] = pp[j] - step_size * (mm[j] / denom);
             if (clip) pp[j] = fminf(fmaxf(pp[j], clo), chi);

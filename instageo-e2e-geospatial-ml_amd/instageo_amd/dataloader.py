@@ -1,0 +1,180 @@
+"""Chip dataset pieces of the hot path, device side (reference: ``instageo/model/dataloader.py``).
+
+In scope: normalisation + tensor layout (``normalize_and_convert_to_tensor``
+dataloader.py:495-524), random crop / flips hand-off (``process_and_augment`` :527-585), evaluation
+window tiling (``process_test`` + ``crop_array`` :588-669) and the dataset item contract
+(``InstaGeoDataset.__getitem__`` :875-902: ``(x:(C,T,H,W) f32, y:(H,W))``).  GeoTIFF/CSV I/O (rasterio) and
+the photometric augmentations are outside the path; chips come from arrays or are synthetic.
+The arithmetic (constant multiplier, mean/std normalisation) runs in ``ig_normalize_chips``; crops, flips
+and window extraction are pure data movement on the device.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+def _as_device_chip(x, device) -> torch.Tensor:
+    t = torch.as_tensor(np.asarray(x)) if not torch.is_tensor(x) else x
+    if t.dtype == torch.float64:
+        t = t.float()
+    if t.dtype not in (torch.int16, torch.float32):
+        t = t.float()
+    return t.to(device)
+
+
+def normalize_and_convert_to_tensor(ims, label, mean: Sequence[float], std: Sequence[float], temporal_size: int = 1,
+                                    constant_multiplier: Optional[float] = None, device: str = "cuda"):
+    """(T*C,H,W) bands [band = t*C + c] -> (C,T,H,W) f32 ``(x - mean_c)/std_c`` ; label -> (H,W) tensor.
+
+    ``ims`` may be an array/tensor (T*C,H,W) or a list of 2-D band arrays (the reference passes PIL images).
+    """
+    if isinstance(ims, (list, tuple)):
+        ims = np.stack([np.asarray(i) for i in ims])
+    x = _as_device_chip(ims, device)
+    out = normalize_batch(x.unsqueeze(0), mean, std, temporal_size, constant_multiplier)[0]
+    if label is not None:
+        label = torch.as_tensor(np.asarray(label) if not torch.is_tensor(label) else label).squeeze().to(device)
+    return out, label
+
+
+def normalize_batch(x: torch.Tensor, mean: Sequence[float], std: Sequence[float], temporal_size: int = 1,
+                    constant_multiplier: Optional[float] = None) -> torch.Tensor:
+    """(B,T*C,H,W) int16|f32 device tensor -> (B,C,T,H,W) f32 normalised."""
+    m = torch.as_tensor(mean, dtype=torch.float32, device=x.device)
+    s = torch.as_tensor(std, dtype=torch.float32, device=x.device)
+    return ops.normalize_chips(x.contiguous(), m, s, temporal_size, constant_multiplier)
+
+
+def crop_array(arr, left: int, top: int, right: int, bottom: int):
+    """dataloader.py:588-615 (2-D, 3-D or 4-D arrays/tensors)."""
+    if arr.ndim == 2:
+        return arr[top:bottom, left:right]
+    if arr.ndim == 3:
+        return arr[:, top:bottom, left:right]
+    if arr.ndim == 4:
+        return arr[:, :, top:bottom, left:right]
+    raise ValueError("Input array must be a 2D, 3D or 4D array")
+
+
+def window_origins(img_size: int, crop_size: int, stride: int) -> List[Tuple[int, int]]:
+    """``for top in range(0, S-crop+1, stride): for left in ...`` (dataloader.py:655-664) -> [(top, left)]."""
+    return [
+        (top, left)
+        for top in range(0, img_size - crop_size + 1, stride)
+        for left in range(0, img_size - crop_size + 1, stride)
+    ]
+
+
+def extract_windows(tile: torch.Tensor, origins: Sequence[Tuple[int, int]], crop_size: int) -> torch.Tensor:
+    """tile (T*C,S,S) [or label (S,S)] -> stacked windows (n, T*C, crop, crop) [(n, crop, crop)]: pure copies."""
+    if tile.dim() == 2:
+        return torch.stack([tile[t : t + crop_size, l : l + crop_size] for t, l in origins])
+    return torch.stack([tile[:, t : t + crop_size, l : l + crop_size] for t, l in origins])
+
+
+def process_test(x, y, mean: Sequence[float], std: Sequence[float], temporal_size: int = 1, img_size: int = 512,
+                 crop_size: int = 224, stride: int = 224, constant_multiplier: Optional[float] = None, device: str = "cuda"):
+    """Evaluation tiling (dataloader.py:618-669): -> (imgs (n,C,T,crop,crop) f32, labels (n,crop,crop))."""
+    xt = _as_device_chip(x, device)
+    yt = torch.as_tensor(np.asarray(y) if not torch.is_tensor(y) else y).to(device)
+    origins = window_origins(img_size, crop_size, stride)
+    imgs = normalize_batch(extract_windows(xt, origins, crop_size), mean, std, temporal_size, constant_multiplier)
+    labels = extract_windows(yt, origins, crop_size)
+    return imgs, labels
+
+
+def process_and_augment(x, y, mean, std, temporal_size: int = 1, im_size: int = 224, crop: bool = True,
+                        augmentations: Optional[Dict] = None, constant_multiplier: Optional[float] = None,
+                        generator: Optional[torch.Generator] = None, device: str = "cuda"):
+    """Random crop to ``im_size`` + optional h/v flips + normalise (dataloader.py:527-585).
+
+    Only the ``hflip``/``vflip`` augmentations (the ones enabled in ``sen1floods11.yaml:44-49``) are data
+    movement; rotate/brightness/blur/noise are photometric/geometric resampling and out of scope here.
+    """
+    xt = _as_device_chip(x, device)
+    yt = None if y is None else torch.as_tensor(np.asarray(y) if not torch.is_tensor(y) else y).to(device)
+    H, W = xt.shape[-2:]
+    if crop and (H > im_size or W > im_size):
+        top = int(torch.randint(0, H - im_size + 1, (1,), generator=generator))
+        left = int(torch.randint(0, W - im_size + 1, (1,), generator=generator))
+        xt = xt[:, top : top + im_size, left : left + im_size]
+        if yt is not None:
+            yt = yt[top : top + im_size, left : left + im_size]
+    for name, cfg in (augmentations or {}).items():
+        if not cfg.get("use", False):
+            continue
+        if name not in ("hflip", "vflip"):
+            raise NotImplementedError(f"augmentation {name!r} is outside the hot-path scope (SURVEY.md 8f item 1)")
+        if float(torch.rand((), generator=generator)) < cfg.get("p", 0.5):
+            dim = -1 if name == "hflip" else -2
+            xt = xt.flip(dim)
+            if yt is not None:
+                yt = yt.flip(dim)
+    return normalize_and_convert_to_tensor(xt.contiguous(), None if yt is None else yt.contiguous(), mean, std, temporal_size,
+                                           constant_multiplier, device)
+
+
+class SyntheticChipDataset(torch.utils.data.Dataset):
+    """HLS-shaped synthetic chips generated on the device (there is no network for real data).
+
+    Item contract of ``InstaGeoDataset`` (dataloader.py:875-902): ``(x:(C,T,H,W) f32 normalised, y:(H,W) f32)``.
+    Raw domain: int16 uniform[0,10000), ``constant_multiplier`` 1e-4, 5 % of the label pixels = ignore_index.
+    """
+
+    def __init__(self, n: int, temporal: int, num_classes: int, mean, std, im_size: int = 224, ignore_index: int = -1,
+                 constant_multiplier: Optional[float] = 1e-4, seed: int = 1042, device: str = "cuda"):
+        self.n, self.T, self.k = n, temporal, num_classes
+        self.mean, self.std, self.S = list(mean), list(std), im_size
+        self.ignore_index, self.mult, self.seed, self.device = ignore_index, constant_multiplier, seed, device
+
+    def __len__(self) -> int:
+        return self.n
+
+    def raw(self, i: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        g = torch.Generator(device=self.device).manual_seed(self.seed + i)
+        C = len(self.mean)
+        x = torch.randint(0, 10000, (self.T * C, self.S, self.S), generator=g, device=self.device, dtype=torch.int16)
+        y = torch.randint(0, self.k, (self.S, self.S), generator=g, device=self.device).float()
+        y[torch.rand((self.S, self.S), generator=g, device=self.device) < 0.05] = float(self.ignore_index)
+        return x, y
+
+    def __getitem__(self, i: int):
+        x, y = self.raw(i)
+        return normalize_and_convert_to_tensor(x, y, self.mean, self.std, self.T, self.mult, self.device)
+
+
+class ArrayChipDataset(torch.utils.data.Dataset):
+    """Chips/labels held as arrays ``chips (N,T*C,H,W)``, ``labels (N,H,W)`` (stand-in for the GeoTIFF reader)."""
+
+    def __init__(self, chips, labels, mean, std, temporal: int = 1, constant_multiplier: Optional[float] = None,
+                 include_filenames: bool = False, names: Optional[List[str]] = None, device: str = "cuda"):
+        assert len(chips) == len(labels)
+        self.chips, self.labels = chips, labels
+        self.mean, self.std, self.T, self.mult = list(mean), list(std), temporal, constant_multiplier
+        self.include_filenames, self.names, self.device = include_filenames, names, device
+
+    def __len__(self) -> int:
+        return len(self.chips)
+
+    def __getitem__(self, i: int):
+        x, y = normalize_and_convert_to_tensor(self.chips[i], self.labels[i], self.mean, self.std, self.T, self.mult, self.device)
+        if self.include_filenames:
+            return (x, y), (self.names[i] if self.names else f"chip_{i:06d}")
+        return x, y
+
+
+def eval_collate_fn(batch):
+    """Concatenate windowed samples across the batch (pipeline_utils.py:78-89)."""
+    return torch.cat([b[0] for b in batch], 0), torch.cat([b[1] for b in batch], 0)
+
+
+def infer_collate_fn(batch):
+    """((data, label), filenames) batches (pipeline_utils.py:92-104)."""
+    data = torch.stack([b[0][0] for b in batch])
+    labels = torch.stack([b[0][1] for b in batch])
+    return (data, labels), [b[1] for b in batch]

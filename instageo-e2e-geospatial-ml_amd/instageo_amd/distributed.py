@@ -1,0 +1,161 @@
+"""Data parallelism for the Prithvi path: one process per GPU, RCCL over xGMI through ``torch.distributed``.
+
+The reference has no distributed code: multi-GPU only happens implicitly through Lightning's DDP
+(``instageo/model/pipeline_utils.py:368-374``).  Here the exchange is explicit:
+
+* training: chips are sharded over ranks; the only exchange per step is the gradient mean.  Because all
+  gradients live in ONE flat buffer laid out in forward order, "buckets" are contiguous slices.  The engine
+  reports slices as their gradients become final during backward (head first, then blocks L-1..0, patch
+  embedding last) and :class:`GradSync` launches one asynchronous all-reduce per >= ``bucket_bytes`` slice so
+  that communication overlaps the remaining backward kernels.  xGMI is point-to-point (7 links/GPU): a few
+  large buckets (default 32 MiB ~ one ViT block) keep every link busy without per-call latency dominating.
+* metrics: k x k int64 confusion matrices and (loss_sum, count) pairs are summed across ranks at epoch end
+  (a deliberate fix of the reference's rank-local metrics).
+* inference: windows/chips are partitioned contiguously by rank with no data-path collective; a final gather
+  of the per-rank int8 class maps (or only of the counters) goes to rank 0.
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """Initialise the default process group from RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* (torchrun contract).
+
+    Returns (rank, local_rank, world_size).  With WORLD_SIZE unset or 1 nothing is initialised.
+    """
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous partition of ``n_items`` units: the first ``n % world`` ranks get one extra unit."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class GradSync:
+    """Bucketed, overlapped gradient averaging over a flat gradient buffer.
+
+    ``ready(lo, hi)`` is called (by ``SegEngine.on_grad_ready``) with flat index ranges whose gradients are
+    final, in descending address order; adjacent ranges are merged and flushed as one asynchronous
+    all-reduce once they reach ``bucket_bytes``.  ``wait()`` flushes the remainder and makes the current
+    stream wait for all reductions (then divides by the world size when the backend has no AVG).
+    """
+
+    def __init__(self, get_grad: Callable[[], torch.Tensor], bucket_bytes: int = 32 << 20, group=None):
+        self.get_grad = get_grad
+        self.bucket_bytes = bucket_bytes
+        self.group = group
+        self.handles: List = []
+        self.ranges: List[Tuple[int, int]] = []
+        self.cur: Optional[Tuple[int, int]] = None
+        self.launched: List[Tuple[int, int]] = []  # for tests / introspection
+        backend = dist.get_backend(group) if dist.is_initialized() else "none"
+        self.use_avg = backend == "nccl"
+
+    def ready(self, lo: int, hi: int) -> None:
+        if world_size() == 1 or hi <= lo:
+            return
+        if self.cur is not None and hi == self.cur[0]:
+            self.cur = (lo, self.cur[1])
+        elif self.cur is not None and lo == self.cur[1]:
+            self.cur = (self.cur[0], hi)
+        else:
+            self._flush()
+            self.cur = (lo, hi)
+        if (self.cur[1] - self.cur[0]) * 4 >= self.bucket_bytes:
+            self._flush()
+
+    def _flush(self) -> None:
+        if self.cur is None:
+            return
+        lo, hi = self.cur
+        self.cur = None
+        g = self.get_grad()[lo:hi]
+        op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
+        self.handles.append(dist.all_reduce(g, op=op, group=self.group, async_op=True))
+        self.ranges.append((lo, hi))
+        self.launched.append((lo, hi))
+
+    def wait(self) -> None:
+        if world_size() == 1:
+            return
+        self._flush()
+        for h in self.handles:
+            h.wait()
+        if not self.use_avg:
+            g = self.get_grad()
+            w = float(world_size())
+            for lo, hi in self.ranges:
+                g[lo:hi].div_(w)
+        self.handles.clear()
+        self.ranges.clear()
+
+
+def attach_data_parallel(module, bucket_bytes: int = 32 << 20) -> Optional[GradSync]:
+    """Wire a :class:`GradSync` into a ``PrithviSegmentationModule`` (fused path) and broadcast rank 0's
+    parameters/buffers so all replicas start equal (Lightning/DDP semantics)."""
+    if world_size() == 1:
+        return None
+    net = module.net
+    dist.broadcast(net.store.flat, src=0)
+    for t in net._buffers_flat.values():
+        dist.broadcast(t, src=0)
+    net.params_changed()
+    sync = GradSync(lambda: net.store.ensure_grad(), bucket_bytes)
+    net.engine.on_grad_ready = sync.ready
+    module.grad_sync = sync.wait
+    return sync
+
+
+def reduce_confusion(matrix: torch.Tensor) -> torch.Tensor:
+    """Sum the k x k int64 confusion matrix over ranks (C2 of SURVEY.md 2.2)."""
+    if world_size() > 1:
+        dist.all_reduce(matrix, op=dist.ReduceOp.SUM)
+    return matrix
+
+
+def reduce_loss_stats(stats: torch.Tensor) -> torch.Tensor:
+    """Sum (loss_sum, count) over ranks."""
+    if world_size() > 1:
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+    return stats
+
+
+def gather_class_maps(local: torch.Tensor, counts: Sequence[int], dst: int = 0) -> Optional[torch.Tensor]:
+    """Gather per-rank int8 class maps (n_r, H, W) to ``dst`` (C3 of SURVEY.md 2.2).  ``counts[r]`` = n_r."""
+    world = world_size()
+    if world == 1:
+        return local
+    rank = dist.get_rank()
+    nmax = max(counts)
+    pad = torch.zeros((nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    outs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, outs, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([o[: counts[r]] for r, o in enumerate(outs)], dim=0)

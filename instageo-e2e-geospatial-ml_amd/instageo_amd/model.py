@@ -1,0 +1,728 @@
+"""``PrithviSeg`` for MI355X: same constructor / ``forward`` / ``state_dict`` contract as the reference
+(``instageo/model/model.py:292-419``, encoder ``instageo/model/pritvhi.py:370-530``), every arithmetic op
+executed by the HIP library through :mod:`instageo_amd.ops`.
+
+Design
+------
+* All parameters live in ONE flat fp32 buffer (plus flat grad / bf16-shadow buffers): AdamW, gradient
+  all-reduce buckets and the bf16 operand refresh are single streaming passes; ``nn.Parameter`` objects are
+  views into it so ``state_dict()`` / ``load_state_dict(strict=True)`` keep the reference's keys and shapes.
+  Conv weights are *stored* ``[Cout][9][Cin]`` (the layout the gather-GEMM wants) and exposed as permuted
+  views with the PyTorch shapes.
+* ``SegEngine`` runs the explicit forward / backward schedule on preallocated workspaces (no autograd
+  graph, graph-capturable).  ``PrithviSeg.forward`` wraps it in one ``torch.autograd.Function`` so that
+  ``loss.backward()`` of an unmodified training loop still works.
+* precision: ``"bf16"`` (bf16 MFMA operands, fp32 accumulate/residual stream) or ``"bf16x3"`` (split
+  hi/lo operands, fp32-grade results; used for the 1e-3 parity tests).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Any, Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import BT
+
+# --------------------------------------------------------------------------------------------------
+# configuration (reference: model.py:39-177)
+# --------------------------------------------------------------------------------------------------
+PRITHVI_VARIANTS = {
+    # variant: (embed_dim, depth, num_heads, patch, default num_frames)
+    "prithvi_eo_tiny": (256, 4, 4, 16, 1),
+    "prithvi_eo_v1_100": (768, 12, 12, 16, 3),
+    "prithvi_eo_v2_100": (768, 12, 12, 16, 4),
+    "prithvi_eo_v2_300": (1024, 24, 16, 16, 4),
+}
+HEAD_KERNELS = {k: (3, 3, 3, 3) for k in PRITHVI_VARIANTS}
+UNSUPPORTED_VARIANTS = ("prithvi_eo_v2_300_tl", "prithvi_eo_v2_600", "prithvi_eo_v2_600_tl")
+
+
+@dataclass
+class SegConfig:
+    variant: str = "prithvi_eo_v1_100"
+    embed_dim: int = 768
+    depth: int = 12
+    num_heads: int = 12
+    patch: int = 16
+    in_chans: int = 6
+    num_frames: int = 1
+    img_size: int = 224
+    num_classes: int = 2
+    mlp_ratio: int = 4
+    drop_p: float = 0.1  # nn.Dropout(0.1) x5 in the head (model.py:369,388)
+
+    @property
+    def grid(self) -> int:
+        return self.img_size // self.patch
+
+    @property
+    def G(self) -> int:
+        return self.grid * self.grid
+
+    @property
+    def tokens(self) -> int:
+        return 1 + self.num_frames * self.G
+
+    @property
+    def head_dims(self) -> List[int]:
+        return [(self.embed_dim * self.num_frames) // (2**i) for i in range(5)]  # model.py:380-383
+
+    @property
+    def patch_k(self) -> int:
+        return self.in_chans * self.patch * self.patch
+
+
+def make_seg_config(variant: str, temporal_step: int, image_size: int, num_classes: int, depth: int = -1,
+                    in_chans: int = 6) -> SegConfig:
+    if variant in UNSUPPORTED_VARIANTS:
+        raise NotImplementedError(
+            f"variant {variant}: patch-14 / 5x5-7x7 head kernels / temporal-location encoders are outside the "
+            "hot-path scope (SURVEY.md section 8f item 4)"
+        )
+    if variant not in PRITHVI_VARIANTS:
+        raise KeyError(f"unknown Prithvi variant {variant!r}")
+    d, l, h, p, _ = PRITHVI_VARIANTS[variant]
+    if depth != -1:  # model.py:208-209
+        l = depth
+    assert image_size % p == 0, "image_size must be divisible by the patch size"
+    assert d // h == 64, "head_dim must be 64"
+    return SegConfig(variant, d, l, h, p, in_chans, temporal_step, image_size, num_classes)
+
+
+# --------------------------------------------------------------------------------------------------
+# positional embedding (pritvhi.py:67-127), float64 numpy -> f32 buffer exactly like the reference
+# --------------------------------------------------------------------------------------------------
+def _sincos_1d(embed_dim: int, pos: np.ndarray) -> np.ndarray:
+    omega = np.arange(embed_dim // 2, dtype=np.float32)
+    omega /= embed_dim / 2.0
+    omega = 1.0 / 10000**omega
+    out = np.einsum("m,d->md", pos.reshape(-1), omega)
+    return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+
+
+def get_3d_sincos_pos_embed(embed_dim: int, grid_size: Tuple[int, int, int], cls_token: bool = False) -> np.ndarray:
+    """Fixed 3-D sin-cos table; column blocks (w | h | t) of widths 6D/16, 6D/16, 4D/16."""
+    assert embed_dim % 16 == 0
+    t, h, w = grid_size
+    wd = hd = embed_dim // 16 * 6
+    td = embed_dim // 16 * 4
+    we = np.tile(_sincos_1d(wd, np.arange(w)), (t * h, 1))
+    he = np.tile(np.repeat(_sincos_1d(hd, np.arange(h)), w, axis=0), (t, 1))
+    te = np.repeat(_sincos_1d(td, np.arange(t)), h * w, axis=0)
+    pe = np.concatenate((we, he, te), axis=1)
+    if cls_token:
+        pe = np.concatenate([np.zeros([1, embed_dim]), pe], axis=0)
+    return pe
+
+
+# --------------------------------------------------------------------------------------------------
+# flat parameter store
+# --------------------------------------------------------------------------------------------------
+@dataclass
+class _Entry:
+    name: str
+    shape: Tuple[int, ...]  # API (PyTorch) shape
+    offset: int
+    numel: int
+    kind: str  # "plain" | "conv" (Cout,Cin,3,3 stored [Cout][9][Cin]) | "convT" (Cin,Cout,3,3 stored [Cout][9][Cin])
+
+    def api_view(self, flat: torch.Tensor) -> torch.Tensor:
+        seg = flat[self.offset : self.offset + self.numel]
+        if self.kind == "plain":
+            return seg.view(self.shape)
+        if self.kind == "conv":
+            co, ci = self.shape[0], self.shape[1]
+            return seg.view(co, 3, 3, ci).permute(0, 3, 1, 2)
+        ci, co = self.shape[0], self.shape[1]
+        return seg.view(co, 3, 3, ci).permute(3, 0, 1, 2)
+
+
+def _param_specs(cfg: SegConfig) -> List[Tuple[str, Tuple[int, ...], str]]:
+    d, hid = cfg.embed_dim, cfg.embed_dim * cfg.mlp_ratio
+    e = "prithvi_encoder."
+    s: List[Tuple[str, Tuple[int, ...], str]] = [
+        (e + "cls_token", (1, 1, d), "plain"),
+        (e + "patch_embed.proj.weight", (d, cfg.in_chans, 1, cfg.patch, cfg.patch), "plain"),
+        (e + "patch_embed.proj.bias", (d,), "plain"),
+    ]
+    for i in range(cfg.depth):
+        b = f"{e}blocks.{i}."
+        s += [
+            (b + "norm1.weight", (d,), "plain"), (b + "norm1.bias", (d,), "plain"),
+            (b + "attn.qkv.weight", (3 * d, d), "plain"), (b + "attn.qkv.bias", (3 * d,), "plain"),
+            (b + "attn.proj.weight", (d, d), "plain"), (b + "attn.proj.bias", (d,), "plain"),
+            (b + "norm2.weight", (d,), "plain"), (b + "norm2.bias", (d,), "plain"),
+            (b + "mlp.fc1.weight", (hid, d), "plain"), (b + "mlp.fc1.bias", (hid,), "plain"),
+            (b + "mlp.fc2.weight", (d, hid), "plain"), (b + "mlp.fc2.bias", (d,), "plain"),
+        ]  # fmt: skip
+    s += [(e + "norm.weight", (d,), "plain"), (e + "norm.bias", (d,), "plain")]
+    dims = cfg.head_dims
+    h = "segmentation_head."
+    for i in range(4):
+        s += [
+            (f"{h}{i}.0.weight", (dims[i], dims[i + 1], 3, 3), "convT"), (f"{h}{i}.0.bias", (dims[i + 1],), "plain"),
+            (f"{h}{i}.2.weight", (dims[i + 1], dims[i + 1], 3, 3), "conv"), (f"{h}{i}.2.bias", (dims[i + 1],), "plain"),
+            (f"{h}{i}.3.weight", (dims[i + 1],), "plain"), (f"{h}{i}.3.bias", (dims[i + 1],), "plain"),
+        ]  # fmt: skip
+    s += [(h + "5.weight", (cfg.num_classes, dims[4], 1, 1), "plain"), (h + "5.bias", (cfg.num_classes,), "plain")]
+    return s
+
+
+class ParamStore:
+    """Flat fp32 parameters (+grad, +bf16 shadow) with named, 8-element-aligned segments."""
+
+    ALIGN = 8
+
+    def __init__(self, cfg: SegConfig, device: torch.device):
+        self.cfg = cfg
+        self.entries: Dict[str, _Entry] = {}
+        off = 0
+        self.encoder_end = 0
+        for name, shape, kind in _param_specs(cfg):
+            n = int(np.prod(shape))
+            self.entries[name] = _Entry(name, tuple(shape), off, n, kind)
+            off += (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+            if name.startswith("prithvi_encoder."):
+                self.encoder_end = off
+        self.total = off
+        self.flat = torch.zeros(self.total, dtype=torch.float32, device=device)
+        self.grad: Optional[torch.Tensor] = None
+        self.shadow: Optional[BT] = None
+        self.shadow_split: Optional[bool] = None
+
+    def seg(self, buf: torch.Tensor, name: str) -> torch.Tensor:
+        e = self.entries[name]
+        return buf[e.offset : e.offset + e.numel]
+
+    def ensure_grad(self) -> torch.Tensor:
+        if self.grad is None or self.grad.device != self.flat.device:
+            self.grad = torch.zeros_like(self.flat)
+        return self.grad
+
+    def refresh_shadow(self, split: bool) -> BT:
+        """(Re)build the bf16 (hi/lo) operand copy of all parameters from the fp32 master."""
+        if self.shadow is None or self.shadow_split != split or self.shadow.hi.device != self.flat.device:
+            self.shadow = BT.empty((self.total,), split, self.flat.device)
+            self.shadow_split = split
+        ops.split_bf16(self.flat, self.shadow)
+        return self.shadow
+
+    def w(self, name: str) -> BT:
+        """bf16 operand view of a parameter (storage layout)."""
+        e = self.entries[name]
+        sh = self.shadow
+        return BT(sh.hi[e.offset : e.offset + e.numel], None if sh.lo is None else sh.lo[e.offset : e.offset + e.numel])
+
+
+# --------------------------------------------------------------------------------------------------
+# the explicit forward / backward engine
+# --------------------------------------------------------------------------------------------------
+class SegEngine:
+    """Runs the Prithvi segmentation network on HIP kernels with preallocated workspaces."""
+
+    def __init__(self, cfg: SegConfig, store: ParamStore, buffers: Dict[str, torch.Tensor], precision: str = "bf16"):
+        assert precision in ("bf16", "bf16x3")
+        self.cfg, self.store, self.buffers = cfg, store, buffers
+        self.precision = precision
+        self.split = precision == "bf16x3"
+        self._ws: Dict[Any, Dict[str, Any]] = {}
+        self.shadow_dirty = True
+        self.drop_seed = 1042
+        self.freeze_backbone = False
+        self.on_grad_ready: Optional[Callable[[int, int], None]] = None
+        self._last: Optional[Dict[str, Any]] = None
+
+    # ---- helpers -------------------------------------------------------------------------------
+    def P(self, name: str) -> torch.Tensor:  # fp32 master segment (biases, norm affine, classifier)
+        return self.store.seg(self.store.flat, name)
+
+    def Gd(self, name: str) -> torch.Tensor:
+        return self.store.seg(self.store.grad, name)
+
+    def W(self, name: str) -> BT:
+        return self.store.w(name)
+
+    def mark_params_changed(self) -> None:
+        self.shadow_dirty = True
+
+    def _prepare_shadow(self) -> None:
+        if self.shadow_dirty or self.store.shadow is None or self.store.shadow_split != self.split:
+            self.store.refresh_shadow(self.split)
+            self.shadow_dirty = False
+
+    def workspace(self, B: int, training: bool) -> Dict[str, Any]:
+        key = (B, training, self.split, str(self.store.flat.device))
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        cfg, dev, sp = self.cfg, self.store.flat.device, self.split
+        D, L, N, T, G = cfg.embed_dim, cfg.depth, cfg.tokens, cfg.num_frames, cfg.G
+        M = B * N
+        f32 = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
+        ws = {"B": B, "M": M}
+        ws["patches"] = BT.empty((B * T * G, cfg.patch_k), sp, dev)
+        nsave = L if training else 1
+        ws["x_in"] = [f32(M, D) for _ in range(nsave + 1 if training else 2)]
+        ws["x_mid"] = [f32(M, D) for _ in range(nsave)]
+        ws["a"] = [BT.empty((M, D), sp, dev) for _ in range(nsave)]
+        ws["qkv"] = [BT.empty((M, 3 * D), sp, dev) for _ in range(nsave)]
+        ws["o"] = [BT.empty((M, D), sp, dev) for _ in range(nsave)]
+        ws["c"] = [BT.empty((M, D), sp, dev) for _ in range(nsave)]
+        ws["hact"] = [BT.empty((M, 4 * D), sp, dev) for _ in range(nsave)]
+        ws["hpre"] = [BT.empty((M, 4 * D), sp, dev) for _ in range(nsave)] if training else None
+        ws["lse"] = [f32(B, cfg.num_heads, N) for _ in range(nsave)] if training else None
+        ws["mean1"] = [f32(M) for _ in range(nsave)]
+        ws["rstd1"] = [f32(M) for _ in range(nsave)]
+        ws["mean2"] = [f32(M) for _ in range(nsave)]
+        ws["rstd2"] = [f32(M) for _ in range(nsave)]
+        ws["meanF"], ws["rstdF"] = f32(M), f32(M)
+        dims = cfg.head_dims
+        g = cfg.grid
+        ws["f"] = [BT.empty((B, g << i, g << i, dims[i]), sp, dev) for i in range(5)]
+        ws["u"] = [BT.empty((B, g << (i + 1), g << (i + 1), dims[i + 1]), sp, dev) for i in range(4)]
+        ws["cv"] = [BT.empty((B, g << (i + 1), g << (i + 1), dims[i + 1]), sp, dev) for i in range(4)]
+        ws["bn_scale"] = [f32(dims[i + 1]) for i in range(4)]
+        ws["bn_shift"] = [f32(dims[i + 1]) for i in range(4)]
+        ws["bn_mean"] = [f32(dims[i + 1]) for i in range(4)]
+        ws["bn_rstd"] = [f32(dims[i + 1]) for i in range(4)]
+        ws["bn_sums"] = torch.empty(2 * max(dims), dtype=torch.float64, device=dev)
+        if training:
+            # backward scratch (reused across blocks / stages)
+            ws["dx"] = f32(M, D)
+            ws["dxb"] = BT.empty((M, D), sp, dev)
+            ws["dtmp"] = BT.empty((M, D), sp, dev)
+            ws["dh"] = BT.empty((M, 4 * D), sp, dev)
+            ws["dqkv"] = BT.empty((M, 3 * D), sp, dev)
+            ws["delta"] = f32(B * cfg.num_heads * N)
+            ws["dpe"] = BT.empty((B * T * G, D), sp, dev)
+            ws["df"] = [BT.empty(tuple(ws["f"][i].shape), sp, dev) for i in range(5)]
+            ws["dcv"] = [BT.empty(tuple(ws["cv"][i].shape), sp, dev) for i in range(4)]
+            ws["du"] = [BT.empty(tuple(ws["u"][i].shape), sp, dev) for i in range(4)]
+        self._ws[key] = ws
+        return ws
+
+    # ---- forward -------------------------------------------------------------------------------
+    def forward(self, img: torch.Tensor, training: bool, save: bool, out: Optional[torch.Tensor] = None,
+                update_running: bool = True) -> torch.Tensor:
+        """img (B,C,T,H,W) f32 [or (B,C,H,W) when T==1, pritvhi.py:507-509] -> logits (B,ncls,H,W) f32.
+
+        ``training`` selects BatchNorm batch statistics + dropout (nn.Module.train()); ``save`` keeps the
+        activations needed by :meth:`backward`.
+        """
+        cfg = self.cfg
+        if img.dim() == 4 and cfg.num_frames == 1:
+            img = img.unsqueeze(2)
+        if img.dim() != 5 or img.shape[1] != cfg.in_chans or img.shape[2] != cfg.num_frames:
+            raise ValueError(f"expected (B,{cfg.in_chans},{cfg.num_frames},H,W) input, got {tuple(img.shape)}")
+        if img.shape[3] != cfg.img_size or img.shape[4] != cfg.img_size:
+            raise ValueError(f"image size {tuple(img.shape[3:])} != configured {cfg.img_size} (pos-embed interpolation is out of scope)")
+        if not img.is_cuda:
+            raise ops._lib.HipLibraryError("PrithviSeg.forward needs a HIP device tensor: instageo_amd has no CPU path")
+        img = img.contiguous().float()
+        B = img.shape[0]
+        if B == 0:  # empty batch: nothing to launch
+            return torch.empty((0, cfg.num_classes, cfg.img_size, cfg.img_size), dtype=torch.float32, device=img.device)
+        self._prepare_shadow()
+        ws = self.workspace(B, save)
+        D, L, N, T, G, H = cfg.embed_dim, cfg.depth, cfg.tokens, cfg.num_frames, cfg.G, cfg.num_heads
+        M = B * N
+        e = "prithvi_encoder."
+        pos = self.buffers[e + "pos_embed"]
+        ops.patchify(img, cfg.patch, ws["patches"])
+        x = ws["x_in"][0]
+        ops.cls_rows(x, self.P(e + "cls_token"), pos, B, N, D)
+        ops.patch_embed_fwd(ws["patches"], self.W(e + "patch_embed.proj.weight"), self.P(e + "patch_embed.proj.bias"), pos, x, B,
+                            T * G, D, cfg.patch_k)
+        for i in range(L):
+            s = i if save else 0
+            b = f"{e}blocks.{i}."
+            x_in = ws["x_in"][i if save else i % 2]
+            x_out = ws["x_in"][i + 1 if save else (i + 1) % 2]
+            x_mid = ws["x_mid"][s]
+            ops.layernorm_fwd(x_in, self.P(b + "norm1.weight"), self.P(b + "norm1.bias"), ws["a"][s], ws["mean1"][s], ws["rstd1"][s], M, D)
+            ops.linear_fwd(ws["a"][s], self.W(b + "attn.qkv.weight"), self.P(b + "attn.qkv.bias"), ws["qkv"][s], M, 3 * D, D)
+            ops.attention_fwd(ws["qkv"][s], ws["o"][s], ws["lse"][s] if save else None, B, N, H)
+            ops.linear_residual_fwd(ws["o"][s], self.W(b + "attn.proj.weight"), self.P(b + "attn.proj.bias"), x_in, x_mid, M, D, D)
+            ops.layernorm_fwd(x_mid, self.P(b + "norm2.weight"), self.P(b + "norm2.bias"), ws["c"][s], ws["mean2"][s], ws["rstd2"][s], M, D)
+            ops.linear_fwd(ws["c"][s], self.W(b + "mlp.fc1.weight"), self.P(b + "mlp.fc1.bias"), ws["hact"][s], M, 4 * D, D, act=1,
+                           pre=ws["hpre"][s] if save else None)
+            ops.linear_residual_fwd(ws["hact"][s], self.W(b + "mlp.fc2.weight"), self.P(b + "mlp.fc2.bias"), x_mid, x_out, M, D, 4 * D)
+        x_fin = ws["x_in"][L if save else L % 2]
+        # final LayerNorm writes the (B, 14, 14, D*T) feature image directly (model.py:406-413, c = d*T + t)
+        ops.layernorm_fwd(x_fin, self.P(e + "norm.weight"), self.P(e + "norm.bias"), ws["f"][0], ws["meanF"], ws["rstdF"], M, D,
+                          feat_T=T, feat_G=G, ntok=N)
+        logits = self._head_forward(ws, B, training, out, update_running)
+        self._last = {"ws": ws, "B": B, "training": training} if save else None
+        return logits
+
+    def _head_forward(self, ws, B: int, training: bool, out, update_running: bool) -> torch.Tensor:
+        cfg = self.cfg
+        dims, g = cfg.head_dims, cfg.grid
+        p = cfg.drop_p if training else 0.0
+        h = "segmentation_head."
+        for i in range(4):
+            Hs = g << i
+            ops.convT_fwd(ws["f"][i], self.W(f"{h}{i}.0.weight"), self.P(f"{h}{i}.0.bias"), ws["u"][i], B, Hs, Hs, dims[i], dims[i + 1],
+                          seed=self.drop_seed + i, p=p)
+            ops.conv3x3_fwd(ws["u"][i], self.W(f"{h}{i}.2.weight"), self.P(f"{h}{i}.2.bias"), ws["cv"][i], B, 2 * Hs, 2 * Hs, dims[i + 1],
+                            dims[i + 1])
+            ops.bn_relu_fwd(ws["cv"][i], self.P(f"{h}{i}.3.weight"), self.P(f"{h}{i}.3.bias"), self.buffers[f"{h}{i}.3.running_mean"],
+                            self.buffers[f"{h}{i}.3.running_var"], ws["f"][i + 1], ws["bn_scale"][i], ws["bn_shift"][i], ws["bn_mean"][i],
+                            ws["bn_rstd"][i], ws["bn_sums"], B * 4 * Hs * Hs, dims[i + 1], training, training and update_running)
+            if training and update_running:
+                self.buffers[f"{h}{i}.3.num_batches_tracked"] += 1
+        S = cfg.img_size
+        if out is None:
+            out = torch.empty((B, cfg.num_classes, S, S), dtype=torch.float32, device=ws["f"][4].hi.device)
+        ops.classifier_fwd(ws["f"][4], self.P(h + "5.weight"), self.P(h + "5.bias"), out, B, S * S, dims[4], cfg.num_classes,
+                           seed=self.drop_seed + 4, p=p)
+        return out
+
+    def features_nchw(self) -> torch.Tensor:
+        """reshaped_features of ``forward(..., return_features=True)``: (B, D*T, 14, 14) f32."""
+        assert self._last is not None
+        return self._last["ws"]["f"][0].float().permute(0, 3, 1, 2).contiguous()
+
+    # ---- backward ------------------------------------------------------------------------------
+    def backward(self, dlogits: torch.Tensor, count: Optional[torch.Tensor] = None) -> None:
+        """Accumulate d loss / d params into the flat grad buffer from d loss / d logits.
+
+        ``count``: optional device double[2] (``ig_ce_loss`` stats) whose [1] normalises un-normalised dlogits.
+        """
+        assert self._last is not None, "forward(save=True) must precede backward"
+        cfg = self.cfg
+        ws, B, training = self._last["ws"], self._last["B"], self._last["training"]
+        self.store.ensure_grad()
+        D, L, N, T, G, H = cfg.embed_dim, cfg.depth, cfg.tokens, cfg.num_frames, cfg.G, cfg.num_heads
+        M = B * N
+        dims, g = cfg.head_dims, cfg.grid
+        p = cfg.drop_p if training else 0.0
+        h = "segmentation_head."
+        S = cfg.img_size
+        ops.classifier_bwd(dlogits.contiguous(), ws["f"][4], self.P(h + "5.weight"), ws["df"][4], self.Gd(h + "5.weight"),
+                           self.Gd(h + "5.bias"), count, B, S * S, dims[4], cfg.num_classes, seed=self.drop_seed + 4, p=p)
+        for i in range(3, -1, -1):
+            Hs = g << i
+            Mo = B * 4 * Hs * Hs
+            C1 = dims[i + 1]
+            if not training:
+                raise RuntimeError("backward through eval-mode BatchNorm is not supported (reference trains in train mode)")
+            ops.bn_relu_bwd(ws["cv"][i], ws["df"][i + 1], ws["bn_scale"][i], ws["bn_shift"][i], ws["bn_mean"][i], ws["bn_rstd"][i],
+                            ws["dcv"][i], self.Gd(f"{h}{i}.3.weight"), self.Gd(f"{h}{i}.3.bias"), ws["bn_sums"], Mo, C1)
+            ops.conv3x3_wgrad(ws["dcv"][i], ws["u"][i], self.Gd(f"{h}{i}.2.weight"), B, 2 * Hs, 2 * Hs, C1, C1)
+            ops.colsum(ws["dcv"][i], self.Gd(f"{h}{i}.2.bias"), Mo, C1)
+            ops.conv3x3_dgrad(ws["dcv"][i], self.W(f"{h}{i}.2.weight"), ws["du"][i], B, 2 * Hs, 2 * Hs, C1, C1, seed=self.drop_seed + i, p=p)
+            ops.convT_wgrad(ws["du"][i], ws["f"][i], self.Gd(f"{h}{i}.0.weight"), B, Hs, Hs, dims[i], C1)
+            ops.colsum(ws["du"][i], self.Gd(f"{h}{i}.0.bias"), Mo, C1)
+            if i > 0 or not self.freeze_backbone:
+                ops.convT_dgrad(ws["du"][i], self.W(f"{h}{i}.0.weight"), ws["df"][i], B, Hs, Hs, dims[i], C1)
+        head0 = "segmentation_head.0.0.weight"
+        self._grad_ready(head0, None)
+        if self.freeze_backbone:
+            return
+        e = "prithvi_encoder."
+        dx, dxb = ws["dx"], ws["dxb"]
+
+        def block_start(i: int) -> str:
+            return f"{e}blocks.{i}.norm1.weight" if i < L else e + "norm.weight"
+
+        last_fc2_bias = self.Gd(f"{e}blocks.{L - 1}.mlp.fc2.bias") if L > 0 else None
+        ops.layernorm_bwd(ws["df"][0], ws["x_in"][L], ws["meanF"], ws["rstdF"], self.P(e + "norm.weight"), dx, False, dxb,
+                          self.Gd(e + "norm.weight"), self.Gd(e + "norm.bias"), last_fc2_bias, M, D, feat_T=T, feat_G=G, ntok=N)
+        self._grad_ready(e + "norm.weight", head0)
+        for i in range(L - 1, -1, -1):
+            b = f"{e}blocks.{i}."
+            # fc2: x_out = x_mid + hact @ W2^T + b2   (its bias grad came from the LayerNorm backward that produced dx)
+            ops.linear_wgrad(dxb, ws["hact"][i], self.Gd(b + "mlp.fc2.weight"), M, D, 4 * D)
+            ops.linear_dgrad(dxb, self.W(b + "mlp.fc2.weight"), ws["dh"], M, D, 4 * D, pre=ws["hpre"][i])
+            # fc1
+            ops.linear_wgrad(ws["dh"], ws["c"][i], self.Gd(b + "mlp.fc1.weight"), M, 4 * D, D)
+            ops.colsum(ws["dh"], self.Gd(b + "mlp.fc1.bias"), M, 4 * D)
+            ops.linear_dgrad(ws["dh"], self.W(b + "mlp.fc1.weight"), ws["dtmp"], M, 4 * D, D)
+            ops.layernorm_bwd(ws["dtmp"], ws["x_mid"][i], ws["mean2"][i], ws["rstd2"][i], self.P(b + "norm2.weight"), dx, True, dxb,
+                              self.Gd(b + "norm2.weight"), self.Gd(b + "norm2.bias"), self.Gd(b + "attn.proj.bias"), M, D)
+            # proj
+            ops.linear_wgrad(dxb, ws["o"][i], self.Gd(b + "attn.proj.weight"), M, D, D)
+            ops.linear_dgrad(dxb, self.W(b + "attn.proj.weight"), ws["dtmp"], M, D, D)
+            ops.attention_bwd(ws["qkv"][i], ws["o"][i], ws["dtmp"], ws["lse"][i], ws["delta"], ws["dqkv"], B, N, H)
+            # qkv
+            ops.linear_wgrad(ws["dqkv"], ws["a"][i], self.Gd(b + "attn.qkv.weight"), M, 3 * D, D)
+            ops.colsum(ws["dqkv"], self.Gd(b + "attn.qkv.bias"), M, 3 * D)
+            ops.linear_dgrad(ws["dqkv"], self.W(b + "attn.qkv.weight"), ws["dtmp"], M, 3 * D, D)
+            prev_bias = self.Gd(f"{e}blocks.{i - 1}.mlp.fc2.bias") if i > 0 else None
+            ops.layernorm_bwd(ws["dtmp"], ws["x_in"][i], ws["mean1"][i], ws["rstd1"][i], self.P(b + "norm1.weight"), dx, True, dxb,
+                              self.Gd(b + "norm1.weight"), self.Gd(b + "norm1.bias"), prev_bias, M, D)
+            self._grad_ready(block_start(i), block_start(i + 1))  # all grads of block i are final
+        # patch embedding + cls token
+        ops.patch_grad_prep(dx, ws["dpe"], self.Gd(e + "cls_token"), self.Gd(e + "patch_embed.proj.bias"), B, N, D)
+        ops.linear_wgrad(ws["dpe"], ws["patches"], self.Gd(e + "patch_embed.proj.weight"), B * T * G, D, cfg.patch_k)
+        self._grad_ready(e + "cls_token", block_start(0))
+
+    def _grad_ready(self, first: str, until: Optional[str]) -> None:
+        """Tell the data-parallel layer that grads of flat range [offset(first), offset(until)) are final."""
+        if self.on_grad_ready is None:
+            return
+        lo = self.store.entries[first].offset
+        hi = self.store.total if until is None else self.store.entries[until].offset
+        if hi > lo:
+            self.on_grad_ready(lo, hi)
+
+
+# --------------------------------------------------------------------------------------------------
+# autograd bridge + nn.Module with the reference's contract
+# --------------------------------------------------------------------------------------------------
+class _SegFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, module, *params):
+        ctx.module = module
+        eng = module.engine
+        logits = eng.forward(img, module.training, save=True)
+        ctx.n = len(params)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        module = ctx.module
+        eng = module.engine
+        store = module.store
+        g = store.ensure_grad()
+        g.zero_()
+        eng.backward(dlogits.contiguous().float())
+        grads = []
+        for name, p in module._flat_params():
+            if p.requires_grad:
+                grads.append(store.entries[name].api_view(g).clone())
+            else:
+                grads.append(None)
+        return (None, None, *grads)
+
+
+class _Holder(nn.Module):
+    """Name-only container so that parameter paths equal the reference's state_dict keys."""
+
+
+class PrithviSeg(nn.Module):
+    """Prithvi Segmentation Model (drop-in for ``instageo.model.model.PrithviSeg``, model.py:292-419).
+
+    Same constructor arguments, ``forward(img, return_features=False)`` semantics, attribute names
+    (``prithvi_encoder``, ``segmentation_head``, ``model_args``) and ``state_dict()`` keys/shapes.
+    Extra keyword ``precision`` ("bf16" | "bf16x3") and ``device``.
+    """
+
+    def __init__(
+        self,
+        temporal_step: int = 1,
+        image_size: int = 224,
+        num_classes: int = 2,
+        load_pretrained_weights: bool = True,
+        freeze_backbone: bool = True,
+        model_bands: List[int] = list(range(6)),
+        variant: str = "prithvi_eo_v1_100",
+        embed_dims: Optional[List[int]] = None,
+        depth: int = -1,
+        precision: str = "bf16",
+        device: Optional[Any] = None,
+        **kwargs: Any,
+    ) -> None:
+        super().__init__()
+        if embed_dims is not None:
+            raise NotImplementedError("custom embed_dims for the head are not supported (reference default: D*T / 2^i)")
+        if kwargs:
+            raise TypeError(f"unsupported PrithviSeg arguments: {sorted(kwargs)}")
+        in_chans = 6 * max(1, len(model_bands) // 6)  # model.py:330 PRETRAINED_BANDS * (len(model_bands)//6)
+        cfg = make_seg_config(variant, temporal_step, image_size, num_classes, depth, in_chans)
+        self.cfg = cfg
+        if device is None:
+            device = "cuda" if torch.cuda.is_available() else "cpu"
+        device = torch.device(device)
+        self.store = ParamStore(cfg, device)
+        self._buffers_flat: Dict[str, torch.Tensor] = {}
+        self.model_args = {
+            "img_size": image_size, "num_frames": temporal_step, "patch_size": [1, cfg.patch, cfg.patch], "in_chans": in_chans,
+            "embed_dim": cfg.embed_dim, "depth": cfg.depth, "num_heads": cfg.num_heads, "mlp_ratio": cfg.mlp_ratio,
+        }  # fmt: skip
+        self._build_tree()
+        self.engine = SegEngine(cfg, self.store, self._buffers_flat, precision)
+        self.reset_parameters()
+        if load_pretrained_weights:
+            raise RuntimeError(
+                "load_pretrained_weights=True needs the Hugging Face hub (model.py:221-251); this build has no network. "
+                "Construct with load_pretrained_weights=False and call load_state_dict() / load_prithvi_checkpoint()."
+            )
+        self.freeze_backbone = bool(freeze_backbone)
+        if freeze_backbone:  # model.py:341-343
+            for p in self.prithvi_encoder.parameters():
+                p.requires_grad = False
+        self.engine.freeze_backbone = self.freeze_backbone
+
+    # ---- module tree ---------------------------------------------------------------------------
+    def _build_tree(self) -> None:
+        cfg = self.cfg
+        dev = self.store.flat.device
+
+        def attach(path: str, tensor: torch.Tensor, is_param: bool) -> None:
+            parts = path.split(".")
+            mod: nn.Module = self
+            for part in parts[:-1]:
+                if part not in mod._modules:
+                    mod.add_module(part, _Holder())
+                mod = mod._modules[part]
+            if is_param:
+                mod.register_parameter(parts[-1], nn.Parameter(tensor))
+            else:
+                mod.register_buffer(parts[-1], tensor)
+
+        # order matters: state_dict key order follows registration order (reference order)
+        e = "prithvi_encoder."
+        attach(e + "cls_token", self.store.entries[e + "cls_token"].api_view(self.store.flat), True)
+        pos = torch.zeros(1, cfg.tokens, cfg.embed_dim, dtype=torch.float32, device=dev)
+        attach(e + "pos_embed", pos, False)
+        self._buffers_flat[e + "pos_embed"] = pos
+        for name, ent in self.store.entries.items():
+            if name == e + "cls_token":
+                continue
+            attach(name, ent.api_view(self.store.flat), True)
+            if name.startswith("segmentation_head.") and name.endswith(".3.bias"):
+                base = name[: -len("bias")]
+                c = ent.shape[0]
+                for bn, val in (("running_mean", torch.zeros(c, device=dev)), ("running_var", torch.ones(c, device=dev)),
+                                ("num_batches_tracked", torch.zeros((), dtype=torch.int64, device=dev))):  # fmt: skip
+                    attach(base + bn, val, False)
+                    self._buffers_flat[base + bn] = val
+
+    def _flat_params(self):
+        if getattr(self, "_param_list", None) is None:
+            named = dict(self.named_parameters())
+            self._param_list = [(name, named[name]) for name in self.store.entries]
+        return self._param_list
+
+    def _apply(self, fn, recurse=True):
+        """Keep parameters as views of the flat buffer across .to()/.cuda()."""
+        new_flat = fn(self.store.flat)
+        if new_flat.dtype != torch.float32:
+            raise TypeError("PrithviSeg master parameters must stay float32 (bf16 operands are managed internally)")
+        moved = new_flat.data_ptr() != self.store.flat.data_ptr() or new_flat.device != self.store.flat.device
+        if moved:
+            self.store.flat = new_flat.contiguous()
+            self.store.grad = None
+            self.store.shadow = None
+            named = dict(self.named_parameters())
+            for name, ent in self.store.entries.items():
+                p = named[name]
+                p.data = ent.api_view(self.store.flat)
+                p.grad = None
+            for name in list(self._buffers_flat):
+                parts = name.split(".")
+                mod = self
+                for part in parts[:-1]:
+                    mod = mod._modules[part]
+                nb = fn(mod._buffers[parts[-1]])
+                mod._buffers[parts[-1]] = nb
+                self._buffers_flat[name] = nb
+            self.engine._ws.clear()
+            self.engine.mark_params_changed()
+        return self
+
+    # ---- init / checkpoint ---------------------------------------------------------------------
+    @torch.no_grad()
+    def reset_parameters(self) -> None:
+        """Reference initialisation (pritvhi.py:463-477; head layers keep PyTorch defaults, model.py:360-378)."""
+        cfg = self.cfg
+        e = "prithvi_encoder."
+        sd = dict(self.named_parameters())
+        pe = get_3d_sincos_pos_embed(cfg.embed_dim, (cfg.num_frames, cfg.grid, cfg.grid), cls_token=True)
+        self._buffers_flat[e + "pos_embed"].copy_(torch.from_numpy(pe).float().unsqueeze(0))
+        for name, p in sd.items():
+            if name.startswith(e):
+                if name.endswith("cls_token"):
+                    nn.init.normal_(p, std=0.02)
+                elif name.endswith("patch_embed.proj.weight"):
+                    w = torch.empty(p.shape[0], int(np.prod(p.shape[1:])))
+                    nn.init.xavier_uniform_(w)
+                    p.copy_(w.view(p.shape))
+                elif name.endswith("patch_embed.proj.bias"):  # nn.Conv3d default bias init (untouched by init_weights)
+                    bound = 1 / math.sqrt(cfg.patch_k)
+                    p.copy_(torch.empty(p.shape).uniform_(-bound, bound))
+                elif p.dim() == 2:
+                    w = torch.empty(p.shape)
+                    nn.init.xavier_uniform_(w)
+                    p.copy_(w)
+                elif ".norm" in name and name.endswith("weight"):
+                    p.fill_(1.0)
+                else:
+                    p.zero_()
+            else:
+                if p.dim() == 4:  # kaiming_uniform_(a=sqrt(5)) as nn.Conv2d / nn.ConvTranspose2d.reset_parameters
+                    w = torch.empty(p.shape)
+                    nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+                    p.copy_(w)
+                elif name.endswith(".3.weight"):
+                    p.fill_(1.0)
+                elif name.endswith(".3.bias"):
+                    p.zero_()
+                else:  # conv biases: U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+                    wname = name[: -len("bias")] + "weight"
+                    wshape = sd[wname].shape
+                    fan_in = wshape[1] * wshape[2] * wshape[3]
+                    bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+                    p.copy_(torch.empty(p.shape).uniform_(-bound, bound))
+        self.engine.mark_params_changed() if hasattr(self, "engine") else None
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        out = super().load_state_dict(state_dict, strict=strict, assign=False)
+        self.engine.mark_params_changed()
+        return out
+
+    def params_changed(self) -> None:
+        """Call after modifying parameters outside this package (e.g. a foreign optimizer step)."""
+        self.engine.mark_params_changed()
+
+    # ---- forward -------------------------------------------------------------------------------
+    def forward(self, img: torch.Tensor, return_features: bool = False):
+        """(B,C,T,H,W) [or (B,C,H,W) if T==1] -> logits (B,num_classes,H,W) [, features (B,D*T,14,14)]."""
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if needs_grad:
+            # foreign optimizers write into the fp32 views directly: always refresh the bf16 operands
+            self.engine.mark_params_changed()
+            params = [p for _, p in self._flat_params()]
+            out = _SegFunction.apply(img, self, *params)
+        else:
+            self.engine.mark_params_changed()
+            out = self.engine.forward(img, self.training, save=return_features, update_running=True)
+        if return_features:
+            return out, self.engine.features_nchw()
+        return out
+
+
+def load_prithvi_checkpoint(model: PrithviSeg, state_dict: Dict[str, torch.Tensor]) -> None:
+    """Load a Prithvi MAE/ViT checkpoint into ``model.prithvi_encoder`` following
+    ``checkpoint_filter_fn_vit`` (instageo/model/utils.py:271-315): drop decoder/mask-token keys, strip the
+    ``encoder.`` prefix, keep the model's own fixed ``pos_embed``, truncate blocks to ``depth``."""
+    clean = {}
+    enc = {k[len("prithvi_encoder.") :]: v for k, v in model.state_dict().items() if k.startswith("prithvi_encoder.")}
+    for k, v in state_dict.items():
+        k = k.replace("_timm_module.", "")
+        if "decoder" in k or "_dec" in k or k == "mask_token":
+            continue
+        if "temporal_embed" in k or "location_embed" in k:
+            continue
+        if k.startswith("encoder."):
+            k = k[len("encoder.") :]
+        if "pos_embed" in k:
+            v = enc["pos_embed"]
+        if k.startswith("blocks.") and int(k.split(".")[1]) >= model.cfg.depth:
+            continue
+        clean[k] = v
+    missing = set(enc) - set(clean)
+    unexpected = set(clean) - set(enc)
+    if missing or unexpected:
+        raise RuntimeError(f"checkpoint mismatch: missing {sorted(missing)[:5]}, unexpected {sorted(unexpected)[:5]}")
+    full = model.state_dict()
+    for k, v in clean.items():
+        full["prithvi_encoder." + k] = v
+    model.load_state_dict(full, strict=True)

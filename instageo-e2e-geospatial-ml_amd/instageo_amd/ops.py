@@ -1,0 +1,239 @@
+"""Thin torch-tensor wrappers over the C-ABI (``include/instageo_hip.h``).
+
+PyTorch is plumbing only: it owns device memory and the current HIP stream; every arithmetic op on
+the hot path is a HIP kernel reached through :func:`instageo_amd._lib.call`.  All wrappers require
+contiguous CUDA(HIP) tensors and raise otherwise -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+BF16 = torch.bfloat16
+
+
+class BT:
+    """A bf16 device tensor, optionally *split* (hi + lo) for the bf16x3 precision mode."""
+
+    __slots__ = ("hi", "lo")
+
+    def __init__(self, hi: torch.Tensor, lo: Optional[torch.Tensor] = None):
+        assert hi.dtype == BF16 and (lo is None or (lo.dtype == BF16 and lo.shape == hi.shape))
+        self.hi, self.lo = hi, lo
+
+    @staticmethod
+    def empty(shape, split: bool, device) -> "BT":
+        hi = torch.empty(shape, dtype=BF16, device=device)
+        return BT(hi, torch.empty(shape, dtype=BF16, device=device) if split else None)
+
+    @staticmethod
+    def zeros(shape, split: bool, device) -> "BT":
+        hi = torch.zeros(shape, dtype=BF16, device=device)
+        return BT(hi, torch.zeros(shape, dtype=BF16, device=device) if split else None)
+
+    @staticmethod
+    def from_float(x: torch.Tensor, split: bool) -> "BT":
+        x = x.contiguous().float()
+        out = BT.empty(x.shape, split, x.device)
+        split_bf16(x, out)
+        return out
+
+    @property
+    def split(self) -> bool:
+        return self.lo is not None
+
+    @property
+    def shape(self):
+        return self.hi.shape
+
+    def view(self, *shape) -> "BT":
+        return BT(self.hi.view(*shape), None if self.lo is None else self.lo.view(*shape))
+
+    def float(self) -> torch.Tensor:
+        out = torch.empty(self.hi.shape, dtype=torch.float32, device=self.hi.device)
+        _lib.call("ig_merge_bf16", _p(self.hi), _p(self.lo), _p(out), out.numel(), _stream())
+        return out
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.HipLibraryError("instageo_amd ops need HIP device tensors (no CPU fallback)")
+    if not t.is_contiguous():
+        raise _lib.HipLibraryError("instageo_amd ops need contiguous tensors")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    assert t.dtype == torch.float32, t.dtype
+    return t
+
+
+# ------------------------------------------------------------------------------------------------------
+def split_bf16(src: torch.Tensor, out: BT) -> None:
+    _lib.call("ig_split_bf16", _p(_f32(src)), _p(out.hi), _p(out.lo), src.numel(), _stream())
+
+
+def normalize_chips(src: torch.Tensor, mean: torch.Tensor, std: torch.Tensor, temporal: int,
+                    constant_multiplier: Optional[float] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(B, T*C, H, W) int16|f32 -> (B, C, T, H, W) f32 normalised  (dataloader.py:495-524)."""
+    B, TC, H, W = src.shape
+    C = TC // temporal
+    assert C * temporal == TC and mean.numel() == C and std.numel() == C
+    dt = {torch.int16: 0, torch.float32: 1}[src.dtype]
+    if out is None:
+        out = torch.empty((B, C, temporal, H, W), dtype=torch.float32, device=src.device)
+    mult = 1.0 if constant_multiplier is None else float(constant_multiplier)
+    _lib.call("ig_normalize_chips", _p(src), dt, _p(_f32(mean)), _p(_f32(std)), mult, int(constant_multiplier is not None),
+              _p(out), B, temporal, C, H, W, _stream())
+    return out
+
+
+def patchify(img: torch.Tensor, p: int, out: BT) -> None:
+    B, C, T, H, W = img.shape
+    _lib.call("ig_patchify", _p(_f32(img)), _p(out.hi), _p(out.lo), B, C, T, H, W, p, _stream())
+
+
+def cls_rows(x: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, B: int, ntok: int, D: int) -> None:
+    _lib.call("ig_cls_rows", _p(x), _p(cls), _p(pos), B, ntok, D, _stream())
+
+
+def patch_embed_fwd(patches: BT, w: BT, bias, pos, x, batch: int, tpc: int, D: int, K: int) -> None:
+    _lib.call("ig_patch_embed_fwd", _p(patches.hi), _p(patches.lo), _p(w.hi), _p(w.lo), _p(bias), _p(pos), _p(x), batch, tpc, D, K,
+              _stream())
+
+
+def layernorm_fwd(x, gamma, beta, out: BT, mean, rstd, M: int, D: int, eps: float = 1e-5, feat_T: int = 0, feat_G: int = 0,
+                  ntok: int = 0) -> None:
+    _lib.call("ig_layernorm_fwd", _p(x), _p(gamma), _p(beta), _p(out.hi), _p(out.lo), _p(mean), _p(rstd), M, D, eps, feat_T, feat_G,
+              ntok, _stream())
+
+
+def layernorm_bwd(dy: BT, x, mean, rstd, gamma, dx, accumulate: bool, dxb: Optional[BT], dgamma, dbeta, dcol, M: int, D: int,
+                  feat_T: int = 0, feat_G: int = 0, ntok: int = 0) -> None:
+    _lib.call("ig_layernorm_bwd", _p(dy.hi), _p(dy.lo), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), int(accumulate),
+              _p(dxb.hi) if dxb else None, _p(dxb.lo) if dxb else None, _p(dgamma), _p(dbeta), _p(dcol), M, D, feat_T, feat_G, ntok,
+              _stream())
+
+
+def linear_fwd(x: BT, w: BT, bias, y: BT, M: int, N: int, K: int, act: int = 0, pre: Optional[BT] = None) -> None:
+    _lib.call("ig_linear_fwd", _p(x.hi), _p(x.lo), _p(w.hi), _p(w.lo), _p(bias), _p(y.hi), _p(y.lo),
+              _p(pre.hi) if pre else None, _p(pre.lo) if pre else None, M, N, K, act, _stream())
+
+
+def linear_residual_fwd(x: BT, w: BT, bias, resid, out, M: int, N: int, K: int) -> None:
+    _lib.call("ig_linear_residual_fwd", _p(x.hi), _p(x.lo), _p(w.hi), _p(w.lo), _p(bias), _p(resid), _p(out), M, N, K, _stream())
+
+
+def linear_dgrad(dy: BT, w: BT, dx: BT, M: int, N: int, K: int, pre: Optional[BT] = None) -> None:
+    _lib.call("ig_linear_dgrad", _p(dy.hi), _p(dy.lo), _p(w.hi), _p(w.lo), _p(dx.hi), _p(dx.lo),
+              _p(pre.hi) if pre else None, _p(pre.lo) if pre else None, M, N, K, 1 if pre else 0, _stream())
+
+
+def linear_wgrad(dy: BT, x: BT, dw, M: int, N: int, K: int) -> None:
+    _lib.call("ig_linear_wgrad", _p(dy.hi), _p(dy.lo), _p(x.hi), _p(x.lo), _p(dw), M, N, K, _stream())
+
+
+def attention_fwd(qkv: BT, out: BT, lse, B: int, N: int, H: int, hd: int = 64) -> None:
+    _lib.call("ig_attention_fwd", _p(qkv.hi), _p(qkv.lo), _p(out.hi), _p(out.lo), _p(lse), B, N, H, hd, _stream())
+
+
+def attention_bwd(qkv: BT, out: BT, dout: BT, lse, delta, dqkv: BT, B: int, N: int, H: int, hd: int = 64) -> None:
+    _lib.call("ig_attention_bwd", _p(qkv.hi), _p(qkv.lo), _p(out.hi), _p(out.lo), _p(dout.hi), _p(dout.lo), _p(lse), _p(delta),
+              _p(dqkv.hi), _p(dqkv.lo), B, N, H, hd, _stream())
+
+
+def colsum(x: BT, out, M: int, C: int) -> None:
+    _lib.call("ig_colsum", _p(x.hi), _p(x.lo), _p(out), M, C, _stream())
+
+
+def patch_grad_prep(dx, out: BT, dcls, dbias, B: int, ntok: int, D: int) -> None:
+    _lib.call("ig_patch_grad_prep", _p(dx), _p(out.hi), _p(out.lo), _p(dcls), _p(dbias), B, ntok, D, _stream())
+
+
+def convT_fwd(x: BT, w: BT, bias, y: BT, B, H, W, Cin, Cout, seed: int = 0, p: float = 0.0) -> None:
+    _lib.call("ig_convT_fwd", _p(x.hi), _p(x.lo), _p(w.hi), _p(w.lo), _p(bias), _p(y.hi), _p(y.lo), B, H, W, Cin, Cout, seed, p,
+              _stream())
+
+
+def convT_dgrad(dy: BT, w: BT, dx: BT, B, H, W, Cin, Cout) -> None:
+    _lib.call("ig_convT_dgrad", _p(dy.hi), _p(dy.lo), _p(w.hi), _p(w.lo), _p(dx.hi), _p(dx.lo), B, H, W, Cin, Cout, _stream())
+
+
+def convT_wgrad(dy: BT, x: BT, dw, B, H, W, Cin, Cout) -> None:
+    _lib.call("ig_convT_wgrad", _p(dy.hi), _p(dy.lo), _p(x.hi), _p(x.lo), _p(dw), B, H, W, Cin, Cout, _stream())
+
+
+def conv3x3_fwd(x: BT, w: BT, bias, y: BT, B, H, W, Cin, Cout) -> None:
+    _lib.call("ig_conv3x3_fwd", _p(x.hi), _p(x.lo), _p(w.hi), _p(w.lo), _p(bias), _p(y.hi), _p(y.lo), B, H, W, Cin, Cout, _stream())
+
+
+def conv3x3_dgrad(dy: BT, w: BT, dx: BT, B, H, W, Cin, Cout, seed: int = 0, p: float = 0.0) -> None:
+    _lib.call("ig_conv3x3_dgrad", _p(dy.hi), _p(dy.lo), _p(w.hi), _p(w.lo), _p(dx.hi), _p(dx.lo), B, H, W, Cin, Cout, seed, p,
+              _stream())
+
+
+def conv3x3_wgrad(dy: BT, x: BT, dw, B, H, W, Cin, Cout) -> None:
+    _lib.call("ig_conv3x3_wgrad", _p(dy.hi), _p(dy.lo), _p(x.hi), _p(x.lo), _p(dw), B, H, W, Cin, Cout, _stream())
+
+
+def bn_relu_fwd(x: BT, gamma, beta, rmean, rvar, y: BT, scale, shift, mean, rstd, sums, M: int, C: int, training: bool,
+                update_running: bool, eps: float = 1e-5, momentum: float = 0.1) -> None:
+    _lib.call("ig_bn_relu_fwd", _p(x.hi), _p(x.lo), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(y.hi), _p(y.lo), _p(scale), _p(shift),
+              _p(mean), _p(rstd), _p(sums), M, C, eps, momentum, int(training), int(update_running), _stream())
+
+
+def bn_relu_bwd(x: BT, dy: BT, scale, shift, mean, rstd, dx: BT, dgamma, dbeta, sums, M: int, C: int) -> None:
+    _lib.call("ig_bn_relu_bwd", _p(x.hi), _p(x.lo), _p(dy.hi), _p(dy.lo), _p(scale), _p(shift), _p(mean), _p(rstd), _p(dx.hi), _p(dx.lo),
+              _p(dgamma), _p(dbeta), _p(sums), M, C, _stream())
+
+
+def classifier_fwd(f: BT, w, bias, logits, B: int, HW: int, C: int, ncls: int, seed: int = 0, p: float = 0.0) -> None:
+    _lib.call("ig_classifier_fwd", _p(f.hi), _p(f.lo), _p(w), _p(bias), _p(logits), B, HW, C, ncls, seed, p, _stream())
+
+
+def classifier_bwd(dlogits, f: BT, w, df: BT, dw, db, count, B: int, HW: int, C: int, ncls: int, seed: int = 0, p: float = 0.0) -> None:
+    _lib.call("ig_classifier_bwd", _p(dlogits), _p(f.hi), _p(f.lo), _p(w), _p(df.hi), _p(df.lo), _p(dw), _p(db), _p(count), B, HW, C,
+              ncls, seed, p, _stream())
+
+
+_LABEL_DT = {torch.int64: 0, torch.int32: 1, torch.float32: 2}
+
+
+def ce_loss(logits, labels, class_weights, ignore_index: int, stats, dlogits=None, preds=None, preds_i8=None, confusion=None) -> None:
+    B, ncls = logits.shape[0], logits.shape[1]
+    HW = logits.numel() // (B * ncls)
+    _lib.call("ig_ce_loss", _p(_f32(logits)), _p(labels), _LABEL_DT[labels.dtype], _p(class_weights), int(ignore_index), _p(stats),
+              _p(dlogits), _p(preds), _p(preds_i8), _p(confusion), B, HW, ncls, _stream())
+
+
+def argmax_i8(logits, out=None):
+    B, ncls = logits.shape[0], logits.shape[1]
+    HW = logits.numel() // (B * ncls)
+    if out is None:
+        out = torch.empty((B,) + tuple(logits.shape[2:]), dtype=torch.int8, device=logits.device)
+    _lib.call("ig_argmax_i8", _p(_f32(logits)), _p(out), B, HW, ncls, _stream())
+    return out
+
+
+def confusion_update(y_true, y_pred, confusion, k: int, ignore_index: Optional[int]) -> None:
+    assert y_true.dtype == torch.int64 and y_pred.dtype == torch.int64 and confusion.dtype == torch.int64
+    _lib.call("ig_confusion_update", _p(y_true), _p(y_pred), _p(confusion), y_true.numel(), k,
+              0 if ignore_index is None else int(ignore_index), int(ignore_index is not None), _stream())
+
+
+def adamw_advance(hyper) -> None:
+    _lib.call("ig_adamw_advance", _p(hyper), _stream())
+
+
+def adamw_step(p, g, m, v, shadow: Optional[BT], hyper, n: int) -> None:
+    _lib.call("ig_adamw_step", _p(p), _p(g), _p(m), _p(v), _p(shadow.hi) if shadow else None,
+              _p(shadow.lo) if shadow and shadow.lo is not None else None, _p(hyper), n, _stream())

@@ -1,0 +1,346 @@
+"""Segmentation task module (reference: ``instageo/model/base.py:33-231`` + ``segmentation.py:33-213``).
+
+``PrithviSegmentationModule`` keeps the reference's constructor arguments, step methods, metric names
+and optimiser/scheduler choices.  Two execution paths share the same kernels:
+
+* the *compatible* path -- ``loss = module.training_step(batch, i); loss.backward(); optimizer.step()`` --
+  works under an unmodified (Lightning-style) loop through two ``torch.autograd.Function`` bridges;
+* the *fused* path -- :meth:`fused_train_step` -- runs forward, loss+metrics, backward, (gradient
+  all-reduce) and AdamW as one stream of HIP launches with no host synchronisation; this is what
+  ``run.py``, ``bench.py`` and the data-parallel trainer use.
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, Callable, Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .metrics import RunningConfusionMatrix
+from .model import PrithviSeg
+
+try:  # the module must still work as a LightningModule when Lightning is installed
+    import pytorch_lightning as pl  # type: ignore
+
+    _Base = pl.LightningModule
+except Exception:  # pragma: no cover - Lightning is absent in this image
+    pl = None
+    _Base = nn.Module
+
+
+# --------------------------------------------------------------------------------------------------
+# AdamW on the flat parameter buffer (base.py:124-126: torch.optim.AdamW defaults)
+# --------------------------------------------------------------------------------------------------
+class FusedAdamW(torch.optim.Optimizer):
+    """``torch.optim.AdamW`` semantics, one HIP launch over the flat buffer of a :class:`PrithviSeg`.
+
+    Subclasses ``torch.optim.Optimizer`` so LR schedulers (CosineAnnealingWarmRestarts, base.py:128-131)
+    drive ``param_groups[0]["lr"]`` as usual.  Gradients are taken from the flat grad buffer when the
+    fused path produced them, otherwise gathered from ``p.grad``.
+    """
+
+    def __init__(self, net: PrithviSeg, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
+                 clip_range: Optional[List[float]] = None):
+        params = [p for p in net.parameters() if p.requires_grad]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.net = net
+        self.clip_range = clip_range
+        store = net.store
+        self.lo = store.encoder_end if net.freeze_backbone else 0
+        self.hi = store.total
+        dev = store.flat.device
+        self.m = torch.zeros(self.hi - self.lo, dtype=torch.float32, device=dev)
+        self.v = torch.zeros_like(self.m)
+        self.hyper = torch.zeros(16, dtype=torch.float32, device=dev)
+        self._host_step = 0
+        self._write_hyper()
+
+    def _write_hyper(self) -> None:
+        g = self.param_groups[0]
+        b1, b2 = g["betas"]
+        h = [g["lr"], b1, b2, g["eps"], g["weight_decay"], 0.0, 0.0, 0.0, 0.0, 0.0, float(self._host_step), 1 - b1, 1 - b2]
+        if self.clip_range is not None:
+            h[7], h[8], h[9] = float(self.clip_range[0]), float(self.clip_range[1]), 1.0
+        self.hyper[: len(h)] = torch.tensor(h, dtype=torch.float32)
+        self._lr_written = g["lr"]
+
+    def gather_grads(self) -> None:
+        """Copy autograd-produced ``p.grad`` tensors into the flat grad buffer (compatible path)."""
+        store = self.net.store
+        g = store.ensure_grad()
+        for name, p in self.net._flat_params():
+            if p.requires_grad and p.grad is not None:
+                store.entries[name].api_view(g).copy_(p.grad)
+
+    @torch.no_grad()
+    def step(self, closure=None, grads_in_flat: bool = False):
+        loss = closure() if closure is not None else None
+        if self.param_groups[0]["lr"] != self._lr_written:
+            self.hyper[0] = float(self.param_groups[0]["lr"])
+            self._lr_written = self.param_groups[0]["lr"]
+        if not grads_in_flat:
+            self.gather_grads()
+        store = self.net.store
+        self._host_step += 1
+        ops.adamw_advance(self.hyper)
+        # the kernel also refreshes the bf16 (hi/lo) operand copy used by the MFMA kernels
+        eng = self.net.engine
+        if store.shadow is None or store.shadow_split != eng.split:
+            store.refresh_shadow(eng.split)
+        sh = store.shadow
+        shadow = ops.BT(sh.hi[self.lo : self.hi], None if sh.lo is None else sh.lo[self.lo : self.hi])
+        ops.adamw_step(store.flat[self.lo : self.hi], store.grad[self.lo : self.hi], self.m, self.v, shadow, self.hyper, self.hi - self.lo)
+        eng.shadow_dirty = False
+        return loss
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        super().zero_grad(set_to_none=set_to_none)
+        if self.net.store.grad is not None:
+            self.net.store.grad.zero_()
+
+
+# --------------------------------------------------------------------------------------------------
+# loss bridge: CrossEntropyLoss(weight, ignore_index, 'none') + loss[mask].mean()  (segmentation.py:85-87,117-122)
+# --------------------------------------------------------------------------------------------------
+class _SegLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, weight, ignore_index, confusion, preds):
+        stats = torch.zeros(2, dtype=torch.float64, device=logits.device)
+        dlog = torch.empty_like(logits)
+        ops.ce_loss(logits.contiguous(), labels.contiguous(), weight, ignore_index, stats, dlog, preds, None, confusion)
+        ctx.save_for_backward(dlog, stats)
+        return (stats[0] / stats[1]).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        dlog, stats = ctx.saved_tensors
+        return dlog * (g / stats[1].float()), None, None, None, None, None
+
+
+def segmentation_loss(logits: torch.Tensor, labels: torch.Tensor, class_weights: Optional[torch.Tensor], ignore_index: int,
+                      confusion: Optional[torch.Tensor] = None, preds: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """sum_valid(w_y * nll) / #valid -- NOT torch's weighted mean.  NaN when nothing is valid,
+    exactly like ``loss[mask].mean()`` of an empty selection."""
+    if labels.dtype not in (torch.int64, torch.int32, torch.float32):
+        labels = labels.long()
+    return _SegLoss.apply(logits, labels, class_weights, ignore_index, confusion, preds)
+
+
+# --------------------------------------------------------------------------------------------------
+class PrithviSegmentationModule(_Base):
+    """Prithvi Segmentation module with the reference's constructor (segmentation.py:36-98)."""
+
+    def __init__(
+        self,
+        image_size: int = 224,
+        learning_rate: float = 1e-4,
+        freeze_backbone: bool = True,
+        load_pretrained_weights: bool = True,
+        num_classes: int = 2,
+        temporal_step: int = 1,
+        class_weights: Optional[List[float]] = None,
+        ignore_index: int = -100,
+        weight_decay: float = 1e-2,
+        scheduler: bool = True,
+        model_name: str = "prithvi_eo_v1_100",
+        weight_clip_range: Optional[List[float]] = None,
+        depth: int = -1,
+        precision: str = "bf16",
+        device: Optional[Any] = None,
+    ) -> None:
+        super().__init__()
+        self._num_classes = num_classes
+        self.net = PrithviSeg(
+            image_size=image_size, temporal_step=temporal_step, freeze_backbone=freeze_backbone, variant=model_name,
+            load_pretrained_weights=load_pretrained_weights, depth=depth, num_classes=num_classes, precision=precision, device=device,
+        )  # fmt: skip
+        self.learning_rate = learning_rate
+        self.weight_decay = weight_decay
+        self.scheduler = scheduler
+        self.weight_clip_range = weight_clip_range
+        self.ignore_index = ignore_index
+        dev = self.net.store.flat.device
+        # `criterion.weight` is part of the reference checkpoint: keep the same buffer path
+        self.criterion = nn.Module()
+        if class_weights:
+            self.criterion.register_buffer("weight", torch.tensor(class_weights).float().to(dev))
+        else:
+            self.criterion.weight = None
+        self.train_metrics = RunningConfusionMatrix(num_classes, ignore_index)
+        self.val_metrics = RunningConfusionMatrix(num_classes, ignore_index)
+        self.test_metrics = RunningConfusionMatrix(num_classes, ignore_index)
+        self.logged: Dict[str, Any] = {}
+        self._loss_sums: Dict[str, torch.Tensor] = {}
+        self._optimizer: Optional[FusedAdamW] = None
+        self.grad_sync: Optional[Callable[[], None]] = None  # set by the data-parallel wrapper
+
+    # ---- reference API -------------------------------------------------------------------------
+    @property
+    def num_classes(self) -> int:
+        return self._num_classes
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.net(x)
+
+    def log(self, name: str, value: Any, **kw: Any) -> None:  # Lightning's self.log when available
+        if pl is not None and getattr(self, "_trainer", None) is not None:  # pragma: no cover
+            return super().log(name, value, **kw)
+        self.logged[name] = value
+
+    def clip_weights(self) -> None:
+        """base.py:103-113 -- in the fused path the clamp runs inside the AdamW kernel instead."""
+        if self.weight_clip_range is not None:
+            lo, hi = self.weight_clip_range
+            with torch.no_grad():
+                self.net.store.flat.clamp_(lo, hi)
+                self.net.params_changed()
+
+    def configure_optimizers(self):
+        opt = FusedAdamW(self.net, lr=self.learning_rate, weight_decay=self.weight_decay, clip_range=None)
+        self._optimizer = opt
+        if self.scheduler:
+            sch = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(opt, T_0=10, T_mult=2, eta_min=0)
+            return [opt], [sch]
+        return [opt], []
+
+    def _weights(self) -> Optional[torch.Tensor]:
+        return getattr(self.criterion, "weight", None)
+
+    def _shared_step(self, batch: Any, step_type: str) -> torch.Tensor:
+        """forward, loss, argmax, confusion-matrix update (segmentation.py:107-168) without host copies."""
+        inputs, labels = batch
+        outputs = self.forward(inputs)
+        metrics: RunningConfusionMatrix = getattr(self, f"{step_type}_metrics")
+        loss = segmentation_loss(outputs, labels, self._weights(), self.ignore_index, confusion=metrics.device_matrix(outputs.device))
+        self._accumulate_loss(step_type, loss.detach())
+        return loss
+
+    def _accumulate_loss(self, step_type: str, loss: torch.Tensor) -> None:
+        acc = self._loss_sums.get(step_type)
+        if acc is None:
+            acc = torch.zeros(2, dtype=torch.float64, device=loss.device)
+            self._loss_sums[step_type] = acc
+        acc[0] += loss.double()
+        acc[1] += 1
+
+    def training_step(self, batch: Any, batch_idx: int = 0) -> torch.Tensor:
+        loss = self._shared_step(batch, "train")
+        if self._optimizer is not None:
+            self.log("learning_rate", self._optimizer.param_groups[0]["lr"])
+        self.clip_weights()
+        return loss
+
+    def validation_step(self, batch: Any, batch_idx: int = 0) -> torch.Tensor:
+        with torch.no_grad():
+            return self._shared_step(batch, "val")
+
+    def test_step(self, batch: Any, batch_idx: int = 0) -> torch.Tensor:
+        with torch.no_grad():
+            return self._shared_step(batch, "test")
+
+    def predict_step(self, batch: Any) -> torch.Tensor:
+        """softmax probability of class 1 (segmentation.py:202-213)."""
+        with torch.no_grad():
+            prediction = self.forward(batch)
+            return torch.softmax(prediction, dim=1)[:, 1, :, :]
+
+    def _shared_epoch_end(self, step_type: str) -> None:
+        metrics = getattr(self, f"{step_type}_metrics")
+        m = metrics.compute()
+        acc = self._loss_sums.pop(step_type, None)
+        if acc is not None:
+            self.log(f"{step_type}_loss", (acc[0] / acc[1]).item())
+        self.log(f"{step_type}_Acc", m["accuracy"])
+        self.log(f"{step_type}_IoU", m["jaccard"])
+        self.log(f"{step_type}_F1", m["f1"])
+        self.log(f"{step_type}_Precision", m["precision"])
+        self.log(f"{step_type}_Recall", m["recall"])
+        for idx, value in enumerate(m["jaccard_per_class"]):
+            self.log(f"{step_type}_IoU_{idx}", value)
+        for idx, value in enumerate(m["f1_per_class"]):
+            self.log(f"{step_type}_F1_{idx}", value)
+        metrics.reset()
+
+    def on_train_epoch_end(self) -> None:
+        self._shared_epoch_end("train")
+
+    def on_validation_epoch_end(self) -> None:
+        self._shared_epoch_end("val")
+
+    def on_test_epoch_end(self) -> None:
+        self._shared_epoch_end("test")
+
+    # ---- fused path ----------------------------------------------------------------------------
+    def optimizer(self) -> FusedAdamW:
+        if self._optimizer is None:
+            self._optimizer = FusedAdamW(self.net, lr=self.learning_rate, weight_decay=self.weight_decay, clip_range=self.weight_clip_range)
+        return self._optimizer
+
+    def fused_train_step(self, inputs: torch.Tensor, labels: torch.Tensor, stats: Optional[torch.Tensor] = None,
+                         grad_scale_world: int = 1) -> torch.Tensor:
+        """One full training step (forward, loss+metrics, backward, all-reduce hook, AdamW) with no host sync.
+
+        Returns the device double[2] = (sum of weighted nll, #valid pixels) of this batch; loss = [0]/[1].
+        """
+        net, eng = self.net, self.net.engine
+        opt = self.optimizer()
+        if not net.training:
+            net.train()
+        if labels.dtype not in (torch.int64, torch.int32, torch.float32):
+            labels = labels.long()
+        logits = eng.forward(inputs, training=True, save=True)
+        if stats is None:
+            stats = torch.zeros(2, dtype=torch.float64, device=logits.device)
+        else:
+            stats.zero_()
+        ws = eng._last["ws"]
+        dlog = ws.get("dlogits")
+        if dlog is None or dlog.shape != logits.shape:
+            dlog = torch.empty_like(logits)
+            ws["dlogits"] = dlog
+        ops.ce_loss(logits, labels.contiguous(), self._weights(), self.ignore_index, stats, dlog, None, None,
+                    self.train_metrics.device_matrix(logits.device))
+        g = net.store.ensure_grad()
+        g[opt.lo : opt.hi].zero_()
+        eng.backward(dlog, count=stats)
+        if self.grad_sync is not None:
+            self.grad_sync()
+        opt.step(grads_in_flat=True)
+        acc = self._loss_sums.get("train")
+        if acc is None:
+            acc = torch.zeros(2, dtype=torch.float64, device=logits.device)
+            self._loss_sums["train"] = acc
+        acc[0] += stats[0] / stats[1]
+        acc[1] += 1
+        return stats
+
+    @torch.no_grad()
+    def fused_eval_step(self, inputs: torch.Tensor, labels: torch.Tensor, step_type: str = "val") -> torch.Tensor:
+        net, eng = self.net, self.net.engine
+        if net.training:
+            net.eval()
+        logits = eng.forward(inputs, training=False, save=False)
+        stats = torch.zeros(2, dtype=torch.float64, device=logits.device)
+        if labels.dtype not in (torch.int64, torch.int32, torch.float32):
+            labels = labels.long()
+        metrics: RunningConfusionMatrix = getattr(self, f"{step_type}_metrics")
+        ops.ce_loss(logits, labels.contiguous(), self._weights(), self.ignore_index, stats, None, None, None,
+                    metrics.device_matrix(logits.device))
+        self._accumulate_loss(step_type, (stats[0] / stats[1]).float())
+        return stats
+
+    # ---- checkpoints (pipeline_utils.py:347-355, factory.py:113-115) ----------------------------
+    def checkpoint_state_dict(self) -> Dict[str, torch.Tensor]:
+        """``{"net.<...>": tensor, "criterion.weight": tensor}`` -- the reference's Lightning key layout."""
+        sd = {"net." + k: v.detach().clone().contiguous().cpu() for k, v in self.net.state_dict().items()}
+        if self._weights() is not None:
+            sd["criterion.weight"] = self._weights().detach().cpu()
+        return sd
+
+    def load_checkpoint_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> None:
+        net_sd = {k[len("net.") :]: v for k, v in sd.items() if k.startswith("net.")}
+        self.net.load_state_dict(net_sd, strict=strict)
+        if "criterion.weight" in sd and self._weights() is not None:
+            self.criterion.weight.copy_(sd["criterion.weight"])

@@ -1,0 +1,277 @@
+"""End-to-end parity of the HIP path (-m gpu) against the CPU oracle and the committed golden fixtures.
+
+Tolerances (stated per north_star):
+* precision "bf16x3" (split-bf16 MFMA): logits within 1e-3 abs of the fp32 reference -- the north-star bar.
+* precision "bf16" (the fast/bench mode): bf16 has 8 mantissa bits; through 12+ residual blocks a 1e-3 abs
+  bound on O(1) logits is not attainable (a CPU emulation of the same roundings gives ~3e-2 max).  Its
+  deviation is *measured* here and bounded by max-abs <= 8e-2, mean-abs <= 1e-2, argmax agreement >= 99 %.
+* gradients: the fp32 reference's own autograd noise on these cases is ~3e-3 relative (fixture key
+  grad_fp32_noise__*), so bf16x3 gradients are held to 1e-2 relative L2 against the fp64 fixture.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from instageo_amd import ops  # noqa: E402
+from instageo_amd.model import PrithviSeg  # noqa: E402
+from instageo_amd.segmentation import FusedAdamW, PrithviSegmentationModule, segmentation_loss  # noqa: E402
+from oracle import prithvi_oracle as O  # noqa: E402
+from oracle.cases import CASES, GRAD_KEYS, case_config, class_weights_for, make_inputs, sub  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda"
+
+
+def build(name, precision, freeze=False):
+    variant, T, ncls, B, depth = CASES[name]
+    cfg = case_config(name)
+    sd = O.make_state_dict(cfg, seed=1042)
+    net = PrithviSeg(temporal_step=T, image_size=224, num_classes=ncls, load_pretrained_weights=False, freeze_backbone=freeze,
+                     variant=variant, depth=depth, precision=precision, device=DEV)
+    net.load_state_dict(sd, strict=True)
+    img, lab = make_inputs(name, cfg, B)
+    return cfg, sd, net, img, lab
+
+
+def report(tag, got, ref):
+    d = (got.double().cpu() - ref.double()).abs()
+    print(f"[{tag}] max {d.max().item():.3e} mean {d.mean().item():.3e} (ref absmax {ref.abs().max().item():.3f})")
+    return d.max().item(), d.mean().item()
+
+
+@pytest.mark.parametrize("name", ["tiny_t1_c2", "tiny_t3_c13", "v1_100_t1_c2", "v1_100_t3_c13"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_eval_logits_parity(name, precision):
+    cfg, sd, net, img, lab = build(name, precision)
+    net.eval()
+    with torch.no_grad():
+        logits = net(img.to(DEV))
+        ref = O.prithvi_seg_forward(cfg, sd, img, training=False)
+    mx, mean = report(f"{name}/{precision} eval logits", logits, ref)
+    gold = np.load(os.path.join(GOLD, f"{name}.npz"))
+    gmx = np.abs(sub(logits) - gold["eval_logits_sub"]).max()
+    agree = (logits.argmax(1).cpu() == ref.argmax(1)).float().mean().item()
+    print(f"   vs golden fixture {gmx:.3e}; argmax agreement {agree:.5f}")
+    if precision == "bf16x3":
+        assert mx <= 1e-3, f"bf16x3 logits differ from the fp32 reference by {mx}"
+        assert gmx <= 1e-3
+        assert agree >= 0.9995
+    else:
+        assert mx <= 8e-2 and mean <= 1e-2 and agree >= 0.99
+
+
+@pytest.mark.parametrize("name", ["tiny_t1_c2", "tiny_t3_c13"])
+def test_stage_activations_bf16x3(name):
+    """Per-stage check (features image layout c = d*T+t, head stages) against the golden sub-samples."""
+    cfg, sd, net, img, lab = build(name, "bf16x3")
+    net.eval()
+    gold = np.load(os.path.join(GOLD, f"{name}.npz"))
+    with torch.no_grad():
+        logits, feats = net(img.to(DEV), return_features=True)
+    assert feats.shape == (img.shape[0], cfg.embed_dim * cfg.num_frames, 14, 14)
+    assert np.abs(sub(feats) - gold["features_sub"]).max() <= 1e-3
+    ws = net.engine._last["ws"]
+    head0 = ws["f"][1].float().permute(0, 3, 1, 2).contiguous()
+    head3 = ws["f"][4].float().permute(0, 3, 1, 2).contiguous()
+    assert np.abs(sub(head0) - gold["stage_head0_sub"]).max() <= 1e-3
+    assert np.abs(sub(head3) - gold["stage_head3_sub"]).max() <= 1e-3
+    x_enc = ws["x_in"][1].view(img.shape[0], cfg.tokens, cfg.embed_dim)
+    assert np.abs(sub(x_enc) - gold["stage_block0_sub"]).max() <= 1e-3
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu().reshape(-1), b.double().reshape(-1)
+    return ((a - b).norm() / (b.norm() + 1e-300)).item()
+
+
+@pytest.mark.parametrize("name", ["tiny_t1_c2", "tiny_t3_c13"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_train_step_gradients(name, precision):
+    """forward(train-mode BN, dropout p=0) + loss + backward: loss, logits and gradients vs the fp64 fixture."""
+    cfg, sd, net, img, lab = build(name, precision)
+    net.cfg.drop_p = 0.0
+    net.train()
+    gold = np.load(os.path.join(GOLD, f"{name}.npz"))
+    cw = class_weights_for(cfg.num_classes).to(DEV)
+    eng = net.engine
+    rm_before = {k: v.clone() for k, v in net.state_dict().items() if "running_" in k}
+    logits = eng.forward(img.to(DEV), training=True, save=True)
+    stats = torch.zeros(2, dtype=torch.float64, device=DEV)
+    dlog = torch.empty_like(logits)
+    conf = torch.zeros(cfg.num_classes, cfg.num_classes, dtype=torch.int64, device=DEV)
+    ops.ce_loss(logits, lab.to(DEV), cw, -1, stats, dlog, None, None, conf)
+    net.store.ensure_grad().zero_()
+    eng.backward(dlog, count=stats)
+    loss = (stats[0] / stats[1]).item()
+    lerr = np.abs(sub(logits) - gold["train_logits_sub"]).max()
+    print(f"[{name}/{precision}] train logits err {lerr:.3e}; loss {loss:.6f} vs {float(gold['train_loss']):.6f}")
+    worst = 0.0
+    for k in GRAD_KEYS:
+        g = net.store.entries[k].api_view(net.store.grad)
+        got = sub(g.contiguous(), 1024)
+        ref = gold["grad_sub__" + k]
+        err = np.linalg.norm(got.astype(np.float64) - ref) / (np.linalg.norm(ref) + 1e-300)
+        nrm = g.double().norm().item() / float(gold["grad_norm__" + k])
+        worst = max(worst, err)
+        print(f"   grad {k:48s} rel-L2 {err:.3e}  norm ratio {nrm:.5f}  (fp32 ref noise {float(gold['grad_fp32_noise__' + k]):.1e})")
+        tol = 1e-2 if precision == "bf16x3" else 0.25
+        assert err <= tol, f"{k}: rel L2 {err}"
+    # mIoU / confusion (metrics.py semantics) from the device histogram
+    from instageo_amd.metrics import metrics_from_matrix
+
+    m = metrics_from_matrix(conf.cpu().numpy())
+    print(f"   mIoU {m['jaccard']:.6f} vs {float(gold['miou']):.6f}; acc {m['accuracy']:.6f} vs {float(gold['acc']):.6f}")
+    if precision == "bf16x3":
+        assert lerr <= 1e-3 and abs(loss - float(gold["train_loss"])) <= 1e-3
+        assert abs(m["jaccard"] - float(gold["miou"])) <= 1e-3 and abs(m["accuracy"] - float(gold["acc"])) <= 1e-3
+        assert int(conf.sum().item()) == int(gold["confusion"].sum())
+    else:
+        assert lerr <= 8e-2 and abs(loss - float(gold["train_loss"])) <= 2e-2
+    # BatchNorm running statistics (momentum 0.1, unbiased variance) vs the oracle
+    upd = {}
+    with torch.no_grad():
+        O.prithvi_seg_forward(cfg, sd, img, training=True, bn_momentum_update=upd)
+    new_sd = net.state_dict()
+    for k, v in upd.items():
+        assert (new_sd["" + k].cpu() - v).abs().max().item() <= (1e-3 if precision == "bf16x3" else 5e-2), k
+        assert not torch.equal(new_sd[k].cpu(), rm_before[k].cpu())
+    assert int(new_sd["segmentation_head.0.3.num_batches_tracked"].item()) == 1
+
+
+def test_autograd_path_matches_fused():
+    """`loss.backward()` through PrithviSeg.forward (compatible path) gives the same grads as the engine."""
+    name = "tiny_t1_c2"
+    cfg, sd, net, img, lab = build(name, "bf16x3")
+    net.cfg.drop_p = 0.0
+    net.train()
+    cw = class_weights_for(cfg.num_classes).to(DEV)
+    logits = net(img.to(DEV))
+    assert logits.requires_grad
+    loss = segmentation_loss(logits, lab.to(DEV), cw, -1)
+    loss.backward()
+    gold = np.load(os.path.join(GOLD, f"{name}.npz"))
+    assert abs(loss.item() - float(gold["train_loss"])) <= 1e-3
+    named = dict(net.named_parameters())
+    for k in GRAD_KEYS:
+        got = sub(named[k].grad.contiguous(), 1024)
+        ref = gold["grad_sub__" + k]
+        err = np.linalg.norm(got.astype(np.float64) - ref) / (np.linalg.norm(ref) + 1e-300)
+        assert err <= 1e-2, (k, err)
+
+
+def test_frozen_backbone_and_state_dict_roundtrip(tmp_path):
+    name = "tiny_t1_c2"
+    cfg, sd, net, img, lab = build(name, "bf16", freeze=True)
+    assert all(not p.requires_grad for p in net.prithvi_encoder.parameters())
+    assert all(p.requires_grad for p in net.segmentation_head.parameters())
+    mod_sd = net.state_dict()
+    assert list(mod_sd.keys()) == list(O.state_dict_shapes(cfg).keys())
+    for k, v in sd.items():
+        assert torch.equal(mod_sd[k].cpu(), v), k
+    torch.save({"state_dict": {k: v.cpu().contiguous() for k, v in mod_sd.items()}}, tmp_path / "c.ckpt")
+    net2 = PrithviSeg(temporal_step=1, num_classes=2, load_pretrained_weights=False, freeze_backbone=True, variant="prithvi_eo_tiny", device=DEV)
+    net2.load_state_dict(torch.load(tmp_path / "c.ckpt")["state_dict"], strict=True)
+    net.eval(), net2.eval()
+    with torch.no_grad():
+        assert torch.equal(net(img.to(DEV)), net2(img.to(DEV)))
+    # frozen backbone: a fused step must leave encoder weights untouched and move head weights
+    mod = PrithviSegmentationModule(freeze_backbone=True, load_pretrained_weights=False, num_classes=2, model_name="prithvi_eo_tiny",
+                                    class_weights=[1, 3], ignore_index=-1, device=DEV)
+    mod.net.load_state_dict(sd)
+    before = mod.net.store.flat.clone()
+    mod.fused_train_step(img.to(DEV), lab.to(DEV))
+    after = mod.net.store.flat
+    ee = mod.net.store.encoder_end
+    assert torch.equal(before[:ee], after[:ee]) and not torch.equal(before[ee:], after[ee:])
+
+
+def test_three_fused_steps_track_reference_training():
+    """3 x (forward, CE, backward, AdamW) vs the fp32 CPU restatement with torch.optim.AdamW (dropout p=0)."""
+    name = "tiny_t1_c2"
+    cfg = case_config(name)
+    sd = O.make_state_dict(cfg, seed=1042)
+    img, lab = make_inputs(name, cfg, 2)
+    mod = PrithviSegmentationModule(freeze_backbone=False, load_pretrained_weights=False, num_classes=2, model_name="prithvi_eo_tiny",
+                                    class_weights=[1, 3], ignore_index=-1, learning_rate=1e-3, precision="bf16x3", device=DEV)
+    mod.net.load_state_dict(sd)
+    mod.net.cfg.drop_p = 0.0
+    # reference loop
+    names = [k for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k and not k.endswith("pos_embed")]
+    ref_p = {k: sd[k].clone().requires_grad_(True) for k in names}
+    opt = torch.optim.AdamW(list(ref_p.values()), lr=1e-3, weight_decay=1e-2)
+    cw = torch.tensor([1.0, 3.0])
+    full = dict(sd)
+    ref_losses, losses = [], []
+    for _ in range(3):
+        full.update(ref_p)
+        upd = {}
+        out = O.prithvi_seg_forward(cfg, full, img, training=True, bn_momentum_update=upd)
+        loss = O.seg_loss(out, lab, cw, -1)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        full.update(upd)
+        ref_losses.append(loss.item())
+        st = mod.fused_train_step(img.to(DEV), lab.to(DEV))
+        losses.append((st[0] / st[1]).item())
+    print("losses", losses, "reference", ref_losses)
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) <= 5e-3
+    assert losses[-1] < losses[0]
+    new = mod.net.state_dict()
+    # first AdamW steps move every weight by ~lr regardless of gradient scale: compare the *updates*
+    for k in ["segmentation_head.5.weight", "segmentation_head.3.2.weight", "prithvi_encoder.blocks.0.attn.qkv.weight"]:
+        d_ref = ref_p[k].detach() - sd[k]
+        d_got = new[k].cpu() - sd[k]
+        cos = torch.nn.functional.cosine_similarity(d_ref.reshape(1, -1), d_got.reshape(1, -1)).item()
+        print(f"   update cosine {k}: {cos:.5f}")
+        assert cos >= 0.98, (k, cos)
+
+
+def test_module_api_and_metrics_names():
+    name = "tiny_t1_c2"
+    cfg = case_config(name)
+    img, lab = make_inputs(name, cfg, 2)
+    mod = PrithviSegmentationModule(freeze_backbone=False, load_pretrained_weights=False, num_classes=2, model_name="prithvi_eo_tiny",
+                                    class_weights=[1, 3], ignore_index=-1, device=DEV)
+    (opt,), scheds = mod.configure_optimizers()
+    assert isinstance(opt, FusedAdamW) and isinstance(scheds[0], torch.optim.lr_scheduler.CosineAnnealingWarmRestarts)
+    batch = (img.to(DEV), lab.to(DEV).float())  # reference labels are float tensors
+    loss = mod.training_step(batch, 0)
+    assert loss.requires_grad and torch.isfinite(loss)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    vloss = mod.validation_step(batch, 0)
+    tloss = mod.test_step(batch, 0)
+    assert not vloss.requires_grad and not tloss.requires_grad
+    probs = mod.predict_step(batch[0])
+    assert probs.shape == (2, 224, 224) and probs.min() >= 0 and probs.max() <= 1
+    mod.on_train_epoch_end(), mod.on_validation_epoch_end(), mod.on_test_epoch_end()
+    for st in ("train", "val", "test"):
+        for m in ("loss", "Acc", "IoU", "F1", "Precision", "Recall", "IoU_0", "IoU_1", "F1_0", "F1_1"):
+            assert f"{st}_{m}" in mod.logged, f"{st}_{m}"
+    assert mod.train_metrics.total == 0  # reset at epoch end
+    ck = mod.checkpoint_state_dict()
+    assert "criterion.weight" in ck and "net.prithvi_encoder.cls_token" in ck and "net.segmentation_head.5.bias" in ck
+
+
+def test_input_validation():
+    net = PrithviSeg(temporal_step=1, num_classes=2, load_pretrained_weights=False, freeze_backbone=True, variant="prithvi_eo_tiny", device=DEV)
+    net.eval()
+    with torch.no_grad():
+        a = net(torch.zeros(1, 6, 224, 224, device=DEV))  # 4-D input accepted when T == 1 (pritvhi.py:507-509)
+        assert a.shape == (1, 2, 224, 224)
+        assert net(torch.zeros(0, 6, 1, 224, 224, device=DEV)).shape == (0, 2, 224, 224)  # empty batch
+        with pytest.raises(ValueError):
+            net(torch.zeros(1, 5, 1, 224, 224, device=DEV))
+        with pytest.raises(Exception):
+            net(torch.zeros(1, 6, 1, 224, 224))  # CPU tensor: no CPU fallback
+    with pytest.raises(NotImplementedError):
+        PrithviSeg(variant="prithvi_eo_v2_600", load_pretrained_weights=False, device=DEV)
+    with pytest.raises(RuntimeError):
+        PrithviSeg(variant="prithvi_eo_tiny", load_pretrained_weights=True, device=DEV)
