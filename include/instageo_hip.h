@@ -11,6 +11,8 @@
  * plain bf16; non-NULL selects the split "bf16x3" precision mode (value = hi + lo, products hi*hi+hi*lo+lo*hi).
  * Either all bf16 operands of a call are split or none.  Activations in the decode head are NHWC.
  * Conv weights (3x3 and transposed) are stored Wc[Cout][9][Cin], tap = ky*3+kx.
+ * Dropout is a counter-based hash of (drop_seed + *drop_seed_dev, element index): backward regenerates the mask;
+ * drop_seed_dev (device uint32, may be NULL) lets a captured graph advance the seed without new host arguments.
  */
 #ifndef INSTAGEO_HIP_H
 #define INSTAGEO_HIP_H
@@ -74,7 +76,8 @@ int ig_merge_bf16(const void* hi, const void* lo, float* dst, long n, void* stre
 /* ---- decode head (instageo/model/model.py:349-390) --------------------------------------------------- */
 /* nn.ConvTranspose2d(k=3,s=2,p=1,op=1) + nn.Dropout(p): x (B,H,W,Cin) -> y (B,2H,2W,Cout)             :361-369 */
 int ig_convT_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias, void* y_hi,
-                 void* y_lo, int B, int H, int W, int Cin, int Cout, unsigned drop_seed, float drop_p, void* stream);
+                 void* y_lo, int B, int H, int W, int Cin, int Cout, unsigned drop_seed, const unsigned* drop_seed_dev, float drop_p,
+                 void* stream);
 int ig_convT_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, const void* w_lo, void* dx_hi, void* dx_lo, int B,
                    int H, int W, int Cin, int Cout, void* stream);
 int ig_convT_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const void* x_lo, float* dw, int B, int H, int W,
@@ -83,7 +86,7 @@ int ig_convT_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const
 int ig_conv3x3_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias, void* y_hi,
                    void* y_lo, int B, int H, int W, int Cin, int Cout, void* stream);
 int ig_conv3x3_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, const void* w_lo, void* dx_hi, void* dx_lo, int B,
-                     int H, int W, int Cin, int Cout, unsigned drop_seed, float drop_p, void* stream);
+                     int H, int W, int Cin, int Cout, unsigned drop_seed, const unsigned* drop_seed_dev, float drop_p, void* stream);
 int ig_conv3x3_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const void* x_lo, float* dw, int B, int H, int W,
                      int Cin, int Cout, void* stream);
 /* nn.BatchNorm2d + nn.ReLU on [M][C] (M = B*H*W)                                                      :376-377 */
@@ -95,10 +98,10 @@ int ig_bn_relu_bwd(const void* x_hi, const void* x_lo, const void* dy_hi, const 
                    float* dbeta, double* sums, long M, int C, void* stream);
 /* nn.Dropout(p) + nn.Conv2d(k=1): f (B,HW,C) -> logits (B,ncls,HW) f32                                 :388-389 */
 int ig_classifier_fwd(const void* f_hi, const void* f_lo, const float* w, const float* bias, float* logits, int B, long HW, int C,
-                      int ncls, unsigned drop_seed, float drop_p, void* stream);
+                      int ncls, unsigned drop_seed, const unsigned* drop_seed_dev, float drop_p, void* stream);
 int ig_classifier_bwd(const float* dlogits, const void* f_hi, const void* f_lo, const float* w, void* df_hi, void* df_lo,
                       float* dw, float* db, const double* count, int B, long HW, int C, int ncls, unsigned drop_seed,
-                      float drop_p, void* stream);
+                      const unsigned* drop_seed_dev, float drop_p, void* stream);
 
 /* ---- task module (instageo/model/segmentation.py, metrics.py, infer_utils.py, base.py) --------------- */
 /* CE(weight, ignore_index,'none') + masked mean pieces, argmax, int64 confusion matrix   segmentation.py:85-87,117-151 */

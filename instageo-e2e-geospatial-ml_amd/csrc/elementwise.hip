@@ -291,7 +291,17 @@ __global__ __launch_bounds__(TPB) void colsum_kernel(const bf16_t* __restrict__ 
     if (sl < nslice) {
         for (int ub = u; ub < units; ub += tu) {
             float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (long r = r0 + sl; r < r1; r += nslice) {
+            long r = r0 + sl;
+            for (; r + 3L * nslice < r1; r += 4L * nslice) {  // 4 independent loads in flight
+                float f0[8], f1[8], f2[8], f3[8];
+                load8_split(hi, lo, (size_t)r * C + ub * 8, f0);
+                load8_split(hi, lo, (size_t)(r + nslice) * C + ub * 8, f1);
+                load8_split(hi, lo, (size_t)(r + 2L * nslice) * C + ub * 8, f2);
+                load8_split(hi, lo, (size_t)(r + 3L * nslice) * C + ub * 8, f3);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += (f0[j] + f1[j]) + (f2[j] + f3[j]);
+            }
+            for (; r < r1; r += nslice) {
                 float f[8];
                 load8_split(hi, lo, (size_t)r * C + ub * 8, f);
 #pragma unroll
@@ -622,7 +632,7 @@ int ig_colsum(const void* hi, const void* lo, float* out, long M, int C, void* s
     IG_REQUIRE(hi && out, "ig_colsum: null pointer");
     IG_REQUIRE(C % 8 == 0, "ig_colsum: C must be a multiple of 8 (got %d)", C);
     if (M == 0) return IG_OK;
-    const int rpb = M > 65536 ? 1024 : 128;
+    const int rpb = M > 65536 ? 512 : 32;
     hipLaunchKernelGGL(colsum_kernel, dim3(ig_cdiv(M, rpb)), dim3(TPB), (size_t)C * sizeof(float), ST(stream), (const bf16_t*)hi, (const bf16_t*)lo, out, M,
                        C, rpb);
     return ig_check_launch("ig_colsum");

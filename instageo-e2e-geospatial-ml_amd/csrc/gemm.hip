@@ -60,7 +60,14 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int bm = blockIdx.x / tiles_n, bn = blockIdx.x - bm * tiles_n;
+    // XCD-aware tile order: hardware deals consecutive workgroups round-robin over the 8 XCDs (private L2s);
+    // remap so that each XCD owns a CONTIGUOUS run of tiles (neighbours share the A row panel / B panels).
+    int bid = blockIdx.x;
+    {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bm = bid / tiles_n, bn = bid - bm * tiles_n;
     al.init(blockIdx.z);
     bl.init(blockIdx.z);
     ep.init(blockIdx.z);
@@ -79,47 +86,49 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     uint4 ra[4], rb[4];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
 
-    auto gload = [&](int it) {
-        int seg = (NSEG == 1) ? 0 : it / nk;
-        int kt = kt0 + it - seg * nk;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int u = tid + i * NTHR;
-            const bf16_t* p;
-            if constexpr (!A_TR) p = al.ptr(seg, bm * BM + (u >> 3), kt * 8 + (u & 7));
-            else p = al.ptr(seg, kt * BK + (u >> 4), bm * 16 + (u & 15));
-            ra[i] = p ? *reinterpret_cast<const uint4*>(p) : zero4;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int u = tid + i * NTHR;
-            const bf16_t* p;
-            if constexpr (!B_TR) p = bl.ptr(seg, bn * BN + (u >> 3), kt * 8 + (u & 7));
-            else p = bl.ptr(seg, kt * BK + (u >> 4), bn * 16 + (u & 15));
-            rb[i] = p ? *reinterpret_cast<const uint4*>(p) : zero4;
-        }
-    };
-    auto lstore = [&](int buf) {
-        char* ta = smem + buf * 2 * TILE_BYTES;
-        char* tb = ta + TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int u = tid + i * NTHR;
-            int oa = A_TR ? lds_tr(u >> 4, u & 15) : lds_kc(u >> 3, u & 7);
-            int ob = B_TR ? lds_tr(u >> 4, u & 15) : lds_kc(u >> 3, u & 7);
-            *reinterpret_cast<uint4*>(ta + oa) = ra[i];
-            *reinterpret_cast<uint4*>(tb + ob) = rb[i];
-        }
-    };
+    // Loads are UNCONDITIONAL (invalid units read a dummy valid address and are zeroed by a select): a
+    // branch around each load makes hipcc wait vmcnt(0) per load and serialises the whole tile fetch.
+#define GEMM_GLOAD(IT)                                                                                   \
+    {                                                                                                     \
+        const int seg_ = (NSEG == 1) ? 0 : (IT) / nk;                                                     \
+        const int kt_ = kt0 + (IT)-seg_ * nk;                                                             \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
+            const int u = tid + i * NTHR;                                                                 \
+            bool ok;                                                                                      \
+            const bf16_t* p = A_TR ? al.ptr(seg_, kt_ * BK + (u >> 4), bm * 16 + (u & 15), ok)            \
+                                   : al.ptr(seg_, bm * BM + (u >> 3), kt_ * 8 + (u & 7), ok);             \
+            uint4 v = *reinterpret_cast<const uint4*>(p);                                                 \
+            ra[i] = ok ? v : make_uint4(0, 0, 0, 0);                                                      \
+        }                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
+            const int u = tid + i * NTHR;                                                                 \
+            bool ok;                                                                                      \
+            const bf16_t* p = B_TR ? bl.ptr(seg_, kt_ * BK + (u >> 4), bn * 16 + (u & 15), ok)            \
+                                   : bl.ptr(seg_, bn * BN + (u >> 3), kt_ * 8 + (u & 7), ok);             \
+            uint4 v = *reinterpret_cast<const uint4*>(p);                                                 \
+            rb[i] = ok ? v : make_uint4(0, 0, 0, 0);                                                      \
+        }                                                                                                 \
+    }
+#define GEMM_LSTORE(BUF)                                                                                 \
+    {                                                                                                     \
+        char* ta_ = smem + (BUF)*2 * TILE_BYTES;                                                          \
+        char* tb_ = ta_ + TILE_BYTES;                                                                     \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
+            const int u = tid + i * NTHR;                                                                 \
+            const int oa = A_TR ? lds_tr(u >> 4, u & 15) : lds_kc(u >> 3, u & 7);                         \
+            const int ob = B_TR ? lds_tr(u >> 4, u & 15) : lds_kc(u >> 3, u & 7);                         \
+            *reinterpret_cast<uint4*>(ta_ + oa) = ra[i];                                                  \
+            *reinterpret_cast<uint4*>(tb_ + ob) = rb[i];                                                  \
+        }                                                                                                 \
+    }
 
-    gload(0);
-    lstore(0);
+    GEMM_GLOAD(0);
+    GEMM_LSTORE(0);
     __syncthreads();
     for (int it = 0; it < total; ++it) {
         const int cur = it & 1;
-        if (it + 1 < total) gload(it + 1);
+        if (it + 1 < total) GEMM_GLOAD(it + 1);
         const char* ta = smem + cur * 2 * TILE_BYTES;
         const char* tb = ta + TILE_BYTES;
 #pragma unroll
@@ -135,10 +144,38 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
                 for (int tm = 0; tm < 4; ++tm)
                     acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[tn], af[tm], acc[tn][tm], 0, 0, 0);
         }
-        if (it + 1 < total) lstore(cur ^ 1);
+        if (it + 1 < total) GEMM_LSTORE(cur ^ 1);
         __syncthreads();
     }
+#undef GEMM_GLOAD
+#undef GEMM_LSTORE
 
+    if constexpr (EP::kStagedAtomic) {
+        // wgrad: stage the fp32 tile in LDS (16-byte slots XOR-swizzled by row) and issue the global atomics
+        // row-contiguously: every wave-instruction adds 256 contiguous bytes (the full-rate atomic shape).
+        float* st = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+            const int ml = wm * 64 + tm * 16 + (lane & 15);
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) {
+                const int c4 = (wn * 64 + tn * 16 + 4 * (lane >> 4)) >> 2;
+                *reinterpret_cast<f32x4*>(st + ml * 128 + ((c4 ^ (ml & 7)) << 2)) = acc[tn][tm];
+            }
+        }
+        __syncthreads();
+        for (int rr = wave; rr < BM; rr += NTHR / 64) {
+            const int m = bm * BM + rr;
+            if (m >= M) break;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int nl = half * 64 + lane;
+                const int n = bn * BN + nl;
+                if (n < N) ep.add(m, n, st[rr * 128 + ((((nl >> 2) ^ (rr & 7)) << 2) | (nl & 3))]);
+            }
+        }
+        return;
+    }
     // epilogue: lane owns C[m][n..n+3]
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm) {
@@ -159,9 +196,10 @@ struct PlainLoader {  // row-major [R][ld], logical width C (multiple of 8)
     long ld;
     __device__ void init(int) {}
     __device__ int kdim() const { return -1; }
-    __device__ const bf16_t* ptr(int seg, int r, int c8) const {
+    __device__ const bf16_t* ptr(int seg, int r, int c8, bool& ok) const {
         int c = c8 * 8;
-        return (r < R && c < C) ? base[seg] + (long)r * ld + c : nullptr;
+        ok = (r < R) & (c < C);
+        return base[seg] + (ok ? (long)r * ld + c : 0L);
     }
 };
 
@@ -172,17 +210,16 @@ struct Conv3Loader {
     int Mtot, H, W, C, sign;
     __device__ void init(int) {}
     __device__ int kdim() const { return -1; }
-    __device__ const bf16_t* ptr(int seg, int r, int c8) const {
+    __device__ const bf16_t* ptr(int seg, int r, int c8, bool& ok) const {
         int k = c8 * 8;
-        if (r >= Mtot || k >= 9 * C) return nullptr;
         int tap = k / C, c = k - tap * C;
         int ky = tap / 3, kx = tap - ky * 3;
         int hw = H * W;
         int b = r / hw, rem = r - b * hw;
         int y = rem / W, x = rem - y * W;
         int sy = y + sign * (ky - 1), sx = x + sign * (kx - 1);
-        if ((unsigned)sy >= (unsigned)H || (unsigned)sx >= (unsigned)W) return nullptr;
-        return base[seg] + ((long)(b * H + sy) * W + sx) * C + c;
+        ok = (r < Mtot) & (k < 9 * C) & ((unsigned)sy < (unsigned)H) & ((unsigned)sx < (unsigned)W);
+        return base[seg] + (ok ? ((long)(b * H + sy) * W + sx) * C + c : 0L);
     }
 };
 
@@ -199,9 +236,8 @@ struct ConvTFwdALoader {
         K = nky * nkx * C;
     }
     __device__ int kdim() const { return K; }
-    __device__ const bf16_t* ptr(int seg, int r, int c8) const {
+    __device__ const bf16_t* ptr(int seg, int r, int c8, bool& ok) const {
         int k = c8 * 8;
-        if (r >= Mtot || k >= K) return nullptr;
         int tl = k / C, c = k - tl * C;
         int tyi = tl / nkx, txi = tl - tyi * nkx;
         int ky = ky0 + 2 * tyi, kx = kx0 + 2 * txi;
@@ -209,8 +245,8 @@ struct ConvTFwdALoader {
         int b = r / hw, rem = r - b * hw;
         int y = rem / W, x = rem - y * W;
         int sy = y + (ky == 0), sx = x + (kx == 0);
-        if (sy >= H || sx >= W) return nullptr;
-        return base[seg] + ((long)(b * H + sy) * W + sx) * C + c;
+        ok = (r < Mtot) & (k < K) & (sy < H) & (sx < W);
+        return base[seg] + (ok ? ((long)(b * H + sy) * W + sx) * C + c : 0L);
     }
 };
 // matching weight view: n = co, k = (local tap, ci) of storage Wc[co][tap][ci]
@@ -225,13 +261,13 @@ struct ConvTFwdBLoader {
         K = nky * nkx * C;
     }
     __device__ int kdim() const { return K; }
-    __device__ const bf16_t* ptr(int seg, int r, int c8) const {
+    __device__ const bf16_t* ptr(int seg, int r, int c8, bool& ok) const {
         int k = c8 * 8;
-        if (r >= Cout || k >= K) return nullptr;
         int tl = k / C, c = k - tl * C;
         int tyi = tl / nkx, txi = tl - tyi * nkx;
         int tap = (ky0 + 2 * tyi) * 3 + (kx0 + 2 * txi);
-        return base[seg] + ((long)r * 9 + tap) * C + c;
+        ok = (r < Cout) & (k < K);
+        return base[seg] + (ok ? ((long)r * 9 + tap) * C + c : 0L);
     }
 };
 
@@ -241,11 +277,11 @@ struct ConvWgtTRLoader {
     int Cout, Cin;
     __device__ void init(int) {}
     __device__ int kdim() const { return -1; }
-    __device__ const bf16_t* ptr(int seg, int r, int c8) const {
+    __device__ const bf16_t* ptr(int seg, int r, int c8, bool& ok) const {
         int c = c8 * 8;
         int tap = r / Cout, co = r - tap * Cout;
-        if (tap >= 9 || c >= Cin) return nullptr;
-        return base[seg] + ((long)co * 9 + tap) * Cin + c;
+        ok = (tap < 9) & (c < Cin);
+        return base[seg] + (ok ? ((long)co * 9 + tap) * Cin + c : 0L);
     }
 };
 
@@ -258,40 +294,38 @@ struct ConvTGradLoader {
     int tapz;
     __device__ void init(int z) { tapz = z; }
     __device__ int kdim() const { return -1; }
-    __device__ const bf16_t* ptr(int seg, int r, int c8) const {
+    __device__ const bf16_t* ptr(int seg, int r, int c8, bool& ok) const {
         int k = c8 * 8;
-        int tap, c;
-        if (fixed_tap == -1) {
-            tap = k / Cout, c = k - tap * Cout;
-            if (tap >= 9) return nullptr;
-        } else {
-            tap = tapz, c = k;
-            if (c >= Cout) return nullptr;
-        }
-        if (r >= Mtot) return nullptr;
+        int tap = (fixed_tap == -1) ? k / Cout : tapz;
+        int c = (fixed_tap == -1) ? k - tap * Cout : k;
         int ky = tap / 3, kx = tap - ky * 3;
         int hw = H * W;
         int b = r / hw, rem = r - b * hw;
         int y = rem / W, x = rem - y * W;
         int oy = 2 * y - 1 + ky, ox = 2 * x - 1 + kx;
-        if ((unsigned)oy >= (unsigned)(2 * H) || (unsigned)ox >= (unsigned)(2 * W)) return nullptr;
-        return base[seg] + ((long)(b * 2 * H + oy) * (2 * W) + ox) * Cout + c;
+        ok = (tap < 9) & (c < Cout) & (r < Mtot) & ((unsigned)oy < (unsigned)(2 * H)) & ((unsigned)ox < (unsigned)(2 * W));
+        return base[seg] + (ok ? ((long)(b * 2 * H + oy) * (2 * W) + ox) * Cout + c : 0L);
     }
 };
 
 // ---------------------------------------------------------------------------------- epilogues
 // bf16/split store: out = drop(act(acc + bias)); optional pre-activation copy; optional ConvT phase row map
 struct EpStore {
+    static constexpr bool kStagedAtomic = false;
     bf16_t *out_hi, *out_lo;
     bf16_t *pre_hi, *pre_lo;
     const float* bias;
     long ldo;
     int act;  // 0 none, 1 exact GELU
     uint32_t drop_seed, drop_thresh;
+    const uint32_t* drop_seed_dev;  // optional per-step offset read on the device (graph-replay safe)
     float drop_inv;
     int phase_map, H, W;  // phase_map=1: row (b,iy,ix) -> (b, 2iy+py, 2ix+px) of a (2H,2W) image
     int py, px;
-    __device__ void init(int z) { py = z >> 1, px = z & 1; }
+    __device__ void init(int z) {
+        py = z >> 1, px = z & 1;
+        if (drop_seed_dev) drop_seed += *drop_seed_dev;
+    }
     __device__ void store(int m, int n, f32x4 a) const {
         long row = m;
         if (phase_map) {
@@ -321,13 +355,17 @@ struct EpStore {
 
 // dgrad store with an elementwise factor: mode 1: * gelu'(pre[m][n]); mode 2: * dropout mask(idx)
 struct EpGradStore {
+    static constexpr bool kStagedAtomic = false;
     bf16_t *out_hi, *out_lo;
     const bf16_t *pre_hi, *pre_lo;
     long ldo;
     int mode;
     uint32_t drop_seed, drop_thresh;
+    const uint32_t* drop_seed_dev;
     float drop_inv;
-    __device__ void init(int) {}
+    __device__ void init(int) {
+        if (drop_seed_dev) drop_seed += *drop_seed_dev;
+    }
     __device__ void store(int m, int n, f32x4 a) const {
         size_t idx = (size_t)m * ldo + n;
         float v[4] = {a[0], a[1], a[2], a[3]};
@@ -344,6 +382,7 @@ struct EpGradStore {
 
 // fp32 residual: out[m][n] = resid[m][n] + acc + bias[n]
 struct EpResidual {
+    static constexpr bool kStagedAtomic = false;
     float* out;
     const float* resid;
     const float* bias;
@@ -360,6 +399,7 @@ struct EpResidual {
 
 // patch embed: token row m=(b, tp) -> x[b*Ntok + 1 + tp][n] = acc + bias[n] + pos[1+tp][n]   (pritvhi.py:513-517)
 struct EpPatchEmbed {
+    static constexpr bool kStagedAtomic = false;
     float* x;
     const float* bias;
     const float* pos;  // [Ntok][D]
@@ -378,11 +418,13 @@ struct EpPatchEmbed {
 
 // wgrad: fp32 atomic accumulate into the gradient buffer; column offset z*zstride (ConvT taps)
 struct EpAtomic {
+    static constexpr bool kStagedAtomic = true;
     float* out;
     long ldo;
     long zstride;
     long zoff;
     __device__ void init(int z) { zoff = (long)z * zstride; }
+    __device__ void add(int m, int n, float v) const { atomicAdd(out + (size_t)m * ldo + zoff + n, v); }
     __device__ void store(int m, int n, f32x4 a) const {
         float* p = out + (size_t)m * ldo + zoff + n;
         atomicAdd(p + 0, a[0]);
@@ -402,8 +444,8 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, i
     int ksplit = 1;
     if (allow_ksplit) {  // atomic epilogues only: aim for ~4 blocks per CU, at least 4 k-tiles per block
         int tiles = tm * tn * Z;
-        ksplit = (1024 + tiles - 1) / tiles;
-        if (ksplit > nk_all / 4) ksplit = nk_all / 4;
+        ksplit = (512 + tiles - 1) / tiles;  // ~2 workgroups per CU; every extra split is one more atomic pass
+        if (ksplit > nk_all / 8) ksplit = nk_all / 8;
         if (ksplit < 1) ksplit = 1;
     }
     int kchunk = ig_cdiv(nk_all, ksplit);
@@ -544,7 +586,8 @@ int ig_conv3x3_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const v
 
 // dx = conv_dgrad(dy, w) [* dropout mask of the conv input when drop_p > 0]
 int ig_conv3x3_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, const void* w_lo, void* dx_hi, void* dx_lo,
-                     int B, int H, int W, int Cin, int Cout, unsigned drop_seed, float drop_p, void* stream) {
+                     int B, int H, int W, int Cin, int Cout, unsigned drop_seed, const unsigned* drop_seed_dev, float drop_p,
+                     void* stream) {
     IG_REQUIRE(dy_hi && w_hi && dx_hi, "ig_conv3x3_dgrad: null pointer");
     IG_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, "ig_conv3x3_dgrad: channels must be multiples of 8");
     IG_SPLIT_CONSISTENT(dy_lo, w_lo);
@@ -556,7 +599,7 @@ int ig_conv3x3_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, con
     bl.Cout = Cout, bl.Cin = Cin;
     EpGradStore ep{};
     ep.out_hi = (bf16_t*)dx_hi, ep.out_lo = (bf16_t*)dx_lo, ep.ldo = Cin, ep.mode = 2;
-    ep.drop_seed = drop_seed;
+    ep.drop_seed = drop_seed, ep.drop_seed_dev = drop_seed_dev;
     ep.drop_thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
     ep.drop_inv = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     return launch_gemm<Conv3Loader, ConvWgtTRLoader, EpGradStore, false, true>(
@@ -582,7 +625,8 @@ int ig_conv3x3_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, con
 // ---- ConvTranspose2d(k=3,s=2,p=1,op=1), NHWC, weight storage Wc[Cout][9][Cin]  (model.py:361-368) ----
 // y (2H,2W) = drop(convT(x) + bias): four sub-pixel phase GEMMs in one launch (blockIdx.z = phase)
 int ig_convT_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias, void* y_hi,
-                 void* y_lo, int B, int H, int W, int Cin, int Cout, unsigned drop_seed, float drop_p, void* stream) {
+                 void* y_lo, int B, int H, int W, int Cin, int Cout, unsigned drop_seed, const unsigned* drop_seed_dev, float drop_p,
+                 void* stream) {
     IG_REQUIRE(x_hi && w_hi && y_hi, "ig_convT_fwd: null pointer");
     IG_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, "ig_convT_fwd: channels must be multiples of 8");
     IG_SPLIT_CONSISTENT(x_lo, w_lo);
@@ -595,7 +639,7 @@ int ig_convT_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const voi
     EpStore ep{};
     ep.out_hi = (bf16_t*)y_hi, ep.out_lo = (bf16_t*)y_lo, ep.bias = bias, ep.ldo = Cout;
     ep.phase_map = 1, ep.H = H, ep.W = W;
-    ep.drop_seed = drop_seed;
+    ep.drop_seed = drop_seed, ep.drop_seed_dev = drop_seed_dev;
     ep.drop_thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
     ep.drop_inv = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     return launch_gemm<ConvTFwdALoader, ConvTFwdBLoader, EpStore, false, false>(

@@ -15,8 +15,10 @@ constexpr int MAXC = 16;  // max classes held in registers
 __global__ __launch_bounds__(TPB) void classifier_fwd_kernel(const bf16_t* __restrict__ f_hi, const bf16_t* __restrict__ f_lo,
                                                              const float* __restrict__ w, const float* __restrict__ bias,
                                                              float* __restrict__ logits, long M, long HW, int C, int ncls,
-                                                             uint32_t drop_seed, uint32_t drop_thresh, float drop_inv) {
+                                                             uint32_t drop_seed, const uint32_t* drop_seed_dev, uint32_t drop_thresh,
+                                                             float drop_inv) {
     extern __shared__ float sw[];  // [ncls][C] + [ncls]
+    if (drop_seed_dev) drop_seed += *drop_seed_dev;
     for (int i = threadIdx.x; i < ncls * C; i += TPB) sw[i] = w[i];
     for (int i = threadIdx.x; i < ncls; i += TPB) sw[ncls * C + i] = bias[i];
     __syncthreads();
@@ -55,8 +57,9 @@ __global__ __launch_bounds__(TPB) void classifier_bwd_kernel(const float* __rest
                                                              bf16_t* __restrict__ df_hi, bf16_t* __restrict__ df_lo,
                                                              float* __restrict__ dw, float* __restrict__ db, const double* count,
                                                              long M, long HW, int C, int ncls, uint32_t drop_seed,
-                                                             uint32_t drop_thresh, float drop_inv) {
+                                                             const uint32_t* drop_seed_dev, uint32_t drop_thresh, float drop_inv) {
     extern __shared__ float sm[];  // w[ncls*C] | dwacc[ncls*C] | dbacc[ncls]
+    if (drop_seed_dev) drop_seed += *drop_seed_dev;
     float* sw = sm;
     float* sdw = sm + ncls * C;
     float* sdb = sdw + ncls * C;
@@ -218,22 +221,22 @@ inline uint32_t thresh_of(float p) { return p > 0.f ? (uint32_t)((double)p * 429
 extern "C" {
 
 int ig_classifier_fwd(const void* f_hi, const void* f_lo, const float* w, const float* bias, float* logits, int B, long HW, int C,
-                      int ncls, unsigned drop_seed, float drop_p, void* stream) {
+                      int ncls, unsigned drop_seed, const unsigned* drop_seed_dev, float drop_p, void* stream) {
     IG_REQUIRE(f_hi && w && bias && logits, "ig_classifier_fwd: null pointer");
     IG_REQUIRE(C % 8 == 0 && ncls >= 1 && ncls <= MAXC, "ig_classifier_fwd: need C %% 8 == 0 and 1 <= ncls <= %d (C=%d ncls=%d)", MAXC, C, ncls);
     long M = (long)B * HW;
     if (M == 0) return IG_OK;
     size_t sm = ((size_t)ncls * C + ncls) * sizeof(float);
     hipLaunchKernelGGL(classifier_fwd_kernel, dim3((unsigned)((M + TPB - 1) / TPB)), dim3(TPB), sm, (hipStream_t)stream,
-                       (const bf16_t*)f_hi, (const bf16_t*)f_lo, w, bias, logits, M, HW, C, ncls, drop_seed, thresh_of(drop_p),
+                       (const bf16_t*)f_hi, (const bf16_t*)f_lo, w, bias, logits, M, HW, C, ncls, drop_seed, drop_seed_dev, thresh_of(drop_p),
                        drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f);
     return ig_check_launch("ig_classifier_fwd");
 }
 
 // count: NULL, or the loss kernel's stats buffer (uses stats[1] = #valid pixels to normalise dlogits)
 int ig_classifier_bwd(const float* dlogits, const void* f_hi, const void* f_lo, const float* w, void* df_hi, void* df_lo, float* dw,
-                      float* db, const double* count, int B, long HW, int C, int ncls, unsigned drop_seed, float drop_p,
-                      void* stream) {
+                      float* db, const double* count, int B, long HW, int C, int ncls, unsigned drop_seed,
+                      const unsigned* drop_seed_dev, float drop_p, void* stream) {
     IG_REQUIRE(dlogits && f_hi && w && df_hi && dw && db, "ig_classifier_bwd: null pointer");
     IG_REQUIRE(C % 8 == 0 && ncls >= 1 && ncls <= MAXC, "ig_classifier_bwd: need C %% 8 == 0 and 1 <= ncls <= %d", MAXC);
     long M = (long)B * HW;
@@ -241,7 +244,7 @@ int ig_classifier_bwd(const float* dlogits, const void* f_hi, const void* f_lo, 
     size_t sm = (2 * (size_t)ncls * C + ncls) * sizeof(float);
     hipLaunchKernelGGL(classifier_bwd_kernel, dim3((unsigned)((M + TPB - 1) / TPB)), dim3(TPB), sm, (hipStream_t)stream, dlogits,
                        (const bf16_t*)f_hi, (const bf16_t*)f_lo, w, (bf16_t*)df_hi, (bf16_t*)df_lo, dw, db, count, M, HW, C, ncls,
-                       drop_seed, thresh_of(drop_p), drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f);
+                       drop_seed, drop_seed_dev, thresh_of(drop_p), drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f);
     return ig_check_launch("ig_classifier_bwd");
 }
 

@@ -233,6 +233,7 @@ class SegEngine:
         self._ws: Dict[Any, Dict[str, Any]] = {}
         self.shadow_dirty = True
         self.drop_seed = 1042
+        self._drop_step: Optional[torch.Tensor] = None  # device uint32 counter mixed into the dropout hash each step
         self.freeze_backbone = False
         self.on_grad_ready: Optional[Callable[[int, int], None]] = None
         self._last: Optional[Dict[str, Any]] = None
@@ -360,15 +361,24 @@ class SegEngine:
         self._last = {"ws": ws, "B": B, "training": training} if save else None
         return logits
 
+    def _drop_counter(self, advance: bool) -> Optional[torch.Tensor]:
+        dev = self.store.flat.device
+        if self._drop_step is None or self._drop_step.device != dev:
+            self._drop_step = torch.zeros(1, dtype=torch.int32, device=dev)
+        if advance:
+            self._drop_step += 5  # five dropout sites use seeds +0..+4
+        return self._drop_step
+
     def _head_forward(self, ws, B: int, training: bool, out, update_running: bool) -> torch.Tensor:
         cfg = self.cfg
         dims, g = cfg.head_dims, cfg.grid
         p = cfg.drop_p if training else 0.0
+        sd = self._drop_counter(advance=True) if p > 0 else None
         h = "segmentation_head."
         for i in range(4):
             Hs = g << i
             ops.convT_fwd(ws["f"][i], self.W(f"{h}{i}.0.weight"), self.P(f"{h}{i}.0.bias"), ws["u"][i], B, Hs, Hs, dims[i], dims[i + 1],
-                          seed=self.drop_seed + i, p=p)
+                          seed=self.drop_seed + i, p=p, seed_dev=sd)
             ops.conv3x3_fwd(ws["u"][i], self.W(f"{h}{i}.2.weight"), self.P(f"{h}{i}.2.bias"), ws["cv"][i], B, 2 * Hs, 2 * Hs, dims[i + 1],
                             dims[i + 1])
             ops.bn_relu_fwd(ws["cv"][i], self.P(f"{h}{i}.3.weight"), self.P(f"{h}{i}.3.bias"), self.buffers[f"{h}{i}.3.running_mean"],
@@ -380,7 +390,7 @@ class SegEngine:
         if out is None:
             out = torch.empty((B, cfg.num_classes, S, S), dtype=torch.float32, device=ws["f"][4].hi.device)
         ops.classifier_fwd(ws["f"][4], self.P(h + "5.weight"), self.P(h + "5.bias"), out, B, S * S, dims[4], cfg.num_classes,
-                           seed=self.drop_seed + 4, p=p)
+                           seed=self.drop_seed + 4, p=p, seed_dev=sd)
         return out
 
     def features_nchw(self) -> torch.Tensor:
@@ -402,10 +412,11 @@ class SegEngine:
         M = B * N
         dims, g = cfg.head_dims, cfg.grid
         p = cfg.drop_p if training else 0.0
+        sd = self._drop_counter(advance=False) if p > 0 else None
         h = "segmentation_head."
         S = cfg.img_size
         ops.classifier_bwd(dlogits.contiguous(), ws["f"][4], self.P(h + "5.weight"), ws["df"][4], self.Gd(h + "5.weight"),
-                           self.Gd(h + "5.bias"), count, B, S * S, dims[4], cfg.num_classes, seed=self.drop_seed + 4, p=p)
+                           self.Gd(h + "5.bias"), count, B, S * S, dims[4], cfg.num_classes, seed=self.drop_seed + 4, p=p, seed_dev=sd)
         for i in range(3, -1, -1):
             Hs = g << i
             Mo = B * 4 * Hs * Hs
@@ -416,7 +427,7 @@ class SegEngine:
                             ws["dcv"][i], self.Gd(f"{h}{i}.3.weight"), self.Gd(f"{h}{i}.3.bias"), ws["bn_sums"], Mo, C1)
             ops.conv3x3_wgrad(ws["dcv"][i], ws["u"][i], self.Gd(f"{h}{i}.2.weight"), B, 2 * Hs, 2 * Hs, C1, C1)
             ops.colsum(ws["dcv"][i], self.Gd(f"{h}{i}.2.bias"), Mo, C1)
-            ops.conv3x3_dgrad(ws["dcv"][i], self.W(f"{h}{i}.2.weight"), ws["du"][i], B, 2 * Hs, 2 * Hs, C1, C1, seed=self.drop_seed + i, p=p)
+            ops.conv3x3_dgrad(ws["dcv"][i], self.W(f"{h}{i}.2.weight"), ws["du"][i], B, 2 * Hs, 2 * Hs, C1, C1, seed=self.drop_seed + i, p=p, seed_dev=sd)
             ops.convT_wgrad(ws["du"][i], ws["f"][i], self.Gd(f"{h}{i}.0.weight"), B, Hs, Hs, dims[i], C1)
             ops.colsum(ws["du"][i], self.Gd(f"{h}{i}.0.bias"), Mo, C1)
             if i > 0 or not self.freeze_backbone:

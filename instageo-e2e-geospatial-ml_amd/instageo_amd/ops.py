@@ -72,6 +72,37 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---- optional per-launch HIP-event profiling (bench.py: roofline of the dominant kernels) ----------------
+# PROF maps entry point -> {"work": flops or bytes summed over launches, "events": [(start, end), ...]}.
+# torch.cuda.Event records on torch's current stream, which is the stream every kernel here is launched on.
+PROF = None
+
+
+def profile_begin(names) -> None:
+    global PROF
+    PROF = {n: {"work": 0.0, "events": []} for n in names}
+
+
+def profile_end():
+    """Synchronise and return {name: (launches, total_ms, total_work)}."""
+    global PROF
+    prof, PROF = PROF, None
+    torch.cuda.synchronize()
+    return {n: (len(d["events"]), sum(a.elapsed_time(b) for a, b in d["events"]), d["work"]) for n, d in prof.items()}
+
+
+def _call(name: str, work: float, *args) -> None:
+    if PROF is None or name not in PROF:
+        _lib.call(name, *args)
+        return
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    _lib.call(name, *args)
+    b.record()
+    PROF[name]["events"].append((a, b))
+    PROF[name]["work"] += work
+
+
 def _f32(t: torch.Tensor) -> torch.Tensor:
     assert t.dtype == torch.float32, t.dtype
     return t
@@ -107,7 +138,7 @@ def cls_rows(x: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, B: int, ntok
 
 
 def patch_embed_fwd(patches: BT, w: BT, bias, pos, x, batch: int, tpc: int, D: int, K: int) -> None:
-    _lib.call("ig_patch_embed_fwd", _p(patches.hi), _p(patches.lo), _p(w.hi), _p(w.lo), _p(bias), _p(pos), _p(x), batch, tpc, D, K,
+    _call("ig_patch_embed_fwd", 2.0 * batch * tpc * D * K, _p(patches.hi), _p(patches.lo), _p(w.hi), _p(w.lo), _p(bias), _p(pos), _p(x), batch, tpc, D, K,
               _stream())
 
 
@@ -125,29 +156,29 @@ def layernorm_bwd(dy: BT, x, mean, rstd, gamma, dx, accumulate: bool, dxb: Optio
 
 
 def linear_fwd(x: BT, w: BT, bias, y: BT, M: int, N: int, K: int, act: int = 0, pre: Optional[BT] = None) -> None:
-    _lib.call("ig_linear_fwd", _p(x.hi), _p(x.lo), _p(w.hi), _p(w.lo), _p(bias), _p(y.hi), _p(y.lo),
+    _call("ig_linear_fwd", 2.0 * M * N * K, _p(x.hi), _p(x.lo), _p(w.hi), _p(w.lo), _p(bias), _p(y.hi), _p(y.lo),
               _p(pre.hi) if pre else None, _p(pre.lo) if pre else None, M, N, K, act, _stream())
 
 
 def linear_residual_fwd(x: BT, w: BT, bias, resid, out, M: int, N: int, K: int) -> None:
-    _lib.call("ig_linear_residual_fwd", _p(x.hi), _p(x.lo), _p(w.hi), _p(w.lo), _p(bias), _p(resid), _p(out), M, N, K, _stream())
+    _call("ig_linear_residual_fwd", 2.0 * M * N * K, _p(x.hi), _p(x.lo), _p(w.hi), _p(w.lo), _p(bias), _p(resid), _p(out), M, N, K, _stream())
 
 
 def linear_dgrad(dy: BT, w: BT, dx: BT, M: int, N: int, K: int, pre: Optional[BT] = None) -> None:
-    _lib.call("ig_linear_dgrad", _p(dy.hi), _p(dy.lo), _p(w.hi), _p(w.lo), _p(dx.hi), _p(dx.lo),
+    _call("ig_linear_dgrad", 2.0 * M * N * K, _p(dy.hi), _p(dy.lo), _p(w.hi), _p(w.lo), _p(dx.hi), _p(dx.lo),
               _p(pre.hi) if pre else None, _p(pre.lo) if pre else None, M, N, K, 1 if pre else 0, _stream())
 
 
 def linear_wgrad(dy: BT, x: BT, dw, M: int, N: int, K: int) -> None:
-    _lib.call("ig_linear_wgrad", _p(dy.hi), _p(dy.lo), _p(x.hi), _p(x.lo), _p(dw), M, N, K, _stream())
+    _call("ig_linear_wgrad", 2.0 * M * N * K, _p(dy.hi), _p(dy.lo), _p(x.hi), _p(x.lo), _p(dw), M, N, K, _stream())
 
 
 def attention_fwd(qkv: BT, out: BT, lse, B: int, N: int, H: int, hd: int = 64) -> None:
-    _lib.call("ig_attention_fwd", _p(qkv.hi), _p(qkv.lo), _p(out.hi), _p(out.lo), _p(lse), B, N, H, hd, _stream())
+    _call("ig_attention_fwd", 4.0 * B * H * N * N * hd, _p(qkv.hi), _p(qkv.lo), _p(out.hi), _p(out.lo), _p(lse), B, N, H, hd, _stream())
 
 
 def attention_bwd(qkv: BT, out: BT, dout: BT, lse, delta, dqkv: BT, B: int, N: int, H: int, hd: int = 64) -> None:
-    _lib.call("ig_attention_bwd", _p(qkv.hi), _p(qkv.lo), _p(out.hi), _p(out.lo), _p(dout.hi), _p(dout.lo), _p(lse), _p(delta),
+    _call("ig_attention_bwd", 10.0 * B * H * N * N * hd, _p(qkv.hi), _p(qkv.lo), _p(out.hi), _p(out.lo), _p(dout.hi), _p(dout.lo), _p(lse), _p(delta),
               _p(dqkv.hi), _p(dqkv.lo), B, N, H, hd, _stream())
 
 
@@ -159,30 +190,30 @@ def patch_grad_prep(dx, out: BT, dcls, dbias, B: int, ntok: int, D: int) -> None
     _lib.call("ig_patch_grad_prep", _p(dx), _p(out.hi), _p(out.lo), _p(dcls), _p(dbias), B, ntok, D, _stream())
 
 
-def convT_fwd(x: BT, w: BT, bias, y: BT, B, H, W, Cin, Cout, seed: int = 0, p: float = 0.0) -> None:
-    _lib.call("ig_convT_fwd", _p(x.hi), _p(x.lo), _p(w.hi), _p(w.lo), _p(bias), _p(y.hi), _p(y.lo), B, H, W, Cin, Cout, seed, p,
+def convT_fwd(x: BT, w: BT, bias, y: BT, B, H, W, Cin, Cout, seed: int = 0, p: float = 0.0, seed_dev=None) -> None:
+    _call("ig_convT_fwd", 2.0 * B * H * W * Cin * Cout * 9, _p(x.hi), _p(x.lo), _p(w.hi), _p(w.lo), _p(bias), _p(y.hi), _p(y.lo), B, H, W, Cin, Cout, seed, _p(seed_dev), p,
               _stream())
 
 
 def convT_dgrad(dy: BT, w: BT, dx: BT, B, H, W, Cin, Cout) -> None:
-    _lib.call("ig_convT_dgrad", _p(dy.hi), _p(dy.lo), _p(w.hi), _p(w.lo), _p(dx.hi), _p(dx.lo), B, H, W, Cin, Cout, _stream())
+    _call("ig_convT_dgrad", 2.0 * B * H * W * Cin * Cout * 9, _p(dy.hi), _p(dy.lo), _p(w.hi), _p(w.lo), _p(dx.hi), _p(dx.lo), B, H, W, Cin, Cout, _stream())
 
 
 def convT_wgrad(dy: BT, x: BT, dw, B, H, W, Cin, Cout) -> None:
-    _lib.call("ig_convT_wgrad", _p(dy.hi), _p(dy.lo), _p(x.hi), _p(x.lo), _p(dw), B, H, W, Cin, Cout, _stream())
+    _call("ig_convT_wgrad", 2.0 * B * H * W * Cin * Cout * 9, _p(dy.hi), _p(dy.lo), _p(x.hi), _p(x.lo), _p(dw), B, H, W, Cin, Cout, _stream())
 
 
 def conv3x3_fwd(x: BT, w: BT, bias, y: BT, B, H, W, Cin, Cout) -> None:
-    _lib.call("ig_conv3x3_fwd", _p(x.hi), _p(x.lo), _p(w.hi), _p(w.lo), _p(bias), _p(y.hi), _p(y.lo), B, H, W, Cin, Cout, _stream())
+    _call("ig_conv3x3_fwd", 2.0 * B * H * W * Cin * Cout * 9, _p(x.hi), _p(x.lo), _p(w.hi), _p(w.lo), _p(bias), _p(y.hi), _p(y.lo), B, H, W, Cin, Cout, _stream())
 
 
-def conv3x3_dgrad(dy: BT, w: BT, dx: BT, B, H, W, Cin, Cout, seed: int = 0, p: float = 0.0) -> None:
-    _lib.call("ig_conv3x3_dgrad", _p(dy.hi), _p(dy.lo), _p(w.hi), _p(w.lo), _p(dx.hi), _p(dx.lo), B, H, W, Cin, Cout, seed, p,
+def conv3x3_dgrad(dy: BT, w: BT, dx: BT, B, H, W, Cin, Cout, seed: int = 0, p: float = 0.0, seed_dev=None) -> None:
+    _call("ig_conv3x3_dgrad", 2.0 * B * H * W * Cin * Cout * 9, _p(dy.hi), _p(dy.lo), _p(w.hi), _p(w.lo), _p(dx.hi), _p(dx.lo), B, H, W, Cin, Cout, seed, _p(seed_dev), p,
               _stream())
 
 
 def conv3x3_wgrad(dy: BT, x: BT, dw, B, H, W, Cin, Cout) -> None:
-    _lib.call("ig_conv3x3_wgrad", _p(dy.hi), _p(dy.lo), _p(x.hi), _p(x.lo), _p(dw), B, H, W, Cin, Cout, _stream())
+    _call("ig_conv3x3_wgrad", 2.0 * B * H * W * Cin * Cout * 9, _p(dy.hi), _p(dy.lo), _p(x.hi), _p(x.lo), _p(dw), B, H, W, Cin, Cout, _stream())
 
 
 def bn_relu_fwd(x: BT, gamma, beta, rmean, rvar, y: BT, scale, shift, mean, rstd, sums, M: int, C: int, training: bool,
@@ -196,13 +227,14 @@ def bn_relu_bwd(x: BT, dy: BT, scale, shift, mean, rstd, dx: BT, dgamma, dbeta, 
               _p(dgamma), _p(dbeta), _p(sums), M, C, _stream())
 
 
-def classifier_fwd(f: BT, w, bias, logits, B: int, HW: int, C: int, ncls: int, seed: int = 0, p: float = 0.0) -> None:
-    _lib.call("ig_classifier_fwd", _p(f.hi), _p(f.lo), _p(w), _p(bias), _p(logits), B, HW, C, ncls, seed, p, _stream())
+def classifier_fwd(f: BT, w, bias, logits, B: int, HW: int, C: int, ncls: int, seed: int = 0, p: float = 0.0, seed_dev=None) -> None:
+    _lib.call("ig_classifier_fwd", _p(f.hi), _p(f.lo), _p(w), _p(bias), _p(logits), B, HW, C, ncls, seed, _p(seed_dev), p, _stream())
 
 
-def classifier_bwd(dlogits, f: BT, w, df: BT, dw, db, count, B: int, HW: int, C: int, ncls: int, seed: int = 0, p: float = 0.0) -> None:
+def classifier_bwd(dlogits, f: BT, w, df: BT, dw, db, count, B: int, HW: int, C: int, ncls: int, seed: int = 0, p: float = 0.0,
+                   seed_dev=None) -> None:
     _lib.call("ig_classifier_bwd", _p(dlogits), _p(f.hi), _p(f.lo), _p(w), _p(df.hi), _p(df.lo), _p(dw), _p(db), _p(count), B, HW, C,
-              ncls, seed, p, _stream())
+              ncls, seed, _p(seed_dev), p, _stream())
 
 
 _LABEL_DT = {torch.int64: 0, torch.int32: 1, torch.float32: 2}
