@@ -1,0 +1,43 @@
+"""Model factory (reference: ``instageo/model/factory.py:35-116``): config -> task module (+ checkpoint)."""
+from __future__ import annotations
+
+from typing import Any, Dict
+
+import torch
+
+from .segmentation import PrithviSegmentationModule
+
+
+def create_model(cfg: Dict[str, Any], precision: str = "bf16", device=None) -> PrithviSegmentationModule:
+    """Build the segmentation module from a run.py config; non-train modes load ``checkpoint_path`` strictly
+    (``torch.load(path)["state_dict"]``, factory.py:113-115)."""
+    if cfg.get("is_reg_task", False):
+        raise NotImplementedError("regression task is outside the hot-path scope (SURVEY.md 8f item 4)")
+    if cfg["train"].get("distillation", False):
+        raise NotImplementedError("distillation is outside the hot-path scope (SURVEY.md 8f item 4)")
+    m, t, d = cfg["model"], cfg["train"], cfg["dataloader"]
+    train_mode = cfg["mode"] == "train"
+    model = PrithviSegmentationModule(
+        image_size=d["img_size"] if train_mode else cfg["test"]["crop_size"],
+        learning_rate=t["learning_rate"],
+        freeze_backbone=m["freeze_backbone"],
+        load_pretrained_weights=bool(m["load_pretrained_weights"]) and train_mode and cfg.get("allow_hub_download", False),
+        num_classes=m["num_classes"],
+        temporal_step=d["temporal_dim"],
+        class_weights=t["class_weights"],
+        ignore_index=t["ignore_index"],
+        weight_decay=t["weight_decay"],
+        scheduler=t.get("scheduler", False),
+        model_name=m["model_name"],
+        weight_clip_range=m.get("weight_clip_range"),
+        depth=m.get("depth", -1),
+        precision=precision,
+        device=device,
+    )
+    if not train_mode:
+        ckpt = cfg.get("checkpoint_path")
+        if not ckpt or str(ckpt) == "None":
+            raise RuntimeError("checkpoint_path is required for eval / chip_inference")
+        sd = torch.load(ckpt, map_location="cpu")["state_dict"]
+        model.load_checkpoint_state_dict(sd, strict=True)
+    return model

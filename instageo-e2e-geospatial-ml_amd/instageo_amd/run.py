@@ -1,0 +1,184 @@
+"""Runner entry point with the reference's ``run.py`` surface (``instageo/model/run.py:60-245``).
+
+    python -m instageo_amd.run [--config-name sen1floods11] [--config-path DIR] key=value ...
+
+Modes ``stats | train | eval | chip_inference`` and every config key are those of the reference.  Hydra,
+Lightning and Neptune are replaced by :mod:`instageo_amd.config` and the explicit loop below, which logs the
+same metric names and writes ``instageo_best_checkpoint.ckpt`` (``{"state_dict": ...}``) on the best
+``val_IoU`` (pipeline_utils.py:347-355).  Data: ``*_filepath`` may be ``synthetic:<n>`` (on-device HLS-shaped
+chips) or an ``.npz`` with ``chips (N,T*C,H,W)`` and ``labels (N,H,W)`` relative to ``root_dir`` (GeoTIFF/CSV
+I/O is outside the hot path).  Multi-GPU: launch with ``python -m torch.distributed.run``; ranks shard the
+dataset and average gradients over RCCL (:mod:`instageo_amd.distributed`).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import distributed as D
+from .config import check_required_flags, load_config
+from .dataloader import (ArrayChipDataset, SyntheticChipDataset, eval_collate_fn, infer_collate_fn, normalize_batch,
+                         process_and_augment, process_test)
+from .factory import create_model
+from .infer_utils import chip_inference
+
+SEED = 1042  # pl.seed_everything(1042) in the reference (run.py:50)
+
+
+def get_device() -> str:
+    """pipeline_utils.py:58-75 returns gpu/cpu; there is no CPU path here."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("instageo_amd needs a HIP device (MI355X): no CPU fallback")
+    return "gpu"
+
+
+def create_dataset(spec: Optional[str], cfg: Dict[str, Any], kind: str, device: str):
+    """``synthetic:<n>`` or an .npz archive -> dataset following the reference item contract."""
+    d = cfg["dataloader"]
+    T, mean, std = d["temporal_dim"], d["mean"], d["std"]
+    mult = d.get("constant_multiplier", 1.0)
+    mult = None if mult in (None, 1, 1.0) else float(mult)
+    ncls, ign = cfg["model"]["num_classes"], cfg["train"]["ignore_index"]
+    if spec is None or str(spec) == "None":
+        raise RuntimeError(f"{kind}_filepath is required")
+    if str(spec).startswith("synthetic:"):
+        n = int(str(spec).split(":")[1])
+        size = cfg["test"]["img_size"] if kind == "test" and cfg["mode"] == "eval" else d["img_size"]
+        return SyntheticChipDataset(n, T, ncls, mean, std, im_size=size, ignore_index=ign, constant_multiplier=1e-4, seed=SEED, device=device)
+    path = spec if os.path.isabs(str(spec)) or cfg.get("root_dir") in (None, "None") else os.path.join(cfg["root_dir"], spec)
+    z = np.load(path)
+    return ArrayChipDataset(z["chips"], z["labels"], mean, std, T, mult, include_filenames=(kind == "test"), device=device)
+
+
+def _batches(ds, batch_size: int, shuffle: bool, epoch: int, rank: int, world: int):
+    """Rank-sharded batch index lists (DistributedSampler semantics: shuffle per epoch, same seed on all ranks)."""
+    n = len(ds)
+    idx = torch.randperm(n, generator=torch.Generator().manual_seed(SEED + epoch)).tolist() if shuffle else list(range(n))
+    lo, hi = D.shard_range(n, rank, world)
+    idx = idx[lo:hi]
+    for i in range(0, len(idx), batch_size):
+        yield idx[i : i + batch_size]
+
+
+def _stack(ds, ids: List[int]) -> Tuple[torch.Tensor, torch.Tensor]:
+    items = [ds[i] for i in ids]
+    items = [it[0] if isinstance(it[0], tuple) else it for it in items]
+    return torch.stack([it[0] for it in items]), torch.stack([it[1] for it in items])
+
+
+def train(cfg: Dict[str, Any], model, out_dir: str, rank: int, world: int) -> Dict[str, float]:
+    dev = str(model.net.store.flat.device)
+    train_ds = create_dataset(cfg["train_filepath"], cfg, "train", dev)
+    valid_ds = create_dataset(cfg["valid_filepath"], cfg, "valid", dev)
+    bs = cfg["train"]["batch_size"]
+    opt = model.optimizer()
+    sched = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(opt, T_0=10, T_mult=2, eta_min=0) if cfg["train"].get("scheduler") else None
+    D.attach_data_parallel(model)
+    best, history = -1.0, {}
+    for epoch in range(cfg["train"]["num_epochs"]):
+        model.net.train()
+        for ids in _batches(train_ds, bs, True, epoch, rank, world):
+            x, y = _stack(train_ds, ids)
+            model.fused_train_step(x, y)
+        D.reduce_confusion(model.train_metrics.device_matrix(dev))
+        model.on_train_epoch_end()
+        for ids in _batches(valid_ds, bs, False, epoch, rank, world):
+            x, y = _stack(valid_ds, ids)
+            model.fused_eval_step(x, y, "val")
+        D.reduce_confusion(model.val_metrics.device_matrix(dev))
+        model.on_validation_epoch_end()
+        if sched is not None:
+            sched.step()
+        model.log("learning_rate", opt.param_groups[0]["lr"])
+        history = {k: (float(v) if not isinstance(v, (list, tuple)) else v) for k, v in model.logged.items()}
+        if rank == 0:
+            print(json.dumps({"epoch": epoch, **{k: round(v, 6) for k, v in history.items() if isinstance(v, float)}}))
+            if history.get("val_IoU", 0.0) > best:  # ModelCheckpoint(monitor="val_IoU", mode="max", save_top_k=1)
+                best = history["val_IoU"]
+                torch.save({"state_dict": model.checkpoint_state_dict(), "epoch": epoch}, os.path.join(out_dir, "instageo_best_checkpoint.ckpt"))
+    return history
+
+
+def evaluate(cfg: Dict[str, Any], model, rank: int, world: int) -> Dict[str, float]:
+    dev = str(model.net.store.flat.device)
+    test_ds = create_dataset(cfg["test_filepath"], cfg, "test", dev)
+    d, t = cfg["dataloader"], cfg["test"]
+    model.net.eval()
+    lo, hi = D.shard_range(len(test_ds), rank, world)
+    for i in range(lo, hi):
+        raw_x, raw_y = test_ds.raw(i) if hasattr(test_ds, "raw") else (test_ds.chips[i], test_ds.labels[i])
+        mult = 1e-4 if hasattr(test_ds, "raw") else None
+        x, y = process_test(raw_x, raw_y, d["mean"], d["std"], d["temporal_dim"], t["img_size"], t["crop_size"], t["stride"], mult, dev)
+        model.fused_eval_step(x, y, "test")
+    D.reduce_confusion(model.test_metrics.device_matrix(dev))
+    model.on_test_epoch_end()
+    return {k: float(v) for k, v in model.logged.items() if k.startswith("test_") and not isinstance(v, (list, tuple))}
+
+
+def main(argv: Optional[List[str]] = None) -> int:
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--config-name", default="config")
+    ap.add_argument("--config-path", default=None)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
+    ap.add_argument("--output-dir", default=None, help="replaces the Hydra run dir (checkpoint + resolved config)")
+    ap.add_argument("overrides", nargs="*")
+    args = ap.parse_args(argv)
+    cfg = load_config(args.config_name, args.overrides, args.config_path)
+    start = time.time()
+    torch.manual_seed(SEED)
+    np.random.seed(SEED)
+    rank, local_rank, world = D.init_from_env()
+    get_device()
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    out_dir = args.output_dir or os.path.join(os.getcwd(), "outputs", time.strftime("%Y-%m-%d_%H-%M-%S"))
+    if rank == 0:
+        os.makedirs(os.path.join(out_dir, ".hydra"), exist_ok=True)
+        import yaml
+
+        yaml.safe_dump(cfg, open(os.path.join(out_dir, ".hydra", "config.yaml"), "w"), sort_keys=False)
+
+    if cfg["mode"] == "stats":
+        raise NotImplementedError("mode=stats (dataset mean/std reduction) is a 'next' item (SURVEY.md 8f item 1)")
+    model = create_model(cfg, precision=args.precision, device=dev)
+    if cfg["mode"] == "train":
+        check_required_flags(["train_filepath", "valid_filepath"], cfg)
+        hist = train(cfg, model, out_dir, rank, world)
+        if rank == 0:
+            print(f"Elapsed time: {time.time() - start:.2f} seconds")
+    elif cfg["mode"] == "eval":
+        check_required_flags(["test_filepath", "checkpoint_path"], cfg)
+        res = evaluate(cfg, model, rank, world)
+        if rank == 0:
+            print(json.dumps({"Evaluation results": {k: round(v, 6) for k, v in res.items()}}))
+            print(f"Elapsed time: {time.time() - start:.2f} seconds")
+    elif cfg["mode"] == "chip_inference":
+        check_required_flags(["root_dir", "test_filepath", "checkpoint_path"], cfg)
+        model.net.eval()
+        output_dir = os.path.join(cfg["root_dir"], "predictions")
+        ds = create_dataset(cfg["test_filepath"], cfg, "test", dev)
+        if isinstance(ds, SyntheticChipDataset):
+            ds = ArrayChipDataset([ds.raw(i)[0] for i in range(len(ds))], [ds.raw(i)[1] for i in range(len(ds))], ds.mean, ds.std, ds.T,
+                                  1e-4, include_filenames=True, device=dev)
+        lo, hi = D.shard_range(len(ds), rank, world)
+        bs = cfg["train"]["batch_size"]
+        loader = (infer_collate_fn([ds[j] for j in range(i, min(i + bs, hi))]) for i in range(lo, hi, bs))
+        info = chip_inference(loader, output_dir, model, device="gpu")
+        if rank == 0:
+            print(f"Carbon tracking information: {info}")
+    else:
+        raise ValueError(f"unknown mode {cfg['mode']!r}")
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

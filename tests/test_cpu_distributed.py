@@ -1,0 +1,107 @@
+"""CPU tests (-m "not gpu") of the N>1 path: two gloo ranks exercise the bucketed gradient averaging, the metric
+reductions, the inference sharding and the final gather exactly as the RCCL ranks do on MI355X."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank: int, world: int, port: int, q) -> None:
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "instageo-e2e-geospatial-ml_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from instageo_amd import distributed as D
+
+    r, lr, w = D.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world) and D.world_size() == world
+    try:
+        # flat gradient of a toy "network": ranges arrive head-first in descending address order, like SegEngine
+        n = 10_000
+        g = torch.arange(n, dtype=torch.float32) * (rank + 1)
+        sync = D.GradSync(lambda: g, bucket_bytes=4 * 3000)
+        ranges = [(9000, 10000), (8000, 9000), (5000, 8000), (4000, 5000), (1000, 4000), (0, 1000)]
+        for lo, hi in ranges:
+            sync.ready(lo, hi)
+        sync.wait()
+        expect = torch.arange(n, dtype=torch.float32) * (sum(range(1, world + 1)) / world)
+        assert torch.allclose(g, expect), "gradient mean mismatch"
+        launched = list(sync.launched)
+        # buckets are merged adjacent ranges >= 3000 elements; together they tile [0, n) exactly once
+        assert sorted(launched) == [(0, 4000), (4000, 8000), (8000, 10000)] or sum(h - l for l, h in launched) == n
+        assert all((h - l) >= 3000 or l == 0 or h == n for l, h in launched)
+        # confusion-matrix + loss-stat reductions (C2)
+        cm = torch.full((3, 3), rank + 1, dtype=torch.int64)
+        D.reduce_confusion(cm)
+        assert int(cm[0, 0]) == sum(range(1, world + 1))
+        st = torch.tensor([1.5 * (rank + 1), 10.0], dtype=torch.float64)
+        D.reduce_loss_stats(st)
+        assert st.tolist() == [1.5 * sum(range(1, world + 1)), 10.0 * world]
+        # inference sharding (C3): 2401 windows of the 10980^2 tile, contiguous blocks, gather to rank 0
+        lo, hi = D.shard_range(2401, rank, world)
+        counts = [D.shard_range(2401, k, world)[1] - D.shard_range(2401, k, world)[0] for k in range(world)]
+        assert sum(counts) == 2401 and max(counts) - min(counts) <= 1
+        local = torch.arange(lo, hi, dtype=torch.int8).view(-1, 1, 1).expand(-1, 2, 2).contiguous()
+        out = D.gather_class_maps(local, counts, dst=0)
+        if rank == 0:
+            assert out.shape == (2401, 2, 2)
+            assert torch.equal(out[:, 0, 0], torch.arange(2401, dtype=torch.int8))
+        else:
+            assert out is None
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_data_parallel_path():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_shard_range_properties():
+    from instageo_amd.distributed import shard_range
+
+    for n in (0, 1, 7, 2401, 2400):
+        for w in (1, 2, 3, 8):
+            parts = [shard_range(n, r, w) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1
+    # BASELINE.json configs[3]: 2401 windows over 8 ranks = 1 x 301 + 7 x 300
+    sizes = sorted(b - a for a, b in (shard_range(2401, r, 8) for r in range(8)))
+    assert sizes == [300] * 7 + [301]
+
+
+def test_single_process_is_a_no_op():
+    from instageo_amd import distributed as D
+
+    g = torch.ones(10)
+    s = D.GradSync(lambda: g)
+    s.ready(0, 10)
+    s.wait()
+    assert torch.equal(g, torch.ones(10)) and s.launched == []
+    assert D.gather_class_maps(torch.zeros(2, 1, 1, dtype=torch.int8), [2]) is not None

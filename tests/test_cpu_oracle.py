@@ -1,0 +1,143 @@
+"""CPU tests (-m "not gpu"): the oracle against the committed golden vectors (generated from an import of the
+reference by oracle/gen_golden.py) and against the reference test-suite's known answers."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import prithvi_oracle as O
+from oracle.cases import CASES, GRAD_KEYS, case_config, class_weights_for, make_inputs, sub
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_pos_embed_tables_match_reference_fixture():
+    g = np.load(os.path.join(GOLD, "pos_embed.npz"))
+    for D in (256, 768, 1024):
+        for T in (1, 3):
+            pe = O.sincos_pos_embed_3d(D, (T, 14, 14), True).astype(np.float32)
+            assert pe.shape == (1 + T * 196, D)
+            assert np.all(pe[0] == 0)  # cls row is zeros (tests/model_tests/test_model.py:53)
+            assert abs(pe.astype(np.float64).sum() - float(g[f"D{D}_T{T}_sum"])) < 1e-6
+            assert np.array_equal(pe[[0, 1, 2, 15, 196, pe.shape[0] - 1]], g[f"D{D}_T{T}_rows"])
+
+
+@pytest.mark.parametrize("name", ["tiny_t1_c2", "tiny_t3_c13"])
+def test_oracle_eval_forward_matches_golden(name):
+    variant, T, ncls, B, depth = CASES[name]
+    cfg = case_config(name)
+    sd = O.make_state_dict(cfg, seed=1042)
+    img, _ = make_inputs(name, cfg, B)
+    g = np.load(os.path.join(GOLD, f"{name}.npz"))
+    stages = {}
+    with torch.no_grad():
+        logits = O.prithvi_seg_forward(cfg, sd, img, training=False, stages=stages)
+    assert logits.shape == (B, ncls, 224, 224)
+    assert np.abs(sub(logits) - g["eval_logits_sub"]).max() < 5e-5
+    assert np.abs(sub(stages["features"]) - g["features_sub"]).max() < 5e-5
+    for k in ("patch_embed", "block0", "encoder_out", "head0", "head3"):
+        assert np.abs(sub(stages[k]) - g[f"stage_{k}_sub"]).max() < 1e-4, k
+    assert np.array_equal(np.bincount(logits.argmax(1).reshape(-1).numpy(), minlength=ncls), g["eval_argmax_hist"])
+
+
+def test_oracle_train_step_matches_golden_fp64():
+    name = "tiny_t1_c2"
+    cfg = case_config(name)
+    sd = O.make_state_dict(cfg, seed=1042)
+    img, lab = make_inputs(name, cfg, 2)
+    g = np.load(os.path.join(GOLD, f"{name}.npz"))
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    keys = GRAD_KEYS[:3] + GRAD_KEYS[-3:]
+    logits, loss, grads = O.train_step_reference(cfg, sd64, img.double(), lab, class_weights_for(2).double(), -1, keys)
+    assert abs(loss.item() - float(g["train_loss"])) < 1e-10
+    assert np.abs(sub(logits) - g["train_logits_sub"]).max() < 1e-9
+    for k in keys:
+        assert np.abs(sub(grads[k], 1024) - g["grad_sub__" + k]).max() <= 1e-9 * max(1.0, float(g["grad_norm__" + k]))
+    pred = logits.argmax(1)
+    cm = O.confusion_matrix(lab.numpy(), pred.numpy(), 2, -1)
+    assert np.array_equal(cm, g["confusion"])
+    assert abs(O.confusion_metrics(cm)["jaccard"] - float(g["miou"])) < 1e-12
+
+
+def test_metrics_known_answers():
+    """Reference tests/model_tests/test_metrics.py:27-74: streaming matrix == sklearn-style macro scores."""
+    g = np.load(os.path.join(GOLD, "metrics.npz"))
+    cm = np.zeros((3, 3), dtype=np.int64)
+    for a, b in zip(np.array_split(g["y_true"], 10), np.array_split(g["y_pred"], 10)):
+        cm += O.confusion_matrix(a, b, 3, None)
+    assert np.array_equal(cm, g["matrix"])
+    m = O.confusion_metrics(cm)
+    got = np.array([m[k] for k in ("accuracy", "precision", "recall", "f1", "jaccard")])
+    assert np.allclose(got, g["scalars"], atol=1e-12)
+    assert np.allclose(m["jaccard_per_class"], g["jaccard_per_class"], atol=1e-12)
+    from sklearn.metrics import accuracy_score, f1_score, jaccard_score, precision_score, recall_score
+
+    yt, yp = g["y_true"], g["y_pred"]
+    assert abs(m["accuracy"] - accuracy_score(yt, yp)) < 1e-12
+    assert abs(m["precision"] - precision_score(yt, yp, average="macro")) < 1e-12
+    assert abs(m["recall"] - recall_score(yt, yp, average="macro")) < 1e-12
+    assert abs(m["f1"] - f1_score(yt, yp, average="macro")) < 1e-12
+    assert abs(m["jaccard"] - jaccard_score(yt, yp, average="macro")) < 1e-12
+
+
+def test_metrics_edge_cases():
+    assert O.confusion_matrix(np.array([]), np.array([]), 3, None).sum() == 0
+    m = O.confusion_metrics(np.zeros((2, 2), dtype=np.int64))
+    assert np.isnan(m["accuracy"]) and m["jaccard"] == 0.0  # _safe_div returns 0 where the denominator is 0
+    cm = O.confusion_matrix(np.array([-1, -1, 0]), np.array([1, 0, 0]), 2, -1)
+    assert cm.tolist() == [[1, 0], [0, 0]]
+
+
+def test_loss_semantics_not_torch_weighted_mean():
+    """segmentation.py:120-122: sum(w_y nll)/#valid, which differs from CrossEntropyLoss(reduction='mean')."""
+    g = torch.Generator().manual_seed(0)
+    logits = torch.randn(2, 3, 5, 5, generator=g)
+    labels = torch.randint(0, 3, (2, 5, 5), generator=g)
+    labels[0, 0, :] = -1
+    w = torch.tensor([1.0, 3.0, 0.7])
+    ours = O.seg_loss(logits, labels, w, -1)
+    lsm = torch.log_softmax(logits, 1)
+    mask = labels != -1
+    nll = -lsm.gather(1, labels.clamp(min=0).unsqueeze(1)).squeeze(1)
+    manual = (w[labels.clamp(min=0)] * nll)[mask].sum() / mask.sum()
+    assert torch.allclose(ours, manual)
+    torch_mean = torch.nn.functional.cross_entropy(logits, labels, weight=w, ignore_index=-1)
+    assert not torch.allclose(ours, torch_mean)
+
+
+def test_window_origins_and_normalize():
+    g = np.load(os.path.join(GOLD, "windows.npz"))
+    assert np.array_equal(np.array(O.window_origins(512, 224, 224)), g["S512"]) and len(g["S512"]) == 4
+    w = O.window_origins(10980, 224, 224)
+    assert np.array_equal(np.array(w), g["S10980"]) and len(w) == 49 * 49 and w[-1] == (10752, 10752)
+    chip = np.arange(2 * 3 * 4 * 4, dtype=np.float64).reshape(6, 4, 4)  # T=2, C=3, band = t*C + c
+    out = O.normalize_chip(chip, [1.0, 2.0, 3.0], [2.0, 4.0, 8.0], 2)
+    assert out.shape == (3, 2, 4, 4)
+    assert np.allclose(out[1, 1], (chip[1 * 3 + 1] - 2.0) / 4.0)
+
+
+def test_adamw_and_scheduler_restatement():
+    p0, gr = torch.randn(50), torch.randn(50)
+    q = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([q], lr=1e-3, weight_decay=1e-2)
+    sch = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(opt, T_0=10, T_mult=2, eta_min=0)
+    p, m, v = p0.clone(), torch.zeros(50), torch.zeros(50)
+    for step in range(1, 5):
+        q.grad = gr.clone()
+        opt.step()
+        O.adamw_step(p, gr, m, v, step, lr=1e-3, wd=1e-2)
+    assert torch.allclose(p, q.detach(), atol=1e-7)
+    for epoch in range(35):
+        assert abs(O.cosine_warm_restarts_lr(1e-3, epoch) - opt.param_groups[0]["lr"]) < 1e-12
+        sch.step()
+
+
+def test_state_dict_contract_counts():
+    """Parameter counts probed from the reference."""
+    for variant, T, ncls, enc, head in [("prithvi_eo_v1_100", 1, 2, 86237184, 5290658), ("prithvi_eo_v1_100", 3, 13, 86237184 + 2 * 196 * 0, 47599645)]:
+        cfg = O.make_config(variant, T, ncls)
+        shapes = O.state_dict_shapes(cfg)
+        n_enc = sum(int(np.prod(s)) for k, s in shapes.items() if k.startswith("prithvi_encoder.") and not k.endswith("pos_embed"))
+        n_head = sum(int(np.prod(s)) for k, s in shapes.items() if k.startswith("segmentation_head.") and "running" not in k and "num_batches" not in k)
+        assert n_enc == enc and n_head == head
