@@ -82,7 +82,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="chips per GPU per step")
+    ap.add_argument("--batch", type=int, default=54, help="chips per GPU per step")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP events (roofline objects become null)")

@@ -277,33 +277,37 @@ __global__ __launch_bounds__(TPB) void layernorm_bwd_kernel(const bf16_t* __rest
 }
 
 // column sums of a bf16/split matrix: out[c] += sum_m x[m][c]   (bias gradients)
-// threads tile (row slice, 8-column unit); per-block LDS reduction, then one atomic per (block, column)
+// grid (row chunk, 2048-column chunk); threads tile (row slice, 8-column unit) with 4 independent 16-byte loads in
+// flight; per-block LDS reduction, then one atomic per (block, column)
 __global__ __launch_bounds__(TPB) void colsum_kernel(const bf16_t* __restrict__ hi, const bf16_t* __restrict__ lo,
                                                      float* __restrict__ out, long M, int C, int rows_per_block) {
-    extern __shared__ float red[];  // [C]
-    const int units = C / 8;
+    __shared__ float red[2048];
+    const int c0 = blockIdx.y * 2048;
+    const int cw = min(2048, C - c0);  // columns of this block
+    const int units = cw / 8;
     const int tu = min(units, TPB), nslice = TPB / tu;
     const int u = threadIdx.x % tu, sl = threadIdx.x / tu;
     const long r0 = (long)blockIdx.x * rows_per_block;
     const long r1 = min(M, r0 + rows_per_block);
-    for (int i = threadIdx.x; i < C; i += TPB) red[i] = 0.f;
+    for (int i = threadIdx.x; i < cw; i += TPB) red[i] = 0.f;
     __syncthreads();
     if (sl < nslice) {
         for (int ub = u; ub < units; ub += tu) {
+            const size_t col = (size_t)c0 + ub * 8;
             float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             long r = r0 + sl;
-            for (; r + 3L * nslice < r1; r += 4L * nslice) {  // 4 independent loads in flight
+            for (; r + 3L * nslice < r1; r += 4L * nslice) {
                 float f0[8], f1[8], f2[8], f3[8];
-                load8_split(hi, lo, (size_t)r * C + ub * 8, f0);
-                load8_split(hi, lo, (size_t)(r + nslice) * C + ub * 8, f1);
-                load8_split(hi, lo, (size_t)(r + 2L * nslice) * C + ub * 8, f2);
-                load8_split(hi, lo, (size_t)(r + 3L * nslice) * C + ub * 8, f3);
+                load8_split(hi, lo, (size_t)r * C + col, f0);
+                load8_split(hi, lo, (size_t)(r + nslice) * C + col, f1);
+                load8_split(hi, lo, (size_t)(r + 2L * nslice) * C + col, f2);
+                load8_split(hi, lo, (size_t)(r + 3L * nslice) * C + col, f3);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] += (f0[j] + f1[j]) + (f2[j] + f3[j]);
             }
             for (; r < r1; r += nslice) {
                 float f[8];
-                load8_split(hi, lo, (size_t)r * C + ub * 8, f);
+                load8_split(hi, lo, (size_t)r * C + col, f);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] += f[j];
             }
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(TPB) void colsum_kernel(const bf16_t* __restrict__ 
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < C; i += TPB) atomicAdd(out + i, red[i]);
+    for (int i = threadIdx.x; i < cw; i += TPB) atomicAdd(out + c0 + i, red[i]);
 }
 
 // f32 -> bf16 hi (+ lo)
@@ -614,7 +618,7 @@ int ig_layernorm_bwd(const void* dy_hi, const void* dy_lo, const float* x, const
     IG_REQUIRE(dy_hi && x && mean && rstd && gamma && dx, "ig_layernorm_bwd: null pointer");
     IG_REQUIRE(D % 4 == 0 && D <= 2048, "ig_layernorm_bwd: D must be a multiple of 4 and <= 2048 (got %d)", D);
     if (M == 0) return IG_OK;
-    const int rpb = 32;
+    const int rpb = 16;
     dim3 grid(ig_cdiv(M, rpb));
     size_t sm = 3 * (size_t)D * sizeof(float);
     if (D <= 1024)
@@ -632,8 +636,8 @@ int ig_colsum(const void* hi, const void* lo, float* out, long M, int C, void* s
     IG_REQUIRE(hi && out, "ig_colsum: null pointer");
     IG_REQUIRE(C % 8 == 0, "ig_colsum: C must be a multiple of 8 (got %d)", C);
     if (M == 0) return IG_OK;
-    const int rpb = M > 65536 ? 512 : 32;
-    hipLaunchKernelGGL(colsum_kernel, dim3(ig_cdiv(M, rpb)), dim3(TPB), (size_t)C * sizeof(float), ST(stream), (const bf16_t*)hi, (const bf16_t*)lo, out, M,
+    const int rpb = M > 65536 ? 512 : 16;
+    hipLaunchKernelGGL(colsum_kernel, dim3(ig_cdiv(M, rpb), ig_cdiv(C, 2048)), dim3(TPB), 0, ST(stream), (const bf16_t*)hi, (const bf16_t*)lo, out, M,
                        C, rpb);
     return ig_check_launch("ig_colsum");
 }

@@ -18,6 +18,8 @@
 // Reference ops replaced (file:line in /root/reference): nn.Conv3d patch embed pritvhi.py:243-268;
 // timm Block linears (qkv/proj/fc1/fc2) pritvhi.py:446-456; nn.ConvTranspose2d / nn.Conv2d of the
 // decode head model.py:361-375.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -187,6 +189,192 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
             if (n < N) ep.store(m, n, acc[tn][tm]);
         }
     }
+}
+
+// ==============================================================================================
+// v2: 256x128 tile, 8 waves (4x2, 64x64 each), LDS-DMA (global_load_lds_dwordx4) into a 3-stage LDS ring with
+// counted vmcnt + raw s_barrier: two K-steps (96 KiB) stay in flight per CU across the barrier, no VGPR staging and
+// no ds_write pass.  The LDS image is lane-linear per wave-instruction (1 KiB = 8 rows x 128 B, or 4 k-rows x
+// 256 B for TR operands); the XOR swizzle is applied on the SOURCE chunk, the fragment reads use the same
+// involution.  Invalid units read a 16-byte zero page.  The LDS-DMA is issued from inline asm so that hipcc does
+// not drain it with vmcnt(0) at the next ds_read / barrier (cdna_hip_programming.md 5, "Pipelining across barriers").
+// ==============================================================================================
+constexpr int BM2 = 256, NTHR2 = 512;
+constexpr int A_BYTES2 = 32768, STAGE2 = 49152, NSTAGE2 = 3, SMEM2 = STAGE2 * NSTAGE2;
+typedef __attribute__((address_space(3))) char* lds_char_ptr;
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ int tr_key(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
+template <class AL, class BL, class EP, bool A_TR, bool B_TR, int NSEG>
+__global__ __launch_bounds__(NTHR2) void gemm2_kernel(AL al, BL bl, EP ep, int M, int N, int K, int tiles_n, int ntiles,
+                                                      int kchunk, const bf16_t* zero_page) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    // PERSISTENT tile schedule: workgroups are dealt round-robin over the 8 XCDs (private L2s); XCD x owns the
+    // contiguous tile range [lo, lo+cnt) and its workgroups walk it with stride nbx, so the CUs of one XCD always
+    // work on neighbouring tiles (shared A row panel / B panels).  With gridDim.x == ntiles this degenerates to
+    // one tile per workgroup.
+    const int nb = gridDim.x, xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int nbx = (nb >> 3) + (xcd < (nb & 7) ? 1 : 0);
+    const int qT = ntiles >> 3, rT = ntiles & 7;
+    const int tlo = xcd * qT + min(xcd, rT), tcnt = qT + (xcd < rT ? 1 : 0);
+    const int my_tiles = tcnt > jx ? (tcnt - jx + nbx - 1) / nbx : 0;
+    al.init(blockIdx.z);
+    bl.init(blockIdx.z);
+    ep.init(blockIdx.z);
+    if (al.kdim() >= 0) K = al.kdim();
+    const int nk_all = (K + BK - 1) / BK;
+    const int kt0 = blockIdx.y * kchunk;
+    const int nk = min(kchunk, nk_all - kt0);
+    if (nk <= 0 || my_tiles <= 0) return;
+    const int total = nk * NSEG;      // K-steps per tile
+    const int G = my_tiles * total;   // flattened (tile, K-step) sequence of this workgroup
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_char_ptr)smem;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // one stage = 48 wave-instructions of 1 KiB: ids 0..31 -> A, 32..47 -> B; wave w issues ids i*8 + w
+#define GEMM2_ISSUE(IT, SLOT, BM_, BN_)                                                                    \
+    {                                                                                                       \
+        const int seg_ = (NSEG == 1) ? 0 : (IT) / nk;                                                       \
+        const int kt_ = kt0 + (IT)-seg_ * nk;                                                               \
+        const unsigned sbase_ = lds_base + (SLOT)*STAGE2;                                                   \
+        _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                                     \
+            const int id = i * 8 + wave;                                                                    \
+            bool ok;                                                                                        \
+            const bf16_t* p;                                                                                \
+            if (id < 32) {                                                                                  \
+                if constexpr (!A_TR) {                                                                      \
+                    const int row = id * 8 + (lane >> 3);                                                   \
+                    p = al.ptr(seg_, (BM_)*BM2 + row, kt_ * 8 + ((lane & 7) ^ (row & 7)), ok);              \
+                } else {                                                                                    \
+                    const int k = (id & 15) * 4 + (lane >> 4);                                              \
+                    p = al.ptr(seg_, kt_ * BK + k, (BM_)*32 + (id >> 4) * 16 + ((lane & 15) ^ (tr_key(k) << 1)), ok); \
+                }                                                                                           \
+            } else {                                                                                        \
+                const int id2 = id - 32;                                                                    \
+                if constexpr (!B_TR) {                                                                      \
+                    const int row = id2 * 8 + (lane >> 3);                                                  \
+                    p = bl.ptr(seg_, (BN_)*BN + row, kt_ * 8 + ((lane & 7) ^ (row & 7)), ok);               \
+                } else {                                                                                    \
+                    const int k = id2 * 4 + (lane >> 4);                                                    \
+                    p = bl.ptr(seg_, kt_ * BK + k, (BN_)*16 + ((lane & 15) ^ (tr_key(k) << 1)), ok);        \
+                }                                                                                           \
+            }                                                                                               \
+            glds16(ok ? p : zero_page, sbase_ + id * 1024);                                                 \
+        }                                                                                                   \
+    }
+
+    // issue-side cursor (runs two K-steps ahead of the compute-side cursor, across tile boundaries)
+    int it_i = 0;
+    int tile_i = tlo + jx;
+    int bm_i = tile_i / tiles_n, bn_i = tile_i - bm_i * tiles_n;
+#define GEMM2_ADVANCE_ISSUE()                                  \
+    {                                                           \
+        if (++it_i == total) {                                  \
+            it_i = 0;                                           \
+            tile_i += nbx;                                      \
+            bm_i = tile_i / tiles_n, bn_i = tile_i - bm_i * tiles_n; \
+        }                                                       \
+    }
+    GEMM2_ISSUE(it_i, 0, bm_i, bn_i);
+    GEMM2_ADVANCE_ISSUE();
+    if (G > 1) {
+        GEMM2_ISSUE(it_i, 1, bm_i, bn_i);
+        GEMM2_ADVANCE_ISSUE();
+    }
+    int slot = 0, it_c = 0;
+    int tile_c = tlo + jx;
+    for (int g = 0; g < G; ++g) {
+        // K-step g landed for THIS wave once at most the 6 DMAs of step g+1 are outstanding (vmcnt also counts the
+        // epilogue's stores, which only makes the wait at a tile boundary conservative); the barrier then covers
+        // the other waves' pieces (RAW) and everybody's reads of the slot that is refilled next (WAR)
+        if (g + 1 < G) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        if (g + 2 < G) {
+            const int s2 = slot >= 1 ? slot - 1 : slot + 2;  // (slot + 2) % 3
+            GEMM2_ISSUE(it_i, s2, bm_i, bn_i);
+            GEMM2_ADVANCE_ISSUE();
+        }
+        const char* ta = smem + slot * STAGE2;
+        const char* tb = ta + A_BYTES2;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8_t af[4], bf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if constexpr (!A_TR) af[t] = read_frag<false>(ta, wm * 64 + t * 16, s, lane);
+                else af[t] = read_frag<true>(ta + (wm >> 1) * 16384, (wm & 1) * 64 + t * 16, s, lane);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bf[t] = read_frag<B_TR>(tb, wn * 64 + t * 16, s, lane);
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[tn], af[tm], acc[tn][tm], 0, 0, 0);
+        }
+        slot = slot == 2 ? 0 : slot + 1;
+        if (++it_c < total) continue;
+        // ---- tile finished: epilogue (next tile's first K-steps are already in flight) ----
+        it_c = 0;
+        const int bm = tile_c / tiles_n, bn = tile_c - bm * tiles_n;
+        tile_c += nbx;
+        if constexpr (EP::kStagedAtomic) {
+            // launched with one tile per workgroup: the LDS ring is idle here
+            __syncthreads();
+            float* st = reinterpret_cast<float*>(smem);  // 256 x 128 fp32 = 128 KiB
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) {
+                const int ml = wm * 64 + tm * 16 + (lane & 15);
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) {
+                    const int c4 = (wn * 64 + tn * 16 + 4 * (lane >> 4)) >> 2;
+                    *reinterpret_cast<f32x4*>(st + ml * 128 + ((c4 ^ (ml & 7)) << 2)) = acc[tn][tm];
+                }
+            }
+            __syncthreads();
+            for (int rr = wave; rr < BM2; rr += NTHR2 / 64) {
+                const int m = bm * BM2 + rr;
+                if (m >= M) break;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int nl = half * 64 + lane;
+                    const int n = bn * BN + nl;
+                    if (n < N) ep.add(m, n, st[rr * 128 + ((((nl >> 2) ^ (rr & 7)) << 2) | (nl & 3))]);
+                }
+            }
+            return;
+        } else {
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) {
+                int m = bm * BM2 + wm * 64 + tm * 16 + (lane & 15);
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) {
+                    int n = bn * BN + wn * 64 + tn * 16 + 4 * (lane >> 4);
+                    if (m < M && n < N) ep.store(m, n, acc[tn][tm]);
+                    acc[tn][tm] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            asm volatile("" ::: "memory");
+        }
+    }
+#undef GEMM2_ISSUE
+#undef GEMM2_ADVANCE_ISSUE
 }
 
 // ------------------------------------------------------------------------------------ loaders
@@ -435,22 +623,72 @@ struct EpAtomic {
 };
 
 // ------------------------------------------------------------------------------------ launch
+inline int gemm_version() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("IG_GEMM");
+        v = (e && e[0] == '1') ? 1 : 2;
+    }
+    return v;
+}
+inline const bf16_t* zero_page() {
+    static void* z = nullptr;
+    if (!z) {
+        if (hipMalloc(&z, 256) != hipSuccess) return nullptr;
+        (void)hipMemset(z, 0, 256);
+    }
+    return (const bf16_t*)z;
+}
+
 template <class AL, class BL, class EP, bool A_TR, bool B_TR>
 int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int Z, bool split, hipStream_t st,
-                const char* what, bool allow_ksplit = false) {
+                const char* what, bool allow_ksplit = false, int force_ver = 0) {
     if (M <= 0 || N <= 0 || K <= 0) return IG_OK;
-    int tm = ig_cdiv(M, BM), tn = ig_cdiv(N, BN);
+    // v2 (256x128, LDS-DMA ring) wins on the encoder linears; the head convolutions (Cout 48..384, huge M) are
+    // better served by the 128x128 register-staged tile at 2 workgroups/CU until a narrow-N tile exists
+    const int ver = force_ver ? force_ver : gemm_version();
+    const int bm_rows = ver == 2 ? BM2 : BM;
+    int tm = ig_cdiv(M, bm_rows), tn = ig_cdiv(N, BN);
     int nk_all = ig_cdiv(K, BK);
     int ksplit = 1;
-    if (allow_ksplit) {  // atomic epilogues only: aim for ~4 blocks per CU, at least 4 k-tiles per block
+    if (allow_ksplit) {  // atomic epilogues only: fill the chip once; every extra split is one more atomic pass
         int tiles = tm * tn * Z;
-        ksplit = (512 + tiles - 1) / tiles;  // ~2 workgroups per CU; every extra split is one more atomic pass
+        int slots = ver == 2 ? 256 : 512;
+        ksplit = slots / tiles;  // floor: tiles*ksplit must not spill into a second, mostly empty round
         if (ksplit > nk_all / 8) ksplit = nk_all / 8;
         if (ksplit < 1) ksplit = 1;
     }
     int kchunk = ig_cdiv(nk_all, ksplit);
     ksplit = ig_cdiv(nk_all, kchunk);
-    dim3 grid(tm * tn, ksplit, Z), block(NTHR);
+    dim3 grid(tm * tn, ksplit, Z);
+    if (ver == 2) {
+        const int ntiles = tm * tn;
+        if (!EP::kStagedAtomic && ntiles > 256) grid.x = 256;  // persistent: one workgroup per CU walks its tiles
+        const bf16_t* zp = zero_page();
+        if (!zp) {
+            ig_set_error("%s: could not allocate the zero page", what);
+            return IG_ERR_HIP;
+        }
+        if (split) {
+            auto kern = gemm2_kernel<AL, BL, EP, A_TR, B_TR, 3>;
+            static bool attr_done = false;
+            if (!attr_done) {
+                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2);
+                attr_done = true;
+            }
+            hipLaunchKernelGGL(kern, grid, dim3(NTHR2), SMEM2, st, al, bl, ep, M, N, K, tn, ntiles, kchunk, zp);
+        } else {
+            auto kern = gemm2_kernel<AL, BL, EP, A_TR, B_TR, 1>;
+            static bool attr_done = false;
+            if (!attr_done) {
+                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2);
+                attr_done = true;
+            }
+            hipLaunchKernelGGL(kern, grid, dim3(NTHR2), SMEM2, st, al, bl, ep, M, N, K, tn, ntiles, kchunk, zp);
+        }
+        return ig_check_launch(what);
+    }
+    dim3 block(NTHR);
     if (split) {
         auto kern = gemm_kernel<AL, BL, EP, A_TR, B_TR, 3>;
         static bool attr_done = false;
@@ -581,7 +819,7 @@ int ig_conv3x3_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const v
     ep.out_hi = (bf16_t*)y_hi, ep.out_lo = (bf16_t*)y_lo, ep.bias = bias, ep.ldo = Cout;
     return launch_gemm<Conv3Loader, PlainLoader, EpStore, false, false>(
         al, plain_b(w_hi, w_lo, Cout, 9 * Cin, 9L * Cin), ep, al.Mtot, Cout, 9 * Cin, 1, x_lo != nullptr,
-        (hipStream_t)stream, "ig_conv3x3_fwd");
+        (hipStream_t)stream, "ig_conv3x3_fwd", false, 1);
 }
 
 // dx = conv_dgrad(dy, w) [* dropout mask of the conv input when drop_p > 0]
@@ -603,7 +841,7 @@ int ig_conv3x3_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, con
     ep.drop_thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
     ep.drop_inv = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     return launch_gemm<Conv3Loader, ConvWgtTRLoader, EpGradStore, false, true>(
-        al, bl, ep, al.Mtot, Cin, 9 * Cout, 1, dy_lo != nullptr, (hipStream_t)stream, "ig_conv3x3_dgrad");
+        al, bl, ep, al.Mtot, Cin, 9 * Cout, 1, dy_lo != nullptr, (hipStream_t)stream, "ig_conv3x3_dgrad", false, 1);
 }
 
 // dWc[Cout][9][Cin] += sum_pixels dy[p][co] * x[shift_tap(p)][ci]
@@ -619,7 +857,7 @@ int ig_conv3x3_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, con
     EpAtomic ep{dw, 9L * Cin, 0, 0};
     return launch_gemm<PlainLoader, Conv3Loader, EpAtomic, true, true>(
         plain_a(dy_hi, dy_lo, Mtot, Cout, Cout), bl, ep, Cout, 9 * Cin, Mtot, 1, dy_lo != nullptr, (hipStream_t)stream,
-        "ig_conv3x3_wgrad", true);
+        "ig_conv3x3_wgrad", true, 1);
 }
 
 // ---- ConvTranspose2d(k=3,s=2,p=1,op=1), NHWC, weight storage Wc[Cout][9][Cin]  (model.py:361-368) ----
@@ -643,7 +881,7 @@ int ig_convT_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const voi
     ep.drop_thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
     ep.drop_inv = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     return launch_gemm<ConvTFwdALoader, ConvTFwdBLoader, EpStore, false, false>(
-        al, bl, ep, al.Mtot, Cout, 4 * Cin, 4, x_lo != nullptr, (hipStream_t)stream, "ig_convT_fwd");
+        al, bl, ep, al.Mtot, Cout, 4 * Cin, 4, x_lo != nullptr, (hipStream_t)stream, "ig_convT_fwd", false, 1);
 }
 
 // dx (H,W,Cin) = stride-2 gather of dy (2H,2W,Cout) against Wc
@@ -661,7 +899,7 @@ int ig_convT_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, const
     EpGradStore ep{};
     ep.out_hi = (bf16_t*)dx_hi, ep.out_lo = (bf16_t*)dx_lo, ep.ldo = Cin, ep.mode = 0;
     return launch_gemm<ConvTGradLoader, ConvWgtTRLoader, EpGradStore, false, true>(
-        al, bl, ep, al.Mtot, Cin, 9 * Cout, 1, dy_lo != nullptr, (hipStream_t)stream, "ig_convT_dgrad");
+        al, bl, ep, al.Mtot, Cin, 9 * Cout, 1, dy_lo != nullptr, (hipStream_t)stream, "ig_convT_dgrad", false, 1);
 }
 
 // dWc[Cout][tap][Cin] += sum_{input pixels} dy[shift_tap(p)][co] * x[p][ci]     (blockIdx.z = tap)
@@ -677,7 +915,7 @@ int ig_convT_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const
     EpAtomic ep{dw, 9L * Cin, (long)Cin, 0};
     return launch_gemm<ConvTGradLoader, PlainLoader, EpAtomic, true, true>(
         al, plain_b(x_hi, x_lo, Mtot, Cin, Cin), ep, Cout, Cin, Mtot, 9, dy_lo != nullptr, (hipStream_t)stream,
-        "ig_convT_wgrad", true);
+        "ig_convT_wgrad", true, 1);
 }
 
 }  // extern "C"
