@@ -162,8 +162,9 @@ __global__ __launch_bounds__(TPB) void layernorm_fwd_kernel(const float* __restr
 //   dgamma += sum_rows dy*xhat ; dbeta += sum_rows dy ; optional: dxb = bf16(dx), dcol += sum_rows dx
 // Each block owns ROWS_PER_BLOCK rows; each wave keeps its column partials in registers, then one
 // LDS reduction + one fp32 atomic per (block, column).
+constexpr int LNB_TPB = 256;  // measured: 4 waves x 32 rows per workgroup beats 16-row and 1024-thread variants
 template <int MAXV>
-__global__ __launch_bounds__(TPB) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy_hi, const bf16_t* __restrict__ dy_lo,
+__global__ __launch_bounds__(LNB_TPB) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy_hi, const bf16_t* __restrict__ dy_lo,
                                                             const float* __restrict__ x, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                             float* __restrict__ dx, int accumulate, bf16_t* __restrict__ dxb_hi,
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(TPB) void layernorm_bwd_kernel(const bf16_t* __rest
     for (int i = 0; i < MAXV; ++i) ag[i] = ab[i] = ac[i] = make_float4(0, 0, 0, 0);
     const int row0 = blockIdx.x * rows_per_block;
     const int row1 = min(M, row0 + rows_per_block);
-    for (int row = row0 + wave; row < row1; row += TPB / 64) {
+    for (int row = row0 + wave; row < row1; row += LNB_TPB / 64) {
         const float mu = mean[row], rs = rstd[row];
         bool zero_dy = false;
         long dbase = (long)row * D;
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(TPB) void layernorm_bwd_kernel(const bf16_t* __rest
         }
     }
     // cross-wave column reduction
-    for (int i = threadIdx.x; i < 3 * D; i += TPB) red[i] = 0.f;
+    for (int i = threadIdx.x; i < 3 * D; i += LNB_TPB) red[i] = 0.f;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(TPB) void layernorm_bwd_kernel(const bf16_t* __rest
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < D; i += TPB) {
+    for (int i = threadIdx.x; i < D; i += LNB_TPB) {
         if (dgamma) atomicAdd(dgamma + i, red[i]);
         if (dbeta) atomicAdd(dbeta + i, red[D + i]);
         if (dcol) atomicAdd(dcol + i, red[2 * D + i]);
@@ -618,15 +619,15 @@ int ig_layernorm_bwd(const void* dy_hi, const void* dy_lo, const float* x, const
     IG_REQUIRE(dy_hi && x && mean && rstd && gamma && dx, "ig_layernorm_bwd: null pointer");
     IG_REQUIRE(D % 4 == 0 && D <= 2048, "ig_layernorm_bwd: D must be a multiple of 4 and <= 2048 (got %d)", D);
     if (M == 0) return IG_OK;
-    const int rpb = 16;
+    const int rpb = 32;
     dim3 grid(ig_cdiv(M, rpb));
     size_t sm = 3 * (size_t)D * sizeof(float);
     if (D <= 1024)
-        hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, dim3(TPB), sm, ST(stream), (const bf16_t*)dy_hi, (const bf16_t*)dy_lo, x,
+        hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, dim3(LNB_TPB), sm, ST(stream), (const bf16_t*)dy_hi, (const bf16_t*)dy_lo, x,
                            mean, rstd, gamma, dx, accumulate, (bf16_t*)dxb_hi, (bf16_t*)dxb_lo, dgamma, dbeta, dcol, M, D, rpb,
                            feat_T, feat_G, ntok);
     else
-        hipLaunchKernelGGL(layernorm_bwd_kernel<8>, grid, dim3(TPB), sm, ST(stream), (const bf16_t*)dy_hi, (const bf16_t*)dy_lo, x,
+        hipLaunchKernelGGL(layernorm_bwd_kernel<8>, grid, dim3(LNB_TPB), sm, ST(stream), (const bf16_t*)dy_hi, (const bf16_t*)dy_lo, x,
                            mean, rstd, gamma, dx, accumulate, (bf16_t*)dxb_hi, (bf16_t*)dxb_lo, dgamma, dbeta, dcol, M, D, rpb,
                            feat_T, feat_G, ntok);
     return ig_check_launch("ig_layernorm_bwd");
@@ -636,7 +637,7 @@ int ig_colsum(const void* hi, const void* lo, float* out, long M, int C, void* s
     IG_REQUIRE(hi && out, "ig_colsum: null pointer");
     IG_REQUIRE(C % 8 == 0, "ig_colsum: C must be a multiple of 8 (got %d)", C);
     if (M == 0) return IG_OK;
-    const int rpb = M > 65536 ? 512 : 16;
+    const int rpb = M > 65536 ? 512 : 32;
     hipLaunchKernelGGL(colsum_kernel, dim3(ig_cdiv(M, rpb), ig_cdiv(C, 2048)), dim3(TPB), 0, ST(stream), (const bf16_t*)hi, (const bf16_t*)lo, out, M,
                        C, rpb);
     return ig_check_launch("ig_colsum");

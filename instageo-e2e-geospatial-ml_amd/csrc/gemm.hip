@@ -57,11 +57,13 @@ __device__ __forceinline__ bf16x8_t read_frag(const char* tile, int row0, int s,
     }
 }
 
-template <class AL, class BL, class EP, bool A_TR, bool B_TR, int NSEG>
+// NT = 16-column MFMA tiles per wave along n: 4 -> 128-wide block tile, 2 -> 64-wide (narrow Cout of the decode head)
+template <class AL, class BL, class EP, bool A_TR, bool B_TR, int NSEG, int NT>
 __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, int N, int K, int tiles_n, int kchunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    constexpr int BNE = NT * 32;  // effective block width
     // XCD-aware tile order: hardware deals consecutive workgroups round-robin over the 8 XCDs (private L2s);
     // remap so that each XCD owns a CONTIGUOUS run of tiles (neighbours share the A row panel / B panels).
     int bid = blockIdx.x;
@@ -81,9 +83,9 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
     if (nk <= 0) return;
     const int total = nk * NSEG;
 
-    f32x4 acc[4][4];
+    f32x4 acc[NT][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -103,11 +105,12 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
             uint4 v = *reinterpret_cast<const uint4*>(p);                                                 \
             ra[i] = ok ? v : make_uint4(0, 0, 0, 0);                                                      \
         }                                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
+        _Pragma("unroll") for (int i = 0; i < (B_TR ? 4 : NT); ++i) {                                     \
             const int u = tid + i * NTHR;                                                                 \
             bool ok;                                                                                      \
-            const bf16_t* p = B_TR ? bl.ptr(seg_, kt_ * BK + (u >> 4), bn * 16 + (u & 15), ok)            \
-                                   : bl.ptr(seg_, bn * BN + (u >> 3), kt_ * 8 + (u & 7), ok);             \
+            const bf16_t* p = B_TR ? bl.ptr(seg_, kt_ * BK + (u >> 4), bn * (BNE / 8) + (u & 15), ok)     \
+                                   : bl.ptr(seg_, bn * BNE + (u >> 3), kt_ * 8 + (u & 7), ok);            \
+            if (B_TR && NT < 4) ok = ok && ((u & 15) < BNE / 8);                                          \
             uint4 v = *reinterpret_cast<const uint4*>(p);                                                 \
             rb[i] = ok ? v : make_uint4(0, 0, 0, 0);                                                      \
         }                                                                                                 \
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
             const int oa = A_TR ? lds_tr(u >> 4, u & 15) : lds_kc(u >> 3, u & 7);                         \
             const int ob = B_TR ? lds_tr(u >> 4, u & 15) : lds_kc(u >> 3, u & 7);                         \
             *reinterpret_cast<uint4*>(ta_ + oa) = ra[i];                                                  \
-            *reinterpret_cast<uint4*>(tb_ + ob) = rb[i];                                                  \
+            if (B_TR || i < NT) *reinterpret_cast<uint4*>(tb_ + ob) = rb[i];                              \
         }                                                                                                 \
     }
 
@@ -135,13 +138,13 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
         const char* tb = ta + TILE_BYTES;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8_t af[4], bf[4];
+            bf16x8_t af[4], bf[NT];
 #pragma unroll
             for (int t = 0; t < 4; ++t) af[t] = read_frag<A_TR>(ta, wm * 64 + t * 16, s, lane);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) bf[t] = read_frag<B_TR>(tb, wn * 64 + t * 16, s, lane);
+            for (int t = 0; t < NT; ++t) bf[t] = read_frag<B_TR>(tb, wn * (NT * 16) + t * 16, s, lane);
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn)
+            for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
                 for (int tm = 0; tm < 4; ++tm)
                     acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[tn], af[tm], acc[tn][tm], 0, 0, 0);
@@ -160,8 +163,8 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
         for (int tm = 0; tm < 4; ++tm) {
             const int ml = wm * 64 + tm * 16 + (lane & 15);
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn) {
-                const int c4 = (wn * 64 + tn * 16 + 4 * (lane >> 4)) >> 2;
+            for (int tn = 0; tn < NT; ++tn) {
+                const int c4 = (wn * (NT * 16) + tn * 16 + 4 * (lane >> 4)) >> 2;
                 *reinterpret_cast<f32x4*>(st + ml * 128 + ((c4 ^ (ml & 7)) << 2)) = acc[tn][tm];
             }
         }
@@ -170,9 +173,9 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
             const int m = bm * BM + rr;
             if (m >= M) break;
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
+            for (int half = 0; half < NT / 2; ++half) {
                 const int nl = half * 64 + lane;
-                const int n = bn * BN + nl;
+                const int n = bn * BNE + nl;
                 if (n < N) ep.add(m, n, st[rr * 128 + ((((nl >> 2) ^ (rr & 7)) << 2) | (nl & 3))]);
             }
         }
@@ -184,8 +187,8 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
         int m = bm * BM + wm * 64 + tm * 16 + (lane & 15);
         if (m >= M) continue;
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-            int n = bn * BN + wn * 64 + tn * 16 + 4 * (lane >> 4);
+        for (int tn = 0; tn < NT; ++tn) {
+            int n = bn * BNE + wn * (NT * 16) + tn * 16 + 4 * (lane >> 4);
             if (n < N) ep.store(m, n, acc[tn][tm]);
         }
     }
@@ -200,6 +203,10 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
 // not drain it with vmcnt(0) at the next ds_read / barrier (cdna_hip_programming.md 5, "Pipelining across barriers").
 // ==============================================================================================
 constexpr int BM2 = 256, NTHR2 = 512;
+#ifndef IG_GM2
+#define IG_GM2 1
+#endif
+constexpr int GM2 = IG_GM2;  // row panels per L2 tile group (1 = bn-fastest; 4 measured no better at these shapes)
 constexpr int A_BYTES2 = 32768, STAGE2 = 49152, NSTAGE2 = 3, SMEM2 = STAGE2 * NSTAGE2;
 typedef __attribute__((address_space(3))) char* lds_char_ptr;
 
@@ -279,15 +286,27 @@ __global__ __launch_bounds__(NTHR2) void gemm2_kernel(AL al, BL bl, EP ep, int M
     }
 
     // issue-side cursor (runs two K-steps ahead of the compute-side cursor, across tile boundaries)
+    // tile index -> (bm, bn): column-major inside groups of GM2 row panels, so the 32 tiles an XCD works on at any
+    // time form a compact GM2 x 8 block (A panels of the group stay in that XCD's L2 while the B panels stream)
+    const int tiles_m = ntiles / tiles_n;
+#define GEMM2_TILE_COORDS(T_, BM_, BN_)                                   \
+    {                                                                      \
+        const int gsz_ = GM2 * tiles_n;                                    \
+        const int grp_ = (T_) / gsz_, r_ = (T_)-grp_ * gsz_;               \
+        const int rows_ = min(GM2, tiles_m - grp_ * GM2);                  \
+        BN_ = r_ / rows_;                                                  \
+        BM_ = grp_ * GM2 + (r_ - BN_ * rows_);                             \
+    }
     int it_i = 0;
     int tile_i = tlo + jx;
-    int bm_i = tile_i / tiles_n, bn_i = tile_i - bm_i * tiles_n;
+    int bm_i, bn_i;
+    GEMM2_TILE_COORDS(tile_i, bm_i, bn_i);
 #define GEMM2_ADVANCE_ISSUE()                                  \
     {                                                           \
         if (++it_i == total) {                                  \
             it_i = 0;                                           \
             tile_i += nbx;                                      \
-            bm_i = tile_i / tiles_n, bn_i = tile_i - bm_i * tiles_n; \
+            GEMM2_TILE_COORDS(tile_i, bm_i, bn_i);              \
         }                                                       \
     }
     GEMM2_ISSUE(it_i, 0, bm_i, bn_i);
@@ -332,7 +351,8 @@ __global__ __launch_bounds__(NTHR2) void gemm2_kernel(AL al, BL bl, EP ep, int M
         if (++it_c < total) continue;
         // ---- tile finished: epilogue (next tile's first K-steps are already in flight) ----
         it_c = 0;
-        const int bm = tile_c / tiles_n, bn = tile_c - bm * tiles_n;
+        int bm, bn;
+        GEMM2_TILE_COORDS(tile_c, bm, bn);
         tile_c += nbx;
         if constexpr (EP::kStagedAtomic) {
             // launched with one tile per workgroup: the LDS ring is idle here
@@ -375,6 +395,7 @@ __global__ __launch_bounds__(NTHR2) void gemm2_kernel(AL al, BL bl, EP ep, int M
     }
 #undef GEMM2_ISSUE
 #undef GEMM2_ADVANCE_ISSUE
+#undef GEMM2_TILE_COORDS
 }
 
 // ------------------------------------------------------------------------------------ loaders
@@ -648,7 +669,9 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, i
     // better served by the 128x128 register-staged tile at 2 workgroups/CU until a narrow-N tile exists
     const int ver = force_ver ? force_ver : gemm_version();
     const int bm_rows = ver == 2 ? BM2 : BM;
-    int tm = ig_cdiv(M, bm_rows), tn = ig_cdiv(N, BN);
+    // 64-wide tile when it wastes fewer MFMA columns than the 128-wide one (Cout = 48, 192, ...); not for atomic epilogues
+    const bool narrow = ver == 1 && !EP::kStagedAtomic && ig_cdiv(N, 64) * 64 < ig_cdiv(N, BN) * BN;
+    int tm = ig_cdiv(M, bm_rows), tn = narrow ? ig_cdiv(N, 64) : ig_cdiv(N, BN);
     int nk_all = ig_cdiv(K, BK);
     int ksplit = 1;
     if (allow_ksplit) {  // atomic epilogues only: fill the chip once; every extra split is one more atomic pass
@@ -689,23 +712,22 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, i
         return ig_check_launch(what);
     }
     dim3 block(NTHR);
-    if (split) {
-        auto kern = gemm_kernel<AL, BL, EP, A_TR, B_TR, 3>;
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-            attr_done = true;
-        }
-        hipLaunchKernelGGL(kern, grid, block, SMEM_BYTES, st, al, bl, ep, M, N, K, tn, kchunk);
-    } else {
-        auto kern = gemm_kernel<AL, BL, EP, A_TR, B_TR, 1>;
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-            attr_done = true;
-        }
-        hipLaunchKernelGGL(kern, grid, block, SMEM_BYTES, st, al, bl, ep, M, N, K, tn, kchunk);
+#define IG_LAUNCH_V1(NSEG_, NT_)                                                                                      \
+    {                                                                                                                  \
+        auto kern = gemm_kernel<AL, BL, EP, A_TR, B_TR, NSEG_, NT_>;                                                   \
+        static bool attr_done = false;                                                                                 \
+        if (!attr_done) {                                                                                              \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);      \
+            attr_done = true;                                                                                          \
+        }                                                                                                              \
+        hipLaunchKernelGGL(kern, grid, block, SMEM_BYTES, st, al, bl, ep, M, N, K, tn, kchunk);                        \
     }
+    if (narrow) {
+        if (split) IG_LAUNCH_V1(3, 2) else IG_LAUNCH_V1(1, 2)
+    } else {
+        if (split) IG_LAUNCH_V1(3, 4) else IG_LAUNCH_V1(1, 4)
+    }
+#undef IG_LAUNCH_V1
     return ig_check_launch(what);
 }
 

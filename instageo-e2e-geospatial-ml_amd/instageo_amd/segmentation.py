@@ -316,6 +316,42 @@ class PrithviSegmentationModule(_Base):
         acc[1] += 1
         return stats
 
+    def make_graphed_train_step(self, inputs: torch.Tensor, labels: torch.Tensor):
+        """Capture :meth:`fused_train_step` into one hipGraph (single-process only: no collectives inside).
+
+        Returns ``run(inputs, labels) -> stats``: copies the batch into the graph's static buffers and replays ~250
+        kernel launches with one host call.  Everything the step needs is device resident (AdamW step counter and
+        bias corrections, dropout seed counter, loss statistics), so replays need no host-side scalars.
+        """
+        assert self.grad_sync is None, "graph capture is for the single-GPU path (RCCL calls are not captured)"
+        static_x = inputs.clone()
+        static_y = labels.clone()
+        stats = torch.zeros(2, dtype=torch.float64, device=inputs.device)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # warm-up on a side stream: allocates workspaces, sets kernel attributes
+            for _ in range(2):
+                self.fused_train_step(static_x, static_y, stats)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.fused_train_step(static_x, static_y, stats)
+        opt = self.optimizer()
+
+        def run(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+            if opt.param_groups[0]["lr"] != opt._lr_written:  # scheduler changed the LR: one scalar write, outside the graph
+                opt.hyper[0] = float(opt.param_groups[0]["lr"])
+                opt._lr_written = opt.param_groups[0]["lr"]
+            static_x.copy_(x)
+            static_y.copy_(y)
+            graph.replay()
+            opt._host_step += 1
+            return stats
+
+        run.graph = graph
+        return run
+
     @torch.no_grad()
     def fused_eval_step(self, inputs: torch.Tensor, labels: torch.Tensor, step_type: str = "val") -> torch.Tensor:
         net, eng = self.net, self.net.engine
