@@ -31,6 +31,18 @@ MEAN = [0.14245495, 0.13921481, 0.12434631, 0.31420089, 0.20743526, 0.12046503] 
 STD = [0.04036231, 0.04186983, 0.05267646, 0.0822221, 0.06834774, 0.05294205]
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 FLOP_PER_CHIP_FWD = 47.85e9  # 100M, T=1, 2 classes
+
+
+def flop_per_chip_fwd(D: int, L: int, T: int, ncls: int) -> float:
+    """blocks 24*N*D^2 + 4*N^2*D, patch embed, 4 head stages, classifier."""
+    N = 1 + 196 * T
+    enc = L * (24.0 * N * D * D + 4.0 * N * N * D) + 2.0 * (196 * T) * 1536 * D
+    head = 0.0
+    for i in range(4):
+        cin, hin = D * T / 2**i, 14 * 2**i
+        cout = cin / 2
+        head += 2 * cin * cout * 9 * hin**2 + 2 * cout * cout * 9 * (2 * hin) ** 2
+    return enc + head + 2.0 * (D * T / 16) * ncls * 224**2
 GEMM_OPS = ["ig_linear_fwd", "ig_linear_residual_fwd", "ig_linear_dgrad", "ig_linear_wgrad", "ig_attention_fwd", "ig_attention_bwd",
             "ig_convT_fwd", "ig_convT_dgrad", "ig_convT_wgrad", "ig_conv3x3_fwd", "ig_conv3x3_dgrad", "ig_conv3x3_wgrad",
             "ig_patch_embed_fwd"]  # fmt: skip
@@ -85,6 +97,9 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=54, help="chips per GPU per step")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
+    ap.add_argument("--model", default="prithvi_eo_v1_100", help="variant (other BASELINE configs: prithvi_eo_v2_300)")
+    ap.add_argument("--temporal", type=int, default=1, help="T: 1 = configs[1] (default), 3 = configs[2] multi-temporal crop")
+    ap.add_argument("--classes", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP events (roofline objects become null)")
     ap.add_argument("--graph", action="store_true", help="replay the train step from one captured hipGraph (N=1 only; implies --no-profile)")
@@ -102,31 +117,35 @@ def main() -> None:
     torch.manual_seed(1042 + rank)
 
     B = args.batch
+    T, NCLS = args.temporal, args.classes
+    from oracle.cases import CROP_WEIGHTS  # data only (class weights of multitemporal_crop_classification.yaml)
+
+    cw = [1, 3] if NCLS == 2 else (CROP_WEIGHTS if NCLS == 13 else [1.0] * NCLS)
     mod = PrithviSegmentationModule(image_size=224, learning_rate=1e-4, freeze_backbone=False, load_pretrained_weights=False,
-                                    num_classes=2, temporal_step=1, class_weights=[1, 3], ignore_index=-1, weight_decay=0.01,
-                                    scheduler=False, model_name="prithvi_eo_v1_100", precision=args.precision, device=dev)  # fmt: skip
+                                    num_classes=NCLS, temporal_step=T, class_weights=cw, ignore_index=-1, weight_decay=0.01,
+                                    scheduler=False, model_name=args.model, precision=args.precision, device=dev)  # fmt: skip
     D.attach_data_parallel(mod)
     mean = torch.tensor(MEAN, device=dev)
     std = torch.tensor(STD, device=dev)
     nb = 4  # resident synthetic batches (raw int16 HLS domain), cycled
     g = torch.Generator(device=dev).manual_seed(1042 + rank)
-    raws = [torch.randint(0, 10000, (B, 6, 224, 224), generator=g, device=dev, dtype=torch.int16) for _ in range(nb)]
+    raws = [torch.randint(0, 10000, (B, 6 * T, 224, 224), generator=g, device=dev, dtype=torch.int16) for _ in range(nb)]
     labels = []
     for _ in range(nb):
-        y = torch.randint(0, 2, (B, 224, 224), generator=g, device=dev)
+        y = torch.randint(0, NCLS, (B, 224, 224), generator=g, device=dev)
         y[torch.rand((B, 224, 224), generator=g, device=dev) < 0.05] = -1
         labels.append(y)
-    xbuf = torch.empty((B, 6, 1, 224, 224), dtype=torch.float32, device=dev)
+    xbuf = torch.empty((B, 6, T, 224, 224), dtype=torch.float32, device=dev)
     stats = torch.zeros(2, dtype=torch.float64, device=dev)
 
     graphed = None
     if args.graph and world == 1:
         args.no_profile = True
-        ops.normalize_chips(raws[0], mean, std, 1, 1e-4, out=xbuf)
+        ops.normalize_chips(raws[0], mean, std, T, 1e-4, out=xbuf)
         graphed = mod.make_graphed_train_step(xbuf, labels[0])
 
     def train_step(i: int) -> None:
-        ops.normalize_chips(raws[i % nb], mean, std, 1, 1e-4, out=xbuf)
+        ops.normalize_chips(raws[i % nb], mean, std, T, 1e-4, out=xbuf)
         if graphed is not None:
             stats.copy_(graphed(xbuf, labels[i % nb]))
         else:
@@ -165,7 +184,7 @@ def main() -> None:
     pred = torch.empty((B, 224, 224), dtype=torch.int8, device=dev)
 
     def infer_step(i: int) -> None:
-        ops.normalize_chips(raws[i % nb], mean, std, 1, 1e-4, out=xbuf)
+        ops.normalize_chips(raws[i % nb], mean, std, T, 1e-4, out=xbuf)
         logits = mod.net.engine.forward(xbuf, training=False, save=False)
         ops.argmax_i8(logits, pred)
 
@@ -189,8 +208,10 @@ def main() -> None:
         return
 
     value = world * B * args.steps / dt
+    cfgm = mod.net.cfg
+    fpc = flop_per_chip_fwd(cfgm.embed_dim, cfgm.depth, T, NCLS)
     out = {
-        "metric": "HLS chips/sec (train fwd+bwd+AdamW), Prithvi-100M 224x224x6 T=1",
+        "metric": f"HLS chips/sec (train fwd+bwd+AdamW), {args.model} 224x224x6 T={T}",
         "value": round(value, 2),
         "unit": "chips/s",
         "n_gpus": world,
@@ -202,14 +223,17 @@ def main() -> None:
         "vs_baseline": None,
         "dtype": args.precision,
         "data": "synthetic",
-        "config": {"workload": "BASELINE.json configs[1]: Prithvi-100M fine-tune, Sen1Floods11-shaped synthetic int16 chips "
-                               "(6 bands, T=1, 224x224, 2 classes, class_weights [1,3], ignore_index -1, dropout 0.1), random-init weights",
+        "config": {"workload": ("BASELINE.json configs[1]: Prithvi-100M fine-tune, Sen1Floods11-shaped synthetic int16 chips "
+                                "(6 bands, T=1, 224x224, 2 classes, class_weights [1,3], ignore_index -1, dropout 0.1), random-init weights")
+                   if (T, NCLS, args.model) == (1, 2, "prithvi_eo_v1_100") else
+                   f"{args.model} T={T} {NCLS} classes, synthetic int16 chips, dropout 0.1, random-init weights",
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "optimizer": "AdamW lr 1e-4 wd 1e-2",
                    "launch": "hipGraph" if graphed is not None else "eager",
                    "final_loss": round(loss, 5)},  # fmt: skip
-        "mfma_frac_whole_step": round(value / world * 3 * FLOP_PER_CHIP_FWD / (PEAK_BF16_TFLOPS * 1e12), 4),
+        "mfma_frac_whole_step": round(value / world * 3 * fpc / (PEAK_BF16_TFLOPS * 1e12), 4),
+        "gflop_per_chip_fwd": round(fpc / 1e9, 2),
         "inference": {"value": round(world * B * args.steps / dti, 2), "unit": "chips/s", "ms_per_step": round(1e3 * dti / args.steps, 3),
-                      "mfma_frac": round(B * args.steps / dti * FLOP_PER_CHIP_FWD / (PEAK_BF16_TFLOPS * 1e12), 4)},  # fmt: skip
+                      "mfma_frac": round(B * args.steps / dti * fpc / (PEAK_BF16_TFLOPS * 1e12), 4)},  # fmt: skip
     }
     if prof is not None:
         def table(p):

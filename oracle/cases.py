@@ -15,6 +15,7 @@ CASES = {
     "tiny_t3_c13": ("prithvi_eo_tiny", 3, 13, 2, -1),
     "v1_100_t1_c2": ("prithvi_eo_v1_100", 1, 2, 4, -1),  # BASELINE.json configs[0]
     "v1_100_t3_c13": ("prithvi_eo_v1_100", 3, 13, 1, -1),
+    "v2_300_t1_c2": ("prithvi_eo_v2_300", 1, 2, 1, -1),  # BASELINE.json configs[4] architecture (D=1024, L=24, 16 heads)
 }
 
 # instageo/model/configs/multitemporal_crop_classification.yaml:15-30

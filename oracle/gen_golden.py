@@ -174,7 +174,7 @@ def main() -> None:
         # fp32 autograd noise on these gradients is ~3e-3 relative (train-mode BN backward
         # cancellations), so the restatement is pinned in fp64 (agreement ~1e-15) and the
         # fixture stores the fp64 gradients plus the fp32 run's own distance from them.
-        if not name.startswith("v1_100_t3"):
+        if not (name.startswith("v1_100_t3") or name.startswith("v2_300")):
             cw = class_weights_for(ncls)
 
             def ref_train(dt):

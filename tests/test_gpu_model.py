@@ -43,7 +43,7 @@ def report(tag, got, ref):
     return d.max().item(), d.mean().item()
 
 
-@pytest.mark.parametrize("name", ["tiny_t1_c2", "tiny_t3_c13", "v1_100_t1_c2", "v1_100_t3_c13"])
+@pytest.mark.parametrize("name", ["tiny_t1_c2", "tiny_t3_c13", "v1_100_t1_c2", "v1_100_t3_c13", "v2_300_t1_c2"])
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
 def test_eval_logits_parity(name, precision):
     cfg, sd, net, img, lab = build(name, precision)
