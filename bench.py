@@ -60,6 +60,9 @@ def cpu_baseline(target_s: float = 12.0) -> dict:
     from oracle import prithvi_oracle as O
     from oracle.cases import class_weights_for
 
+    # a batch of 4 chips does not scale to 100+ threads (MKL/oneDNN oversubscription made it 4x slower than 8 threads)
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+
     cfg = O.make_config("prithvi_eo_v1_100", 1, 2)
     sd = O.make_state_dict(cfg, seed=1042)
     B = 4
@@ -248,6 +251,16 @@ def main() -> None:
         out["roofline"] = {"kernel": KERNEL_OF.get(dom, dom), "entry_point": dom, "bound": "mfma", "achieved": round(ach, 1),
                            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
                            "launches": n, "avg_launch_us": round(1e3 * ms / n, 2), "flops_per_launch": work / n}  # fmt: skip
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_bench_b54.json")
+        if os.path.exists(pmc_path) and B == 54 and (T, NCLS, args.model) == (1, 2, "prithvi_eo_v1_100"):
+            # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+            # (tools: see DESIGN.md 6); FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md
+            pmc = json.load(open(pmc_path))
+            key = KERNEL_OF.get(dom, dom).replace(",", ", ")
+            ent = next((v for k, v in pmc.items() if k.replace(" ", "") == key.replace(" ", "")), None)
+            if ent:
+                out["roofline"]["traffic"] = round((2 * ent["fetch_kb_raw"] + ent["write_kb"]) * 1024)
+                out["roofline"]["traffic_note"] = "bytes/launch, offline PMC passes (profiles/r01_pmc_bench_b54.json)"
         out["roofline_timed_region"] = timed
         out["roofline_all"] = allk  # separate untimed pass (3 steps) with events on every MFMA entry point
     if world == 1 and not args.no_cpu_baseline:

@@ -56,9 +56,10 @@ int ig_linear_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const vo
 /* timm Block residual linears (proj / fc2): out = resid + x @ w^T + b (fp32 residual stream)          :446-456 */
 int ig_linear_residual_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
                            const float* resid, float* out, int M, int N, int K, void* stream);
-/* dx = dy @ w  (mode 1: * gelu'(pre)) ; dw += dy^T @ x (fp32 atomics) */
+/* dx = dy @ w  (mode 1: * gelu'(pre)); optional dx_colsum[k] += sum_m dx[m][k] (bias grad of the producing layer);
+ * dw += dy^T @ x (fp32 atomics) */
 int ig_linear_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, const void* w_lo, void* dx_hi, void* dx_lo,
-                    const void* pre_hi, const void* pre_lo, int M, int N, int K, int mode, void* stream);
+                    const void* pre_hi, const void* pre_lo, float* dx_colsum, int M, int N, int K, int mode, void* stream);
 int ig_linear_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const void* x_lo, float* dw, int M, int N, int K,
                     void* stream);
 /* F.scaled_dot_product_attention of timm Attention: qkv [B][N][3][H][64] -> out [B][N][H*64], lse [B][H][N] */

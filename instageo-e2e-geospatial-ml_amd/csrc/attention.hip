@@ -16,6 +16,11 @@ namespace {
 constexpr int HD = 64;
 constexpr int KT = 32;                 // streamed rows per tile
 constexpr int TILE = KT * HD * 2;      // 4 KiB per bf16 tile
+// tiles streamed per barrier pair: one cooperative load + 2 barriers now cover 128 (64 in split mode) rows
+template <bool SPLIT>
+struct Ntl {
+    static constexpr int v = SPLIT ? 2 : 4;
+};
 
 __device__ __forceinline__ int lds_kc(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
 
@@ -89,11 +94,12 @@ template <bool SPLIT>
 __global__ __launch_bounds__(1024) void attn_fwd_kernel(const bf16_t* __restrict__ qkv_hi, const bf16_t* __restrict__ qkv_lo,
                                                         bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo,
                                                         float* __restrict__ lse, int N, int H, float scale) {
-    __shared__ __attribute__((aligned(16))) char smem[SPLIT ? 4 * TILE : 2 * TILE];
-    char* k_hi = smem;
-    char* v_hi = smem + TILE;
-    char* k_lo = smem + 2 * TILE;  // only SPLIT
-    char* v_lo = smem + 3 * TILE;
+    constexpr int NTL = Ntl<SPLIT>::v;
+    __shared__ __attribute__((aligned(16))) char smem[(SPLIT ? 4 : 2) * NTL * TILE];
+    char* k_hi0 = smem;
+    char* v_hi0 = smem + NTL * TILE;
+    char* k_lo0 = smem + 2 * NTL * TILE;  // only SPLIT
+    char* v_lo0 = smem + 3 * NTL * TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int h = blockIdx.y, b = blockIdx.z;
     const long RS = 3L * H * HD;
@@ -114,15 +120,20 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(const bf16_t* __restrict
     float m_run = -INFINITY, l_run = 0.f;
 
     const int ntiles = (N + KT - 1) / KT;
-    for (int kt = 0; kt < ntiles; ++kt) {
-        __syncthreads();  // previous tile fully consumed
-        load_tile(k_hi, base_hi + H * HD, RS, kt * KT, N, tid, blockDim.x);
-        load_tile(v_hi, base_hi + 2 * H * HD, RS, kt * KT, N, tid, blockDim.x);
-        if constexpr (SPLIT) {
-            load_tile(k_lo, base_lo + H * HD, RS, kt * KT, N, tid, blockDim.x);
-            load_tile(v_lo, base_lo + 2 * H * HD, RS, kt * KT, N, tid, blockDim.x);
+    for (int kt0 = 0; kt0 < ntiles; kt0 += NTL) {
+        __syncthreads();  // previous tiles fully consumed
+        for (int j = 0; j < NTL && kt0 + j < ntiles; ++j) {
+            load_tile(k_hi0 + j * TILE, base_hi + H * HD, RS, (kt0 + j) * KT, N, tid, blockDim.x);
+            load_tile(v_hi0 + j * TILE, base_hi + 2 * H * HD, RS, (kt0 + j) * KT, N, tid, blockDim.x);
+            if constexpr (SPLIT) {
+                load_tile(k_lo0 + j * TILE, base_lo + H * HD, RS, (kt0 + j) * KT, N, tid, blockDim.x);
+                load_tile(v_lo0 + j * TILE, base_lo + 2 * H * HD, RS, (kt0 + j) * KT, N, tid, blockDim.x);
+            }
         }
         __syncthreads();
+        for (int j = 0; j < NTL && kt0 + j < ntiles; ++j) {
+        const int kt = kt0 + j;
+        const char *k_hi = k_hi0 + j * TILE, *v_hi = v_hi0 + j * TILE, *k_lo = k_lo0 + j * TILE, *v_lo = v_lo0 + j * TILE;
         // S^T[key][q] for two 16-key sub-tiles
         f32x4 st[2];
 #pragma unroll
@@ -173,6 +184,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(const bf16_t* __restrict
             bf16x8_t vl = SPLIT ? frag_tr(v_lo, dt * 16, lane) : vh;
             o[dt] = mma<SPLIT>(vh, vl, ph, pl, o[dt]);
         }
+        }  // j
     }
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
@@ -221,11 +233,12 @@ __global__ __launch_bounds__(1024) void attn_bwd_dq_kernel(const bf16_t* __restr
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            bf16_t* __restrict__ dqkv_hi, bf16_t* __restrict__ dqkv_lo, int N, int H,
                                                            float scale) {
-    __shared__ __attribute__((aligned(16))) char smem[SPLIT ? 4 * TILE : 2 * TILE];
-    char* k_hi = smem;
-    char* v_hi = smem + TILE;
-    char* k_lo = smem + 2 * TILE;
-    char* v_lo = smem + 3 * TILE;
+    constexpr int NTL = Ntl<SPLIT>::v;
+    __shared__ __attribute__((aligned(16))) char smem[(SPLIT ? 4 : 2) * NTL * TILE];
+    char* k_hi0 = smem;
+    char* v_hi0 = smem + NTL * TILE;
+    char* k_lo0 = smem + 2 * NTL * TILE;
+    char* v_lo0 = smem + 3 * NTL * TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int h = blockIdx.y, b = blockIdx.z;
     const long RS = 3L * H * HD, OS = (long)H * HD;
@@ -252,15 +265,20 @@ __global__ __launch_bounds__(1024) void attn_bwd_dq_kernel(const bf16_t* __restr
     for (int i = 0; i < 4; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int ntiles = (N + KT - 1) / KT;
-    for (int kt = 0; kt < ntiles; ++kt) {
+    for (int kt0 = 0; kt0 < ntiles; kt0 += NTL) {
         __syncthreads();
-        load_tile(k_hi, base_hi + H * HD, RS, kt * KT, N, tid, blockDim.x);
-        load_tile(v_hi, base_hi + 2 * H * HD, RS, kt * KT, N, tid, blockDim.x);
-        if constexpr (SPLIT) {
-            load_tile(k_lo, base_lo + H * HD, RS, kt * KT, N, tid, blockDim.x);
-            load_tile(v_lo, base_lo + 2 * H * HD, RS, kt * KT, N, tid, blockDim.x);
+        for (int j = 0; j < NTL && kt0 + j < ntiles; ++j) {
+            load_tile(k_hi0 + j * TILE, base_hi + H * HD, RS, (kt0 + j) * KT, N, tid, blockDim.x);
+            load_tile(v_hi0 + j * TILE, base_hi + 2 * H * HD, RS, (kt0 + j) * KT, N, tid, blockDim.x);
+            if constexpr (SPLIT) {
+                load_tile(k_lo0 + j * TILE, base_lo + H * HD, RS, (kt0 + j) * KT, N, tid, blockDim.x);
+                load_tile(v_lo0 + j * TILE, base_lo + 2 * H * HD, RS, (kt0 + j) * KT, N, tid, blockDim.x);
+            }
         }
         __syncthreads();
+        for (int j = 0; j < NTL && kt0 + j < ntiles; ++j) {
+        const int kt = kt0 + j;
+        const char *k_hi = k_hi0 + j * TILE, *v_hi = v_hi0 + j * TILE, *k_lo = k_lo0 + j * TILE, *v_lo = v_lo0 + j * TILE;
         f32x4 ds[2];
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -291,6 +309,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_dq_kernel(const bf16_t* __restr
             bf16x8_t kl = SPLIT ? frag_tr(k_lo, dt * 16, lane) : kh;
             dq[dt] = mma<SPLIT>(kh, kl, sh, sl, dq[dt]);
         }
+        }  // j
     }
     if (q < N) {
         long orow = ((long)b * N + q) * RS + h * HD;  // q slot of dqkv
@@ -311,13 +330,14 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_kernel(const bf16_t* __rest
                                                             const float* __restrict__ lse, const float* __restrict__ delta,
                                                             bf16_t* __restrict__ dqkv_hi, bf16_t* __restrict__ dqkv_lo, int N, int H,
                                                             float scale) {
-    __shared__ __attribute__((aligned(16))) char smem[(SPLIT ? 4 * TILE : 2 * TILE) + 2 * KT * 4];
-    char* q_hi = smem;
-    char* d_hi = smem + TILE;
-    char* q_lo = smem + 2 * TILE;
-    char* d_lo = smem + 3 * TILE;
-    float* s_lse = reinterpret_cast<float*>(smem + (SPLIT ? 4 * TILE : 2 * TILE));
-    float* s_del = s_lse + KT;
+    constexpr int NTL = Ntl<SPLIT>::v;
+    __shared__ __attribute__((aligned(16))) char smem[(SPLIT ? 4 : 2) * NTL * TILE + 2 * NTL * KT * 4];
+    char* q_hi0 = smem;
+    char* d_hi0 = smem + NTL * TILE;
+    char* q_lo0 = smem + 2 * NTL * TILE;
+    char* d_lo0 = smem + 3 * NTL * TILE;
+    float* s_lse0 = reinterpret_cast<float*>(smem + (SPLIT ? 4 : 2) * NTL * TILE);
+    float* s_del0 = s_lse0 + NTL * KT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int h = blockIdx.y, b = blockIdx.z;
     const long RS = 3L * H * HD, OS = (long)H * HD;
@@ -341,20 +361,25 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_kernel(const bf16_t* __rest
     for (int i = 0; i < 4; ++i) dk[i] = dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int ntiles = (N + KT - 1) / KT;
-    for (int qt = 0; qt < ntiles; ++qt) {
+    for (int qt0 = 0; qt0 < ntiles; qt0 += NTL) {
         __syncthreads();
-        load_tile(q_hi, base_hi, RS, qt * KT, N, tid, blockDim.x);
-        load_tile(d_hi, dob_hi, OS, qt * KT, N, tid, blockDim.x);
-        if constexpr (SPLIT) {
-            load_tile(q_lo, base_lo, RS, qt * KT, N, tid, blockDim.x);
-            load_tile(d_lo, dob_lo, OS, qt * KT, N, tid, blockDim.x);
+        for (int j = 0; j < NTL && qt0 + j < ntiles; ++j) {
+            load_tile(q_hi0 + j * TILE, base_hi, RS, (qt0 + j) * KT, N, tid, blockDim.x);
+            load_tile(d_hi0 + j * TILE, dob_hi, OS, (qt0 + j) * KT, N, tid, blockDim.x);
+            if constexpr (SPLIT) {
+                load_tile(q_lo0 + j * TILE, base_lo, RS, (qt0 + j) * KT, N, tid, blockDim.x);
+                load_tile(d_lo0 + j * TILE, dob_lo, OS, (qt0 + j) * KT, N, tid, blockDim.x);
+            }
         }
-        if (tid < KT) {
-            int qq = qt * KT + tid;
-            s_lse[tid] = qq < N ? lse[((long)b * H + h) * N + qq] : INFINITY;
-            s_del[tid] = qq < N ? delta[((long)b * H + h) * N + qq] : 0.f;
+        if (tid < NTL * KT) {
+            int qq = qt0 * KT + tid;
+            s_lse0[tid] = qq < N ? lse[((long)b * H + h) * N + qq] : INFINITY;
+            s_del0[tid] = qq < N ? delta[((long)b * H + h) * N + qq] : 0.f;
         }
         __syncthreads();
+        for (int j = 0; j < NTL && qt0 + j < ntiles; ++j) {
+        const char *q_hi = q_hi0 + j * TILE, *d_hi = d_hi0 + j * TILE, *q_lo = q_lo0 + j * TILE, *d_lo = d_lo0 + j * TILE;
+        const float *s_lse = s_lse0 + j * KT, *s_del = s_del0 + j * KT;
         f32x4 pp[2], ds[2];
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -389,6 +414,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_kernel(const bf16_t* __rest
             bf16x8_t ul = SPLIT ? frag_tr(q_lo, dt * 16, lane) : uh;
             dk[dt] = mma<SPLIT>(uh, ul, sh, sl, dk[dt]);
         }
+        }  // j
     }
     const int key = k0 + (lane & 15);
     if (key < N) {

@@ -510,6 +510,7 @@ __global__ void bn_bwd_apply_kernel(const bf16_t* __restrict__ xh, const bf16_t*
 // hyper (device): [0]=lr [1]=beta1 [2]=beta2 [3]=eps [4]=weight_decay [5]=bias_corr1 [6]=sqrt(bias_corr2)
 //                 [7]=clip_lo [8]=clip_hi [9]=clip_enabled  [10]=step (as float)
 //                 [11]=1-beta1 [12]=1-beta2 (host computes them in double like torch does)
+//                 [13]=gradient scale (1/world_size after a SUM all-reduce; 0 is treated as 1)
 // ----------------------------------------------------------------------------------------------
 __global__ void adamw_advance_kernel(float* hyper) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -524,6 +525,7 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     const float lr = hyper[0], b2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5], bc2s = hyper[6];
     const float clo = hyper[7], chi = hyper[8];
     const float omb1 = hyper[11], omb2 = hyper[12];
+    const float gscale = hyper[13] == 0.f ? 1.f : hyper[13];
     const bool clip = hyper[9] != 0.f;
     const float step_size = lr / bc1;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -531,7 +533,7 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
         float4 G = reinterpret_cast<const float4*>(g)[i];
         float4 Mv = reinterpret_cast<float4*>(m)[i];
         float4 V = reinterpret_cast<float4*>(v)[i];
-        float pp[4] = {P.x, P.y, P.z, P.w}, gg[4] = {G.x, G.y, G.z, G.w}, mm[4] = {Mv.x, Mv.y, Mv.z, Mv.w},
+        float pp[4] = {P.x, P.y, P.z, P.w}, gg[4] = {G.x * gscale, G.y * gscale, G.z * gscale, G.w * gscale}, mm[4] = {Mv.x, Mv.y, Mv.z, Mv.w},
               vv[4] = {V.x, V.y, V.z, V.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {

@@ -380,14 +380,37 @@ __global__ __launch_bounds__(NTHR2) void gemm2_kernel(AL al, BL bl, EP ep, int M
             }
             return;
         } else {
+            f32x4 cs[4];  // per-lane partial column sums (4 consecutive n per n-tile) over this wave's 64 rows
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) cs[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int tm = 0; tm < 4; ++tm) {
                 int m = bm * BM2 + wm * 64 + tm * 16 + (lane & 15);
 #pragma unroll
                 for (int tn = 0; tn < 4; ++tn) {
                     int n = bn * BN + wn * 64 + tn * 16 + 4 * (lane >> 4);
-                    if (m < M && n < N) ep.store(m, n, acc[tn][tm]);
+                    if (m < M && n < N) {
+                        if constexpr (EP::kColSum) cs[tn] += ep.store_ret(m, n, acc[tn][tm]);
+                        else ep.store(m, n, acc[tn][tm]);
+                    }
                     acc[tn][tm] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            if constexpr (EP::kColSum) {
+                if (ep.colsum) {  // wave-uniform: reduce over the 16 lanes that share (lane >> 4), one atomic per column
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn) {
+                        const int n = bn * BN + wn * 64 + tn * 16 + 4 * (lane >> 4);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            float v = cs[tn][c];
+                            v += __shfl_xor(v, 1, 64);
+                            v += __shfl_xor(v, 2, 64);
+                            v += __shfl_xor(v, 4, 64);
+                            v += __shfl_xor(v, 8, 64);
+                            if ((lane & 15) == 0 && n + c < N) atomicAdd(ep.colsum + n + c, v);
+                        }
+                    }
                 }
             }
             asm volatile("" ::: "memory");
@@ -520,6 +543,7 @@ struct ConvTGradLoader {
 // ---------------------------------------------------------------------------------- epilogues
 // bf16/split store: out = drop(act(acc + bias)); optional pre-activation copy; optional ConvT phase row map
 struct EpStore {
+    static constexpr bool kColSum = false;
     static constexpr bool kStagedAtomic = false;
     bf16_t *out_hi, *out_lo;
     bf16_t *pre_hi, *pre_lo;
@@ -565,6 +589,8 @@ struct EpStore {
 // dgrad store with an elementwise factor: mode 1: * gelu'(pre[m][n]); mode 2: * dropout mask(idx)
 struct EpGradStore {
     static constexpr bool kStagedAtomic = false;
+    static constexpr bool kColSum = true;  // optional fused column sums of the stored values (bias gradient)
+    float* colsum;
     bf16_t *out_hi, *out_lo;
     const bf16_t *pre_hi, *pre_lo;
     long ldo;
@@ -575,7 +601,7 @@ struct EpGradStore {
     __device__ void init(int) {
         if (drop_seed_dev) drop_seed += *drop_seed_dev;
     }
-    __device__ void store(int m, int n, f32x4 a) const {
+    __device__ f32x4 store_ret(int m, int n, f32x4 a) const {
         size_t idx = (size_t)m * ldo + n;
         float v[4] = {a[0], a[1], a[2], a[3]};
         if (mode == 1) {
@@ -586,11 +612,14 @@ struct EpGradStore {
             for (int i = 0; i < 4; ++i) v[i] *= dropout_scale(drop_seed, idx + i, drop_thresh, drop_inv);
         }
         store4_split(out_hi, out_lo, idx, v);
+        return f32x4{v[0], v[1], v[2], v[3]};
     }
+    __device__ void store(int m, int n, f32x4 a) const { (void)store_ret(m, n, a); }
 };
 
 // fp32 residual: out[m][n] = resid[m][n] + acc + bias[n]
 struct EpResidual {
+    static constexpr bool kColSum = false;
     static constexpr bool kStagedAtomic = false;
     float* out;
     const float* resid;
@@ -608,6 +637,7 @@ struct EpResidual {
 
 // patch embed: token row m=(b, tp) -> x[b*Ntok + 1 + tp][n] = acc + bias[n] + pos[1+tp][n]   (pritvhi.py:513-517)
 struct EpPatchEmbed {
+    static constexpr bool kColSum = false;
     static constexpr bool kStagedAtomic = false;
     float* x;
     const float* bias;
@@ -627,6 +657,7 @@ struct EpPatchEmbed {
 
 // wgrad: fp32 atomic accumulate into the gradient buffer; column offset z*zstride (ConvT taps)
 struct EpAtomic {
+    static constexpr bool kColSum = false;
     static constexpr bool kStagedAtomic = true;
     float* out;
     long ldo;
@@ -788,7 +819,7 @@ int ig_linear_residual_fwd(const void* x_hi, const void* x_lo, const void* w_hi,
 
 // dx[M][K] = dy[M][N] @ w[N][K]       mode 0: plain store, 1: * gelu'(pre[M][K])
 int ig_linear_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, const void* w_lo, void* dx_hi, void* dx_lo,
-                    const void* pre_hi, const void* pre_lo, int M, int N, int K, int mode, void* stream) {
+                    const void* pre_hi, const void* pre_lo, float* dx_colsum, int M, int N, int K, int mode, void* stream) {
     IG_REQUIRE(dy_hi && w_hi && dx_hi, "ig_linear_dgrad: null pointer");
     IG_REQUIRE(N % 8 == 0 && K % 8 == 0, "ig_linear_dgrad: N and K must be multiples of 8");
     IG_REQUIRE(mode == 0 || (mode == 1 && pre_hi), "ig_linear_dgrad: mode 1 needs the pre-activation tensor");
@@ -796,6 +827,7 @@ int ig_linear_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, cons
     EpGradStore ep{};
     ep.out_hi = (bf16_t*)dx_hi, ep.out_lo = (bf16_t*)dx_lo, ep.pre_hi = (const bf16_t*)pre_hi, ep.pre_lo = (const bf16_t*)pre_lo;
     ep.ldo = K, ep.mode = mode;
+    ep.colsum = dx_colsum;  // optional: dx_colsum[k] += sum_m dx[m][k] (bias gradient of the layer that produced x)
     // C[m][k] = sum_n dy[m][n] * w[n][k]: reduce dim = N; B operand is TR (rows n, contiguous k)
     return launch_gemm<PlainLoader, PlainLoader, EpGradStore, false, true>(
         plain_a(dy_hi, dy_lo, M, N, N), plain_b(w_hi, w_lo, N, K, K), ep, M, K, N, 1, dy_lo != nullptr, (hipStream_t)stream,

@@ -31,6 +31,10 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # functional testing of the multi-rank path on a one-GPU box: IG_DIST_BACKEND=gloo IG_SINGLE_DEVICE=1
+    backend = backend or os.environ.get("IG_DIST_BACKEND") or None
+    if os.environ.get("IG_SINGLE_DEVICE") == "1":
+        local_rank = 0
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -65,7 +69,7 @@ class GradSync:
     stream wait for all reductions (then divides by the world size when the backend has no AVG).
     """
 
-    def __init__(self, get_grad: Callable[[], torch.Tensor], bucket_bytes: int = 32 << 20, group=None):
+    def __init__(self, get_grad: Callable[[], torch.Tensor], bucket_bytes: int = 32 << 20, group=None, scale_in_optimizer: bool = False):
         self.get_grad = get_grad
         self.bucket_bytes = bucket_bytes
         self.group = group
@@ -73,8 +77,9 @@ class GradSync:
         self.ranges: List[Tuple[int, int]] = []
         self.cur: Optional[Tuple[int, int]] = None
         self.launched: List[Tuple[int, int]] = []  # for tests / introspection
-        backend = dist.get_backend(group) if dist.is_initialized() else "none"
-        self.use_avg = backend == "nccl"
+        # SUM everywhere (ReduceOp.AVG is not available on every backend / RCCL build); the 1/world factor is applied
+        # either here after the wait, or for free inside the AdamW kernel (scale_in_optimizer=True)
+        self.scale_in_optimizer = scale_in_optimizer
 
     def ready(self, lo: int, hi: int) -> None:
         if world_size() == 1 or hi <= lo:
@@ -95,8 +100,7 @@ class GradSync:
         lo, hi = self.cur
         self.cur = None
         g = self.get_grad()[lo:hi]
-        op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
-        self.handles.append(dist.all_reduce(g, op=op, group=self.group, async_op=True))
+        self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self.ranges.append((lo, hi))
         self.launched.append((lo, hi))
 
@@ -106,7 +110,7 @@ class GradSync:
         self._flush()
         for h in self.handles:
             h.wait()
-        if not self.use_avg:
+        if not self.scale_in_optimizer:
             g = self.get_grad()
             w = float(world_size())
             for lo, hi in self.ranges:
@@ -125,7 +129,8 @@ def attach_data_parallel(module, bucket_bytes: int = 32 << 20) -> Optional[GradS
     for t in net._buffers_flat.values():
         dist.broadcast(t, src=0)
     net.params_changed()
-    sync = GradSync(lambda: net.store.ensure_grad(), bucket_bytes)
+    sync = GradSync(lambda: net.store.ensure_grad(), bucket_bytes, scale_in_optimizer=True)
+    module.optimizer().set_grad_scale(1.0 / world_size())
     net.engine.on_grad_ready = sync.ready
     module.grad_sync = sync.wait
     return sync

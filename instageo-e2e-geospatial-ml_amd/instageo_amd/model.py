@@ -450,10 +450,10 @@ class SegEngine:
             b = f"{e}blocks.{i}."
             # fc2: x_out = x_mid + hact @ W2^T + b2   (its bias grad came from the LayerNorm backward that produced dx)
             ops.linear_wgrad(dxb, ws["hact"][i], self.Gd(b + "mlp.fc2.weight"), M, D, 4 * D)
-            ops.linear_dgrad(dxb, self.W(b + "mlp.fc2.weight"), ws["dh"], M, D, 4 * D, pre=ws["hpre"][i])
+            # (the fc1 bias gradient = column sums of dh is fused into this dgrad's epilogue)
+            ops.linear_dgrad(dxb, self.W(b + "mlp.fc2.weight"), ws["dh"], M, D, 4 * D, pre=ws["hpre"][i], colsum=self.Gd(b + "mlp.fc1.bias"))
             # fc1
             ops.linear_wgrad(ws["dh"], ws["c"][i], self.Gd(b + "mlp.fc1.weight"), M, 4 * D, D)
-            ops.colsum(ws["dh"], self.Gd(b + "mlp.fc1.bias"), M, 4 * D)
             ops.linear_dgrad(ws["dh"], self.W(b + "mlp.fc1.weight"), ws["dtmp"], M, 4 * D, D)
             ops.layernorm_bwd(ws["dtmp"], ws["x_mid"][i], ws["mean2"][i], ws["rstd2"][i], self.P(b + "norm2.weight"), dx, True, dxb,
                               self.Gd(b + "norm2.weight"), self.Gd(b + "norm2.bias"), self.Gd(b + "attn.proj.bias"), M, D)

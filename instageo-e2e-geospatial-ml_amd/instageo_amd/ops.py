@@ -164,9 +164,10 @@ def linear_residual_fwd(x: BT, w: BT, bias, resid, out, M: int, N: int, K: int) 
     _call("ig_linear_residual_fwd", 2.0 * M * N * K, _p(x.hi), _p(x.lo), _p(w.hi), _p(w.lo), _p(bias), _p(resid), _p(out), M, N, K, _stream())
 
 
-def linear_dgrad(dy: BT, w: BT, dx: BT, M: int, N: int, K: int, pre: Optional[BT] = None) -> None:
+def linear_dgrad(dy: BT, w: BT, dx: BT, M: int, N: int, K: int, pre: Optional[BT] = None, colsum=None) -> None:
+    """dx = dy @ w [* gelu'(pre)]; ``colsum`` (fp32 [K]) additionally accumulates the column sums of dx."""
     _call("ig_linear_dgrad", 2.0 * M * N * K, _p(dy.hi), _p(dy.lo), _p(w.hi), _p(w.lo), _p(dx.hi), _p(dx.lo),
-              _p(pre.hi) if pre else None, _p(pre.lo) if pre else None, M, N, K, 1 if pre else 0, _stream())
+              _p(pre.hi) if pre else None, _p(pre.lo) if pre else None, _p(colsum), M, N, K, 1 if pre else 0, _stream())
 
 
 def linear_wgrad(dy: BT, x: BT, dw, M: int, N: int, K: int) -> None:

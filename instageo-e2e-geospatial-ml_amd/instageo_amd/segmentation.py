@@ -66,6 +66,10 @@ class FusedAdamW(torch.optim.Optimizer):
         self.hyper[: len(h)] = torch.tensor(h, dtype=torch.float32)
         self._lr_written = g["lr"]
 
+    def set_grad_scale(self, scale: float) -> None:
+        """Multiply gradients by ``scale`` inside the AdamW kernel (1/world_size after a SUM all-reduce)."""
+        self.hyper[13] = float(scale)
+
     def gather_grads(self) -> None:
         """Copy autograd-produced ``p.grad`` tensors into the flat grad buffer (compatible path)."""
         store = self.net.store

@@ -86,10 +86,12 @@ def test_linear_dgrad_wgrad(split, M, N, K):
     ops.linear_dgrad(dy, w, dx, M, N, K)
     close(dx.float(), dyr @ wr, tol_out(split), what="dgrad")
     pre, prer = bt(rnd(M, K, seed=8), split)
-    ops.linear_dgrad(dy, w, dx, M, N, K, pre=pre)
+    cs = torch.zeros(K, device=DEV)
+    ops.linear_dgrad(dy, w, dx, M, N, K, pre=pre, colsum=cs)
     pr = prer.clone().requires_grad_(True)
     (gref,) = torch.autograd.grad(F.gelu(pr).sum(), pr)
     close(dx.float(), (dyr @ wr) * gref, tol_out(split), what="dgrad*gelu'")
+    close(cs, ((dyr @ wr) * gref).sum(0), 3e-5, what="fused column sums (bias grad)")
     dw = torch.zeros(N, K, device=DEV)
     ops.linear_wgrad(dy, x, dw, M, N, K)
     close(dw, dyr.t() @ xr, 3e-5 if split else 2e-5, what="wgrad")
