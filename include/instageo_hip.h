@@ -84,8 +84,12 @@ int ig_convT_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, const
 int ig_convT_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const void* x_lo, float* dw, int B, int H, int W,
                    int Cin, int Cout, void* stream);
 /* nn.Conv2d(k=3,padding=1)                                                                           :370-375 */
-int ig_conv3x3_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias, void* y_hi,
-                   void* y_lo, int B, int H, int W, int Cin, int Cout, void* stream);
+/* bn_scale/bn_shift (may be NULL): eval-mode BatchNorm2d + ReLU folded into the epilogue, y = relu((conv+bias)*s + t) */
+int ig_conv3x3_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
+                   const float* bn_scale, const float* bn_shift, void* y_hi, void* y_lo, int B, int H, int W, int Cin, int Cout,
+                   void* stream);
+int ig_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float* scale,
+                      float* shift, int C, float eps, void* stream);
 int ig_conv3x3_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, const void* w_lo, void* dx_hi, void* dx_lo, int B,
                      int H, int W, int Cin, int Cout, unsigned drop_seed, const unsigned* drop_seed_dev, float drop_p, void* stream);
 int ig_conv3x3_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const void* x_lo, float* dw, int B, int H, int W,

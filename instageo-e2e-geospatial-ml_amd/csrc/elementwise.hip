@@ -709,6 +709,17 @@ int ig_bn_relu_bwd(const void* x_hi, const void* x_lo, const void* dy_hi, const 
     return ig_check_launch("ig_bn_relu_bwd");
 }
 
+// eval-mode BatchNorm as a per-channel affine: scale = gamma*rsqrt(running_var+eps), shift = beta - running_mean*scale
+// (used by ig_conv3x3_fwd's fused BN+ReLU epilogue at inference)
+int ig_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float* scale,
+                      float* shift, int C, float eps, void* stream) {
+    IG_REQUIRE(gamma && beta && running_mean && running_var && scale && shift, "ig_bn_eval_affine: null pointer");
+    if (C == 0) return IG_OK;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ig_cdiv(C, TPB)), dim3(TPB), 0, ST(stream), (const double*)nullptr, gamma, beta,
+                       (float*)running_mean, (float*)running_var, scale, shift, (float*)nullptr, (float*)nullptr, 1.0, C, eps, 0.f, 0, 0);
+    return ig_check_launch("ig_bn_eval_affine");
+}
+
 // hyper: device float[16] (layout above).  ig_adamw_advance increments the step and the bias corrections
 // on the device so that a captured graph can be replayed without host-side scalars.
 int ig_adamw_advance(float* hyper, void* stream) {

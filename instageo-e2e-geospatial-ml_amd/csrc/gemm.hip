@@ -548,6 +548,7 @@ struct EpStore {
     bf16_t *out_hi, *out_lo;
     bf16_t *pre_hi, *pre_lo;
     const float* bias;
+    const float *col_scale, *col_shift;  // optional: v = relu((acc+bias)*scale[n] + shift[n]) (eval-mode BatchNorm+ReLU)
     long ldo;
     int act;  // 0 none, 1 exact GELU
     uint32_t drop_seed, drop_thresh;
@@ -571,6 +572,12 @@ struct EpStore {
         if (bias) {
             float4 bb = *reinterpret_cast<const float4*>(bias + n);
             v[0] += bb.x, v[1] += bb.y, v[2] += bb.z, v[3] += bb.w;
+        }
+        if (col_scale) {
+            float4 sc = *reinterpret_cast<const float4*>(col_scale + n);
+            float4 sh = *reinterpret_cast<const float4*>(col_shift + n);
+            v[0] = fmaxf(v[0] * sc.x + sh.x, 0.f), v[1] = fmaxf(v[1] * sc.y + sh.y, 0.f);
+            v[2] = fmaxf(v[2] * sc.z + sh.z, 0.f), v[3] = fmaxf(v[3] * sc.w + sh.w, 0.f);
         }
         size_t idx = (size_t)row * ldo + n;
         if (act == 1) {
@@ -861,8 +868,9 @@ int ig_patch_embed_fwd(const void* p_hi, const void* p_lo, const void* w_hi, con
 
 // ---- 3x3 pad-1 convolution, NHWC activations, weight storage Wc[Cout][9][Cin] (tap = ky*3+kx) ----
 // model.py:370-375 (nn.Conv2d(k=3,padding=1))
-int ig_conv3x3_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias, void* y_hi,
-                   void* y_lo, int B, int H, int W, int Cin, int Cout, void* stream) {
+int ig_conv3x3_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
+                   const float* bn_scale, const float* bn_shift, void* y_hi, void* y_lo, int B, int H, int W, int Cin, int Cout,
+                   void* stream) {
     IG_REQUIRE(x_hi && w_hi && y_hi, "ig_conv3x3_fwd: null pointer");
     IG_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, "ig_conv3x3_fwd: channels must be multiples of 8");
     IG_SPLIT_CONSISTENT(x_lo, w_lo);
@@ -871,6 +879,8 @@ int ig_conv3x3_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const v
     al.Mtot = B * H * W, al.H = H, al.W = W, al.C = Cin, al.sign = 1;
     EpStore ep{};
     ep.out_hi = (bf16_t*)y_hi, ep.out_lo = (bf16_t*)y_lo, ep.bias = bias, ep.ldo = Cout;
+    IG_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "ig_conv3x3_fwd: bn_scale and bn_shift go together");
+    ep.col_scale = bn_scale, ep.col_shift = bn_shift;  // eval-mode BatchNorm + ReLU folded into the epilogue
     return launch_gemm<Conv3Loader, PlainLoader, EpStore, false, false>(
         al, plain_b(w_hi, w_lo, Cout, 9 * Cin, 9L * Cin), ep, al.Mtot, Cout, 9 * Cin, 1, x_lo != nullptr,
         (hipStream_t)stream, "ig_conv3x3_fwd", false, 1);

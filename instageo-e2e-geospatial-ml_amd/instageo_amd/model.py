@@ -379,6 +379,13 @@ class SegEngine:
             Hs = g << i
             ops.convT_fwd(ws["f"][i], self.W(f"{h}{i}.0.weight"), self.P(f"{h}{i}.0.bias"), ws["u"][i], B, Hs, Hs, dims[i], dims[i + 1],
                           seed=self.drop_seed + i, p=p, seed_dev=sd)
+            if not training:
+                # eval mode: BatchNorm(running stats)+ReLU is a per-channel affine folded into the conv epilogue (one HBM pass less)
+                ops.bn_eval_affine(self.P(f"{h}{i}.3.weight"), self.P(f"{h}{i}.3.bias"), self.buffers[f"{h}{i}.3.running_mean"],
+                                   self.buffers[f"{h}{i}.3.running_var"], ws["bn_scale"][i], ws["bn_shift"][i], dims[i + 1])
+                ops.conv3x3_fwd(ws["u"][i], self.W(f"{h}{i}.2.weight"), self.P(f"{h}{i}.2.bias"), ws["f"][i + 1], B, 2 * Hs, 2 * Hs,
+                                dims[i + 1], dims[i + 1], bn_scale=ws["bn_scale"][i], bn_shift=ws["bn_shift"][i])
+                continue
             ops.conv3x3_fwd(ws["u"][i], self.W(f"{h}{i}.2.weight"), self.P(f"{h}{i}.2.bias"), ws["cv"][i], B, 2 * Hs, 2 * Hs, dims[i + 1],
                             dims[i + 1])
             ops.bn_relu_fwd(ws["cv"][i], self.P(f"{h}{i}.3.weight"), self.P(f"{h}{i}.3.bias"), self.buffers[f"{h}{i}.3.running_mean"],

@@ -204,8 +204,14 @@ def convT_wgrad(dy: BT, x: BT, dw, B, H, W, Cin, Cout) -> None:
     _call("ig_convT_wgrad", 2.0 * B * H * W * Cin * Cout * 9, _p(dy.hi), _p(dy.lo), _p(x.hi), _p(x.lo), _p(dw), B, H, W, Cin, Cout, _stream())
 
 
-def conv3x3_fwd(x: BT, w: BT, bias, y: BT, B, H, W, Cin, Cout) -> None:
-    _call("ig_conv3x3_fwd", 2.0 * B * H * W * Cin * Cout * 9, _p(x.hi), _p(x.lo), _p(w.hi), _p(w.lo), _p(bias), _p(y.hi), _p(y.lo), B, H, W, Cin, Cout, _stream())
+def conv3x3_fwd(x: BT, w: BT, bias, y: BT, B, H, W, Cin, Cout, bn_scale=None, bn_shift=None) -> None:
+    """3x3 conv (+bias); with bn_scale/bn_shift also eval-mode BatchNorm + ReLU in the same epilogue."""
+    _call("ig_conv3x3_fwd", 2.0 * B * H * W * Cin * Cout * 9, _p(x.hi), _p(x.lo), _p(w.hi), _p(w.lo), _p(bias), _p(bn_scale), _p(bn_shift),
+          _p(y.hi), _p(y.lo), B, H, W, Cin, Cout, _stream())
+
+
+def bn_eval_affine(gamma, beta, rmean, rvar, scale, shift, C: int, eps: float = 1e-5) -> None:
+    _lib.call("ig_bn_eval_affine", _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(scale), _p(shift), C, eps, _stream())
 
 
 def conv3x3_dgrad(dy: BT, w: BT, dx: BT, B, H, W, Cin, Cout, seed: int = 0, p: float = 0.0, seed_dev=None) -> None:

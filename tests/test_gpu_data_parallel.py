@@ -63,7 +63,8 @@ def _worker(rank, world, port, q):
             mod.fused_train_step(x, y)
         torch.cuda.synchronize()
         flat = mod.net.store.flat.detach().cpu()
-        q.put((rank, flat, len(sync.launched), mod.train_metrics.matrix.sum()))
+        # numpy (pickled by value): a torch tensor would travel as a shared-memory fd that dies with this process
+        q.put((rank, flat.numpy().copy(), len(sync.launched), int(mod.train_metrics.matrix.sum())))
     except Exception as e:  # pragma: no cover
         import traceback
 
@@ -84,8 +85,8 @@ def test_two_rank_fused_training_equals_manual_gradient_mean():
     for p in procs:
         p.join(timeout=60)
     for r in res:
-        assert torch.is_tensor(r[1]), r[1]
-    flat0, flat1 = res[0][1], res[1][1]
+        assert not isinstance(r[1], str), r[1]
+    flat0, flat1 = torch.from_numpy(res[0][1]), torch.from_numpy(res[1][1])
     assert torch.equal(flat0, flat1), "replicas diverged"
     assert res[0][2] >= 2, "expected several gradient buckets per step"
     # single-process restatement: per-rank grads (rank-local BN), mean, one AdamW step -- twice
