@@ -98,7 +98,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=54, help="chips per GPU per step")
+    ap.add_argument("--batch", type=int, default=108, help="chips per GPU per step")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
     ap.add_argument("--model", default="prithvi_eo_v1_100", help="variant (other BASELINE configs: prithvi_eo_v2_300)")
     ap.add_argument("--temporal", type=int, default=1, help="T: 1 = configs[1] (default), 3 = configs[2] multi-temporal crop")
@@ -251,8 +251,8 @@ def main() -> None:
         out["roofline"] = {"kernel": KERNEL_OF.get(dom, dom), "entry_point": dom, "bound": "mfma", "achieved": round(ach, 1),
                            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
                            "launches": n, "avg_launch_us": round(1e3 * ms / n, 2), "flops_per_launch": work / n}  # fmt: skip
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_bench_b54.json")
-        if os.path.exists(pmc_path) and B == 54 and (T, NCLS, args.model) == (1, 2, "prithvi_eo_v1_100"):
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_bench_b108.json")
+        if os.path.exists(pmc_path) and B == 108 and (T, NCLS, args.model) == (1, 2, "prithvi_eo_v1_100"):
             # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
             # (tools: see DESIGN.md 6); FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md
             pmc = json.load(open(pmc_path))
@@ -260,7 +260,7 @@ def main() -> None:
             ent = next((v for k, v in pmc.items() if k.replace(" ", "") == key.replace(" ", "")), None)
             if ent:
                 out["roofline"]["traffic"] = round((2 * ent["fetch_kb_raw"] + ent["write_kb"]) * 1024)
-                out["roofline"]["traffic_note"] = "bytes/launch, offline PMC passes (profiles/r01_pmc_bench_b54.json)"
+                out["roofline"]["traffic_note"] = "bytes/launch, offline PMC passes (profiles/r01_pmc_bench_b108.json)"
         out["roofline_timed_region"] = timed
         out["roofline_all"] = allk  # separate untimed pass (3 steps) with events on every MFMA entry point
     if world == 1 and not args.no_cpu_baseline:
