@@ -203,12 +203,23 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
 // not drain it with vmcnt(0) at the next ds_read / barrier (cdna_hip_programming.md 5, "Pipelining across barriers").
 // ==============================================================================================
 constexpr int BM2 = 256, NTHR2 = 512;
-#ifndef IG_GM2
-#define IG_GM2 1
-#endif
-constexpr int GM2 = IG_GM2;  // row panels per L2 tile group (1 = bn-fastest; 4 measured no better at these shapes)
-constexpr int A_BYTES2 = 32768, STAGE2 = 49152, NSTAGE2 = 3, SMEM2 = STAGE2 * NSTAGE2;
 typedef __attribute__((address_space(3))) char* lds_char_ptr;
+
+// Geometry of one ring stage for K-step BKT (64: 48 KiB/stage, 1 workgroup/CU -- used by the LDS-staged wgrad epilogue;
+// 32: 24 KiB/stage, 72 KiB ring => 2 workgroups (16 waves) per CU so one workgroup's barrier / DMA waits are covered by
+// the other's MFMAs)
+template <int BKT>
+struct G2 {
+    static constexpr int UPR = BKT / 8;                // 16-byte units per K-contiguous row
+    static constexpr int RPI = 64 / UPR;               // rows per 1-KiB wave-instruction (K-contiguous image)
+    static constexpr int A_BYTES = BM2 * BKT * 2;
+    static constexpr int B_BYTES = BN * BKT * 2;
+    static constexpr int STAGE = A_BYTES + B_BYTES;
+    static constexpr int NA = A_BYTES / 1024, NB = B_BYTES / 1024;  // wave-instructions per stage
+    static constexpr int PER_WAVE = (NA + NB) / 8;
+    static constexpr int SMEM = 3 * STAGE;
+    static constexpr int TRH = BKT * 256;              // bytes of one 128-column half of a TR image
+};
 
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
     unsigned keep;
@@ -218,18 +229,35 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
                  : "memory");
 }
 __device__ __forceinline__ int tr_key(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+// K-contiguous image swizzle: physical 16-byte chunk of logical chunk c in row r (an involution in c)
+template <int BKT>
+__device__ __forceinline__ int kc_swz(int r, int c) {
+    if constexpr (BKT == 64) return c ^ (r & 7);
+    else return c ^ ((0x1230 >> (4 * ((r >> 2) & 3))) & 3);  // f = {0,3,2,1}: conflict-free for ds_read_b128 on 64-byte rows
+}
+template <int BKT, bool TR>
+__device__ __forceinline__ bf16x8_t read_frag2(const char* tile, int row0, int s, int lane) {
+    if constexpr (!TR) {
+        const int r = row0 + (lane & 15);
+        const int c = s * 4 + (lane >> 4);
+        return *reinterpret_cast<const bf16x8_t*>(tile + r * (BKT * 2) + (kc_swz<BKT>(r, c) << 4));
+    } else {
+        return read_frag<true>(tile, row0, s, lane);
+    }
+}
 
-template <class AL, class BL, class EP, bool A_TR, bool B_TR, int NSEG>
-__global__ __launch_bounds__(NTHR2) void gemm2_kernel(AL al, BL bl, EP ep, int M, int N, int K, int tiles_n, int ntiles,
-                                                      int kchunk, const bf16_t* zero_page) {
+template <class AL, class BL, class EP, bool A_TR, bool B_TR, int NSEG, int BKT>
+__global__ __launch_bounds__(NTHR2, (BKT == 32 ? 4 : 2)) void gemm2_kernel(AL al, BL bl, EP ep, int M, int N, int K, int tiles_n,
+                                                                       int ntiles, int kchunk, const bf16_t* zero_page) {
+    using G = G2<BKT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    // PERSISTENT tile schedule: workgroups are dealt round-robin over the 8 XCDs (private L2s); XCD x owns the
-    // contiguous tile range [lo, lo+cnt) and its workgroups walk it with stride nbx, so the CUs of one XCD always
-    // work on neighbouring tiles (shared A row panel / B panels).  With gridDim.x == ntiles this degenerates to
-    // one tile per workgroup.
+    // PERSISTENT tile schedule: workgroups are dealt round-robin over the 8 XCDs (private L2s; XCD = linear workgroup
+    // id % 8, tools/xcc_probe.hip); XCD x owns the contiguous tile range [tlo, tlo+tcnt) and its workgroups walk it with
+    // stride nbx, so the CUs of one XCD always work on neighbouring tiles (shared A row panel / B panels).  With
+    // gridDim.x == ntiles this degenerates to one tile per workgroup.
     const int nb = gridDim.x, xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
     const int nbx = (nb >> 3) + (xcd < (nb & 7) ? 1 : 0);
     const int qT = ntiles >> 3, rT = ntiles & 7;
@@ -239,12 +267,12 @@ __global__ __launch_bounds__(NTHR2) void gemm2_kernel(AL al, BL bl, EP ep, int M
     bl.init(blockIdx.z);
     ep.init(blockIdx.z);
     if (al.kdim() >= 0) K = al.kdim();
-    const int nk_all = (K + BK - 1) / BK;
+    const int nk_all = (K + BKT - 1) / BKT;
     const int kt0 = blockIdx.y * kchunk;
     const int nk = min(kchunk, nk_all - kt0);
     if (nk <= 0 || my_tiles <= 0) return;
     const int total = nk * NSEG;      // K-steps per tile
-    const int G = my_tiles * total;   // flattened (tile, K-step) sequence of this workgroup
+    const int G_ = my_tiles * total;  // flattened (tile, K-step) sequence of this workgroup
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_char_ptr)smem;
 
     f32x4 acc[4][4];
@@ -253,32 +281,32 @@ __global__ __launch_bounds__(NTHR2) void gemm2_kernel(AL al, BL bl, EP ep, int M
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // one stage = 48 wave-instructions of 1 KiB: ids 0..31 -> A, 32..47 -> B; wave w issues ids i*8 + w
+    // one stage = NA + NB wave-instructions of 1 KiB (ids 0..NA-1 -> A, then B); wave w issues ids i*8 + w
 #define GEMM2_ISSUE(IT, SLOT, BM_, BN_)                                                                    \
     {                                                                                                       \
         const int seg_ = (NSEG == 1) ? 0 : (IT) / nk;                                                       \
         const int kt_ = kt0 + (IT)-seg_ * nk;                                                               \
-        const unsigned sbase_ = lds_base + (SLOT)*STAGE2;                                                   \
-        _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                                     \
+        const unsigned sbase_ = lds_base + (SLOT)*G::STAGE;                                                 \
+        _Pragma("unroll") for (int i = 0; i < G::PER_WAVE; ++i) {                                           \
             const int id = i * 8 + wave;                                                                    \
             bool ok;                                                                                        \
             const bf16_t* p;                                                                                \
-            if (id < 32) {                                                                                  \
+            if (id < G::NA) {                                                                               \
                 if constexpr (!A_TR) {                                                                      \
-                    const int row = id * 8 + (lane >> 3);                                                   \
-                    p = al.ptr(seg_, (BM_)*BM2 + row, kt_ * 8 + ((lane & 7) ^ (row & 7)), ok);              \
+                    const int row = id * G::RPI + lane / G::UPR;                                            \
+                    p = al.ptr(seg_, (BM_)*BM2 + row, kt_ * G::UPR + kc_swz<BKT>(row, lane % G::UPR), ok);  \
                 } else {                                                                                    \
-                    const int k = (id & 15) * 4 + (lane >> 4);                                              \
-                    p = al.ptr(seg_, kt_ * BK + k, (BM_)*32 + (id >> 4) * 16 + ((lane & 15) ^ (tr_key(k) << 1)), ok); \
+                    const int k = (id % (BKT / 4)) * 4 + (lane >> 4);                                       \
+                    p = al.ptr(seg_, kt_ * BKT + k, (BM_)*32 + (id / (BKT / 4)) * 16 + ((lane & 15) ^ (tr_key(k) << 1)), ok); \
                 }                                                                                           \
             } else {                                                                                        \
-                const int id2 = id - 32;                                                                    \
+                const int id2 = id - G::NA;                                                                 \
                 if constexpr (!B_TR) {                                                                      \
-                    const int row = id2 * 8 + (lane >> 3);                                                  \
-                    p = bl.ptr(seg_, (BN_)*BN + row, kt_ * 8 + ((lane & 7) ^ (row & 7)), ok);               \
+                    const int row = id2 * G::RPI + lane / G::UPR;                                           \
+                    p = bl.ptr(seg_, (BN_)*BN + row, kt_ * G::UPR + kc_swz<BKT>(row, lane % G::UPR), ok);   \
                 } else {                                                                                    \
                     const int k = id2 * 4 + (lane >> 4);                                                    \
-                    p = bl.ptr(seg_, kt_ * BK + k, (BN_)*16 + ((lane & 15) ^ (tr_key(k) << 1)), ok);        \
+                    p = bl.ptr(seg_, kt_ * BKT + k, (BN_)*16 + ((lane & 15) ^ (tr_key(k) << 1)), ok);       \
                 }                                                                                           \
             }                                                                                               \
             glds16(ok ? p : zero_page, sbase_ + id * 1024);                                                 \
@@ -286,61 +314,53 @@ __global__ __launch_bounds__(NTHR2) void gemm2_kernel(AL al, BL bl, EP ep, int M
     }
 
     // issue-side cursor (runs two K-steps ahead of the compute-side cursor, across tile boundaries)
-    // tile index -> (bm, bn): column-major inside groups of GM2 row panels, so the 32 tiles an XCD works on at any
-    // time form a compact GM2 x 8 block (A panels of the group stay in that XCD's L2 while the B panels stream)
-    const int tiles_m = ntiles / tiles_n;
-#define GEMM2_TILE_COORDS(T_, BM_, BN_)                                   \
-    {                                                                      \
-        const int gsz_ = GM2 * tiles_n;                                    \
-        const int grp_ = (T_) / gsz_, r_ = (T_)-grp_ * gsz_;               \
-        const int rows_ = min(GM2, tiles_m - grp_ * GM2);                  \
-        BN_ = r_ / rows_;                                                  \
-        BM_ = grp_ * GM2 + (r_ - BN_ * rows_);                             \
-    }
     int it_i = 0;
     int tile_i = tlo + jx;
-    int bm_i, bn_i;
-    GEMM2_TILE_COORDS(tile_i, bm_i, bn_i);
+    int bm_i = tile_i / tiles_n, bn_i = tile_i - bm_i * tiles_n;
 #define GEMM2_ADVANCE_ISSUE()                                  \
     {                                                           \
         if (++it_i == total) {                                  \
             it_i = 0;                                           \
             tile_i += nbx;                                      \
-            GEMM2_TILE_COORDS(tile_i, bm_i, bn_i);              \
+            bm_i = tile_i / tiles_n, bn_i = tile_i - bm_i * tiles_n; \
         }                                                       \
     }
     GEMM2_ISSUE(it_i, 0, bm_i, bn_i);
     GEMM2_ADVANCE_ISSUE();
-    if (G > 1) {
+    if (G_ > 1) {
         GEMM2_ISSUE(it_i, 1, bm_i, bn_i);
         GEMM2_ADVANCE_ISSUE();
     }
     int slot = 0, it_c = 0;
     int tile_c = tlo + jx;
-    for (int g = 0; g < G; ++g) {
-        // K-step g landed for THIS wave once at most the 6 DMAs of step g+1 are outstanding (vmcnt also counts the
+    for (int g = 0; g < G_; ++g) {
+        // K-step g landed for THIS wave once at most the DMAs of step g+1 are outstanding (vmcnt also counts the
         // epilogue's stores, which only makes the wait at a tile boundary conservative); the barrier then covers
         // the other waves' pieces (RAW) and everybody's reads of the slot that is refilled next (WAR)
-        if (g + 1 < G) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (g + 1 < G_) {
+            if constexpr (G::PER_WAVE == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         asm volatile("s_barrier" ::: "memory");
-        if (g + 2 < G) {
+        if (g + 2 < G_) {
             const int s2 = slot >= 1 ? slot - 1 : slot + 2;  // (slot + 2) % 3
             GEMM2_ISSUE(it_i, s2, bm_i, bn_i);
             GEMM2_ADVANCE_ISSUE();
         }
-        const char* ta = smem + slot * STAGE2;
-        const char* tb = ta + A_BYTES2;
+        const char* ta = smem + slot * G::STAGE;
+        const char* tb = ta + G::A_BYTES;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < BKT / 32; ++s) {
             bf16x8_t af[4], bf[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                if constexpr (!A_TR) af[t] = read_frag<false>(ta, wm * 64 + t * 16, s, lane);
-                else af[t] = read_frag<true>(ta + (wm >> 1) * 16384, (wm & 1) * 64 + t * 16, s, lane);
+                if constexpr (!A_TR) af[t] = read_frag2<BKT, false>(ta, wm * 64 + t * 16, s, lane);
+                else af[t] = read_frag2<BKT, true>(ta + (wm >> 1) * G::TRH, (wm & 1) * 64 + t * 16, s, lane);
             }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) bf[t] = read_frag<B_TR>(tb, wn * 64 + t * 16, s, lane);
+            for (int t = 0; t < 4; ++t) bf[t] = read_frag2<BKT, B_TR>(tb, wn * 64 + t * 16, s, lane);
 #pragma unroll
             for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
@@ -351,10 +371,10 @@ __global__ __launch_bounds__(NTHR2) void gemm2_kernel(AL al, BL bl, EP ep, int M
         if (++it_c < total) continue;
         // ---- tile finished: epilogue (next tile's first K-steps are already in flight) ----
         it_c = 0;
-        int bm, bn;
-        GEMM2_TILE_COORDS(tile_c, bm, bn);
+        const int bm = tile_c / tiles_n, bn = tile_c - bm * tiles_n;
         tile_c += nbx;
         if constexpr (EP::kStagedAtomic) {
+            static_assert(!EP::kStagedAtomic || BKT == 64, "the LDS-staged atomic epilogue needs the 144 KiB ring");
             // launched with one tile per workgroup: the LDS ring is idle here
             __syncthreads();
             float* st = reinterpret_cast<float*>(smem);  // 256 x 128 fp32 = 128 KiB
@@ -418,7 +438,6 @@ __global__ __launch_bounds__(NTHR2) void gemm2_kernel(AL al, BL bl, EP ep, int M
     }
 #undef GEMM2_ISSUE
 #undef GEMM2_ADVANCE_ISSUE
-#undef GEMM2_TILE_COORDS
 }
 
 // ------------------------------------------------------------------------------------ loaders
@@ -724,29 +743,31 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, i
     dim3 grid(tm * tn, ksplit, Z);
     if (ver == 2) {
         const int ntiles = tm * tn;
-        if (!EP::kStagedAtomic && ntiles > 256) grid.x = 256;  // persistent: one workgroup per CU walks its tiles
         const bf16_t* zp = zero_page();
         if (!zp) {
             ig_set_error("%s: could not allocate the zero page", what);
             return IG_ERR_HIP;
         }
-        if (split) {
-            auto kern = gemm2_kernel<AL, BL, EP, A_TR, B_TR, 3>;
-            static bool attr_done = false;
-            if (!attr_done) {
-                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2);
-                attr_done = true;
-            }
-            hipLaunchKernelGGL(kern, grid, dim3(NTHR2), SMEM2, st, al, bl, ep, M, N, K, tn, ntiles, kchunk, zp);
+#define IG_LAUNCH_V2(NSEG_, BKT_)                                                                                        \
+    {                                                                                                                     \
+        auto kern = gemm2_kernel<AL, BL, EP, A_TR, B_TR, NSEG_, BKT_>;                                                    \
+        static bool attr_done = false;                                                                                    \
+        if (!attr_done) {                                                                                                 \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G2<BKT_>::SMEM);     \
+            attr_done = true;                                                                                             \
+        }                                                                                                                 \
+        hipLaunchKernelGGL(kern, grid, dim3(NTHR2), G2<BKT_>::SMEM, st, al, bl, ep, M, N, K, tn, ntiles, kchunk, zp);     \
+    }
+        if constexpr (EP::kStagedAtomic) {
+            // one tile per workgroup, BK = 64 (the fp32 tile is staged through the 144 KiB ring)
+            if (split) IG_LAUNCH_V2(3, 64) else IG_LAUNCH_V2(1, 64)
         } else {
-            auto kern = gemm2_kernel<AL, BL, EP, A_TR, B_TR, 1>;
-            static bool attr_done = false;
-            if (!attr_done) {
-                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2);
-                attr_done = true;
-            }
-            hipLaunchKernelGGL(kern, grid, dim3(NTHR2), SMEM2, st, al, bl, ep, M, N, K, tn, ntiles, kchunk, zp);
+            // persistent: two workgroups per CU walk the tile list; BK = 32 keeps the ring at 72 KiB
+            if ((int)grid.x > 512) grid.x = 512;
+            kchunk = ig_cdiv(K, 32);
+            if (split) IG_LAUNCH_V2(3, 32) else IG_LAUNCH_V2(1, 32)
         }
+#undef IG_LAUNCH_V2
         return ig_check_launch(what);
     }
     dim3 block(NTHR);
