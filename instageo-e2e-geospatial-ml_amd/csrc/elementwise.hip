@@ -162,7 +162,7 @@ __global__ __launch_bounds__(TPB) void layernorm_fwd_kernel(const float* __restr
 //   dgamma += sum_rows dy*xhat ; dbeta += sum_rows dy ; optional: dxb = bf16(dx), dcol += sum_rows dx
 // Each block owns ROWS_PER_BLOCK rows; each wave keeps its column partials in registers, then one
 // LDS reduction + one fp32 atomic per (block, column).
-constexpr int LNB_TPB = 256;  // measured: 4 waves x 32 rows per workgroup beats 16-row and 1024-thread variants
+constexpr int LNB_TPB = 256;  // measured: 4 waves x 32 rows per workgroup beats 16-row, 512- and 1024-thread variants
 template <int MAXV>
 __global__ __launch_bounds__(LNB_TPB) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy_hi, const bf16_t* __restrict__ dy_lo,
                                                             const float* __restrict__ x, const float* __restrict__ mean,
@@ -261,6 +261,121 @@ __global__ __launch_bounds__(LNB_TPB) void layernorm_bwd_kernel(const bf16_t* __
     for (int i = 0; i < MAXV; ++i) {
         int c = lane + i * 64;
         if (c < nv) {
+            float* r0 = red + c * 4;
+            atomicAdd(r0 + 0, ag[i].x), atomicAdd(r0 + 1, ag[i].y), atomicAdd(r0 + 2, ag[i].z), atomicAdd(r0 + 3, ag[i].w);
+            float* r1 = red + D + c * 4;
+            atomicAdd(r1 + 0, ab[i].x), atomicAdd(r1 + 1, ab[i].y), atomicAdd(r1 + 2, ab[i].z), atomicAdd(r1 + 3, ab[i].w);
+            float* r2 = red + 2 * D + c * 4;
+            atomicAdd(r2 + 0, ac[i].x), atomicAdd(r2 + 1, ac[i].y), atomicAdd(r2 + 2, ac[i].z), atomicAdd(r2 + 3, ac[i].w);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < D; i += LNB_TPB) {
+        if (dgamma) atomicAdd(dgamma + i, red[i]);
+        if (dbeta) atomicAdd(dbeta + i, red[D + i]);
+        if (dcol) atomicAdd(dcol + i, red[2 * D + i]);
+    }
+}
+
+// exact variant: D == NCH*256, so every lane owns NCH full float4 chunks -- no per-chunk guards (a guard per load made
+// hipcc branch around each load and wait vmcnt(0) 52 times per row; 180 VGPRs) and the feature layout is a template flag
+template <int NCH, bool FEAT>
+__global__ __launch_bounds__(LNB_TPB) void layernorm_bwd_exact_kernel(const bf16_t* __restrict__ dy_hi, const bf16_t* __restrict__ dy_lo,
+                                                            const float* __restrict__ x, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                            float* __restrict__ dx, int accumulate, bf16_t* __restrict__ dxb_hi,
+                                                            bf16_t* __restrict__ dxb_lo, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, float* __restrict__ dcol, int M, int D,
+                                                            int rows_per_block, int feat_T, int feat_G, int ntok) {
+    extern __shared__ float red[];  // [3][D]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        float4 ag[NCH], ab[NCH], ac[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) ag[i] = ab[i] = ac[i] = make_float4(0, 0, 0, 0);
+    const int row0 = blockIdx.x * rows_per_block;
+    const int row1 = min(M, row0 + rows_per_block);
+    for (int row = row0 + wave; row < row1; row += LNB_TPB / 64) {
+        const float mu = mean[row], rs = rstd[row];
+        bool zero_dy = false;
+        long dbase = (long)row * D;
+        int tfr = 0;
+        if (FEAT) {
+            int b = row / ntok, tok = row - b * ntok;
+            if (tok == 0) zero_dy = true;
+            else {
+                int tp = tok - 1;
+                tfr = tp / feat_G;
+                int p = tp - tfr * feat_G;
+                dbase = ((long)b * feat_G + p) * ((long)D * feat_T);
+            }
+        }
+        float4 xh[NCH], dyv[NCH];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            int c = lane + i * 64;
+            {
+                float4 xv = *reinterpret_cast<const float4*>(x + (size_t)row * D + c * 4);
+                xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                float d[4] = {0.f, 0.f, 0.f, 0.f};
+                if (!zero_dy) {
+                    if (!FEAT || feat_T <= 1) {
+                        const bf16_t* ph = dy_hi + dbase + c * 4;
+                        uint2 u = *reinterpret_cast<const uint2*>(ph);
+                        d[0] = __uint_as_float(u.x << 16), d[1] = __uint_as_float(u.x & 0xffff0000u);
+                        d[2] = __uint_as_float(u.y << 16), d[3] = __uint_as_float(u.y & 0xffff0000u);
+                        if (dy_lo) {
+                            uint2 w = *reinterpret_cast<const uint2*>(dy_lo + dbase + c * 4);
+                            d[0] += __uint_as_float(w.x << 16), d[1] += __uint_as_float(w.x & 0xffff0000u);
+                            d[2] += __uint_as_float(w.y << 16), d[3] += __uint_as_float(w.y & 0xffff0000u);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) d[j] = load1_split(dy_hi, dy_lo, (size_t)dbase + (long)(c * 4 + j) * feat_T + tfr);
+                    }
+                }
+                dyv[i] = make_float4(d[0], d[1], d[2], d[3]);
+                float4 g = *reinterpret_cast<const float4*>(gamma + c * 4);
+                float a0 = d[0] * g.x, a1 = d[1] * g.y, a2 = d[2] * g.z, a3 = d[3] * g.w;
+                s1 += a0 + a1 + a2 + a3;
+                s2 += a0 * xh[i].x + a1 * xh[i].y + a2 * xh[i].z + a3 * xh[i].w;
+            }
+        }
+        s1 = wave_sum(s1) / D;
+        s2 = wave_sum(s2) / D;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            int c = lane + i * 64;
+            {
+                float4 g = *reinterpret_cast<const float4*>(gamma + c * 4);
+                float4 r;
+                r.x = rs * (dyv[i].x * g.x - s1 - xh[i].x * s2);
+                r.y = rs * (dyv[i].y * g.y - s1 - xh[i].y * s2);
+                r.z = rs * (dyv[i].z * g.z - s1 - xh[i].z * s2);
+                r.w = rs * (dyv[i].w * g.w - s1 - xh[i].w * s2);
+                float* dp = dx + (size_t)row * D + c * 4;
+                if (accumulate) {
+                    float4 o = *reinterpret_cast<const float4*>(dp);
+                    r.x += o.x, r.y += o.y, r.z += o.z, r.w += o.w;
+                }
+                *reinterpret_cast<float4*>(dp) = r;
+                if (dxb_hi) {
+                    float f[4] = {r.x, r.y, r.z, r.w};
+                    store4_split(dxb_hi, dxb_lo, (size_t)row * D + c * 4, f);
+                }
+                ag[i].x += dyv[i].x * xh[i].x, ag[i].y += dyv[i].y * xh[i].y, ag[i].z += dyv[i].z * xh[i].z, ag[i].w += dyv[i].w * xh[i].w;
+                ab[i].x += dyv[i].x, ab[i].y += dyv[i].y, ab[i].z += dyv[i].z, ab[i].w += dyv[i].w;
+                ac[i].x += r.x, ac[i].y += r.y, ac[i].z += r.z, ac[i].w += r.w;
+            }
+        }
+    }
+    // cross-wave column reduction
+    for (int i = threadIdx.x; i < 3 * D; i += LNB_TPB) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        int c = lane + i * 64;
+        {
             float* r0 = red + c * 4;
             atomicAdd(r0 + 0, ag[i].x), atomicAdd(r0 + 1, ag[i].y), atomicAdd(r0 + 2, ag[i].z), atomicAdd(r0 + 3, ag[i].w);
             float* r1 = red + D + c * 4;
@@ -624,6 +739,23 @@ int ig_layernorm_bwd(const void* dy_hi, const void* dy_lo, const float* x, const
     const int rpb = 32;
     dim3 grid(ig_cdiv(M, rpb));
     size_t sm = 3 * (size_t)D * sizeof(float);
+#define IG_LNB_EXACT(NCH_)                                                                                              \
+    {                                                                                                                 \
+        if (feat_T > 0)                                                                                               \
+            hipLaunchKernelGGL((layernorm_bwd_exact_kernel<NCH_, true>), grid, dim3(LNB_TPB), sm, ST(stream),        \
+                               (const bf16_t*)dy_hi, (const bf16_t*)dy_lo, x, mean, rstd, gamma, dx, accumulate,      \
+                               (bf16_t*)dxb_hi, (bf16_t*)dxb_lo, dgamma, dbeta, dcol, M, D, rpb, feat_T, feat_G, ntok); \
+        else                                                                                                          \
+            hipLaunchKernelGGL((layernorm_bwd_exact_kernel<NCH_, false>), grid, dim3(LNB_TPB), sm, ST(stream),       \
+                               (const bf16_t*)dy_hi, (const bf16_t*)dy_lo, x, mean, rstd, gamma, dx, accumulate,      \
+                               (bf16_t*)dxb_hi, (bf16_t*)dxb_lo, dgamma, dbeta, dcol, M, D, rpb, feat_T, feat_G, ntok); \
+        return ig_check_launch("ig_layernorm_bwd");                                                                   \
+    }
+    if (D == 256) IG_LNB_EXACT(1)
+    if (D == 768) IG_LNB_EXACT(3)
+    if (D == 1024) IG_LNB_EXACT(4)
+    if (D == 1280) IG_LNB_EXACT(5)
+#undef IG_LNB_EXACT
     if (D <= 1024)
         hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, dim3(LNB_TPB), sm, ST(stream), (const bf16_t*)dy_hi, (const bf16_t*)dy_lo, x,
                            mean, rstd, gamma, dx, accumulate, (bf16_t*)dxb_hi, (bf16_t*)dxb_lo, dgamma, dbeta, dcol, M, D, rpb,

@@ -374,28 +374,33 @@ __global__ __launch_bounds__(NTHR2, (BKT == 32 ? 4 : 2)) void gemm2_kernel(AL al
         const int bm = tile_c / tiles_n, bn = tile_c - bm * tiles_n;
         tile_c += nbx;
         if constexpr (EP::kStagedAtomic) {
-            static_assert(!EP::kStagedAtomic || BKT == 64, "the LDS-staged atomic epilogue needs the 144 KiB ring");
-            // launched with one tile per workgroup: the LDS ring is idle here
-            __syncthreads();
-            float* st = reinterpret_cast<float*>(smem);  // 256 x 128 fp32 = 128 KiB
+            // launched with one tile per workgroup: the LDS ring is idle here.  The 256 x 128 fp32 tile is staged in two
+            // 128-row halves (64 KiB each) so that the 72 KiB BK=32 ring (2 workgroups/CU) is enough.
 #pragma unroll
-            for (int tm = 0; tm < 4; ++tm) {
-                const int ml = wm * 64 + tm * 16 + (lane & 15);
+            for (int hpass = 0; hpass < 2; ++hpass) {
+                __syncthreads();
+                float* st = reinterpret_cast<float*>(smem);
+                if ((wm >> 1) == hpass) {
 #pragma unroll
-                for (int tn = 0; tn < 4; ++tn) {
-                    const int c4 = (wn * 64 + tn * 16 + 4 * (lane >> 4)) >> 2;
-                    *reinterpret_cast<f32x4*>(st + ml * 128 + ((c4 ^ (ml & 7)) << 2)) = acc[tn][tm];
+                    for (int tm = 0; tm < 4; ++tm) {
+                        const int ml = (wm & 1) * 64 + tm * 16 + (lane & 15);
+#pragma unroll
+                        for (int tn = 0; tn < 4; ++tn) {
+                            const int c4 = (wn * 64 + tn * 16 + 4 * (lane >> 4)) >> 2;
+                            *reinterpret_cast<f32x4*>(st + ml * 128 + ((c4 ^ (ml & 7)) << 2)) = acc[tn][tm];
+                        }
+                    }
                 }
-            }
-            __syncthreads();
-            for (int rr = wave; rr < BM2; rr += NTHR2 / 64) {
-                const int m = bm * BM2 + rr;
-                if (m >= M) break;
+                __syncthreads();
+                for (int rr = wave; rr < 128; rr += NTHR2 / 64) {
+                    const int m = bm * BM2 + hpass * 128 + rr;
+                    if (m >= M) break;
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int nl = half * 64 + lane;
-                    const int n = bn * BN + nl;
-                    if (n < N) ep.add(m, n, st[rr * 128 + ((((nl >> 2) ^ (rr & 7)) << 2) | (nl & 3))]);
+                    for (int half = 0; half < 2; ++half) {
+                        const int nl = half * 64 + lane;
+                        const int n = bn * BN + nl;
+                        if (n < N) ep.add(m, n, st[rr * 128 + ((((nl >> 2) ^ (rr & 7)) << 2) | (nl & 3))]);
+                    }
                 }
             }
             return;
@@ -759,8 +764,14 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, i
         hipLaunchKernelGGL(kern, grid, dim3(NTHR2), G2<BKT_>::SMEM, st, al, bl, ep, M, N, K, tn, ntiles, kchunk, zp);     \
     }
         if constexpr (EP::kStagedAtomic) {
-            // one tile per workgroup, BK = 64 (the fp32 tile is staged through the 144 KiB ring)
-            if (split) IG_LAUNCH_V2(3, 64) else IG_LAUNCH_V2(1, 64)
+            // one tile per workgroup (split-K over blockIdx.y); the fp32 tile is staged through the ring in two halves
+            const int nk32 = ig_cdiv(K, 32);
+            int ks = 512 / (tm * tn * Z);  // two workgroups per CU
+            if (ks > nk32 / 16) ks = nk32 / 16;
+            if (ks < 1) ks = 1;
+            kchunk = ig_cdiv(nk32, ks);
+            grid.y = ig_cdiv(nk32, kchunk);
+            if (split) IG_LAUNCH_V2(3, 32) else IG_LAUNCH_V2(1, 32)
         } else {
             // persistent: two workgroups per CU walk the tile list; BK = 32 keeps the ring at 72 KiB
             if ((int)grid.x > 512) grid.x = 512;
