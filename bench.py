@@ -48,10 +48,10 @@ GEMM_OPS = ["ig_linear_fwd", "ig_linear_residual_fwd", "ig_linear_dgrad", "ig_li
             "ig_patch_embed_fwd"]  # fmt: skip
 TIMED_OPS = ["ig_linear_fwd", "ig_linear_residual_fwd", "ig_linear_dgrad", "ig_linear_wgrad"]
 KERNEL_OF = {
-    "ig_linear_fwd": "gemm2_kernel<PlainLoader,PlainLoader,EpStore,false,false,1>",
-    "ig_linear_residual_fwd": "gemm2_kernel<PlainLoader,PlainLoader,EpResidual,false,false,1>",
-    "ig_linear_dgrad": "gemm2_kernel<PlainLoader,PlainLoader,EpGradStore,false,true,1>",
-    "ig_linear_wgrad": "gemm2_kernel<PlainLoader,PlainLoader,EpAtomic,true,true,1>",
+    "ig_linear_fwd": "gemm2_kernel<PlainLoader,PlainLoader,EpStore,false,false,1,32>",
+    "ig_linear_residual_fwd": "gemm2_kernel<PlainLoader,PlainLoader,EpResidual,false,false,1,32>",
+    "ig_linear_dgrad": "gemm2_kernel<PlainLoader,PlainLoader,EpGradStore,false,true,1,32>",
+    "ig_linear_wgrad": "gemm2_kernel<PlainLoader,PlainLoader,EpAtomic,true,true,1,32>",
 }
 
 

@@ -714,6 +714,17 @@ inline int gemm_version() {
     }
     return v;
 }
+// engine for the head convolutions: v2 (256x128 LDS-DMA ring) when the output width fills 128-wide tiles, else v1
+inline int conv_version(int n_out) {
+    static int mode = -1;  // IG_CONV_V2: 0 = always v1 (default), 1 = v2 when n_out % 128 == 0, 2 = v2 when n_out >= 128
+    if (mode < 0) {
+        const char* e = getenv("IG_CONV_V2");
+        mode = e ? atoi(e) : 0;  // measured: v1 is faster for every conv stage (gather address math per LDS-DMA issue)
+    }
+    if (mode == 1 && n_out % 128 == 0) return 2;
+    if (mode == 2 && n_out >= 128) return 2;
+    return 1;
+}
 inline const bf16_t* zero_page() {
     static void* z = nullptr;
     if (!z) {
@@ -915,7 +926,7 @@ int ig_conv3x3_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const v
     ep.col_scale = bn_scale, ep.col_shift = bn_shift;  // eval-mode BatchNorm + ReLU folded into the epilogue
     return launch_gemm<Conv3Loader, PlainLoader, EpStore, false, false>(
         al, plain_b(w_hi, w_lo, Cout, 9 * Cin, 9L * Cin), ep, al.Mtot, Cout, 9 * Cin, 1, x_lo != nullptr,
-        (hipStream_t)stream, "ig_conv3x3_fwd", false, 1);
+        (hipStream_t)stream, "ig_conv3x3_fwd", false, conv_version(Cout));
 }
 
 // dx = conv_dgrad(dy, w) [* dropout mask of the conv input when drop_p > 0]
@@ -937,7 +948,7 @@ int ig_conv3x3_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, con
     ep.drop_thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
     ep.drop_inv = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     return launch_gemm<Conv3Loader, ConvWgtTRLoader, EpGradStore, false, true>(
-        al, bl, ep, al.Mtot, Cin, 9 * Cout, 1, dy_lo != nullptr, (hipStream_t)stream, "ig_conv3x3_dgrad", false, 1);
+        al, bl, ep, al.Mtot, Cin, 9 * Cout, 1, dy_lo != nullptr, (hipStream_t)stream, "ig_conv3x3_dgrad", false, conv_version(Cin));
 }
 
 // dWc[Cout][9][Cin] += sum_pixels dy[p][co] * x[shift_tap(p)][ci]
@@ -977,7 +988,7 @@ int ig_convT_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const voi
     ep.drop_thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
     ep.drop_inv = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     return launch_gemm<ConvTFwdALoader, ConvTFwdBLoader, EpStore, false, false>(
-        al, bl, ep, al.Mtot, Cout, 4 * Cin, 4, x_lo != nullptr, (hipStream_t)stream, "ig_convT_fwd", false, 1);
+        al, bl, ep, al.Mtot, Cout, 4 * Cin, 4, x_lo != nullptr, (hipStream_t)stream, "ig_convT_fwd", false, conv_version(Cout));
 }
 
 // dx (H,W,Cin) = stride-2 gather of dy (2H,2W,Cout) against Wc
@@ -995,7 +1006,7 @@ int ig_convT_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, const
     EpGradStore ep{};
     ep.out_hi = (bf16_t*)dx_hi, ep.out_lo = (bf16_t*)dx_lo, ep.ldo = Cin, ep.mode = 0;
     return launch_gemm<ConvTGradLoader, ConvWgtTRLoader, EpGradStore, false, true>(
-        al, bl, ep, al.Mtot, Cin, 9 * Cout, 1, dy_lo != nullptr, (hipStream_t)stream, "ig_convT_dgrad", false, 1);
+        al, bl, ep, al.Mtot, Cin, 9 * Cout, 1, dy_lo != nullptr, (hipStream_t)stream, "ig_convT_dgrad", false, conv_version(Cin));
 }
 
 // dWc[Cout][tap][Cin] += sum_{input pixels} dy[shift_tap(p)][co] * x[p][ci]     (blockIdx.z = tap)
