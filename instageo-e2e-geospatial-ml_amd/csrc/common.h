@@ -128,19 +128,27 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// Counter-based dropout mask: keep iff hash(seed, idx) >= p * 2^32.  Stateless so the backward pass
-// regenerates the same mask from the element index (no mask tensor in HBM).
-__device__ __forceinline__ uint32_t ig_hash(uint32_t seed, uint64_t idx) {
-    uint64_t z = idx + 0x9E3779B97F4A7C15ull * (uint64_t)(seed + 1u);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (uint32_t)(z >> 32);
+// Counter-based dropout mask (stateless: the backward pass regenerates it from the element index, no mask tensor in
+// HBM).  Elements are handled four at a time: two murmur3-finaliser hashes of (seed, idx/2) give four 16-bit uniforms;
+// keep iff u16 >= p * 65536.  (A 64-bit splitmix hash per element made the ConvTranspose epilogue issue-bound.)
+// idx4 must be a multiple of 4 and the tensor must have < 2^32 elements.
+__device__ __forceinline__ uint32_t ig_fmix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h;
 }
-// returns the multiplier (0 or 1/(1-p)) for element idx
-__device__ __forceinline__ float dropout_scale(uint32_t seed, uint64_t idx, uint32_t thresh, float inv_keep) {
-    return ig_hash(seed, idx) >= thresh ? inv_keep : 0.0f;
+__device__ __forceinline__ void dropout_scale4(uint32_t seed, uint32_t idx4, uint32_t thresh16, float inv_keep, float* m) {
+    const uint32_t base = seed * 0x9E3779B1u + (idx4 >> 1);
+    const uint32_t h0 = ig_fmix32(base), h1 = ig_fmix32(base + 1u);
+    m[0] = (h0 & 0xffffu) >= thresh16 ? inv_keep : 0.0f;
+    m[1] = (h0 >> 16) >= thresh16 ? inv_keep : 0.0f;
+    m[2] = (h1 & 0xffffu) >= thresh16 ? inv_keep : 0.0f;
+    m[3] = (h1 >> 16) >= thresh16 ? inv_keep : 0.0f;
 }
+static inline uint32_t ig_drop_thresh16(float p) { return p > 0.f ? (uint32_t)((double)p * 65536.0 + 0.5) : 0u; }
 
 // erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7): 1 rcp + 1 exp + 5 fma instead of the ~40-instruction
 // branchy libm erff -- the GELU epilogue of the fc1 GEMM (64 values per lane) was costing as much as its K loop.

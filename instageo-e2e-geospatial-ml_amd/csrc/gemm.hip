@@ -90,6 +90,18 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     uint4 ra[4], rb[4];
+    // row decode hoisted out of the K loop (K-contiguous operands: a thread keeps the same 4 rows for the whole tile);
+    // the convolution gathers were issue-bound on integer divisions recomputed per 16-byte unit per K-step
+    typename AL::Row arow[4];
+    typename BL::Row brow[4];
+    if constexpr (!A_TR) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) arow[i] = al.row(bm * BM + ((tid + i * NTHR) >> 3));
+    }
+    if constexpr (!B_TR) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) brow[i] = bl.row(bn * BNE + ((tid + i * NTHR) >> 3));
+    }
 
     // Loads are UNCONDITIONAL (invalid units read a dummy valid address and are zeroed by a select): a
     // branch around each load makes hipcc wait vmcnt(0) per load and serialises the whole tile fetch.
@@ -97,19 +109,23 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
     {                                                                                                     \
         const int seg_ = (NSEG == 1) ? 0 : (IT) / nk;                                                     \
         const int kt_ = kt0 + (IT)-seg_ * nk;                                                             \
+        const typename AL::Col acol_ = al.col(kt_ * 8 + (tid & 7));                                       \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
             const int u = tid + i * NTHR;                                                                 \
             bool ok;                                                                                      \
-            const bf16_t* p = A_TR ? al.ptr(seg_, kt_ * BK + (u >> 4), bm * 16 + (u & 15), ok)            \
-                                   : al.ptr(seg_, bm * BM + (u >> 3), kt_ * 8 + (u & 7), ok);             \
+            const bf16_t* p;                                                                              \
+            if constexpr (A_TR) p = al.ptr(seg_, kt_ * BK + (u >> 4), bm * 16 + (u & 15), ok);            \
+            else p = al.at(seg_, arow[i], acol_, ok);                                                     \
             uint4 v = *reinterpret_cast<const uint4*>(p);                                                 \
             ra[i] = ok ? v : make_uint4(0, 0, 0, 0);                                                      \
         }                                                                                                 \
+        const typename BL::Col bcol_ = bl.col(kt_ * 8 + (tid & 7));                                                                                                 \
         _Pragma("unroll") for (int i = 0; i < (B_TR ? 4 : NT); ++i) {                                     \
             const int u = tid + i * NTHR;                                                                 \
             bool ok;                                                                                      \
-            const bf16_t* p = B_TR ? bl.ptr(seg_, kt_ * BK + (u >> 4), bn * (BNE / 8) + (u & 15), ok)     \
-                                   : bl.ptr(seg_, bn * BNE + (u >> 3), kt_ * 8 + (u & 7), ok);            \
+            const bf16_t* p;                                                                              \
+            if constexpr (B_TR) p = bl.ptr(seg_, kt_ * BK + (u >> 4), bn * (BNE / 8) + (u & 15), ok);     \
+            else p = bl.at(seg_, brow[i], bcol_, ok);                                                     \
             if (B_TR && NT < 4) ok = ok && ((u & 15) < BNE / 8);                                          \
             uint4 v = *reinterpret_cast<const uint4*>(p);                                                 \
             rb[i] = ok ? v : make_uint4(0, 0, 0, 0);                                                      \
@@ -457,6 +473,14 @@ struct PlainLoader {  // row-major [R][ld], logical width C (multiple of 8)
         ok = (r < R) & (c < C);
         return base[seg] + (ok ? (long)r * ld + c : 0L);
     }
+    struct Row { long off; bool ok; };
+    struct Col { int c; bool ok; };
+    __device__ Row row(int r) const { return Row{(long)r * ld, r < R}; }
+    __device__ Col col(int c8) const { return Col{c8 * 8, c8 * 8 < C}; }
+    __device__ const bf16_t* at(int seg, const Row& rw, const Col& cl, bool& ok) const {
+        ok = rw.ok & cl.ok;
+        return base[seg] + (ok ? rw.off + cl.c : 0L);
+    }
 };
 
 // NHWC 3x3 pad-1 gather: row r = pixel (b,y,x), column unit -> (tap, channel).  sign=+1 reads
@@ -476,6 +500,26 @@ struct Conv3Loader {
         int sy = y + sign * (ky - 1), sx = x + sign * (kx - 1);
         ok = (r < Mtot) & (k < 9 * C) & ((unsigned)sy < (unsigned)H) & ((unsigned)sx < (unsigned)W);
         return base[seg] + (ok ? ((long)(b * H + sy) * W + sx) * C + c : 0L);
+    }
+    // split decode: 2 integer divisions per ROW (once per tile) + 1 per COLUMN unit (once per K-step, shared by 4 rows)
+    struct Row { int y, x; long pix; bool ok; };
+    struct Col { int dy, dx, c; bool ok; };
+    __device__ Row row(int r) const {
+        int hw = H * W;
+        int b = r / hw, rem = r - b * hw;
+        int y = rem / W, x = rem - y * W;
+        return Row{y, x, (long)r, r < Mtot};
+    }
+    __device__ Col col(int c8) const {
+        int k = c8 * 8;
+        int tap = k / C, c = k - tap * C;
+        int ky = (tap * 11) >> 5, kx = tap - ky * 3;  // tap / 3 for tap < 32
+        return Col{sign * (ky - 1), sign * (kx - 1), c, k < 9 * C};
+    }
+    __device__ const bf16_t* at(int seg, const Row& rw, const Col& cl, bool& ok) const {
+        int sy = rw.y + cl.dy, sx = rw.x + cl.dx;
+        ok = rw.ok & cl.ok & ((unsigned)sy < (unsigned)H) & ((unsigned)sx < (unsigned)W);
+        return base[seg] + (ok ? (rw.pix + cl.dy * W + cl.dx) * C + cl.c : 0L);
     }
 };
 
@@ -504,6 +548,25 @@ struct ConvTFwdALoader {
         ok = (r < Mtot) & (k < K) & (sy < H) & (sx < W);
         return base[seg] + (ok ? ((long)(b * H + sy) * W + sx) * C + c : 0L);
     }
+    struct Row { int y, x; long pix; bool ok; };
+    struct Col { int dy, dx, c; bool ok; };
+    __device__ Row row(int r) const {
+        int hw = H * W;
+        int b = r / hw, rem = r - b * hw;
+        int y = rem / W, x = rem - y * W;
+        return Row{y, x, (long)r, r < Mtot};
+    }
+    __device__ Col col(int c8) const {
+        int k = c8 * 8;
+        int tl = k / C, c = k - tl * C;
+        int tyi = tl / nkx, txi = tl - tyi * nkx;
+        int ky = ky0 + 2 * tyi, kx = kx0 + 2 * txi;
+        return Col{ky == 0, kx == 0, c, k < K};
+    }
+    __device__ const bf16_t* at(int seg, const Row& rw, const Col& cl, bool& ok) const {
+        ok = rw.ok & cl.ok & (rw.y + cl.dy < H) & (rw.x + cl.dx < W);
+        return base[seg] + (ok ? (rw.pix + cl.dy * W + cl.dx) * C + cl.c : 0L);
+    }
 };
 // matching weight view: n = co, k = (local tap, ci) of storage Wc[co][tap][ci]
 struct ConvTFwdBLoader {
@@ -525,6 +588,12 @@ struct ConvTFwdBLoader {
         ok = (r < Cout) & (k < K);
         return base[seg] + (ok ? ((long)r * 9 + tap) * C + c : 0L);
     }
+    // (row, column) decode split: the K loop re-uses a row decode across K-steps and a column decode across rows
+    struct Row { int r; };
+    struct Col { int c8; };
+    __device__ Row row(int r) const { return Row{r}; }
+    __device__ Col col(int c8) const { return Col{c8}; }
+    __device__ const bf16_t* at(int seg, const Row& rw, const Col& cl, bool& ok) const { return ptr(seg, rw.r, cl.c8, ok); }
 };
 
 // dgrad weight view (TR operand): reduce row = (tap, co), contiguous columns = ci of Wc[co][tap][ci]
@@ -539,6 +608,12 @@ struct ConvWgtTRLoader {
         ok = (tap < 9) & (c < Cin);
         return base[seg] + (ok ? ((long)co * 9 + tap) * Cin + c : 0L);
     }
+    // (row, column) decode split: the K loop re-uses a row decode across K-steps and a column decode across rows
+    struct Row { int r; };
+    struct Col { int c8; };
+    __device__ Row row(int r) const { return Row{r}; }
+    __device__ Col col(int c8) const { return Col{c8}; }
+    __device__ const bf16_t* at(int seg, const Row& rw, const Col& cl, bool& ok) const { return ptr(seg, rw.r, cl.c8, ok); }
 };
 
 // ConvTranspose dgrad A: row = input pixel (b,iy,ix), k = (tap, co): reads dOut(2iy-1+ky, 2ix-1+kx).
@@ -561,6 +636,26 @@ struct ConvTGradLoader {
         int oy = 2 * y - 1 + ky, ox = 2 * x - 1 + kx;
         ok = (tap < 9) & (c < Cout) & (r < Mtot) & ((unsigned)oy < (unsigned)(2 * H)) & ((unsigned)ox < (unsigned)(2 * W));
         return base[seg] + (ok ? ((long)(b * 2 * H + oy) * (2 * W) + ox) * Cout + c : 0L);
+    }
+    struct Row { int y, x; long opix; bool ok; };  // opix = index of output pixel (2y, 2x) in the (2H, 2W) image
+    struct Col { int ky, kx, c; bool ok; };
+    __device__ Row row(int r) const {
+        int hw = H * W;
+        int b = r / hw, rem = r - b * hw;
+        int y = rem / W, x = rem - y * W;
+        return Row{y, x, ((long)(b * 2 * H + 2 * y)) * (2 * W) + 2 * x, r < Mtot};
+    }
+    __device__ Col col(int c8) const {
+        int k = c8 * 8;
+        int tap = (fixed_tap == -1) ? k / Cout : tapz;
+        int c = (fixed_tap == -1) ? k - tap * Cout : k;
+        int ky = (tap * 11) >> 5, kx = tap - ky * 3;
+        return Col{ky, kx, c, (tap < 9) && (c < Cout)};
+    }
+    __device__ const bf16_t* at(int seg, const Row& rw, const Col& cl, bool& ok) const {
+        int oy = 2 * rw.y - 1 + cl.ky, ox = 2 * rw.x - 1 + cl.kx;
+        ok = rw.ok & cl.ok & ((unsigned)oy < (unsigned)(2 * H)) & ((unsigned)ox < (unsigned)(2 * W));
+        return base[seg] + (ok ? (rw.opix + (long)(cl.ky - 1) * (2 * W) + (cl.kx - 1)) * Cout + cl.c : 0L);
     }
 };
 
@@ -610,8 +705,10 @@ struct EpStore {
             for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
         }
         if (drop_thresh) {
+            float mk[4];
+            dropout_scale4(drop_seed, (uint32_t)idx, drop_thresh, drop_inv, mk);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] *= dropout_scale(drop_seed, idx + i, drop_thresh, drop_inv);
+            for (int i = 0; i < 4; ++i) v[i] *= mk[i];
         }
         store4_split(out_hi, out_lo, idx, v);
     }
@@ -639,8 +736,10 @@ struct EpGradStore {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] *= gelu_erf_grad(load1_split(pre_hi, pre_lo, idx + i));
         } else if (mode == 2 && drop_thresh) {
+            float mk[4];
+            dropout_scale4(drop_seed, (uint32_t)idx, drop_thresh, drop_inv, mk);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] *= dropout_scale(drop_seed, idx + i, drop_thresh, drop_inv);
+            for (int i = 0; i < 4; ++i) v[i] *= mk[i];
         }
         store4_split(out_hi, out_lo, idx, v);
         return f32x4{v[0], v[1], v[2], v[3]};
@@ -943,9 +1042,10 @@ int ig_conv3x3_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, con
     seg_b(bl.base, w_hi, w_lo);
     bl.Cout = Cout, bl.Cin = Cin;
     EpGradStore ep{};
+    IG_REQUIRE(drop_p <= 0.f || (double)B * H * W * Cin < 4294967296.0, "ig_conv3x3_dgrad: dropout needs < 2^32 elements");
     ep.out_hi = (bf16_t*)dx_hi, ep.out_lo = (bf16_t*)dx_lo, ep.ldo = Cin, ep.mode = 2;
     ep.drop_seed = drop_seed, ep.drop_seed_dev = drop_seed_dev;
-    ep.drop_thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    ep.drop_thresh = ig_drop_thresh16(drop_p);
     ep.drop_inv = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     return launch_gemm<Conv3Loader, ConvWgtTRLoader, EpGradStore, false, true>(
         al, bl, ep, al.Mtot, Cin, 9 * Cout, 1, dy_lo != nullptr, (hipStream_t)stream, "ig_conv3x3_dgrad", false, conv_version(Cin));
@@ -983,9 +1083,10 @@ int ig_convT_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const voi
     bl.Cout = Cout, bl.C = Cin;
     EpStore ep{};
     ep.out_hi = (bf16_t*)y_hi, ep.out_lo = (bf16_t*)y_lo, ep.bias = bias, ep.ldo = Cout;
+    IG_REQUIRE(drop_p <= 0.f || (double)B * 4 * H * W * Cout < 4294967296.0, "ig_convT_fwd: dropout needs < 2^32 elements");
     ep.phase_map = 1, ep.H = H, ep.W = W;
     ep.drop_seed = drop_seed, ep.drop_seed_dev = drop_seed_dev;
-    ep.drop_thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    ep.drop_thresh = ig_drop_thresh16(drop_p);
     ep.drop_inv = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     return launch_gemm<ConvTFwdALoader, ConvTFwdBLoader, EpStore, false, false>(
         al, bl, ep, al.Mtot, Cout, 4 * Cin, 4, x_lo != nullptr, (hipStream_t)stream, "ig_convT_fwd", false, conv_version(Cout));

@@ -32,8 +32,11 @@ __global__ __launch_bounds__(TPB) void classifier_fwd_kernel(const bf16_t* __res
         size_t idx = (size_t)m * C + c8 * 8;
         load8_split(f_hi, f_lo, idx, f);
         if (drop_thresh) {
+            float mk[8];
+            dropout_scale4(drop_seed, (uint32_t)idx, drop_thresh, drop_inv, mk);
+            dropout_scale4(drop_seed, (uint32_t)idx + 4u, drop_thresh, drop_inv, mk + 4);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] *= dropout_scale(drop_seed, idx + j, drop_thresh, drop_inv);
+            for (int j = 0; j < 8; ++j) f[j] *= mk[j];
         }
 #pragma unroll
         for (int n = 0; n < MAXC; ++n) {
@@ -83,9 +86,15 @@ __global__ __launch_bounds__(TPB) void classifier_bwd_kernel(const float* __rest
             for (int j = 0; j < 8; ++j) f[j] = 0.f;
         }
         float msk[8];
+        if (drop_thresh && act) {
+            dropout_scale4(drop_seed, (uint32_t)idx, drop_thresh, drop_inv, msk);
+            dropout_scale4(drop_seed, (uint32_t)idx + 4u, drop_thresh, drop_inv, msk + 4);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) msk[j] = 1.f;
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            msk[j] = (drop_thresh && act) ? dropout_scale(drop_seed, idx + j, drop_thresh, drop_inv) : 1.f;
             f[j] *= msk[j];
             o[j] = 0.f;
         }
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(TPB) void confusion_kernel(const long long* __restr
         if (hist[i]) atomicAdd(confusion + i, (unsigned long long)hist[i]);
 }
 
-inline uint32_t thresh_of(float p) { return p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u; }
+inline uint32_t thresh_of(float p) { return ig_drop_thresh16(p); }
 
 }  // namespace
 
