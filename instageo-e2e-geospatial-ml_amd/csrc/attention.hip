@@ -69,15 +69,49 @@ __device__ __forceinline__ void pack_acc(const f32x4& a0, const f32x4& a1, bf16x
     }
 }
 
-// cooperative load of one 32 x 64 tile: rows [r0, r0+32) of a (token-major) slice, zero beyond nrows
-__device__ __forceinline__ void load_tile(char* tile, const bf16_t* base, long row_stride, int r0, int nrows, int tid, int nthr) {
-    for (int u = tid; u < KT * 8; u += nthr) {
-        int r = u >> 3, c = u & 7;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (r0 + r < nrows) v = *reinterpret_cast<const uint4*>(base + (long)(r0 + r) * row_stride + c * 8);
-        *reinterpret_cast<uint4*>(tile + lds_kc(r, c)) = v;
+// Cooperative, register-staged load of one GROUP of streamed tiles: NT tensors x NTL tiles of 32 x 64 bf16, laid out in
+// LDS as tile index (tensor * NTL + j).  fetch() issues every global load back to back (unconditional loads from a
+// clamped address + select: a branch around a load would serialise them on vmcnt(0)); commit() writes the staged
+// registers to LDS.  With nthr * NR >= UPG a whole group is one pass, so the NEXT group's fetch can stay in flight
+// while the current one is consumed; smaller workgroups fall back to synchronous passes.
+template <int NT, int NTL>
+struct TileGroup {
+    static constexpr int UPG = NT * NTL * KT * 8;  // 16-byte units per group
+    static constexpr int NR = 3;                   // staged units per thread and pass (13 waves x 3 >= 2048 units)
+    uint4 v[NR];
+
+    __device__ __forceinline__ void fetch(int u0, const bf16_t* b0, const bf16_t* b1, const bf16_t* b2, const bf16_t* b3, long rs0,
+                                          long rs1, int tile0, int nrows, int tid, int nthr) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            if (u0 + i * nthr >= UPG) break;  // uniform
+            const int u = u0 + i * nthr + tid;
+            const int t = u >> 8, tensor = t / NTL, j = t - tensor * NTL, r = (u >> 3) & 31, c = u & 7;
+            const int row = (tile0 + j) * KT + r;
+            const bool ok = u < UPG && row < nrows;
+            const bf16_t* base = tensor == 0 ? b0 : tensor == 1 ? b1 : tensor == 2 ? b2 : b3;
+            const long rs = (tensor & 1) ? rs1 : rs0;
+            const uint4 x = *reinterpret_cast<const uint4*>(base + (ok ? (long)row * rs + c * 8 : 0L));
+            v[i] = ok ? x : make_uint4(0, 0, 0, 0);
+        }
     }
-}
+    __device__ __forceinline__ void commit(int u0, char* smem, int tid, int nthr) const {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            if (u0 + i * nthr >= UPG) break;
+            const int u = u0 + i * nthr + tid;
+            if (u < UPG) *reinterpret_cast<uint4*>(smem + (u >> 8) * TILE + lds_kc((u >> 3) & 31, u & 7)) = v[i];
+        }
+    }
+    // synchronous variant for small workgroups
+    __device__ __forceinline__ void load_sync(char* smem, const bf16_t* b0, const bf16_t* b1, const bf16_t* b2, const bf16_t* b3,
+                                              long rs0, long rs1, int tile0, int nrows, int tid, int nthr) {
+        for (int u0 = 0; u0 < UPG; u0 += NR * nthr) {
+            fetch(u0, b0, b1, b2, b3, rs0, rs1, tile0, nrows, tid, nthr);
+            commit(u0, smem, tid, nthr);
+        }
+    }
+};
 
 // register fragment of the wave-owned 16-row tile straight from global memory (zero beyond nrows)
 __device__ __forceinline__ bf16x8_t load_own(const bf16_t* base, long row_stride, int row0, int nrows, int s, int lane) {
@@ -120,17 +154,19 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(const bf16_t* __restrict
     float m_run = -INFINITY, l_run = 0.f;
 
     const int ntiles = (N + KT - 1) / KT;
+    TileGroup<SPLIT ? 4 : 2, NTL> tg;
+    const int nthr = blockDim.x;
+    // whole group in one pass -> prefetch the next group during compute (not in split mode: no registers to spare)
+    const bool pre = !SPLIT && nthr * tg.NR >= tg.UPG;
+    const bf16_t *gk_hi = base_hi + H * HD, *gv_hi = base_hi + 2 * H * HD;
+    const bf16_t *gk_lo = SPLIT ? base_lo + H * HD : nullptr, *gv_lo = SPLIT ? base_lo + 2 * H * HD : nullptr;
+    if (pre) tg.fetch(0, gk_hi, gv_hi, gk_lo, gv_lo, RS, RS, 0, N, tid, nthr);
     for (int kt0 = 0; kt0 < ntiles; kt0 += NTL) {
         __syncthreads();  // previous tiles fully consumed
-        for (int j = 0; j < NTL && kt0 + j < ntiles; ++j) {
-            load_tile(k_hi0 + j * TILE, base_hi + H * HD, RS, (kt0 + j) * KT, N, tid, blockDim.x);
-            load_tile(v_hi0 + j * TILE, base_hi + 2 * H * HD, RS, (kt0 + j) * KT, N, tid, blockDim.x);
-            if constexpr (SPLIT) {
-                load_tile(k_lo0 + j * TILE, base_lo + H * HD, RS, (kt0 + j) * KT, N, tid, blockDim.x);
-                load_tile(v_lo0 + j * TILE, base_lo + 2 * H * HD, RS, (kt0 + j) * KT, N, tid, blockDim.x);
-            }
-        }
+        if (pre) tg.commit(0, smem, tid, nthr);
+        else tg.load_sync(smem, gk_hi, gv_hi, gk_lo, gv_lo, RS, RS, kt0, N, tid, nthr);
         __syncthreads();
+        if (pre && kt0 + NTL < ntiles) tg.fetch(0, gk_hi, gv_hi, gk_lo, gv_lo, RS, RS, kt0 + NTL, N, tid, nthr);
         for (int j = 0; j < NTL && kt0 + j < ntiles; ++j) {
         const int kt = kt0 + j;
         const char *k_hi = k_hi0 + j * TILE, *v_hi = v_hi0 + j * TILE, *k_lo = k_lo0 + j * TILE, *v_lo = v_lo0 + j * TILE;
@@ -201,27 +237,33 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(const bf16_t* __restrict
     }
 }
 
-// delta[b][h][q] = sum_d dO[q][d] * O[q][d]
+// delta[b][h][q] = sum_d dO[q][d] * O[q][d].  Eight consecutive lanes share one (b, q, h) row of 64 values: every
+// wave-instruction reads 1 KiB contiguous (a thread-per-row version touched 64 different lines per load).
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o_hi, const bf16_t* __restrict__ o_lo,
-                                  const bf16_t* __restrict__ do_hi, const bf16_t* __restrict__ do_lo, float* __restrict__ delta,
-                                  int B, int N, int H) {
-    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;  // over B*N*H
-    if (i >= (long)B * N * H) return;
-    int h = (int)(i % H);
-    long bn = i / H;
-    int q = (int)(bn % N);
-    long b = bn / N;
-    size_t base = (size_t)bn * H * HD + h * HD;
+                                                         const bf16_t* __restrict__ do_hi, const bf16_t* __restrict__ do_lo,
+                                                         float* __restrict__ delta, int B, int N, int H) {
+    const long t = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const long i = t >> 3;  // (b, q, h) index; rows are padded to a multiple of 32 by the launch so shuffles stay full
+    const int c = (int)(t & 7);
+    const bool ok = i < (long)B * N * H;
     float acc = 0.f;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
+    if (ok) {
         float a[8], d[8];
-        load8_split(o_hi, o_lo, base + c * 8, a);
-        load8_split(do_hi, do_lo, base + c * 8, d);
+        load8_split(o_hi, o_lo, (size_t)i * HD + c * 8, a);
+        load8_split(do_hi, do_lo, (size_t)i * HD + c * 8, d);
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc += a[j] * d[j];
     }
-    delta[(b * H + h) * N + q] = acc;
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (ok && c == 0) {
+        const int h = (int)(i % H);
+        const long bn = i / H;
+        const int q = (int)(bn % N);
+        const long bb = bn / N;
+        delta[(bb * H + h) * N + q] = acc;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -265,17 +307,19 @@ __global__ __launch_bounds__(1024) void attn_bwd_dq_kernel(const bf16_t* __restr
     for (int i = 0; i < 4; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int ntiles = (N + KT - 1) / KT;
+    TileGroup<SPLIT ? 4 : 2, NTL> tg;
+    const int nthr = blockDim.x;
+    // whole group in one pass -> prefetch the next group during compute (not in split mode: no registers to spare)
+    const bool pre = !SPLIT && nthr * tg.NR >= tg.UPG;
+    const bf16_t *gk_hi = base_hi + H * HD, *gv_hi = base_hi + 2 * H * HD;
+    const bf16_t *gk_lo = SPLIT ? base_lo + H * HD : nullptr, *gv_lo = SPLIT ? base_lo + 2 * H * HD : nullptr;
+    if (pre) tg.fetch(0, gk_hi, gv_hi, gk_lo, gv_lo, RS, RS, 0, N, tid, nthr);
     for (int kt0 = 0; kt0 < ntiles; kt0 += NTL) {
+        __syncthreads();  // previous tiles fully consumed
+        if (pre) tg.commit(0, smem, tid, nthr);
+        else tg.load_sync(smem, gk_hi, gv_hi, gk_lo, gv_lo, RS, RS, kt0, N, tid, nthr);
         __syncthreads();
-        for (int j = 0; j < NTL && kt0 + j < ntiles; ++j) {
-            load_tile(k_hi0 + j * TILE, base_hi + H * HD, RS, (kt0 + j) * KT, N, tid, blockDim.x);
-            load_tile(v_hi0 + j * TILE, base_hi + 2 * H * HD, RS, (kt0 + j) * KT, N, tid, blockDim.x);
-            if constexpr (SPLIT) {
-                load_tile(k_lo0 + j * TILE, base_lo + H * HD, RS, (kt0 + j) * KT, N, tid, blockDim.x);
-                load_tile(v_lo0 + j * TILE, base_lo + 2 * H * HD, RS, (kt0 + j) * KT, N, tid, blockDim.x);
-            }
-        }
-        __syncthreads();
+        if (pre && kt0 + NTL < ntiles) tg.fetch(0, gk_hi, gv_hi, gk_lo, gv_lo, RS, RS, kt0 + NTL, N, tid, nthr);
         for (int j = 0; j < NTL && kt0 + j < ntiles; ++j) {
         const int kt = kt0 + j;
         const char *k_hi = k_hi0 + j * TILE, *v_hi = v_hi0 + j * TILE, *k_lo = k_lo0 + j * TILE, *v_lo = v_lo0 + j * TILE;
@@ -361,22 +405,21 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_kernel(const bf16_t* __rest
     for (int i = 0; i < 4; ++i) dk[i] = dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int ntiles = (N + KT - 1) / KT;
+    TileGroup<SPLIT ? 4 : 2, NTL> tg;
+    const int nthr = blockDim.x;
+    const bool pre = !SPLIT && nthr * tg.NR >= tg.UPG;
+    if (pre) tg.fetch(0, base_hi, dob_hi, base_lo, dob_lo, RS, OS, 0, N, tid, nthr);
     for (int qt0 = 0; qt0 < ntiles; qt0 += NTL) {
         __syncthreads();
-        for (int j = 0; j < NTL && qt0 + j < ntiles; ++j) {
-            load_tile(q_hi0 + j * TILE, base_hi, RS, (qt0 + j) * KT, N, tid, blockDim.x);
-            load_tile(d_hi0 + j * TILE, dob_hi, OS, (qt0 + j) * KT, N, tid, blockDim.x);
-            if constexpr (SPLIT) {
-                load_tile(q_lo0 + j * TILE, base_lo, RS, (qt0 + j) * KT, N, tid, blockDim.x);
-                load_tile(d_lo0 + j * TILE, dob_lo, OS, (qt0 + j) * KT, N, tid, blockDim.x);
-            }
-        }
+        if (pre) tg.commit(0, smem, tid, nthr);
+        else tg.load_sync(smem, base_hi, dob_hi, base_lo, dob_lo, RS, OS, qt0, N, tid, nthr);
         if (tid < NTL * KT) {
             int qq = qt0 * KT + tid;
             s_lse0[tid] = qq < N ? lse[((long)b * H + h) * N + qq] : INFINITY;
             s_del0[tid] = qq < N ? delta[((long)b * H + h) * N + qq] : 0.f;
         }
         __syncthreads();
+        if (pre && qt0 + NTL < ntiles) tg.fetch(0, base_hi, dob_hi, base_lo, dob_lo, RS, OS, qt0 + NTL, N, tid, nthr);
         for (int j = 0; j < NTL && qt0 + j < ntiles; ++j) {
         const char *q_hi = q_hi0 + j * TILE, *d_hi = d_hi0 + j * TILE, *q_lo = q_lo0 + j * TILE, *d_lo = d_lo0 + j * TILE;
         const float *s_lse = s_lse0 + j * KT, *s_del = s_del0 + j * KT;
@@ -471,7 +514,7 @@ int ig_attention_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi,
     if (B == 0 || N == 0) return IG_OK;
     hipStream_t st = (hipStream_t)stream;
     long rows = (long)B * N * H;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, (const bf16_t*)out_hi,
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows * 8 + 255) / 256)), dim3(256), 0, st, (const bf16_t*)out_hi,
                        (const bf16_t*)out_lo, (const bf16_t*)dout_hi, (const bf16_t*)dout_lo, delta, B, N, H);
     int nblk, nw;
     wave_geometry(N, nblk, nw);

@@ -393,13 +393,13 @@ __global__ __launch_bounds__(LNB_TPB) void layernorm_bwd_exact_kernel(const bf16
 }
 
 // column sums of a bf16/split matrix: out[c] += sum_m x[m][c]   (bias gradients)
-// grid (row chunk, 2048-column chunk); threads tile (row slice, 8-column unit) with 4 independent 16-byte loads in
+// grid (row chunk, 1024-column chunk); threads tile (row slice, 8-column unit) with 4 independent 16-byte loads in
 // flight; per-block LDS reduction, then one atomic per (block, column)
 __global__ __launch_bounds__(TPB) void colsum_kernel(const bf16_t* __restrict__ hi, const bf16_t* __restrict__ lo,
                                                      float* __restrict__ out, long M, int C, int rows_per_block) {
-    __shared__ float red[2048];
-    const int c0 = blockIdx.y * 2048;
-    const int cw = min(2048, C - c0);  // columns of this block
+    __shared__ float red[1024];
+    const int c0 = blockIdx.y * 1024;
+    const int cw = min(1024, C - c0);  // columns of this block (128 units: two row slices per 256 threads)
     const int units = cw / 8;
     const int tu = min(units, TPB), nslice = TPB / tu;
     const int u = threadIdx.x % tu, sl = threadIdx.x / tu;
@@ -772,7 +772,7 @@ int ig_colsum(const void* hi, const void* lo, float* out, long M, int C, void* s
     IG_REQUIRE(C % 8 == 0, "ig_colsum: C must be a multiple of 8 (got %d)", C);
     if (M == 0) return IG_OK;
     const int rpb = M > 65536 ? 512 : 32;
-    hipLaunchKernelGGL(colsum_kernel, dim3(ig_cdiv(M, rpb), ig_cdiv(C, 2048)), dim3(TPB), 0, ST(stream), (const bf16_t*)hi, (const bf16_t*)lo, out, M,
+    hipLaunchKernelGGL(colsum_kernel, dim3(ig_cdiv(M, rpb), ig_cdiv(C, 1024)), dim3(TPB), 0, ST(stream), (const bf16_t*)hi, (const bf16_t*)lo, out, M,
                        C, rpb);
     return ig_check_launch("ig_colsum");
 }

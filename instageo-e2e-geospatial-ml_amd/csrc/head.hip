@@ -54,14 +54,18 @@ __global__ __launch_bounds__(TPB) void classifier_fwd_kernel(const bf16_t* __res
 }
 
 // df[m][c] = drop_mask * sum_n dl[b][n][pix] * w[n][c] * gscale ; dW[n][c] += sum_m dl*f_dropped ; db[n] += sum_m dl
-// gscale = 1/(*count) when count != NULL (fused trainer: dlogits left un-normalised by the loss kernel)
+// gscale = 1/(*count) when count != NULL (fused trainer: dlogits left un-normalised by the loss kernel).
+// A thread owns ONE 8-channel unit and walks BWD_ITER pixels (stride = pixel slices per block), so dW partials stay in
+// registers and are reduced once per block (a thread-per-pixel version spent its time in 96 wave reductions per pixel).
+constexpr int BWD_ITER = 32;
+template <int NC>  // class-count bucket (register accumulators are NC x 8)
 __global__ __launch_bounds__(TPB) void classifier_bwd_kernel(const float* __restrict__ dl, const bf16_t* __restrict__ f_hi,
                                                              const bf16_t* __restrict__ f_lo, const float* __restrict__ w,
                                                              bf16_t* __restrict__ df_hi, bf16_t* __restrict__ df_lo,
                                                              float* __restrict__ dw, float* __restrict__ db, const double* count,
                                                              long M, long HW, int C, int ncls, uint32_t drop_seed,
                                                              const uint32_t* drop_seed_dev, uint32_t drop_thresh, float drop_inv) {
-    extern __shared__ float sm[];  // w[ncls*C] | dwacc[ncls*C] | dbacc[ncls]
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // w[ncls*C] | dwacc[ncls*C] | dbacc[ncls]
     if (drop_seed_dev) drop_seed += *drop_seed_dev;
     float* sw = sm;
     float* sdw = sm + ncls * C;
@@ -70,57 +74,62 @@ __global__ __launch_bounds__(TPB) void classifier_bwd_kernel(const float* __rest
     for (int i = threadIdx.x; i < ncls; i += TPB) sdb[i] = 0.f;
     __syncthreads();
     const float gscale = count ? (float)(1.0 / fmax(count[1], 1.0)) : 1.f;
-    long m = blockIdx.x * (long)TPB + threadIdx.x;
-    const bool act = m < M;
-    float g[MAXC];
-    long b = act ? m / HW : 0, pix = act ? m - b * HW : 0;
+    const int nu = C / 8, nsl = TPB / nu;
+    const int u = threadIdx.x % nu, sl = threadIdx.x / nu;
+    if (sl < nsl) {
+        float dwa[NC][8], dba[NC];
 #pragma unroll
-    for (int n = 0; n < MAXC; ++n) g[n] = (act && n < ncls) ? dl[(b * ncls + n) * HW + pix] * gscale : 0.f;
-    const int lane = threadIdx.x & 63;
-    for (int c8 = 0; c8 < C / 8; ++c8) {
-        float f[8], o[8];
-        size_t idx = (size_t)m * C + c8 * 8;
-        if (act) load8_split(f_hi, f_lo, idx, f);
-        else {
+        for (int n = 0; n < NC; ++n) {
+            dba[n] = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = 0.f;
+            for (int j = 0; j < 8; ++j) dwa[n][j] = 0.f;
         }
-        float msk[8];
-        if (drop_thresh && act) {
-            dropout_scale4(drop_seed, (uint32_t)idx, drop_thresh, drop_inv, msk);
-            dropout_scale4(drop_seed, (uint32_t)idx + 4u, drop_thresh, drop_inv, msk + 4);
-        } else {
+        const long m0 = (long)blockIdx.x * nsl * BWD_ITER + sl;
+        for (int it = 0; it < BWD_ITER; ++it) {
+            const long m = m0 + (long)it * nsl;
+            if (m >= M) break;
+            const long b = m / HW, pix = m - b * HW;
+            const size_t idx = (size_t)m * C + u * 8;
+            float f[8], o[8], msk[8];
+            load8_split(f_hi, f_lo, idx, f);
+            if (drop_thresh) {
+                dropout_scale4(drop_seed, (uint32_t)idx, drop_thresh, drop_inv, msk);
+                dropout_scale4(drop_seed, (uint32_t)idx + 4u, drop_thresh, drop_inv, msk + 4);
+            } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) msk[j] = 1.f;
-        }
+                for (int j = 0; j < 8; ++j) msk[j] = 1.f;
+            }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            f[j] *= msk[j];
-            o[j] = 0.f;
-        }
+            for (int j = 0; j < 8; ++j) {
+                f[j] *= msk[j];
+                o[j] = 0.f;
+            }
 #pragma unroll
-        for (int n = 0; n < MAXC; ++n) {
-            if (n < ncls) {
-                const float* wr = sw + n * C + c8 * 8;
+            for (int n = 0; n < NC; ++n) {
+                if (n < ncls) {
+                    const float g = dl[(b * ncls + n) * HW + pix] * gscale;
+                    const float4 w0 = *reinterpret_cast<const float4*>(sw + n * C + u * 8);
+                    const float4 w1 = *reinterpret_cast<const float4*>(sw + n * C + u * 8 + 4);
+                    const float wr[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+                    dba[n] += g;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    o[j] += g[n] * wr[j];
-                    float t = wave_sum(g[n] * f[j]);  // wave-level partial of dW[n][c]
-                    if (lane == 0) atomicAdd(sdw + n * C + c8 * 8 + j, t);
+                    for (int j = 0; j < 8; ++j) {
+                        o[j] += g * wr[j];
+                        dwa[n][j] += g * f[j];
+                    }
                 }
             }
-        }
-        if (act) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] *= msk[j];
             store8_split(df_hi, df_lo, idx, o);
         }
-    }
 #pragma unroll
-    for (int n = 0; n < MAXC; ++n) {
-        if (n < ncls) {
-            float t = wave_sum(g[n]);
-            if (lane == 0) atomicAdd(sdb + n, t);
+        for (int n = 0; n < NC; ++n) {
+            if (n < ncls) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) atomicAdd(sdw + n * C + u * 8 + j, dwa[n][j]);
+                if (u == 0) atomicAdd(sdb + n, dba[n]);
+            }
         }
     }
     __syncthreads();
@@ -250,10 +259,19 @@ int ig_classifier_bwd(const float* dlogits, const void* f_hi, const void* f_lo, 
     IG_REQUIRE(C % 8 == 0 && ncls >= 1 && ncls <= MAXC, "ig_classifier_bwd: need C %% 8 == 0 and 1 <= ncls <= %d", MAXC);
     long M = (long)B * HW;
     if (M == 0) return IG_OK;
+    IG_REQUIRE(C / 8 <= TPB, "ig_classifier_bwd: C must be <= %d", TPB * 8);
     size_t sm = (2 * (size_t)ncls * C + ncls) * sizeof(float);
-    hipLaunchKernelGGL(classifier_bwd_kernel, dim3((unsigned)((M + TPB - 1) / TPB)), dim3(TPB), sm, (hipStream_t)stream, dlogits,
-                       (const bf16_t*)f_hi, (const bf16_t*)f_lo, w, (bf16_t*)df_hi, (bf16_t*)df_lo, dw, db, count, M, HW, C, ncls,
-                       drop_seed, drop_seed_dev, thresh_of(drop_p), drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f);
+    const long ppb = (long)(TPB / (C / 8)) * BWD_ITER;  // pixels per block
+    const dim3 grid((unsigned)((M + ppb - 1) / ppb));
+#define IG_CLS_BWD(NC)                                                                                                          \
+    hipLaunchKernelGGL(classifier_bwd_kernel<NC>, grid, dim3(TPB), sm, (hipStream_t)stream, dlogits, (const bf16_t*)f_hi,       \
+                       (const bf16_t*)f_lo, w, (bf16_t*)df_hi, (bf16_t*)df_lo, dw, db, count, M, HW, C, ncls, drop_seed,        \
+                       drop_seed_dev, thresh_of(drop_p), drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f)
+    if (ncls <= 2) IG_CLS_BWD(2);
+    else if (ncls <= 4) IG_CLS_BWD(4);
+    else if (ncls <= 8) IG_CLS_BWD(8);
+    else IG_CLS_BWD(16);
+#undef IG_CLS_BWD
     return ig_check_launch("ig_classifier_bwd");
 }
 
