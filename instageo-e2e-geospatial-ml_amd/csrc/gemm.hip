@@ -29,15 +29,25 @@ constexpr int TILE_BYTES = 16384;           // one operand tile
 constexpr int SMEM_BYTES = 4 * TILE_BYTES;  // 2 buffers x (A + B)
 
 // LDS images ------------------------------------------------------------------------------------
-// K-contiguous tile: 128 rows x 8 chunks(16 B); chunk ^= row&7  (ds_read_b128 conflict-free)
+// K-contiguous tile: up to 128 rows x 8 chunks(16 B); chunk ^= row&7  (ds_read_b128 conflict-free)
 __device__ __forceinline__ int lds_kc(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
-// TR tile: 64 k-rows x 16 chunks; chunk pair index ^= key(k) (ds_read_b64_tr_b16 conflict-free)
-__device__ __forceinline__ int lds_tr(int k, int c) {
-    int key = (k & 3) | (((k >> 3) & 1) << 2);
-    return k * 256 + ((c ^ (key << 1)) << 4);
+// TR tile: 64 k-rows x UPR chunks (UPR = 16 / 12 / 8 for a 128 / 96 / 64-column tile).  A ds_read_b64_tr_b16 pass covers
+// k-rows {k..k+3, k+8..k+11} x 32 B; the chunk-pair XOR key separates the rows that alias in the 256-byte bank span:
+//   256 B rows: all 8 alias        -> 3-bit key (k&3, k>>3)
+//   192 B rows: k and k+8 alias    -> 1-bit key (k>>3)      (rows k..k+3 sit 64 B apart)
+//   128 B rows: k, k+2, k+8, k+10  -> 2-bit key (k>>1, k>>3)
+template <int UPR>
+__device__ __forceinline__ int lds_trw(int k, int c) {
+    static_assert(UPR == 16 || UPR == 12 || UPR == 8, "unsupported TR tile width");
+    int key;
+    if constexpr (UPR == 16) key = (k & 3) | (((k >> 3) & 1) << 2);
+    else if constexpr (UPR == 12) key = (k >> 3) & 1;
+    else key = ((k >> 1) & 1) | (((k >> 3) & 1) << 1);
+    return k * (UPR * 16) + ((c ^ (key << 1)) << 4);
 }
+__device__ __forceinline__ int lds_tr(int k, int c) { return lds_trw<16>(k, c); }
 
-template <bool TR>
+template <bool TR, int UPR = 16>
 __device__ __forceinline__ bf16x8_t read_frag(const char* tile, int row0, int s, int lane) {
     if constexpr (!TR) {
         int r = row0 + (lane & 15);
@@ -49,21 +59,27 @@ __device__ __forceinline__ bf16x8_t read_frag(const char* tile, int row0, int s,
         int col = row0 + 4 * p;
         int chunk = col >> 3, sub = (col & 7) * 2;
         typedef __attribute__((address_space(3))) s16x4* lds_ptr;
-        s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(tile + lds_tr(k0, chunk) + sub));
-        s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(tile + lds_tr(k0 + 4, chunk) + sub));
+        s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(tile + lds_trw<UPR>(k0, chunk) + sub));
+        s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(tile + lds_trw<UPR>(k0 + 4, chunk) + sub));
         typedef __attribute__((ext_vector_type(8))) short s16x8;
         s16x8 r = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         return __builtin_bit_cast(bf16x8_t, r);
     }
 }
 
-// NT = 16-column MFMA tiles per wave along n: 4 -> 128-wide block tile, 2 -> 64-wide (narrow Cout of the decode head)
-template <class AL, class BL, class EP, bool A_TR, bool B_TR, int NSEG, int NT>
+// v1: 4 waves (2 x 2), each owning MT x NT MFMA tiles of 16 x 16 => block tile (32 MT) x (32 NT), MT, NT in {2, 3, 4}.
+// The decode head's channel counts are multiples of 48 (48, 96, 192, 384): 96- and 64-wide tiles avoid the 25-60 % of
+// wasted MFMA columns (or rows, for the weight gradients) a fixed 128 x 128 tile would spend on them, and the smaller
+// LDS footprint (2 x (MT + NT) x 4 KiB) lets a third workgroup share the CU.
+template <class AL, class BL, class EP, bool A_TR, bool B_TR, int NSEG, int MT, int NT>
 __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, int N, int K, int tiles_n, int kchunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    constexpr int BNE = NT * 32;  // effective block width
+    constexpr int BME = MT * 32, BNE = NT * 32;   // block tile
+    constexpr int UPA = MT * 4, UPB = NT * 4;     // 16-byte units per k-row of a TR tile
+    constexpr int TA_BYTES = MT * 4096, TB_BYTES = NT * 4096;
+    constexpr int BUF_BYTES = TA_BYTES + TB_BYTES;
     // XCD-aware tile order: hardware deals consecutive workgroups round-robin over the 8 XCDs (private L2s);
     // remap so that each XCD owns a CONTIGUOUS run of tiles (neighbours share the A row panel / B panels).
     int bid = blockIdx.x;
@@ -83,20 +99,20 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
     if (nk <= 0) return;
     const int total = nk * NSEG;
 
-    f32x4 acc[NT][4];
+    f32x4 acc[NT][MT];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    uint4 ra[4], rb[4];
-    // row decode hoisted out of the K loop (K-contiguous operands: a thread keeps the same 4 rows for the whole tile);
+    uint4 ra[MT], rb[NT];
+    // row decode hoisted out of the K loop (K-contiguous operands: a thread keeps the same rows for the whole tile);
     // the convolution gathers were issue-bound on integer divisions recomputed per 16-byte unit per K-step
-    typename AL::Row arow[4];
-    typename BL::Row brow[4];
+    typename AL::Row arow[MT];
+    typename BL::Row brow[NT];
     if constexpr (!A_TR) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) arow[i] = al.row(bm * BM + ((tid + i * NTHR) >> 3));
+        for (int i = 0; i < MT; ++i) arow[i] = al.row(bm * BME + ((tid + i * NTHR) >> 3));
     }
     if constexpr (!B_TR) {
 #pragma unroll
@@ -110,37 +126,39 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
         const int seg_ = (NSEG == 1) ? 0 : (IT) / nk;                                                     \
         const int kt_ = kt0 + (IT)-seg_ * nk;                                                             \
         const typename AL::Col acol_ = al.col(kt_ * 8 + (tid & 7));                                       \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                  \
             const int u = tid + i * NTHR;                                                                 \
             bool ok;                                                                                      \
             const bf16_t* p;                                                                              \
-            if constexpr (A_TR) p = al.ptr(seg_, kt_ * BK + (u >> 4), bm * 16 + (u & 15), ok);            \
+            if constexpr (A_TR) p = al.ptr(seg_, kt_ * BK + u / UPA, bm * UPA + u % UPA, ok);             \
             else p = al.at(seg_, arow[i], acol_, ok);                                                     \
             uint4 v = *reinterpret_cast<const uint4*>(p);                                                 \
             ra[i] = ok ? v : make_uint4(0, 0, 0, 0);                                                      \
         }                                                                                                 \
-        const typename BL::Col bcol_ = bl.col(kt_ * 8 + (tid & 7));                                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < (B_TR ? 4 : NT); ++i) {                                     \
+        const typename BL::Col bcol_ = bl.col(kt_ * 8 + (tid & 7));                                       \
+        _Pragma("unroll") for (int i = 0; i < NT; ++i) {                                                  \
             const int u = tid + i * NTHR;                                                                 \
             bool ok;                                                                                      \
             const bf16_t* p;                                                                              \
-            if constexpr (B_TR) p = bl.ptr(seg_, kt_ * BK + (u >> 4), bn * (BNE / 8) + (u & 15), ok);     \
+            if constexpr (B_TR) p = bl.ptr(seg_, kt_ * BK + u / UPB, bn * UPB + u % UPB, ok);             \
             else p = bl.at(seg_, brow[i], bcol_, ok);                                                     \
-            if (B_TR && NT < 4) ok = ok && ((u & 15) < BNE / 8);                                          \
             uint4 v = *reinterpret_cast<const uint4*>(p);                                                 \
             rb[i] = ok ? v : make_uint4(0, 0, 0, 0);                                                      \
         }                                                                                                 \
     }
 #define GEMM_LSTORE(BUF)                                                                                 \
     {                                                                                                     \
-        char* ta_ = smem + (BUF)*2 * TILE_BYTES;                                                          \
-        char* tb_ = ta_ + TILE_BYTES;                                                                     \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
+        char* ta_ = smem + (BUF)*BUF_BYTES;                                                               \
+        char* tb_ = ta_ + TA_BYTES;                                                                       \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                  \
             const int u = tid + i * NTHR;                                                                 \
-            const int oa = A_TR ? lds_tr(u >> 4, u & 15) : lds_kc(u >> 3, u & 7);                         \
-            const int ob = B_TR ? lds_tr(u >> 4, u & 15) : lds_kc(u >> 3, u & 7);                         \
+            const int oa = A_TR ? lds_trw<UPA>(u / UPA, u % UPA) : lds_kc(u >> 3, u & 7);                 \
             *reinterpret_cast<uint4*>(ta_ + oa) = ra[i];                                                  \
-            if (B_TR || i < NT) *reinterpret_cast<uint4*>(tb_ + ob) = rb[i];                              \
+        }                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < NT; ++i) {                                                  \
+            const int u = tid + i * NTHR;                                                                 \
+            const int ob = B_TR ? lds_trw<UPB>(u / UPB, u % UPB) : lds_kc(u >> 3, u & 7);                 \
+            *reinterpret_cast<uint4*>(tb_ + ob) = rb[i];                                                  \
         }                                                                                                 \
     }
 
@@ -150,19 +168,19 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
     for (int it = 0; it < total; ++it) {
         const int cur = it & 1;
         if (it + 1 < total) GEMM_GLOAD(it + 1);
-        const char* ta = smem + cur * 2 * TILE_BYTES;
-        const char* tb = ta + TILE_BYTES;
+        const char* ta = smem + cur * BUF_BYTES;
+        const char* tb = ta + TA_BYTES;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8_t af[4], bf[NT];
+            bf16x8_t af[MT], bf[NT];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) af[t] = read_frag<A_TR>(ta, wm * 64 + t * 16, s, lane);
+            for (int t = 0; t < MT; ++t) af[t] = read_frag<A_TR, UPA>(ta, wm * (MT * 16) + t * 16, s, lane);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) bf[t] = read_frag<B_TR>(tb, wn * (NT * 16) + t * 16, s, lane);
+            for (int t = 0; t < NT; ++t) bf[t] = read_frag<B_TR, UPB>(tb, wn * (NT * 16) + t * 16, s, lane);
 #pragma unroll
             for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
-                for (int tm = 0; tm < 4; ++tm)
+                for (int tm = 0; tm < MT; ++tm)
                     acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[tn], af[tm], acc[tn][tm], 0, 0, 0);
         }
         if (it + 1 < total) GEMM_LSTORE(cur ^ 1);
@@ -176,8 +194,8 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
         // row-contiguously: every wave-instruction adds 256 contiguous bytes (the full-rate atomic shape).
         float* st = reinterpret_cast<float*>(smem);
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm) {
-            const int ml = wm * 64 + tm * 16 + (lane & 15);
+        for (int tm = 0; tm < MT; ++tm) {
+            const int ml = wm * (MT * 16) + tm * 16 + (lane & 15);
 #pragma unroll
             for (int tn = 0; tn < NT; ++tn) {
                 const int c4 = (wn * (NT * 16) + tn * 16 + 4 * (lane >> 4)) >> 2;
@@ -185,12 +203,10 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
             }
         }
         __syncthreads();
-        for (int rr = wave; rr < BM; rr += NTHR / 64) {
-            const int m = bm * BM + rr;
+        for (int rr = wave; rr < BME; rr += NTHR / 64) {
+            const int m = bm * BME + rr;
             if (m >= M) break;
-#pragma unroll
-            for (int half = 0; half < NT / 2; ++half) {
-                const int nl = half * 64 + lane;
+            for (int nl = lane; nl < BNE; nl += 64) {
                 const int n = bn * BNE + nl;
                 if (n < N) ep.add(m, n, st[rr * 128 + ((((nl >> 2) ^ (rr & 7)) << 2) | (nl & 3))]);
             }
@@ -199,8 +215,8 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
     }
     // epilogue: lane owns C[m][n..n+3]
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm) {
-        int m = bm * BM + wm * 64 + tm * 16 + (lane & 15);
+    for (int tm = 0; tm < MT; ++tm) {
+        int m = bm * BME + wm * (MT * 16) + tm * 16 + (lane & 15);
         if (m >= M) continue;
 #pragma unroll
         for (int tn = 0; tn < NT; ++tn) {
@@ -840,10 +856,20 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, i
     // v2 (256x128, LDS-DMA ring) wins on the encoder linears; the head convolutions (Cout 48..384, huge M) are
     // better served by the 128x128 register-staged tile at 2 workgroups/CU until a narrow-N tile exists
     const int ver = force_ver ? force_ver : gemm_version();
-    const int bm_rows = ver == 2 ? BM2 : BM;
-    // 64-wide tile when it wastes fewer MFMA columns than the 128-wide one (Cout = 48, 192, ...); not for atomic epilogues
-    const bool narrow = ver == 1 && !EP::kStagedAtomic && ig_cdiv(N, 64) * 64 < ig_cdiv(N, BN) * BN;
-    int tm = ig_cdiv(M, bm_rows), tn = narrow ? ig_cdiv(N, 64) : ig_cdiv(N, BN);
+    // v1 tile shape (32 MT x 32 NT): the candidate with the fewest padded rows/columns, ties to the larger tile.
+    // Weight gradients (atomic epilogue) vary MT (M = Cout), everything else varies NT (N = Cout).
+    int mt = 4, nt = 4;
+    if (ver == 1) {
+        if constexpr (EP::kStagedAtomic) {
+            if (ig_cdiv(M, 96) * 96 < ig_cdiv(M, 128) * 128) mt = 3;
+        } else {
+            long best = (long)ig_cdiv(N, 128) * 128;
+            for (int c = 3; c >= 2; --c)
+                if ((long)ig_cdiv(N, 32 * c) * 32 * c < best) best = (long)ig_cdiv(N, 32 * c) * 32 * c, nt = c;
+        }
+    }
+    const int bm_rows = ver == 2 ? BM2 : 32 * mt;
+    int tm = ig_cdiv(M, bm_rows), tn = ver == 2 ? ig_cdiv(N, BN) : ig_cdiv(N, 32 * nt);
     int nk_all = ig_cdiv(K, BK);
     int ksplit = 1;
     if (allow_ksplit) {  // atomic epilogues only: fill the chip once; every extra split is one more atomic pass
@@ -892,20 +918,32 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, i
         return ig_check_launch(what);
     }
     dim3 block(NTHR);
-#define IG_LAUNCH_V1(NSEG_, NT_)                                                                                      \
+#define IG_LAUNCH_V1(NSEG_, MT_, NT_)                                                                                 \
     {                                                                                                                  \
-        auto kern = gemm_kernel<AL, BL, EP, A_TR, B_TR, NSEG_, NT_>;                                                   \
+        auto kern = gemm_kernel<AL, BL, EP, A_TR, B_TR, NSEG_, MT_, NT_>;                                              \
+        constexpr int ring_ = 2 * (MT_ + NT_) * 4096, stage_ = EP::kStagedAtomic ? MT_ * 32 * 512 : 0;                 \
+        constexpr int lds_ = ring_ > stage_ ? ring_ : stage_;                                                          \
         static bool attr_done = false;                                                                                 \
         if (!attr_done) {                                                                                              \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);      \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_);            \
             attr_done = true;                                                                                          \
         }                                                                                                              \
-        hipLaunchKernelGGL(kern, grid, block, SMEM_BYTES, st, al, bl, ep, M, N, K, tn, kchunk);                        \
+        hipLaunchKernelGGL(kern, grid, block, lds_, st, al, bl, ep, M, N, K, tn, kchunk);                              \
     }
-    if (narrow) {
-        if (split) IG_LAUNCH_V1(3, 2) else IG_LAUNCH_V1(1, 2)
+    if constexpr (EP::kStagedAtomic) {
+        if (mt == 3) {
+            if (split) IG_LAUNCH_V1(3, 3, 4) else IG_LAUNCH_V1(1, 3, 4)
+        } else {
+            if (split) IG_LAUNCH_V1(3, 4, 4) else IG_LAUNCH_V1(1, 4, 4)
+        }
     } else {
-        if (split) IG_LAUNCH_V1(3, 4) else IG_LAUNCH_V1(1, 4)
+        if (nt == 2) {
+            if (split) IG_LAUNCH_V1(3, 4, 2) else IG_LAUNCH_V1(1, 4, 2)
+        } else if (nt == 3) {
+            if (split) IG_LAUNCH_V1(3, 4, 3) else IG_LAUNCH_V1(1, 4, 3)
+        } else {
+            if (split) IG_LAUNCH_V1(3, 4, 4) else IG_LAUNCH_V1(1, 4, 4)
+        }
     }
 #undef IG_LAUNCH_V1
     return ig_check_launch(what);
