@@ -67,18 +67,21 @@ __device__ __forceinline__ bf16x8_t read_frag(const char* tile, int row0, int s,
     }
 }
 
-// v1: 4 waves (2 x 2), each owning MT x NT MFMA tiles of 16 x 16 => block tile (32 MT) x (32 NT), MT, NT in {2, 3, 4}.
-// The decode head's channel counts are multiples of 48 (48, 96, 192, 384): 96- and 64-wide tiles avoid the 25-60 % of
-// wasted MFMA columns (or rows, for the weight gradients) a fixed 128 x 128 tile would spend on them, and the smaller
-// LDS footprint (2 x (MT + NT) x 4 KiB) lets a third workgroup share the CU.
-template <class AL, class BL, class EP, bool A_TR, bool B_TR, int NSEG, int MT, int NT>
+// v1: 4 waves laid out WM x WN (2 x 2, 4 x 1 or 1 x 4), each owning MT x NT MFMA tiles of 16 x 16 => block tile
+// (16 WM MT) x (16 WN NT).  The decode head's channel counts are multiples of 48 (48, 96, 192, 384): 48-, 96- and
+// 64-wide tiles avoid the 25-60 % of wasted MFMA columns (or rows, for the weight gradients) a fixed 128 x 128 tile
+// would spend on them, and the smaller LDS footprint lets a third workgroup share the CU.
+template <class AL, class BL, class EP, bool A_TR, bool B_TR, int NSEG, int MT, int NT, int WM>
 __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, int N, int K, int tiles_n, int kchunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    constexpr int BME = MT * 32, BNE = NT * 32;   // block tile
-    constexpr int UPA = MT * 4, UPB = NT * 4;     // 16-byte units per k-row of a TR tile
-    constexpr int TA_BYTES = MT * 4096, TB_BYTES = NT * 4096;
+    constexpr int WN = 4 / WM;
+    const int wm = wave / WN, wn = wave % WN;
+    constexpr int BME = WM * MT * 16, BNE = WN * NT * 16;  // block tile
+    constexpr int UPA = BME / 8, UPB = BNE / 8;            // 16-byte units per k-row of a TR tile
+    constexpr int UPA_L = UPA <= 8 ? 8 : UPA <= 12 ? 12 : 16, UPB_L = UPB <= 8 ? 8 : UPB <= 12 ? 12 : 16;  // LDS row pitch
+    constexpr int NA = (BME * 8 + NTHR - 1) / NTHR, NB = (BNE * 8 + NTHR - 1) / NTHR;  // staged units per thread
+    constexpr int TA_BYTES = A_TR ? 1024 * UPA_L : 128 * BME, TB_BYTES = B_TR ? 1024 * UPB_L : 128 * BNE;
     constexpr int BUF_BYTES = TA_BYTES + TB_BYTES;
     // XCD-aware tile order: hardware deals consecutive workgroups round-robin over the 8 XCDs (private L2s);
     // remap so that each XCD owns a CONTIGUOUS run of tiles (neighbours share the A row panel / B panels).
@@ -105,18 +108,18 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    uint4 ra[MT], rb[NT];
+    uint4 ra[NA], rb[NB];
     // row decode hoisted out of the K loop (K-contiguous operands: a thread keeps the same rows for the whole tile);
     // the convolution gathers were issue-bound on integer divisions recomputed per 16-byte unit per K-step
-    typename AL::Row arow[MT];
-    typename BL::Row brow[NT];
+    typename AL::Row arow[NA];
+    typename BL::Row brow[NB];
     if constexpr (!A_TR) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) arow[i] = al.row(bm * BME + ((tid + i * NTHR) >> 3));
+        for (int i = 0; i < NA; ++i) arow[i] = al.row(bm * BME + ((tid + i * NTHR) >> 3));
     }
     if constexpr (!B_TR) {
 #pragma unroll
-        for (int i = 0; i < NT; ++i) brow[i] = bl.row(bn * BNE + ((tid + i * NTHR) >> 3));
+        for (int i = 0; i < NB; ++i) brow[i] = bl.row(bn * BNE + ((tid + i * NTHR) >> 3));
     }
 
     // Loads are UNCONDITIONAL (invalid units read a dummy valid address and are zeroed by a select): a
@@ -126,22 +129,24 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
         const int seg_ = (NSEG == 1) ? 0 : (IT) / nk;                                                     \
         const int kt_ = kt0 + (IT)-seg_ * nk;                                                             \
         const typename AL::Col acol_ = al.col(kt_ * 8 + (tid & 7));                                       \
-        _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                  \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                  \
             const int u = tid + i * NTHR;                                                                 \
             bool ok;                                                                                      \
             const bf16_t* p;                                                                              \
             if constexpr (A_TR) p = al.ptr(seg_, kt_ * BK + u / UPA, bm * UPA + u % UPA, ok);             \
             else p = al.at(seg_, arow[i], acol_, ok);                                                     \
+            if ((BME * 8) % NTHR) ok = ok && u < BME * 8; /* k-row beyond the tile -> masked by ptr/at too */ \
             uint4 v = *reinterpret_cast<const uint4*>(p);                                                 \
             ra[i] = ok ? v : make_uint4(0, 0, 0, 0);                                                      \
         }                                                                                                 \
         const typename BL::Col bcol_ = bl.col(kt_ * 8 + (tid & 7));                                       \
-        _Pragma("unroll") for (int i = 0; i < NT; ++i) {                                                  \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                  \
             const int u = tid + i * NTHR;                                                                 \
             bool ok;                                                                                      \
             const bf16_t* p;                                                                              \
             if constexpr (B_TR) p = bl.ptr(seg_, kt_ * BK + u / UPB, bn * UPB + u % UPB, ok);             \
             else p = bl.at(seg_, brow[i], bcol_, ok);                                                     \
+            if ((BNE * 8) % NTHR) ok = ok && u < BNE * 8;                                                 \
             uint4 v = *reinterpret_cast<const uint4*>(p);                                                 \
             rb[i] = ok ? v : make_uint4(0, 0, 0, 0);                                                      \
         }                                                                                                 \
@@ -150,15 +155,19 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
     {                                                                                                     \
         char* ta_ = smem + (BUF)*BUF_BYTES;                                                               \
         char* tb_ = ta_ + TA_BYTES;                                                                       \
-        _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                  \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                  \
             const int u = tid + i * NTHR;                                                                 \
-            const int oa = A_TR ? lds_trw<UPA>(u / UPA, u % UPA) : lds_kc(u >> 3, u & 7);                 \
-            *reinterpret_cast<uint4*>(ta_ + oa) = ra[i];                                                  \
+            int oa;                                                                                       \
+            if constexpr (A_TR) oa = lds_trw<UPA_L>(u / UPA, u % UPA);                                    \
+            else oa = lds_kc(u >> 3, u & 7);                                                              \
+            if (((BME * 8) % NTHR) == 0 || u < BME * 8) *reinterpret_cast<uint4*>(ta_ + oa) = ra[i];      \
         }                                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < NT; ++i) {                                                  \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                  \
             const int u = tid + i * NTHR;                                                                 \
-            const int ob = B_TR ? lds_trw<UPB>(u / UPB, u % UPB) : lds_kc(u >> 3, u & 7);                 \
-            *reinterpret_cast<uint4*>(tb_ + ob) = rb[i];                                                  \
+            int ob;                                                                                       \
+            if constexpr (B_TR) ob = lds_trw<UPB_L>(u / UPB, u % UPB);                                    \
+            else ob = lds_kc(u >> 3, u & 7);                                                              \
+            if (((BNE * 8) % NTHR) == 0 || u < BNE * 8) *reinterpret_cast<uint4*>(tb_ + ob) = rb[i];      \
         }                                                                                                 \
     }
 
@@ -174,9 +183,9 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
         for (int s = 0; s < 2; ++s) {
             bf16x8_t af[MT], bf[NT];
 #pragma unroll
-            for (int t = 0; t < MT; ++t) af[t] = read_frag<A_TR, UPA>(ta, wm * (MT * 16) + t * 16, s, lane);
+            for (int t = 0; t < MT; ++t) af[t] = read_frag<A_TR, UPA_L>(ta, wm * (MT * 16) + t * 16, s, lane);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) bf[t] = read_frag<B_TR, UPB>(tb, wn * (NT * 16) + t * 16, s, lane);
+            for (int t = 0; t < NT; ++t) bf[t] = read_frag<B_TR, UPB_L>(tb, wn * (NT * 16) + t * 16, s, lane);
 #pragma unroll
             for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
@@ -849,6 +858,8 @@ inline const bf16_t* zero_page() {
     return (const bf16_t*)z;
 }
 
+constexpr int tr_pitch(int upr) { return upr <= 8 ? 8 : upr <= 12 ? 12 : 16; }
+
 template <class AL, class BL, class EP, bool A_TR, bool B_TR>
 int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int Z, bool split, hipStream_t st,
                 const char* what, bool allow_ksplit = false, int force_ver = 0) {
@@ -856,20 +867,25 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, i
     // v2 (256x128, LDS-DMA ring) wins on the encoder linears; the head convolutions (Cout 48..384, huge M) are
     // better served by the 128x128 register-staged tile at 2 workgroups/CU until a narrow-N tile exists
     const int ver = force_ver ? force_ver : gemm_version();
-    // v1 tile shape (32 MT x 32 NT): the candidate with the fewest padded rows/columns, ties to the larger tile.
-    // Weight gradients (atomic epilogue) vary MT (M = Cout), everything else varies NT (N = Cout).
+    // v1 tile shape: the candidate with the fewest padded rows/columns, ties to the larger tile.  Weight gradients
+    // (atomic epilogue) vary the tile height (M = Cout), everything else the width (N = Cout).  Code 1 = 48.
     int mt = 4, nt = 4;
+    int bm_rows = BM2, bn_cols = BN;
     if (ver == 1) {
-        if constexpr (EP::kStagedAtomic) {
-            if (ig_cdiv(M, 96) * 96 < ig_cdiv(M, 128) * 128) mt = 3;
-        } else {
-            long best = (long)ig_cdiv(N, 128) * 128;
-            for (int c = 3; c >= 2; --c)
-                if ((long)ig_cdiv(N, 32 * c) * 32 * c < best) best = (long)ig_cdiv(N, 32 * c) * 32 * c, nt = c;
+        static const int cand[4] = {128, 96, 64, 48};
+        static const int code[4] = {4, 3, 2, 1};
+        const int dim = EP::kStagedAtomic ? M : N;
+        long best = -1;
+        int pick = 0;
+        for (int c = 0; c < 4; ++c) {
+            if (EP::kStagedAtomic && cand[c] == 64) continue;
+            const long padded = (long)ig_cdiv(dim, cand[c]) * cand[c];
+            if (best < 0 || padded < best) best = padded, pick = c;
         }
+        if (EP::kStagedAtomic) mt = code[pick], bm_rows = cand[pick], bn_cols = 128;
+        else nt = code[pick], bn_cols = cand[pick], bm_rows = nt == 1 ? 256 : 128;
     }
-    const int bm_rows = ver == 2 ? BM2 : 32 * mt;
-    int tm = ig_cdiv(M, bm_rows), tn = ver == 2 ? ig_cdiv(N, BN) : ig_cdiv(N, 32 * nt);
+    int tm = ig_cdiv(M, bm_rows), tn = ig_cdiv(N, bn_cols);
     int nk_all = ig_cdiv(K, BK);
     int ksplit = 1;
     if (allow_ksplit) {  // atomic epilogues only: fill the chip once; every extra split is one more atomic pass
@@ -918,10 +934,13 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, i
         return ig_check_launch(what);
     }
     dim3 block(NTHR);
-#define IG_LAUNCH_V1(NSEG_, MT_, NT_)                                                                                 \
+#define IG_LAUNCH_V1(NSEG_, MT_, NT_, WM_)                                                                            \
     {                                                                                                                  \
-        auto kern = gemm_kernel<AL, BL, EP, A_TR, B_TR, NSEG_, MT_, NT_>;                                              \
-        constexpr int ring_ = 2 * (MT_ + NT_) * 4096, stage_ = EP::kStagedAtomic ? MT_ * 32 * 512 : 0;                 \
+        auto kern = gemm_kernel<AL, BL, EP, A_TR, B_TR, NSEG_, MT_, NT_, WM_>;                                         \
+        constexpr int bme_ = WM_ * MT_ * 16, bne_ = (4 / WM_) * NT_ * 16;                                              \
+        constexpr int ta_ = A_TR ? 1024 * tr_pitch(bme_ / 8) : 128 * bme_;                                             \
+        constexpr int tb_ = B_TR ? 1024 * tr_pitch(bne_ / 8) : 128 * bne_;                                             \
+        constexpr int ring_ = 2 * (ta_ + tb_), stage_ = EP::kStagedAtomic ? bme_ * 512 : 0;                            \
         constexpr int lds_ = ring_ > stage_ ? ring_ : stage_;                                                          \
         static bool attr_done = false;                                                                                 \
         if (!attr_done) {                                                                                              \
@@ -931,18 +950,22 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, i
         hipLaunchKernelGGL(kern, grid, block, lds_, st, al, bl, ep, M, N, K, tn, kchunk);                              \
     }
     if constexpr (EP::kStagedAtomic) {
-        if (mt == 3) {
-            if (split) IG_LAUNCH_V1(3, 3, 4) else IG_LAUNCH_V1(1, 3, 4)
+        if (mt == 1) {  // 48 x 128
+            if (split) IG_LAUNCH_V1(3, 3, 2, 1) else IG_LAUNCH_V1(1, 3, 2, 1)
+        } else if (mt == 3) {
+            if (split) IG_LAUNCH_V1(3, 3, 4, 2) else IG_LAUNCH_V1(1, 3, 4, 2)
         } else {
-            if (split) IG_LAUNCH_V1(3, 4, 4) else IG_LAUNCH_V1(1, 4, 4)
+            if (split) IG_LAUNCH_V1(3, 4, 4, 2) else IG_LAUNCH_V1(1, 4, 4, 2)
         }
     } else {
-        if (nt == 2) {
-            if (split) IG_LAUNCH_V1(3, 4, 2) else IG_LAUNCH_V1(1, 4, 2)
+        if (nt == 1) {  // 256 x 48
+            if (split) IG_LAUNCH_V1(3, 4, 3, 4) else IG_LAUNCH_V1(1, 4, 3, 4)
+        } else if (nt == 2) {
+            if (split) IG_LAUNCH_V1(3, 4, 2, 2) else IG_LAUNCH_V1(1, 4, 2, 2)
         } else if (nt == 3) {
-            if (split) IG_LAUNCH_V1(3, 4, 3) else IG_LAUNCH_V1(1, 4, 3)
+            if (split) IG_LAUNCH_V1(3, 4, 3, 2) else IG_LAUNCH_V1(1, 4, 3, 2)
         } else {
-            if (split) IG_LAUNCH_V1(3, 4, 4) else IG_LAUNCH_V1(1, 4, 4)
+            if (split) IG_LAUNCH_V1(3, 4, 4, 2) else IG_LAUNCH_V1(1, 4, 4, 2)
         }
     }
 #undef IG_LAUNCH_V1
