@@ -16,11 +16,7 @@ namespace {
 constexpr int HD = 64;
 constexpr int KT = 32;                 // streamed rows per tile
 constexpr int TILE = KT * HD * 2;      // 4 KiB per bf16 tile
-// tiles streamed per barrier pair: one cooperative load + 2 barriers now cover 128 (64 in split mode) rows
-template <bool SPLIT>
-struct Ntl {
-    static constexpr int v = SPLIT ? 2 : 4;
-};
+// tiles streamed per barrier pair (NTL): one cooperative load + 2 barriers cover 32 * NTL rows
 
 __device__ __forceinline__ int lds_kc(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
 
@@ -74,10 +70,10 @@ __device__ __forceinline__ void pack_acc(const f32x4& a0, const f32x4& a1, bf16x
 // clamped address + select: a branch around a load would serialise them on vmcnt(0)); commit() writes the staged
 // registers to LDS.  With nthr * NR >= UPG a whole group is one pass, so the NEXT group's fetch can stay in flight
 // while the current one is consumed; smaller workgroups fall back to synchronous passes.
-template <int NT, int NTL>
+template <int NT, int NTL, int NR_>
 struct TileGroup {
     static constexpr int UPG = NT * NTL * KT * 8;  // 16-byte units per group
-    static constexpr int NR = 3;                   // staged units per thread and pass (13 waves x 3 >= 2048 units)
+    static constexpr int NR = NR_;                 // staged units per thread and pass (one pass needs nthr * NR >= UPG)
     uint4 v[NR];
 
     __device__ __forceinline__ void fetch(int u0, const bf16_t* b0, const bf16_t* b1, const bf16_t* b2, const bf16_t* b3, long rs0,
@@ -124,11 +120,13 @@ __device__ __forceinline__ bf16x8_t load_own(const bf16_t* base, long row_stride
 // ------------------------------------------------------------------------------------------------------
 // forward: O = softmax(scale * Q K^T) V ; LSE saved for backward
 // ------------------------------------------------------------------------------------------------------
-template <bool SPLIT>
-__global__ __launch_bounds__(1024) void attn_fwd_kernel(const bf16_t* __restrict__ qkv_hi, const bf16_t* __restrict__ qkv_lo,
+template <bool SPLIT, int NTLP, int MAXT>
+__global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const bf16_t* __restrict__ qkv_hi, const bf16_t* __restrict__ qkv_lo,
                                                         bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo,
                                                         float* __restrict__ lse, int N, int H, float scale) {
-    constexpr int NTL = Ntl<SPLIT>::v;
+    constexpr int NTL = SPLIT ? 2 : NTLP;
+    // staging registers: one pass must cover the group with >= 13 waves (MAXT = 1024) or >= 7 waves (MAXT = 512)
+    constexpr int NRS = ((SPLIT ? 4 : 2) * NTL * KT * 8 + (MAXT == 1024 ? 832 : 448) - 1) / (MAXT == 1024 ? 832 : 448);
     __shared__ __attribute__((aligned(16))) char smem[(SPLIT ? 4 : 2) * NTL * TILE];
     char* k_hi0 = smem;
     char* v_hi0 = smem + NTL * TILE;
@@ -154,7 +152,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(const bf16_t* __restrict
     float m_run = -INFINITY, l_run = 0.f;
 
     const int ntiles = (N + KT - 1) / KT;
-    TileGroup<SPLIT ? 4 : 2, NTL> tg;
+    TileGroup<SPLIT ? 4 : 2, NTL, NRS> tg;
     const int nthr = blockDim.x;
     // whole group in one pass -> prefetch the next group during compute (not in split mode: no registers to spare)
     const bool pre = !SPLIT && nthr * tg.NR >= tg.UPG;
@@ -269,13 +267,15 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // ------------------------------------------------------------------------------------------------------
 // backward, query-owner pass: dQ = scale * dS K   (streams K,V tiles; recomputes P^T from LSE)
 // ------------------------------------------------------------------------------------------------------
-template <bool SPLIT>
-__global__ __launch_bounds__(1024) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv_hi, const bf16_t* __restrict__ qkv_lo,
+template <bool SPLIT, int NTLP, int MAXT>
+__global__ __launch_bounds__(MAXT) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv_hi, const bf16_t* __restrict__ qkv_lo,
                                                            const bf16_t* __restrict__ do_hi, const bf16_t* __restrict__ do_lo,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            bf16_t* __restrict__ dqkv_hi, bf16_t* __restrict__ dqkv_lo, int N, int H,
                                                            float scale) {
-    constexpr int NTL = Ntl<SPLIT>::v;
+    constexpr int NTL = SPLIT ? 2 : NTLP;
+    // staging registers: one pass must cover the group with >= 13 waves (MAXT = 1024) or >= 7 waves (MAXT = 512)
+    constexpr int NRS = ((SPLIT ? 4 : 2) * NTL * KT * 8 + (MAXT == 1024 ? 832 : 448) - 1) / (MAXT == 1024 ? 832 : 448);
     __shared__ __attribute__((aligned(16))) char smem[(SPLIT ? 4 : 2) * NTL * TILE];
     char* k_hi0 = smem;
     char* v_hi0 = smem + NTL * TILE;
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_dq_kernel(const bf16_t* __restr
     for (int i = 0; i < 4; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int ntiles = (N + KT - 1) / KT;
-    TileGroup<SPLIT ? 4 : 2, NTL> tg;
+    TileGroup<SPLIT ? 4 : 2, NTL, NRS> tg;
     const int nthr = blockDim.x;
     // whole group in one pass -> prefetch the next group during compute (not in split mode: no registers to spare)
     const bool pre = !SPLIT && nthr * tg.NR >= tg.UPG;
@@ -368,13 +368,15 @@ __global__ __launch_bounds__(1024) void attn_bwd_dq_kernel(const bf16_t* __restr
 // ------------------------------------------------------------------------------------------------------
 // backward, key-owner pass: dV = P^T dO ; dK = scale * dS^T Q   (streams Q,dO tiles)
 // ------------------------------------------------------------------------------------------------------
-template <bool SPLIT>
-__global__ __launch_bounds__(1024) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv_hi, const bf16_t* __restrict__ qkv_lo,
+template <bool SPLIT, int NTLP, int MAXT>
+__global__ __launch_bounds__(MAXT) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv_hi, const bf16_t* __restrict__ qkv_lo,
                                                             const bf16_t* __restrict__ do_hi, const bf16_t* __restrict__ do_lo,
                                                             const float* __restrict__ lse, const float* __restrict__ delta,
                                                             bf16_t* __restrict__ dqkv_hi, bf16_t* __restrict__ dqkv_lo, int N, int H,
                                                             float scale) {
-    constexpr int NTL = Ntl<SPLIT>::v;
+    constexpr int NTL = SPLIT ? 2 : NTLP;
+    // staging registers: one pass must cover the group with >= 13 waves (MAXT = 1024) or >= 7 waves (MAXT = 512)
+    constexpr int NRS = ((SPLIT ? 4 : 2) * NTL * KT * 8 + (MAXT == 1024 ? 832 : 448) - 1) / (MAXT == 1024 ? 832 : 448);
     __shared__ __attribute__((aligned(16))) char smem[(SPLIT ? 4 : 2) * NTL * TILE + 2 * NTL * KT * 4];
     char* q_hi0 = smem;
     char* d_hi0 = smem + NTL * TILE;
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_kernel(const bf16_t* __rest
     for (int i = 0; i < 4; ++i) dk[i] = dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int ntiles = (N + KT - 1) / KT;
-    TileGroup<SPLIT ? 4 : 2, NTL> tg;
+    TileGroup<SPLIT ? 4 : 2, NTL, NRS> tg;
     const int nthr = blockDim.x;
     const bool pre = !SPLIT && nthr * tg.NR >= tg.UPG;
     if (pre) tg.fetch(0, base_hi, dob_hi, base_lo, dob_lo, RS, OS, 0, N, tid, nthr);
@@ -472,9 +474,17 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_kernel(const bf16_t* __rest
     }
 }
 
+// Workgroup geometry.  cfg 0: up to 16 waves per workgroup (one workgroup per (b, h) for N = 197), 4 tiles per group;
+// cfg 1/2: up to 8 waves, 2 / 4 tiles per group (several smaller workgroups per CU overlap each other's fill/drain).
+inline int attn_cfg() {
+    static int cfg = getenv("IG_ATTN_CFG") ? atoi(getenv("IG_ATTN_CFG")) : 0;
+    return cfg;
+}
 inline void wave_geometry(int N, int& nblk, int& nw) {
     int tiles = (N + 15) / 16;
-    nblk = (tiles + 15) / 16;
+    static int maxw_env = getenv("IG_ATTN_MAXW") ? atoi(getenv("IG_ATTN_MAXW")) : 0;
+    const int maxw = attn_cfg() == 0 ? 16 : (maxw_env > 0 && maxw_env <= 8 ? maxw_env : 8);
+    nblk = (tiles + maxw - 1) / maxw;
     nw = (tiles + nblk - 1) / nblk;
 }
 
@@ -493,12 +503,17 @@ int ig_attention_fwd(const void* qkv_hi, const void* qkv_lo, void* out_hi, void*
     wave_geometry(N, nblk, nw);
     dim3 grid(nblk, H, B), block(nw * 64);
     float scale = 1.0f / sqrtf((float)head_dim);
-    if (qkv_lo)
-        hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)qkv_hi, (const bf16_t*)qkv_lo,
-                           (bf16_t*)out_hi, (bf16_t*)out_lo, lse, N, H, scale);
-    else
-        hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)qkv_hi, nullptr,
-                           (bf16_t*)out_hi, nullptr, lse, N, H, scale);
+#define IG_ATTN_FWD(SPLIT_, NTL_, MAXT_)                                                                                     \
+    hipLaunchKernelGGL((attn_fwd_kernel<SPLIT_, NTL_, MAXT_>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)qkv_hi,       \
+                       (const bf16_t*)qkv_lo, (bf16_t*)out_hi, (bf16_t*)out_lo, lse, N, H, scale)
+    const int cfg = attn_cfg();
+    if (qkv_lo) {
+        if (cfg == 0) IG_ATTN_FWD(true, 2, 1024);
+        else IG_ATTN_FWD(true, 2, 512);
+    } else if (cfg == 0) IG_ATTN_FWD(false, 4, 1024);
+    else if (cfg == 1) IG_ATTN_FWD(false, 2, 512);
+    else IG_ATTN_FWD(false, 4, 512);
+#undef IG_ATTN_FWD
     return ig_check_launch("ig_attention_fwd");
 }
 
@@ -520,17 +535,22 @@ int ig_attention_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi,
     wave_geometry(N, nblk, nw);
     dim3 grid(nblk, H, B), block(nw * 64);
     float scale = 1.0f / sqrtf((float)head_dim);
-    if (split) {
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, grid, block, 0, st, (const bf16_t*)qkv_hi, (const bf16_t*)qkv_lo,
-                           (const bf16_t*)dout_hi, (const bf16_t*)dout_lo, lse, delta, (bf16_t*)dqkv_hi, (bf16_t*)dqkv_lo, N, H, scale);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, block, 0, st, (const bf16_t*)qkv_hi, (const bf16_t*)qkv_lo,
-                           (const bf16_t*)dout_hi, (const bf16_t*)dout_lo, lse, delta, (bf16_t*)dqkv_hi, (bf16_t*)dqkv_lo, N, H, scale);
-    } else {
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, block, 0, st, (const bf16_t*)qkv_hi, nullptr, (const bf16_t*)dout_hi,
-                           nullptr, lse, delta, (bf16_t*)dqkv_hi, nullptr, N, H, scale);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, block, 0, st, (const bf16_t*)qkv_hi, nullptr, (const bf16_t*)dout_hi,
-                           nullptr, lse, delta, (bf16_t*)dqkv_hi, nullptr, N, H, scale);
+#define IG_ATTN_BWD(SPLIT_, NTL_, MAXT_)                                                                                     \
+    {                                                                                                                         \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<SPLIT_, NTL_, MAXT_>), grid, block, 0, st, (const bf16_t*)qkv_hi,                  \
+                           (const bf16_t*)qkv_lo, (const bf16_t*)dout_hi, (const bf16_t*)dout_lo, lse, delta, (bf16_t*)dqkv_hi,  \
+                           (bf16_t*)dqkv_lo, N, H, scale);                                                                    \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<SPLIT_, NTL_, MAXT_>), grid, block, 0, st, (const bf16_t*)qkv_hi,                 \
+                           (const bf16_t*)qkv_lo, (const bf16_t*)dout_hi, (const bf16_t*)dout_lo, lse, delta, (bf16_t*)dqkv_hi,  \
+                           (bf16_t*)dqkv_lo, N, H, scale);                                                                    \
     }
+    const int cfg = attn_cfg();
+    if (split) {
+        if (cfg == 0) IG_ATTN_BWD(true, 2, 1024) else IG_ATTN_BWD(true, 2, 512)
+    } else if (cfg == 0) IG_ATTN_BWD(false, 4, 1024)
+    else if (cfg == 1) IG_ATTN_BWD(false, 2, 512)
+    else IG_ATTN_BWD(false, 4, 512)
+#undef IG_ATTN_BWD
     return ig_check_launch("ig_attention_bwd");
 }
 

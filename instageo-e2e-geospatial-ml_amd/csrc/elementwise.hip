@@ -492,11 +492,21 @@ __global__ __launch_bounds__(TPB) void bn_stats_kernel(const bf16_t* __restrict_
     if (sl < nslice) {
         for (int ub = u; ub < units; ub += tu) {
             float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (long r = r0 + sl; r < r1; r += nslice) {
+            long r = r0 + sl;
+            for (; r + 3L * nslice < r1; r += 4L * nslice) {  // four rows in flight per thread
+                float f[4][8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) load8_split(hi, lo, (size_t)(r + (long)k * nslice) * C + ub * 8, f[k]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) s[j] += f[k][j], q[j] = fmaf(f[k][j], f[k][j], q[j]);
+            }
+            for (; r < r1; r += nslice) {
                 float f[8];
                 load8_split(hi, lo, (size_t)r * C + ub * 8, f);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) s[j] += f[j], q[j] += f[j] * f[j];
+                for (int j = 0; j < 8; ++j) s[j] += f[j], q[j] = fmaf(f[j], f[j], q[j]);
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -538,17 +548,41 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, const float*
     if (mean_o) mean_o[c] = mu;
     if (rstd_o) rstd_o[c] = rs;
 }
-// y = relu(x*scale + shift)
-__global__ void bn_relu_apply_kernel(const bf16_t* __restrict__ xh, const bf16_t* __restrict__ xl, const float* __restrict__ scale,
-                                     const float* __restrict__ shift, bf16_t* __restrict__ yh, bf16_t* __restrict__ yl, long units,
-                                     int C) {
-    for (long u = blockIdx.x * (long)blockDim.x + threadIdx.x; u < units; u += (long)gridDim.x * blockDim.x) {
-        int c = (int)((u * 8) % C);
-        float f[8];
-        load8_split(xh, xl, (size_t)u * 8, f);
+// y = relu(x*scale + shift).  Thread = one fixed 8-channel unit walking rows (stride = row slices per block): the
+// per-channel constants are loaded once, not per element, and four rows are in flight per thread.
+__global__ __launch_bounds__(TPB) void bn_relu_apply_kernel(const bf16_t* __restrict__ xh, const bf16_t* __restrict__ xl,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            bf16_t* __restrict__ yh, bf16_t* __restrict__ yl, long M, int C,
+                                                            int rows_per_block) {
+    const int units = C / 8;
+    const int tu = min(units, TPB), nslice = TPB / tu;
+    const int u = threadIdx.x % tu, sl = threadIdx.x / tu;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(M, r0 + rows_per_block);
+    if (sl >= nslice) return;
+    for (int ub = u; ub < units; ub += tu) {
+        float sc[8], sh[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * scale[c + j] + shift[c + j], 0.f);
-        store8_split(yh, yl, (size_t)u * 8, f);
+        for (int j = 0; j < 8; ++j) sc[j] = scale[ub * 8 + j], sh[j] = shift[ub * 8 + j];
+        long r = r0 + sl;
+        for (; r + 3L * nslice < r1; r += 4L * nslice) {
+            float f[4][8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) load8_split(xh, xl, (size_t)(r + (long)k * nslice) * C + ub * 8, f[k]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[k][j] = fmaxf(fmaf(f[k][j], sc[j], sh[j]), 0.f);
+                store8_split(yh, yl, (size_t)(r + (long)k * nslice) * C + ub * 8, f[k]);
+            }
+        }
+        for (; r < r1; r += nslice) {
+            float f[8];
+            load8_split(xh, xl, (size_t)r * C + ub * 8, f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = fmaxf(fmaf(f[j], sc[j], sh[j]), 0.f);
+            store8_split(yh, yl, (size_t)r * C + ub * 8, f);
+        }
     }
 }
 // backward pass 1: sums[c] += dyr ; sums[C+c] += dyr*xhat   (dyr = dy * [bn(x) > 0])
@@ -568,16 +602,35 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const bf16_t* __rest
     if (sl < nslice) {
         for (int ub = u; ub < units; ub += tu) {
             float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (long r = r0 + sl; r < r1; r += nslice) {
+            float sc[8], sh[8], mu[8], rs[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sc[j] = scale[ub * 8 + j], sh[j] = shift[ub * 8 + j], mu[j] = mean[ub * 8 + j], rs[j] = rstd[ub * 8 + j];
+            long r = r0 + sl;
+            for (; r + 1L * nslice < r1; r += 2L * nslice) {  // two rows (four loads) in flight per thread
+                float x[2][8], d[2][8];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    load8_split(xh, xl, (size_t)(r + (long)k * nslice) * C + ub * 8, x[k]);
+                    load8_split(dyh, dyl, (size_t)(r + (long)k * nslice) * C + ub * 8, d[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float dyr = fmaf(x[k][j], sc[j], sh[j]) > 0.f ? d[k][j] : 0.f;
+                        s[j] += dyr;
+                        q[j] += dyr * (x[k][j] - mu[j]) * rs[j];
+                    }
+            }
+            for (; r < r1; r += nslice) {
                 float x[8], d[8];
                 load8_split(xh, xl, (size_t)r * C + ub * 8, x);
                 load8_split(dyh, dyl, (size_t)r * C + ub * 8, d);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    int c = ub * 8 + j;
-                    float dyr = (x[j] * scale[c] + shift[c]) > 0.f ? d[j] : 0.f;
+                    const float dyr = fmaf(x[j], sc[j], sh[j]) > 0.f ? d[j] : 0.f;
                     s[j] += dyr;
-                    q[j] += dyr * (x[j] - mean[c]) * rstd[c];
+                    q[j] += dyr * (x[j] - mu[j]) * rs[j];
                 }
             }
 #pragma unroll
@@ -590,32 +643,69 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const bf16_t* __rest
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * C; i += TPB) atomicAdd(sums + i, (double)red[i]);
 }
-// backward pass 2: dx = scale*(dyr - sum_dy/n - xhat*sum_dyxhat/n); also emits dgamma/dbeta once (block 0)
-__global__ void bn_bwd_apply_kernel(const bf16_t* __restrict__ xh, const bf16_t* __restrict__ xl, const bf16_t* __restrict__ dyh,
-                                    const bf16_t* __restrict__ dyl, const float* __restrict__ scale, const float* __restrict__ shift,
-                                    const float* __restrict__ mean, const float* __restrict__ rstd, const double* __restrict__ sums,
-                                    bf16_t* __restrict__ dxh, bf16_t* __restrict__ dxl, float* __restrict__ dgamma,
-                                    float* __restrict__ dbeta, long units, int C, double n) {
+// backward pass 2: dx = scale*(dyr - sum_dy/n - xhat*sum_dyxhat/n); also emits dgamma/dbeta once (block 0).
+// Same thread -> fixed-channel-unit walk as the forward apply: six per-channel constants live in registers.
+__global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const bf16_t* __restrict__ xh, const bf16_t* __restrict__ xl,
+                                                           const bf16_t* __restrict__ dyh, const bf16_t* __restrict__ dyl,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const double* __restrict__ sums, bf16_t* __restrict__ dxh,
+                                                           bf16_t* __restrict__ dxl, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, long M, int C, double n, int rows_per_block) {
     if (blockIdx.x == 0) {
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
             if (dbeta) atomicAdd(dbeta + c, (float)sums[c]);
             if (dgamma) atomicAdd(dgamma + c, (float)sums[C + c]);
         }
     }
-    const float inv_n = (float)(1.0 / n);
-    for (long u = blockIdx.x * (long)blockDim.x + threadIdx.x; u < units; u += (long)gridDim.x * blockDim.x) {
-        int c0 = (int)((u * 8) % C);
-        float x[8], d[8], o[8];
-        load8_split(xh, xl, (size_t)u * 8, x);
-        load8_split(dyh, dyl, (size_t)u * 8, d);
+    const int units = C / 8;
+    const int tu = min(units, TPB), nslice = TPB / tu;
+    const int u = threadIdx.x % tu, sl = threadIdx.x / tu;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(M, r0 + rows_per_block);
+    if (sl >= nslice) return;
+    const double inv_n = 1.0 / n;
+    for (int ub = u; ub < units; ub += tu) {
+        // dx = sc*dyr - a - b*x with  xhat = (x - mu)*rs :  a = sc*(k1 - mu*rs*k2),  b = sc*rs*k2
+        float sc[8], sh[8], ca[8], cb[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            int c = c0 + j;
-            float dyr = (x[j] * scale[c] + shift[c]) > 0.f ? d[j] : 0.f;
-            float xhat = (x[j] - mean[c]) * rstd[c];
-            o[j] = scale[c] * (dyr - (float)sums[c] * inv_n - xhat * (float)sums[C + c] * inv_n);
+            const int c = ub * 8 + j;
+            const float k1 = (float)(sums[c] * inv_n), k2 = (float)(sums[C + c] * inv_n);
+            sc[j] = scale[c], sh[j] = shift[c];
+            cb[j] = sc[j] * rstd[c] * k2;
+            ca[j] = sc[j] * k1 - mean[c] * cb[j];
         }
-        store8_split(dxh, dxl, (size_t)u * 8, o);
+        long r = r0 + sl;
+        for (; r + 1L * nslice < r1; r += 2L * nslice) {
+            float x[2][8], d[2][8];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                load8_split(xh, xl, (size_t)(r + (long)k * nslice) * C + ub * 8, x[k]);
+                load8_split(dyh, dyl, (size_t)(r + (long)k * nslice) * C + ub * 8, d[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float dyr = fmaf(x[k][j], sc[j], sh[j]) > 0.f ? d[k][j] : 0.f;
+                    o[j] = fmaf(sc[j], dyr, -fmaf(cb[j], x[k][j], ca[j]));
+                }
+                store8_split(dxh, dxl, (size_t)(r + (long)k * nslice) * C + ub * 8, o);
+            }
+        }
+        for (; r < r1; r += nslice) {
+            float x[8], d[8], o[8];
+            load8_split(xh, xl, (size_t)r * C + ub * 8, x);
+            load8_split(dyh, dyl, (size_t)r * C + ub * 8, d);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float dyr = fmaf(x[j], sc[j], sh[j]) > 0.f ? d[j] : 0.f;
+                o[j] = fmaf(sc[j], dyr, -fmaf(cb[j], x[j], ca[j]));
+            }
+            store8_split(dxh, dxl, (size_t)r * C + ub * 8, o);
+        }
     }
 }
 
@@ -804,6 +894,14 @@ int ig_patch_grad_prep(const float* dx, void* hi, void* lo, float* dcls, float* 
     return ig_check_launch("ig_patch_grad_prep");
 }
 
+// rows per workgroup: reductions end in global atomics -> ~768 workgroups (see ig_colsum); streaming apply passes give
+// every thread 8 rows of its channel unit
+static inline int bn_reduce_rows(long M) { return (int)(((M + 767) / 768 + 31) / 32 * 32); }
+static inline int bn_apply_rows(int C) {
+    const int units = C / 8, tu = units < TPB ? units : TPB;
+    return (TPB / tu) * 8;
+}
+
 // BatchNorm(+ReLU) forward.  sums: device scratch double[2*C] (zeroed here).  training=1: batch statistics
 // and (update_running=1) running-stat update; training=0: running statistics.
 int ig_bn_relu_fwd(const void* x_hi, const void* x_lo, const float* gamma, const float* beta, float* running_mean,
@@ -814,15 +912,15 @@ int ig_bn_relu_fwd(const void* x_hi, const void* x_lo, const float* gamma, const
     if (M == 0) return IG_OK;
     if (training) {
         (void)hipMemsetAsync(sums, 0, 2 * (size_t)C * sizeof(double), ST(stream));
-        const int rpb = M > 65536 ? 1024 : 128;
+        const int rpb = bn_reduce_rows(M);
         hipLaunchKernelGGL(bn_stats_kernel, dim3(ig_cdiv(M, rpb)), dim3(TPB), 2 * (size_t)C * sizeof(float), ST(stream), (const bf16_t*)x_hi, (const bf16_t*)x_lo,
                            sums, M, C, rpb);
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(ig_cdiv(C, TPB)), dim3(TPB), 0, ST(stream), sums, gamma, beta, running_mean,
                        running_var, scale, shift, mean, rstd, (double)M, C, eps, momentum, training, update_running);
-    long units = M * C / 8;
-    hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(grid_for(units, TPB, 16384)), dim3(TPB), 0, ST(stream), (const bf16_t*)x_hi,
-                       (const bf16_t*)x_lo, scale, shift, (bf16_t*)y_hi, (bf16_t*)y_lo, units, C);
+    const int arpb = bn_apply_rows(C);
+    hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(ig_cdiv(M, arpb)), dim3(TPB), 0, ST(stream), (const bf16_t*)x_hi,
+                       (const bf16_t*)x_lo, scale, shift, (bf16_t*)y_hi, (bf16_t*)y_lo, M, C, arpb);
     return ig_check_launch("ig_bn_relu_fwd");
 }
 
@@ -834,13 +932,13 @@ int ig_bn_relu_bwd(const void* x_hi, const void* x_lo, const void* dy_hi, const 
     IG_REQUIRE(C % 8 == 0 && C <= 4096, "ig_bn_relu_bwd: C must be a multiple of 8 and <= 4096 (got %d)", C);
     if (M == 0) return IG_OK;
     (void)hipMemsetAsync(sums, 0, 2 * (size_t)C * sizeof(double), ST(stream));
-    const int rpb = M > 65536 ? 1024 : 128;
+    const int rpb = bn_reduce_rows(M);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ig_cdiv(M, rpb)), dim3(TPB), 2 * (size_t)C * sizeof(float), ST(stream), (const bf16_t*)x_hi, (const bf16_t*)x_lo,
                        (const bf16_t*)dy_hi, (const bf16_t*)dy_lo, scale, shift, mean, rstd, sums, M, C, rpb);
-    long units = M * C / 8;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(units, TPB, 16384)), dim3(TPB), 0, ST(stream), (const bf16_t*)x_hi,
+    const int arpb = bn_apply_rows(C);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ig_cdiv(M, arpb)), dim3(TPB), 0, ST(stream), (const bf16_t*)x_hi,
                        (const bf16_t*)x_lo, (const bf16_t*)dy_hi, (const bf16_t*)dy_lo, scale, shift, mean, rstd, sums, (bf16_t*)dx_hi,
-                       (bf16_t*)dx_lo, dgamma, dbeta, units, C, (double)M);
+                       (bf16_t*)dx_lo, dgamma, dbeta, M, C, (double)M, arpb);
     return ig_check_launch("ig_bn_relu_bwd");
 }
 

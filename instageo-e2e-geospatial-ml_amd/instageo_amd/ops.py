@@ -76,15 +76,23 @@ def _stream():
 # PROF maps entry point -> {"work": flops or bytes summed over launches, "events": [(start, end), ...]}.
 # torch.cuda.Event records on torch's current stream, which is the stream every kernel here is launched on.
 PROF = None
+PROF_STRIDE = 1
 
 
-def profile_begin(names) -> None:
-    global PROF
-    PROF = {n: {"work": 0.0, "events": []} for n in names}
+def profile_begin(names, stride: int = 1) -> None:
+    """Start per-launch event profiling of the named entry points.
+
+    ``stride`` > 1 brackets only every stride-th launch of each entry point: an event pair drains the queue around the
+    kernel (a few microseconds of bubble per pair), so inside a timed region only a sample is bracketed.  Pick a stride
+    coprime with the per-layer launch pattern (7 is) so the sample keeps the mix of shapes.
+    """
+    global PROF, PROF_STRIDE
+    PROF = {n: {"work": 0.0, "events": [], "seen": 0} for n in names}
+    PROF_STRIDE = max(1, int(stride))
 
 
 def profile_end():
-    """Synchronise and return {name: (launches, total_ms, total_work)}."""
+    """Synchronise and return {name: (bracketed launches, total_ms, total_work)}."""
     global PROF
     prof, PROF = PROF, None
     torch.cuda.synchronize()
@@ -95,12 +103,17 @@ def _call(name: str, work: float, *args) -> None:
     if PROF is None or name not in PROF:
         _lib.call(name, *args)
         return
+    d = PROF[name]
+    d["seen"] += 1
+    if (d["seen"] - 1) % PROF_STRIDE:
+        _lib.call(name, *args)
+        return
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     _lib.call(name, *args)
     b.record()
-    PROF[name]["events"].append((a, b))
-    PROF[name]["work"] += work
+    d["events"].append((a, b))
+    d["work"] += work
 
 
 def _f32(t: torch.Tensor) -> torch.Tensor:
@@ -123,8 +136,8 @@ def normalize_chips(src: torch.Tensor, mean: torch.Tensor, std: torch.Tensor, te
     if out is None:
         out = torch.empty((B, C, temporal, H, W), dtype=torch.float32, device=src.device)
     mult = 1.0 if constant_multiplier is None else float(constant_multiplier)
-    _lib.call("ig_normalize_chips", _p(src), dt, _p(_f32(mean)), _p(_f32(std)), mult, int(constant_multiplier is not None),
-              _p(out), B, temporal, C, H, W, _stream())
+    _call("ig_normalize_chips", float(src.numel()) * (src.element_size() + 4), _p(src), dt, _p(_f32(mean)), _p(_f32(std)), mult,
+          int(constant_multiplier is not None), _p(out), B, temporal, C, H, W, _stream())
     return out
 
 
@@ -144,15 +157,18 @@ def patch_embed_fwd(patches: BT, w: BT, bias, pos, x, batch: int, tpc: int, D: i
 
 def layernorm_fwd(x, gamma, beta, out: BT, mean, rstd, M: int, D: int, eps: float = 1e-5, feat_T: int = 0, feat_G: int = 0,
                   ntok: int = 0) -> None:
-    _lib.call("ig_layernorm_fwd", _p(x), _p(gamma), _p(beta), _p(out.hi), _p(out.lo), _p(mean), _p(rstd), M, D, eps, feat_T, feat_G,
-              ntok, _stream())
+    # algorithmic bytes: fp32 residual stream in, bf16 (hi [+ lo]) out
+    _call("ig_layernorm_fwd", float(M) * D * (4 + (4 if out.lo is not None else 2)), _p(x), _p(gamma), _p(beta), _p(out.hi), _p(out.lo),
+          _p(mean), _p(rstd), M, D, eps, feat_T, feat_G, ntok, _stream())
 
 
 def layernorm_bwd(dy: BT, x, mean, rstd, gamma, dx, accumulate: bool, dxb: Optional[BT], dgamma, dbeta, dcol, M: int, D: int,
                   feat_T: int = 0, feat_G: int = 0, ntok: int = 0) -> None:
-    _lib.call("ig_layernorm_bwd", _p(dy.hi), _p(dy.lo), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), int(accumulate),
-              _p(dxb.hi) if dxb else None, _p(dxb.lo) if dxb else None, _p(dgamma), _p(dbeta), _p(dcol), M, D, feat_T, feat_G, ntok,
-              _stream())
+    nb = 2 if dy.lo is None else 4
+    work = float(M) * D * (nb + 4 + 4 + (4 if accumulate else 0) + (nb if dxb else 0))  # dy, x, dx (r)w, bf16 copy of dx
+    _call("ig_layernorm_bwd", work, _p(dy.hi), _p(dy.lo), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), int(accumulate),
+          _p(dxb.hi) if dxb else None, _p(dxb.lo) if dxb else None, _p(dgamma), _p(dbeta), _p(dcol), M, D, feat_T, feat_G, ntok,
+          _stream())
 
 
 def linear_fwd(x: BT, w: BT, bias, y: BT, M: int, N: int, K: int, act: int = 0, pre: Optional[BT] = None) -> None:
@@ -184,7 +200,7 @@ def attention_bwd(qkv: BT, out: BT, dout: BT, lse, delta, dqkv: BT, B: int, N: i
 
 
 def colsum(x: BT, out, M: int, C: int) -> None:
-    _lib.call("ig_colsum", _p(x.hi), _p(x.lo), _p(out), M, C, _stream())
+    _call("ig_colsum", float(M) * C * (2 if x.lo is None else 4), _p(x.hi), _p(x.lo), _p(out), M, C, _stream())
 
 
 def patch_grad_prep(dx, out: BT, dcls, dbias, B: int, ntok: int, D: int) -> None:
@@ -225,23 +241,27 @@ def conv3x3_wgrad(dy: BT, x: BT, dw, B, H, W, Cin, Cout) -> None:
 
 def bn_relu_fwd(x: BT, gamma, beta, rmean, rvar, y: BT, scale, shift, mean, rstd, sums, M: int, C: int, training: bool,
                 update_running: bool, eps: float = 1e-5, momentum: float = 0.1) -> None:
-    _lib.call("ig_bn_relu_fwd", _p(x.hi), _p(x.lo), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(y.hi), _p(y.lo), _p(scale), _p(shift),
-              _p(mean), _p(rstd), _p(sums), M, C, eps, momentum, int(training), int(update_running), _stream())
+    nb = 2 if x.lo is None else 4
+    # training: statistics pass (read) + apply pass (read + write); eval: one read + write pass
+    _call("ig_bn_relu_fwd", float(M) * C * nb * (3 if training else 2), _p(x.hi), _p(x.lo), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(y.hi), _p(y.lo), _p(scale), _p(shift),
+          _p(mean), _p(rstd), _p(sums), M, C, eps, momentum, int(training), int(update_running), _stream())
 
 
 def bn_relu_bwd(x: BT, dy: BT, scale, shift, mean, rstd, dx: BT, dgamma, dbeta, sums, M: int, C: int) -> None:
-    _lib.call("ig_bn_relu_bwd", _p(x.hi), _p(x.lo), _p(dy.hi), _p(dy.lo), _p(scale), _p(shift), _p(mean), _p(rstd), _p(dx.hi), _p(dx.lo),
-              _p(dgamma), _p(dbeta), _p(sums), M, C, _stream())
+    nb = 2 if x.lo is None else 4
+    # reduction pass reads x, dy; apply pass reads x, dy and writes dx
+    _call("ig_bn_relu_bwd", float(M) * C * nb * 5, _p(x.hi), _p(x.lo), _p(dy.hi), _p(dy.lo), _p(scale), _p(shift), _p(mean), _p(rstd),
+          _p(dx.hi), _p(dx.lo), _p(dgamma), _p(dbeta), _p(sums), M, C, _stream())
 
 
 def classifier_fwd(f: BT, w, bias, logits, B: int, HW: int, C: int, ncls: int, seed: int = 0, p: float = 0.0, seed_dev=None) -> None:
-    _lib.call("ig_classifier_fwd", _p(f.hi), _p(f.lo), _p(w), _p(bias), _p(logits), B, HW, C, ncls, seed, _p(seed_dev), p, _stream())
+    _call("ig_classifier_fwd", float(B) * HW * (C * (2 if f.lo is None else 4) + ncls * 4), _p(f.hi), _p(f.lo), _p(w), _p(bias), _p(logits), B, HW, C, ncls, seed, _p(seed_dev), p, _stream())
 
 
 def classifier_bwd(dlogits, f: BT, w, df: BT, dw, db, count, B: int, HW: int, C: int, ncls: int, seed: int = 0, p: float = 0.0,
                    seed_dev=None) -> None:
-    _lib.call("ig_classifier_bwd", _p(dlogits), _p(f.hi), _p(f.lo), _p(w), _p(df.hi), _p(df.lo), _p(dw), _p(db), _p(count), B, HW, C,
-              ncls, seed, _p(seed_dev), p, _stream())
+    _call("ig_classifier_bwd", float(B) * HW * (2 * C * (2 if f.lo is None else 4) + ncls * 4), _p(dlogits), _p(f.hi), _p(f.lo), _p(w),
+          _p(df.hi), _p(df.lo), _p(dw), _p(db), _p(count), B, HW, C, ncls, seed, _p(seed_dev), p, _stream())
 
 
 _LABEL_DT = {torch.int64: 0, torch.int32: 1, torch.float32: 2}
@@ -250,8 +270,10 @@ _LABEL_DT = {torch.int64: 0, torch.int32: 1, torch.float32: 2}
 def ce_loss(logits, labels, class_weights, ignore_index: int, stats, dlogits=None, preds=None, preds_i8=None, confusion=None) -> None:
     B, ncls = logits.shape[0], logits.shape[1]
     HW = logits.numel() // (B * ncls)
-    _lib.call("ig_ce_loss", _p(_f32(logits)), _p(labels), _LABEL_DT[labels.dtype], _p(class_weights), int(ignore_index), _p(stats),
-              _p(dlogits), _p(preds), _p(preds_i8), _p(confusion), B, HW, ncls, _stream())
+    work = float(B) * HW * (ncls * 4 + labels.element_size() + (ncls * 4 if dlogits is not None else 0) + (8 if preds is not None else 0)
+                            + (1 if preds_i8 is not None else 0))
+    _call("ig_ce_loss", work, _p(_f32(logits)), _p(labels), _LABEL_DT[labels.dtype], _p(class_weights), int(ignore_index), _p(stats),
+          _p(dlogits), _p(preds), _p(preds_i8), _p(confusion), B, HW, ncls, _stream())
 
 
 def argmax_i8(logits, out=None):
@@ -259,7 +281,7 @@ def argmax_i8(logits, out=None):
     HW = logits.numel() // (B * ncls)
     if out is None:
         out = torch.empty((B,) + tuple(logits.shape[2:]), dtype=torch.int8, device=logits.device)
-    _lib.call("ig_argmax_i8", _p(_f32(logits)), _p(out), B, HW, ncls, _stream())
+    _call("ig_argmax_i8", float(B) * HW * (ncls * 4 + 1), _p(_f32(logits)), _p(out), B, HW, ncls, _stream())
     return out
 
 
@@ -274,5 +296,7 @@ def adamw_advance(hyper) -> None:
 
 
 def adamw_step(p, g, m, v, shadow: Optional[BT], hyper, n: int) -> None:
-    _lib.call("ig_adamw_step", _p(p), _p(g), _p(m), _p(v), _p(shadow.hi) if shadow else None,
-              _p(shadow.lo) if shadow and shadow.lo is not None else None, _p(hyper), n, _stream())
+    # 28 B/param fp32 state (read p, g, m, v; write p, m, v) + the refreshed bf16 shadow
+    work = float(n) * (28 + (0 if not shadow else 2 if shadow.lo is None else 4))
+    _call("ig_adamw_step", work, _p(p), _p(g), _p(m), _p(v), _p(shadow.hi) if shadow else None,
+          _p(shadow.lo) if shadow and shadow.lo is not None else None, _p(hyper), n, _stream())
