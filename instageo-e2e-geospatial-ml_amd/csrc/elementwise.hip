@@ -826,7 +826,8 @@ int ig_layernorm_bwd(const void* dy_hi, const void* dy_lo, const float* x, const
     IG_REQUIRE(dy_hi && x && mean && rstd && gamma && dx, "ig_layernorm_bwd: null pointer");
     IG_REQUIRE(D % 4 == 0 && D <= 2048, "ig_layernorm_bwd: D must be a multiple of 4 and <= 2048 (got %d)", D);
     if (M == 0) return IG_OK;
-    const int rpb = 32;
+    static const int rpb_env = getenv("IG_LNB_RPB") ? atoi(getenv("IG_LNB_RPB")) : 0;
+    const int rpb = rpb_env > 0 ? rpb_env : 32;
     dim3 grid(ig_cdiv(M, rpb));
     size_t sm = 3 * (size_t)D * sizeof(float);
 #define IG_LNB_EXACT(NCH_)                                                                                              \

@@ -264,6 +264,7 @@ struct G2 {
 
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
     unsigned keep;
+    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);  // wave-uniform by construction; keeps the "s" operand in an SGPR
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(gsrc), "s"(lds_dst)
@@ -322,36 +323,78 @@ __global__ __launch_bounds__(NTHR2, (BKT == 32 ? 4 : 2)) void gemm2_kernel(AL al
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // one stage = NA + NB wave-instructions of 1 KiB (ids 0..NA-1 -> A, then B); wave w issues ids i*8 + w
-#define GEMM2_ISSUE(IT, SLOT, BM_, BN_)                                                                    \
+    // one stage = NA + NB wave-instructions ("pieces") of 1 KiB (ids 0..NA-1 -> A, then B); wave w issues ids i*8 + w.
+    // The source pointer of a piece advances by a constant per K-step, so it is decoded once per (tile, segment) and
+    // then stepped with one 64-bit add: recomputing row*ld + bounds for every piece and K-step cost more issue cycles
+    // than the 16 MFMAs of the step (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost').  Needs K % BKT == 0 and a
+    // loader whose address is linear in k (kLinearK); otherwise the generic per-step decode below is used.
+#define GEMM2_PIECE_PTR(SEG, KT, BM_, BN_, ID, P, OK)                                                       \
+    {                                                                                                       \
+        if ((ID) < G::NA) {                                                                                 \
+            if constexpr (!A_TR) {                                                                          \
+                const int row = (ID)*G::RPI + lane / G::UPR;                                                \
+                P = al.ptr(SEG, (BM_)*BM2 + row, (KT)*G::UPR + kc_swz<BKT>(row, lane % G::UPR), OK);        \
+            } else {                                                                                        \
+                const int k = ((ID) % (BKT / 4)) * 4 + (lane >> 4);                                         \
+                P = al.ptr(SEG, (KT)*BKT + k, (BM_)*32 + ((ID) / (BKT / 4)) * 16 + ((lane & 15) ^ (tr_key(k) << 1)), OK); \
+            }                                                                                               \
+        } else {                                                                                            \
+            const int id2 = (ID)-G::NA;                                                                     \
+            if constexpr (!B_TR) {                                                                          \
+                const int row = id2 * G::RPI + lane / G::UPR;                                               \
+                P = bl.ptr(SEG, (BN_)*BN + row, (KT)*G::UPR + kc_swz<BKT>(row, lane % G::UPR), OK);         \
+            } else {                                                                                        \
+                const int k = id2 * 4 + (lane >> 4);                                                        \
+                P = bl.ptr(SEG, (KT)*BKT + k, (BN_)*16 + ((lane & 15) ^ (tr_key(k) << 1)), OK);             \
+            }                                                                                               \
+        }                                                                                                   \
+    }
+    constexpr bool kFast = AL::kLinearK && BL::kLinearK;  // a K tail (K % BKT != 0) takes the generic decode for that step only
+    const char* pp[G::PER_WAVE];   // fast path: current source of this wave's pieces
+    long pstep[G::PER_WAVE];       // bytes per K-step (0 for out-of-range rows, which read the zero page)
+#define GEMM2_SETUP(IT, BM_, BN_)                                                                           \
     {                                                                                                       \
         const int seg_ = (NSEG == 1) ? 0 : (IT) / nk;                                                       \
         const int kt_ = kt0 + (IT)-seg_ * nk;                                                               \
-        const unsigned sbase_ = lds_base + (SLOT)*G::STAGE;                                                 \
         _Pragma("unroll") for (int i = 0; i < G::PER_WAVE; ++i) {                                           \
             const int id = i * 8 + wave;                                                                    \
             bool ok;                                                                                        \
             const bf16_t* p;                                                                                \
-            if (id < G::NA) {                                                                               \
-                if constexpr (!A_TR) {                                                                      \
-                    const int row = id * G::RPI + lane / G::UPR;                                            \
-                    p = al.ptr(seg_, (BM_)*BM2 + row, kt_ * G::UPR + kc_swz<BKT>(row, lane % G::UPR), ok);  \
-                } else {                                                                                    \
-                    const int k = (id % (BKT / 4)) * 4 + (lane >> 4);                                       \
-                    p = al.ptr(seg_, kt_ * BKT + k, (BM_)*32 + (id / (BKT / 4)) * 16 + ((lane & 15) ^ (tr_key(k) << 1)), ok); \
-                }                                                                                           \
-            } else {                                                                                        \
-                const int id2 = id - G::NA;                                                                 \
-                if constexpr (!B_TR) {                                                                      \
-                    const int row = id2 * G::RPI + lane / G::UPR;                                           \
-                    p = bl.ptr(seg_, (BN_)*BN + row, kt_ * G::UPR + kc_swz<BKT>(row, lane % G::UPR), ok);   \
-                } else {                                                                                    \
-                    const int k = id2 * 4 + (lane >> 4);                                                    \
-                    p = bl.ptr(seg_, kt_ * BKT + k, (BN_)*16 + ((lane & 15) ^ (tr_key(k) << 1)), ok);       \
-                }                                                                                           \
-            }                                                                                               \
+            GEMM2_PIECE_PTR(seg_, kt_, BM_, BN_, id, p, ok);                                                \
+            pp[i] = ok ? (const char*)p : (const char*)zero_page;                                           \
+            const bool tr_ = id < G::NA ? A_TR : B_TR;                                                      \
+            const long ld_ = id < G::NA ? al.kstride() : bl.kstride();                                      \
+            pstep[i] = !ok ? 0L : tr_ ? (long)BKT * ld_ * 2 : (long)BKT * 2;                                \
+        }                                                                                                   \
+    }
+    // Issue of one K-step's pieces: BEGIN decodes the step (and re-seeds the piece pointers at a tile/segment start),
+    // ONE(i) issues piece i.  In the main loop the pieces are spread BETWEEN the MFMA groups of the step: issued in one
+    // burst right after the barrier, every wave of the SIMD sits in its ~100-cycle DMA issues at the same time and the
+    // matrix pipe idles; spread out, one wave's DMA issue overlaps the other waves' MFMAs.
+#define GEMM2_ISSUE_BEGIN(IT, SLOT, BM_, BN_)                                                              \
+    const unsigned sbase_ = lds_base + (SLOT)*G::STAGE;                                                     \
+    const int seg_ = (NSEG == 1) ? 0 : (IT) / nk;                                                           \
+    const int kt_ = kt0 + (IT)-seg_ * nk;                                                                   \
+    const int ibm_ = (BM_), ibn_ = (BN_);                                                                   \
+    const bool fast_ = kFast && (kt_ + 1) * BKT <= K;                                                       \
+    if (fast_ && (IT) == seg_ * nk) GEMM2_SETUP(IT, BM_, BN_);
+#define GEMM2_ISSUE_ONE(I)                                                                                  \
+    {                                                                                                       \
+        if (fast_) {                                                                                        \
+            glds16(pp[I], sbase_ + ((I)*8 + wave) * 1024);                                                  \
+            pp[I] += pstep[I];                                                                              \
+        } else {                                                                                            \
+            const int id = (I)*8 + wave;                                                                    \
+            bool ok;                                                                                        \
+            const bf16_t* p;                                                                                \
+            GEMM2_PIECE_PTR(seg_, kt_, ibm_, ibn_, id, p, ok);                                              \
             glds16(ok ? p : zero_page, sbase_ + id * 1024);                                                 \
         }                                                                                                   \
+    }
+#define GEMM2_ISSUE(IT, SLOT, BM_, BN_)                                                                    \
+    {                                                                                                       \
+        GEMM2_ISSUE_BEGIN(IT, SLOT, BM_, BN_)                                                               \
+        _Pragma("unroll") for (int i = 0; i < G::PER_WAVE; ++i) GEMM2_ISSUE_ONE(i)                          \
     }
 
     // issue-side cursor (runs two K-steps ahead of the compute-side cursor, across tile boundaries)
@@ -385,10 +428,17 @@ __global__ __launch_bounds__(NTHR2, (BKT == 32 ? 4 : 2)) void gemm2_kernel(AL al
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         asm volatile("s_barrier" ::: "memory");
-        if (g + 2 < G_) {
-            const int s2 = slot >= 1 ? slot - 1 : slot + 2;  // (slot + 2) % 3
-            GEMM2_ISSUE(it_i, s2, bm_i, bn_i);
-            GEMM2_ADVANCE_ISSUE();
+        const bool do_issue = g + 2 < G_;
+        const int s2 = slot >= 1 ? slot - 1 : slot + 2;  // (slot + 2) % 3
+        GEMM2_ISSUE_BEGIN(do_issue ? it_i : 0, s2, bm_i, bn_i)
+        // spreading pays for the K-contiguous operands (forward GEMMs); with transposed operands the scheduling fences
+        // cost more than the overlap gains (measured), so those issue the whole step right after the barrier
+        constexpr bool kSpread = !A_TR && !B_TR;
+        if constexpr (!kSpread) {
+            if (do_issue) {
+#pragma unroll
+                for (int i = 0; i < G::PER_WAVE; ++i) GEMM2_ISSUE_ONE(i)
+            }
         }
         const char* ta = smem + slot * G::STAGE;
         const char* tb = ta + G::A_BYTES;
@@ -403,11 +453,18 @@ __global__ __launch_bounds__(NTHR2, (BKT == 32 ? 4 : 2)) void gemm2_kernel(AL al
 #pragma unroll
             for (int t = 0; t < 4; ++t) bf[t] = read_frag2<BKT, B_TR>(tb, wn * 64 + t * 16, s, lane);
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn)
+            for (int tn = 0; tn < 4; ++tn) {
 #pragma unroll
                 for (int tm = 0; tm < 4; ++tm)
                     acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[tn], af[tm], acc[tn][tm], 0, 0, 0);
+                if (kSpread && s * 4 + tn < G::PER_WAVE) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (do_issue) GEMM2_ISSUE_ONE(s * 4 + tn)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
+        if (do_issue) GEMM2_ADVANCE_ISSUE();
         slot = slot == 2 ? 0 : slot + 1;
         if (++it_c < total) continue;
         // ---- tile finished: epilogue (next tile's first K-steps are already in flight) ----
@@ -483,14 +540,20 @@ __global__ __launch_bounds__(NTHR2, (BKT == 32 ? 4 : 2)) void gemm2_kernel(AL al
         }
     }
 #undef GEMM2_ISSUE
+#undef GEMM2_ISSUE_ONE
+#undef GEMM2_ISSUE_BEGIN
+#undef GEMM2_SETUP
+#undef GEMM2_PIECE_PTR
 #undef GEMM2_ADVANCE_ISSUE
 }
 
 // ------------------------------------------------------------------------------------ loaders
 struct PlainLoader {  // row-major [R][ld], logical width C (multiple of 8)
+    static constexpr bool kLinearK = true;  // ptr() is affine in the K index (v2 steps piece pointers instead of re-decoding)
     const bf16_t* base[3];
     int R, C;
     long ld;
+    __device__ long kstride() const { return ld; }  // elements between consecutive k-rows of a TR (k-major) operand
     __device__ void init(int) {}
     __device__ int kdim() const { return -1; }
     __device__ const bf16_t* ptr(int seg, int r, int c8, bool& ok) const {
@@ -511,6 +574,8 @@ struct PlainLoader {  // row-major [R][ld], logical width C (multiple of 8)
 // NHWC 3x3 pad-1 gather: row r = pixel (b,y,x), column unit -> (tap, channel).  sign=+1 reads
 // (y+ky-1, x+kx-1) (conv forward / wgrad input side), sign=-1 reads (y+1-ky, x+1-kx) (dgrad).
 struct Conv3Loader {
+    static constexpr bool kLinearK = false;
+    __device__ long kstride() const { return 0; }
     const bf16_t* base[3];
     int Mtot, H, W, C, sign;
     __device__ void init(int) {}
@@ -551,6 +616,8 @@ struct Conv3Loader {
 // ConvTranspose2d(k3,s2,p1,op1) forward, sub-pixel phase z=(py,px): output (2iy+py, 2ix+px) reads taps
 // ky in {1} (py=0) or {0,2} (py=1); tap ky==0 reads input row iy+1, otherwise iy (same for x).
 struct ConvTFwdALoader {
+    static constexpr bool kLinearK = false;
+    __device__ long kstride() const { return 0; }
     const bf16_t* base[3];
     int Mtot, H, W, C;
     int nky, nkx, ky0, kx0, K;
@@ -595,6 +662,8 @@ struct ConvTFwdALoader {
 };
 // matching weight view: n = co, k = (local tap, ci) of storage Wc[co][tap][ci]
 struct ConvTFwdBLoader {
+    static constexpr bool kLinearK = false;
+    __device__ long kstride() const { return 0; }
     const bf16_t* base[3];
     int Cout, C;
     int nky, nkx, ky0, kx0, K;
@@ -623,6 +692,8 @@ struct ConvTFwdBLoader {
 
 // dgrad weight view (TR operand): reduce row = (tap, co), contiguous columns = ci of Wc[co][tap][ci]
 struct ConvWgtTRLoader {
+    static constexpr bool kLinearK = false;
+    __device__ long kstride() const { return 0; }
     const bf16_t* base[3];
     int Cout, Cin;
     __device__ void init(int) {}
@@ -644,6 +715,8 @@ struct ConvWgtTRLoader {
 // ConvTranspose dgrad A: row = input pixel (b,iy,ix), k = (tap, co): reads dOut(2iy-1+ky, 2ix-1+kx).
 // With fixed_tap >= 0 (wgrad, TR operand) the column unit is co only and the tap comes from init(z).
 struct ConvTGradLoader {
+    static constexpr bool kLinearK = false;
+    __device__ long kstride() const { return 0; }
     const bf16_t* base[3];
     int Mtot, H, W, Cout;  // H,W = input resolution; dOut is (2H,2W)
     int fixed_tap;         // -1: k=(tap,co); -2: take tap from blockIdx.z

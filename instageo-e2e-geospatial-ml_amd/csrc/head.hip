@@ -55,16 +55,16 @@ __global__ __launch_bounds__(TPB) void classifier_fwd_kernel(const bf16_t* __res
 
 // df[m][c] = drop_mask * sum_n dl[b][n][pix] * w[n][c] * gscale ; dW[n][c] += sum_m dl*f_dropped ; db[n] += sum_m dl
 // gscale = 1/(*count) when count != NULL (fused trainer: dlogits left un-normalised by the loss kernel).
-// A thread owns ONE 8-channel unit and walks BWD_ITER pixels (stride = pixel slices per block), so dW partials stay in
+// A thread owns ONE 8-channel unit and walks `iters` pixels (stride = pixel slices per block), so dW partials stay in
 // registers and are reduced once per block (a thread-per-pixel version spent its time in 96 wave reductions per pixel).
-constexpr int BWD_ITER = 32;
 template <int NC>  // class-count bucket (register accumulators are NC x 8)
 __global__ __launch_bounds__(TPB) void classifier_bwd_kernel(const float* __restrict__ dl, const bf16_t* __restrict__ f_hi,
                                                              const bf16_t* __restrict__ f_lo, const float* __restrict__ w,
                                                              bf16_t* __restrict__ df_hi, bf16_t* __restrict__ df_lo,
                                                              float* __restrict__ dw, float* __restrict__ db, const double* count,
                                                              long M, long HW, int C, int ncls, uint32_t drop_seed,
-                                                             const uint32_t* drop_seed_dev, uint32_t drop_thresh, float drop_inv) {
+                                                             const uint32_t* drop_seed_dev, uint32_t drop_thresh, float drop_inv,
+                                                             int iters) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // w[ncls*C] | dwacc[ncls*C] | dbacc[ncls]
     if (drop_seed_dev) drop_seed += *drop_seed_dev;
     float* sw = sm;
@@ -84,8 +84,8 @@ __global__ __launch_bounds__(TPB) void classifier_bwd_kernel(const float* __rest
 #pragma unroll
             for (int j = 0; j < 8; ++j) dwa[n][j] = 0.f;
         }
-        const long m0 = (long)blockIdx.x * nsl * BWD_ITER + sl;
-        for (int it = 0; it < BWD_ITER; ++it) {
+        const long m0 = (long)blockIdx.x * nsl * iters + sl;
+        for (int it = 0; it < iters; ++it) {
             const long m = m0 + (long)it * nsl;
             if (m >= M) break;
             const long b = m / HW, pix = m - b * HW;
@@ -151,9 +151,10 @@ __global__ __launch_bounds__(TPB) void ce_loss_kernel(const float* __restrict__ 
     for (int i = threadIdx.x; i < ncls * ncls; i += TPB) hist[i] = 0u;
     if (threadIdx.x < 2) red[threadIdx.x] = 0.f;
     __syncthreads();
-    long m = blockIdx.x * (long)TPB + threadIdx.x;
+    // grid-stride over pixels: ~1k workgroups end in one round of global atomics each (a workgroup per 256 pixels made
+    // the 21k same-address double atomics the whole cost of the kernel)
     float my_loss = 0.f, my_cnt = 0.f;
-    if (m < M) {
+    for (long m = blockIdx.x * (long)TPB + threadIdx.x; m < M; m += (long)gridDim.x * TPB) {
         long b = m / HW, pix = m - b * HW;
         float z[MAXC];
         float mx = -INFINITY;
@@ -178,8 +179,8 @@ __global__ __launch_bounds__(TPB) void ce_loss_kernel(const float* __restrict__ 
 #pragma unroll
             for (int n = 0; n < MAXC; ++n)
                 if (n == (int)y) zy = z[n];
-            my_loss = wy * (lse - zy);
-            my_cnt = 1.f;
+            my_loss += wy * (lse - zy);
+            my_cnt += 1.f;
             if (confusion) atomicAdd(hist + (int)y * ncls + am, 1u);
         }
         if (dlogits) {
@@ -261,12 +262,15 @@ int ig_classifier_bwd(const float* dlogits, const void* f_hi, const void* f_lo, 
     if (M == 0) return IG_OK;
     IG_REQUIRE(C / 8 <= TPB, "ig_classifier_bwd: C must be <= %d", TPB * 8);
     size_t sm = (2 * (size_t)ncls * C + ncls) * sizeof(float);
-    const long ppb = (long)(TPB / (C / 8)) * BWD_ITER;  // pixels per block
+    const long nsl = TPB / (C / 8);
+    long iters = (M + nsl * 1024 - 1) / (nsl * 1024);  // ~1k workgroups: one round of dW/db atomics each
+    if (iters < 8) iters = 8;
+    const long ppb = nsl * iters;  // pixels per block
     const dim3 grid((unsigned)((M + ppb - 1) / ppb));
 #define IG_CLS_BWD(NC)                                                                                                          \
     hipLaunchKernelGGL(classifier_bwd_kernel<NC>, grid, dim3(TPB), sm, (hipStream_t)stream, dlogits, (const bf16_t*)f_hi,       \
                        (const bf16_t*)f_lo, w, (bf16_t*)df_hi, (bf16_t*)df_lo, dw, db, count, M, HW, C, ncls, drop_seed,        \
-                       drop_seed_dev, thresh_of(drop_p), drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f)
+                       drop_seed_dev, thresh_of(drop_p), drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, (int)iters)
     if (ncls <= 2) IG_CLS_BWD(2);
     else if (ncls <= 4) IG_CLS_BWD(4);
     else if (ncls <= 8) IG_CLS_BWD(8);
@@ -284,7 +288,9 @@ int ig_ce_loss(const float* logits, const void* labels, int label_dtype, const f
     long M = (long)B * HW;
     if (M == 0) return IG_OK;
     size_t sm = (size_t)ncls * ncls * sizeof(unsigned) + 2 * sizeof(float);
-    dim3 grid((unsigned)((M + TPB - 1) / TPB)), block(TPB);
+    long nblk = (M + TPB - 1) / TPB;
+    if (nblk > 1024) nblk = 1024;  // grid-stride: one round of global atomics per workgroup
+    dim3 grid((unsigned)nblk), block(TPB);
     hipStream_t st = (hipStream_t)stream;
     if (label_dtype == 0)
         hipLaunchKernelGGL(ce_loss_kernel<long long>, grid, block, sm, st, logits, (const long long*)labels, class_weights,
