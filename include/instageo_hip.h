@@ -50,16 +50,17 @@ int ig_layernorm_fwd(const float* x, const float* gamma, const float* beta, void
 int ig_layernorm_bwd(const void* dy_hi, const void* dy_lo, const float* x, const float* mean, const float* rstd,
                      const float* gamma, float* dx, int accumulate, void* dxb_hi, void* dxb_lo, float* dgamma, float* dbeta,
                      float* dcol, int M, int D, int feat_T, int feat_G, int ntok, void* stream);
-/* timm Block linears (qkv / fc1 [+GELU]) : y = act(x @ w^T + b), act 0 none, 1 exact GELU            :446-456 */
+/* timm Block linears (qkv / fc1 [+GELU]) : y = act(x @ w^T + b), act 0 none, 1 exact GELU            :446-456
+ * act 1 with dact != NULL (training) also stores dact = gelu'(x @ w^T + b), the factor ig_linear_dgrad mode 1 applies */
 int ig_linear_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias, void* y_hi,
-                  void* y_lo, void* pre_hi, void* pre_lo, int M, int N, int K, int act, void* stream);
+                  void* y_lo, void* dact_hi, void* dact_lo, int M, int N, int K, int act, void* stream);
 /* timm Block residual linears (proj / fc2): out = resid + x @ w^T + b (fp32 residual stream)          :446-456 */
 int ig_linear_residual_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
                            const float* resid, float* out, int M, int N, int K, void* stream);
-/* dx = dy @ w  (mode 1: * gelu'(pre)); optional dx_colsum[k] += sum_m dx[m][k] (bias grad of the producing layer);
+/* dx = dy @ w  (mode 1: * dact elementwise, the saved gelu'); optional dx_colsum[k] += sum_m dx[m][k] (bias grad of the producing layer);
  * dw += dy^T @ x (fp32 atomics) */
 int ig_linear_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, const void* w_lo, void* dx_hi, void* dx_lo,
-                    const void* pre_hi, const void* pre_lo, float* dx_colsum, int M, int N, int K, int mode, void* stream);
+                    const void* dact_hi, const void* dact_lo, float* dx_colsum, int M, int N, int K, int mode, void* stream);
 int ig_linear_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const void* x_lo, float* dw, int M, int N, int K,
                     void* stream);
 /* F.scaled_dot_product_attention of timm Attention: qkv [B][N][3][H][64] -> out [B][N][H*64], lse [B][H][N] */

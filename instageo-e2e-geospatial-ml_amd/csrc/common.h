@@ -163,6 +163,20 @@ __device__ __forceinline__ float erf_fast(float x) {
     return copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
+// GELU and its derivative from ONE exponential: erf(x/sqrt2) = 1 - poly(t) e,  pdf(x) = e / sqrt(2 pi),  e = exp(-x^2/2)
+__device__ __forceinline__ void gelu_erf_both(float x, float& g, float& dg) {
+    const float a = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(fmaf(0.3275911f, a, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __expf(-a * a);
+    const float erfv = copysignf(1.0f - p * t * e, x);
+    const float cdf = 0.5f * (1.0f + erfv);
+    g = x * cdf;
+    dg = fmaf(x, 0.39894228040143267794f * e, cdf);
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
     float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));
     float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);

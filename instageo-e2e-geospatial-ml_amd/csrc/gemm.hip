@@ -113,13 +113,21 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
     // the convolution gathers were issue-bound on integer divisions recomputed per 16-byte unit per K-step
     typename AL::Row arow[NA];
     typename BL::Row brow[NB];
+    typename AL::Col acolT[NA];  // TR operands: a thread keeps the same column units for the whole tile
+    typename BL::Col bcolT[NB];
     if constexpr (!A_TR) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) arow[i] = al.row(bm * BME + ((tid + i * NTHR) >> 3));
+    } else {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) acolT[i] = al.col(bm * UPA + (tid + i * NTHR) % UPA);
     }
     if constexpr (!B_TR) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) brow[i] = bl.row(bn * BNE + ((tid + i * NTHR) >> 3));
+    } else {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) bcolT[i] = bl.col(bn * UPB + (tid + i * NTHR) % UPB);
     }
 
     // Loads are UNCONDITIONAL (invalid units read a dummy valid address and are zeroed by a select): a
@@ -133,7 +141,7 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
             const int u = tid + i * NTHR;                                                                 \
             bool ok;                                                                                      \
             const bf16_t* p;                                                                              \
-            if constexpr (A_TR) p = al.ptr(seg_, kt_ * BK + u / UPA, bm * UPA + u % UPA, ok);             \
+            if constexpr (A_TR) p = al.ptr_tr(seg_, kt_ * BK + u / UPA, acolT[i], ok);                    \
             else p = al.at(seg_, arow[i], acol_, ok);                                                     \
             if ((BME * 8) % NTHR) ok = ok && u < BME * 8; /* k-row beyond the tile -> masked by ptr/at too */ \
             uint4 v = *reinterpret_cast<const uint4*>(p);                                                 \
@@ -144,7 +152,7 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
             const int u = tid + i * NTHR;                                                                 \
             bool ok;                                                                                      \
             const bf16_t* p;                                                                              \
-            if constexpr (B_TR) p = bl.ptr(seg_, kt_ * BK + u / UPB, bn * UPB + u % UPB, ok);             \
+            if constexpr (B_TR) p = bl.ptr_tr(seg_, kt_ * BK + u / UPB, bcolT[i], ok);                    \
             else p = bl.at(seg_, brow[i], bcol_, ok);                                                     \
             if ((BNE * 8) % NTHR) ok = ok && u < BNE * 8;                                                 \
             uint4 v = *reinterpret_cast<const uint4*>(p);                                                 \
@@ -547,6 +555,24 @@ __global__ __launch_bounds__(NTHR2, (BKT == 32 ? 4 : 2)) void gemm2_kernel(AL al
 #undef GEMM2_ADVANCE_ISSUE
 }
 
+// Division by a launch-time constant as multiply-high + shift (dividends < 2^31): the pixel -> (b, y, x) and
+// k -> (tap, channel) decodes of the convolution gathers were integer divisions per 16-byte unit.
+struct FDiv {
+    unsigned mul, shr, d;
+    __device__ __forceinline__ int div(int n) const { return d == 1 ? n : (int)(__umulhi((unsigned)n, mul) >> shr); }
+};
+static inline FDiv make_fdiv(int d) {
+    FDiv f{0u, 0u, (unsigned)d};
+    if (d > 1) {
+        unsigned lg = 0;
+        while ((1u << lg) < (unsigned)d) ++lg;  // ceil(log2 d)
+        const unsigned p = 31 + lg;
+        f.mul = (unsigned)((((unsigned long long)1 << p) + (unsigned)d - 1) / (unsigned)d);
+        f.shr = p - 32;
+    }
+    return f;
+}
+
 // ------------------------------------------------------------------------------------ loaders
 struct PlainLoader {  // row-major [R][ld], logical width C (multiple of 8)
     static constexpr bool kLinearK = true;  // ptr() is affine in the K index (v2 steps piece pointers instead of re-decoding)
@@ -569,6 +595,11 @@ struct PlainLoader {  // row-major [R][ld], logical width C (multiple of 8)
         ok = rw.ok & cl.ok;
         return base[seg] + (ok ? rw.off + cl.c : 0L);
     }
+    // TR operand: k-row r, hoisted column decode
+    __device__ const bf16_t* ptr_tr(int seg, int r, const Col& cl, bool& ok) const {
+        ok = (r < R) & cl.ok;
+        return base[seg] + (ok ? (long)r * ld + cl.c : 0L);
+    }
 };
 
 // NHWC 3x3 pad-1 gather: row r = pixel (b,y,x), column unit -> (tap, channel).  sign=+1 reads
@@ -578,39 +609,53 @@ struct Conv3Loader {
     __device__ long kstride() const { return 0; }
     const bf16_t* base[3];
     int Mtot, H, W, C, sign;
+    FDiv f_hw, f_w, f_c;  // set by finish()
+    void finish() { f_hw = make_fdiv(H * W), f_w = make_fdiv(W), f_c = make_fdiv(C); }
     __device__ void init(int) {}
     __device__ int kdim() const { return -1; }
-    __device__ const bf16_t* ptr(int seg, int r, int c8, bool& ok) const {
-        int k = c8 * 8;
-        int tap = k / C, c = k - tap * C;
-        int ky = tap / 3, kx = tap - ky * 3;
-        int hw = H * W;
-        int b = r / hw, rem = r - b * hw;
-        int y = rem / W, x = rem - y * W;
-        int sy = y + sign * (ky - 1), sx = x + sign * (kx - 1);
-        ok = (r < Mtot) & (k < 9 * C) & ((unsigned)sy < (unsigned)H) & ((unsigned)sx < (unsigned)W);
-        return base[seg] + (ok ? ((long)(b * H + sy) * W + sx) * C + c : 0L);
+    // split decode: the ROW (pixel) part is done once per tile -- element offset of the pixel and a 9-bit mask of the
+    // taps that stay inside the image -- the COLUMN (tap, channel) part once per K-step; at() is then a shift, an and,
+    // a 64-bit add and a select per 16-byte unit (it used to redo the bounds tests and a 64-bit multiply).
+    struct Row { long off; unsigned mask; };
+    struct Col { int tap, delta, dy, dx; bool ok; };
+    __device__ void pixel(int r, int& y, int& x) const {
+        const int b = f_hw.div(r), rem = r - b * (H * W);
+        y = f_w.div(rem), x = rem - y * W;
     }
-    // split decode: 2 integer divisions per ROW (once per tile) + 1 per COLUMN unit (once per K-step, shared by 4 rows)
-    struct Row { int y, x; long pix; bool ok; };
-    struct Col { int dy, dx, c; bool ok; };
     __device__ Row row(int r) const {
-        int hw = H * W;
-        int b = r / hw, rem = r - b * hw;
-        int y = rem / W, x = rem - y * W;
-        return Row{y, x, (long)r, r < Mtot};
+        int y, x;
+        pixel(r, y, x);
+        unsigned mask = 0;
+        if (r < Mtot) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const bool v = ((unsigned)(y + sign * (ky - 1)) < (unsigned)H) & ((unsigned)(x + sign * (kx - 1)) < (unsigned)W);
+                    mask |= (v ? 1u : 0u) << (ky * 3 + kx);
+                }
+        }
+        return Row{(long)r * C, mask};
     }
     __device__ Col col(int c8) const {
-        int k = c8 * 8;
-        int tap = k / C, c = k - tap * C;
-        int ky = (tap * 11) >> 5, kx = tap - ky * 3;  // tap / 3 for tap < 32
-        return Col{sign * (ky - 1), sign * (kx - 1), c, k < 9 * C};
+        const int k = c8 * 8;
+        const int tap = f_c.div(k), c = k - tap * C;
+        const int ky = (tap * 11) >> 5, kx = tap - ky * 3;  // tap / 3 for tap < 32
+        const int dy = sign * (ky - 1), dx = sign * (kx - 1);
+        return Col{tap, (dy * W + dx) * C + c, dy, dx, k < 9 * C};
     }
     __device__ const bf16_t* at(int seg, const Row& rw, const Col& cl, bool& ok) const {
-        int sy = rw.y + cl.dy, sx = rw.x + cl.dx;
-        ok = rw.ok & cl.ok & ((unsigned)sy < (unsigned)H) & ((unsigned)sx < (unsigned)W);
-        return base[seg] + (ok ? (rw.pix + cl.dy * W + cl.dx) * C + cl.c : 0L);
+        ok = cl.ok & ((rw.mask >> cl.tap) & 1u);
+        return base[seg] + (ok ? rw.off + cl.delta : 0L);
     }
+    // TR operand (weight gradient): k-row = pixel r (changes every K-step), column decode hoisted
+    __device__ const bf16_t* ptr_tr(int seg, int r, const Col& cl, bool& ok) const {
+        int y, x;
+        pixel(r, y, x);
+        ok = cl.ok & (r < Mtot) & ((unsigned)(y + cl.dy) < (unsigned)H) & ((unsigned)(x + cl.dx) < (unsigned)W);
+        return base[seg] + (ok ? (long)r * C + cl.delta : 0L);
+    }
+    __device__ const bf16_t* ptr(int seg, int r, int c8, bool& ok) const { return ptr_tr(seg, r, col(c8), ok); }
 };
 
 // ConvTranspose2d(k3,s2,p1,op1) forward, sub-pixel phase z=(py,px): output (2iy+py, 2ix+px) reads taps
@@ -620,6 +665,8 @@ struct ConvTFwdALoader {
     __device__ long kstride() const { return 0; }
     const bf16_t* base[3];
     int Mtot, H, W, C;
+    FDiv f_hw, f_w, f_c;
+    void finish() { f_hw = make_fdiv(H * W), f_w = make_fdiv(W), f_c = make_fdiv(C); }
     int nky, nkx, ky0, kx0, K;
     __device__ void init(int z) {
         int py = z >> 1, px = z & 1;
@@ -628,37 +675,28 @@ struct ConvTFwdALoader {
         K = nky * nkx * C;
     }
     __device__ int kdim() const { return K; }
-    __device__ const bf16_t* ptr(int seg, int r, int c8, bool& ok) const {
-        int k = c8 * 8;
-        int tl = k / C, c = k - tl * C;
-        int tyi = tl / nkx, txi = tl - tyi * nkx;
-        int ky = ky0 + 2 * tyi, kx = kx0 + 2 * txi;
-        int hw = H * W;
-        int b = r / hw, rem = r - b * hw;
-        int y = rem / W, x = rem - y * W;
-        int sy = y + (ky == 0), sx = x + (kx == 0);
-        ok = (r < Mtot) & (k < K) & (sy < H) & (sx < W);
-        return base[seg] + (ok ? ((long)(b * H + sy) * W + sx) * C + c : 0L);
-    }
-    struct Row { int y, x; long pix; bool ok; };
-    struct Col { int dy, dx, c; bool ok; };
+    struct Row { long off; unsigned mask; };  // mask bit (dy*2 + dx): input pixel (y+dy, x+dx) exists
+    struct Col { int idx, delta; bool ok; };
     __device__ Row row(int r) const {
-        int hw = H * W;
-        int b = r / hw, rem = r - b * hw;
-        int y = rem / W, x = rem - y * W;
-        return Row{y, x, (long)r, r < Mtot};
+        const int b = f_hw.div(r), rem = r - b * (H * W);
+        const int y = f_w.div(rem), x = rem - y * W;
+        unsigned mask = 0;
+        if (r < Mtot) mask = 1u | ((x + 1 < W) ? 2u : 0u) | ((y + 1 < H) ? 4u : 0u) | ((x + 1 < W && y + 1 < H) ? 8u : 0u);
+        return Row{(long)r * C, mask};
     }
     __device__ Col col(int c8) const {
-        int k = c8 * 8;
-        int tl = k / C, c = k - tl * C;
-        int tyi = tl / nkx, txi = tl - tyi * nkx;
-        int ky = ky0 + 2 * tyi, kx = kx0 + 2 * txi;
-        return Col{ky == 0, kx == 0, c, k < K};
+        const int k = c8 * 8;
+        const int tl = f_c.div(k), c = k - tl * C;
+        const int tyi = nkx == 2 ? (tl >> 1) : tl, txi = tl - tyi * nkx;
+        const int dy = (ky0 + 2 * tyi) == 0, dx = (kx0 + 2 * txi) == 0;  // tap 0 reads the next input row / column
+        return Col{dy * 2 + dx, (dy * W + dx) * C + c, k < K};
     }
     __device__ const bf16_t* at(int seg, const Row& rw, const Col& cl, bool& ok) const {
-        ok = rw.ok & cl.ok & (rw.y + cl.dy < H) & (rw.x + cl.dx < W);
-        return base[seg] + (ok ? (rw.pix + cl.dy * W + cl.dx) * C + cl.c : 0L);
+        ok = cl.ok & ((rw.mask >> cl.idx) & 1u);
+        return base[seg] + (ok ? rw.off + cl.delta : 0L);
     }
+    __device__ const bf16_t* ptr_tr(int seg, int r, const Col& cl, bool& ok) const { return at(seg, row(r), cl, ok); }
+    __device__ const bf16_t* ptr(int seg, int r, int c8, bool& ok) const { return at(seg, row(r), col(c8), ok); }
 };
 // matching weight view: n = co, k = (local tap, ci) of storage Wc[co][tap][ci]
 struct ConvTFwdBLoader {
@@ -688,6 +726,7 @@ struct ConvTFwdBLoader {
     __device__ Row row(int r) const { return Row{r}; }
     __device__ Col col(int c8) const { return Col{c8}; }
     __device__ const bf16_t* at(int seg, const Row& rw, const Col& cl, bool& ok) const { return ptr(seg, rw.r, cl.c8, ok); }
+    __device__ const bf16_t* ptr_tr(int seg, int r, const Col& cl, bool& ok) const { return ptr(seg, r, cl.c8, ok); }
 };
 
 // dgrad weight view (TR operand): reduce row = (tap, co), contiguous columns = ci of Wc[co][tap][ci]
@@ -710,6 +749,7 @@ struct ConvWgtTRLoader {
     __device__ Row row(int r) const { return Row{r}; }
     __device__ Col col(int c8) const { return Col{c8}; }
     __device__ const bf16_t* at(int seg, const Row& rw, const Col& cl, bool& ok) const { return ptr(seg, rw.r, cl.c8, ok); }
+    __device__ const bf16_t* ptr_tr(int seg, int r, const Col& cl, bool& ok) const { return ptr(seg, r, cl.c8, ok); }
 };
 
 // ConvTranspose dgrad A: row = input pixel (b,iy,ix), k = (tap, co): reads dOut(2iy-1+ky, 2ix-1+kx).
@@ -720,41 +760,51 @@ struct ConvTGradLoader {
     const bf16_t* base[3];
     int Mtot, H, W, Cout;  // H,W = input resolution; dOut is (2H,2W)
     int fixed_tap;         // -1: k=(tap,co); -2: take tap from blockIdx.z
+    FDiv f_hw, f_w, f_c;
+    void finish() { f_hw = make_fdiv(H * W), f_w = make_fdiv(W), f_c = make_fdiv(Cout); }
     int tapz;
     __device__ void init(int z) { tapz = z; }
     __device__ int kdim() const { return -1; }
-    __device__ const bf16_t* ptr(int seg, int r, int c8, bool& ok) const {
-        int k = c8 * 8;
-        int tap = (fixed_tap == -1) ? k / Cout : tapz;
-        int c = (fixed_tap == -1) ? k - tap * Cout : k;
-        int ky = tap / 3, kx = tap - ky * 3;
-        int hw = H * W;
-        int b = r / hw, rem = r - b * hw;
-        int y = rem / W, x = rem - y * W;
-        int oy = 2 * y - 1 + ky, ox = 2 * x - 1 + kx;
-        ok = (tap < 9) & (c < Cout) & (r < Mtot) & ((unsigned)oy < (unsigned)(2 * H)) & ((unsigned)ox < (unsigned)(2 * W));
-        return base[seg] + (ok ? ((long)(b * 2 * H + oy) * (2 * W) + ox) * Cout + c : 0L);
+    struct Row { long off; unsigned mask; };  // off = element offset of output pixel (2y, 2x); mask bit tap: (2y-1+ky, 2x-1+kx) exists
+    struct Col { int tap, delta, ky, kx; bool ok; };
+    __device__ void pixel(int r, int& b, int& y, int& x) const {
+        b = f_hw.div(r);
+        const int rem = r - b * (H * W);
+        y = f_w.div(rem), x = rem - y * W;
     }
-    struct Row { int y, x; long opix; bool ok; };  // opix = index of output pixel (2y, 2x) in the (2H, 2W) image
-    struct Col { int ky, kx, c; bool ok; };
     __device__ Row row(int r) const {
-        int hw = H * W;
-        int b = r / hw, rem = r - b * hw;
-        int y = rem / W, x = rem - y * W;
-        return Row{y, x, ((long)(b * 2 * H + 2 * y)) * (2 * W) + 2 * x, r < Mtot};
+        int b, y, x;
+        pixel(r, b, y, x);
+        unsigned mask = 0;
+        if (r < Mtot) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const bool v = ((unsigned)(2 * y - 1 + ky) < (unsigned)(2 * H)) & ((unsigned)(2 * x - 1 + kx) < (unsigned)(2 * W));
+                    mask |= (v ? 1u : 0u) << (ky * 3 + kx);
+                }
+        }
+        return Row{(((long)(b * 2 * H + 2 * y)) * (2 * W) + 2 * x) * Cout, mask};
     }
     __device__ Col col(int c8) const {
-        int k = c8 * 8;
-        int tap = (fixed_tap == -1) ? k / Cout : tapz;
-        int c = (fixed_tap == -1) ? k - tap * Cout : k;
-        int ky = (tap * 11) >> 5, kx = tap - ky * 3;
-        return Col{ky, kx, c, (tap < 9) && (c < Cout)};
+        const int k = c8 * 8;
+        const int tap = (fixed_tap == -1) ? f_c.div(k) : tapz;
+        const int c = (fixed_tap == -1) ? k - tap * Cout : k;
+        const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
+        return Col{tap, ((ky - 1) * (2 * W) + (kx - 1)) * Cout + c, ky, kx, (tap < 9) && (c < Cout)};
     }
     __device__ const bf16_t* at(int seg, const Row& rw, const Col& cl, bool& ok) const {
-        int oy = 2 * rw.y - 1 + cl.ky, ox = 2 * rw.x - 1 + cl.kx;
-        ok = rw.ok & cl.ok & ((unsigned)oy < (unsigned)(2 * H)) & ((unsigned)ox < (unsigned)(2 * W));
-        return base[seg] + (ok ? (rw.opix + (long)(cl.ky - 1) * (2 * W) + (cl.kx - 1)) * Cout + cl.c : 0L);
+        ok = cl.ok & ((rw.mask >> cl.tap) & 1u);
+        return base[seg] + (ok ? rw.off + cl.delta : 0L);
     }
+    __device__ const bf16_t* ptr_tr(int seg, int r, const Col& cl, bool& ok) const {
+        int b, y, x;
+        pixel(r, b, y, x);
+        ok = cl.ok & (r < Mtot) & ((unsigned)(2 * y - 1 + cl.ky) < (unsigned)(2 * H)) & ((unsigned)(2 * x - 1 + cl.kx) < (unsigned)(2 * W));
+        return base[seg] + (ok ? (((long)(b * 2 * H + 2 * y)) * (2 * W) + 2 * x) * Cout + cl.delta : 0L);
+    }
+    __device__ const bf16_t* ptr(int seg, int r, int c8, bool& ok) const { return ptr_tr(seg, r, col(c8), ok); }
 };
 
 // ---------------------------------------------------------------------------------- epilogues
@@ -798,9 +848,15 @@ struct EpStore {
         }
         size_t idx = (size_t)row * ldo + n;
         if (act == 1) {
-            if (pre_hi) store4_split(pre_hi, pre_lo, idx, v);
+            if (pre_hi) {  // training: also save gelu'(pre-activation), the only thing backward needs of it
+                float dg[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
+                for (int i = 0; i < 4; ++i) gelu_erf_both(v[i], v[i], dg[i]);
+                store4_split(pre_hi, pre_lo, idx, dg);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
+            }
         }
         if (drop_thresh) {
             float mk[4];
@@ -812,7 +868,7 @@ struct EpStore {
     }
 };
 
-// dgrad store with an elementwise factor: mode 1: * gelu'(pre[m][n]); mode 2: * dropout mask(idx)
+// dgrad store with an elementwise factor: mode 1: * dact[m][n] (the gelu' saved by the forward); mode 2: * dropout mask(idx)
 struct EpGradStore {
     static constexpr bool kStagedAtomic = false;
     static constexpr bool kColSum = true;  // optional fused column sums of the stored values (bias gradient)
@@ -830,9 +886,17 @@ struct EpGradStore {
     __device__ f32x4 store_ret(int m, int n, f32x4 a) const {
         size_t idx = (size_t)m * ldo + n;
         float v[4] = {a[0], a[1], a[2], a[3]};
-        if (mode == 1) {
+        if (mode == 1) {  // elementwise factor saved by the forward epilogue (gelu'), 4 values = one 8-byte load
+            const uint2 u = *reinterpret_cast<const uint2*>(pre_hi + idx);
+            float f[4] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                          __uint_as_float(u.y & 0xffff0000u)};
+            if (pre_lo) {
+                const uint2 l = *reinterpret_cast<const uint2*>(pre_lo + idx);
+                f[0] += __uint_as_float(l.x << 16), f[1] += __uint_as_float(l.x & 0xffff0000u);
+                f[2] += __uint_as_float(l.y << 16), f[3] += __uint_as_float(l.y & 0xffff0000u);
+            }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] *= gelu_erf_grad(load1_split(pre_hi, pre_lo, idx + i));
+            for (int i = 0; i < 4; ++i) v[i] *= f[i];
         } else if (mode == 2 && drop_thresh) {
             float mk[4];
             dropout_scale4(drop_seed, (uint32_t)idx, drop_thresh, drop_inv, mk);
@@ -1105,7 +1169,7 @@ int ig_linear_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, cons
                     const void* pre_hi, const void* pre_lo, float* dx_colsum, int M, int N, int K, int mode, void* stream) {
     IG_REQUIRE(dy_hi && w_hi && dx_hi, "ig_linear_dgrad: null pointer");
     IG_REQUIRE(N % 8 == 0 && K % 8 == 0, "ig_linear_dgrad: N and K must be multiples of 8");
-    IG_REQUIRE(mode == 0 || (mode == 1 && pre_hi), "ig_linear_dgrad: mode 1 needs the pre-activation tensor");
+    IG_REQUIRE(mode == 0 || (mode == 1 && pre_hi), "ig_linear_dgrad: mode 1 needs the saved activation-derivative tensor (dact)");
     IG_SPLIT_CONSISTENT(dy_lo, w_lo);
     EpGradStore ep{};
     ep.out_hi = (bf16_t*)dx_hi, ep.out_lo = (bf16_t*)dx_lo, ep.pre_hi = (const bf16_t*)pre_hi, ep.pre_lo = (const bf16_t*)pre_lo;
@@ -1153,6 +1217,7 @@ int ig_conv3x3_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const v
     Conv3Loader al{};
     seg_a(al.base, x_hi, x_lo);
     al.Mtot = B * H * W, al.H = H, al.W = W, al.C = Cin, al.sign = 1;
+    al.finish();
     EpStore ep{};
     ep.out_hi = (bf16_t*)y_hi, ep.out_lo = (bf16_t*)y_lo, ep.bias = bias, ep.ldo = Cout;
     IG_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "ig_conv3x3_fwd: bn_scale and bn_shift go together");
@@ -1172,6 +1237,7 @@ int ig_conv3x3_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, con
     Conv3Loader al{};
     seg_a(al.base, dy_hi, dy_lo);
     al.Mtot = B * H * W, al.H = H, al.W = W, al.C = Cout, al.sign = -1;
+    al.finish();
     ConvWgtTRLoader bl{};
     seg_b(bl.base, w_hi, w_lo);
     bl.Cout = Cout, bl.Cin = Cin;
@@ -1195,6 +1261,7 @@ int ig_conv3x3_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, con
     Conv3Loader bl{};
     seg_b(bl.base, x_hi, x_lo);
     bl.Mtot = Mtot, bl.H = H, bl.W = W, bl.C = Cin, bl.sign = 1;
+    bl.finish();
     EpAtomic ep{dw, 9L * Cin, 0, 0};
     return launch_gemm<PlainLoader, Conv3Loader, EpAtomic, true, true>(
         plain_a(dy_hi, dy_lo, Mtot, Cout, Cout), bl, ep, Cout, 9 * Cin, Mtot, 1, dy_lo != nullptr, (hipStream_t)stream,
@@ -1212,6 +1279,7 @@ int ig_convT_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const voi
     ConvTFwdALoader al{};
     seg_a(al.base, x_hi, x_lo);
     al.Mtot = B * H * W, al.H = H, al.W = W, al.C = Cin;
+    al.finish();
     ConvTFwdBLoader bl{};
     seg_b(bl.base, w_hi, w_lo);
     bl.Cout = Cout, bl.C = Cin;
@@ -1235,6 +1303,7 @@ int ig_convT_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, const
     ConvTGradLoader al{};
     seg_a(al.base, dy_hi, dy_lo);
     al.Mtot = B * H * W, al.H = H, al.W = W, al.Cout = Cout, al.fixed_tap = -1;
+    al.finish();
     ConvWgtTRLoader bl{};
     seg_b(bl.base, w_hi, w_lo);
     bl.Cout = Cout, bl.Cin = Cin;
@@ -1254,6 +1323,7 @@ int ig_convT_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const
     ConvTGradLoader al{};
     seg_a(al.base, dy_hi, dy_lo);
     al.Mtot = Mtot, al.H = H, al.W = W, al.Cout = Cout, al.fixed_tap = -2;
+    al.finish();
     EpAtomic ep{dw, 9L * Cin, (long)Cin, 0};
     return launch_gemm<ConvTGradLoader, PlainLoader, EpAtomic, true, true>(
         al, plain_b(x_hi, x_lo, Mtot, Cin, Cin), ep, Cout, Cin, Mtot, 9, dy_lo != nullptr, (hipStream_t)stream,

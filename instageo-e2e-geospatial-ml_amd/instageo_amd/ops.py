@@ -172,6 +172,8 @@ def layernorm_bwd(dy: BT, x, mean, rstd, gamma, dx, accumulate: bool, dxb: Optio
 
 
 def linear_fwd(x: BT, w: BT, bias, y: BT, M: int, N: int, K: int, act: int = 0, pre: Optional[BT] = None) -> None:
+    """y = act(x @ w^T + b).  With act=1 and ``pre`` given, ``pre`` receives gelu'(x @ w^T + b) -- the elementwise factor
+    :func:`linear_dgrad` applies in backward (the pre-activation itself is never needed again)."""
     _call("ig_linear_fwd", 2.0 * M * N * K, _p(x.hi), _p(x.lo), _p(w.hi), _p(w.lo), _p(bias), _p(y.hi), _p(y.lo),
               _p(pre.hi) if pre else None, _p(pre.lo) if pre else None, M, N, K, act, _stream())
 
@@ -181,7 +183,7 @@ def linear_residual_fwd(x: BT, w: BT, bias, resid, out, M: int, N: int, K: int) 
 
 
 def linear_dgrad(dy: BT, w: BT, dx: BT, M: int, N: int, K: int, pre: Optional[BT] = None, colsum=None) -> None:
-    """dx = dy @ w [* gelu'(pre)]; ``colsum`` (fp32 [K]) additionally accumulates the column sums of dx."""
+    """dx = dy @ w [* pre, the gelu' saved by linear_fwd]; ``colsum`` (fp32 [K]) additionally accumulates the column sums of dx."""
     _call("ig_linear_dgrad", 2.0 * M * N * K, _p(dy.hi), _p(dy.lo), _p(w.hi), _p(w.lo), _p(dx.hi), _p(dx.lo),
               _p(pre.hi) if pre else None, _p(pre.lo) if pre else None, _p(colsum), M, N, K, 1 if pre else 0, _stream())
 

@@ -55,9 +55,13 @@ def test_linear_fwd(split, M, N, K):
     ops.linear_fwd(x, w, b, y, M, N, K, act=0)
     ref = xr @ wr.t() + b.double().cpu()
     close(y.float(), ref, tol_out(split), what="linear")
-    ops.linear_fwd(x, w, b, y, M, N, K, act=1, pre=pre)
-    close(pre.float(), ref, tol_out(split), what="linear pre")
+    ops.linear_fwd(x, w, b, y, M, N, K, act=1, pre=pre)  # training form: also saves gelu'(pre-activation)
+    rr = ref.clone().requires_grad_(True)
+    (dref,) = torch.autograd.grad(F.gelu(rr).sum(), rr)
+    close(pre.float(), dref, tol_out(split), what="linear saved gelu'")
     close(y.float(), F.gelu(ref), tol_out(split), what="linear gelu")
+    ops.linear_fwd(x, w, b, y, M, N, K, act=1)  # inference form
+    close(y.float(), F.gelu(ref), tol_out(split), what="linear gelu (no save)")
 
 
 @pytest.mark.parametrize("split", SPLITS)
@@ -85,12 +89,10 @@ def test_linear_dgrad_wgrad(split, M, N, K):
     dx = BT.empty((M, K), split, DEV)
     ops.linear_dgrad(dy, w, dx, M, N, K)
     close(dx.float(), dyr @ wr, tol_out(split), what="dgrad")
-    pre, prer = bt(rnd(M, K, seed=8), split)
+    pre, gref = bt(rnd(M, K, seed=8), split)  # the elementwise factor the forward saved (gelu' there; any tensor here)
     cs = torch.zeros(K, device=DEV)
     ops.linear_dgrad(dy, w, dx, M, N, K, pre=pre, colsum=cs)
-    pr = prer.clone().requires_grad_(True)
-    (gref,) = torch.autograd.grad(F.gelu(pr).sum(), pr)
-    close(dx.float(), (dyr @ wr) * gref, tol_out(split), what="dgrad*gelu'")
+    close(dx.float(), (dyr @ wr) * gref, tol_out(split), what="dgrad*dact")
     close(cs, ((dyr @ wr) * gref).sum(0), 3e-5, what="fused column sums (bias grad)")
     dw = torch.zeros(N, K, device=DEV)
     ops.linear_wgrad(dy, x, dw, M, N, K)

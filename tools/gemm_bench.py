@@ -45,6 +45,10 @@ for M, N, K in shapes:
     t_res = timeit(lambda: ops.linear_residual_fwd(x, w, bias, res, res, M, N, K))
     dy, dx = rnd(M, N), BT(torch.empty(M, K, device=dev, dtype=torch.bfloat16))
     t_dg = timeit(lambda: ops.linear_dgrad(dy, w, dx, M, N, K))
+    pre = rnd(M, K)
+    t_dgg = timeit(lambda: ops.linear_dgrad(dy, w, dx, M, N, K, pre=pre))
+    cs = torch.zeros(K, device=dev)
+    t_dgc = timeit(lambda: ops.linear_dgrad(dy, w, dx, M, N, K, colsum=cs))
     dw = torch.zeros(N, K, device=dev)
     t_wg = timeit(lambda: ops.linear_wgrad(dy, x, dw, M, N, K))
-    print(f"M{M} N{N} K{K}: fwd {fl/t_fwd/1e12:6.0f}  fwd+gelu {fl/t_gelu/1e12:6.0f}  resid {fl/t_res/1e12:6.0f}  dgrad {fl/t_dg/1e12:6.0f}  wgrad {fl/t_wg/1e12:6.0f} TFLOP/s   (fwd {t_fwd*1e6:.0f} us)")
+    print(f"M{M} N{N} K{K}: fwd {fl/t_fwd/1e12:6.0f}  fwd+gelu {fl/t_gelu/1e12:6.0f}  resid {fl/t_res/1e12:6.0f}  dgrad {fl/t_dg/1e12:6.0f} (+gelu' {fl/t_dgg/1e12:4.0f}, +colsum {fl/t_dgc/1e12:4.0f})  wgrad {fl/t_wg/1e12:6.0f} TFLOP/s   (fwd {t_fwd*1e6:.0f} us)")
