@@ -149,7 +149,8 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const bf16_t* __restrict
     f32x4 o[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;  // running max in the base-2 domain (m_run = max(s) * c2)
+    const float c2 = scale * 1.44269504088896340736f;
 
     const int ntiles = (N + KT - 1) / KT;
     TileGroup<SPLIT ? 4 : 2, NTL, NRS> tg;
@@ -180,27 +181,28 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const bf16_t* __restrict
                 st[sub] = mma<SPLIT>(kh, kl, qh[s], ql[s], st[sub]);
             }
         }
-        // online softmax over this lane's query column (keys live in regs and in lanes l^16, l^32, l^48)
-        float mx = -INFINITY;
+        // online softmax over this lane's query column (keys live in regs and in lanes l^16, l^32, l^48), in the
+        // base-2 domain: p = exp2(s*c - m) with c = scale*log2(e) folded into one fma per element (v_exp_f32 IS exp2);
+        // the key < N mask is only evaluated on the tail tile
+        if (kt * KT + KT > N) {
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
+            for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int key = kt * KT + sub * 16 + 4 * g + r;
-                float v = key < N ? st[sub][r] * scale : -INFINITY;
-                st[sub][r] = v;
-                mx = fmaxf(mx, v);
-            }
+                for (int r = 0; r < 4; ++r)
+                    if (kt * KT + sub * 16 + 4 * g + r >= N) st[sub][r] = -INFINITY;
+        }
+        float mx = fmaxf(fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3])),
+                         fmaxf(fmaxf(st[1][0], st[1][1]), fmaxf(st[1][2], st[1][3])));
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float m_new = fmaxf(m_run, mx);
-        float alpha = __expf(m_run - m_new);  // m_run=-inf on the first tile -> 0
+        const float m_new = fmaxf(m_run, mx * c2);  // c2 > 0: max commutes with the scaling
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // m_run=-inf on the first tile -> 0
         float psum = 0.f;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float p = __expf(st[sub][r] - m_new);
+                const float p = __builtin_amdgcn_exp2f(fmaf(st[sub][r], c2, -m_new));
                 st[sub][r] = p;
                 psum += p;
             }
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const bf16_t* __restrict
             float f[4] = {o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv};
             store4_split(out_hi, out_lo, (size_t)orow + dt * 16 + 4 * g, f);
         }
-        if (lse && g == 0) lse[((long)b * H + h) * N + q] = m_run + __logf(l_run);
+        if (lse && g == 0) lse[((long)b * H + h) * N + q] = (m_run + __log2f(l_run)) * 0.69314718055994530942f;
     }
 }
 
@@ -300,7 +302,8 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dq_kernel(const bf16_t* __restr
         ql[s] = SPLIT ? load_own(base_lo, RS, q0, N, s, lane) : qh[s];
         dl[s] = SPLIT ? load_own(dob_lo, OS, q0, N, s, lane) : dh[s];
     }
-    const float my_lse = q < N ? lse[((long)b * H + h) * N + q] : INFINITY;  // +inf -> P = 0 on padded queries
+    const float c2 = scale * 1.44269504088896340736f;  // P = exp2(s*c2 - lse*log2e): one fma + v_exp_f32 per element
+    const float my_lse = q < N ? lse[((long)b * H + h) * N + q] * 1.44269504088896340736f : INFINITY;  // +inf -> P = 0 on padded queries
     const float my_delta = q < N ? delta[((long)b * H + h) * N + q] : 0.f;
     f32x4 dq[4];
 #pragma unroll
@@ -323,6 +326,7 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dq_kernel(const bf16_t* __restr
         for (int j = 0; j < NTL && kt0 + j < ntiles; ++j) {
         const int kt = kt0 + j;
         const char *k_hi = k_hi0 + j * TILE, *v_hi = v_hi0 + j * TILE, *k_lo = k_lo0 + j * TILE, *v_lo = v_lo0 + j * TILE;
+        const bool tail = kt * KT + KT > N;  // only the last tile has keys beyond N
         f32x4 ds[2];
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -338,9 +342,9 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dq_kernel(const bf16_t* __restr
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                int key = kt * KT + sub * 16 + 4 * g + r;
-                float p = key < N ? __expf(st[r] * scale - my_lse) : 0.f;
-                ds[sub][r] = p * (dp[r] - my_delta) * scale;
+                float p = __builtin_amdgcn_exp2f(fmaf(st[r], c2, -my_lse));
+                if (tail && kt * KT + sub * 16 + 4 * g + r >= N) p = 0.f;
+                ds[sub][r] = p * (dp[r] - my_delta);  // the softmax scale is applied once to the finished dQ tile
             }
         }
         bf16x8_t sh, sl;
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dq_kernel(const bf16_t* __restr
         long orow = ((long)b * N + q) * RS + h * HD;  // q slot of dqkv
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            float f[4] = {dq[dt][0], dq[dt][1], dq[dt][2], dq[dt][3]};
+            float f[4] = {dq[dt][0] * scale, dq[dt][1] * scale, dq[dt][2] * scale, dq[dt][3] * scale};
             store4_split(dqkv_hi, dqkv_lo, (size_t)orow + dt * 16 + 4 * g, f);
         }
     }
@@ -393,6 +397,7 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dkv_kernel(const bf16_t* __rest
     const bf16_t* dob_lo = SPLIT ? do_lo + (long)b * N * OS + h * HD : nullptr;
     const int k0 = (blockIdx.x * nw + wave) * 16;
     const int g = lane >> 4;
+    const float c2 = scale * 1.44269504088896340736f;
 
     bf16x8_t kh[2], kl[2], vh[2], vl[2];
 #pragma unroll
@@ -417,7 +422,7 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dkv_kernel(const bf16_t* __rest
         else tg.load_sync(smem, base_hi, dob_hi, base_lo, dob_lo, RS, OS, qt0, N, tid, nthr);
         if (tid < NTL * KT) {
             int qq = qt0 * KT + tid;
-            s_lse0[tid] = qq < N ? lse[((long)b * H + h) * N + qq] : INFINITY;
+            s_lse0[tid] = qq < N ? lse[((long)b * H + h) * N + qq] * 1.44269504088896340736f : INFINITY;  // base-2 domain
             s_del0[tid] = qq < N ? delta[((long)b * H + h) * N + qq] : 0.f;
         }
         __syncthreads();
@@ -441,9 +446,9 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dkv_kernel(const bf16_t* __rest
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int ql_ = sub * 16 + 4 * g + r;
-                float p = __expf(st[r] * scale - s_lse[ql_]);  // padded queries: lse=+inf -> 0
+                float p = __builtin_amdgcn_exp2f(fmaf(st[r], c2, -s_lse[ql_]));  // padded queries: lse=+inf -> 0
                 pp[sub][r] = p;
-                ds[sub][r] = p * (dp[r] - s_del[ql_]) * scale;
+                ds[sub][r] = p * (dp[r] - s_del[ql_]);  // scale applied once to the finished dK tile
             }
         }
         bf16x8_t ph, pl, sh, sl;
@@ -466,7 +471,7 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dkv_kernel(const bf16_t* __rest
         long orow = ((long)b * N + key) * RS + h * HD;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            float fk[4] = {dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]};
+            float fk[4] = {dk[dt][0] * scale, dk[dt][1] * scale, dk[dt][2] * scale, dk[dt][3] * scale};
             float fv[4] = {dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]};
             store4_split(dqkv_hi, dqkv_lo, (size_t)orow + (long)H * HD + dt * 16 + 4 * g, fk);
             store4_split(dqkv_hi, dqkv_lo, (size_t)orow + 2L * H * HD + dt * 16 + 4 * g, fv);
