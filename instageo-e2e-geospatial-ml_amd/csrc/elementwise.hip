@@ -294,34 +294,41 @@ __global__ __launch_bounds__(LNB_TPB) void layernorm_bwd_exact_kernel(const bf16
     for (int i = 0; i < NCH; ++i) ag[i] = ab[i] = ac[i] = make_float4(0, 0, 0, 0);
     const int row0 = blockIdx.x * rows_per_block;
     const int row1 = min(M, row0 + rows_per_block);
-    for (int row = row0 + wave; row < row1; row += LNB_TPB / 64) {
-        const float mu = mean[row], rs = rstd[row];
-        bool zero_dy = false;
-        long dbase = (long)row * D;
-        int tfr = 0;
-        if (FEAT) {
-            int b = row / ntok, tok = row - b * ntok;
-            if (tok == 0) zero_dy = true;
-            else {
-                int tp = tok - 1;
-                tfr = tp / feat_G;
-                int p = tp - tfr * feat_G;
-                dbase = ((long)b * feat_G + p) * ((long)D * feat_T);
-            }
-        }
-        float4 xh[NCH], dyv[NCH];
-        float s1 = 0.f, s2 = 0.f;
+    // TWO rows per wave and iteration, every load of both rows (x, dy and -- when accumulating -- the old dx) issued before
+    // the first reduction: one exposed memory latency per pair of rows instead of two per row
+    constexpr int NW = LNB_TPB / 64;
+    for (int rbase = row0 + wave; rbase < row1; rbase += 2 * NW) {
+        float4 xh[2][NCH], dyv[2][NCH], old[2][NCH];
+        float mu[2], rs[2];
+        bool live[2];
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            int c = lane + i * 64;
-            {
-                float4 xv = *reinterpret_cast<const float4*>(x + (size_t)row * D + c * 4);
-                xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+        for (int q = 0; q < 2; ++q) {
+            const int rowq = rbase + q * NW;
+            live[q] = rowq < row1;
+            const int row = live[q] ? rowq : rbase;  // dead second row: harmless duplicate loads, no stores
+            mu[q] = mean[row], rs[q] = rstd[row];
+            bool zero_dy = false;
+            long dbase = (long)row * D;
+            int tfr = 0;
+            if (FEAT) {
+                int b = row / ntok, tok = row - b * ntok;
+                if (tok == 0) zero_dy = true;
+                else {
+                    int tp = tok - 1;
+                    tfr = tp / feat_G;
+                    int p = tp - tfr * feat_G;
+                    dbase = ((long)b * feat_G + p) * ((long)D * feat_T);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = lane + i * 64;
+                xh[q][i] = *reinterpret_cast<const float4*>(x + (size_t)row * D + c * 4);
+                old[q][i] = accumulate ? *reinterpret_cast<const float4*>(dx + (size_t)row * D + c * 4) : make_float4(0, 0, 0, 0);
                 float d[4] = {0.f, 0.f, 0.f, 0.f};
                 if (!zero_dy) {
                     if (!FEAT || feat_T <= 1) {
-                        const bf16_t* ph = dy_hi + dbase + c * 4;
-                        uint2 u = *reinterpret_cast<const uint2*>(ph);
+                        uint2 u = *reinterpret_cast<const uint2*>(dy_hi + dbase + c * 4);
                         d[0] = __uint_as_float(u.x << 16), d[1] = __uint_as_float(u.x & 0xffff0000u);
                         d[2] = __uint_as_float(u.y << 16), d[3] = __uint_as_float(u.y & 0xffff0000u);
                         if (dy_lo) {
@@ -334,37 +341,45 @@ __global__ __launch_bounds__(LNB_TPB) void layernorm_bwd_exact_kernel(const bf16
                         for (int j = 0; j < 4; ++j) d[j] = load1_split(dy_hi, dy_lo, (size_t)dbase + (long)(c * 4 + j) * feat_T + tfr);
                     }
                 }
-                dyv[i] = make_float4(d[0], d[1], d[2], d[3]);
-                float4 g = *reinterpret_cast<const float4*>(gamma + c * 4);
-                float a0 = d[0] * g.x, a1 = d[1] * g.y, a2 = d[2] * g.z, a3 = d[3] * g.w;
-                s1 += a0 + a1 + a2 + a3;
-                s2 += a0 * xh[i].x + a1 * xh[i].y + a2 * xh[i].z + a3 * xh[i].w;
+                dyv[q][i] = make_float4(d[0], d[1], d[2], d[3]);
             }
         }
-        s1 = wave_sum(s1) / D;
-        s2 = wave_sum(s2) / D;
+        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            int c = lane + i * 64;
-            {
-                float4 g = *reinterpret_cast<const float4*>(gamma + c * 4);
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = lane + i * 64;
+                const float4 xv = xh[q][i];
+                xh[q][i] = make_float4((xv.x - mu[q]) * rs[q], (xv.y - mu[q]) * rs[q], (xv.z - mu[q]) * rs[q], (xv.w - mu[q]) * rs[q]);
+                const float4 g = *reinterpret_cast<const float4*>(gamma + c * 4);
+                const float a0 = dyv[q][i].x * g.x, a1 = dyv[q][i].y * g.y, a2 = dyv[q][i].z * g.z, a3 = dyv[q][i].w * g.w;
+                s1[q] += a0 + a1 + a2 + a3;
+                s2[q] += a0 * xh[q][i].x + a1 * xh[q][i].y + a2 * xh[q][i].z + a3 * xh[q][i].w;
+            }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) s1[q] = wave_sum(s1[q]) / D, s2[q] = wave_sum(s2[q]) / D;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (!live[q]) continue;  // wave-uniform
+            const int row = rbase + q * NW;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = lane + i * 64;
+                const float4 g = *reinterpret_cast<const float4*>(gamma + c * 4);
                 float4 r;
-                r.x = rs * (dyv[i].x * g.x - s1 - xh[i].x * s2);
-                r.y = rs * (dyv[i].y * g.y - s1 - xh[i].y * s2);
-                r.z = rs * (dyv[i].z * g.z - s1 - xh[i].z * s2);
-                r.w = rs * (dyv[i].w * g.w - s1 - xh[i].w * s2);
-                float* dp = dx + (size_t)row * D + c * 4;
-                if (accumulate) {
-                    float4 o = *reinterpret_cast<const float4*>(dp);
-                    r.x += o.x, r.y += o.y, r.z += o.z, r.w += o.w;
-                }
-                *reinterpret_cast<float4*>(dp) = r;
+                r.x = rs[q] * (dyv[q][i].x * g.x - s1[q] - xh[q][i].x * s2[q]) + old[q][i].x;
+                r.y = rs[q] * (dyv[q][i].y * g.y - s1[q] - xh[q][i].y * s2[q]) + old[q][i].y;
+                r.z = rs[q] * (dyv[q][i].z * g.z - s1[q] - xh[q][i].z * s2[q]) + old[q][i].z;
+                r.w = rs[q] * (dyv[q][i].w * g.w - s1[q] - xh[q][i].w * s2[q]) + old[q][i].w;
+                *reinterpret_cast<float4*>(dx + (size_t)row * D + c * 4) = r;
                 if (dxb_hi) {
                     float f[4] = {r.x, r.y, r.z, r.w};
                     store4_split(dxb_hi, dxb_lo, (size_t)row * D + c * 4, f);
                 }
-                ag[i].x += dyv[i].x * xh[i].x, ag[i].y += dyv[i].y * xh[i].y, ag[i].z += dyv[i].z * xh[i].z, ag[i].w += dyv[i].w * xh[i].w;
-                ab[i].x += dyv[i].x, ab[i].y += dyv[i].y, ab[i].z += dyv[i].z, ab[i].w += dyv[i].w;
+                ag[i].x += dyv[q][i].x * xh[q][i].x, ag[i].y += dyv[q][i].y * xh[q][i].y, ag[i].z += dyv[q][i].z * xh[q][i].z,
+                    ag[i].w += dyv[q][i].w * xh[q][i].w;
+                ab[i].x += dyv[q][i].x, ab[i].y += dyv[q][i].y, ab[i].z += dyv[q][i].z, ab[i].w += dyv[q][i].w;
                 ac[i].x += r.x, ac[i].y += r.y, ac[i].z += r.z, ac[i].w += r.w;
             }
         }
@@ -827,7 +842,7 @@ int ig_layernorm_bwd(const void* dy_hi, const void* dy_lo, const float* x, const
     IG_REQUIRE(D % 4 == 0 && D <= 2048, "ig_layernorm_bwd: D must be a multiple of 4 and <= 2048 (got %d)", D);
     if (M == 0) return IG_OK;
     static const int rpb_env = getenv("IG_LNB_RPB") ? atoi(getenv("IG_LNB_RPB")) : 0;
-    const int rpb = rpb_env > 0 ? rpb_env : 32;
+    const int rpb = rpb_env > 0 ? rpb_env : 48;  // 8 waves-iterations of 2 rows x 4 waves... measured best of 16..128 (tools/ln_bench.py)
     dim3 grid(ig_cdiv(M, rpb));
     size_t sm = 3 * (size_t)D * sizeof(float);
 #define IG_LNB_EXACT(NCH_)                                                                                              \
