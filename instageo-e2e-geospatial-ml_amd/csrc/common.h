@@ -152,33 +152,40 @@ static inline uint32_t ig_drop_thresh16(float p) { return p > 0.f ? (uint32_t)((
 
 // erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7): 1 rcp + 1 exp + 5 fma instead of the ~40-instruction
 // branchy libm erff -- the GELU epilogue of the fc1 GEMM (64 values per lane) was costing as much as its K loop.
+// v_rcp_f32 / v_exp_f32 are used raw (1 ulp): __frcp_rn expands to the ~10-instruction IEEE division sequence.
 __device__ __forceinline__ float erf_fast(float x) {
     const float ax = fabsf(x);
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
     float p = fmaf(1.061405429f, t, -1.453152027f);
     p = fmaf(p, t, 1.421413741f);
     p = fmaf(p, t, -0.284496736f);
     p = fmaf(p, t, 0.254829592f);
-    const float r = 1.0f - p * t * __expf(-ax * ax);
+    const float r = 1.0f - p * t * __builtin_amdgcn_exp2f(ax * ax * -1.44269504088896340736f);
     return copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
-// GELU and its derivative from ONE exponential: erf(x/sqrt2) = 1 - poly(t) e,  pdf(x) = e / sqrt(2 pi),  e = exp(-x^2/2)
-__device__ __forceinline__ void gelu_erf_both(float x, float& g, float& dg) {
-    const float a = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(fmaf(0.3275911f, a, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = __expf(-a * a);
-    const float erfv = copysignf(1.0f - p * t * e, x);
-    const float cdf = 0.5f * (1.0f + erfv);
+// Two elements at a time in packed fp32 (v_pk_fma_f32 / v_pk_mul_f32: one issue slot per PAIR), GELU and optionally its
+// derivative from ONE exponential: erf(x/sqrt2) = 1 - poly(t) e,  pdf(x) = e / sqrt(2 pi),  e = exp(-x^2/2).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <bool WITH_GRAD>
+__device__ __forceinline__ void gelu_erf_pair(f32x2 x, f32x2& g, f32x2& dg) {
+    const f32x2 a = __builtin_elementwise_abs(x) * 0.70710678118654752440f;
+    const f32x2 den = a * 0.3275911f + 1.0f;
+    const f32x2 t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    f32x2 p = t * 1.061405429f + (-1.453152027f);
+    p = p * t + 1.421413741f;
+    p = p * t + (-0.284496736f);
+    p = p * t + 0.254829592f;
+    const f32x2 na = a * a * (-1.44269504088896340736f);
+    const f32x2 e = {__builtin_amdgcn_exp2f(na.x), __builtin_amdgcn_exp2f(na.y)};
+    const f32x2 r = 1.0f - p * t * e;
+    const f32x2 erfv = {copysignf(r.x, x.x), copysignf(r.y, x.y)};
+    const f32x2 cdf = erfv * 0.5f + 0.5f;
     g = x * cdf;
-    dg = fmaf(x, 0.39894228040143267794f * e, cdf);
+    if constexpr (WITH_GRAD) dg = x * (e * 0.39894228040143267794f) + cdf;
 }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
     float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));
-    float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);
     return cdf + x * pdf;
 }

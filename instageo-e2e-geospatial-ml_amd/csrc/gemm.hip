@@ -848,15 +848,18 @@ struct EpStore {
         }
         size_t idx = (size_t)row * ldo + n;
         if (act == 1) {
+            // packed fp32 pairs (v_pk_fma_f32): the scalar form cost as many issue cycles as the K loop of a K = 768 tile
+            f32x2 g0, g1, d0, d1;
             if (pre_hi) {  // training: also save gelu'(pre-activation), the only thing backward needs of it
-                float dg[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) gelu_erf_both(v[i], v[i], dg[i]);
+                gelu_erf_pair<true>(f32x2{v[0], v[1]}, g0, d0);
+                gelu_erf_pair<true>(f32x2{v[2], v[3]}, g1, d1);
+                const float dg[4] = {d0.x, d0.y, d1.x, d1.y};
                 store4_split(pre_hi, pre_lo, idx, dg);
             } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
+                gelu_erf_pair<false>(f32x2{v[0], v[1]}, g0, d0);
+                gelu_erf_pair<false>(f32x2{v[2], v[3]}, g1, d1);
             }
+            v[0] = g0.x, v[1] = g0.y, v[2] = g1.x, v[3] = g1.y;
         }
         if (drop_thresh) {
             float mk[4];
