@@ -555,6 +555,247 @@ __global__ __launch_bounds__(NTHR2, (BKT == 32 ? 4 : 2)) void gemm2_kernel(AL al
 #undef GEMM2_ADVANCE_ISSUE
 }
 
+// ==============================================================================================
+// v5 (IG_GEMM=5): "ping-pong" 256x256 tile.  8 waves = 2 row groups (wr) x 4 column waves (wc); a wave owns 128 x 64
+// (acc[4][8], 128 accumulator registers, one workgroup per CU => 256 registers per wave).  BK = 32, LDS-DMA into a
+// 4-stage ring (4 x 32 KiB), two K-steps in flight.  Every K-step is two PHASES (the two 64-row halves of the wave's
+// rows); a phase = [fragment ds_reads + 2 DMA pieces] s_barrier [16 MFMAs under s_setprio 1] s_barrier.  The two row
+// groups run ONE barrier apart (group 1 executes an extra barrier first): between two barriers one group issues
+// memory instructions while the other group's waves -- one per SIMD -- own the matrix pipe, so the ~100-cycle DMA
+// issues and the fragment-read latency of one group are hidden under the MFMAs of the other (the structure of the
+// CDNA guide's 8-phase template; here with BK = 32 phases and the loaders / epilogues of v2).
+//   RAW: a wave retires its own pieces of step g+1 with vmcnt(4) in phase (g,1) before that phase's first barrier;
+//        step g+1 is first read two barriers later.      WAR: slot (g+2)%4 was last read during step g-2.
+// ==============================================================================================
+constexpr int NTHR5 = 512;
+constexpr int G5_OP = 256 * 32 * 2;     // one operand image: 16 KiB
+constexpr int G5_STAGE = 2 * G5_OP;     // A + B
+constexpr int G5_SMEM = 4 * G5_STAGE;   // 128 KiB
+
+template <class AL, class BL, class EP, bool A_TR, bool B_TR, int NSEG>
+__global__ __launch_bounds__(NTHR5, 2) void gemm5_kernel(AL al, BL bl, EP ep, int M, int N, int K, int tiles_n, int ntiles,
+                                                         int kchunk, const bf16_t* zero_page) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int nb = gridDim.x, xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int nbx = (nb >> 3) + (xcd < (nb & 7) ? 1 : 0);
+    const int qT = ntiles >> 3, rT = ntiles & 7;
+    const int tlo = xcd * qT + min(xcd, rT), tcnt = qT + (xcd < rT ? 1 : 0);
+    const int my_tiles = tcnt > jx ? (tcnt - jx + nbx - 1) / nbx : 0;
+    al.init(blockIdx.z);
+    bl.init(blockIdx.z);
+    ep.init(blockIdx.z);
+    const int nk_all = (K + 31) / 32;  // a K tail takes the generic per-piece decode for that step
+    const int kt0 = blockIdx.y * kchunk;
+    const int nk = min(kchunk, nk_all - kt0);
+    if (nk <= 0 || my_tiles <= 0) return;
+    const int total = nk * NSEG;
+    const int G_ = my_tiles * total;
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_char_ptr)smem;
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // 32 pieces of 1 KiB per stage: ids 0..15 -> A, 16..31 -> B; wave w owns ids i*8 + w (i = 0, 1: A; 2, 3: B)
+    const char* pp[4];
+    long pstep[4];
+    int kpos_i = 0, seg_i = 0, tile_i = tlo + jx;  // issue cursor: K-step inside the segment, segment, tile
+    int bm_i = tile_i / tiles_n, bn_i = tile_i - bm_i * tiles_n;
+    const bool has_tail = (K & 31) != 0 && kt0 + nk == nk_all;  // this workgroup's last K-step of a segment is partial
+    int kb[4];  // this lane's k offset inside a K-step for each piece (K-tail predicate)
+#define GEMM5_SETUP(SEG, KT)                                                                                \
+    {                                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
+            const int id = (i & 1) * 8 + wave;                                                              \
+            bool ok;                                                                                        \
+            const bf16_t* p;                                                                                \
+            if (i < 2) {                                                                                    \
+                if constexpr (!A_TR) {                                                                      \
+                    const int row = id * 16 + (lane >> 2), ch = kc_swz<32>(row, lane & 3);                  \
+                    p = al.ptr(SEG, bm_i * 256 + row, (KT)*4 + ch, ok);                                     \
+                    ok = bm_i * 256 + row < M;                                                              \
+                    kb[i] = ch * 8;                                                                         \
+                } else {                                                                                    \
+                    const int k = (id & 7) * 4 + (lane >> 4), cu = bm_i * 32 + (id >> 3) * 16 + ((lane & 15) ^ (tr_key(k) << 1)); \
+                    p = al.ptr(SEG, (KT)*32 + k, cu, ok);                                                   \
+                    ok = cu * 8 < M;                                                                        \
+                    kb[i] = k;                                                                              \
+                }                                                                                           \
+                pstep[i] = !ok ? 0L : A_TR ? 64L * al.kstride() : 64L;                                      \
+            } else {                                                                                        \
+                if constexpr (!B_TR) {                                                                      \
+                    const int row = id * 16 + (lane >> 2), ch = kc_swz<32>(row, lane & 3);                  \
+                    p = bl.ptr(SEG, bn_i * 256 + row, (KT)*4 + ch, ok);                                     \
+                    ok = bn_i * 256 + row < N;                                                              \
+                    kb[i] = ch * 8;                                                                         \
+                } else {                                                                                    \
+                    const int k = (id & 7) * 4 + (lane >> 4), cu = bn_i * 32 + (id >> 3) * 16 + ((lane & 15) ^ (tr_key(k) << 1)); \
+                    p = bl.ptr(SEG, (KT)*32 + k, cu, ok);                                                   \
+                    ok = cu * 8 < N;                                                                        \
+                    kb[i] = k;                                                                              \
+                }                                                                                           \
+                pstep[i] = !ok ? 0L : B_TR ? 64L * bl.kstride() : 64L;                                      \
+            }                                                                                               \
+            pp[i] = ok ? (const char*)p : (const char*)zero_page;                                           \
+        }                                                                                                   \
+    }
+    // pieces 2h, 2h+1 of the stage for the issue cursor's K-step go out in phase h.  The piece pointers are stepped for
+    // every K-step; only the (wave-uniform, rare) last partial step masks the lanes whose k index is beyond K.
+#define GEMM5_ISSUE_HALF(SLOT, H)                                                                           \
+    {                                                                                                       \
+        const unsigned sb_ = lds_base + (SLOT)*G5_STAGE + ((H) ? G5_OP : 0);                                \
+        if ((H) == 0 && kpos_i == 0) GEMM5_SETUP(seg_i, kt0);                                               \
+        const char *q0 = pp[2 * (H)], *q1 = pp[2 * (H) + 1];                                                \
+        if (has_tail && kpos_i == nk - 1) {                                                                 \
+            const int k0_ = (kt0 + kpos_i) * 32;                                                            \
+            q0 = (k0_ + kb[2 * (H)] < K) ? q0 : (const char*)zero_page;                                     \
+            q1 = (k0_ + kb[2 * (H) + 1] < K) ? q1 : (const char*)zero_page;                                 \
+        }                                                                                                   \
+        glds16(q0, sb_ + (0 * 8 + wave) * 1024);                                                            \
+        glds16(q1, sb_ + (1 * 8 + wave) * 1024);                                                            \
+        pp[2 * (H)] += pstep[2 * (H)], pp[2 * (H) + 1] += pstep[2 * (H) + 1];                               \
+        if ((H) == 1 && ++kpos_i == nk) {                                                                   \
+            kpos_i = 0;                                                                                     \
+            if (NSEG == 1 || ++seg_i == NSEG) {                                                             \
+                seg_i = 0;                                                                                  \
+                tile_i += nbx;                                                                              \
+                bm_i = tile_i / tiles_n, bn_i = tile_i - bm_i * tiles_n;                                    \
+            }                                                                                               \
+        }                                                                                                   \
+    }
+    // prologue: two stages in flight, the first one landed for everybody
+    GEMM5_ISSUE_HALF(0, 0);
+    GEMM5_ISSUE_HALF(0, 1);
+    if (G_ > 1) {
+        GEMM5_ISSUE_HALF(1, 0);
+        GEMM5_ISSUE_HALF(1, 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_barrier" ::: "memory");
+    if (wr == 1) asm volatile("s_barrier" ::: "memory");  // stagger: group 1 runs one barrier behind group 0
+
+    int it_c = 0, tile_c = tlo + jx;
+    bf16x8_t bf[4];
+    for (int g = 0; g < G_; ++g) {
+        const int slot = g & 3;
+        const char* ta = smem + slot * G5_STAGE;
+        const char* tb = ta + G5_OP;
+        const bool do_issue = g + 2 < G_;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            bf16x8_t af[4];
+            if (h == 0) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if constexpr (!B_TR) bf[t] = read_frag2<32, false>(tb, wc * 64 + t * 16, 0, lane);
+                    else bf[t] = read_frag2<32, true>(tb + (wc >> 1) * 8192, (wc & 1) * 64 + t * 16, 0, lane);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if constexpr (!A_TR) af[t] = read_frag2<32, false>(ta, wr * 128 + h * 64 + t * 16, 0, lane);
+                else af[t] = read_frag2<32, true>(ta + wr * 8192, h * 64 + t * 16, 0, lane);
+            }
+            if (do_issue) GEMM5_ISSUE_HALF((g + 2) & 3, h);
+            if (h == 1 && g + 1 < G_) {
+                if (do_issue) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_barrier" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+                    acc[tn][h * 4 + tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[tn], af[tm], acc[tn][h * 4 + tm], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            asm volatile("s_barrier" ::: "memory");
+        }
+        if (++it_c < total) continue;
+        it_c = 0;
+        if constexpr (EP::kStagedAtomic) break;  // one tile per workgroup: staged epilogue after the loop
+        const int bm = tile_c / tiles_n, bn = tile_c - bm * tiles_n;
+        tile_c += nbx;
+        f32x4 cs[4];
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) cs[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tm = 0; tm < 8; ++tm) {
+            const int m = bm * 256 + wr * 128 + tm * 16 + (lane & 15);
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) {
+                const int n = bn * 256 + wc * 64 + tn * 16 + 4 * (lane >> 4);
+                if (m < M && n < N) {
+                    if constexpr (EP::kColSum) cs[tn] += ep.store_ret(m, n, acc[tn][tm]);
+                    else ep.store(m, n, acc[tn][tm]);
+                }
+                acc[tn][tm] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            asm volatile("" ::: "memory");
+        }
+        if constexpr (EP::kColSum) {
+            if (ep.colsum) {
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) {
+                    const int n = bn * 256 + wc * 64 + tn * 16 + 4 * (lane >> 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float v = cs[tn][c];
+                        v += __shfl_xor(v, 1, 64);
+                        v += __shfl_xor(v, 2, 64);
+                        v += __shfl_xor(v, 4, 64);
+                        v += __shfl_xor(v, 8, 64);
+                        if ((lane & 15) == 0 && n + c < N) atomicAdd(ep.colsum + n + c, v);
+                    }
+                }
+            }
+        }
+    }
+    if (wr == 0) asm volatile("s_barrier" ::: "memory");  // balance group 1's extra barrier: the groups are aligned again
+    if constexpr (EP::kStagedAtomic) {
+        // weight gradient (one tile per workgroup, split-K over blockIdx.y): the fp32 tile goes through the idle ring in two
+        // 128-row passes (128 KiB each) and is added with row-contiguous 256-byte atomic wave-instructions
+        const int bm = tile_c / tiles_n, bn = tile_c - bm * tiles_n;
+        float* st = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            __syncthreads();
+            if (wr == pass) {
+#pragma unroll
+                for (int tm = 0; tm < 8; ++tm) {
+                    const int ml = tm * 16 + (lane & 15);
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn) {
+                        const int c4 = (wc * 64 + tn * 16 + 4 * (lane >> 4)) >> 2;
+                        *reinterpret_cast<f32x4*>(st + ml * 256 + ((c4 ^ (ml & 7)) << 2)) = acc[tn][tm];
+                    }
+                }
+            }
+            __syncthreads();
+            for (int rr = wave; rr < 128; rr += NTHR5 / 64) {
+                const int m = bm * 256 + pass * 128 + rr;
+                if (m >= M) break;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int nl = q * 64 + lane;
+                    const int n = bn * 256 + nl;
+                    if (n < N) ep.add(m, n, st[rr * 256 + ((((nl >> 2) ^ (rr & 7)) << 2) | (nl & 3))]);
+                }
+            }
+        }
+    }
+#undef GEMM5_ISSUE_HALF
+#undef GEMM5_SETUP
+}
+
 // Division by a launch-time constant as multiply-high + shift (dividends < 2^31): the pixel -> (b, y, x) and
 // k -> (tap, channel) decodes of the convolution gathers were integer divisions per 16-byte unit.
 struct FDiv {
@@ -970,15 +1211,19 @@ struct EpAtomic {
 };
 
 // ------------------------------------------------------------------------------------ launch
-inline int gemm_version() {
+// Engine choice for the plain-matrix GEMMs.  IG_GEMM=1|2|5 forces one engine (A/B runs); unset: v2 everywhere except
+// the shapes where the ping-pong v5 measured faster on the same box (tools/gemm_bench.py): dgrad without an
+// elementwise factor (+8-9 %) and the residual GEMM with a long reduction (fc2, K = 4D: +9 %).
+inline int gemm_env() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("IG_GEMM");
-        v = (e && e[0] == '1') ? 1 : 2;
+        v = (e && e[0] == '1') ? 1 : (e && e[0] == '2') ? 2 : (e && e[0] == '5') ? 5 : 0;
     }
     return v;
 }
-// engine for the head convolutions: v2 (256x128 LDS-DMA ring) when the output width fills 128-wide tiles, else v1
+inline int gemm_version() { return gemm_env() ? gemm_env() : 2; }
+inline int gemm_version_prefer5(bool prefer) { return gemm_env() ? gemm_env() : (prefer ? 5 : 2); }
 inline int conv_version(int n_out) {
     static int mode = -1;  // IG_CONV_V2: 0 = always v1 (default), 1 = v2 when n_out % 128 == 0, 2 = v2 when n_out >= 128
     if (mode < 0) {
@@ -1006,7 +1251,42 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, i
     if (M <= 0 || N <= 0 || K <= 0) return IG_OK;
     // v2 (256x128, LDS-DMA ring) wins on the encoder linears; the head convolutions (Cout 48..384, huge M) are
     // better served by the 128x128 register-staged tile at 2 workgroups/CU until a narrow-N tile exists
-    const int ver = force_ver ? force_ver : gemm_version();
+    int ver = force_ver ? force_ver : gemm_version();
+    if constexpr (AL::kLinearK && BL::kLinearK) {
+        if (ver == 5) {
+            const int tm5 = ig_cdiv(M, 256), tn5 = ig_cdiv(N, 256), ntiles = tm5 * tn5;
+            dim3 grid5(ntiles > 256 ? 256 : ntiles, 1, Z);
+            int kchunk5 = ig_cdiv(K, 32);
+            if constexpr (EP::kStagedAtomic) {  // one tile per workgroup, split-K over blockIdx.y, one workgroup per CU
+                grid5.x = ntiles;
+                const int nk32 = kchunk5;
+                int ks = 256 / (ntiles * Z);
+                if (ks > nk32 / 16) ks = nk32 / 16;
+                if (ks < 1) ks = 1;
+                kchunk5 = ig_cdiv(nk32, ks);
+                grid5.y = ig_cdiv(nk32, kchunk5);
+            }
+            const bf16_t* zp5 = zero_page();
+            if (!zp5) {
+                ig_set_error("%s: could not allocate the zero page", what);
+                return IG_ERR_HIP;
+            }
+#define IG_LAUNCH_V5(NSEG_)                                                                                           \
+    {                                                                                                                  \
+        auto kern = gemm5_kernel<AL, BL, EP, A_TR, B_TR, NSEG_>;                                                       \
+        static bool attr_done = false;                                                                                 \
+        if (!attr_done) {                                                                                              \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G5_SMEM);         \
+            attr_done = true;                                                                                          \
+        }                                                                                                              \
+        hipLaunchKernelGGL(kern, grid5, dim3(NTHR5), G5_SMEM, st, al, bl, ep, M, N, K, tn5, ntiles, kchunk5, zp5);     \
+    }
+            if (split) IG_LAUNCH_V5(3) else IG_LAUNCH_V5(1)
+#undef IG_LAUNCH_V5
+            return ig_check_launch(what);
+        }
+    }
+    if (ver == 5) ver = 2;  // shapes / epilogues v5 does not cover
     // v1 tile shape: the candidate with the fewest padded rows/columns, ties to the larger tile.  Weight gradients
     // (atomic epilogue) vary the tile height (M = Cout), everything else the width (N = Cout).  Code 1 = 48.
     int mt = 4, nt = 4;
@@ -1164,7 +1444,7 @@ int ig_linear_residual_fwd(const void* x_hi, const void* x_lo, const void* w_hi,
     EpResidual ep{out, resid, bias, (long)N};
     return launch_gemm<PlainLoader, PlainLoader, EpResidual, false, false>(
         plain_a(x_hi, x_lo, M, K, K), plain_b(w_hi, w_lo, N, K, K), ep, M, N, K, 1, x_lo != nullptr, (hipStream_t)stream,
-        "ig_linear_residual_fwd");
+        "ig_linear_residual_fwd", false, gemm_version_prefer5(K >= 2048 && x_lo == nullptr));
 }
 
 // dx[M][K] = dy[M][N] @ w[N][K]       mode 0: plain store, 1: * gelu'(pre[M][K])
@@ -1181,7 +1461,7 @@ int ig_linear_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, cons
     // C[m][k] = sum_n dy[m][n] * w[n][k]: reduce dim = N; B operand is TR (rows n, contiguous k)
     return launch_gemm<PlainLoader, PlainLoader, EpGradStore, false, true>(
         plain_a(dy_hi, dy_lo, M, N, N), plain_b(w_hi, w_lo, N, K, K), ep, M, K, N, 1, dy_lo != nullptr, (hipStream_t)stream,
-        "ig_linear_dgrad");
+        "ig_linear_dgrad", false, gemm_version_prefer5(mode == 0 && dx_colsum == nullptr && dy_lo == nullptr));
 }
 
 // dw[N][K] += dy[M][N]^T @ x[M][K]   (fp32 atomic accumulate)
