@@ -1473,7 +1473,9 @@ int ig_linear_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, cons
     EpAtomic ep{dw, (long)K, 0, 0};
     return launch_gemm<PlainLoader, PlainLoader, EpAtomic, true, true>(
         plain_a(dy_hi, dy_lo, M, N, N), plain_b(x_hi, x_lo, M, K, K), ep, N, K, M, 1, dy_lo != nullptr, (hipStream_t)stream,
-        "ig_linear_wgrad", true);
+        "ig_linear_wgrad", true,
+        // small outputs (proj: 768 x 768 = 18 v2 tiles): the 128 x 128 engine's 36 tiles split the reduction less deeply (+18 %)
+        gemm_env() ? gemm_env() : ((long)N * K <= (1L << 20) ? 1 : 2));
 }
 
 // Patch embedding (pritvhi.py:243-268,513-517): x[b][1+tp][:] = patches[b*TP+tp] @ w^T + bias + pos[1+tp]

@@ -64,6 +64,37 @@ def test_linear_fwd(split, M, N, K):
     close(y.float(), F.gelu(ref), tol_out(split), what="linear gelu (no save)")
 
 
+def test_linear_big_shapes_repeatable():
+    """Model-sized GEMMs (the shapes routed to the ping-pong v5 engine): repeated launches are bit-identical (race screen:
+    an LDS-DMA / barrier ordering bug shows up as rare differing tiles) and agree with an fp32 matmul of the bf16 inputs."""
+    M, D = 4300, 768
+    # dgrad without elementwise factor: dx[M, K] = dy[M, N] @ w[N, K]
+    for N, K in [(2304, 768), (768, 3072)]:
+        dy, dyr = bt(rnd(M, N, seed=11), False)
+        w, wr = bt(rnd(N, K, seed=12, scale=N**-0.5), False)
+        dx = BT.empty((M, K), False, DEV)
+        ops.linear_dgrad(dy, w, dx, M, N, K)
+        first = dx.hi.clone()
+        close(dx.float(), dyr @ wr, tol_out(False), what="big dgrad")
+        for _ in range(15):
+            dx.hi.zero_()
+            ops.linear_dgrad(dy, w, dx, M, N, K)
+            assert torch.equal(dx.hi, first), "dgrad differs between identical launches"
+    # residual GEMM with the long reduction (fc2): out = resid + x[M, 4D] @ w[D, 4D]^T + b
+    x, xr = bt(rnd(M, 4 * D, seed=13), False)
+    w, wr = bt(rnd(D, 4 * D, seed=14, scale=(4 * D) ** -0.5), False)
+    b = rnd(D, seed=15).to(DEV)
+    res = rnd(M, D, seed=16).to(DEV)
+    out = torch.empty_like(res)
+    ops.linear_residual_fwd(x, w, b, res, out, M, D, 4 * D)
+    first = out.clone()
+    close(out, res.double().cpu() + xr @ wr.t() + b.double().cpu(), 2e-5, what="big residual")
+    for _ in range(15):
+        out.zero_()
+        ops.linear_residual_fwd(x, w, b, res, out, M, D, 4 * D)
+        assert torch.equal(out, first), "residual GEMM differs between identical launches"
+
+
 @pytest.mark.parametrize("split", SPLITS)
 def test_linear_residual(split):
     M, N, K = 333, 256, 1024
@@ -212,6 +243,10 @@ def test_attention_fwd_bwd(split, N):
     delta = torch.empty(B * H * N, device=DEV)
     ops.attention_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H)
     close(dqkv.float(), gref, 1e-4 if split else 2e-2, what="attn bwd")
+    # fused qkv-bias gradient (column sums of dqkv), accumulating into an existing buffer
+    cs = torch.full((3 * H * 64,), 0.5, device=DEV)
+    ops.attention_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, colsum=cs)
+    close(cs - 0.5, gref.reshape(B * N, -1).sum(0), 1e-4 if split else 2e-2, what="attn bwd fused colsum")
 
 
 @pytest.mark.parametrize("split", SPLITS)
