@@ -66,11 +66,9 @@ int ig_linear_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, cons
 /* F.scaled_dot_product_attention of timm Attention: qkv [B][N][3][H][64] -> out [B][N][H*64], lse [B][H][N] */
 int ig_attention_fwd(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, float* lse, int B, int N, int H,
                      int head_dim, void* stream);
-/* backward: dqkv from dout; delta = scratch float[B*H*N]; dqkv_colsum (optional, fp32 [3*H*64]) += column sums of dqkv over
- * all rows = gradient of the qkv bias (saves a pass over dqkv) */
 int ig_attention_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi, const void* out_lo, const void* dout_hi,
-                     const void* dout_lo, const float* lse, float* delta, void* dqkv_hi, void* dqkv_lo, float* dqkv_colsum, int B,
-                     int N, int H, int head_dim, void* stream);
+                     const void* dout_lo, const float* lse, float* delta, void* dqkv_hi, void* dqkv_lo, int B, int N, int H,
+                     int head_dim, void* stream);
 /* gradient plumbing: column sums (bias grads), patch-embed grad prep (cls_token / conv bias grads) */
 int ig_colsum(const void* hi, const void* lo, float* out, long M, int C, void* stream);
 int ig_patch_grad_prep(const float* dx, void* hi, void* lo, float* dcls, float* dbias, int B, int ntok, int D, void* stream);

@@ -266,25 +266,6 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
     }
 }
 
-// Column sums of a wave-owned 16-row x 64 tile (lane (g, i) holds row i, columns dt*16 + 4g + r) accumulated over the
-// workgroup's waves in LDS and added to bias_grad[col0 + d] with one atomic per column and workgroup: the qkv bias
-// gradient = colsum(dqkv) without a separate pass over dqkv.  `valid` masks padded rows.  All waves must call.
-__device__ __forceinline__ void block_colsum64(const f32x4 (&t)[4], bool valid, float scale, float* sred, float* dst, int lane, int tid) {
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = valid ? t[dt][r] * scale : 0.f;
-            v += __shfl_xor(v, 1, 64);
-            v += __shfl_xor(v, 2, 64);
-            v += __shfl_xor(v, 4, 64);
-            v += __shfl_xor(v, 8, 64);
-            if ((lane & 15) == 0) atomicAdd(sred + dt * 16 + 4 * (lane >> 4) + r, v);
-        }
-    __syncthreads();
-    if (tid < 64) atomicAdd(dst + tid, sred[tid]);
-}
-
 // ------------------------------------------------------------------------------------------------------
 // backward, query-owner pass: dQ = scale * dS K   (streams K,V tiles; recomputes P^T from LSE)
 // ------------------------------------------------------------------------------------------------------
@@ -293,7 +274,7 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dq_kernel(const bf16_t* __restr
                                                            const bf16_t* __restrict__ do_hi, const bf16_t* __restrict__ do_lo,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            bf16_t* __restrict__ dqkv_hi, bf16_t* __restrict__ dqkv_lo, int N, int H,
-                                                           float scale, float* __restrict__ bias_grad) {
+                                                           float scale) {
     constexpr int NTL = SPLIT ? 2 : NTLP;
     // staging registers: one pass must cover the group with >= 13 waves (MAXT = 1024) or >= 7 waves (MAXT = 512)
     constexpr int NRS = ((SPLIT ? 4 : 2) * NTL * KT * 8 + (MAXT == 1024 ? 832 : 448) - 1) / (MAXT == 1024 ? 832 : 448);
@@ -386,13 +367,6 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dq_kernel(const bf16_t* __restr
             store4_split(dqkv_hi, dqkv_lo, (size_t)orow + dt * 16 + 4 * g, f);
         }
     }
-    if (bias_grad) {  // uniform
-        float* sred = reinterpret_cast<float*>(smem);
-        __syncthreads();  // the streamed tiles are dead
-        if (tid < 64) sred[tid] = 0.f;
-        __syncthreads();
-        block_colsum64(dq, q < N, scale, sred, bias_grad + h * HD, lane, tid);
-    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -403,7 +377,7 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dkv_kernel(const bf16_t* __rest
                                                             const bf16_t* __restrict__ do_hi, const bf16_t* __restrict__ do_lo,
                                                             const float* __restrict__ lse, const float* __restrict__ delta,
                                                             bf16_t* __restrict__ dqkv_hi, bf16_t* __restrict__ dqkv_lo, int N, int H,
-                                                            float scale, float* __restrict__ bias_grad) {
+                                                            float scale) {
     constexpr int NTL = SPLIT ? 2 : NTLP;
     // staging registers: one pass must cover the group with >= 13 waves (MAXT = 1024) or >= 7 waves (MAXT = 512)
     constexpr int NRS = ((SPLIT ? 4 : 2) * NTL * KT * 8 + (MAXT == 1024 ? 832 : 448) - 1) / (MAXT == 1024 ? 832 : 448);
@@ -503,14 +477,6 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dkv_kernel(const bf16_t* __rest
             store4_split(dqkv_hi, dqkv_lo, (size_t)orow + 2L * H * HD + dt * 16 + 4 * g, fv);
         }
     }
-    if (bias_grad) {  // uniform
-        float* sred = reinterpret_cast<float*>(smem);
-        __syncthreads();
-        for (int i = tid; i < 128; i += blockDim.x) sred[i] = 0.f;
-        __syncthreads();
-        block_colsum64(dk, key < N, scale, sred, bias_grad + (long)H * HD + h * HD, lane, tid);
-        block_colsum64(dv, key < N, 1.f, sred + 64, bias_grad + 2L * H * HD + h * HD, lane, tid);
-    }
 }
 
 // Workgroup geometry.  cfg 0: up to 16 waves per workgroup (one workgroup per (b, h) for N = 197), 4 tiles per group;
@@ -556,11 +522,10 @@ int ig_attention_fwd(const void* qkv_hi, const void* qkv_lo, void* out_hi, void*
     return ig_check_launch("ig_attention_fwd");
 }
 
-// dqkv[B][N][3][H][64] from dout, qkv, out, lse ; delta: device scratch float[B*H*N] ;
-// dqkv_colsum (optional, fp32 [3*H*64]) += column sums of dqkv over all B*N rows = gradient of the qkv bias
+// dqkv[B][N][3][H][64] from dout, qkv, out, lse ; delta: device scratch float[B*H*N]
 int ig_attention_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi, const void* out_lo, const void* dout_hi,
-                     const void* dout_lo, const float* lse, float* delta, void* dqkv_hi, void* dqkv_lo, float* dqkv_colsum, int B,
-                     int N, int H, int head_dim, void* stream) {
+                     const void* dout_lo, const float* lse, float* delta, void* dqkv_hi, void* dqkv_lo, int B, int N, int H,
+                     int head_dim, void* stream) {
     IG_REQUIRE(qkv_hi && out_hi && dout_hi && lse && delta && dqkv_hi, "ig_attention_bwd: null pointer");
     IG_REQUIRE(head_dim == HD, "ig_attention_bwd: head_dim must be 64 (got %d)", head_dim);
     bool split = qkv_lo != nullptr;
@@ -579,10 +544,10 @@ int ig_attention_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi,
     {                                                                                                                         \
         hipLaunchKernelGGL((attn_bwd_dq_kernel<SPLIT_, NTL_, MAXT_>), grid, block, 0, st, (const bf16_t*)qkv_hi,                  \
                            (const bf16_t*)qkv_lo, (const bf16_t*)dout_hi, (const bf16_t*)dout_lo, lse, delta, (bf16_t*)dqkv_hi,  \
-                           (bf16_t*)dqkv_lo, N, H, scale, dqkv_colsum);                                                       \
+                           (bf16_t*)dqkv_lo, N, H, scale);                                                                    \
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<SPLIT_, NTL_, MAXT_>), grid, block, 0, st, (const bf16_t*)qkv_hi,                 \
                            (const bf16_t*)qkv_lo, (const bf16_t*)dout_hi, (const bf16_t*)dout_lo, lse, delta, (bf16_t*)dqkv_hi,  \
-                           (bf16_t*)dqkv_lo, N, H, scale, dqkv_colsum);                                                       \
+                           (bf16_t*)dqkv_lo, N, H, scale);                                                                    \
     }
     const int cfg = attn_cfg();
     if (split) {

@@ -467,11 +467,10 @@ class SegEngine:
             # proj
             ops.linear_wgrad(dxb, ws["o"][i], self.Gd(b + "attn.proj.weight"), M, D, D)
             ops.linear_dgrad(dxb, self.W(b + "attn.proj.weight"), ws["dtmp"], M, D, D)
-            # the attention backward kernels also accumulate colsum(dqkv) = qkv bias gradient
-            ops.attention_bwd(ws["qkv"][i], ws["o"][i], ws["dtmp"], ws["lse"][i], ws["delta"], ws["dqkv"], B, N, H,
-                              colsum=self.Gd(b + "attn.qkv.bias"))
+            ops.attention_bwd(ws["qkv"][i], ws["o"][i], ws["dtmp"], ws["lse"][i], ws["delta"], ws["dqkv"], B, N, H)
             # qkv
             ops.linear_wgrad(ws["dqkv"], ws["a"][i], self.Gd(b + "attn.qkv.weight"), M, 3 * D, D)
+            ops.colsum(ws["dqkv"], self.Gd(b + "attn.qkv.bias"), M, 3 * D)
             ops.linear_dgrad(ws["dqkv"], self.W(b + "attn.qkv.weight"), ws["dtmp"], M, 3 * D, D)
             prev_bias = self.Gd(f"{e}blocks.{i - 1}.mlp.fc2.bias") if i > 0 else None
             ops.layernorm_bwd(ws["dtmp"], ws["x_in"][i], ws["mean1"][i], ws["rstd1"][i], self.P(b + "norm1.weight"), dx, True, dxb,

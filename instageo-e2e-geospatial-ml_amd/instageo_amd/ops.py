@@ -196,10 +196,9 @@ def attention_fwd(qkv: BT, out: BT, lse, B: int, N: int, H: int, hd: int = 64) -
     _call("ig_attention_fwd", 4.0 * B * H * N * N * hd, _p(qkv.hi), _p(qkv.lo), _p(out.hi), _p(out.lo), _p(lse), B, N, H, hd, _stream())
 
 
-def attention_bwd(qkv: BT, out: BT, dout: BT, lse, delta, dqkv: BT, B: int, N: int, H: int, hd: int = 64, colsum=None) -> None:
-    """``colsum`` (fp32 [3*H*hd]) additionally accumulates the column sums of dqkv (the qkv bias gradient)."""
+def attention_bwd(qkv: BT, out: BT, dout: BT, lse, delta, dqkv: BT, B: int, N: int, H: int, hd: int = 64) -> None:
     _call("ig_attention_bwd", 10.0 * B * H * N * N * hd, _p(qkv.hi), _p(qkv.lo), _p(out.hi), _p(out.lo), _p(dout.hi), _p(dout.lo), _p(lse), _p(delta),
-              _p(dqkv.hi), _p(dqkv.lo), _p(colsum), B, N, H, hd, _stream())
+              _p(dqkv.hi), _p(dqkv.lo), B, N, H, hd, _stream())
 
 
 def colsum(x: BT, out, M: int, C: int) -> None:
