@@ -275,6 +275,7 @@ class SegEngine:
         ws["o"] = [BT.empty((M, D), sp, dev) for _ in range(nsave)]
         ws["c"] = [BT.empty((M, D), sp, dev) for _ in range(nsave)]
         ws["hact"] = [BT.empty((M, 4 * D), sp, dev) for _ in range(nsave)]
+        # "hpre" holds gelu'(fc1 pre-activation), written by the fc1 epilogue and consumed by the fc2 dgrad epilogue
         ws["hpre"] = [BT.empty((M, 4 * D), sp, dev) for _ in range(nsave)] if training else None
         ws["lse"] = [f32(B, cfg.num_heads, N) for _ in range(nsave)] if training else None
         ws["mean1"] = [f32(M) for _ in range(nsave)]
