@@ -35,6 +35,17 @@ int ig_device_info(int device, char* name, int name_len, int* cu_count, int* lds
 /* src (B, T*C, H, W) band = t*C+c, src_dtype 0=int16 1=float32 -> dst (B, C, T, H, W) f32 = (src*mult-mean_c)/std_c */
 int ig_normalize_chips(const void* src, int src_dtype, const float* mean, const float* stdv, double mult, int mult_enabled,
                        float* dst, int B, int T, int C, int H, int W, void* stream);
+/* On-device input pipeline.
+ * RandomCrop(im) + hflip/vflip + per-band normalise in one pass (dataloader.py:58-141, 495-585): src (B, T*C, Hs, Ws)
+ * int16|f32, params[b] = {top, left, hflip, vflip} (host-drawn, so the reference's RNG stream can be replayed);
+ * labels (optional, f32 (B, Hs, Ws) -> (B, im, im)) get the same crop and flips. */
+int ig_crop_flip_normalize(const void* src, int src_dtype, const float* mean, const float* stdv, double mult, int mult_enabled,
+                           const int* params, float* dst, const float* labels_in, float* labels_out, int B, int T, int C, int Hs,
+                           int Ws, int im, void* stream);
+/* mode=stats reduction (pipeline_utils.py:207-254): sums[c] += mean_bc, sums[C+c] += biased var_bc over (T,H,W) for every
+ * chip b of x (B, C, T, H, W) f32; counts[v - lo] += 1 per label value (counts[nbins] = everything else) */
+int ig_chip_stats(const float* x, double* sums, int B, int C, long n_per_channel, void* stream);
+int ig_label_hist(const float* labels, unsigned long long* counts, long n, int lo, int nbins, void* stream);
 
 /* ---- encoder (instageo/model/pritvhi.py) ------------------------------------------------------------- */
 /* Conv3d(k=s=(1,p,p)) im2col: img (B,C,T,H,W) f32 -> patches [B*T*gh*gw][C*p*p], token order (t,row,col)  :243-268 */

@@ -46,6 +46,130 @@ __global__ void normalize_kernel(const SRC* __restrict__ src, float* __restrict_
 }
 
 // ----------------------------------------------------------------------------------------------
+// K0 with the training-time data movement fused in: RandomCrop(im) + hflip/vflip + Normalize in one pass
+// (dataloader.py:58-77 crop_image_and_label, :80-141 RandomHorizontal/VerticalFlip, :495-524 normalise).
+//   src (B, T*C, Hs, Ws) int16|f32 ; params[b] = {top, left, hflip, vflip}
+//   dst[b][c][t][y][x] = (src[b][t*C+c][top + y'][left + x'] * mult - mean_c) / std_c,
+//   y' = vflip ? im-1-y : y, x' = hflip ? im-1-x : x   (crop first, then the flips, as the reference order)
+//   labels (optional, f32 (B, Hs, Ws)) get the same crop + flips -> (B, im, im)
+// One thread = 4 consecutive OUTPUT pixels of a row (16-byte store; reads are contiguous, reversed when hflip).
+// ----------------------------------------------------------------------------------------------
+template <typename SRC>
+__global__ void crop_flip_normalize_kernel(const SRC* __restrict__ src, float* __restrict__ dst, const float* __restrict__ mean,
+                                           const float* __restrict__ stdv, double mult, int use_mult, const int* __restrict__ params,
+                                           const float* __restrict__ lab_in, float* __restrict__ lab_out, int T, int C, int Hs,
+                                           int Ws, int im, long total4, long img4) {
+    const int q = im / 4;  // quads per output row
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const bool is_lab = i >= img4;
+        long r = is_lab ? i - img4 : i;
+        const int xq = (int)(r % q);
+        r /= q;
+        const int y = (int)(r % im);
+        r /= im;
+        int t = 0, c = 0;
+        long b;
+        if (!is_lab) {
+            t = (int)(r % T);
+            r /= T;
+            c = (int)(r % C);
+            b = r / C;
+        } else {
+            b = r;
+        }
+        const int top = params[b * 4 + 0], left = params[b * 4 + 1], hf = params[b * 4 + 2], vf = params[b * 4 + 3];
+        const int sy = top + (vf ? im - 1 - y : y);
+        float v[4];
+        if (!is_lab) {
+            const SRC* row = src + (((long)b * T + t) * C + c) * ((long)Hs * Ws) + (long)sy * Ws + left;
+            const float m = mean[c], sd = stdv[c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int x = xq * 4 + j;
+                const SRC sv = row[hf ? im - 1 - x : x];
+                const float xv = use_mult ? (float)((double)sv * mult) : (float)sv;
+                v[j] = (xv - m) / sd;
+            }
+            *reinterpret_cast<float4*>(dst + ((((long)b * C + c) * T + t) * im + y) * im + xq * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            const float* row = lab_in + (long)b * Hs * Ws + (long)sy * Ws + left;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int x = xq * 4 + j;
+                v[j] = row[hf ? im - 1 - x : x];
+            }
+            *reinterpret_cast<float4*>(lab_out + ((long)b * im + y) * im + xq * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// mode=stats (pipeline_utils.py:207-254): for every chip b and channel c the mean and the BIASED variance over
+// (T, H, W); sums[c] += mean_bc, sums[C+c] += var_bc (the reference averages per-chip statistics over the chips:
+// std = sqrt(mean_b var_bc), not the pooled standard deviation).  One workgroup per (b, c), two passes over the
+// chip's T*H*W values (the second one hits L2), fp64 accumulation.
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void chip_stats_kernel(const float* __restrict__ x, double* __restrict__ sums, int C, long n) {
+    __shared__ double red[TPB / 64];
+    __shared__ double s_mean;
+    const long bc = blockIdx.x;
+    const int c = (int)(bc % C);
+    const float* p = x + bc * n;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double acc = 0.0;
+    for (long i = threadIdx.x * 4L; i < n; i += TPB * 4L) {
+        const float4 v = *reinterpret_cast<const float4*>(p + i);
+        acc += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < TPB / 64; ++w) t += red[w];
+        s_mean = t / (double)n;
+    }
+    __syncthreads();
+    const double mu = s_mean;
+    acc = 0.0;
+    for (long i = threadIdx.x * 4L; i < n; i += TPB * 4L) {
+        const float4 v = *reinterpret_cast<const float4*>(p + i);
+        const double d0 = v.x - mu, d1 = v.y - mu, d2 = v.z - mu, d3 = v.w - mu;
+        acc += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    __syncthreads();
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < TPB / 64; ++w) t += red[w];
+        atomicAdd(sums + c, mu);
+        atomicAdd(sums + C + c, t / (double)n);
+    }
+}
+
+// class counts of a float label map (np.unique(label, return_counts=True) of pipeline_utils.py:240-243):
+// counts[v - lo] += 1 for integer-valued labels lo <= v < lo + nbins; anything else goes to counts[nbins]
+__global__ __launch_bounds__(TPB) void label_hist_kernel(const float* __restrict__ lab, unsigned long long* __restrict__ counts,
+                                                         long n, int lo, int nbins) {
+    extern __shared__ unsigned int h[];  // nbins + 1
+    for (int i = threadIdx.x; i <= nbins; i += TPB) h[i] = 0u;
+    __syncthreads();
+    for (long i = blockIdx.x * (long)TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB) {
+        const float v = lab[i];
+        const int k = (int)v - lo;
+        const bool ok = (float)(int)v == v && k >= 0 && k < nbins;
+        atomicAdd(h + (ok ? k : nbins), 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= nbins; i += TPB)
+        if (h[i]) atomicAdd(counts + i, (unsigned long long)h[i]);
+}
+
+// ----------------------------------------------------------------------------------------------
 // K1 gather: (B,C,T,H,W) f32 -> patches [B*T*gh*gw][C*p*p] bf16/split, k = c*p*p + iy*p + ix,
 // token order (t, row, col)  (pritvhi.py:266-268 flatten(2).transpose(1,2) of Conv3d k=s=(1,p,p))
 // ----------------------------------------------------------------------------------------------
@@ -798,6 +922,49 @@ int ig_normalize_chips(const void* src, int src_dtype, const float* mean, const 
         return IG_ERR_UNSUPPORTED;
     }
     return ig_check_launch("ig_normalize_chips");
+}
+
+int ig_crop_flip_normalize(const void* src, int src_dtype, const float* mean, const float* stdv, double mult, int mult_enabled,
+                           const int* params, float* dst, const float* labels_in, float* labels_out, int B, int T, int C, int Hs,
+                           int Ws, int im, void* stream) {
+    IG_REQUIRE(src && mean && stdv && params && dst, "ig_crop_flip_normalize: null pointer");
+    IG_REQUIRE((labels_in == nullptr) == (labels_out == nullptr), "ig_crop_flip_normalize: labels_in and labels_out go together");
+    IG_REQUIRE(B >= 0 && T > 0 && C > 0 && im > 0 && im <= Hs && im <= Ws, "ig_crop_flip_normalize: need 0 < im <= Hs, Ws");
+    IG_REQUIRE(im % 4 == 0, "ig_crop_flip_normalize: im must be a multiple of 4 (got %d)", im);
+    const long img4 = (long)B * T * C * im * (im / 4);
+    const long total4 = img4 + (labels_in ? (long)B * im * (im / 4) : 0L);
+    if (total4 == 0) return IG_OK;
+    const int grid = grid_for(total4, TPB, 8192);
+    if (src_dtype == 0)
+        hipLaunchKernelGGL(crop_flip_normalize_kernel<int16_t>, dim3(grid), dim3(TPB), 0, ST(stream), (const int16_t*)src, dst, mean,
+                           stdv, mult, mult_enabled, params, labels_in, labels_out, T, C, Hs, Ws, im, total4, img4);
+    else if (src_dtype == 1)
+        hipLaunchKernelGGL(crop_flip_normalize_kernel<float>, dim3(grid), dim3(TPB), 0, ST(stream), (const float*)src, dst, mean, stdv,
+                           mult, mult_enabled, params, labels_in, labels_out, T, C, Hs, Ws, im, total4, img4);
+    else {
+        ig_set_error("ig_crop_flip_normalize: unsupported src_dtype %d", src_dtype);
+        return IG_ERR_UNSUPPORTED;
+    }
+    return ig_check_launch("ig_crop_flip_normalize");
+}
+
+int ig_chip_stats(const float* x, double* sums, int B, int C, long n_per_channel, void* stream) {
+    IG_REQUIRE(x && sums, "ig_chip_stats: null pointer");
+    IG_REQUIRE(C > 0 && n_per_channel > 0 && n_per_channel % 4 == 0, "ig_chip_stats: T*H*W must be a positive multiple of 4");
+    if (B == 0) return IG_OK;
+    hipLaunchKernelGGL(chip_stats_kernel, dim3((unsigned)((long)B * C)), dim3(TPB), 0, ST(stream), x, sums, C, n_per_channel);
+    return ig_check_launch("ig_chip_stats");
+}
+
+int ig_label_hist(const float* labels, unsigned long long* counts, long n, int lo, int nbins, void* stream) {
+    IG_REQUIRE(labels && counts, "ig_label_hist: null pointer");
+    IG_REQUIRE(nbins > 0 && nbins <= 4096, "ig_label_hist: 1 <= nbins <= 4096");
+    if (n == 0) return IG_OK;
+    long nb = (n + TPB - 1) / TPB;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(label_hist_kernel, dim3((unsigned)nb), dim3(TPB), (nbins + 1) * sizeof(unsigned int), ST(stream), labels, counts,
+                       n, lo, nbins);
+    return ig_check_launch("ig_label_hist");
 }
 
 int ig_patchify(const float* img, void* out_hi, void* out_lo, int B, int C, int T, int H, int W, int p, void* stream) {

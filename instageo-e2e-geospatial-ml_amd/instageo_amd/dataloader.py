@@ -5,8 +5,9 @@ dataloader.py:495-524), random crop / flips hand-off (``process_and_augment`` :5
 window tiling (``process_test`` + ``crop_array`` :588-669) and the dataset item contract
 (``InstaGeoDataset.__getitem__`` :875-902: ``(x:(C,T,H,W) f32, y:(H,W))``).  GeoTIFF/CSV I/O (rasterio) and
 the photometric augmentations are outside the path; chips come from arrays or are synthetic.
-The arithmetic (constant multiplier, mean/std normalisation) runs in ``ig_normalize_chips``; crops, flips
-and window extraction are pure data movement on the device.
+The arithmetic (constant multiplier, mean/std normalisation) runs in ``ig_normalize_chips``; the training-time random
+crop + flips + normalisation of a batch is ONE kernel (``ig_crop_flip_normalize``; the random draws stay on the host so
+the reference's RNG stream can be replayed); window extraction is pure data movement on the device.
 """
 from __future__ import annotations
 
@@ -88,35 +89,55 @@ def process_test(x, y, mean: Sequence[float], std: Sequence[float], temporal_siz
     return imgs, labels
 
 
-def process_and_augment(x, y, mean, std, temporal_size: int = 1, im_size: int = 224, crop: bool = True,
-                        augmentations: Optional[Dict] = None, constant_multiplier: Optional[float] = None,
-                        generator: Optional[torch.Generator] = None, device: str = "cuda"):
-    """Random crop to ``im_size`` + optional h/v flips + normalise (dataloader.py:527-585).
+def draw_augment_params(batch: int, src_hw: Tuple[int, int], im_size: int, crop: bool = True, augmentations: Optional[Dict] = None,
+                        generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    """Host-side random draws of ``process_and_augment`` for a batch: (B, 4) int32 rows (top, left, hflip, vflip).
 
-    Only the ``hflip``/``vflip`` augmentations (the ones enabled in ``sen1floods11.yaml:44-49``) are data
-    movement; rotate/brightness/blur/noise are photometric/geometric resampling and out of scope here.
-    """
-    xt = _as_device_chip(x, device)
-    yt = None if y is None else torch.as_tensor(np.asarray(y) if not torch.is_tensor(y) else y).to(device)
-    H, W = xt.shape[-2:]
+    Crop origin as ``RandomCrop.get_params`` (uniform in [0, H - im], [0, W - im]; dataloader.py:73), each enabled flip
+    with its probability ``p`` (dataloader.py:99, 131).  Only ``hflip``/``vflip`` (the augmentations enabled in
+    ``sen1floods11.yaml:44-49``) are data movement; rotate/brightness/blur/noise resample or rescale pixels and are
+    outside the hot path."""
+    H, W = src_hw
+    p = torch.zeros((batch, 4), dtype=torch.int32)
     if crop and (H > im_size or W > im_size):
-        top = int(torch.randint(0, H - im_size + 1, (1,), generator=generator))
-        left = int(torch.randint(0, W - im_size + 1, (1,), generator=generator))
-        xt = xt[:, top : top + im_size, left : left + im_size]
-        if yt is not None:
-            yt = yt[top : top + im_size, left : left + im_size]
+        p[:, 0] = torch.randint(0, H - im_size + 1, (batch,), generator=generator, dtype=torch.int32)
+        p[:, 1] = torch.randint(0, W - im_size + 1, (batch,), generator=generator, dtype=torch.int32)
     for name, cfg in (augmentations or {}).items():
         if not cfg.get("use", False):
             continue
         if name not in ("hflip", "vflip"):
             raise NotImplementedError(f"augmentation {name!r} is outside the hot-path scope (SURVEY.md 8f item 1)")
-        if float(torch.rand((), generator=generator)) < cfg.get("p", 0.5):
-            dim = -1 if name == "hflip" else -2
-            xt = xt.flip(dim)
-            if yt is not None:
-                yt = yt.flip(dim)
-    return normalize_and_convert_to_tensor(xt.contiguous(), None if yt is None else yt.contiguous(), mean, std, temporal_size,
-                                           constant_multiplier, device)
+        p[:, 2 if name == "hflip" else 3] = (torch.rand(batch, generator=generator) < cfg.get("p", 0.5)).to(torch.int32)
+    return p
+
+
+def process_and_augment_batch(x: torch.Tensor, y: Optional[torch.Tensor], mean, std, temporal_size: int = 1, im_size: int = 224,
+                              crop: bool = True, augmentations: Optional[Dict] = None, constant_multiplier: Optional[float] = None,
+                              generator: Optional[torch.Generator] = None, params: Optional[torch.Tensor] = None):
+    """Batched ``process_and_augment`` on the device: x (B, T*C, Hs, Ws) int16|f32, y (B, Hs, Ws) or None ->
+    ((B, C, T, im, im) f32 normalised, (B, im, im) f32).  One fused kernel (``ig_crop_flip_normalize``)."""
+    B, _, Hs, Ws = x.shape
+    size = im_size if crop else Hs
+    if not crop:
+        assert Hs == Ws, "crop=False expects square chips"
+    if params is None:
+        params = draw_augment_params(B, (Hs, Ws), size, crop, augmentations, generator)
+    m = torch.as_tensor(mean, dtype=torch.float32, device=x.device)
+    s = torch.as_tensor(std, dtype=torch.float32, device=x.device)
+    lab = None if y is None else y.to(device=x.device, dtype=torch.float32).contiguous()
+    return ops.crop_flip_normalize(x.contiguous(), params.to(x.device), m, s, temporal_size, size, constant_multiplier, lab)
+
+
+def process_and_augment(x, y, mean, std, temporal_size: int = 1, im_size: int = 224, crop: bool = True,
+                        augmentations: Optional[Dict] = None, constant_multiplier: Optional[float] = None,
+                        generator: Optional[torch.Generator] = None, device: str = "cuda"):
+    """Random crop to ``im_size`` + optional h/v flips + normalise (dataloader.py:527-585), single chip."""
+    xt = _as_device_chip(x, device).unsqueeze(0)
+    yt = None if y is None else torch.as_tensor(np.asarray(y) if not torch.is_tensor(y) else y).to(device).reshape(1, *xt.shape[-2:])
+    if not crop or (xt.shape[-2] <= im_size and xt.shape[-1] <= im_size):
+        im_size, crop = xt.shape[-1], True  # nothing to crop: the kernel copies the whole chip (flips still apply)
+    out, lab = process_and_augment_batch(xt, yt, mean, std, temporal_size, im_size, crop, augmentations, constant_multiplier, generator)
+    return out[0], (None if lab is None else lab[0])
 
 
 class SyntheticChipDataset(torch.utils.data.Dataset):

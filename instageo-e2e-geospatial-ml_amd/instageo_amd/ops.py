@@ -141,6 +141,44 @@ def normalize_chips(src: torch.Tensor, mean: torch.Tensor, std: torch.Tensor, te
     return out
 
 
+def crop_flip_normalize(src: torch.Tensor, params: torch.Tensor, mean: torch.Tensor, std: torch.Tensor, temporal: int, im: int,
+                        constant_multiplier: Optional[float] = None, labels: Optional[torch.Tensor] = None,
+                        out: Optional[torch.Tensor] = None):
+    """(B, T*C, Hs, Ws) int16|f32 -> (B, C, T, im, im) f32: per-chip crop at params[b] = (top, left) + optional
+    hflip/vflip (params[b, 2:4]) + normalisation in one kernel; ``labels`` (B, Hs, Ws) f32 follow (dataloader.py:58-141, 527-585)."""
+    B, TC, Hs, Ws = src.shape
+    C = TC // temporal
+    assert C * temporal == TC and mean.numel() == C and std.numel() == C
+    assert params.dtype == torch.int32 and params.shape == (B, 4)
+    dt = {torch.int16: 0, torch.float32: 1}[src.dtype]
+    if out is None:
+        out = torch.empty((B, C, temporal, im, im), dtype=torch.float32, device=src.device)
+    lab_out = None
+    if labels is not None:
+        labels = _f32(labels)
+        assert labels.shape == (B, Hs, Ws)
+        lab_out = torch.empty((B, im, im), dtype=torch.float32, device=src.device)
+    mult = 1.0 if constant_multiplier is None else float(constant_multiplier)
+    work = float(B) * TC * im * im * (src.element_size() + 4) + (float(B) * im * im * 8 if labels is not None else 0.0)
+    _call("ig_crop_flip_normalize", work, _p(src), dt, _p(_f32(mean)), _p(_f32(std)), mult, int(constant_multiplier is not None), _p(params),
+          _p(out), _p(labels), _p(lab_out), B, temporal, C, Hs, Ws, im, _stream())
+    return out, lab_out
+
+
+def chip_stats(x: torch.Tensor, sums: torch.Tensor) -> None:
+    """x (B, C, T, H, W) f32; sums (2C,) f64: sums[c] += per-chip mean, sums[C+c] += per-chip biased variance (mode=stats)."""
+    B, C = x.shape[0], x.shape[1]
+    n = x.numel() // max(B * C, 1)
+    assert sums.dtype == torch.float64 and sums.numel() == 2 * C
+    _call("ig_chip_stats", float(x.numel()) * 8, _p(_f32(x)), _p(sums), B, C, n, _stream())
+
+
+def label_hist(labels: torch.Tensor, counts: torch.Tensor, lo: int = -1) -> None:
+    """counts (nbins + 1,) int64: counts[v - lo] += #pixels with integer label v; counts[-1] collects everything else."""
+    assert counts.dtype == torch.int64
+    _call("ig_label_hist", float(labels.numel()) * 4, _p(_f32(labels)), _p(counts), labels.numel(), lo, counts.numel() - 1, _stream())
+
+
 def patchify(img: torch.Tensor, p: int, out: BT) -> None:
     B, C, T, H, W = img.shape
     _lib.call("ig_patchify", _p(_f32(img)), _p(out.hi), _p(out.lo), B, C, T, H, W, p, _stream())

@@ -28,6 +28,7 @@ from .dataloader import (ArrayChipDataset, SyntheticChipDataset, eval_collate_fn
                          process_and_augment, process_test)
 from .factory import create_model
 from .infer_utils import chip_inference
+from .pipeline_utils import compute_stats
 
 SEED = 1042  # pl.seed_everything(1042) in the reference (run.py:50)
 
@@ -146,7 +147,17 @@ def main(argv: Optional[List[str]] = None) -> int:
         yaml.safe_dump(cfg, open(os.path.join(out_dir, ".hydra", "config.yaml"), "w"), sort_keys=False)
 
     if cfg["mode"] == "stats":
-        raise NotImplementedError("mode=stats (dataset mean/std reduction) is a 'next' item (SURVEY.md 8f item 1)")
+        # run.py:89-111: the train set with mean 0 / std 1 and no augmentation, reduced to per-band mean/std + class weights
+        check_required_flags(["train_filepath"], cfg)
+        scfg = {**cfg, "dataloader": {**cfg["dataloader"], "mean": [0.0] * len(cfg["dataloader"]["mean"]),
+                                      "std": [1.0] * len(cfg["dataloader"]["std"])}}  # fmt: skip
+        ds = create_dataset(cfg["train_filepath"], scfg, "train", dev)
+        bs = cfg["train"]["batch_size"]
+        loader = (_stack(ds, ids) for ids in _batches(ds, bs, False, 0, 0, 1))
+        mean, std, class_weights = compute_stats(loader, is_reg_task=bool(cfg.get("is_reg_task", False)), device=dev)
+        if rank == 0:
+            print(json.dumps({"mean": mean, "std": std, "class_weights": class_weights}))
+        return 0
     model = create_model(cfg, precision=args.precision, device=dev)
     if cfg["mode"] == "train":
         check_required_flags(["train_filepath", "valid_filepath"], cfg)

@@ -67,3 +67,19 @@ def sub(x: torch.Tensor, n: int = 4096) -> np.ndarray:
     f = x.detach().reshape(-1)
     step = max(1, f.numel() // n)
     return f[::step][:n].cpu().numpy().copy()
+
+
+def make_stats_batches(case: str):
+    """Seeded (data (B,C,T,H,W) f32 un-normalised reflectances, label (B,H,W) f32 with ignore value -1) batches for the
+    mode=stats fixtures: ``t1`` = two batches of 3 single-date chips with 3 classes, ``t3`` = three batches of 2
+    three-date chips with 5 classes.  Per-band offsets/scales differ so that a band mix-up shows."""
+    T, nb, B, ncls = {"t1": (1, 2, 3, 3), "t3": (3, 3, 2, 5)}[case]
+    g = torch.Generator().manual_seed(77 + T)
+    out = []
+    for _ in range(nb):
+        scale = torch.linspace(0.02, 0.12, 6).view(1, 6, 1, 1, 1)
+        shift = torch.linspace(0.05, 0.30, 6).view(1, 6, 1, 1, 1)
+        data = torch.rand(B, 6, T, 32, 32, generator=g) * scale + shift
+        label = torch.randint(-1, ncls, (B, 32, 32), generator=g).float()
+        out.append((data, label))
+    return out

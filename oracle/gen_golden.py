@@ -100,6 +100,7 @@ def install_shims() -> None:
     pl.Trainer = object
     cb = types.ModuleType("pytorch_lightning.callbacks")
     cb.Callback = object
+    cb.ModelCheckpoint = object
     pl.callbacks = cb
     sys.modules.setdefault("pytorch_lightning", pl)
     sys.modules.setdefault("pytorch_lightning.callbacks", cb)
@@ -246,6 +247,31 @@ def main() -> None:
         wins[f"S{S}"] = np.array(o, dtype=np.int64)
     np.savez_compressed(os.path.join(out_dir, "windows.npz"), **wins)
     print("metrics + windows fixtures written")
+
+    # 5. mode=stats (pipeline_utils.py:207-254) from the reference's own compute_stats ---------------
+    for name in ["hydra", "omegaconf", "rasterio", "rasterio.crs", "xarray", "absl", "absl.logging", "rioxarray"]:
+        sys.modules.setdefault(name, MagicMock())
+    nl = types.ModuleType("instageo.model.neptune_logger")  # only used in type annotations of pipeline_utils
+    nl.AIchorNeptuneLogger = type("AIchorNeptuneLogger", (), {})
+    nl.set_neptune_api_token = lambda *a, **k: None
+    sys.modules["instageo.model.neptune_logger"] = nl
+    tv, tvt, tvf = types.ModuleType("torchvision"), types.ModuleType("torchvision.transforms"), types.ModuleType("torchvision.transforms.functional")
+    tv.transforms, tvt.functional = tvt, tvf
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt, "torchvision.transforms.functional": tvf})
+    from instageo.model import pipeline_utils as ref_pu  # noqa
+
+    from oracle.cases import make_stats_batches  # noqa
+
+    st = {}
+    for case in ("t1", "t3"):
+        batches = make_stats_batches(case)
+        mean, std, cw = ref_pu.compute_stats(batches)
+        om, os_, ow = O.compute_stats(batches)
+        assert np.allclose(mean, om, rtol=2e-6, atol=2e-6) and np.allclose(std, os_, rtol=2e-6, atol=2e-6), "stats oracle mismatch"
+        assert np.allclose(np.array(cw, dtype=np.float64), np.array(ow), rtol=1e-12), "class-weight oracle mismatch"
+        st[f"{case}_mean"], st[f"{case}_std"], st[f"{case}_class_weights"] = np.array(mean), np.array(std), np.array(cw, dtype=np.float64)
+    np.savez_compressed(os.path.join(out_dir, "stats.npz"), **st)
+    print("stats fixtures written (reference compute_stats == oracle)")
 
 
 if __name__ == "__main__":

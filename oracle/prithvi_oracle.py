@@ -427,6 +427,62 @@ def normalize_chip(chip: np.ndarray, mean: List[float], std: List[float], tempor
     return x.permute(1, 0, 2, 3).contiguous().numpy()
 
 
+def crop_flip_chip(chip: np.ndarray, label: Optional[np.ndarray], top: int, left: int, hflip: bool, vflip: bool,
+                   im_size: int) -> Tuple[np.ndarray, Optional[np.ndarray]]:
+    """dataloader.py:58-77 (crop at (i=top, j=left) to im_size) followed by :80-141 (hflip = reverse the last axis,
+    vflip = reverse the row axis), applied to every band and to the label alike.  The random draws themselves
+    (RandomCrop.get_params, random.random() < p) stay on the host; this is the data movement they select."""
+    x = np.asarray(chip)[:, top : top + im_size, left : left + im_size]
+    y = None if label is None else np.asarray(label)[top : top + im_size, left : left + im_size]
+    if hflip:
+        x = x[:, :, ::-1]
+        y = None if y is None else y[:, ::-1]
+    if vflip:
+        x = x[:, ::-1, :]
+        y = None if y is None else y[::-1, :]
+    return np.ascontiguousarray(x), (None if y is None else np.ascontiguousarray(y))
+
+
+def compute_class_weights(counts: Dict[int, int]) -> List[float]:
+    """pipeline_utils.py:183-203: w_c = total / (number of classes present * count_c), list indexed by class id."""
+    total = sum(counts.values())
+    ncls = len(counts)
+    out = [0.0] * (int(max(counts.keys())) + 1)
+    for cls, cnt in counts.items():
+        out[int(cls)] = total / (ncls * cnt)
+    return out
+
+
+def compute_stats(batches, is_reg_task: bool = False):
+    """pipeline_utils.py:207-254 (mode=stats).  ``batches`` yields (data (B,C,T,H,W), label (B,H,W)).
+
+    mean_c = (1/N) sum_b mean_{t,h,w} x ; std_c = sqrt((1/N) sum_b biased-var_{t,h,w} x) -- the average of the per-chip
+    variances, not the pooled variance; class weights from the label counts with the ignore value -1 removed.
+    Accumulated in float64 here (the reference accumulates float32 tensors)."""
+    mean = 0.0
+    var = 0.0
+    n = 0
+    counts: Dict[int, int] = {}
+    for data, label in batches:
+        d = torch.as_tensor(np.asarray(data)).double()
+        b = d.shape[0]
+        d = d.reshape(b, d.shape[1], -1)
+        n += b
+        mean = mean + d.mean(2).sum(0)
+        var = var + d.var(2, unbiased=False).sum(0)
+        if not is_reg_task:
+            vals, cnts = np.unique(np.asarray(label), return_counts=True)
+            for v, c in zip(vals, cnts):
+                counts[v] = counts.get(v, 0) + int(c)
+    mean = mean / n
+    std = torch.sqrt(var / n)
+    weights = None
+    if not is_reg_task:
+        counts.pop(-1, None)
+        weights = compute_class_weights(counts)
+    return mean.tolist(), std.tolist(), weights
+
+
 def window_origins(img_size: int, crop_size: int, stride: int) -> List[Tuple[int, int]]:
     """dataloader.py:655-664: ``for top in range(0,S-crop+1,stride) for left in ...`` -> (top,left)."""
     return [

@@ -141,3 +141,32 @@ def test_state_dict_contract_counts():
         n_enc = sum(int(np.prod(s)) for k, s in shapes.items() if k.startswith("prithvi_encoder.") and not k.endswith("pos_embed"))
         n_head = sum(int(np.prod(s)) for k, s in shapes.items() if k.startswith("segmentation_head.") and "running" not in k and "num_batches" not in k)
         assert n_enc == enc and n_head == head
+
+
+def test_compute_stats_oracle_matches_reference_fixture():
+    """mode=stats: the oracle restatement against the outputs of the reference's own compute_stats (gen_golden.py step 5)."""
+    from oracle.cases import make_stats_batches
+
+    z = np.load(os.path.join(GOLD, "stats.npz"))
+    for case in ("t1", "t3"):
+        mean, std, cw = O.compute_stats(make_stats_batches(case))
+        assert np.allclose(mean, z[f"{case}_mean"], rtol=2e-6, atol=2e-6)
+        assert np.allclose(std, z[f"{case}_std"], rtol=2e-6, atol=2e-6)
+        assert np.allclose(cw, z[f"{case}_class_weights"], rtol=1e-12)
+    # std is the root of the MEAN per-chip variance, not the pooled standard deviation
+    a = torch.zeros(1, 1, 1, 4, 4)
+    b = torch.ones(1, 1, 1, 4, 4) * 2
+    mean, std, _ = O.compute_stats([(torch.cat([a, b]), torch.zeros(2, 4, 4))])
+    assert mean == [1.0] and std == [0.0]
+    assert O.compute_class_weights({0: 30, 2: 10}) == [40 / (2 * 30), 0.0, 40 / (2 * 10)]
+
+
+def test_crop_flip_restatement():
+    x = np.arange(2 * 6 * 8).reshape(2, 6, 8)
+    y = np.arange(6 * 8).reshape(6, 8) + 100
+    cx, cy = O.crop_flip_chip(x, y, top=1, left=2, hflip=False, vflip=False, im_size=4)
+    assert np.array_equal(cx, x[:, 1:5, 2:6]) and np.array_equal(cy, y[1:5, 2:6])
+    hx, hy = O.crop_flip_chip(x, y, 1, 2, True, False, 4)
+    assert np.array_equal(hx[:, :, 0], x[:, 1:5, 5]) and np.array_equal(hy[:, 0], y[1:5, 5])
+    vx, vy = O.crop_flip_chip(x, y, 1, 2, True, True, 4)
+    assert vx[0, 0, 0] == x[0, 4, 5] and vy[0, 0] == y[4, 5] and vx[1, 3, 3] == x[1, 1, 2]

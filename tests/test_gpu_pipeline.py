@@ -56,6 +56,68 @@ def test_process_and_augment_crop_flip_layout():
         DL.process_and_augment(x, y, [0.0] * 6, [1.0] * 6, 3, augmentations={"rotate": {"use": True}})
 
 
+@pytest.mark.parametrize("dtype", [torch.int16, torch.float32])
+def test_crop_flip_normalize_kernel_matches_oracle(dtype):
+    """ig_crop_flip_normalize (batched random crop + flips + normalise, images and labels) against the oracle restatement."""
+    B, T, C, Hs, Ws, im = 5, 3, 6, 72, 80, 64
+    g = torch.Generator().manual_seed(5)
+    raw = torch.randint(0, 10000, (B, T * C, Hs, Ws), generator=g).to(dtype)
+    lab = torch.randint(-1, 13, (B, Hs, Ws), generator=g).float()
+    params = torch.tensor([[0, 0, 0, 0], [8, 16, 1, 0], [3, 5, 0, 1], [8, 16, 1, 1], [1, 0, 1, 1]], dtype=torch.int32)
+    mult = 1e-4 if dtype == torch.int16 else None
+    out, lo = ops.crop_flip_normalize(raw.to(DEV), params.to(DEV), torch.tensor(MEAN, device=DEV), torch.tensor(STD, device=DEV), T, im,
+                                      mult, lab.to(DEV))
+    assert out.shape == (B, C, T, im, im) and lo.shape == (B, im, im)
+    for b in range(B):
+        top, left, hf, vf = params[b].tolist()
+        cx, cy = O.crop_flip_chip(raw[b].numpy(), lab[b].numpy(), top, left, bool(hf), bool(vf), im)
+        ref = O.normalize_chip(cx.astype(np.float64) * (mult or 1.0), MEAN, STD, T)
+        assert np.allclose(out[b].cpu().numpy(), ref, rtol=1e-6, atol=1e-6), f"chip {b}"
+        assert np.array_equal(lo[b].cpu().numpy(), cy), f"label {b}"
+    # the batched host path draws per-chip parameters and produces the same thing as chip-by-chip calls with those draws
+    p = DL.draw_augment_params(B, (Hs, Ws), im, True, {"hflip": {"use": True, "p": 0.5}, "vflip": {"use": True, "p": 0.5}},
+                               torch.Generator().manual_seed(9))
+    assert p.shape == (B, 4) and int(p[:, 0].max()) <= Hs - im and int(p[:, 1].max()) <= Ws - im and set(p[:, 2:].flatten().tolist()) <= {0, 1}
+    o2, l2 = DL.process_and_augment_batch(raw.to(DEV), lab.to(DEV), MEAN, STD, T, im, constant_multiplier=mult, params=p)
+    cx, cy = O.crop_flip_chip(raw[2].numpy(), lab[2].numpy(), *[int(v) for v in p[2, :2]], bool(p[2, 2]), bool(p[2, 3]), im)
+    assert np.allclose(o2[2].cpu().numpy(), O.normalize_chip(cx.astype(np.float64) * (mult or 1.0), MEAN, STD, T), rtol=1e-6, atol=1e-6)
+    assert np.array_equal(l2[2].cpu().numpy(), cy)
+
+
+def test_compute_stats_matches_reference_fixture_and_oracle():
+    """mode=stats on the device: ig_chip_stats + ig_label_hist against the reference's compute_stats outputs (golden) and
+    the oracle on a second, larger seeded set."""
+    from instageo_amd.pipeline_utils import compute_stats
+    from oracle.cases import make_stats_batches
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "stats.npz"))
+    for case in ("t1", "t3"):
+        mean, std, cw = compute_stats(make_stats_batches(case), device=DEV)
+        assert np.allclose(mean, z[f"{case}_mean"], rtol=2e-6, atol=2e-6)
+        assert np.allclose(std, z[f"{case}_std"], rtol=2e-6, atol=2e-6)
+        assert np.allclose(cw, z[f"{case}_class_weights"], rtol=1e-12)
+    g = torch.Generator().manual_seed(21)
+    batches = [(torch.rand(4, 6, 1, 224, 224, generator=g) * 0.3 + 0.1 * i, torch.randint(-1, 2, (4, 224, 224), generator=g).float()) for i in range(3)]
+    mean, std, cw = compute_stats(batches, device=DEV)
+    om, os_, ow = O.compute_stats(batches)
+    assert np.allclose(mean, om, rtol=1e-9) and np.allclose(std, os_, rtol=1e-9) and np.allclose(cw, ow, rtol=1e-12)
+    m2, s2, w2 = compute_stats(batches, is_reg_task=True, device=DEV)
+    assert w2 is None and np.allclose(m2, mean, rtol=1e-12)  # fp64 atomics: order-dependent last bit
+    with pytest.raises(ValueError):
+        compute_stats([(batches[0][0], batches[0][1] + 0.5)], device=DEV)
+
+
+def test_run_mode_stats_prints_reference_json(capsys):
+    from instageo_amd import run as R
+
+    rc = R.main(["mode=stats", "train_filepath=synthetic:6", "train.batch_size=4", "dataloader.temporal_dim=1", "train.ignore_index=-1"])
+    assert rc == 0
+    out = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert set(out) == {"mean", "std", "class_weights"} and len(out["mean"]) == 6 and len(out["std"]) == 6
+    assert all(0.0 < m < 1.0 for m in out["mean"]) and all(s > 0 for s in out["std"])  # reflectances = int16 * 1e-4, un-normalised
+    assert len(out["class_weights"]) == 2 and all(w > 0 for w in out["class_weights"])
+
+
 def _tiny(ncls=2, T=1):
     net = PrithviSeg(temporal_step=T, num_classes=ncls, load_pretrained_weights=False, freeze_backbone=True, variant="prithvi_eo_tiny", device=DEV)
     cfg = O.make_config("prithvi_eo_tiny", T, ncls)
