@@ -168,6 +168,11 @@ class SyntheticChipDataset(torch.utils.data.Dataset):
         x, y = self.raw(i)
         return normalize_and_convert_to_tensor(x, y, self.mean, self.std, self.T, self.mult, self.device)
 
+    def raw_batch(self, ids: Sequence[int]) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Un-normalised batch for the fused crop/flip/normalise kernel: (B, T*C, S, S) int16, (B, S, S) f32."""
+        items = [self.raw(i) for i in ids]
+        return torch.stack([a for a, _ in items]), torch.stack([b for _, b in items])
+
 
 class ArrayChipDataset(torch.utils.data.Dataset):
     """Chips/labels held as arrays ``chips (N,T*C,H,W)``, ``labels (N,H,W)`` (stand-in for the GeoTIFF reader)."""
@@ -181,6 +186,12 @@ class ArrayChipDataset(torch.utils.data.Dataset):
 
     def __len__(self) -> int:
         return len(self.chips)
+
+    def raw_batch(self, ids: Sequence[int]) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Un-normalised batch (B, T*C, H, W) int16|f32 and labels (B, H, W) f32 on the device."""
+        x = torch.stack([_as_device_chip(self.chips[i], self.device) for i in ids])
+        y = torch.stack([torch.as_tensor(np.asarray(self.labels[i])).float().squeeze() for i in ids]).to(self.device)
+        return x, y
 
     def __getitem__(self, i: int):
         x, y = normalize_and_convert_to_tensor(self.chips[i], self.labels[i], self.mean, self.std, self.T, self.mult, self.device)

@@ -25,7 +25,7 @@ import torch
 from . import distributed as D
 from .config import check_required_flags, load_config
 from .dataloader import (ArrayChipDataset, SyntheticChipDataset, eval_collate_fn, infer_collate_fn, normalize_batch,
-                         process_and_augment, process_test)
+                         process_and_augment, process_and_augment_batch, process_test)
 from .factory import create_model
 from .infer_utils import chip_inference
 from .pipeline_utils import compute_stats
@@ -83,10 +83,20 @@ def train(cfg: Dict[str, Any], model, out_dir: str, rank: int, world: int) -> Di
     sched = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(opt, T_0=10, T_mult=2, eta_min=0) if cfg["train"].get("scheduler") else None
     D.attach_data_parallel(model)
     best, history = -1.0, {}
+    augs = cfg["dataloader"].get("augmentations") or {}
+    train_augs = {k: v for k, v in augs.items() if k in ("hflip", "vflip") and v.get("use", False)}
+    skipped = [k for k, v in augs.items() if k not in ("hflip", "vflip") and v.get("use", False)]
+    if skipped and rank == 0:
+        print(f"[instageo_amd] augmentations outside the hot path are ignored: {skipped} (SURVEY.md 8f)", file=sys.stderr)
+    aug_gen = torch.Generator().manual_seed(SEED + 7919 * rank)  # different crops/flips per rank, reproducible
     for epoch in range(cfg["train"]["num_epochs"]):
         model.net.train()
         for ids in _batches(train_ds, bs, True, epoch, rank, world):
-            x, y = _stack(train_ds, ids)
+            # training items go through process_and_augment (dataloader.py:527-585): random crop to img_size + the enabled
+            # flips + normalise, here as ONE kernel per batch on the raw chips
+            xr, yr = train_ds.raw_batch(ids)
+            x, y = process_and_augment_batch(xr, yr, train_ds.mean, train_ds.std, train_ds.T, cfg["dataloader"]["img_size"], True,
+                                             train_augs, train_ds.mult, aug_gen)
             model.fused_train_step(x, y)
         D.reduce_confusion(model.train_metrics.device_matrix(dev))
         model.on_train_epoch_end()
