@@ -128,6 +128,12 @@ int ig_ce_loss(const float* logits, const void* labels, int label_dtype, const f
 /* torch.argmax(dim=1) -> int8                                                           infer_utils.py:99-101 */
 int ig_argmax_i8(const float* logits, signed char* out, int B, long HW, int ncls, void* stream);
 /* RunningConfusionMatrix.update                                                         metrics.py:86-108 */
+/* test-time metrics on the device: RunningAUC histograms of softmax(logits) (metrics.py:214-256 via
+ * segmentation.py:153-156; hist = uint64 [2][ncls][nbins], 0 = positives / 1 = negatives of each class, ignored pixels
+ * skipped) and predict_step's softmax(logits, 1)[:, cls] (segmentation.py:202-213) */
+int ig_auc_update(const float* logits, const void* labels, int label_dtype, long ignore_index, unsigned long long* hist, int B,
+                  long HW, int ncls, int nbins, float min_score, float max_score, void* stream);
+int ig_softmax_prob(const float* logits, float* out, int B, long HW, int ncls, int cls, void* stream);
 int ig_confusion_update(const long long* y_true, const long long* y_pred, unsigned long long* confusion, long n, int k,
                         long ignore_index, int has_ignore, void* stream);
 /* torch.optim.AdamW step on a flat buffer (+ clip_weights, + bf16 shadow refresh)        base.py:103-126 */

@@ -201,6 +201,75 @@ __global__ __launch_bounds__(TPB) void ce_loss_kernel(const float* __restrict__ 
             if (hist[i]) atomicAdd(confusion + i, (unsigned long long)hist[i]);
 }
 
+// K16b streaming ROC-AUC histograms (metrics.py:214-256, called with softmax probabilities at segmentation.py:153-156):
+// for every valid pixel and class c: bin = int((clamp(p_c, lo, hi) - lo) / (hi - lo) * (nbins - 1)) in float32 (numpy 2
+// scalar arithmetic on float32 probabilities), hist[y == c ? 0 : 1][c][bin] += 1.  The reference does this in a Python
+// loop per pixel; here one thread per pixel, histograms in LDS when they fit (2 * ncls * nbins * 4 B <= 64 KiB).
+template <typename LABEL, bool USE_LDS>
+__global__ __launch_bounds__(TPB) void auc_update_kernel(const float* __restrict__ logits, const LABEL* __restrict__ labels,
+                                                         long ignore_index, unsigned long long* __restrict__ hist, long M, long HW,
+                                                         int ncls, int nbins, float lo, float hi) {
+    extern __shared__ unsigned int sh[];  // [2][ncls][nbins] when USE_LDS
+    const int nh = 2 * ncls * nbins;
+    if (USE_LDS) {
+        for (int i = threadIdx.x; i < nh; i += TPB) sh[i] = 0u;
+        __syncthreads();
+    }
+    const float inv = (float)(nbins - 1);
+    for (long m = blockIdx.x * (long)TPB + threadIdx.x; m < M; m += (long)gridDim.x * TPB) {
+        const long y = (long)labels[m];
+        if (y == ignore_index) continue;
+        const long b = m / HW, pix = m - b * HW;
+        float z[MAXC];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int n = 0; n < MAXC; ++n)
+            if (n < ncls) {
+                z[n] = logits[(b * ncls + n) * HW + pix];
+                mx = fmaxf(mx, z[n]);
+            }
+        float se = 0.f;
+#pragma unroll
+        for (int n = 0; n < MAXC; ++n)
+            if (n < ncls) {
+                z[n] = __expf(z[n] - mx);
+                se += z[n];
+            }
+#pragma unroll
+        for (int n = 0; n < MAXC; ++n)
+            if (n < ncls) {
+                float p = z[n] / se;
+                p = fminf(hi, fmaxf(lo, p));
+                const int bin = (int)((p - lo) / (hi - lo) * inv);
+                const int idx = ((y == n ? 0 : 1) * ncls + n) * nbins + bin;
+                if (USE_LDS) atomicAdd(sh + idx, 1u);
+                else atomicAdd(hist + idx, 1ull);
+            }
+    }
+    if (USE_LDS) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < nh; i += TPB)
+            if (sh[i]) atomicAdd(hist + i, (unsigned long long)sh[i]);
+    }
+}
+
+// predict_step (segmentation.py:202-213): softmax(logits, dim=1)[:, cls]
+__global__ __launch_bounds__(TPB) void softmax_prob_kernel(const float* __restrict__ logits, float* __restrict__ out, long M, long HW,
+                                                           int ncls, int cls) {
+    const long m = blockIdx.x * (long)TPB + threadIdx.x;
+    if (m >= M) return;
+    const long b = m / HW, pix = m - b * HW;
+    float mx = -INFINITY, zc = 0.f;
+    for (int n = 0; n < ncls; ++n) mx = fmaxf(mx, logits[(b * ncls + n) * HW + pix]);
+    float se = 0.f;
+    for (int n = 0; n < ncls; ++n) {
+        const float e = __expf(logits[(b * ncls + n) * HW + pix] - mx);
+        se += e;
+        if (n == cls) zc = e;
+    }
+    out[m] = zc / se;
+}
+
 // argmax over classes -> int8 class map (infer_utils.py:99-101)
 __global__ void argmax_kernel(const float* __restrict__ logits, signed char* __restrict__ out, long M, long HW, int ncls) {
     long m = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -306,6 +375,49 @@ int ig_ce_loss(const float* logits, const void* labels, int label_dtype, const f
         return IG_ERR_UNSUPPORTED;
     }
     return ig_check_launch("ig_ce_loss");
+}
+
+// hist: device uint64 [2][ncls][nbins] (0 = positives of class c, 1 = negatives); label_dtype as ig_ce_loss
+int ig_auc_update(const float* logits, const void* labels, int label_dtype, long ignore_index, unsigned long long* hist, int B,
+                  long HW, int ncls, int nbins, float min_score, float max_score, void* stream) {
+    IG_REQUIRE(logits && labels && hist, "ig_auc_update: null pointer");
+    IG_REQUIRE(ncls >= 1 && ncls <= MAXC, "ig_auc_update: 1 <= ncls <= %d (got %d)", MAXC, ncls);
+    IG_REQUIRE(nbins >= 2 && max_score > min_score, "ig_auc_update: need nbins >= 2 and max_score > min_score");
+    const long M = (long)B * HW;
+    if (M == 0) return IG_OK;
+    long nblk = (M + TPB - 1) / TPB;
+    if (nblk > 1024) nblk = 1024;
+    const size_t lds = 2 * (size_t)ncls * nbins * sizeof(unsigned int);
+    const bool use_lds = lds <= 65536;
+    hipStream_t st = (hipStream_t)stream;
+#define IG_AUC(LT)                                                                                                              \
+    {                                                                                                                            \
+        if (use_lds)                                                                                                             \
+            hipLaunchKernelGGL((auc_update_kernel<LT, true>), dim3((unsigned)nblk), dim3(TPB), lds, st, logits, (const LT*)labels, \
+                               ignore_index, hist, M, HW, ncls, nbins, min_score, max_score);                                     \
+        else                                                                                                                     \
+            hipLaunchKernelGGL((auc_update_kernel<LT, false>), dim3((unsigned)nblk), dim3(TPB), 0, st, logits, (const LT*)labels, \
+                               ignore_index, hist, M, HW, ncls, nbins, min_score, max_score);                                     \
+    }
+    if (label_dtype == 0) IG_AUC(long long)
+    else if (label_dtype == 1) IG_AUC(int)
+    else if (label_dtype == 2) IG_AUC(float)
+    else {
+        ig_set_error("ig_auc_update: unsupported label dtype %d", label_dtype);
+        return IG_ERR_UNSUPPORTED;
+    }
+#undef IG_AUC
+    return ig_check_launch("ig_auc_update");
+}
+
+int ig_softmax_prob(const float* logits, float* out, int B, long HW, int ncls, int cls, void* stream) {
+    IG_REQUIRE(logits && out, "ig_softmax_prob: null pointer");
+    IG_REQUIRE(ncls >= 1 && cls >= 0 && cls < ncls, "ig_softmax_prob: need 0 <= cls < ncls");
+    const long M = (long)B * HW;
+    if (M == 0) return IG_OK;
+    hipLaunchKernelGGL(softmax_prob_kernel, dim3((unsigned)((M + TPB - 1) / TPB)), dim3(TPB), 0, (hipStream_t)stream, logits, out, M, HW,
+                       ncls, cls);
+    return ig_check_launch("ig_softmax_prob");
 }
 
 int ig_argmax_i8(const float* logits, signed char* out, int B, long HW, int ncls, void* stream) {

@@ -14,7 +14,7 @@ import torch
 
 from . import ops
 
-__all__ = ["RunningConfusionMatrix", "metrics_from_matrix"]
+__all__ = ["RunningConfusionMatrix", "RunningAUC", "metrics_from_matrix", "auc_from_histograms"]
 
 
 def _safe_div(num: np.ndarray, den: np.ndarray) -> np.ndarray:
@@ -94,3 +94,91 @@ class RunningConfusionMatrix:
     def reset(self) -> None:
         if self._matrix is not None:
             self._matrix.zero_()
+
+
+def auc_from_histograms(pos_hist: np.ndarray, neg_hist: np.ndarray) -> np.ndarray:
+    """Per-class one-vs-rest ROC-AUC from score histograms, the arithmetic of metrics.py:238-248: positives outrank the
+    negatives of lower bins, ties inside a bin count one half; NaN for a class without positives or without negatives."""
+    pos = np.asarray(pos_hist, dtype=np.float64)
+    neg = np.asarray(neg_hist, dtype=np.float64)
+    cum_neg = np.cumsum(neg, axis=1) - neg  # negatives in strictly lower bins
+    num = (pos * cum_neg + 0.5 * pos * neg).sum(axis=1)
+    n_pos, n_neg = pos.sum(axis=1), neg.sum(axis=1)
+    out = np.full(pos.shape[0], np.nan)
+    ok = (n_pos > 0) & (n_neg > 0)
+    out[ok] = num[ok] / (n_pos[ok] * n_neg[ok])
+    return out
+
+
+class RunningAUC:
+    """Histogram-based streaming one-vs-rest ROC-AUC (reference: ``metrics.py:179-281``), device resident.
+
+    ``update_from_logits`` bins softmax(logits) on the GPU (``ig_auc_update``; the reference walks the valid pixels in a
+    Python loop, ``metrics.py:225-236``); ``update`` keeps the reference's (y_true, y_score) signature for host arrays.
+    """
+
+    def __init__(self, num_classes: int, n_bins: int = 1024, min_score: float = 0.0, max_score: float = 1.0,
+                 ignore_index: Optional[int] = None, device: Optional[str] = None) -> None:
+        self.num_classes, self.n_bins = num_classes, n_bins
+        self.min_score, self.max_score = min_score, max_score
+        self.ignore_index = ignore_index
+        self._device = device
+        self._hist: Optional[torch.Tensor] = None
+
+    def device_hist(self, device=None) -> torch.Tensor:
+        if self._hist is None:
+            self._hist = torch.zeros(2, self.num_classes, self.n_bins, dtype=torch.int64, device=device or self._device or "cuda")
+        return self._hist
+
+    def update_from_logits(self, logits: torch.Tensor, labels: torch.Tensor) -> None:
+        """logits (B, ncls, H, W) f32, labels (B, H, W) int64|int32|f32 on the device; ignored pixels are skipped."""
+        if labels.dtype not in (torch.int64, torch.int32, torch.float32):
+            labels = labels.long()
+        ops.auc_update(logits.contiguous(), labels.contiguous(), self.ignore_index, self.device_hist(logits.device), self.n_bins,
+                       self.min_score, self.max_score)
+
+    def _bin(self, scores: np.ndarray) -> np.ndarray:
+        s = np.minimum(self.max_score, np.maximum(self.min_score, scores))
+        return ((s - self.min_score) / (self.max_score - self.min_score) * (self.n_bins - 1)).astype(np.int64)
+
+    def update(self, y_true, y_score) -> None:
+        """Reference signature: y_true (n,), y_score (n, C) probabilities (or (n,) positive-class scores when C == 2)."""
+        y_true = np.asarray(y_true).ravel()
+        y_score = np.asarray(y_score)
+        if y_score.ndim == 1:
+            if self.num_classes != 2:
+                raise ValueError("For 1-D y_score, num_classes must be 2.")
+            y_score = np.stack([1 - y_score, y_score], axis=1)
+        if y_true.shape[0] != y_score.shape[0]:
+            raise ValueError("y_true and y_score length mismatch.")
+        if y_score.shape[1] != self.num_classes:
+            raise ValueError("Second dim of y_score must equal num_classes.")
+        add = np.zeros((2, self.num_classes, self.n_bins), dtype=np.int64)
+        for c in range(self.num_classes):
+            bins = self._bin(y_score[:, c])
+            pos = y_true == c
+            add[0, c] = np.bincount(bins[pos], minlength=self.n_bins)
+            add[1, c] = np.bincount(bins[~pos], minlength=self.n_bins)
+        h = self.device_hist()
+        h += torch.from_numpy(add).to(h.device)
+
+    @property
+    def pos_hist(self) -> np.ndarray:
+        return self.device_hist().cpu().numpy()[0]
+
+    @property
+    def neg_hist(self) -> np.ndarray:
+        return self.device_hist().cpu().numpy()[1]
+
+    def score(self, include_per_class: bool = True) -> dict:
+        h = self.device_hist().cpu().numpy()
+        per_class = auc_from_histograms(h[0], h[1])
+        with np.errstate(all="ignore"):
+            macro = np.nanmean(per_class) if np.isfinite(per_class).any() else float("nan")
+        if include_per_class:
+            return {"roc_auc_macro": macro, "roc_auc_per_class": per_class.tolist()}
+        return {"roc_auc_macro": macro}
+
+    def reset(self) -> None:
+        if self._hist is not None:
+            self._hist.zero_()

@@ -316,6 +316,26 @@ def ce_loss(logits, labels, class_weights, ignore_index: int, stats, dlogits=Non
           _p(dlogits), _p(preds), _p(preds_i8), _p(confusion), B, HW, ncls, _stream())
 
 
+def auc_update(logits, labels, ignore_index: Optional[int], hist, nbins: int, min_score: float = 0.0, max_score: float = 1.0) -> None:
+    """RunningAUC histograms of softmax(logits): hist int64 [2, ncls, nbins] (0 positives, 1 negatives of each class)."""
+    B, ncls = logits.shape[0], logits.shape[1]
+    HW = logits.numel() // (B * ncls)
+    assert hist.dtype == torch.int64 and hist.numel() == 2 * ncls * nbins
+    ign = -(2**62) if ignore_index is None else int(ignore_index)
+    _call("ig_auc_update", float(B) * HW * (ncls * 4 + labels.element_size()), _p(_f32(logits)), _p(labels), _LABEL_DT[labels.dtype], ign,
+          _p(hist), B, HW, ncls, nbins, float(min_score), float(max_score), _stream())
+
+
+def softmax_prob(logits, cls: int = 1, out=None):
+    """softmax(logits, dim=1)[:, cls] -> (B, H, W) f32 (predict_step, segmentation.py:202-213)."""
+    B, ncls = logits.shape[0], logits.shape[1]
+    HW = logits.numel() // (B * ncls)
+    if out is None:
+        out = torch.empty((B,) + tuple(logits.shape[2:]), dtype=torch.float32, device=logits.device)
+    _call("ig_softmax_prob", float(B) * HW * (ncls * 4 + 4), _p(_f32(logits)), _p(out), B, HW, ncls, int(cls), _stream())
+    return out
+
+
 def argmax_i8(logits, out=None):
     B, ncls = logits.shape[0], logits.shape[1]
     HW = logits.numel() // (B * ncls)

@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .metrics import RunningConfusionMatrix
+from .metrics import RunningAUC, RunningConfusionMatrix
 from .model import PrithviSeg
 
 try:  # the module must still work as a LightningModule when Lightning is installed
@@ -175,6 +175,7 @@ class PrithviSegmentationModule(_Base):
         self.train_metrics = RunningConfusionMatrix(num_classes, ignore_index)
         self.val_metrics = RunningConfusionMatrix(num_classes, ignore_index)
         self.test_metrics = RunningConfusionMatrix(num_classes, ignore_index)
+        self.test_auc = RunningAUC(num_classes, ignore_index=ignore_index)  # ROC-AUC only at test time (segmentation.py:153-156)
         self.logged: Dict[str, Any] = {}
         self._loss_sums: Dict[str, torch.Tensor] = {}
         self._optimizer: Optional[FusedAdamW] = None
@@ -263,9 +264,13 @@ class PrithviSegmentationModule(_Base):
         self.log(f"{step_type}_Recall", m["recall"])
         for idx, value in enumerate(m["jaccard_per_class"]):
             self.log(f"{step_type}_IoU_{idx}", value)
+        if step_type == "test":
+            self.log(f"{step_type}_roc_auc", float(self.test_auc.score()["roc_auc_macro"]))
         for idx, value in enumerate(m["f1_per_class"]):
             self.log(f"{step_type}_F1_{idx}", value)
         metrics.reset()
+        if step_type == "test":
+            self.test_auc.reset()
 
     def on_train_epoch_end(self) -> None:
         self._shared_epoch_end("train")
@@ -368,8 +373,19 @@ class PrithviSegmentationModule(_Base):
         metrics: RunningConfusionMatrix = getattr(self, f"{step_type}_metrics")
         ops.ce_loss(logits, labels.contiguous(), self._weights(), self.ignore_index, stats, None, None, None,
                     metrics.device_matrix(logits.device))
+        if step_type == "test":
+            self.test_auc.update_from_logits(logits, labels)
         self._accumulate_loss(step_type, (stats[0] / stats[1]).float())
         return stats
+
+    def predict_step(self, batch: Any) -> torch.Tensor:
+        """softmax(forward(batch), dim=1)[:, 1] (segmentation.py:202-213), fused on the device."""
+        inputs = batch[0] if isinstance(batch, (tuple, list)) else batch
+        if self.net.training:
+            self.net.eval()
+        with torch.no_grad():
+            logits = self.net.engine.forward(inputs, training=False, save=False)
+        return ops.softmax_prob(logits, 1)
 
     # ---- checkpoints (pipeline_utils.py:347-355, factory.py:113-115) ----------------------------
     def checkpoint_state_dict(self) -> Dict[str, torch.Tensor]:

@@ -236,6 +236,23 @@ def main() -> None:
         scalars=np.array([res[k] for k in ("accuracy", "precision", "recall", "f1", "jaccard")]),
         jaccard_per_class=np.array(res["jaccard_per_class"]),
     )  # fmt: skip
+    # 3b. RunningAUC (metrics.py:179-281): seeded 3-class float32 probabilities through the reference class ---------
+    rng = np.random.default_rng(5)
+    lg = rng.normal(size=(4000, 3)).astype(np.float32) * 2
+    pr = np.exp(lg - lg.max(1, keepdims=True))
+    pr = (pr / pr.sum(1, keepdims=True)).astype(np.float32)
+    ya = (rng.random(4000) < 0.6).astype(np.int64) * lg.argmax(1) + (rng.random(4000) < 0.2) * rng.integers(0, 3, 4000)
+    ya = np.clip(ya, 0, 2)
+    ra = ref_metrics.RunningAUC(3, n_bins=1024)
+    ra.update(ya[:1500], pr[:1500])
+    ra.update(ya[1500:], pr[1500:])
+    sc = ra.score()
+    op, on = O.auc_histograms(ya, pr, 3, 1024)
+    assert np.array_equal(op, ra.pos_hist) and np.array_equal(on, ra.neg_hist), "AUC histogram oracle mismatch"
+    om, oper = O.auc_score(op, on)
+    assert om == sc["roc_auc_macro"] and oper == sc["roc_auc_per_class"], "AUC score oracle mismatch"
+    np.savez_compressed(os.path.join(out_dir, "auc.npz"), y_true=ya, probs=pr, pos_hist=ra.pos_hist, neg_hist=ra.neg_hist,
+                        macro=np.float64(sc["roc_auc_macro"]), per_class=np.array(sc["roc_auc_per_class"]))
     # 4. window origins (process_test semantics: dataloader.py:655-664) --------------------
     wins = {}
     for S in (512, 10980):

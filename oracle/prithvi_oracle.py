@@ -412,6 +412,39 @@ def confusion_metrics(matrix: np.ndarray) -> dict:
 # --------------------------------------------------------------------------------------
 
 
+def auc_histograms(y_true: np.ndarray, y_score: np.ndarray, num_classes: int, n_bins: int = 1024, min_score: float = 0.0,
+                   max_score: float = 1.0) -> Tuple[np.ndarray, np.ndarray]:
+    """metrics.py:204-236 (RunningAUC._bin / update): per class c, histogram of the class-c score of the positives
+    (y == c) and of the negatives; bin = int((clamp(s) - min) / (max - min) * (n_bins - 1)) in the scores' own dtype."""
+    y_true = np.asarray(y_true).ravel()
+    y_score = np.asarray(y_score)
+    pos = np.zeros((num_classes, n_bins), dtype=np.int64)
+    neg = np.zeros((num_classes, n_bins), dtype=np.int64)
+    for c in range(num_classes):
+        s = np.minimum(max_score, np.maximum(min_score, y_score[:, c]))
+        bins = ((s - min_score) / (max_score - min_score) * (n_bins - 1)).astype(np.int64)
+        np.add.at(pos[c], bins[y_true == c], 1)
+        np.add.at(neg[c], bins[y_true != c], 1)
+    return pos, neg
+
+
+def auc_score(pos: np.ndarray, neg: np.ndarray) -> Tuple[float, List[float]]:
+    """metrics.py:238-264: AUC_c = sum_bins pos * (negatives in lower bins + half of the negatives in the same bin) /
+    (n_pos n_neg), NaN without positives or negatives; macro = nanmean."""
+    per = []
+    for c in range(pos.shape[0]):
+        n_pos, n_neg = int(pos[c].sum()), int(neg[c].sum())
+        if n_pos == 0 or n_neg == 0:
+            per.append(float("nan"))
+            continue
+        auc, cum = 0.0, 0
+        for p_, n_ in zip(pos[c].tolist(), neg[c].tolist()):
+            auc += p_ * cum + 0.5 * p_ * n_
+            cum += n_
+        per.append(auc / (n_pos * n_neg))
+    return float(np.nanmean(np.array(per))), per
+
+
 def normalize_chip(chip: np.ndarray, mean: List[float], std: List[float], temporal_size: int) -> np.ndarray:
     """dataloader.py:495-524: (T*C,H,W) -> reshape (T,C,H,W) -> (x-mean_c)/std_c -> (C,T,H,W) f32.
 

@@ -170,3 +170,24 @@ def test_crop_flip_restatement():
     assert np.array_equal(hx[:, :, 0], x[:, 1:5, 5]) and np.array_equal(hy[:, 0], y[1:5, 5])
     vx, vy = O.crop_flip_chip(x, y, 1, 2, True, True, 4)
     assert vx[0, 0, 0] == x[0, 4, 5] and vy[0, 0] == y[4, 5] and vx[1, 3, 3] == x[1, 1, 2]
+
+
+def test_running_auc_oracle_known_answers_and_fixture():
+    """RunningAUC restatement: the reference test-suite's known answers (tests/model_tests/test_metrics.py:77-139: 0.75 and
+    0.375 against scikit-learn) and the histograms/scores the reference class produced for a seeded 3-class set."""
+    y_true = np.array([1, 1, 1, 1, 1, 0, 1, 1, 0, 1])
+    p1 = np.array([0.9, 0.8, 0.7, 0.6, 0.55, 0.45, 0.4, 0.3, 0.2, 0.1])
+    pos, neg = O.auc_histograms(y_true, np.stack([1 - p1, p1], 1), 2, n_bins=2048)
+    assert O.auc_score(pos, neg)[0] == 0.75
+    p2 = np.array([0.6, 0.55, 0.5, 0.45, 0.4, 0.6, 0.55, 0.5, 0.45, 0.4])
+    pos, neg = O.auc_histograms(y_true, np.stack([1 - p2, p2], 1), 2, n_bins=2048)
+    assert O.auc_score(pos, neg)[0] == 0.375
+    z = np.load(os.path.join(GOLD, "auc.npz"))
+    pos, neg = O.auc_histograms(z["y_true"], z["probs"], 3, 1024)
+    assert np.array_equal(pos, z["pos_hist"]) and np.array_equal(neg, z["neg_hist"])
+    macro, per = O.auc_score(pos, neg)
+    assert macro == float(z["macro"]) and per == z["per_class"].tolist()
+    # a class without positives scores NaN and is left out of the macro mean
+    pos, neg = O.auc_histograms(np.array([0, 0, 1]), np.array([[0.7, 0.2, 0.1], [0.6, 0.3, 0.1], [0.2, 0.7, 0.1]]), 3, 64)
+    macro, per = O.auc_score(pos, neg)
+    assert np.isnan(per[2]) and macro == 1.0

@@ -491,3 +491,46 @@ def test_bad_arguments_raise():
         ops.attention_fwd(x, x, None, 1, 8, 1, hd=32)
     with pytest.raises(HipLibraryError):
         ops.linear_fwd(BT.empty((8, 16), True, DEV), BT.empty((8, 16), False, DEV), None, BT.empty((8, 8), False, DEV), 8, 8, 16)
+
+
+def test_auc_histograms_and_softmax_prob():
+    """ig_auc_update / ig_softmax_prob against the oracle (and through it the reference RunningAUC fixture)."""
+    import os
+
+    from instageo_amd.metrics import RunningAUC, auc_from_histograms
+    from oracle import prithvi_oracle as O
+
+    for ncls, nbins in [(2, 1024), (13, 1024), (3, 64)]:  # 13 x 1024 exceeds the LDS histogram budget -> global atomics
+        B, H, W = 3, 40, 56
+        g = torch.Generator().manual_seed(31 + ncls)
+        logits = torch.randn(B, ncls, H, W, generator=g) * 2
+        labels = torch.randint(-1, ncls, (B, H, W), generator=g)
+        auc = RunningAUC(ncls, n_bins=nbins, ignore_index=-1, device=DEV)
+        auc.update_from_logits(logits.to(DEV), labels.to(DEV))
+        auc.update_from_logits(logits.to(DEV), labels.float().to(DEV))  # float labels as the reference datasets deliver them
+        probs = torch.softmax(logits, 1).permute(0, 2, 3, 1).reshape(-1, ncls).numpy()
+        y = labels.reshape(-1).numpy()
+        keep = y != -1
+        pos, neg = O.auc_histograms(y[keep], probs[keep], ncls, nbins)
+        # softmax differs from torch's in the last ulp: a score within 1e-6 of a bin edge may land in the neighbour bin
+        assert np.abs(auc.pos_hist - 2 * pos).sum() <= 8 and np.abs(auc.neg_hist - 2 * neg).sum() <= 8 * ncls
+        assert auc.pos_hist.sum() == 2 * pos.sum() and auc.neg_hist.sum() == 2 * neg.sum()
+        ref_macro, ref_per = O.auc_score(pos, neg)
+        got = auc.score()
+        assert abs(got["roc_auc_macro"] - ref_macro) < 1e-4  # tolerance: bin-edge flips only
+        assert np.allclose(auc_from_histograms(pos, neg), ref_per, rtol=0, atol=1e-15, equal_nan=True)
+        auc.reset()
+        assert auc.pos_hist.sum() == 0
+    # host-array path with the reference signature reproduces the reference fixture exactly
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "auc.npz"))
+    auc = RunningAUC(3, device=DEV)
+    auc.update(z["y_true"][:1500], z["probs"][:1500])
+    auc.update(z["y_true"][1500:], z["probs"][1500:])
+    assert np.array_equal(auc.pos_hist, z["pos_hist"]) and np.array_equal(auc.neg_hist, z["neg_hist"])
+    sc = auc.score()
+    assert sc["roc_auc_macro"] == float(z["macro"]) and sc["roc_auc_per_class"] == z["per_class"].tolist()
+    with pytest.raises(ValueError):
+        RunningAUC(3, device=DEV).update(np.zeros(4), np.zeros(4))
+    # predict_step's probability map
+    logits = torch.randn(2, 2, 32, 48, generator=torch.Generator().manual_seed(2))
+    close(ops.softmax_prob(logits.to(DEV), 1), torch.softmax(logits.double(), 1)[:, 1], 1e-6, what="softmax prob")

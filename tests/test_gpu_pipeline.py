@@ -178,7 +178,8 @@ def test_run_train_eval_chip_inference(tmp_path, capsys):
     rc = run.main(["--output-dir", out, "mode=eval", "test_filepath=synthetic:2", "test.img_size=448", f"checkpoint_path={ck}"] + common)
     assert rc == 0
     res = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1]["Evaluation results"]
-    assert {"test_loss", "test_IoU", "test_Acc"} <= set(res) and 0 <= res["test_IoU"] <= 1
+    assert {"test_loss", "test_IoU", "test_Acc", "test_roc_auc"} <= set(res) and 0 <= res["test_IoU"] <= 1
+    assert 0.0 <= res["test_roc_auc"] <= 1.0  # ROC-AUC is logged at test time only (segmentation.py:185-189)
     rc = run.main(["--output-dir", out, "mode=chip_inference", "test_filepath=synthetic:3", "test.img_size=224", f"checkpoint_path={ck}"] + common)
     assert rc == 0 and len(os.listdir(tmp_path / "predictions")) == 3
     with pytest.raises(RuntimeError):
