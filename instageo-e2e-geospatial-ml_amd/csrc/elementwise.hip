@@ -508,35 +508,34 @@ __global__ __launch_bounds__(LNB_TPB) void layernorm_bwd_exact_kernel(const bf16
             }
         }
     }
-    // cross-wave column reduction
-    for (int i = threadIdx.x; i < 3 * D; i += LNB_TPB) red[i] = 0.f;
-    __syncthreads();
+    // cross-wave column reduction through LDS with PLAIN stores and loads: every wave writes its 3 x D partials to its own
+    // slab, then each thread sums one column over the waves.  (36 ds_add_f32 per lane cost 25 us of a 68 us launch: LDS
+    // float atomics retire a few lanes per cycle.)
+    constexpr int NWV = LNB_TPB / 64;
+    float* mine = red + (size_t)wave * 3 * D;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        int c = lane + i * 64;
-        {
-            float* r0 = red + c * 4;
-            atomicAdd(r0 + 0, ag[i].x), atomicAdd(r0 + 1, ag[i].y), atomicAdd(r0 + 2, ag[i].z), atomicAdd(r0 + 3, ag[i].w);
-            float* r1 = red + D + c * 4;
-            atomicAdd(r1 + 0, ab[i].x), atomicAdd(r1 + 1, ab[i].y), atomicAdd(r1 + 2, ab[i].z), atomicAdd(r1 + 3, ab[i].w);
-            float* r2 = red + 2 * D + c * 4;
-            atomicAdd(r2 + 0, ac[i].x), atomicAdd(r2 + 1, ac[i].y), atomicAdd(r2 + 2, ac[i].z), atomicAdd(r2 + 3, ac[i].w);
-        }
+        const int c = lane + i * 64;
+        *reinterpret_cast<float4*>(mine + c * 4) = ag[i];
+        *reinterpret_cast<float4*>(mine + D + c * 4) = ab[i];
+        *reinterpret_cast<float4*>(mine + 2 * D + c * 4) = ac[i];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < D; i += LNB_TPB) {
-        if (dgamma) atomicAdd(dgamma + i, red[i]);
-        if (dbeta) atomicAdd(dbeta + i, red[D + i]);
-        if (dcol) atomicAdd(dcol + i, red[2 * D + i]);
+    for (int i = threadIdx.x; i < 3 * D; i += LNB_TPB) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) t += red[(size_t)w * 3 * D + i];
+        float* dst = i < D ? dgamma : i < 2 * D ? dbeta : dcol;
+        if (dst) atomicAdd(dst + (i < D ? i : i < 2 * D ? i - D : i - 2 * D), t);
     }
 }
 
 // column sums of a bf16/split matrix: out[c] += sum_m x[m][c]   (bias gradients)
 // grid (row chunk, 1024-column chunk); threads tile (row slice, 8-column unit) with 4 independent 16-byte loads in
-// flight; per-block LDS reduction, then one atomic per (block, column)
+// flight; per-block LDS reduction over the row slices (plain stores + loads), then one atomic per (block, column)
 __global__ __launch_bounds__(TPB) void colsum_kernel(const bf16_t* __restrict__ hi, const bf16_t* __restrict__ lo,
                                                      float* __restrict__ out, long M, int C, int rows_per_block) {
-    __shared__ float red[1024];
+    __shared__ float red[TPB * 8];  // [row slice][columns of this block]: plain stores, no LDS float atomics (slow)
     const int c0 = blockIdx.y * 1024;
     const int cw = min(1024, C - c0);  // columns of this block (128 units: two row slices per 256 threads)
     const int units = cw / 8;
@@ -544,34 +543,36 @@ __global__ __launch_bounds__(TPB) void colsum_kernel(const bf16_t* __restrict__ 
     const int u = threadIdx.x % tu, sl = threadIdx.x / tu;
     const long r0 = (long)blockIdx.x * rows_per_block;
     const long r1 = min(M, r0 + rows_per_block);
-    for (int i = threadIdx.x; i < cw; i += TPB) red[i] = 0.f;
-    __syncthreads();
     if (sl < nslice) {
-        for (int ub = u; ub < units; ub += tu) {
-            const size_t col = (size_t)c0 + ub * 8;
-            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            long r = r0 + sl;
-            for (; r + 3L * nslice < r1; r += 4L * nslice) {
-                float f0[8], f1[8], f2[8], f3[8];
-                load8_split(hi, lo, (size_t)r * C + col, f0);
-                load8_split(hi, lo, (size_t)(r + nslice) * C + col, f1);
-                load8_split(hi, lo, (size_t)(r + 2L * nslice) * C + col, f2);
-                load8_split(hi, lo, (size_t)(r + 3L * nslice) * C + col, f3);
+        // units <= tu here (cw <= 1024 and tu = min(units, 256) with units <= 128), so one pass covers the block's columns
+        const size_t col = (size_t)c0 + u * 8;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        long r = r0 + sl;
+        for (; r + 3L * nslice < r1; r += 4L * nslice) {
+            float f0[8], f1[8], f2[8], f3[8];
+            load8_split(hi, lo, (size_t)r * C + col, f0);
+            load8_split(hi, lo, (size_t)(r + nslice) * C + col, f1);
+            load8_split(hi, lo, (size_t)(r + 2L * nslice) * C + col, f2);
+            load8_split(hi, lo, (size_t)(r + 3L * nslice) * C + col, f3);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] += (f0[j] + f1[j]) + (f2[j] + f3[j]);
-            }
-            for (; r < r1; r += nslice) {
-                float f[8];
-                load8_split(hi, lo, (size_t)r * C + col, f);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] += f[j];
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) atomicAdd(red + ub * 8 + j, acc[j]);
+            for (int j = 0; j < 8; ++j) acc[j] += (f0[j] + f1[j]) + (f2[j] + f3[j]);
         }
+        for (; r < r1; r += nslice) {
+            float f[8];
+            load8_split(hi, lo, (size_t)r * C + col, f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += f[j];
+        }
+        float* dst = red + (size_t)sl * cw + u * 8;
+        *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < cw; i += TPB) atomicAdd(out + c0 + i, red[i]);
+    for (int i = threadIdx.x; i < cw; i += TPB) {
+        float t = 0.f;
+        for (int q = 0; q < nslice; ++q) t += red[(size_t)q * cw + i];
+        atomicAdd(out + c0 + i, t);
+    }
 }
 
 // f32 -> bf16 hi (+ lo)
@@ -626,8 +627,11 @@ __global__ __launch_bounds__(TPB) void bn_stats_kernel(const bf16_t* __restrict_
     const int u = threadIdx.x % tu, sl = threadIdx.x / tu;
     const long r0 = (long)blockIdx.x * rows_per_block;
     const long r1 = min(M, r0 + rows_per_block);
-    for (int i = threadIdx.x; i < 2 * C; i += TPB) red[i] = 0.f;
-    __syncthreads();
+    const bool direct = units <= TPB;  // one column pass: every (slice, column) cell is written exactly once
+    if (!direct) {
+        for (int i = threadIdx.x; i < 2 * C; i += TPB) red[i] = 0.f;
+        __syncthreads();
+    }
     if (sl < nslice) {
         for (int ub = u; ub < units; ub += tu) {
             float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -647,15 +651,25 @@ __global__ __launch_bounds__(TPB) void bn_stats_kernel(const bf16_t* __restrict_
 #pragma unroll
                 for (int j = 0; j < 8; ++j) s[j] += f[j], q[j] = fmaf(f[j], f[j], q[j]);
             }
+            if (direct) {  // slab per row slice: plain stores (LDS float atomics retire a few lanes per cycle)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                atomicAdd(red + ub * 8 + j, s[j]);
-                atomicAdd(red + C + ub * 8 + j, q[j]);
+                for (int j = 0; j < 8; ++j) red[(size_t)sl * 2 * C + ub * 8 + j] = s[j], red[(size_t)sl * 2 * C + C + ub * 8 + j] = q[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    atomicAdd(red + ub * 8 + j, s[j]);
+                    atomicAdd(red + C + ub * 8 + j, q[j]);
+                }
             }
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += TPB) atomicAdd(sums + i, (double)red[i]);
+    for (int i = threadIdx.x; i < 2 * C; i += TPB) {
+        float t = red[i];
+        if (direct)
+            for (int q2 = 1; q2 < nslice; ++q2) t += red[(size_t)q2 * 2 * C + i];
+        atomicAdd(sums + i, (double)t);
+    }
 }
 // finalize: train -> batch statistics (+ running update), eval -> running statistics
 //   scale = gamma*rstd ; shift = beta - mean*scale ; saves mean/rstd for backward
@@ -736,8 +750,11 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const bf16_t* __rest
     const int u = threadIdx.x % tu, sl = threadIdx.x / tu;
     const long r0 = (long)blockIdx.x * rows_per_block;
     const long r1 = min(M, r0 + rows_per_block);
-    for (int i = threadIdx.x; i < 2 * C; i += TPB) red[i] = 0.f;
-    __syncthreads();
+    const bool direct = units <= TPB;  // one column pass: every (slice, column) cell is written exactly once
+    if (!direct) {
+        for (int i = threadIdx.x; i < 2 * C; i += TPB) red[i] = 0.f;
+        __syncthreads();
+    }
     if (sl < nslice) {
         for (int ub = u; ub < units; ub += tu) {
             float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -772,15 +789,25 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const bf16_t* __rest
                     q[j] += dyr * (x[j] - mu[j]) * rs[j];
                 }
             }
+            if (direct) {  // slab per row slice: plain stores (LDS float atomics retire a few lanes per cycle)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                atomicAdd(red + ub * 8 + j, s[j]);
-                atomicAdd(red + C + ub * 8 + j, q[j]);
+                for (int j = 0; j < 8; ++j) red[(size_t)sl * 2 * C + ub * 8 + j] = s[j], red[(size_t)sl * 2 * C + C + ub * 8 + j] = q[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    atomicAdd(red + ub * 8 + j, s[j]);
+                    atomicAdd(red + C + ub * 8 + j, q[j]);
+                }
             }
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += TPB) atomicAdd(sums + i, (double)red[i]);
+    for (int i = threadIdx.x; i < 2 * C; i += TPB) {
+        float t = red[i];
+        if (direct)
+            for (int q2 = 1; q2 < nslice; ++q2) t += red[(size_t)q2 * 2 * C + i];
+        atomicAdd(sums + i, (double)t);
+    }
 }
 // backward pass 2: dx = scale*(dyr - sum_dy/n - xhat*sum_dyxhat/n); also emits dgamma/dbeta once (block 0).
 // Same thread -> fixed-channel-unit walk as the forward apply: six per-channel constants live in registers.
@@ -1012,14 +1039,15 @@ int ig_layernorm_bwd(const void* dy_hi, const void* dy_lo, const float* x, const
     const int rpb = rpb_env > 0 ? rpb_env : 48;  // 8 waves-iterations of 2 rows x 4 waves... measured best of 16..128 (tools/ln_bench.py)
     dim3 grid(ig_cdiv(M, rpb));
     size_t sm = 3 * (size_t)D * sizeof(float);
+    const size_t sm_exact = (LNB_TPB / 64) * sm;  // one slab per wave (plain-store reduction)
 #define IG_LNB_EXACT(NCH_)                                                                                              \
     {                                                                                                                 \
         if (feat_T > 0)                                                                                               \
-            hipLaunchKernelGGL((layernorm_bwd_exact_kernel<NCH_, true>), grid, dim3(LNB_TPB), sm, ST(stream),        \
+            hipLaunchKernelGGL((layernorm_bwd_exact_kernel<NCH_, true>), grid, dim3(LNB_TPB), sm_exact, ST(stream),  \
                                (const bf16_t*)dy_hi, (const bf16_t*)dy_lo, x, mean, rstd, gamma, dx, accumulate,      \
                                (bf16_t*)dxb_hi, (bf16_t*)dxb_lo, dgamma, dbeta, dcol, M, D, rpb, feat_T, feat_G, ntok); \
         else                                                                                                          \
-            hipLaunchKernelGGL((layernorm_bwd_exact_kernel<NCH_, false>), grid, dim3(LNB_TPB), sm, ST(stream),       \
+            hipLaunchKernelGGL((layernorm_bwd_exact_kernel<NCH_, false>), grid, dim3(LNB_TPB), sm_exact, ST(stream), \
                                (const bf16_t*)dy_hi, (const bf16_t*)dy_lo, x, mean, rstd, gamma, dx, accumulate,      \
                                (bf16_t*)dxb_hi, (bf16_t*)dxb_lo, dgamma, dbeta, dcol, M, D, rpb, feat_T, feat_G, ntok); \
         return ig_check_launch("ig_layernorm_bwd");                                                                   \
@@ -1079,6 +1107,11 @@ int ig_patch_grad_prep(const float* dx, void* hi, void* lo, float* dcls, float* 
 
 // rows per workgroup: reductions end in global atomics -> ~768 workgroups (see ig_colsum); streaming apply passes give
 // every thread 8 rows of its channel unit
+// LDS of the BN reductions: one [2C] slab per row slice when a workgroup covers all channels in one pass
+static inline size_t bn_red_bytes(int C) {
+    const int units = C / 8;
+    return (units <= TPB ? (size_t)(TPB / units) : (size_t)1) * 2 * C * sizeof(float);
+}
 static inline int bn_reduce_rows(long M) { return (int)(((M + 767) / 768 + 31) / 32 * 32); }
 static inline int bn_apply_rows(int C) {
     const int units = C / 8, tu = units < TPB ? units : TPB;
@@ -1096,7 +1129,7 @@ int ig_bn_relu_fwd(const void* x_hi, const void* x_lo, const float* gamma, const
     if (training) {
         (void)hipMemsetAsync(sums, 0, 2 * (size_t)C * sizeof(double), ST(stream));
         const int rpb = bn_reduce_rows(M);
-        hipLaunchKernelGGL(bn_stats_kernel, dim3(ig_cdiv(M, rpb)), dim3(TPB), 2 * (size_t)C * sizeof(float), ST(stream), (const bf16_t*)x_hi, (const bf16_t*)x_lo,
+        hipLaunchKernelGGL(bn_stats_kernel, dim3(ig_cdiv(M, rpb)), dim3(TPB), bn_red_bytes(C), ST(stream), (const bf16_t*)x_hi, (const bf16_t*)x_lo,
                            sums, M, C, rpb);
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(ig_cdiv(C, TPB)), dim3(TPB), 0, ST(stream), sums, gamma, beta, running_mean,
@@ -1116,7 +1149,7 @@ int ig_bn_relu_bwd(const void* x_hi, const void* x_lo, const void* dy_hi, const 
     if (M == 0) return IG_OK;
     (void)hipMemsetAsync(sums, 0, 2 * (size_t)C * sizeof(double), ST(stream));
     const int rpb = bn_reduce_rows(M);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ig_cdiv(M, rpb)), dim3(TPB), 2 * (size_t)C * sizeof(float), ST(stream), (const bf16_t*)x_hi, (const bf16_t*)x_lo,
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ig_cdiv(M, rpb)), dim3(TPB), bn_red_bytes(C), ST(stream), (const bf16_t*)x_hi, (const bf16_t*)x_lo,
                        (const bf16_t*)dy_hi, (const bf16_t*)dy_lo, scale, shift, mean, rstd, sums, M, C, rpb);
     const int arpb = bn_apply_rows(C);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ig_cdiv(M, arpb)), dim3(TPB), 0, ST(stream), (const bf16_t*)x_hi,

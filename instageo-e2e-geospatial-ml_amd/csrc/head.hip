@@ -64,13 +64,18 @@ __global__ __launch_bounds__(TPB) void classifier_bwd_kernel(const float* __rest
                                                              float* __restrict__ dw, float* __restrict__ db, const double* count,
                                                              long M, long HW, int C, int ncls, uint32_t drop_seed,
                                                              const uint32_t* drop_seed_dev, uint32_t drop_thresh, float drop_inv,
-                                                             int iters) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];  // w[ncls*C] | dwacc[ncls*C] | dbacc[ncls]
+                                                             int iters, int slab) {
+    // w[ncls*C] | dbacc[ncls] (padded to 4) | dW partials: one [ncls*C] slab per pixel slice when `slab` (plain stores; LDS
+    // float atomics retire only a few lanes per cycle), else a single [ncls*C] accumulated with atomics
+    extern __shared__ __attribute__((aligned(16))) float sm[];
     if (drop_seed_dev) drop_seed += *drop_seed_dev;
     float* sw = sm;
-    float* sdw = sm + ncls * C;
-    float* sdb = sdw + ncls * C;
-    for (int i = threadIdx.x; i < ncls * C; i += TPB) sw[i] = w[i], sdw[i] = 0.f;
+    float* sdb = sm + ncls * C;
+    float* sdw = sdb + ((ncls + 3) & ~3);
+    for (int i = threadIdx.x; i < ncls * C; i += TPB) {
+        sw[i] = w[i];
+        if (!slab) sdw[i] = 0.f;
+    }
     for (int i = threadIdx.x; i < ncls; i += TPB) sdb[i] = 0.f;
     __syncthreads();
     const float gscale = count ? (float)(1.0 / fmax(count[1], 1.0)) : 1.f;
@@ -126,14 +131,25 @@ __global__ __launch_bounds__(TPB) void classifier_bwd_kernel(const float* __rest
 #pragma unroll
         for (int n = 0; n < NC; ++n) {
             if (n < ncls) {
+                if (slab) {
+                    float* dst = sdw + (size_t)sl * ncls * C + n * C + u * 8;
+                    *reinterpret_cast<float4*>(dst) = make_float4(dwa[n][0], dwa[n][1], dwa[n][2], dwa[n][3]);
+                    *reinterpret_cast<float4*>(dst + 4) = make_float4(dwa[n][4], dwa[n][5], dwa[n][6], dwa[n][7]);
+                } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) atomicAdd(sdw + n * C + u * 8 + j, dwa[n][j]);
+                    for (int j = 0; j < 8; ++j) atomicAdd(sdw + n * C + u * 8 + j, dwa[n][j]);
+                }
                 if (u == 0) atomicAdd(sdb + n, dba[n]);
             }
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < ncls * C; i += TPB) atomicAdd(dw + i, sdw[i]);
+    for (int i = threadIdx.x; i < ncls * C; i += TPB) {
+        float t = sdw[i];
+        if (slab)
+            for (int q = 1; q < nsl; ++q) t += sdw[(size_t)q * ncls * C + i];
+        atomicAdd(dw + i, t);
+    }
     for (int i = threadIdx.x; i < ncls; i += TPB) atomicAdd(db + i, sdb[i]);
 }
 
@@ -330,8 +346,10 @@ int ig_classifier_bwd(const float* dlogits, const void* f_hi, const void* f_lo, 
     long M = (long)B * HW;
     if (M == 0) return IG_OK;
     IG_REQUIRE(C / 8 <= TPB, "ig_classifier_bwd: C must be <= %d", TPB * 8);
-    size_t sm = (2 * (size_t)ncls * C + ncls) * sizeof(float);
     const long nsl = TPB / (C / 8);
+    const size_t slab_floats = (size_t)nsl * ncls * C;
+    const int slab = slab_floats * sizeof(float) <= 32768;
+    size_t sm = ((size_t)ncls * C + ((ncls + 3) & ~3) + (slab ? slab_floats : (size_t)ncls * C)) * sizeof(float);
     long iters = (M + nsl * 1024 - 1) / (nsl * 1024);  // ~1k workgroups: one round of dW/db atomics each
     if (iters < 8) iters = 8;
     const long ppb = nsl * iters;  // pixels per block
@@ -339,7 +357,7 @@ int ig_classifier_bwd(const float* dlogits, const void* f_hi, const void* f_lo, 
 #define IG_CLS_BWD(NC)                                                                                                          \
     hipLaunchKernelGGL(classifier_bwd_kernel<NC>, grid, dim3(TPB), sm, (hipStream_t)stream, dlogits, (const bf16_t*)f_hi,       \
                        (const bf16_t*)f_lo, w, (bf16_t*)df_hi, (bf16_t*)df_lo, dw, db, count, M, HW, C, ncls, drop_seed,        \
-                       drop_seed_dev, thresh_of(drop_p), drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, (int)iters)
+                       drop_seed_dev, thresh_of(drop_p), drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, (int)iters, slab)
     if (ncls <= 2) IG_CLS_BWD(2);
     else if (ncls <= 4) IG_CLS_BWD(4);
     else if (ncls <= 8) IG_CLS_BWD(8);
