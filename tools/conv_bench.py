@@ -1,0 +1,21 @@
+import os, sys
+sys.path.insert(0, "/root/repo/instageo-e2e-geospatial-ml_amd")
+import torch
+from instageo_amd import ops
+from instageo_amd.ops import BT
+dev="cuda"
+def timeit(fn,n=10):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    a,b=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b)/n*1e3
+B=108
+for H,C in [(224,48),(112,96),(28,384)]:
+    x=BT(torch.randn(B,H,H,C,device=dev).bfloat16()); w=BT(torch.randn(C,9,C,device=dev).bfloat16()*0.05); bias=torch.zeros(C,device=dev)
+    y=BT.empty((B,H,H,C),False,dev)
+    t=timeit(lambda: ops.conv3x3_fwd(x,w,bias,y,B,H,H,C,C))
+    fl=2.0*B*H*H*C*C*9
+    print(f"conv3x3 fwd H{H} C{C}: {t:8.1f} us {fl/t/1e6:6.0f} TF  dbg={os.environ.get('IG_GEMM_DBG','0')}")
