@@ -67,11 +67,14 @@ __device__ __forceinline__ bf16x8_t read_frag(const char* tile, int row0, int s,
     }
 }
 
+// 64-byte-row K-contiguous image (BK = 32): physical chunk of logical chunk c in row r (conflict-free for ds_read_b128)
+__device__ __forceinline__ int kc32_off(int r, int c) { return r * 64 + ((c ^ ((0x1230 >> (4 * ((r >> 2) & 3))) & 3)) << 4); }
+
 // v1: 4 waves laid out WM x WN (2 x 2, 4 x 1 or 1 x 4), each owning MT x NT MFMA tiles of 16 x 16 => block tile
 // (16 WM MT) x (16 WN NT).  The decode head's channel counts are multiples of 48 (48, 96, 192, 384): 48-, 96- and
 // 64-wide tiles avoid the 25-60 % of wasted MFMA columns (or rows, for the weight gradients) a fixed 128 x 128 tile
 // would spend on them, and the smaller LDS footprint lets a third workgroup share the CU.
-template <class AL, class BL, class EP, bool A_TR, bool B_TR, int NSEG, int MT, int NT, int WM>
+template <class AL, class BL, class EP, bool A_TR, bool B_TR, int NSEG, int MT, int NT, int WM, int BKT = 64>
 __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, int N, int K, int tiles_n, int kchunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -80,8 +83,12 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
     constexpr int BME = WM * MT * 16, BNE = WN * NT * 16;  // block tile
     constexpr int UPA = BME / 8, UPB = BNE / 8;            // 16-byte units per k-row of a TR tile
     constexpr int UPA_L = UPA <= 8 ? 8 : UPA <= 12 ? 12 : 16, UPB_L = UPB <= 8 ? 8 : UPB <= 12 ? 12 : 16;  // LDS row pitch
-    constexpr int NA = (BME * 8 + NTHR - 1) / NTHR, NB = (BNE * 8 + NTHR - 1) / NTHR;  // staged units per thread
-    constexpr int TA_BYTES = A_TR ? 1024 * UPA_L : 128 * BME, TB_BYTES = B_TR ? 1024 * UPB_L : 128 * BNE;
+    // BKT = K-step: 64, or 32 for the small-channel convolutions (half the LDS => twice the resident workgroups; those
+    // tiles have only a few K-steps and every step exposes a global-load round trip, so concurrency is what hides it)
+    constexpr int UPK = BKT / 8;                           // 16-byte units per K-contiguous row
+    constexpr int UA = BME * UPK, UB = BNE * UPK;          // units per operand tile (same count for TR images)
+    constexpr int NA = (UA + NTHR - 1) / NTHR, NB = (UB + NTHR - 1) / NTHR;  // staged units per thread
+    constexpr int TA_BYTES = A_TR ? BKT * 16 * UPA_L : BKT * 2 * BME, TB_BYTES = B_TR ? BKT * 16 * UPB_L : BKT * 2 * BNE;
     constexpr int BUF_BYTES = TA_BYTES + TB_BYTES;
     // XCD-aware tile order: hardware deals consecutive workgroups round-robin over the 8 XCDs (private L2s);
     // remap so that each XCD owns a CONTIGUOUS run of tiles (neighbours share the A row panel / B panels).
@@ -96,7 +103,7 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
     ep.init(blockIdx.z);
     if (al.kdim() >= 0) K = al.kdim();
     // split-K (wgrad): blockIdx.y owns k-tiles [kt0, kt0+nk) of every segment
-    const int nk_all = (K + BK - 1) / BK;
+    const int nk_all = (K + BKT - 1) / BKT;
     const int kt0 = blockIdx.y * kchunk;
     const int nk = min(kchunk, nk_all - kt0);
     if (nk <= 0) return;
@@ -117,14 +124,14 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
     typename BL::Col bcolT[NB];
     if constexpr (!A_TR) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) arow[i] = al.row(bm * BME + ((tid + i * NTHR) >> 3));
+        for (int i = 0; i < NA; ++i) arow[i] = al.row(bm * BME + (tid + i * NTHR) / UPK);
     } else {
 #pragma unroll
         for (int i = 0; i < NA; ++i) acolT[i] = al.col(bm * UPA + (tid + i * NTHR) % UPA);
     }
     if constexpr (!B_TR) {
 #pragma unroll
-        for (int i = 0; i < NB; ++i) brow[i] = bl.row(bn * BNE + ((tid + i * NTHR) >> 3));
+        for (int i = 0; i < NB; ++i) brow[i] = bl.row(bn * BNE + (tid + i * NTHR) / UPK);
     } else {
 #pragma unroll
         for (int i = 0; i < NB; ++i) bcolT[i] = bl.col(bn * UPB + (tid + i * NTHR) % UPB);
@@ -136,25 +143,25 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
     {                                                                                                     \
         const int seg_ = (NSEG == 1) ? 0 : (IT) / nk;                                                     \
         const int kt_ = kt0 + (IT)-seg_ * nk;                                                             \
-        const typename AL::Col acol_ = al.col(kt_ * 8 + (tid & 7));                                       \
+        const typename AL::Col acol_ = al.col(kt_ * UPK + (tid % UPK));                                   \
         _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                  \
             const int u = tid + i * NTHR;                                                                 \
             bool ok;                                                                                      \
             const bf16_t* p;                                                                              \
-            if constexpr (A_TR) p = al.ptr_tr(seg_, kt_ * BK + u / UPA, acolT[i], ok);                    \
+            if constexpr (A_TR) p = al.ptr_tr(seg_, kt_ * BKT + u / UPA, acolT[i], ok);                   \
             else p = al.at(seg_, arow[i], acol_, ok);                                                     \
-            if ((BME * 8) % NTHR) ok = ok && u < BME * 8; /* k-row beyond the tile -> masked by ptr/at too */ \
+            if (UA % NTHR) ok = ok && u < UA; /* unit beyond the tile */                                  \
             uint4 v = *reinterpret_cast<const uint4*>(p);                                                 \
             ra[i] = ok ? v : make_uint4(0, 0, 0, 0);                                                      \
         }                                                                                                 \
-        const typename BL::Col bcol_ = bl.col(kt_ * 8 + (tid & 7));                                       \
+        const typename BL::Col bcol_ = bl.col(kt_ * UPK + (tid % UPK));                                   \
         _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                  \
             const int u = tid + i * NTHR;                                                                 \
             bool ok;                                                                                      \
             const bf16_t* p;                                                                              \
-            if constexpr (B_TR) p = bl.ptr_tr(seg_, kt_ * BK + u / UPB, bcolT[i], ok);                    \
+            if constexpr (B_TR) p = bl.ptr_tr(seg_, kt_ * BKT + u / UPB, bcolT[i], ok);                   \
             else p = bl.at(seg_, brow[i], bcol_, ok);                                                     \
-            if ((BNE * 8) % NTHR) ok = ok && u < BNE * 8;                                                 \
+            if (UB % NTHR) ok = ok && u < UB;                                                             \
             uint4 v = *reinterpret_cast<const uint4*>(p);                                                 \
             rb[i] = ok ? v : make_uint4(0, 0, 0, 0);                                                      \
         }                                                                                                 \
@@ -167,15 +174,15 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
             const int u = tid + i * NTHR;                                                                 \
             int oa;                                                                                       \
             if constexpr (A_TR) oa = lds_trw<UPA_L>(u / UPA, u % UPA);                                    \
-            else oa = lds_kc(u >> 3, u & 7);                                                              \
-            if (((BME * 8) % NTHR) == 0 || u < BME * 8) *reinterpret_cast<uint4*>(ta_ + oa) = ra[i];      \
+            else oa = BKT == 64 ? lds_kc(u >> 3, u & 7) : kc32_off(u >> 2, u & 3);                        \
+            if ((UA % NTHR) == 0 || u < UA) *reinterpret_cast<uint4*>(ta_ + oa) = ra[i];                  \
         }                                                                                                 \
         _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                  \
             const int u = tid + i * NTHR;                                                                 \
             int ob;                                                                                       \
             if constexpr (B_TR) ob = lds_trw<UPB_L>(u / UPB, u % UPB);                                    \
-            else ob = lds_kc(u >> 3, u & 7);                                                              \
-            if (((BNE * 8) % NTHR) == 0 || u < BNE * 8) *reinterpret_cast<uint4*>(tb_ + ob) = rb[i];      \
+            else ob = BKT == 64 ? lds_kc(u >> 3, u & 7) : kc32_off(u >> 2, u & 3);                        \
+            if ((UB % NTHR) == 0 || u < UB) *reinterpret_cast<uint4*>(tb_ + ob) = rb[i];                  \
         }                                                                                                 \
     }
 
@@ -188,12 +195,20 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
         const char* ta = smem + cur * BUF_BYTES;
         const char* tb = ta + TA_BYTES;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < BKT / 32; ++s) {
             bf16x8_t af[MT], bf[NT];
 #pragma unroll
-            for (int t = 0; t < MT; ++t) af[t] = read_frag<A_TR, UPA_L>(ta, wm * (MT * 16) + t * 16, s, lane);
+            for (int t = 0; t < MT; ++t) {
+                if constexpr (!A_TR && BKT == 32)
+                    af[t] = *reinterpret_cast<const bf16x8_t*>(ta + kc32_off(wm * (MT * 16) + t * 16 + (lane & 15), lane >> 4));
+                else af[t] = read_frag<A_TR, UPA_L>(ta, wm * (MT * 16) + t * 16, s, lane);
+            }
 #pragma unroll
-            for (int t = 0; t < NT; ++t) bf[t] = read_frag<B_TR, UPB_L>(tb, wn * (NT * 16) + t * 16, s, lane);
+            for (int t = 0; t < NT; ++t) {
+                if constexpr (!B_TR && BKT == 32)
+                    bf[t] = *reinterpret_cast<const bf16x8_t*>(tb + kc32_off(wn * (NT * 16) + t * 16 + (lane & 15), lane >> 4));
+                else bf[t] = read_frag<B_TR, UPB_L>(tb, wn * (NT * 16) + t * 16, s, lane);
+            }
 #pragma unroll
             for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
@@ -1306,7 +1321,10 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, i
         else nt = code[pick], bn_cols = cand[pick], bm_rows = nt == 1 ? 256 : 128;
     }
     int tm = ig_cdiv(M, bm_rows), tn = ig_cdiv(N, bn_cols);
-    int nk_all = ig_cdiv(K, BK);
+    // K-step 32 for the narrow (<= 96 columns) non-atomic v1 tiles: IG_V1_BK32=0 disables
+    static const int bk32_env = getenv("IG_V1_BK32") ? atoi(getenv("IG_V1_BK32")) : 1;
+    const bool bk32 = ver == 1 && !EP::kStagedAtomic && nt <= 3 && bk32_env;
+    int nk_all = ig_cdiv(K, bk32 ? 32 : BK);
     int ksplit = 1;
     if (allow_ksplit) {  // atomic epilogues only: fill the chip once; every extra split is one more atomic pass
         int tiles = tm * tn * Z;
@@ -1354,12 +1372,12 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, i
         return ig_check_launch(what);
     }
     dim3 block(NTHR);
-#define IG_LAUNCH_V1(NSEG_, MT_, NT_, WM_)                                                                            \
+#define IG_LAUNCH_V1K(NSEG_, MT_, NT_, WM_, BKT_)                                                                      \
     {                                                                                                                  \
-        auto kern = gemm_kernel<AL, BL, EP, A_TR, B_TR, NSEG_, MT_, NT_, WM_>;                                         \
+        auto kern = gemm_kernel<AL, BL, EP, A_TR, B_TR, NSEG_, MT_, NT_, WM_, BKT_>;                                   \
         constexpr int bme_ = WM_ * MT_ * 16, bne_ = (4 / WM_) * NT_ * 16;                                              \
-        constexpr int ta_ = A_TR ? 1024 * tr_pitch(bme_ / 8) : 128 * bme_;                                             \
-        constexpr int tb_ = B_TR ? 1024 * tr_pitch(bne_ / 8) : 128 * bne_;                                             \
+        constexpr int ta_ = A_TR ? BKT_ * 16 * tr_pitch(bme_ / 8) : BKT_ * 2 * bme_;                                   \
+        constexpr int tb_ = B_TR ? BKT_ * 16 * tr_pitch(bne_ / 8) : BKT_ * 2 * bne_;                                   \
         constexpr int ring_ = 2 * (ta_ + tb_), stage_ = EP::kStagedAtomic ? bme_ * 512 : 0;                            \
         constexpr int lds_ = ring_ > stage_ ? ring_ : stage_;                                                          \
         static bool attr_done = false;                                                                                 \
@@ -1369,6 +1387,7 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, i
         }                                                                                                              \
         hipLaunchKernelGGL(kern, grid, block, lds_, st, al, bl, ep, M, N, K, tn, kchunk);                              \
     }
+#define IG_LAUNCH_V1(NSEG_, MT_, NT_, WM_) IG_LAUNCH_V1K(NSEG_, MT_, NT_, WM_, 64)
     if constexpr (EP::kStagedAtomic) {
         if (mt == 1) {  // 48 x 128
             if (split) IG_LAUNCH_V1(3, 3, 2, 1) else IG_LAUNCH_V1(1, 3, 2, 1)
@@ -1376,6 +1395,15 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, i
             if (split) IG_LAUNCH_V1(3, 3, 4, 2) else IG_LAUNCH_V1(1, 3, 4, 2)
         } else {
             if (split) IG_LAUNCH_V1(3, 4, 4, 2) else IG_LAUNCH_V1(1, 4, 4, 2)
+        }
+    } else if (bk32) {
+        // small-channel convolution: K-step 32 (grid / kchunk were computed for it above)
+        if (nt == 1) {
+            if (split) IG_LAUNCH_V1K(3, 4, 3, 4, 32) else IG_LAUNCH_V1K(1, 4, 3, 4, 32)
+        } else if (nt == 2) {
+            if (split) IG_LAUNCH_V1K(3, 4, 2, 2, 32) else IG_LAUNCH_V1K(1, 4, 2, 2, 32)
+        } else {
+            if (split) IG_LAUNCH_V1K(3, 4, 3, 2, 32) else IG_LAUNCH_V1K(1, 4, 3, 2, 32)
         }
     } else {
         if (nt == 1) {  // 256 x 48
@@ -1388,6 +1416,7 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, i
             if (split) IG_LAUNCH_V1(3, 4, 4, 2) else IG_LAUNCH_V1(1, 4, 4, 2)
         }
     }
+#undef IG_LAUNCH_V1K
 #undef IG_LAUNCH_V1
     return ig_check_launch(what);
 }
