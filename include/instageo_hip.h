@@ -128,6 +128,11 @@ int ig_ce_loss(const float* logits, const void* labels, int label_dtype, const f
 /* torch.argmax(dim=1) -> int8                                                           infer_utils.py:99-101 */
 int ig_argmax_i8(const float* logits, signed char* out, int B, long HW, int ncls, void* stream);
 /* RunningConfusionMatrix.update                                                         metrics.py:86-108 */
+/* regression head (regression.py:141-191, metrics.py:330-352): masked MSE (+ log1p label scale) of the
+ * single-channel output: stats double[2] += (sum sq. err, #valid), dpred = 2 (pred - label') un-normalised, msums double[9] =
+ * streaming sums of RunningRegressionMetrics on the de-scaled values {n, Sx, Sy, Sxy, Sxx, Syy, S|e|, See, #within EE} */
+int ig_mse_loss(const float* pred, const float* labels, float ignore_value, int use_log_scale, double* stats, float* dpred,
+                double* msums, float ee_bias, float ee_coef, int include_ee, long n, void* stream);
 /* test-time metrics on the device: RunningAUC histograms of softmax(logits) (metrics.py:214-256 via
  * segmentation.py:153-156; hist = uint64 [2][ncls][nbins], 0 = positives / 1 = negatives of each class, ignored pixels
  * skipped) and predict_step's softmax(logits, 1)[:, cls] (segmentation.py:202-213) */

@@ -286,6 +286,54 @@ __global__ __launch_bounds__(TPB) void softmax_prob_kernel(const float* __restri
     out[m] = zc / se;
 }
 
+// Regression head (regression.py:141-191): masked MSE on the single-channel output, optional log1p label scale,
+// gradient of the mean squared error (left UN-normalised like the CE kernel: dpred = 2 (pred - label'), divide by stats[1]
+// downstream) and the streaming sums of RunningRegressionMetrics (metrics.py:330-352) on the de-scaled values:
+//   msums = { n, sum x, sum y, sum xy, sum x^2, sum y^2, sum |e|, sum e^2, #(|e| <= ee_bias + ee_coef x) }, x = label, y = prediction
+__global__ __launch_bounds__(TPB) void mse_loss_kernel(const float* __restrict__ pred, const float* __restrict__ labels, float ignore_value,
+                                                       int use_log, double* __restrict__ stats, float* __restrict__ dpred,
+                                                       double* __restrict__ msums, float ee_bias, float ee_coef, int include_ee,
+                                                       long M) {
+    __shared__ double red[TPB / 64][10];
+    double a[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [0] = sum of squared error in the (possibly log) training domain
+    for (long m = blockIdx.x * (long)TPB + threadIdx.x; m < M; m += (long)gridDim.x * TPB) {
+        const float lab = labels[m];
+        const bool valid = lab != ignore_value;
+        const float p = pred[m];
+        const float t = use_log ? log1pf(lab) : lab;
+        const float d = p - t;
+        if (dpred) dpred[m] = valid ? 2.f * d : 0.f;
+        if (valid) {
+            a[0] += (double)(d * d);
+            const float y = use_log ? expm1f(p) : p;   // de-scaled prediction
+            const float x = use_log ? expm1f(t) : lab;  // the reference round-trips the label through the scaler too
+            const float e = fabsf(y - x);
+            a[1] += 1.0, a[2] += x, a[3] += y, a[4] += (double)(x * y), a[5] += (double)(x * x), a[6] += (double)(y * y);
+            a[7] += e, a[8] += (double)(e * e);
+            if (include_ee && e <= ee_bias + ee_coef * x) a[9] += 1.0;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        double v = a[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 10) {
+        double t = 0.0;
+        for (int w = 0; w < TPB / 64; ++w) t += red[w][threadIdx.x];
+        const int i = threadIdx.x;
+        if (i == 0) atomicAdd(stats + 0, t);
+        else if (i == 1) {
+            atomicAdd(stats + 1, t);
+            if (msums) atomicAdd(msums + 0, t);
+        } else if (msums) atomicAdd(msums + (i - 1), t);
+    }
+}
+
 // argmax over classes -> int8 class map (infer_utils.py:99-101)
 __global__ void argmax_kernel(const float* __restrict__ logits, signed char* __restrict__ out, long M, long HW, int ncls) {
     long m = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -436,6 +484,18 @@ int ig_softmax_prob(const float* logits, float* out, int B, long HW, int ncls, i
     hipLaunchKernelGGL(softmax_prob_kernel, dim3((unsigned)((M + TPB - 1) / TPB)), dim3(TPB), 0, (hipStream_t)stream, logits, out, M, HW,
                        ncls, cls);
     return ig_check_launch("ig_softmax_prob");
+}
+
+// stats: double[2] += (sum of squared error, #valid); msums: optional double[9] (see the kernel)
+int ig_mse_loss(const float* pred, const float* labels, float ignore_value, int use_log_scale, double* stats, float* dpred,
+                double* msums, float ee_bias, float ee_coef, int include_ee, long n, void* stream) {
+    IG_REQUIRE(pred && labels && stats, "ig_mse_loss: null pointer");
+    if (n == 0) return IG_OK;
+    long nblk = (n + TPB - 1) / TPB;
+    if (nblk > 1024) nblk = 1024;
+    hipLaunchKernelGGL(mse_loss_kernel, dim3((unsigned)nblk), dim3(TPB), 0, (hipStream_t)stream, pred, labels, ignore_value, use_log_scale,
+                       stats, dpred, msums, ee_bias, ee_coef, include_ee, n);
+    return ig_check_launch("ig_mse_loss");
 }
 
 int ig_argmax_i8(const float* logits, signed char* out, int B, long HW, int ncls, void* stream) {

@@ -148,7 +148,8 @@ class SyntheticChipDataset(torch.utils.data.Dataset):
     """
 
     def __init__(self, n: int, temporal: int, num_classes: int, mean, std, im_size: int = 224, ignore_index: int = -1,
-                 constant_multiplier: Optional[float] = 1e-4, seed: int = 1042, device: str = "cuda"):
+                 constant_multiplier: Optional[float] = 1e-4, seed: int = 1042, device: str = "cuda", regression: bool = False):
+        self.regression = regression  # labels = non-negative floats (e.g. aerosol optical depth) instead of class ids
         self.n, self.T, self.k = n, temporal, num_classes
         self.mean, self.std, self.S = list(mean), list(std), im_size
         self.ignore_index, self.mult, self.seed, self.device = ignore_index, constant_multiplier, seed, device
@@ -160,7 +161,10 @@ class SyntheticChipDataset(torch.utils.data.Dataset):
         g = torch.Generator(device=self.device).manual_seed(self.seed + i)
         C = len(self.mean)
         x = torch.randint(0, 10000, (self.T * C, self.S, self.S), generator=g, device=self.device, dtype=torch.int16)
-        y = torch.randint(0, self.k, (self.S, self.S), generator=g, device=self.device).float()
+        if self.regression:
+            y = torch.rand((self.S, self.S), generator=g, device=self.device) * 2.0
+        else:
+            y = torch.randint(0, self.k, (self.S, self.S), generator=g, device=self.device).float()
         y[torch.rand((self.S, self.S), generator=g, device=self.device) < 0.05] = float(self.ignore_index)
         return x, y
 

@@ -5,26 +5,23 @@ from typing import Any, Dict
 
 import torch
 
+from .regression import PrithviRegressionModule
 from .segmentation import PrithviSegmentationModule
 
 
 def create_model(cfg: Dict[str, Any], precision: str = "bf16", device=None) -> PrithviSegmentationModule:
-    """Build the segmentation module from a run.py config; non-train modes load ``checkpoint_path`` strictly
+    """Build the segmentation (or, with ``is_reg_task``, regression) module from a run.py config; non-train modes load ``checkpoint_path`` strictly
     (``torch.load(path)["state_dict"]``, factory.py:113-115)."""
-    if cfg.get("is_reg_task", False):
-        raise NotImplementedError("regression task is outside the hot-path scope (SURVEY.md 8f item 4)")
     if cfg["train"].get("distillation", False):
         raise NotImplementedError("distillation is outside the hot-path scope (SURVEY.md 8f item 4)")
     m, t, d = cfg["model"], cfg["train"], cfg["dataloader"]
     train_mode = cfg["mode"] == "train"
-    model = PrithviSegmentationModule(
+    common = dict(
         image_size=d["img_size"] if train_mode else cfg["test"]["crop_size"],
         learning_rate=t["learning_rate"],
         freeze_backbone=m["freeze_backbone"],
         load_pretrained_weights=bool(m["load_pretrained_weights"]) and train_mode and cfg.get("allow_hub_download", False),
-        num_classes=m["num_classes"],
         temporal_step=d["temporal_dim"],
-        class_weights=t["class_weights"],
         ignore_index=t["ignore_index"],
         weight_decay=t["weight_decay"],
         scheduler=t.get("scheduler", False),
@@ -34,6 +31,11 @@ def create_model(cfg: Dict[str, Any], precision: str = "bf16", device=None) -> P
         precision=precision,
         device=device,
     )
+    if cfg.get("is_reg_task", False):  # factory.py:58-76, 97-104
+        model = PrithviRegressionModule(use_log_scale=m.get("use_log_scale", False), plot_reg_results=m.get("plot_reg_results", False),
+                                        include_ee=m.get("include_ee_metric", False), **common)
+    else:
+        model = PrithviSegmentationModule(num_classes=m["num_classes"], class_weights=t["class_weights"], **common)
     if not train_mode:
         ckpt = cfg.get("checkpoint_path")
         if not ckpt or str(ckpt) == "None":

@@ -14,7 +14,8 @@ import torch
 
 from . import ops
 
-__all__ = ["RunningConfusionMatrix", "RunningAUC", "metrics_from_matrix", "auc_from_histograms"]
+__all__ = ["RunningConfusionMatrix", "RunningAUC", "RunningRegressionMetrics", "metrics_from_matrix", "auc_from_histograms",
+           "regression_metrics_from_sums"]
 
 
 def _safe_div(num: np.ndarray, den: np.ndarray) -> np.ndarray:
@@ -182,3 +183,61 @@ class RunningAUC:
     def reset(self) -> None:
         if self._hist is not None:
             self._hist.zero_()
+
+
+def regression_metrics_from_sums(sums, ee_bias: float = 0.05, ee_coef: float = 0.15, include_ee: bool = False) -> dict:
+    """mae / rmse / r2 / pearson / ee_percentage from the streaming sums {n, Sx, Sy, Sxy, Sxx, Syy, S|e|, See, #EE}
+    (x = truth, y = prediction), the formulas of metrics.py:354-420."""
+    n, sx, sy, sxy, sxx, syy, sae, sse, nee = [float(v) for v in sums]
+    nan = float("nan")
+    mae = sae / n if n else nan
+    rmse = float(np.sqrt(sse / n)) if n else nan
+    r2 = pear = nan
+    if n >= 2:
+        xm, ym = sx / n, sy / n
+        ss_tot = sxx - n * xm * xm
+        r2 = nan if ss_tot == 0 else 1 - sse / ss_tot
+        with np.errstate(invalid="ignore"):
+            std_x, std_y = np.sqrt(sxx - n * xm * xm), np.sqrt(syy - n * ym * ym)
+        pear = nan if std_x == 0 or std_y == 0 else float((sxy - n * xm * ym) / (std_x * std_y))
+    return {"mae": mae, "rmse": rmse, "r2_score": r2, "pearson_corrcoef": pear,
+            "ee_percentage": ((nee / n) * 100 if n else nan) if include_ee else None, "ee_bias": ee_bias, "ee_coef": ee_coef}  # fmt: skip
+
+
+class RunningRegressionMetrics:
+    """Streaming regression metrics (reference: ``metrics.py:288-420``); the nine running sums live on the device and are
+    accumulated by ``ig_mse_loss`` (fused with the loss) or by :meth:`update` for host arrays."""
+
+    def __init__(self, ee_bias: float = 0.05, ee_coef: float = 0.15, include_ee: bool = False, device: Optional[str] = None) -> None:
+        self.ee_bias, self.ee_coef, self.include_ee = ee_bias, ee_coef, include_ee
+        self._device = device
+        self._sums: Optional[torch.Tensor] = None
+
+    def device_sums(self, device=None) -> torch.Tensor:
+        if self._sums is None:
+            self._sums = torch.zeros(9, dtype=torch.float64, device=device or self._device or "cuda")
+        return self._sums
+
+    def update(self, y_true, y_pred) -> None:
+        """Reference signature (host or device arrays of equal shape); no value is ignored here."""
+        yt = torch.as_tensor(np.asarray(y_true) if not torch.is_tensor(y_true) else y_true).reshape(-1).float()
+        yp = torch.as_tensor(np.asarray(y_pred) if not torch.is_tensor(y_pred) else y_pred).reshape(-1).float()
+        if yt.shape != yp.shape:
+            raise ValueError("y_true and y_pred shapes differ.")
+        if yt.numel() == 0:
+            return
+        s = self.device_sums(yt.device if yt.is_cuda else None)
+        scratch = torch.zeros(2, dtype=torch.float64, device=s.device)
+        ops.mse_loss(yp.to(s.device).contiguous(), yt.to(s.device).contiguous(), float("nan"), False, scratch, None, s, self.ee_bias,
+                     self.ee_coef, self.include_ee)
+
+    @property
+    def n(self) -> int:
+        return int(self.device_sums()[0].item())
+
+    def compute(self) -> dict:
+        return regression_metrics_from_sums(self.device_sums().cpu().tolist(), self.ee_bias, self.ee_coef, self.include_ee)
+
+    def reset(self) -> None:
+        if self._sums is not None:
+            self._sums.zero_()

@@ -316,6 +316,16 @@ def ce_loss(logits, labels, class_weights, ignore_index: int, stats, dlogits=Non
           _p(dlogits), _p(preds), _p(preds_i8), _p(confusion), B, HW, ncls, _stream())
 
 
+def mse_loss(pred, labels, ignore_index: float, use_log_scale: bool, stats, dpred=None, msums=None, ee_bias: float = 0.05,
+             ee_coef: float = 0.15, include_ee: bool = False) -> None:
+    """Masked MSE of the regression head + streaming regression-metric sums (regression.py:141-191, metrics.py:330-352)."""
+    n = pred.numel()
+    assert labels.numel() == n and stats.dtype == torch.float64
+    work = float(n) * (8 + (4 if dpred is not None else 0))
+    _call("ig_mse_loss", work, _p(_f32(pred)), _p(_f32(labels)), float(ignore_index), int(use_log_scale), _p(stats), _p(dpred), _p(msums),
+          float(ee_bias), float(ee_coef), int(include_ee), n, _stream())
+
+
 def auc_update(logits, labels, ignore_index: Optional[int], hist, nbins: int, min_score: float = 0.0, max_score: float = 1.0) -> None:
     """RunningAUC histograms of softmax(logits): hist int64 [2, ncls, nbins] (0 positives, 1 negatives of each class)."""
     B, ncls = logits.shape[0], logits.shape[1]

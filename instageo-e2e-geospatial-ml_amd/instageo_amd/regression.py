@@ -1,0 +1,91 @@
+"""Regression module on the same network (reference: ``instageo/model/regression.py:34-343``).
+
+``PrithviRegressionModule`` = the Prithvi encoder + decode head with ONE output channel, masked MSE loss
+(``labels != ignore_index``), optional ``log1p`` label scale, and streaming RMSE / MAE / R2 / Pearson / expected-error
+metrics.  Loss, its gradient and the nine running metric sums come from one kernel (``ig_mse_loss``); everything else
+(forward, backward, AdamW, data parallelism, checkpoint layout) is the segmentation module's fused path.
+"""
+from __future__ import annotations
+
+from typing import Any, List, Optional
+
+import torch
+
+from . import ops
+from .metrics import RunningRegressionMetrics
+from .segmentation import PrithviSegmentationModule
+
+__all__ = ["LogScaler", "PrithviRegressionModule"]
+
+
+class LogScaler:
+    """log1p / expm1 label scale (regression.py:34-61)."""
+
+    def transform(self, x: torch.Tensor) -> torch.Tensor:
+        return torch.log1p(x)
+
+    def inverse_transform(self, x: torch.Tensor) -> torch.Tensor:
+        return torch.expm1(x)
+
+
+class PrithviRegressionModule(PrithviSegmentationModule):
+    """Same constructor surface as the reference (regression.py:67-131); ``num_classes`` is fixed to 1."""
+
+    def __init__(self, image_size: int = 224, learning_rate: float = 1e-4, freeze_backbone: bool = True,
+                 load_pretrained_weights: bool = True, temporal_step: int = 1, ignore_index: int = -100, weight_decay: float = 1e-2,
+                 scheduler: bool = True, model_name: str = "prithvi_eo_v1_100", use_log_scale: bool = False,
+                 plot_reg_results: bool = False, include_ee: bool = False, weight_clip_range: Optional[List[float]] = None,
+                 depth: int = -1, precision: str = "bf16", device: Optional[Any] = None, **kwargs: Any) -> None:
+        super().__init__(image_size=image_size, learning_rate=learning_rate, freeze_backbone=freeze_backbone,
+                         load_pretrained_weights=load_pretrained_weights, num_classes=1, temporal_step=temporal_step,
+                         class_weights=None, ignore_index=ignore_index, weight_decay=weight_decay, scheduler=scheduler,
+                         model_name=model_name, weight_clip_range=weight_clip_range, depth=depth, precision=precision, device=device)
+        if plot_reg_results:
+            raise NotImplementedError("plot_reg_results (matplotlib/seaborn scatter plots) is outside the hot path")
+        self.use_log_scale = use_log_scale
+        self.include_ee = include_ee
+        self.log_scaler = LogScaler()
+        self.train_metrics = RunningRegressionMetrics(include_ee=include_ee)
+        self.val_metrics = RunningRegressionMetrics(include_ee=include_ee)
+        self.test_metrics = RunningRegressionMetrics(include_ee=include_ee)
+
+    @property
+    def num_classes(self) -> int:
+        return 1
+
+    def _fused_loss(self, logits, labels, stats, dlogits, step_type: str) -> None:
+        """outputs.squeeze(1)[mask] vs labels[mask] (log1p-scaled when use_log_scale): MSE mean, metrics on the de-scaled
+        values (regression.py:153-174) -- one kernel; ``stats`` = (sum of squared errors, #valid)."""
+        metrics: RunningRegressionMetrics = getattr(self, f"{step_type}_metrics")
+        ops.mse_loss(logits, labels.to(torch.float32).contiguous(), float(self.ignore_index), self.use_log_scale, stats, dlogits,
+                     metrics.device_sums(logits.device), metrics.ee_bias, metrics.ee_coef, metrics.include_ee)
+
+    def _shared_step(self, batch: Any, step_type: str) -> torch.Tensor:
+        if step_type == "train":
+            raise NotImplementedError("the regression module trains through fused_train_step (no autograd loss function)")
+        inputs, labels = batch
+        stats = self.fused_eval_step(inputs, labels, step_type)
+        return (stats[0] / stats[1]).float()
+
+    def _shared_epoch_end(self, step_type: str) -> None:
+        metrics = getattr(self, f"{step_type}_metrics")
+        m = metrics.compute()
+        acc = self._loss_sums.pop(step_type, None)
+        if acc is not None:
+            self.log(f"{step_type}_loss", (acc[0] / acc[1]).item())
+        self.log(f"{step_type}_RMSE", m["rmse"])
+        self.log(f"{step_type}_MAE", m["mae"])
+        self.log(f"{step_type}_R2", m["r2_score"])
+        self.log(f"{step_type}_Pearson", m["pearson_corrcoef"])
+        if m["ee_percentage"] is not None:
+            self.log(f"{step_type}_EE_Percentage", m["ee_percentage"])
+        metrics.reset()
+
+    def predict_step(self, batch: Any) -> torch.Tensor:
+        """forward(batch).squeeze(1), de-scaled when use_log_scale (regression.py:329-342)."""
+        inputs = batch[0] if isinstance(batch, (tuple, list)) else batch
+        if self.net.training:
+            self.net.eval()
+        with torch.no_grad():
+            pred = self.net.engine.forward(inputs, training=False, save=False).squeeze(1)
+        return self.log_scaler.inverse_transform(pred) if self.use_log_scale else pred

@@ -52,7 +52,8 @@ def create_dataset(spec: Optional[str], cfg: Dict[str, Any], kind: str, device: 
     if str(spec).startswith("synthetic:"):
         n = int(str(spec).split(":")[1])
         size = cfg["test"]["img_size"] if kind == "test" and cfg["mode"] == "eval" else d["img_size"]
-        return SyntheticChipDataset(n, T, ncls, mean, std, im_size=size, ignore_index=ign, constant_multiplier=1e-4, seed=SEED, device=device)
+        return SyntheticChipDataset(n, T, ncls, mean, std, im_size=size, ignore_index=ign, constant_multiplier=1e-4, seed=SEED, device=device,
+                                    regression=bool(cfg.get("is_reg_task", False)))
     path = spec if os.path.isabs(str(spec)) or cfg.get("root_dir") in (None, "None") else os.path.join(cfg["root_dir"], spec)
     z = np.load(path)
     return ArrayChipDataset(z["chips"], z["labels"], mean, std, T, mult, include_filenames=(kind == "test"), device=device)
@@ -74,6 +75,11 @@ def _stack(ds, ids: List[int]) -> Tuple[torch.Tensor, torch.Tensor]:
     return torch.stack([it[0] for it in items]), torch.stack([it[1] for it in items])
 
 
+def _reduce_metrics(metrics, dev) -> None:
+    """Sum the rank-local streaming metric state over ranks (confusion matrix, or the regression sums)."""
+    D.reduce_confusion(metrics.device_matrix(dev) if hasattr(metrics, "device_matrix") else metrics.device_sums(dev))
+
+
 def train(cfg: Dict[str, Any], model, out_dir: str, rank: int, world: int) -> Dict[str, float]:
     dev = str(model.net.store.flat.device)
     train_ds = create_dataset(cfg["train_filepath"], cfg, "train", dev)
@@ -82,7 +88,8 @@ def train(cfg: Dict[str, Any], model, out_dir: str, rank: int, world: int) -> Di
     opt = model.optimizer()
     sched = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(opt, T_0=10, T_mult=2, eta_min=0) if cfg["train"].get("scheduler") else None
     D.attach_data_parallel(model)
-    best, history = -1.0, {}
+    reg = bool(cfg.get("is_reg_task", False))
+    best, history = (-float("inf") if reg else -1.0), {}
     augs = cfg["dataloader"].get("augmentations") or {}
     train_augs = {k: v for k, v in augs.items() if k in ("hflip", "vflip") and v.get("use", False)}
     skipped = [k for k, v in augs.items() if k not in ("hflip", "vflip") and v.get("use", False)]
@@ -98,12 +105,12 @@ def train(cfg: Dict[str, Any], model, out_dir: str, rank: int, world: int) -> Di
             x, y = process_and_augment_batch(xr, yr, train_ds.mean, train_ds.std, train_ds.T, cfg["dataloader"]["img_size"], True,
                                              train_augs, train_ds.mult, aug_gen)
             model.fused_train_step(x, y)
-        D.reduce_confusion(model.train_metrics.device_matrix(dev))
+        _reduce_metrics(model.train_metrics, dev)
         model.on_train_epoch_end()
         for ids in _batches(valid_ds, bs, False, epoch, rank, world):
             x, y = _stack(valid_ds, ids)
             model.fused_eval_step(x, y, "val")
-        D.reduce_confusion(model.val_metrics.device_matrix(dev))
+        _reduce_metrics(model.val_metrics, dev)
         model.on_validation_epoch_end()
         if sched is not None:
             sched.step()
@@ -111,8 +118,10 @@ def train(cfg: Dict[str, Any], model, out_dir: str, rank: int, world: int) -> Di
         history = {k: (float(v) if not isinstance(v, (list, tuple)) else v) for k, v in model.logged.items()}
         if rank == 0:
             print(json.dumps({"epoch": epoch, **{k: round(v, 6) for k, v in history.items() if isinstance(v, float)}}))
-            if history.get("val_IoU", 0.0) > best:  # ModelCheckpoint(monitor="val_IoU", mode="max", save_top_k=1)
-                best = history["val_IoU"]
+            # ModelCheckpoint(monitor = "val_RMSE" (min) for regression else "val_IoU" (max), save_top_k=1)  (run.py:163-164)
+            score = -history.get("val_RMSE", float("inf")) if reg else history.get("val_IoU", 0.0)
+            if score > best:
+                best = score
                 torch.save({"state_dict": model.checkpoint_state_dict(), "epoch": epoch}, os.path.join(out_dir, "instageo_best_checkpoint.ckpt"))
     return history
 
@@ -128,7 +137,7 @@ def evaluate(cfg: Dict[str, Any], model, rank: int, world: int) -> Dict[str, flo
         mult = 1e-4 if hasattr(test_ds, "raw") else None
         x, y = process_test(raw_x, raw_y, d["mean"], d["std"], d["temporal_dim"], t["img_size"], t["crop_size"], t["stride"], mult, dev)
         model.fused_eval_step(x, y, "test")
-    D.reduce_confusion(model.test_metrics.device_matrix(dev))
+    _reduce_metrics(model.test_metrics, dev)
     model.on_test_epoch_end()
     return {k: float(v) for k, v in model.logged.items() if k.startswith("test_") and not isinstance(v, (list, tuple))}
 

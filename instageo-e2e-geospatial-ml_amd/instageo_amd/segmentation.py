@@ -245,11 +245,6 @@ class PrithviSegmentationModule(_Base):
         with torch.no_grad():
             return self._shared_step(batch, "test")
 
-    def predict_step(self, batch: Any) -> torch.Tensor:
-        """softmax probability of class 1 (segmentation.py:202-213)."""
-        with torch.no_grad():
-            prediction = self.forward(batch)
-            return torch.softmax(prediction, dim=1)[:, 1, :, :]
 
     def _shared_epoch_end(self, step_type: str) -> None:
         metrics = getattr(self, f"{step_type}_metrics")
@@ -309,8 +304,7 @@ class PrithviSegmentationModule(_Base):
         if dlog is None or dlog.shape != logits.shape:
             dlog = torch.empty_like(logits)
             ws["dlogits"] = dlog
-        ops.ce_loss(logits, labels.contiguous(), self._weights(), self.ignore_index, stats, dlog, None, None,
-                    self.train_metrics.device_matrix(logits.device))
+        self._fused_loss(logits, labels, stats, dlog, "train")
         g = net.store.ensure_grad()
         g[opt.lo : opt.hi].zero_()
         eng.backward(dlog, count=stats)
@@ -370,13 +364,19 @@ class PrithviSegmentationModule(_Base):
         stats = torch.zeros(2, dtype=torch.float64, device=logits.device)
         if labels.dtype not in (torch.int64, torch.int32, torch.float32):
             labels = labels.long()
+        self._fused_loss(logits, labels, stats, None, step_type)
+        self._accumulate_loss(step_type, (stats[0] / stats[1]).float())
+        return stats
+
+    def _fused_loss(self, logits: torch.Tensor, labels: torch.Tensor, stats: torch.Tensor, dlogits: Optional[torch.Tensor],
+                    step_type: str) -> None:
+        """Loss statistics (+ un-normalised dlogits when training) and the step's streaming metrics, all on the device.
+        Overridden by the regression module."""
         metrics: RunningConfusionMatrix = getattr(self, f"{step_type}_metrics")
-        ops.ce_loss(logits, labels.contiguous(), self._weights(), self.ignore_index, stats, None, None, None,
+        ops.ce_loss(logits, labels.contiguous(), self._weights(), self.ignore_index, stats, dlogits, None, None,
                     metrics.device_matrix(logits.device))
         if step_type == "test":
             self.test_auc.update_from_logits(logits, labels)
-        self._accumulate_loss(step_type, (stats[0] / stats[1]).float())
-        return stats
 
     def predict_step(self, batch: Any) -> torch.Tensor:
         """softmax(forward(batch), dim=1)[:, 1] (segmentation.py:202-213), fused on the device."""

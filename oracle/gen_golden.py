@@ -253,6 +253,20 @@ def main() -> None:
     assert om == sc["roc_auc_macro"] and oper == sc["roc_auc_per_class"], "AUC score oracle mismatch"
     np.savez_compressed(os.path.join(out_dir, "auc.npz"), y_true=ya, probs=pr, pos_hist=ra.pos_hist, neg_hist=ra.neg_hist,
                         macro=np.float64(sc["roc_auc_macro"]), per_class=np.array(sc["roc_auc_per_class"]))
+    # 3c. RunningRegressionMetrics (metrics.py:288-420) on seeded float64 data, streamed in two halves ----------------
+    rng = np.random.default_rng(11)
+    xt = rng.random(3000) * 2.0
+    yp = xt + rng.normal(size=3000) * 0.15
+    rr = ref_metrics.RunningRegressionMetrics(include_ee=True)
+    rr.update(xt[:1200], yp[:1200])
+    rr.update(xt[1200:], yp[1200:])
+    rc = rr.compute()
+    osums = O.regression_sums(xt, yp)
+    om = O.regression_metrics(osums, include_ee=True)
+    for k in ("mae", "rmse", "r2_score", "pearson_corrcoef", "ee_percentage"):
+        assert abs(om[k] - rc[k]) <= 1e-12 * max(1.0, abs(rc[k])), f"regression metric oracle mismatch: {k}"
+    np.savez_compressed(os.path.join(out_dir, "regression.npz"), y_true=xt, y_pred=yp,
+                        metrics=np.array([rc[k] for k in ("mae", "rmse", "r2_score", "pearson_corrcoef", "ee_percentage")]))
     # 4. window origins (process_test semantics: dataloader.py:655-664) --------------------
     wins = {}
     for S in (512, 10980):

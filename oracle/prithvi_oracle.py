@@ -412,6 +412,47 @@ def confusion_metrics(matrix: np.ndarray) -> dict:
 # --------------------------------------------------------------------------------------
 
 
+def regression_loss(outputs: torch.Tensor, labels: torch.Tensor, ignore_index: float, use_log_scale: bool = False):
+    """regression.py:153-168: outputs (B,1,H,W).squeeze(1), mask = labels != ignore_index, labels -> log1p when
+    use_log_scale, MSE mean over the masked pixels; returns (loss, de-scaled predictions, de-scaled labels)."""
+    out = outputs.squeeze(1)
+    mask = labels.ne(ignore_index)
+    lab = torch.log1p(labels) if use_log_scale else labels
+    o, l = out[mask], lab[mask]
+    loss = ((o - l) ** 2).mean()
+    preds, l2 = o.detach(), l
+    if use_log_scale:
+        preds, l2 = torch.expm1(preds), torch.expm1(l2)
+    return loss, preds, l2
+
+
+def regression_sums(y_true: np.ndarray, y_pred: np.ndarray, ee_bias: float = 0.05, ee_coef: float = 0.15) -> List[float]:
+    """metrics.py:330-352 (RunningRegressionMetrics.update) as one batch, accumulated in float64:
+    [n, Sx, Sy, Sxy, Sxx, Syy, S|e|, See, #(|e| <= ee_bias + ee_coef x)]."""
+    x = np.asarray(y_true, dtype=np.float64).ravel()
+    y = np.asarray(y_pred, dtype=np.float64).ravel()
+    e = np.abs(y - x)
+    return [float(x.size), x.sum(), y.sum(), (x * y).sum(), (x * x).sum(), (y * y).sum(), e.sum(), (e * e).sum(),
+            float(np.sum(e <= ee_bias + ee_coef * x))]
+
+
+def regression_metrics(sums: List[float], include_ee: bool = False) -> dict:
+    """metrics.py:354-420: mae, rmse, r2 = 1 - SSE / (Sxx - n xm^2), pearson, expected-error percentage."""
+    n, sx, sy, sxy, sxx, syy, sae, sse, nee = sums
+    nan = float("nan")
+    out = {"mae": sae / n if n else nan, "rmse": float(np.sqrt(sse / n)) if n else nan, "r2_score": nan, "pearson_corrcoef": nan,
+           "ee_percentage": (nee / n * 100 if n else nan) if include_ee else None}
+    if n >= 2:
+        xm, ym = sx / n, sy / n
+        ss_tot = sxx - n * xm * xm
+        if ss_tot != 0:
+            out["r2_score"] = 1 - sse / ss_tot
+        std_x, std_y = np.sqrt(sxx - n * xm * xm), np.sqrt(syy - n * ym * ym)
+        if std_x != 0 and std_y != 0:
+            out["pearson_corrcoef"] = float((sxy - n * xm * ym) / (std_x * std_y))
+    return out
+
+
 def auc_histograms(y_true: np.ndarray, y_score: np.ndarray, num_classes: int, n_bins: int = 1024, min_score: float = 0.0,
                    max_score: float = 1.0) -> Tuple[np.ndarray, np.ndarray]:
     """metrics.py:204-236 (RunningAUC._bin / update): per class c, histogram of the class-c score of the positives

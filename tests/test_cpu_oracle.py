@@ -191,3 +191,21 @@ def test_running_auc_oracle_known_answers_and_fixture():
     pos, neg = O.auc_histograms(np.array([0, 0, 1]), np.array([[0.7, 0.2, 0.1], [0.6, 0.3, 0.1], [0.2, 0.7, 0.1]]), 3, 64)
     macro, per = O.auc_score(pos, neg)
     assert np.isnan(per[2]) and macro == 1.0
+
+
+def test_regression_oracle_matches_reference_fixture():
+    """Regression metrics restatement against the reference RunningRegressionMetrics outputs (gen_golden.py step 3c) and
+    the loss semantics of regression.py:153-168."""
+    z = np.load(os.path.join(GOLD, "regression.npz"))
+    m = O.regression_metrics(O.regression_sums(z["y_true"], z["y_pred"]), include_ee=True)
+    got = np.array([m[k] for k in ("mae", "rmse", "r2_score", "pearson_corrcoef", "ee_percentage")])
+    assert np.allclose(got, z["metrics"], rtol=1e-12, atol=0)
+    out = torch.tensor([[[[1.0, 2.0], [3.0, 4.0]]]])
+    lab = torch.tensor([[[0.0, -100.0], [5.0, 4.0]]])
+    loss, preds, l2 = O.regression_loss(out, lab, -100.0)
+    assert abs(loss.item() - (1.0 + 4.0 + 0.0) / 3) < 1e-6 and preds.tolist() == [1.0, 3.0, 4.0] and l2.tolist() == [0.0, 5.0, 4.0]
+    loss2, preds2, l22 = O.regression_loss(out, lab, -100.0, use_log_scale=True)
+    ref = ((torch.tensor([1.0, 3.0, 4.0]) - torch.log1p(torch.tensor([0.0, 5.0, 4.0]))) ** 2).mean()
+    assert torch.allclose(loss2, ref) and torch.allclose(preds2, torch.expm1(torch.tensor([1.0, 3.0, 4.0])))
+    e = O.regression_metrics([1, 1.0, 1.0, 1.0, 1.0, 1.0, 0.0, 0.0, 1.0])
+    assert np.isnan(e["r2_score"]) and np.isnan(e["pearson_corrcoef"]) and e["mae"] == 0.0

@@ -534,3 +534,46 @@ def test_auc_histograms_and_softmax_prob():
     # predict_step's probability map
     logits = torch.randn(2, 2, 32, 48, generator=torch.Generator().manual_seed(2))
     close(ops.softmax_prob(logits.to(DEV), 1), torch.softmax(logits.double(), 1)[:, 1], 1e-6, what="softmax prob")
+
+
+@pytest.mark.parametrize("use_log", [False, True])
+def test_mse_loss_and_regression_metrics(use_log):
+    """ig_mse_loss (masked MSE + gradient + streaming metric sums) against the oracle restatement of regression.py /
+    RunningRegressionMetrics; the host-array path against the reference fixture."""
+    import os
+
+    from instageo_amd.metrics import RunningRegressionMetrics
+    from oracle import prithvi_oracle as O
+
+    B, H, W = 3, 64, 80
+    g = torch.Generator().manual_seed(41)
+    out = torch.rand(B, 1, H, W, generator=g) * 1.5
+    lab = torch.rand(B, H, W, generator=g) * 2.0
+    lab[torch.rand(B, H, W, generator=g) < 0.1] = -100.0
+    stats = torch.zeros(2, dtype=torch.float64, device=DEV)
+    dl = torch.empty(B, 1, H, W, device=DEV)
+    met = RunningRegressionMetrics(include_ee=True, device=DEV)
+    ops.mse_loss(out.to(DEV), lab.to(DEV), -100.0, use_log, stats, dl, met.device_sums(DEV), met.ee_bias, met.ee_coef, True)
+    od = out.double().clone().requires_grad_(True)
+    loss, preds, l2 = O.regression_loss(od, lab.double(), -100.0, use_log)
+    loss.backward()
+    n = int((lab != -100.0).sum())
+    assert int(stats[1].item()) == n
+    assert abs(stats[0].item() / n - loss.item()) <= 2e-6 * max(1.0, loss.item())  # fp32 arithmetic per element, fp64 sums
+    close(dl / n, od.grad, 2e-6, what="mse grad")
+    ref = O.regression_metrics(O.regression_sums(l2.numpy(), preds.numpy()), include_ee=True)
+    got = met.compute()
+    for k in ("mae", "rmse", "r2_score", "pearson_corrcoef"):
+        assert abs(got[k] - ref[k]) <= 2e-5 * max(1.0, abs(ref[k])), k  # expm1f/log1pf of the device vs torch in float64
+    assert abs(got["ee_percentage"] - ref["ee_percentage"]) <= 0.05  # boundary pixels of |e| <= bias + coef x
+    if not use_log:
+        z = np.load(os.path.join(os.path.dirname(__file__), "golden", "regression.npz"))
+        m2 = RunningRegressionMetrics(include_ee=True, device=DEV)
+        m2.update(z["y_true"][:1200], z["y_pred"][:1200])
+        m2.update(z["y_true"][1200:], z["y_pred"][1200:])
+        c = m2.compute()
+        got2 = np.array([c[k] for k in ("mae", "rmse", "r2_score", "pearson_corrcoef", "ee_percentage")])
+        assert np.allclose(got2, z["metrics"], rtol=5e-6, atol=0.05)  # the device path holds the values in float32
+        assert m2.n == 3000
+        m2.reset()
+        assert m2.n == 0 and np.isnan(m2.compute()["mae"])

@@ -184,3 +184,51 @@ def test_run_train_eval_chip_inference(tmp_path, capsys):
     assert rc == 0 and len(os.listdir(tmp_path / "predictions")) == 3
     with pytest.raises(RuntimeError):
         run.main(["--output-dir", out, "mode=eval", "test_filepath=synthetic:2"] + common)  # checkpoint_path required
+
+
+def test_regression_module_train_step_matches_oracle_and_run_modes(tmp_path, capsys):
+    """is_reg_task: the regression module (one output channel, masked MSE, log scale) against the oracle network + loss in
+    float64, then run.py train/eval with the reference's metric names and val_RMSE checkpointing."""
+    from instageo_amd import run
+    from instageo_amd.regression import PrithviRegressionModule
+
+    mod = PrithviRegressionModule(freeze_backbone=False, load_pretrained_weights=False, model_name="prithvi_eo_tiny", ignore_index=-100,
+                                  use_log_scale=True, include_ee=True, precision="bf16x3", device=DEV)
+    cfg = O.make_config("prithvi_eo_tiny", 1, 1)
+    sd = O.make_state_dict(cfg, seed=5)
+    mod.net.load_state_dict(sd)
+    mod.net.eval()  # BatchNorm running stats + no dropout: deterministic forward for the comparison
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 6, 1, 224, 224, generator=g)
+    y = torch.rand(2, 224, 224, generator=g) * 2
+    y[torch.rand(2, 224, 224, generator=g) < 0.1] = -100.0
+    stats = mod.fused_eval_step(x.to(DEV), y.to(DEV), "val")
+    with torch.no_grad():
+        ref_out = O.prithvi_seg_forward(cfg, {k: v.double() for k, v in sd.items()}, x.double(), training=False)
+    ref_loss, ref_pred, ref_lab = O.regression_loss(ref_out, y.double(), -100.0, True)
+    assert abs(stats[0].item() / stats[1].item() - ref_loss.item()) < 1e-3 * max(1.0, ref_loss.item())  # north_star tolerance
+    pred = mod.predict_step(x.to(DEV))
+    assert pred.shape == (2, 224, 224)
+    assert torch.allclose(pred.cpu().double(), torch.expm1(ref_out.squeeze(1)), rtol=1e-3, atol=1e-3), "regression predict_step"
+    mod.on_validation_epoch_end()
+    assert {"val_loss", "val_RMSE", "val_MAE", "val_R2", "val_Pearson", "val_EE_Percentage"} <= set(mod.logged)
+    ref_m = O.regression_metrics(O.regression_sums(ref_lab.numpy(), ref_pred.numpy()), include_ee=True)
+    assert abs(mod.logged["val_RMSE"] - ref_m["rmse"]) < 1e-3 * max(1.0, ref_m["rmse"])
+    # one fused training step moves the loss down on the same batch
+    l0 = mod.fused_train_step(x.to(DEV), y.to(DEV))
+    l0 = (l0[0] / l0[1]).item()
+    for _ in range(5):
+        l1 = mod.fused_train_step(x.to(DEV), y.to(DEV))
+    assert (l1[0] / l1[1]).item() < l0
+    # run.py surface
+    common = ["is_reg_task=True", "model.model_name=prithvi_eo_tiny", "model.load_pretrained_weights=False", "train.batch_size=2",
+              "model.include_ee_metric=True", f"root_dir={tmp_path}"]
+    out = str(tmp_path / "out")
+    assert run.main(["--output-dir", out, "mode=train", "train.num_epochs=2", "train_filepath=synthetic:4", "valid_filepath=synthetic:2"] + common) == 0
+    ck = os.path.join(out, "instageo_best_checkpoint.ckpt")
+    assert os.path.exists(ck)
+    lines = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    assert len(lines) == 2 and {"train_loss", "train_RMSE", "val_RMSE", "val_MAE", "val_R2", "val_Pearson", "val_EE_Percentage"} <= set(lines[0])
+    assert run.main(["--output-dir", out, "mode=eval", "test_filepath=synthetic:2", f"checkpoint_path={ck}"] + common) == 0
+    res = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1]["Evaluation results"]
+    assert {"test_loss", "test_RMSE", "test_MAE"} <= set(res) and res["test_RMSE"] > 0
