@@ -140,6 +140,19 @@ def process_and_augment(x, y, mean, std, temporal_size: int = 1, im_size: int = 
     return out[0], (None if lab is None else lab[0])
 
 
+def process_label(label, replace_label: Optional[Sequence[float]] = None, reduce_to_zero: bool = False):
+    """``np.where(y == replace_label[0], replace_label[1], y)`` then ``y -= 1`` (dataloader.py:742-746)."""
+    y = label.clone() if torch.is_tensor(label) else np.array(label)
+    if replace_label:
+        if torch.is_tensor(y):
+            y = torch.where(y == replace_label[0], torch.as_tensor(replace_label[1], dtype=y.dtype, device=y.device), y)
+        else:
+            y = np.where(y == replace_label[0], replace_label[1], y)
+    if reduce_to_zero:
+        y = y - 1
+    return y
+
+
 class SyntheticChipDataset(torch.utils.data.Dataset):
     """HLS-shaped synthetic chips generated on the device (there is no network for real data).
 
@@ -182,9 +195,12 @@ class ArrayChipDataset(torch.utils.data.Dataset):
     """Chips/labels held as arrays ``chips (N,T*C,H,W)``, ``labels (N,H,W)`` (stand-in for the GeoTIFF reader)."""
 
     def __init__(self, chips, labels, mean, std, temporal: int = 1, constant_multiplier: Optional[float] = None,
-                 include_filenames: bool = False, names: Optional[List[str]] = None, device: str = "cuda"):
+                 include_filenames: bool = False, names: Optional[List[str]] = None, device: str = "cuda",
+                 replace_label: Optional[Sequence[float]] = None, reduce_to_zero: bool = False):
         assert len(chips) == len(labels)
-        self.chips, self.labels = chips, labels
+        self.chips = chips
+        # label clean-up of process_data (dataloader.py:742-746): value replacement, then shift to start from zero
+        self.labels = [process_label(l, replace_label, reduce_to_zero) for l in labels] if (replace_label or reduce_to_zero) else labels
         self.mean, self.std, self.T, self.mult = list(mean), list(std), temporal, constant_multiplier
         self.include_filenames, self.names, self.device = include_filenames, names, device
 

@@ -56,7 +56,8 @@ def create_dataset(spec: Optional[str], cfg: Dict[str, Any], kind: str, device: 
                                     regression=bool(cfg.get("is_reg_task", False)))
     path = spec if os.path.isabs(str(spec)) or cfg.get("root_dir") in (None, "None") else os.path.join(cfg["root_dir"], spec)
     z = np.load(path)
-    return ArrayChipDataset(z["chips"], z["labels"], mean, std, T, mult, include_filenames=(kind == "test"), device=device)
+    return ArrayChipDataset(z["chips"], z["labels"], mean, std, T, mult, include_filenames=(kind == "test"), device=device,
+                            replace_label=d.get("replace_label"), reduce_to_zero=bool(d.get("reduce_to_zero", False)))
 
 
 def _batches(ds, batch_size: int, shuffle: bool, epoch: int, rank: int, world: int):

@@ -232,3 +232,16 @@ def test_regression_module_train_step_matches_oracle_and_run_modes(tmp_path, cap
     assert run.main(["--output-dir", out, "mode=eval", "test_filepath=synthetic:2", f"checkpoint_path={ck}"] + common) == 0
     res = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1]["Evaluation results"]
     assert {"test_loss", "test_RMSE", "test_MAE"} <= set(res) and res["test_RMSE"] > 0
+
+
+def test_label_cleanup_of_process_data():
+    """replace_label then reduce_to_zero (dataloader.py:742-746) on arrays and tensors, and through ArrayChipDataset."""
+    y = np.array([[-9999, 1, 2], [3, -9999, 1]], dtype=np.float32)
+    exp = np.array([[-2, 0, 1], [2, -2, 0]], dtype=np.float32)
+    assert np.array_equal(DL.process_label(y, [-9999, -1], True), exp)
+    assert torch.equal(DL.process_label(torch.from_numpy(y), [-9999, -1], True), torch.from_numpy(exp))
+    assert np.array_equal(DL.process_label(y), y)
+    chips = np.zeros((1, 6, 224, 224), dtype=np.int16)
+    lab = np.full((1, 224, 224), -9999, dtype=np.float32)
+    ds = DL.ArrayChipDataset(chips, lab, MEAN, STD, 1, 1e-4, device=DEV, replace_label=[-9999, -1])
+    assert float(ds[0][1].min()) == -1.0 and float(lab.min()) == -9999.0  # dataset copy, caller's array untouched
