@@ -68,6 +68,11 @@ def load():
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             f"or `make -C {os.path.join(_PKG_ROOT, 'csrc')}`.  instageo_amd has no CPU fallback."
         )
+    # PyTorch-ROCm bundles its own libamdhip64: it must be the HIP runtime already in the process when this library's
+    # dependency is resolved, otherwise two runtimes coexist and launches here fail with "no ROCm-capable device" on
+    # memory that torch allocated.  (torch is the plumbing for device memory and streams anyway.)
+    import torch  # noqa: F401
+
     lib = ctypes.CDLL(LIB_PATH)
     protos = parse_header()
     for name, (ret, types) in protos.items():
