@@ -128,6 +128,11 @@ int ig_ce_loss(const float* logits, const void* labels, int label_dtype, const f
 /* torch.argmax(dim=1) -> int8                                                           infer_utils.py:99-101 */
 int ig_argmax_i8(const float* logits, signed char* out, int B, long HW, int ncls, void* stream);
 /* RunningConfusionMatrix.update                                                         metrics.py:86-108 */
+/* knowledge distillation (segmentation.py:352-378): KLDivLoss(batchmean)(log_softmax(student),
+ * softmax(teacher)) over the valid pixels: *kl_sum += KL sum, dlogits += softmax(student) - softmax(teacher) (un-normalised,
+ * on top of the cross-entropy gradient written by ig_ce_loss) */
+int ig_kd_loss(const float* student_logits, const float* teacher_logits, const void* labels, int label_dtype, long ignore_index,
+               double* kl_sum, float* dlogits, int B, long HW, int ncls, void* stream);
 /* regression head (regression.py:141-191, metrics.py:330-352): masked MSE (+ log1p label scale) of the
  * single-channel output: stats double[2] += (sum sq. err, #valid), dpred = 2 (pred - label') un-normalised, msums double[9] =
  * streaming sums of RunningRegressionMetrics on the de-scaled values {n, Sx, Sy, Sxy, Sxx, Syy, S|e|, See, #within EE} */

@@ -217,6 +217,55 @@ __global__ __launch_bounds__(TPB) void ce_loss_kernel(const float* __restrict__ 
             if (hist[i]) atomicAdd(confusion + i, (unsigned long long)hist[i]);
 }
 
+// Knowledge-distillation term (segmentation.py:352-378): KLDivLoss(batchmean)(log_softmax(student), softmax(teacher)) over
+// the valid pixels: kl_sum += sum_valid sum_c t_c (log t_c - log s_c); its gradient w.r.t. the student logits,
+// (s_c - t_c) per valid pixel (un-normalised: the shared 1 / #valid is applied downstream like the CE term), is ADDED to
+// dlogits, which ig_ce_loss has filled with the cross-entropy part.
+template <typename LABEL>
+__global__ __launch_bounds__(TPB) void kd_loss_kernel(const float* __restrict__ student, const float* __restrict__ teacher,
+                                                      const LABEL* __restrict__ labels, long ignore_index, double* __restrict__ kl_sum,
+                                                      float* __restrict__ dlogits, long M, long HW, int ncls) {
+    __shared__ double red[TPB / 64];
+    double my = 0.0;
+    for (long m = blockIdx.x * (long)TPB + threadIdx.x; m < M; m += (long)gridDim.x * TPB) {
+        if ((long)labels[m] == ignore_index) continue;
+        const long b = m / HW, pix = m - b * HW;
+        float zs[MAXC], zt[MAXC];
+        float ms = -INFINITY, mt = -INFINITY;
+#pragma unroll
+        for (int n = 0; n < MAXC; ++n)
+            if (n < ncls) {
+                zs[n] = student[(b * ncls + n) * HW + pix];
+                zt[n] = teacher[(b * ncls + n) * HW + pix];
+                ms = fmaxf(ms, zs[n]), mt = fmaxf(mt, zt[n]);
+            }
+        float ses = 0.f, set = 0.f;
+#pragma unroll
+        for (int n = 0; n < MAXC; ++n)
+            if (n < ncls) ses += __expf(zs[n] - ms), set += __expf(zt[n] - mt);
+        const float lses = ms + __logf(ses), lset = mt + __logf(set);
+        float kl = 0.f;
+#pragma unroll
+        for (int n = 0; n < MAXC; ++n)
+            if (n < ncls) {
+                const float lt = zt[n] - lset, ls = zs[n] - lses;
+                const float t = __expf(lt);
+                kl += t * (lt - ls);
+                if (dlogits) dlogits[(b * ncls + n) * HW + pix] += __expf(ls) - t;
+            }
+        my += (double)kl;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) my += __shfl_xor(my, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = my;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < TPB / 64; ++w) t += red[w];
+        atomicAdd(kl_sum, t);
+    }
+}
+
 // K16b streaming ROC-AUC histograms (metrics.py:214-256, called with softmax probabilities at segmentation.py:153-156):
 // for every valid pixel and class c: bin = int((clamp(p_c, lo, hi) - lo) / (hi - lo) * (nbins - 1)) in float32 (numpy 2
 // scalar arithmetic on float32 probabilities), hist[y == c ? 0 : 1][c][bin] += 1.  The reference does this in a Python
@@ -441,6 +490,32 @@ int ig_ce_loss(const float* logits, const void* labels, int label_dtype, const f
         return IG_ERR_UNSUPPORTED;
     }
     return ig_check_launch("ig_ce_loss");
+}
+
+// kl_sum: device double += KL sum over valid pixels; dlogits (optional) += softmax(student) - softmax(teacher) on valid pixels
+int ig_kd_loss(const float* student_logits, const float* teacher_logits, const void* labels, int label_dtype, long ignore_index,
+               double* kl_sum, float* dlogits, int B, long HW, int ncls, void* stream) {
+    IG_REQUIRE(student_logits && teacher_logits && labels && kl_sum, "ig_kd_loss: null pointer");
+    IG_REQUIRE(ncls >= 1 && ncls <= MAXC, "ig_kd_loss: 1 <= ncls <= %d (got %d)", MAXC, ncls);
+    const long M = (long)B * HW;
+    if (M == 0) return IG_OK;
+    long nblk = (M + TPB - 1) / TPB;
+    if (nblk > 1024) nblk = 1024;
+    hipStream_t st = (hipStream_t)stream;
+    if (label_dtype == 0)
+        hipLaunchKernelGGL(kd_loss_kernel<long long>, dim3((unsigned)nblk), dim3(TPB), 0, st, student_logits, teacher_logits,
+                           (const long long*)labels, ignore_index, kl_sum, dlogits, M, HW, ncls);
+    else if (label_dtype == 1)
+        hipLaunchKernelGGL(kd_loss_kernel<int>, dim3((unsigned)nblk), dim3(TPB), 0, st, student_logits, teacher_logits, (const int*)labels,
+                           ignore_index, kl_sum, dlogits, M, HW, ncls);
+    else if (label_dtype == 2)
+        hipLaunchKernelGGL(kd_loss_kernel<float>, dim3((unsigned)nblk), dim3(TPB), 0, st, student_logits, teacher_logits,
+                           (const float*)labels, ignore_index, kl_sum, dlogits, M, HW, ncls);
+    else {
+        ig_set_error("ig_kd_loss: unsupported label dtype %d", label_dtype);
+        return IG_ERR_UNSUPPORTED;
+    }
+    return ig_check_launch("ig_kd_loss");
 }
 
 // hist: device uint64 [2][ncls][nbins] (0 = positives of class c, 1 = negatives); label_dtype as ig_ce_loss

@@ -6,14 +6,12 @@ from typing import Any, Dict
 import torch
 
 from .regression import PrithviRegressionModule
-from .segmentation import PrithviSegmentationModule
+from .segmentation import PrithviDistillationSegmentationModule, PrithviSegmentationModule
 
 
 def create_model(cfg: Dict[str, Any], precision: str = "bf16", device=None) -> PrithviSegmentationModule:
     """Build the segmentation (or, with ``is_reg_task``, regression) module from a run.py config; non-train modes load ``checkpoint_path`` strictly
     (``torch.load(path)["state_dict"]``, factory.py:113-115)."""
-    if cfg["train"].get("distillation", False):
-        raise NotImplementedError("distillation is outside the hot-path scope (SURVEY.md 8f item 4)")
     m, t, d = cfg["model"], cfg["train"], cfg["dataloader"]
     train_mode = cfg["mode"] == "train"
     common = dict(
@@ -31,7 +29,15 @@ def create_model(cfg: Dict[str, Any], precision: str = "bf16", device=None) -> P
         precision=precision,
         device=device,
     )
-    if cfg.get("is_reg_task", False):  # factory.py:58-76, 97-104
+    distill = bool(t.get("distillation", False)) and train_mode
+    if distill and cfg.get("is_reg_task", False):
+        raise NotImplementedError("distillation of the regression task is outside the hot-path scope (SURVEY.md 8f item 4)")
+    if distill:  # factory.py:84-91: frozen teacher from train.teacher_ckpt_path, student of model.depth blocks
+        common_d = {k: v for k, v in common.items() if k != "depth"}
+        model = PrithviDistillationSegmentationModule(teacher_ckpt_path=t["teacher_ckpt_path"], num_classes=m["num_classes"],
+                                                      class_weights=t["class_weights"], depth=t.get("teacher_depth", -1),
+                                                      student_depth=m.get("depth", -1), **common_d)
+    elif cfg.get("is_reg_task", False):  # factory.py:58-76, 97-104
         model = PrithviRegressionModule(use_log_scale=m.get("use_log_scale", False), plot_reg_results=m.get("plot_reg_results", False),
                                         include_ee=m.get("include_ee_metric", False), **common)
     else:

@@ -316,6 +316,16 @@ def ce_loss(logits, labels, class_weights, ignore_index: int, stats, dlogits=Non
           _p(dlogits), _p(preds), _p(preds_i8), _p(confusion), B, HW, ncls, _stream())
 
 
+def kd_loss(student_logits, teacher_logits, labels, ignore_index: Optional[int], kl_sum, dlogits=None) -> None:
+    """KLDivLoss(batchmean) numerator over the valid pixels into ``kl_sum`` (f64 [1]); ``dlogits`` += softmax(s) - softmax(t)."""
+    B, ncls = student_logits.shape[0], student_logits.shape[1]
+    HW = student_logits.numel() // (B * ncls)
+    assert teacher_logits.shape == student_logits.shape and kl_sum.dtype == torch.float64
+    ign = -(2**62) if ignore_index is None else int(ignore_index)
+    _call("ig_kd_loss", float(B) * HW * ncls * 12, _p(_f32(student_logits)), _p(_f32(teacher_logits)), _p(labels), _LABEL_DT[labels.dtype], ign,
+          _p(kl_sum), _p(dlogits), B, HW, ncls, _stream())
+
+
 def mse_loss(pred, labels, ignore_index: float, use_log_scale: bool, stats, dpred=None, msums=None, ee_bias: float = 0.05,
              ee_coef: float = 0.15, include_ee: bool = False) -> None:
     """Masked MSE of the regression head + streaming regression-metric sums (regression.py:141-191, metrics.py:330-352)."""

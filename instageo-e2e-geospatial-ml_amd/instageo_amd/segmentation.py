@@ -400,3 +400,70 @@ class PrithviSegmentationModule(_Base):
         self.net.load_state_dict(net_sd, strict=strict)
         if "criterion.weight" in sd and self._weights() is not None:
             self.criterion.weight.copy_(sd["criterion.weight"])
+
+
+class PrithviDistillationSegmentationModule(PrithviSegmentationModule):
+    """Knowledge distillation (reference: ``segmentation.py:216-451``, ``base.py:234-334``): a frozen teacher of ``depth``
+    blocks loaded from ``teacher_ckpt_path`` and a student (normally shallower, ``student_depth``); loss = CE(student)
+    + KLDivLoss(batchmean)(log_softmax(student), softmax(teacher)) over the valid pixels.  The KL term and its gradient come
+    from ``ig_kd_loss`` on top of the fused CE kernel; the teacher runs the inference path of the same engine.
+
+    Differences from the reference surface: ``student_depth`` is explicit (the reference passes the student depth through
+    ``**kwargs`` of ``PrithviSeg``); the student's head keeps this package's seeded initialisation.
+    """
+
+    def __init__(self, teacher_ckpt_path: str, image_size: int = 224, learning_rate: float = 1e-4, num_classes: int = 2,
+                 temporal_step: int = 1, class_weights: Optional[List[float]] = None, ignore_index: int = -100,
+                 weight_decay: float = 1e-2, model_name: str = "prithvi_eo_v1_100", depth: int = -1, student_depth: int = -1,
+                 load_pretrained_weights: bool = True, scheduler: bool = True, weight_clip_range: Optional[List[float]] = None,
+                 freeze_backbone: bool = False, precision: str = "bf16", device: Optional[Any] = None, **kwargs: Any) -> None:
+        super().__init__(image_size=image_size, learning_rate=learning_rate, freeze_backbone=freeze_backbone,
+                         load_pretrained_weights=False, num_classes=num_classes, temporal_step=temporal_step,
+                         class_weights=class_weights, ignore_index=ignore_index, weight_decay=weight_decay, scheduler=scheduler,
+                         model_name=model_name, weight_clip_range=weight_clip_range, depth=student_depth, precision=precision,
+                         device=device)
+        self.teacher = PrithviSegmentationModule(image_size=image_size, learning_rate=learning_rate, freeze_backbone=True,
+                                                 load_pretrained_weights=False, num_classes=num_classes, temporal_step=temporal_step,
+                                                 class_weights=class_weights, ignore_index=ignore_index, weight_decay=weight_decay,
+                                                 scheduler=scheduler, model_name=model_name, depth=depth, precision=precision,
+                                                 device=device)
+        sd = torch.load(teacher_ckpt_path, map_location="cpu")["state_dict"]
+        # old checkpoints name the encoder "prithvi_100M_backbone" (segmentation.py:333-337)
+        sd = {k.replace("prithvi_100M_backbone", "prithvi_encoder"): v for k, v in sd.items()}
+        self.teacher.load_checkpoint_state_dict(sd, strict=True)
+        self.teacher.net.eval()
+        for p_ in self.teacher.parameters():
+            p_.requires_grad_(False)
+        if load_pretrained_weights:  # shared encoder tensors of equal shape are copied into the student (base.py:312-324)
+            t_sd = {k: v for k, v in self.teacher.net.state_dict().items() if k.startswith("prithvi_encoder.")}
+            s_sd = self.net.state_dict()
+            shared = {k: v for k, v in t_sd.items() if k in s_sd and v.shape == s_sd[k].shape}
+            self.net.load_state_dict({**s_sd, **shared}, strict=True)
+        self._kl = torch.zeros(1, dtype=torch.float64, device=self.net.store.flat.device)
+
+    def _fused_loss(self, logits, labels, stats, dlogits, step_type: str) -> None:
+        super()._fused_loss(logits, labels, stats, dlogits, step_type)  # CE statistics, CE gradient, confusion matrix, AUC
+        with torch.no_grad():
+            t_logits = self.teacher.net.engine.forward(self._last_inputs, training=False, save=False)
+        self._kl.zero_()
+        ops.kd_loss(logits, t_logits, labels.contiguous(), self.ignore_index, self._kl, dlogits)
+        # total = (ce_sum + kl_sum) / #valid: fold the KL numerator into the loss statistic; keep the parts for logging
+        self._parts = (stats[0].clone(), self._kl[0].clone(), stats[1].clone())
+        stats[0] += self._kl[0]
+
+    def fused_train_step(self, inputs, labels, stats=None, grad_scale_world: int = 1):
+        self._last_inputs = inputs
+        out = super().fused_train_step(inputs, labels, stats, grad_scale_world)
+        self._log_parts("train")
+        return out
+
+    def fused_eval_step(self, inputs, labels, step_type: str = "val"):
+        self._last_inputs = inputs
+        out = super().fused_eval_step(inputs, labels, step_type)
+        self._log_parts(step_type)
+        return out
+
+    def _log_parts(self, step_type: str) -> None:
+        ce, kl, n = self._parts
+        self.log(f"{step_type}_ce_loss", (ce / n).item())
+        self.log(f"{step_type}_distill_loss", (kl / n).item())

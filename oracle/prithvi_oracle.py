@@ -412,6 +412,22 @@ def confusion_metrics(matrix: np.ndarray) -> dict:
 # --------------------------------------------------------------------------------------
 
 
+def distillation_loss(student_logits: torch.Tensor, teacher_logits: torch.Tensor, labels: torch.Tensor, ignore_index: int,
+                      class_weights: Optional[torch.Tensor] = None):
+    """segmentation.py:352-378 (_compute_loss): ce = CrossEntropyLoss(weight, ignore_index, 'none')[valid].mean();
+    distill = KLDivLoss('batchmean')(log_softmax(student[valid]), softmax(teacher[valid])) = sum / #valid;
+    returns (total, ce, distill)."""
+    k = student_logits.shape[1]
+    lab = labels.long()
+    ce = F.cross_entropy(student_logits, lab, weight=class_weights, ignore_index=ignore_index, reduction="none")
+    valid = lab.ne(ignore_index).reshape(-1)
+    s = student_logits.permute(0, 2, 3, 1).reshape(-1, k)[valid]
+    t = teacher_logits.permute(0, 2, 3, 1).reshape(-1, k)[valid]
+    ce = ce.reshape(-1)[valid].mean()
+    distill = F.kl_div(F.log_softmax(s, dim=1), F.softmax(t, dim=1), reduction="batchmean")
+    return ce + distill, ce, distill
+
+
 def regression_loss(outputs: torch.Tensor, labels: torch.Tensor, ignore_index: float, use_log_scale: bool = False):
     """regression.py:153-168: outputs (B,1,H,W).squeeze(1), mask = labels != ignore_index, labels -> log1p when
     use_log_scale, MSE mean over the masked pixels; returns (loss, de-scaled predictions, de-scaled labels)."""

@@ -209,3 +209,17 @@ def test_regression_oracle_matches_reference_fixture():
     assert torch.allclose(loss2, ref) and torch.allclose(preds2, torch.expm1(torch.tensor([1.0, 3.0, 4.0])))
     e = O.regression_metrics([1, 1.0, 1.0, 1.0, 1.0, 1.0, 0.0, 0.0, 1.0])
     assert np.isnan(e["r2_score"]) and np.isnan(e["pearson_corrcoef"]) and e["mae"] == 0.0
+
+
+def test_distillation_loss_restatement():
+    """CE + KLDiv(batchmean) of segmentation.py:352-378 on a hand-checkable case."""
+    s_log = torch.tensor([[[[0.0, 2.0]], [[0.0, 0.0]]]])  # (1, 2, 1, 2): pixel 0 logits (0,0), pixel 1 logits (2,0)
+    t_log = torch.tensor([[[[0.0, 0.0]], [[0.0, 2.0]]]])  # teacher: pixel 0 (0,0), pixel 1 (0,2)
+    lab = torch.tensor([[[1.0, -1.0]]])                   # pixel 1 ignored
+    total, ce, kd = O.distillation_loss(s_log, t_log, lab, -1)
+    assert abs(ce.item() - np.log(2.0)) < 1e-6 and abs(kd.item()) < 1e-7  # same distribution on the only valid pixel
+    lab2 = torch.tensor([[[1.0, 0.0]]])
+    total, ce, kd = O.distillation_loss(s_log.double(), t_log.double(), lab2, -1)
+    p = np.exp(2) / (1 + np.exp(2))
+    kl_pix1 = (1 - p) * (np.log(1 - p) - np.log(p)) + p * (np.log(p) - np.log(1 - p))  # t = (1-p, p), s = (p, 1-p)
+    assert abs(kd.item() - kl_pix1 / 2) < 1e-12 and abs(total.item() - (ce + kd).item()) < 1e-15

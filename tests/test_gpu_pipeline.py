@@ -245,3 +245,41 @@ def test_label_cleanup_of_process_data():
     lab = np.full((1, 224, 224), -9999, dtype=np.float32)
     ds = DL.ArrayChipDataset(chips, lab, MEAN, STD, 1, 1e-4, device=DEV, replace_label=[-9999, -1])
     assert float(ds[0][1].min()) == -1.0 and float(lab.min()) == -9999.0  # dataset copy, caller's array untouched
+
+
+def test_distillation_module_loss_gradient_and_run(tmp_path, capsys):
+    """train.distillation: the KL kernel against the oracle (loss parts and the gradient w.r.t. the student logits), then a
+    teacher checkpoint -> student run through run.py."""
+    from instageo_amd import run
+
+    B, ncls, H, W = 2, 3, 32, 40
+    g = torch.Generator().manual_seed(3)
+    s_log = torch.randn(B, ncls, H, W, generator=g)
+    t_log = torch.randn(B, ncls, H, W, generator=g) * 1.5
+    lab = torch.randint(-1, ncls, (B, H, W), generator=g)
+    cw = torch.tensor([1.0, 2.0, 0.5])
+    stats = torch.zeros(2, dtype=torch.float64, device=DEV)
+    kl = torch.zeros(1, dtype=torch.float64, device=DEV)
+    dl = torch.empty(B, ncls, H, W, device=DEV)
+    ops.ce_loss(s_log.to(DEV), lab.to(DEV), cw.to(DEV), -1, stats, dl)
+    ops.kd_loss(s_log.to(DEV), t_log.to(DEV), lab.to(DEV), -1, kl, dl)
+    sd_ = s_log.double().clone().requires_grad_(True)
+    total, ce, kd = O.distillation_loss(sd_, t_log.double(), lab, -1, cw.double())
+    total.backward()
+    n = stats[1].item()
+    assert abs(stats[0].item() / n - ce.item()) < 1e-5 and abs(kl.item() / n - kd.item()) < 1e-5
+    assert torch.allclose((dl / n).cpu().double(), sd_.grad, atol=2e-6), "CE + KD gradient"
+    # run.py: train a 4-block tiny teacher, then distil into a 2-block student
+    common = ["model.model_name=prithvi_eo_tiny", "model.load_pretrained_weights=False", "train.batch_size=2", "train.ignore_index=-1",
+              "train.class_weights=[1,3]", f"root_dir={tmp_path}", "train.num_epochs=1", "train_filepath=synthetic:4", "valid_filepath=synthetic:2"]
+    t_out, s_out = str(tmp_path / "teacher"), str(tmp_path / "student")
+    assert run.main(["--output-dir", t_out, "mode=train"] + common) == 0
+    ck = os.path.join(t_out, "instageo_best_checkpoint.ckpt")
+    capsys.readouterr()
+    assert run.main(["--output-dir", s_out, "mode=train", "train.distillation=True", f"train.teacher_ckpt_path={ck}", "model.depth=2"] + common) == 0
+    line = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1]
+    assert {"train_loss", "train_ce_loss", "train_distill_loss", "val_distill_loss", "val_IoU"} <= set(line)
+    assert abs(line["val_loss"] - (line["val_ce_loss"] + line["val_distill_loss"])) < 0.3  # epoch mean vs last-step parts
+    s_sd = torch.load(os.path.join(s_out, "instageo_best_checkpoint.ckpt"))["state_dict"]
+    assert "net.prithvi_encoder.blocks.1.attn.qkv.weight" in s_sd and "net.prithvi_encoder.blocks.2.attn.qkv.weight" not in s_sd
+    assert not any(k.startswith("teacher.") for k in s_sd)
