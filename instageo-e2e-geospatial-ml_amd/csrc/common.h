@@ -40,8 +40,14 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     return __builtin_bit_cast(bf16_t, b);
 }
 
-// pack two floats into one dword of 2 x bf16 (lo = a, hi = b)
-__device__ __forceinline__ uint32_t pack_bf2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+// pack two floats into one dword of 2 x bf16 (lo = a, hi = b): ONE v_cvt_pk_bf16_f32 (converting the halves separately and
+// or-ing them costs two conversions plus a shift/or -- and every epilogue packs 64 values per lane)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32pair_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf2(float a, float b) {
+    const f32pair_t f = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
+}
 
 __device__ __forceinline__ void unpack8(const uint4& u, float* f) {
     f[0] = __uint_as_float(u.x << 16);
