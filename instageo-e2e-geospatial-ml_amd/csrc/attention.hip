@@ -185,6 +185,7 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const bf16_t* __restrict
         // base-2 domain: p = exp2(s*c - m) with c = scale*log2(e) folded into one fma per element (v_exp_f32 IS exp2);
         // the key < N mask is only evaluated on the tail tile
         if (kt * KT + KT > N) {
+            asm volatile("" ::: "memory");  // keep this a (uniform) branch: if-converted, the 7 compares + selects ran on every tile
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
@@ -340,10 +341,15 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dq_kernel(const bf16_t* __restr
                 bf16x8_t vl = SPLIT ? frag_rows(v_lo, sub * 16, s, lane) : vh;
                 dp = mma<SPLIT>(vh, vl, dh[s], dl[s], dp);
             }
+            if (tail) {  // keys beyond N: S = -inf -> P = 0 (a real branch: the selects would otherwise run on every tile)
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kt * KT + sub * 16 + 4 * g + r >= N) st[r] = -INFINITY;
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float p = __builtin_amdgcn_exp2f(fmaf(st[r], c2, -my_lse));
-                if (tail && kt * KT + sub * 16 + 4 * g + r >= N) p = 0.f;
+                const float p = __builtin_amdgcn_exp2f(fmaf(st[r], c2, -my_lse));
                 ds[sub][r] = p * (dp[r] - my_delta);  // the softmax scale is applied once to the finished dQ tile
             }
         }
