@@ -485,17 +485,11 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dkv_kernel(const bf16_t* __rest
     }
 }
 
-// Workgroup geometry.  cfg 0: up to 16 waves per workgroup (one workgroup per (b, h) for N = 197), 4 tiles per group;
-// cfg 1/2: up to 8 waves, 2 / 4 tiles per group (several smaller workgroups per CU overlap each other's fill/drain).
-inline int attn_cfg() {
-    static int cfg = getenv("IG_ATTN_CFG") ? atoi(getenv("IG_ATTN_CFG")) : 0;
-    return cfg;
-}
+// Workgroup geometry: up to 16 waves (one 16-row tile each) per workgroup, i.e. one workgroup per (batch, head) for N = 197
+// (13 waves) and three for N = 589.  Smaller workgroups (2-3 per CU) measured slower: the kernels are issue-bound per tile.
 inline void wave_geometry(int N, int& nblk, int& nw) {
-    int tiles = (N + 15) / 16;
-    static int maxw_env = getenv("IG_ATTN_MAXW") ? atoi(getenv("IG_ATTN_MAXW")) : 0;
-    const int maxw = attn_cfg() == 0 ? 16 : (maxw_env > 0 && maxw_env <= 8 ? maxw_env : 8);
-    nblk = (tiles + maxw - 1) / maxw;
+    const int tiles = (N + 15) / 16;
+    nblk = (tiles + 15) / 16;
     nw = (tiles + nblk - 1) / nblk;
 }
 
@@ -517,13 +511,8 @@ int ig_attention_fwd(const void* qkv_hi, const void* qkv_lo, void* out_hi, void*
 #define IG_ATTN_FWD(SPLIT_, NTL_, MAXT_)                                                                                     \
     hipLaunchKernelGGL((attn_fwd_kernel<SPLIT_, NTL_, MAXT_>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)qkv_hi,       \
                        (const bf16_t*)qkv_lo, (bf16_t*)out_hi, (bf16_t*)out_lo, lse, N, H, scale)
-    const int cfg = attn_cfg();
-    if (qkv_lo) {
-        if (cfg == 0) IG_ATTN_FWD(true, 2, 1024);
-        else IG_ATTN_FWD(true, 2, 512);
-    } else if (cfg == 0) IG_ATTN_FWD(false, 4, 1024);
-    else if (cfg == 1) IG_ATTN_FWD(false, 2, 512);
-    else IG_ATTN_FWD(false, 4, 512);
+    if (qkv_lo) IG_ATTN_FWD(true, 2, 1024);
+    else IG_ATTN_FWD(false, 4, 1024);
 #undef IG_ATTN_FWD
     return ig_check_launch("ig_attention_fwd");
 }
@@ -555,12 +544,8 @@ int ig_attention_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi,
                            (const bf16_t*)qkv_lo, (const bf16_t*)dout_hi, (const bf16_t*)dout_lo, lse, delta, (bf16_t*)dqkv_hi,  \
                            (bf16_t*)dqkv_lo, N, H, scale);                                                                    \
     }
-    const int cfg = attn_cfg();
-    if (split) {
-        if (cfg == 0) IG_ATTN_BWD(true, 2, 1024) else IG_ATTN_BWD(true, 2, 512)
-    } else if (cfg == 0) IG_ATTN_BWD(false, 4, 1024)
-    else if (cfg == 1) IG_ATTN_BWD(false, 2, 512)
-    else IG_ATTN_BWD(false, 4, 512)
+    if (split) IG_ATTN_BWD(true, 2, 1024)
+    else IG_ATTN_BWD(false, 4, 1024)
 #undef IG_ATTN_BWD
     return ig_check_launch("ig_attention_bwd");
 }

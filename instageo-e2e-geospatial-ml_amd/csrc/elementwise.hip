@@ -1075,7 +1075,8 @@ int ig_colsum(const void* hi, const void* lo, float* out, long M, int C, void* s
     // ~768 workgroups in total: fewer leave HBM idle, more are bound by the final global atomics (measured, tools/colsum_bench.py)
     const long cchunks = ig_cdiv(C, 1024);
     int rpb = (int)(((M * cchunks + 767) / 768 + 31) / 32 * 32);
-    if (const char* e = getenv("IG_COLSUM_BLOCKS")) rpb = (int)(((M * cchunks + atoi(e) - 1) / atoi(e) + 31) / 32 * 32);
+    static const int blocks_env = getenv("IG_COLSUM_BLOCKS") ? atoi(getenv("IG_COLSUM_BLOCKS")) : 0;  // tuning knob (tools/colsum_bench.py)
+    if (blocks_env > 0) rpb = (int)(((M * cchunks + blocks_env - 1) / blocks_env + 31) / 32 * 32);
     hipLaunchKernelGGL(colsum_kernel, dim3(ig_cdiv(M, rpb), ig_cdiv(C, 1024)), dim3(TPB), 0, ST(stream), (const bf16_t*)hi, (const bf16_t*)lo, out, M,
                        C, rpb);
     return ig_check_launch("ig_colsum");

@@ -23,4 +23,4 @@ for B, N, H in [(108, 197, 12), (36, 589, 12), (54, 197, 16)]:
     tf = timeit(lambda: ops.attention_fwd(qkv, out, lse, B, N, H))
     tb = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H))
     fl = 4.0 * B * H * N * N * 64
-    print(f"B{B} N{N} H{H}: fwd {tf:7.1f} us ({fl/tf/1e6:5.0f} TF)  bwd {tb:7.1f} us ({2.5*fl/tb/1e6:5.0f} TF)  cfg={os.environ.get('IG_ATTN_CFG','0')} maxw={os.environ.get('IG_ATTN_MAXW','-')}")
+    print(f"B{B} N{N} H{H}: fwd {tf:7.1f} us ({fl/tf/1e6:5.0f} TF)  bwd {tb:7.1f} us ({2.5*fl/tb/1e6:5.0f} TF)  ")
