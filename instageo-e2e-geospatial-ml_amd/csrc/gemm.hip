@@ -1267,6 +1267,16 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, i
     // v2 (256x128, LDS-DMA ring) wins on the encoder linears; the head convolutions (Cout 48..384, huge M) are
     // better served by the 128x128 register-staged tile at 2 workgroups/CU until a narrow-N tile exists
     int ver = force_ver ? force_ver : gemm_version();
+    if (!gemm_env() && !EP::kStagedAtomic && AL::kLinearK && BL::kLinearK) {
+        // small problems (e.g. the YAML's batch 16: M = 3152 rows): the big tiles leave most CUs idle -- a 256x256 tile
+        // needs >= 192 tiles to be worth one workgroup per CU, a 256x128 tile >= 256; below that the 128x128 engine's
+        // 2-4x larger tile count wins (measured at B = 16: fc2 94.9 us on v5)
+        if (ver == 5 && (long)ig_cdiv(M, 256) * ig_cdiv(N, 256) < 192) ver = 2;
+        if (ver == 2 && (long)ig_cdiv(M, 256) * ig_cdiv(N, 128) < 256) ver = 1;
+    }
+    if constexpr (EP::kColSum) {
+        if (ver == 1 && ep.colsum) ver = 2;  // the fused column sums live in the v2 / v5 epilogues only
+    }
     if constexpr (AL::kLinearK && BL::kLinearK) {
         if (ver == 5) {
             const int tm5 = ig_cdiv(M, 256), tn5 = ig_cdiv(N, 256), ntiles = tm5 * tn5;
