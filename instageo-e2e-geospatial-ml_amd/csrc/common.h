@@ -21,6 +21,10 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 // host side ------------------------------------------------------------------------------------
 void ig_set_error(const char* fmt, ...);
 int ig_check_launch(const char* what);
+// conv_direct.hip: IG_ERR_UNSUPPORTED (no error string) when the shape is not covered
+int ig_conv3x3_direct(const void* x, const void* w, const float* bias, const float* bn_scale, const float* bn_shift, void* y,
+                      int B, int H, int W, int Cin, int Cout, int dgrad, unsigned drop_seed, const unsigned* drop_seed_dev,
+                      float drop_p, void* stream);
 
 #define IG_REQUIRE(cond, ...)          \
     do {                               \

@@ -1,0 +1,239 @@
+// Direct (halo-tile) 3x3 pad-1 convolution for the narrow last stage of the decode head (C = Cin = Cout = 48), gfx950.
+//   model.py:370-375 nn.Conv2d(C, C, kernel_size=3, padding=1) of the 224 x 224 x 48 stage, forward and data gradient.
+//
+// Why not the implicit GEMM of gemm.hip: at 48 output channels a 256 x 48 GEMM tile is 10.6 MFLOP, and gathering its
+// A operand (every input pixel is fetched for 9 taps), re-reading the 41 KiB of weights per tile, the per-tile address
+// decode and the 21 k tile launches cost more than its MFMAs.  Here
+//   * the whole weight tensor Wc[C][9*C] sits in LDS for the lifetime of a persistent workgroup,
+//   * a workgroup walks 16 x 16-pixel output tiles; the 18 x 18 x C input halo of a tile is staged ONCE in LDS (zero-filled
+//     outside the image) and all 9 taps read it from there,
+//   * the reduction index is k = tap * C + c, consumed 32 at a time by v_mfma_f32_16x16x32_bf16: a lane's 8-element
+//     k-group never straddles a tap (C % 8 == 0), so its operand is ONE ds_read_b128 at  pixel(row + dy, col + dx) * pitch
+//     + c * 2; the (dy, dx, c) part of that address is tile-independent and precomputed per lane and K-step,
+//   * pixel pitch 2C + 16 bytes and weight pitch 64 * KSTEPS + 16 bytes make every ds_read_b128 bank-conflict free,
+//   * the next tile's halo is prefetched into registers while the current tile's MFMAs run; two workgroups per CU
+//     (2 x 80 KiB of LDS) overlap one's LDS fill / epilogue with the other's MFMAs.
+// The data gradient is the same kernel over dy with the weights gathered as W'[ci][8 - tap][co] at LDS-fill time.
+// Results are those of the implicit-GEMM path up to fp32 summation order (same bf16 operands, fp32 accumulation).
+#include "common.h"
+
+namespace {
+
+constexpr int CD_TPB = 256;
+constexpr int TH = 16, TW = 16;    // output tile
+constexpr int HH = TH + 2, HW_ = TW + 2;  // halo
+
+template <int C>
+struct CDCfg {
+    static constexpr int KG = 9 * C / 8;            // 8-element k-groups
+    static constexpr int KSTEPS = (KG + 3) / 4;     // K-steps of 32
+    static constexpr int NB = C / 16;               // 16-wide output-channel blocks
+    static constexpr int WP = KSTEPS * 64 + 16;     // weight row pitch (bytes)
+    static constexpr int PP = 2 * C + 16;           // halo pixel pitch (bytes)
+    static constexpr int W_BYTES = C * WP;
+    static constexpr int H_BYTES = HH * HW_ * PP;
+    static constexpr int UNITS = C / 8;              // 16-byte units per pixel
+    static constexpr int HUNITS = HH * HW_ * UNITS;  // 16-byte units per halo
+    static constexpr int ROUNDS = (HUNITS + CD_TPB - 1) / CD_TPB;
+    static constexpr int SMEM = W_BYTES + H_BYTES + 16;  // + one zero slot for the padded k-groups
+};
+
+struct CDParams {
+    const bf16_t* x;   // [B][H][W][C] input (forward) or dy (data gradient)
+    const bf16_t* w;   // Wc[C][9][C]
+    bf16_t* y;         // [B][H][W][C]
+    const float* bias;                    // optional, forward
+    const float *col_scale, *col_shift;   // optional eval-mode BatchNorm + ReLU, forward
+    int B, H, W;
+    int tiles_x, tiles_y;
+    long ntiles;
+    int dgrad;  // 1: weights gathered transposed + flipped
+    uint32_t drop_seed, drop_thresh;
+    const uint32_t* drop_seed_dev;
+    float drop_inv;
+};
+
+template <int C>
+__global__ __launch_bounds__(CD_TPB, 2) void conv3x3_direct_kernel(CDParams p) {
+    using G = CDCfg<C>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* wl = smem;
+    char* hal = smem + G::W_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t drop_seed = p.drop_seed;
+    if (p.drop_seed_dev) drop_seed += *p.drop_seed_dev;
+
+    // ---- weights -> LDS (once per workgroup); pad k-groups and the zero slot are cleared first
+    for (int i = tid; i < (G::W_BYTES + G::H_BYTES + 16) / 16; i += CD_TPB) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    if (!p.dgrad) {
+        for (int u = tid; u < C * G::KG; u += CD_TPB) {
+            const int co = u / G::KG, g = u - co * G::KG;
+            *reinterpret_cast<uint4*>(wl + co * G::WP + g * 16) = *reinterpret_cast<const uint4*>(p.w + ((size_t)co * G::KG + g) * 8);
+        }
+    } else {
+        // W'[ci][tap'][co] = Wc[co][8 - tap'][ci]: 2-byte gathers, once per workgroup (L2-resident 41 KiB)
+        for (int e = tid; e < C * 9 * C; e += CD_TPB) {
+            const int co = e % C, r = e / C, tap = r % 9, ci = r / 9;
+            reinterpret_cast<bf16_t*>(wl + ci * G::WP)[tap * C + co] = p.w[((size_t)co * 9 + (8 - tap)) * C + ci];
+        }
+    }
+
+    // ---- tile-independent per-thread tables
+    // halo fill: unit u = round * 256 + tid -> (halo pixel, 16-byte unit)
+    int h_lds[G::ROUNDS], h_goff[G::ROUNDS], h_yx[G::ROUNDS];
+#pragma unroll
+    for (int r = 0; r < G::ROUNDS; ++r) {
+        const int u = r * CD_TPB + tid;
+        const int hp = u / G::UNITS, c8 = u - hp * G::UNITS;
+        const int hy = hp / HW_, hx = hp - hy * HW_;
+        h_lds[r] = hp * G::PP + c8 * 16;
+        h_goff[r] = ((hy - 1) * p.W + (hx - 1)) * C + c8 * 8;
+        h_yx[r] = u < G::HUNITS ? ((hy - 1) << 16) | ((hx - 1) & 0xffff) : 0x7fff0000;  // sentinel row: never inside the image
+    }
+    // operand reads: pixel-side address of this lane's k-group per K-step (relative to the px-block's first pixel)
+    const int g = lane >> 4, j = lane & 15;
+    int offk[G::KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < G::KSTEPS; ++ks) {
+        const int kg = ks * 4 + g;
+        const int tap = kg / G::UNITS, cg = kg - tap * G::UNITS;
+        const int dy = tap / 3, dx = tap - dy * 3;
+        offk[ks] = (dy * HW_ + dx) * G::PP + cg * 16;
+    }
+    const int pix_lane = ((wave * 4) * HW_ + j) * G::PP;              // px-block 0 of this wave, pixel j
+    const int zero_slot = G::H_BYTES;                                  // relative to hal
+    const char* wl_lane = wl + j * G::WP + g * 16;
+
+    auto tile_coords = [&](long t, int& b, int& ty0, int& tx0) {
+        const int per_img = p.tiles_x * p.tiles_y;
+        b = (int)(t / per_img);
+        const int r = (int)(t - (long)b * per_img);
+        const int ty = r / p.tiles_x;
+        ty0 = ty * TH, tx0 = (r - ty * p.tiles_x) * TW;
+    };
+    uint4 pre[G::ROUNDS];
+    auto fetch = [&](long t) {
+        int b, ty0, tx0;
+        tile_coords(t, b, ty0, tx0);
+        const bf16_t* base = p.x + (((size_t)b * p.H + ty0) * p.W + tx0) * C;
+#pragma unroll
+        for (int r = 0; r < G::ROUNDS; ++r) {
+            const int gy = ty0 + (h_yx[r] >> 16), gx = tx0 + (int)(short)(h_yx[r] & 0xffff);
+            const bool ok = ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
+            pre[r] = make_uint4(0, 0, 0, 0);
+            if (ok) pre[r] = *reinterpret_cast<const uint4*>(base + h_goff[r]);
+        }
+    };
+
+    long t = blockIdx.x;
+    if (t < p.ntiles) fetch(t);
+    for (; t < p.ntiles; t += gridDim.x) {
+        // ---- halo registers -> LDS
+#pragma unroll
+        for (int r = 0; r < G::ROUNDS; ++r)
+            if (r * CD_TPB + tid < G::HUNITS) *reinterpret_cast<uint4*>(hal + h_lds[r]) = pre[r];
+        __syncthreads();
+        int b, ty0, tx0;
+        tile_coords(t, b, ty0, tx0);
+        const long tn = t + gridDim.x;
+        if (tn < p.ntiles) fetch(tn);  // next tile's halo in flight under this tile's MFMAs
+
+        // ---- 4 px-blocks (rows 4*wave .. +3 of the tile) x NB channel blocks per wave
+        f32x4 acc[G::NB][4];
+#pragma unroll
+        for (int nb = 0; nb < G::NB; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) acc[nb][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < G::KSTEPS; ++ks) {
+            bf16x8_t wf[G::NB], pf[4];
+            int po = pix_lane + offk[ks];
+            if (G::KG % 4 != 0 && ks == G::KSTEPS - 1 && g >= G::KG % 4) po = zero_slot;  // padded k-groups read zeros
+#pragma unroll
+            for (int nb = 0; nb < G::NB; ++nb) wf[nb] = *reinterpret_cast<const bf16x8_t*>(wl_lane + nb * 16 * G::WP + ks * 64);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const int o = (G::KG % 4 != 0 && ks == G::KSTEPS - 1 && g >= G::KG % 4) ? po : po + mb * HW_ * G::PP;
+                pf[mb] = *reinterpret_cast<const bf16x8_t*>(hal + o);
+            }
+#pragma unroll
+            for (int nb = 0; nb < G::NB; ++nb)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], pf[mb], acc[nb][mb], 0, 0, 0);
+        }
+
+        // ---- epilogue: lane holds channels nb*16 + 4g .. +3 of pixel (row 4*wave + mb, column j)
+        const int ox = tx0 + j;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const int oy = ty0 + wave * 4 + mb;
+            if (oy < p.H && ox < p.W) {
+                const size_t pix = ((size_t)b * p.H + oy) * p.W + ox;
+#pragma unroll
+                for (int nb = 0; nb < G::NB; ++nb) {
+                    const int n = nb * 16 + 4 * g;
+                    float v[4] = {acc[nb][mb][0], acc[nb][mb][1], acc[nb][mb][2], acc[nb][mb][3]};
+                    if (p.bias) {
+                        const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+                        v[0] += bb.x, v[1] += bb.y, v[2] += bb.z, v[3] += bb.w;
+                    }
+                    if (p.col_scale) {
+                        const float4 sc = *reinterpret_cast<const float4*>(p.col_scale + n);
+                        const float4 sh = *reinterpret_cast<const float4*>(p.col_shift + n);
+                        v[0] = fmaxf(v[0] * sc.x + sh.x, 0.f), v[1] = fmaxf(v[1] * sc.y + sh.y, 0.f);
+                        v[2] = fmaxf(v[2] * sc.z + sh.z, 0.f), v[3] = fmaxf(v[3] * sc.w + sh.w, 0.f);
+                    }
+                    const size_t idx = pix * C + n;
+                    if (p.drop_thresh) {
+                        float mk[4];
+                        dropout_scale4(drop_seed, (uint32_t)idx, p.drop_thresh, p.drop_inv, mk);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] *= mk[i];
+                    }
+                    store4_split(p.y, nullptr, idx, v);
+                }
+            }
+        }
+        __syncthreads();  // every wave is done with the halo before the next tile overwrites it
+    }
+}
+
+template <int C>
+int launch_direct(const CDParams& p, hipStream_t st, const char* what) {
+    using G = CDCfg<C>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_direct_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
+        attr_done = true;
+    }
+    static const int nwg_env = getenv("IG_CONV_DIRECT_WGS") ? atoi(getenv("IG_CONV_DIRECT_WGS")) : 0;
+    long nwg = nwg_env > 0 ? nwg_env : 512;  // two persistent workgroups per CU
+    if (nwg > p.ntiles) nwg = p.ntiles;
+    hipLaunchKernelGGL(conv3x3_direct_kernel<C>, dim3((unsigned)nwg), dim3(CD_TPB), G::SMEM, st, p);
+    return ig_check_launch(what);
+}
+
+}  // namespace
+
+// Called by ig_conv3x3_fwd / ig_conv3x3_dgrad (gemm.hip) for the shapes this kernel covers; returns IG_ERR_UNSUPPORTED
+// (without setting the error string) when it does not, and the caller falls through to the implicit GEMM.
+int ig_conv3x3_direct(const void* x, const void* w, const float* bias, const float* bn_scale, const float* bn_shift, void* y,
+                      int B, int H, int W, int Cin, int Cout, int dgrad, unsigned drop_seed, const unsigned* drop_seed_dev,
+                      float drop_p, void* stream) {
+    static const int enabled = getenv("IG_CONV_DIRECT") ? atoi(getenv("IG_CONV_DIRECT")) : 1;
+    if (!enabled || Cin != Cout || Cin != 48) return IG_ERR_UNSUPPORTED;
+    if ((long)B * H * W * Cin >= (1L << 31)) return IG_ERR_UNSUPPORTED;  // 32-bit halo offsets
+    CDParams p{};
+    p.x = (const bf16_t*)x, p.w = (const bf16_t*)w, p.y = (bf16_t*)y;
+    p.bias = bias, p.col_scale = bn_scale, p.col_shift = bn_shift;
+    p.B = B, p.H = H, p.W = W;
+    p.tiles_x = (W + TW - 1) / TW, p.tiles_y = (H + TH - 1) / TH;
+    p.ntiles = (long)B * p.tiles_x * p.tiles_y;
+    p.dgrad = dgrad;
+    p.drop_seed = drop_seed, p.drop_seed_dev = drop_seed_dev;
+    p.drop_thresh = ig_drop_thresh16(drop_p);
+    p.drop_inv = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    if (p.ntiles == 0) return IG_OK;
+    return launch_direct<48>(p, (hipStream_t)stream, dgrad ? "ig_conv3x3_dgrad(direct)" : "ig_conv3x3_fwd(direct)");
+}

@@ -1538,6 +1538,11 @@ int ig_conv3x3_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const v
     IG_REQUIRE(x_hi && w_hi && y_hi, "ig_conv3x3_fwd: null pointer");
     IG_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, "ig_conv3x3_fwd: channels must be multiples of 8");
     IG_SPLIT_CONSISTENT(x_lo, w_lo);
+    IG_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "ig_conv3x3_fwd: bn_scale and bn_shift go together");
+    if (!x_lo && !y_lo) {  // narrow last stage: halo-tile direct convolution (conv_direct.hip)
+        const int rc = ig_conv3x3_direct(x_hi, w_hi, bias, bn_scale, bn_shift, y_hi, B, H, W, Cin, Cout, 0, 0, nullptr, 0.f, stream);
+        if (rc != IG_ERR_UNSUPPORTED) return rc;
+    }
     Conv3Loader al{};
     seg_a(al.base, x_hi, x_lo);
     al.Mtot = B * H * W, al.H = H, al.W = W, al.C = Cin, al.sign = 1;
@@ -1558,6 +1563,12 @@ int ig_conv3x3_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, con
     IG_REQUIRE(dy_hi && w_hi && dx_hi, "ig_conv3x3_dgrad: null pointer");
     IG_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, "ig_conv3x3_dgrad: channels must be multiples of 8");
     IG_SPLIT_CONSISTENT(dy_lo, w_lo);
+    IG_REQUIRE(drop_p <= 0.f || (double)B * H * W * Cin < 4294967296.0, "ig_conv3x3_dgrad: dropout needs < 2^32 elements");
+    if (!dy_lo && !dx_lo) {
+        const int rc = ig_conv3x3_direct(dy_hi, w_hi, nullptr, nullptr, nullptr, dx_hi, B, H, W, Cin, Cout, 1, drop_seed, drop_seed_dev,
+                                         drop_p, stream);
+        if (rc != IG_ERR_UNSUPPORTED) return rc;
+    }
     Conv3Loader al{};
     seg_a(al.base, dy_hi, dy_lo);
     al.Mtot = B * H * W, al.H = H, al.W = W, al.C = Cout, al.sign = -1;

@@ -11,27 +11,60 @@ namespace {
 constexpr int TPB = 256;
 constexpr int MAXC = 16;  // max classes held in registers
 
+// Copy `total` 16-byte units (units per pixel row) from global to LDS rows of `pitch` bytes: consecutive threads take
+// consecutive units; four loads are in flight per thread before the LDS stores.
+__device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ src, char* dst, int total, int units, int pitch) {
+    for (int base = threadIdx.x; base < total; base += TPB * 4) {
+        uint4 b0 = make_uint4(0, 0, 0, 0), b1 = b0, b2 = b0, b3 = b0;
+        const int u0 = base, u1 = base + TPB, u2 = base + 2 * TPB, u3 = base + 3 * TPB;
+        if (u0 < total) b0 = *reinterpret_cast<const uint4*>(src + (size_t)u0 * 8);
+        if (u1 < total) b1 = *reinterpret_cast<const uint4*>(src + (size_t)u1 * 8);
+        if (u2 < total) b2 = *reinterpret_cast<const uint4*>(src + (size_t)u2 * 8);
+        if (u3 < total) b3 = *reinterpret_cast<const uint4*>(src + (size_t)u3 * 8);
+        if (u0 < total) *reinterpret_cast<uint4*>(dst + (u0 / units) * pitch + (u0 % units) * 16) = b0;
+        if (u1 < total) *reinterpret_cast<uint4*>(dst + (u1 / units) * pitch + (u1 % units) * 16) = b1;
+        if (u2 < total) *reinterpret_cast<uint4*>(dst + (u2 / units) * pitch + (u2 % units) * 16) = b2;
+        if (u3 < total) *reinterpret_cast<uint4*>(dst + (u3 / units) * pitch + (u3 % units) * 16) = b3;
+    }
+}
+
 // logits[b][n][pix] = bias[n] + sum_c drop(f[b][pix][c]) * w[n][c]
+// One thread per pixel, but the workgroup's 256 pixels x C channels are first copied to LDS with fully coalesced 16-byte
+// loads (a thread reading its own 96-byte pixel row straight from global touched 48 cache lines per wave-instruction);
+// LDS rows are padded to C*2 + 16 bytes to spread the per-pixel ds_read_b128 over the banks.
 __global__ __launch_bounds__(TPB) void classifier_fwd_kernel(const bf16_t* __restrict__ f_hi, const bf16_t* __restrict__ f_lo,
                                                              const float* __restrict__ w, const float* __restrict__ bias,
                                                              float* __restrict__ logits, long M, long HW, int C, int ncls,
                                                              uint32_t drop_seed, const uint32_t* drop_seed_dev, uint32_t drop_thresh,
                                                              float drop_inv) {
-    extern __shared__ float sw[];  // [ncls][C] + [ncls]
+    extern __shared__ __attribute__((aligned(16))) float sw[];  // [ncls][C] + [ncls] (padded to 4) | staged pixels (hi [, lo])
     if (drop_seed_dev) drop_seed += *drop_seed_dev;
+    const int units = C / 8, pitch = C * 2 + 16;  // bytes per staged pixel row
+    char* stage = reinterpret_cast<char*>(sw + ncls * C + ((ncls + 3) & ~3));
     for (int i = threadIdx.x; i < ncls * C; i += TPB) sw[i] = w[i];
     for (int i = threadIdx.x; i < ncls; i += TPB) sw[ncls * C + i] = bias[i];
+    const long m0 = blockIdx.x * (long)TPB;
+    const int npix = (int)min((long)TPB, M - m0);
+    stage_rows(f_hi + (size_t)m0 * C, stage, npix * units, units, pitch);
+    if (f_lo) stage_rows(f_lo + (size_t)m0 * C, stage + (size_t)TPB * pitch, npix * units, units, pitch);
     __syncthreads();
-    long m = blockIdx.x * (long)TPB + threadIdx.x;
+    const long m = m0 + threadIdx.x;
     if (m >= M) return;
     float acc[MAXC];
 #pragma unroll
     for (int n = 0; n < MAXC; ++n) acc[n] = n < ncls ? sw[ncls * C + n] : 0.f;
-    for (int c8 = 0; c8 < C / 8; ++c8) {
+    const char* row = stage + threadIdx.x * pitch;
+    for (int c8 = 0; c8 < units; ++c8) {
         float f[8];
-        size_t idx = (size_t)m * C + c8 * 8;
-        load8_split(f_hi, f_lo, idx, f);
+        unpack8(*reinterpret_cast<const uint4*>(row + c8 * 16), f);
+        if (f_lo) {
+            float g[8];
+            unpack8(*reinterpret_cast<const uint4*>(row + (size_t)TPB * pitch + c8 * 16), g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] += g[j];
+        }
         if (drop_thresh) {
+            const size_t idx = (size_t)m * C + c8 * 8;
             float mk[8];
             dropout_scale4(drop_seed, (uint32_t)idx, drop_thresh, drop_inv, mk);
             dropout_scale4(drop_seed, (uint32_t)idx + 4u, drop_thresh, drop_inv, mk + 4);
@@ -156,7 +189,7 @@ __global__ __launch_bounds__(TPB) void classifier_bwd_kernel(const float* __rest
 // stats[0] += sum w_y*nll over valid pixels ; stats[1] += #valid.  dlogits (optional) is left UN-normalised:
 // dl[n] = w_y*(softmax_n - [n==y]) (0 on ignored pixels); divide by stats[1] downstream.
 // preds (optional): int64 argmax (first maximal index, as torch.argmax); confusion (optional): int64 [k][k].
-template <typename LABEL>
+template <typename LABEL, int VEC>
 __global__ __launch_bounds__(TPB) void ce_loss_kernel(const float* __restrict__ logits, const LABEL* __restrict__ labels,
                                                       const float* __restrict__ cw, long ignore_index, double* __restrict__ stats,
                                                       float* __restrict__ dlogits, long long* __restrict__ preds,
@@ -168,44 +201,84 @@ __global__ __launch_bounds__(TPB) void ce_loss_kernel(const float* __restrict__ 
     if (threadIdx.x < 2) red[threadIdx.x] = 0.f;
     __syncthreads();
     // grid-stride over pixels: ~1k workgroups end in one round of global atomics each (a workgroup per 256 pixels made
-    // the 21k same-address double atomics the whole cost of the kernel)
+    // the 21k same-address double atomics the whole cost of the kernel).  VEC = 4 (HW % 4 == 0): a thread takes four
+    // consecutive pixels of one image per iteration with 16-byte loads/stores -- the scalar loop had too few bytes in
+    // flight per CU to cover the HBM latency.
     float my_loss = 0.f, my_cnt = 0.f;
-    for (long m = blockIdx.x * (long)TPB + threadIdx.x; m < M; m += (long)gridDim.x * TPB) {
-        long b = m / HW, pix = m - b * HW;
-        float z[MAXC];
-        float mx = -INFINITY;
-        int am = 0;
+    for (long m0 = (blockIdx.x * (long)TPB + threadIdx.x) * VEC; m0 < M; m0 += (long)gridDim.x * TPB * VEC) {
+        const long b = m0 / HW, pix = m0 - b * HW;
+        float z[MAXC][VEC];
+        LABEL lab[VEC];
 #pragma unroll
         for (int n = 0; n < MAXC; ++n) {
             if (n < ncls) {
-                z[n] = logits[(b * ncls + n) * HW + pix];
-                if (z[n] > mx) mx = z[n], am = n;
+                const float* src = logits + (b * ncls + n) * HW + pix;
+                if constexpr (VEC == 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(src);
+                    z[n][0] = v.x, z[n][1] = v.y, z[n][2] = v.z, z[n][3] = v.w;
+                } else {
+                    z[n][0] = *src;
+                }
             }
         }
-        float se = 0.f;
 #pragma unroll
-        for (int n = 0; n < MAXC; ++n)
-            if (n < ncls) se += __expf(z[n] - mx);
-        float lse = mx + __logf(se);
-        long y = (long)labels[m];
-        bool valid = (y != ignore_index) && y >= 0 && y < ncls;
-        float wy = valid ? (cw ? cw[y] : 1.f) : 0.f;
-        if (valid) {
-            float zy = 0.f;
+        for (int e = 0; e < VEC; ++e) lab[e] = labels[m0 + e];
+        int amv[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float mx = -INFINITY;
+            int am = 0;
 #pragma unroll
             for (int n = 0; n < MAXC; ++n)
-                if (n == (int)y) zy = z[n];
-            my_loss += wy * (lse - zy);
-            my_cnt += 1.f;
-            if (confusion) atomicAdd(hist + (int)y * ncls + am, 1u);
+                if (n < ncls && z[n][e] > mx) mx = z[n][e], am = n;
+            float se = 0.f;
+#pragma unroll
+            for (int n = 0; n < MAXC; ++n)
+                if (n < ncls) se += __expf(z[n][e] - mx);
+            const float lse = mx + __logf(se);
+            const long y = (long)lab[e];
+            const bool valid = (y != ignore_index) && y >= 0 && y < ncls;
+            const float wy = valid ? (cw ? cw[y] : 1.f) : 0.f;
+            if (valid) {
+                float zy = 0.f;
+#pragma unroll
+                for (int n = 0; n < MAXC; ++n)
+                    if (n == (int)y) zy = z[n][e];
+                my_loss += wy * (lse - zy);
+                my_cnt += 1.f;
+                if (confusion) atomicAdd(hist + (int)y * ncls + am, 1u);
+            }
+#pragma unroll
+            for (int n = 0; n < MAXC; ++n)
+                if (n < ncls) z[n][e] = wy * (__expf(z[n][e] - lse) - (n == (int)y ? 1.f : 0.f));  // z now holds dlogits
+            amv[e] = am;
         }
         if (dlogits) {
 #pragma unroll
-            for (int n = 0; n < MAXC; ++n)
-                if (n < ncls) dlogits[(b * ncls + n) * HW + pix] = wy * (__expf(z[n] - lse) - (n == (int)y ? 1.f : 0.f));
+            for (int n = 0; n < MAXC; ++n) {
+                if (n < ncls) {
+                    float* dst = dlogits + (b * ncls + n) * HW + pix;
+                    if constexpr (VEC == 4)
+                        *reinterpret_cast<float4*>(dst) = make_float4(z[n][0], z[n][1], z[n][2], z[n][3]);
+                    else
+                        *dst = z[n][0];
+                }
+            }
         }
-        if (preds) preds[m] = am;
-        if (preds_i8) preds_i8[m] = (signed char)am;
+        if (preds) {
+            if constexpr (VEC == 4) {
+                *reinterpret_cast<longlong2*>(preds + m0) = make_longlong2(amv[0], amv[1]);
+                *reinterpret_cast<longlong2*>(preds + m0 + 2) = make_longlong2(amv[2], amv[3]);
+            } else {
+                preds[m0] = amv[0];
+            }
+        }
+        if (preds_i8) {
+            if constexpr (VEC == 4)
+                *reinterpret_cast<char4*>(preds_i8 + m0) = make_char4((signed char)amv[0], (signed char)amv[1], (signed char)amv[2], (signed char)amv[3]);
+            else
+                preds_i8[m0] = (signed char)amv[0];
+        }
     }
     my_loss = wave_sum(my_loss);
     my_cnt = wave_sum(my_cnt);
@@ -427,7 +500,13 @@ int ig_classifier_fwd(const void* f_hi, const void* f_lo, const float* w, const 
     IG_REQUIRE(C % 8 == 0 && ncls >= 1 && ncls <= MAXC, "ig_classifier_fwd: need C %% 8 == 0 and 1 <= ncls <= %d (C=%d ncls=%d)", MAXC, C, ncls);
     long M = (long)B * HW;
     if (M == 0) return IG_OK;
-    size_t sm = ((size_t)ncls * C + ncls) * sizeof(float);
+    size_t sm = ((size_t)ncls * C + ((ncls + 3) & ~3)) * sizeof(float) + (size_t)TPB * (C * 2 + 16) * (f_lo ? 2 : 1);
+    IG_REQUIRE(sm <= 160 * 1024, "ig_classifier_fwd: C=%d too wide for the staged kernel", C);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)classifier_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
     hipLaunchKernelGGL(classifier_fwd_kernel, dim3((unsigned)((M + TPB - 1) / TPB)), dim3(TPB), sm, (hipStream_t)stream,
                        (const bf16_t*)f_hi, (const bf16_t*)f_lo, w, bias, logits, M, HW, C, ncls, drop_seed, drop_seed_dev, thresh_of(drop_p),
                        drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f);
@@ -472,23 +551,33 @@ int ig_ce_loss(const float* logits, const void* labels, int label_dtype, const f
     long M = (long)B * HW;
     if (M == 0) return IG_OK;
     size_t sm = (size_t)ncls * ncls * sizeof(unsigned) + 2 * sizeof(float);
-    long nblk = (M + TPB - 1) / TPB;
+    const bool vec4 = HW % 4 == 0 && (reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits) |
+                                      reinterpret_cast<uintptr_t>(preds) | reinterpret_cast<uintptr_t>(preds_i8)) % 16 == 0;
+    const int vec = vec4 ? 4 : 1;
+    long nblk = (M + (long)TPB * vec - 1) / ((long)TPB * vec);
     if (nblk > 1024) nblk = 1024;  // grid-stride: one round of global atomics per workgroup
     dim3 grid((unsigned)nblk), block(TPB);
     hipStream_t st = (hipStream_t)stream;
+#define IG_CE(LT)                                                                                                              \
+    {                                                                                                                          \
+        if (vec4)                                                                                                              \
+            hipLaunchKernelGGL((ce_loss_kernel<LT, 4>), grid, block, sm, st, logits, (const LT*)labels, class_weights,         \
+                               ignore_index, stats, dlogits, preds, preds_i8, confusion, M, HW, ncls);                         \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((ce_loss_kernel<LT, 1>), grid, block, sm, st, logits, (const LT*)labels, class_weights,         \
+                               ignore_index, stats, dlogits, preds, preds_i8, confusion, M, HW, ncls);                         \
+    }
     if (label_dtype == 0)
-        hipLaunchKernelGGL(ce_loss_kernel<long long>, grid, block, sm, st, logits, (const long long*)labels, class_weights,
-                           ignore_index, stats, dlogits, preds, preds_i8, confusion, M, HW, ncls);
+        IG_CE(long long)
     else if (label_dtype == 1)
-        hipLaunchKernelGGL(ce_loss_kernel<int>, grid, block, sm, st, logits, (const int*)labels, class_weights, ignore_index, stats,
-                           dlogits, preds, preds_i8, confusion, M, HW, ncls);
+        IG_CE(int)
     else if (label_dtype == 2)
-        hipLaunchKernelGGL(ce_loss_kernel<float>, grid, block, sm, st, logits, (const float*)labels, class_weights, ignore_index,
-                           stats, dlogits, preds, preds_i8, confusion, M, HW, ncls);
+        IG_CE(float)
     else {
         ig_set_error("ig_ce_loss: unsupported label dtype %d", label_dtype);
         return IG_ERR_UNSUPPORTED;
     }
+#undef IG_CE
     return ig_check_launch("ig_ce_loss");
 }
 

@@ -262,8 +262,8 @@ def nhwc(x):  # NCHW -> NHWC
 
 
 @pytest.mark.parametrize("split", SPLITS)
-@pytest.mark.parametrize("B,H,Cin,Cout", [(2, 14, 48, 24), (1, 28, 144, 72), (3, 7, 8, 136)])
-def test_conv3x3(split, B, H, Cin, Cout):
+@pytest.mark.parametrize("B,H,Cin,Cout", [(2, 14, 48, 24), (1, 28, 144, 72), (3, 7, 8, 136), (2, 21, 48, 48), (1, 48, 48, 48), (3, 5, 48, 48)])
+def test_conv3x3(split, B, H, Cin, Cout):  # 48 -> 48 unsplit runs the halo-tile direct kernel (conv_direct.hip)
     W = H + 2
     x, xr = bt(nhwc(rnd(B, Cin, H, W, seed=26)), split)
     wt = rnd(Cout, Cin, 3, 3, seed=27, scale=(9 * Cin) ** -0.5)
@@ -311,9 +311,23 @@ def test_convT(split, B, H, Cin, Cout):
     close(dw, gw.permute(1, 2, 3, 0).reshape(Cout, 9, Cin), 3e-5, what="convT wgrad")
 
 
-def test_dropout_mask_consistency():
+def test_conv3x3_direct_bn_fold():
+    """48 -> 48 forward with the eval-mode BatchNorm + ReLU folded into the epilogue (direct kernel), ragged tile edges."""
+    B, H, W, C = 2, 19, 35, 48
+    x, xr = bt(nhwc(rnd(B, C, H, W, seed=60)), False)
+    w, wr = bt(rnd(C, C, 3, 3, seed=61, scale=(9 * C) ** -0.5).permute(0, 2, 3, 1).reshape(C, 9, C).contiguous(), False)
+    bias, sc, sh = rnd(C, seed=62), 1 + 0.2 * rnd(C, seed=63), 0.3 * rnd(C, seed=64)
+    y = BT.empty((B, H, W, C), False, DEV)
+    ops.conv3x3_fwd(x, w, bias.to(DEV), y, B, H, W, C, C, bn_scale=sc.float().to(DEV), bn_shift=sh.float().to(DEV))
+    ref = F.conv2d(xr.permute(0, 3, 1, 2), wr.reshape(C, 3, 3, C).permute(0, 3, 1, 2), bias.double(), padding=1)
+    ref = torch.relu(ref * sc.double().view(1, C, 1, 1).to(ref.device) + sh.double().view(1, C, 1, 1).to(ref.device))
+    close(y.float(), nhwc(ref), tol_out(False), what="direct conv + bn fold")
+
+
+@pytest.mark.parametrize("Cout", [16, 48])
+def test_dropout_mask_consistency(Cout):
     """ConvT forward mask == conv dgrad mask (same counter-based hash), keep rate ~ 1-p."""
-    B, H, W, Cin, Cout = 1, 8, 8, 8, 16
+    B, H, W, Cin = 1, 8, 8, 8
     x = BT.from_float(torch.zeros(B, H, W, Cin, device=DEV), False)
     w = BT.from_float(torch.zeros(Cout, 9, Cin, device=DEV), False)
     y = BT.empty((B, 2 * H, 2 * W, Cout), False, DEV)

@@ -16,6 +16,9 @@ B=108
 for H,C in [(224,48),(112,96),(28,384)]:
     x=BT(torch.randn(B,H,H,C,device=dev).bfloat16()); w=BT(torch.randn(C,9,C,device=dev).bfloat16()*0.05); bias=torch.zeros(C,device=dev)
     y=BT.empty((B,H,H,C),False,dev)
-    t=timeit(lambda: ops.conv3x3_fwd(x,w,bias,y,B,H,H,C,C))
     fl=2.0*B*H*H*C*C*9
+    t=timeit(lambda: ops.conv3x3_fwd(x,w,bias,y,B,H,H,C,C))
+    dx=BT.empty((B,H,H,C),False,dev)
+    td=timeit(lambda: ops.conv3x3_dgrad(y,w,dx,B,H,H,C,C,seed=1,p=0.1))
+    print(f"conv3x3 dgrad H{H} C{C}: {td:8.1f} us {fl/td/1e6:6.0f} TF")
     print(f"conv3x3 fwd H{H} C{C}: {t:8.1f} us {fl/t/1e6:6.0f} TF  dbg={os.environ.get('IG_GEMM_DBG','0')}")
