@@ -10,9 +10,14 @@
 //   * the reduction index is k = tap * C + c, consumed 32 at a time by v_mfma_f32_16x16x32_bf16: a lane's 8-element
 //     k-group never straddles a tap (C % 8 == 0), so its operand is ONE ds_read_b128 at  pixel(row + dy, col + dx) * pitch
 //     + c * 2; the (dy, dx, c) part of that address is tile-independent and precomputed per lane and K-step,
-//   * pixel pitch 2C + 16 bytes and weight pitch 64 * KSTEPS + 16 bytes make every ds_read_b128 bank-conflict free,
-//   * the next tile's halo is prefetched into registers while the current tile's MFMAs run; two workgroups per CU
-//     (2 x 80 KiB of LDS) overlap one's LDS fill / epilogue with the other's MFMAs.
+//   * pixel pitch 2C bytes and weight pitch 64 * KSTEPS + 32 bytes make every ds_read_b128 bank-conflict free,
+//   * the halo of the tile after next is prefetched into registers while the current tile's MFMAs run, and those loads
+//     are issued ahead of the epilogue's stores; two workgroups per CU (2 x 76 KiB of LDS),
+//   * output channels are interleaved over the MFMA row blocks so that a lane stores 16 contiguous bytes; bias / folded
+//     BatchNorm constants are read from LDS (a global read in the epilogue waits on vmcnt, i.e. on the draining stores).
+// Measured at 108 x 224 x 224 x 48: 366 us against 614 us for the implicit GEMM; with the MFMAs switched off 210 us and with
+// the stores off 215 us remain -- at 1.04 GB of compulsory traffic (216 FLOP/B, below the chip's 312) this stage is bound
+// by HBM streaming, not by the matrix cores.
 // The data gradient is the same kernel over dy with the weights gathered as W'[ci][8 - tap][co] at LDS-fill time.
 // Results are those of the implicit-GEMM path up to fp32 summation order (same bf16 operands, fp32 accumulation).
 #include "common.h"
@@ -28,14 +33,25 @@ struct CDCfg {
     static constexpr int KG = 9 * C / 8;            // 8-element k-groups
     static constexpr int KSTEPS = (KG + 3) / 4;     // K-steps of 32
     static constexpr int NB = C / 16;               // 16-wide output-channel blocks
-    static constexpr int WP = KSTEPS * 64 + 16;     // weight row pitch (bytes)
-    static constexpr int PP = 2 * C + 16;           // halo pixel pitch (bytes)
+    // pitches chosen against the ds_read_b128 lane groups of gfx950 ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32): with lane =
+    // (k-group g, row j) a 24-dword pixel pitch and a 232-dword weight pitch are conflict-free, the 'obvious' +16-byte pads
+    // (28 / 228 dwords) are 2-way (tools/lds_bank_model.py)
+    static constexpr int WP = KSTEPS * 64 + 32;     // weight row pitch (bytes)
+    static constexpr int PP = 2 * C;                // halo pixel pitch (bytes)
     static constexpr int W_BYTES = C * WP;
     static constexpr int H_BYTES = HH * HW_ * PP;
     static constexpr int UNITS = C / 8;              // 16-byte units per pixel
     static constexpr int HUNITS = HH * HW_ * UNITS;  // 16-byte units per halo
     static constexpr int ROUNDS = (HUNITS + CD_TPB - 1) / CD_TPB;
-    static constexpr int SMEM = W_BYTES + H_BYTES + 16;  // + one zero slot for the padded k-groups
+    static constexpr int PAR_OFF = W_BYTES + H_BYTES + 16;  // after the zero slot: bias | scale | shift, fp32 [C] each
+    static constexpr int SMEM = PAR_OFF + 3 * C * 4;
+    static constexpr int NPAIR = NB / 2;  // channel blocks (2p, 2p+1) are interleaved so that a lane owns 8 consecutive channels
+    // MFMA row position of output channel c.  A lane (g = lane / 16) holds rows 4g..4g+3 of every 16-row block; placing
+    // channels 32p + 8g + {0..3} in block 2p and 32p + 8g + {4..7} in block 2p+1 turns two 8-byte stores into one 16-byte
+    // store.  An odd last block keeps the identity order.
+    __host__ __device__ static constexpr int pos_of(int c) {
+        return c < NPAIR * 32 ? (c / 32) * 32 + ((c % 8) / 4) * 16 + ((c % 32) / 8) * 4 + c % 4 : c;
+    }
 };
 
 struct CDParams {
@@ -64,20 +80,35 @@ __global__ __launch_bounds__(CD_TPB, 2) void conv3x3_direct_kernel(CDParams p) {
     if (p.drop_seed_dev) drop_seed += *p.drop_seed_dev;
 
     // ---- weights -> LDS (once per workgroup); pad k-groups and the zero slot are cleared first
-    for (int i = tid; i < (G::W_BYTES + G::H_BYTES + 16) / 16; i += CD_TPB) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < G::PAR_OFF / 16; i += CD_TPB) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     if (!p.dgrad) {
         for (int u = tid; u < C * G::KG; u += CD_TPB) {
             const int co = u / G::KG, g = u - co * G::KG;
-            *reinterpret_cast<uint4*>(wl + co * G::WP + g * 16) = *reinterpret_cast<const uint4*>(p.w + ((size_t)co * G::KG + g) * 8);
+            *reinterpret_cast<uint4*>(wl + G::pos_of(co) * G::WP + g * 16) = *reinterpret_cast<const uint4*>(p.w + ((size_t)co * G::KG + g) * 8);
         }
     } else {
-        // W'[ci][tap'][co] = Wc[co][8 - tap'][ci]: 2-byte gathers, once per workgroup (L2-resident 41 KiB)
-        for (int e = tid; e < C * 9 * C; e += CD_TPB) {
-            const int co = e % C, r = e / C, tap = r % 9, ci = r / 9;
-            reinterpret_cast<bf16_t*>(wl + ci * G::WP)[tap * C + co] = p.w[((size_t)co * 9 + (8 - tap)) * C + ci];
+        // W'[ci][tap'][co] = Wc[co][8 - tap'][ci]: coalesced 16-byte reads of Wc, eight 2-byte LDS scatters each
+        for (int u = tid; u < C * G::KG; u += CD_TPB) {
+            const int co = u / G::KG, gk = u - co * G::KG;
+            const int tap = gk / G::UNITS, ci0 = (gk - tap * G::UNITS) * 8;
+            const uint4 v = *reinterpret_cast<const uint4*>(p.w + ((size_t)co * G::KG + gk) * 8);
+            const uint32_t q[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                reinterpret_cast<bf16_t*>(wl + G::pos_of(ci0 + i) * G::WP)[(8 - tap) * C + co] = (bf16_t)(q[i >> 1] >> ((i & 1) * 16));
         }
     }
+
+    // per-channel epilogue constants live in LDS: reading them from global inside the tile loop made every epilogue wait on
+    // vmcnt, i.e. on the previous tile's still-draining stores
+    float* par = reinterpret_cast<float*>(smem + G::PAR_OFF);
+    for (int c = tid; c < C; c += CD_TPB) {
+        par[c] = p.bias ? p.bias[c] : 0.f;
+        par[C + c] = p.col_scale ? p.col_scale[c] : 1.f;
+        par[2 * C + c] = p.col_scale ? p.col_shift[c] : 0.f;
+    }
+    const bool has_bn = p.col_scale != nullptr;
 
     // ---- tile-independent per-thread tables
     // halo fill: unit u = round * 256 + tid -> (halo pixel, 16-byte unit)
@@ -126,18 +157,42 @@ __global__ __launch_bounds__(CD_TPB, 2) void conv3x3_direct_kernel(CDParams p) {
         }
     };
 
-    long t = blockIdx.x;
-    if (t < p.ntiles) fetch(t);
-    for (; t < p.ntiles; t += gridDim.x) {
-        // ---- halo registers -> LDS
+    auto halo_to_lds = [&]() {
 #pragma unroll
         for (int r = 0; r < G::ROUNDS; ++r)
             if (r * CD_TPB + tid < G::HUNITS) *reinterpret_cast<uint4*>(hal + h_lds[r]) = pre[r];
-        __syncthreads();
+    };
+
+    // one output group = 4 consecutive channels starting at `n` of pixel `pix`, finished and stored (8 bytes) -- or, for an
+    // interleaved block pair, 8 consecutive channels (16 bytes)
+    auto finish4 = [&](f32x4 a, int n, size_t idx, float* v) {
+        const float4 bb = *reinterpret_cast<const float4*>(par + n);
+        v[0] = a[0] + bb.x, v[1] = a[1] + bb.y, v[2] = a[2] + bb.z, v[3] = a[3] + bb.w;
+        if (has_bn) {
+            const float4 sc = *reinterpret_cast<const float4*>(par + C + n);
+            const float4 sh = *reinterpret_cast<const float4*>(par + 2 * C + n);
+            v[0] = fmaxf(v[0] * sc.x + sh.x, 0.f), v[1] = fmaxf(v[1] * sc.y + sh.y, 0.f);
+            v[2] = fmaxf(v[2] * sc.z + sh.z, 0.f), v[3] = fmaxf(v[3] * sc.w + sh.w, 0.f);
+        }
+        if (p.drop_thresh) {
+            float mk[4];
+            dropout_scale4(drop_seed, (uint32_t)idx, p.drop_thresh, p.drop_inv, mk);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] *= mk[i];
+        }
+    };
+
+    long t = blockIdx.x;
+    if (t < p.ntiles) {
+        fetch(t);
+        halo_to_lds();
+        if (t + gridDim.x < p.ntiles) fetch(t + gridDim.x);
+    }
+    __syncthreads();
+    for (; t < p.ntiles; t += gridDim.x) {
         int b, ty0, tx0;
         tile_coords(t, b, ty0, tx0);
-        const long tn = t + gridDim.x;
-        if (tn < p.ntiles) fetch(tn);  // next tile's halo in flight under this tile's MFMAs
+        const long tn = t + gridDim.x, tnn = tn + gridDim.x;
 
         // ---- 4 px-blocks (rows 4*wave .. +3 of the tile) x NB channel blocks per wave
         f32x4 acc[G::NB][4];
@@ -148,22 +203,28 @@ __global__ __launch_bounds__(CD_TPB, 2) void conv3x3_direct_kernel(CDParams p) {
 #pragma unroll
         for (int ks = 0; ks < G::KSTEPS; ++ks) {
             bf16x8_t wf[G::NB], pf[4];
-            int po = pix_lane + offk[ks];
-            if (G::KG % 4 != 0 && ks == G::KSTEPS - 1 && g >= G::KG % 4) po = zero_slot;  // padded k-groups read zeros
+            const bool padded = G::KG % 4 != 0 && ks == G::KSTEPS - 1 && g >= G::KG % 4;  // these k-groups read zeros
+            const int po = padded ? zero_slot : pix_lane + offk[ks];
 #pragma unroll
             for (int nb = 0; nb < G::NB; ++nb) wf[nb] = *reinterpret_cast<const bf16x8_t*>(wl_lane + nb * 16 * G::WP + ks * 64);
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                const int o = (G::KG % 4 != 0 && ks == G::KSTEPS - 1 && g >= G::KG % 4) ? po : po + mb * HW_ * G::PP;
-                pf[mb] = *reinterpret_cast<const bf16x8_t*>(hal + o);
-            }
+            for (int mb = 0; mb < 4; ++mb) pf[mb] = *reinterpret_cast<const bf16x8_t*>(hal + (padded ? po : po + mb * HW_ * G::PP));
 #pragma unroll
             for (int nb = 0; nb < G::NB; ++nb)
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], pf[mb], acc[nb][mb], 0, 0, 0);
         }
 
-        // ---- epilogue: lane holds channels nb*16 + 4g .. +3 of pixel (row 4*wave + mb, column j)
+        // ---- the halo is free once every wave has finished its reads: stage the next one, then put the loads of the
+        // tile after it in flight BEFORE this tile's stores -- the memory pipeline serves a wave's requests in order, and
+        // loads queued behind 12 stores per lane did not land within one tile's MFMAs
+        __syncthreads();
+        if (tn < p.ntiles) halo_to_lds();
+        __syncthreads();
+        if (tnn < p.ntiles) fetch(tnn);
+
+        // ---- epilogue (its stores drain under the next tile's MFMAs): lane holds, of pixel (row 4*wave + mb, column j),
+        // channels 32p + 8g .. +7 from block pair p and channels 16*nb + 4g .. +3 from an unpaired last block
         const int ox = tx0 + j;
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
@@ -171,31 +232,23 @@ __global__ __launch_bounds__(CD_TPB, 2) void conv3x3_direct_kernel(CDParams p) {
             if (oy < p.H && ox < p.W) {
                 const size_t pix = ((size_t)b * p.H + oy) * p.W + ox;
 #pragma unroll
-                for (int nb = 0; nb < G::NB; ++nb) {
-                    const int n = nb * 16 + 4 * g;
-                    float v[4] = {acc[nb][mb][0], acc[nb][mb][1], acc[nb][mb][2], acc[nb][mb][3]};
-                    if (p.bias) {
-                        const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-                        v[0] += bb.x, v[1] += bb.y, v[2] += bb.z, v[3] += bb.w;
-                    }
-                    if (p.col_scale) {
-                        const float4 sc = *reinterpret_cast<const float4*>(p.col_scale + n);
-                        const float4 sh = *reinterpret_cast<const float4*>(p.col_shift + n);
-                        v[0] = fmaxf(v[0] * sc.x + sh.x, 0.f), v[1] = fmaxf(v[1] * sc.y + sh.y, 0.f);
-                        v[2] = fmaxf(v[2] * sc.z + sh.z, 0.f), v[3] = fmaxf(v[3] * sc.w + sh.w, 0.f);
-                    }
+                for (int pr = 0; pr < G::NPAIR; ++pr) {
+                    const int n = pr * 32 + 8 * g;
                     const size_t idx = pix * C + n;
-                    if (p.drop_thresh) {
-                        float mk[4];
-                        dropout_scale4(drop_seed, (uint32_t)idx, p.drop_thresh, p.drop_inv, mk);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] *= mk[i];
-                    }
+                    float v[8];
+                    finish4(acc[2 * pr][mb], n, idx, v);
+                    finish4(acc[2 * pr + 1][mb], n + 4, idx + 4, v + 4);
+                    *reinterpret_cast<uint4*>(p.y + idx) = pack8(v);
+                }
+                if (G::NB & 1) {
+                    const int n = (G::NB - 1) * 16 + 4 * g;
+                    const size_t idx = pix * C + n;
+                    float v[4];
+                    finish4(acc[G::NB - 1][mb], n, idx, v);
                     store4_split(p.y, nullptr, idx, v);
                 }
             }
         }
-        __syncthreads();  // every wave is done with the halo before the next tile overwrites it
     }
 }
 
