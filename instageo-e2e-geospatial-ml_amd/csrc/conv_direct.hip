@@ -267,6 +267,159 @@ int launch_direct(const CDParams& p, hipStream_t st, const char* what) {
     return ig_check_launch(what);
 }
 
+// ---------------------------------------------------------------------------------------------- weight gradient
+// dWc[co][tap][ci] += sum_pixels dy[p][co] * x[p + off(tap)][ci] for the same 48-channel stage.  The implicit GEMM needs a
+// split-K grid with an atomic pass per split and gathers x nine times (843 us at 108 x 224 x 224); here a persistent
+// workgroup keeps its 48 x 432 partial sum in registers (4 waves x 3 x 7 MFMA accumulators) over ALL its tiles and adds
+// it to dWc once at the end.  Per 16 x 16 tile the x halo and the dy tile are staged in LDS ([pixel][C], 96-byte pitch);
+// the reduction runs over the tile's 256 pixels, so both operands are k-strided and read with ds_read_b64_tr_b16.  The
+// k order inside a K-step (two tile rows) is chosen so that the 8 k-rows a 32-lane half reads together are 8 CONSECUTIVE
+// pixels: with the 96-byte pitch they then fall on 8 distinct 32-byte bank windows (k-rows 8 apart would collide).
+struct CWParams {
+    const bf16_t* x;   // [B][H][W][C] conv input
+    const bf16_t* dy;  // [B][H][W][C] gradient of the conv output
+    float* dw;         // [C][9][C] fp32, accumulated
+    int B, H, W;
+    int tiles_x, tiles_y;
+    long ntiles;
+};
+
+template <int C>
+__global__ __launch_bounds__(CD_TPB, 2) void conv3x3_wgrad_direct_kernel(CWParams p) {
+    constexpr int PP = 2 * C;                   // pixel pitch (bytes) of both images
+    constexpr int UNITS = C / 8;
+    constexpr int XH_BYTES = HH * HW_ * PP, DY_BYTES = TH * TW * PP;
+    constexpr int XUNITS = HH * HW_ * UNITS, XROUNDS = (XUNITS + CD_TPB - 1) / CD_TPB;
+    constexpr int DUNITS = TH * TW * UNITS, DROUNDS = DUNITS / CD_TPB;
+    static_assert(DUNITS % CD_TPB == 0, "dy tile units must divide evenly");
+    constexpr int CB = C / 16;                  // output-channel blocks (rows of dWc)
+    constexpr int NBLK = 9 * C / 16;            // (tap, ci) column blocks
+    constexpr int NBW = (NBLK + 3) / 4;         // column blocks per wave
+    constexpr int KS = TH * TW / 32;            // K-steps per tile (two tile rows each)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* xh = smem;
+    char* dyt = smem + XH_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pq = i16 & 3;
+
+    // global offsets of this thread's 16-byte units (x halo: unit u = (halo pixel, c8), LDS offset u * 16; dy tile likewise);
+    // the pixel coordinates for the bounds tests are recomputed per fetch (registers are the scarce resource here)
+    int h_goff[XROUNDS], d_goff[DROUNDS];
+#pragma unroll
+    for (int r = 0; r < XROUNDS; ++r) {
+        const int u = r * CD_TPB + tid;
+        const int hp = u / UNITS, c8 = u - hp * UNITS;
+        const int hy = hp / HW_, hx = hp - hy * HW_;
+        h_goff[r] = ((hy - 1) * p.W + (hx - 1)) * C + c8 * 8;
+    }
+#pragma unroll
+    for (int r = 0; r < DROUNDS; ++r) {
+        const int u = r * CD_TPB + tid;
+        const int px = u / UNITS, c8 = u - px * UNITS;
+        const int ty = px / TW, tx = px - ty * TW;
+        d_goff[r] = (ty * p.W + tx) * C + c8 * 8;
+    }
+    // operand addresses: k-row of lane (g, q) in read h of K-step s is pixel (row 2s + (g>>1), column 8h + 4(g&1) + q)
+    const int a_base = (((g >> 1) * TW + 4 * (g & 1) + q) * PP) + pq * 8;
+    const int b_lane = (((g >> 1) * HW_ + 4 * (g & 1) + q) * PP) + pq * 8;
+    int b_base[NBW];
+#pragma unroll
+    for (int b = 0; b < NBW; ++b) {
+        const int nb = min(wave * NBW + b, NBLK - 1);
+        const int tap = nb / CB, cib = nb - tap * CB;
+        const int dy = tap / 3, dx = tap - dy * 3;
+        b_base[b] = b_lane + (dy * HW_ + dx) * PP + cib * 32;
+    }
+
+    auto tile_coords = [&](long t, int& b, int& ty0, int& tx0) {
+        const int per_img = p.tiles_x * p.tiles_y;
+        b = (int)(t / per_img);
+        const int r = (int)(t - (long)b * per_img);
+        const int ty = r / p.tiles_x;
+        ty0 = ty * TH, tx0 = (r - ty * p.tiles_x) * TW;
+    };
+    uint4 prex[XROUNDS], pred[DROUNDS];
+    auto fetch = [&](long t) {
+        int b, ty0, tx0;
+        tile_coords(t, b, ty0, tx0);
+        const size_t origin = (((size_t)b * p.H + ty0) * p.W + tx0) * C;
+#pragma unroll
+        for (int r = 0; r < XROUNDS; ++r) {
+            const int u = r * CD_TPB + tid, hp = u / UNITS, hy = hp / HW_, hx = hp - hy * HW_;
+            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            prex[r] = make_uint4(0, 0, 0, 0);
+            if ((u < XUNITS) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W)) prex[r] = *reinterpret_cast<const uint4*>(p.x + origin + h_goff[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < DROUNDS; ++r) {
+            const int px = (r * CD_TPB + tid) / UNITS;
+            const int gy = ty0 + px / TW, gx = tx0 + px % TW;
+            pred[r] = make_uint4(0, 0, 0, 0);  // pixels of a ragged tile outside the image contribute nothing
+            if ((gy < p.H) & (gx < p.W)) pred[r] = *reinterpret_cast<const uint4*>(p.dy + origin + d_goff[r]);
+        }
+    };
+    auto to_lds = [&]() {
+#pragma unroll
+        for (int r = 0; r < XROUNDS; ++r)
+            if (r * CD_TPB + tid < XUNITS) *reinterpret_cast<uint4*>(xh + (r * CD_TPB + tid) * 16) = prex[r];
+#pragma unroll
+        for (int r = 0; r < DROUNDS; ++r) *reinterpret_cast<uint4*>(dyt + (r * CD_TPB + tid) * 16) = pred[r];
+    };
+    typedef __attribute__((address_space(3))) s16x4* lds_ptr;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    auto tr_frag = [&](const char* base, int off) {  // 8 k-values: reads h = 0 and h = 1 (8 pixels further along the row)
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(base + off));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(base + off + 8 * PP));
+        const s16x8 r = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        return __builtin_bit_cast(bf16x8_t, r);
+    };
+
+    f32x4 acc[CB][NBW];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int b = 0; b < NBW; ++b) acc[cb][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    long t = blockIdx.x;
+    if (t < p.ntiles) {
+        fetch(t);
+        to_lds();
+        if (t + gridDim.x < p.ntiles) fetch(t + gridDim.x);
+    }
+    __syncthreads();
+    for (; t < p.ntiles; t += gridDim.x) {
+        const long tn = t + gridDim.x, tnn = tn + gridDim.x;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            bf16x8_t af[CB];
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) af[cb] = tr_frag(dyt, a_base + s * 2 * TW * PP + cb * 32);
+#pragma unroll
+            for (int b = 0; b < NBW; ++b) {
+                const bf16x8_t bf = tr_frag(xh, b_base[b] + s * 2 * HW_ * PP);
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) acc[cb][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cb], bf, acc[cb][b], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (tn < p.ntiles) to_lds();
+        __syncthreads();
+        if (tnn < p.ntiles) fetch(tnn);
+    }
+
+    // ---- one atomic pass per workgroup: lane holds rows co = 16 cb + 4g + r of column n = 16 nb + (lane & 15)
+#pragma unroll
+    for (int b = 0; b < NBW; ++b) {
+        const int nb = wave * NBW + b;
+        if (nb < NBLK) {
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) atomicAdd(p.dw + (size_t)(cb * 16 + 4 * g + r) * (9 * C) + nb * 16 + i16, acc[cb][b][r]);
+        }
+    }
+}
+
 }  // namespace
 
 // Called by ig_conv3x3_fwd / ig_conv3x3_dgrad (gemm.hip) for the shapes this kernel covers; returns IG_ERR_UNSUPPORTED
@@ -289,4 +442,28 @@ int ig_conv3x3_direct(const void* x, const void* w, const float* bias, const flo
     p.drop_inv = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     if (p.ntiles == 0) return IG_OK;
     return launch_direct<48>(p, (hipStream_t)stream, dgrad ? "ig_conv3x3_dgrad(direct)" : "ig_conv3x3_fwd(direct)");
+}
+
+// Called by ig_conv3x3_wgrad (gemm.hip); IG_ERR_UNSUPPORTED when the shape is not covered.
+int ig_conv3x3_wgrad_direct(const void* dy, const void* x, float* dw, int B, int H, int W, int Cin, int Cout, void* stream) {
+    static const int enabled = getenv("IG_CONV_DIRECT") ? atoi(getenv("IG_CONV_DIRECT")) : 1;
+    if (!enabled || Cin != Cout || Cin != 48) return IG_ERR_UNSUPPORTED;
+    if ((long)B * H * W * Cin >= (1L << 31)) return IG_ERR_UNSUPPORTED;
+    CWParams p{};
+    p.x = (const bf16_t*)x, p.dy = (const bf16_t*)dy, p.dw = dw;
+    p.B = B, p.H = H, p.W = W;
+    p.tiles_x = (W + TW - 1) / TW, p.tiles_y = (H + TH - 1) / TH;
+    p.ntiles = (long)B * p.tiles_x * p.tiles_y;
+    if (p.ntiles == 0) return IG_OK;
+    constexpr int smem = (HH * HW_ + TH * TW) * 2 * 48;
+    static const int nwg_env = getenv("IG_CONV_DIRECT_WGS") ? atoi(getenv("IG_CONV_DIRECT_WGS")) : 0;
+    long nwg = nwg_env > 0 ? nwg_env : 512;
+    if (nwg > p.ntiles) nwg = p.ntiles;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_direct_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(conv3x3_wgrad_direct_kernel<48>, dim3((unsigned)nwg), dim3(CD_TPB), smem, (hipStream_t)stream, p);
+    return ig_check_launch("ig_conv3x3_wgrad(direct)");
 }

@@ -1592,6 +1592,10 @@ int ig_conv3x3_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, con
     IG_REQUIRE(dy_hi && x_hi && dw, "ig_conv3x3_wgrad: null pointer");
     IG_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, "ig_conv3x3_wgrad: channels must be multiples of 8");
     IG_SPLIT_CONSISTENT(dy_lo, x_lo);
+    if (!dy_lo) {  // narrow last stage: register-resident partial sums over halo tiles (conv_direct.hip)
+        const int rc = ig_conv3x3_wgrad_direct(dy_hi, x_hi, dw, B, H, W, Cin, Cout, stream);
+        if (rc != IG_ERR_UNSUPPORTED) return rc;
+    }
     int Mtot = B * H * W;
     Conv3Loader bl{};
     seg_b(bl.base, x_hi, x_lo);

@@ -13,7 +13,7 @@ def timeit(fn,n=10):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b)/n*1e3
 B=108
-for H,C in [(224,48),(112,96),(28,384)]:
+for H,C in [(224,48),(112,96),(56,192),(28,384)]:
     x=BT(torch.randn(B,H,H,C,device=dev).bfloat16()); w=BT(torch.randn(C,9,C,device=dev).bfloat16()*0.05); bias=torch.zeros(C,device=dev)
     y=BT.empty((B,H,H,C),False,dev)
     fl=2.0*B*H*H*C*C*9
@@ -21,4 +21,7 @@ for H,C in [(224,48),(112,96),(28,384)]:
     dx=BT.empty((B,H,H,C),False,dev)
     td=timeit(lambda: ops.conv3x3_dgrad(y,w,dx,B,H,H,C,C,seed=1,p=0.1))
     print(f"conv3x3 dgrad H{H} C{C}: {td:8.1f} us {fl/td/1e6:6.0f} TF")
+    dw=torch.zeros(C,9,C,device=dev)
+    tw=timeit(lambda: ops.conv3x3_wgrad(y,x,dw,B,H,H,C,C))
+    print(f"conv3x3 wgrad H{H} C{C}: {tw:8.1f} us {fl/tw/1e6:6.0f} TF")
     print(f"conv3x3 fwd H{H} C{C}: {t:8.1f} us {fl/t/1e6:6.0f} TF  dbg={os.environ.get('IG_GEMM_DBG','0')}")

@@ -31,3 +31,21 @@ for P in range(24,68,4):
     r=pix_cost(P); print("pix pitch dw",P,"sum",sum(r),r)
 for WPd in range(224,260,4):
     print("w pitch dw",WPd,w_cost(WPd))
+
+# ---- the GEMM engines' K-contiguous images (gemm.hip): lane = (row = row0 + l%16, chunk = s*4 + l/16)
+def kc32(r, c):  # 64-byte rows (BK = 32), kc_swz<32>
+    return r * 16 + ((c ^ ((0x1230 >> (4 * ((r >> 2) & 3))) & 3)) << 2)
+def kc64(r, c):  # 128-byte rows (BK = 64), lds_kc
+    return r * 32 + ((c ^ (r & 7)) << 2)
+print("kc32 read (want 4):", [cost([kc32(row0 + l % 16, l // 16) for l in range(64)]) for row0 in (0, 16, 32, 48)])
+print("kc64 read (want 4):", [cost([kc64(row0 + l % 16, s * 4 + l // 16) for l in range(64)]) for row0 in (0, 16) for s in (0, 1)])
+# search: best 2-bit XOR key function of the row for 64-byte rows
+best = None
+for keys in itertools.product(range(4), repeat=16):
+    if keys[0] != 0: continue
+    f = lambda r, c: r * 16 + ((c ^ keys[r % 16]) << 2)
+    cst = cost([f(l % 16, l // 16) for l in range(64)])
+    if best is None or cst < best[0]:
+        best = (cst, keys)
+        if cst == 4: break
+print("best 64-byte-row key table (period 16):", best)
