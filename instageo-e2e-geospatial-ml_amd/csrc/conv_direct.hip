@@ -420,6 +420,176 @@ __global__ __launch_bounds__(CD_TPB, 2) void conv3x3_wgrad_direct_kernel(CWParam
     }
 }
 
+// ---------------------------------------------------------------------------------------------- ConvTranspose2d forward
+// nn.ConvTranspose2d(k=3, s=2, p=1, op=1) of the last stage (112 x 112 x 96 -> 224 x 224 x 48; model.py:361-368), weights
+// Wc[Cout][9][Cin].  Output (2iy+py, 2ix+px) reads tap rows ky = 1 (py = 0, input row iy) or ky = 0 / 2 (py = 1, input rows
+// iy+1 / iy), the same along x: every tap belongs to exactly one of the four sub-pixel phases, so one sweep over the 9 taps
+// x Cin of the LDS-resident weights produces all four phases of a block of 16 input pixels.
+// One 8-wave workgroup per CU: a 16 x 16 input tile (+1 row/column of halo, zero-filled outside) in LDS, each wave owns two
+// rows of 16 input pixels = 2 x 4 phases x 3 channel blocks of accumulators; next-but-one tile prefetched in registers.
+// The stage moves 780 MB for 112 GFLOP (144 FLOP/B): it is HBM-bound, the implicit GEMM ran it at 607 us.
+constexpr int CT_TPB = 512;
+constexpr int CT_T = 16;          // input tile edge
+constexpr int CT_P = CT_T + 1;    // patch edge
+
+struct CTParams {
+    const bf16_t* x;   // [B][H][W][CIN]
+    const bf16_t* w;   // Wc[COUT][9][CIN]
+    bf16_t* y;         // [B][2H][2W][COUT]
+    const float* bias;
+    int B, H, W;
+    int tiles_x, tiles_y;
+    long ntiles;
+    uint32_t drop_seed, drop_thresh;
+    const uint32_t* drop_seed_dev;
+    float drop_inv;
+};
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(CT_TPB, 1) void convT_direct_kernel(CTParams p) {
+    constexpr int KSUB = CIN / 32;                   // K-steps per tap
+    constexpr int WP = 9 * KSUB * 64 + 32;           // weight row pitch (bytes): 440 dwords for CIN = 96, conflict-free
+    constexpr int PP = 2 * CIN + 32;                 // patch pixel pitch (bytes): 56 dwords for CIN = 96, conflict-free
+    static_assert((WP / 4) % 16 == 8 && (PP / 4) % 16 == 8, "pitches must be = 8 (mod 16) dwords for ds_read_b128");
+    constexpr int NB = COUT / 16, NPAIR = NB / 2;
+    constexpr int W_BYTES = COUT * WP, X_BYTES = CT_P * CT_P * PP;
+    constexpr int UNITS = CIN / 8, XUNITS = CT_P * CT_P * UNITS, ROUNDS = (XUNITS + CT_TPB - 1) / CT_TPB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* wl = smem;
+    char* xp = smem + W_BYTES;
+    float* par = reinterpret_cast<float*>(smem + W_BYTES + X_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, j = lane & 15;
+    uint32_t drop_seed = p.drop_seed;
+    if (p.drop_seed_dev) drop_seed += *p.drop_seed_dev;
+
+    // ---- weights -> LDS once (channel rows interleaved as in the 3x3 kernel: a lane owns 8 consecutive output channels)
+    auto pos_of = [](int c) { return c < NPAIR * 32 ? (c / 32) * 32 + ((c % 8) / 4) * 16 + ((c % 32) / 8) * 4 + c % 4 : c; };
+    constexpr int WUNITS = 9 * CIN / 8;
+    for (int u = tid; u < COUT * WUNITS; u += CT_TPB) {
+        const int co = u / WUNITS, k8 = u - co * WUNITS;
+        *reinterpret_cast<uint4*>(wl + pos_of(co) * WP + k8 * 16) = *reinterpret_cast<const uint4*>(p.w + ((size_t)co * WUNITS + k8) * 8);
+    }
+    for (int c = tid; c < COUT; c += CT_TPB) par[c] = p.bias ? p.bias[c] : 0.f;
+
+    int h_goff[ROUNDS], h_lds[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int u = r * CT_TPB + tid;
+        const int hp = u / UNITS, c8 = u - hp * UNITS;
+        const int hy = hp / CT_P, hx = hp - hy * CT_P;
+        h_goff[r] = (hy * p.W + hx) * CIN + c8 * 8;
+        h_lds[r] = hp * PP + c8 * 16;
+    }
+    auto tile_coords = [&](long t, int& b, int& ty0, int& tx0) {
+        const int per_img = p.tiles_x * p.tiles_y;
+        b = (int)(t / per_img);
+        const int r = (int)(t - (long)b * per_img);
+        const int ty = r / p.tiles_x;
+        ty0 = ty * CT_T, tx0 = (r - ty * p.tiles_x) * CT_T;
+    };
+    uint4 pre[ROUNDS];
+    auto fetch = [&](long t) {
+        int b, ty0, tx0;
+        tile_coords(t, b, ty0, tx0);
+        const bf16_t* base = p.x + (((size_t)b * p.H + ty0) * p.W + tx0) * CIN;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int u = r * CT_TPB + tid, hp = u / UNITS, hy = hp / CT_P, hx = hp - hy * CT_P;
+            pre[r] = make_uint4(0, 0, 0, 0);
+            if ((u < XUNITS) & (ty0 + hy < p.H) & (tx0 + hx < p.W)) pre[r] = *reinterpret_cast<const uint4*>(base + h_goff[r]);
+        }
+    };
+    auto to_lds = [&]() {
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r)
+            if (r * CT_TPB + tid < XUNITS) *reinterpret_cast<uint4*>(xp + h_lds[r]) = pre[r];
+    };
+    const char* x_lane = xp + ((wave * 2) * CT_P + j) * PP + g * 16;  // px-block 0 of this wave (input row 2*wave), pixel j
+    const char* w_lane = wl + j * WP + g * 16;
+
+    long t = blockIdx.x;
+    if (t < p.ntiles) {
+        fetch(t);
+        to_lds();
+        if (t + gridDim.x < p.ntiles) fetch(t + gridDim.x);
+    }
+    __syncthreads();
+    for (; t < p.ntiles; t += gridDim.x) {
+        int b, ty0, tx0;
+        tile_coords(t, b, ty0, tx0);
+        const long tn = t + gridDim.x, tnn = tn + gridDim.x;
+        f32x4 acc[2][4][NB];  // [input row of the wave][phase py*2+px][channel block]
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[mb][ph][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            const int ph = (ky != 1) * 2 + (kx != 1);
+            const int xoff = ((ky == 0) * CT_P + (kx == 0)) * PP;  // tap row/column 0 reads the next input row/column
+#pragma unroll
+            for (int ks = 0; ks < KSUB; ++ks) {
+                bf16x8_t wf[NB], pf[2];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) wf[nb] = *reinterpret_cast<const bf16x8_t*>(w_lane + nb * 16 * WP + (tap * KSUB + ks) * 64);
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) pf[mb] = *reinterpret_cast<const bf16x8_t*>(x_lane + mb * CT_P * PP + xoff + ks * 64);
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) acc[mb][ph][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], pf[mb], acc[mb][ph][nb], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (tn < p.ntiles) to_lds();
+        __syncthreads();
+        if (tnn < p.ntiles) fetch(tnn);
+
+        // ---- epilogue: bias, dropout, bf16; lane = input pixel (ty0 + 2*wave + mb, tx0 + j), channels 8g..8g+7 | 32+4g..+3
+        auto finish4 = [&](f32x4 a, int n, size_t idx, float* v) {
+            const float4 bb = *reinterpret_cast<const float4*>(par + n);
+            v[0] = a[0] + bb.x, v[1] = a[1] + bb.y, v[2] = a[2] + bb.z, v[3] = a[3] + bb.w;
+            if (p.drop_thresh) {
+                float mk[4];
+                dropout_scale4(drop_seed, (uint32_t)idx, p.drop_thresh, p.drop_inv, mk);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] *= mk[i];
+            }
+        };
+        const int ix = tx0 + j;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const int iy = ty0 + wave * 2 + mb;
+            if (iy < p.H && ix < p.W) {
+#pragma unroll
+                for (int ph = 0; ph < 4; ++ph) {
+                    const size_t pix = ((size_t)b * 2 * p.H + 2 * iy + (ph >> 1)) * (2 * p.W) + 2 * ix + (ph & 1);
+#pragma unroll
+                    for (int pr = 0; pr < NPAIR; ++pr) {
+                        const int n = pr * 32 + 8 * g;
+                        const size_t idx = pix * COUT + n;
+                        float v[8];
+                        finish4(acc[mb][ph][2 * pr], n, idx, v);
+                        finish4(acc[mb][ph][2 * pr + 1], n + 4, idx + 4, v + 4);
+                        *reinterpret_cast<uint4*>(p.y + idx) = pack8(v);
+                    }
+                    if (NB & 1) {
+                        const int n = (NB - 1) * 16 + 4 * g;
+                        const size_t idx = pix * COUT + n;
+                        float v[4];
+                        finish4(acc[mb][ph][NB - 1], n, idx, v);
+                        store4_split(p.y, nullptr, idx, v);
+                    }
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // Called by ig_conv3x3_fwd / ig_conv3x3_dgrad (gemm.hip) for the shapes this kernel covers; returns IG_ERR_UNSUPPORTED
@@ -466,4 +636,30 @@ int ig_conv3x3_wgrad_direct(const void* dy, const void* x, float* dw, int B, int
     }
     hipLaunchKernelGGL(conv3x3_wgrad_direct_kernel<48>, dim3((unsigned)nwg), dim3(CD_TPB), smem, (hipStream_t)stream, p);
     return ig_check_launch("ig_conv3x3_wgrad(direct)");
+}
+
+// Called by ig_convT_fwd (gemm.hip); IG_ERR_UNSUPPORTED when the shape is not covered.
+int ig_convT_fwd_direct(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,
+                        unsigned drop_seed, const unsigned* drop_seed_dev, float drop_p, void* stream) {
+    static const int enabled = getenv("IG_CONV_DIRECT") ? atoi(getenv("IG_CONV_DIRECT")) : 1;
+    if (!enabled || Cin != 96 || Cout != 48) return IG_ERR_UNSUPPORTED;
+    if ((long)B * H * W * Cin >= (1L << 31)) return IG_ERR_UNSUPPORTED;
+    CTParams p{};
+    p.x = (const bf16_t*)x, p.w = (const bf16_t*)w, p.y = (bf16_t*)y, p.bias = bias;
+    p.B = B, p.H = H, p.W = W;
+    p.tiles_x = (W + CT_T - 1) / CT_T, p.tiles_y = (H + CT_T - 1) / CT_T;
+    p.ntiles = (long)B * p.tiles_x * p.tiles_y;
+    p.drop_seed = drop_seed, p.drop_seed_dev = drop_seed_dev;
+    p.drop_thresh = ig_drop_thresh16(drop_p);
+    p.drop_inv = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    if (p.ntiles == 0) return IG_OK;
+    constexpr int smem = 48 * (27 * 64 + 32) + CT_P * CT_P * (2 * 96 + 32) + 48 * 4;
+    long nwg = p.ntiles < 256 ? p.ntiles : 256;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)convT_direct_kernel<96, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((convT_direct_kernel<96, 48>), dim3((unsigned)nwg), dim3(CT_TPB), smem, (hipStream_t)stream, p);
+    return ig_check_launch("ig_convT_fwd(direct)");
 }

@@ -1615,6 +1615,11 @@ int ig_convT_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const voi
     IG_REQUIRE(x_hi && w_hi && y_hi, "ig_convT_fwd: null pointer");
     IG_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, "ig_convT_fwd: channels must be multiples of 8");
     IG_SPLIT_CONSISTENT(x_lo, w_lo);
+    IG_REQUIRE(drop_p <= 0.f || (double)B * 4 * H * W * Cout < 4294967296.0, "ig_convT_fwd: dropout needs < 2^32 elements");
+    if (!x_lo && !y_lo) {  // last stage (96 -> 48): direct sub-pixel kernel (conv_direct.hip)
+        const int rc = ig_convT_fwd_direct(x_hi, w_hi, bias, y_hi, B, H, W, Cin, Cout, drop_seed, drop_seed_dev, drop_p, stream);
+        if (rc != IG_ERR_UNSUPPORTED) return rc;
+    }
     ConvTFwdALoader al{};
     seg_a(al.base, x_hi, x_lo);
     al.Mtot = B * H * W, al.H = H, al.W = W, al.C = Cin;

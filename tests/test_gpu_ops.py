@@ -287,8 +287,8 @@ def test_conv3x3(split, B, H, Cin, Cout):  # 48 -> 48 unsplit runs the halo-tile
 
 
 @pytest.mark.parametrize("split", SPLITS)
-@pytest.mark.parametrize("B,H,Cin,Cout", [(2, 14, 48, 24), (1, 7, 256, 128), (2, 5, 16, 8)])
-def test_convT(split, B, H, Cin, Cout):
+@pytest.mark.parametrize("B,H,Cin,Cout", [(2, 14, 48, 24), (1, 7, 256, 128), (2, 5, 16, 8), (2, 20, 96, 48), (1, 33, 96, 48), (3, 4, 96, 48)])
+def test_convT(split, B, H, Cin, Cout):  # 96 -> 48 unsplit runs the direct sub-pixel kernel (conv_direct.hip)
     W = H + 1
     x, xr = bt(nhwc(rnd(B, Cin, H, W, seed=30)), split)
     wt = rnd(Cin, Cout, 3, 3, seed=31, scale=(2.25 * Cin) ** -0.5)  # torch ConvTranspose2d layout (Cin,Cout,kh,kw)
@@ -324,10 +324,10 @@ def test_conv3x3_direct_bn_fold():
     close(y.float(), nhwc(ref), tol_out(False), what="direct conv + bn fold")
 
 
-@pytest.mark.parametrize("Cout", [16, 48])
-def test_dropout_mask_consistency(Cout):
-    """ConvT forward mask == conv dgrad mask (same counter-based hash), keep rate ~ 1-p."""
-    B, H, W, Cin = 1, 8, 8, 8
+@pytest.mark.parametrize("Cin,Cout", [(8, 16), (8, 48), (96, 48)])
+def test_dropout_mask_consistency(Cin, Cout):
+    """ConvT forward mask == conv dgrad mask (same counter-based hash; implicit-GEMM and direct kernels), keep rate ~ 1-p."""
+    B, H, W = 1, 8, 8
     x = BT.from_float(torch.zeros(B, H, W, Cin, device=DEV), False)
     w = BT.from_float(torch.zeros(Cout, 9, Cin, device=DEV), False)
     y = BT.empty((B, 2 * H, 2 * W, Cout), False, DEV)
