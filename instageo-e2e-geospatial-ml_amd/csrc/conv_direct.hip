@@ -268,67 +268,75 @@ int launch_direct(const CDParams& p, hipStream_t st, const char* what) {
 }
 
 // ---------------------------------------------------------------------------------------------- weight gradient
-// dWc[co][tap][ci] += sum_pixels dy[p][co] * x[p + off(tap)][ci] for the same 48-channel stage.  The implicit GEMM needs a
-// split-K grid with an atomic pass per split and gathers x nine times (843 us at 108 x 224 x 224); here a persistent
-// workgroup keeps its 48 x 432 partial sum in registers (4 waves x 3 x 7 MFMA accumulators) over ALL its tiles and adds
-// it to dWc once at the end.  Per 16 x 16 tile the x halo and the dy tile are staged in LDS ([pixel][C], 96-byte pitch);
-// the reduction runs over the tile's 256 pixels, so both operands are k-strided and read with ds_read_b64_tr_b16.  The
-// k order inside a K-step (two tile rows) is chosen so that the 8 k-rows a 32-lane half reads together are 8 CONSECUTIVE
-// pixels: with the 96-byte pitch they then fall on 8 distinct 32-byte bank windows (k-rows 8 apart would collide).
+// dWc[co][tap][ci] += sum_pixels dy[p][co] * x[p + off(tap)][ci] for the 48- and 96-channel stages.  The implicit GEMM needs
+// a split-K grid with an atomic pass per split and gathers x nine times (843 us at 108 x 224 x 224 x 48); here a persistent
+// workgroup keeps a 48 x 9*CIN partial sum in registers (3 x 7 MFMA accumulators per wave; 4 waves for CIN = 48, 8 for 96)
+// over ALL its tiles and adds it to dWc once at the end.  A workgroup covers a 48-wide slice of the output channels
+// (blockIdx.y); with Cout = 96 the x halo is therefore staged by two workgroups.  Per 16 x 16 tile the x halo and the dy
+// tile are staged in LDS ([pixel][channel]); the reduction runs over the tile's 256 pixels, so both operands are k-strided
+// and read with ds_read_b64_tr_b16.  The k order inside a K-step (two tile rows) is chosen so that the 8 k-rows a 32-lane
+// half reads together are 8 CONSECUTIVE pixels: with a pixel pitch = 8 (mod 16) dwords they fall on 8 distinct 32-byte bank
+// windows (k-rows 8 apart would collide whatever the pitch).
 struct CWParams {
-    const bf16_t* x;   // [B][H][W][C] conv input
-    const bf16_t* dy;  // [B][H][W][C] gradient of the conv output
-    float* dw;         // [C][9][C] fp32, accumulated
-    int B, H, W;
+    const bf16_t* x;   // [B][H][W][CIN] conv input
+    const bf16_t* dy;  // [B][H][W][Cout] gradient of the conv output
+    float* dw;         // [Cout][9][CIN] fp32, accumulated
+    int B, H, W, Cout;
     int tiles_x, tiles_y;
     long ntiles;
 };
 
-template <int C>
-__global__ __launch_bounds__(CD_TPB, 2) void conv3x3_wgrad_direct_kernel(CWParams p) {
-    constexpr int PP = 2 * C;                   // pixel pitch (bytes) of both images
-    constexpr int UNITS = C / 8;
-    constexpr int XH_BYTES = HH * HW_ * PP, DY_BYTES = TH * TW * PP;
-    constexpr int XUNITS = HH * HW_ * UNITS, XROUNDS = (XUNITS + CD_TPB - 1) / CD_TPB;
-    constexpr int DUNITS = TH * TW * UNITS, DROUNDS = DUNITS / CD_TPB;
-    static_assert(DUNITS % CD_TPB == 0, "dy tile units must divide evenly");
-    constexpr int CB = C / 16;                  // output-channel blocks (rows of dWc)
-    constexpr int NBLK = 9 * C / 16;            // (tap, ci) column blocks
-    constexpr int NBW = (NBLK + 3) / 4;         // column blocks per wave
+template <int CIN, int NWAVES>
+__global__ __launch_bounds__(64 * NWAVES, NWAVES == 4 ? 2 : 1) void conv3x3_wgrad_direct_kernel(CWParams p) {
+    constexpr int TPB_ = 64 * NWAVES;
+    constexpr int COB = 48;                                    // output channels per workgroup
+    constexpr int PPX = 2 * CIN + ((CIN / 2) % 16 == 8 ? 0 : 32 - (CIN % 16) * 2);  // x pixel pitch: = 8 (mod 16) dwords
+    constexpr int PPD = 2 * COB;                               // dy pixel pitch (24 dwords)
+    static_assert((PPX / 4) % 16 == 8 && (PPD / 4) % 16 == 8, "pixel pitches must be = 8 (mod 16) dwords");
+    constexpr int XU = CIN / 8, DU = COB / 8;
+    constexpr int XH_BYTES = HH * HW_ * PPX;
+    constexpr int XUNITS = HH * HW_ * XU, XROUNDS = (XUNITS + TPB_ - 1) / TPB_;
+    constexpr int DUNITS = TH * TW * DU, DROUNDS = DUNITS / TPB_;
+    static_assert(DUNITS % TPB_ == 0, "dy tile units must divide evenly");
+    constexpr int CB = COB / 16;                // output-channel blocks (rows of dWc)
+    constexpr int CIB = CIN / 16;               // input-channel blocks per tap
+    constexpr int NBLK = 9 * CIB;               // (tap, ci) column blocks
+    constexpr int NBW = (NBLK + NWAVES - 1) / NWAVES;  // column blocks per wave
     constexpr int KS = TH * TW / 32;            // K-steps per tile (two tile rows each)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* xh = smem;
     char* dyt = smem + XH_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pq = i16 & 3;
+    const int co0 = blockIdx.y * COB;
 
-    // global offsets of this thread's 16-byte units (x halo: unit u = (halo pixel, c8), LDS offset u * 16; dy tile likewise);
-    // the pixel coordinates for the bounds tests are recomputed per fetch (registers are the scarce resource here)
+    // global offsets of this thread's 16-byte units; the pixel coordinates for the bounds tests are recomputed per fetch
+    // (registers are the scarce resource here)
     int h_goff[XROUNDS], d_goff[DROUNDS];
 #pragma unroll
     for (int r = 0; r < XROUNDS; ++r) {
-        const int u = r * CD_TPB + tid;
-        const int hp = u / UNITS, c8 = u - hp * UNITS;
+        const int u = r * TPB_ + tid;
+        const int hp = u / XU, c8 = u - hp * XU;
         const int hy = hp / HW_, hx = hp - hy * HW_;
-        h_goff[r] = ((hy - 1) * p.W + (hx - 1)) * C + c8 * 8;
+        h_goff[r] = ((hy - 1) * p.W + (hx - 1)) * CIN + c8 * 8;
     }
 #pragma unroll
     for (int r = 0; r < DROUNDS; ++r) {
-        const int u = r * CD_TPB + tid;
-        const int px = u / UNITS, c8 = u - px * UNITS;
+        const int u = r * TPB_ + tid;
+        const int px = u / DU, c8 = u - px * DU;
         const int ty = px / TW, tx = px - ty * TW;
-        d_goff[r] = (ty * p.W + tx) * C + c8 * 8;
+        d_goff[r] = (ty * p.W + tx) * p.Cout + co0 + c8 * 8;
     }
     // operand addresses: k-row of lane (g, q) in read h of K-step s is pixel (row 2s + (g>>1), column 8h + 4(g&1) + q)
-    const int a_base = (((g >> 1) * TW + 4 * (g & 1) + q) * PP) + pq * 8;
-    const int b_lane = (((g >> 1) * HW_ + 4 * (g & 1) + q) * PP) + pq * 8;
+    const int a_base = (((g >> 1) * TW + 4 * (g & 1) + q) * PPD) + pq * 8;
+    const int b_lane = (((g >> 1) * HW_ + 4 * (g & 1) + q) * PPX) + pq * 8;
     int b_base[NBW];
 #pragma unroll
     for (int b = 0; b < NBW; ++b) {
         const int nb = min(wave * NBW + b, NBLK - 1);
-        const int tap = nb / CB, cib = nb - tap * CB;
+        const int tap = nb / CIB, cib = nb - tap * CIB;
         const int dy = tap / 3, dx = tap - dy * 3;
-        b_base[b] = b_lane + (dy * HW_ + dx) * PP + cib * 32;
+        b_base[b] = b_lane + (dy * HW_ + dx) * PPX + cib * 32;
     }
 
     auto tile_coords = [&](long t, int& b, int& ty0, int& tx0) {
@@ -342,34 +350,38 @@ __global__ __launch_bounds__(CD_TPB, 2) void conv3x3_wgrad_direct_kernel(CWParam
     auto fetch = [&](long t) {
         int b, ty0, tx0;
         tile_coords(t, b, ty0, tx0);
-        const size_t origin = (((size_t)b * p.H + ty0) * p.W + tx0) * C;
+        const size_t origin = ((size_t)b * p.H + ty0) * p.W + tx0;
 #pragma unroll
         for (int r = 0; r < XROUNDS; ++r) {
-            const int u = r * CD_TPB + tid, hp = u / UNITS, hy = hp / HW_, hx = hp - hy * HW_;
+            const int u = r * TPB_ + tid, hp = u / XU, hy = hp / HW_, hx = hp - hy * HW_;
             const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
             prex[r] = make_uint4(0, 0, 0, 0);
-            if ((u < XUNITS) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W)) prex[r] = *reinterpret_cast<const uint4*>(p.x + origin + h_goff[r]);
+            if ((u < XUNITS) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W))
+                prex[r] = *reinterpret_cast<const uint4*>(p.x + origin * CIN + h_goff[r]);
         }
 #pragma unroll
         for (int r = 0; r < DROUNDS; ++r) {
-            const int px = (r * CD_TPB + tid) / UNITS;
+            const int px = (r * TPB_ + tid) / DU;
             const int gy = ty0 + px / TW, gx = tx0 + px % TW;
             pred[r] = make_uint4(0, 0, 0, 0);  // pixels of a ragged tile outside the image contribute nothing
-            if ((gy < p.H) & (gx < p.W)) pred[r] = *reinterpret_cast<const uint4*>(p.dy + origin + d_goff[r]);
+            if ((gy < p.H) & (gx < p.W)) pred[r] = *reinterpret_cast<const uint4*>(p.dy + origin * p.Cout + d_goff[r]);
         }
     };
     auto to_lds = [&]() {
 #pragma unroll
-        for (int r = 0; r < XROUNDS; ++r)
-            if (r * CD_TPB + tid < XUNITS) *reinterpret_cast<uint4*>(xh + (r * CD_TPB + tid) * 16) = prex[r];
+        for (int r = 0; r < XROUNDS; ++r) {
+            const int u = r * TPB_ + tid, hp = u / XU;
+            const int off = PPX == XU * 16 ? u * 16 : hp * PPX + (u - hp * XU) * 16;  // unpadded pitch: units are contiguous
+            if (u < XUNITS) *reinterpret_cast<uint4*>(xh + off) = prex[r];
+        }
 #pragma unroll
-        for (int r = 0; r < DROUNDS; ++r) *reinterpret_cast<uint4*>(dyt + (r * CD_TPB + tid) * 16) = pred[r];
+        for (int r = 0; r < DROUNDS; ++r) *reinterpret_cast<uint4*>(dyt + (r * TPB_ + tid) * 16) = pred[r];  // pitch = DU * 16
     };
     typedef __attribute__((address_space(3))) s16x4* lds_ptr;
     typedef __attribute__((ext_vector_type(8))) short s16x8;
-    auto tr_frag = [&](const char* base, int off) {  // 8 k-values: reads h = 0 and h = 1 (8 pixels further along the row)
+    auto tr_frag = [&](const char* base, int off, int pitch) {  // 8 k-values: reads h = 0 and h = 1 (8 pixels further along the row)
         const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(base + off));
-        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(base + off + 8 * PP));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(base + off + 8 * pitch));
         const s16x8 r = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         return __builtin_bit_cast(bf16x8_t, r);
     };
@@ -393,10 +405,10 @@ __global__ __launch_bounds__(CD_TPB, 2) void conv3x3_wgrad_direct_kernel(CWParam
         for (int s = 0; s < KS; ++s) {
             bf16x8_t af[CB];
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb) af[cb] = tr_frag(dyt, a_base + s * 2 * TW * PP + cb * 32);
+            for (int cb = 0; cb < CB; ++cb) af[cb] = tr_frag(dyt, a_base + s * 2 * TW * PPD + cb * 32, PPD);
 #pragma unroll
             for (int b = 0; b < NBW; ++b) {
-                const bf16x8_t bf = tr_frag(xh, b_base[b] + s * 2 * HW_ * PP);
+                const bf16x8_t bf = tr_frag(xh, b_base[b] + s * 2 * HW_ * PPX, PPX);
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb) acc[cb][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cb], bf, acc[cb][b], 0, 0, 0);
             }
@@ -407,7 +419,7 @@ __global__ __launch_bounds__(CD_TPB, 2) void conv3x3_wgrad_direct_kernel(CWParam
         if (tnn < p.ntiles) fetch(tnn);
     }
 
-    // ---- one atomic pass per workgroup: lane holds rows co = 16 cb + 4g + r of column n = 16 nb + (lane & 15)
+    // ---- one atomic pass per workgroup: lane holds rows co = co0 + 16 cb + 4g + r of column n = 16 nb + (lane & 15)
 #pragma unroll
     for (int b = 0; b < NBW; ++b) {
         const int nb = wave * NBW + b;
@@ -415,7 +427,7 @@ __global__ __launch_bounds__(CD_TPB, 2) void conv3x3_wgrad_direct_kernel(CWParam
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) atomicAdd(p.dw + (size_t)(cb * 16 + 4 * g + r) * (9 * C) + nb * 16 + i16, acc[cb][b][r]);
+                for (int r = 0; r < 4; ++r) atomicAdd(p.dw + (size_t)(co0 + cb * 16 + 4 * g + r) * (9 * CIN) + nb * 16 + i16, acc[cb][b][r]);
         }
     }
 }
@@ -615,27 +627,34 @@ int ig_conv3x3_direct(const void* x, const void* w, const float* bias, const flo
 }
 
 // Called by ig_conv3x3_wgrad (gemm.hip); IG_ERR_UNSUPPORTED when the shape is not covered.
-int ig_conv3x3_wgrad_direct(const void* dy, const void* x, float* dw, int B, int H, int W, int Cin, int Cout, void* stream) {
-    static const int enabled = getenv("IG_CONV_DIRECT") ? atoi(getenv("IG_CONV_DIRECT")) : 1;
-    if (!enabled || Cin != Cout || Cin != 48) return IG_ERR_UNSUPPORTED;
-    if ((long)B * H * W * Cin >= (1L << 31)) return IG_ERR_UNSUPPORTED;
-    CWParams p{};
-    p.x = (const bf16_t*)x, p.dy = (const bf16_t*)dy, p.dw = dw;
-    p.B = B, p.H = H, p.W = W;
-    p.tiles_x = (W + TW - 1) / TW, p.tiles_y = (H + TH - 1) / TH;
-    p.ntiles = (long)B * p.tiles_x * p.tiles_y;
-    if (p.ntiles == 0) return IG_OK;
-    constexpr int smem = (HH * HW_ + TH * TW) * 2 * 48;
+template <int CIN, int NWAVES>
+static int launch_wgrad_direct(const CWParams& p, int nslices, hipStream_t st) {
+    constexpr int ppx = 2 * CIN + ((CIN / 2) % 16 == 8 ? 0 : 32 - (CIN % 16) * 2);
+    constexpr int smem = HH * HW_ * ppx + TH * TW * 96;
     static const int nwg_env = getenv("IG_CONV_DIRECT_WGS") ? atoi(getenv("IG_CONV_DIRECT_WGS")) : 0;
-    long nwg = nwg_env > 0 ? nwg_env : 512;
+    long nwg = (nwg_env > 0 ? nwg_env : (NWAVES == 4 ? 512 : 256)) / nslices;  // all workgroups co-resident
     if (nwg > p.ntiles) nwg = p.ntiles;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_direct_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_direct_kernel<CIN, NWAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_done = true;
     }
-    hipLaunchKernelGGL(conv3x3_wgrad_direct_kernel<48>, dim3((unsigned)nwg), dim3(CD_TPB), smem, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((conv3x3_wgrad_direct_kernel<CIN, NWAVES>), dim3((unsigned)nwg, nslices), dim3(64 * NWAVES), smem, st, p);
     return ig_check_launch("ig_conv3x3_wgrad(direct)");
+}
+
+int ig_conv3x3_wgrad_direct(const void* dy, const void* x, float* dw, int B, int H, int W, int Cin, int Cout, void* stream) {
+    static const int enabled = getenv("IG_CONV_DIRECT") ? atoi(getenv("IG_CONV_DIRECT")) : 1;
+    if (!enabled || Cout % 48 != 0 || (Cin != 48 && Cin != 96)) return IG_ERR_UNSUPPORTED;
+    if ((long)B * H * W * (Cin > Cout ? Cin : Cout) >= (1L << 31)) return IG_ERR_UNSUPPORTED;
+    CWParams p{};
+    p.x = (const bf16_t*)x, p.dy = (const bf16_t*)dy, p.dw = dw;
+    p.B = B, p.H = H, p.W = W, p.Cout = Cout;
+    p.tiles_x = (W + TW - 1) / TW, p.tiles_y = (H + TH - 1) / TH;
+    p.ntiles = (long)B * p.tiles_x * p.tiles_y;
+    if (p.ntiles == 0) return IG_OK;
+    if (Cin == 48) return launch_wgrad_direct<48, 4>(p, Cout / 48, (hipStream_t)stream);
+    return launch_wgrad_direct<96, 8>(p, Cout / 48, (hipStream_t)stream);
 }
 
 // Called by ig_convT_fwd (gemm.hip); IG_ERR_UNSUPPORTED when the shape is not covered.

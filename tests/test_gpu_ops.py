@@ -262,8 +262,9 @@ def nhwc(x):  # NCHW -> NHWC
 
 
 @pytest.mark.parametrize("split", SPLITS)
-@pytest.mark.parametrize("B,H,Cin,Cout", [(2, 14, 48, 24), (1, 28, 144, 72), (3, 7, 8, 136), (2, 21, 48, 48), (1, 48, 48, 48), (3, 5, 48, 48)])
-def test_conv3x3(split, B, H, Cin, Cout):  # 48 -> 48 unsplit runs the halo-tile direct kernel (conv_direct.hip)
+@pytest.mark.parametrize("B,H,Cin,Cout", [(2, 14, 48, 24), (1, 28, 144, 72), (3, 7, 8, 136), (2, 21, 48, 48), (1, 48, 48, 48), (3, 5, 48, 48),
+                                          (2, 21, 96, 96), (1, 18, 48, 96), (1, 35, 96, 48)])
+def test_conv3x3(split, B, H, Cin, Cout):  # unsplit 48 -> 48 (fwd, dgrad) and Cin 48 / 96 (wgrad) run the halo-tile direct kernels
     W = H + 2
     x, xr = bt(nhwc(rnd(B, Cin, H, W, seed=26)), split)
     wt = rnd(Cout, Cin, 3, 3, seed=27, scale=(9 * Cin) ** -0.5)
