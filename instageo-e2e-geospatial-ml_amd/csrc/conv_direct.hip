@@ -15,9 +15,10 @@
 //     are issued ahead of the epilogue's stores; two workgroups per CU (2 x 76 KiB of LDS),
 //   * output channels are interleaved over the MFMA row blocks so that a lane stores 16 contiguous bytes; bias / folded
 //     BatchNorm constants are read from LDS (a global read in the epilogue waits on vmcnt, i.e. on the draining stores).
-// Measured at 108 x 224 x 224 x 48: 366 us against 614 us for the implicit GEMM; with the MFMAs switched off 210 us and with
-// the stores off 215 us remain -- at 1.04 GB of compulsory traffic (216 FLOP/B, below the chip's 312) this stage is bound
-// by HBM streaming, not by the matrix cores.
+// Measured at 108 x 224 x 224 x 48: 345-365 us against 614 us for the implicit GEMM; with the MFMAs switched off 210-260 us
+// and with the stores off 215 us remain -- at 1.04 GB of compulsory traffic (216 FLOP/B, below the chip's 312) this stage is
+// bound by HBM streaming, not by the matrix cores (SQ counters: MFMA busy 93 us, waves parked on waitcnt/barrier 39 %).
+// Tried without gain: staggered start of the two co-resident workgroups, L2 prefetch touches 1-3 tiles ahead.
 // The data gradient is the same kernel over dy with the weights gathered as W'[ci][8 - tap][co] at LDS-fill time.
 // Results are those of the implicit-GEMM path up to fp32 summation order (same bf16 operands, fp32 accumulation).
 #include "common.h"
@@ -111,17 +112,19 @@ __global__ __launch_bounds__(CD_TPB, 2) void conv3x3_direct_kernel(CDParams p) {
     const bool has_bn = p.col_scale != nullptr;
 
     // ---- tile-independent per-thread tables
-    // halo fill: unit u = round * 256 + tid -> (halo pixel, 16-byte unit)
-    int h_lds[G::ROUNDS], h_goff[G::ROUNDS], h_yx[G::ROUNDS];
+    // halo fill: unit u = round * 256 + tid -> (halo pixel, 16-byte unit); LDS offset = u * 16 (pitch = UNITS * 16).  Global
+    // offsets are relative to the halo's top-left pixel (ty0 - 1, tx0 - 1), i.e. non-negative: uniform base + 32-bit offset.
+    static_assert(G::PP == G::UNITS * 16, "halo units must be contiguous in LDS");
+    int h_goff[G::ROUNDS], h_yx[G::ROUNDS];
 #pragma unroll
     for (int r = 0; r < G::ROUNDS; ++r) {
         const int u = r * CD_TPB + tid;
         const int hp = u / G::UNITS, c8 = u - hp * G::UNITS;
         const int hy = hp / HW_, hx = hp - hy * HW_;
-        h_lds[r] = hp * G::PP + c8 * 16;
-        h_goff[r] = ((hy - 1) * p.W + (hx - 1)) * C + c8 * 8;
+        h_goff[r] = (hy * p.W + hx) * C + c8 * 8;
         h_yx[r] = u < G::HUNITS ? ((hy - 1) << 16) | ((hx - 1) & 0xffff) : 0x7fff0000;  // sentinel row: never inside the image
     }
+    const bool last_round_on = (G::ROUNDS - 1) * CD_TPB + tid < G::HUNITS;
     // operand reads: pixel-side address of this lane's k-group per K-step (relative to the px-block's first pixel)
     const int g = lane >> 4, j = lane & 15;
     int offk[G::KSTEPS];
@@ -136,33 +139,40 @@ __global__ __launch_bounds__(CD_TPB, 2) void conv3x3_direct_kernel(CDParams p) {
     const int zero_slot = G::H_BYTES;                                  // relative to hal
     const char* wl_lane = wl + j * G::WP + g * 16;
 
-    auto tile_coords = [&](long t, int& b, int& ty0, int& tx0) {
+    auto tile_coords = [&](int t, int& b, int& ty0, int& tx0) {
         const int per_img = p.tiles_x * p.tiles_y;
-        b = (int)(t / per_img);
-        const int r = (int)(t - (long)b * per_img);
+        b = t / per_img;
+        const int r = t - b * per_img;
         const int ty = r / p.tiles_x;
         ty0 = ty * TH, tx0 = (r - ty * p.tiles_x) * TW;
     };
     uint4 pre[G::ROUNDS];
-    auto fetch = [&](long t) {
+    auto fetch = [&](int t) {
         int b, ty0, tx0;
         tile_coords(t, b, ty0, tx0);
-        const bf16_t* base = p.x + (((size_t)b * p.H + ty0) * p.W + tx0) * C;
+        const bf16_t* base = p.x + (((long)b * p.H + ty0 - 1) * p.W + tx0 - 1) * C;  // halo origin (may lie outside: masked)
+        if (ty0 >= 1 && tx0 >= 1 && ty0 + TH < p.H && tx0 + TW < p.W) {
+            // interior tile (3 of 4 at 224 x 224): the whole halo is inside the image, no per-unit bounds tests
 #pragma unroll
-        for (int r = 0; r < G::ROUNDS; ++r) {
-            const int gy = ty0 + (h_yx[r] >> 16), gx = tx0 + (int)(short)(h_yx[r] & 0xffff);
-            const bool ok = ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
-            pre[r] = make_uint4(0, 0, 0, 0);
-            if (ok) pre[r] = *reinterpret_cast<const uint4*>(base + h_goff[r]);
+            for (int r = 0; r < G::ROUNDS - 1; ++r) pre[r] = *reinterpret_cast<const uint4*>(base + (unsigned)h_goff[r]);
+            pre[G::ROUNDS - 1] = make_uint4(0, 0, 0, 0);
+            if (last_round_on) pre[G::ROUNDS - 1] = *reinterpret_cast<const uint4*>(base + (unsigned)h_goff[G::ROUNDS - 1]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < G::ROUNDS; ++r) {
+                const int gy = ty0 + (h_yx[r] >> 16), gx = tx0 + (int)(short)(h_yx[r] & 0xffff);
+                const bool ok = ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
+                pre[r] = make_uint4(0, 0, 0, 0);
+                if (ok) pre[r] = *reinterpret_cast<const uint4*>(base + h_goff[r]);
+            }
         }
     };
 
     auto halo_to_lds = [&]() {
 #pragma unroll
         for (int r = 0; r < G::ROUNDS; ++r)
-            if (r * CD_TPB + tid < G::HUNITS) *reinterpret_cast<uint4*>(hal + h_lds[r]) = pre[r];
+            if (r * CD_TPB + tid < G::HUNITS) *reinterpret_cast<uint4*>(hal + (r * CD_TPB + tid) * 16) = pre[r];
     };
-
     // one output group = 4 consecutive channels starting at `n` of pixel `pix`, finished and stored (8 bytes) -- or, for an
     // interleaved block pair, 8 consecutive channels (16 bytes)
     auto finish4 = [&](f32x4 a, int n, size_t idx, float* v) {
@@ -182,17 +192,20 @@ __global__ __launch_bounds__(CD_TPB, 2) void conv3x3_direct_kernel(CDParams p) {
         }
     };
 
-    long t = blockIdx.x;
-    if (t < p.ntiles) {
+    // output element offset of this lane's pixel (row 4*wave of the tile, column j) relative to the tile origin, + channel 8g
+    const int e_lane = ((wave * 4) * p.W + j) * C;
+    const int nt = (int)p.ntiles, gstep = (int)gridDim.x;
+    int t = blockIdx.x;
+    if (t < nt) {
         fetch(t);
         halo_to_lds();
-        if (t + gridDim.x < p.ntiles) fetch(t + gridDim.x);
+        if (t + gstep < nt) fetch(t + gstep);
     }
     __syncthreads();
-    for (; t < p.ntiles; t += gridDim.x) {
+    for (; t < nt; t += gstep) {
         int b, ty0, tx0;
         tile_coords(t, b, ty0, tx0);
-        const long tn = t + gridDim.x, tnn = tn + gridDim.x;
+        const int tn = t + gstep, tnn = tn + gstep;
 
         // ---- 4 px-blocks (rows 4*wave .. +3 of the tile) x NB channel blocks per wave
         f32x4 acc[G::NB][4];
@@ -219,22 +232,23 @@ __global__ __launch_bounds__(CD_TPB, 2) void conv3x3_direct_kernel(CDParams p) {
         // tile after it in flight BEFORE this tile's stores -- the memory pipeline serves a wave's requests in order, and
         // loads queued behind 12 stores per lane did not land within one tile's MFMAs
         __syncthreads();
-        if (tn < p.ntiles) halo_to_lds();
+        if (tn < nt) halo_to_lds();
         __syncthreads();
-        if (tnn < p.ntiles) fetch(tnn);
+        if (tnn < nt) fetch(tnn);
 
         // ---- epilogue (its stores drain under the next tile's MFMAs): lane holds, of pixel (row 4*wave + mb, column j),
         // channels 32p + 8g .. +7 from block pair p and channels 16*nb + 4g .. +3 from an unpaired last block
         const int ox = tx0 + j;
+        const size_t origin = (((size_t)b * p.H + ty0) * p.W + tx0) * C;  // uniform: first element of the output tile
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             const int oy = ty0 + wave * 4 + mb;
             if (oy < p.H && ox < p.W) {
-                const size_t pix = ((size_t)b * p.H + oy) * p.W + ox;
+                const size_t pixc = origin + (unsigned)(e_lane + mb * p.W * C);  // element index of channel 0 of the pixel
 #pragma unroll
                 for (int pr = 0; pr < G::NPAIR; ++pr) {
                     const int n = pr * 32 + 8 * g;
-                    const size_t idx = pix * C + n;
+                    const size_t idx = pixc + n;
                     float v[8];
                     finish4(acc[2 * pr][mb], n, idx, v);
                     finish4(acc[2 * pr + 1][mb], n + 4, idx + 4, v + 4);
@@ -242,7 +256,7 @@ __global__ __launch_bounds__(CD_TPB, 2) void conv3x3_direct_kernel(CDParams p) {
                 }
                 if (G::NB & 1) {
                     const int n = (G::NB - 1) * 16 + 4 * g;
-                    const size_t idx = pix * C + n;
+                    const size_t idx = pixc + n;
                     float v[4];
                     finish4(acc[G::NB - 1][mb], n, idx, v);
                     store4_split(p.y, nullptr, idx, v);
@@ -602,6 +616,156 @@ __global__ __launch_bounds__(CT_TPB, 1) void convT_direct_kernel(CTParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------- ConvTranspose2d weight gradient
+// dWc[co][tap][ci] += sum over base pixels (iy, ix) of dy[2iy + py(tap)][2ix + px(tap)][co] * x[iy + (ky==0)][ix + (kx==0)][ci]
+// for the 96 -> 48 stage (the implicit GEMM ran one split-K GEMM per tap: 440 us).  Same scheme as the 3x3 weight gradient:
+// register-resident 48 x 864 partial sum per persistent workgroup, one atomic pass at the end.  Six waves: wave w owns the
+// input-channel block ci = 16w .. 16w+15 of ALL nine taps (9 x 3 accumulators), so the dy fragments of the four sub-pixel
+// phases (4 x 3 per K-step) are shared by its nine taps and the code is identical for every wave.  Tile = 8 x 16 base pixels:
+// x patch 9 x 17 (zero-filled outside), dy tile 16 x 32 output pixels stored as four phase planes of 8 x 16 pixels so that
+// the 8 pixels a 32-lane half reads together are consecutive (see the 3x3 weight gradient).
+constexpr int TW_TPB = 384;
+constexpr int TWH = 8, TWW = 16;  // base-pixel tile
+
+struct CTWParams {
+    const bf16_t* x;   // [B][H][W][CIN]
+    const bf16_t* dy;  // [B][2H][2W][COUT]
+    float* dw;         // [COUT][9][CIN]
+    int B, H, W;
+    int tiles_x, tiles_y;
+    long ntiles;
+};
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(TW_TPB, 1) void convT_wgrad_direct_kernel(CTWParams p) {
+    static_assert(CIN == 16 * (TW_TPB / 64), "one 16-channel input block per wave");
+    constexpr int PPX = 2 * CIN + 32;   // 56 dwords
+    constexpr int PPD = 2 * COUT;       // 24 dwords
+    static_assert((PPX / 4) % 16 == 8 && (PPD / 4) % 16 == 8, "pixel pitches must be = 8 (mod 16) dwords");
+    constexpr int PH = TWH + 1, PW = TWW + 1;
+    constexpr int X_BYTES = PH * PW * PPX, PLANE = TWH * TWW * PPD;
+    constexpr int XU = CIN / 8, DU = COUT / 8;
+    constexpr int XUNITS = PH * PW * XU, XROUNDS = (XUNITS + TW_TPB - 1) / TW_TPB;
+    constexpr int DUNITS = 4 * TWH * TWW * DU, DROUNDS = DUNITS / TW_TPB;
+    static_assert(DUNITS % TW_TPB == 0, "dy tile units must divide evenly");
+    constexpr int CB = COUT / 16;
+    constexpr int KS = TWH * TWW / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* xp = smem;
+    char* dyp = smem + X_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pq = i16 & 3;
+
+    int h_goff[XROUNDS], d_goff[DROUNDS], d_lds[DROUNDS];
+#pragma unroll
+    for (int r = 0; r < XROUNDS; ++r) {
+        const int u = r * TW_TPB + tid;
+        const int hp = u / XU, c8 = u - hp * XU;
+        const int hy = hp / PW, hx = hp - hy * PW;
+        h_goff[r] = (hy * p.W + hx) * CIN + c8 * 8;
+    }
+#pragma unroll
+    for (int r = 0; r < DROUNDS; ++r) {
+        const int u = r * TW_TPB + tid;
+        const int px = u / DU, c8 = u - px * DU;
+        const int oy = px / (2 * TWW), ox = px - oy * (2 * TWW);
+        d_goff[r] = (oy * 2 * p.W + ox) * COUT + c8 * 8;
+        d_lds[r] = ((oy & 1) * 2 + (ox & 1)) * PLANE + ((oy >> 1) * TWW + (ox >> 1)) * PPD + c8 * 16;
+    }
+    // k-row of lane (g, q) in read h of K-step s: base pixel (row 2s + (g>>1), column 8h + 4(g&1) + q)
+    const int a_base = (((g >> 1) * TWW + 4 * (g & 1) + q) * PPD) + pq * 8;
+    const int b_base = (((g >> 1) * PW + 4 * (g & 1) + q) * PPX) + pq * 8 + wave * 32;
+
+    auto tile_coords = [&](long t, int& b, int& ty0, int& tx0) {
+        const int per_img = p.tiles_x * p.tiles_y;
+        b = (int)(t / per_img);
+        const int r = (int)(t - (long)b * per_img);
+        const int ty = r / p.tiles_x;
+        ty0 = ty * TWH, tx0 = (r - ty * p.tiles_x) * TWW;
+    };
+    uint4 prex[XROUNDS], pred[DROUNDS];
+    auto fetch = [&](long t) {
+        int b, ty0, tx0;
+        tile_coords(t, b, ty0, tx0);
+        const bf16_t* xb = p.x + (((size_t)b * p.H + ty0) * p.W + tx0) * CIN;
+        const bf16_t* db = p.dy + (((size_t)b * 2 * p.H + 2 * ty0) * (2 * p.W) + 2 * tx0) * COUT;
+#pragma unroll
+        for (int r = 0; r < XROUNDS; ++r) {
+            const int u = r * TW_TPB + tid, hp = u / XU, hy = hp / PW, hx = hp - hy * PW;
+            prex[r] = make_uint4(0, 0, 0, 0);
+            if ((u < XUNITS) & (ty0 + hy < p.H) & (tx0 + hx < p.W)) prex[r] = *reinterpret_cast<const uint4*>(xb + h_goff[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < DROUNDS; ++r) {
+            const int px = (r * TW_TPB + tid) / DU, oy = px / (2 * TWW), ox = px - oy * (2 * TWW);
+            pred[r] = make_uint4(0, 0, 0, 0);
+            if ((2 * ty0 + oy < 2 * p.H) & (2 * tx0 + ox < 2 * p.W)) pred[r] = *reinterpret_cast<const uint4*>(db + d_goff[r]);
+        }
+    };
+    auto to_lds = [&]() {
+#pragma unroll
+        for (int r = 0; r < XROUNDS; ++r) {
+            const int u = r * TW_TPB + tid, hp = u / XU;
+            if (u < XUNITS) *reinterpret_cast<uint4*>(xp + hp * PPX + (u - hp * XU) * 16) = prex[r];
+        }
+#pragma unroll
+        for (int r = 0; r < DROUNDS; ++r) *reinterpret_cast<uint4*>(dyp + d_lds[r]) = pred[r];
+    };
+    typedef __attribute__((address_space(3))) s16x4* lds_ptr;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    auto tr_frag = [&](const char* base, int off, int pitch) {
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(base + off));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(base + off + 8 * pitch));
+        const s16x8 r = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        return __builtin_bit_cast(bf16x8_t, r);
+    };
+
+    f32x4 acc[9][CB];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) acc[tap][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    long t = blockIdx.x;
+    if (t < p.ntiles) {
+        fetch(t);
+        to_lds();
+        if (t + gridDim.x < p.ntiles) fetch(t + gridDim.x);
+    }
+    __syncthreads();
+    for (; t < p.ntiles; t += gridDim.x) {
+        const long tn = t + gridDim.x, tnn = tn + gridDim.x;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph) {  // phase (py, px) = (ph >> 1, ph & 1): taps with (ky != 1) == py and (kx != 1) == px
+                bf16x8_t af[CB];
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) af[cb] = tr_frag(dyp, ph * PLANE + a_base + s * 2 * TWW * PPD + cb * 32, PPD);
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int ky = tap / 3, kx = tap % 3;
+                    if ((ky != 1) * 2 + (kx != 1) != ph) continue;
+                    const bf16x8_t bf = tr_frag(xp, b_base + (s * 2 * PW + (ky == 0) * PW + (kx == 0)) * PPX, PPX);
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb) acc[tap][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cb], bf, acc[tap][cb], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        if (tn < p.ntiles) to_lds();
+        __syncthreads();
+        if (tnn < p.ntiles) fetch(tnn);
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                atomicAdd(p.dw + (size_t)(cb * 16 + 4 * g + r) * (9 * CIN) + tap * CIN + wave * 16 + i16, acc[tap][cb][r]);
+}
+
 }  // namespace
 
 // Called by ig_conv3x3_fwd / ig_conv3x3_dgrad (gemm.hip) for the shapes this kernel covers; returns IG_ERR_UNSUPPORTED
@@ -681,4 +845,26 @@ int ig_convT_fwd_direct(const void* x, const void* w, const float* bias, void* y
     }
     hipLaunchKernelGGL((convT_direct_kernel<96, 48>), dim3((unsigned)nwg), dim3(CT_TPB), smem, (hipStream_t)stream, p);
     return ig_check_launch("ig_convT_fwd(direct)");
+}
+
+// Called by ig_convT_wgrad (gemm.hip); IG_ERR_UNSUPPORTED when the shape is not covered.
+int ig_convT_wgrad_direct(const void* dy, const void* x, float* dw, int B, int H, int W, int Cin, int Cout, void* stream) {
+    static const int enabled = getenv("IG_CONV_DIRECT") ? atoi(getenv("IG_CONV_DIRECT")) : 1;
+    if (!enabled || Cin != 96 || Cout != 48) return IG_ERR_UNSUPPORTED;
+    if ((long)B * H * W * 4 * Cout >= (1L << 31)) return IG_ERR_UNSUPPORTED;
+    CTWParams p{};
+    p.x = (const bf16_t*)x, p.dy = (const bf16_t*)dy, p.dw = dw;
+    p.B = B, p.H = H, p.W = W;
+    p.tiles_x = (W + TWW - 1) / TWW, p.tiles_y = (H + TWH - 1) / TWH;
+    p.ntiles = (long)B * p.tiles_x * p.tiles_y;
+    if (p.ntiles == 0) return IG_OK;
+    constexpr int smem = (TWH + 1) * (TWW + 1) * (2 * 96 + 32) + 4 * TWH * TWW * 96;
+    long nwg = p.ntiles < 256 ? p.ntiles : 256;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)convT_wgrad_direct_kernel<96, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((convT_wgrad_direct_kernel<96, 48>), dim3((unsigned)nwg), dim3(TW_TPB), smem, (hipStream_t)stream, p);
+    return ig_check_launch("ig_convT_wgrad(direct)");
 }

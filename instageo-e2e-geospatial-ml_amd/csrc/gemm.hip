@@ -1663,6 +1663,10 @@ int ig_convT_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const
     IG_REQUIRE(dy_hi && x_hi && dw, "ig_convT_wgrad: null pointer");
     IG_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, "ig_convT_wgrad: channels must be multiples of 8");
     IG_SPLIT_CONSISTENT(dy_lo, x_lo);
+    if (!dy_lo) {  // last stage (96 -> 48): register-resident partial sums (conv_direct.hip)
+        const int rc = ig_convT_wgrad_direct(dy_hi, x_hi, dw, B, H, W, Cin, Cout, stream);
+        if (rc != IG_ERR_UNSUPPORTED) return rc;
+    }
     int Mtot = B * H * W;
     ConvTGradLoader al{};
     seg_a(al.base, dy_hi, dy_lo);
