@@ -29,6 +29,9 @@ extern "C" {
 /* ---- runtime ---------------------------------------------------------------------------------------- */
 const char* ig_last_error(void);
 int ig_version(void);
+/* first 32 bits of the MD5 of this header as the library was built against it: the host mirror refuses a library whose
+ * entry points were compiled from a different revision of the declarations (stale .so next to a newer header) */
+int ig_header_stamp(void);
 int ig_device_info(int device, char* name, int name_len, int* cu_count, int* lds_per_block, long* hbm_bytes);
 
 /* ---- dataset side: normalise + layout (instageo/model/dataloader.py:495-524, 707-750) ---------------- */

@@ -29,6 +29,11 @@ const char* ig_last_error(void) { return g_err; }
 
 int ig_version(void) { return 100; }  // 0.1.0
 
+#ifndef IG_HEADER_STAMP
+#error "build through the Makefile: IG_HEADER_STAMP (MD5 prefix of include/instageo_hip.h) is not defined"
+#endif
+int ig_header_stamp(void) { return (int)(IG_HEADER_STAMP); }
+
 // name: buffer >= 64 bytes; returns 0 or IG_ERR_HIP when no usable device is present
 int ig_device_info(int device, char* name, int name_len, int* cu_count, int* lds_per_block, long* hbm_bytes) {
     hipDeviceProp_t p;

@@ -82,6 +82,15 @@ def load():
             raise HipLibraryError(f"symbol {name} declared in instageo_hip.h is missing from {LIB_PATH}") from e
         fn.restype = ctypes.c_char_p if ret.startswith("const char") else ctypes.c_int
         fn.argtypes = [_ctype(t) for t in types]
+    import hashlib
+
+    want = int(hashlib.md5(open(HEADER_PATH, "rb").read()).hexdigest()[:7], 16)
+    got = lib.ig_header_stamp()
+    if got != want:
+        raise HipLibraryError(
+            f"{LIB_PATH} was built against another revision of {HEADER_PATH} (stamp {got:#x}, header {want:#x}): rebuild it "
+            f"(`make -C {os.path.join(_PKG_ROOT, 'csrc')}`) -- calling it with this header's signatures would pass shifted arguments."
+        )
     _lib, _protos = lib, protos
     return lib
 
