@@ -25,6 +25,14 @@
 
 namespace {
 
+// First tile of a persistent workgroup.  Workgroups are dealt round-robin over the 8 XCDs (private L2s): with t = blockIdx.x
+// the eight neighbours of a tile run on eight different XCDs and every halo is fetched from HBM/MALL again (FETCH_SIZE showed
+// 655 MB against 520 MB of input).  Give XCD k the k-th contiguous eighth of each round of gridDim.x tiles instead.
+__device__ __forceinline__ int xcd_first_tile() {
+    const int nb = gridDim.x;
+    return (nb & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (nb >> 3) + (int)(blockIdx.x >> 3);
+}
+
 constexpr int CD_TPB = 256;
 constexpr int TH = 16, TW = 16;    // output tile
 constexpr int HH = TH + 2, HW_ = TW + 2;  // halo
@@ -195,7 +203,7 @@ __global__ __launch_bounds__(CD_TPB, 2) void conv3x3_direct_kernel(CDParams p) {
     // output element offset of this lane's pixel (row 4*wave of the tile, column j) relative to the tile origin, + channel 8g
     const int e_lane = ((wave * 4) * p.W + j) * C;
     const int nt = (int)p.ntiles, gstep = (int)gridDim.x;
-    int t = blockIdx.x;
+    int t = xcd_first_tile();
     if (t < nt) {
         fetch(t);
         halo_to_lds();
@@ -406,7 +414,7 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES == 4 ? 2 : 1) void conv3x3_wgra
 #pragma unroll
         for (int b = 0; b < NBW; ++b) acc[cb][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    long t = blockIdx.x;
+    long t = xcd_first_tile();
     if (t < p.ntiles) {
         fetch(t);
         to_lds();
@@ -534,7 +542,7 @@ __global__ __launch_bounds__(CT_TPB, 1) void convT_direct_kernel(CTParams p) {
     const char* x_lane = xp + ((wave * 2) * CT_P + j) * PP + g * 16;  // px-block 0 of this wave (input row 2*wave), pixel j
     const char* w_lane = wl + j * WP + g * 16;
 
-    long t = blockIdx.x;
+    long t = xcd_first_tile();
     if (t < p.ntiles) {
         fetch(t);
         to_lds();
@@ -726,7 +734,7 @@ __global__ __launch_bounds__(TW_TPB, 1) void convT_wgrad_direct_kernel(CTWParams
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) acc[tap][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    long t = blockIdx.x;
+    long t = xcd_first_tile();
     if (t < p.ntiles) {
         fetch(t);
         to_lds();
@@ -756,6 +764,145 @@ __global__ __launch_bounds__(TW_TPB, 1) void convT_wgrad_direct_kernel(CTWParams
         if (tn < p.ntiles) to_lds();
         __syncthreads();
         if (tnn < p.ntiles) fetch(tnn);
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                atomicAdd(p.dw + (size_t)(cb * 16 + 4 * g + r) * (9 * CIN) + tap * CIN + wave * 16 + i16, acc[tap][cb][r]);
+}
+
+// ---- LDS-DMA variant of the ConvTranspose weight gradient ------------------------------------------------------
+// The register-prefetch kernel above keeps one tile (83 KB) of loads in flight per CU and nothing while it computes: one
+// workgroup per CU reached 2 TB/s (the two-workgroup 3x3 kernels reach 4).  Here the tile is 4 x 16 base pixels (48 KiB
+// stage, both images lane-linear so that global_load_lds_dwordx4 can fill them: x patch 5 x 17 pixels x 224 B, dy as four
+// phase planes of 4 x 16 pixels x 96 B) and a 3-stage ring keeps two tiles in flight while a third is consumed -- the
+// protocol of gemm2_kernel: every wave issues exactly 8 DMAs per tile, waits for its own with a counted vmcnt, one barrier
+// per tile covers the other waves' pieces (RAW) and the slot that is refilled next (WAR).  No global stores in the loop, so
+// the vmcnt count is exact.
+__device__ __forceinline__ void cd_glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(TW_TPB, 1) void convT_wgrad_dma_kernel(CTWParams p, const bf16_t* zero_page) {
+    static_assert(CIN == 96 && COUT == 48, "unit tables below are written for 96 -> 48");
+    constexpr int T4 = 4;                       // base-pixel rows per tile
+    constexpr int PPX = 2 * CIN + 32, PPD = 2 * COUT;
+    constexpr int PH = T4 + 1, PW = TWW + 1;
+    constexpr int XUP = PPX / 16;               // 14 units per patch pixel (12 data + 2 pad)
+    constexpr int XUNITS = PH * PW * XUP;       // 1190
+    constexpr int XSLOTS = (XUNITS + 63) / 64;  // 19 wave-DMAs
+    constexpr int PLANE = T4 * TWW * PPD;       // 6144 B = 384 units
+    constexpr int DUNITS = 4 * PLANE / 16;      // 1536
+    constexpr int DSLOTS = DUNITS / 64;         // 24
+    constexpr int NW = TW_TPB / 64;             // 6 waves
+    constexpr int PER_WAVE = (XSLOTS + DSLOTS + NW - 1) / NW;  // 8
+    constexpr int STAGE = PER_WAVE * NW * 1024; // 48 KiB (slots beyond 43 are scratch)
+    constexpr int D_OFF = XSLOTS * 1024;
+    constexpr int CB = COUT / 16;
+    constexpr int KS = T4 * TWW / 32;           // 2 K-steps per tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) char* lds_char_ptr;
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_char_ptr)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pq = i16 & 3;
+
+    // per-lane unit tables: element offset from the tile origin of its image, image kind, pixel offset for the bounds test
+    int u_off[PER_WAVE], u_meta[PER_WAVE];  // meta: 0 = always zero page; else (kind << 16) | (dy << 8) | dx, kind 1 = x, 2 = dy
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const int slot = i * NW + wave, u = slot * 64 + lane;
+        u_off[i] = 0, u_meta[i] = 0;
+        if (slot < XSLOTS) {
+            const int hp = u / XUP, c = u - hp * XUP;
+            const int hy = hp / PW, hx = hp - hy * PW;
+            if (u < XUNITS && c < CIN / 8) u_off[i] = (hy * p.W + hx) * CIN + c * 8, u_meta[i] = (1 << 16) | (hy << 8) | hx;
+        } else if (slot < XSLOTS + DSLOTS) {
+            const int ud = u - XSLOTS * 64;
+            const int plane = ud / (PLANE / 16), rem = ud - plane * (PLANE / 16);
+            const int pix = rem / (COUT / 8), c8 = rem - pix * (COUT / 8);
+            const int iy = pix / TWW, ix = pix - iy * TWW;
+            u_off[i] = ((2 * iy + (plane >> 1)) * 2 * p.W + 2 * ix + (plane & 1)) * COUT + c8 * 8;
+            u_meta[i] = (2 << 16) | (iy << 8) | ix;
+        }
+    }
+    auto tile_coords = [&](long t, int& b, int& ty0, int& tx0) {
+        const int per_img = p.tiles_x * p.tiles_y;
+        b = (int)(t / per_img);
+        const int r = (int)(t - (long)b * per_img);
+        const int ty = r / p.tiles_x;
+        ty0 = ty * T4, tx0 = (r - ty * p.tiles_x) * TWW;
+    };
+    auto issue = [&](long t, int slot3) {
+        int b, ty0, tx0;
+        tile_coords(t, b, ty0, tx0);
+        const bf16_t* xb = p.x + (((size_t)b * p.H + ty0) * p.W + tx0) * CIN;
+        const bf16_t* db = p.dy + (((size_t)b * 2 * p.H + 2 * ty0) * (2 * p.W) + 2 * tx0) * COUT;
+        const unsigned sbase = lds_base + slot3 * STAGE;
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i) {
+            const int m = u_meta[i];
+            const bool ok = (m != 0) & (ty0 + ((m >> 8) & 0xff) < p.H) & (tx0 + (m & 0xff) < p.W);
+            const bf16_t* src = ((m >> 16) == 1 ? xb : db) + u_off[i];
+            cd_glds16(ok ? src : zero_page, sbase + (i * NW + wave) * 1024);
+        }
+    };
+    // operand addresses (see convT_wgrad_direct_kernel): k-row of lane (g, q) in read h of K-step s = base pixel
+    // (row 2s + (g>>1), column 8h + 4(g&1) + q)
+    const int a_base = D_OFF + (((g >> 1) * TWW + 4 * (g & 1) + q) * PPD) + pq * 8;
+    const int b_base = (((g >> 1) * PW + 4 * (g & 1) + q) * PPX) + pq * 8 + wave * 32;
+    typedef __attribute__((address_space(3))) s16x4* lds_ptr;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    auto tr_frag = [&](const char* base, int off, int pitch) {
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(base + off));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(base + off + 8 * pitch));
+        const s16x8 r = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        return __builtin_bit_cast(bf16x8_t, r);
+    };
+    f32x4 acc[9][CB];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) acc[tap][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const long t0 = xcd_first_tile(), gstep = gridDim.x;
+    const long mine = t0 < p.ntiles ? (p.ntiles - t0 + gstep - 1) / gstep : 0;
+    if (mine > 0) issue(t0, 0);
+    if (mine > 1) issue(t0 + gstep, 1);
+    int slot = 0;
+    for (long n = 0; n < mine; ++n) {
+        if (n + 1 < mine) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        if (n + 2 < mine) issue(t0 + (n + 2) * gstep, slot >= 1 ? slot - 1 : slot + 2);
+        const char* st = smem + slot * STAGE;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph) {
+                bf16x8_t af[CB];
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) af[cb] = tr_frag(st, ph * PLANE + a_base + s * 2 * TWW * PPD + cb * 32, PPD);
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int ky = tap / 3, kx = tap % 3;
+                    if ((ky != 1) * 2 + (kx != 1) != ph) continue;
+                    const bf16x8_t bf = tr_frag(st, b_base + (s * 2 * PW + (ky == 0) * PW + (kx == 0)) * PPX, PPX);
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb) acc[tap][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cb], bf, acc[tap][cb], 0, 0, 0);
+                }
+            }
+        }
+        slot = slot == 2 ? 0 : slot + 1;
     }
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
@@ -848,18 +995,44 @@ int ig_convT_fwd_direct(const void* x, const void* w, const float* bias, void* y
 }
 
 // Called by ig_convT_wgrad (gemm.hip); IG_ERR_UNSUPPORTED when the shape is not covered.
+static const bf16_t* cd_zero_page() {
+    static void* z = nullptr;
+    if (!z) {
+        if (hipMalloc(&z, 256) != hipSuccess) return nullptr;
+        (void)hipMemset(z, 0, 256);
+    }
+    return (const bf16_t*)z;
+}
+
 int ig_convT_wgrad_direct(const void* dy, const void* x, float* dw, int B, int H, int W, int Cin, int Cout, void* stream) {
     static const int enabled = getenv("IG_CONV_DIRECT") ? atoi(getenv("IG_CONV_DIRECT")) : 1;
+    static const int use_dma = getenv("IG_CTW_DMA") ? atoi(getenv("IG_CTW_DMA")) : 1;
     if (!enabled || Cin != 96 || Cout != 48) return IG_ERR_UNSUPPORTED;
     if ((long)B * H * W * 4 * Cout >= (1L << 31)) return IG_ERR_UNSUPPORTED;
     CTWParams p{};
     p.x = (const bf16_t*)x, p.dy = (const bf16_t*)dy, p.dw = dw;
     p.B = B, p.H = H, p.W = W;
-    p.tiles_x = (W + TWW - 1) / TWW, p.tiles_y = (H + TWH - 1) / TWH;
+    const int th = use_dma ? 4 : TWH;
+    p.tiles_x = (W + TWW - 1) / TWW, p.tiles_y = (H + th - 1) / th;
     p.ntiles = (long)B * p.tiles_x * p.tiles_y;
     if (p.ntiles == 0) return IG_OK;
-    constexpr int smem = (TWH + 1) * (TWW + 1) * (2 * 96 + 32) + 4 * TWH * TWW * 96;
     long nwg = p.ntiles < 256 ? p.ntiles : 256;
+    if (use_dma) {
+        constexpr int smem = 3 * 48 * 1024;
+        const bf16_t* zp = cd_zero_page();
+        if (!zp) {
+            ig_set_error("ig_convT_wgrad: could not allocate the zero page");
+            return IG_ERR_HIP;
+        }
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)convT_wgrad_dma_kernel<96, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((convT_wgrad_dma_kernel<96, 48>), dim3((unsigned)nwg), dim3(TW_TPB), smem, (hipStream_t)stream, p, zp);
+        return ig_check_launch("ig_convT_wgrad(direct, dma)");
+    }
+    constexpr int smem = (TWH + 1) * (TWW + 1) * (2 * 96 + 32) + 4 * TWH * TWW * 96;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)convT_wgrad_direct_kernel<96, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
