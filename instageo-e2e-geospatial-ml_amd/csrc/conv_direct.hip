@@ -913,6 +913,141 @@ __global__ __launch_bounds__(TW_TPB, 1) void convT_wgrad_dma_kernel(CTWParams p,
                 atomicAdd(p.dw + (size_t)(cb * 16 + 4 * g + r) * (9 * CIN) + tap * CIN + wave * 16 + i16, acc[tap][cb][r]);
 }
 
+// ---- LDS-DMA variant of the 3x3 weight gradient for 96 input channels (one 8-wave workgroup per CU) ------------------
+// Same ring protocol as convT_wgrad_dma_kernel.  Tile = 8 x 16 pixels: x halo 10 x 18 pixels x 224 B (40 wave-DMAs), dy tile
+// 8 x 16 pixels x 96 B of this workgroup's 48-channel slice (12 wave-DMAs); 3 stages x 52 KiB.  Waves 0-3 issue 7 DMAs per
+// tile, waves 4-7 issue 6 (52 = 4 x 7 + 4 x 6), so the counted vmcnt differs by wave.
+template <int CIN>
+__global__ __launch_bounds__(512, 1) void conv3x3_wgrad_dma_kernel(CWParams p, const bf16_t* zero_page) {
+    static_assert(CIN == 96, "unit tables below are written for 96 input channels");
+    constexpr int COB = 48, R8 = 8;
+    constexpr int PPX = 2 * CIN + 32, PPD = 2 * COB;
+    constexpr int PHh = R8 + 2;                 // halo rows
+    constexpr int XUP = PPX / 16;               // 14 units per halo pixel (12 data + 2 pad)
+    constexpr int XUNITS = PHh * HW_ * XUP;     // 2520
+    constexpr int XSLOTS = (XUNITS + 63) / 64;  // 40
+    constexpr int DUNITS = R8 * TW * (COB / 8); // 768
+    constexpr int DSLOTS = DUNITS / 64;         // 12
+    constexpr int SLOTS = XSLOTS + DSLOTS;      // 52
+    constexpr int NW = 8, PER_WAVE = (SLOTS + NW - 1) / NW;  // 7
+    constexpr int STAGE = SLOTS * 1024, D_OFF = XSLOTS * 1024;
+    constexpr int CB = COB / 16, CIB = CIN / 16, NBLK = 9 * CIB, NBW = (NBLK + NW - 1) / NW;
+    constexpr int KS = R8 * TW / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) char* lds_char_ptr;
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_char_ptr)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pq = i16 & 3;
+    const int co0 = blockIdx.y * COB;
+
+    int u_off[PER_WAVE], u_meta[PER_WAVE];  // meta: 0 = zero page; else (kind << 16) | (row << 8) | col, kind 1 = x halo, 2 = dy
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const int slot = i * NW + wave, u = slot * 64 + lane;
+        u_off[i] = 0, u_meta[i] = 0;
+        if (slot < XSLOTS) {
+            const int hp = u / XUP, c = u - hp * XUP;
+            const int hy = hp / HW_, hx = hp - hy * HW_;
+            if (u < XUNITS && c < CIN / 8) u_off[i] = (hy * p.W + hx) * CIN + c * 8, u_meta[i] = (1 << 16) | (hy << 8) | hx;
+        } else if (slot < SLOTS) {
+            const int ud = u - XSLOTS * 64;
+            const int pix = ud / (COB / 8), c8 = ud - pix * (COB / 8);
+            const int ty = pix / TW, tx = pix - ty * TW;
+            u_off[i] = (ty * p.W + tx) * p.Cout + co0 + c8 * 8;
+            u_meta[i] = (2 << 16) | (ty << 8) | tx;
+        }
+    }
+    auto tile_coords = [&](long t, int& b, int& ty0, int& tx0) {
+        const int per_img = p.tiles_x * p.tiles_y;
+        b = (int)(t / per_img);
+        const int r = (int)(t - (long)b * per_img);
+        const int ty = r / p.tiles_x;
+        ty0 = ty * R8, tx0 = (r - ty * p.tiles_x) * TW;
+    };
+    auto issue = [&](long t, int slot3) {
+        int b, ty0, tx0;
+        tile_coords(t, b, ty0, tx0);
+        const bf16_t* xb = p.x + (((long)b * p.H + ty0 - 1) * p.W + tx0 - 1) * CIN;  // halo origin (outside units are masked)
+        const bf16_t* db = p.dy + (((size_t)b * p.H + ty0) * p.W + tx0) * p.Cout;
+        const unsigned sbase = lds_base + slot3 * STAGE;
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i) {
+            if (i * NW + wave >= SLOTS) break;  // wave-uniform: waves 4-7 have one DMA less
+            const int m = u_meta[i];
+            const int r = (m >> 8) & 0xff, c = m & 0xff;
+            const bool isx = (m >> 16) == 1;
+            const bool ok = (m != 0) & (isx ? ((unsigned)(ty0 + r - 1) < (unsigned)p.H) & ((unsigned)(tx0 + c - 1) < (unsigned)p.W)
+                                            : (ty0 + r < p.H) & (tx0 + c < p.W));
+            const bf16_t* src = (isx ? xb : db) + u_off[i];
+            cd_glds16(ok ? src : zero_page, sbase + (i * NW + wave) * 1024);
+        }
+    };
+    const int a_base = D_OFF + (((g >> 1) * TW + 4 * (g & 1) + q) * PPD) + pq * 8;
+    const int b_lane = (((g >> 1) * HW_ + 4 * (g & 1) + q) * PPX) + pq * 8;
+    int b_base[NBW];
+#pragma unroll
+    for (int b = 0; b < NBW; ++b) {
+        const int nb = min(wave * NBW + b, NBLK - 1);
+        const int tap = nb / CIB, cib = nb - tap * CIB;
+        const int dy = tap / 3, dx = tap - dy * 3;
+        b_base[b] = b_lane + (dy * HW_ + dx) * PPX + cib * 32;
+    }
+    typedef __attribute__((address_space(3))) s16x4* lds_ptr;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    auto tr_frag = [&](const char* base, int off, int pitch) {
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(base + off));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(base + off + 8 * pitch));
+        const s16x8 r = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        return __builtin_bit_cast(bf16x8_t, r);
+    };
+    f32x4 acc[CB][NBW];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int b = 0; b < NBW; ++b) acc[cb][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const long t0 = xcd_first_tile(), gstep = gridDim.x;
+    const long mine = t0 < p.ntiles ? (p.ntiles - t0 + gstep - 1) / gstep : 0;
+    if (mine > 0) issue(t0, 0);
+    if (mine > 1) issue(t0 + gstep, 1);
+    int slot = 0;
+    for (long n = 0; n < mine; ++n) {
+        if (n + 1 < mine) {
+            if (wave < SLOTS - (PER_WAVE - 1) * NW) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_barrier" ::: "memory");
+        if (n + 2 < mine) issue(t0 + (n + 2) * gstep, slot >= 1 ? slot - 1 : slot + 2);
+        const char* st = smem + slot * STAGE;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            bf16x8_t af[CB];
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) af[cb] = tr_frag(st, a_base + s * 2 * TW * PPD + cb * 32, PPD);
+#pragma unroll
+            for (int b = 0; b < NBW; ++b) {
+                const bf16x8_t bf = tr_frag(st, b_base[b] + s * 2 * HW_ * PPX, PPX);
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) acc[cb][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cb], bf, acc[cb][b], 0, 0, 0);
+            }
+        }
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+#pragma unroll
+    for (int b = 0; b < NBW; ++b) {
+        const int nb = wave * NBW + b;
+        if (nb < NBLK) {
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) atomicAdd(p.dw + (size_t)(co0 + cb * 16 + 4 * g + r) * (9 * CIN) + nb * 16 + i16, acc[cb][b][r]);
+        }
+    }
+}
+
 }  // namespace
 
 // Called by ig_conv3x3_fwd / ig_conv3x3_dgrad (gemm.hip) for the shapes this kernel covers; returns IG_ERR_UNSUPPORTED
@@ -935,6 +1070,15 @@ int ig_conv3x3_direct(const void* x, const void* w, const float* bias, const flo
     p.drop_inv = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     if (p.ntiles == 0) return IG_OK;
     return launch_direct<48>(p, (hipStream_t)stream, dgrad ? "ig_conv3x3_dgrad(direct)" : "ig_conv3x3_fwd(direct)");
+}
+
+static const bf16_t* cd_zero_page() {
+    static void* z = nullptr;
+    if (!z) {
+        if (hipMalloc(&z, 256) != hipSuccess) return nullptr;
+        (void)hipMemset(z, 0, 256);
+    }
+    return (const bf16_t*)z;
 }
 
 // Called by ig_conv3x3_wgrad (gemm.hip); IG_ERR_UNSUPPORTED when the shape is not covered.
@@ -965,7 +1109,26 @@ int ig_conv3x3_wgrad_direct(const void* dy, const void* x, float* dw, int B, int
     p.ntiles = (long)B * p.tiles_x * p.tiles_y;
     if (p.ntiles == 0) return IG_OK;
     if (Cin == 48) return launch_wgrad_direct<48, 4>(p, Cout / 48, (hipStream_t)stream);
-    return launch_wgrad_direct<96, 8>(p, Cout / 48, (hipStream_t)stream);
+    static const int use_dma = getenv("IG_CW_DMA") ? atoi(getenv("IG_CW_DMA")) : 1;
+    if (!use_dma) return launch_wgrad_direct<96, 8>(p, Cout / 48, (hipStream_t)stream);
+    p.tiles_y = (H + 7) / 8;  // the DMA kernel walks 8 x 16 tiles
+    p.ntiles = (long)B * p.tiles_x * p.tiles_y;
+    const bf16_t* zp = cd_zero_page();
+    if (!zp) {
+        ig_set_error("ig_conv3x3_wgrad: could not allocate the zero page");
+        return IG_ERR_HIP;
+    }
+    constexpr int smem = 3 * 52 * 1024;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_dma_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    const int nslices = Cout / 48;
+    long nwg = 256 / nslices;
+    if (nwg > p.ntiles) nwg = p.ntiles;
+    hipLaunchKernelGGL((conv3x3_wgrad_dma_kernel<96>), dim3((unsigned)nwg, nslices), dim3(512), smem, (hipStream_t)stream, p, zp);
+    return ig_check_launch("ig_conv3x3_wgrad(direct, dma)");
 }
 
 // Called by ig_convT_fwd (gemm.hip); IG_ERR_UNSUPPORTED when the shape is not covered.
@@ -995,15 +1158,6 @@ int ig_convT_fwd_direct(const void* x, const void* w, const float* bias, void* y
 }
 
 // Called by ig_convT_wgrad (gemm.hip); IG_ERR_UNSUPPORTED when the shape is not covered.
-static const bf16_t* cd_zero_page() {
-    static void* z = nullptr;
-    if (!z) {
-        if (hipMalloc(&z, 256) != hipSuccess) return nullptr;
-        (void)hipMemset(z, 0, 256);
-    }
-    return (const bf16_t*)z;
-}
-
 int ig_convT_wgrad_direct(const void* dy, const void* x, float* dw, int B, int H, int W, int Cin, int Cout, void* stream) {
     static const int enabled = getenv("IG_CONV_DIRECT") ? atoi(getenv("IG_CONV_DIRECT")) : 1;
     static const int use_dma = getenv("IG_CTW_DMA") ? atoi(getenv("IG_CTW_DMA")) : 1;
