@@ -18,7 +18,9 @@
 // Measured at 108 x 224 x 224 x 48: 345-365 us against 614 us for the implicit GEMM; with the MFMAs switched off 210-260 us
 // and with the stores off 215 us remain -- at 1.04 GB of compulsory traffic (216 FLOP/B, below the chip's 312) this stage is
 // bound by HBM streaming, not by the matrix cores (SQ counters: MFMA busy 93 us, waves parked on waitcnt/barrier 39 %).
-// Tried without gain: staggered start of the two co-resident workgroups, L2 prefetch touches 1-3 tiles ahead.
+// Tried without gain: staggered start of the two co-resident workgroups; L2 prefetch touches 1-3 tiles ahead; a loader wave
+// feeding a 3-stage LDS-DMA halo ring to 4 or 8 MFMA waves (one workgroup per CU: 364 / 330 us against 333 us) -- the
+// load-only weight-gradient kernels below gain 10-50 % from such a ring, this kernel is bound by its 520 MB of stores.
 // The data gradient is the same kernel over dy with the weights gathered as W'[ci][8 - tap][co] at LDS-fill time.
 // Results are those of the implicit-GEMM path up to fp32 summation order (same bf16 operands, fp32 accumulation).
 #include "common.h"
@@ -1050,6 +1052,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_dma_kernel(CWParams p, c
 
 }  // namespace
 
+static const bf16_t* cd_zero_page() {
+    static void* z = nullptr;
+    if (!z) {
+        if (hipMalloc(&z, 256) != hipSuccess) return nullptr;
+        (void)hipMemset(z, 0, 256);
+    }
+    return (const bf16_t*)z;
+}
+
 // Called by ig_conv3x3_fwd / ig_conv3x3_dgrad (gemm.hip) for the shapes this kernel covers; returns IG_ERR_UNSUPPORTED
 // (without setting the error string) when it does not, and the caller falls through to the implicit GEMM.
 int ig_conv3x3_direct(const void* x, const void* w, const float* bias, const float* bn_scale, const float* bn_shift, void* y,
@@ -1070,15 +1081,6 @@ int ig_conv3x3_direct(const void* x, const void* w, const float* bias, const flo
     p.drop_inv = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     if (p.ntiles == 0) return IG_OK;
     return launch_direct<48>(p, (hipStream_t)stream, dgrad ? "ig_conv3x3_dgrad(direct)" : "ig_conv3x3_fwd(direct)");
-}
-
-static const bf16_t* cd_zero_page() {
-    static void* z = nullptr;
-    if (!z) {
-        if (hipMalloc(&z, 256) != hipSuccess) return nullptr;
-        (void)hipMemset(z, 0, 256);
-    }
-    return (const bf16_t*)z;
 }
 
 // Called by ig_conv3x3_wgrad (gemm.hip); IG_ERR_UNSUPPORTED when the shape is not covered.
