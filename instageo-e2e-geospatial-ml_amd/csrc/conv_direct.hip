@@ -1050,6 +1050,151 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_dma_kernel(CWParams p, c
     }
 }
 
+// ---- LDS-DMA variant of the ConvTranspose forward: 8 MFMA waves + 1 loader wave per CU --------------------------------
+// convT_direct_kernel (one workgroup per CU, register prefetch, nothing in flight while it waits) moves its 830 MB at
+// 2.3 TB/s.  Here the tile is 8 x 16 input pixels (patch 9 x 17 pixels x 224 B = 34 wave-DMAs), each MFMA wave owns one input
+// row (4 phases x 3 channel blocks), and a ninth wave only issues the patch DMAs into a 2-stage ring and waits for them
+// (exact vmcnt: it never stores), so the MFMA waves never wait on memory and their stores drain under the next tile.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(576, 1) void convT_direct_dma_kernel(CTParams p, const bf16_t* zero_page) {
+    constexpr int NCW = 8, R8 = 8;
+    constexpr int KSUB = CIN / 32;
+    constexpr int WP = 9 * KSUB * 64 + 32, PP = 2 * CIN + 32;
+    static_assert((WP / 4) % 16 == 8 && (PP / 4) % 16 == 8, "pitches must be = 8 (mod 16) dwords for ds_read_b128");
+    constexpr int NB = COUT / 16, NPAIR = NB / 2;
+    constexpr int W_BYTES = COUT * WP;
+    constexpr int PH = R8 + 1, PW = CT_T + 1;
+    constexpr int XUP = PP / 16;                     // 14 units per patch pixel
+    constexpr int XUNITS = PH * PW * XUP;            // 2142
+    constexpr int XSLOTS = (XUNITS + 63) / 64;       // 34
+    constexpr int STAGE = XSLOTS * 1024;
+    constexpr int PAR_OFF = W_BYTES + 2 * STAGE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) char* lds_char_ptr;
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_char_ptr)smem;
+    char* wl = smem;
+    float* par = reinterpret_cast<float*>(smem + PAR_OFF);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint32_t drop_seed = p.drop_seed;
+    if (p.drop_seed_dev) drop_seed += *p.drop_seed_dev;
+
+    auto pos_of = [](int c) { return c < NPAIR * 32 ? (c / 32) * 32 + ((c % 8) / 4) * 16 + ((c % 32) / 8) * 4 + c % 4 : c; };
+    constexpr int WUNITS = 9 * CIN / 8;
+    for (int u = tid; u < COUT * WUNITS; u += 576) {
+        const int co = u / WUNITS, k8 = u - co * WUNITS;
+        *reinterpret_cast<uint4*>(wl + pos_of(co) * WP + k8 * 16) = *reinterpret_cast<const uint4*>(p.w + ((size_t)co * WUNITS + k8) * 8);
+    }
+    for (int c = tid; c < COUT; c += 576) par[c] = p.bias ? p.bias[c] : 0.f;
+    __syncthreads();
+
+    auto tile_coords = [&](int t, int& b, int& ty0, int& tx0) {
+        const int per_img = p.tiles_x * p.tiles_y;
+        b = t / per_img;
+        const int r = t - b * per_img;
+        const int ty = r / p.tiles_x;
+        ty0 = ty * R8, tx0 = (r - ty * p.tiles_x) * CT_T;
+    };
+    const int nt = (int)p.ntiles, gstep = (int)gridDim.x;
+    const int t0 = xcd_first_tile();
+    const int mine = t0 < nt ? (nt - t0 + gstep - 1) / gstep : 0;
+
+    if (wave == NCW) {
+        // ================================= loader wave =================================
+        int u_off[XSLOTS], u_yx[XSLOTS];
+#pragma unroll
+        for (int i = 0; i < XSLOTS; ++i) {
+            const int u = i * 64 + lane;
+            const int hp = u / XUP, c = u - hp * XUP;
+            const int hy = hp / PW, hx = hp - hy * PW;
+            u_off[i] = (hy * p.W + hx) * CIN + c * 8;
+            u_yx[i] = (u < XUNITS && c < CIN / 8) ? (hy << 8) | hx : 0xffff;  // pad units and the tail: always the zero page
+        }
+        auto issue = [&](int t, int st) {
+            int b, ty0, tx0;
+            tile_coords(t, b, ty0, tx0);
+            const bf16_t* base = p.x + (((size_t)b * p.H + ty0) * p.W + tx0) * CIN;
+            const unsigned sbase = lds_base + W_BYTES + st * STAGE;
+#pragma unroll
+            for (int i = 0; i < XSLOTS; ++i) {
+                const bool ok = u_yx[i] != 0xffff && (ty0 + (u_yx[i] >> 8) < p.H) & (tx0 + (u_yx[i] & 0xff) < p.W);
+                cd_glds16(ok ? base + u_off[i] : zero_page, sbase + i * 1024);
+            }
+        };
+        if (mine > 0) issue(t0, 0);
+        for (int n = 0; n < mine; ++n) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile n has landed (nothing else is outstanding with two stages)
+            asm volatile("s_barrier" ::: "memory");
+            if (n + 1 < mine) issue(t0 + (n + 1) * gstep, (n + 1) & 1);  // the consumers are past tile n-1: its stage is free
+        }
+        return;
+    }
+
+    // ================================= MFMA waves: input row `wave` of the tile =================================
+    const int g = lane >> 4, j = lane & 15;
+    const int x_lane = (wave * PW + j) * PP + g * 16;
+    const char* w_lane = wl + j * WP + g * 16;
+    auto finish4 = [&](f32x4 a, int n, size_t idx, float* v) {
+        const float4 bb = *reinterpret_cast<const float4*>(par + n);
+        v[0] = a[0] + bb.x, v[1] = a[1] + bb.y, v[2] = a[2] + bb.z, v[3] = a[3] + bb.w;
+        if (p.drop_thresh) {
+            float mk[4];
+            dropout_scale4(drop_seed, (uint32_t)idx, p.drop_thresh, p.drop_inv, mk);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] *= mk[i];
+        }
+    };
+    for (int n = 0; n < mine; ++n) {
+        asm volatile("s_barrier" ::: "memory");
+        int b, ty0, tx0;
+        tile_coords(t0 + n * gstep, b, ty0, tx0);
+        const char* xs = smem + W_BYTES + (n & 1) * STAGE + x_lane;
+        f32x4 acc[4][NB];
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[ph][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            const int ph = (ky != 1) * 2 + (kx != 1);
+            const int xoff = ((ky == 0) * PW + (kx == 0)) * PP;
+#pragma unroll
+            for (int ks = 0; ks < KSUB; ++ks) {
+                bf16x8_t wf[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) wf[nb] = *reinterpret_cast<const bf16x8_t*>(w_lane + nb * 16 * WP + (tap * KSUB + ks) * 64);
+                const bf16x8_t pf = *reinterpret_cast<const bf16x8_t*>(xs + xoff + ks * 64);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[ph][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], pf, acc[ph][nb], 0, 0, 0);
+            }
+        }
+        const int iy = ty0 + wave, ix = tx0 + j;
+        if (iy < p.H && ix < p.W) {
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph) {
+                const size_t pix = ((size_t)b * 2 * p.H + 2 * iy + (ph >> 1)) * (2 * p.W) + 2 * ix + (ph & 1);
+#pragma unroll
+                for (int pr = 0; pr < NPAIR; ++pr) {
+                    const int nn = pr * 32 + 8 * g;
+                    const size_t idx = pix * COUT + nn;
+                    float v[8];
+                    finish4(acc[ph][2 * pr], nn, idx, v);
+                    finish4(acc[ph][2 * pr + 1], nn + 4, idx + 4, v + 4);
+                    *reinterpret_cast<uint4*>(p.y + idx) = pack8(v);
+                }
+                if (NB & 1) {
+                    const int nn = (NB - 1) * 16 + 4 * g;
+                    const size_t idx = pix * COUT + nn;
+                    float v[4];
+                    finish4(acc[ph][NB - 1], nn, idx, v);
+                    store4_split(p.y, nullptr, idx, v);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 static const bf16_t* cd_zero_page() {
@@ -1148,6 +1293,25 @@ int ig_convT_fwd_direct(const void* x, const void* w, const float* bias, void* y
     p.drop_thresh = ig_drop_thresh16(drop_p);
     p.drop_inv = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     if (p.ntiles == 0) return IG_OK;
+    static const int use_dma = getenv("IG_CT_DMA") ? atoi(getenv("IG_CT_DMA")) : 1;
+    if (use_dma) {
+        p.tiles_y = (H + 7) / 8;  // 8 x 16 input tiles
+        p.ntiles = (long)B * p.tiles_x * p.tiles_y;
+        constexpr int smem_d = 48 * (27 * 64 + 32) + 2 * 34 * 1024 + 48 * 4;
+        const bf16_t* zp = cd_zero_page();
+        if (!zp) {
+            ig_set_error("ig_convT_fwd: could not allocate the zero page");
+            return IG_ERR_HIP;
+        }
+        static bool attr_d = false;
+        if (!attr_d) {
+            (void)hipFuncSetAttribute((const void*)convT_direct_dma_kernel<96, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_d);
+            attr_d = true;
+        }
+        const long nwg_d = p.ntiles < 256 ? p.ntiles : 256;
+        hipLaunchKernelGGL((convT_direct_dma_kernel<96, 48>), dim3((unsigned)nwg_d), dim3(576), smem_d, (hipStream_t)stream, p, zp);
+        return ig_check_launch("ig_convT_fwd(direct, dma)");
+    }
     constexpr int smem = 48 * (27 * 64 + 32) + CT_P * CT_P * (2 * 96 + 32) + 48 * 4;
     long nwg = p.ntiles < 256 ? p.ntiles : 256;
     static bool attr_done = false;
