@@ -238,42 +238,14 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const bf16_t* __restrict
     }
 }
 
-// delta[b][h][q] = sum_d dO[q][d] * O[q][d].  Eight consecutive lanes share one (b, q, h) row of 64 values: every
-// wave-instruction reads 1 KiB contiguous (a thread-per-row version touched 64 different lines per load).
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o_hi, const bf16_t* __restrict__ o_lo,
-                                                         const bf16_t* __restrict__ do_hi, const bf16_t* __restrict__ do_lo,
-                                                         float* __restrict__ delta, int B, int N, int H) {
-    const long t = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    const long i = t >> 3;  // (b, q, h) index; rows are padded to a multiple of 32 by the launch so shuffles stay full
-    const int c = (int)(t & 7);
-    const bool ok = i < (long)B * N * H;
-    float acc = 0.f;
-    if (ok) {
-        float a[8], d[8];
-        load8_split(o_hi, o_lo, (size_t)i * HD + c * 8, a);
-        load8_split(do_hi, do_lo, (size_t)i * HD + c * 8, d);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc += a[j] * d[j];
-    }
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    acc += __shfl_xor(acc, 4, 64);
-    if (ok && c == 0) {
-        const int h = (int)(i % H);
-        const long bn = i / H;
-        const int q = (int)(bn % N);
-        const long bb = bn / N;
-        delta[(bb * H + h) * N + q] = acc;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------
 // backward, query-owner pass: dQ = scale * dS K   (streams K,V tiles; recomputes P^T from LSE)
 // ------------------------------------------------------------------------------------------------------
 template <bool SPLIT, int NTLP, int MAXT>
 __global__ __launch_bounds__(MAXT) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv_hi, const bf16_t* __restrict__ qkv_lo,
                                                            const bf16_t* __restrict__ do_hi, const bf16_t* __restrict__ do_lo,
-                                                           const float* __restrict__ lse, const float* __restrict__ delta,
+                                                           const bf16_t* __restrict__ o_hi, const bf16_t* __restrict__ o_lo,
+                                                           const float* __restrict__ lse, float* __restrict__ delta,
                                                            bf16_t* __restrict__ dqkv_hi, bf16_t* __restrict__ dqkv_lo, int N, int H,
                                                            float scale) {
     constexpr int NTL = SPLIT ? 2 : NTLP;
@@ -305,7 +277,28 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dq_kernel(const bf16_t* __restr
     }
     const float c2 = scale * 1.44269504088896340736f;  // P = exp2(s*c2 - lse*log2e): one fma + v_exp_f32 per element
     const float my_lse = q < N ? lse[((long)b * H + h) * N + q] * 1.44269504088896340736f : INFINITY;  // +inf -> P = 0 on padded queries
-    const float my_delta = q < N ? delta[((long)b * H + h) * N + q] : 0.f;
+    // delta[q] = sum_d dO[q][d] * O[q][d], computed here from the dO fragments this wave owns anyway (its four k-group lanes
+    // hold the 64 values of a row) and stored for the key-owner pass that runs next -- a separate delta kernel was 17 us per
+    // block of launch + one more pass over O and dO
+    float my_delta = 0.f;
+    {
+        const bf16_t* ob_hi = o_hi + (long)b * N * OS + h * HD;
+        const bf16_t* ob_lo = SPLIT ? o_lo + (long)b * N * OS + h * HD : nullptr;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bf16x8_t oh = load_own(ob_hi, OS, q0, N, s, lane);
+            const bf16x8_t ol = SPLIT ? load_own(ob_lo, OS, q0, N, s, lane) : oh;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float ov = SPLIT ? (float)oh[e] + (float)ol[e] : (float)oh[e];
+                const float dv = SPLIT ? (float)dh[s][e] + (float)dl[s][e] : (float)dh[s][e];
+                my_delta = fmaf(ov, dv, my_delta);
+            }
+        }
+        my_delta += __shfl_xor(my_delta, 16, 64);
+        my_delta += __shfl_xor(my_delta, 32, 64);
+        if (g == 0 && q < N) delta[((long)b * H + h) * N + q] = my_delta;
+    }
     f32x4 dq[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -528,9 +521,7 @@ int ig_attention_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi,
                "ig_attention_bwd: split pointers must be given for all tensors or none");
     if (B == 0 || N == 0) return IG_OK;
     hipStream_t st = (hipStream_t)stream;
-    long rows = (long)B * N * H;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows * 8 + 255) / 256)), dim3(256), 0, st, (const bf16_t*)out_hi,
-                       (const bf16_t*)out_lo, (const bf16_t*)dout_hi, (const bf16_t*)dout_lo, delta, B, N, H);
+    // delta is produced by the query-owner pass (first launch) and consumed by the key-owner pass (second)
     int nblk, nw;
     wave_geometry(N, nblk, nw);
     dim3 grid(nblk, H, B), block(nw * 64);
@@ -538,7 +529,8 @@ int ig_attention_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi,
 #define IG_ATTN_BWD(SPLIT_, NTL_, MAXT_)                                                                                     \
     {                                                                                                                         \
         hipLaunchKernelGGL((attn_bwd_dq_kernel<SPLIT_, NTL_, MAXT_>), grid, block, 0, st, (const bf16_t*)qkv_hi,                  \
-                           (const bf16_t*)qkv_lo, (const bf16_t*)dout_hi, (const bf16_t*)dout_lo, lse, delta, (bf16_t*)dqkv_hi,  \
+                           (const bf16_t*)qkv_lo, (const bf16_t*)dout_hi, (const bf16_t*)dout_lo, (const bf16_t*)out_hi,          \
+                           (const bf16_t*)out_lo, lse, delta, (bf16_t*)dqkv_hi,                                                   \
                            (bf16_t*)dqkv_lo, N, H, scale);                                                                    \
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<SPLIT_, NTL_, MAXT_>), grid, block, 0, st, (const bf16_t*)qkv_hi,                 \
                            (const bf16_t*)qkv_lo, (const bf16_t*)dout_hi, (const bf16_t*)dout_lo, lse, delta, (bf16_t*)dqkv_hi,  \
