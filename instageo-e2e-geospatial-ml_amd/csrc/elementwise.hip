@@ -1036,7 +1036,13 @@ int ig_layernorm_bwd(const void* dy_hi, const void* dy_lo, const float* x, const
     IG_REQUIRE(D % 4 == 0 && D <= 2048, "ig_layernorm_bwd: D must be a multiple of 4 and <= 2048 (got %d)", D);
     if (M == 0) return IG_OK;
     static const int rpb_env = getenv("IG_LNB_RPB") ? atoi(getenv("IG_LNB_RPB")) : 0;
-    const int rpb = rpb_env > 0 ? rpb_env : 48;  // 8 waves-iterations of 2 rows x 4 waves... measured best of 16..128 (tools/ln_bench.py)
+    // 48 rows per workgroup (measured best of 16..128 at M = 21168, tools/ln_bench.py); for small M (the YAML's batch 16:
+    // 3152 rows = 66 workgroups on 256 CUs) fewer rows so that ~440 workgroups remain (multiples of the 8 rows per trip)
+    int rpb = 48;
+    if ((long)M < 48L * 440) rpb = (int)((((long)M + 439) / 440 + 7) / 8 * 8);
+    if (rpb < 8) rpb = 8;
+    if (rpb > 48) rpb = 48;
+    if (rpb_env > 0) rpb = rpb_env;
     dim3 grid(ig_cdiv(M, rpb));
     size_t sm = 3 * (size_t)D * sizeof(float);
     const size_t sm_exact = (LNB_TPB / 64) * sm;  // one slab per wave (plain-store reduction)

@@ -1513,8 +1513,11 @@ int ig_linear_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, cons
     return launch_gemm<PlainLoader, PlainLoader, EpAtomic, true, true>(
         plain_a(dy_hi, dy_lo, M, N, N), plain_b(x_hi, x_lo, M, K, K), ep, N, K, M, 1, dy_lo != nullptr, (hipStream_t)stream,
         "ig_linear_wgrad", true,
-        // small outputs (proj: 768 x 768 = 18 v2 tiles): the 128 x 128 engine's 36 tiles split the reduction less deeply (+18 %)
-        gemm_env() ? gemm_env() : ((long)N * K <= (1L << 20) ? 1 : 2));
+        // small outputs (proj: 768 x 768 = 18 v2 tiles): the 128 x 128 engine's 36 tiles split the reduction less deeply (+18 %);
+        // short reductions (M <= 13000 rows, e.g. the YAML's batch 16): the 256 x 128 tiles cannot be split deep enough to fill
+        // the chip and their 128 KiB staged-atomic epilogue dominates (128 x 128 engine: +20-30 % at M = 3152, +16 % / 0 % at
+        // 12608, -1..-9 % at 16384; tools/gemm_bench.py)
+        gemm_env() ? gemm_env() : (((long)N * K <= (1L << 20) || M <= 13000) ? 1 : 2));
 }
 
 // Patch embedding (pritvhi.py:243-268,513-517): x[b][1+tp][:] = patches[b*TP+tp] @ w^T + bias + pos[1+tp]
