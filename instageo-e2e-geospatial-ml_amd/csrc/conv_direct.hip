@@ -919,19 +919,21 @@ __global__ __launch_bounds__(TW_TPB, 1) void convT_wgrad_dma_kernel(CTWParams p,
 // Same ring protocol as convT_wgrad_dma_kernel.  Tile = 8 x 16 pixels: x halo 10 x 18 pixels x 224 B (40 wave-DMAs), dy tile
 // 8 x 16 pixels x 96 B of this workgroup's 48-channel slice (12 wave-DMAs); 3 stages x 52 KiB.  Waves 0-3 issue 7 DMAs per
 // tile, waves 4-7 issue 6 (52 = 4 x 7 + 4 x 6), so the counted vmcnt differs by wave.
-template <int CIN>
+template <int CIN, int R8>  // R8 = tile rows: 8 for 96 input channels, 4 for 192 (three stages must fit 160 KiB)
 __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_dma_kernel(CWParams p, const bf16_t* zero_page) {
-    static_assert(CIN == 96, "unit tables below are written for 96 input channels");
-    constexpr int COB = 48, R8 = 8;
+    constexpr int COB = 48;
+    static_assert((2 * CIN + 32) / 4 % 16 == 8, "x pixel pitch must be = 8 (mod 16) dwords");
     constexpr int PPX = 2 * CIN + 32, PPD = 2 * COB;
     constexpr int PHh = R8 + 2;                 // halo rows
-    constexpr int XUP = PPX / 16;               // 14 units per halo pixel (12 data + 2 pad)
-    constexpr int XUNITS = PHh * HW_ * XUP;     // 2520
-    constexpr int XSLOTS = (XUNITS + 63) / 64;  // 40
-    constexpr int DUNITS = R8 * TW * (COB / 8); // 768
-    constexpr int DSLOTS = DUNITS / 64;         // 12
-    constexpr int SLOTS = XSLOTS + DSLOTS;      // 52
+    constexpr int XUP = PPX / 16;               // units per halo pixel (CIN / 8 data + 2 pad)
+    constexpr int XUNITS = PHh * HW_ * XUP;
+    constexpr int XSLOTS = (XUNITS + 63) / 64;  // 40 (96 ch, 8 rows) / 44 (192 ch, 4 rows)
+    constexpr int DUNITS = R8 * TW * (COB / 8);
+    constexpr int DSLOTS = DUNITS / 64;         // 12 / 6
+    constexpr int SLOTS = XSLOTS + DSLOTS;      // 52 / 50
     constexpr int NW = 8, PER_WAVE = (SLOTS + NW - 1) / NW;  // 7
+    static_assert(3 * SLOTS * 1024 <= 160 * 1024, "three stages must fit the LDS");
+    static_assert(PER_WAVE == 7 && SLOTS > 6 * NW, "the counted vmcnt below assumes 6 or 7 DMAs per wave");
     constexpr int STAGE = SLOTS * 1024, D_OFF = XSLOTS * 1024;
     constexpr int CB = COB / 16, CIB = CIN / 16, NBLK = 9 * CIB, NBW = (NBLK + NW - 1) / NW;
     constexpr int KS = R8 * TW / 32;
@@ -1247,7 +1249,8 @@ static int launch_wgrad_direct(const CWParams& p, int nslices, hipStream_t st) {
 
 int ig_conv3x3_wgrad_direct(const void* dy, const void* x, float* dw, int B, int H, int W, int Cin, int Cout, void* stream) {
     static const int enabled = getenv("IG_CONV_DIRECT") ? atoi(getenv("IG_CONV_DIRECT")) : 1;
-    if (!enabled || Cout % 48 != 0 || (Cin != 48 && Cin != 96)) return IG_ERR_UNSUPPORTED;
+    static const int use192 = getenv("IG_CW_192") ? atoi(getenv("IG_CW_192")) : 1;
+    if (!enabled || Cout % 48 != 0 || (Cin != 48 && Cin != 96 && !(Cin == 192 && use192))) return IG_ERR_UNSUPPORTED;
     if ((long)B * H * W * (Cin > Cout ? Cin : Cout) >= (1L << 31)) return IG_ERR_UNSUPPORTED;
     CWParams p{};
     p.x = (const bf16_t*)x, p.dy = (const bf16_t*)dy, p.dw = dw;
@@ -1257,24 +1260,29 @@ int ig_conv3x3_wgrad_direct(const void* dy, const void* x, float* dw, int B, int
     if (p.ntiles == 0) return IG_OK;
     if (Cin == 48) return launch_wgrad_direct<48, 4>(p, Cout / 48, (hipStream_t)stream);
     static const int use_dma = getenv("IG_CW_DMA") ? atoi(getenv("IG_CW_DMA")) : 1;
-    if (!use_dma) return launch_wgrad_direct<96, 8>(p, Cout / 48, (hipStream_t)stream);
-    p.tiles_y = (H + 7) / 8;  // the DMA kernel walks 8 x 16 tiles
+    if (!use_dma && Cin == 96) return launch_wgrad_direct<96, 8>(p, Cout / 48, (hipStream_t)stream);
+    const int rows = Cin == 96 ? 8 : 4;  // the DMA kernels walk 8 x 16 (96 channels) or 4 x 16 (192 channels) tiles
+    p.tiles_y = (H + rows - 1) / rows;
     p.ntiles = (long)B * p.tiles_x * p.tiles_y;
     const bf16_t* zp = cd_zero_page();
     if (!zp) {
         ig_set_error("ig_conv3x3_wgrad: could not allocate the zero page");
         return IG_ERR_HIP;
     }
-    constexpr int smem = 3 * 52 * 1024;
+    constexpr int smem96 = 3 * 52 * 1024, smem192 = 3 * 50 * 1024;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_dma_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_dma_kernel<96, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, smem96);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_dma_kernel<192, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem192);
         attr_done = true;
     }
     const int nslices = Cout / 48;
     long nwg = 256 / nslices;
     if (nwg > p.ntiles) nwg = p.ntiles;
-    hipLaunchKernelGGL((conv3x3_wgrad_dma_kernel<96>), dim3((unsigned)nwg, nslices), dim3(512), smem, (hipStream_t)stream, p, zp);
+    if (Cin == 96)
+        hipLaunchKernelGGL((conv3x3_wgrad_dma_kernel<96, 8>), dim3((unsigned)nwg, nslices), dim3(512), smem96, (hipStream_t)stream, p, zp);
+    else
+        hipLaunchKernelGGL((conv3x3_wgrad_dma_kernel<192, 4>), dim3((unsigned)nwg, nslices), dim3(512), smem192, (hipStream_t)stream, p, zp);
     return ig_check_launch("ig_conv3x3_wgrad(direct, dma)");
 }
 

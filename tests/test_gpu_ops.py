@@ -263,7 +263,7 @@ def nhwc(x):  # NCHW -> NHWC
 
 @pytest.mark.parametrize("split", SPLITS)
 @pytest.mark.parametrize("B,H,Cin,Cout", [(2, 14, 48, 24), (1, 28, 144, 72), (3, 7, 8, 136), (2, 21, 48, 48), (1, 48, 48, 48), (3, 5, 48, 48),
-                                          (2, 21, 96, 96), (1, 18, 48, 96), (1, 35, 96, 48)])
+                                          (2, 21, 96, 96), (1, 18, 48, 96), (1, 35, 96, 48), (2, 13, 192, 192), (1, 9, 192, 48)])
 def test_conv3x3(split, B, H, Cin, Cout):  # unsplit 48 -> 48 (fwd, dgrad) and Cin 48 / 96 (wgrad) run the halo-tile direct kernels
     W = H + 2
     x, xr = bt(nhwc(rnd(B, Cin, H, W, seed=26)), split)
