@@ -1036,10 +1036,10 @@ int ig_layernorm_bwd(const void* dy_hi, const void* dy_lo, const float* x, const
     IG_REQUIRE(D % 4 == 0 && D <= 2048, "ig_layernorm_bwd: D must be a multiple of 4 and <= 2048 (got %d)", D);
     if (M == 0) return IG_OK;
     static const int rpb_env = getenv("IG_LNB_RPB") ? atoi(getenv("IG_LNB_RPB")) : 0;
-    // 48 rows per workgroup (measured best of 16..128 at M = 21168, tools/ln_bench.py); for small M (the YAML's batch 16:
-    // 3152 rows = 66 workgroups on 256 CUs) fewer rows so that ~440 workgroups remain (multiples of the 8 rows per trip)
-    int rpb = 48;
-    if ((long)M < 48L * 440) rpb = (int)((((long)M + 439) / 440 + 7) / 8 * 8);
+    // 48 rows per workgroup (measured best of 16..128 at M = 21168, tools/ln_bench.py).  For small M keep ~200 workgroups
+    // (every workgroup ends in 3 D atomics, so more is not better): M = 3152 (the YAML's batch 16) 16 rows -> 21 us against
+    // 38 us at 48 and 24 us at 8; M = 10638 stays at 48 (60 us; 32 rows: 75 us)
+    int rpb = (int)((((long)M + 209) / 210 + 7) / 8 * 8);
     if (rpb < 8) rpb = 8;
     if (rpb > 48) rpb = 48;
     if (rpb_env > 0) rpb = rpb_env;

@@ -1510,14 +1510,20 @@ int ig_linear_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, cons
     IG_REQUIRE(N % 8 == 0 && K % 8 == 0, "ig_linear_wgrad: N and K must be multiples of 8");
     IG_SPLIT_CONSISTENT(dy_lo, x_lo);
     EpAtomic ep{dw, (long)K, 0, 0};
+    // K-steps of 32 per workgroup if the 256 x 128 engine ran this problem (its split-K rule, see launch_gemm)
+    const int nk32 = ig_cdiv(M, 32), tiles2 = ig_cdiv(N, 256) * ig_cdiv(K, 128);
+    int ks2 = 512 / tiles2;
+    if (ks2 > nk32 / 16) ks2 = nk32 / 16;
+    if (ks2 < 1) ks2 = 1;
+    const int v2_steps = nk32 / ks2;
     return launch_gemm<PlainLoader, PlainLoader, EpAtomic, true, true>(
         plain_a(dy_hi, dy_lo, M, N, N), plain_b(x_hi, x_lo, M, K, K), ep, N, K, M, 1, dy_lo != nullptr, (hipStream_t)stream,
         "ig_linear_wgrad", true,
         // small outputs (proj: 768 x 768 = 18 v2 tiles): the 128 x 128 engine's 36 tiles split the reduction less deeply (+18 %);
-        // short reductions (M <= 13000 rows, e.g. the YAML's batch 16): the 256 x 128 tiles cannot be split deep enough to fill
-        // the chip and their 128 KiB staged-atomic epilogue dominates (128 x 128 engine: +20-30 % at M = 3152, +16 % / 0 % at
-        // 12608, -1..-9 % at 16384; tools/gemm_bench.py)
-        gemm_env() ? gemm_env() : (((long)N * K <= (1L << 20) || M <= 13000) ? 1 : 2));
+        // short reductions: what decides is the number of K-steps a 256 x 128 workgroup gets between its ring fill and its
+        // 128 KiB staged-atomic epilogue -- below ~50 the 128 x 128 engine wins (768-wide model: +20-30 % at M = 3152, +16 % /
+        // -3 % at 12608, -1..-9 % at 16384; 1024-wide model at M = 10638: -9 % / -1 %; tools/gemm_bench.py)
+        gemm_env() ? gemm_env() : (((long)N * K <= (1L << 20) || v2_steps < 50) ? 1 : 2));
 }
 
 // Patch embedding (pritvhi.py:243-268,513-517): x[b][1+tp][:] = patches[b*TP+tp] @ w^T + bias + pos[1+tp]
