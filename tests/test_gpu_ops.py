@@ -263,7 +263,8 @@ def nhwc(x):  # NCHW -> NHWC
 
 @pytest.mark.parametrize("split", SPLITS)
 @pytest.mark.parametrize("B,H,Cin,Cout", [(2, 14, 48, 24), (1, 28, 144, 72), (3, 7, 8, 136), (2, 21, 48, 48), (1, 48, 48, 48), (3, 5, 48, 48),
-                                          (2, 21, 96, 96), (1, 18, 48, 96), (1, 35, 96, 48), (2, 13, 192, 192), (1, 9, 192, 48)])
+                                          (2, 21, 96, 96), (1, 18, 48, 96), (1, 35, 96, 48), (2, 13, 192, 192), (1, 9, 192, 48),
+                                          (1, 1, 48, 48), (1, 16, 48, 48), (1, 3, 96, 96), (5, 2, 192, 96)])
 def test_conv3x3(split, B, H, Cin, Cout):  # unsplit 48 -> 48 (fwd, dgrad) and Cin 48 / 96 (wgrad) run the halo-tile direct kernels
     W = H + 2
     x, xr = bt(nhwc(rnd(B, Cin, H, W, seed=26)), split)
@@ -288,7 +289,7 @@ def test_conv3x3(split, B, H, Cin, Cout):  # unsplit 48 -> 48 (fwd, dgrad) and C
 
 
 @pytest.mark.parametrize("split", SPLITS)
-@pytest.mark.parametrize("B,H,Cin,Cout", [(2, 14, 48, 24), (1, 7, 256, 128), (2, 5, 16, 8), (2, 20, 96, 48), (1, 33, 96, 48), (3, 4, 96, 48)])
+@pytest.mark.parametrize("B,H,Cin,Cout", [(2, 14, 48, 24), (1, 7, 256, 128), (2, 5, 16, 8), (2, 20, 96, 48), (1, 33, 96, 48), (3, 4, 96, 48), (1, 1, 96, 48), (2, 8, 96, 48), (1, 17, 96, 48)])
 def test_convT(split, B, H, Cin, Cout):  # 96 -> 48 unsplit runs the direct sub-pixel kernel (conv_direct.hip)
     W = H + 1
     x, xr = bt(nhwc(rnd(B, Cin, H, W, seed=30)), split)
