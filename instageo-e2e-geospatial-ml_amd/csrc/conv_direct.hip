@@ -1197,6 +1197,171 @@ __global__ __launch_bounds__(576, 1) void convT_direct_dma_kernel(CTParams p, co
     }
 }
 
+// ---- 3x3 forward / data gradient at 96 channels: 48-channel output slices, 8 MFMA waves + 1 loader wave per CU ------------
+// All of Wc[96][864] (166 KiB) does not fit the LDS next to a halo, so a workgroup owns a 48-wide slice of the output channels
+// (blockIdx.y; 84.5 KiB of weights) and the input halo is staged by both slices' workgroups (the second read is an L2 / MALL
+// hit).  Tile = 8 x 16 pixels, one row per MFMA wave; the halo (10 x 18 pixels x 192 B, lane-linear, 34 wave-DMAs) goes
+// through a 2-stage ring filled by the loader wave (see convT_direct_dma_kernel).  The unpadded 192-byte pixel pitch makes
+// the pixel-side ds_read_b128 2-way conflicted -- the conflict-free 224 bytes would not leave room for the second stage.
+template <int C>
+__global__ __launch_bounds__(576, 1) void conv3x3_direct_slice_kernel(CDParams p, const bf16_t* zero_page) {
+    static_assert(C == 96, "written for 96 channels (48-wide output slices)");
+    constexpr int NCW = 8, R8 = 8, COB = 48;
+    constexpr int UNITS = C / 8;                 // 12 units per pixel
+    constexpr int KSTEPS = 9 * C / 32;           // 27, three per tap
+    constexpr int WP = KSTEPS * 64 + 32;         // 440 dwords: conflict-free weight reads
+    constexpr int PP = 2 * C;                    // 192 B (see above)
+    constexpr int NB = COB / 16, NPAIR = NB / 2;
+    constexpr int W_BYTES = COB * WP;
+    constexpr int PHh = R8 + 2;
+    constexpr int HUNITS = PHh * HW_ * UNITS;    // 2160
+    constexpr int HSLOTS = (HUNITS + 63) / 64;   // 34
+    constexpr int STAGE = HSLOTS * 1024;
+    constexpr int PAR_OFF = W_BYTES + 2 * STAGE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) char* lds_char_ptr;
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_char_ptr)smem;
+    char* wl = smem;
+    float* par = reinterpret_cast<float*>(smem + PAR_OFF);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int co0 = blockIdx.y * COB;
+    uint32_t drop_seed = p.drop_seed;
+    if (p.drop_seed_dev) drop_seed += *p.drop_seed_dev;
+
+    auto pos_of = [](int c) { return c < NPAIR * 32 ? (c / 32) * 32 + ((c % 8) / 4) * 16 + ((c % 32) / 8) * 4 + c % 4 : c; };
+    constexpr int KG = 9 * UNITS;  // 108 k-groups per weight row
+    for (int i = tid; i < W_BYTES / 16; i += 576) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    if (!p.dgrad) {
+        for (int u = tid; u < COB * KG; u += 576) {
+            const int co = u / KG, gk = u - co * KG;
+            *reinterpret_cast<uint4*>(wl + pos_of(co) * WP + gk * 16) = *reinterpret_cast<const uint4*>(p.w + ((size_t)(co0 + co) * KG + gk) * 8);
+        }
+    } else {
+        // rows = this slice's input channels ci0 .. ci0+47: W'[ci][tap'][co] = Wc[co][8 - tap'][ci], co over all C
+        constexpr int SU = COB / 8;  // 16-byte units of the slice per (co, tap)
+        for (int u = tid; u < C * 9 * SU; u += 576) {
+            const int co = u / (9 * SU), r = u - co * (9 * SU), tap = r / SU, c8 = r - tap * SU;
+            const uint4 v = *reinterpret_cast<const uint4*>(p.w + ((size_t)co * 9 + tap) * C + co0 + c8 * 8);
+            const uint32_t qv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                reinterpret_cast<bf16_t*>(wl + pos_of(c8 * 8 + i) * WP)[(8 - tap) * C + co] = (bf16_t)(qv[i >> 1] >> ((i & 1) * 16));
+        }
+    }
+    for (int c = tid; c < COB; c += 576) {
+        par[c] = p.bias ? p.bias[co0 + c] : 0.f;
+        par[COB + c] = p.col_scale ? p.col_scale[co0 + c] : 1.f;
+        par[2 * COB + c] = p.col_scale ? p.col_shift[co0 + c] : 0.f;
+    }
+    const bool has_bn = p.col_scale != nullptr;
+    __syncthreads();
+
+    auto tile_coords = [&](int t, int& b, int& ty0, int& tx0) {
+        const int per_img = p.tiles_x * p.tiles_y;
+        b = t / per_img;
+        const int r = t - b * per_img;
+        const int ty = r / p.tiles_x;
+        ty0 = ty * R8, tx0 = (r - ty * p.tiles_x) * TW;
+    };
+    const int nt = (int)p.ntiles, gstep = (int)gridDim.x;
+    const int t0 = xcd_first_tile();
+    const int mine = t0 < nt ? (nt - t0 + gstep - 1) / gstep : 0;
+
+    if (wave == NCW) {
+        // ================================= loader wave =================================
+        int u_off[HSLOTS], u_yx[HSLOTS];
+#pragma unroll
+        for (int i = 0; i < HSLOTS; ++i) {
+            const int u = i * 64 + lane;
+            const int hp = u / UNITS, c8 = u - hp * UNITS;
+            const int hy = hp / HW_, hx = hp - hy * HW_;
+            u_off[i] = (hy * p.W + hx) * C + c8 * 8;
+            u_yx[i] = u < HUNITS ? (hy << 8) | hx : 0xffff;
+        }
+        auto issue = [&](int t, int st) {
+            int b, ty0, tx0;
+            tile_coords(t, b, ty0, tx0);
+            const bf16_t* base = p.x + (((long)b * p.H + ty0 - 1) * p.W + tx0 - 1) * C;  // halo origin (outside units masked)
+            const unsigned sbase = lds_base + W_BYTES + st * STAGE;
+#pragma unroll
+            for (int i = 0; i < HSLOTS; ++i) {
+                const int hy = u_yx[i] >> 8, hx = u_yx[i] & 0xff;
+                const bool ok = u_yx[i] != 0xffff && ((unsigned)(ty0 + hy - 1) < (unsigned)p.H) & ((unsigned)(tx0 + hx - 1) < (unsigned)p.W);
+                cd_glds16(ok ? base + u_off[i] : zero_page, sbase + i * 1024);
+            }
+        };
+        if (mine > 0) issue(t0, 0);
+        for (int n = 0; n < mine; ++n) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+            if (n + 1 < mine) issue(t0 + (n + 1) * gstep, (n + 1) & 1);
+        }
+        return;
+    }
+
+    // ================================= MFMA waves: row `wave` of the tile =================================
+    const int g = lane >> 4, j = lane & 15;
+    const int x_lane = (wave * HW_ + j) * PP + g * 16;
+    const char* w_lane = wl + j * WP + g * 16;
+    auto finish4 = [&](f32x4 a, int n, size_t idx, float* v) {
+        const float4 bb = *reinterpret_cast<const float4*>(par + n);
+        v[0] = a[0] + bb.x, v[1] = a[1] + bb.y, v[2] = a[2] + bb.z, v[3] = a[3] + bb.w;
+        if (has_bn) {
+            const float4 sc = *reinterpret_cast<const float4*>(par + COB + n);
+            const float4 sh = *reinterpret_cast<const float4*>(par + 2 * COB + n);
+            v[0] = fmaxf(v[0] * sc.x + sh.x, 0.f), v[1] = fmaxf(v[1] * sc.y + sh.y, 0.f);
+            v[2] = fmaxf(v[2] * sc.z + sh.z, 0.f), v[3] = fmaxf(v[3] * sc.w + sh.w, 0.f);
+        }
+        if (p.drop_thresh) {
+            float mk[4];
+            dropout_scale4(drop_seed, (uint32_t)idx, p.drop_thresh, p.drop_inv, mk);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] *= mk[i];
+        }
+    };
+    for (int n = 0; n < mine; ++n) {
+        asm volatile("s_barrier" ::: "memory");
+        int b, ty0, tx0;
+        tile_coords(t0 + n * gstep, b, ty0, tx0);
+        const char* xs = smem + W_BYTES + (n & 1) * STAGE + x_lane;
+        f32x4 acc[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int tap = ks / 3, dy = tap / 3, dx = tap % 3;
+            bf16x8_t wf[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) wf[nb] = *reinterpret_cast<const bf16x8_t*>(w_lane + nb * 16 * WP + ks * 64);
+            const bf16x8_t pf = *reinterpret_cast<const bf16x8_t*>(xs + (dy * HW_ + dx) * PP + (ks % 3) * 64);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], pf, acc[nb], 0, 0, 0);
+        }
+        const int oy = ty0 + wave, ox = tx0 + j;
+        if (oy < p.H && ox < p.W) {
+            const size_t pixc = (((size_t)b * p.H + oy) * p.W + ox) * C + co0;
+#pragma unroll
+            for (int pr = 0; pr < NPAIR; ++pr) {
+                const int nn = pr * 32 + 8 * g;
+                const size_t idx = pixc + nn;
+                float v[8];
+                finish4(acc[2 * pr], nn, idx, v);
+                finish4(acc[2 * pr + 1], nn + 4, idx + 4, v + 4);
+                *reinterpret_cast<uint4*>(p.y + idx) = pack8(v);
+            }
+            if (NB & 1) {
+                const int nn = (NB - 1) * 16 + 4 * g;
+                const size_t idx = pixc + nn;
+                float v[4];
+                finish4(acc[NB - 1], nn, idx, v);
+                store4_split(p.y, nullptr, idx, v);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 static const bf16_t* cd_zero_page() {
@@ -1214,7 +1379,8 @@ int ig_conv3x3_direct(const void* x, const void* w, const float* bias, const flo
                       int B, int H, int W, int Cin, int Cout, int dgrad, unsigned drop_seed, const unsigned* drop_seed_dev,
                       float drop_p, void* stream) {
     static const int enabled = getenv("IG_CONV_DIRECT") ? atoi(getenv("IG_CONV_DIRECT")) : 1;
-    if (!enabled || Cin != Cout || Cin != 48) return IG_ERR_UNSUPPORTED;
+    static const int use96 = getenv("IG_CD_96") ? atoi(getenv("IG_CD_96")) : 1;
+    if (!enabled || Cin != Cout || (Cin != 48 && !(Cin == 96 && use96))) return IG_ERR_UNSUPPORTED;
     if ((long)B * H * W * Cin >= (1L << 31)) return IG_ERR_UNSUPPORTED;  // 32-bit halo offsets
     CDParams p{};
     p.x = (const bf16_t*)x, p.w = (const bf16_t*)w, p.y = (bf16_t*)y;
@@ -1227,6 +1393,24 @@ int ig_conv3x3_direct(const void* x, const void* w, const float* bias, const flo
     p.drop_thresh = ig_drop_thresh16(drop_p);
     p.drop_inv = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     if (p.ntiles == 0) return IG_OK;
+    if (Cin == 96) {
+        p.tiles_y = (H + 7) / 8;  // 8 x 16 tiles
+        p.ntiles = (long)B * p.tiles_x * p.tiles_y;
+        constexpr int smem96 = 48 * (27 * 64 + 32) + 2 * 34 * 1024 + 3 * 48 * 4;
+        const bf16_t* zp = cd_zero_page();
+        if (!zp) {
+            ig_set_error("ig_conv3x3: could not allocate the zero page");
+            return IG_ERR_HIP;
+        }
+        static bool attr96 = false;
+        if (!attr96) {
+            (void)hipFuncSetAttribute((const void*)conv3x3_direct_slice_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, smem96);
+            attr96 = true;
+        }
+        const long nwg = p.ntiles < 128 ? p.ntiles : 128;
+        hipLaunchKernelGGL(conv3x3_direct_slice_kernel<96>, dim3((unsigned)nwg, 2), dim3(576), smem96, (hipStream_t)stream, p, zp);
+        return ig_check_launch(dgrad ? "ig_conv3x3_dgrad(direct, slices)" : "ig_conv3x3_fwd(direct, slices)");
+    }
     return launch_direct<48>(p, (hipStream_t)stream, dgrad ? "ig_conv3x3_dgrad(direct)" : "ig_conv3x3_fwd(direct)");
 }
 

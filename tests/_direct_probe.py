@@ -41,9 +41,17 @@ out["conv_dgrad"] = digest(dx.float())
 dw = torch.zeros(48, 9, 48, device=dev)
 ops.conv3x3_wgrad(dy, x, dw, B, H, H, 48, 48)
 out["conv_wgrad"] = digest(dw)
-# 3x3 weight gradient with 96 input channels at (H/2, H/2)
+# 96 channels at (H/2, H/2): forward, data gradient (dropout), weight gradient
 h2 = H // 2
 x96, dy96 = rnd(B, h2, h2, 96, seed=4), rnd(B, h2, h2, 96, seed=5)
+w96 = rnd(96, 9, 96, seed=7, scale=0.04)
+bias96 = torch.linspace(-0.5, 0.5, 96, device=dev)
+y96 = BT.empty((B, h2, h2, 96), False, dev)
+ops.conv3x3_fwd(x96, w96, bias96, y96, B, h2, h2, 96, 96)
+out["conv_fwd96"] = digest(y96.float())
+dx96 = BT.empty((B, h2, h2, 96), False, dev)
+ops.conv3x3_dgrad(dy96, w96, dx96, B, h2, h2, 96, 96, seed=79, p=0.1)
+out["conv_dgrad96"] = digest(dx96.float())
 dw96 = torch.zeros(96, 9, 96, device=dev)
 ops.conv3x3_wgrad(dy96, x96, dw96, B, h2, h2, 96, 96)
 out["conv_wgrad96"] = digest(dw96)

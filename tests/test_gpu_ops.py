@@ -313,9 +313,10 @@ def test_convT(split, B, H, Cin, Cout):  # 96 -> 48 unsplit runs the direct sub-
     close(dw, gw.permute(1, 2, 3, 0).reshape(Cout, 9, Cin), 3e-5, what="convT wgrad")
 
 
-def test_conv3x3_direct_bn_fold():
-    """48 -> 48 forward with the eval-mode BatchNorm + ReLU folded into the epilogue (direct kernel), ragged tile edges."""
-    B, H, W, C = 2, 19, 35, 48
+@pytest.mark.parametrize("C", [48, 96])
+def test_conv3x3_direct_bn_fold(C):
+    """C -> C forward with the eval-mode BatchNorm + ReLU folded into the epilogue (direct kernels), ragged tile edges."""
+    B, H, W = 2, 19, 35
     x, xr = bt(nhwc(rnd(B, C, H, W, seed=60)), False)
     w, wr = bt(rnd(C, C, 3, 3, seed=61, scale=(9 * C) ** -0.5).permute(0, 2, 3, 1).reshape(C, 9, C).contiguous(), False)
     bias, sc, sh = rnd(C, seed=62), 1 + 0.2 * rnd(C, seed=63), 0.3 * rnd(C, seed=64)
@@ -326,7 +327,7 @@ def test_conv3x3_direct_bn_fold():
     close(y.float(), nhwc(ref), tol_out(False), what="direct conv + bn fold")
 
 
-@pytest.mark.parametrize("Cin,Cout", [(8, 16), (8, 48), (96, 48)])
+@pytest.mark.parametrize("Cin,Cout", [(8, 16), (8, 48), (96, 48), (8, 96)])
 def test_dropout_mask_consistency(Cin, Cout):
     """ConvT forward mask == conv dgrad mask (same counter-based hash; implicit-GEMM and direct kernels), keep rate ~ 1-p."""
     B, H, W = 1, 8, 8
