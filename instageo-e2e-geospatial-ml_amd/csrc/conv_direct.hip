@@ -1362,6 +1362,154 @@ __global__ __launch_bounds__(576, 1) void conv3x3_direct_slice_kernel(CDParams p
     }
 }
 
+// ---- ConvTranspose data gradient, 96 -> 48 stage: dx[a][b][ci] = sum_{tap,co} dy[2a-1+ky][2b-1+kx][co] * Wc[co][tap][ci] --------
+// A stride-2 3x3 gather over dy (K = 9 * 48 = 432).  The loader wave de-interleaves dy into four sub-pixel phase planes
+// (plane (py,px)[r][c] = dy[2(a0+r)-py][2(b0+c)-px], 5 x 17 pixels x 96 B each) so that the 16 pixels of an MFMA operand are
+// consecutive in LDS; tap (ky,kx) of base pixel (a0+i, b0+j) reads plane ((ky!=1),(kx!=1)) at (i + (ky==2), j + (kx==2)).
+// All of W'[ci][tap*48+co] (96 rows x 928 B) is LDS-resident; tile = 4 x 16 base pixels, 8 MFMA waves = 4 rows x 2 halves of the
+// 96 output channels, 2-stage ring (see convT_direct_dma_kernel).
+struct CTDParams {
+    const bf16_t* dy;  // [B][2H][2W][COUT]
+    const bf16_t* w;   // Wc[COUT][9][CIN]
+    bf16_t* dx;        // [B][H][W][CIN]
+    int B, H, W;
+    int tiles_x, tiles_y;
+    long ntiles;
+};
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(576, 1) void convT_dgrad_direct_kernel(CTDParams p, const bf16_t* zero_page) {
+    static_assert(CIN == 96 && COUT == 48, "written for the 96 -> 48 stage");
+    constexpr int NCW = 8, R4 = 4;
+    constexpr int UN = COUT / 8;                   // 6 units per dy pixel = k-groups per tap
+    constexpr int KG = 9 * UN, KSTEPS = (KG + 3) / 4;  // 54 k-groups, 14 K-steps (the last half padded)
+    constexpr int WP = KSTEPS * 64 + 32;           // 232 dwords
+    constexpr int PPD = 2 * COUT;                  // 24 dwords: conflict-free
+    constexpr int PR = R4 + 1, PC = TW + 1;        // plane rows / columns
+    constexpr int PLANE = PR * PC * PPD;           // 8160 B
+    constexpr int DUNITS = 4 * PLANE / 16;         // 2040
+    constexpr int DSLOTS = (DUNITS + 63) / 64;     // 32
+    constexpr int STAGE = DSLOTS * 1024;
+    constexpr int W_BYTES = CIN * WP;
+    constexpr int ZERO_OFF = W_BYTES + 2 * STAGE;
+    constexpr int NB = 3;                          // 16-channel blocks per wave (half of the 96 output channels)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) char* lds_char_ptr;
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_char_ptr)smem;
+    char* wl = smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- W'[ci][tap*COUT + co] -> LDS (rows interleaved per 48-channel half: a lane owns 8 consecutive output channels)
+    auto pos48 = [](int c) { return c < 32 ? ((c % 8) / 4) * 16 + (c / 8) * 4 + c % 4 : c; };
+    for (int i = tid; i < (W_BYTES) / 16; i += 576) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+    if (tid == 0) *reinterpret_cast<uint4*>(smem + ZERO_OFF) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    constexpr int CU = CIN / 8;
+    for (int u = tid; u < COUT * 9 * CU; u += 576) {
+        const int co = u / (9 * CU), r = u - co * (9 * CU), tap = r / CU, c8 = r - tap * CU;
+        const uint4 v = *reinterpret_cast<const uint4*>(p.w + ((size_t)co * 9 + tap) * CIN + c8 * 8);
+        const uint32_t qv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ci = c8 * 8 + i;
+            reinterpret_cast<bf16_t*>(wl + ((ci / 48) * 48 + pos48(ci % 48)) * WP)[tap * COUT + co] = (bf16_t)(qv[i >> 1] >> ((i & 1) * 16));
+        }
+    }
+    __syncthreads();
+
+    auto tile_coords = [&](int t, int& b, int& ty0, int& tx0) {
+        const int per_img = p.tiles_x * p.tiles_y;
+        b = t / per_img;
+        const int r = t - b * per_img;
+        const int ty = r / p.tiles_x;
+        ty0 = ty * R4, tx0 = (r - ty * p.tiles_x) * TW;
+    };
+    const int nt = (int)p.ntiles, gstep = (int)gridDim.x;
+    const int t0 = xcd_first_tile();
+    const int mine = t0 < nt ? (nt - t0 + gstep - 1) / gstep : 0;
+
+    if (wave == NCW) {
+        // ================================= loader wave =================================
+        int u_off[DSLOTS], u_yx[DSLOTS];  // yx: (row offset << 8) | column offset of the dy pixel from (2a0 - 1, 2b0 - 1)
+#pragma unroll
+        for (int i = 0; i < DSLOTS; ++i) {
+            const int u = i * 64 + lane;
+            const int plane = u / (PLANE / 16), rem = u - plane * (PLANE / 16);
+            const int pix = rem / UN, c8 = rem - pix * UN;
+            const int r = pix / PC, c = pix - r * PC;
+            const int py = plane >> 1, px = plane & 1;
+            const int dyo = 2 * r - py + 1, dxo = 2 * c - px + 1;
+            const bool used = u < DUNITS && r < R4 + py && c < TW + px;
+            u_off[i] = (dyo * 2 * p.W + dxo) * COUT + c8 * 8;
+            u_yx[i] = used ? (dyo << 8) | dxo : 0xffff;
+        }
+        auto issue = [&](int t, int st) {
+            int b, ty0, tx0;
+            tile_coords(t, b, ty0, tx0);
+            const bf16_t* base = p.dy + (((long)b * 2 * p.H + 2 * ty0 - 1) * (2 * p.W) + 2 * tx0 - 1) * COUT;  // (2a0-1, 2b0-1)
+            const unsigned sbase = lds_base + W_BYTES + st * STAGE;
+#pragma unroll
+            for (int i = 0; i < DSLOTS; ++i) {
+                const int oy = 2 * ty0 - 1 + (u_yx[i] >> 8), ox = 2 * tx0 - 1 + (u_yx[i] & 0xff);
+                const bool ok = u_yx[i] != 0xffff && ((unsigned)oy < (unsigned)(2 * p.H)) & ((unsigned)ox < (unsigned)(2 * p.W));
+                cd_glds16(ok ? base + u_off[i] : zero_page, sbase + i * 1024);
+            }
+        };
+        if (mine > 0) issue(t0, 0);
+        for (int n = 0; n < mine; ++n) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+            if (n + 1 < mine) issue(t0 + (n + 1) * gstep, (n + 1) & 1);
+        }
+        return;
+    }
+
+    // ================================= MFMA waves: row (wave >> 1), channel half (wave & 1) =================================
+    const int g = lane >> 4, j = lane & 15;
+    const int row = wave >> 1, half = wave & 1;
+    int offk[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+        const int kg = ks * 4 + g;
+        const int tap = kg / UN, cg = kg - tap * UN;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        offk[ks] = ((ky != 1) * 2 + (kx != 1)) * PLANE + ((ky == 2) * PC + (kx == 2)) * PPD + cg * 16;
+    }
+    const int x_lane = (row * PC + j) * PPD;
+    const char* w_lane = wl + (half * 48 + j) * WP + g * 16;
+    const char* zero_ptr = smem + ZERO_OFF;
+    for (int n = 0; n < mine; ++n) {
+        asm volatile("s_barrier" ::: "memory");
+        int b, ty0, tx0;
+        tile_coords(t0 + n * gstep, b, ty0, tx0);
+        const char* st = smem + W_BYTES + (n & 1) * STAGE + x_lane;
+        f32x4 acc[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const bool padded = KG % 4 != 0 && ks == KSTEPS - 1 && g >= KG % 4;
+            bf16x8_t wf[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) wf[nb] = *reinterpret_cast<const bf16x8_t*>(w_lane + nb * 16 * WP + ks * 64);
+            const bf16x8_t pf = *reinterpret_cast<const bf16x8_t*>(padded ? zero_ptr : st + offk[ks]);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], pf, acc[nb], 0, 0, 0);
+        }
+        const int a = ty0 + row, bx = tx0 + j;
+        if (a < p.H && bx < p.W) {
+            const size_t pixc = (((size_t)b * p.H + a) * p.W + bx) * CIN + half * 48;
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = acc[0][i], v[4 + i] = acc[1][i];
+            *reinterpret_cast<uint4*>(p.dx + pixc + 8 * g) = pack8(v);
+            const float v2[4] = {acc[2][0], acc[2][1], acc[2][2], acc[2][3]};
+            store4_split(p.dx, nullptr, pixc + 32 + 4 * g, v2);
+        }
+    }
+}
+
 }  // namespace
 
 static const bf16_t* cd_zero_page() {
@@ -1552,4 +1700,32 @@ int ig_convT_wgrad_direct(const void* dy, const void* x, float* dw, int B, int H
     }
     hipLaunchKernelGGL((convT_wgrad_direct_kernel<96, 48>), dim3((unsigned)nwg), dim3(TW_TPB), smem, (hipStream_t)stream, p);
     return ig_check_launch("ig_convT_wgrad(direct)");
+}
+
+// Called by ig_convT_dgrad (gemm.hip); IG_ERR_UNSUPPORTED when the shape is not covered.
+int ig_convT_dgrad_direct(const void* dy, const void* w, void* dx, int B, int H, int W, int Cin, int Cout, void* stream) {
+    static const int enabled = getenv("IG_CONV_DIRECT") ? atoi(getenv("IG_CONV_DIRECT")) : 1;
+    static const int use_it = getenv("IG_CTD") ? atoi(getenv("IG_CTD")) : 1;
+    if (!enabled || !use_it || Cin != 96 || Cout != 48) return IG_ERR_UNSUPPORTED;
+    if ((long)B * H * W * 4 * Cout >= (1L << 31)) return IG_ERR_UNSUPPORTED;
+    CTDParams p{};
+    p.dy = (const bf16_t*)dy, p.w = (const bf16_t*)w, p.dx = (bf16_t*)dx;
+    p.B = B, p.H = H, p.W = W;
+    p.tiles_x = (W + TW - 1) / TW, p.tiles_y = (H + 3) / 4;
+    p.ntiles = (long)B * p.tiles_x * p.tiles_y;
+    if (p.ntiles == 0) return IG_OK;
+    const bf16_t* zp = cd_zero_page();
+    if (!zp) {
+        ig_set_error("ig_convT_dgrad: could not allocate the zero page");
+        return IG_ERR_HIP;
+    }
+    constexpr int smem = 96 * (14 * 64 + 32) + 2 * 32 * 1024 + 16;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)convT_dgrad_direct_kernel<96, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    const long nwg = p.ntiles < 256 ? p.ntiles : 256;
+    hipLaunchKernelGGL((convT_dgrad_direct_kernel<96, 48>), dim3((unsigned)nwg), dim3(576), smem, (hipStream_t)stream, p, zp);
+    return ig_check_launch("ig_convT_dgrad(direct)");
 }

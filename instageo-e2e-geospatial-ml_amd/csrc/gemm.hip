@@ -1653,6 +1653,10 @@ int ig_convT_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, const
     IG_REQUIRE(dy_hi && w_hi && dx_hi, "ig_convT_dgrad: null pointer");
     IG_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, "ig_convT_dgrad: channels must be multiples of 8");
     IG_SPLIT_CONSISTENT(dy_lo, w_lo);
+    if (!dy_lo && !dx_lo) {  // last stage (96 -> 48): direct stride-2 gather over phase planes (conv_direct.hip)
+        const int rc = ig_convT_dgrad_direct(dy_hi, w_hi, dx_hi, B, H, W, Cin, Cout, stream);
+        if (rc != IG_ERR_UNSUPPORTED) return rc;
+    }
     ConvTGradLoader al{};
     seg_a(al.base, dy_hi, dy_lo);
     al.Mtot = B * H * W, al.H = H, al.W = W, al.Cout = Cout, al.fixed_tap = -1;

@@ -60,6 +60,9 @@ wt = rnd(48, 9, 96, seed=6, scale=0.05)
 yt = BT.empty((B, H, H, 48), False, dev)
 ops.convT_fwd(x96, wt, bias, yt, B, h2, h2, 96, 48, seed=78, p=0.1)
 out["convT_fwd"] = digest(yt.float())
+dxt = BT.empty((B, h2, h2, 96), False, dev)
+ops.convT_dgrad(dy, wt, dxt, B, h2, h2, 96, 48)
+out["convT_dgrad"] = digest(dxt.float())
 dwt = torch.zeros(48, 9, 96, device=dev)
 ops.convT_wgrad(dy, x96, dwt, B, h2, h2, 96, 48)
 out["convT_wgrad"] = digest(dwt)
