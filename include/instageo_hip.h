@@ -96,8 +96,10 @@ int ig_convT_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const voi
                  void* stream);
 int ig_convT_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, const void* w_lo, void* dx_hi, void* dx_lo, int B,
                    int H, int W, int Cin, int Cout, void* stream);
-int ig_convT_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const void* x_lo, float* dw, int B, int H, int W,
-                   int Cin, int Cout, void* stream);
+/* dbias (optional): dbias[co] += sum over the output pixels of dy (the ConvTranspose2d bias gradient); fused into the direct
+ * kernel of the 96 -> 48 stage, one column-sum pass otherwise */
+int ig_convT_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const void* x_lo, float* dw, float* dbias, int B, int H,
+                   int W, int Cin, int Cout, void* stream);
 /* nn.Conv2d(k=3,padding=1)                                                                           :370-375 */
 /* bn_scale/bn_shift (may be NULL): eval-mode BatchNorm2d + ReLU folded into the epilogue, y = relu((conv+bias)*s + t) */
 int ig_conv3x3_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
@@ -107,8 +109,10 @@ int ig_bn_eval_affine(const float* gamma, const float* beta, const float* runnin
                       float* shift, int C, float eps, void* stream);
 int ig_conv3x3_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, const void* w_lo, void* dx_hi, void* dx_lo, int B,
                      int H, int W, int Cin, int Cout, unsigned drop_seed, const unsigned* drop_seed_dev, float drop_p, void* stream);
-int ig_conv3x3_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const void* x_lo, float* dw, int B, int H, int W,
-                     int Cin, int Cout, void* stream);
+/* dbias (optional): dbias[co] += sum_pixels dy[p][co] (the Conv2d bias gradient); fused into the direct kernels (48 / 96 / 192
+ * input channels: an all-ones MFMA operand against the dy fragments), one column-sum pass otherwise */
+int ig_conv3x3_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const void* x_lo, float* dw, float* dbias, int B, int H,
+                     int W, int Cin, int Cout, void* stream);
 /* nn.BatchNorm2d + nn.ReLU on [M][C] (M = B*H*W)                                                      :376-377 */
 int ig_bn_relu_fwd(const void* x_hi, const void* x_lo, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, void* y_hi, void* y_lo, float* scale, float* shift, float* mean, float* rstd,

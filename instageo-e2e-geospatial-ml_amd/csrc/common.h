@@ -27,9 +27,13 @@ int ig_conv3x3_direct(const void* x, const void* w, const float* bias, const flo
                       float drop_p, void* stream);
 int ig_convT_fwd_direct(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,
                         unsigned drop_seed, const unsigned* drop_seed_dev, float drop_p, void* stream);
+// elementwise.hip (public C ABI): out[c] += sum_m x[m][c]
+extern "C" int ig_colsum(const void* hi, const void* lo, float* out, long M, int C, void* stream);
 int ig_convT_dgrad_direct(const void* dy, const void* w, void* dx, int B, int H, int W, int Cin, int Cout, void* stream);
-int ig_convT_wgrad_direct(const void* dy, const void* x, float* dw, int B, int H, int W, int Cin, int Cout, void* stream);
-int ig_conv3x3_wgrad_direct(const void* dy, const void* x, float* dw, int B, int H, int W, int Cin, int Cout, void* stream);
+int ig_convT_wgrad_direct(const void* dy, const void* x, float* dw, float* dbias, int* bias_fused, int B, int H, int W, int Cin,
+                          int Cout, void* stream);
+int ig_conv3x3_wgrad_direct(const void* dy, const void* x, float* dw, float* dbias, int* bias_fused, int B, int H, int W, int Cin,
+                            int Cout, void* stream);
 
 #define IG_REQUIRE(cond, ...)          \
     do {                               \

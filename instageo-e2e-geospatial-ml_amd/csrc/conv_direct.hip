@@ -305,6 +305,7 @@ struct CWParams {
     const bf16_t* x;   // [B][H][W][CIN] conv input
     const bf16_t* dy;  // [B][H][W][Cout] gradient of the conv output
     float* dw;         // [Cout][9][CIN] fp32, accumulated
+    float* dbias;      // optional [Cout]: += column sums of dy (DMA-ring kernels only)
     int B, H, W, Cout;
     int tiles_x, tiles_y;
     long ntiles;
@@ -641,6 +642,7 @@ struct CTWParams {
     const bf16_t* x;   // [B][H][W][CIN]
     const bf16_t* dy;  // [B][2H][2W][COUT]
     float* dw;         // [COUT][9][CIN]
+    float* dbias;      // optional [COUT]: += column sums of dy (DMA-ring kernel only)
     int B, H, W;
     int tiles_x, tiles_y;
     long ntiles;
@@ -876,6 +878,15 @@ __global__ __launch_bounds__(TW_TPB, 1) void convT_wgrad_dma_kernel(CTWParams p,
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) acc[tap][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // ConvT bias gradient = column sums of dy over all four phases: wave ph (< 4) adds the row sums of phase ph's dy fragments
+    // through an all-ones MFMA operand (3 extra MFMAs per K-step) -- no separate column-sum pass over the 520 MB of dy
+    f32x4 rs[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) rs[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_rs = p.dbias != nullptr && wave < 4;
+    typedef __attribute__((ext_vector_type(8))) short ones_s16x8;
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_s16x8{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80});
+
     const long t0 = xcd_first_tile(), gstep = gridDim.x;
     const long mine = t0 < p.ntiles ? (p.ntiles - t0 + gstep - 1) / gstep : 0;
     if (mine > 0) issue(t0, 0);
@@ -894,6 +905,10 @@ __global__ __launch_bounds__(TW_TPB, 1) void convT_wgrad_dma_kernel(CTWParams p,
                 bf16x8_t af[CB];
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb) af[cb] = tr_frag(st, ph * PLANE + a_base + s * 2 * TWW * PPD + cb * 32, PPD);
+                if (do_rs && ph == wave) {
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb) rs[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cb], ones, rs[cb], 0, 0, 0);
+                }
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     const int ky = tap / 3, kx = tap % 3;
@@ -913,17 +928,23 @@ __global__ __launch_bounds__(TW_TPB, 1) void convT_wgrad_dma_kernel(CTWParams p,
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 atomicAdd(p.dw + (size_t)(cb * 16 + 4 * g + r) * (9 * CIN) + tap * CIN + wave * 16 + i16, acc[tap][cb][r]);
+    if (do_rs && i16 == 0) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(p.dbias + cb * 16 + 4 * g + r, rs[cb][r]);
+    }
 }
 
 // ---- LDS-DMA variant of the 3x3 weight gradient for 96 input channels (one 8-wave workgroup per CU) ------------------
 // Same ring protocol as convT_wgrad_dma_kernel.  Tile = 8 x 16 pixels: x halo 10 x 18 pixels x 224 B (40 wave-DMAs), dy tile
 // 8 x 16 pixels x 96 B of this workgroup's 48-channel slice (12 wave-DMAs); 3 stages x 52 KiB.  Waves 0-3 issue 7 DMAs per
 // tile, waves 4-7 issue 6 (52 = 4 x 7 + 4 x 6), so the counted vmcnt differs by wave.
-template <int CIN, int R8>  // R8 = tile rows: 8 for 96 input channels, 4 for 192 (three stages must fit 160 KiB)
+template <int CIN, int R8>  // R8 = tile rows: 8 for 48 / 96 input channels, 4 for 192 (three stages must fit 160 KiB)
 __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_dma_kernel(CWParams p, const bf16_t* zero_page) {
     constexpr int COB = 48;
-    static_assert((2 * CIN + 32) / 4 % 16 == 8, "x pixel pitch must be = 8 (mod 16) dwords");
-    constexpr int PPX = 2 * CIN + 32, PPD = 2 * COB;
+    constexpr int PPX = 2 * CIN + ((CIN / 2) % 16 == 8 ? 0 : 32), PPD = 2 * COB;
+    static_assert((PPX / 4) % 16 == 8, "x pixel pitch must be = 8 (mod 16) dwords");
     constexpr int PHh = R8 + 2;                 // halo rows
     constexpr int XUP = PPX / 16;               // units per halo pixel (CIN / 8 data + 2 pad)
     constexpr int XUNITS = PHh * HW_ * XUP;
@@ -933,7 +954,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_dma_kernel(CWParams p, c
     constexpr int SLOTS = XSLOTS + DSLOTS;      // 52 / 50
     constexpr int NW = 8, PER_WAVE = (SLOTS + NW - 1) / NW;  // 7
     static_assert(3 * SLOTS * 1024 <= 160 * 1024, "three stages must fit the LDS");
-    static_assert(PER_WAVE == 7 && SLOTS > 6 * NW, "the counted vmcnt below assumes 6 or 7 DMAs per wave");
+    constexpr int FULL_WAVES = SLOTS - (PER_WAVE - 1) * NW;  // waves 0 .. FULL_WAVES-1 issue PER_WAVE DMAs per tile, the rest one less
     constexpr int STAGE = SLOTS * 1024, D_OFF = XSLOTS * 1024;
     constexpr int CB = COB / 16, CIB = CIN / 16, NBLK = 9 * CIB, NBW = (NBLK + NW - 1) / NW;
     constexpr int KS = R8 * TW / 32;
@@ -1011,6 +1032,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_dma_kernel(CWParams p, c
 #pragma unroll
         for (int b = 0; b < NBW; ++b) acc[cb][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // bias gradient of this convolution = column sums of dy = row sums of the A operand: wave cb (< CB) multiplies the dy
+    // fragment of channel block cb, which it holds anyway, by an all-ones operand (one extra MFMA per K-step) instead of a
+    // separate column-sum pass over dy
+    f32x4 rs = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_rs = p.dbias != nullptr && wave < CB;
+    typedef __attribute__((ext_vector_type(8))) short ones_s16x8;
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_s16x8{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80});
+
     const long t0 = xcd_first_tile(), gstep = gridDim.x;
     const long mine = t0 < p.ntiles ? (p.ntiles - t0 + gstep - 1) / gstep : 0;
     if (mine > 0) issue(t0, 0);
@@ -1018,8 +1047,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_dma_kernel(CWParams p, c
     int slot = 0;
     for (long n = 0; n < mine; ++n) {
         if (n + 1 < mine) {
-            if (wave < SLOTS - (PER_WAVE - 1) * NW) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            if (wave < FULL_WAVES) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE - 1) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -1031,6 +1060,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_dma_kernel(CWParams p, c
             bf16x8_t af[CB];
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) af[cb] = tr_frag(st, a_base + s * 2 * TW * PPD + cb * 32, PPD);
+            if (do_rs) {
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+                    if (cb == wave) rs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cb], ones, rs, 0, 0, 0);
+            }
 #pragma unroll
             for (int b = 0; b < NBW; ++b) {
                 const bf16x8_t bf = tr_frag(st, b_base[b] + s * 2 * HW_ * PPX, PPX);
@@ -1049,6 +1083,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_dma_kernel(CWParams p, c
 #pragma unroll
                 for (int r = 0; r < 4; ++r) atomicAdd(p.dw + (size_t)(co0 + cb * 16 + 4 * g + r) * (9 * CIN) + nb * 16 + i16, acc[cb][b][r]);
         }
+    }
+    if (do_rs && i16 == 0) {  // every column of the ones-product holds the row sum: lanes with column 0 own rows 4g .. 4g+3
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(p.dbias + co0 + wave * 16 + 4 * g + r, rs[r]);
     }
 }
 
@@ -1579,31 +1617,38 @@ static int launch_wgrad_direct(const CWParams& p, int nslices, hipStream_t st) {
     return ig_check_launch("ig_conv3x3_wgrad(direct)");
 }
 
-int ig_conv3x3_wgrad_direct(const void* dy, const void* x, float* dw, int B, int H, int W, int Cin, int Cout, void* stream) {
+int ig_conv3x3_wgrad_direct(const void* dy, const void* x, float* dw, float* dbias, int* bias_fused, int B, int H, int W, int Cin,
+                            int Cout, void* stream) {
     static const int enabled = getenv("IG_CONV_DIRECT") ? atoi(getenv("IG_CONV_DIRECT")) : 1;
     static const int use192 = getenv("IG_CW_192") ? atoi(getenv("IG_CW_192")) : 1;
+    static const int use_dma = getenv("IG_CW_DMA") ? atoi(getenv("IG_CW_DMA")) : 1;  // 0: register-prefetch kernels for 48 / 96 channels
+    *bias_fused = 0;
     if (!enabled || Cout % 48 != 0 || (Cin != 48 && Cin != 96 && !(Cin == 192 && use192))) return IG_ERR_UNSUPPORTED;
     if ((long)B * H * W * (Cin > Cout ? Cin : Cout) >= (1L << 31)) return IG_ERR_UNSUPPORTED;
     CWParams p{};
-    p.x = (const bf16_t*)x, p.dy = (const bf16_t*)dy, p.dw = dw;
+    p.x = (const bf16_t*)x, p.dy = (const bf16_t*)dy, p.dw = dw, p.dbias = nullptr;
     p.B = B, p.H = H, p.W = W, p.Cout = Cout;
     p.tiles_x = (W + TW - 1) / TW, p.tiles_y = (H + TH - 1) / TH;
     p.ntiles = (long)B * p.tiles_x * p.tiles_y;
     if (p.ntiles == 0) return IG_OK;
-    if (Cin == 48) return launch_wgrad_direct<48, 4>(p, Cout / 48, (hipStream_t)stream);
-    static const int use_dma = getenv("IG_CW_DMA") ? atoi(getenv("IG_CW_DMA")) : 1;
+    if (!use_dma && Cin == 48) return launch_wgrad_direct<48, 4>(p, Cout / 48, (hipStream_t)stream);
     if (!use_dma && Cin == 96) return launch_wgrad_direct<96, 8>(p, Cout / 48, (hipStream_t)stream);
-    const int rows = Cin == 96 ? 8 : 4;  // the DMA kernels walk 8 x 16 (96 channels) or 4 x 16 (192 channels) tiles
+    static const int r48 = getenv("IG_CW_R48") ? atoi(getenv("IG_CW_R48")) : 12;
+    const int rows = Cin == 192 ? 4 : Cin == 48 ? r48 : 8;  // tile rows of the DMA kernels (x 16 columns)
     p.tiles_y = (H + rows - 1) / rows;
     p.ntiles = (long)B * p.tiles_x * p.tiles_y;
+    p.dbias = dbias;
+    *bias_fused = dbias != nullptr;
     const bf16_t* zp = cd_zero_page();
     if (!zp) {
         ig_set_error("ig_conv3x3_wgrad: could not allocate the zero page");
         return IG_ERR_HIP;
     }
-    constexpr int smem96 = 3 * 52 * 1024, smem192 = 3 * 50 * 1024;
+    constexpr int smem48 = 3 * 29 * 1024, smem48b = 3 * 42 * 1024, smem96 = 3 * 52 * 1024, smem192 = 3 * 50 * 1024;
     static bool attr_done = false;
     if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_dma_kernel<48, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, smem48);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_dma_kernel<48, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, smem48b);
         (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_dma_kernel<96, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, smem96);
         (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_dma_kernel<192, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem192);
         attr_done = true;
@@ -1611,10 +1656,11 @@ int ig_conv3x3_wgrad_direct(const void* dy, const void* x, float* dw, int B, int
     const int nslices = Cout / 48;
     long nwg = 256 / nslices;
     if (nwg > p.ntiles) nwg = p.ntiles;
-    if (Cin == 96)
-        hipLaunchKernelGGL((conv3x3_wgrad_dma_kernel<96, 8>), dim3((unsigned)nwg, nslices), dim3(512), smem96, (hipStream_t)stream, p, zp);
-    else
-        hipLaunchKernelGGL((conv3x3_wgrad_dma_kernel<192, 4>), dim3((unsigned)nwg, nslices), dim3(512), smem192, (hipStream_t)stream, p, zp);
+    const dim3 grid((unsigned)nwg, nslices);
+    if (Cin == 48 && rows == 12) hipLaunchKernelGGL((conv3x3_wgrad_dma_kernel<48, 12>), grid, dim3(512), smem48b, (hipStream_t)stream, p, zp);
+    else if (Cin == 48) hipLaunchKernelGGL((conv3x3_wgrad_dma_kernel<48, 8>), grid, dim3(512), smem48, (hipStream_t)stream, p, zp);
+    else if (Cin == 96) hipLaunchKernelGGL((conv3x3_wgrad_dma_kernel<96, 8>), grid, dim3(512), smem96, (hipStream_t)stream, p, zp);
+    else hipLaunchKernelGGL((conv3x3_wgrad_dma_kernel<192, 4>), grid, dim3(512), smem192, (hipStream_t)stream, p, zp);
     return ig_check_launch("ig_conv3x3_wgrad(direct, dma)");
 }
 
@@ -1664,13 +1710,17 @@ int ig_convT_fwd_direct(const void* x, const void* w, const float* bias, void* y
 }
 
 // Called by ig_convT_wgrad (gemm.hip); IG_ERR_UNSUPPORTED when the shape is not covered.
-int ig_convT_wgrad_direct(const void* dy, const void* x, float* dw, int B, int H, int W, int Cin, int Cout, void* stream) {
+int ig_convT_wgrad_direct(const void* dy, const void* x, float* dw, float* dbias, int* bias_fused, int B, int H, int W, int Cin,
+                          int Cout, void* stream) {
+    *bias_fused = 0;
     static const int enabled = getenv("IG_CONV_DIRECT") ? atoi(getenv("IG_CONV_DIRECT")) : 1;
     static const int use_dma = getenv("IG_CTW_DMA") ? atoi(getenv("IG_CTW_DMA")) : 1;
     if (!enabled || Cin != 96 || Cout != 48) return IG_ERR_UNSUPPORTED;
     if ((long)B * H * W * 4 * Cout >= (1L << 31)) return IG_ERR_UNSUPPORTED;
     CTWParams p{};
     p.x = (const bf16_t*)x, p.dy = (const bf16_t*)dy, p.dw = dw;
+    p.dbias = use_dma ? dbias : nullptr;
+    *bias_fused = p.dbias != nullptr;
     p.B = B, p.H = H, p.W = W;
     const int th = use_dma ? 4 : TWH;
     p.tiles_x = (W + TWW - 1) / TWW, p.tiles_y = (H + th - 1) / th;

@@ -1596,14 +1596,24 @@ int ig_conv3x3_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, con
 }
 
 // dWc[Cout][9][Cin] += sum_pixels dy[p][co] * x[shift_tap(p)][ci]
-int ig_conv3x3_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const void* x_lo, float* dw, int B, int H,
-                     int W, int Cin, int Cout, void* stream) {
+int ig_conv3x3_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const void* x_lo, float* dw, float* dbias, int B,
+                     int H, int W, int Cin, int Cout, void* stream) {
     IG_REQUIRE(dy_hi && x_hi && dw, "ig_conv3x3_wgrad: null pointer");
     IG_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, "ig_conv3x3_wgrad: channels must be multiples of 8");
     IG_SPLIT_CONSISTENT(dy_lo, x_lo);
-    if (!dy_lo) {  // narrow last stage: register-resident partial sums over halo tiles (conv_direct.hip)
-        const int rc = ig_conv3x3_wgrad_direct(dy_hi, x_hi, dw, B, H, W, Cin, Cout, stream);
-        if (rc != IG_ERR_UNSUPPORTED) return rc;
+    // dbias (optional): the convolution's bias gradient, dbias[co] += sum_pixels dy[p][co] -- fused into the direct kernels,
+    // otherwise one column-sum pass over dy
+    if (!dy_lo) {  // narrow stages: register-resident partial sums over halo tiles (conv_direct.hip)
+        int fused = 0;
+        const int rc = ig_conv3x3_wgrad_direct(dy_hi, x_hi, dw, dbias, &fused, B, H, W, Cin, Cout, stream);
+        if (rc != IG_ERR_UNSUPPORTED) {
+            if (rc == IG_OK && dbias && !fused) return ig_colsum(dy_hi, dy_lo, dbias, (long)B * H * W, Cout, stream);
+            return rc;
+        }
+    }
+    if (dbias) {
+        const int rc = ig_colsum(dy_hi, dy_lo, dbias, (long)B * H * W, Cout, stream);
+        if (rc != IG_OK) return rc;
     }
     int Mtot = B * H * W;
     Conv3Loader bl{};
@@ -1671,14 +1681,24 @@ int ig_convT_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, const
 }
 
 // dWc[Cout][tap][Cin] += sum_{input pixels} dy[shift_tap(p)][co] * x[p][ci]     (blockIdx.z = tap)
-int ig_convT_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const void* x_lo, float* dw, int B, int H,
-                   int W, int Cin, int Cout, void* stream) {
+int ig_convT_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const void* x_lo, float* dw, float* dbias, int B,
+                   int H, int W, int Cin, int Cout, void* stream) {
     IG_REQUIRE(dy_hi && x_hi && dw, "ig_convT_wgrad: null pointer");
     IG_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, "ig_convT_wgrad: channels must be multiples of 8");
     IG_SPLIT_CONSISTENT(dy_lo, x_lo);
+    // dbias (optional): dbias[co] += sum over the (2H, 2W) output pixels of dy -- fused into the direct kernel, otherwise one
+    // column-sum pass over dy
     if (!dy_lo) {  // last stage (96 -> 48): register-resident partial sums (conv_direct.hip)
-        const int rc = ig_convT_wgrad_direct(dy_hi, x_hi, dw, B, H, W, Cin, Cout, stream);
-        if (rc != IG_ERR_UNSUPPORTED) return rc;
+        int fused = 0;
+        const int rc = ig_convT_wgrad_direct(dy_hi, x_hi, dw, dbias, &fused, B, H, W, Cin, Cout, stream);
+        if (rc != IG_ERR_UNSUPPORTED) {
+            if (rc == IG_OK && dbias && !fused) return ig_colsum(dy_hi, dy_lo, dbias, 4L * B * H * W, Cout, stream);
+            return rc;
+        }
+    }
+    if (dbias) {
+        const int rc = ig_colsum(dy_hi, dy_lo, dbias, 4L * B * H * W, Cout, stream);
+        if (rc != IG_OK) return rc;
     }
     int Mtot = B * H * W;
     ConvTGradLoader al{};

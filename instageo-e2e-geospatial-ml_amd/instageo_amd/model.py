@@ -433,11 +433,10 @@ class SegEngine:
                 raise RuntimeError("backward through eval-mode BatchNorm is not supported (reference trains in train mode)")
             ops.bn_relu_bwd(ws["cv"][i], ws["df"][i + 1], ws["bn_scale"][i], ws["bn_shift"][i], ws["bn_mean"][i], ws["bn_rstd"][i],
                             ws["dcv"][i], self.Gd(f"{h}{i}.3.weight"), self.Gd(f"{h}{i}.3.bias"), ws["bn_sums"], Mo, C1)
-            ops.conv3x3_wgrad(ws["dcv"][i], ws["u"][i], self.Gd(f"{h}{i}.2.weight"), B, 2 * Hs, 2 * Hs, C1, C1)
-            ops.colsum(ws["dcv"][i], self.Gd(f"{h}{i}.2.bias"), Mo, C1)
+            # (the bias gradients ride on the weight-gradient kernels' dy fragments where those are the direct kernels)
+            ops.conv3x3_wgrad(ws["dcv"][i], ws["u"][i], self.Gd(f"{h}{i}.2.weight"), B, 2 * Hs, 2 * Hs, C1, C1, dbias=self.Gd(f"{h}{i}.2.bias"))
             ops.conv3x3_dgrad(ws["dcv"][i], self.W(f"{h}{i}.2.weight"), ws["du"][i], B, 2 * Hs, 2 * Hs, C1, C1, seed=self.drop_seed + i, p=p, seed_dev=sd)
-            ops.convT_wgrad(ws["du"][i], ws["f"][i], self.Gd(f"{h}{i}.0.weight"), B, Hs, Hs, dims[i], C1)
-            ops.colsum(ws["du"][i], self.Gd(f"{h}{i}.0.bias"), Mo, C1)
+            ops.convT_wgrad(ws["du"][i], ws["f"][i], self.Gd(f"{h}{i}.0.weight"), B, Hs, Hs, dims[i], C1, dbias=self.Gd(f"{h}{i}.0.bias"))
             if i > 0 or not self.freeze_backbone:
                 ops.convT_dgrad(ws["du"][i], self.W(f"{h}{i}.0.weight"), ws["df"][i], B, Hs, Hs, dims[i], C1)
         head0 = "segmentation_head.0.0.weight"

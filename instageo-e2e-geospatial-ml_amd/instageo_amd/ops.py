@@ -256,8 +256,9 @@ def convT_dgrad(dy: BT, w: BT, dx: BT, B, H, W, Cin, Cout) -> None:
     _call("ig_convT_dgrad", 2.0 * B * H * W * Cin * Cout * 9, _p(dy.hi), _p(dy.lo), _p(w.hi), _p(w.lo), _p(dx.hi), _p(dx.lo), B, H, W, Cin, Cout, _stream())
 
 
-def convT_wgrad(dy: BT, x: BT, dw, B, H, W, Cin, Cout) -> None:
-    _call("ig_convT_wgrad", 2.0 * B * H * W * Cin * Cout * 9, _p(dy.hi), _p(dy.lo), _p(x.hi), _p(x.lo), _p(dw), B, H, W, Cin, Cout, _stream())
+def convT_wgrad(dy: BT, x: BT, dw, B, H, W, Cin, Cout, dbias=None) -> None:
+    """dw += per-tap dy^T x; ``dbias`` (fp32 [Cout]) additionally accumulates the column sums of dy (the bias gradient)."""
+    _call("ig_convT_wgrad", 2.0 * B * H * W * Cin * Cout * 9, _p(dy.hi), _p(dy.lo), _p(x.hi), _p(x.lo), _p(dw), _p(dbias), B, H, W, Cin, Cout, _stream())
 
 
 def conv3x3_fwd(x: BT, w: BT, bias, y: BT, B, H, W, Cin, Cout, bn_scale=None, bn_shift=None) -> None:
@@ -275,8 +276,9 @@ def conv3x3_dgrad(dy: BT, w: BT, dx: BT, B, H, W, Cin, Cout, seed: int = 0, p: f
               _stream())
 
 
-def conv3x3_wgrad(dy: BT, x: BT, dw, B, H, W, Cin, Cout) -> None:
-    _call("ig_conv3x3_wgrad", 2.0 * B * H * W * Cin * Cout * 9, _p(dy.hi), _p(dy.lo), _p(x.hi), _p(x.lo), _p(dw), B, H, W, Cin, Cout, _stream())
+def conv3x3_wgrad(dy: BT, x: BT, dw, B, H, W, Cin, Cout, dbias=None) -> None:
+    """dw += dy^T x_gathered; ``dbias`` (fp32 [Cout]) additionally accumulates the column sums of dy (the bias gradient)."""
+    _call("ig_conv3x3_wgrad", 2.0 * B * H * W * Cin * Cout * 9, _p(dy.hi), _p(dy.lo), _p(x.hi), _p(x.lo), _p(dw), _p(dbias), B, H, W, Cin, Cout, _stream())
 
 
 def bn_relu_fwd(x: BT, gamma, beta, rmean, rvar, y: BT, scale, shift, mean, rstd, sums, M: int, C: int, training: bool,

@@ -283,9 +283,10 @@ def test_conv3x3(split, B, H, Cin, Cout):  # unsplit 48 -> 48 (fwd, dgrad) and C
     dx = BT.empty((B, H, W, Cin), split, DEV)
     ops.conv3x3_dgrad(dy, w, dx, B, H, W, Cin, Cout)
     close(dx.float(), nhwc(gx), tol_out(split), what="conv dgrad")
-    dw = torch.zeros(Cout, 9, Cin, device=DEV)
-    ops.conv3x3_wgrad(dy, x, dw, B, H, W, Cin, Cout)
+    dw, db = torch.zeros(Cout, 9, Cin, device=DEV), torch.full((Cout,), 0.25, device=DEV)
+    ops.conv3x3_wgrad(dy, x, dw, B, H, W, Cin, Cout, dbias=db)
     close(dw, gw.permute(0, 2, 3, 1).reshape(Cout, 9, Cin), 3e-5, what="conv wgrad")
+    close(db - 0.25, dyr.sum((0, 1, 2)), 3e-5, what="conv bias gradient (fused into the direct kernels / column-sum fallback)")
 
 
 @pytest.mark.parametrize("split", SPLITS)
@@ -308,9 +309,10 @@ def test_convT(split, B, H, Cin, Cout):  # 96 -> 48 unsplit runs the direct sub-
     dx = BT.empty((B, H, W, Cin), split, DEV)
     ops.convT_dgrad(dy, w, dx, B, H, W, Cin, Cout)
     close(dx.float(), nhwc(gx), tol_out(split), what="convT dgrad")
-    dw = torch.zeros(Cout, 9, Cin, device=DEV)
-    ops.convT_wgrad(dy, x, dw, B, H, W, Cin, Cout)
+    dw, db = torch.zeros(Cout, 9, Cin, device=DEV), torch.full((Cout,), 0.25, device=DEV)
+    ops.convT_wgrad(dy, x, dw, B, H, W, Cin, Cout, dbias=db)
     close(dw, gw.permute(1, 2, 3, 0).reshape(Cout, 9, Cin), 3e-5, what="convT wgrad")
+    close(db - 0.25, dyr.sum((0, 1, 2)), 3e-5, what="convT bias gradient")
 
 
 @pytest.mark.parametrize("C", [48, 96])
