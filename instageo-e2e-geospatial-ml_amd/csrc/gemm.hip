@@ -925,6 +925,7 @@ struct ConvTFwdALoader {
     void finish() { f_hw = make_fdiv(H * W), f_w = make_fdiv(W), f_c = make_fdiv(C); }
     int nky, nkx, ky0, kx0, K;
     __device__ void init(int z) {
+        z = 3 - z;  // heaviest phase (4 taps) first: blockIdx.z is dispatched slowest, so the launch ends on the 1-tap phase
         int py = z >> 1, px = z & 1;
         nky = py ? 2 : 1, nkx = px ? 2 : 1;
         ky0 = py ? 0 : 1, kx0 = px ? 0 : 1;  // tap lists: {1} or {0,2}
@@ -962,6 +963,7 @@ struct ConvTFwdBLoader {
     int Cout, C;
     int nky, nkx, ky0, kx0, K;
     __device__ void init(int z) {
+        z = 3 - z;  // heaviest phase (4 taps) first: blockIdx.z is dispatched slowest, so the launch ends on the 1-tap phase
         int py = z >> 1, px = z & 1;
         nky = py ? 2 : 1, nkx = px ? 2 : 1;
         ky0 = py ? 0 : 1, kx0 = px ? 0 : 1;
@@ -1080,6 +1082,7 @@ struct EpStore {
     int phase_map, H, W;  // phase_map=1: row (b,iy,ix) -> (b, 2iy+py, 2ix+px) of a (2H,2W) image
     int py, px;
     __device__ void init(int z) {
+        if (phase_map) z = 3 - z;  // same phase order as the ConvT loaders (heaviest first)
         py = z >> 1, px = z & 1;
         if (drop_seed_dev) drop_seed += *drop_seed_dev;
     }
