@@ -1080,6 +1080,7 @@ struct EpStore {
     const uint32_t* drop_seed_dev;  // optional per-step offset read on the device (graph-replay safe)
     float drop_inv;
     int phase_map, H, W;  // phase_map=1: row (b,iy,ix) -> (b, 2iy+py, 2ix+px) of a (2H,2W) image
+    FDiv f_hw, f_w;       // multiply-high division by H*W and W (set with phase_map; a runtime integer division per store was ~80 instructions)
     int py, px;
     __device__ void init(int z) {
         if (phase_map) z = 3 - z;  // same phase order as the ConvT loaders (heaviest first)
@@ -1090,8 +1091,8 @@ struct EpStore {
         long row = m;
         if (phase_map) {
             int hw = H * W;
-            int b = m / hw, rem = m - b * hw;
-            int y = rem / W, x = rem - y * W;
+            int b = f_hw.div(m), rem = m - b * hw;
+            int y = f_w.div(rem), x = rem - y * W;
             row = ((long)(b * 2 * H + 2 * y + py)) * (2 * W) + 2 * x + px;
         }
         float v[4] = {a[0], a[1], a[2], a[3]};
@@ -1653,6 +1654,7 @@ int ig_convT_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const voi
     ep.out_hi = (bf16_t*)y_hi, ep.out_lo = (bf16_t*)y_lo, ep.bias = bias, ep.ldo = Cout;
     IG_REQUIRE(drop_p <= 0.f || (double)B * 4 * H * W * Cout < 4294967296.0, "ig_convT_fwd: dropout needs < 2^32 elements");
     ep.phase_map = 1, ep.H = H, ep.W = W;
+    ep.f_hw = make_fdiv(H * W), ep.f_w = make_fdiv(W);
     ep.drop_seed = drop_seed, ep.drop_seed_dev = drop_seed_dev;
     ep.drop_thresh = ig_drop_thresh16(drop_p);
     ep.drop_inv = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
