@@ -961,6 +961,8 @@ struct ConvTFwdBLoader {
     __device__ long kstride() const { return 0; }
     const bf16_t* base[3];
     int Cout, C;
+    FDiv f_c;  // set by finish(): multiply-high division by C (a runtime division per 16-byte unit sat in every K-step)
+    void finish() { f_c = make_fdiv(C); }
     int nky, nkx, ky0, kx0, K;
     __device__ void init(int z) {
         z = 3 - z;  // heaviest phase (4 taps) first: blockIdx.z is dispatched slowest, so the launch ends on the 1-tap phase
@@ -972,8 +974,8 @@ struct ConvTFwdBLoader {
     __device__ int kdim() const { return K; }
     __device__ const bf16_t* ptr(int seg, int r, int c8, bool& ok) const {
         int k = c8 * 8;
-        int tl = k / C, c = k - tl * C;
-        int tyi = tl / nkx, txi = tl - tyi * nkx;
+        int tl = f_c.div(k), c = k - tl * C;
+        int tyi = tl >> (nkx - 1), txi = tl - tyi * nkx;  // nkx is 1 or 2
         int tap = (ky0 + 2 * tyi) * 3 + (kx0 + 2 * txi);
         ok = (r < Cout) & (k < K);
         return base[seg] + (ok ? ((long)r * 9 + tap) * C + c : 0L);
@@ -993,11 +995,13 @@ struct ConvWgtTRLoader {
     __device__ long kstride() const { return 0; }
     const bf16_t* base[3];
     int Cout, Cin;
+    FDiv f_co;  // set by finish()
+    void finish() { f_co = make_fdiv(Cout); }
     __device__ void init(int) {}
     __device__ int kdim() const { return -1; }
     __device__ const bf16_t* ptr(int seg, int r, int c8, bool& ok) const {
         int c = c8 * 8;
-        int tap = r / Cout, co = r - tap * Cout;
+        int tap = f_co.div(r), co = r - tap * Cout;
         ok = (tap < 9) & (c < Cin);
         return base[seg] + (ok ? ((long)co * 9 + tap) * Cin + c : 0L);
     }
@@ -1589,6 +1593,7 @@ int ig_conv3x3_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, con
     ConvWgtTRLoader bl{};
     seg_b(bl.base, w_hi, w_lo);
     bl.Cout = Cout, bl.Cin = Cin;
+    bl.finish();
     EpGradStore ep{};
     IG_REQUIRE(drop_p <= 0.f || (double)B * H * W * Cin < 4294967296.0, "ig_conv3x3_dgrad: dropout needs < 2^32 elements");
     ep.out_hi = (bf16_t*)dx_hi, ep.out_lo = (bf16_t*)dx_lo, ep.ldo = Cin, ep.mode = 2;
@@ -1650,6 +1655,7 @@ int ig_convT_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const voi
     ConvTFwdBLoader bl{};
     seg_b(bl.base, w_hi, w_lo);
     bl.Cout = Cout, bl.C = Cin;
+    bl.finish();
     EpStore ep{};
     ep.out_hi = (bf16_t*)y_hi, ep.out_lo = (bf16_t*)y_lo, ep.bias = bias, ep.ldo = Cout;
     IG_REQUIRE(drop_p <= 0.f || (double)B * 4 * H * W * Cout < 4294967296.0, "ig_convT_fwd: dropout needs < 2^32 elements");
@@ -1679,6 +1685,7 @@ int ig_convT_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, const
     ConvWgtTRLoader bl{};
     seg_b(bl.base, w_hi, w_lo);
     bl.Cout = Cout, bl.Cin = Cin;
+    bl.finish();
     EpGradStore ep{};
     ep.out_hi = (bf16_t*)dx_hi, ep.out_lo = (bf16_t*)dx_lo, ep.ldo = Cin, ep.mode = 0;
     return launch_gemm<ConvTGradLoader, ConvWgtTRLoader, EpGradStore, false, true>(
