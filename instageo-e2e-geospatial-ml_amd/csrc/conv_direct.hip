@@ -905,10 +905,6 @@ __global__ __launch_bounds__(TW_TPB, 1) void convT_wgrad_dma_kernel(CTWParams p,
                 bf16x8_t af[CB];
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb) af[cb] = tr_frag(st, ph * PLANE + a_base + s * 2 * TWW * PPD + cb * 32, PPD);
-                if (do_rs && ph == wave) {
-#pragma unroll
-                    for (int cb = 0; cb < CB; ++cb) rs[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cb], ones, rs[cb], 0, 0, 0);
-                }
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     const int ky = tap / 3, kx = tap % 3;
@@ -916,6 +912,13 @@ __global__ __launch_bounds__(TW_TPB, 1) void convT_wgrad_dma_kernel(CTWParams p,
                     const bf16x8_t bf = tr_frag(st, b_base + (s * 2 * PW + (ky == 0) * PW + (kx == 0)) * PPX, PPX);
 #pragma unroll
                     for (int cb = 0; cb < CB; ++cb) acc[tap][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cb], bf, acc[tap][cb], 0, 0, 0);
+                }
+            }
+            if (do_rs) {  // one wave-uniform block per K-step, outside the phase loop: re-read phase `wave`'s dy fragments
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    const bf16x8_t a2 = tr_frag(st, wave * PLANE + a_base + s * 2 * TWW * PPD + cb * 32, PPD);
+                    rs[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, ones, rs[cb], 0, 0, 0);
                 }
             }
         }
@@ -928,11 +931,19 @@ __global__ __launch_bounds__(TW_TPB, 1) void convT_wgrad_dma_kernel(CTWParams p,
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 atomicAdd(p.dw + (size_t)(cb * 16 + 4 * g + r) * (9 * CIN) + tap * CIN + wave * 16 + i16, acc[tap][cb][r]);
-    if (do_rs && i16 == 0) {
+    if (p.dbias != nullptr) {
+        // the four phase waves' partial sums are folded through LDS first: 4 x 48 same-address atomics per workgroup, issued
+        // by all 256 workgroups as they finish together, were 60 us of serialised atomics at the tail of a 200 us kernel
+        __syncthreads();  // every wave is done with the ring
+        float* red = reinterpret_cast<float*>(smem);
+        if (do_rs && i16 == 0) {
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
+            for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(p.dbias + cb * 16 + 4 * g + r, rs[cb][r]);
+                for (int r = 0; r < 4; ++r) red[wave * COUT + cb * 16 + 4 * g + r] = rs[cb][r];
+        }
+        __syncthreads();
+        if (tid < COUT) atomicAdd(p.dbias + tid, red[tid] + red[COUT + tid] + red[2 * COUT + tid] + red[3 * COUT + tid]);
     }
 }
 

@@ -22,7 +22,8 @@ for H,C in [(224,48),(112,96),(56,192),(28,384)]:
     td=timeit(lambda: ops.conv3x3_dgrad(y,w,dx,B,H,H,C,C,seed=1,p=0.1))
     print(f"conv3x3 dgrad H{H} C{C}: {td:8.1f} us {fl/td/1e6:6.0f} TF")
     dw=torch.zeros(C,9,C,device=dev)
-    tw=timeit(lambda: ops.conv3x3_wgrad(y,x,dw,B,H,H,C,C))
+    db=torch.zeros(C,device=dev)
+    tw=timeit(lambda: ops.conv3x3_wgrad(y,x,dw,B,H,H,C,C,dbias=db))
     print(f"conv3x3 wgrad H{H} C{C}: {tw:8.1f} us {fl/tw/1e6:6.0f} TF")
     print(f"conv3x3 fwd H{H} C{C}: {t:8.1f} us {fl/t/1e6:6.0f} TF  dbg={os.environ.get('IG_GEMM_DBG','0')}")
 for H,Ci,Co in [(112,96,48),(56,192,96),(28,384,192),(14,768,384)]:
@@ -33,5 +34,6 @@ for H,Ci,Co in [(112,96,48),(56,192,96),(28,384,192),(14,768,384)]:
     dx=BT.empty((B,H,H,Ci),False,dev)
     td=timeit(lambda: ops.convT_dgrad(y,w,dx,B,H,H,Ci,Co))
     dw=torch.zeros(Co,9,Ci,device=dev)
-    tw=timeit(lambda: ops.convT_wgrad(y,x,dw,B,H,H,Ci,Co))
+    db=torch.zeros(Co,device=dev)
+    tw=timeit(lambda: ops.convT_wgrad(y,x,dw,B,H,H,Ci,Co,dbias=db))
     print(f"convT H{H} {Ci}->{Co}: fwd {t:7.1f} us {fl/t/1e6:5.0f} TF | dgrad {td:7.1f} us {fl/td/1e6:5.0f} TF | wgrad {tw:7.1f} us {fl/tw/1e6:5.0f} TF")
