@@ -311,13 +311,22 @@ __device__ __forceinline__ bf16x8_t read_frag2(const char* tile, int row0, int s
     }
 }
 
-template <class AL, class BL, class EP, bool A_TR, bool B_TR, int NSEG, int BKT>
-__global__ __launch_bounds__(NTHR2, (BKT == 32 ? 4 : 2)) void gemm2_kernel(AL al, BL bl, EP ep, int M, int N, int K, int tiles_n,
-                                                                       int ntiles, int kchunk, const bf16_t* zero_page) {
+// DUALK = 2 (staged-atomic weight gradients only): ONE 16-wave workgroup per CU instead of two 8-wave ones.  Its two wave
+// groups run this kernel's body on their own rings over the two halves of the workgroup's K slice (they meet at the same
+// barriers, so both execute the same number of K-steps; the shorter half idles through its last one) and fold their two fp32
+// tiles through LDS before the atomic pass: the split-K atomic volume (#workgroups x tile) is halved -- with the adds
+// switched off the weight gradient ran at 890-990 TFLOP/s against 675-785.
+template <class AL, class BL, class EP, bool A_TR, bool B_TR, int NSEG, int BKT, int DUALK = 1>
+__global__ __launch_bounds__(NTHR2 * DUALK, (BKT == 32 ? 4 : 2)) void gemm2_kernel(AL al, BL bl, EP ep, int M, int N, int K, int tiles_n,
+                                                                               int ntiles, int kchunk, const bf16_t* zero_page) {
     using G = G2<BKT>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(DUALK == 1 || (DUALK == 2 && EP::kStagedAtomic && BKT == 32), "the dual-group form exists for the staged-atomic epilogue");
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave16 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = DUALK == 2 ? wave16 >> 3 : 0;
+    const int wave = wave16 & 7;
+    char* smem = smem_all + grp * G::SMEM;  // this wave group's ring
     const int wm = wave >> 1, wn = wave & 1;
     // PERSISTENT tile schedule: workgroups are dealt round-robin over the 8 XCDs (private L2s; XCD = linear workgroup
     // id % 8, tools/xcc_probe.hip); XCD x owns the contiguous tile range [tlo, tlo+tcnt) and its workgroups walk it with
@@ -333,11 +342,19 @@ __global__ __launch_bounds__(NTHR2, (BKT == 32 ? 4 : 2)) void gemm2_kernel(AL al
     ep.init(blockIdx.z);
     if (al.kdim() >= 0) K = al.kdim();
     const int nk_all = (K + BKT - 1) / BKT;
-    const int kt0 = blockIdx.y * kchunk;
-    const int nk = min(kchunk, nk_all - kt0);
+    int kt0 = blockIdx.y * kchunk;
+    int nk = min(kchunk, nk_all - kt0);
     if (nk <= 0 || my_tiles <= 0) return;
+    int G_loop = 0;  // DUALK == 2: iterations (barriers) both wave groups execute
+    if constexpr (DUALK == 2) {
+        const int nkh = (nk + 1) >> 1;  // group 0: [kt0, kt0 + nkh), group 1: the rest (possibly one step shorter, or empty)
+        G_loop = nkh * NSEG;
+        kt0 += grp * nkh;
+        nk = grp == 0 ? nkh : nk - nkh;
+    }
     const int total = nk * NSEG;      // K-steps per tile
-    const int G_ = my_tiles * total;  // flattened (tile, K-step) sequence of this workgroup
+    const int G_ = my_tiles * total;  // flattened (tile, K-step) sequence of this workgroup (wave group)
+    if constexpr (DUALK == 1) G_loop = G_;
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_char_ptr)smem;
 
     f32x4 acc[4][4];
@@ -432,15 +449,17 @@ __global__ __launch_bounds__(NTHR2, (BKT == 32 ? 4 : 2)) void gemm2_kernel(AL al
             bm_i = tile_i / tiles_n, bn_i = tile_i - bm_i * tiles_n; \
         }                                                       \
     }
-    GEMM2_ISSUE(it_i, 0, bm_i, bn_i);
-    GEMM2_ADVANCE_ISSUE();
+    if (G_ > 0) {
+        GEMM2_ISSUE(it_i, 0, bm_i, bn_i);
+        GEMM2_ADVANCE_ISSUE();
+    }
     if (G_ > 1) {
         GEMM2_ISSUE(it_i, 1, bm_i, bn_i);
         GEMM2_ADVANCE_ISSUE();
     }
     int slot = 0, it_c = 0;
     int tile_c = tlo + jx;
-    for (int g = 0; g < G_; ++g) {
+    for (int g = 0; g < G_loop; ++g) {
         // K-step g landed for THIS wave once at most the DMAs of step g+1 are outstanding (vmcnt also counts the
         // epilogue's stores, which only makes the wait at a tile boundary conservative); the barrier then covers
         // the other waves' pieces (RAW) and everybody's reads of the slot that is refilled next (WAR)
@@ -451,6 +470,9 @@ __global__ __launch_bounds__(NTHR2, (BKT == 32 ? 4 : 2)) void gemm2_kernel(AL al
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         asm volatile("s_barrier" ::: "memory");
+        if constexpr (DUALK == 2) {
+            if (g >= G_) continue;  // the shorter wave group only keeps the barrier count (its last iteration, or all of them)
+        }
         const bool do_issue = g + 2 < G_;
         const int s2 = slot >= 1 ? slot - 1 : slot + 2;  // (slot + 2) % 3
         GEMM2_ISSUE_BEGIN(do_issue ? it_i : 0, s2, bm_i, bn_i)
@@ -489,6 +511,7 @@ __global__ __launch_bounds__(NTHR2, (BKT == 32 ? 4 : 2)) void gemm2_kernel(AL al
         }
         if (do_issue) GEMM2_ADVANCE_ISSUE();
         slot = slot == 2 ? 0 : slot + 1;
+        if constexpr (DUALK == 2) continue;  // one tile per workgroup: the epilogue follows the loop, entered by both groups together
         if (++it_c < total) continue;
         // ---- tile finished: epilogue (next tile's first K-steps are already in flight) ----
         it_c = 0;
@@ -560,6 +583,41 @@ __global__ __launch_bounds__(NTHR2, (BKT == 32 ? 4 : 2)) void gemm2_kernel(AL al
                 }
             }
             asm volatile("" ::: "memory");
+        }
+    }
+    if constexpr (DUALK == 2) {
+        // both wave groups hold a partial 256 x 128 fp32 tile: stage 128 rows of each (2 x 64 KiB of the 144 KiB of rings), add
+        // the pair and issue ONE row-contiguous atomic pass
+        const int bm = tile_c / tiles_n, bn = tile_c - bm * tiles_n;
+#pragma unroll
+        for (int hpass = 0; hpass < 2; ++hpass) {
+            __syncthreads();
+            float* st = reinterpret_cast<float*>(smem_all) + grp * (128 * 128);
+            if ((wm >> 1) == hpass) {
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm) {
+                    const int ml = (wm & 1) * 64 + tm * 16 + (lane & 15);
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn) {
+                        const int c4 = (wn * 64 + tn * 16 + 4 * (lane >> 4)) >> 2;
+                        *reinterpret_cast<f32x4*>(st + ml * 128 + ((c4 ^ (ml & 7)) << 2)) = acc[tn][tm];
+                    }
+                }
+            }
+            __syncthreads();
+            const float* s0 = reinterpret_cast<const float*>(smem_all);
+            const float* s1 = s0 + 128 * 128;
+            for (int rr = wave16; rr < 128; rr += 16) {
+                const int m = bm * BM2 + hpass * 128 + rr;
+                if (m >= M) break;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int nl = half * 64 + lane;
+                    const int n = bn * BN + nl;
+                    const int o = rr * 128 + ((((nl >> 2) ^ (rr & 7)) << 2) | (nl & 3));
+                    if (n < N) ep.add(m, n, s0[o] + s1[o]);
+                }
+            }
         }
     }
 #undef GEMM2_ISSUE
@@ -1374,11 +1432,25 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, i
         if constexpr (EP::kStagedAtomic) {
             // one tile per workgroup (split-K over blockIdx.y); the fp32 tile is staged through the ring in two halves
             const int nk32 = ig_cdiv(K, 32);
-            int ks = 512 / (tm * tn * Z);  // two workgroups per CU
-            if (ks > nk32 / 16) ks = nk32 / 16;
+            static const int dual_env = getenv("IG_WGRAD_DUAL") ? atoi(getenv("IG_WGRAD_DUAL")) : 1;
+            const bool dual = dual_env && !split && AL::kLinearK && BL::kLinearK && nk32 >= 64;
+            int ks = (dual ? 256 : 512) / (tm * tn * Z);  // two 8-wave workgroups per CU, or one 16-wave workgroup (two K halves)
+            if (ks > nk32 / (dual ? 32 : 16)) ks = nk32 / (dual ? 32 : 16);
             if (ks < 1) ks = 1;
             kchunk = ig_cdiv(nk32, ks);
             grid.y = ig_cdiv(nk32, kchunk);
+            if constexpr (AL::kLinearK && BL::kLinearK) {
+                if (dual) {
+                    auto kern = gemm2_kernel<AL, BL, EP, A_TR, B_TR, 1, 32, 2>;
+                    static bool attr_dual = false;
+                    if (!attr_dual) {
+                        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2<32>::SMEM);
+                        attr_dual = true;
+                    }
+                    hipLaunchKernelGGL(kern, grid, dim3(2 * NTHR2), 2 * G2<32>::SMEM, st, al, bl, ep, M, N, K, tn, ntiles, kchunk, zp);
+                    return ig_check_launch(what);
+                }
+            }
             if (split) IG_LAUNCH_V2(3, 32) else IG_LAUNCH_V2(1, 32)
         } else {
             // persistent: two workgroups per CU walk the tile list; BK = 32 keeps the ring at 72 KiB

@@ -112,7 +112,7 @@ def test_linear_residual(split):
 
 
 @pytest.mark.parametrize("split", SPLITS)
-@pytest.mark.parametrize("M,N,K", [(300, 256, 192), (197, 768, 256), (1000, 64, 72)])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 192), (197, 768, 256), (1000, 64, 72), (4100, 2304, 768), (2100, 1280, 1536), (21168, 768, 3072)])
 def test_linear_dgrad_wgrad(split, M, N, K):
     dy, dyr = bt(rnd(M, N, seed=5), split)
     w, wr = bt(rnd(N, K, seed=6, scale=N**-0.5), split)
