@@ -54,7 +54,7 @@ KERNEL_OF = {
     "ig_linear_fwd": "gemm2_kernel<PlainLoader,PlainLoader,EpStore,false,false,1,32>",
     "ig_linear_residual_fwd": "gemm2_kernel<PlainLoader,PlainLoader,EpResidual,false,false,1,32>",  # fc2 (K = 4D) runs on gemm5_kernel
     "ig_linear_dgrad": "gemm5_kernel<PlainLoader,PlainLoader,EpGradStore,false,true,1>",  # d_fc2 (with gelu') stays on gemm2_kernel
-    "ig_linear_wgrad": "gemm2_kernel<PlainLoader,PlainLoader,EpAtomic,true,true,1,32>",
+    "ig_linear_wgrad": "gemm2_kernel<PlainLoader,PlainLoader,EpAtomic,true,true,1,32,2>",
 }
 
 

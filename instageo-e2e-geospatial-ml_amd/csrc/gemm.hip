@@ -1599,11 +1599,13 @@ int ig_linear_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, cons
     return launch_gemm<PlainLoader, PlainLoader, EpAtomic, true, true>(
         plain_a(dy_hi, dy_lo, M, N, N), plain_b(x_hi, x_lo, M, K, K), ep, N, K, M, 1, dy_lo != nullptr, (hipStream_t)stream,
         "ig_linear_wgrad", true,
-        // small outputs (proj: 768 x 768 = 18 v2 tiles): the 128 x 128 engine's 36 tiles split the reduction less deeply (+18 %);
-        // short reductions: what decides is the number of K-steps a 256 x 128 workgroup gets between its ring fill and its
-        // 128 KiB staged-atomic epilogue -- below ~50 the 128 x 128 engine wins (768-wide model: +20-30 % at M = 3152, +16 % /
-        // -3 % at 12608, -1..-9 % at 16384; 1024-wide model at M = 10638: -9 % / -1 %; tools/gemm_bench.py)
-        gemm_env() ? gemm_env() : (((long)N * K <= (1L << 20) || v2_steps < 50) ? 1 : 2));
+        // engine: the 256 x 128 engine in its dual-group form (half the split-K atomic volume, launch_gemm) wins from M = 2048 up
+        // on every shape measured (M = 3152 .. 21168: +6 .. +20 % over the 128 x 128 engine, proj 768 x 768 included from
+        // M = 6304) except the smallest output at the YAML's batch (M = 3152, 768 x 768: 151 vs 175 TFLOP/s); below M = 2048
+        // the dual form does not apply and the old rule stands (128 x 128 unless a 256 x 128 workgroup gets >= 50 K-steps)
+        gemm_env() ? gemm_env()
+                   : (nk32 >= 64 ? (((long)N * K <= (1L << 20) && M < 6000) ? 1 : 2)
+                                 : (((long)N * K <= (1L << 20) || v2_steps < 50) ? 1 : 2)));
 }
 
 // Patch embedding (pritvhi.py:243-268,513-517): x[b][1+tp][:] = patches[b*TP+tp] @ w^T + bias + pos[1+tp]
