@@ -7,16 +7,16 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sq -o pmc -- python3 $R/"$@" > $OUT/pmc_sq.log 2>&1
 python3 - <<PY
-import csv,glob,collections
+import csv,glob,collections,os
 f=glob.glob("$OUT/pmc_sq/**/*counter_collection.csv",recursive=True)
 agg=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.Counter()
 for fn in f:
     for r in csv.DictReader(open(fn)):
-        k=r["Kernel_Name"][:60]
+        k=r["Kernel_Name"].replace("(anonymous namespace)::","").split("(")[0][:150]
         agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); 
         if r["Counter_Name"]=="SQ_WAVE_CYCLES": n[k]+=1
 for k,v in agg.items():
-    if "direct" not in k: continue
+    if os.environ.get("PMC_FILTER", "direct") not in k and os.environ.get("PMC_FILTER", "direct") != "*": continue
     wc=v["SQ_WAVE_CYCLES"]
     print(k, "launches",n[k])
     for c in v: print(f"   {c:28s} {v[c]/max(n[k],1):14.0f}  {v[c]/wc:6.3f} of wave cycles")
