@@ -33,6 +33,11 @@ int ig_version(void);
  * entry points were compiled from a different revision of the declarations (stale .so next to a newer header) */
 int ig_header_stamp(void);
 int ig_device_info(int device, char* name, int name_len, int* cu_count, int* lds_per_block, long* hbm_bytes);
+/* Compute units the persistent kernels (one workgroup per CU) leave free.  Data-parallel training (Lightning DDP in the
+ * reference, pipeline_utils.py:368-374) launches RCCL all-reduce kernels beside the backward GEMMs: a grid that pins all
+ * 256 CUs serialises them behind a whole GEMM.  Default 0, or the IG_RESERVED_CUS environment variable. */
+int ig_set_reserved_cus(int n);
+int ig_get_reserved_cus(void);
 
 /* ---- dataset side: normalise + layout (instageo/model/dataloader.py:495-524, 707-750) ---------------- */
 /* src (B, T*C, H, W) band = t*C+c, src_dtype 0=int16 1=float32 -> dst (B, C, T, H, W) f32 = (src*mult-mean_c)/std_c */

@@ -35,6 +35,24 @@ int ig_convT_wgrad_direct(const void* dy, const void* x, float* dw, float* dbias
 int ig_conv3x3_wgrad_direct(const void* dy, const void* x, float* dw, float* dbias, int* bias_fused, int B, int H, int W, int Cin,
                             int Cout, void* stream);
 
+// gemm8.hip: the 256 x 256 x 64 8-phase engine for the K-contiguous ("NT") linear GEMMs.  kind 0: bf16 (split) store of
+// act(acc + bias) [+ gelu' copy]; kind 1: fp32 out = resid + acc + bias.  a / b: segment pointer sets (nseg 1 or 3).
+struct G8Params {
+    const bf16_t* a[3];
+    const bf16_t* b[3];
+    int nseg, M, N, K;
+    long lda, ldb, ldo;
+    int kind, act;
+    const float* bias;
+    bf16_t *out_hi, *out_lo, *dact_hi, *dact_lo;
+    float* outf;
+    const float* resid;
+};
+int ig_gemm8_nt(const G8Params& p, void* stream);  // IG_ERR_UNSUPPORTED (no error string) when the shape is not covered
+// runtime.hip: compute units the persistent kernels leave free (for RCCL's kernels when world > 1); ig_set_reserved_cus()
+int ig_reserved_cus();
+int ig_cu_count();
+
 #define IG_REQUIRE(cond, ...)          \
     do {                               \
         if (!(cond)) {                 \

@@ -1546,6 +1546,15 @@ int ig_linear_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const vo
     IG_REQUIRE(N % 8 == 0 && K % 8 == 0, "ig_linear_fwd: N and K must be multiples of 8 (got %d, %d)", N, K);
     IG_REQUIRE(aligned16(x_hi) && aligned16(w_hi) && aligned16(y_hi), "ig_linear_fwd: pointers must be 16-byte aligned");
     IG_SPLIT_CONSISTENT(x_lo, w_lo);
+    IG_REQUIRE((x_lo == nullptr) == (y_lo == nullptr), "ig_linear_fwd: input and output must both be split or both plain");
+    if (!gemm_env()) {  // 256 x 256 x 64 8-phase engine (gemm8.hip) for the shapes it covers
+        G8Params g{};
+        seg_a(g.a, x_hi, x_lo), seg_b(g.b, w_hi, w_lo);
+        g.nseg = x_lo ? 3 : 1, g.M = M, g.N = N, g.K = K, g.lda = K, g.ldb = K, g.ldo = N, g.kind = 0, g.act = act, g.bias = bias;
+        g.out_hi = (bf16_t*)y_hi, g.out_lo = (bf16_t*)y_lo, g.dact_hi = (bf16_t*)pre_hi, g.dact_lo = (bf16_t*)pre_lo;
+        const int rc = ig_gemm8_nt(g, stream);
+        if (rc != IG_ERR_UNSUPPORTED) return rc;
+    }
     EpStore ep{};
     ep.out_hi = (bf16_t*)y_hi, ep.out_lo = (bf16_t*)y_lo, ep.pre_hi = (bf16_t*)pre_hi, ep.pre_lo = (bf16_t*)pre_lo;
     ep.bias = bias, ep.ldo = N, ep.act = act;
@@ -1560,6 +1569,14 @@ int ig_linear_residual_fwd(const void* x_hi, const void* x_lo, const void* w_hi,
     IG_REQUIRE(x_hi && w_hi && resid && out, "ig_linear_residual_fwd: null pointer");
     IG_REQUIRE(N % 8 == 0 && K % 8 == 0, "ig_linear_residual_fwd: N and K must be multiples of 8");
     IG_SPLIT_CONSISTENT(x_lo, w_lo);
+    if (!gemm_env() && aligned16(x_hi) && aligned16(w_hi) && aligned16(resid) && aligned16(out)) {
+        G8Params g{};
+        seg_a(g.a, x_hi, x_lo), seg_b(g.b, w_hi, w_lo);
+        g.nseg = x_lo ? 3 : 1, g.M = M, g.N = N, g.K = K, g.lda = K, g.ldb = K, g.ldo = N, g.kind = 1, g.bias = bias;
+        g.outf = out, g.resid = resid;
+        const int rc = ig_gemm8_nt(g, stream);
+        if (rc != IG_ERR_UNSUPPORTED) return rc;
+    }
     EpResidual ep{out, resid, bias, (long)N};
     return launch_gemm<PlainLoader, PlainLoader, EpResidual, false, false>(
         plain_a(x_hi, x_lo, M, K, K), plain_b(w_hi, w_lo, N, K, K), ep, M, N, K, 1, x_lo != nullptr, (hipStream_t)stream,

@@ -1,0 +1,400 @@
+// v8: the forward ("NT", both operands K-contiguous) linear GEMM of the timm Block (pritvhi.py:446-456: qkv / proj /
+// fc1 / fc2) and of the patch embedding as a 256 x 256 x 64 "8-phase" ping-pong kernel for gfx950.
+//
+//   C[m][n] = sum_seg sum_k A_seg[m][k] * B_seg[n][k]      A = activations [M][K], B = nn.Linear weight [N][K]
+//
+// * One 512-thread workgroup per CU (8 waves = 2 row groups x 4 column waves), persistent over an XCD-contiguous tile
+//   list.  A wave owns 128 x 64 of the tile: 4 quadrants (h, g) of 64 x 32 = 32 MFMA 16x16x32 accumulators (128 VGPRs).
+// * K-step 64: an operand half-tile is 128 rows x 128 B = 16 KiB and is moved global -> LDS by LDS-DMA in FULL cache
+//   lines (one global_load_lds_dwordx4 = 8 rows x 128 B; BK = 32 moved half lines).  LDS = 2 buffers x {A0 A1 B0 B1}
+//   = 128 KiB + 8 x 4 KiB epilogue staging = 160 KiB.  The image is lane-linear; the bank swizzle (16-byte chunk ^=
+//   row & 7) is applied on the SOURCE address and by the same involution on the fragment reads (conflict-free
+//   ds_read_b128).
+// * The halves interleave over the waves: A half h = tile rows with ((row >> 6) & 1) == h, B half g = tile columns with
+//   ((col >> 5) & 1) == g, so quadrant (h, g) of EVERY wave reads half-tiles (A_h, B_g) and a half-tile is dead for the
+//   whole workgroup as soon as its quadrant phase is over -- it is refilled two phases later (K-tile t+2), four
+//   half-tiles (64 KiB) in flight.  Per K-tile 4 phases:
+//       P1: read B0 A0, MFMA A0xB0 | P2: read B1, MFMA A0xB1 | P3: read A1, MFMA A1xB1 | P4: MFMA A1xB0
+//   a phase = [ds_reads + 2 DMA issues + counted vmcnt] s_barrier [16 MFMAs, s_setprio 1] s_barrier.  The two row
+//   groups run ONE barrier apart, so one group's MFMAs cover the other group's LDS reads and DMA issues.
+//       RAW: a half-tile is read one phase after the counted vmcnt(8) (+ barrier) that retires it;
+//       WAR: a half-tile is re-issued >= 2 phases after its last ds_read.
+// * Epilogue: the groups are re-aligned first (both epilogues run concurrently on the SIMD's two waves), the bias is the
+//   accumulator INIT (no epilogue loads), results go through a wave-private 4 KiB LDS staging slab and leave as
+//   row-contiguous 16-byte stores (8 full 128-byte lines per wave-instruction instead of 16 x 32-byte pieces).
+// * NSEG = 3 runs the split-bf16 (hi*hi + hi*lo + lo*hi) precision mode through the same loop.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int G8_HALF = 16384;    // one half-tile: 128 rows x 64 k
+constexpr int G8_BUF = 65536;     // A0 A1 B0 B1
+constexpr int G8_STAGE = 131072;  // epilogue staging: 8 waves x 4 KiB
+constexpr int G8_SMEM = 163840;
+typedef __attribute__((address_space(3))) char* lds_char_ptr;
+
+// LDS-DMA with a scalar base + 32-bit per-lane offset (the K advance is one scalar add per issue)
+__device__ __forceinline__ void glds16_s(unsigned voff, const void* sbase, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+
+struct Cur {  // issue cursor of one half-tile type (all wave-uniform)
+    const char* base;
+    int kt, seg, tile, vr, left;
+};
+
+template <int KIND, int NSEG, int ACT, bool DACT, bool SPLIT_OUT>
+__global__ __launch_bounds__(512, 2) void gemm8_kernel(G8Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int tiles_n = p.N >> 8, tiles_m = (p.M + 255) >> 8, ntiles = tiles_m * tiles_n;
+    // persistent, XCD-aware: workgroups are dealt round-robin over the 8 XCDs; XCD x owns a contiguous tile range
+    const int nb = gridDim.x, xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int nbx = (nb >> 3) + (xcd < (nb & 7) ? 1 : 0);
+    const int qT = ntiles >> 3, rT = ntiles & 7;
+    const int tlo = xcd * qT + min(xcd, rT), tcnt = qT + (xcd < rT ? 1 : 0);
+    const int my_tiles = tcnt > jx ? (tcnt - jx + nbx - 1) / nbx : 0;
+    if (my_tiles <= 0) return;
+    const int nk = p.K >> 6;         // K-tiles per segment (even: K % 128 == 0)
+    const int per_tile = nk * NSEG;  // K-tiles per output tile
+    const int Gtot = my_tiles * per_tile;
+    const int lda2 = (int)(p.lda * 2), ldb2 = (int)(p.ldb * 2);
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_char_ptr)smem;
+
+    // fragment read offsets inside a half-tile (k-substep 1: ^ 64)
+    const int sw = ((lane >> 4) ^ (lane & 7)) << 4;
+    const int aoff = (wr * 64 + (lane & 15)) * 128 + sw;
+    const int boff = 2 * G8_HALF + (wc * 32 + (lane & 15)) * 128 + sw;
+    // LDS-DMA lane constants: LDS row of instruction i of this wave = wave*16 + i*8 + (lane >> 3)
+    const int rbaseA = (wave >> 2) * 128 + (wave & 3) * 16 + (lane >> 3);  // + h*64 + i*8  -> tile row
+    const int rbaseB = (wave >> 1) * 64 + (wave & 1) * 16 + (lane >> 3);   // + g*32 + i*8  -> tile column
+    const int c16 = ((lane & 7) ^ (lane >> 3)) << 4;
+    const unsigned ldsw = lds_base + wave * 2048;
+
+    Cur cA0, cA1, cB0, cB1;
+#define G8_REBASE(C, ISA)                                                                   \
+    {                                                                                       \
+        const int bm_ = (C).tile / tiles_n, bn_ = (C).tile - bm_ * tiles_n;                 \
+        const int s_ = NSEG == 1 ? 0 : (C).seg;                                             \
+        if (ISA) {                                                                          \
+            const bf16_t* b_ = s_ == 0 ? p.a[0] : s_ == 1 ? p.a[1] : p.a[2];                \
+            (C).base = (const char*)b_ + (long)bm_ * 256 * lda2;                            \
+            (C).vr = min(256, p.M - bm_ * 256);                                             \
+        } else {                                                                            \
+            const bf16_t* b_ = s_ == 0 ? p.b[0] : s_ == 1 ? p.b[1] : p.b[2];                \
+            (C).base = (const char*)b_ + (long)bn_ * 256 * ldb2;                            \
+            (C).vr = 256;                                                                   \
+        }                                                                                   \
+    }
+#define G8_INIT(C, ISA)                                        \
+    {                                                          \
+        (C).kt = 0, (C).seg = 0, (C).tile = tlo + jx, (C).left = Gtot; \
+        G8_REBASE(C, ISA)                                      \
+    }
+    // issue the two wave-instructions of this wave for half-tile (ISA ? A : B, HG) of the cursor's K-tile into buffer BUF
+#define G8_ISSUE(C, ISA, HG, BUF)                                                                              \
+    if ((C).left > 0) {                                                                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                     \
+            int row_ = ((ISA) ? rbaseA + (HG)*64 : rbaseB + (HG)*32) + i_ * 8;                                 \
+            row_ = min(row_, (C).vr - 1);                                                                      \
+            const unsigned voff_ = (unsigned)(__mul24(row_, (ISA) ? lda2 : ldb2) + c16);                       \
+            glds16_s(voff_, (C).base, ldsw + (BUF)*G8_BUF + ((ISA) ? 0 : 2 * G8_HALF) + (HG)*G8_HALF + i_ * 1024); \
+        }                                                                                                      \
+        (C).left--;                                                                                            \
+        (C).base += 128;                                                                                       \
+        if (++(C).kt == nk) {                                                                                  \
+            (C).kt = 0;                                                                                        \
+            if (NSEG == 1 || ++(C).seg == NSEG) {                                                              \
+                (C).seg = 0;                                                                                   \
+                (C).tile += nbx;                                                                               \
+            }                                                                                                  \
+            G8_REBASE(C, ISA)                                                                                  \
+        }                                                                                                      \
+    }
+
+    f32x4 acc[2][2][2][4];  // [h][g][nt][mt]
+    f32x4 binit[2][2];      // accumulator init = bias in MFMA layout (4 consecutive n per lane)
+    int tile_c = tlo + jx;
+#define G8_LOAD_BIAS(TILE)                                                                                       \
+    {                                                                                                            \
+        const int bn_ = (TILE) % tiles_n;                                                                        \
+        _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_) _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_) {   \
+            if (p.bias) {                                                                                        \
+                const float4 b4_ = *reinterpret_cast<const float4*>(p.bias + bn_ * 256 + wc * 64 + g_ * 32 + nt_ * 16 + 4 * (lane >> 4)); \
+                binit[g_][nt_] = f32x4{b4_.x, b4_.y, b4_.z, b4_.w};                                              \
+            } else {                                                                                             \
+                binit[g_][nt_] = f32x4{0.f, 0.f, 0.f, 0.f};                                                      \
+            }                                                                                                    \
+        }                                                                                                        \
+    }
+#define G8_INIT_ACC()                                                                                            \
+    _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_)            \
+        _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_) _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_)  \
+            acc[h_][g_][nt_][mt_] = binit[g_][nt_];
+    G8_LOAD_BIAS(tile_c)
+    G8_INIT_ACC()
+
+    // prologue: K-tile 0 complete + A0, B0 of K-tile 1 (the state the steady-state schedule leaves behind)
+    G8_INIT(cA0, true)
+    G8_INIT(cA1, true)
+    G8_INIT(cB0, false)
+    G8_INIT(cB1, false)
+    G8_ISSUE(cA0, true, 0, 0)
+    G8_ISSUE(cB0, false, 0, 0)
+    G8_ISSUE(cB1, false, 1, 0)
+    G8_ISSUE(cA1, true, 1, 0)
+    G8_ISSUE(cA0, true, 0, 1)
+    G8_ISSUE(cB0, false, 0, 1)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+
+    bf16x8_t af[4][2], bf0[2][2], bf1[2][2];
+#define G8_READ_A(BUF, H)                                                                                          \
+    _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)           \
+        af[mt_][s_] = *reinterpret_cast<const bf16x8_t*>(smem + (BUF)*G8_BUF + (H)*G8_HALF + mt_ * 2048 + (aoff ^ (s_ * 64)));
+#define G8_READ_B(BUF, G, DST)                                                                                     \
+    _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)           \
+        DST[nt_][s_] = *reinterpret_cast<const bf16x8_t*>(smem + (BUF)*G8_BUF + (G)*G8_HALF + nt_ * 2048 + (boff ^ (s_ * 64)));
+#define G8_MFMA(H, G, BSRC)                                                                                        \
+    {                                                                                                              \
+        asm volatile("s_barrier" ::: "memory");                                                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
+        __builtin_amdgcn_s_setprio(1);                                                                             \
+        _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_) _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_)    \
+            _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                       \
+                acc[H][G][nt_][mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BSRC[nt_][s_], af[mt_][s_], acc[H][G][nt_][mt_], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                             \
+        asm volatile("s_barrier" ::: "memory");                                                                    \
+    }
+#define G8_WAIT(LASTCNT)                                                                     \
+    {                                                                                        \
+        if (last) asm volatile("s_waitcnt vmcnt(" #LASTCNT ")" ::: "memory");                \
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                \
+    }
+
+    int it_c = 0;  // iterations (K-tile pairs) done of the current tile
+    const int iters = Gtot >> 1, per_tile2 = per_tile >> 1;
+    bool staggered = false;
+    for (int it = 0; it < iters; ++it) {
+        const bool last = it == iters - 1;
+        if (!staggered) {  // (re-)establish the stagger: group 1 runs one barrier behind group 0
+            if (wr == 1) asm volatile("s_barrier" ::: "memory");
+            staggered = true;
+        }
+        // ---- even K-tile (buffer 0) ----
+        G8_READ_B(0, 0, bf0)
+        G8_READ_A(0, 0)
+        G8_ISSUE(cB1, false, 1, 1)
+        G8_WAIT(8)
+        G8_MFMA(0, 0, bf0)
+        G8_READ_B(0, 1, bf1)
+        G8_ISSUE(cA1, true, 1, 1)
+        G8_WAIT(8)
+        G8_MFMA(0, 1, bf1)
+        G8_READ_A(0, 1)
+        G8_ISSUE(cA0, true, 0, 0)
+        G8_MFMA(1, 1, bf1)
+        G8_ISSUE(cB0, false, 0, 0)
+        G8_WAIT(4)
+        G8_MFMA(1, 0, bf0)
+        // ---- odd K-tile (buffer 1) ----
+        G8_READ_B(1, 0, bf0)
+        G8_READ_A(1, 0)
+        G8_ISSUE(cB1, false, 1, 0)
+        G8_WAIT(2)
+        G8_MFMA(0, 0, bf0)
+        G8_READ_B(1, 1, bf1)
+        G8_ISSUE(cA1, true, 1, 0)
+        G8_WAIT(0)
+        G8_MFMA(0, 1, bf1)
+        G8_READ_A(1, 1)
+        G8_ISSUE(cA0, true, 0, 1)
+        G8_MFMA(1, 1, bf1)
+        G8_ISSUE(cB0, false, 0, 1)
+        G8_WAIT(0)
+        G8_MFMA(1, 0, bf0)
+        if (++it_c < per_tile2) continue;
+        // ================= tile finished: epilogue (the next tile's first K-tiles are in flight) =================
+        it_c = 0;
+        if (wr == 0) asm volatile("s_barrier" ::: "memory");  // re-align the groups: both epilogues run concurrently
+        staggered = false;
+        const int bm = tile_c / tiles_n, bn = tile_c - bm * tiles_n;
+        tile_c += nbx;
+        if (!last) G8_LOAD_BIAS(tile_c)  // next tile's accumulator init: in flight during the epilogue
+        char* st = smem + G8_STAGE + wave * 4096;
+        const int erow = lane & 15, eq = lane >> 4;
+        const int n0 = bn * 256 + wc * 64;
+        if constexpr (KIND == 0) {
+            // bf16 (split) store of act(acc): two 2 KiB staging slots (16 rows x 64 bf16, chunk ^= row & 7)
+            const int rrow = lane >> 3, rch = ((lane & 7) ^ (lane >> 3)) << 4, rcol = (lane & 7) * 8;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int m0 = bm * 256 + wr * 128 + h * 64 + mt * 16;
+                    uint2 po[2][2], pd[2][2], pol[2][2], pdl[2][2];
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const f32x4 a = acc[h][g][nt][mt];
+                            float v[4] = {a[0], a[1], a[2], a[3]}, d[4] = {0.f, 0.f, 0.f, 0.f};
+                            if constexpr (ACT == 1) {
+                                f32x2 g0, g1, d0, d1;
+                                gelu_erf_pair<DACT>(f32x2{v[0], v[1]}, g0, d0);
+                                gelu_erf_pair<DACT>(f32x2{v[2], v[3]}, g1, d1);
+                                v[0] = g0.x, v[1] = g0.y, v[2] = g1.x, v[3] = g1.y;
+                                if constexpr (DACT) d[0] = d0.x, d[1] = d0.y, d[2] = d1.x, d[3] = d1.y;
+                            }
+                            po[g][nt].x = pack_bf2(v[0], v[1]), po[g][nt].y = pack_bf2(v[2], v[3]);
+                            if constexpr (SPLIT_OUT) {
+                                pol[g][nt].x = pack_bf2(v[0] - __uint_as_float(po[g][nt].x << 16), v[1] - __uint_as_float(po[g][nt].x & 0xffff0000u));
+                                pol[g][nt].y = pack_bf2(v[2] - __uint_as_float(po[g][nt].y << 16), v[3] - __uint_as_float(po[g][nt].y & 0xffff0000u));
+                            }
+                            if constexpr (DACT) {
+                                pd[g][nt].x = pack_bf2(d[0], d[1]), pd[g][nt].y = pack_bf2(d[2], d[3]);
+                                if constexpr (SPLIT_OUT) {
+                                    pdl[g][nt].x = pack_bf2(d[0] - __uint_as_float(pd[g][nt].x << 16), d[1] - __uint_as_float(pd[g][nt].x & 0xffff0000u));
+                                    pdl[g][nt].y = pack_bf2(d[2] - __uint_as_float(pd[g][nt].y << 16), d[3] - __uint_as_float(pd[g][nt].y & 0xffff0000u));
+                                }
+                            }
+                        }
+                        // one pass = two staged arrays (X -> slot 0, Y -> slot 1) written in MFMA layout, read back row-contiguous
+#define G8_STAGE_PASS(PX, PY, HAVE_Y, DSTX, DSTY)                                                                      \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int g = 0; g < 2; ++g) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {               \
+            const int chunk_ = g * 4 + nt * 2 + (eq >> 1);                                                             \
+            const int off_ = erow * 128 + ((chunk_ ^ (erow & 7)) << 4) + (eq & 1) * 8;                                 \
+            *reinterpret_cast<uint2*>(st + off_) = PX[g][nt];                                                          \
+            if (HAVE_Y) *reinterpret_cast<uint2*>(st + 2048 + off_) = PY[g][nt];                                       \
+        }                                                                                                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                             \
+            const int r_ = i_ * 8 + rrow;                                                                              \
+            const uint4 ux_ = *reinterpret_cast<const uint4*>(st + r_ * 128 + rch);                                    \
+            uint4 uy_ = ux_;                                                                                           \
+            if (HAVE_Y) uy_ = *reinterpret_cast<const uint4*>(st + 2048 + r_ * 128 + rch);                             \
+            const int m_ = m0 + r_;                                                                                    \
+            if (m_ < p.M) {                                                                                            \
+                const size_t o_ = (size_t)m_ * p.ldo + n0 + rcol;                                                      \
+                *reinterpret_cast<uint4*>((DSTX) + o_) = ux_;                                                          \
+                if (HAVE_Y) *reinterpret_cast<uint4*>((DSTY) + o_) = uy_;                                              \
+            }                                                                                                          \
+        }                                                                                                              \
+    }
+                    if constexpr (SPLIT_OUT) {
+                        G8_STAGE_PASS(po, pol, true, p.out_hi, p.out_lo)
+                        if constexpr (DACT) G8_STAGE_PASS(pd, pdl, true, p.dact_hi, p.dact_lo)
+                    } else if constexpr (DACT) {
+                        G8_STAGE_PASS(po, pd, true, p.out_hi, p.dact_hi)
+                    } else {
+                        G8_STAGE_PASS(po, po, false, p.out_hi, p.out_hi)
+                    }
+#undef G8_STAGE_PASS
+                }
+        } else {
+            // fp32 residual: out = resid + acc (bias is in the accumulator init); 16 rows x 64 fp32 = 4 KiB staged
+            const int rrow = lane >> 4, rc = lane & 15;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int m0 = bm * 256 + wr * 128 + h * 64 + mt * 16;
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const int c4 = g * 8 + nt * 4 + eq;
+                            *reinterpret_cast<f32x4*>(st + erow * 256 + ((c4 ^ (erow & 7)) << 4)) = acc[h][g][nt][mt];
+                        }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = i * 4 + rrow;
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(st + r * 256 + ((rc ^ (r & 7)) << 4));
+                        const int m = m0 + r;
+                        if (m < p.M) {
+                            const size_t o = (size_t)m * p.ldo + n0 + rc * 4;
+                            const float4 rs = *reinterpret_cast<const float4*>(p.resid + o);
+                            *reinterpret_cast<float4*>(p.outf + o) = make_float4(rs.x + a[0], rs.y + a[1], rs.z + a[2], rs.w + a[3]);
+                        }
+                    }
+                }
+        }
+        G8_INIT_ACC()
+    }
+    if (staggered && wr == 0) asm volatile("s_barrier" ::: "memory");  // (unreachable in practice: every tile ends re-aligned)
+#undef G8_WAIT
+#undef G8_MFMA
+#undef G8_READ_A
+#undef G8_READ_B
+#undef G8_ISSUE
+#undef G8_INIT
+#undef G8_REBASE
+#undef G8_LOAD_BIAS
+#undef G8_INIT_ACC
+}
+
+// IG_GEMM8: 0 = off, 1 = default (shapes with enough tiles), 2 = every covered shape.  Read per call (tests and A/B benches flip it).
+inline int g8_env() {
+    const char* e = getenv("IG_GEMM8");
+    return e ? atoi(e) : 1;
+}
+
+template <int KIND, int NSEG, int ACT, bool DACT, bool SPLIT_OUT>
+int g8_launch(const G8Params& p, int grid, hipStream_t st) {
+    auto kern = gemm8_kernel<KIND, NSEG, ACT, DACT, SPLIT_OUT>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G8_SMEM) != hipSuccess) {
+            ig_set_error("gemm8: could not reserve %d bytes of LDS", G8_SMEM);
+            return IG_ERR_HIP;
+        }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), G8_SMEM, st, p);
+    return ig_check_launch("gemm8");
+}
+
+}  // namespace
+
+// IG_ERR_UNSUPPORTED (no error string) when the shape is not covered: the caller falls back to the generic engines.
+int ig_gemm8_nt(const G8Params& p, void* stream) {
+    if (!g8_env()) return IG_ERR_UNSUPPORTED;
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0) return IG_ERR_UNSUPPORTED;
+    if ((p.K & 127) || (p.N & 255)) return IG_ERR_UNSUPPORTED;
+    if (p.lda * 2 * 256 >= (1L << 24) || p.ldb * 2 * 256 >= (1L << 24)) return IG_ERR_UNSUPPORTED;  // 24-bit offset multiply
+    const int ntiles = ((p.M + 255) >> 8) * (p.N >> 8);
+    const int min_tiles = getenv("IG_GEMM8_MIN_TILES") ? atoi(getenv("IG_GEMM8_MIN_TILES")) : 192;
+    if (ntiles < min_tiles && g8_env() != 2) return IG_ERR_UNSUPPORTED;  // small problems: the 256 x 256 tile leaves CUs idle
+    int grid = ig_cu_count() - ig_reserved_cus();
+    if (grid < 8) grid = 8;
+    if (grid > ntiles) grid = ntiles;
+    hipStream_t st = (hipStream_t)stream;
+    const bool split_in = p.nseg == 3;
+    if (p.kind == 0) {
+        const bool split_out = p.out_lo != nullptr;
+        const bool dact = p.dact_hi != nullptr;
+        if (split_in != split_out) return IG_ERR_UNSUPPORTED;
+        if (p.act == 0 && dact) return IG_ERR_UNSUPPORTED;
+        if (!split_in) {
+            if (p.act == 0) return g8_launch<0, 1, 0, false, false>(p, grid, st);
+            if (!dact) return g8_launch<0, 1, 1, false, false>(p, grid, st);
+            return g8_launch<0, 1, 1, true, false>(p, grid, st);
+        }
+        if (p.act == 0) return g8_launch<0, 3, 0, false, true>(p, grid, st);
+        if (!dact) return g8_launch<0, 3, 1, false, true>(p, grid, st);
+        return g8_launch<0, 3, 1, true, true>(p, grid, st);
+    }
+    if (p.kind == 1) {
+        if (!split_in) return g8_launch<1, 1, 0, false, false>(p, grid, st);
+        return g8_launch<1, 3, 0, false, false>(p, grid, st);
+    }
+    return IG_ERR_UNSUPPORTED;
+}

@@ -1,6 +1,7 @@
 // Error reporting, launch checks and device queries for the C-ABI library.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -23,7 +24,36 @@ int ig_check_launch(const char* what) {
     return IG_OK;
 }
 
+// Compute units left free by the persistent (one workgroup per CU) kernels.  With data parallelism RCCL's all-reduce kernels
+// are launched on a side stream while the backward GEMMs run; a grid that pins every CU makes them wait for a whole kernel.
+static int g_reserved_cus = -1;
+int ig_reserved_cus() {
+    if (g_reserved_cus < 0) {
+        const char* e = getenv("IG_RESERVED_CUS");
+        g_reserved_cus = e ? atoi(e) : 0;
+        if (g_reserved_cus < 0) g_reserved_cus = 0;
+    }
+    return g_reserved_cus;
+}
+int ig_cu_count() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        else cus = 256;
+    }
+    return cus;
+}
+
 extern "C" {
+
+int ig_set_reserved_cus(int n) {
+    IG_REQUIRE(n >= 0 && n < 128, "ig_set_reserved_cus: n must be in [0, 128) (got %d)", n);
+    g_reserved_cus = n;
+    return IG_OK;
+}
+int ig_get_reserved_cus(void) { return ig_reserved_cus(); }
 
 const char* ig_last_error(void) { return g_err; }
 

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""A/B of the forward linear GEMM engines in ONE process (interleaved rounds, random data, HIP events):
+IG_GEMM8=0 (gemm2 / gemm5) vs IG_GEMM8=1 (gemm8.hip).  Usage: python tools/gemm8_bench.py [M] [--x3]"""
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "instageo-e2e-geospatial-ml_amd"))
+import torch
+
+from instageo_amd import ops
+from instageo_amd.ops import BT
+
+dev = "cuda"
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+M = int(args[0]) if args else 108 * 197
+D = int(args[1]) if len(args) > 1 else 768
+split = "--x3" in sys.argv
+
+
+def timeit(fn, n=20):
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3  # us
+
+
+def rnd(*s):
+    return BT.from_float(torch.randn(*s, device=dev), split)
+
+
+cases = []
+x = rnd(M, D)
+x4 = rnd(M, 4 * D)
+for name, N, K, kind in [("qkv", 3 * D, D, "plain"), ("fc1 (gelu, infer)", 4 * D, D, "gelu"), ("fc1 (gelu + gelu', train)", 4 * D, D, "gelu_train"),
+                         ("proj (+resid)", D, D, "resid"), ("fc2 (+resid)", D, 4 * D, "resid")]:
+    w = BT.from_float(torch.randn(N, K, device=dev) * K**-0.5, split)
+    bias = torch.randn(N, device=dev)
+    xin = x4 if K == 4 * D else x
+    if kind == "resid":
+        res = torch.randn(M, N, device=dev)
+        out = torch.empty_like(res)
+        fn = (lambda xin=xin, w=w, bias=bias, res=res, out=out, N=N, K=K: ops.linear_residual_fwd(xin, w, bias, res, out, M, N, K))
+    else:
+        y = BT.empty((M, N), split, dev)
+        pre = BT.empty((M, N), split, dev) if kind == "gelu_train" else None
+        act = 0 if kind == "plain" else 1
+        fn = (lambda xin=xin, w=w, bias=bias, y=y, pre=pre, act=act, N=N, K=K: ops.linear_fwd(xin, w, bias, y, M, N, K, act=act, pre=pre))
+    cases.append((name, N, K, fn))
+
+print(f"M={M} D={D} mode={'bf16x3' if split else 'bf16'}")
+for name, N, K, fn in cases:
+    res = {"0": [], "1": []}
+    for rnd_i in range(5):
+        for eng in ("0", "1"):
+            os.environ["IG_GEMM8"] = eng
+            if rnd_i == 0:
+                for _ in range(3):
+                    fn()
+            res[eng].append(timeit(fn))
+    fl = 2.0 * M * N * K * (3 if split else 1)
+    t0, t1 = statistics.median(res["0"]), statistics.median(res["1"])
+    print(f"{name:28s} N={N:5d} K={K:5d}: old {t0:7.1f} us ({fl/t0/1e6:6.0f} TF/s mfma-level)   v8 {t1:7.1f} us ({fl/t1/1e6:6.0f} TF/s)   min {min(res['0']):.1f} / {min(res['1']):.1f}")
