@@ -28,6 +28,9 @@ extern "C" {
 
 /* ---- runtime ---------------------------------------------------------------------------------------- */
 const char* ig_last_error(void);
+/* name of the (last) kernel the most recent MFMA entry point of this thread launched, as rocprofv3 prints it minus
+ * "(anonymous namespace)::" and blanks -- bench.py keys its per-kernel roofline table by it */
+const char* ig_last_kernel(void);
 int ig_version(void);
 /* first 32 bits of the MD5 of this header as the library was built against it: the host mirror refuses a library whose
  * entry points were compiled from a different revision of the declarations (stale .so next to a newer header) */
@@ -82,6 +85,15 @@ int ig_linear_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, cons
                     const void* dact_hi, const void* dact_lo, float* dx_colsum, int M, int N, int K, int mode, void* stream);
 int ig_linear_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const void* x_lo, float* dw, int M, int N, int K,
                     void* stream);
+/* ig_linear_dgrad with the weight handed over TRANSPOSED (wt [K][N] = w^T, see ig_transpose_bf16): same result, but both
+ * operands are contiguous in the reduce dimension, the form of the forward linears (dx = dy @ w is autograd's grad_input of
+ * F.linear, pritvhi.py:446-456) */
+int ig_linear_dgrad_wt(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, void* dx_hi, void* dx_lo,
+                       const void* dact_hi, const void* dact_lo, float* dx_colsum, int M, int N, int K, int mode, void* stream);
+/* dst[b][c][r] = src[b][r][c] for b < batch: bf16 matrix transposes (R, C multiples of 64; strides in elements).  The engine
+ * keeps a transposed operand copy of the Block linears' weights next to the bf16 shadow and refreshes it once per step. */
+int ig_transpose_bf16(const void* src_hi, const void* src_lo, void* dst_hi, void* dst_lo, int R, int C, int batch, long src_stride,
+                      long dst_stride, void* stream);
 /* F.scaled_dot_product_attention of timm Attention: qkv [B][N][3][H][64] -> out [B][N][H*64], lse [B][H][N] */
 int ig_attention_fwd(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, float* lse, int B, int N, int H,
                      int head_dim, void* stream);

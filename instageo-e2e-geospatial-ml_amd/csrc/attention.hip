@@ -502,10 +502,13 @@ int ig_attention_fwd(const void* qkv_hi, const void* qkv_lo, void* out_hi, void*
     dim3 grid(nblk, H, B), block(nw * 64);
     float scale = 1.0f / sqrtf((float)head_dim);
 #define IG_ATTN_FWD(SPLIT_, NTL_, MAXT_)                                                                                     \
-    hipLaunchKernelGGL((attn_fwd_kernel<SPLIT_, NTL_, MAXT_>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)qkv_hi,       \
-                       (const bf16_t*)qkv_lo, (bf16_t*)out_hi, (bf16_t*)out_lo, lse, N, H, scale)
-    if (qkv_lo) IG_ATTN_FWD(true, 2, 1024);
-    else IG_ATTN_FWD(false, 4, 1024);
+    {                                                                                                                         \
+        ig_note_kernel("attn_fwd_kernel<%s,%d,%d>", SPLIT_ ? "true" : "false", NTL_, MAXT_);                                      \
+        hipLaunchKernelGGL((attn_fwd_kernel<SPLIT_, NTL_, MAXT_>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)qkv_hi,   \
+                           (const bf16_t*)qkv_lo, (bf16_t*)out_hi, (bf16_t*)out_lo, lse, N, H, scale);                        \
+    }
+    if (qkv_lo) IG_ATTN_FWD(true, 2, 1024)
+    else IG_ATTN_FWD(false, 4, 1024)
 #undef IG_ATTN_FWD
     return ig_check_launch("ig_attention_fwd");
 }
@@ -532,6 +535,7 @@ int ig_attention_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi,
                            (const bf16_t*)qkv_lo, (const bf16_t*)dout_hi, (const bf16_t*)dout_lo, (const bf16_t*)out_hi,          \
                            (const bf16_t*)out_lo, lse, delta, (bf16_t*)dqkv_hi,                                                   \
                            (bf16_t*)dqkv_lo, N, H, scale);                                                                    \
+        ig_note_kernel("attn_bwd_dq_kernel<%s,%d,%d>+attn_bwd_dkv_kernel<%s,%d,%d>", SPLIT_ ? "true" : "false", NTL_, MAXT_, SPLIT_ ? "true" : "false", NTL_, MAXT_); \
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<SPLIT_, NTL_, MAXT_>), grid, block, 0, st, (const bf16_t*)qkv_hi,                 \
                            (const bf16_t*)qkv_lo, (const bf16_t*)dout_hi, (const bf16_t*)dout_lo, lse, delta, (bf16_t*)dqkv_hi,  \
                            (bf16_t*)dqkv_lo, N, H, scale);                                                                    \

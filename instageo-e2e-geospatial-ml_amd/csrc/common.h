@@ -36,7 +36,8 @@ int ig_conv3x3_wgrad_direct(const void* dy, const void* x, float* dw, float* dbi
                             int Cout, void* stream);
 
 // gemm8.hip: the 256 x 256 x 64 8-phase engine for the K-contiguous ("NT") linear GEMMs.  kind 0: bf16 (split) store of
-// act(acc + bias) [+ gelu' copy]; kind 1: fp32 out = resid + acc + bias.  a / b: segment pointer sets (nseg 1 or 3).
+// act(acc + bias) [+ gelu' copy]; kind 1: fp32 out = resid + acc + bias; kind 2: bf16 (split) store of acc * dact (dact_hi /
+// dact_lo are INPUTS here) with optional fused column sums.  a / b: segment pointer sets (nseg 1 or 3).
 struct G8Params {
     const bf16_t* a[3];
     const bf16_t* b[3];
@@ -47,9 +48,13 @@ struct G8Params {
     bf16_t *out_hi, *out_lo, *dact_hi, *dact_lo;
     float* outf;
     const float* resid;
+    float* colsum;
 };
 int ig_gemm8_nt(const G8Params& p, void* stream);  // IG_ERR_UNSUPPORTED (no error string) when the shape is not covered
 // runtime.hip: compute units the persistent kernels leave free (for RCCL's kernels when world > 1); ig_set_reserved_cus()
+// runtime.hip: name of the kernel an entry point launched last on this thread (rocprofv3's demangled name without namespaces and
+// spaces), so bench.py can key its per-kernel roofline table by the names the rocprof summaries under profiles/ use
+void ig_note_kernel(const char* fmt, ...);
 int ig_reserved_cus();
 int ig_cu_count();
 

@@ -287,6 +287,7 @@ int launch_direct(const CDParams& p, hipStream_t st, const char* what) {
     static const int nwg_env = getenv("IG_CONV_DIRECT_WGS") ? atoi(getenv("IG_CONV_DIRECT_WGS")) : 0;
     long nwg = nwg_env > 0 ? nwg_env : 512;  // two persistent workgroups per CU
     if (nwg > p.ntiles) nwg = p.ntiles;
+    ig_note_kernel("conv3x3_direct_kernel<%d>", C);
     hipLaunchKernelGGL(conv3x3_direct_kernel<C>, dim3((unsigned)nwg), dim3(CD_TPB), G::SMEM, st, p);
     return ig_check_launch(what);
 }
@@ -1605,6 +1606,7 @@ int ig_conv3x3_direct(const void* x, const void* w, const float* bias, const flo
             attr96 = true;
         }
         const long nwg = p.ntiles < 128 ? p.ntiles : 128;
+        ig_note_kernel("conv3x3_direct_slice_kernel<96>");
         hipLaunchKernelGGL(conv3x3_direct_slice_kernel<96>, dim3((unsigned)nwg, 2), dim3(576), smem96, (hipStream_t)stream, p, zp);
         return ig_check_launch(dgrad ? "ig_conv3x3_dgrad(direct, slices)" : "ig_conv3x3_fwd(direct, slices)");
     }
@@ -1624,6 +1626,7 @@ static int launch_wgrad_direct(const CWParams& p, int nslices, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_direct_kernel<CIN, NWAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_done = true;
     }
+    ig_note_kernel("conv3x3_wgrad_direct_kernel<%d,%d>", CIN, NWAVES);
     hipLaunchKernelGGL((conv3x3_wgrad_direct_kernel<CIN, NWAVES>), dim3((unsigned)nwg, nslices), dim3(64 * NWAVES), smem, st, p);
     return ig_check_launch("ig_conv3x3_wgrad(direct)");
 }
@@ -1668,6 +1671,7 @@ int ig_conv3x3_wgrad_direct(const void* dy, const void* x, float* dw, float* dbi
     long nwg = 256 / nslices;
     if (nwg > p.ntiles) nwg = p.ntiles;
     const dim3 grid((unsigned)nwg, nslices);
+    ig_note_kernel("conv3x3_wgrad_dma_kernel<%d,%d>", Cin, Cin == 48 ? rows : Cin == 96 ? 8 : 4);
     if (Cin == 48 && rows == 12) hipLaunchKernelGGL((conv3x3_wgrad_dma_kernel<48, 12>), grid, dim3(512), smem48b, (hipStream_t)stream, p, zp);
     else if (Cin == 48) hipLaunchKernelGGL((conv3x3_wgrad_dma_kernel<48, 8>), grid, dim3(512), smem48, (hipStream_t)stream, p, zp);
     else if (Cin == 96) hipLaunchKernelGGL((conv3x3_wgrad_dma_kernel<96, 8>), grid, dim3(512), smem96, (hipStream_t)stream, p, zp);
@@ -1706,6 +1710,7 @@ int ig_convT_fwd_direct(const void* x, const void* w, const float* bias, void* y
             attr_d = true;
         }
         const long nwg_d = p.ntiles < 256 ? p.ntiles : 256;
+        ig_note_kernel("convT_direct_dma_kernel<96,48>");
         hipLaunchKernelGGL((convT_direct_dma_kernel<96, 48>), dim3((unsigned)nwg_d), dim3(576), smem_d, (hipStream_t)stream, p, zp);
         return ig_check_launch("ig_convT_fwd(direct, dma)");
     }
@@ -1716,6 +1721,7 @@ int ig_convT_fwd_direct(const void* x, const void* w, const float* bias, void* y
         (void)hipFuncSetAttribute((const void*)convT_direct_kernel<96, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_done = true;
     }
+    ig_note_kernel("convT_direct_kernel<96,48>");
     hipLaunchKernelGGL((convT_direct_kernel<96, 48>), dim3((unsigned)nwg), dim3(CT_TPB), smem, (hipStream_t)stream, p);
     return ig_check_launch("ig_convT_fwd(direct)");
 }
@@ -1750,6 +1756,7 @@ int ig_convT_wgrad_direct(const void* dy, const void* x, float* dw, float* dbias
             (void)hipFuncSetAttribute((const void*)convT_wgrad_dma_kernel<96, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
             attr_done = true;
         }
+        ig_note_kernel("convT_wgrad_dma_kernel<96,48>");
         hipLaunchKernelGGL((convT_wgrad_dma_kernel<96, 48>), dim3((unsigned)nwg), dim3(TW_TPB), smem, (hipStream_t)stream, p, zp);
         return ig_check_launch("ig_convT_wgrad(direct, dma)");
     }
@@ -1759,6 +1766,7 @@ int ig_convT_wgrad_direct(const void* dy, const void* x, float* dw, float* dbias
         (void)hipFuncSetAttribute((const void*)convT_wgrad_direct_kernel<96, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_done = true;
     }
+    ig_note_kernel("convT_wgrad_direct_kernel<96,48>");
     hipLaunchKernelGGL((convT_wgrad_direct_kernel<96, 48>), dim3((unsigned)nwg), dim3(TW_TPB), smem, (hipStream_t)stream, p);
     return ig_check_launch("ig_convT_wgrad(direct)");
 }
@@ -1787,6 +1795,7 @@ int ig_convT_dgrad_direct(const void* dy, const void* w, void* dx, int B, int H,
         attr_done = true;
     }
     const long nwg = p.ntiles < 256 ? p.ntiles : 256;
+    ig_note_kernel("convT_dgrad_direct_kernel<96,48>");
     hipLaunchKernelGGL((convT_dgrad_direct_kernel<96, 48>), dim3((unsigned)nwg), dim3(576), smem, (hipStream_t)stream, p, zp);
     return ig_check_launch("ig_convT_dgrad(direct)");
 }

@@ -922,6 +922,39 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     }
 }
 
+// dst[b][c][r] = src[b][r][c], bf16, 64 x 64 tiles through LDS (16-byte global loads and stores on both sides).  Used once per
+// optimizer step on the Block linears' weights: the transposed copy makes their data gradients K-contiguous GEMMs (gemm8.hip).
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int R, int C,
+                                                             long src_stride, long dst_stride) {
+    __shared__ bf16_t tile[64][66];
+    const int t = threadIdx.x;
+    const long b = blockIdx.z;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const bf16_t* s = src + b * src_stride;
+    bf16_t* d = dst + b * dst_stride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (t >> 3) + i * 32, ch = t & 7;
+        const uint4 u = *reinterpret_cast<const uint4*>(s + (long)(r0 + r) * C + c0 + ch * 8);
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tile[r][ch * 8 + 2 * j] = (bf16_t)(w[j] & 0xffffu);
+            tile[r][ch * 8 + 2 * j + 1] = (bf16_t)(w[j] >> 16);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = (t >> 3) + i * 32, ch = t & 7;  // output row = source column c, output columns = source rows ch*8 ..
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = (uint32_t)tile[ch * 8 + 2 * j][c] | ((uint32_t)tile[ch * 8 + 2 * j + 1][c] << 16);
+        *reinterpret_cast<uint4*>(d + (long)(c0 + c) * R + r0 + ch * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+
 }  // namespace
 
 #define ST(s) ((hipStream_t)(s))
@@ -1093,6 +1126,23 @@ int ig_split_bf16(const float* src, void* hi, void* lo, long n, void* stream) {
     if (n == 0) return IG_OK;
     hipLaunchKernelGGL(split_kernel, dim3(grid_for(n, TPB, 16384)), dim3(TPB), 0, ST(stream), src, (bf16_t*)hi, (bf16_t*)lo, n);
     return ig_check_launch("ig_split_bf16");
+}
+
+int ig_transpose_bf16(const void* src_hi, const void* src_lo, void* dst_hi, void* dst_lo, int R, int C, int batch, long src_stride,
+                      long dst_stride, void* stream) {
+    IG_REQUIRE(src_hi && dst_hi, "ig_transpose_bf16: null pointer");
+    IG_REQUIRE((src_lo == nullptr) == (dst_lo == nullptr), "ig_transpose_bf16: source and destination must both be split or both plain");
+    IG_REQUIRE(R > 0 && C > 0 && R % 64 == 0 && C % 64 == 0, "ig_transpose_bf16: R and C must be multiples of 64 (got %d, %d)", R, C);
+    IG_REQUIRE(batch >= 1 && batch <= 65535, "ig_transpose_bf16: 1 <= batch <= 65535");
+    IG_REQUIRE((((uintptr_t)src_hi | (uintptr_t)dst_hi | (uintptr_t)src_lo | (uintptr_t)dst_lo) & 15) == 0 && src_stride % 8 == 0 &&
+                   dst_stride % 8 == 0, "ig_transpose_bf16: pointers and strides must be 16-byte aligned");
+    const dim3 grid(C / 64, R / 64, batch);
+    hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src_hi, (bf16_t*)dst_hi, R, C, src_stride,
+                       dst_stride);
+    if (src_lo)
+        hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src_lo, (bf16_t*)dst_lo, R, C,
+                           src_stride, dst_stride);
+    return ig_check_launch("ig_transpose_bf16");
 }
 
 int ig_merge_bf16(const void* hi, const void* lo, float* dst, long n, void* stream) {

@@ -888,7 +888,11 @@ static inline FDiv make_fdiv(int d) {
 }
 
 // ------------------------------------------------------------------------------------ loaders
-struct PlainLoader {  // row-major [R][ld], logical width C (multiple of 8)
+// segment base pointer by compare/select: a dynamically indexed base[seg] of a by-value loader that init() has modified
+// lives in scratch memory (the split-precision ConvTranspose kernels carried 96-240 bytes of scratch per lane for it)
+__device__ __forceinline__ const bf16_t* bsel(const bf16_t* const (&b)[3], int seg) { return seg == 0 ? b[0] : seg == 1 ? b[1] : b[2]; }
+struct PlainLoader {
+    static constexpr const char* kName = "PlainLoader";  // row-major [R][ld], logical width C (multiple of 8)
     static constexpr bool kLinearK = true;  // ptr() is affine in the K index (v2 steps piece pointers instead of re-decoding)
     const bf16_t* base[3];
     int R, C;
@@ -899,7 +903,7 @@ struct PlainLoader {  // row-major [R][ld], logical width C (multiple of 8)
     __device__ const bf16_t* ptr(int seg, int r, int c8, bool& ok) const {
         int c = c8 * 8;
         ok = (r < R) & (c < C);
-        return base[seg] + (ok ? (long)r * ld + c : 0L);
+        return bsel(base, seg) + (ok ? (long)r * ld + c : 0L);
     }
     struct Row { long off; bool ok; };
     struct Col { int c; bool ok; };
@@ -907,18 +911,19 @@ struct PlainLoader {  // row-major [R][ld], logical width C (multiple of 8)
     __device__ Col col(int c8) const { return Col{c8 * 8, c8 * 8 < C}; }
     __device__ const bf16_t* at(int seg, const Row& rw, const Col& cl, bool& ok) const {
         ok = rw.ok & cl.ok;
-        return base[seg] + (ok ? rw.off + cl.c : 0L);
+        return bsel(base, seg) + (ok ? rw.off + cl.c : 0L);
     }
     // TR operand: k-row r, hoisted column decode
     __device__ const bf16_t* ptr_tr(int seg, int r, const Col& cl, bool& ok) const {
         ok = (r < R) & cl.ok;
-        return base[seg] + (ok ? (long)r * ld + cl.c : 0L);
+        return bsel(base, seg) + (ok ? (long)r * ld + cl.c : 0L);
     }
 };
 
 // NHWC 3x3 pad-1 gather: row r = pixel (b,y,x), column unit -> (tap, channel).  sign=+1 reads
 // (y+ky-1, x+kx-1) (conv forward / wgrad input side), sign=-1 reads (y+1-ky, x+1-kx) (dgrad).
 struct Conv3Loader {
+    static constexpr const char* kName = "Conv3Loader";
     static constexpr bool kLinearK = false;
     __device__ long kstride() const { return 0; }
     const bf16_t* base[3];
@@ -960,14 +965,14 @@ struct Conv3Loader {
     }
     __device__ const bf16_t* at(int seg, const Row& rw, const Col& cl, bool& ok) const {
         ok = cl.ok & ((rw.mask >> cl.tap) & 1u);
-        return base[seg] + (ok ? rw.off + cl.delta : 0L);
+        return bsel(base, seg) + (ok ? rw.off + cl.delta : 0L);
     }
     // TR operand (weight gradient): k-row = pixel r (changes every K-step), column decode hoisted
     __device__ const bf16_t* ptr_tr(int seg, int r, const Col& cl, bool& ok) const {
         int y, x;
         pixel(r, y, x);
         ok = cl.ok & (r < Mtot) & ((unsigned)(y + cl.dy) < (unsigned)H) & ((unsigned)(x + cl.dx) < (unsigned)W);
-        return base[seg] + (ok ? (long)r * C + cl.delta : 0L);
+        return bsel(base, seg) + (ok ? (long)r * C + cl.delta : 0L);
     }
     __device__ const bf16_t* ptr(int seg, int r, int c8, bool& ok) const { return ptr_tr(seg, r, col(c8), ok); }
 };
@@ -975,6 +980,7 @@ struct Conv3Loader {
 // ConvTranspose2d(k3,s2,p1,op1) forward, sub-pixel phase z=(py,px): output (2iy+py, 2ix+px) reads taps
 // ky in {1} (py=0) or {0,2} (py=1); tap ky==0 reads input row iy+1, otherwise iy (same for x).
 struct ConvTFwdALoader {
+    static constexpr const char* kName = "ConvTFwdALoader";
     static constexpr bool kLinearK = false;
     __device__ long kstride() const { return 0; }
     const bf16_t* base[3];
@@ -1008,13 +1014,14 @@ struct ConvTFwdALoader {
     }
     __device__ const bf16_t* at(int seg, const Row& rw, const Col& cl, bool& ok) const {
         ok = cl.ok & ((rw.mask >> cl.idx) & 1u);
-        return base[seg] + (ok ? rw.off + cl.delta : 0L);
+        return bsel(base, seg) + (ok ? rw.off + cl.delta : 0L);
     }
     __device__ const bf16_t* ptr_tr(int seg, int r, const Col& cl, bool& ok) const { return at(seg, row(r), cl, ok); }
     __device__ const bf16_t* ptr(int seg, int r, int c8, bool& ok) const { return at(seg, row(r), col(c8), ok); }
 };
 // matching weight view: n = co, k = (local tap, ci) of storage Wc[co][tap][ci]
 struct ConvTFwdBLoader {
+    static constexpr const char* kName = "ConvTFwdBLoader";
     static constexpr bool kLinearK = false;
     __device__ long kstride() const { return 0; }
     const bf16_t* base[3];
@@ -1036,7 +1043,7 @@ struct ConvTFwdBLoader {
         int tyi = tl >> (nkx - 1), txi = tl - tyi * nkx;  // nkx is 1 or 2
         int tap = (ky0 + 2 * tyi) * 3 + (kx0 + 2 * txi);
         ok = (r < Cout) & (k < K);
-        return base[seg] + (ok ? ((long)r * 9 + tap) * C + c : 0L);
+        return bsel(base, seg) + (ok ? ((long)r * 9 + tap) * C + c : 0L);
     }
     // (row, column) decode split: the K loop re-uses a row decode across K-steps and a column decode across rows
     struct Row { int r; };
@@ -1049,6 +1056,7 @@ struct ConvTFwdBLoader {
 
 // dgrad weight view (TR operand): reduce row = (tap, co), contiguous columns = ci of Wc[co][tap][ci]
 struct ConvWgtTRLoader {
+    static constexpr const char* kName = "ConvWgtTRLoader";
     static constexpr bool kLinearK = false;
     __device__ long kstride() const { return 0; }
     const bf16_t* base[3];
@@ -1061,7 +1069,7 @@ struct ConvWgtTRLoader {
         int c = c8 * 8;
         int tap = f_co.div(r), co = r - tap * Cout;
         ok = (tap < 9) & (c < Cin);
-        return base[seg] + (ok ? ((long)co * 9 + tap) * Cin + c : 0L);
+        return bsel(base, seg) + (ok ? ((long)co * 9 + tap) * Cin + c : 0L);
     }
     // (row, column) decode split: the K loop re-uses a row decode across K-steps and a column decode across rows
     struct Row { int r; };
@@ -1075,6 +1083,7 @@ struct ConvWgtTRLoader {
 // ConvTranspose dgrad A: row = input pixel (b,iy,ix), k = (tap, co): reads dOut(2iy-1+ky, 2ix-1+kx).
 // With fixed_tap >= 0 (wgrad, TR operand) the column unit is co only and the tap comes from init(z).
 struct ConvTGradLoader {
+    static constexpr const char* kName = "ConvTGradLoader";
     static constexpr bool kLinearK = false;
     __device__ long kstride() const { return 0; }
     const bf16_t* base[3];
@@ -1116,13 +1125,13 @@ struct ConvTGradLoader {
     }
     __device__ const bf16_t* at(int seg, const Row& rw, const Col& cl, bool& ok) const {
         ok = cl.ok & ((rw.mask >> cl.tap) & 1u);
-        return base[seg] + (ok ? rw.off + cl.delta : 0L);
+        return bsel(base, seg) + (ok ? rw.off + cl.delta : 0L);
     }
     __device__ const bf16_t* ptr_tr(int seg, int r, const Col& cl, bool& ok) const {
         int b, y, x;
         pixel(r, b, y, x);
         ok = cl.ok & (r < Mtot) & ((unsigned)(2 * y - 1 + cl.ky) < (unsigned)(2 * H)) & ((unsigned)(2 * x - 1 + cl.kx) < (unsigned)(2 * W));
-        return base[seg] + (ok ? (((long)(b * 2 * H + 2 * y)) * (2 * W) + 2 * x) * Cout + cl.delta : 0L);
+        return bsel(base, seg) + (ok ? (((long)(b * 2 * H + 2 * y)) * (2 * W) + 2 * x) * Cout + cl.delta : 0L);
     }
     __device__ const bf16_t* ptr(int seg, int r, int c8, bool& ok) const { return ptr_tr(seg, r, col(c8), ok); }
 };
@@ -1130,6 +1139,7 @@ struct ConvTGradLoader {
 // ---------------------------------------------------------------------------------- epilogues
 // bf16/split store: out = drop(act(acc + bias)); optional pre-activation copy; optional ConvT phase row map
 struct EpStore {
+    static constexpr const char* kName = "EpStore";
     static constexpr bool kColSum = false;
     static constexpr bool kStagedAtomic = false;
     bf16_t *out_hi, *out_lo;
@@ -1195,6 +1205,7 @@ struct EpStore {
 
 // dgrad store with an elementwise factor: mode 1: * dact[m][n] (the gelu' saved by the forward); mode 2: * dropout mask(idx)
 struct EpGradStore {
+    static constexpr const char* kName = "EpGradStore";
     static constexpr bool kStagedAtomic = false;
     static constexpr bool kColSum = true;  // optional fused column sums of the stored values (bias gradient)
     float* colsum;
@@ -1236,6 +1247,7 @@ struct EpGradStore {
 
 // fp32 residual: out[m][n] = resid[m][n] + acc + bias[n]
 struct EpResidual {
+    static constexpr const char* kName = "EpResidual";
     static constexpr bool kColSum = false;
     static constexpr bool kStagedAtomic = false;
     float* out;
@@ -1254,6 +1266,7 @@ struct EpResidual {
 
 // patch embed: token row m=(b, tp) -> x[b*Ntok + 1 + tp][n] = acc + bias[n] + pos[1+tp][n]   (pritvhi.py:513-517)
 struct EpPatchEmbed {
+    static constexpr const char* kName = "EpPatchEmbed";
     static constexpr bool kColSum = false;
     static constexpr bool kStagedAtomic = false;
     float* x;
@@ -1274,6 +1287,7 @@ struct EpPatchEmbed {
 
 // wgrad: fp32 atomic accumulate into the gradient buffer; column offset z*zstride (ConvT taps)
 struct EpAtomic {
+    static constexpr const char* kName = "EpAtomic";
     static constexpr bool kColSum = false;
     static constexpr bool kStagedAtomic = true;
     float* out;
@@ -1370,6 +1384,7 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, i
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G5_SMEM);         \
             attr_done = true;                                                                                          \
         }                                                                                                              \
+        ig_note_kernel("gemm5_kernel<%s,%s,%s,%s,%s,%d>", AL::kName, BL::kName, EP::kName, A_TR ? "true" : "false", B_TR ? "true" : "false", NSEG_); \
         hipLaunchKernelGGL(kern, grid5, dim3(NTHR5), G5_SMEM, st, al, bl, ep, M, N, K, tn5, ntiles, kchunk5, zp5);     \
     }
             if (split) IG_LAUNCH_V5(3) else IG_LAUNCH_V5(1)
@@ -1427,6 +1442,7 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, i
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G2<BKT_>::SMEM);     \
             attr_done = true;                                                                                             \
         }                                                                                                                 \
+        ig_note_kernel("gemm2_kernel<%s,%s,%s,%s,%s,%d,%d,1>", AL::kName, BL::kName, EP::kName, A_TR ? "true" : "false", B_TR ? "true" : "false", NSEG_, BKT_); \
         hipLaunchKernelGGL(kern, grid, dim3(NTHR2), G2<BKT_>::SMEM, st, al, bl, ep, M, N, K, tn, ntiles, kchunk, zp);     \
     }
         if constexpr (EP::kStagedAtomic) {
@@ -1447,6 +1463,7 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, i
                         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2<32>::SMEM);
                         attr_dual = true;
                     }
+                    ig_note_kernel("gemm2_kernel<%s,%s,%s,%s,%s,1,32,2>", AL::kName, BL::kName, EP::kName, A_TR ? "true" : "false", B_TR ? "true" : "false");
                     hipLaunchKernelGGL(kern, grid, dim3(2 * NTHR2), 2 * G2<32>::SMEM, st, al, bl, ep, M, N, K, tn, ntiles, kchunk, zp);
                     return ig_check_launch(what);
                 }
@@ -1475,6 +1492,7 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, i
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_);            \
             attr_done = true;                                                                                          \
         }                                                                                                              \
+        ig_note_kernel("gemm_kernel<%s,%s,%s,%s,%s,%d,%d,%d,%d,%d>", AL::kName, BL::kName, EP::kName, A_TR ? "true" : "false", B_TR ? "true" : "false", NSEG_, MT_, NT_, WM_, BKT_); \
         hipLaunchKernelGGL(kern, grid, block, lds_, st, al, bl, ep, M, N, K, tn, kchunk);                              \
     }
 #define IG_LAUNCH_V1(NSEG_, MT_, NT_, WM_) IG_LAUNCH_V1K(NSEG_, MT_, NT_, WM_, 64)
@@ -1598,6 +1616,35 @@ int ig_linear_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, cons
     return launch_gemm<PlainLoader, PlainLoader, EpGradStore, false, true>(
         plain_a(dy_hi, dy_lo, M, N, N), plain_b(w_hi, w_lo, N, K, K), ep, M, K, N, 1, dy_lo != nullptr, (hipStream_t)stream,
         "ig_linear_dgrad", false, gemm_version_prefer5(mode == 0 && dx_colsum == nullptr && dy_lo == nullptr));
+}
+
+// ig_linear_dgrad with the weight given TRANSPOSED: wt[K][N] = w^T.  Both operands are then contiguous in the reduce dimension N
+// (the forward form), which the 256 x 256 x 64 engine covers; other shapes run the generic engines in the same form.
+int ig_linear_dgrad_wt(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, void* dx_hi, void* dx_lo,
+                       const void* pre_hi, const void* pre_lo, float* dx_colsum, int M, int N, int K, int mode, void* stream) {
+    IG_REQUIRE(dy_hi && wt_hi && dx_hi, "ig_linear_dgrad_wt: null pointer");
+    IG_REQUIRE(N % 8 == 0 && K % 8 == 0, "ig_linear_dgrad_wt: N and K must be multiples of 8");
+    IG_REQUIRE(mode == 0 || (mode == 1 && pre_hi), "ig_linear_dgrad_wt: mode 1 needs the saved activation-derivative tensor (dact)");
+    IG_REQUIRE(aligned16(dy_hi) && aligned16(wt_hi) && aligned16(dx_hi), "ig_linear_dgrad_wt: pointers must be 16-byte aligned");
+    IG_SPLIT_CONSISTENT(dy_lo, wt_lo);
+    IG_REQUIRE((dy_lo == nullptr) == (dx_lo == nullptr), "ig_linear_dgrad_wt: input and output must both be split or both plain");
+    if (!gemm_env() && (mode == 1 || dx_colsum == nullptr)) {
+        G8Params g{};
+        seg_a(g.a, dy_hi, dy_lo), seg_b(g.b, wt_hi, wt_lo);
+        g.nseg = dy_lo ? 3 : 1, g.M = M, g.N = K, g.K = N, g.lda = N, g.ldb = N, g.ldo = K;
+        g.kind = mode == 1 ? 2 : 0, g.act = 0, g.bias = nullptr;
+        g.out_hi = (bf16_t*)dx_hi, g.out_lo = (bf16_t*)dx_lo;
+        if (mode == 1) g.dact_hi = (bf16_t*)pre_hi, g.dact_lo = (bf16_t*)pre_lo, g.colsum = dx_colsum;
+        const int rc = ig_gemm8_nt(g, stream);
+        if (rc != IG_ERR_UNSUPPORTED) return rc;
+    }
+    EpGradStore ep{};
+    ep.out_hi = (bf16_t*)dx_hi, ep.out_lo = (bf16_t*)dx_lo, ep.pre_hi = (const bf16_t*)pre_hi, ep.pre_lo = (const bf16_t*)pre_lo;
+    ep.ldo = K, ep.mode = mode;
+    ep.colsum = dx_colsum;
+    return launch_gemm<PlainLoader, PlainLoader, EpGradStore, false, false>(
+        plain_a(dy_hi, dy_lo, M, N, N), plain_b(wt_hi, wt_lo, K, N, N), ep, M, K, N, 1, dy_lo != nullptr, (hipStream_t)stream,
+        "ig_linear_dgrad_wt");
 }
 
 // dw[N][K] += dy[M][N]^T @ x[M][K]   (fp32 atomic accumulate)

@@ -299,6 +299,66 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(G8Params p) {
                     }
 #undef G8_STAGE_PASS
                 }
+        } else if constexpr (KIND == 2) {
+            // data gradient with an elementwise factor: dx = acc * dact (the gelu' the forward saved), optional fused column
+            // sums of dx (the bias gradient of the producing layer).  The fp32 tile rows are staged (16 rows x 64 fp32) and read
+            // back row-contiguous, 8 columns per lane, so the factor is ONE coalesced 16-byte load per 8 values (in the MFMA
+            // layout it was an 8-byte load per 4 values behind the stores).
+            const int rrow = lane >> 3, rcol = (lane & 7) * 8;
+            float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int m0 = bm * 256 + wr * 128 + h * 64 + mt * 16;
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const int c4 = g * 8 + nt * 4 + eq;
+                            *reinterpret_cast<f32x4*>(st + erow * 256 + ((c4 ^ (erow & 7)) << 4)) = acc[h][g][nt][mt];
+                        }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int r = i * 8 + rrow;
+                        const f32x4 a0 = *reinterpret_cast<const f32x4*>(st + r * 256 + (((2 * (lane & 7)) ^ (r & 7)) << 4));
+                        const f32x4 a1 = *reinterpret_cast<const f32x4*>(st + r * 256 + (((2 * (lane & 7) + 1) ^ (r & 7)) << 4));
+                        const int m = m0 + r;
+                        if (m < p.M) {
+                            const size_t o = (size_t)m * p.ldo + n0 + rcol;
+                            float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                            float f[8];
+                            unpack8(*reinterpret_cast<const uint4*>(p.dact_hi + o), f);
+                            if constexpr (SPLIT_OUT) {
+                                float fl[8];
+                                unpack8(*reinterpret_cast<const uint4*>(p.dact_lo + o), fl);
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) f[j] += fl[j];
+                            }
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] *= f[j], cs[j] += v[j];
+                            const uint4 u = pack8(v);
+                            *reinterpret_cast<uint4*>(p.out_hi + o) = u;
+                            if constexpr (SPLIT_OUT) {
+                                float hv[8], rv[8];
+                                unpack8(u, hv);
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) rv[j] = v[j] - hv[j];
+                                *reinterpret_cast<uint4*>(p.out_lo + o) = pack8(rv);
+                            }
+                        }
+                    }
+                }
+            if (p.colsum) {  // lanes with equal (lane & 7) own the same 8 columns: fold over lane >> 3, one atomic per column
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float v = cs[j];
+                    v += __shfl_xor(v, 8, 64);
+                    v += __shfl_xor(v, 16, 64);
+                    v += __shfl_xor(v, 32, 64);
+                    if (lane < 8) atomicAdd(p.colsum + n0 + rcol + j, v);
+                }
+            }
         } else {
             // fp32 residual: out = resid + acc (bias is in the accumulator init); 16 rows x 64 fp32 = 4 KiB staged
             const int rrow = lane >> 4, rc = lane & 15;
@@ -358,6 +418,7 @@ int g8_launch(const G8Params& p, int grid, hipStream_t st) {
         }
         attr_done = true;
     }
+    ig_note_kernel("gemm8_kernel<%d,%d,%d,%s,%s>", KIND, NSEG, ACT, DACT ? "true" : "false", SPLIT_OUT ? "true" : "false");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), G8_SMEM, st, p);
     return ig_check_launch("gemm8");
 }
@@ -395,6 +456,11 @@ int ig_gemm8_nt(const G8Params& p, void* stream) {
     if (p.kind == 1) {
         if (!split_in) return g8_launch<1, 1, 0, false, false>(p, grid, st);
         return g8_launch<1, 3, 0, false, false>(p, grid, st);
+    }
+    if (p.kind == 2) {
+        if (!p.dact_hi || (split_in != (p.out_lo != nullptr)) || (split_in != (p.dact_lo != nullptr))) return IG_ERR_UNSUPPORTED;
+        if (!split_in) return g8_launch<2, 1, 0, false, false>(p, grid, st);
+        return g8_launch<2, 3, 0, false, true>(p, grid, st);
     }
     return IG_ERR_UNSUPPORTED;
 }

@@ -301,7 +301,10 @@ __global__ __launch_bounds__(TPB) void kd_loss_kernel(const float* __restrict__ 
     __shared__ double red[TPB / 64];
     double my = 0.0;
     for (long m = blockIdx.x * (long)TPB + threadIdx.x; m < M; m += (long)gridDim.x * TPB) {
-        if ((long)labels[m] == ignore_index) continue;
+        {  // the validity predicate of ce_loss_kernel: ignored AND out-of-range labels carry neither loss nor gradient
+            const long y = (long)labels[m];
+            if (y == ignore_index || y < 0 || y >= ncls) continue;
+        }
         const long b = m / HW, pix = m - b * HW;
         float zs[MAXC], zt[MAXC];
         float ms = -INFINITY, mt = -INFINITY;

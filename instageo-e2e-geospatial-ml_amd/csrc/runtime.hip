@@ -15,6 +15,14 @@ void ig_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static thread_local char g_kernel[256] = "";
+void ig_note_kernel(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+    va_end(ap);
+}
+
 int ig_check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -56,6 +64,7 @@ int ig_set_reserved_cus(int n) {
 int ig_get_reserved_cus(void) { return ig_reserved_cus(); }
 
 const char* ig_last_error(void) { return g_err; }
+const char* ig_last_kernel(void) { return g_kernel; }
 
 int ig_version(void) { return 100; }  // 0.1.0
 

@@ -194,6 +194,13 @@ class ParamStore:
         self.grad: Optional[torch.Tensor] = None
         self.shadow: Optional[BT] = None
         self.shadow_split: Optional[bool] = None
+        # transposed operand copy of the Block linears' weights (dgrad as a K-contiguous GEMM): per block
+        # [qkv^T (D,3D) | proj^T (D,D) | fc1^T (D,4D) | fc2^T (4D,D)] = 12 D^2 elements
+        self.shadow_t: Optional[BT] = None
+        d = cfg.embed_dim
+        self.t_block = 12 * d * d
+        self.t_offsets = {"attn.qkv.weight": (0, 3 * d, d), "attn.proj.weight": (3 * d * d, d, d),
+                          "mlp.fc1.weight": (4 * d * d, 4 * d, d), "mlp.fc2.weight": (8 * d * d, d, 4 * d)}  # name: (offset, R, C)
 
     def seg(self, buf: torch.Tensor, name: str) -> torch.Tensor:
         e = self.entries[name]
@@ -211,6 +218,30 @@ class ParamStore:
             self.shadow_split = split
         ops.split_bf16(self.flat, self.shadow)
         return self.shadow
+
+    def refresh_shadow_t(self) -> None:
+        """Re-transpose the Block linears' bf16 (hi/lo) weights from the shadow: 4 batched launches (x2 in split mode)."""
+        cfg, sh = self.cfg, self.shadow
+        if cfg.depth == 0 or cfg.embed_dim % 64:
+            return
+        split = sh.lo is not None
+        if self.shadow_t is None or self.shadow_t.split != split or self.shadow_t.hi.device != sh.hi.device:
+            self.shadow_t = BT.empty((cfg.depth * self.t_block,), split, sh.hi.device)
+        e0 = "prithvi_encoder.blocks.0."
+        stride = self.entries["prithvi_encoder.blocks.1.norm1.weight"].offset - self.entries[e0 + "norm1.weight"].offset if cfg.depth > 1 else 0
+        for name, (toff, R, C) in self.t_offsets.items():
+            so = self.entries[e0 + name].offset
+            src = BT(sh.hi[so:], None if sh.lo is None else sh.lo[so:])
+            dst = BT(self.shadow_t.hi[toff:], None if self.shadow_t.lo is None else self.shadow_t.lo[toff:])
+            ops.transpose_bf16(src, dst, R, C, cfg.depth, stride, self.t_block)
+
+    def wt(self, block: int, name: str) -> Optional[BT]:
+        """Transposed bf16 operand view (C, R) of a Block linear weight, or None when no transposed copy is kept."""
+        if self.shadow_t is None:
+            return None
+        toff, R, C = self.t_offsets[name]
+        o = block * self.t_block + toff
+        return BT(self.shadow_t.hi[o : o + R * C], None if self.shadow_t.lo is None else self.shadow_t.lo[o : o + R * C])
 
     def w(self, name: str) -> BT:
         """bf16 operand view of a parameter (storage layout)."""
@@ -232,11 +263,13 @@ class SegEngine:
         self.split = precision == "bf16x3"
         self._ws: Dict[Any, Dict[str, Any]] = {}
         self.shadow_dirty = True
+        self.shadow_t_dirty = True  # the transposed weight copy lags the shadow until the next backward needs it
         self.drop_seed = 1042
         self._drop_step: Optional[torch.Tensor] = None  # device uint32 counter mixed into the dropout hash each step
         self.freeze_backbone = False
         self.on_grad_ready: Optional[Callable[[int, int], None]] = None
         self._last: Optional[Dict[str, Any]] = None
+        self._generation = 0  # bumped by every forward(save=True): the saved activations belong to exactly one forward
 
     # ---- helpers -------------------------------------------------------------------------------
     def P(self, name: str) -> torch.Tensor:  # fp32 master segment (biases, norm affine, classifier)
@@ -250,11 +283,19 @@ class SegEngine:
 
     def mark_params_changed(self) -> None:
         self.shadow_dirty = True
+        self.shadow_t_dirty = True
 
     def _prepare_shadow(self) -> None:
         if self.shadow_dirty or self.store.shadow is None or self.store.shadow_split != self.split:
             self.store.refresh_shadow(self.split)
             self.shadow_dirty = False
+            self.shadow_t_dirty = True
+
+    def _prepare_shadow_t(self) -> None:
+        st = self.store.shadow_t
+        if self.shadow_t_dirty or st is None or st.split != self.split:
+            self.store.refresh_shadow_t()
+            self.shadow_t_dirty = False
 
     def workspace(self, B: int, training: bool) -> Dict[str, Any]:
         key = (B, training, self.split, str(self.store.flat.device))
@@ -359,7 +400,9 @@ class SegEngine:
         ops.layernorm_fwd(x_fin, self.P(e + "norm.weight"), self.P(e + "norm.bias"), ws["f"][0], ws["meanF"], ws["rstdF"], M, D,
                           feat_T=T, feat_G=G, ntok=N)
         logits = self._head_forward(ws, B, training, out, update_running)
-        self._last = {"ws": ws, "B": B, "training": training} if save else None
+        if save:
+            self._generation += 1
+        self._last = {"ws": ws, "B": B, "training": training, "generation": self._generation} if save else None
         return logits
 
     def _drop_counter(self, advance: bool) -> Optional[torch.Tensor]:
@@ -407,12 +450,18 @@ class SegEngine:
         return self._last["ws"]["f"][0].float().permute(0, 3, 1, 2).contiguous()
 
     # ---- backward ------------------------------------------------------------------------------
-    def backward(self, dlogits: torch.Tensor, count: Optional[torch.Tensor] = None) -> None:
+    def backward(self, dlogits: torch.Tensor, count: Optional[torch.Tensor] = None, generation: Optional[int] = None) -> None:
         """Accumulate d loss / d params into the flat grad buffer from d loss / d logits.
 
         ``count``: optional device double[2] (``ig_ce_loss`` stats) whose [1] normalises un-normalised dlogits.
+        ``generation``: the forward this backward belongs to (autograd bridge); the engine keeps ONE set of saved
+        activations, so a backward after a newer grad-enabled forward would silently use the wrong ones -- it raises.
         """
         assert self._last is not None, "forward(save=True) must precede backward"
+        if generation is not None and generation != self._last["generation"]:
+            raise RuntimeError(
+                "PrithviSeg: backward of a forward whose saved activations were overwritten by a later grad-enabled forward "
+                "(one set of activations per engine: run backward before the next training forward, or use a second module)")
         cfg = self.cfg
         ws, B, training = self._last["ws"], self._last["B"], self._last["training"]
         self.store.ensure_grad()
@@ -445,6 +494,8 @@ class SegEngine:
             return
         e = "prithvi_encoder."
         dx, dxb = ws["dx"], ws["dxb"]
+        self._prepare_shadow_t()
+        WT = self.store.wt
 
         def block_start(i: int) -> str:
             return f"{e}blocks.{i}.norm1.weight" if i < L else e + "norm.weight"
@@ -458,20 +509,21 @@ class SegEngine:
             # fc2: x_out = x_mid + hact @ W2^T + b2   (its bias grad came from the LayerNorm backward that produced dx)
             ops.linear_wgrad(dxb, ws["hact"][i], self.Gd(b + "mlp.fc2.weight"), M, D, 4 * D)
             # (the fc1 bias gradient = column sums of dh is fused into this dgrad's epilogue)
-            ops.linear_dgrad(dxb, self.W(b + "mlp.fc2.weight"), ws["dh"], M, D, 4 * D, pre=ws["hpre"][i], colsum=self.Gd(b + "mlp.fc1.bias"))
+            ops.linear_dgrad(dxb, self.W(b + "mlp.fc2.weight"), ws["dh"], M, D, 4 * D, pre=ws["hpre"][i], colsum=self.Gd(b + "mlp.fc1.bias"),
+                             wt=WT(i, "mlp.fc2.weight"))
             # fc1
             ops.linear_wgrad(ws["dh"], ws["c"][i], self.Gd(b + "mlp.fc1.weight"), M, 4 * D, D)
-            ops.linear_dgrad(ws["dh"], self.W(b + "mlp.fc1.weight"), ws["dtmp"], M, 4 * D, D)
+            ops.linear_dgrad(ws["dh"], self.W(b + "mlp.fc1.weight"), ws["dtmp"], M, 4 * D, D, wt=WT(i, "mlp.fc1.weight"))
             ops.layernorm_bwd(ws["dtmp"], ws["x_mid"][i], ws["mean2"][i], ws["rstd2"][i], self.P(b + "norm2.weight"), dx, True, dxb,
                               self.Gd(b + "norm2.weight"), self.Gd(b + "norm2.bias"), self.Gd(b + "attn.proj.bias"), M, D)
             # proj
             ops.linear_wgrad(dxb, ws["o"][i], self.Gd(b + "attn.proj.weight"), M, D, D)
-            ops.linear_dgrad(dxb, self.W(b + "attn.proj.weight"), ws["dtmp"], M, D, D)
+            ops.linear_dgrad(dxb, self.W(b + "attn.proj.weight"), ws["dtmp"], M, D, D, wt=WT(i, "attn.proj.weight"))
             ops.attention_bwd(ws["qkv"][i], ws["o"][i], ws["dtmp"], ws["lse"][i], ws["delta"], ws["dqkv"], B, N, H)
             # qkv
             ops.linear_wgrad(ws["dqkv"], ws["a"][i], self.Gd(b + "attn.qkv.weight"), M, 3 * D, D)
             ops.colsum(ws["dqkv"], self.Gd(b + "attn.qkv.bias"), M, 3 * D)
-            ops.linear_dgrad(ws["dqkv"], self.W(b + "attn.qkv.weight"), ws["dtmp"], M, 3 * D, D)
+            ops.linear_dgrad(ws["dqkv"], self.W(b + "attn.qkv.weight"), ws["dtmp"], M, 3 * D, D, wt=WT(i, "attn.qkv.weight"))
             prev_bias = self.Gd(f"{e}blocks.{i - 1}.mlp.fc2.bias") if i > 0 else None
             ops.layernorm_bwd(ws["dtmp"], ws["x_in"][i], ws["mean1"][i], ws["rstd1"][i], self.P(b + "norm1.weight"), dx, True, dxb,
                               self.Gd(b + "norm1.weight"), self.Gd(b + "norm1.bias"), prev_bias, M, D)
@@ -501,6 +553,7 @@ class _SegFunction(torch.autograd.Function):
         eng = module.engine
         logits = eng.forward(img, module.training, save=True)
         ctx.n = len(params)
+        ctx.generation = eng._generation
         return logits
 
     @staticmethod
@@ -510,7 +563,7 @@ class _SegFunction(torch.autograd.Function):
         store = module.store
         g = store.ensure_grad()
         g.zero_()
-        eng.backward(dlogits.contiguous().float())
+        eng.backward(dlogits.contiguous().float(), generation=ctx.generation)
         grads = []
         for name, p in module._flat_params():
             if p.requires_grad:

@@ -99,18 +99,20 @@ def profile_end():
     return {n: (len(d["events"]), sum(a.elapsed_time(b) for a, b in d["events"]), d["work"]) for n, d in prof.items()}
 
 
-def _call(name: str, work: float, *args) -> None:
+def _call(name: str, work: float, *args, entry: Optional[str] = None) -> None:
+    """Call entry point ``entry`` (default ``name``); ``name`` is the key the launch is profiled under."""
+    entry = entry or name
     if PROF is None or name not in PROF:
-        _lib.call(name, *args)
+        _lib.call(entry, *args)
         return
     d = PROF[name]
     d["seen"] += 1
     if (d["seen"] - 1) % PROF_STRIDE:
-        _lib.call(name, *args)
+        _lib.call(entry, *args)
         return
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    _lib.call(name, *args)
+    _lib.call(entry, *args)
     b.record()
     d["events"].append((a, b))
     d["work"] += work
@@ -220,10 +222,22 @@ def linear_residual_fwd(x: BT, w: BT, bias, resid, out, M: int, N: int, K: int) 
     _call("ig_linear_residual_fwd", 2.0 * M * N * K, _p(x.hi), _p(x.lo), _p(w.hi), _p(w.lo), _p(bias), _p(resid), _p(out), M, N, K, _stream())
 
 
-def linear_dgrad(dy: BT, w: BT, dx: BT, M: int, N: int, K: int, pre: Optional[BT] = None, colsum=None) -> None:
-    """dx = dy @ w [* pre, the gelu' saved by linear_fwd]; ``colsum`` (fp32 [K]) additionally accumulates the column sums of dx."""
+def linear_dgrad(dy: BT, w: Optional[BT], dx: BT, M: int, N: int, K: int, pre: Optional[BT] = None, colsum=None,
+                 wt: Optional[BT] = None) -> None:
+    """dx = dy @ w [* pre, the gelu' saved by linear_fwd]; ``colsum`` (fp32 [K]) additionally accumulates the column sums of dx.
+    ``wt`` = the same weight stored transposed ([K][N], :func:`transpose_bf16`): the K-contiguous form (``ig_linear_dgrad_wt``)."""
+    if wt is not None:
+        _call("ig_linear_dgrad", 2.0 * M * N * K, _p(dy.hi), _p(dy.lo), _p(wt.hi), _p(wt.lo), _p(dx.hi), _p(dx.lo),
+              _p(pre.hi) if pre else None, _p(pre.lo) if pre else None, _p(colsum), M, N, K, 1 if pre else 0, _stream(),
+              entry="ig_linear_dgrad_wt")
+        return
     _call("ig_linear_dgrad", 2.0 * M * N * K, _p(dy.hi), _p(dy.lo), _p(w.hi), _p(w.lo), _p(dx.hi), _p(dx.lo),
               _p(pre.hi) if pre else None, _p(pre.lo) if pre else None, _p(colsum), M, N, K, 1 if pre else 0, _stream())
+
+
+def transpose_bf16(src: BT, dst: BT, R: int, C: int, batch: int = 1, src_stride: int = 0, dst_stride: int = 0) -> None:
+    """dst[b] (C, R) = src[b] (R, C)^T for b < batch (strides in elements between consecutive matrices)."""
+    _lib.call("ig_transpose_bf16", _p(src.hi), _p(src.lo), _p(dst.hi), _p(dst.lo), R, C, batch, src_stride, dst_stride, _stream())
 
 
 def linear_wgrad(dy: BT, x: BT, dw, M: int, N: int, K: int) -> None:

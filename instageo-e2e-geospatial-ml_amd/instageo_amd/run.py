@@ -60,12 +60,30 @@ def create_dataset(spec: Optional[str], cfg: Dict[str, Any], kind: str, device: 
                             replace_label=d.get("replace_label"), reduce_to_zero=bool(d.get("reduce_to_zero", False)))
 
 
-def _batches(ds, batch_size: int, shuffle: bool, epoch: int, rank: int, world: int):
-    """Rank-sharded batch index lists (DistributedSampler semantics: shuffle per epoch, same seed on all ranks)."""
-    n = len(ds)
+def shard_indices(n: int, shuffle: bool, epoch: int, rank: int, world: int, equal: bool) -> List[int]:
+    """Item indices of one rank for one epoch.
+
+    ``equal=True`` is ``torch.utils.data.DistributedSampler`` (what Lightning DDP gives the reference's train loader): the
+    (shuffled) index list is padded by wrap-around to ``ceil(n / world) * world`` and rank r takes ``idx[r::world]``, so EVERY
+    rank gets the same number of items and therefore the same number of optimizer steps -- a rank with one batch fewer would
+    leave the others waiting in a gradient all-reduce while it has already entered the epoch-end metric all-reduce.
+    ``equal=False`` is an exact contiguous partition (no duplicates; sizes differ by at most one): used for validation /
+    test, whose steps contain no collective, so that the reduced metrics count every item exactly once."""
     idx = torch.randperm(n, generator=torch.Generator().manual_seed(SEED + epoch)).tolist() if shuffle else list(range(n))
-    lo, hi = D.shard_range(n, rank, world)
-    idx = idx[lo:hi]
+    if not equal or world == 1:
+        lo, hi = D.shard_range(n, rank, world)
+        return idx[lo:hi]
+    if n == 0:
+        return []
+    total = -(-n // world) * world
+    while len(idx) < total:
+        idx += idx[: total - len(idx)]
+    return idx[rank:total:world]
+
+
+def _batches(ds, batch_size: int, shuffle: bool, epoch: int, rank: int, world: int, equal: bool = False):
+    """Rank-sharded batch index lists (same shuffle seed on all ranks; see :func:`shard_indices`)."""
+    idx = shard_indices(len(ds), shuffle, epoch, rank, world, equal)
     for i in range(0, len(idx), batch_size):
         yield idx[i : i + batch_size]
 
@@ -76,9 +94,19 @@ def _stack(ds, ids: List[int]) -> Tuple[torch.Tensor, torch.Tensor]:
     return torch.stack([it[0] for it in items]), torch.stack([it[1] for it in items])
 
 
-def _reduce_metrics(metrics, dev) -> None:
-    """Sum the rank-local streaming metric state over ranks (confusion matrix, or the regression sums)."""
+def _reduce_metrics(metrics, dev, model=None, step_type: Optional[str] = None) -> None:
+    """Sum the rank-local streaming state over ranks before the epoch-end hooks: the confusion matrix (or the regression
+    sums), the (sum of batch losses, #batches) pair behind ``<step>_loss`` and, for the test epoch, the ROC-AUC histograms."""
     D.reduce_confusion(metrics.device_matrix(dev) if hasattr(metrics, "device_matrix") else metrics.device_sums(dev))
+    if model is None or D.world_size() == 1:
+        return
+    acc = model._loss_sums.get(step_type)
+    if acc is None:  # a rank whose shard was empty still has to take part in the collective
+        acc = torch.zeros(2, dtype=torch.float64, device=dev)
+        model._loss_sums[step_type] = acc
+    D.reduce_loss_stats(acc)
+    if step_type == "test" and hasattr(model, "test_auc"):
+        D.reduce_confusion(model.test_auc.device_hist(dev))
 
 
 def train(cfg: Dict[str, Any], model, out_dir: str, rank: int, world: int) -> Dict[str, float]:
@@ -99,19 +127,19 @@ def train(cfg: Dict[str, Any], model, out_dir: str, rank: int, world: int) -> Di
     aug_gen = torch.Generator().manual_seed(SEED + 7919 * rank)  # different crops/flips per rank, reproducible
     for epoch in range(cfg["train"]["num_epochs"]):
         model.net.train()
-        for ids in _batches(train_ds, bs, True, epoch, rank, world):
+        for ids in _batches(train_ds, bs, True, epoch, rank, world, equal=True):
             # training items go through process_and_augment (dataloader.py:527-585): random crop to img_size + the enabled
             # flips + normalise, here as ONE kernel per batch on the raw chips
             xr, yr = train_ds.raw_batch(ids)
             x, y = process_and_augment_batch(xr, yr, train_ds.mean, train_ds.std, train_ds.T, cfg["dataloader"]["img_size"], True,
                                              train_augs, train_ds.mult, aug_gen)
             model.fused_train_step(x, y)
-        _reduce_metrics(model.train_metrics, dev)
+        _reduce_metrics(model.train_metrics, dev, model, "train")
         model.on_train_epoch_end()
         for ids in _batches(valid_ds, bs, False, epoch, rank, world):
             x, y = _stack(valid_ds, ids)
             model.fused_eval_step(x, y, "val")
-        _reduce_metrics(model.val_metrics, dev)
+        _reduce_metrics(model.val_metrics, dev, model, "val")
         model.on_validation_epoch_end()
         if sched is not None:
             sched.step()
@@ -135,10 +163,10 @@ def evaluate(cfg: Dict[str, Any], model, rank: int, world: int) -> Dict[str, flo
     lo, hi = D.shard_range(len(test_ds), rank, world)
     for i in range(lo, hi):
         raw_x, raw_y = test_ds.raw(i) if hasattr(test_ds, "raw") else (test_ds.chips[i], test_ds.labels[i])
-        mult = 1e-4 if hasattr(test_ds, "raw") else None
+        mult = getattr(test_ds, "mult", None)  # the constant multiplier applies in every mode (dataloader.py:707-750)
         x, y = process_test(raw_x, raw_y, d["mean"], d["std"], d["temporal_dim"], t["img_size"], t["crop_size"], t["stride"], mult, dev)
         model.fused_eval_step(x, y, "test")
-    _reduce_metrics(model.test_metrics, dev)
+    _reduce_metrics(model.test_metrics, dev, model, "test")
     model.on_test_epoch_end()
     return {k: float(v) for k, v in model.logged.items() if k.startswith("test_") and not isinstance(v, (list, tuple))}
 

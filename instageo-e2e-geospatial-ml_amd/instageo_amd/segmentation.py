@@ -97,6 +97,7 @@ class FusedAdamW(torch.optim.Optimizer):
         shadow = ops.BT(sh.hi[self.lo : self.hi], None if sh.lo is None else sh.lo[self.lo : self.hi])
         ops.adamw_step(store.flat[self.lo : self.hi], store.grad[self.lo : self.hi], self.m, self.v, shadow, self.hyper, self.hi - self.lo)
         eng.shadow_dirty = False
+        eng.shadow_t_dirty = True  # the transposed weight copy is rebuilt by the next backward
         return loss
 
     def zero_grad(self, set_to_none: bool = True) -> None:
@@ -130,6 +131,26 @@ def segmentation_loss(logits: torch.Tensor, labels: torch.Tensor, class_weights:
     if labels.dtype not in (torch.int64, torch.int32, torch.float32):
         labels = labels.long()
     return _SegLoss.apply(logits, labels, class_weights, ignore_index, confusion, preds)
+
+
+class _SegKDLoss(torch.autograd.Function):
+    """CE(student) + KLDivLoss(batchmean)(log_softmax(student), softmax(teacher)) over the valid pixels
+    (segmentation.py:352-378): total, and the two parts for logging."""
+
+    @staticmethod
+    def forward(ctx, logits, t_logits, labels, weight, ignore_index, confusion):
+        stats = torch.zeros(2, dtype=torch.float64, device=logits.device)
+        kl = torch.zeros(1, dtype=torch.float64, device=logits.device)
+        dlog = torch.empty_like(logits)
+        ops.ce_loss(logits.contiguous(), labels.contiguous(), weight, ignore_index, stats, dlog, None, None, confusion)
+        ops.kd_loss(logits.contiguous(), t_logits.contiguous(), labels.contiguous(), ignore_index, kl, dlog)
+        ctx.save_for_backward(dlog, stats)
+        return ((stats[0] + kl[0]) / stats[1]).float(), (stats[0] / stats[1]).float().detach(), (kl[0] / stats[1]).float().detach()
+
+    @staticmethod
+    def backward(ctx, g, _g_ce, _g_kl):
+        dlog, stats = ctx.saved_tensors
+        return dlog * (g / stats[1].float()), None, None, None, None, None
 
 
 # --------------------------------------------------------------------------------------------------
@@ -219,6 +240,8 @@ class PrithviSegmentationModule(_Base):
         outputs = self.forward(inputs)
         metrics: RunningConfusionMatrix = getattr(self, f"{step_type}_metrics")
         loss = segmentation_loss(outputs, labels, self._weights(), self.ignore_index, confusion=metrics.device_matrix(outputs.device))
+        if step_type == "test":  # ROC-AUC is a test-time metric (segmentation.py:153-156)
+            self.test_auc.update_from_logits(outputs.detach(), labels)
         self._accumulate_loss(step_type, loss.detach())
         return loss
 
@@ -330,6 +353,19 @@ class PrithviSegmentationModule(_Base):
         static_x = inputs.clone()
         static_y = labels.clone()
         stats = torch.zeros(2, dtype=torch.float64, device=inputs.device)
+        # The warm-up below runs two REAL optimizer steps and the capture pass itself must not count as training either:
+        # snapshot everything a step mutates (parameters, AdamW moments + step counter, BatchNorm running statistics,
+        # dropout counter, streaming metrics, loss accumulator) and restore it afterwards, so that capturing is free of
+        # side effects and the first replay is training step 1.
+        opt = self.optimizer()
+        eng = self.net.engine
+        eng._drop_counter(advance=False)
+        self.train_metrics.device_matrix(inputs.device)
+        if "train" not in self._loss_sums:
+            self._loss_sums["train"] = torch.zeros(2, dtype=torch.float64, device=inputs.device)
+        snap = {"flat": self.net.store.flat.clone(), "m": opt.m.clone(), "v": opt.v.clone(), "hyper": opt.hyper.clone(),
+                "host_step": opt._host_step, "drop": eng._drop_step.clone(), "cm": self.train_metrics.device_matrix().clone(),
+                "loss": self._loss_sums["train"].clone(), "bufs": {k: t.clone() for k, t in self.net._buffers_flat.items()}}
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # warm-up on a side stream: allocates workspaces, sets kernel attributes
@@ -340,7 +376,18 @@ class PrithviSegmentationModule(_Base):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             self.fused_train_step(static_x, static_y, stats)
-        opt = self.optimizer()
+        with torch.no_grad():  # in-place restores: the graph keeps writing into these very tensors
+            self.net.store.flat.copy_(snap["flat"])
+            opt.m.copy_(snap["m"]), opt.v.copy_(snap["v"]), opt.hyper.copy_(snap["hyper"])
+            opt._host_step = snap["host_step"]
+            eng._drop_step.copy_(snap["drop"])
+            self.train_metrics.device_matrix().copy_(snap["cm"])
+            self._loss_sums["train"].copy_(snap["loss"])
+            for k, t in self.net._buffers_flat.items():
+                t.copy_(snap["bufs"][k])
+            self.net.params_changed()
+            eng._prepare_shadow()
+        loss_acc = self._loss_sums["train"]  # the captured kernels accumulate into THIS tensor: keep it alive across epochs
 
         def run(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
             if opt.param_groups[0]["lr"] != opt._lr_written:  # scheduler changed the LR: one scalar write, outside the graph
@@ -348,6 +395,9 @@ class PrithviSegmentationModule(_Base):
                 opt._lr_written = opt.param_groups[0]["lr"]
             static_x.copy_(x)
             static_y.copy_(y)
+            if self._loss_sums.get("train") is not loss_acc:  # epoch end popped the accumulator: re-install it, zeroed
+                loss_acc.zero_()
+                self._loss_sums["train"] = loss_acc
             graph.replay()
             opt._host_step += 1
             return stats
@@ -440,6 +490,25 @@ class PrithviDistillationSegmentationModule(PrithviSegmentationModule):
             shared = {k: v for k, v in t_sd.items() if k in s_sd and v.shape == s_sd[k].shape}
             self.net.load_state_dict({**s_sd, **shared}, strict=True)
         self._kl = torch.zeros(1, dtype=torch.float64, device=self.net.store.flat.device)
+
+    def _shared_step(self, batch: Any, step_type: str) -> torch.Tensor:
+        """Compatible (Lightning-style) path of the reference's ``_shared_step`` (segmentation.py:380-451): student forward
+        through autograd, teacher forward under no_grad, loss = CE + KLDiv(batchmean); logs ``<step>_ce_loss`` and
+        ``<step>_distill_loss`` like the fused path."""
+        inputs, labels = batch
+        outputs = self.forward(inputs)
+        with torch.no_grad():
+            t_logits = self.teacher.net.engine.forward(inputs, training=False, save=False)
+        if labels.dtype not in (torch.int64, torch.int32, torch.float32):
+            labels = labels.long()
+        metrics: RunningConfusionMatrix = getattr(self, f"{step_type}_metrics")
+        loss, ce, kl = _SegKDLoss.apply(outputs, t_logits, labels, self._weights(), self.ignore_index, metrics.device_matrix(outputs.device))
+        if step_type == "test":
+            self.test_auc.update_from_logits(outputs.detach(), labels)
+        self.log(f"{step_type}_ce_loss", ce.item())
+        self.log(f"{step_type}_distill_loss", kl.item())
+        self._accumulate_loss(step_type, loss.detach())
+        return loss
 
     def _fused_loss(self, logits, labels, stats, dlogits, step_type: str) -> None:
         super()._fused_loss(logits, labels, stats, dlogits, step_type)  # CE statistics, CE gradient, confusion matrix, AUC

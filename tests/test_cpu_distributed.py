@@ -81,6 +81,66 @@ def test_two_rank_gloo_data_parallel_path():
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
 
 
+def _uneven_worker(rank: int, world: int, port: int, q) -> None:
+    """The collective pattern of run.train() on a dataset that does not split evenly: one gradient all-reduce per step,
+    then the epoch-end metric all-reduce.  With unequal step counts the ranks would issue MISMATCHED collectives (hang)."""
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "instageo-e2e-geospatial-ml_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from instageo_amd import distributed as D
+    from instageo_amd.run import _batches
+
+    D.init_from_env(backend="gloo")
+    try:
+        out = []
+        for n, bs in ((17, 8), (1025, 16), (5, 4)):
+            ds = list(range(n))
+            steps = 0
+            for ids in _batches(ds, bs, True, 3, rank, world, equal=True):
+                g = torch.ones(4) * len(ids)
+                dist.all_reduce(g)  # the per-step gradient exchange
+                steps += 1
+            cm = torch.ones(2, 2, dtype=torch.int64)
+            D.reduce_confusion(cm)  # epoch end
+            assert int(cm[0, 0]) == world
+            out.append(steps)
+        q.put((rank, out))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_uneven_dataset_same_step_count():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res[0] == res[1] == [2, 33, 1], res  # ceil(ceil(n / world) / bs) on BOTH ranks
+
+
+def test_shard_indices_distributed_sampler_semantics():
+    from instageo_amd.run import shard_indices
+
+    for n, world in ((17, 2), (1025, 8), (5, 4), (16, 4), (3, 8)):
+        parts = [shard_indices(n, True, 1, r, world, equal=True) for r in range(world)]
+        per = -(-n // world)
+        assert all(len(p) == per for p in parts), (n, world, [len(p) for p in parts])  # equal counts: same number of steps
+        assert set(i for p in parts for i in p) == set(range(n))                      # every item is seen
+        exact = [shard_indices(n, False, 0, r, world, equal=False) for r in range(world)]
+        assert sorted(i for p in exact for i in p) == list(range(n))                   # eval: each item exactly once
+    assert shard_indices(0, True, 0, 0, 2, equal=True) == []
+    # the shuffle is a function of the epoch only (same permutation on every rank)
+    assert shard_indices(10, True, 5, 0, 1, True) == shard_indices(10, True, 5, 0, 1, True) != shard_indices(10, True, 6, 0, 1, True)
+
+
 def test_shard_range_properties():
     from instageo_amd.distributed import shard_range
 

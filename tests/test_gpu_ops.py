@@ -175,6 +175,52 @@ def test_linear_dgrad_wgrad(split, M, N, K):
 
 
 @pytest.mark.parametrize("split", SPLITS)
+@pytest.mark.parametrize("M,N,K,force", [(1000, 256, 512, "2"), (21276, 768, 3072, "1"), (5000, 2304, 768, "2"), (333, 192, 64, "1"), (2300, 768, 768, "2")])
+def test_linear_dgrad_wt(split, M, N, K, force, monkeypatch):
+    """dx = dy @ w through the TRANSPOSED weight copy (ig_transpose_bf16 + ig_linear_dgrad_wt): the K-contiguous form on the
+    256 x 256 x 64 engine (forced for every covered shape with IG_GEMM8=2) or the generic engines, plain and with the saved
+    gelu' factor + fused column sums; bit-identical across launches."""
+    monkeypatch.setenv("IG_GEMM8", force)
+    dy, dyr = bt(rnd(M, N, seed=5), split)
+    w, wr = bt(rnd(N, K, seed=6, scale=N**-0.5), split)
+    wt = BT.empty((K, N), split, DEV)
+    if N % 64 == 0 and K % 64 == 0:
+        ops.transpose_bf16(w, wt, N, K)
+    else:
+        wt = BT(w.hi.t().contiguous(), None if w.lo is None else w.lo.t().contiguous())
+    assert torch.equal(wt.hi, w.hi.t().contiguous()) and (not split or torch.equal(wt.lo, w.lo.t().contiguous())), "transpose"
+    dx = BT.zeros((M, K), split, DEV)
+    ops.linear_dgrad(dy, None, dx, M, N, K, wt=wt)
+    close(dx.float(), dyr @ wr, tol_out(split), what="dgrad (wt)")
+    first = dx.hi.clone()
+    for _ in range(4):
+        dx.hi.zero_()
+        ops.linear_dgrad(dy, None, dx, M, N, K, wt=wt)
+        assert torch.equal(dx.hi, first), "dgrad (wt) differs between identical launches"
+    pre, gref = bt(rnd(M, K, seed=8), split)
+    cs = torch.zeros(K, device=DEV)
+    ops.linear_dgrad(dy, None, dx, M, N, K, pre=pre, colsum=cs, wt=wt)
+    close(dx.float(), (dyr @ wr) * gref, tol_out(split), what="dgrad*dact (wt)")
+    close(cs, ((dyr @ wr) * gref).sum(0), 3e-5, what="fused column sums (wt)")
+    ops.linear_dgrad(dy, None, dx, M, N, K, pre=pre, wt=wt)  # without the column sums
+    close(dx.float(), (dyr @ wr) * gref, tol_out(split), what="dgrad*dact, no colsum (wt)")
+
+
+def test_transpose_bf16_batched():
+    R, C, nb = 192, 128, 3
+    src = BT.from_float(torch.randn(nb * R * C + 64, device=DEV), True)  # matrices 8 elements apart from contiguous
+    dst = BT.zeros((nb * R * C + 128,), True, DEV)
+    ops.transpose_bf16(src, dst, R, C, nb, R * C + 8, R * C + 16)
+    for b in range(nb):
+        for a, o in ((src.hi, dst.hi), (src.lo, dst.lo)):
+            m = a[b * (R * C + 8) : b * (R * C + 8) + R * C].view(R, C)
+            t = o[b * (R * C + 16) : b * (R * C + 16) + R * C].view(C, R)
+            assert torch.equal(t, m.t()), f"matrix {b}"
+    with pytest.raises(Exception):
+        ops.transpose_bf16(src, dst, 100, 64)
+
+
+@pytest.mark.parametrize("split", SPLITS)
 @pytest.mark.parametrize("T", [1, 3])
 def test_patch_embed(split, T):
     B, C, H, W, p, D = 2, 6, 64, 48, 16, 64
