@@ -1,19 +1,30 @@
 #!/usr/bin/env python3
 """Headline benchmark: Prithvi-100M segmentation training step (fwd + CE + bwd + AdamW) in chips/s.
 
-Contract: ``python bench.py --gpus N --steps K --warmup W`` (for N>1 launched by torch.distributed.run, one
-rank per GPU over RCCL).  Prints ONE JSON line on rank 0.  Workload = BASELINE.json configs[1]: Prithvi-100M
-fine-tune on Sen1Floods11-shaped synthetic chips (6 bands, T=1, 224x224, 2 classes, class weights [1,3],
-ignore_index -1, dropout on), bf16 MFMA, per-GPU batch ``--batch`` (weak scaling).  A step = K0 normalise of a
-resident int16 batch -> forward -> loss/metrics -> backward -> (gradient all-reduce) -> AdamW.
+Contract: ``python bench.py --gpus N --steps K --warmup W`` (for N>1 launched by torch.distributed.run, one rank per GPU over
+RCCL).  Prints ONE JSON line on rank 0.  Workload = BASELINE.json configs[1]: Prithvi-100M fine-tune on Sen1Floods11-shaped
+synthetic chips (6 bands, T=1, 224x224, 2 classes, class weights [1,3], ignore_index -1, dropout on), bf16 MFMA, per-GPU batch
+``--batch`` (weak scaling).  A step = K0 normalise of a resident int16 batch -> forward -> loss/metrics -> backward ->
+(gradient all-reduce) -> AdamW.
 
-Extra objects: ``roofline`` (dominant MFMA kernel: algorithmic FLOPs / HIP-event time per launch over the timed
-region), ``roofline_all`` (every profiled entry point), ``inference`` (fwd + argmax chips/s), and at N=1
-``cpu_baseline`` (the CPU oracle's training step timed on the host cores).
+Objects on the line (besides the contract keys):
+  roofline           the dominant KERNEL of the timed region (per-step time = launches/step x average launch): algorithmic FLOPs
+                     of its launches / HIP-event time, against the dense bf16 MFMA peak; `traffic` from the committed PMC passes
+  roofline_kernels   every MFMA kernel, keyed by the name rocprofv3 prints (namespaces / blanks stripped), from a separate
+                     untimed 3-step pass with events on every launch -- re-derivable from profiles/r02_*_kernel_stats.csv
+  encoder_fwd        the encoder forward alone (patch embed + L blocks + final LayerNorm): the north-star target is stated on it
+  inference          K0 + forward + argmax(int8) chips/s
+  parity_mode        the SAME workload in the bf16x3 precision mode -- the mode that meets the 1e-3 logits/mIoU parity bar
+  tile_inference     BASELINE.json configs[3]: sliding-window chip inference over a resident 10980^2 int16 tile, windows/s
+                     including the window gather (N=1 only)
+  hbm_ops            HBM-bound entry points: algorithmic bytes / HIP-event time against 8 TB/s
+  cpu_baseline       N=1: the CPU oracle (kind "port") on the host cores: configs[0] forward (B=4) and the train step
+  dist               N>1: ranks, backend, per-bucket all-reduce milliseconds of the last step
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
 import sys
@@ -31,11 +42,10 @@ MEAN = [0.14245495, 0.13921481, 0.12434631, 0.31420089, 0.20743526, 0.12046503] 
 STD = [0.04036231, 0.04186983, 0.05267646, 0.0822221, 0.06834774, 0.05294205]
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBPS = 8000.0     # HBM3E (MI355X_MICROARCH.md)
-FLOP_PER_CHIP_FWD = 47.85e9  # 100M, T=1, 2 classes
 
 
-def flop_per_chip_fwd(D: int, L: int, T: int, ncls: int) -> float:
-    """blocks 24*N*D^2 + 4*N^2*D, patch embed, 4 head stages, classifier."""
+def flop_per_chip_fwd(D: int, L: int, T: int, ncls: int):
+    """blocks 24*N*D^2 + 4*N^2*D, patch embed, 4 head stages, classifier -> (total, encoder)."""
     N = 1 + 196 * T
     enc = L * (24.0 * N * D * D + 4.0 * N * N * D) + 2.0 * (196 * T) * 1536 * D
     head = 0.0
@@ -43,40 +53,52 @@ def flop_per_chip_fwd(D: int, L: int, T: int, ncls: int) -> float:
         cin, hin = D * T / 2**i, 14 * 2**i
         cout = cin / 2
         head += 2 * cin * cout * 9 * hin**2 + 2 * cout * cout * 9 * (2 * hin) ** 2
-    return enc + head + 2.0 * (D * T / 16) * ncls * 224**2
+    return enc + head + 2.0 * (D * T / 16) * ncls * 224**2, enc
+
+
 GEMM_OPS = ["ig_linear_fwd", "ig_linear_residual_fwd", "ig_linear_dgrad", "ig_linear_wgrad", "ig_attention_fwd", "ig_attention_bwd",
             "ig_convT_fwd", "ig_convT_dgrad", "ig_convT_wgrad", "ig_conv3x3_fwd", "ig_conv3x3_dgrad", "ig_conv3x3_wgrad",
             "ig_patch_embed_fwd"]  # fmt: skip
 HBM_OPS = ["ig_normalize_chips", "ig_layernorm_fwd", "ig_layernorm_bwd", "ig_colsum", "ig_bn_relu_fwd", "ig_bn_relu_bwd",
            "ig_classifier_fwd", "ig_classifier_bwd", "ig_ce_loss", "ig_adamw_step"]
 TIMED_OPS = ["ig_linear_fwd", "ig_linear_residual_fwd", "ig_linear_dgrad", "ig_linear_wgrad"]
-KERNEL_OF = {
-    "ig_linear_fwd": "gemm2_kernel<PlainLoader,PlainLoader,EpStore,false,false,1,32>",
-    "ig_linear_residual_fwd": "gemm2_kernel<PlainLoader,PlainLoader,EpResidual,false,false,1,32>",  # fc2 (K = 4D) runs on gemm5_kernel
-    "ig_linear_dgrad": "gemm5_kernel<PlainLoader,PlainLoader,EpGradStore,false,true,1>",  # d_fc2 (with gelu') stays on gemm2_kernel
-    "ig_linear_wgrad": "gemm2_kernel<PlainLoader,PlainLoader,EpAtomic,true,true,1,32,2>",
-}
 
 
-def cpu_baseline(target_s: float = 12.0) -> dict:
-    """The oracle's reference-semantics training step (fp32, B=4, 100M T=1) on the host cores: kind 'port'."""
+def cpu_baseline(target_s: float = 10.0) -> dict:
+    """The oracle's reference-semantics path on the host cores (fp32, Prithvi-100M T=1, B=4): kind 'port'.
+    (i) BASELINE.json configs[0]: forward of 4 chips, median of >= 10 runs after 2 warm-ups (BASELINE.md section 4);
+    (ii) the training step (fwd + CE + bwd + AdamW) for a bounded sample."""
+    import statistics
+
+    from instageo_amd.config import PRESETS
     from oracle import prithvi_oracle as O
-    from oracle.cases import class_weights_for
 
+    host_cores = os.cpu_count() or 1
     # a batch of 4 chips does not scale to 100+ threads (MKL/oneDNN oversubscription made it 4x slower than 8 threads)
-    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
-
+    threads = max(1, min(32, host_cores))
+    torch.set_num_threads(threads)
     cfg = O.make_config("prithvi_eo_v1_100", 1, 2)
     sd = O.make_state_dict(cfg, seed=1042)
     B = 4
     g = torch.Generator().manual_seed(1042)
     img = torch.randn(B, 6, 1, 224, 224, generator=g)
     lab = torch.randint(0, 2, (B, 224, 224), generator=g)
+    with torch.no_grad():
+        for _ in range(2):
+            O.prithvi_seg_forward(cfg, sd, img, training=False)
+        ts = []
+        t_all = time.time()
+        while len(ts) < 10 or (time.time() - t_all < 0.4 * target_s and len(ts) < 40):
+            t0 = time.time()
+            O.prithvi_seg_forward(cfg, sd, img, training=False)
+            ts.append(time.time() - t0)
+    fwd = {"value": round(B / statistics.median(ts), 3), "unit": "chips/s", "runs": len(ts), "median_s": round(statistics.median(ts), 4),
+           "workload": "BASELINE.json configs[0]: PrithviSeg forward, 4 random 224x224x6 T=1 chips, fp32"}  # fmt: skip
     names = [k for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k and not k.endswith("pos_embed")]
     params = {k: sd[k].clone().requires_grad_(True) for k in names}
     opt = torch.optim.AdamW(list(params.values()), lr=1e-4, weight_decay=1e-2)
     full = dict(sd)
-    cw = class_weights_for(2)
+    cw = torch.tensor([float(w) for w in PRESETS["sen1floods11"]["train"]["class_weights"]])
 
     def step():
         full.update(params)
@@ -88,12 +110,14 @@ def cpu_baseline(target_s: float = 12.0) -> dict:
     step()  # warm-up
     t0 = time.time()
     n = 0
-    while n < 2 or time.time() - t0 < target_s:
+    while n < 2 or time.time() - t0 < 0.6 * target_s:
         step()
         n += 1
     dt = time.time() - t0
-    return {"value": round(B * n / dt, 3), "unit": "chips/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} train steps (fwd+CE+bwd+AdamW) of batch {B}, Prithvi-100M T=1, fp32 CPU oracle, {dt:.1f} s"}  # fmt: skip
+    return {"value": round(B * n / dt, 3), "unit": "chips/s", "cores": threads, "host_cores": host_cores, "kind": "port",
+            "sample": f"{n} train steps (fwd+CE+bwd+AdamW) of batch {B}, Prithvi-100M T=1, fp32 CPU oracle, {dt:.1f} s; {threads} of "
+                      f"{host_cores} host cores (torch intra-op threads)",
+            "forward_configs0": fwd}  # fmt: skip
 
 
 def main() -> None:
@@ -107,6 +131,9 @@ def main() -> None:
     ap.add_argument("--temporal", type=int, default=1, help="T: 1 = configs[1] (default), 3 = configs[2] multi-temporal crop")
     ap.add_argument("--classes", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-leg", action="store_true", help="skip the bf16x3 (1e-3-parity) leg")
+    ap.add_argument("--no-tile", action="store_true", help="skip the configs[3] sliding-window leg")
+    ap.add_argument("--tile-size", type=int, default=10980)
     ap.add_argument("--event-stride", type=int, default=7, help="bracket every n-th launch of the timed entry points with HIP events")
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP events (roofline objects become null)")
     ap.add_argument("--graph", action="store_true", help="replay the train step from one captured hipGraph (N=1 only; implies --no-profile)")
@@ -114,6 +141,7 @@ def main() -> None:
 
     from instageo_amd import distributed as D
     from instageo_amd import ops
+    from instageo_amd.config import PRESETS
     from instageo_amd.segmentation import PrithviSegmentationModule
 
     rank, local_rank, world = D.init_from_env()
@@ -125,13 +153,8 @@ def main() -> None:
 
     B = args.batch
     T, NCLS = args.temporal, args.classes
-    from oracle.cases import CROP_WEIGHTS  # data only (class weights of multitemporal_crop_classification.yaml)
-
-    cw = [1, 3] if NCLS == 2 else (CROP_WEIGHTS if NCLS == 13 else [1.0] * NCLS)
-    mod = PrithviSegmentationModule(image_size=224, learning_rate=1e-4, freeze_backbone=False, load_pretrained_weights=False,
-                                    num_classes=NCLS, temporal_step=T, class_weights=cw, ignore_index=-1, weight_decay=0.01,
-                                    scheduler=False, model_name=args.model, precision=args.precision, device=dev)  # fmt: skip
-    D.attach_data_parallel(mod)
+    crop_w = PRESETS["multitemporal_crop_classification"]["train"]["class_weights"]  # multitemporal_crop_classification.yaml:15-30
+    cw = [1, 3] if NCLS == 2 else (crop_w if NCLS == len(crop_w) else [1.0] * NCLS)
     mean = torch.tensor(MEAN, device=dev)
     std = torch.tensor(STD, device=dev)
     nb = 4  # resident synthetic batches (raw int16 HLS domain), cycled
@@ -143,83 +166,136 @@ def main() -> None:
         y[torch.rand((B, 224, 224), generator=g, device=dev) < 0.05] = -1
         labels.append(y)
     xbuf = torch.empty((B, 6, T, 224, 224), dtype=torch.float32, device=dev)
-    stats = torch.zeros(2, dtype=torch.float64, device=dev)
-
-    graphed = None
-    if args.graph and world == 1:
-        args.no_profile = True
-        ops.normalize_chips(raws[0], mean, std, T, 1e-4, out=xbuf)
-        graphed = mod.make_graphed_train_step(xbuf, labels[0])
-
-    def train_step(i: int) -> None:
-        ops.normalize_chips(raws[i % nb], mean, std, T, 1e-4, out=xbuf)
-        if graphed is not None:
-            stats.copy_(graphed(xbuf, labels[i % nb]))
-        else:
-            mod.fused_train_step(xbuf, labels[i % nb], stats=stats)
 
     def barrier() -> None:
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        train_step(i)
-    barrier()
-    if not args.no_profile:
-        # Only the dominant (linear GEMM) entry points carry events inside the timed region, and only every 7th launch of
-        # each: an event pair costs a few microseconds of queue drain, which at ~145 GEMM launches per step was 8 % of the
-        # step.  7 is coprime with the per-block launch pattern (qkv/proj/fc1/fc2), so the sample keeps the shape mix.
-        ops.profile_begin(TIMED_OPS, stride=args.event_stride)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        train_step(i)
-    barrier()
-    dt = time.perf_counter() - t0
-    prof = ops.profile_end() if not args.no_profile else None
-    loss = (stats[0] / stats[1]).item()
-    prof_all = None
-    if not args.no_profile:  # every MFMA entry point, in a separate untimed pass of 3 steps
-        ops.profile_begin(GEMM_OPS + HBM_OPS)
-        for i in range(3):
+    def max_over_ranks(x: float) -> float:
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.item()
+
+    def run_mode(precision: str, profile: bool, graph: bool):
+        """Train + inference (+ encoder-forward) legs of one precision mode; returns a dict of raw measurements."""
+        mod = PrithviSegmentationModule(image_size=224, learning_rate=1e-4, freeze_backbone=False, load_pretrained_weights=False,
+                                        num_classes=NCLS, temporal_step=T, class_weights=cw, ignore_index=-1, weight_decay=0.01,
+                                        scheduler=False, model_name=args.model, precision=precision, device=dev)  # fmt: skip
+        sync = D.attach_data_parallel(mod)
+        stats = torch.zeros(2, dtype=torch.float64, device=dev)
+        graphed = None
+        if graph and world == 1:
+            ops.normalize_chips(raws[0], mean, std, T, 1e-4, out=xbuf)
+            graphed = mod.make_graphed_train_step(xbuf, labels[0])
+
+        def train_step(i: int) -> None:
+            ops.normalize_chips(raws[i % nb], mean, std, T, 1e-4, out=xbuf)
+            if graphed is not None:
+                stats.copy_(graphed(xbuf, labels[i % nb]))
+            else:
+                mod.fused_train_step(xbuf, labels[i % nb], stats=stats)
+
+        for i in range(args.warmup):
             train_step(i)
-        prof_all = ops.profile_end()
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = t.item()
-
-    # inference leg: K0 + forward + argmax(int8)  (chip_inference loop, infer_utils.py:93-101)
-    mod.net.eval()
-    pred = torch.empty((B, 224, 224), dtype=torch.int8, device=dev)
-
-    def infer_step(i: int) -> None:
-        ops.normalize_chips(raws[i % nb], mean, std, T, 1e-4, out=xbuf)
-        logits = mod.net.engine.forward(xbuf, training=False, save=False)
-        ops.argmax_i8(logits, pred)
-
-    with torch.no_grad():
-        for i in range(max(2, args.warmup // 2)):
-            infer_step(i)
         barrier()
-        t1 = time.perf_counter()
+        if profile:
+            # Only the dominant (linear GEMM) entry points carry events inside the timed region, and only every 7th launch of
+            # each: an event pair costs a few microseconds of queue drain, which at ~145 GEMM launches per step was 8 % of the
+            # step.  7 is coprime with the per-block launch pattern (qkv/proj/fc1/fc2), so the sample keeps the shape mix.
+            ops.profile_begin(TIMED_OPS, stride=args.event_stride)
+        t0 = time.perf_counter()
         for i in range(args.steps):
-            infer_step(i)
+            train_step(i)
         barrier()
-        dti = time.perf_counter() - t1
-    ti = torch.tensor([dti], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(ti, op=dist.ReduceOp.MAX)
-    dti = ti.item()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        res = {"mod": mod, "dt": dt, "prof": ops.profile_end() if profile else None, "prof_all": None, "graphed": graphed is not None,
+               "loss": (stats[0] / stats[1]).item(), "buckets": None}
+        if sync is not None:  # per-bucket all-reduce time of one extra, instrumented step (outside the timed region)
+            sync.time_buckets = True
+            train_step(0)
+            torch.cuda.synchronize()
+            res["buckets"] = [{"mbytes": round((hi - lo) * 4 / 2**20, 1), "ms": round(ms, 3)} for (lo, hi), ms in sync.bucket_times()]
+            sync.time_buckets = False
+        if profile:  # every MFMA / HBM entry point, in a separate untimed pass of 3 steps
+            ops.profile_begin(GEMM_OPS + HBM_OPS)
+            for i in range(3):
+                train_step(i)
+            res["prof_all"] = ops.profile_end()
+        # inference leg: K0 + forward + argmax(int8)  (chip_inference loop, infer_utils.py:93-101)
+        mod.net.eval()
+        pred = torch.empty((B, 224, 224), dtype=torch.int8, device=dev)
+        eng = mod.net.engine
+
+        def infer_step(i: int) -> None:
+            ops.normalize_chips(raws[i % nb], mean, std, T, 1e-4, out=xbuf)
+            ops.argmax_i8(eng.forward(xbuf, training=False, save=False), pred)
+
+        with torch.no_grad():
+            for i in range(max(2, args.warmup // 2)):
+                infer_step(i)
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                infer_step(i)
+            barrier()
+            res["dti"] = max_over_ranks(time.perf_counter() - t1)
+            # encoder forward alone: HIP events on the launch stream around K passes
+            for _ in range(2):
+                eng.encoder_forward(xbuf, save=False)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.steps):
+                eng.encoder_forward(xbuf, save=False)
+            e1.record()
+            torch.cuda.synchronize()
+            res["enc_ms"] = e0.elapsed_time(e1) / args.steps
+        return res
+
+    main_res = run_mode(args.precision, not args.no_profile and not args.graph, args.graph)
+    mod = main_res["mod"]
+    cfgm = mod.net.cfg
+    fpc, fpc_enc = flop_per_chip_fwd(cfgm.embed_dim, cfgm.depth, T, NCLS)
+
+    tile_leg = None
+    if world == 1 and not args.no_tile and (T, args.model) == (1, "prithvi_eo_v1_100"):
+        # BASELINE.json configs[3]: one resident 6 x S x S int16 tile -> (S // 224)^2 windows, gather + normalise + forward + argmax
+        from instageo_amd.infer_utils import sliding_window_inference
+
+        S = args.tile_size
+        gt = torch.Generator(device=dev).manual_seed(7)
+        tile = torch.randint(0, 10000, (6, S, S), generator=gt, device=dev, dtype=torch.int16)
+        half = torch.randint(0, 10000, (6, 1344, 1344), generator=gt, device=dev, dtype=torch.int16)
+        sliding_window_inference(half, mod, MEAN, STD, 1, 224, 224, batch_size=B, constant_multiplier=1e-4)  # warm-up (36 windows)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        maps, origins = sliding_window_inference(tile, mod, MEAN, STD, 1, 224, 224, batch_size=B, constant_multiplier=1e-4)
+        torch.cuda.synchronize()
+        dtt = time.perf_counter() - t0
+        tile_leg = {"workload": f"BASELINE.json configs[3]: sliding-window chip_inference over a resident 6x{S}x{S} int16 tile, "
+                                f"{len(origins)} windows of 224 (stride 224), batch {B}, window gather + normalise included",
+                    "value": round(len(origins) / dtt, 1), "unit": "windows/s", "seconds": round(dtt, 4), "windows": len(origins),
+                    "class_histogram": torch.bincount(maps.flatten().long() + 1, minlength=NCLS + 1)[1:].tolist()}  # fmt: skip
+        del tile, half, maps
+
+    parity = None
+    if args.precision == "bf16" and not args.no_parity_leg and not args.graph:
+        del mod
+        main_mod_freed = main_res.pop("mod")
+        del main_mod_freed
+        torch.cuda.empty_cache()
+        parity = run_mode("bf16x3", False, False)
+        parity.pop("mod")
+        torch.cuda.empty_cache()
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
+    dt, dti = main_res["dt"], main_res["dti"]
     value = world * B * args.steps / dt
-    cfgm = mod.net.cfg
-    fpc = flop_per_chip_fwd(cfgm.embed_dim, cfgm.depth, T, NCLS)
     out = {
         "metric": f"HLS chips/sec (train fwd+bwd+AdamW), {args.model} 224x224x6 T={T}",
         "value": round(value, 2),
@@ -238,44 +314,68 @@ def main() -> None:
                    if (T, NCLS, args.model) == (1, 2, "prithvi_eo_v1_100") else
                    f"{args.model} T={T} {NCLS} classes, synthetic int16 chips, dropout 0.1, random-init weights",
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "optimizer": "AdamW lr 1e-4 wd 1e-2",
-                   "launch": "hipGraph" if graphed is not None else "eager",
-                   "final_loss": round(loss, 5)},  # fmt: skip
+                   "launch": "hipGraph" if main_res["graphed"] else "eager",
+                   "final_loss": round(main_res["loss"], 5)},  # fmt: skip
         "mfma_frac_whole_step": round(value / world * 3 * fpc / (PEAK_BF16_TFLOPS * 1e12), 4),
         "gflop_per_chip_fwd": round(fpc / 1e9, 2),
         "inference": {"value": round(world * B * args.steps / dti, 2), "unit": "chips/s", "ms_per_step": round(1e3 * dti / args.steps, 3),
                       "mfma_frac": round(B * args.steps / dti * fpc / (PEAK_BF16_TFLOPS * 1e12), 4)},  # fmt: skip
+        "encoder_fwd": {"ms": round(main_res["enc_ms"], 3), "gflop_per_chip": round(fpc_enc / 1e9, 2),
+                        "achieved_tflops": round(B * fpc_enc / (main_res["enc_ms"] * 1e-3) / 1e12, 1),
+                        "mfma_frac": round(B * fpc_enc / (main_res["enc_ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                        "chips_per_s": round(B / (main_res["enc_ms"] * 1e-3), 1),
+                        "note": "patch embed + blocks + final LayerNorm on one GPU, HIP events over the same K passes"},  # fmt: skip
     }
+    if parity is not None:
+        pv = world * B * args.steps / parity["dt"]
+        pi = world * B * args.steps / parity["dti"]
+        out["parity_mode"] = {
+            "dtype": "bf16x3", "value": round(pv, 2), "unit": "chips/s", "ms_per_step": round(1e3 * parity["dt"] / args.steps, 3),
+            "mfma_frac_of_x3_ceiling": round(pv / world * 3 * fpc / (PEAK_BF16_TFLOPS / 3 * 1e12), 4),
+            "inference": {"value": round(pi, 2), "unit": "chips/s", "ms_per_step": round(1e3 * parity["dti"] / args.steps, 3)},
+            "encoder_fwd_ms": round(parity["enc_ms"], 3), "final_loss": round(parity["loss"], 5),
+            "note": "same workload, batch and step; split-bf16 operands (hi*hi + hi*lo + lo*hi, 3 MFMAs per product: ceiling = "
+                    "peak / 3); this mode meets the north-star 1e-3 logits / mIoU tolerance (tests/test_gpu_model.py)"}  # fmt: skip
+    if tile_leg is not None:
+        out["tile_inference"] = tile_leg
+    prof, prof_all = main_res["prof"], main_res["prof_all"]
     if prof is not None:
-        def table(p):
-            return {name: {"launches": n, "avg_us": round(1e3 * ms / n, 2), "total_ms": round(ms, 2),
-                           "achieved_tflops": round(work / (ms * 1e-3) / 1e12, 1)} for name, (n, ms, work) in p.items() if n}  # fmt: skip
+        def table(p, per_step):
+            return {name: {"launches_per_step": round(r["calls"] / per_step, 2), "timed_launches": r["n"], "avg_us": round(1e3 * r["ms"] / r["n"], 2),
+                           "ms_per_step": round(r["ms"] / r["n"] * r["calls"] / per_step, 3),
+                           "gflop_per_launch": round(r["work"] / r["n"] / 1e9, 2),
+                           "achieved_tflops": round(r["work"] / (r["ms"] * 1e-3) / 1e12, 1),
+                           "frac": round(r["work"] / (r["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
+                    for name, r in p.items() if r["n"]}  # fmt: skip
 
-        timed = table(prof)
-        allk = table({k: v for k, v in prof_all.items() if k in GEMM_OPS})
+        timed_k = table(prof["kernels"], args.steps)
+        all_k = table({k: v for k, v in prof_all["kernels"].items() if v["op"] in GEMM_OPS}, 3)
         # HBM-bound entry points: algorithmic bytes / HIP-event time against the 8 TB/s HBM3E peak
         out["hbm_ops"] = {name: {"launches": n, "avg_us": round(1e3 * ms / n, 2), "total_ms": round(ms, 2),
                                  "achieved_GBps": round(work / (ms * 1e-3) / 1e9, 1),
                                  "frac_of_peak": round(work / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 3)}
-                          for name, (n, ms, work) in prof_all.items() if n and name in HBM_OPS}  # fmt: skip
-        dom = max(timed, key=lambda k: timed[k]["total_ms"])
-        n, ms, work = prof[dom]
-        ach = work / (ms * 1e-3) / 1e12
-        out["roofline"] = {"kernel": KERNEL_OF.get(dom, dom), "entry_point": dom, "bound": "mfma", "achieved": round(ach, 1),
-                           "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                           "launches": n, "avg_launch_us": round(1e3 * ms / n, 2), "flops_per_launch": work / n,
-                           "event_stride": args.event_stride}  # fmt: skip
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_bench_b108.json")
-        if os.path.exists(pmc_path) and B == 108 and (T, NCLS, args.model) == (1, 2, "prithvi_eo_v1_100"):
+                          for name, (n, ms, work) in prof_all["ops"].items() if n and name in HBM_OPS}  # fmt: skip
+        dom = max(timed_k, key=lambda k: timed_k[k]["ms_per_step"])
+        d = timed_k[dom]
+        out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": d["achieved_tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                           "frac": d["frac"], "traffic": None, "launches_per_step": d["launches_per_step"], "avg_launch_us": d["avg_us"],
+                           "ms_per_step": d["ms_per_step"], "gflop_per_launch": d["gflop_per_launch"], "timed_launches": d["timed_launches"],
+                           "event_stride": args.event_stride,
+                           "note": "dominant kernel of the timed region by launches/step x average launch; events on the launch stream"}  # fmt: skip
+        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_bench_b108.json")))
+        if pmc_files and B == 108 and (T, NCLS, args.model) == (1, 2, "prithvi_eo_v1_100"):
             # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
-            # (tools: see DESIGN.md 6); FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md
-            pmc = json.load(open(pmc_path))
-            key = KERNEL_OF.get(dom, dom).replace(",", ", ")
-            ent = next((v for k, v in pmc.items() if k.replace(" ", "") == key.replace(" ", "")), None)
+            # (tools/pmc_bench.sh); FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md
+            pmc = json.load(open(pmc_files[-1]))
+            ent = next((v for k, v in pmc.items() if k.replace(" ", "") == dom), None)
             if ent:
                 out["roofline"]["traffic"] = round((2 * ent["fetch_kb_raw"] + ent["write_kb"]) * 1024)
-                out["roofline"]["traffic_note"] = "bytes/launch, offline PMC passes (profiles/r01_pmc_bench_b108.json)"
-        out["roofline_timed_region"] = timed
-        out["roofline_all"] = allk  # separate untimed pass (3 steps) with events on every MFMA entry point
+                out["roofline"]["traffic_note"] = f"bytes/launch, offline PMC passes ({os.path.relpath(pmc_files[-1], ROOT)})"
+        out["roofline_timed_region"] = timed_k
+        out["roofline_kernels"] = all_k
+    if world > 1:
+        out["dist"] = {"ranks": world, "backend": dist.get_backend(), "reserved_cus": ops.reserved_cus(),
+                       "allreduce_buckets": main_res["buckets"]}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))

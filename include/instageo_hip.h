@@ -31,6 +31,8 @@ const char* ig_last_error(void);
 /* name of the (last) kernel the most recent MFMA entry point of this thread launched, as rocprofv3 prints it minus
  * "(anonymous namespace)::" and blanks -- bench.py keys its per-kernel roofline table by it */
 const char* ig_last_kernel(void);
+int ig_note_reset(void); /* forget the name (an entry point without a named kernel then reports "") */
+int ig_last_grid(void);  /* workgroups of the last persistent GEMM launch of this thread (see ig_set_reserved_cus) */
 int ig_version(void);
 /* first 32 bits of the MD5 of this header as the library was built against it: the host mirror refuses a library whose
  * entry points were compiled from a different revision of the declarations (stale .so next to a newer header) */
@@ -53,6 +55,12 @@ int ig_normalize_chips(const void* src, int src_dtype, const float* mean, const 
 int ig_crop_flip_normalize(const void* src, int src_dtype, const float* mean, const float* stdv, double mult, int mult_enabled,
                            const int* params, float* dst, const float* labels_in, float* labels_out, int B, int T, int C, int Hs,
                            int Ws, int im, void* stream);
+/* Sliding-window gather + normalise (process_test / crop_array, dataloader.py:588-669; chip_inference over a tile,
+ * BASELINE configs[3]): tile (T*C, Hs, Ws) int16|f32 and origins[i] = {top, left} -> dst (n, C, T, crop, crop) f32 normalised,
+ * optionally the same windows of a label tile (Hs, Ws) f32 -> (n, crop, crop).  One launch for all n windows. */
+int ig_normalize_windows(const void* tile, int src_dtype, const float* mean, const float* stdv, double mult, int mult_enabled,
+                         const int* origins, float* dst, const float* labels_tile, float* labels_out, int n, int T, int C, int Hs,
+                         int Ws, int crop, void* stream);
 /* mode=stats reduction (pipeline_utils.py:207-254): sums[c] += mean_bc, sums[C+c] += biased var_bc over (T,H,W) for every
  * chip b of x (B, C, T, H, W) f32; counts[v - lo] += 1 per label value (counts[nbins] = everything else) */
 int ig_chip_stats(const float* x, double* sums, int B, int C, long n_per_channel, void* stream);

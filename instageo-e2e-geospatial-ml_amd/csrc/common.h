@@ -55,6 +55,7 @@ int ig_gemm8_nt(const G8Params& p, void* stream);  // IG_ERR_UNSUPPORTED (no err
 // runtime.hip: name of the kernel an entry point launched last on this thread (rocprofv3's demangled name without namespaces and
 // spaces), so bench.py can key its per-kernel roofline table by the names the rocprof summaries under profiles/ use
 void ig_note_kernel(const char* fmt, ...);
+void ig_note_grid(int workgroups);  // workgroups of the last persistent GEMM launch (ig_last_grid: the reserved-CU rule is testable)
 int ig_reserved_cus();
 int ig_cu_count();
 

@@ -58,7 +58,7 @@ template <typename SRC>
 __global__ void crop_flip_normalize_kernel(const SRC* __restrict__ src, float* __restrict__ dst, const float* __restrict__ mean,
                                            const float* __restrict__ stdv, double mult, int use_mult, const int* __restrict__ params,
                                            const float* __restrict__ lab_in, float* __restrict__ lab_out, int T, int C, int Hs,
-                                           int Ws, int im, long total4, long img4) {
+                                           int Ws, int im, long total4, long img4, long chip_stride, long lab_stride, int pw) {
     const int q = im / 4;  // quads per output row
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         const bool is_lab = i >= img4;
@@ -77,11 +77,13 @@ __global__ void crop_flip_normalize_kernel(const SRC* __restrict__ src, float* _
         } else {
             b = r;
         }
-        const int top = params[b * 4 + 0], left = params[b * 4 + 1], hf = params[b * 4 + 2], vf = params[b * 4 + 3];
+        // pw = 4: {top, left, hflip, vflip} per chip (training crops); pw = 2: {top, left} window origins into ONE shared tile
+        // (chip_stride = lab_stride = 0: sliding-window inference, dataloader.py:655-664)
+        const int top = params[b * pw + 0], left = params[b * pw + 1], hf = pw == 4 ? params[b * 4 + 2] : 0, vf = pw == 4 ? params[b * 4 + 3] : 0;
         const int sy = top + (vf ? im - 1 - y : y);
         float v[4];
         if (!is_lab) {
-            const SRC* row = src + (((long)b * T + t) * C + c) * ((long)Hs * Ws) + (long)sy * Ws + left;
+            const SRC* row = src + b * chip_stride + ((long)t * C + c) * ((long)Hs * Ws) + (long)sy * Ws + left;
             const float m = mean[c], sd = stdv[c];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -92,7 +94,7 @@ __global__ void crop_flip_normalize_kernel(const SRC* __restrict__ src, float* _
             }
             *reinterpret_cast<float4*>(dst + ((((long)b * C + c) * T + t) * im + y) * im + xq * 4) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
-            const float* row = lab_in + (long)b * Hs * Ws + (long)sy * Ws + left;
+            const float* row = lab_in + b * lab_stride + (long)sy * Ws + left;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int x = xq * 4 + j;
@@ -997,15 +999,43 @@ int ig_crop_flip_normalize(const void* src, int src_dtype, const float* mean, co
     const int grid = grid_for(total4, TPB, 8192);
     if (src_dtype == 0)
         hipLaunchKernelGGL(crop_flip_normalize_kernel<int16_t>, dim3(grid), dim3(TPB), 0, ST(stream), (const int16_t*)src, dst, mean,
-                           stdv, mult, mult_enabled, params, labels_in, labels_out, T, C, Hs, Ws, im, total4, img4);
+                           stdv, mult, mult_enabled, params, labels_in, labels_out, T, C, Hs, Ws, im, total4, img4,
+                           (long)T * C * Hs * Ws, (long)Hs * Ws, 4);
     else if (src_dtype == 1)
         hipLaunchKernelGGL(crop_flip_normalize_kernel<float>, dim3(grid), dim3(TPB), 0, ST(stream), (const float*)src, dst, mean, stdv,
-                           mult, mult_enabled, params, labels_in, labels_out, T, C, Hs, Ws, im, total4, img4);
+                           mult, mult_enabled, params, labels_in, labels_out, T, C, Hs, Ws, im, total4, img4, (long)T * C * Hs * Ws,
+                           (long)Hs * Ws, 4);
     else {
         ig_set_error("ig_crop_flip_normalize: unsupported src_dtype %d", src_dtype);
         return IG_ERR_UNSUPPORTED;
     }
     return ig_check_launch("ig_crop_flip_normalize");
+}
+
+// Sliding-window gather + normalise: n windows of ONE tile in one launch (the reference's process_test loops over the origins
+// in Python and crops / normalises window by window, dataloader.py:618-669)
+int ig_normalize_windows(const void* tile, int src_dtype, const float* mean, const float* stdv, double mult, int mult_enabled,
+                         const int* origins, float* dst, const float* labels_tile, float* labels_out, int n, int T, int C, int Hs,
+                         int Ws, int crop, void* stream) {
+    IG_REQUIRE(tile && mean && stdv && origins && dst, "ig_normalize_windows: null pointer");
+    IG_REQUIRE((labels_tile == nullptr) == (labels_out == nullptr), "ig_normalize_windows: labels_tile and labels_out go together");
+    IG_REQUIRE(n >= 0 && T > 0 && C > 0 && crop > 0 && crop <= Hs && crop <= Ws, "ig_normalize_windows: need 0 < crop <= Hs, Ws");
+    IG_REQUIRE(crop % 4 == 0, "ig_normalize_windows: crop must be a multiple of 4 (got %d)", crop);
+    const long img4 = (long)n * T * C * crop * (crop / 4);
+    const long total4 = img4 + (labels_tile ? (long)n * crop * (crop / 4) : 0L);
+    if (total4 == 0) return IG_OK;
+    const int grid = grid_for(total4, TPB, 8192);
+    if (src_dtype == 0)
+        hipLaunchKernelGGL(crop_flip_normalize_kernel<int16_t>, dim3(grid), dim3(TPB), 0, ST(stream), (const int16_t*)tile, dst, mean,
+                           stdv, mult, mult_enabled, origins, labels_tile, labels_out, T, C, Hs, Ws, crop, total4, img4, 0L, 0L, 2);
+    else if (src_dtype == 1)
+        hipLaunchKernelGGL(crop_flip_normalize_kernel<float>, dim3(grid), dim3(TPB), 0, ST(stream), (const float*)tile, dst, mean, stdv,
+                           mult, mult_enabled, origins, labels_tile, labels_out, T, C, Hs, Ws, crop, total4, img4, 0L, 0L, 2);
+    else {
+        ig_set_error("ig_normalize_windows: unsupported src_dtype %d", src_dtype);
+        return IG_ERR_UNSUPPORTED;
+    }
+    return ig_check_launch("ig_normalize_windows");
 }
 
 int ig_chip_stats(const float* x, double* sums, int B, int C, long n_per_channel, void* stream) {

@@ -1360,7 +1360,8 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, i
     if constexpr (AL::kLinearK && BL::kLinearK) {
         if (ver == 5) {
             const int tm5 = ig_cdiv(M, 256), tn5 = ig_cdiv(N, 256), ntiles = tm5 * tn5;
-            dim3 grid5(ntiles > 256 ? 256 : ntiles, 1, Z);
+            const int cus5 = ig_cu_count() - ig_reserved_cus();  // persistent: one workgroup per (unreserved) CU
+            dim3 grid5(ntiles > cus5 ? cus5 : ntiles, 1, Z);
             int kchunk5 = ig_cdiv(K, 32);
             if constexpr (EP::kStagedAtomic) {  // one tile per workgroup, split-K over blockIdx.y, one workgroup per CU
                 grid5.x = ntiles;
@@ -1385,6 +1386,7 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, i
             attr_done = true;                                                                                          \
         }                                                                                                              \
         ig_note_kernel("gemm5_kernel<%s,%s,%s,%s,%s,%d>", AL::kName, BL::kName, EP::kName, A_TR ? "true" : "false", B_TR ? "true" : "false", NSEG_); \
+        ig_note_grid((int)grid5.x);                                                                                    \
         hipLaunchKernelGGL(kern, grid5, dim3(NTHR5), G5_SMEM, st, al, bl, ep, M, N, K, tn5, ntiles, kchunk5, zp5);     \
     }
             if (split) IG_LAUNCH_V5(3) else IG_LAUNCH_V5(1)
@@ -1443,6 +1445,7 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, i
             attr_done = true;                                                                                             \
         }                                                                                                                 \
         ig_note_kernel("gemm2_kernel<%s,%s,%s,%s,%s,%d,%d,1>", AL::kName, BL::kName, EP::kName, A_TR ? "true" : "false", B_TR ? "true" : "false", NSEG_, BKT_); \
+        ig_note_grid((int)grid.x);                                                                                        \
         hipLaunchKernelGGL(kern, grid, dim3(NTHR2), G2<BKT_>::SMEM, st, al, bl, ep, M, N, K, tn, ntiles, kchunk, zp);     \
     }
         if constexpr (EP::kStagedAtomic) {
@@ -1471,7 +1474,8 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, i
             if (split) IG_LAUNCH_V2(3, 32) else IG_LAUNCH_V2(1, 32)
         } else {
             // persistent: two workgroups per CU walk the tile list; BK = 32 keeps the ring at 72 KiB
-            if ((int)grid.x > 512) grid.x = 512;
+            const int slots2 = 2 * (ig_cu_count() - ig_reserved_cus());  // persistent: two workgroups per (unreserved) CU
+            if ((int)grid.x > slots2) grid.x = slots2;
             kchunk = ig_cdiv(K, 32);
             if (split) IG_LAUNCH_V2(3, 32) else IG_LAUNCH_V2(1, 32)
         }

@@ -419,6 +419,7 @@ int g8_launch(const G8Params& p, int grid, hipStream_t st) {
         attr_done = true;
     }
     ig_note_kernel("gemm8_kernel<%d,%d,%d,%s,%s>", KIND, NSEG, ACT, DACT ? "true" : "false", SPLIT_OUT ? "true" : "false");
+    ig_note_grid(grid);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), G8_SMEM, st, p);
     return ig_check_launch("gemm8");
 }

@@ -16,6 +16,8 @@ void ig_set_error(const char* fmt, ...) {
 }
 
 static thread_local char g_kernel[256] = "";
+static thread_local int g_grid = 0;
+void ig_note_grid(int workgroups) { g_grid = workgroups; }
 void ig_note_kernel(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -65,6 +67,11 @@ int ig_get_reserved_cus(void) { return ig_reserved_cus(); }
 
 const char* ig_last_error(void) { return g_err; }
 const char* ig_last_kernel(void) { return g_kernel; }
+int ig_note_reset(void) {
+    g_kernel[0] = 0;
+    return IG_OK;
+}
+int ig_last_grid(void) { return g_grid; }
 
 int ig_version(void) { return 100; }  // 0.1.0
 

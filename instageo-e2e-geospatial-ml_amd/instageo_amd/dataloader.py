@@ -78,12 +78,34 @@ def extract_windows(tile: torch.Tensor, origins: Sequence[Tuple[int, int]], crop
     return torch.stack([tile[:, t : t + crop_size, l : l + crop_size] for t, l in origins])
 
 
+def origins_tensor(origins: Sequence[Tuple[int, int]], device) -> torch.Tensor:
+    """(n, 2) int32 device tensor of (top, left) rows for ``ig_normalize_windows``."""
+    return torch.tensor(list(origins), dtype=torch.int32).reshape(-1, 2).to(device)
+
+
+def gather_windows(tile: torch.Tensor, origins, mean: Sequence[float], std: Sequence[float], temporal_size: int, crop_size: int,
+                   constant_multiplier: Optional[float] = None, labels: Optional[torch.Tensor] = None,
+                   out: Optional[torch.Tensor] = None):
+    """Windows of ONE tile, gathered and normalised by a single kernel launch (replaces the per-window Python loop of
+    ``crop_array`` + ``normalize_and_convert_to_tensor``): tile (T*C, S, S) int16|f32 on the device, ``origins`` a list of
+    (top, left) or an (n, 2) int32 device tensor -> ((n, C, T, crop, crop) f32, labels (n, crop, crop) f32 or None)."""
+    if not torch.is_tensor(origins):
+        origins = origins_tensor(origins, tile.device)
+    m = torch.as_tensor(mean, dtype=torch.float32, device=tile.device)
+    s = torch.as_tensor(std, dtype=torch.float32, device=tile.device)
+    lab = None if labels is None else labels.to(device=tile.device, dtype=torch.float32).contiguous()
+    return ops.normalize_windows(tile.contiguous(), origins, m, s, temporal_size, crop_size, constant_multiplier, lab, out)
+
+
 def process_test(x, y, mean: Sequence[float], std: Sequence[float], temporal_size: int = 1, img_size: int = 512,
                  crop_size: int = 224, stride: int = 224, constant_multiplier: Optional[float] = None, device: str = "cuda"):
     """Evaluation tiling (dataloader.py:618-669): -> (imgs (n,C,T,crop,crop) f32, labels (n,crop,crop))."""
     xt = _as_device_chip(x, device)
     yt = torch.as_tensor(np.asarray(y) if not torch.is_tensor(y) else y).to(device)
     origins = window_origins(img_size, crop_size, stride)
+    if crop_size % 4 == 0 and yt.dim() == 2 and xt.shape[-2:] == yt.shape:
+        imgs, labels = gather_windows(xt, origins, mean, std, temporal_size, crop_size, constant_multiplier, labels=yt)
+        return imgs, (labels if yt.dtype == torch.float32 else labels.to(yt.dtype))
     imgs = normalize_batch(extract_windows(xt, origins, crop_size), mean, std, temporal_size, constant_multiplier)
     labels = extract_windows(yt, origins, crop_size)
     return imgs, labels
@@ -196,8 +218,9 @@ class ArrayChipDataset(torch.utils.data.Dataset):
 
     def __init__(self, chips, labels, mean, std, temporal: int = 1, constant_multiplier: Optional[float] = None,
                  include_filenames: bool = False, names: Optional[List[str]] = None, device: str = "cuda",
-                 replace_label: Optional[Sequence[float]] = None, reduce_to_zero: bool = False):
+                 replace_label: Optional[Sequence[float]] = None, reduce_to_zero: bool = False, no_data_value: Optional[float] = -9999):
         assert len(chips) == len(labels)
+        self.no_data_value = no_data_value
         self.chips = chips
         # label clean-up of process_data (dataloader.py:742-746): value replacement, then shift to start from zero
         self.labels = [process_label(l, replace_label, reduce_to_zero) for l in labels] if (replace_label or reduce_to_zero) else labels
@@ -216,17 +239,89 @@ class ArrayChipDataset(torch.utils.data.Dataset):
     def __getitem__(self, i: int):
         x, y = normalize_and_convert_to_tensor(self.chips[i], self.labels[i], self.mean, self.std, self.T, self.mult, self.device)
         if self.include_filenames:
-            return (x, y), (self.names[i] if self.names else f"chip_{i:06d}")
+            # third element: the NODATA mask of the chip, ``arr_x == no_data_value`` AFTER the constant multiplier exactly as the
+            # reference computes it (dataloader.py:895-900; process_data has already scaled arr_x there)
+            return (x, y), (self.names[i] if self.names else f"chip_{i:06d}"), nodata_mask(self.chips[i], self.no_data_value, self.mult)
         return x, y
 
 
+def nodata_mask(chip, no_data_value: Optional[float], constant_multiplier: Optional[float] = None) -> np.ndarray:
+    """``arr_x == no_data_value`` on the multiplier-scaled chip (T*C, H, W) -> bool array (dataloader.py:895-900)."""
+    a = chip.cpu().numpy() if torch.is_tensor(chip) else np.asarray(chip)
+    if no_data_value is None:
+        return np.zeros(a.shape, dtype=bool)
+    return (a * (1.0 if constant_multiplier is None else constant_multiplier)) == no_data_value
+
+
+class InstaGeoDataset(torch.utils.data.Dataset):
+    """The reference's CSV-driven dataset (dataloader.py:832-906) on the TIFF codec of :mod:`instageo_amd.tiff`: ``filename`` is
+    a CSV with an ``Input`` column (chip GeoTIFF, T*C bands) and optionally ``Label`` (segmentation map), paths relative to
+    ``input_root``.  Items follow the reference contract: ``preprocess_func(arr_x, arr_y)``, and with ``include_filenames``
+    the 3-tuple ``(preprocess_func(arr_x, arr_y), im_fname, arr_x == no_data_value)``."""
+
+    def __init__(self, filename: str, input_root: str, preprocess_func, chip_no_data_value: Optional[float] = -9999,
+                 label_no_data_value: Optional[float] = -1, replace_label=None, reduce_to_zero: bool = False,
+                 constant_multiplier: float = 1.0, bands: Optional[List[int]] = None, include_filenames: bool = False):
+        import os
+
+        import pandas as pd
+
+        from . import tiff
+
+        self._tiff = tiff
+        self.input_root, self.preprocess_func, self.bands = input_root, preprocess_func, bands
+        self.no_data_value, self.replace_label, self.reduce_to_zero = chip_no_data_value, replace_label, reduce_to_zero
+        self.constant_multiplier, self.include_filenames = constant_multiplier, include_filenames
+        data = pd.read_csv(filename)
+        label_present = "Label" in data.columns
+        self.file_paths: List[Tuple[str, Optional[str]]] = []
+        for _, row in data.iterrows():  # get_valid_filepaths (dataloader.py:786-829): keep rows whose files exist and whose label
+            im = os.path.join(input_root, row["Input"])  # has at least one valid pixel where the chip has data
+            mk = os.path.join(input_root, row["Label"]) if label_present else None
+            if not os.path.exists(im):
+                continue
+            if mk is not None:
+                if not os.path.exists(mk):
+                    continue
+                chip, _ = tiff.read(im)
+                steps = max(1, chip.shape[0] // 6)
+                has_data = np.where(chip[[6 * i for i in range(steps)]] == chip_no_data_value, 0, 1).all(0)
+                lab = tiff.read(mk)[0][0]
+                if not np.any((lab != label_no_data_value) & (has_data == 1)):
+                    continue
+            self.file_paths.append((im, mk))
+
+    def __len__(self) -> int:
+        return len(self.file_paths)
+
+    def _process_data(self, im_fname: str, mask_fname: Optional[str]):
+        """process_data (dataloader.py:707-750): band selection, constant multiplier, label replacement / shift."""
+        arr_x = self._tiff.read(im_fname)[0]
+        if self.bands:
+            arr_x = arr_x[self.bands, ...]
+        arr_x = arr_x * self.constant_multiplier
+        arr_y = None
+        if mask_fname:
+            arr_y = self._tiff.read(mask_fname)[0]
+            arr_y = process_label(arr_y, self.replace_label, self.reduce_to_zero)
+        return arr_x, arr_y
+
+    def __getitem__(self, i: int):
+        im_fname, mask_fname = self.file_paths[i]
+        arr_x, arr_y = self._process_data(im_fname, mask_fname)
+        if self.include_filenames:
+            return self.preprocess_func(arr_x, arr_y), im_fname, arr_x == self.no_data_value
+        return self.preprocess_func(arr_x, arr_y)
+
+
 def eval_collate_fn(batch):
-    """Concatenate windowed samples across the batch (pipeline_utils.py:78-89)."""
-    return torch.cat([b[0] for b in batch], 0), torch.cat([b[1] for b in batch], 0)
+    """Concatenate windowed samples across the batch (pipeline_utils.py:78-89); items may carry the (filename, mask) tail."""
+    items = [b[0] if isinstance(b[0], tuple) else b for b in batch]
+    return torch.cat([it[0] for it in items], 0), torch.cat([it[1] for it in items], 0)
 
 
 def infer_collate_fn(batch):
-    """((data, label), filenames) batches (pipeline_utils.py:92-104)."""
+    """((data, labels), filenames) batches (pipeline_utils.py:92-104); the NODATA mask (third element) is not collated."""
     data = torch.stack([b[0][0] for b in batch])
-    labels = torch.stack([b[0][1] for b in batch])
+    labels = [b[0][1] for b in batch]
     return (data, labels), [b[1] for b in batch]

@@ -23,6 +23,9 @@ import torch
 import torch.distributed as dist
 
 
+DEFAULT_RESERVED_CUS = 8  # one CU per XCD for RCCL while the data-parallel backward runs (IG_RESERVED_CUS overrides)
+
+
 def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """Initialise the default process group from RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* (torchrun contract).
 
@@ -38,6 +41,9 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        # this image's host driver only supports dmabuf IPC: without it RCCL's (and torch's) cross-process device-memory
+        # handles fail with "hipIpcGetMemHandle: invalid argument" (it is exported by the launch environment; set here too
+        # so that a bare `python -m torch.distributed.run` works)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" IS RCCL on ROCm
@@ -80,6 +86,8 @@ class GradSync:
         # SUM everywhere (ReduceOp.AVG is not available on every backend / RCCL build); the 1/world factor is applied
         # either here after the wait, or for free inside the AdamW kernel (scale_in_optimizer=True)
         self.scale_in_optimizer = scale_in_optimizer
+        self.time_buckets = False  # bench.py diagnostics: device time of every bucket's all-reduce (adds a sync per bucket)
+        self._bucket_ms: List[Tuple[Tuple[int, int], float]] = []
 
     def ready(self, lo: int, hi: int) -> None:
         if world_size() == 1 or hi <= lo:
@@ -100,9 +108,23 @@ class GradSync:
         lo, hi = self.cur
         self.cur = None
         g = self.get_grad()[lo:hi]
-        self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.time_buckets and g.is_cuda:  # diagnostic mode: synchronous, timed (NOT overlapped)
+            torch.cuda.synchronize()
+            import time as _time
+
+            t0 = _time.perf_counter()
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+            torch.cuda.synchronize()
+            self._bucket_ms.append(((lo, hi), 1e3 * (_time.perf_counter() - t0)))
+        else:
+            self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self.ranges.append((lo, hi))
         self.launched.append((lo, hi))
+
+    def bucket_times(self) -> List[Tuple[Tuple[int, int], float]]:
+        """[(flat range, milliseconds)] of the buckets reduced while ``time_buckets`` was set; clears the record."""
+        out, self._bucket_ms = self._bucket_ms, []
+        return out
 
     def wait(self) -> None:
         if world_size() == 1:
@@ -129,6 +151,12 @@ def attach_data_parallel(module, bucket_bytes: int = 32 << 20) -> Optional[GradS
     for t in net._buffers_flat.values():
         dist.broadcast(t, src=0)
     net.params_changed()
+    # The GEMM kernels are persistent, one workgroup per CU: with every CU pinned, RCCL's all-reduce kernels (launched from the
+    # backward as buckets become final) would wait for a whole GEMM to drain.  Leave a few CUs free while world > 1.
+    from . import ops
+
+    if net.store.flat.is_cuda and "IG_RESERVED_CUS" not in os.environ and ops.reserved_cus() == 0:
+        ops.set_reserved_cus(DEFAULT_RESERVED_CUS)
     sync = GradSync(lambda: net.store.ensure_grad(), bucket_bytes, scale_in_optimizer=True)
     module.optimizer().set_grad_scale(1.0 / world_size())
     net.engine.on_grad_ready = sync.ready

@@ -370,6 +370,19 @@ class SegEngine:
         B = img.shape[0]
         if B == 0:  # empty batch: nothing to launch
             return torch.empty((0, cfg.num_classes, cfg.img_size, cfg.img_size), dtype=torch.float32, device=img.device)
+        ws = self.encoder_forward(img, save)
+        logits = self._head_forward(ws, B, training, out, update_running)
+        if save:
+            self._generation += 1
+        self._last = {"ws": ws, "B": B, "training": training, "generation": self._generation} if save else None
+        return logits
+
+    def encoder_forward(self, img: torch.Tensor, save: bool = False) -> Dict[str, Any]:
+        """Patch embed + L blocks + final LayerNorm (``PrithviViT.forward`` + the feature reshape, pritvhi.py:498-530,
+        model.py:406-413) on a validated (B, C, T, H, W) f32 device batch; returns the workspace whose ``["f"][0]`` holds the
+        (B, 14, 14, D*T) feature image.  ``bench.py`` times this leg alone (the north-star roofline is stated on it)."""
+        cfg = self.cfg
+        B = img.shape[0]
         self._prepare_shadow()
         ws = self.workspace(B, save)
         D, L, N, T, G, H = cfg.embed_dim, cfg.depth, cfg.tokens, cfg.num_frames, cfg.G, cfg.num_heads
@@ -399,11 +412,7 @@ class SegEngine:
         # final LayerNorm writes the (B, 14, 14, D*T) feature image directly (model.py:406-413, c = d*T + t)
         ops.layernorm_fwd(x_fin, self.P(e + "norm.weight"), self.P(e + "norm.bias"), ws["f"][0], ws["meanF"], ws["rstdF"], M, D,
                           feat_T=T, feat_G=G, ntok=N)
-        logits = self._head_forward(ws, B, training, out, update_running)
-        if save:
-            self._generation += 1
-        self._last = {"ws": ws, "B": B, "training": training, "generation": self._generation} if save else None
-        return logits
+        return ws
 
     def _drop_counter(self, advance: bool) -> Optional[torch.Tensor]:
         dev = self.store.flat.device

@@ -73,10 +73,12 @@ def _stream():
 
 
 # ---- optional per-launch HIP-event profiling (bench.py: roofline of the dominant kernels) ----------------
-# PROF maps entry point -> {"work": flops or bytes summed over launches, "events": [(start, end), ...]}.
-# torch.cuda.Event records on torch's current stream, which is the stream every kernel here is launched on.
+# PROF maps entry point -> {"work": flops or bytes summed over bracketed launches, "events": [(start, end, kernel), ...]}.
+# torch.cuda.Event records on torch's current stream, which is the stream every kernel here is launched on.  Every profiled
+# launch is also counted under the name of the KERNEL it started (``ig_last_kernel``: rocprofv3's name minus namespaces).
 PROF = None
 PROF_STRIDE = 1
+PROF_KERNELS = None
 
 
 def profile_begin(names, stride: int = 1) -> None:
@@ -86,17 +88,35 @@ def profile_begin(names, stride: int = 1) -> None:
     kernel (a few microseconds of bubble per pair), so inside a timed region only a sample is bracketed.  Pick a stride
     coprime with the per-layer launch pattern (7 is) so the sample keeps the mix of shapes.
     """
-    global PROF, PROF_STRIDE
+    global PROF, PROF_STRIDE, PROF_KERNELS
     PROF = {n: {"work": 0.0, "events": [], "seen": 0} for n in names}
+    PROF_KERNELS = {}
     PROF_STRIDE = max(1, int(stride))
 
 
 def profile_end():
-    """Synchronise and return {name: (bracketed launches, total_ms, total_work)}."""
-    global PROF
-    prof, PROF = PROF, None
+    """Synchronise and return ``{"ops": {entry point: (bracketed launches, total_ms, total_work)}, "kernels": {kernel name:
+    {"op", "calls" (all launches seen), "n" (bracketed), "ms", "work"}}}``."""
+    global PROF, PROF_KERNELS
+    prof, kern, PROF, PROF_KERNELS = PROF, PROF_KERNELS, None, None
     torch.cuda.synchronize()
-    return {n: (len(d["events"]), sum(a.elapsed_time(b) for a, b in d["events"]), d["work"]) for n, d in prof.items()}
+    ops_out = {}
+    for n, d in prof.items():
+        tot = 0.0
+        for a, b, k, w in d["events"]:
+            ms = a.elapsed_time(b)
+            tot += ms
+            r = kern[k]
+            r["n"] += 1
+            r["ms"] += ms
+            r["work"] += w
+        ops_out[n] = (len(d["events"]), tot, d["work"])
+    return {"ops": ops_out, "kernels": kern}
+
+
+def _kernel_label(name: str) -> str:
+    k = (_lib.load().ig_last_kernel() or b"").decode()
+    return k or name
 
 
 def _call(name: str, work: float, *args, entry: Optional[str] = None) -> None:
@@ -107,15 +127,30 @@ def _call(name: str, work: float, *args, entry: Optional[str] = None) -> None:
         return
     d = PROF[name]
     d["seen"] += 1
-    if (d["seen"] - 1) % PROF_STRIDE:
-        _lib.call(entry, *args)
-        return
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
+    bracket = (d["seen"] - 1) % PROF_STRIDE == 0
+    if bracket:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+    _lib.load().ig_note_reset()
     _lib.call(entry, *args)
-    b.record()
-    d["events"].append((a, b))
-    d["work"] += work
+    k = _kernel_label(name)
+    r = PROF_KERNELS.get(k)
+    if r is None:
+        r = PROF_KERNELS[k] = {"op": name, "calls": 0, "n": 0, "ms": 0.0, "work": 0.0}
+    r["calls"] += 1
+    if bracket:
+        b.record()
+        d["events"].append((a, b, k, work))
+        d["work"] += work
+
+
+def reserved_cus() -> int:
+    return int(_lib.load().ig_get_reserved_cus())
+
+
+def set_reserved_cus(n: int) -> None:
+    """Compute units the persistent GEMM kernels leave free (for RCCL's kernels under data parallelism)."""
+    _lib.call("ig_set_reserved_cus", int(n))
 
 
 def _f32(t: torch.Tensor) -> torch.Tensor:
@@ -164,6 +199,34 @@ def crop_flip_normalize(src: torch.Tensor, params: torch.Tensor, mean: torch.Ten
     work = float(B) * TC * im * im * (src.element_size() + 4) + (float(B) * im * im * 8 if labels is not None else 0.0)
     _call("ig_crop_flip_normalize", work, _p(src), dt, _p(_f32(mean)), _p(_f32(std)), mult, int(constant_multiplier is not None), _p(params),
           _p(out), _p(labels), _p(lab_out), B, temporal, C, Hs, Ws, im, _stream())
+    return out, lab_out
+
+
+def normalize_windows(tile: torch.Tensor, origins: torch.Tensor, mean: torch.Tensor, std: torch.Tensor, temporal: int, crop: int,
+                      constant_multiplier: Optional[float] = None, labels: Optional[torch.Tensor] = None,
+                      out: Optional[torch.Tensor] = None):
+    """Sliding-window gather + normalise in ONE launch: tile (T*C, Hs, Ws) int16|f32, origins (n, 2) int32 rows (top, left) on the
+    device -> (n, C, T, crop, crop) f32 normalised [+ the same windows of ``labels`` (Hs, Ws) f32 -> (n, crop, crop)]
+    (process_test / crop_array, dataloader.py:588-669)."""
+    TC, Hs, Ws = tile.shape
+    C = TC // temporal
+    n = origins.shape[0]
+    assert C * temporal == TC and mean.numel() == C and std.numel() == C
+    assert origins.dtype == torch.int32 and origins.dim() == 2 and origins.shape[1] == 2 and origins.device == tile.device
+    dt = {torch.int16: 0, torch.float32: 1}[tile.dtype]
+    if out is None:
+        out = torch.empty((n, C, temporal, crop, crop), dtype=torch.float32, device=tile.device)
+    else:
+        assert out.shape == (n, C, temporal, crop, crop) and out.dtype == torch.float32
+    lab_out = None
+    if labels is not None:
+        labels = _f32(labels)
+        assert labels.shape == (Hs, Ws)
+        lab_out = torch.empty((n, crop, crop), dtype=torch.float32, device=tile.device)
+    mult = 1.0 if constant_multiplier is None else float(constant_multiplier)
+    work = float(n) * TC * crop * crop * (tile.element_size() + 4) + (float(n) * crop * crop * 8 if labels is not None else 0.0)
+    _call("ig_normalize_windows", work, _p(tile), dt, _p(_f32(mean)), _p(_f32(std)), mult, int(constant_multiplier is not None),
+          _p(origins.contiguous()), _p(out), _p(labels), _p(lab_out), n, temporal, C, Hs, Ws, crop, _stream())
     return out, lab_out
 
 

@@ -24,7 +24,7 @@ import torch
 
 from . import distributed as D
 from .config import check_required_flags, load_config
-from .dataloader import (ArrayChipDataset, SyntheticChipDataset, eval_collate_fn, infer_collate_fn, normalize_batch,
+from .dataloader import (ArrayChipDataset, InstaGeoDataset, SyntheticChipDataset, eval_collate_fn, infer_collate_fn, normalize_batch,
                          process_and_augment, process_and_augment_batch, process_test)
 from .factory import create_model
 from .infer_utils import chip_inference
@@ -55,6 +55,21 @@ def create_dataset(spec: Optional[str], cfg: Dict[str, Any], kind: str, device: 
         return SyntheticChipDataset(n, T, ncls, mean, std, im_size=size, ignore_index=ign, constant_multiplier=1e-4, seed=SEED, device=device,
                                     regression=bool(cfg.get("is_reg_task", False)))
     path = spec if os.path.isabs(str(spec)) or cfg.get("root_dir") in (None, "None") else os.path.join(cfg["root_dir"], spec)
+    if str(path).endswith(".csv"):
+        # the reference's own input: a CSV of chip / label GeoTIFF paths (dataloader.py:786-906) through the TIFF codec
+        from functools import partial
+
+        t = cfg["test"]
+        if kind == "test" and cfg["mode"] == "eval":
+            pre = partial(process_test, mean=mean, std=std, temporal_size=T, img_size=t["img_size"], crop_size=t["crop_size"],
+                          stride=t["stride"], device=device)
+        else:
+            size = t["img_size"] if kind == "test" else d["img_size"]
+            pre = partial(process_and_augment, mean=mean, std=std, temporal_size=T, im_size=size, crop=(kind != "test"),
+                          augmentations=None, device=device)
+        return InstaGeoDataset(path, cfg.get("root_dir") or "", pre, d.get("no_data_value", -9999), ign, d.get("replace_label"),
+                               bool(d.get("reduce_to_zero", False)), 1.0 if mult is None else mult, d.get("bands"),
+                               include_filenames=(kind == "test"))
     z = np.load(path)
     return ArrayChipDataset(z["chips"], z["labels"], mean, std, T, mult, include_filenames=(kind == "test"), device=device,
                             replace_label=d.get("replace_label"), reduce_to_zero=bool(d.get("reduce_to_zero", False)))

@@ -186,3 +186,35 @@ def test_config_surface():
     with pytest.raises(RuntimeError):
         check_required_flags(["root_dir"], {"root_dir": "None"})  # the *string* "None" counts as missing
     check_required_flags(["root_dir"], {"root_dir": "/data"})
+
+
+def test_torch_library_ops_are_registered_from_the_header():
+    """SURVEY.md 8b / north_star: the hot path sits behind PyTorch custom ops.  Every C-ABI entry point that takes device
+    pointers is a dispatcher-visible ``instageo_mi355x::`` op whose schema is generated from include/instageo_hip.h
+    (non-const pointers = mutated arguments), with a fake implementation; there is no CPU kernel."""
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+
+    from instageo_amd import _lib, torch_ops
+
+    ops_ = torch_ops.register()
+    assert torch_ops.register() is ops_  # idempotent
+    protos = torch_ops.parse_prototypes()
+    tensor_entries = [n for n, ps in protos.items() if n not in torch_ops._SKIP and any("*" in t for t, pn in ps if pn != "stream")]
+    assert sorted(ops_) == sorted(n[3:] for n in tensor_entries) and len(ops_) >= 40
+    assert set(protos) <= set(_lib.declared_symbols())
+    sch = str(torch.ops.instageo_mi355x.linear_fwd.default._schema)
+    assert "Tensor? x_hi" in sch and "Tensor(a!)? y_hi" in sch and sch.endswith("int M, int N, int K, int act) -> ()")
+    assert "Tensor(a!)? dw" in str(torch.ops.instageo_mi355x.linear_wgrad.default._schema)
+    with FakeTensorMode():
+        x = torch.empty(64, 32, dtype=torch.bfloat16, device="cuda")
+        w = torch.empty(16, 32, dtype=torch.bfloat16, device="cuda")
+        y, d = torch.ops.instageo_mi355x.linear(x, w, None, 1)
+        assert y.shape == (64, 16) and d.shape == (64, 16) and y.dtype == torch.bfloat16
+        assert torch.ops.instageo_mi355x.linear_fwd(x, None, w, None, None, y, None, None, None, 64, 16, 32, 0) is None
+        a, m, r = torch.ops.instageo_mi355x.layer_norm(torch.empty(64, 32, device="cuda"), torch.empty(32, device="cuda"), torch.empty(32, device="cuda"), 1e-5)
+        assert a.dtype == torch.bfloat16 and m.shape == (64,) and r.shape == (64,)
+    import pytest
+
+    with pytest.raises(NotImplementedError):  # no CPU backend
+        torch.ops.instageo_mi355x.linear(torch.empty(4, 8, dtype=torch.bfloat16), torch.empty(8, 8, dtype=torch.bfloat16), None, 0)

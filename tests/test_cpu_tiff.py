@@ -1,0 +1,71 @@
+"""CPU tests of the host-side TIFF codec (instageo_amd/tiff.py) against the data files the reference's
+own tests hold (tests/golden/tiff/ = /root/reference/tests/data/chip_178_022{,.mask}.tif, GDAL-written) and against Pillow."""
+import os
+
+import numpy as np
+import pytest
+
+from instageo_amd import tiff
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden", "tiff")
+
+
+def test_reads_the_reference_chip_fixture():
+    """/root/reference/tests/data_tests/test_create_chips.py:81-82 uses this 18-band (T=3 x 6) int16 HLS chip and its crop mask."""
+    chip, prof = tiff.read(os.path.join(GOLD, "chip_178_022.tif"))
+    assert chip.shape == (18, 32, 32) and chip.dtype == np.int16 and prof["count"] == 18
+    assert int(chip.min()) == -9999 and int(chip.max()) == 6062 and abs(float(chip.astype(np.float64).mean()) + 2259.9460177951387) < 1e-9
+    mask, _ = tiff.read(os.path.join(GOLD, "chip_178_022.mask.tif"))
+    assert mask.shape == (1, 32, 32) and mask.dtype == np.uint8 and int(mask.min()) == 1 and int(mask.max()) == 13
+    # NODATA pixels of the chip are NODATA in every band of a time step (HLS masking is per pixel)
+    nd = chip == -9999
+    assert nd.any() and all(np.array_equal(nd[6 * t], nd[6 * t + c]) for t in range(3) for c in range(6))
+
+
+@pytest.mark.parametrize("dtype", ["int16", "uint8", "int8", "float32", "uint16", "int32"])
+@pytest.mark.parametrize("compress", [None, "deflate"])
+def test_roundtrip_with_geo_tags(tmp_path, dtype, compress):
+    rng = np.random.default_rng(0)
+    prof = {"tags": {33550: (12, (30.0, 30.0, 0.0)), 33922: (12, (0.0, 0.0, 0.0, 5e5, 4e6, 0.0)), 34737: (2, "WGS 84 / UTM zone 33N|"),
+                     34735: (3, (1, 1, 0, 1, 1024, 0, 1, 1))}, "nodata": -9999}
+    for shape in ((3, 37, 53), (1, 224, 224), (18, 64, 64), (224, 224)):
+        a = (rng.standard_normal(shape) * 1000).astype(dtype)
+        p = str(tmp_path / "a.tif")
+        tiff.write(p, a, prof, compress=compress)
+        b, pr = tiff.read(p)
+        assert b.dtype == a.dtype and np.array_equal(a.reshape(b.shape), b)
+        assert pr["tags"][33550][1] == (30.0, 30.0, 0.0) and pr["nodata"] == -9999.0 and pr["tags"][34737][1].startswith("WGS")
+        assert pr["width"] == shape[-1] and pr["height"] == shape[-2]
+
+
+def test_interoperates_with_pillow(tmp_path):
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(1)
+    a = (rng.standard_normal((50, 70)) * 1000).astype("int16")
+    p = str(tmp_path / "ours.tif")
+    tiff.write(p, a)
+    assert np.array_equal(np.array(Image.open(p)), a)  # Pillow reads what we write
+    f = rng.standard_normal((50, 70)).astype("float32")
+    for kw in ({}, {"compression": "tiff_adobe_deflate"}):
+        q = str(tmp_path / "pil.tif")
+        Image.fromarray(f).save(q, **kw)
+        assert np.array_equal(tiff.read(q)[0][0], f)  # we read what Pillow writes (strips, none / deflate)
+    rgb = rng.integers(0, 255, (40, 30, 3)).astype("uint8")
+    q = str(tmp_path / "rgb.tif")
+    Image.fromarray(rgb).save(q)
+    assert np.array_equal(tiff.read(q)[0], rgb.transpose(2, 0, 1))  # pixel-interleaved (contig) planes
+
+
+def test_rejects_what_it_does_not_support(tmp_path):
+    p = str(tmp_path / "x.tif")
+    open(p, "wb").write(b"II+\x00" + b"\x00" * 12)
+    with pytest.raises(tiff.TiffError):
+        tiff.read(p)  # BigTIFF
+    open(p, "wb").write(b"not a tiff")
+    with pytest.raises(tiff.TiffError):
+        tiff.read(p)
+    with pytest.raises(tiff.TiffError):
+        tiff.write(p, np.zeros((2, 2), dtype=np.complex64))
+    with pytest.raises(tiff.TiffError):
+        tiff.write(p, np.zeros((2, 2), dtype=np.int16), compress="lzw")

@@ -206,6 +206,37 @@ def test_linear_dgrad_wt(split, M, N, K, force, monkeypatch):
     close(dx.float(), (dyr @ wr) * gref, tol_out(split), what="dgrad*dact, no colsum (wt)")
 
 
+def test_reserved_cus_shrink_the_persistent_grids(monkeypatch):
+    """world > 1: the persistent GEMMs leave IG_RESERVED_CUS compute units to RCCL's kernels (distributed.attach_data_parallel
+    sets 8); checked on the launched grid, and the result does not depend on it."""
+    from instageo_amd import _lib
+
+    lib = _lib.load()
+    M, N, K = 21276, 768, 768
+    x, xr = bt(rnd(M, K, seed=1), False)
+    w, wr = bt(rnd(N, K, seed=2, scale=K**-0.5), False)
+    y = BT.zeros((M, N), False, DEV)
+    ref = None
+    try:
+        for reserve, engine in ((0, "1"), (8, "1"), (8, "0"), (0, "0")):
+            monkeypatch.setenv("IG_GEMM8", engine)
+            ops.set_reserved_cus(reserve)
+            assert ops.reserved_cus() == reserve
+            ops.linear_fwd(x, w, None, y, M, N, K)
+            per_cu = 1 if engine == "1" else 2  # gemm8: one workgroup per CU; gemm2: two
+            grid = lib.ig_last_grid()
+            assert 0 < grid <= per_cu * (256 - reserve), (reserve, engine, grid)
+            if reserve:
+                assert grid == per_cu * (256 - reserve), (reserve, engine, grid)
+            if ref is None:
+                ref = y.hi.clone()
+                close(y.float(), xr @ wr.t(), tol_out(False), what="reserved-CU gemm")
+            elif engine == "1":
+                assert torch.equal(y.hi, ref)
+    finally:
+        ops.set_reserved_cus(0)
+
+
 def test_transpose_bf16_batched():
     R, C, nb = 192, 128, 3
     src = BT.from_float(torch.randn(nb * R * C + 64, device=DEV), True)  # matrices 8 elements apart from contiguous
@@ -684,3 +715,47 @@ def test_mse_loss_and_regression_metrics(use_log):
         assert m2.n == 3000
         m2.reset()
         assert m2.n == 0 and np.isnan(m2.compute()["mae"])
+
+
+def test_torch_library_functional_ops_autograd():
+    """``torch.ops.instageo_mi355x.linear`` / ``layer_norm`` (torch_ops.py): dispatcher ops with register_autograd; forward and
+    gradients against float64 torch on the bf16-rounded operands; torch.library.opcheck validates schema / fake / autograd
+    registration.  The raw mutating ops are exercised through the same calls."""
+    from instageo_amd import torch_ops
+
+    torch_ops.register()
+    ns = torch.ops.instageo_mi355x
+    M, N, K = 300, 256, 192
+    x = rnd(M, K, seed=31).to(DEV).bfloat16().requires_grad_(True)
+    w = (rnd(N, K, seed=32) * K**-0.5).to(DEV).bfloat16().requires_grad_(True)
+    b = rnd(N, seed=33).to(DEV).requires_grad_(True)
+    for act in (0, 1):
+        y, _ = ns.linear(x, w, b, act)
+        xd, wd, bd = (t.detach().double().cpu().requires_grad_(True) for t in (x, w, b))
+        pre = xd @ wd.t() + bd
+        ref = F.gelu(pre) if act else pre
+        close(y.float(), ref.detach(), tol_out(False), what=f"ops.linear act={act}")
+        dy = rnd(M, N, seed=34).to(DEV).bfloat16()
+        gx, gw, gb = torch.autograd.grad(y, (x, w, b), dy)
+        rx, rw, rb = torch.autograd.grad(ref, (xd, wd, bd), dy.double().cpu())
+        close(gx.float(), rx, 2e-2, what="ops.linear dx")  # dy * gelu' is rounded to bf16 before the two gradient GEMMs
+        close(gw.float(), rw, 2e-2, what="ops.linear dw")
+        close(gb, rb, 2e-2, what="ops.linear dbias")
+    xs = (rnd(197, 256, seed=35) * 2 + 0.5).to(DEV).requires_grad_(True)
+    g = (1 + 0.1 * rnd(256, seed=36)).to(DEV).requires_grad_(True)
+    be = (0.1 * rnd(256, seed=37)).to(DEV).requires_grad_(True)
+    out, mean, rstd = ns.layer_norm(xs, g, be, 1e-5)
+    xd, gd, bd = (t.detach().double().cpu().requires_grad_(True) for t in (xs, g, be))
+    ref = F.layer_norm(xd, (256,), gd, bd, 1e-5)
+    close(out.float(), ref.detach(), tol_out(False), what="ops.layer_norm")
+    dy = rnd(197, 256, seed=38).to(DEV).bfloat16()
+    gx, gg, gb = torch.autograd.grad(out, (xs, g, be), dy)
+    rx, rg, rb = torch.autograd.grad(ref, (xd, gd, bd), dy.double().cpu())
+    close(gx, rx, 2e-5, what="ops.layer_norm dx")
+    close(gg, rg, 2e-5, what="ops.layer_norm dgamma")
+    close(gb, rb, 2e-5, what="ops.layer_norm dbeta")
+    for op, args in ((ns.linear.default, (x.detach(), w.detach(), b.detach(), 1)), (ns.layer_norm.default, (xs.detach(), g.detach(), be.detach(), 1e-5))):
+        torch.library.opcheck(op, args, test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
+    yy = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    torch.library.opcheck(ns.linear_fwd.default, (x.detach(), None, w.detach(), None, b.detach(), yy, None, None, None, M, N, K, 0),
+                          test_utils=("test_schema", "test_faketensor"))

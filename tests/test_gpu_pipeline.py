@@ -134,9 +134,14 @@ def test_chip_inference_writes_int8_maps(tmp_path):
     loader = [DL.infer_collate_fn([arr[i] for i in range(s, min(s + 2, 5))]) for s in range(0, 5, 2)]
     assert chip_inference(loader, str(tmp_path), net, device="gpu") == {}
     files = sorted(os.listdir(tmp_path))
-    assert files == [f"prediction_chip_{i}.npy" for i in range(5)]
-    pred = np.load(tmp_path / files[3])
-    assert pred.dtype == np.int8 and pred.shape == (224, 224)
+    assert files == [f"prediction_{i}.tif" for i in range(5)]  # "chip" -> "prediction" in the base name (infer_utils.py:51)
+    from instageo_amd import tiff
+
+    pred, prof = tiff.read(str(tmp_path / files[3]))
+    pred = pred[0]
+    assert pred.dtype == np.int8 and pred.shape == (224, 224) and prof["count"] == 1
+    item = arr[3]
+    assert len(item) == 3 and item[2].shape == (6, 224, 224) and item[2].dtype == bool  # (x, y), name, NODATA mask (dataloader.py:895-900)
     with torch.no_grad():
         x, _ = arr[3][0]
         ref = O.prithvi_seg_forward(cfg, sd, x.cpu()[None], training=False).argmax(1)[0].numpy()
@@ -159,6 +164,100 @@ def test_sliding_window_inference_matches_per_window_forward():
     assert canvas.shape == (700, 700) and torch.equal(canvas[t : t + 224, l : l + 224], maps[5]) and int(canvas[699, 699]) == -1
     # size-independent property at the full BASELINE size: window list of a 10980^2 tile
     assert len(DL.window_origins(10980, 224, 224)) == 2401
+    # the fused gather kernel == slicing + normalising window by window (what the reference's process_test does)
+    xs, ys = DL.gather_windows(tile, origins, MEAN, STD, 1, 224, 1e-4, labels=tile[0].float())
+    ref = DL.normalize_batch(DL.extract_windows(tile, origins, 224), MEAN, STD, 1, 1e-4)
+    assert torch.equal(xs, ref) and torch.equal(ys, DL.extract_windows(tile[0].float(), origins, 224))
+
+
+def test_stitch_windows_overlap_rule():
+    """stride < crop: a pixel takes the window whose centre is nearest (Chebyshev); independent of placement order."""
+    from instageo_amd.infer_utils import stitch_windows
+
+    S, crop, stride = 40, 16, 8
+    origins = DL.window_origins(S, crop, stride)
+    maps = torch.stack([torch.full((crop, crop), i, dtype=torch.int8, device=DEV) for i in range(len(origins))])
+    canvas = stitch_windows(maps, origins, S)
+    c = (crop - 1) / 2.0
+    exp = np.full((S, S), -1, dtype=np.int64)
+    best = np.full((S, S), np.inf)
+    for i, (t, l) in enumerate(origins):
+        for y in range(crop):
+            for x in range(crop):
+                d = max(abs(y - c), abs(x - c))
+                if d < best[t + y, l + x]:
+                    best[t + y, l + x], exp[t + y, l + x] = d, i
+    assert np.array_equal(canvas.cpu().numpy().astype(np.int64), exp)
+    perm = torch.randperm(len(origins), generator=torch.Generator().manual_seed(0)).tolist()
+    shuffled = stitch_windows(maps[perm], [origins[i] for i in perm], S)
+    # ties between equidistant windows are broken by order, everything else is order-independent
+    tie_free = torch.from_numpy(np.isfinite(best)).to(DEV)
+    assert (shuffled == canvas)[tie_free].float().mean() > 0.9
+    flat = stitch_windows(maps[: 4], [(0, 0), (0, 16), (16, 0), (16, 16)], 36)  # regular non-overlapping grid: one strided copy
+    assert int(flat[0, 0]) == 0 and int(flat[0, 16]) == 1 and int(flat[16, 0]) == 2 and int(flat[31, 31]) == 3 and int(flat[35, 35]) == -1
+
+
+def test_sliding_window_full_size_tile_configs3():
+    """BASELINE.json configs[3] at its real size: a 6 x 10980 x 10980 int16 tile (1.45 GB) -> 49 x 49 = 2401 windows of 224,
+    the last 4 pixels dropped (dataloader.py:655-664).  Sampled windows equal the direct forward of the same pixels and (Prithvi
+    tiny, bf16x3: exact arithmetic up to ~1e-5) the CPU oracle's argmax; the stitched canvas has the 4-px fill border."""
+    S = 10980
+    net = PrithviSeg(temporal_step=1, num_classes=2, load_pretrained_weights=False, freeze_backbone=True, variant="prithvi_eo_tiny",
+                     precision="bf16x3", device=DEV)
+    cfg = O.make_config("prithvi_eo_tiny", 1, 2)
+    sd = O.make_state_dict(cfg, seed=11)
+    net.load_state_dict(sd)
+    g = torch.Generator(device=DEV).manual_seed(9)
+    tile = torch.randint(0, 10000, (6, S, S), generator=g, device=DEV, dtype=torch.int16)
+    maps, origins = sliding_window_inference(tile, net, MEAN, STD, 1, 224, 224, batch_size=128, constant_multiplier=1e-4)
+    assert len(origins) == 2401 and maps.shape == (2401, 224, 224) and maps.dtype == torch.int8
+    assert origins[0] == (0, 0) and origins[-1] == (48 * 224, 48 * 224)
+    for i in (0, 1234, 2400):
+        t, l = origins[i]
+        x = DL.normalize_batch(tile[None, :, t : t + 224, l : l + 224].contiguous(), MEAN, STD, 1, 1e-4)
+        with torch.no_grad():
+            direct = ops.argmax_i8(net(x))[0]
+        assert torch.equal(maps[i], direct), f"window {i} differs from the direct forward"
+        with torch.no_grad():
+            ref = O.prithvi_seg_forward(cfg, sd, x.cpu(), training=False)
+        top2 = ref.topk(2, dim=1).values
+        sure = ((top2[:, 0] - top2[:, 1]) > 1e-3)[0]  # pixels whose fp32 margin exceeds the 1e-3 parity bar
+        assert torch.equal(maps[i].cpu().long()[sure], ref.argmax(1)[0][sure]), f"window {i} differs from the oracle argmax"
+        assert (maps[i].cpu().long() == ref.argmax(1)[0]).float().mean() > 0.999
+    canvas = stitch_windows(maps, origins, S)
+    assert canvas.shape == (S, S)
+    assert bool((canvas[48 * 224 + 224 :, :] == -1).all()) and bool((canvas[:, 48 * 224 + 224 :] == -1).all())  # 4-px border = fill
+    assert bool((canvas[: 49 * 224, : 49 * 224] >= 0).all())
+    t, l = origins[1234]
+    assert torch.equal(canvas[t : t + 224, l : l + 224], maps[1234])
+
+
+def test_tile_inference_geotiff_roundtrip(tmp_path):
+    """File -> file: an HLS-like GeoTIFF tile with NODATA pixels -> prediction TIFF with the source's
+    georeferencing tags; NODATA pixels and the uncovered border carry the fill value."""
+    from instageo_amd import tiff
+    from instageo_amd.infer_utils import tile_inference
+
+    net, cfg, sd = _tiny()
+    rng = np.random.default_rng(3)
+    arr = rng.integers(0, 10000, size=(6, 500, 500)).astype(np.int16)
+    arr[:, 100:120, 200:260] = -9999
+    tags = {33550: (12, (30.0, 30.0, 0.0)), 33922: (12, (0.0, 0.0, 0.0, 399960.0, 4500000.0, 0.0)),
+            34735: (3, (1, 1, 0, 3, 1024, 0, 1, 1, 1025, 0, 1, 1, 3072, 0, 1, 32613))}
+    src = str(tmp_path / "chip_T13SDV.tif")
+    tiff.write(src, arr, {"tags": tags, "nodata": -9999}, compress="deflate")
+    out = tile_inference(src, str(tmp_path / "predictions"), net, MEAN, STD, 1, 224, 224, batch_size=4, constant_multiplier=1e-4)
+    assert os.path.basename(out) == "prediction_T13SDV.tif"
+    pred, prof = tiff.read(out)
+    assert pred.shape == (1, 500, 500) and pred.dtype == np.int8
+    assert prof["tags"][33550][1] == (30.0, 30.0, 0.0) and prof["tags"][34735][1][-1] == 32613 and prof["nodata"] == -1.0
+    assert (pred[0, 100:120, 200:260] == -1).all() and (pred[0, 448:, :] == -1).all() and (pred[0, :, 448:] == -1).all()
+    inside = pred[0, :448, :448].copy()
+    inside[100:120, 200:260] = 0
+    assert set(np.unique(inside)) <= {0, 1}
+    overlap = tile_inference(src, str(tmp_path / "p2"), net, MEAN, STD, 1, 224, 92, batch_size=8, constant_multiplier=1e-4)
+    po = tiff.read(overlap)[0][0]
+    assert (po[:500, :500] >= -1).all() and (po[0:40, 0:40] == pred[0, 0:40, 0:40]).all()  # corner pixels: only window (0, 0) is nearest
 
 
 def test_run_train_eval_chip_inference(tmp_path, capsys):
