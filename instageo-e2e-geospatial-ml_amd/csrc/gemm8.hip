@@ -49,7 +49,14 @@ struct Cur {  // issue cursor of one half-tile type (all wave-uniform)
     int kt, seg, tile, vr, left;
 };
 
-template <int KIND, int NSEG, int ACT, bool DACT, bool SPLIT_OUT>
+// SCHED 2 (default): two "big phases" of 32 MFMAs per K-tile (4 barriers per K-tile instead of 8; +2-4 %); SCHED 0: the four
+// 16-MFMA phases of the header comment (kept for A/B runs, IG_G8_SCHED=0).  A third schedule that balanced the LDS reads over the
+// four phases (8/4/8/4 instead of 12/4/8/0) measured no gain and was removed.
+// DBG (timing ablations, built with -DIG_G8_ABLATE only; results are garbage): 1 = no LDS-DMA inside the loop, 2 = + no fragment
+// reads, 3 = + no barriers, 4 = everything but the epilogue stores.  profiles/r02_v8_ablation_qkv.log: of 71 us (qkv, B = 108)
+// the epilogue is 13.7 (its 33 MB store burst per round sits in front of the next loads in the in-order vmcnt), LDS-DMA 10.2,
+// fragment reads 2.5, barriers 1.7 and the MFMAs themselves 43 us.
+template <int KIND, int NSEG, int ACT, bool DACT, bool SPLIT_OUT, int SCHED = 2, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(G8Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -80,6 +87,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(G8Params p) {
     const unsigned ldsw = lds_base + wave * 2048;
 
     Cur cA0, cA1, cB0, cB1;
+    bool in_loop = false;
 #define G8_REBASE(C, ISA)                                                                   \
     {                                                                                       \
         const int bm_ = (C).tile / tiles_n, bn_ = (C).tile - bm_ * tiles_n;                 \
@@ -101,7 +109,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(G8Params p) {
     }
     // issue the two wave-instructions of this wave for half-tile (ISA ? A : B, HG) of the cursor's K-tile into buffer BUF
 #define G8_ISSUE(C, ISA, HG, BUF)                                                                              \
-    if ((C).left > 0) {                                                                                        \
+    if ((DBG == 0 || DBG == 4 || !in_loop) && (C).left > 0) {                                                                                        \
         _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                     \
             int row_ = ((ISA) ? rbaseA + (HG)*64 : rbaseB + (HG)*32) + i_ * 8;                                 \
             row_ = min(row_, (C).vr - 1);                                                                      \
@@ -153,15 +161,16 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(G8Params p) {
     G8_ISSUE(cA1, true, 1, 0)
     G8_ISSUE(cA0, true, 0, 1)
     G8_ISSUE(cB0, false, 0, 1)
+    if constexpr (SCHED == 2) G8_ISSUE(cB1, false, 1, 1)
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
 
     bf16x8_t af[4][2], bf0[2][2], bf1[2][2];
 #define G8_READ_A(BUF, H)                                                                                          \
-    _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)           \
+    if (DBG < 2 || DBG == 4 || !in_loop) _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) \
         af[mt_][s_] = *reinterpret_cast<const bf16x8_t*>(smem + (BUF)*G8_BUF + (H)*G8_HALF + mt_ * 2048 + (aoff ^ (s_ * 64)));
 #define G8_READ_B(BUF, G, DST)                                                                                     \
-    _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)           \
+    if (DBG < 2 || DBG == 4 || !in_loop) _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) \
         DST[nt_][s_] = *reinterpret_cast<const bf16x8_t*>(smem + (BUF)*G8_BUF + (G)*G8_HALF + nt_ * 2048 + (boff ^ (s_ * 64)));
 #define G8_MFMA(H, G, BSRC)                                                                                        \
     {                                                                                                              \
@@ -174,6 +183,19 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(G8Params p) {
         __builtin_amdgcn_s_setprio(0);                                                                             \
         asm volatile("s_barrier" ::: "memory");                                                                    \
     }
+    // SCHED 2 "big phase": 32 MFMAs (two quadrants) between one barrier pair; reads are retired BEFORE the first barrier
+    // (lgkmcnt(0)), so a half-tile may be refilled in the very next phase
+#define G8_MFMA2(H)                                                                                                \
+    {                                                                                                              \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
+        if (DBG != 3) asm volatile("s_barrier" ::: "memory");                                                      \
+        __builtin_amdgcn_s_setprio(1);                                                                             \
+        _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_) _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_)       \
+            _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)   \
+                acc[H][g_][nt_][mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g_ ? bf1[nt_][s_] : bf0[nt_][s_], af[mt_][s_], acc[H][g_][nt_][mt_], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                             \
+        if (DBG != 3) asm volatile("s_barrier" ::: "memory");                                                      \
+    }
 #define G8_WAIT(LASTCNT)                                                                     \
     {                                                                                        \
         if (last) asm volatile("s_waitcnt vmcnt(" #LASTCNT ")" ::: "memory");                \
@@ -183,44 +205,79 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(G8Params p) {
     int it_c = 0;  // iterations (K-tile pairs) done of the current tile
     const int iters = Gtot >> 1, per_tile2 = per_tile >> 1;
     bool staggered = false;
+    if constexpr (DBG >= 2) {
+        G8_READ_A(0, 0)
+        G8_READ_B(0, 0, bf0)
+        G8_READ_B(0, 1, bf1)
+    }
+    in_loop = true;
     for (int it = 0; it < iters; ++it) {
         const bool last = it == iters - 1;
         if (!staggered) {  // (re-)establish the stagger: group 1 runs one barrier behind group 0
             if (wr == 1) asm volatile("s_barrier" ::: "memory");
             staggered = true;
         }
-        // ---- even K-tile (buffer 0) ----
-        G8_READ_B(0, 0, bf0)
-        G8_READ_A(0, 0)
-        G8_ISSUE(cB1, false, 1, 1)
-        G8_WAIT(8)
-        G8_MFMA(0, 0, bf0)
-        G8_READ_B(0, 1, bf1)
-        G8_ISSUE(cA1, true, 1, 1)
-        G8_WAIT(8)
-        G8_MFMA(0, 1, bf1)
-        G8_READ_A(0, 1)
-        G8_ISSUE(cA0, true, 0, 0)
-        G8_MFMA(1, 1, bf1)
-        G8_ISSUE(cB0, false, 0, 0)
-        G8_WAIT(4)
-        G8_MFMA(1, 0, bf0)
-        // ---- odd K-tile (buffer 1) ----
-        G8_READ_B(1, 0, bf0)
-        G8_READ_A(1, 0)
-        G8_ISSUE(cB1, false, 1, 0)
-        G8_WAIT(2)
-        G8_MFMA(0, 0, bf0)
-        G8_READ_B(1, 1, bf1)
-        G8_ISSUE(cA1, true, 1, 0)
-        G8_WAIT(0)
-        G8_MFMA(0, 1, bf1)
-        G8_READ_A(1, 1)
-        G8_ISSUE(cA0, true, 0, 1)
-        G8_MFMA(1, 1, bf1)
-        G8_ISSUE(cB0, false, 0, 1)
-        G8_WAIT(0)
-        G8_MFMA(1, 0, bf0)
+        if constexpr (SCHED == 0) {
+            // ---- even K-tile (buffer 0) ----
+            G8_READ_B(0, 0, bf0)
+            G8_READ_A(0, 0)
+            G8_ISSUE(cB1, false, 1, 1)
+            G8_WAIT(8)
+            G8_MFMA(0, 0, bf0)
+            G8_READ_B(0, 1, bf1)
+            G8_ISSUE(cA1, true, 1, 1)
+            G8_WAIT(8)
+            G8_MFMA(0, 1, bf1)
+            G8_READ_A(0, 1)
+            G8_ISSUE(cA0, true, 0, 0)
+            G8_MFMA(1, 1, bf1)
+            G8_ISSUE(cB0, false, 0, 0)
+            G8_WAIT(4)
+            G8_MFMA(1, 0, bf0)
+            // ---- odd K-tile (buffer 1) ----
+            G8_READ_B(1, 0, bf0)
+            G8_READ_A(1, 0)
+            G8_ISSUE(cB1, false, 1, 0)
+            G8_WAIT(2)
+            G8_MFMA(0, 0, bf0)
+            G8_READ_B(1, 1, bf1)
+            G8_ISSUE(cA1, true, 1, 0)
+            G8_WAIT(0)
+            G8_MFMA(0, 1, bf1)
+            G8_READ_A(1, 1)
+            G8_ISSUE(cA0, true, 0, 1)
+            G8_MFMA(1, 1, bf1)
+            G8_ISSUE(cB0, false, 0, 1)
+            G8_WAIT(0)
+            G8_MFMA(1, 0, bf0)
+        } else if constexpr (SCHED == 2) {
+            // two big phases per K-tile: BP1 reads A0 B0 B1 + issues A1 of the next K-tile; BP2 reads A1 + issues A0 B0 B1 of
+            // K-tile + 2 into the slots BP1 has just retired.  Every wait is vmcnt(8) (see the header comment).
+            G8_READ_B(0, 0, bf0)
+            G8_READ_B(0, 1, bf1)
+            G8_READ_A(0, 0)
+            G8_ISSUE(cA1, true, 1, 1)
+            G8_WAIT(8)
+            G8_MFMA2(0)
+            G8_READ_A(0, 1)
+            G8_ISSUE(cA0, true, 0, 0)
+            G8_ISSUE(cB0, false, 0, 0)
+            G8_ISSUE(cB1, false, 1, 0)
+            G8_WAIT(2)
+            G8_MFMA2(1)
+            G8_READ_B(1, 0, bf0)
+            G8_READ_B(1, 1, bf1)
+            G8_READ_A(1, 0)
+            G8_ISSUE(cA1, true, 1, 0)
+            G8_WAIT(0)
+            G8_MFMA2(0)
+            G8_READ_A(1, 1)
+            G8_ISSUE(cA0, true, 0, 1)
+            G8_ISSUE(cB0, false, 0, 1)
+            G8_ISSUE(cB1, false, 1, 1)
+            G8_WAIT(0)
+            G8_MFMA2(1)
+        }
         if (++it_c < per_tile2) continue;
         // ================= tile finished: epilogue (the next tile's first K-tiles are in flight) =================
         it_c = 0;
@@ -232,7 +289,16 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(G8Params p) {
         char* st = smem + G8_STAGE + wave * 4096;
         const int erow = lane & 15, eq = lane >> 4;
         const int n0 = bn * 256 + wc * 64;
-        if constexpr (KIND == 0) {
+        if constexpr (DBG == 4) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) asm volatile("" ::"v"(acc[h][g][nt][mt]));
+        } else if constexpr (KIND == 0) {
             // bf16 (split) store of act(acc): two 2 KiB staging slots (16 rows x 64 bf16, chunk ^= row & 7)
             const int rrow = lane >> 3, rch = ((lane & 7) ^ (lane >> 3)) << 4, rcol = (lane & 7) * 8;
 #pragma unroll
@@ -391,6 +457,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(G8Params p) {
     }
     if (staggered && wr == 0) asm volatile("s_barrier" ::: "memory");  // (unreachable in practice: every tile ends re-aligned)
 #undef G8_WAIT
+#undef G8_MFMA2
 #undef G8_MFMA
 #undef G8_READ_A
 #undef G8_READ_B
@@ -407,9 +474,9 @@ inline int g8_env() {
     return e ? atoi(e) : 1;
 }
 
-template <int KIND, int NSEG, int ACT, bool DACT, bool SPLIT_OUT>
-int g8_launch(const G8Params& p, int grid, hipStream_t st) {
-    auto kern = gemm8_kernel<KIND, NSEG, ACT, DACT, SPLIT_OUT>;
+template <int KIND, int NSEG, int ACT, bool DACT, bool SPLIT_OUT, int SCHED = 1, int DBG = 0>
+int g8_launch_v(const G8Params& p, int grid, hipStream_t st) {
+    auto kern = gemm8_kernel<KIND, NSEG, ACT, DACT, SPLIT_OUT, SCHED, DBG>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G8_SMEM) != hipSuccess) {
@@ -418,10 +485,29 @@ int g8_launch(const G8Params& p, int grid, hipStream_t st) {
         }
         attr_done = true;
     }
-    ig_note_kernel("gemm8_kernel<%d,%d,%d,%s,%s>", KIND, NSEG, ACT, DACT ? "true" : "false", SPLIT_OUT ? "true" : "false");
+    ig_note_kernel("gemm8_kernel<%d,%d,%d,%s,%s,%d,%d>", KIND, NSEG, ACT, DACT ? "true" : "false", SPLIT_OUT ? "true" : "false", SCHED, DBG);
     ig_note_grid(grid);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), G8_SMEM, st, p);
     return ig_check_launch("gemm8");
+}
+
+// IG_G8_SCHED = 0 selects the 16-MFMA-phase schedule (A/B runs); with -DIG_G8_ABLATE, IG_G8_DBG = 1..4 the timing ablations
+template <int KIND, int NSEG, int ACT, bool DACT, bool SPLIT_OUT>
+int g8_launch(const G8Params& p, int grid, hipStream_t st) {
+    const char* e = getenv("IG_G8_SCHED");
+    const int sched = e ? atoi(e) : 2;
+#ifdef IG_G8_ABLATE
+    if constexpr (KIND == 0 && NSEG == 1 && ACT == 0) {
+        const char* d = getenv("IG_G8_DBG");
+        const int dbg = d ? atoi(d) : 0;
+        if (dbg == 1) return g8_launch_v<KIND, NSEG, ACT, DACT, SPLIT_OUT, 2, 1>(p, grid, st);
+        if (dbg == 2) return g8_launch_v<KIND, NSEG, ACT, DACT, SPLIT_OUT, 2, 2>(p, grid, st);
+        if (dbg == 3) return g8_launch_v<KIND, NSEG, ACT, DACT, SPLIT_OUT, 2, 3>(p, grid, st);
+        if (dbg == 4) return g8_launch_v<KIND, NSEG, ACT, DACT, SPLIT_OUT, 2, 4>(p, grid, st);
+    }
+#endif
+    if (sched == 0) return g8_launch_v<KIND, NSEG, ACT, DACT, SPLIT_OUT, 0, 0>(p, grid, st);
+    return g8_launch_v<KIND, NSEG, ACT, DACT, SPLIT_OUT, 2, 0>(p, grid, st);
 }
 
 }  // namespace

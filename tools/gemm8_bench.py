@@ -54,15 +54,30 @@ for name, N, K, kind in [("qkv", 3 * D, D, "plain"), ("fc1 (gelu, infer)", 4 * D
     cases.append((name, N, K, fn))
 
 print(f"M={M} D={D} mode={'bf16x3' if split else 'bf16'}")
-for name, N, K, fn in cases:
-    res = {"0": [], "1": []}
+if "--v8-only" in sys.argv:  # profiling passes: a few launches of each case on the 8-phase engine only
+    os.environ["IG_GEMM8"] = "1"
+    for name, N, K, fn in cases:
+        for _ in range(6):
+            fn()
+    torch.cuda.synchronize()
+    sys.exit(0)
+VARIANTS = [("old", {"IG_GEMM8": "0"}), ("v8 s0", {"IG_GEMM8": "1", "IG_G8_SCHED": "0"}), ("v8 s2", {"IG_GEMM8": "1", "IG_G8_SCHED": "2"})]
+ABL = [("s2 noDMA", {"IG_GEMM8": "1", "IG_G8_DBG": "1"}), ("s2 noDMA noLDS", {"IG_GEMM8": "1", "IG_G8_DBG": "2"}),
+       ("s2 noDMA noLDS noBAR", {"IG_GEMM8": "1", "IG_G8_DBG": "3"}), ("s2 noEPI", {"IG_GEMM8": "1", "IG_G8_DBG": "4"})]
+for ci, (name, N, K, fn) in enumerate(cases):
+    variants = VARIANTS + (ABL if (ci == 0 and not split and "--ablate" in sys.argv) else [])
+    res = {v: [] for v, _ in variants}
     for rnd_i in range(5):
-        for eng in ("0", "1"):
-            os.environ["IG_GEMM8"] = eng
+        for v, env in variants:
+            for k in ("IG_GEMM8", "IG_G8_SCHED", "IG_G8_DBG"):
+                os.environ.pop(k, None)
+            os.environ.update(env)
             if rnd_i == 0:
                 for _ in range(3):
                     fn()
-            res[eng].append(timeit(fn))
+            res[v].append(timeit(fn))
     fl = 2.0 * M * N * K * (3 if split else 1)
-    t0, t1 = statistics.median(res["0"]), statistics.median(res["1"])
-    print(f"{name:28s} N={N:5d} K={K:5d}: old {t0:7.1f} us ({fl/t0/1e6:6.0f} TF/s mfma-level)   v8 {t1:7.1f} us ({fl/t1/1e6:6.0f} TF/s)   min {min(res['0']):.1f} / {min(res['1']):.1f}")
+    line = f"{name:28s} N={N:5d} K={K:5d}: " + "   ".join(f"{v} {statistics.median(t):7.1f} us ({fl/statistics.median(t)/1e6:5.0f} TF/s)" for v, t in res.items())
+    print(line)
+for k in ("IG_GEMM8", "IG_G8_SCHED", "IG_G8_DBG"):
+    os.environ.pop(k, None)

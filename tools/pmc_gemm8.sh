@@ -1,0 +1,33 @@
+#!/bin/bash
+# SQ / LDS counter passes for the forward GEMM microbench: tools/pmc_gemm8.sh OUTDIR [gemm8_bench.py args]
+# (separate --pmc passes with --kernel-trace only, as MI355X_MICROARCH.md prescribes).  Prints per-kernel averages with
+#   mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x CUs x GRBM_GUI_ACTIVE / 8 XCDs)      (cycles / cycles)
+#   wait fractions = SQ_WAIT_* / SQ_WAVE_CYCLES                                           (quad-cycles / quad-cycles)
+OUT=$1; shift
+R=${GRAFT_REPO_ROOT:-/root/repo}
+case $OUT in /*) ;; *) OUT=$R/$OUT;; esac
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -o pmc -- python3 $R/tools/gemm8_bench.py --v8-only "$@" > $OUT/pmc_sq.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-trace --output-format csv -d $OUT/pmc_lds -o pmc -- python3 $R/tools/gemm8_bench.py --v8-only "$@" > $OUT/pmc_lds.log 2>&1
+python3 - <<PY
+import csv,glob,collections
+agg=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.defaultdict(collections.Counter)
+for fn in glob.glob("$OUT/pmc_*/**/*counter_collection.csv",recursive=True):
+    for r in csv.DictReader(open(fn)):
+        k=r["Kernel_Name"].replace("(anonymous namespace)::","").split("(")[0].replace("void ","").replace(" ","")
+        if "gemm" not in k: continue
+        agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); n[k][r["Counter_Name"]]+=1
+for k,v in agg.items():
+    print(k)
+    a={c: v[c]/max(n[k][c],1) for c in v}
+    for c in sorted(a): print(f"   {c:32s} {a[c]:16.0f}")
+    if a.get("GRBM_GUI_ACTIVE"):
+        cyc=a["GRBM_GUI_ACTIVE"]/8
+        print(f"   -> kernel cycles (GRBM_GUI_ACTIVE/8) {cyc:.0f}; mfma_util = {a.get('SQ_VALU_MFMA_BUSY_CYCLES',0)/(4*256*cyc):.3f}")
+    wc=a.get("SQ_WAVE_CYCLES")
+    if wc:
+        for c in ("SQ_WAIT_ANY","SQ_WAIT_INST_ANY","SQ_ACTIVE_INST_ANY","SQ_WAIT_INST_LDS","SQ_ACTIVE_INST_VALU"):
+            if c in a: print(f"   -> {c}/SQ_WAVE_CYCLES = {a[c]/wc:.3f}")
+    if a.get("SQ_LDS_IDX_ACTIVE"): print(f"   -> LDS bank-conflict cycles / LDS active cycles = {a.get('SQ_LDS_BANK_CONFLICT',0)/a['SQ_LDS_IDX_ACTIVE']:.3f}")
+PY
