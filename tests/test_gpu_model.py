@@ -277,3 +277,63 @@ def test_input_validation():
         PrithviSeg(variant="prithvi_eo_v2_600", load_pretrained_weights=False, device=DEV)
     with pytest.raises(RuntimeError):
         PrithviSeg(variant="prithvi_eo_tiny", load_pretrained_weights=True, device=DEV)
+
+
+def test_trained_weights_bf16_miou_and_loss_vs_oracle():
+    """north_star: "outputs (logits, mIoU) must match the reference CPU path within 1e-3".  Random-init logits have std ~0.05,
+    so their argmax is maximally fragile; this test first TRAINS Prithvi-tiny for 60 fused steps (bf16 kernels, lr 1e-3) on a
+    learnable synthetic task (label = sign of a low-frequency field in band 0), then evaluates the trained weights on held-out
+    chips three ways: CPU oracle fp32, the bf16x3 parity mode and the bf16 bench mode.  bf16x3 is held to the 1e-3 bar; the
+    bf16 deltas are MEASURED and printed (and bounded loosely) -- see README "precision modes"."""
+    from instageo_amd.metrics import metrics_from_matrix
+
+    cfg = O.make_config("prithvi_eo_tiny", 1, 2)
+    cw = class_weights_for(2)
+
+    def batch(seed, B=8):
+        g = torch.Generator().manual_seed(seed)
+        blocks = torch.randn(B, 6, 1, 14, 14, generator=g)
+        x = blocks.repeat_interleave(16, 3).repeat_interleave(16, 4) + 0.3 * torch.randn(B, 6, 1, 224, 224, generator=g)
+        y = (blocks[:, 0, 0] > 0).long().repeat_interleave(16, 1).repeat_interleave(16, 2)
+        y[torch.rand(B, 224, 224, generator=g) < 0.05] = -1
+        return x, y
+
+    mod = PrithviSegmentationModule(freeze_backbone=False, load_pretrained_weights=False, num_classes=2, model_name="prithvi_eo_tiny",
+                                    class_weights=[1, 3], ignore_index=-1, learning_rate=1e-3, scheduler=False, precision="bf16", device=DEV)
+    mod.net.load_state_dict(O.make_state_dict(cfg, seed=1042))
+    first = last = None
+    for step in range(60):
+        x, y = batch(100 + step % 12)
+        st = mod.fused_train_step(x.to(DEV), y.to(DEV))
+        loss = (st[0] / st[1]).item()
+        first = loss if first is None else first
+        last = loss
+    assert last < 0.6 * first, f"the task did not train: loss {first:.4f} -> {last:.4f}"
+    sd = {k: v.detach().cpu().clone() for k, v in mod.net.state_dict().items()}
+    xv, yv = batch(999, B=8)
+    with torch.no_grad():
+        ref = O.prithvi_seg_forward(cfg, sd, xv, training=False)
+    ref_loss = O.seg_loss(ref, yv, cw, -1).item()
+    ref_m = O.confusion_metrics(O.confusion_matrix(yv.numpy(), ref.argmax(1).numpy(), 2, -1))
+    conf_ref = ref.softmax(1).max(1).values.mean().item()
+    print(f"[trained tiny] train loss {first:.4f} -> {last:.4f}; oracle eval loss {ref_loss:.5f} mIoU {ref_m['jaccard']:.5f} acc {ref_m['accuracy']:.5f} mean max-prob {conf_ref:.3f}")
+    assert ref_m["jaccard"] > 0.6  # a trained, confident model (random init: ~0.33)
+    out = {}
+    for precision in ("bf16x3", "bf16"):
+        net = PrithviSeg(temporal_step=1, num_classes=2, load_pretrained_weights=False, freeze_backbone=False, variant="prithvi_eo_tiny",
+                         precision=precision, device=DEV)
+        net.load_state_dict(sd)
+        net.eval()
+        with torch.no_grad():
+            logits = net(xv.to(DEV))
+        conf = torch.zeros(2, 2, dtype=torch.int64, device=DEV)
+        loss = segmentation_loss(logits, yv.to(DEV), cw.to(DEV), -1, confusion=conf).item()
+        m = metrics_from_matrix(conf.cpu().numpy())
+        dl, dm, dx = abs(loss - ref_loss), abs(m["jaccard"] - ref_m["jaccard"]), (logits.cpu() - ref).abs().max().item()
+        agree = (logits.argmax(1).cpu() == ref.argmax(1)).float().mean().item()
+        print(f"   {precision:7s}: |dloss| {dl:.2e}  |dmIoU| {dm:.2e}  max|dlogits| {dx:.2e}  argmax agreement {agree:.6f}")
+        out[precision] = (dl, dm, dx, agree)
+    dl, dm, dx, agree = out["bf16x3"]
+    assert dl <= 1e-3 and dm <= 1e-3 and dx <= 1e-3, "bf16x3 misses the 1e-3 bar on trained weights"
+    dl, dm, dx, agree = out["bf16"]
+    assert dl <= 1e-2 and dm <= 5e-3 and agree >= 0.995, f"bf16 on trained weights: dloss {dl} dmIoU {dm} agreement {agree}"
