@@ -497,6 +497,10 @@ int ig_attention_fwd(const void* qkv_hi, const void* qkv_lo, void* out_hi, void*
     IG_REQUIRE(head_dim == HD, "ig_attention_fwd: head_dim must be 64 (got %d)", head_dim);
     IG_REQUIRE((qkv_lo == nullptr) == (out_lo == nullptr), "ig_attention_fwd: split pointers must be given for all tensors or none");
     if (B == 0 || N == 0) return IG_OK;
+    {
+        const int rc = ig_attention2_fwd(qkv_hi, qkv_lo, out_hi, out_lo, lse, B, N, H, stream);
+        if (rc != IG_ERR_UNSUPPORTED) return rc;
+    }
     int nblk, nw;
     wave_geometry(N, nblk, nw);
     dim3 grid(nblk, H, B), block(nw * 64);
@@ -523,6 +527,10 @@ int ig_attention_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi,
     IG_REQUIRE(split == (out_lo != nullptr) && split == (dout_lo != nullptr) && split == (dqkv_lo != nullptr),
                "ig_attention_bwd: split pointers must be given for all tensors or none");
     if (B == 0 || N == 0) return IG_OK;
+    {
+        const int rc = ig_attention2_bwd(qkv_hi, qkv_lo, out_hi, out_lo, dout_hi, dout_lo, lse, delta, dqkv_hi, dqkv_lo, B, N, H, stream);
+        if (rc != IG_ERR_UNSUPPORTED) return rc;
+    }
     hipStream_t st = (hipStream_t)stream;
     // delta is produced by the query-owner pass (first launch) and consumed by the key-owner pass (second)
     int nblk, nw;

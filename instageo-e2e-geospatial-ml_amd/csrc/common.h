@@ -52,6 +52,10 @@ struct G8Params {
 };
 int ig_gemm8_nt(const G8Params& p, void* stream);  // IG_ERR_UNSUPPORTED (no error string) when the shape is not covered
 // runtime.hip: compute units the persistent kernels leave free (for RCCL's kernels when world > 1); ig_set_reserved_cus()
+// attention2.hip: second-generation attention forward (32x32x16 MFMA, whole-head K/V in LDS); IG_ERR_UNSUPPORTED -> first generation
+int ig_attention2_fwd(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, float* lse, int B, int N, int H, void* stream);
+int ig_attention2_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi, const void* out_lo, const void* dout_hi,
+                      const void* dout_lo, const float* lse, float* delta, void* dqkv_hi, void* dqkv_lo, int B, int N, int H, void* stream);
 // runtime.hip: name of the kernel an entry point launched last on this thread (rocprofv3's demangled name without namespaces and
 // spaces), so bench.py can key its per-kernel roofline table by the names the rocprof summaries under profiles/ use
 void ig_note_kernel(const char* fmt, ...);

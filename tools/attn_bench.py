@@ -20,7 +20,16 @@ for B, N, H in [(108, 197, 12), (36, 589, 12), (54, 197, 16)]:
     out = BT.empty((B, N, H * 64), False, dev); lse = torch.empty(B * H * N, device=dev)
     dout = BT(torch.randn(B, N, H * 64, device=dev).bfloat16()); dqkv = BT.empty((B, N, 3 * H * 64), False, dev)
     delta = torch.empty(B * H * N, device=dev)
+    os.environ["IG_ATTN2"] = "0"
+    tf0 = timeit(lambda: ops.attention_fwd(qkv, out, lse, B, N, H))
+    os.environ["IG_ATTN2"] = "1"
     tf = timeit(lambda: ops.attention_fwd(qkv, out, lse, B, N, H))
+    os.environ["IG_ATTN2"] = "2"
+    tb0 = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H))
+    os.environ["IG_ATTN2"] = "1"
+    os.environ["IG_ATTN2_DQLB"] = "4"
+    tb4 = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H))
+    os.environ["IG_ATTN2_DQLB"] = "2"
     tb = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H))
     fl = 4.0 * B * H * N * N * 64
-    print(f"B{B} N{N} H{H}: fwd {tf:7.1f} us ({fl/tf/1e6:5.0f} TF)  bwd {tb:7.1f} us ({2.5*fl/tb/1e6:5.0f} TF)  ")
+    print(f"B{B} N{N} H{H}: fwd gen1 {tf0:7.1f} us ({fl/tf0/1e6:5.0f} TF)  gen2 {tf:7.1f} us ({fl/tf/1e6:5.0f} TF)  bwd gen1 {tb0:7.1f} us  gen2(lb4) {tb4:7.1f} us  gen2 {tb:7.1f} us ({2.5*fl/tb/1e6:5.0f} TF)")
