@@ -1294,8 +1294,15 @@ struct EpAtomic {
     long ldo;
     long zstride;
     long zoff;
+    // deterministic split-K: with `partial` set, split blockIdx.y STORES its tile into slab blockIdx.y of a workspace (plain,
+    // row-contiguous stores) and splitk_reduce_kernel adds the slabs to `out` in split order afterwards -- no float atomics
+    float* partial;
+    long slab;
     __device__ void init(int z) { zoff = (long)z * zstride; }
-    __device__ void add(int m, int n, float v) const { atomicAdd(out + (size_t)m * ldo + zoff + n, v); }
+    __device__ void add(int m, int n, float v) const {
+        if (partial) partial[(size_t)blockIdx.y * slab + (size_t)m * ldo + n] = v;
+        else atomicAdd(out + (size_t)m * ldo + zoff + n, v);
+    }
     __device__ void store(int m, int n, f32x4 a) const {
         float* p = out + (size_t)m * ldo + zoff + n;
         atomicAdd(p + 0, a[0]);
@@ -1304,6 +1311,37 @@ struct EpAtomic {
         atomicAdd(p + 3, a[3]);
     }
 };
+
+// out[i] += sum_s partial[s][i] in split order (fixed summation order: bit-reproducible weight gradients)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __restrict__ part, float4* __restrict__ out, long n4, int ks,
+                                                            long slab4) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 s = part[i];
+        for (int k = 1; k < ks; ++k) {
+            const float4 t = part[k * slab4 + i];
+            s.x += t.x, s.y += t.y, s.z += t.z, s.w += t.w;
+        }
+        float4 o = out[i];
+        o.x += s.x, o.y += s.y, o.z += s.z, o.w += s.w;
+        out[i] = o;
+    }
+}
+// workspace of the split-K partial tiles (grown on demand, never shrunk; all launches are ordered on the caller's stream)
+inline float* splitk_workspace(size_t bytes) {
+    static void* ws = nullptr;
+    static size_t cap = 0;
+    if (bytes > cap) {
+        if (ws) (void)hipFree(ws);
+        ws = nullptr, cap = 0;
+        if (hipMalloc(&ws, bytes) != hipSuccess) return nullptr;
+        cap = bytes;
+    }
+    return (float*)ws;
+}
+inline bool splitk_partial_enabled() {
+    static const int v = getenv("IG_WGRAD_PARTIAL") ? atoi(getenv("IG_WGRAD_PARTIAL")) : 1;
+    return v != 0;
+}
 
 // ------------------------------------------------------------------------------------ launch
 // Engine choice for the plain-matrix GEMMs.  IG_GEMM=1|2|5 forces one engine (A/B runs); unset: v2 everywhere except
@@ -1341,9 +1379,38 @@ inline const bf16_t* zero_page() {
 constexpr int tr_pitch(int upr) { return upr <= 8 ? 8 : upr <= 12 ? 12 : 16; }
 
 template <class AL, class BL, class EP, bool A_TR, bool B_TR>
-int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int Z, bool split, hipStream_t st,
+int launch_gemm(const AL& al, const BL& bl, const EP& ep_in, int M, int N, int K, int Z, bool split, hipStream_t st,
                 const char* what, bool allow_ksplit = false, int force_ver = 0) {
     if (M <= 0 || N <= 0 || K <= 0) return IG_OK;
+    EP ep = ep_in;
+    // Split-K weight gradients (atomic epilogue): `ks` splits store their tiles into workspace slabs and one reduce launch adds them
+    // to the gradient in a fixed order (deterministic; the split-K float atomics were ~25 us of each ~100 us launch).
+    int partial_ks = 0;
+    auto prep_partial = [&](int ks) -> int {
+        if constexpr (EP::kStagedAtomic) {
+            partial_ks = 0;
+            if (ks > 1 && Z == 1 && splitk_partial_enabled() && ((long)M * ep.ldo) % 4 == 0 && (((uintptr_t)ep.out) & 15) == 0) {
+                float* ws = splitk_workspace((size_t)ks * M * ep.ldo * sizeof(float));
+                if (!ws) {
+                    ig_set_error("%s: could not allocate the split-K workspace", what);
+                    return IG_ERR_HIP;
+                }
+                ep.partial = ws, ep.slab = (long)M * ep.ldo;
+                partial_ks = ks;
+            }
+        }
+        return IG_OK;
+    };
+    auto finish_partial = [&]() {
+        if constexpr (EP::kStagedAtomic) {
+            if (partial_ks > 1) {
+                const long n4 = (long)M * ep.ldo / 4;
+                const int blocks = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)ep.partial, (float4*)ep.out, n4,
+                                   partial_ks, n4);
+            }
+        }
+    };
     // v2 (256x128, LDS-DMA ring) wins on the encoder linears; the head convolutions (Cout 48..384, huge M) are
     // better served by the 128x128 register-staged tile at 2 workgroups/CU until a narrow-N tile exists
     int ver = force_ver ? force_ver : gemm_version();
@@ -1389,8 +1456,10 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, i
         ig_note_grid((int)grid5.x);                                                                                    \
         hipLaunchKernelGGL(kern, grid5, dim3(NTHR5), G5_SMEM, st, al, bl, ep, M, N, K, tn5, ntiles, kchunk5, zp5);     \
     }
+            if (prep_partial((int)grid5.y) != IG_OK) return IG_ERR_HIP;
             if (split) IG_LAUNCH_V5(3) else IG_LAUNCH_V5(1)
 #undef IG_LAUNCH_V5
+            finish_partial();
             return ig_check_launch(what);
         }
     }
@@ -1467,11 +1536,15 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, i
                         attr_dual = true;
                     }
                     ig_note_kernel("gemm2_kernel<%s,%s,%s,%s,%s,1,32,2>", AL::kName, BL::kName, EP::kName, A_TR ? "true" : "false", B_TR ? "true" : "false");
+                    if (prep_partial((int)grid.y) != IG_OK) return IG_ERR_HIP;
                     hipLaunchKernelGGL(kern, grid, dim3(2 * NTHR2), 2 * G2<32>::SMEM, st, al, bl, ep, M, N, K, tn, ntiles, kchunk, zp);
+                    finish_partial();
                     return ig_check_launch(what);
                 }
             }
+            if (prep_partial((int)grid.y) != IG_OK) return IG_ERR_HIP;
             if (split) IG_LAUNCH_V2(3, 32) else IG_LAUNCH_V2(1, 32)
+            finish_partial();
         } else {
             // persistent: two workgroups per CU walk the tile list; BK = 32 keeps the ring at 72 KiB
             const int slots2 = 2 * (ig_cu_count() - ig_reserved_cus());  // persistent: two workgroups per (unreserved) CU
@@ -1501,6 +1574,7 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, i
     }
 #define IG_LAUNCH_V1(NSEG_, MT_, NT_, WM_) IG_LAUNCH_V1K(NSEG_, MT_, NT_, WM_, 64)
     if constexpr (EP::kStagedAtomic) {
+        if (prep_partial((int)grid.y) != IG_OK) return IG_ERR_HIP;
         if (mt == 1) {  // 48 x 128
             if (split) IG_LAUNCH_V1(3, 3, 2, 1) else IG_LAUNCH_V1(1, 3, 2, 1)
         } else if (mt == 3) {
@@ -1530,6 +1604,7 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, i
     }
 #undef IG_LAUNCH_V1K
 #undef IG_LAUNCH_V1
+    finish_partial();
     return ig_check_launch(what);
 }
 
@@ -1657,7 +1732,7 @@ int ig_linear_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, cons
     IG_REQUIRE(dy_hi && x_hi && dw, "ig_linear_wgrad: null pointer");
     IG_REQUIRE(N % 8 == 0 && K % 8 == 0, "ig_linear_wgrad: N and K must be multiples of 8");
     IG_SPLIT_CONSISTENT(dy_lo, x_lo);
-    EpAtomic ep{dw, (long)K, 0, 0};
+    EpAtomic ep{dw, (long)K, 0, 0, nullptr, 0};
     // K-steps of 32 per workgroup if the 256 x 128 engine ran this problem (its split-K rule, see launch_gemm)
     const int nk32 = ig_cdiv(M, 32), tiles2 = ig_cdiv(N, 256) * ig_cdiv(K, 128);
     int ks2 = 512 / tiles2;
@@ -1771,7 +1846,7 @@ int ig_conv3x3_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, con
     seg_b(bl.base, x_hi, x_lo);
     bl.Mtot = Mtot, bl.H = H, bl.W = W, bl.C = Cin, bl.sign = 1;
     bl.finish();
-    EpAtomic ep{dw, 9L * Cin, 0, 0};
+    EpAtomic ep{dw, 9L * Cin, 0, 0, nullptr, 0};
     return launch_gemm<PlainLoader, Conv3Loader, EpAtomic, true, true>(
         plain_a(dy_hi, dy_lo, Mtot, Cout, Cout), bl, ep, Cout, 9 * Cin, Mtot, 1, dy_lo != nullptr, (hipStream_t)stream,
         "ig_conv3x3_wgrad", true, 1);
@@ -1859,7 +1934,7 @@ int ig_convT_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const
     seg_a(al.base, dy_hi, dy_lo);
     al.Mtot = Mtot, al.H = H, al.W = W, al.Cout = Cout, al.fixed_tap = -2;
     al.finish();
-    EpAtomic ep{dw, 9L * Cin, (long)Cin, 0};
+    EpAtomic ep{dw, 9L * Cin, (long)Cin, 0, nullptr, 0};
     return launch_gemm<ConvTGradLoader, PlainLoader, EpAtomic, true, true>(
         al, plain_b(x_hi, x_lo, Mtot, Cin, Cin), ep, Cout, Cin, Mtot, 9, dy_lo != nullptr, (hipStream_t)stream,
         "ig_convT_wgrad", true, 1);

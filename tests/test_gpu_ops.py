@@ -252,6 +252,23 @@ def test_transpose_bf16_batched():
 
 
 @pytest.mark.parametrize("split", SPLITS)
+@pytest.mark.parametrize("M,N,K", [(21276, 2304, 768), (21276, 768, 768), (4100, 768, 3072), (3152, 768, 768)])
+def test_linear_wgrad_is_deterministic(split, M, N, K):
+    """The reference trains with deterministic=True: split-K weight gradients go through workspace slabs + one ordered reduce
+    (no float atomics), so repeated launches are bit-identical; IG_WGRAD_PARTIAL=0 would restore the atomic form."""
+    dy, dyr = bt(rnd(M, N, seed=5), split)
+    x, xr = bt(rnd(M, K, seed=7), split)
+    dw = torch.zeros(N, K, device=DEV)
+    ops.linear_wgrad(dy, x, dw, M, N, K)
+    close(dw, dyr.t() @ xr, 3e-5 if split else 2e-5, what="wgrad")
+    first = dw.clone()
+    for _ in range(4):
+        dw.zero_()
+        ops.linear_wgrad(dy, x, dw, M, N, K)
+        assert torch.equal(dw, first), "weight gradient differs between identical launches"
+
+
+@pytest.mark.parametrize("split", SPLITS)
 @pytest.mark.parametrize("T", [1, 3])
 def test_patch_embed(split, T):
     B, C, H, W, p, D = 2, 6, 64, 48, 16, 64
