@@ -372,10 +372,25 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(G8Params p) {
             // layout it was an 8-byte load per 4 values behind the stores).
             const int rrow = lane >> 3, rcol = (lane & 7) * 8;
             float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            constexpr int PF = SPLIT_OUT ? 2 : 4;  // row tiles per batch of factor loads (16 / 32 registers of hi [+ lo] words)
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int bt = 0; bt < 8 / PF; ++bt) {
+                // the factor loads of a batch go out FIRST: interleaved with the stores below, every load sat behind the previous
+                // row tile's stores in the in-order vmcnt and its latency was paid 16 times per tile
+                uint4 fh[PF][2], fl[PF][2];
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
+                for (int j = 0; j < PF; ++j)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int t = bt * PF + j;
+                        const int m = min(bm * 256 + wr * 128 + (t >> 2) * 64 + (t & 3) * 16 + i * 8 + rrow, p.M - 1);
+                        const size_t o = (size_t)m * p.ldo + n0 + rcol;
+                        fh[j][i] = *reinterpret_cast<const uint4*>(p.dact_hi + o);
+                        if constexpr (SPLIT_OUT) fl[j][i] = *reinterpret_cast<const uint4*>(p.dact_lo + o);
+                    }
+#pragma unroll
+                for (int j = 0; j < PF; ++j) {
+                    const int t = bt * PF + j, h = t >> 2, mt = t & 3;
                     const int m0 = bm * 256 + wr * 128 + h * 64 + mt * 16;
 #pragma unroll
                     for (int g = 0; g < 2; ++g)
@@ -390,31 +405,32 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(G8Params p) {
                         const f32x4 a0 = *reinterpret_cast<const f32x4*>(st + r * 256 + (((2 * (lane & 7)) ^ (r & 7)) << 4));
                         const f32x4 a1 = *reinterpret_cast<const f32x4*>(st + r * 256 + (((2 * (lane & 7) + 1) ^ (r & 7)) << 4));
                         const int m = m0 + r;
+                        float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                        float f[8];
+                        unpack8(fh[j][i], f);
+                        if constexpr (SPLIT_OUT) {
+                            float f2[8];
+                            unpack8(fl[j][i], f2);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) f[e] += f2[e];
+                        }
                         if (m < p.M) {
                             const size_t o = (size_t)m * p.ldo + n0 + rcol;
-                            float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                            float f[8];
-                            unpack8(*reinterpret_cast<const uint4*>(p.dact_hi + o), f);
-                            if constexpr (SPLIT_OUT) {
-                                float fl[8];
-                                unpack8(*reinterpret_cast<const uint4*>(p.dact_lo + o), fl);
 #pragma unroll
-                                for (int j = 0; j < 8; ++j) f[j] += fl[j];
-                            }
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) v[j] *= f[j], cs[j] += v[j];
+                            for (int e = 0; e < 8; ++e) v[e] *= f[e], cs[e] += v[e];
                             const uint4 u = pack8(v);
                             *reinterpret_cast<uint4*>(p.out_hi + o) = u;
                             if constexpr (SPLIT_OUT) {
                                 float hv[8], rv[8];
                                 unpack8(u, hv);
 #pragma unroll
-                                for (int j = 0; j < 8; ++j) rv[j] = v[j] - hv[j];
+                                for (int e = 0; e < 8; ++e) rv[e] = v[e] - hv[e];
                                 *reinterpret_cast<uint4*>(p.out_lo + o) = pack8(rv);
                             }
                         }
                     }
                 }
+            }
             if (p.colsum) {  // lanes with equal (lane & 7) own the same 8 columns: fold over lane >> 3, one atomic per column
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -426,32 +442,41 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(G8Params p) {
                 }
             }
         } else {
-            // fp32 residual: out = resid + acc (bias is in the accumulator init); 16 rows x 64 fp32 = 4 KiB staged
+            // fp32 residual: out = resid + acc (bias is in the accumulator init); 16 rows x 64 fp32 = 4 KiB staged.  The residual
+            // rows of row tile t + 1 are loaded before row tile t is stored (their latency hides behind the staging round trip;
+            // loaded after the stores they would wait for them in the in-order vmcnt).
             const int rrow = lane >> 4, rc = lane & 15;
+            float4 rs[2][4];
+#define G8_RESID_LOAD(T, DST)                                                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                                     \
+        const int m_ = min(bm * 256 + wr * 128 + ((T) >> 2) * 64 + ((T)&3) * 16 + i_ * 4 + rrow, p.M - 1);                 \
+        DST[i_] = *reinterpret_cast<const float4*>(p.resid + (size_t)m_ * p.ldo + n0 + rc * 4);                            \
+    }
+            G8_RESID_LOAD(0, rs[0])
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int t = 0; t < 8; ++t) {
+                const int h = t >> 2, mt = t & 3;
+                const int m0 = bm * 256 + wr * 128 + h * 64 + mt * 16;
+                if (t + 1 < 8) G8_RESID_LOAD(t + 1, rs[(t + 1) & 1])
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    const int m0 = bm * 256 + wr * 128 + h * 64 + mt * 16;
+                for (int g = 0; g < 2; ++g)
 #pragma unroll
-                    for (int g = 0; g < 2; ++g)
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const int c4 = g * 8 + nt * 4 + eq;
+                        *reinterpret_cast<f32x4*>(st + erow * 256 + ((c4 ^ (erow & 7)) << 4)) = acc[h][g][nt][mt];
+                    }
 #pragma unroll
-                        for (int nt = 0; nt < 2; ++nt) {
-                            const int c4 = g * 8 + nt * 4 + eq;
-                            *reinterpret_cast<f32x4*>(st + erow * 256 + ((c4 ^ (erow & 7)) << 4)) = acc[h][g][nt][mt];
-                        }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int r = i * 4 + rrow;
-                        const f32x4 a = *reinterpret_cast<const f32x4*>(st + r * 256 + ((rc ^ (r & 7)) << 4));
-                        const int m = m0 + r;
-                        if (m < p.M) {
-                            const size_t o = (size_t)m * p.ldo + n0 + rc * 4;
-                            const float4 rs = *reinterpret_cast<const float4*>(p.resid + o);
-                            *reinterpret_cast<float4*>(p.outf + o) = make_float4(rs.x + a[0], rs.y + a[1], rs.z + a[2], rs.w + a[3]);
-                        }
+                for (int i = 0; i < 4; ++i) {
+                    const int r = i * 4 + rrow;
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(st + r * 256 + ((rc ^ (r & 7)) << 4));
+                    const int m = m0 + r;
+                    if (m < p.M) {
+                        const float4 rv = rs[t & 1][i];
+                        *reinterpret_cast<float4*>(p.outf + (size_t)m * p.ldo + n0 + rc * 4) = make_float4(rv.x + a[0], rv.y + a[1], rv.z + a[2], rv.w + a[3]);
                     }
                 }
+            }
+#undef G8_RESID_LOAD
         }
         G8_INIT_ACC()
     }

@@ -451,6 +451,54 @@ def test_convT(split, B, H, Cin, Cout):  # 96 -> 48 unsplit runs the direct sub-
     close(db - 0.25, dyr.sum((0, 1, 2)), 3e-5, what="convT bias gradient")
 
 
+@pytest.mark.parametrize("kind,C,H", [("conv", 48, 224), ("conv", 96, 112), ("convT", 96, 112)])
+def test_direct_head_kernels_at_model_size_vs_float64(kind, C, H):
+    """The direct (halo-tile / sub-pixel) head kernels at the BASELINE image sizes -- 224 x 224 x 48, 112 x 112 x 96 and the
+    96 -> 48 ConvTranspose 112 -> 224 -- against float64 torch on the SAME bf16-rounded operands (forward, data gradient, weight
+    and bias gradient; full tensors, not samples).  tests/test_gpu_direct_vs_gemm.py only compares two HIP paths with each other."""
+    B = 2
+    if kind == "conv":
+        Cin = Cout = C
+        x, xr = bt(nhwc(rnd(B, Cin, H, H, seed=70)), False)
+        wt = rnd(Cout, Cin, 3, 3, seed=71, scale=(9 * Cin) ** -0.5)
+        w, wr = bt(wt.permute(0, 2, 3, 1).reshape(Cout, 9, Cin).contiguous(), False)
+        bias = rnd(Cout, seed=72)
+        y = BT.empty((B, H, H, Cout), False, DEV)
+        ops.conv3x3_fwd(x, w, bias.to(DEV), y, B, H, H, Cin, Cout)
+        xin = xr.permute(0, 3, 1, 2).clone().requires_grad_(True)
+        wv = wr.reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2).clone().requires_grad_(True)
+        ref = F.conv2d(xin, wv, bias.double(), padding=1)
+        Ho = H
+    else:
+        Cin, Cout = C, C // 2
+        x, xr = bt(nhwc(rnd(B, Cin, H, H, seed=73)), False)
+        wt = rnd(Cin, Cout, 3, 3, seed=74, scale=(9 * Cin) ** -0.5)  # nn.ConvTranspose2d weight (Cin, Cout, 3, 3)
+        w, wr = bt(wt.permute(1, 2, 3, 0).reshape(Cout, 9, Cin).contiguous(), False)  # stored Wc[Cout][9][Cin]
+        bias = rnd(Cout, seed=75)
+        y = BT.empty((B, 2 * H, 2 * H, Cout), False, DEV)
+        ops.convT_fwd(x, w, bias.to(DEV), y, B, H, H, Cin, Cout)
+        xin = xr.permute(0, 3, 1, 2).clone().requires_grad_(True)
+        wv = wr.reshape(Cout, 3, 3, Cin).permute(3, 0, 1, 2).clone().requires_grad_(True)
+        ref = F.conv_transpose2d(xin, wv, bias.double(), stride=2, padding=1, output_padding=1)
+        Ho = 2 * H
+    close(y.float(), nhwc(ref.detach()), tol_out(False), what=f"{kind} fwd {C}ch {H}px")
+    dy, dyr = bt(nhwc(rnd(B, Cout, Ho, Ho, seed=76)), False)
+    gx, gw = torch.autograd.grad((ref * dyr.permute(0, 3, 1, 2)).sum(), [xin, wv])
+    dx = BT.empty((B, H, H, Cin), False, DEV)
+    dw, db = torch.zeros(Cout, 9, Cin, device=DEV), torch.zeros(Cout, device=DEV)
+    if kind == "conv":
+        ops.conv3x3_dgrad(dy, w, dx, B, H, H, Cin, Cout)
+        ops.conv3x3_wgrad(dy, x, dw, B, H, H, Cin, Cout, dbias=db)
+        gw_s = gw.permute(0, 2, 3, 1).reshape(Cout, 9, Cin)
+    else:
+        ops.convT_dgrad(dy, w, dx, B, H, H, Cin, Cout)
+        ops.convT_wgrad(dy, x, dw, B, H, H, Cin, Cout, dbias=db)
+        gw_s = gw.permute(1, 2, 3, 0).reshape(Cout, 9, Cin)
+    close(dx.float(), nhwc(gx), tol_out(False), what=f"{kind} dgrad")
+    close(dw, gw_s, 3e-5, what=f"{kind} wgrad")
+    close(db, dyr.sum((0, 1, 2)), 3e-5, what=f"{kind} bias gradient")
+
+
 @pytest.mark.parametrize("C", [48, 96])
 def test_conv3x3_direct_bn_fold(C):
     """C -> C forward with the eval-mode BatchNorm + ReLU folded into the epilogue (direct kernels), ragged tile edges."""

@@ -53,6 +53,33 @@ for name, N, K, kind in [("qkv", 3 * D, D, "plain"), ("fc1 (gelu, infer)", 4 * D
         fn = (lambda xin=xin, w=w, bias=bias, y=y, pre=pre, act=act, N=N, K=K: ops.linear_fwd(xin, w, bias, y, M, N, K, act=act, pre=pre))
     cases.append((name, N, K, fn))
 
+# data gradients through the transposed weight copy: d_fc2 (x gelu' + fused fc1-bias column sums) and the plain d_fc1
+dy_s, dy_l = rnd(M, D), rnd(M, 4 * D)
+wt_fc2 = BT.from_float(torch.randn(4 * D, D, device=dev) * D**-0.5, split)   # (K, N) = fc2.weight^T
+wt_fc1 = BT.from_float(torch.randn(D, 4 * D, device=dev) * D**-0.5, split)   # fc1.weight^T
+w_fc2 = BT(wt_fc2.hi.t().contiguous(), None if wt_fc2.lo is None else wt_fc2.lo.t().contiguous())
+w_fc1 = BT(wt_fc1.hi.t().contiguous(), None if wt_fc1.lo is None else wt_fc1.lo.t().contiguous())
+dh, dxs = BT.empty((M, 4 * D), split, dev), BT.empty((M, D), split, dev)
+pre = rnd(M, 4 * D)
+cs = torch.zeros(4 * D, device=dev)
+
+
+def d_fc2():
+    if os.environ.get("IG_GEMM8") == "0":
+        ops.linear_dgrad(dy_s, w_fc2, dh, M, D, 4 * D, pre=pre, colsum=cs)
+    else:
+        ops.linear_dgrad(dy_s, None, dh, M, D, 4 * D, pre=pre, colsum=cs, wt=wt_fc2)
+
+
+def d_fc1():
+    if os.environ.get("IG_GEMM8") == "0":
+        ops.linear_dgrad(dy_l, w_fc1, dxs, M, 4 * D, D)
+    else:
+        ops.linear_dgrad(dy_l, None, dxs, M, 4 * D, D, wt=wt_fc1)
+
+
+cases.append(("d_fc2 (x gelu', +colsum)", 4 * D, D, d_fc2))
+cases.append(("d_fc1 (plain dgrad)", D, 4 * D, d_fc1))
 print(f"M={M} D={D} mode={'bf16x3' if split else 'bf16'}")
 if "--v8-only" in sys.argv:  # profiling passes: a few launches of each case on the 8-phase engine only
     os.environ["IG_GEMM8"] = "1"

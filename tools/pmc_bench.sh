@@ -4,8 +4,9 @@
 #        python3 tools/pmc_summarize.py OUTDIR > profiles/<name>.json
 OUT=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
+case $OUT in /*) ;; *) OUT=$R/$OUT;; esac
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for P in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/pmc_$P -o pmc -- python3 $R/bench.py --steps 3 --warmup 1 --no-profile --no-cpu-baseline "$@" > $OUT/pmc_$P.log 2>&1
+  rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/pmc_$P -o pmc -- python3 $R/bench.py --steps 3 --warmup 1 --no-profile --no-cpu-baseline --no-parity-leg --no-tile "$@" > $OUT/pmc_$P.log 2>&1
 done
