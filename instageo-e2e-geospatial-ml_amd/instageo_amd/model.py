@@ -37,9 +37,15 @@ PRITHVI_VARIANTS = {
     "prithvi_eo_v1_100": (768, 12, 12, 16, 3),
     "prithvi_eo_v2_100": (768, 12, 12, 16, 4),
     "prithvi_eo_v2_300": (1024, 24, 16, 16, 4),
+    # coords_encoding=["time", "location"], coords_scale_learn=True (model.py:147-153): the reference builds a TemporalEncoder and a
+    # LocationEncoder (pritvhi.py:273-367) whose only state is a trainable ``scale`` (1,) = 0.1 each -- and never calls them:
+    # PrithviViT.forward (pritvhi.py:498-530) takes no coordinates.  The variant therefore computes exactly what prithvi_eo_v2_300
+    # computes and carries two extra state_dict entries that receive no gradient.
+    "prithvi_eo_v2_300_tl": (1024, 24, 16, 16, 4),
 }
 HEAD_KERNELS = {k: (3, 3, 3, 3) for k in PRITHVI_VARIANTS}
-UNSUPPORTED_VARIANTS = ("prithvi_eo_v2_300_tl", "prithvi_eo_v2_600", "prithvi_eo_v2_600_tl")
+TL_VARIANTS = ("prithvi_eo_v2_300_tl",)
+UNSUPPORTED_VARIANTS = ("prithvi_eo_v2_600", "prithvi_eo_v2_600_tl")
 
 
 @dataclass
@@ -81,8 +87,8 @@ def make_seg_config(variant: str, temporal_step: int, image_size: int, num_class
                     in_chans: int = 6) -> SegConfig:
     if variant in UNSUPPORTED_VARIANTS:
         raise NotImplementedError(
-            f"variant {variant}: patch-14 / 5x5-7x7 head kernels / temporal-location encoders are outside the "
-            "hot-path scope (SURVEY.md section 8f item 4)"
+            f"variant {variant}: patch 14, head_dim 80 and the 5x5 / 7x7 head kernels (model.py:154-176) are not built "
+            "(the attention kernels are head_dim 64; SURVEY.md section 8f item 4)"
         )
     if variant not in PRITHVI_VARIANTS:
         raise KeyError(f"unknown Prithvi variant {variant!r}")
@@ -667,6 +673,12 @@ class PrithviSeg(nn.Module):
             if name == e + "cls_token":
                 continue
             attach(name, ent.api_view(self.store.flat), True)
+            if name == e + "patch_embed.proj.bias" and cfg.variant in TL_VARIANTS:
+                # the reference's (unused) coordinate encoders: one trainable scale each, registered right after the patch
+                # embedding (pritvhi.py:431-437).  They live OUTSIDE the flat buffer: no kernel reads them, they get no gradient,
+                # and like any gradient-less parameter under torch.optim.AdamW they are never stepped (no weight decay either).
+                attach(e + "temporal_embed_enc.scale", torch.full((1,), 0.1, dtype=torch.float32, device=dev), True)
+                attach(e + "location_embed_enc.scale", torch.full((1,), 0.1, dtype=torch.float32, device=dev), True)
             if name.startswith("segmentation_head.") and name.endswith(".3.bias"):
                 base = name[: -len("bias")]
                 c = ent.shape[0]
@@ -696,6 +708,9 @@ class PrithviSeg(nn.Module):
                 p = named[name]
                 p.data = ent.api_view(self.store.flat)
                 p.grad = None
+            for name, p in named.items():  # parameters outside the flat buffer (the _tl variants' unused scales)
+                if name not in self.store.entries:
+                    p.data = fn(p.data)
             for name in list(self._buffers_flat):
                 parts = name.split(".")
                 mod = self
@@ -734,6 +749,8 @@ class PrithviSeg(nn.Module):
                     p.copy_(w)
                 elif ".norm" in name and name.endswith("weight"):
                     p.fill_(1.0)
+                elif name.endswith("_embed_enc.scale"):  # TemporalEncoder / LocationEncoder trainable scale (pritvhi.py:289-290)
+                    p.fill_(0.1)
                 else:
                     p.zero_()
             else:

@@ -73,6 +73,9 @@ _VARIANTS = {
     "prithvi_eo_v1_100": (768, 12, 12, 16),
     "prithvi_eo_v2_100": (768, 12, 12, 16),
     "prithvi_eo_v2_300": (1024, 24, 16, 16),
+    # model.py:147-153: coords_encoding time + location, coords_scale_learn=True.  The encoders (pritvhi.py:273-367) are built but
+    # PrithviViT.forward (pritvhi.py:498-530) never calls them: same arithmetic as prithvi_eo_v2_300, two extra (1,) parameters.
+    "prithvi_eo_v2_300_tl": (1024, 24, 16, 16),
 }
 
 
@@ -146,6 +149,9 @@ def state_dict_shapes(cfg: OracleConfig) -> Dict[str, Tuple[int, ...]]:
     s[e + "pos_embed"] = (1, cfg.tokens, d)
     s[e + "patch_embed.proj.weight"] = (d, cfg.in_chans, 1, cfg.patch, cfg.patch)
     s[e + "patch_embed.proj.bias"] = (d,)
+    if cfg.variant.endswith("_tl"):  # pritvhi.py:431-437, registered after patch_embed and before the blocks
+        s[e + "temporal_embed_enc.scale"] = (1,)
+        s[e + "location_embed_enc.scale"] = (1,)
     for i in range(cfg.depth):
         b = f"{e}blocks.{i}."
         s[b + "norm1.weight"] = (d,)

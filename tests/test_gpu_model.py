@@ -337,3 +337,25 @@ def test_trained_weights_bf16_miou_and_loss_vs_oracle():
     assert dl <= 1e-3 and dm <= 1e-3 and dx <= 1e-3, "bf16x3 misses the 1e-3 bar on trained weights"
     dl, dm, dx, agree = out["bf16"]
     assert dl <= 1e-2 and dm <= 5e-3 and agree >= 0.995, f"bf16 on trained weights: dloss {dl} dmIoU {dm} agreement {agree}"
+
+
+def test_tl_variant_matches_the_oracle_and_its_scales_stay_put():
+    """prithvi_eo_v2_300_tl (2 blocks for speed): logits == oracle (pinned against the reference, whose forward ignores the coordinate
+    encoders); a fused train step leaves the two gradient-less ``scale`` parameters untouched, as torch.optim.AdamW does."""
+    cfg = O.make_config("prithvi_eo_v2_300_tl", 1, 2, 224, 2)
+    sd = O.make_state_dict(cfg, seed=1042)
+    mod = PrithviSegmentationModule(freeze_backbone=False, load_pretrained_weights=False, num_classes=2, model_name="prithvi_eo_v2_300_tl",
+                                    depth=2, class_weights=[1, 3], ignore_index=-1, precision="bf16x3", device=DEV)
+    mod.net.load_state_dict(sd, strict=True)
+    img, lab = make_inputs("tiny_t1_c2", cfg, 2)
+    mod.net.eval()
+    with torch.no_grad():
+        out = mod.net(img.to(DEV))
+        ref = O.prithvi_seg_forward(cfg, sd, img, training=False)
+    assert (out.cpu() - ref).abs().max().item() <= 1e-3
+    before = {k: v.clone() for k, v in mod.net.state_dict().items() if k.endswith("_embed_enc.scale")}
+    w0 = mod.net.state_dict()["prithvi_encoder.blocks.0.attn.qkv.weight"].clone()
+    mod.fused_train_step(img.to(DEV), lab.to(DEV))
+    after = mod.net.state_dict()
+    assert all(torch.equal(after[k], v) for k, v in before.items()) and len(before) == 2
+    assert not torch.equal(after["prithvi_encoder.blocks.0.attn.qkv.weight"], w0)
