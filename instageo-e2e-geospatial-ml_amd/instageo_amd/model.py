@@ -274,6 +274,7 @@ class SegEngine:
         self._drop_step: Optional[torch.Tensor] = None  # device uint32 counter mixed into the dropout hash each step
         self.freeze_backbone = False
         self.on_grad_ready: Optional[Callable[[int, int], None]] = None
+        self._pos_cache: Dict[int, Any] = {}
         self._last: Optional[Dict[str, Any]] = None
         self._generation = 0  # bumped by every forward(save=True): the saved activations belong to exactly one forward
 
@@ -303,12 +304,45 @@ class SegEngine:
             self.store.refresh_shadow_t()
             self.shadow_t_dirty = False
 
-    def workspace(self, B: int, training: bool) -> Dict[str, Any]:
-        key = (B, training, self.split, str(self.store.flat.device))
+    def geometry(self, size: int) -> SegConfig:
+        """The configuration for a square input of ``size`` pixels: the configured one, or the same network on another token
+        grid (the reference interpolates the position table and reshapes by the actual token count, pritvhi.py:149-203,
+        model.py:406-413)."""
+        if size == self.cfg.img_size:
+            return self.cfg
+        if size % self.cfg.patch or size <= 0:
+            raise ValueError(f"image size {size} is not a multiple of the patch size {self.cfg.patch} (the reference would drop the border)")
+        import dataclasses
+
+        return dataclasses.replace(self.cfg, img_size=size)
+
+    def pos_embed_for(self, cfg: SegConfig) -> torch.Tensor:
+        """The (1, 1 + T g^2, D) position table of geometry ``cfg``: the checkpointed buffer, or -- for another input size -- its
+        bicubic, align_corners=True interpolation exactly as ``interpolate_pos_encoding`` computes it (pritvhi.py:149-203),
+        evaluated once per size in float32 on the host (the reference's CPU arithmetic) and cached until the parameters change."""
+        base = self.buffers["prithvi_encoder.pos_embed"]
+        if cfg.img_size == self.cfg.img_size:
+            return base
+        key = (cfg.img_size, base.data_ptr(), int(base._version))
+        hit = self._pos_cache.get(cfg.img_size)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        g0, g1, T, D = self.cfg.grid, cfg.grid, cfg.num_frames, cfg.embed_dim
+        pe = base.detach().float().cpu()
+        cls_pe, patch_pe = pe[:, :1], pe[:, 1:]
+        patch_pe = patch_pe.reshape(T, g0, g0, D).permute(0, 3, 1, 2)
+        patch_pe = torch.nn.functional.interpolate(patch_pe, size=(g1, g1), mode="bicubic", align_corners=True)
+        out = torch.cat((cls_pe, patch_pe.permute(0, 2, 3, 1).reshape(1, -1, D)), dim=1).contiguous().to(base.device)
+        self._pos_cache[cfg.img_size] = (key, out)
+        return out
+
+    def workspace(self, B: int, training: bool, cfg: Optional[SegConfig] = None) -> Dict[str, Any]:
+        cfg = cfg or self.cfg
+        key = (B, training, self.split, str(self.store.flat.device), cfg.img_size)
         ws = self._ws.get(key)
         if ws is not None:
             return ws
-        cfg, dev, sp = self.cfg, self.store.flat.device, self.split
+        dev, sp = self.store.flat.device, self.split
         D, L, N, T, G = cfg.embed_dim, cfg.depth, cfg.tokens, cfg.num_frames, cfg.G
         M = B * N
         f32 = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
@@ -368,8 +402,9 @@ class SegEngine:
             img = img.unsqueeze(2)
         if img.dim() != 5 or img.shape[1] != cfg.in_chans or img.shape[2] != cfg.num_frames:
             raise ValueError(f"expected (B,{cfg.in_chans},{cfg.num_frames},H,W) input, got {tuple(img.shape)}")
-        if img.shape[3] != cfg.img_size or img.shape[4] != cfg.img_size:
-            raise ValueError(f"image size {tuple(img.shape[3:])} != configured {cfg.img_size} (pos-embed interpolation is out of scope)")
+        if img.shape[3] != img.shape[4]:
+            raise ValueError(f"expected square chips, got {tuple(img.shape[3:])} (model.py:406-413 reshapes the tokens to a square grid)")
+        cfg = self.geometry(int(img.shape[3]))
         if not img.is_cuda:
             raise ops._lib.HipLibraryError("PrithviSeg.forward needs a HIP device tensor: instageo_amd has no CPU path")
         img = img.contiguous().float()
@@ -377,24 +412,24 @@ class SegEngine:
         if B == 0:  # empty batch: nothing to launch
             return torch.empty((0, cfg.num_classes, cfg.img_size, cfg.img_size), dtype=torch.float32, device=img.device)
         ws = self.encoder_forward(img, save)
-        logits = self._head_forward(ws, B, training, out, update_running)
+        logits = self._head_forward(ws, B, training, out, update_running, cfg)
         if save:
             self._generation += 1
-        self._last = {"ws": ws, "B": B, "training": training, "generation": self._generation} if save else None
+        self._last = {"ws": ws, "B": B, "training": training, "generation": self._generation, "cfg": cfg} if save else None
         return logits
 
     def encoder_forward(self, img: torch.Tensor, save: bool = False) -> Dict[str, Any]:
         """Patch embed + L blocks + final LayerNorm (``PrithviViT.forward`` + the feature reshape, pritvhi.py:498-530,
         model.py:406-413) on a validated (B, C, T, H, W) f32 device batch; returns the workspace whose ``["f"][0]`` holds the
         (B, 14, 14, D*T) feature image.  ``bench.py`` times this leg alone (the north-star roofline is stated on it)."""
-        cfg = self.cfg
+        cfg = self.geometry(int(img.shape[3]))
         B = img.shape[0]
         self._prepare_shadow()
-        ws = self.workspace(B, save)
+        ws = self.workspace(B, save, cfg)
         D, L, N, T, G, H = cfg.embed_dim, cfg.depth, cfg.tokens, cfg.num_frames, cfg.G, cfg.num_heads
         M = B * N
         e = "prithvi_encoder."
-        pos = self.buffers[e + "pos_embed"]
+        pos = self.pos_embed_for(cfg)
         ops.patchify(img, cfg.patch, ws["patches"])
         x = ws["x_in"][0]
         ops.cls_rows(x, self.P(e + "cls_token"), pos, B, N, D)
@@ -428,8 +463,8 @@ class SegEngine:
             self._drop_step += 5  # five dropout sites use seeds +0..+4
         return self._drop_step
 
-    def _head_forward(self, ws, B: int, training: bool, out, update_running: bool) -> torch.Tensor:
-        cfg = self.cfg
+    def _head_forward(self, ws, B: int, training: bool, out, update_running: bool, cfg: Optional[SegConfig] = None) -> torch.Tensor:
+        cfg = cfg or self.cfg
         dims, g = cfg.head_dims, cfg.grid
         p = cfg.drop_p if training else 0.0
         sd = self._drop_counter(advance=True) if p > 0 else None
@@ -473,11 +508,11 @@ class SegEngine:
         activations, so a backward after a newer grad-enabled forward would silently use the wrong ones -- it raises.
         """
         assert self._last is not None, "forward(save=True) must precede backward"
+        cfg = self._last["cfg"]
         if generation is not None and generation != self._last["generation"]:
             raise RuntimeError(
                 "PrithviSeg: backward of a forward whose saved activations were overwritten by a later grad-enabled forward "
                 "(one set of activations per engine: run backward before the next training forward, or use a second module)")
-        cfg = self.cfg
         ws, B, training = self._last["ws"], self._last["B"], self._last["training"]
         self.store.ensure_grad()
         D, L, N, T, G, H = cfg.embed_dim, cfg.depth, cfg.tokens, cfg.num_frames, cfg.G, cfg.num_heads

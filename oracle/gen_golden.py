@@ -131,6 +131,16 @@ def main() -> None:
             pe[f"D{D}_T{T}_sum"] = np.float64(f32.astype(np.float64).sum())
             pe[f"D{D}_T{T}_abs"] = np.float64(np.abs(f32).astype(np.float64).sum())
             pe[f"D{D}_T{T}_rows"] = f32[[0, 1, 2, 15, 196, f32.shape[0] - 1]]
+    # 1b. interpolate_pos_encoding (pritvhi.py:149-203) for inputs off the configured grid: oracle == reference, rows stored
+    for T in (1, 3):
+        icfg = O.make_config("prithvi_eo_tiny", T, 2, 224)
+        table = torch.from_numpy(O.sincos_pos_embed_3d(256, (T, 14, 14), True)[None].astype(np.float32))
+        for S in (160, 256):
+            ref = ref_vit.interpolate_pos_encoding(table, (T, 14, 14), (1, 16, 16), (T, S, S), 256)
+            mine = O.interpolate_pos_encoding(icfg, table, S, S)
+            assert torch.equal(ref, mine), f"interpolated pos_embed mismatch T={T} S={S}"
+            pe[f"interp_T{T}_S{S}_rows"] = ref[0, [0, 1, 2, (S // 16) ** 2, ref.shape[1] - 1]].numpy()
+            pe[f"interp_T{T}_S{S}_sum"] = np.float64(ref.double().sum().item())
     np.savez_compressed(os.path.join(out_dir, "pos_embed.npz"), **pe)
     print("pos_embed ok")
 

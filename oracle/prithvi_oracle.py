@@ -262,6 +262,20 @@ def vit_block(x: torch.Tensor, sd: Dict[str, torch.Tensor], pre: str, heads: int
     return x
 
 
+def interpolate_pos_encoding(cfg: OracleConfig, pos_embed: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    """pritvhi.py:149-203 for an unchanged number of frames: the table itself when the input matches the configured grid,
+    otherwise the patch rows resampled to (H/p, W/p) with bicubic interpolation, align_corners=True; the cls row is kept."""
+    g = cfg.grid
+    hp, wp = H // cfg.patch, W // cfg.patch
+    if (hp, wp) == (g, g):
+        return pos_embed
+    cls_pe, patch_pe = pos_embed[:, :1], pos_embed[:, 1:]
+    patch_pe = patch_pe.reshape(cfg.num_frames, g, g, cfg.embed_dim).permute(0, 3, 1, 2)
+    patch_pe = F.interpolate(patch_pe, size=(hp, wp), mode="bicubic", align_corners=True)
+    patch_pe = patch_pe.permute(0, 2, 3, 1).reshape(1, -1, cfg.embed_dim)
+    return torch.cat((cls_pe, patch_pe), dim=1)
+
+
 def encoder_forward(
     cfg: OracleConfig, sd: Dict[str, torch.Tensor], img: torch.Tensor, stages: Optional[dict] = None
 ) -> torch.Tensor:
@@ -272,7 +286,7 @@ def encoder_forward(
     x = patch_embed(img, sd[e + "patch_embed.proj.weight"], sd[e + "patch_embed.proj.bias"])
     if stages is not None:
         stages["patch_embed"] = x
-    pos = sd[e + "pos_embed"]
+    pos = interpolate_pos_encoding(cfg, sd[e + "pos_embed"], img.shape[-2], img.shape[-1])
     x = x + pos[:, 1:, :]
     cls = (sd[e + "cls_token"] + pos[:, :1, :]).expand(x.shape[0], -1, -1)
     x = torch.cat((cls, x), dim=1)

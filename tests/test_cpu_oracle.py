@@ -223,3 +223,21 @@ def test_distillation_loss_restatement():
     p = np.exp(2) / (1 + np.exp(2))
     kl_pix1 = (1 - p) * (np.log(1 - p) - np.log(p)) + p * (np.log(p) - np.log(1 - p))  # t = (1-p, p), s = (p, 1-p)
     assert abs(kd.item() - kl_pix1 / 2) < 1e-12 and abs(total.item() - (ce + kd).item()) < 1e-15
+
+
+def test_interpolated_pos_embed_matches_reference_fixture():
+    """interpolate_pos_encoding (pritvhi.py:149-203; inputs off the configured 224 grid): the oracle restatement against the rows
+    gen_golden.py stored from the imported reference function (bicubic, align_corners=True, cls row kept)."""
+    gold = np.load(os.path.join(GOLD, "pos_embed.npz"))
+    for T in (1, 3):
+        cfg = O.make_config("prithvi_eo_tiny", T, 2, 224)
+        table = torch.from_numpy(O.sincos_pos_embed_3d(256, (T, 14, 14), True)[None].astype(np.float32))
+        assert O.interpolate_pos_encoding(cfg, table, 224, 224) is table
+        for S in (160, 256):
+            pe = O.interpolate_pos_encoding(cfg, table, S, S)
+            g = S // 16
+            assert pe.shape == (1, 1 + T * g * g, 256)
+            rows = pe[0, [0, 1, 2, g * g, pe.shape[1] - 1]].numpy()
+            assert np.allclose(rows, gold[f"interp_T{T}_S{S}_rows"], rtol=0, atol=1e-6)
+            assert abs(pe.double().sum().item() - float(gold[f"interp_T{T}_S{S}_sum"])) <= 1e-3
+            assert torch.all(pe[0, 0] == 0)  # the cls row of the sin-cos table is zeros and is not interpolated

@@ -359,3 +359,34 @@ def test_tl_variant_matches_the_oracle_and_its_scales_stay_put():
     after = mod.net.state_dict()
     assert all(torch.equal(after[k], v) for k, v in before.items()) and len(before) == 2
     assert not torch.equal(after["prithvi_encoder.blocks.0.attn.qkv.weight"], w0)
+
+
+def test_other_input_sizes_interpolate_the_position_table():
+    """The reference accepts any square input that is a multiple of the patch size: ``interpolate_pos_encoding`` resamples the
+    position table (bicubic, align_corners=True; pritvhi.py:149-203) and PrithviSeg.forward reshapes by the actual token count
+    (model.py:406-413).  Eval logits and gradients at 160 and 256 pixels against the oracle, which calls the same torch routine."""
+    cfg, sd, net, img, lab = build("tiny_t1_c2", "bf16x3")
+    net.eval()
+    for S in (160, 256):
+        g = torch.Generator().manual_seed(S)
+        x = torch.randn(2, 6, 1, S, S, generator=g)
+        with torch.no_grad():
+            out = net(x.to(DEV))
+            ref = O.prithvi_seg_forward(O.make_config("prithvi_eo_tiny", 1, 2, 224), sd, x, training=False)
+        assert out.shape == (2, 2, S, S) and ref.shape == out.shape
+        assert (out.cpu() - ref).abs().max().item() <= 1e-3, f"size {S}"
+    net.cfg.drop_p = 0.0
+    net.train()
+    x = torch.randn(2, 6, 1, 160, 160, generator=torch.Generator().manual_seed(1))
+    y = torch.randint(0, 2, (2, 160, 160), generator=torch.Generator().manual_seed(2))
+    loss = segmentation_loss(net(x.to(DEV)), y.to(DEV), class_weights_for(2).to(DEV), -1)
+    loss.backward()
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    _, ref_loss, ref_g = O.train_step_reference(O.make_config("prithvi_eo_tiny", 1, 2, 224), sd64, x.double(), y, class_weights_for(2).double(), -1,
+                                                ["prithvi_encoder.blocks.0.attn.qkv.weight", "segmentation_head.3.2.weight"])
+    assert abs(loss.item() - ref_loss.item()) <= 1e-3
+    got = dict(net.named_parameters())
+    for k, rg in ref_g.items():
+        assert rel_l2(got[k].grad, rg) <= 1e-2, k
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 6, 1, 100, 100, device=DEV))  # not a multiple of the patch size
