@@ -62,6 +62,7 @@ void ig_note_kernel(const char* fmt, ...);
 void ig_note_grid(int workgroups);  // workgroups of the last persistent GEMM launch (ig_last_grid: the reserved-CU rule is testable)
 int ig_reserved_cus();
 int ig_cu_count();
+int ig_tile_grid(int ntiles, int per_cu);
 
 #define IG_REQUIRE(cond, ...)          \
     do {                               \

@@ -1427,8 +1427,7 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep_in, int M, int N, int K
     if constexpr (AL::kLinearK && BL::kLinearK) {
         if (ver == 5) {
             const int tm5 = ig_cdiv(M, 256), tn5 = ig_cdiv(N, 256), ntiles = tm5 * tn5;
-            const int cus5 = ig_cu_count() - ig_reserved_cus();  // persistent: one workgroup per (unreserved) CU
-            dim3 grid5(ntiles > cus5 ? cus5 : ntiles, 1, Z);
+            dim3 grid5(ig_tile_grid(ntiles, 1), 1, Z);  // persistent: one workgroup per CU
             int kchunk5 = ig_cdiv(K, 32);
             if constexpr (EP::kStagedAtomic) {  // one tile per workgroup, split-K over blockIdx.y, one workgroup per CU
                 grid5.x = ntiles;
@@ -1547,8 +1546,7 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep_in, int M, int N, int K
             finish_partial();
         } else {
             // persistent: two workgroups per CU walk the tile list; BK = 32 keeps the ring at 72 KiB
-            const int slots2 = 2 * (ig_cu_count() - ig_reserved_cus());  // persistent: two workgroups per (unreserved) CU
-            if ((int)grid.x > slots2) grid.x = slots2;
+            grid.x = ig_tile_grid((int)grid.x, 2);  // persistent: two workgroups per CU
             kchunk = ig_cdiv(K, 32);
             if (split) IG_LAUNCH_V2(3, 32) else IG_LAUNCH_V2(1, 32)
         }

@@ -546,9 +546,7 @@ int ig_gemm8_nt(const G8Params& p, void* stream) {
     const int ntiles = ((p.M + 255) >> 8) * (p.N >> 8);
     const int min_tiles = getenv("IG_GEMM8_MIN_TILES") ? atoi(getenv("IG_GEMM8_MIN_TILES")) : 192;
     if (ntiles < min_tiles && g8_env() != 2) return IG_ERR_UNSUPPORTED;  // small problems: the 256 x 256 tile leaves CUs idle
-    int grid = ig_cu_count() - ig_reserved_cus();
-    if (grid < 8) grid = 8;
-    if (grid > ntiles) grid = ntiles;
+    const int grid = ig_tile_grid(ntiles, 1);
     hipStream_t st = (hipStream_t)stream;
     const bool split_in = p.nseg == 3;
     if (p.kind == 0) {

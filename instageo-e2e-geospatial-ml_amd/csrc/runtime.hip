@@ -45,6 +45,24 @@ int ig_reserved_cus() {
     }
     return g_reserved_cus;
 }
+// Grid of a persistent tile-walking GEMM (per_cu workgroups per CU; XCD x owns a contiguous eighth of the tile list and its
+// workgroups deal it round-robin): the FEWEST workgroups per XCD that keep the number of rounds, so whatever the tile count
+// leaves over is free for RCCL.  The reservation is soft here -- an extra round costs 25-100 % of the launch at the benchmark's
+// tile counts (84 x 3 / 84 x 9 / 84 x 12 tiles on 256 CUs), so it is honoured only when it is free; IG_RESERVED_STRICT=1 makes it
+// strict.  Kernels whose work divides evenly (split-K weight gradients) always honour it.
+int ig_tile_grid(int ntiles, int per_cu) {
+    const char* e = getenv("IG_RESERVED_STRICT");  // read per call: a test switch
+    const int strict = e ? atoi(e) : 0;
+    const int slots_x = ig_cu_count() / 8 * per_cu;
+    int avail_x = slots_x;
+    if (strict) avail_x -= (ig_reserved_cus() * per_cu + 7) / 8;
+    if (avail_x < 1) avail_x = 1;
+    const int tmax = (ntiles + 7) / 8;  // tiles of the fullest XCD
+    const int rounds = (tmax + avail_x - 1) / avail_x;
+    const int nbx = (tmax + rounds - 1) / rounds;
+    const int grid = 8 * nbx;
+    return grid < ntiles ? grid : ntiles;
+}
 int ig_cu_count() {
     static int cus = 0;
     if (!cus) {

@@ -23,7 +23,11 @@ import torch
 import torch.distributed as dist
 
 
-DEFAULT_RESERVED_CUS = 8  # one CU per XCD for RCCL while the data-parallel backward runs (IG_RESERVED_CUS overrides)
+# CUs asked for RCCL while the data-parallel backward runs (IG_RESERVED_CUS overrides).  A SOFT reservation for the tile-walking
+# GEMMs: ig_tile_grid launches the fewest workgroups that keep the number of rounds and gives CUs up only when that is free
+# (at the benchmark's 84 x 3 / x 9 / x 12 tile counts one CU less is one round more: +25...100 % per launch); the split-K weight
+# gradients leave 4-40 CUs idle by construction.  IG_RESERVED_STRICT=1 makes it strict.
+DEFAULT_RESERVED_CUS = 8
 
 
 def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
