@@ -61,6 +61,24 @@ int ig_crop_flip_normalize(const void* src, int src_dtype, const float* mean, co
 int ig_normalize_windows(const void* tile, int src_dtype, const float* mean, const float* stdv, double mult, int mult_enabled,
                          const int* origins, float* dst, const float* labels_tile, float* labels_out, int n, int T, int C, int Hs,
                          int Ws, int crop, void* stream);
+/* Photometric / resampling augmentations of the training pipeline (dataloader.py:144-386) on a raw-domain float32 batch
+ * (B, T*C, S, S) -- the output of ig_crop_flip_normalize with identity statistics -- one launch per augmentation and batch.
+ * Every random decision is drawn on the host, per chip, like the crop origins.
+ * ig_aug_rotate: RandomRotation (dataloader.py:144-187) = Pillow's nearest-neighbour Image.rotate with constant fill;
+ *   params[b] = {apply, a0, a1, a2, a3, a4, a5, 0}: the 16.16 fixed-point inverse affine of the drawn angle (host mirror:
+ *   dataloader.rotate_coeffs); labels (B, S, S) follow with their own fill.  src != dst.
+ * ig_aug_brightness_contrast: RandomBrightnessContrast (dataloader.py:190-260), in place; params[b] = {apply, bright, contrast, 0}.
+ * ig_aug_blur: RandomGaussianBlur (dataloader.py:263-333): clip/scale to [0,1], ksize x ksize kernel2d (outer product of the
+ *   two normalised 1-D Gaussians) with reflect padding, clamp, * max_pixel, truncate to uint16; apply[b] in {0,1}.  src != dst.
+ * ig_aug_noise: RandomGaussianNoise (dataloader.py:336-386), in place; params[b] = {apply, seed}; noise = optional standard-normal
+ *   field of buf's shape (else a counter hash + Box-Muller seeded per chip). */
+int ig_aug_rotate(const float* src, float* dst, const float* labels_in, float* labels_out, const int* params, float fill,
+                  float label_fill, int B, int CT, int S, void* stream);
+int ig_aug_brightness_contrast(float* buf, const float* params, float max_pixel, int B, int CT, int S, void* stream);
+int ig_aug_blur(const float* src, float* dst, const int* apply, const float* kernel2d, int ksize, float max_pixel, int B, int CT,
+                int S, void* stream);
+int ig_aug_noise(float* buf, const int* params, const float* noise, float noise_std, float max_pixel, int B, int CT, int S,
+                 void* stream);
 /* mode=stats reduction (pipeline_utils.py:207-254): sums[c] += mean_bc, sums[C+c] += biased var_bc over (T,H,W) for every
  * chip b of x (B, C, T, H, W) f32; counts[v - lo] += 1 per label value (counts[nbins] = everything else) */
 int ig_chip_stats(const float* x, double* sums, int B, int C, long n_per_channel, void* stream);

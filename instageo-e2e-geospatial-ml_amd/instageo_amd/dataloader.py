@@ -3,14 +3,16 @@
 In scope: normalisation + tensor layout (``normalize_and_convert_to_tensor``
 dataloader.py:495-524), random crop / flips hand-off (``process_and_augment`` :527-585), evaluation
 window tiling (``process_test`` + ``crop_array`` :588-669) and the dataset item contract
-(``InstaGeoDataset.__getitem__`` :875-902: ``(x:(C,T,H,W) f32, y:(H,W))``).  GeoTIFF/CSV I/O (rasterio) and
-the photometric augmentations are outside the path; chips come from arrays or are synthetic.
+(``InstaGeoDataset.__getitem__`` :875-902: ``(x:(C,T,H,W) f32, y:(H,W))``), the CSV-of-GeoTIFF dataset (host TIFF codec,
+``tiff.py``) and the rotate / brightness / blur / noise augmentations (:144-386) as one ``ig_aug_*`` launch per batch.
 The arithmetic (constant multiplier, mean/std normalisation) runs in ``ig_normalize_chips``; the training-time random
 crop + flips + normalisation of a batch is ONE kernel (``ig_crop_flip_normalize``; the random draws stay on the host so
 the reference's RNG stream can be replayed); window extraction is pure data movement on the device.
 """
 from __future__ import annotations
 
+import math
+import random
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -111,43 +113,139 @@ def process_test(x, y, mean: Sequence[float], std: Sequence[float], temporal_siz
     return imgs, labels
 
 
+PHOTOMETRIC = ("rotate", "brightness", "blur", "noise")
+
+
 def draw_augment_params(batch: int, src_hw: Tuple[int, int], im_size: int, crop: bool = True, augmentations: Optional[Dict] = None,
                         generator: Optional[torch.Generator] = None) -> torch.Tensor:
-    """Host-side random draws of ``process_and_augment`` for a batch: (B, 4) int32 rows (top, left, hflip, vflip).
+    """Host-side random draws of the data-movement part of ``process_and_augment`` for a batch: (B, 4) int32 rows
+    (top, left, hflip, vflip).
 
     Crop origin as ``RandomCrop.get_params`` (uniform in [0, H - im], [0, W - im]; dataloader.py:73), each enabled flip
-    with its probability ``p`` (dataloader.py:99, 131).  Only ``hflip``/``vflip`` (the augmentations enabled in
-    ``sen1floods11.yaml:44-49``) are data movement; rotate/brightness/blur/noise resample or rescale pixels and are
-    outside the hot path."""
+    with its probability ``p`` (dataloader.py:99, 131).  The other augmentations are drawn by :func:`draw_photometric_params`."""
     H, W = src_hw
     p = torch.zeros((batch, 4), dtype=torch.int32)
     if crop and (H > im_size or W > im_size):
         p[:, 0] = torch.randint(0, H - im_size + 1, (batch,), generator=generator, dtype=torch.int32)
         p[:, 1] = torch.randint(0, W - im_size + 1, (batch,), generator=generator, dtype=torch.int32)
+    seen_other = False
     for name, cfg in (augmentations or {}).items():
         if not cfg.get("use", False):
             continue
+        if name in PHOTOMETRIC:
+            seen_other = True
+            continue
         if name not in ("hflip", "vflip"):
-            raise NotImplementedError(f"augmentation {name!r} is outside the hot-path scope (SURVEY.md 8f item 1)")
+            raise NotImplementedError(f"unknown augmentation {name!r} (the reference skips it with a warning, pipeline_utils.py:171-173)")
+        if seen_other:  # the flips ride on the crop kernel, i.e. they run first; a rotation does not commute with them
+            raise NotImplementedError("hflip / vflip must precede rotate / brightness / blur / noise in dataloader.augmentations")
         p[:, 2 if name == "hflip" else 3] = (torch.rand(batch, generator=generator) < cfg.get("p", 0.5)).to(torch.int32)
     return p
 
 
+def rotate_coeffs(angle: float, size: int) -> Tuple[int, int, int, int, int, int]:
+    """Pillow's ``Image.rotate`` (what ``transforms.functional.rotate`` calls for a PIL image, dataloader.py:183-186) as the six
+    16.16 fixed-point coefficients of its nearest-neighbour affine walk: input x = (a2 + a1*y + a0*x) >> 16, input y =
+    (a5 + a4*y + a3*x) >> 16 for output pixel (x, y) of a ``size`` x ``size`` image; ``ig_aug_rotate`` consumes them."""
+    a = -math.radians(angle % 360.0)
+    m0, m1, m3, m4 = round(math.cos(a), 15), round(math.sin(a), 15), round(-math.sin(a), 15), round(math.cos(a), 15)
+    c = size / 2.0
+    m2 = m0 * -c + m1 * -c + c
+    m5 = m3 * -c + m4 * -c + c
+    fix = lambda v: int(math.floor(v * 65536.0 + 0.5))
+    return fix(m0), fix(m1), fix(m2 + m0 * 0.5 + m1 * 0.5), fix(m3), fix(m4), fix(m5 + m3 * 0.5 + m4 * 0.5)
+
+
+def gaussian_kernel2d(ksize: int, sigma: Sequence[float]) -> torch.Tensor:
+    """torchvision's ``gaussian_blur`` kernel.  The reference hands its ``sigma_range`` pair to ``sigma=`` (dataloader.py:303-305),
+    which torchvision reads as the fixed (sigma_x, sigma_y) -- there is no random draw; kept as is."""
+    def k1(sig):
+        half = (ksize - 1) * 0.5
+        x = torch.linspace(-half, half, steps=ksize)
+        pdf = torch.exp(-0.5 * (x / sig).pow(2))
+        return pdf / pdf.sum()
+
+    sx, sy = (float(sigma[0]), float(sigma[1])) if len(sigma) == 2 else (float(sigma[0]),) * 2
+    return torch.mm(k1(sy)[:, None], k1(sx)[None, :])
+
+
+def draw_photometric_params(batch: int, im_size: int, augmentations: Optional[Dict] = None, rng: Optional[random.Random] = None) -> List[Dict]:
+    """Host-side draws of RandomRotation / RandomBrightnessContrast / RandomGaussianBlur / RandomGaussianNoise for a batch, in the
+    order of the config (the reference composes them in that order, pipeline_utils.py:157-175): a list of
+    ``{"name", per-chip parameter table, constants}``.  Like the reference the draws use Python's ``random`` (``random.random() < p``,
+    then ``random.uniform`` for the parameters; dataloader.py:179-181, 228-229, 257, 330, 383) -- chip by chip, one augmentation
+    after the other, so that a seeded ``random`` replays the reference's per-chip stream of these four."""
+    rng = rng or random
+    active = [(n, c) for n, c in (augmentations or {}).items() if c.get("use", False) and n in PHOTOMETRIC]
+    if not active:
+        return []
+    tables: Dict[str, list] = {n: [] for n, _ in active}
+    for _ in range(batch):
+        for name, cfg in active:
+            apply = rng.random() < cfg.get("p", 0.5)
+            if name == "rotate":
+                deg = float(cfg.get("degrees", 15))
+                angle = rng.uniform(-deg, deg) if apply else 0.0
+                tables[name].append([int(apply), *rotate_coeffs(angle, im_size), 0])
+            elif name == "brightness":
+                br, cr = cfg.get("brightness_range", (0.8, 1.2)), cfg.get("contrast_range", (0.8, 1.2))
+                tables[name].append([float(apply), rng.uniform(*br), rng.uniform(*cr), 0.0] if apply else [0.0, 1.0, 1.0, 0.0])
+            elif name == "blur":
+                tables[name].append(int(apply))
+            else:
+                tables[name].append([int(apply), rng.getrandbits(31) if apply else 0])
+    out = []
+    for name, cfg in active:
+        t = torch.tensor(tables[name], dtype=torch.float32 if name == "brightness" else torch.int32)
+        out.append({"name": name, "table": t, "cfg": cfg})
+    return out
+
+
+def apply_photometric(buf: torch.Tensor, labels: Optional[torch.Tensor], plan: List[Dict], chip_no_data_value: float = 0.0,
+                      label_no_data_value: float = -1.0, max_pixel_value: float = 10000.0, noise: Optional[torch.Tensor] = None):
+    """Run a plan of :func:`draw_photometric_params` over a raw-domain batch (B, T*C, S, S) f32 [+ labels (B, S, S)]."""
+    for step in plan:
+        name, t, cfg = step["name"], step["table"].to(buf.device), step["cfg"]
+        if name == "rotate":
+            buf, labels = ops.aug_rotate(buf, t, chip_no_data_value, labels, label_no_data_value)
+        elif name == "brightness":
+            buf = ops.aug_brightness_contrast(buf, t, max_pixel_value)
+        elif name == "blur":
+            k2 = gaussian_kernel2d(int(cfg.get("kernel_size", 3)), cfg.get("sigma_range", (0.1, 2.0))).to(buf.device)
+            buf = ops.aug_blur(buf, t, k2, max_pixel_value)
+        else:
+            buf = ops.aug_noise(buf, t, float(cfg.get("noise_std", 0.05)), max_pixel_value, noise)
+    return buf, labels
+
+
 def process_and_augment_batch(x: torch.Tensor, y: Optional[torch.Tensor], mean, std, temporal_size: int = 1, im_size: int = 224,
                               crop: bool = True, augmentations: Optional[Dict] = None, constant_multiplier: Optional[float] = None,
-                              generator: Optional[torch.Generator] = None, params: Optional[torch.Tensor] = None):
+                              generator: Optional[torch.Generator] = None, params: Optional[torch.Tensor] = None,
+                              label_no_data_value: float = -1.0, chip_no_data_value: float = 0.0, max_pixel_value: float = 10000.0,
+                              rng: Optional[random.Random] = None, plan: Optional[List[Dict]] = None):
     """Batched ``process_and_augment`` on the device: x (B, T*C, Hs, Ws) int16|f32, y (B, Hs, Ws) or None ->
-    ((B, C, T, im, im) f32 normalised, (B, im, im) f32).  One fused kernel (``ig_crop_flip_normalize``)."""
-    B, _, Hs, Ws = x.shape
+    ((B, C, T, im, im) f32 normalised, (B, im, im) f32).
+
+    Crop + flips + normalise are ONE kernel (``ig_crop_flip_normalize``).  With rotate / brightness / blur / noise enabled the
+    same kernel first writes the cropped, flipped chips in the raw domain (identity statistics), the ``ig_aug_*`` kernels run in
+    config order, and ``ig_normalize_chips`` finishes (dataloader.py:570-585)."""
+    B, TC, Hs, Ws = x.shape
     size = im_size if crop else Hs
     if not crop:
         assert Hs == Ws, "crop=False expects square chips"
     if params is None:
         params = draw_augment_params(B, (Hs, Ws), size, crop, augmentations, generator)
+    if plan is None:
+        plan = draw_photometric_params(B, size, augmentations, rng)
     m = torch.as_tensor(mean, dtype=torch.float32, device=x.device)
     s = torch.as_tensor(std, dtype=torch.float32, device=x.device)
     lab = None if y is None else y.to(device=x.device, dtype=torch.float32).contiguous()
-    return ops.crop_flip_normalize(x.contiguous(), params.to(x.device), m, s, temporal_size, size, constant_multiplier, lab)
+    if not plan:
+        return ops.crop_flip_normalize(x.contiguous(), params.to(x.device), m, s, temporal_size, size, constant_multiplier, lab)
+    ident0, ident1 = torch.zeros(TC, device=x.device), torch.ones(TC, device=x.device)
+    raw, lab = ops.crop_flip_normalize(x.contiguous(), params.to(x.device), ident0, ident1, 1, size, constant_multiplier, lab)
+    raw, lab = apply_photometric(raw.view(B, TC, size, size), lab, plan, chip_no_data_value, label_no_data_value, max_pixel_value)
+    return ops.normalize_chips(raw, m, s, temporal_size), lab
 
 
 def process_and_augment(x, y, mean, std, temporal_size: int = 1, im_size: int = 224, crop: bool = True,

@@ -202,6 +202,53 @@ def crop_flip_normalize(src: torch.Tensor, params: torch.Tensor, mean: torch.Ten
     return out, lab_out
 
 
+def aug_rotate(buf: torch.Tensor, params: torch.Tensor, fill: float, labels: Optional[torch.Tensor] = None, label_fill: float = -1.0):
+    """RandomRotation of a raw-domain batch (B, T*C, S, S) f32 [+ labels (B, S, S) f32]: nearest neighbour about the centre with
+    constant fill, params (B, 8) int32 = {apply, 16.16 fixed-point inverse affine} (dataloader.py:144-187).  Returns new tensors."""
+    B, CT, S, S2 = buf.shape
+    assert S == S2 and buf.dtype == torch.float32 and params.dtype == torch.int32 and params.shape == (B, 8)
+    out = torch.empty_like(buf)
+    lab_out = None
+    if labels is not None:
+        labels = _f32(labels)
+        assert labels.shape == (B, S, S)
+        lab_out = torch.empty_like(labels)
+    _call("ig_aug_rotate", float(buf.numel() + (0 if labels is None else labels.numel())) * 8, _p(buf), _p(out), _p(labels), _p(lab_out),
+          _p(params), float(fill), float(label_fill), B, CT, S, _stream())
+    return out, lab_out
+
+
+def aug_brightness_contrast(buf: torch.Tensor, params: torch.Tensor, max_pixel: float) -> torch.Tensor:
+    """RandomBrightnessContrast in place: params (B, 4) f32 = {apply, bright, contrast, 0} (dataloader.py:190-260)."""
+    B, CT, S, _ = buf.shape
+    assert buf.dtype == torch.float32 and params.dtype == torch.float32 and params.shape == (B, 4)
+    _call("ig_aug_brightness_contrast", float(buf.numel()) * 12, _p(buf), _p(params), float(max_pixel), B, CT, S, _stream())
+    return buf
+
+
+def aug_blur(buf: torch.Tensor, apply: torch.Tensor, kernel2d: torch.Tensor, max_pixel: float) -> torch.Tensor:
+    """RandomGaussianBlur: apply (B,) int32, kernel2d (k, k) f32 (dataloader.py:263-333).  Returns a new tensor."""
+    B, CT, S, _ = buf.shape
+    assert buf.dtype == torch.float32 and apply.dtype == torch.int32 and apply.numel() == B
+    k = kernel2d.shape[0]
+    out = torch.empty_like(buf)
+    _call("ig_aug_blur", float(buf.numel()) * 8, _p(buf), _p(out), _p(apply), _p(_f32(kernel2d)), k, float(max_pixel), B, CT, S, _stream())
+    return out
+
+
+def aug_noise(buf: torch.Tensor, params: torch.Tensor, noise_std: float, max_pixel: float, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """RandomGaussianNoise in place: params (B, 2) int32 = {apply, seed}; ``noise`` = optional standard-normal field of buf's
+    shape, else generated on the device from the per-chip seed (dataloader.py:336-386)."""
+    B, CT, S, _ = buf.shape
+    assert buf.dtype == torch.float32 and params.dtype == torch.int32 and params.shape == (B, 2)
+    if noise is not None:
+        noise = _f32(noise)
+        assert noise.shape == buf.shape
+    _call("ig_aug_noise", float(buf.numel()) * (8 if noise is None else 12), _p(buf), _p(params), _p(noise), float(noise_std), float(max_pixel),
+          B, CT, S, _stream())
+    return buf
+
+
 def normalize_windows(tile: torch.Tensor, origins: torch.Tensor, mean: torch.Tensor, std: torch.Tensor, temporal: int, crop: int,
                       constant_multiplier: Optional[float] = None, labels: Optional[torch.Tensor] = None,
                       out: Optional[torch.Tensor] = None):

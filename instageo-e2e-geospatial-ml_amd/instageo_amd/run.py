@@ -15,6 +15,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import random
 import sys
 import time
 from typing import Any, Dict, List, Optional, Tuple
@@ -135,19 +136,21 @@ def train(cfg: Dict[str, Any], model, out_dir: str, rank: int, world: int) -> Di
     reg = bool(cfg.get("is_reg_task", False))
     best, history = (-float("inf") if reg else -1.0), {}
     augs = cfg["dataloader"].get("augmentations") or {}
-    train_augs = {k: v for k, v in augs.items() if k in ("hflip", "vflip") and v.get("use", False)}
-    skipped = [k for k, v in augs.items() if k not in ("hflip", "vflip") and v.get("use", False)]
-    if skipped and rank == 0:
-        print(f"[instageo_amd] augmentations outside the hot path are ignored: {skipped} (SURVEY.md 8f)", file=sys.stderr)
+    train_augs = {k: v for k, v in augs.items() if v.get("use", False)}  # config order = order of application
+    aug_rng = random.Random(SEED + 104729 * rank)  # rotate / brightness / blur / noise draws (Python's random, like the reference)
     aug_gen = torch.Generator().manual_seed(SEED + 7919 * rank)  # different crops/flips per rank, reproducible
     for epoch in range(cfg["train"]["num_epochs"]):
         model.net.train()
         for ids in _batches(train_ds, bs, True, epoch, rank, world, equal=True):
             # training items go through process_and_augment (dataloader.py:527-585): random crop to img_size + the enabled
-            # flips + normalise, here as ONE kernel per batch on the raw chips
+            # flips + normalise as ONE kernel per batch on the raw chips; rotate / brightness / blur / noise (off in
+            # sen1floods11.yaml) add one ig_aug_* launch each between the crop and the normalisation
             xr, yr = train_ds.raw_batch(ids)
             x, y = process_and_augment_batch(xr, yr, train_ds.mean, train_ds.std, train_ds.T, cfg["dataloader"]["img_size"], True,
-                                             train_augs, train_ds.mult, aug_gen)
+                                             train_augs, train_ds.mult, aug_gen,
+                                             label_no_data_value=cfg["train"].get("ignore_index", -1),  # run.py:128-129
+                                             chip_no_data_value=cfg["dataloader"].get("no_data_value", -9999),
+                                             max_pixel_value=cfg["dataloader"].get("max_pixel_value", 10000.0), rng=aug_rng)
             model.fused_train_step(x, y)
         _reduce_metrics(model.train_metrics, dev, model, "train")
         model.on_train_epoch_end()

@@ -52,8 +52,122 @@ def test_process_and_augment_crop_flip_layout():
     top = int(torch.randint(0, 33, (1,), generator=g2))
     left = int(torch.randint(0, 33, (1,), generator=g2))
     assert torch.allclose(o[2, 1], xs[1 * 6 + 2, top : top + 224, left : left + 224], atol=1e-5)
-    with pytest.raises(NotImplementedError):
-        DL.process_and_augment(x, y, [0.0] * 6, [1.0] * 6, 3, augmentations={"rotate": {"use": True}})
+    with pytest.raises(NotImplementedError):  # flips ride on the crop kernel: they must come before a rotation
+        DL.process_and_augment(x, y, [0.0] * 6, [1.0] * 6, 3, augmentations={"rotate": {"use": True}, "hflip": {"use": True}})
+
+
+def _aug_batch(B=5, CT=6, S=224, seed=11):
+    g = torch.Generator().manual_seed(seed)
+    raw = torch.randint(0, 10000, (B, CT, S, S), generator=g).float()
+    raw[:, :, : S // 8] = -50.0  # below the valid range: blur / noise clip first
+    raw[:, :, -S // 8 :] = 12000.0  # above max_pixel_value
+    lab = torch.randint(-1, 3, (B, S, S), generator=g).float()
+    return raw, lab
+
+
+@pytest.mark.parametrize("S", [224, 64])
+def test_aug_rotate_kernel_is_pillow_rotation(S):
+    """ig_aug_rotate against the oracle (itself bit-identical to PIL.Image.rotate, tests/test_cpu_augment.py): bit-exact, images and
+    labels, applied and skipped chips, special and generic angles (dataloader.py:144-187)."""
+    from oracle import augment_oracle as AO
+
+    raw, lab = _aug_batch(6, 6, S)
+    angles = [7.3, 0.0, -14.9, 90.0, 180.0, 45.0]
+    apply = [1, 0, 1, 1, 1, 1]
+    prm = torch.tensor([[a, *DL.rotate_coeffs(ang, S), 0] for a, ang in zip(apply, angles)], dtype=torch.int32)
+    out, lo = ops.aug_rotate(raw.to(DEV), prm.to(DEV), 0.0, lab.to(DEV), -1.0)
+    for b in range(6):
+        for c in range(6):
+            ref = AO.rotate_nearest(raw[b, c].numpy(), angles[b], 0.0) if apply[b] else raw[b, c].numpy()
+            assert np.array_equal(out[b, c].cpu().numpy(), ref), (b, c)
+        ref = AO.rotate_nearest(lab[b].numpy(), angles[b], -1.0) if apply[b] else lab[b].numpy()
+        assert np.array_equal(lo[b].cpu().numpy(), ref), b
+    o2, l2 = ops.aug_rotate(raw.to(DEV), prm.to(DEV), 0.0)  # images only
+    assert l2 is None and torch.equal(o2, out)
+
+
+def test_aug_brightness_blur_noise_kernels_match_the_oracle():
+    """ig_aug_brightness_contrast / ig_aug_blur / ig_aug_noise against the per-band restatements of dataloader.py:190-386.
+    Tolerances: brightness/contrast is float arithmetic (the band mean is accumulated in fp64 here, in fp32 by torch):
+    |d| <= 4e-3 on values up to 1e4 (4e-7 relative); blur and noise end in a uint16 truncation, where a last-ulp difference of the
+    filtered value moves a pixel by 1: at most 1 count on at most 0.1 % of the pixels."""
+    from oracle import augment_oracle as AO
+
+    raw, _ = _aug_batch(4, 6, 224)
+    bp = torch.tensor([[1, 0.83, 1.17, 0], [0, 1.0, 1.0, 0], [1, 1.2, 0.8, 0], [1, 1.0, 1.0, 0]], dtype=torch.float32)
+    got = ops.aug_brightness_contrast(raw.clone().to(DEV), bp.to(DEV), 10000.0).cpu().numpy()
+    for b in range(4):
+        for c in range(6):
+            ref = AO.brightness_contrast(raw[b, c].numpy(), float(bp[b, 1]), float(bp[b, 2]), 10000.0) if bp[b, 0] else raw[b, c].numpy()
+            assert np.abs(got[b, c] - ref).max() <= 4e-3, (b, c, np.abs(got[b, c] - ref).max())
+    assert np.array_equal(got[1], raw[1].numpy())
+
+    apply = torch.tensor([1, 0, 1, 1], dtype=torch.int32)
+    for ksize, sigma in ((3, (0.1, 2.0)), (5, (1.0, 1.0))):
+        k2 = DL.gaussian_kernel2d(ksize, sigma)
+        got = ops.aug_blur(raw.to(DEV), apply.to(DEV), k2.to(DEV), 10000.0).cpu().numpy()
+        for b in range(4):
+            for c in range(0, 6, 2):
+                ref = AO.gaussian_blur(raw[b, c].numpy(), ksize, sigma, 10000.0).astype(np.float32) if apply[b] else raw[b, c].numpy()
+                d = np.abs(got[b, c] - ref)
+                assert d.max() <= 1.0 and (d > 0).mean() <= 1e-3, (ksize, b, c, d.max(), (d > 0).mean())
+
+    z = torch.randn(raw.shape, generator=torch.Generator().manual_seed(5))
+    npm = torch.tensor([[1, 123], [0, 0], [1, 7], [1, 99]], dtype=torch.int32)
+    got = ops.aug_noise(raw.clone().to(DEV), npm.to(DEV), 0.05, 10000.0, z.to(DEV)).cpu().numpy()
+    for b in range(4):
+        for c in range(6):
+            ref = AO.gaussian_noise(raw[b, c].numpy(), z[b, c].numpy(), 0.05, 10000.0).astype(np.float32) if npm[b, 0] else raw[b, c].numpy()
+            d = np.abs(got[b, c] - ref)
+            assert d.max() <= 1.0 and (d > 0).mean() <= 1e-3, (b, c, d.max(), (d > 0).mean())
+    # generated noise: standard normal per chip (mean ~0, std ~noise_std * max on mid-range pixels), reproducible from the seed
+    mid = torch.full((2, 6, 224, 224), 5000.0)
+    seeds = torch.tensor([[1, 42], [1, 43]], dtype=torch.int32)
+    n1 = ops.aug_noise(mid.clone().to(DEV), seeds.to(DEV), 0.05, 10000.0).cpu()
+    n2 = ops.aug_noise(mid.clone().to(DEV), seeds.to(DEV), 0.05, 10000.0).cpu()
+    assert torch.equal(n1, n2) and not torch.equal(n1[0], n1[1])
+    r = (n1 - 5000.0) / 500.0
+    assert abs(float(r.mean())) < 5e-3 and abs(float(r.std()) - 1.0) < 5e-3
+    assert abs(float((r > 1.0).float().mean()) - 0.1587) < 3e-3 and abs(float((r.abs() > 2.0).float().mean()) - 0.0455) < 2e-3
+
+
+def test_process_and_augment_batch_with_all_augmentations():
+    """The whole training-time pipeline with every augmentation on (crop + flips -> rotate -> brightness -> blur -> noise ->
+    normalise) against the oracle chain chip by chip, with the host draws replayed (dataloader.py:527-585)."""
+    import random
+
+    from oracle import augment_oracle as AO
+
+    B, T, C, Hs, im = 3, 1, 6, 80, 64
+    g = torch.Generator().manual_seed(2)
+    raw = torch.randint(0, 10000, (B, T * C, Hs, Hs), generator=g).to(torch.int16)
+    lab = torch.randint(-1, 2, (B, Hs, Hs), generator=g).float()
+    augs = {"hflip": {"use": True, "p": 0.5}, "vflip": {"use": True, "p": 0.5}, "rotate": {"use": True, "p": 1.0, "degrees": 10},
+            "brightness": {"use": True, "p": 1.0, "brightness_range": [0.8, 1.2], "contrast_range": [0.8, 1.2]},
+            "blur": {"use": True, "p": 1.0, "kernel_size": 3, "sigma_range": [0.1, 2.0]}, "noise": {"use": True, "p": 0.0, "noise_std": 0.05}}
+    params = DL.draw_augment_params(B, (Hs, Hs), im, True, augs, torch.Generator().manual_seed(4))
+    plan = DL.draw_photometric_params(B, im, augs, random.Random(8))
+    out, lo = DL.process_and_augment_batch(raw.to(DEV), lab.to(DEV), MEAN, STD, T, im, True, augs, 1.0, params=params, plan=plan,
+                                           label_no_data_value=-1, chip_no_data_value=0, max_pixel_value=10000.0)
+    assert out.shape == (B, C, T, im, im) and lo.shape == (B, im, im)
+    r = random.Random(8)
+    for b in range(B):
+        top, left, hf, vf = params[b].tolist()
+        cx, cy = O.crop_flip_chip(raw[b].numpy(), lab[b].numpy(), top, left, bool(hf), bool(vf), im)
+        assert r.random() < 1.0
+        ang = r.uniform(-10, 10)
+        assert r.random() < 1.0
+        bright, contrast = r.uniform(0.8, 1.2), r.uniform(0.8, 1.2)
+        assert r.random() < 1.0 and not (r.random() < 0.0)
+        bands = []
+        for c in range(C):
+            a = AO.rotate_nearest(cx[c].astype(np.float32), ang, 0.0)
+            a = AO.brightness_contrast(a, bright, contrast, 10000.0)
+            bands.append(AO.gaussian_blur(a, 3, (0.1, 2.0), 10000.0).astype(np.float64))
+        ref = O.normalize_chip(np.stack(bands), MEAN, STD, T)
+        d = np.abs(out[b].cpu().numpy() - ref) * np.array(STD)[:, None, None, None]  # back to raw counts
+        assert d.max() <= 1.0 + 1e-3 and (d > 1e-3).mean() <= 2e-3, (b, d.max(), (d > 1e-3).mean())
+        assert np.array_equal(lo[b].cpu().numpy(), AO.rotate_nearest(cy.astype(np.float32), ang, -1.0)), b
 
 
 @pytest.mark.parametrize("dtype", [torch.int16, torch.float32])
