@@ -188,6 +188,11 @@ int ig_kd_loss(const float* student_logits, const float* teacher_logits, const v
  * streaming sums of RunningRegressionMetrics on the de-scaled values {n, Sx, Sy, Sxy, Sxx, Syy, S|e|, See, #within EE} */
 int ig_mse_loss(const float* pred, const float* labels, float ignore_value, int use_log_scale, double* stats, float* dpred,
                 double* msums, float ee_bias, float ee_coef, int include_ee, long n, void* stream);
+/* distillation of the regression task (regression.py:345-534): sum[0] += sum over valid pixels (labels != ignore_value) of
+ * (pred - teacher')^2, teacher' = log1p(teacher) under use_log_scale (regression.py:527-529); dpred += 2 (pred - teacher') on
+ * top of the gradient ig_mse_loss wrote (both terms are means over the same valid count, regression.py:496-503) */
+int ig_kd_mse_loss(const float* pred, const float* teacher, const float* labels, float ignore_value, int use_log_scale, double* sum,
+                   float* dpred, long n, void* stream);
 /* test-time metrics on the device: RunningAUC histograms of softmax(logits) (metrics.py:214-256 via
  * segmentation.py:153-156; hist = uint64 [2][ncls][nbins], 0 = positives / 1 = negatives of each class, ignored pixels
  * skipped) and predict_step's softmax(logits, 1)[:, cls] (segmentation.py:202-213) */

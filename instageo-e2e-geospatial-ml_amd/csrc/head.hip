@@ -459,6 +459,31 @@ __global__ __launch_bounds__(TPB) void mse_loss_kernel(const float* __restrict__
     }
 }
 
+// Distillation term of the regression task (regression.py:477-509, 522-534): mean over the VALID pixels (labels != ignore) of
+// (student - teacher')^2 with teacher' = log1p(teacher) under use_log_scale; sum[0] += the numerator, dpred += 2 (s - t').
+__global__ __launch_bounds__(TPB) void kd_mse_loss_kernel(const float* __restrict__ pred, const float* __restrict__ teacher,
+                                                          const float* __restrict__ labels, float ignore_value, int use_log,
+                                                          double* __restrict__ sum, float* __restrict__ dpred, long M) {
+    __shared__ double red[TPB / 64];
+    double a = 0.0;
+    for (long m = blockIdx.x * (long)TPB + threadIdx.x; m < M; m += (long)gridDim.x * TPB) {
+        if (labels[m] == ignore_value) continue;
+        const float t = use_log ? log1pf(teacher[m]) : teacher[m];
+        const float d = pred[m] - t;
+        a += (double)(d * d);
+        if (dpred) dpred[m] += 2.f * d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < TPB / 64; ++w) t += red[w];
+        atomicAdd(sum, t);
+    }
+}
+
 // argmax over classes -> int8 class map (infer_utils.py:99-101)
 __global__ void argmax_kernel(const float* __restrict__ logits, signed char* __restrict__ out, long M, long HW, int ncls) {
     long m = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -663,6 +688,17 @@ int ig_mse_loss(const float* pred, const float* labels, float ignore_value, int 
     hipLaunchKernelGGL(mse_loss_kernel, dim3((unsigned)nblk), dim3(TPB), 0, (hipStream_t)stream, pred, labels, ignore_value, use_log_scale,
                        stats, dpred, msums, ee_bias, ee_coef, include_ee, n);
     return ig_check_launch("ig_mse_loss");
+}
+
+int ig_kd_mse_loss(const float* pred, const float* teacher, const float* labels, float ignore_value, int use_log_scale, double* sum,
+                   float* dpred, long n, void* stream) {
+    IG_REQUIRE(pred && teacher && labels && sum, "ig_kd_mse_loss: null pointer");
+    if (n == 0) return IG_OK;
+    long nblk = (n + TPB - 1) / TPB;
+    if (nblk > 1024) nblk = 1024;
+    hipLaunchKernelGGL(kd_mse_loss_kernel, dim3((unsigned)nblk), dim3(TPB), 0, (hipStream_t)stream, pred, teacher, labels, ignore_value,
+                       use_log_scale, sum, dpred, n);
+    return ig_check_launch("ig_kd_mse_loss");
 }
 
 int ig_argmax_i8(const float* logits, signed char* out, int B, long HW, int ncls, void* stream) {

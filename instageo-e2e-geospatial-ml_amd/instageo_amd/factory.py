@@ -5,7 +5,7 @@ from typing import Any, Dict
 
 import torch
 
-from .regression import PrithviRegressionModule
+from .regression import PrithviDistillationRegressionModule, PrithviRegressionModule
 from .segmentation import PrithviDistillationSegmentationModule, PrithviSegmentationModule
 
 
@@ -30,9 +30,13 @@ def create_model(cfg: Dict[str, Any], precision: str = "bf16", device=None) -> P
         device=device,
     )
     distill = bool(t.get("distillation", False)) and train_mode
-    if distill and cfg.get("is_reg_task", False):
-        raise NotImplementedError("distillation of the regression task is outside the hot-path scope (SURVEY.md 8f item 4)")
-    if distill:  # factory.py:84-91: frozen teacher from train.teacher_ckpt_path, student of model.depth blocks
+    if distill and cfg.get("is_reg_task", False):  # factory.py:61-69
+        common_d = {k: v for k, v in common.items() if k != "depth"}
+        model = PrithviDistillationRegressionModule(teacher_ckpt_path=t["teacher_ckpt_path"], depth=t.get("teacher_depth", -1),
+                                                    student_depth=m.get("depth", -1), use_log_scale=m.get("use_log_scale", False),
+                                                    plot_reg_results=m.get("plot_reg_results", False),
+                                                    include_ee=m.get("include_ee_metric", False), **common_d)
+    elif distill:  # factory.py:84-91: frozen teacher from train.teacher_ckpt_path, student of model.depth blocks
         common_d = {k: v for k, v in common.items() if k != "depth"}
         model = PrithviDistillationSegmentationModule(teacher_ckpt_path=t["teacher_ckpt_path"], num_classes=m["num_classes"],
                                                       class_weights=t["class_weights"], depth=t.get("teacher_depth", -1),

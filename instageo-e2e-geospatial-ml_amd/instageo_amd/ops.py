@@ -462,6 +462,15 @@ def mse_loss(pred, labels, ignore_index: float, use_log_scale: bool, stats, dpre
           float(ee_bias), float(ee_coef), int(include_ee), n, _stream())
 
 
+def kd_mse_loss(pred, teacher, labels, ignore_index: float, use_log_scale: bool, total, dpred=None) -> None:
+    """Regression distillation term: ``total`` (f64 [1]) += sum over valid pixels of (pred - teacher')^2; ``dpred`` += 2 (pred - teacher')
+    (regression.py:477-534)."""
+    n = pred.numel()
+    assert teacher.numel() == n and labels.numel() == n and total.dtype == torch.float64
+    _call("ig_kd_mse_loss", float(n) * (12 + (8 if dpred is not None else 0)), _p(_f32(pred)), _p(_f32(teacher)), _p(_f32(labels)),
+          float(ignore_index), int(use_log_scale), _p(total), _p(dpred), n, _stream())
+
+
 def auc_update(logits, labels, ignore_index: Optional[int], hist, nbins: int, min_score: float = 0.0, max_score: float = 1.0) -> None:
     """RunningAUC histograms of softmax(logits): hist int64 [2, ncls, nbins] (0 positives, 1 negatives of each class)."""
     B, ncls = logits.shape[0], logits.shape[1]

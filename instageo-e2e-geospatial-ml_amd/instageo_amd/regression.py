@@ -15,7 +15,7 @@ from . import ops
 from .metrics import RunningRegressionMetrics
 from .segmentation import PrithviSegmentationModule
 
-__all__ = ["LogScaler", "PrithviRegressionModule"]
+__all__ = ["LogScaler", "PrithviRegressionModule", "PrithviDistillationRegressionModule"]
 
 
 class LogScaler:
@@ -89,3 +89,65 @@ class PrithviRegressionModule(PrithviSegmentationModule):
         with torch.no_grad():
             pred = self.net.engine.forward(inputs, training=False, save=False).squeeze(1)
         return self.log_scaler.inverse_transform(pred) if self.use_log_scale else pred
+
+
+class PrithviDistillationRegressionModule(PrithviRegressionModule):
+    """Knowledge distillation of the regression task (reference: ``regression.py:345-534``, ``base.py:234-334``): a frozen
+    ``PrithviRegressionModule`` teacher of ``depth`` blocks loaded from ``teacher_ckpt_path`` and a student of ``student_depth``
+    blocks; loss = mean((student - label')^2) + mean((student - teacher')^2) over the valid pixels, label' / teacher' =
+    ``log1p`` of the label / teacher output under ``use_log_scale`` (regression.py:522-534, 496-503).  The second term and its
+    gradient come from ``ig_kd_mse_loss`` on top of the fused ``ig_mse_loss``; the teacher runs the engine's inference path.
+    Like the segmentation variant, ``student_depth`` is explicit (the reference passes it through ``**kwargs``)."""
+
+    def __init__(self, teacher_ckpt_path: str, image_size: int = 224, learning_rate: float = 1e-4, load_pretrained_weights: bool = True,
+                 temporal_step: int = 1, ignore_index: int = -100, weight_decay: float = 1e-2, scheduler: bool = True, depth: int = -1,
+                 student_depth: int = -1, model_name: str = "prithvi_eo_v1_100", use_log_scale: bool = False,
+                 plot_reg_results: bool = False, include_ee: bool = False, weight_clip_range: Optional[List[float]] = None,
+                 freeze_backbone: bool = False, precision: str = "bf16", device: Optional[Any] = None, **kwargs: Any) -> None:
+        super().__init__(image_size=image_size, learning_rate=learning_rate, freeze_backbone=freeze_backbone,
+                         load_pretrained_weights=False, temporal_step=temporal_step, ignore_index=ignore_index,
+                         weight_decay=weight_decay, scheduler=scheduler, model_name=model_name, use_log_scale=use_log_scale,
+                         plot_reg_results=plot_reg_results, include_ee=include_ee, weight_clip_range=weight_clip_range,
+                         depth=student_depth, precision=precision, device=device)
+        self.teacher = PrithviRegressionModule(image_size=image_size, learning_rate=learning_rate, freeze_backbone=True,
+                                               load_pretrained_weights=False, temporal_step=temporal_step, ignore_index=ignore_index,
+                                               weight_decay=weight_decay, scheduler=scheduler, model_name=model_name, depth=depth,
+                                               precision=precision, device=device)
+        sd = torch.load(teacher_ckpt_path, map_location="cpu")["state_dict"]
+        sd = {k.replace("prithvi_100M_backbone", "prithvi_encoder"): v for k, v in sd.items()}  # regression.py:461-464
+        self.teacher.load_checkpoint_state_dict(sd, strict=True)
+        self.teacher.net.eval()
+        for p_ in self.teacher.parameters():
+            p_.requires_grad_(False)
+        if load_pretrained_weights:  # shared encoder tensors of equal shape initialise the student (base.py:312-324)
+            t_sd = {k: v for k, v in self.teacher.net.state_dict().items() if k.startswith("prithvi_encoder.")}
+            s_sd = self.net.state_dict()
+            shared = {k: v for k, v in t_sd.items() if k in s_sd and v.shape == s_sd[k].shape}
+            self.net.load_state_dict({**s_sd, **shared}, strict=True)
+        self._kd = torch.zeros(1, dtype=torch.float64, device=self.net.store.flat.device)
+
+    def _fused_loss(self, logits, labels, stats, dlogits, step_type: str) -> None:
+        super()._fused_loss(logits, labels, stats, dlogits, step_type)  # label term, its gradient, the regression metrics
+        with torch.no_grad():
+            t_out = self.teacher.net.engine.forward(self._last_inputs, training=False, save=False)
+        self._kd.zero_()
+        ops.kd_mse_loss(logits, t_out, labels.to(torch.float32).contiguous(), float(self.ignore_index), self.use_log_scale, self._kd, dlogits)
+        self._parts = (stats[0].clone(), self._kd[0].clone(), stats[1].clone())
+        stats[0] += self._kd[0]  # total = (sum sq. label error + sum sq. teacher error) / #valid
+
+    def fused_train_step(self, inputs, labels, stats=None, grad_scale_world: int = 1):
+        self._last_inputs = inputs
+        out = super().fused_train_step(inputs, labels, stats, grad_scale_world)
+        self._log_parts("train")
+        return out
+
+    def fused_eval_step(self, inputs, labels, step_type: str = "val"):
+        self._last_inputs = inputs
+        out = super().fused_eval_step(inputs, labels, step_type)
+        self._log_parts(step_type)
+        return out
+
+    def _log_parts(self, step_type: str) -> None:
+        mse, kd, n = self._parts
+        self.log(f"{step_type}_mse_loss", (mse / n).item())
+        self.log(f"{step_type}_distill_loss", (kd / n).item())

@@ -462,6 +462,20 @@ def regression_loss(outputs: torch.Tensor, labels: torch.Tensor, ignore_index: f
     return loss, preds, l2
 
 
+def regression_distillation_loss(student: torch.Tensor, teacher: torch.Tensor, labels: torch.Tensor, ignore_index: float,
+                                 use_log_scale: bool = False):
+    """regression.py:477-534 (PrithviDistillationRegressionModule._shared_step + _compute_loss): mask = labels != ignore_index;
+    labels and TEACHER outputs go through log1p under use_log_scale; total = mean((s - y')^2) + mean((s - t')^2) over the mask.
+    Returns (total, mse, distill)."""
+    mask = labels.ne(ignore_index)
+    lab = torch.log1p(labels) if use_log_scale else labels
+    t = torch.log1p(teacher) if use_log_scale else teacher
+    s_, t_, l_ = student.squeeze(1)[mask], t.squeeze(1)[mask], lab[mask]
+    mse = ((s_ - l_) ** 2).mean()
+    kd = ((s_ - t_) ** 2).mean()
+    return mse + kd, mse, kd
+
+
 def regression_sums(y_true: np.ndarray, y_pred: np.ndarray, ee_bias: float = 0.05, ee_coef: float = 0.15) -> List[float]:
     """metrics.py:330-352 (RunningRegressionMetrics.update) as one batch, accumulated in float64:
     [n, Sx, Sy, Sxy, Sxx, Syy, S|e|, See, #(|e| <= ee_bias + ee_coef x)]."""
