@@ -524,6 +524,185 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_dkv_kernel(const bf16_t*
         }
 }
 
+
+// ----------------------------------------------------------------------------------------------------------------------
+// Fused single-pass backward for one-chunk heads (N <= 224, plain bf16): the key-owner pass above + dQ in the same sweep.
+//   dS[q][key] has the keys on the LANES; dQ^T[d][q] += K^T[d][key] dS^T[key][q] contracts over keys, so the tile is transposed
+//   once through a wave-private LDS slab ([key][q] bf16, 72-byte pitch: 8-byte row writes and hardware-transposed reads are both
+//   conflict-free) and the 7 waves' partial dQ tiles are folded into ONE fp32 image dQ[224][64] in LDS.  LDS float atomics are far
+//   too slow for that (ds_add_f32: measured ~240 cycles per wave-instruction -- 858 us per launch); instead the waves walk the
+//   query tiles in ROTATED order (wave w takes tile (w + i) mod 7 in step i, a barrier per step), so that no two waves touch
+//   the same tile in a step and the fold is a plain 16-byte read-add-write (pitch 68 words: conflict-free).
+//   5 MFMA products per (key block, query tile) instead of 7 and Q, K, V, dO read once: 262 MB instead of 426 MB per launch at
+//   B = 108.  delta = rowsum(dO o O) is computed by the workgroup itself.
+constexpr int A2F_DQP = 68;                          // dQ image pitch in floats (row = query)
+constexpr int A2F_SLAB = 32 * 72;                    // per-wave dS slab
+constexpr int A2F_OFF_K = 2 * A2_TILE;               // K image (transposed fragments of the wave's own keys)
+constexpr int A2F_OFF_DQ = 2 * A2_TILE;              // fp32 dQ image: ALIASES the K image (dead once the K^T fragments are in registers)
+constexpr int A2F_OFF_SLAB = A2F_OFF_DQ + A2_CH * A2F_DQP * 4;
+constexpr int A2F_OFF_LSE = A2F_OFF_SLAB + A2_WAVES * A2F_SLAB;
+constexpr int A2F_SMEM = A2F_OFF_LSE + 2 * A2_CH * 4;
+
+// B operand X[n = lane & 31][k] from a [k rows][32 n] bf16 slab of pitch 72 B, accumulator k order (see tr_frag)
+__device__ __forceinline__ bf16x8_t tr_slab(const char* slab, int s, int lane) {
+    const int g16 = lane >> 4, i16 = lane & 15;
+    const int r0 = 16 * s + 4 * (g16 >> 1) + (i16 >> 2), r1 = r0 + 8;
+    const int cb = (16 * (g16 & 1) + 4 * (i16 & 3)) * 2;
+    const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(slab + r0 * 72 + cb));
+    const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(slab + r1 * 72 + cb));
+    const s16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    return __builtin_bit_cast(bf16x8_t, av);
+}
+
+__global__ __launch_bounds__(A2_THREADS) void attn2_bwd_fused_kernel(const bf16_t* __restrict__ qkv_hi, const bf16_t* __restrict__ do_hi,
+                                                                     const bf16_t* __restrict__ o_hi, const float* __restrict__ lse,
+                                                                     float* __restrict__ delta, bf16_t* __restrict__ dqkv_hi, int N, int H,
+                                                                     float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* q_img = smem;
+    char* d_img = smem + A2_TILE;
+    char* k_img = smem + A2F_OFF_K;
+    float* s_dq = reinterpret_cast<float*>(smem + A2F_OFF_DQ);
+    float* s_lse = reinterpret_cast<float*>(smem + A2F_OFF_LSE);
+    float* s_del = s_lse + A2_CH;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* slab = smem + A2F_OFF_SLAB + wave * A2F_SLAB;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const long RS = 3L * H * 64, OS = (long)H * 64;
+    const bf16_t* base = qkv_hi + (long)b * N * RS + h * 64;
+    const bf16_t* dob = do_hi + (long)b * N * OS + h * 64;
+    const bf16_t* ob = o_hi + (long)b * N * OS + h * 64;
+    const int k0 = wave * 32;
+    const bool active = k0 < N;
+    const int key = k0 + lr, kr = min(key, N - 1);
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_char_ptr)smem;
+
+    dma_image(lds_base, base, RS, 0, N, wave, lane);
+    dma_image(lds_base + A2_TILE, dob, OS, 0, N, wave, lane);
+    dma_image(lds_base + A2F_OFF_K, base + H * 64, RS, 0, N, wave, lane);
+    bf16x8_t kh[4], vh[4];  // K^T / V^T B operands of this lane's key
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        kh[s] = own_frag(base + H * 64, RS, kr, s, lh);
+        vh[s] = own_frag(base + 2 * H * 64, RS, kr, s, lh);
+    }
+    if (tid < A2_CH) {
+        float dl = 0.f;
+        if (tid < N) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float fo[8], fd[8];
+                unpack8(*reinterpret_cast<const uint4*>(ob + (long)tid * OS + 8 * c), fo);
+                unpack8(*reinterpret_cast<const uint4*>(dob + (long)tid * OS + 8 * c), fd);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dl = fmaf(fo[e], fd[e], dl);
+            }
+            delta[((long)b * H + h) * N + tid] = dl;
+        }
+        s_lse[tid] = tid < N ? lse[((long)b * H + h) * N + tid] * 1.44269504088896340736f : INFINITY;  // +inf -> P = 0 on padded queries
+        s_del[tid] = dl;
+    }
+    const float c2 = scale * 1.44269504088896340736f;
+    const float kmask = key < N ? 1.f : 0.f;  // padded keys must not reach dQ
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dk[i][r] = 0.f, dv[i][r] = 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int ntile = (N + 31) >> 5;  // = number of active waves: tile qt is first touched by wave qt in step 0
+    bf16x8_t kt[2][2];                // K^T A operands of the wave's 32 keys: [k-step][d half]
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int dhf = 0; dhf < 2; ++dhf) kt[s][dhf] = tr_frag(k_img, k0, s, 32 * dhf, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();  // the dQ image takes the K image's place
+    for (int step = 0; step < A2_WAVES; ++step) {
+        const int qt = (wave + step) % A2_WAVES;
+        if (active && qt < ntile) {
+            f32x16 st, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.f, dp[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) st = mfma32(rows_frag(q_img, qt * 32, s, lr, lh), kh[s], st);  // S[q][key]
+#pragma unroll
+            for (int s = 0; s < 4; ++s) dp = mfma32(rows_frag(d_img, qt * 32, s, lr, lh), vh[s], dp);  // dP[q][key]
+            f32x16 ds;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {  // accumulator rows 8 g + 4 lh + (0..3) = four consecutive queries
+                const float4 l4 = *reinterpret_cast<const float4*>(s_lse + qt * 32 + 8 * g + 4 * lh);
+                const float4 d4 = *reinterpret_cast<const float4*>(s_del + qt * 32 + 8 * g + 4 * lh);
+                const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(st[4 * g + e], c2, -ll[e])) * kmask;
+                    st[4 * g + e] = pv;
+                    ds[4 * g + e] = pv * (dp[4 * g + e] - dd[e]);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8_t ph, pl, sh, sl;
+                pack_step<false>(st, s, ph, pl);
+                pack_step<false>(ds, s, sh, sl);
+                // dS rows of this lane's key: queries 16 s + 4 lh + (0..3) and 16 s + 8 + 4 lh + (0..3)
+                const uint4 su = __builtin_bit_cast(uint4, sh);
+                *reinterpret_cast<uint2*>(slab + lr * 72 + (16 * s + 4 * lh) * 2) = make_uint2(su.x, su.y);
+                *reinterpret_cast<uint2*>(slab + lr * 72 + (16 * s + 8 + 4 * lh) * 2) = make_uint2(su.z, su.w);
+#pragma unroll
+                for (int dhf = 0; dhf < 2; ++dhf) {
+                    dv[dhf] = mfma32(tr_frag(d_img, qt * 32, s, 32 * dhf, lane), ph, dv[dhf]);  // dV^T += dO^T P
+                    dk[dhf] = mfma32(tr_frag(q_img, qt * 32, s, 32 * dhf, lane), sh, dk[dhf]);  // dK^T += Q^T dS
+                }
+            }
+            // dQ^T[d][q tile] partial of this key block, folded into the workgroup's fp32 image (this wave owns tile qt in this step)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const bf16x8_t b0 = tr_slab(slab, 0, lane), b1 = tr_slab(slab, 1, lane);
+#pragma unroll
+            for (int dhf = 0; dhf < 2; ++dhf) {
+                f32x16 dq;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+                dq = mfma32(kt[0][dhf], b0, dq);
+                dq = mfma32(kt[1][dhf], b1, dq);
+                float* row = s_dq + (qt * 32 + lr) * A2F_DQP + 32 * dhf + 4 * lh;  // lane = query; registers 4 g .. 4 g + 3 = columns 8 g + 4 lh + (0..3)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float4 v = make_float4(dq[4 * g], dq[4 * g + 1], dq[4 * g + 2], dq[4 * g + 3]);
+                    if (step > 0) {
+                        const float4 o = *reinterpret_cast<const float4*>(row + 8 * g);
+                        v.x += o.x, v.y += o.y, v.z += o.z, v.w += o.w;
+                    }
+                    *reinterpret_cast<float4*>(row + 8 * g) = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // dQ write-out: item = (query, 8-column chunk); 8 lanes cover one 128-byte row segment of dqkv's Q slot
+    for (int it = tid; it < N * 8; it += A2_THREADS) {
+        const int q = it >> 3, c = it & 7;
+        const float4 v0 = *reinterpret_cast<const float4*>(s_dq + q * A2F_DQP + 8 * c), v1 = *reinterpret_cast<const float4*>(s_dq + q * A2F_DQP + 8 * c + 4);
+        const float f[8] = {v0.x * scale, v0.y * scale, v0.z * scale, v0.w * scale, v1.x * scale, v1.y * scale, v1.z * scale, v1.w * scale};
+        *reinterpret_cast<uint4*>(dqkv_hi + ((size_t)b * N + q) * RS + h * 64 + 8 * c) = pack8(f);
+    }
+    if (!active || key >= N) return;
+    const size_t orow = ((size_t)b * N + key) * RS + h * 64;
+#pragma unroll
+    for (int dhf = 0; dhf < 2; ++dhf)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float fk[4] = {dk[dhf][4 * g] * scale, dk[dhf][4 * g + 1] * scale, dk[dhf][4 * g + 2] * scale, dk[dhf][4 * g + 3] * scale};
+            const float fv[4] = {dv[dhf][4 * g], dv[dhf][4 * g + 1], dv[dhf][4 * g + 2], dv[dhf][4 * g + 3]};
+            store4_split(dqkv_hi, nullptr, orow + (size_t)H * 64 + 32 * dhf + 8 * g + 4 * lh, fk);
+            store4_split(dqkv_hi, nullptr, orow + 2 * (size_t)H * 64 + 32 * dhf + 8 * g + 4 * lh, fv);
+        }
+}
+
 }  // namespace
 
 // IG_ERR_UNSUPPORTED (no error string): the caller runs the first-generation kernel.  IG_ATTN2=0 disables (A/B runs).
@@ -570,6 +749,18 @@ int ig_attention2_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi
     const int lds_q = (split ? 4 : 2) * A2_TILE, lds_kv = lds_q + 2 * A2_CH * (int)sizeof(float);
     const float scale = 0.125f;
     hipStream_t st = (hipStream_t)stream;
+    const char* fe = getenv("IG_ATTN2_FUSED");  // 0: always the two-pass kernels (A/B runs)
+    if (!split && N <= A2_CH && !(fe && atoi(fe) == 0)) {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)attn2_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, A2F_SMEM);
+            attr = true;
+        }
+        ig_note_kernel("attn2_bwd_fused_kernel");
+        hipLaunchKernelGGL(attn2_bwd_fused_kernel, dim3(1, H, B), dim3(A2_THREADS), A2F_SMEM, st, (const bf16_t*)qkv_hi, (const bf16_t*)dout_hi,
+                           (const bf16_t*)out_hi, lse, delta, (bf16_t*)dqkv_hi, N, H, scale);
+        return ig_check_launch("ig_attention_bwd(attn2 fused)");
+    }
     const char* lb = getenv("IG_ATTN2_DQLB");  // 4 (default): two dQ workgroups per CU at 128 registers (56 B of scratch); 2: one at 143 -- measured 75 vs 85 us
     const int dqlb = lb ? atoi(lb) : 4;
 #define IG_A2_BWD(SPLIT_)                                                                                                          \

@@ -28,8 +28,11 @@ for B, N, H in [(108, 197, 12), (36, 589, 12), (54, 197, 16)]:
     tb0 = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H))
     os.environ["IG_ATTN2"] = "1"
     os.environ["IG_ATTN2_DQLB"] = "4"
+    os.environ["IG_ATTN2_FUSED"] = "1"
+    tbf = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H))
+    os.environ["IG_ATTN2_FUSED"] = "0"
     tb4 = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H))
     os.environ["IG_ATTN2_DQLB"] = "2"
     tb = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H))
     fl = 4.0 * B * H * N * N * 64
-    print(f"B{B} N{N} H{H}: fwd gen1 {tf0:7.1f} us ({fl/tf0/1e6:5.0f} TF)  gen2 {tf:7.1f} us ({fl/tf/1e6:5.0f} TF)  bwd gen1 {tb0:7.1f} us  gen2(lb4) {tb4:7.1f} us  gen2 {tb:7.1f} us ({2.5*fl/tb/1e6:5.0f} TF)")
+    print(f"B{B} N{N} H{H}: fwd gen1 {tf0:7.1f} us ({fl/tf0/1e6:5.0f} TF)  gen2 {tf:7.1f} us ({fl/tf/1e6:5.0f} TF)  bwd gen1 {tb0:7.1f} us  gen2(lb4) {tb4:7.1f} us  gen2 {tb:7.1f} us ({2.5*fl/tb/1e6:5.0f} TF)  fused {tbf:7.1f} us ({2.5*fl/tbf/1e6:5.0f} TF)")
