@@ -588,21 +588,22 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_fused_kernel(const bf16_
         kh[s] = own_frag(base + H * 64, RS, kr, s, lh);
         vh[s] = own_frag(base + 2 * H * 64, RS, kr, s, lh);
     }
-    if (tid < A2_CH) {
+    {   // delta = rowsum(dO o O) and lse of the wave's own 32 QUERY rows (same row numbers as its keys): 8 + 8 coalesced 16-byte
+        // loads per lane issued behind the DMAs, two half-row partial sums folded with one permlane swap
         float dl = 0.f;
-        if (tid < N) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                float fo[8], fd[8];
-                unpack8(*reinterpret_cast<const uint4*>(ob + (long)tid * OS + 8 * c), fo);
-                unpack8(*reinterpret_cast<const uint4*>(dob + (long)tid * OS + 8 * c), fd);
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8_t oh = own_frag(ob, OS, kr, s, lh), dh = own_frag(dob, OS, kr, s, lh);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) dl = fmaf(fo[e], fd[e], dl);
-            }
-            delta[((long)b * H + h) * N + tid] = dl;
+            for (int e = 0; e < 8; ++e) dl = fmaf((float)oh[e], (float)dh[e], dl);
         }
-        s_lse[tid] = tid < N ? lse[((long)b * H + h) * N + tid] * 1.44269504088896340736f : INFINITY;  // +inf -> P = 0 on padded queries
-        s_del[tid] = dl;
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(dl), __float_as_uint(dl), false, false);
+        dl = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        if (lh == 0) {
+            if (key < N) delta[((long)b * H + h) * N + key] = dl;
+            s_lse[key] = key < N ? lse[((long)b * H + h) * N + key] * 1.44269504088896340736f : INFINITY;  // +inf -> P = 0 on padded queries
+            s_del[key] = key < N ? dl : 0.f;
+        }
     }
     const float c2 = scale * 1.44269504088896340736f;
     const float kmask = key < N ? 1.f : 0.f;  // padded keys must not reach dQ
