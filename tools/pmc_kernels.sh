@@ -19,5 +19,14 @@ for k,v in agg.items():
     if os.environ.get("PMC_FILTER", "direct") not in k and os.environ.get("PMC_FILTER", "direct") != "*": continue
     wc=v["SQ_WAVE_CYCLES"]
     print(k, "launches",n[k])
-    for c in v: print(f"   {c:28s} {v[c]/max(n[k],1):14.0f}  {v[c]/wc:6.3f} of wave cycles")
+    # units (MI355X_MICROARCH.md): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count QUAD-cycles (4 shader cycles), so their ratio
+    # to SQ_WAVE_CYCLES is a fraction of wave time; SQ_VALU_MFMA_BUSY_CYCLES and SQ_BUSY_CYCLES count shader CYCLES: MFMA-pipe
+    # utilisation = MFMA busy cycles / SQ_BUSY_CYCLES (both in cycles), and against wave time it is divided by 4 x quad-cycles
+    cyc = ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES")
+    for c in v:
+        if c in cyc:
+            extra = f"{v[c]/max(v['SQ_BUSY_CYCLES'],1):6.3f} of SQ busy cycles, {v[c]/(4*wc):6.3f} of wave cycles (cycles / 4 x quad-cycles)"
+        else:
+            extra = f"{v[c]/wc:6.3f} of wave quad-cycles"
+        print(f"   {c:28s} {v[c]/max(n[k],1):14.0f}  {extra}")
 PY
