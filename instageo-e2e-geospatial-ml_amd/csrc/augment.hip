@@ -147,6 +147,7 @@ extern "C" {
 
 int ig_aug_rotate(const float* src, float* dst, const float* labels_in, float* labels_out, const int* params, float fill, float label_fill,
                   int B, int CT, int S, void* stream) {
+    if (B == 0) return IG_OK;  // an empty batch carries null data pointers
     IG_REQUIRE(src && dst && params && src != dst, "ig_aug_rotate: null pointer or in-place call (src and dst must differ)");
     IG_REQUIRE((labels_in == nullptr) == (labels_out == nullptr), "ig_aug_rotate: labels_in and labels_out go together");
     IG_REQUIRE(B >= 0 && CT > 0 && S > 0 && S <= 4096, "ig_aug_rotate: need B >= 0, CT > 0, 0 < S <= 4096");
@@ -160,6 +161,7 @@ int ig_aug_rotate(const float* src, float* dst, const float* labels_in, float* l
 }
 
 int ig_aug_brightness_contrast(float* buf, const float* params, float max_pixel, int B, int CT, int S, void* stream) {
+    if (B == 0) return IG_OK;  // an empty batch carries null data pointers
     IG_REQUIRE(buf && params, "ig_aug_brightness_contrast: null pointer");
     IG_REQUIRE(B >= 0 && CT > 0 && S > 0 && (S * S) % 4 == 0, "ig_aug_brightness_contrast: S*S must be a positive multiple of 4");
     if (B == 0) return IG_OK;
@@ -171,6 +173,7 @@ int ig_aug_brightness_contrast(float* buf, const float* params, float max_pixel,
 
 int ig_aug_blur(const float* src, float* dst, const int* apply, const float* kernel2d, int ksize, float max_pixel, int B, int CT, int S,
                 void* stream) {
+    if (B == 0) return IG_OK;  // an empty batch carries null data pointers
     IG_REQUIRE(src && dst && apply && kernel2d && src != dst, "ig_aug_blur: null pointer or in-place call (src and dst must differ)");
     IG_REQUIRE(ksize > 0 && (ksize & 1) && ksize / 2 < S, "ig_aug_blur: kernel size must be odd and smaller than 2*S (got %d)", ksize);
     IG_REQUIRE(B >= 0 && CT > 0 && S > 0 && max_pixel > 0.f, "ig_aug_blur: bad sizes");
@@ -183,6 +186,7 @@ int ig_aug_blur(const float* src, float* dst, const int* apply, const float* ker
 }
 
 int ig_aug_noise(float* buf, const int* params, const float* noise, float noise_std, float max_pixel, int B, int CT, int S, void* stream) {
+    if (B == 0) return IG_OK;  // an empty batch carries null data pointers
     IG_REQUIRE(buf && params, "ig_aug_noise: null pointer");
     IG_REQUIRE(B >= 0 && CT > 0 && S > 0 && max_pixel > 0.f, "ig_aug_noise: bad sizes");
     const long per_chip = (long)CT * S * S, total = (long)B * per_chip;

@@ -966,6 +966,7 @@ extern "C" {
 // src_dtype: 0 = int16, 1 = float32.  mult_enabled=0 skips the constant multiplier.
 int ig_normalize_chips(const void* src, int src_dtype, const float* mean, const float* stdv, double mult, int mult_enabled,
                        float* dst, int B, int T, int C, int H, int W, void* stream) {
+    if (B == 0) return IG_OK;  // an empty batch carries null data pointers
     IG_REQUIRE(src && mean && stdv && dst, "ig_normalize_chips: null pointer");
     IG_REQUIRE(B >= 0 && T > 0 && C > 0 && H > 0 && W > 0, "ig_normalize_chips: bad dims");
     long HW = (long)H * W;
@@ -989,6 +990,7 @@ int ig_normalize_chips(const void* src, int src_dtype, const float* mean, const 
 int ig_crop_flip_normalize(const void* src, int src_dtype, const float* mean, const float* stdv, double mult, int mult_enabled,
                            const int* params, float* dst, const float* labels_in, float* labels_out, int B, int T, int C, int Hs,
                            int Ws, int im, void* stream) {
+    if (B == 0) return IG_OK;  // an empty batch carries null data pointers
     IG_REQUIRE(src && mean && stdv && params && dst, "ig_crop_flip_normalize: null pointer");
     IG_REQUIRE((labels_in == nullptr) == (labels_out == nullptr), "ig_crop_flip_normalize: labels_in and labels_out go together");
     IG_REQUIRE(B >= 0 && T > 0 && C > 0 && im > 0 && im <= Hs && im <= Ws, "ig_crop_flip_normalize: need 0 < im <= Hs, Ws");
@@ -1017,6 +1019,7 @@ int ig_crop_flip_normalize(const void* src, int src_dtype, const float* mean, co
 int ig_normalize_windows(const void* tile, int src_dtype, const float* mean, const float* stdv, double mult, int mult_enabled,
                          const int* origins, float* dst, const float* labels_tile, float* labels_out, int n, int T, int C, int Hs,
                          int Ws, int crop, void* stream) {
+    if (n == 0) return IG_OK;  // no windows: origins / dst are null
     IG_REQUIRE(tile && mean && stdv && origins && dst, "ig_normalize_windows: null pointer");
     IG_REQUIRE((labels_tile == nullptr) == (labels_out == nullptr), "ig_normalize_windows: labels_tile and labels_out go together");
     IG_REQUIRE(n >= 0 && T > 0 && C > 0 && crop > 0 && crop <= Hs && crop <= Ws, "ig_normalize_windows: need 0 < crop <= Hs, Ws");

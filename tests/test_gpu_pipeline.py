@@ -538,3 +538,38 @@ def test_regression_distillation_loss_gradient_and_run(tmp_path, capsys, use_log
     s_sd = torch.load(os.path.join(s_dir, "instageo_best_checkpoint.ckpt"))["state_dict"]
     assert "net.prithvi_encoder.blocks.1.attn.qkv.weight" in s_sd and "net.prithvi_encoder.blocks.2.attn.qkv.weight" not in s_sd
     assert not any(k.startswith("teacher.") for k in s_sd)
+
+
+def test_empty_and_degenerate_inputs():
+    """Zero-size batches are no-ops for every dataset-side entry point (the reference's DataLoader can hand over an empty last
+    shard), an all-ignored label map gives a zero valid count instead of NaNs in the statistics, and a tile smaller than the crop
+    yields no windows."""
+    dev = DEV
+    m, s = torch.tensor(MEAN, device=dev), torch.tensor(STD, device=dev)
+    assert ops.normalize_chips(torch.empty((0, 6, 224, 224), dtype=torch.int16, device=dev), m, s, 1, 1e-4).shape == (0, 6, 1, 224, 224)
+    out, lab = ops.crop_flip_normalize(torch.empty((0, 6, 256, 256), dtype=torch.int16, device=dev), torch.empty((0, 4), dtype=torch.int32, device=dev),
+                                       m, s, 1, 224, 1e-4, torch.empty((0, 256, 256), device=dev))
+    assert out.shape == (0, 6, 1, 224, 224) and lab.shape == (0, 224, 224)
+    tile = torch.zeros((6, 300, 300), dtype=torch.int16, device=dev)
+    w, _ = ops.normalize_windows(tile, torch.empty((0, 2), dtype=torch.int32, device=dev), m, s, 1, 224, 1e-4)
+    assert w.shape == (0, 6, 1, 224, 224)
+    e = torch.empty((0, 6, 64, 64), device=dev)
+    r, _ = ops.aug_rotate(e, torch.empty((0, 8), dtype=torch.int32, device=dev), 0.0)
+    assert r.shape == e.shape
+    ops.aug_brightness_contrast(e, torch.empty((0, 4), device=dev), 1e4)
+    assert ops.aug_blur(e, torch.empty((0,), dtype=torch.int32, device=dev), DL.gaussian_kernel2d(3, (0.1, 2.0)).to(dev), 1e4).shape == e.shape
+    ops.aug_noise(e, torch.empty((0, 2), dtype=torch.int32, device=dev), 0.05, 1e4)
+    assert DL.draw_photometric_params(0, 224, {"rotate": {"use": True, "p": 1.0}})[0]["table"].numel() == 0
+    # every label ignored: zero valid pixels, zero loss sum, zero gradient, untouched confusion matrix
+    B, k, H, W = 2, 3, 16, 24
+    logits = torch.randn(B, k, H, W, device=dev)
+    labels = torch.full((B, H, W), -1, dtype=torch.int64, device=dev)
+    stats = torch.zeros(2, dtype=torch.float64, device=dev)
+    dl = torch.full((B, k, H, W), 7.0, device=dev)
+    conf = torch.zeros(k * k, dtype=torch.int64, device=dev)
+    ops.ce_loss(logits, labels, torch.ones(k, device=dev), -1, stats, dl, confusion=conf)
+    assert stats.tolist() == [0.0, 0.0] and float(dl.abs().max()) == 0.0 and int(conf.sum()) == 0
+    st2 = torch.zeros(2, dtype=torch.float64, device=dev)
+    ops.mse_loss(torch.randn(B, 1, H, W, device=dev), torch.full((B, H, W), -1.0, device=dev), -1.0, False, st2)
+    assert st2.tolist() == [0.0, 0.0]
+    assert DL.window_origins(200, 224, 224) == [] and O.window_origins(200, 224, 224) == []
