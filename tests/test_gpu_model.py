@@ -121,12 +121,13 @@ def rel_l2(a, b):
     return ((a - b).norm() / (b.norm() + 1e-300)).item()
 
 
-@pytest.mark.parametrize("name", ["tiny_t1_c2", "tiny_t3_c13", "v1_100_t1_c2", "v1_100_t3_c13"])
+@pytest.mark.parametrize("name", ["tiny_t1_c2", "tiny_t3_c13", "v1_100_t1_c2", "v1_100_t3_c13", "v2_300_t1_c2"])
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
 def test_train_step_gradients(name, precision):
     """forward(train-mode BN, dropout p=0) + loss + backward: loss, logits and gradients vs the fp64 fixture that
-    oracle/gen_golden.py computed with the REFERENCE network (tiny and the model-size Prithvi-100M cases: D = 768 runs the
-    8-phase / ping-pong / dual-K GEMM engines end to end against reference-generated gradients)."""
+    oracle/gen_golden.py computed with the REFERENCE network (tiny, the model-size Prithvi-100M cases -- D = 768 runs the
+    8-phase / ping-pong / dual-K GEMM engines end to end against reference-generated gradients -- and Prithvi-V2-300M:
+    D = 1024, 24 blocks, 16 heads, the 64-channel head of BASELINE configs[4])."""
     cfg, sd, net, img, lab = build(name, precision)
     net.cfg.drop_p = 0.0
     net.train()
