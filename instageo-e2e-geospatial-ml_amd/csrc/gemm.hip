@@ -1473,9 +1473,14 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep_in, int M, int N, int K
         const int dim = EP::kStagedAtomic ? M : N;
         long best = -1;
         int pick = 0;
+        // cost = padded extent / relative tile efficiency: the 48-wide tiles run at about half the MFMA rate of the 96 / 128 ones
+        // (measured 282 vs 550 TFLOP/s on the 144-channel weight gradient), so 144 = 2 x 96 (25 % padding) beats 3 x 48 (none)
+        static const int eff[4] = {100, 95, 80, 55};
+        static const int cost_env = getenv("IG_V1_TILE_COST") ? atoi(getenv("IG_V1_TILE_COST")) : 1;
         for (int c = 0; c < 4; ++c) {
             if (EP::kStagedAtomic && cand[c] == 64) continue;
-            const long padded = (long)ig_cdiv(dim, cand[c]) * cand[c];
+            long padded = (long)ig_cdiv(dim, cand[c]) * cand[c];
+            if (cost_env) padded = padded * 100 / eff[c];
             if (best < 0 || padded < best) best = padded, pick = c;
         }
         if (EP::kStagedAtomic) mt = code[pick], bm_rows = cand[pick], bn_cols = 128;
