@@ -28,58 +28,95 @@ __device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ src, char*
     }
 }
 
+// The same for a window of `cu` units starting at unit `c0` of rows that are `units` units long (channel-chunked staging).
+__device__ __forceinline__ void stage_cols(const bf16_t* __restrict__ src, char* dst, int nrows, int units, int c0, int cu, int pitch) {
+    const int total = nrows * cu;
+    for (int base = threadIdx.x; base < total; base += TPB * 4) {
+        uint4 b[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int u = base + k * TPB;
+            b[k] = make_uint4(0, 0, 0, 0);
+            if (u < total) b[k] = *reinterpret_cast<const uint4*>(src + ((size_t)(u / cu) * units + c0 + (u % cu)) * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int u = base + k * TPB;
+            if (u < total) *reinterpret_cast<uint4*>(dst + (u / cu) * pitch + (u % cu) * 16) = b[k];
+        }
+    }
+}
+
 // logits[b][n][pix] = bias[n] + sum_c drop(f[b][pix][c]) * w[n][c]
 // One thread per pixel, but the workgroup's 256 pixels x C channels are first copied to LDS with fully coalesced 16-byte
 // loads (a thread reading its own 96-byte pixel row straight from global touched 48 cache lines per wave-instruction);
-// LDS rows are padded to C*2 + 16 bytes to spread the per-pixel ds_read_b128 over the banks.
+// LDS rows are padded by 16 bytes to spread the per-pixel ds_read_b128 over the banks.  The pixels are staged in CHUNKS of
+// CLS_CHUNK channels (accumulators stay in registers across chunks): staging all 144 channels of the multi-temporal head took
+// 78 KiB -- one workgroup per CU -- and the kernel ran at 0.8 TB/s (780 us) where the 48-channel case streams at 3.4.
+constexpr int CLS_CHUNK = 48;
+constexpr int CLS_IG = 8;  // wide backward: iterations per staged dlogits group
 __global__ __launch_bounds__(TPB) void classifier_fwd_kernel(const bf16_t* __restrict__ f_hi, const bf16_t* __restrict__ f_lo,
                                                              const float* __restrict__ w, const float* __restrict__ bias,
                                                              float* __restrict__ logits, long M, long HW, int C, int ncls,
                                                              uint32_t drop_seed, const uint32_t* drop_seed_dev, uint32_t drop_thresh,
                                                              float drop_inv) {
-    extern __shared__ __attribute__((aligned(16))) float sw[];  // [ncls][C] + [ncls] (padded to 4) | staged pixels (hi [, lo])
+    extern __shared__ __attribute__((aligned(16))) float sw[];  // [ncls][C] + [ncls] (padded to 4) | staged pixel chunk (hi [, lo])
     if (drop_seed_dev) drop_seed += *drop_seed_dev;
-    const int units = C / 8, pitch = C * 2 + 16;  // bytes per staged pixel row
+    const int units = C / 8;
+    const int cmax = min(units, CLS_CHUNK / 8), pitch = cmax * 16 + 16;  // bytes per staged pixel row
     char* stage = reinterpret_cast<char*>(sw + ncls * C + ((ncls + 3) & ~3));
     for (int i = threadIdx.x; i < ncls * C; i += TPB) sw[i] = w[i];
     for (int i = threadIdx.x; i < ncls; i += TPB) sw[ncls * C + i] = bias[i];
     const long m0 = blockIdx.x * (long)TPB;
     const int npix = (int)min((long)TPB, M - m0);
-    stage_rows(f_hi + (size_t)m0 * C, stage, npix * units, units, pitch);
-    if (f_lo) stage_rows(f_lo + (size_t)m0 * C, stage + (size_t)TPB * pitch, npix * units, units, pitch);
-    __syncthreads();
     const long m = m0 + threadIdx.x;
-    if (m >= M) return;
     float acc[MAXC];
 #pragma unroll
-    for (int n = 0; n < MAXC; ++n) acc[n] = n < ncls ? sw[ncls * C + n] : 0.f;
+    for (int n = 0; n < MAXC; ++n) acc[n] = 0.f;
     const char* row = stage + threadIdx.x * pitch;
-    for (int c8 = 0; c8 < units; ++c8) {
-        float f[8];
-        unpack8(*reinterpret_cast<const uint4*>(row + c8 * 16), f);
-        if (f_lo) {
-            float g[8];
-            unpack8(*reinterpret_cast<const uint4*>(row + (size_t)TPB * pitch + c8 * 16), g);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] += g[j];
+    for (int c0 = 0; c0 < units; c0 += cmax) {
+        const int cu = min(cmax, units - c0);
+        if (c0) __syncthreads();  // the previous chunk has been consumed
+        if (cu == units) {  // one chunk = whole rows: contiguous copy
+            stage_rows(f_hi + (size_t)m0 * C, stage, npix * units, units, pitch);
+            if (f_lo) stage_rows(f_lo + (size_t)m0 * C, stage + (size_t)TPB * pitch, npix * units, units, pitch);
+        } else {
+            stage_cols(f_hi + (size_t)m0 * C, stage, npix, units, c0, cu, pitch);
+            if (f_lo) stage_cols(f_lo + (size_t)m0 * C, stage + (size_t)TPB * pitch, npix, units, c0, cu, pitch);
         }
-        if (drop_thresh) {
-            const size_t idx = (size_t)m * C + c8 * 8;
-            float mk[8];
-            dropout_scale4(drop_seed, (uint32_t)idx, drop_thresh, drop_inv, mk);
-            dropout_scale4(drop_seed, (uint32_t)idx + 4u, drop_thresh, drop_inv, mk + 4);
+        __syncthreads();
+        if (m >= M) continue;
+        for (int c8 = 0; c8 < cu; ++c8) {
+            float f[8];
+            unpack8(*reinterpret_cast<const uint4*>(row + c8 * 16), f);
+            if (f_lo) {
+                float g[8];
+                unpack8(*reinterpret_cast<const uint4*>(row + (size_t)TPB * pitch + c8 * 16), g);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] *= mk[j];
-        }
+                for (int j = 0; j < 8; ++j) f[j] += g[j];
+            }
+            if (drop_thresh) {
+                const size_t idx = (size_t)m * C + (c0 + c8) * 8;
+                float mk[8];
+                dropout_scale4(drop_seed, (uint32_t)idx, drop_thresh, drop_inv, mk);
+                dropout_scale4(drop_seed, (uint32_t)idx + 4u, drop_thresh, drop_inv, mk + 4);
 #pragma unroll
-        for (int n = 0; n < MAXC; ++n) {
-            if (n < ncls) {
-                const float* wr = sw + n * C + c8 * 8;
+                for (int j = 0; j < 8; ++j) f[j] *= mk[j];
+            }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[n] += f[j] * wr[j];
+            for (int n = 0; n < MAXC; ++n) {
+                if (n < ncls) {
+                    const float* wr = sw + n * C + (c0 + c8) * 8;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[n] += f[j] * wr[j];
+                }
             }
         }
     }
+    if (m >= M) return;
+#pragma unroll
+    for (int n = 0; n < MAXC; ++n)
+        if (n < ncls) acc[n] += sw[ncls * C + n];
     long b = m / HW, pix = m - b * HW;
 #pragma unroll
     for (int n = 0; n < MAXC; ++n)
@@ -184,6 +221,133 @@ __global__ __launch_bounds__(TPB) void classifier_bwd_kernel(const float* __rest
         atomicAdd(dw + i, t);
     }
     for (int i = threadIdx.x; i < ncls; i += TPB) atomicAdd(db + i, sdb[i]);
+}
+
+// Wide variant (ncls x C too large for the per-slice dW slabs above, e.g. 13 classes x 144 channels of the multi-temporal
+// head, where the fallback -- LDS float atomics -- ran at 0.76 TB/s): blockIdx.y selects a chunk of <= 48 channels, so a thread
+// still owns one 8-channel unit but there are 42 pixel slices per workgroup, and the dW partials are folded through a 32 KiB
+// slab FOUR classes at a time.  dlogits are re-read once per channel chunk (13 floats per pixel against 288 bytes of features).
+template <int NC>
+__global__ __launch_bounds__(TPB) void classifier_bwd_wide_kernel(const float* __restrict__ dl, const bf16_t* __restrict__ f_hi,
+                                                                  const bf16_t* __restrict__ f_lo, const float* __restrict__ w,
+                                                                  bf16_t* __restrict__ df_hi, bf16_t* __restrict__ df_lo,
+                                                                  float* __restrict__ dw, float* __restrict__ db, const double* count,
+                                                                  long M, long HW, int C, int ncls, uint32_t drop_seed,
+                                                                  const uint32_t* drop_seed_dev, uint32_t drop_thresh, float drop_inv,
+                                                                  int iters) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    if (drop_seed_dev) drop_seed += *drop_seed_dev;
+    const int c0 = blockIdx.y * CLS_CHUNK;            // first channel of this chunk
+    const int cw = min(CLS_CHUNK, C - c0);            // channels in the chunk
+    const int nu = cw / 8, nsl = TPB / nu;
+    float* sw = sm;                                   // [ncls][cw]
+    float* sdb = sw + ncls * CLS_CHUNK;               // [ncls] (padded to 16)
+    float* slab = sdb + 16;                           // [nsl][4][cw]  (<= 8192 floats)
+    float* sdl = slab + TPB * 32;                     // [ncls][CLS_IG * nsl] dlogits of a group of CLS_IG iterations, pre-scaled
+    for (int i = threadIdx.x; i < ncls * cw; i += TPB) sw[i] = w[(i / cw) * C + c0 + (i % cw)];
+    for (int i = threadIdx.x; i < 16; i += TPB) sdb[i] = 0.f;
+    __syncthreads();
+    const float gscale = count ? (float)(1.0 / fmax(count[1], 1.0)) : 1.f;
+    const int u = threadIdx.x % nu, sl = threadIdx.x / nu;
+    const bool live = sl < nsl;
+    float dwa[NC][8], dba[NC];
+#pragma unroll
+    for (int n = 0; n < NC; ++n) {
+        dba[n] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dwa[n][j] = 0.f;
+    }
+    // the dlogits of CLS_IG iterations (= CLS_IG * nsl consecutive pixels) are staged once per group with coalesced loads: read
+    // straight from global they were 13 loads per pixel and thread, shared by the `nu` threads of a slice and repeated per chunk
+    const long mb = (long)blockIdx.x * nsl * iters;
+    const int gpx = CLS_IG * nsl;
+    for (int it0 = 0; it0 < iters; it0 += CLS_IG) {
+        if (it0) __syncthreads();
+        const long mg = mb + (long)it0 * nsl;
+        for (int i = threadIdx.x; i < ncls * gpx; i += TPB) {
+            const int n = i / gpx, px = i - n * gpx;
+            const long m = mg + px;
+            float g = 0.f;
+            if (m < M && px < (iters - it0) * nsl) {
+                const long b = m / HW, pix = m - b * HW;
+                g = dl[(b * ncls + n) * HW + pix] * gscale;
+            }
+            sdl[i] = g;
+        }
+        __syncthreads();
+        if (!live) continue;
+        const int itn = min(CLS_IG, iters - it0);
+        for (int it = 0; it < itn; ++it) {
+            const int px = it * nsl + sl;
+            const long m = mg + px;
+            if (m >= M) break;
+            const size_t idx = (size_t)m * C + c0 + u * 8;
+            float f[8], o[8], msk[8];
+            load8_split(f_hi, f_lo, idx, f);
+            if (drop_thresh) {
+                dropout_scale4(drop_seed, (uint32_t)idx, drop_thresh, drop_inv, msk);
+                dropout_scale4(drop_seed, (uint32_t)idx + 4u, drop_thresh, drop_inv, msk + 4);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) msk[j] = 1.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                f[j] *= msk[j];
+                o[j] = 0.f;
+            }
+#pragma unroll
+            for (int n = 0; n < NC; ++n) {
+                if (n < ncls) {
+                    const float g = sdl[n * gpx + px];
+                    const float4 w0 = *reinterpret_cast<const float4*>(sw + n * cw + u * 8);
+                    const float4 w1 = *reinterpret_cast<const float4*>(sw + n * cw + u * 8 + 4);
+                    const float wr[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+                    dba[n] += g;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        o[j] += g * wr[j];
+                        dwa[n][j] += g * f[j];
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] *= msk[j];
+            store8_split(df_hi, df_lo, idx, o);
+        }
+    }
+    if (live && blockIdx.y == 0 && u == 0) {
+#pragma unroll
+        for (int n = 0; n < NC; ++n)
+            if (n < ncls) atomicAdd(sdb + n, dba[n]);
+    }
+    __syncthreads();
+    // fold the dW partials of the pixel slices, four classes per pass
+#pragma unroll
+    for (int q = 0; q < NC / 4; ++q) {
+        if (4 * q >= ncls) break;
+        if (q) __syncthreads();
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float* dst = slab + ((size_t)sl * 4 + k) * cw + u * 8;
+                *reinterpret_cast<float4*>(dst) = make_float4(dwa[4 * q + k][0], dwa[4 * q + k][1], dwa[4 * q + k][2], dwa[4 * q + k][3]);
+                *reinterpret_cast<float4*>(dst + 4) = make_float4(dwa[4 * q + k][4], dwa[4 * q + k][5], dwa[4 * q + k][6], dwa[4 * q + k][7]);
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 4 * cw; i += TPB) {
+            const int k = i / cw, c = i - k * cw, n = 4 * q + k;
+            if (n < ncls) {
+                float t = 0.f;
+                for (int s2 = 0; s2 < nsl; ++s2) t += slab[((size_t)s2 * 4 + k) * cw + c];
+                atomicAdd(dw + (size_t)n * C + c0 + c, t);
+            }
+        }
+    }
+    __syncthreads();
+    if (blockIdx.y == 0)
+        for (int i = threadIdx.x; i < ncls; i += TPB) atomicAdd(db + i, sdb[i]);
 }
 
 // stats[0] += sum w_y*nll over valid pixels ; stats[1] += #valid.  dlogits (optional) is left UN-normalised:
@@ -528,8 +692,9 @@ int ig_classifier_fwd(const void* f_hi, const void* f_lo, const float* w, const 
     IG_REQUIRE(C % 8 == 0 && ncls >= 1 && ncls <= MAXC, "ig_classifier_fwd: need C %% 8 == 0 and 1 <= ncls <= %d (C=%d ncls=%d)", MAXC, C, ncls);
     long M = (long)B * HW;
     if (M == 0) return IG_OK;
-    size_t sm = ((size_t)ncls * C + ((ncls + 3) & ~3)) * sizeof(float) + (size_t)TPB * (C * 2 + 16) * (f_lo ? 2 : 1);
-    IG_REQUIRE(sm <= 160 * 1024, "ig_classifier_fwd: C=%d too wide for the staged kernel", C);
+    const int cmax = C / 8 < CLS_CHUNK / 8 ? C / 8 : CLS_CHUNK / 8;
+    size_t sm = ((size_t)ncls * C + ((ncls + 3) & ~3)) * sizeof(float) + (size_t)TPB * (cmax * 16 + 16) * (f_lo ? 2 : 1);
+    IG_REQUIRE(sm <= 160 * 1024, "ig_classifier_fwd: ncls x C = %d x %d weights do not fit the LDS", ncls, C);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)classifier_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -553,6 +718,33 @@ int ig_classifier_bwd(const float* dlogits, const void* f_hi, const void* f_lo, 
     const long nsl = TPB / (C / 8);
     const size_t slab_floats = (size_t)nsl * ncls * C;
     const int slab = slab_floats * sizeof(float) <= 32768;
+    static const int wide_env = getenv("IG_CLS_WIDE") ? atoi(getenv("IG_CLS_WIDE")) : 1;  // 0: LDS-atomic fallback (A/B runs)
+    if (!slab && ncls > 4 && C % 8 == 0 && wide_env) {  // wide head: channel-chunked workgroups, class-grouped dW fold
+        const int nslw = TPB / (CLS_CHUNK / 8);  // 42 slices of 6 units
+        long it = (M + (long)nslw * 1024 - 1) / ((long)nslw * 1024);
+        if (it < 8) it = 8;
+        const long ppbw = (long)nslw * it;
+        const dim3 gridw((unsigned)((M + ppbw - 1) / ppbw), (unsigned)((C + CLS_CHUNK - 1) / CLS_CHUNK));
+        // weights | db | slab (<= 256 threads x 4 classes x 8 channels) | dlogits group (ncls x CLS_IG x <= 128 pixel slices)
+        const int rem_units = (C % CLS_CHUNK) / 8;                                  // units of the last (narrower) chunk, 0 = none
+        const int nsl_max = TPB / (rem_units ? rem_units : CLS_CHUNK / 8);        // its pixel slices
+        const size_t smw = ((size_t)ncls * CLS_CHUNK + 16 + (size_t)TPB * 32 + (size_t)ncls * CLS_IG * nsl_max) * sizeof(float);
+        IG_REQUIRE(smw <= 160 * 1024, "ig_classifier_bwd: ncls x C = %d x %d does not fit the LDS", ncls, C);
+        static bool attrw = false;
+        if (!attrw) {
+            (void)hipFuncSetAttribute((const void*)classifier_bwd_wide_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)classifier_bwd_wide_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attrw = true;
+        }
+#define IG_CLS_BWDW(NC)                                                                                                         \
+    hipLaunchKernelGGL(classifier_bwd_wide_kernel<NC>, gridw, dim3(TPB), smw, (hipStream_t)stream, dlogits, (const bf16_t*)f_hi, \
+                       (const bf16_t*)f_lo, w, (bf16_t*)df_hi, (bf16_t*)df_lo, dw, db, count, M, HW, C, ncls, drop_seed,        \
+                       drop_seed_dev, thresh_of(drop_p), drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, (int)it)
+        if (ncls <= 8) IG_CLS_BWDW(8);
+        else IG_CLS_BWDW(16);
+#undef IG_CLS_BWDW
+        return ig_check_launch("ig_classifier_bwd");
+    }
     size_t sm = ((size_t)ncls * C + ((ncls + 3) & ~3) + (slab ? slab_floats : (size_t)ncls * C)) * sizeof(float);
     long iters = (M + nsl * 1024 - 1) / (nsl * 1024);  // ~1k workgroups: one round of dW/db atomics each
     if (iters < 8) iters = 8;
