@@ -1473,9 +1473,11 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep_in, int M, int N, int K
         const int dim = EP::kStagedAtomic ? M : N;
         long best = -1;
         int pick = 0;
-        // cost = padded extent / relative tile efficiency: the 48-wide tiles run at about half the MFMA rate of the 96 / 128 ones
-        // (measured 282 vs 550 TFLOP/s on the 144-channel weight gradient), so 144 = 2 x 96 (25 % padding) beats 3 x 48 (none)
-        static const int eff[4] = {100, 95, 80, 55};
+        // cost = padded extent / relative tile efficiency, from the rates the head stages reach (configs[2] bench): forward / data
+        // gradient 128-wide ~800, 96-wide (K-step 32) ~620, 48-wide ~450 TFLOP/s; weight gradient 128-row ~580, 96-row ~450,
+        // 48-row ~280.  So 576 channels take 5 x 128 (11 % padding) rather than 6 x 96, and 144 take 2 x 96 rather than 3 x 48.
+        static const int eff_n[4] = {100, 76, 60, 55}, eff_m[4] = {100, 80, 60, 50};
+        const int* eff = EP::kStagedAtomic ? eff_m : eff_n;
         static const int cost_env = getenv("IG_V1_TILE_COST") ? atoi(getenv("IG_V1_TILE_COST")) : 1;
         for (int c = 0; c < 4; ++c) {
             if (EP::kStagedAtomic && cand[c] == 64) continue;
