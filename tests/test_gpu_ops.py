@@ -365,7 +365,7 @@ def attn_ref(qkv, B, N, H):
 
 
 @pytest.mark.parametrize("split", SPLITS)
-@pytest.mark.parametrize("N", [197, 589, 16, 33])
+@pytest.mark.parametrize("N", [197, 589, 16, 33, 1, 224, 225])
 def test_attention_fwd_bwd(split, N):
     B, H = 2, 3
     qkv, qr = bt(rnd(B, N, 3 * H * 64, seed=23), split)
