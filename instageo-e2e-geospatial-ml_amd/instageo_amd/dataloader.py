@@ -351,6 +351,75 @@ def nodata_mask(chip, no_data_value: Optional[float], constant_multiplier: Optio
     return (a * (1.0 if constant_multiplier is None else constant_multiplier)) == no_data_value
 
 
+def get_raster_data(fname, is_label: bool = True, bands: Optional[List[int]] = None, no_data_value: Optional[int] = -9999,
+                    mask_cloud: bool = True, water_mask: bool = False) -> np.ndarray:
+    """All bands of a (Geo)TIFF as ``(count, H, W)`` (dataloader.py:672-704); ``bands`` selects image bands, label files are
+    returned whole.  The reference's multi-file dict form (``open_mf_tiff_dataset``, data-creation side) is not supported."""
+    from . import tiff
+
+    if isinstance(fname, dict):
+        raise NotImplementedError("multi-file tile dictionaries belong to the data-creation pipeline (SURVEY.md 2.1: out of scope)")
+    data = tiff.read(fname)[0]
+    if (not is_label) and bands:
+        data = data[bands, ...]
+    return data
+
+
+def process_data(im_fname: str, mask_fname: Optional[str] = None, no_data_value: Optional[int] = -9999, reduce_to_zero: bool = False,
+                 replace_label: Optional[Sequence[float]] = None, bands: Optional[List[int]] = None, constant_multiplier: float = 1.0,
+                 mask_cloud: bool = False) -> Tuple[np.ndarray, Optional[np.ndarray]]:
+    """Image (band selection, constant multiplier) and label (``replace_label``, ``reduce_to_zero``) arrays of one chip
+    (dataloader.py:707-750)."""
+    arr_x = get_raster_data(im_fname, is_label=False, bands=bands, no_data_value=no_data_value, mask_cloud=mask_cloud, water_mask=False)
+    arr_x = arr_x * constant_multiplier
+    arr_y = None
+    if mask_fname:
+        arr_y = process_label(get_raster_data(mask_fname), replace_label, reduce_to_zero)
+    return arr_x, arr_y
+
+
+def mask_label_with_chip(chips_path: str, labels_path: str, chip_no_data_value: int = 0, label_no_data_value: int = -1) -> bool:
+    """True when the label has NO usable pixel: every pixel is either the label NODATA value or lies where the chip (first band
+    of every time step) is NODATA (dataloader.py:753-783)."""
+    from . import tiff
+
+    chip = tiff.read(chips_path)[0]
+    steps = max(1, chip.shape[0] // 6)
+    has_data = np.where(chip[[6 * i for i in range(steps)]] == chip_no_data_value, 0, 1).all(0)
+    label = tiff.read(labels_path)[0][0]
+    return not bool(np.any((label != label_no_data_value) & (has_data == 1)))
+
+
+def get_valid_filepaths(fname: str, input_root: str, no_data_value: int = -9999, ignore_index: int = -1) -> List[Tuple[str, Optional[str]]]:
+    """(chip, label | None) path pairs of a CSV with an ``Input`` and optionally a ``Label`` column, paths relative to
+    ``input_root``; rows whose chip is missing / unreadable, or whose label has no valid pixel over chip data, are dropped
+    (dataloader.py:786-829)."""
+    import os
+
+    import pandas as pd
+
+    from . import tiff
+
+    data = pd.read_csv(fname)
+    label_present = "Label" in data.columns
+    out: List[Tuple[str, Optional[str]]] = []
+    for _, row in data.iterrows():
+        im = os.path.join(input_root, row["Input"])
+        mk = os.path.join(input_root, row["Label"]) if label_present else None
+        if not os.path.exists(im):
+            continue
+        try:
+            tiff.read_profile(im)
+            if mk is None:
+                out.append((im, None))
+            elif not mask_label_with_chip(im, mk, chip_no_data_value=no_data_value, label_no_data_value=ignore_index):
+                out.append((im, mk))
+        except Exception as exc:  # unreadable raster: the reference logs and skips
+            print(f"[instageo_amd] skipping {im}: {exc}")
+    print(f"Dropped a total of {len(data) - len(out)} rows")
+    return out
+
+
 class InstaGeoDataset(torch.utils.data.Dataset):
     """The reference's CSV-driven dataset (dataloader.py:832-906) on the TIFF codec of :mod:`instageo_amd.tiff`: ``filename`` is
     a CSV with an ``Input`` column (chip GeoTIFF, T*C bands) and optionally ``Label`` (segmentation map), paths relative to
@@ -360,53 +429,18 @@ class InstaGeoDataset(torch.utils.data.Dataset):
     def __init__(self, filename: str, input_root: str, preprocess_func, chip_no_data_value: Optional[float] = -9999,
                  label_no_data_value: Optional[float] = -1, replace_label=None, reduce_to_zero: bool = False,
                  constant_multiplier: float = 1.0, bands: Optional[List[int]] = None, include_filenames: bool = False):
-        import os
-
-        import pandas as pd
-
-        from . import tiff
-
-        self._tiff = tiff
         self.input_root, self.preprocess_func, self.bands = input_root, preprocess_func, bands
         self.no_data_value, self.replace_label, self.reduce_to_zero = chip_no_data_value, replace_label, reduce_to_zero
         self.constant_multiplier, self.include_filenames = constant_multiplier, include_filenames
-        data = pd.read_csv(filename)
-        label_present = "Label" in data.columns
-        self.file_paths: List[Tuple[str, Optional[str]]] = []
-        for _, row in data.iterrows():  # get_valid_filepaths (dataloader.py:786-829): keep rows whose files exist and whose label
-            im = os.path.join(input_root, row["Input"])  # has at least one valid pixel where the chip has data
-            mk = os.path.join(input_root, row["Label"]) if label_present else None
-            if not os.path.exists(im):
-                continue
-            if mk is not None:
-                if not os.path.exists(mk):
-                    continue
-                chip, _ = tiff.read(im)
-                steps = max(1, chip.shape[0] // 6)
-                has_data = np.where(chip[[6 * i for i in range(steps)]] == chip_no_data_value, 0, 1).all(0)
-                lab = tiff.read(mk)[0][0]
-                if not np.any((lab != label_no_data_value) & (has_data == 1)):
-                    continue
-            self.file_paths.append((im, mk))
+        self.file_paths = get_valid_filepaths(filename, input_root, chip_no_data_value, label_no_data_value)
 
     def __len__(self) -> int:
         return len(self.file_paths)
 
-    def _process_data(self, im_fname: str, mask_fname: Optional[str]):
-        """process_data (dataloader.py:707-750): band selection, constant multiplier, label replacement / shift."""
-        arr_x = self._tiff.read(im_fname)[0]
-        if self.bands:
-            arr_x = arr_x[self.bands, ...]
-        arr_x = arr_x * self.constant_multiplier
-        arr_y = None
-        if mask_fname:
-            arr_y = self._tiff.read(mask_fname)[0]
-            arr_y = process_label(arr_y, self.replace_label, self.reduce_to_zero)
-        return arr_x, arr_y
-
     def __getitem__(self, i: int):
         im_fname, mask_fname = self.file_paths[i]
-        arr_x, arr_y = self._process_data(im_fname, mask_fname)
+        arr_x, arr_y = process_data(im_fname, mask_fname, no_data_value=self.no_data_value, replace_label=self.replace_label,
+                                    reduce_to_zero=self.reduce_to_zero, bands=self.bands, constant_multiplier=self.constant_multiplier)
         if self.include_filenames:
             return self.preprocess_func(arr_x, arr_y), im_fname, arr_x == self.no_data_value
         return self.preprocess_func(arr_x, arr_y)

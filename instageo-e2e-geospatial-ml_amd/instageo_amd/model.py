@@ -831,25 +831,21 @@ class PrithviSeg(nn.Module):
         return out
 
 
-def load_prithvi_checkpoint(model: PrithviSeg, state_dict: Dict[str, torch.Tensor]) -> None:
-    """Load a Prithvi MAE/ViT checkpoint into ``model.prithvi_encoder`` following
-    ``checkpoint_filter_fn_vit`` (instageo/model/utils.py:271-315): drop decoder/mask-token keys, strip the
-    ``encoder.`` prefix, keep the model's own fixed ``pos_embed``, truncate blocks to ``depth``."""
-    clean = {}
-    enc = {k[len("prithvi_encoder.") :]: v for k, v in model.state_dict().items() if k.startswith("prithvi_encoder.")}
-    for k, v in state_dict.items():
-        k = k.replace("_timm_module.", "")
-        if "decoder" in k or "_dec" in k or k == "mask_token":
-            continue
-        if "temporal_embed" in k or "location_embed" in k:
-            continue
-        if k.startswith("encoder."):
-            k = k[len("encoder.") :]
-        if "pos_embed" in k:
-            v = enc["pos_embed"]
-        if k.startswith("blocks.") and int(k.split(".")[1]) >= model.cfg.depth:
-            continue
-        clean[k] = v
+def load_prithvi_checkpoint(model: PrithviSeg, state_dict: Dict[str, torch.Tensor], pretrained_bands: Optional[List[int]] = None,
+                            model_bands: Optional[List[int]] = None) -> None:
+    """Load a Prithvi MAE/ViT checkpoint into ``model.prithvi_encoder`` the way ``create_prithvi`` does (model.py:221-251):
+    ``checkpoint_filter_fn_vit`` (instageo/model/utils.py:271-315, mirrored in :mod:`instageo_amd.utils`) drops decoder /
+    mask-token keys, strips the ``encoder.`` prefix, keeps the model's own fixed ``pos_embed`` and selects the patch-embedding
+    bands; blocks beyond ``depth`` are dropped (the reference builds the truncated model and loads non-strictly)."""
+    from .utils import checkpoint_filter_fn_vit, encoder_view, get_state_dict
+
+    view = encoder_view(model)
+    enc = view.state_dict()
+    nb = model.cfg.in_chans
+    pretrained_bands = list(range(6)) if pretrained_bands is None else list(pretrained_bands)
+    model_bands = (pretrained_bands * max(1, nb // len(pretrained_bands)))[:nb] if model_bands is None else list(model_bands)
+    clean = checkpoint_filter_fn_vit(dict(get_state_dict(state_dict)), view, pretrained_bands, model_bands)
+    clean = {k: v for k, v in clean.items() if not (k.startswith("blocks.") and int(k.split(".")[1]) >= model.cfg.depth)}
     missing = set(enc) - set(clean)
     unexpected = set(clean) - set(enc)
     if missing or unexpected:

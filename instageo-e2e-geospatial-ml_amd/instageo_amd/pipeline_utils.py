@@ -7,13 +7,42 @@ reduces every batch with two HIP kernels (``ig_chip_stats``: fp64 two-pass mean/
 """
 from __future__ import annotations
 
-from typing import Dict, Iterable, List, Optional, Tuple
+from typing import Any, Callable, Dict, Iterable, List, Optional, Tuple
 
 import torch
 
 from . import ops
+from .dataloader import eval_collate_fn, infer_collate_fn  # noqa: F401  (the reference keeps them here, pipeline_utils.py:77-104)
 
 MAX_CLASSES = 255  # labels are counted in [-1, MAX_CLASSES)
+
+
+def check_required_flags(required_flags: List[str], config: Any) -> None:
+    """Raise when a required option still has its placeholder value "None" (pipeline_utils.py:43-54); ``config`` may be a dict
+    (this package's run.py) or an attribute container (the reference's DictConfig)."""
+    for flag_name in required_flags:
+        value = config[flag_name] if isinstance(config, dict) else getattr(config, flag_name)
+        if value == "None":
+            raise RuntimeError(f"Flag --{flag_name} is required.")
+
+
+def get_device() -> str:
+    """"gpu" when a HIP device is visible, else "cpu" (pipeline_utils.py:57-74; there is no TPU / MPS path on this platform).
+    The HIP kernels need "gpu": the product never falls back to a CPU implementation."""
+    return "gpu" if torch.cuda.is_available() else "cpu"
+
+
+def create_dataloader(dataset, batch_size: int, shuffle: bool = False, num_workers: Optional[int] = 1,
+                      collate_fn: Optional[Callable] = None, pin_memory: bool = True) -> torch.utils.data.DataLoader:
+    """``torch.utils.data.DataLoader`` with the reference's defaults (pipeline_utils.py:107-140).  Datasets of this package that
+    hold their chips on the device (``ArrayChipDataset``, ``SyntheticChipDataset``) must stay in the main process
+    (``num_workers=0``, no pinning): device tensors cannot cross a worker boundary."""
+    num_workers = num_workers if num_workers is not None else 1
+    on_device = bool(getattr(dataset, "device", None)) and str(getattr(dataset, "device")).startswith("cuda")
+    if on_device:
+        num_workers, pin_memory = 0, False
+    return torch.utils.data.DataLoader(dataset, batch_size=batch_size, shuffle=shuffle, num_workers=num_workers, collate_fn=collate_fn,
+                                       pin_memory=pin_memory)
 
 
 def compute_class_weights(counts: Dict[int, int]) -> List[float]:
