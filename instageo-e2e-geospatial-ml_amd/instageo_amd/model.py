@@ -126,6 +126,34 @@ def get_3d_sincos_pos_embed(embed_dim: int, grid_size: Tuple[int, int, int], cls
     return pe
 
 
+get_1d_sincos_pos_embed_from_grid = _sincos_1d  # the reference's name (pritvhi.py:67-88)
+
+
+def get_1d_sincos_embed_from_grid_torch(embed_dim: int, pos: torch.Tensor) -> torch.Tensor:
+    """Torch twin of :func:`get_1d_sincos_pos_embed_from_grid` (pritvhi.py:130-146): (M,) positions -> (M, D), sin | cos."""
+    assert embed_dim % 2 == 0
+    omega = 1.0 / 10000 ** (torch.arange(embed_dim // 2, dtype=torch.float32, device=pos.device) / (embed_dim / 2.0))
+    out = torch.einsum("m,d->md", pos.reshape(-1).float(), omega)
+    return torch.cat([torch.sin(out), torch.cos(out)], dim=1)
+
+
+def interpolate_pos_encoding(pos_embed: torch.Tensor, grid_size: Tuple[int, int, int], patch_size, shape: Tuple[int, int, int],
+                             embed_dim: int) -> torch.Tensor:
+    """Position table for an input of ``shape`` = (frames, height, width) given the table of token grid ``grid_size``
+    (pritvhi.py:149-203): unchanged when the token grids agree; a changed frame count regenerates the sin-cos table for the new
+    number of frames; the spatial grid is resampled per frame, bicubic with ``align_corners=True``; the cls row is kept."""
+    tg, hg, wg = shape[0] // patch_size[0], shape[1] // patch_size[1], shape[2] // patch_size[2]
+    if (tg, hg, wg) == tuple(grid_size):
+        return pos_embed
+    if tg != grid_size[0]:
+        grid_size = (tg, grid_size[1], grid_size[2])
+        pos_embed = torch.from_numpy(get_3d_sincos_pos_embed(pos_embed.shape[-1], grid_size, cls_token=True)).float().unsqueeze(0)
+    cls_row, body = pos_embed[:, :1], pos_embed[:, 1:]
+    body = body.reshape(*grid_size, embed_dim).permute(0, 3, 1, 2)
+    body = torch.nn.functional.interpolate(body, size=(hg, wg), mode="bicubic", align_corners=True)
+    return torch.cat((cls_row, body.permute(0, 2, 3, 1).reshape(1, -1, embed_dim)), dim=1)
+
+
 # --------------------------------------------------------------------------------------------------
 # flat parameter store
 # --------------------------------------------------------------------------------------------------
@@ -327,12 +355,9 @@ class SegEngine:
         hit = self._pos_cache.get(cfg.img_size)
         if hit is not None and hit[0] == key:
             return hit[1]
-        g0, g1, T, D = self.cfg.grid, cfg.grid, cfg.num_frames, cfg.embed_dim
-        pe = base.detach().float().cpu()
-        cls_pe, patch_pe = pe[:, :1], pe[:, 1:]
-        patch_pe = patch_pe.reshape(T, g0, g0, D).permute(0, 3, 1, 2)
-        patch_pe = torch.nn.functional.interpolate(patch_pe, size=(g1, g1), mode="bicubic", align_corners=True)
-        out = torch.cat((cls_pe, patch_pe.permute(0, 2, 3, 1).reshape(1, -1, D)), dim=1).contiguous().to(base.device)
+        g0, T, D, pch = self.cfg.grid, cfg.num_frames, cfg.embed_dim, cfg.patch
+        out = interpolate_pos_encoding(base.detach().float().cpu(), (T, g0, g0), (1, pch, pch), (T, cfg.img_size, cfg.img_size), D)
+        out = out.contiguous().to(base.device)
         self._pos_cache[cfg.img_size] = (key, out)
         return out
 

@@ -167,3 +167,31 @@ def test_check_required_flags_and_device():
         P.check_required_flags(["valid_filepath"], Cfg())
     assert P.get_device() in ("gpu", "cpu")
     assert P.compute_class_weights({0: 10, 1: 30}) == [2.0, 2.0 / 3.0]
+
+
+# ---- model.py: position tables (tests/model_tests/test_model.py scenarios) ------------------------------------------------
+def test_sincos_tables_and_interpolation():
+    from instageo_amd.model import (get_1d_sincos_embed_from_grid_torch, get_1d_sincos_pos_embed_from_grid, get_3d_sincos_pos_embed,
+                                    interpolate_pos_encoding)
+
+    e = get_1d_sincos_pos_embed_from_grid(8, np.array([0, 1, 2, 3]))
+    assert e.shape == (4, 8) and np.allclose(e[0], [0, 0, 0, 0, 1, 1, 1, 1])
+    assert get_1d_sincos_pos_embed_from_grid(8, np.array([0.5, 1.5])).shape == (2, 8)
+    et = get_1d_sincos_embed_from_grid_torch(8, torch.tensor([0.0, 1.0, 2.0, 3.0]))
+    assert et.shape == (4, 8) and np.allclose(et.numpy(), e, atol=1e-6)
+    grid = (2, 3, 4)
+    pe = get_3d_sincos_pos_embed(32, grid, cls_token=False)
+    assert pe.shape == (24, 32)
+    pc = get_3d_sincos_pos_embed(32, grid, cls_token=True)
+    assert pc.shape == (25, 32) and np.allclose(pc[0], 0) and np.allclose(pc[1:], pe)
+    table = torch.randn(1, 25, 32)
+    assert interpolate_pos_encoding(table, grid, (1, 1, 1), (2, 3, 4), 32) is table  # same token grid: untouched
+    up = interpolate_pos_encoding(table, grid, (1, 1, 1), (2, 6, 8), 32)
+    assert up.shape == (1, 1 + 2 * 6 * 8, 32) and torch.equal(up[:, :1], table[:, :1])
+    # align_corners=True: the corner tokens of every frame are kept exactly
+    body, ub = table[0, 1:].reshape(2, 3, 4, 32), up[0, 1:].reshape(2, 6, 8, 32)
+    assert torch.allclose(ub[:, 0, 0], body[:, 0, 0], atol=1e-6) and torch.allclose(ub[:, -1, -1], body[:, -1, -1], atol=1e-6)
+    # another frame count: the table is regenerated for the new number of frames before the spatial resampling
+    more = interpolate_pos_encoding(table, grid, (1, 1, 1), (4, 3, 4), 32)
+    assert more.shape == (1, 49, 32)
+    assert np.allclose(more[0].numpy(), get_3d_sincos_pos_embed(32, (4, 3, 4), cls_token=True), atol=1e-6)
