@@ -28,6 +28,30 @@ class LogScaler:
         return torch.expm1(x)
 
 
+class _RegLoss(torch.autograd.Function):
+    """mean over the valid pixels of (pred - label')^2 [+ (pred - teacher')^2 with a teacher] through the fused kernels; the
+    gradient w.r.t. the prediction is what ``ig_mse_loss`` [+ ``ig_kd_mse_loss``] wrote, divided by the valid count."""
+
+    @staticmethod
+    def forward(ctx, outputs, labels, teacher, ignore_index, use_log_scale, metrics):
+        stats = torch.zeros(2, dtype=torch.float64, device=outputs.device)
+        kd = torch.zeros(1, dtype=torch.float64, device=outputs.device)
+        dl = torch.empty_like(outputs)
+        lab = labels.to(torch.float32).contiguous()
+        ops.mse_loss(outputs.contiguous(), lab, float(ignore_index), use_log_scale, stats, dl, metrics.device_sums(outputs.device),
+                     metrics.ee_bias, metrics.ee_coef, metrics.include_ee)
+        if teacher is not None:
+            ops.kd_mse_loss(outputs.contiguous(), teacher.contiguous(), lab, float(ignore_index), use_log_scale, kd, dl)
+        ctx.save_for_backward(dl, stats)
+        n = stats[1]
+        return ((stats[0] + kd[0]) / n).float(), (stats[0] / n).float().detach(), (kd[0] / n).float().detach()
+
+    @staticmethod
+    def backward(ctx, g, _g_mse, _g_kd):
+        dl, stats = ctx.saved_tensors
+        return dl * (g / stats[1].float()), None, None, None, None, None
+
+
 class PrithviRegressionModule(PrithviSegmentationModule):
     """Same constructor surface as the reference (regression.py:67-131); ``num_classes`` is fixed to 1."""
 
@@ -60,12 +84,21 @@ class PrithviRegressionModule(PrithviSegmentationModule):
         ops.mse_loss(logits, labels.to(torch.float32).contiguous(), float(self.ignore_index), self.use_log_scale, stats, dlogits,
                      metrics.device_sums(logits.device), metrics.ee_bias, metrics.ee_coef, metrics.include_ee)
 
+    def _teacher_outputs(self, inputs: torch.Tensor) -> Optional[torch.Tensor]:
+        return None  # the distillation subclass runs its frozen teacher here
+
     def _shared_step(self, batch: Any, step_type: str) -> torch.Tensor:
-        if step_type == "train":
-            raise NotImplementedError("the regression module trains through fused_train_step (no autograd loss function)")
+        """Compatible (Lightning-style) path of regression.py:141-191: forward through the autograd bridge, masked MSE and the
+        streaming metrics from the fused kernel; ``training_step(...).backward()`` then works like the reference's."""
         inputs, labels = batch
-        stats = self.fused_eval_step(inputs, labels, step_type)
-        return (stats[0] / stats[1]).float()
+        outputs = self.forward(inputs)
+        metrics = getattr(self, f"{step_type}_metrics")
+        loss, mse, kd = _RegLoss.apply(outputs, labels, self._teacher_outputs(inputs), self.ignore_index, self.use_log_scale, metrics)
+        if self._teacher_outputs.__func__ is not PrithviRegressionModule._teacher_outputs:
+            self.log(f"{step_type}_mse_loss", mse.item())
+            self.log(f"{step_type}_distill_loss", kd.item())
+        self._accumulate_loss(step_type, loss.detach())
+        return loss
 
     def _shared_epoch_end(self, step_type: str) -> None:
         metrics = getattr(self, f"{step_type}_metrics")
@@ -125,6 +158,10 @@ class PrithviDistillationRegressionModule(PrithviRegressionModule):
             shared = {k: v for k, v in t_sd.items() if k in s_sd and v.shape == s_sd[k].shape}
             self.net.load_state_dict({**s_sd, **shared}, strict=True)
         self._kd = torch.zeros(1, dtype=torch.float64, device=self.net.store.flat.device)
+
+    def _teacher_outputs(self, inputs: torch.Tensor) -> Optional[torch.Tensor]:
+        with torch.no_grad():
+            return self.teacher.net.engine.forward(inputs, training=False, save=False)
 
     def _fused_loss(self, logits, labels, stats, dlogits, step_type: str) -> None:
         super()._fused_loss(logits, labels, stats, dlogits, step_type)  # label term, its gradient, the regression metrics

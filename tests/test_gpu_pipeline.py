@@ -573,3 +573,47 @@ def test_empty_and_degenerate_inputs():
     ops.mse_loss(torch.randn(B, 1, H, W, device=dev), torch.full((B, H, W), -1.0, device=dev), -1.0, False, st2)
     assert st2.tolist() == [0.0, 0.0]
     assert DL.window_origins(200, 224, 224) == [] and O.window_origins(200, 224, 224) == []
+
+
+def test_regression_lightning_style_steps():
+    """The compatible path the reference's tests drive (tests/model_tests/test_run.py: test_reg_training_step, _validation_step,
+    _test_step, _predict_step, configure_optimizers): ``training_step`` returns a scalar that back-propagates through the autograd
+    bridge, and its gradients equal the fused step's."""
+    from instageo_amd.regression import PrithviRegressionModule
+
+    def make():
+        m = PrithviRegressionModule(freeze_backbone=False, load_pretrained_weights=False, model_name="prithvi_eo_tiny", ignore_index=-100,
+                                    precision="bf16x3", device=DEV)
+        m.net.load_state_dict(O.make_state_dict(O.make_config("prithvi_eo_tiny", 1, 1), seed=5))
+        m.net.cfg.drop_p = 0.0
+        return m
+
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 6, 1, 224, 224, generator=g).to(DEV)
+    y = (torch.rand(2, 224, 224, generator=g) * 2).to(DEV)
+    y[0, :10] = -100.0
+    a, b = make(), make()
+    a.net.train()
+    loss = a.training_step((x, y), 0)
+    assert loss.dim() == 0 and loss.requires_grad and torch.isfinite(loss)
+    loss.backward()
+    got = {n: p.grad.clone() for n, p in a.net.named_parameters() if p.grad is not None}
+    assert len(got) > 10
+    b.net.train()
+    st = b.fused_train_step(x, y)  # same forward/backward in the fused form (then an AdamW step, which does not touch .grad buffers)
+    assert abs((st[0] / st[1]).item() - loss.item()) < 1e-5 * max(1.0, loss.item())
+    gb = b.net.store.grad
+    for name in ("segmentation_head.5.weight", "prithvi_encoder.blocks.0.attn.qkv.weight", "prithvi_encoder.patch_embed.proj.weight"):
+        ref = b.net.store.entries[name].api_view(gb)
+        assert torch.allclose(got[name], ref, rtol=2e-3, atol=1e-6 + 2e-3 * float(ref.abs().max())), name
+    a.net.eval()
+    with torch.no_grad():
+        v = a.validation_step((x, y), 0)
+        t = a.test_step((x, y), 0)
+    assert torch.isfinite(v) and torch.isfinite(t)
+    a.on_validation_epoch_end()
+    a.on_test_epoch_end()
+    assert {"val_RMSE", "test_RMSE", "val_loss", "test_loss"} <= set(a.logged)
+    assert a.predict_step(x).shape == (2, 224, 224)
+    opt = a.configure_optimizers()
+    assert opt is not None
