@@ -332,17 +332,35 @@ __global__ __launch_bounds__(NTHR2 * DUALK, (BKT == 32 ? 4 : 2)) void gemm2_kern
     // id % 8, tools/xcc_probe.hip); XCD x owns the contiguous tile range [tlo, tlo+tcnt) and its workgroups walk it with
     // stride nbx, so the CUs of one XCD always work on neighbouring tiles (shared A row panel / B panels).  With
     // gridDim.x == ntiles this degenerates to one tile per workgroup.
-    const int nb = gridDim.x, xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-    const int nbx = (nb >> 3) + (xcd < (nb & 7) ? 1 : 0);
+    const int nb = gridDim.x, xcd = blockIdx.x & 7;
+    int jx = blockIdx.x >> 3;
+    int nbx = (nb >> 3) + (xcd < (nb & 7) ? 1 : 0);
     const int qT = ntiles >> 3, rT = ntiles & 7;
-    const int tlo = xcd * qT + min(xcd, rT), tcnt = qT + (xcd < rT ? 1 : 0);
+    int tlo = xcd * qT + min(xcd, rT), tcnt = qT + (xcd < rT ? 1 : 0);
+    int ysplit = blockIdx.y;
+    if constexpr (EP::kStagedAtomic) {
+        // Split-K weight gradients, one (split, tile) pair per workgroup on a 1-D grid: the pairs are ordered split-major and every
+        // XCD takes a contiguous run of them, so an XCD works on ONE (at most two) token ranges and a contiguous tile range
+        // inside it.  Its ~27 concurrent workgroups then stream the SAME rows of dy and x (L2 hits), and each operand slab of a
+        // token range is fetched by the one or two XCDs that own it instead of by all eight (dealing the tiles of every split over
+        // all XCDs made every XCD read the whole of x: 412 MB per launch against 160 MB of algorithmic bytes).
+        if (ep.pairs > 0) {
+            const int P = ntiles * ep.pairs, qP = P >> 3, rP = P & 7;
+            const int plo = xcd * qP + min(xcd, rP), pcnt = qP + (xcd < rP ? 1 : 0);
+            if (jx >= pcnt) return;
+            const int pr = plo + jx;
+            ysplit = pr / ntiles;
+            tlo = pr - ysplit * ntiles, tcnt = 1, jx = 0, nbx = 1;
+            ep.split = ysplit;
+        }
+    }
     const int my_tiles = tcnt > jx ? (tcnt - jx + nbx - 1) / nbx : 0;
     al.init(blockIdx.z);
     bl.init(blockIdx.z);
     ep.init(blockIdx.z);
     if (al.kdim() >= 0) K = al.kdim();
     const int nk_all = (K + BKT - 1) / BKT;
-    int kt0 = blockIdx.y * kchunk;
+    int kt0 = ysplit * kchunk;
     int nk = min(kchunk, nk_all - kt0);
     if (nk <= 0 || my_tiles <= 0) return;
     int G_loop = 0;  // DUALK == 2: iterations (barriers) both wave groups execute
@@ -1298,9 +1316,13 @@ struct EpAtomic {
     // row-contiguous stores) and splitk_reduce_kernel adds the slabs to `out` in split order afterwards -- no float atomics
     float* partial;
     long slab;
+    // gemm2, one tile per workgroup: `pairs` = number of K splits when the launch is ONE-dimensional and the (split, tile) pairs
+    // are dealt to the XCDs in split-major order (see gemm2_kernel); `split` = this workgroup's split (set by the kernel)
+    int pairs = 0;
+    int split = -1;
     __device__ void init(int z) { zoff = (long)z * zstride; }
     __device__ void add(int m, int n, float v) const {
-        if (partial) partial[(size_t)blockIdx.y * slab + (size_t)m * ldo + n] = v;
+        if (partial) partial[(size_t)(split >= 0 ? split : (int)blockIdx.y) * slab + (size_t)m * ldo + n] = v;
         else atomicAdd(out + (size_t)m * ldo + zoff + n, v);
     }
     __device__ void store(int m, int n, f32x4 a) const {
@@ -1543,6 +1565,11 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep_in, int M, int N, int K
                     }
                     ig_note_kernel("gemm2_kernel<%s,%s,%s,%s,%s,1,32,2>", AL::kName, BL::kName, EP::kName, A_TR ? "true" : "false", B_TR ? "true" : "false");
                     if (prep_partial((int)grid.y) != IG_OK) return IG_ERR_HIP;
+                    static const int pairmap = getenv("IG_WGRAD_PAIRMAP") ? atoi(getenv("IG_WGRAD_PAIRMAP")) : 1;
+                    if (pairmap) {  // 1-D grid, (split, tile) pairs dealt split-major to the XCDs (see gemm2_kernel)
+                        ep.pairs = (int)grid.y;
+                        grid.x = grid.x * grid.y, grid.y = 1;
+                    }
                     hipLaunchKernelGGL(kern, grid, dim3(2 * NTHR2), 2 * G2<32>::SMEM, st, al, bl, ep, M, N, K, tn, ntiles, kchunk, zp);
                     finish_partial();
                     return ig_check_launch(what);
