@@ -93,18 +93,29 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
     // XCD-aware tile order: hardware deals consecutive workgroups round-robin over the 8 XCDs (private L2s);
     // remap so that each XCD owns a CONTIGUOUS run of tiles (neighbours share the A row panel / B panels).
     int bid = blockIdx.x;
+    int ysplit = blockIdx.y;
     {
         const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    if constexpr (EP::kStagedAtomic) {
+        // split-K weight gradients on a 1-D grid: `bid` now enumerates the (split, tile) pairs XCD-contiguously in split-major
+        // order, so one XCD works inside one (at most two) K ranges -- its resident workgroups stream the same operand rows --
+        // instead of every XCD touching every range (see gemm2_kernel)
+        if (ep.pairs > 0) {
+            ysplit = bid / ep.ntiles;
+            bid -= ysplit * ep.ntiles;
+            ep.split = ysplit;
+        }
     }
     const int bm = bid / tiles_n, bn = bid - bm * tiles_n;
     al.init(blockIdx.z);
     bl.init(blockIdx.z);
     ep.init(blockIdx.z);
     if (al.kdim() >= 0) K = al.kdim();
-    // split-K (wgrad): blockIdx.y owns k-tiles [kt0, kt0+nk) of every segment
+    // split-K (wgrad): split ysplit owns k-tiles [kt0, kt0+nk) of every segment
     const int nk_all = (K + BKT - 1) / BKT;
-    const int kt0 = blockIdx.y * kchunk;
+    const int kt0 = ysplit * kchunk;
     const int nk = min(kchunk, nk_all - kt0);
     if (nk <= 0) return;
     const int total = nk * NSEG;
@@ -1320,6 +1331,7 @@ struct EpAtomic {
     // are dealt to the XCDs in split-major order (see gemm2_kernel); `split` = this workgroup's split (set by the kernel)
     int pairs = 0;
     int split = -1;
+    int ntiles = 0;  // v1 engine: output tiles of the launch (the kernel is not told otherwise)
     __device__ void init(int z) { zoff = (long)z * zstride; }
     __device__ void add(int m, int n, float v) const {
         if (partial) partial[(size_t)(split >= 0 ? split : (int)blockIdx.y) * slab + (size_t)m * ldo + n] = v;
@@ -1576,6 +1588,13 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep_in, int M, int N, int K
                 }
             }
             if (prep_partial((int)grid.y) != IG_OK) return IG_ERR_HIP;
+            {
+                static const int pairmap2 = getenv("IG_WGRAD_PAIRMAP") ? atoi(getenv("IG_WGRAD_PAIRMAP")) : 1;
+                if (pairmap2 && grid.y > 1) {
+                    ep.pairs = (int)grid.y;
+                    grid.x = grid.x * grid.y, grid.y = 1;
+                }
+            }
             if (split) IG_LAUNCH_V2(3, 32) else IG_LAUNCH_V2(1, 32)
             finish_partial();
         } else {
@@ -1607,6 +1626,11 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep_in, int M, int N, int K
 #define IG_LAUNCH_V1(NSEG_, MT_, NT_, WM_) IG_LAUNCH_V1K(NSEG_, MT_, NT_, WM_, 64)
     if constexpr (EP::kStagedAtomic) {
         if (prep_partial((int)grid.y) != IG_OK) return IG_ERR_HIP;
+        static const int pairmap1 = getenv("IG_WGRAD_PAIRMAP") ? atoi(getenv("IG_WGRAD_PAIRMAP")) : 1;
+        if (pairmap1 && grid.y > 1) {  // 1-D grid of (split, tile) pairs, split-major per XCD (see gemm_kernel)
+            ep.pairs = (int)grid.y, ep.ntiles = (int)grid.x;
+            grid.x = grid.x * grid.y, grid.y = 1;
+        }
         if (mt == 1) {  // 48 x 128
             if (split) IG_LAUNCH_V1(3, 3, 2, 1) else IG_LAUNCH_V1(1, 3, 2, 1)
         } else if (mt == 3) {
