@@ -1360,17 +1360,24 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __rest
         out[i] = o;
     }
 }
-// workspace of the split-K partial tiles (grown on demand, never shrunk; all launches are ordered on the caller's stream)
-inline float* splitk_workspace(size_t bytes) {
-    static void* ws = nullptr;
-    static size_t cap = 0;
-    if (bytes > cap) {
-        if (ws) (void)hipFree(ws);
-        ws = nullptr, cap = 0;
-        if (hipMalloc(&ws, bytes) != hipSuccess) return nullptr;
-        cap = bytes;
+// workspace of the split-K partial tiles, per device: grown on demand and never freed -- a superseded buffer stays allocated,
+// because a captured hipGraph (make_graphed_train_step) may have baked its address into kernel nodes that are replayed after an
+// eager launch with more splits has grown the workspace.  All launches are ordered on the caller's stream.  While a
+// stream capture is active nothing may be allocated: the caller then falls back to atomics unless the workspace already fits.
+inline float* splitk_workspace(size_t bytes, hipStream_t st) {
+    constexpr int kMaxDev = 16;
+    static void* ws[kMaxDev] = {};
+    static size_t cap[kMaxDev] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
+    if (bytes > cap[dev]) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+        ws[dev] = p, cap[dev] = bytes;  // the previous buffer is deliberately leaked (bounded: sizes only grow)
     }
-    return (float*)ws;
+    return (float*)ws[dev];
 }
 inline bool splitk_partial_enabled() {
     static const int v = getenv("IG_WGRAD_PARTIAL") ? atoi(getenv("IG_WGRAD_PARTIAL")) : 1;
@@ -1424,13 +1431,11 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep_in, int M, int N, int K
         if constexpr (EP::kStagedAtomic) {
             partial_ks = 0;
             if (ks > 1 && Z == 1 && splitk_partial_enabled() && ((long)M * ep.ldo) % 4 == 0 && (((uintptr_t)ep.out) & 15) == 0) {
-                float* ws = splitk_workspace((size_t)ks * M * ep.ldo * sizeof(float));
-                if (!ws) {
-                    ig_set_error("%s: could not allocate the split-K workspace", what);
-                    return IG_ERR_HIP;
+                float* ws = splitk_workspace((size_t)ks * M * ep.ldo * sizeof(float), st);
+                if (ws) {  // (no workspace -- allocation failed or a capture is active: the atomic form, still correct)
+                    ep.partial = ws, ep.slab = (long)M * ep.ldo;
+                    partial_ks = ks;
                 }
-                ep.partial = ws, ep.slab = (long)M * ep.ldo;
-                partial_ks = ks;
             }
         }
         return IG_OK;
@@ -1788,6 +1793,10 @@ int ig_linear_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, cons
     IG_REQUIRE(dy_hi && x_hi && dw, "ig_linear_wgrad: null pointer");
     IG_REQUIRE(N % 8 == 0 && K % 8 == 0, "ig_linear_wgrad: N and K must be multiples of 8");
     IG_SPLIT_CONSISTENT(dy_lo, x_lo);
+    if (!gemm_env()) {  // 8-phase engine with transposed fragment reads (gemm8w.hip) for the shapes it covers
+        const int rc = ig_wgrad8_group(1, &dy_hi, &dy_lo, &x_hi, &x_lo, &dw, &N, &K, M, stream);
+        if (rc != IG_ERR_UNSUPPORTED) return rc;
+    }
     EpAtomic ep{dw, (long)K, 0, 0, nullptr, 0};
     // K-steps of 32 per workgroup if the 256 x 128 engine ran this problem (its split-K rule, see launch_gemm)
     const int nk32 = ig_cdiv(M, 32), tiles2 = ig_cdiv(N, 256) * ig_cdiv(K, 128);
@@ -1805,6 +1814,24 @@ int ig_linear_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, cons
         gemm_env() ? gemm_env()
                    : (nk32 >= 64 ? (((long)N * K <= (1L << 20) && M < 6000) ? 1 : 2)
                                  : (((long)N * K <= (1L << 20) || v2_steps < 50) ? 1 : 2)));
+}
+
+// n weight gradients that share the token count M in ONE launch: dw[g][N[g]][K[g]] += dy[g][M][N[g]]^T @ x[g][M][K[g]].  The pointer
+// and size arrays are HOST arrays of n entries (dy_lo / x_lo: NULL or arrays whose entries are all NULL or all set).
+int ig_linear_wgrad_group(int n, const void* const* dy_hi, const void* const* dy_lo, const void* const* x_hi, const void* const* x_lo,
+                          float* const* dw, const int* N, const int* K, int M, void* stream) {
+    IG_REQUIRE(n > 0 && n <= 16 && dy_hi && x_hi && dw && N && K, "ig_linear_wgrad_group: 1..16 GEMMs and non-null arrays");
+    for (int g = 0; g < n; ++g) IG_REQUIRE(dy_hi[g] && x_hi[g] && dw[g], "ig_linear_wgrad_group: null pointer in GEMM %d", g);
+    if (M <= 0) return IG_OK;
+    if (!gemm_env()) {
+        const int rc = ig_wgrad8_group(n, dy_hi, dy_lo, x_hi, x_lo, dw, N, K, M, stream);
+        if (rc != IG_ERR_UNSUPPORTED) return rc;
+    }
+    for (int g = 0; g < n; ++g) {
+        const int rc = ig_linear_wgrad(dy_hi[g], dy_lo ? dy_lo[g] : nullptr, x_hi[g], x_lo ? x_lo[g] : nullptr, dw[g], M, N[g], K[g], stream);
+        if (rc != IG_OK) return rc;
+    }
+    return IG_OK;
 }
 
 // Patch embedding (pritvhi.py:243-268,513-517): x[b][1+tp][:] = patches[b*TP+tp] @ w^T + bias + pos[1+tp]

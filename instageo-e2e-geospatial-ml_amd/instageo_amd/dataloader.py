@@ -379,21 +379,25 @@ def process_data(im_fname: str, mask_fname: Optional[str] = None, no_data_value:
 
 
 def mask_label_with_chip(chips_path: str, labels_path: str, chip_no_data_value: int = 0, label_no_data_value: int = -1) -> bool:
-    """True when the label has NO usable pixel: every pixel is either the label NODATA value or lies where the chip (first band
-    of every time step) is NODATA (dataloader.py:753-783)."""
+    """True when the label has NO usable pixel: every pixel is NaN, the label NODATA value, or lies where the chip (first band
+    of every time step) is NODATA (dataloader.py:753-783).  Only band 0 of every time step of the chip is decoded."""
     from . import tiff
 
-    chip = tiff.read(chips_path)[0]
-    steps = max(1, chip.shape[0] // 6)
-    has_data = np.where(chip[[6 * i for i in range(steps)]] == chip_no_data_value, 0, 1).all(0)
-    label = tiff.read(labels_path)[0][0]
-    return not bool(np.any((label != label_no_data_value) & (has_data == 1)))
+    count = tiff.read_profile(chips_path)["count"]
+    steps = max(1, count // 6)
+    first = tiff.read(chips_path, bands=[6 * i for i in range(steps)])[0]
+    has_data = np.where(first == chip_no_data_value, 0, 1).all(0)
+    label = tiff.read(labels_path, bands=[0])[0][0]
+    valid = (label != label_no_data_value) & (has_data == 1)
+    if label.dtype.kind == "f":
+        valid &= ~np.isnan(label)
+    return not bool(np.any(valid))
 
 
 def get_valid_filepaths(fname: str, input_root: str, no_data_value: int = -9999, ignore_index: int = -1) -> List[Tuple[str, Optional[str]]]:
     """(chip, label | None) path pairs of a CSV with an ``Input`` and optionally a ``Label`` column, paths relative to
     ``input_root``; rows whose chip is missing / unreadable, or whose label has no valid pixel over chip data, are dropped
-    (dataloader.py:786-829)."""
+    (dataloader.py:786-829).  Like the reference, a chip is only OPENED here (header parse) unless its label needs the data mask."""
     import os
 
     import pandas as pd
@@ -409,8 +413,8 @@ def get_valid_filepaths(fname: str, input_root: str, no_data_value: int = -9999,
         if not os.path.exists(im):
             continue
         try:
-            tiff.read_profile(im)
             if mk is None:
+                tiff.read_profile(im)
                 out.append((im, None))
             elif not mask_label_with_chip(im, mk, chip_no_data_value=no_data_value, label_no_data_value=ignore_index):
                 out.append((im, mk))
@@ -424,23 +428,58 @@ class InstaGeoDataset(torch.utils.data.Dataset):
     """The reference's CSV-driven dataset (dataloader.py:832-906) on the TIFF codec of :mod:`instageo_amd.tiff`: ``filename`` is
     a CSV with an ``Input`` column (chip GeoTIFF, T*C bands) and optionally ``Label`` (segmentation map), paths relative to
     ``input_root``.  Items follow the reference contract: ``preprocess_func(arr_x, arr_y)``, and with ``include_filenames``
-    the 3-tuple ``(preprocess_func(arr_x, arr_y), im_fname, arr_x == no_data_value)``."""
+    the 3-tuple ``(preprocess_func(arr_x, arr_y), im_fname, arr_x == no_data_value)``.
+
+    For the batched on-device loops of :mod:`instageo_amd.run` the dataset also offers the raw interface of
+    ``ArrayChipDataset`` -- ``raw(i)`` / ``raw_batch(ids)`` (chips already multiplier-scaled by ``process_data``, hence
+    ``mult = None``) and the ``mean`` / ``std`` / ``T`` / ``device`` attributes, taken from the keyword arguments or from the
+    ``functools.partial`` that ``preprocess_func`` usually is."""
 
     def __init__(self, filename: str, input_root: str, preprocess_func, chip_no_data_value: Optional[float] = -9999,
                  label_no_data_value: Optional[float] = -1, replace_label=None, reduce_to_zero: bool = False,
-                 constant_multiplier: float = 1.0, bands: Optional[List[int]] = None, include_filenames: bool = False):
+                 constant_multiplier: float = 1.0, bands: Optional[List[int]] = None, include_filenames: bool = False,
+                 mean: Optional[Sequence[float]] = None, std: Optional[Sequence[float]] = None, temporal_size: Optional[int] = None,
+                 device: Optional[str] = None):
         self.input_root, self.preprocess_func, self.bands = input_root, preprocess_func, bands
         self.no_data_value, self.replace_label, self.reduce_to_zero = chip_no_data_value, replace_label, reduce_to_zero
         self.constant_multiplier, self.include_filenames = constant_multiplier, include_filenames
         self.file_paths = get_valid_filepaths(filename, input_root, chip_no_data_value, label_no_data_value)
+        kw = getattr(preprocess_func, "keywords", None) or {}
+        self.mean = list(mean if mean is not None else kw.get("mean", []))
+        self.std = list(std if std is not None else kw.get("std", []))
+        self.T = int(temporal_size if temporal_size is not None else kw.get("temporal_size", 1))
+        self.mult = None  # process_data has applied the constant multiplier
+        # items are produced by HIP kernels when the preprocessing runs on the device: such a dataset must stay in the main
+        # process (pipeline_utils.create_dataloader forces num_workers=0 / no pinning from this attribute)
+        self.device = str(device if device is not None else kw.get("device", "cpu"))
 
     def __len__(self) -> int:
         return len(self.file_paths)
 
-    def __getitem__(self, i: int):
+    def _load(self, i: int) -> Tuple[np.ndarray, Optional[np.ndarray]]:
         im_fname, mask_fname = self.file_paths[i]
-        arr_x, arr_y = process_data(im_fname, mask_fname, no_data_value=self.no_data_value, replace_label=self.replace_label,
-                                    reduce_to_zero=self.reduce_to_zero, bands=self.bands, constant_multiplier=self.constant_multiplier)
+        return process_data(im_fname, mask_fname, no_data_value=self.no_data_value, replace_label=self.replace_label,
+                            reduce_to_zero=self.reduce_to_zero, bands=self.bands, constant_multiplier=self.constant_multiplier)
+
+    def raw(self, i: int) -> Tuple[np.ndarray, Optional[np.ndarray]]:
+        """Un-normalised chip (T*C, H, W), multiplier-scaled, and its label (H, W) | None (``process_data``)."""
+        arr_x, arr_y = self._load(i)
+        if arr_y is not None and arr_y.ndim == 3:
+            arr_y = arr_y[0]
+        return arr_x, arr_y
+
+    def raw_batch(self, ids: Sequence[int]) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Un-normalised batch (B, T*C, H, W) f32 and labels (B, H, W) f32 on ``self.device`` (chips of one CSV share a size)."""
+        xs, ys = zip(*[self.raw(i) for i in ids])
+        if any(y is None for y in ys):
+            raise RuntimeError("InstaGeoDataset.raw_batch needs a Label column (training / validation data)")
+        x = torch.from_numpy(np.stack([np.asarray(a, dtype=np.float32) for a in xs])).to(self.device)
+        y = torch.from_numpy(np.stack([np.asarray(a, dtype=np.float32) for a in ys])).to(self.device)
+        return x, y
+
+    def __getitem__(self, i: int):
+        im_fname, _ = self.file_paths[i]
+        arr_x, arr_y = self._load(i)
         if self.include_filenames:
             return self.preprocess_func(arr_x, arr_y), im_fname, arr_x == self.no_data_value
         return self.preprocess_func(arr_x, arr_y)

@@ -403,6 +403,7 @@ class SegEngine:
             # backward scratch (reused across blocks / stages)
             ws["dx"] = f32(M, D)
             ws["dxb"] = BT.empty((M, D), sp, dev)
+            ws["dxb2"] = BT.empty((M, D), sp, dev)
             ws["dtmp"] = BT.empty((M, D), sp, dev)
             ws["dh"] = BT.empty((M, 4 * D), sp, dev)
             ws["dqkv"] = BT.empty((M, 3 * D), sp, dev)
@@ -568,7 +569,7 @@ class SegEngine:
         if self.freeze_backbone:
             return
         e = "prithvi_encoder."
-        dx, dxb = ws["dx"], ws["dxb"]
+        dx, dxb, dxb2 = ws["dx"], ws["dxb"], ws["dxb2"]
         self._prepare_shadow_t()
         WT = self.store.wt
 
@@ -581,24 +582,29 @@ class SegEngine:
         self._grad_ready(e + "norm.weight", head0)
         for i in range(L - 1, -1, -1):
             b = f"{e}blocks.{i}."
-            # fc2: x_out = x_mid + hact @ W2^T + b2   (its bias grad came from the LayerNorm backward that produced dx)
-            ops.linear_wgrad(dxb, ws["hact"][i], self.Gd(b + "mlp.fc2.weight"), M, D, 4 * D)
-            # (the fc1 bias gradient = column sums of dh is fused into this dgrad's epilogue)
+            # The four weight gradients of the block run as ONE grouped launch after its data gradients (ig_linear_wgrad_group):
+            # their 108 output tiles (D = 768) fill the CUs with 2-3 token ranges per tile, where each GEMM alone needed 7-28
+            # splits and as many partial tiles to fold.  dxb2 keeps the proj-side residual gradient alive next to the fc2-side one.
+            # fc2: x_out = x_mid + hact @ W2^T + b2   (its bias grad came from the LayerNorm backward that produced dx;
+            # the fc1 bias gradient = column sums of dh is fused into this dgrad's epilogue)
             ops.linear_dgrad(dxb, self.W(b + "mlp.fc2.weight"), ws["dh"], M, D, 4 * D, pre=ws["hpre"][i], colsum=self.Gd(b + "mlp.fc1.bias"),
                              wt=WT(i, "mlp.fc2.weight"))
             # fc1
-            ops.linear_wgrad(ws["dh"], ws["c"][i], self.Gd(b + "mlp.fc1.weight"), M, 4 * D, D)
             ops.linear_dgrad(ws["dh"], self.W(b + "mlp.fc1.weight"), ws["dtmp"], M, 4 * D, D, wt=WT(i, "mlp.fc1.weight"))
-            ops.layernorm_bwd(ws["dtmp"], ws["x_mid"][i], ws["mean2"][i], ws["rstd2"][i], self.P(b + "norm2.weight"), dx, True, dxb,
+            ops.layernorm_bwd(ws["dtmp"], ws["x_mid"][i], ws["mean2"][i], ws["rstd2"][i], self.P(b + "norm2.weight"), dx, True, dxb2,
                               self.Gd(b + "norm2.weight"), self.Gd(b + "norm2.bias"), self.Gd(b + "attn.proj.bias"), M, D)
             # proj
-            ops.linear_wgrad(dxb, ws["o"][i], self.Gd(b + "attn.proj.weight"), M, D, D)
-            ops.linear_dgrad(dxb, self.W(b + "attn.proj.weight"), ws["dtmp"], M, D, D, wt=WT(i, "attn.proj.weight"))
+            ops.linear_dgrad(dxb2, self.W(b + "attn.proj.weight"), ws["dtmp"], M, D, D, wt=WT(i, "attn.proj.weight"))
             ops.attention_bwd(ws["qkv"][i], ws["o"][i], ws["dtmp"], ws["lse"][i], ws["delta"], ws["dqkv"], B, N, H)
             # qkv
-            ops.linear_wgrad(ws["dqkv"], ws["a"][i], self.Gd(b + "attn.qkv.weight"), M, 3 * D, D)
             ops.colsum(ws["dqkv"], self.Gd(b + "attn.qkv.bias"), M, 3 * D)
             ops.linear_dgrad(ws["dqkv"], self.W(b + "attn.qkv.weight"), ws["dtmp"], M, 3 * D, D, wt=WT(i, "attn.qkv.weight"))
+            ops.linear_wgrad_group([
+                (dxb, ws["hact"][i], self.Gd(b + "mlp.fc2.weight"), D, 4 * D),
+                (ws["dh"], ws["c"][i], self.Gd(b + "mlp.fc1.weight"), 4 * D, D),
+                (dxb2, ws["o"][i], self.Gd(b + "attn.proj.weight"), D, D),
+                (ws["dqkv"], ws["a"][i], self.Gd(b + "attn.qkv.weight"), 3 * D, D),
+            ], M)
             prev_bias = self.Gd(f"{e}blocks.{i - 1}.mlp.fc2.bias") if i > 0 else None
             ops.layernorm_bwd(ws["dtmp"], ws["x_in"][i], ws["mean1"][i], ws["rstd1"][i], self.P(b + "norm1.weight"), dx, True, dxb,
                               self.Gd(b + "norm1.weight"), self.Gd(b + "norm1.bias"), prev_bias, M, D)

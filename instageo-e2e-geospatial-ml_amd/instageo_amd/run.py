@@ -6,8 +6,8 @@ Modes ``stats | train | eval | chip_inference`` and every config key are those o
 Lightning and Neptune are replaced by :mod:`instageo_amd.config` and the explicit loop below, which logs the
 same metric names and writes ``instageo_best_checkpoint.ckpt`` (``{"state_dict": ...}``) on the best
 ``val_IoU`` (pipeline_utils.py:347-355).  Data: ``*_filepath`` may be ``synthetic:<n>`` (on-device HLS-shaped
-chips) or an ``.npz`` with ``chips (N,T*C,H,W)`` and ``labels (N,H,W)`` relative to ``root_dir`` (GeoTIFF/CSV
-I/O is outside the hot path).  Multi-GPU: launch with ``python -m torch.distributed.run``; ranks shard the
+chips), an ``.npz`` with ``chips (N,T*C,H,W)`` and ``labels (N,H,W)``, or the reference's own CSV of chip / label GeoTIFF paths
+(``InstaGeoDataset`` on the host TIFF codec), relative to ``root_dir``.  Multi-GPU: launch with ``python -m torch.distributed.run``; ranks shard the
 dataset and average gradients over RCCL (:mod:`instageo_amd.distributed`).
 """
 from __future__ import annotations
@@ -70,7 +70,7 @@ def create_dataset(spec: Optional[str], cfg: Dict[str, Any], kind: str, device: 
                           augmentations=None, device=device)
         return InstaGeoDataset(path, cfg.get("root_dir") or "", pre, d.get("no_data_value", -9999), ign, d.get("replace_label"),
                                bool(d.get("reduce_to_zero", False)), 1.0 if mult is None else mult, d.get("bands"),
-                               include_filenames=(kind == "test"))
+                               include_filenames=(kind == "test"), mean=mean, std=std, temporal_size=T, device=device)
     z = np.load(path)
     return ArrayChipDataset(z["chips"], z["labels"], mean, std, T, mult, include_filenames=(kind == "test"), device=device,
                             replace_label=d.get("replace_label"), reduce_to_zero=bool(d.get("reduce_to_zero", False)))

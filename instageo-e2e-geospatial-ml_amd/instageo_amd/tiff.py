@@ -2,12 +2,13 @@
 
 The reference reads chips and writes ``prediction_*.tif`` through rasterio/GDAL (``instageo/model/dataloader.py:672-704``,
 ``infer_utils.py:37-54,103-128``), which are absent here.  This module is the host-side stand-in: it reads what GDAL writes by
-default for HLS chips (classic little/big-endian TIFF, strips or tiles, compression none / deflate / LZW-free, predictor 1 or 2,
+default for HLS chips (classic little/big-endian TIFF, strips or tiles, compression none / deflate / LZW, predictor 1 or 2,
 band-interleaved "separate" or pixel-interleaved "contig" planes, 8/16/32-bit integer and 32/64-bit float samples) and writes
 strip-organised files (uncompressed or deflate), carrying the source file's georeferencing tags over verbatim so a prediction
 raster opens in GIS tools at the chip's location -- the role of ``profile`` in the reference's ``save_prediction``.
 
-Not a general TIFF library: no BigTIFF, no JPEG/LZW codecs, no sub-IFDs.  Unsupported features raise ``TiffError``.
+Not a general TIFF library: no BigTIFF, no JPEG codec, no sub-IFDs; LZW (GDAL's COMPRESS=LZW, common for HLS derivatives) is
+READ only, by a pure-Python decoder (a 256 x 256 x 18 int16 chip takes about a second).  Unsupported features raise ``TiffError``.
 """
 from __future__ import annotations
 
@@ -60,63 +61,149 @@ def _unpredict(a: np.ndarray) -> np.ndarray:
     return np.cumsum(a, axis=1, dtype=a.dtype)
 
 
-def read(path: str) -> Tuple[np.ndarray, Dict[str, Any]]:
-    """-> (array (bands, H, W), profile).  ``profile`` holds width/height/count/dtype, ``nodata`` (GDAL_NODATA) and the raw
-    georeferencing tags under ``"tags"`` ({tag: (tiff_type, values)}), ready for :func:`write`."""
+def _lzw_decode(data: bytes) -> bytes:
+    """TIFF 6.0 LZW (compression 5): MSB-first codes of 9..12 bits, ClearCode 256, EndOfInformation 257, the code width grows one
+    code EARLY (at 511 / 1023 / 2047 table entries), as libtiff / GDAL write it."""
+    out = bytearray()
+    table: List[bytes] = []
+    base = [bytes((i,)) for i in range(256)] + [b"", b""]
+    bitbuf = 0
+    nbits = 0
+    width = 9
+    prev: Optional[bytes] = None
+    pos, n = 0, len(data)
+    table = list(base)
+    while True:
+        while nbits < width:
+            if pos >= n:
+                return bytes(out)
+            bitbuf = (bitbuf << 8) | data[pos]
+            pos += 1
+            nbits += 8
+        nbits -= width
+        code = (bitbuf >> nbits) & ((1 << width) - 1)
+        if code == 257:
+            break
+        if code == 256:
+            table = list(base)
+            width = 9
+            prev = None
+            continue
+        if prev is None:
+            entry = table[code]
+        elif code < len(table):
+            entry = table[code]
+            table.append(prev + entry[:1])
+        elif code == len(table):
+            entry = prev + prev[:1]
+            table.append(entry)
+        else:
+            raise TiffError(f"corrupt LZW stream (code {code}, table {len(table)})")
+        out += entry
+        prev = entry
+        ln = len(table)
+        if ln >= 511:
+            width = 10 if ln < 1023 else 11 if ln < 2047 else 12
+    return bytes(out)
+
+
+class _Header:
+    """Parsed first IFD of a classic TIFF (no pixel data touched)."""
+
+    def __init__(self, path: str, buf: bytes):
+        self.path, self.buf = path, buf
+        if buf[:2] == b"II":
+            bo = "<"
+        elif buf[:2] == b"MM":
+            bo = ">"
+        else:
+            raise TiffError(f"{path}: not a TIFF file")
+        (magic,) = struct.unpack_from(bo + "H", buf, 2)
+        if magic == 43:
+            raise TiffError(f"{path}: BigTIFF is not supported")
+        if magic != 42:
+            raise TiffError(f"{path}: bad TIFF magic {magic}")
+        (ifd,) = struct.unpack_from(bo + "I", buf, 4)
+        t = self.t = _read_ifd(buf, bo, ifd)
+        self.bo = bo
+        self.W, self.H = self.one(_W), self.one(_H)
+        self.spp = self.one(_SPP, 1)
+        bps = t.get(_BPS, (3, (1,)))[1]
+        if len(set(bps)) != 1:
+            raise TiffError(f"{path}: mixed bits per sample {bps}")
+        fmt = t.get(_FMT, (3, (1,)))[1][0]
+        key = (fmt, bps[0])
+        if key not in _DTYPES:
+            raise TiffError(f"{path}: unsupported sample format {key}")
+        self.dt = np.dtype(bo + _DTYPES[key])
+        self.comp = self.one(_COMP, 1)
+        if self.comp not in (1, 5, 8, 32946):
+            raise TiffError(f"{path}: unsupported compression {self.comp} (supported: none, LZW, deflate)")
+        self.pred = self.one(_PRED, 1)
+        if self.pred not in (1, 2) or (self.pred == 2 and self.dt.kind == "f"):
+            raise TiffError(f"{path}: unsupported predictor {self.pred}")
+        self.planar = self.one(_PLANAR, 1)
+
+    def one(self, tag, default=None):
+        return self.t[tag][1][0] if tag in self.t else default
+
+    def profile(self) -> Dict[str, Any]:
+        t = self.t
+        nodata: Optional[float] = None
+        if 42113 in t:
+            try:
+                nodata = float(t[42113][1])
+            except ValueError:
+                nodata = None
+        return {"driver": "GTiff", "width": self.W, "height": self.H, "count": self.spp, "dtype": self.dt.newbyteorder("=").name,
+                "nodata": nodata, "tags": {k: t[k] for k in GEO_TAGS if k in t}}  # fmt: skip
+
+
+def _header(path: str, whole: bool) -> _Header:
     with open(path, "rb") as f:
-        buf = f.read()
-    if buf[:2] == b"II":
-        bo = "<"
-    elif buf[:2] == b"MM":
-        bo = ">"
-    else:
-        raise TiffError(f"{path}: not a TIFF file")
-    (magic,) = struct.unpack_from(bo + "H", buf, 2)
-    if magic == 43:
-        raise TiffError(f"{path}: BigTIFF is not supported")
-    if magic != 42:
-        raise TiffError(f"{path}: bad TIFF magic {magic}")
-    (ifd,) = struct.unpack_from(bo + "I", buf, 4)
-    t = _read_ifd(buf, bo, ifd)
+        if whole:
+            return _Header(path, f.read())
+        # header only: the IFD and its out-of-line values normally sit in the first or the last kilobytes; fall back to the whole
+        # file when an offset points outside what was read
+        head = f.read(1 << 16)
+        try:
+            return _Header(path, head)
+        except (struct.error, IndexError):
+            f.seek(0)
+            return _Header(path, f.read())
 
-    def one(tag, default=None):
-        return t[tag][1][0] if tag in t else default
 
-    W, H = one(_W), one(_H)
-    spp = one(_SPP, 1)
-    bps = t.get(_BPS, (3, (1,)))[1]
-    if len(set(bps)) != 1:
-        raise TiffError(f"{path}: mixed bits per sample {bps}")
-    fmt = t.get(_FMT, (3, (1,)))[1][0]
-    key = (fmt, bps[0])
-    if key not in _DTYPES:
-        raise TiffError(f"{path}: unsupported sample format {key}")
-    dt = np.dtype(bo + _DTYPES[key])
-    comp = one(_COMP, 1)
-    if comp not in (1, 8, 32946):
-        raise TiffError(f"{path}: unsupported compression {comp} (supported: none, deflate)")
-    pred = one(_PRED, 1)
-    if pred not in (1, 2) or (pred == 2 and dt.kind == "f"):
-        raise TiffError(f"{path}: unsupported predictor {pred}")
-    planar = one(_PLANAR, 1)
+def read(path: str, bands: Optional[List[int]] = None) -> Tuple[np.ndarray, Dict[str, Any]]:
+    """-> (array (bands, H, W), profile).  ``profile`` holds width/height/count/dtype, ``nodata`` (GDAL_NODATA) and the raw
+    georeferencing tags under ``"tags"`` ({tag: (tiff_type, values)}), ready for :func:`write`.  ``bands`` (0-based) decodes
+    only those sample planes of a band-interleaved file (the reference's ``src.read(band)``); the profile still describes the file."""
+    h = _header(path, True)
+    buf, t, dt, comp, pred, planar = h.buf, h.t, h.dt, h.comp, h.pred, h.planar
+    W, H, spp, one = h.W, h.H, h.spp, h.one
+    sel = list(range(spp)) if bands is None else [int(b) for b in bands]
+    if any(b < 0 or b >= spp for b in sel):
+        raise TiffError(f"{path}: band index out of range (file has {spp} bands)")
     planes = spp if planar == 2 else 1       # separately stored sample planes
     sp = 1 if planar == 2 else spp           # samples per pixel inside one chunk
-    out = np.empty((spp, H, W), dtype=dt.newbyteorder("="))
+    out = np.empty((spp if planar != 2 else len(sel), H, W), dtype=dt.newbyteorder("="))
 
     def chunk(off: int, cnt: int, rows: int, cols: int) -> np.ndarray:
         raw = buf[off : off + cnt]
-        if comp != 1:
+        if comp == 5:
+            raw = _lzw_decode(raw)
+        elif comp != 1:
             raw = zlib.decompress(raw)
         a = np.frombuffer(raw, dtype=dt, count=rows * cols * sp).reshape(rows, cols, sp)
         if pred == 2:
             a = _unpredict(a.astype(dt.newbyteorder("=")))
         return a
 
+    plane_list = sel if planar == 2 else [0]
     if _TILE_OFF in t:
         tw, th = one(_TILE_W), one(_TILE_H)
         offs, cnts = t[_TILE_OFF][1], t[_TILE_CNT][1]
         nx, ny = -(-W // tw), -(-H // th)
-        for p in range(planes):
+        for oi, p in enumerate(plane_list):
             for ty in range(ny):
                 for tx in range(nx):
                     i = (p * ny + ty) * nx + tx
@@ -125,37 +212,32 @@ def read(path: str) -> Tuple[np.ndarray, Dict[str, Any]]:
                     hh, ww = min(th, H - y0), min(tw, W - x0)
                     blk = a[:hh, :ww, :]
                     if planar == 2:
-                        out[p, y0 : y0 + hh, x0 : x0 + ww] = blk[:, :, 0]
+                        out[oi, y0 : y0 + hh, x0 : x0 + ww] = blk[:, :, 0]
                     else:
                         out[:, y0 : y0 + hh, x0 : x0 + ww] = blk.transpose(2, 0, 1)
     else:
         rps = min(one(_RPS, H), H)
         offs, cnts = t[_STRIP_OFF][1], t[_STRIP_CNT][1]
         ns = -(-H // rps)
-        for p in range(planes):
-            for s in range(ns):
-                i = p * ns + s
-                y0 = s * rps
+        for oi, p in enumerate(plane_list):
+            for s_ in range(ns):
+                i = p * ns + s_
+                y0 = s_ * rps
                 hh = min(rps, H - y0)
                 a = chunk(offs[i], cnts[i], hh, W)
                 if planar == 2:
-                    out[p, y0 : y0 + hh] = a[:, :, 0]
+                    out[oi, y0 : y0 + hh] = a[:, :, 0]
                 else:
                     out[:, y0 : y0 + hh] = a.transpose(2, 0, 1)
-    nodata: Optional[float] = None
-    if 42113 in t:
-        try:
-            nodata = float(t[42113][1])
-        except ValueError:
-            nodata = None
-    profile = {"driver": "GTiff", "width": W, "height": H, "count": spp, "dtype": out.dtype.name, "nodata": nodata,
-               "tags": {k: t[k] for k in GEO_TAGS if k in t}}  # fmt: skip
-    return out, profile
+    if planar != 2 and bands is not None:
+        out = out[sel]
+    return out, h.profile()
 
 
 def read_profile(path: str) -> Dict[str, Any]:
-    """The profile only (the reference opens the source chip just for ``src.profile``, infer_utils.py:103-113)."""
-    return read(path)[1]
+    """The profile only, from the header: no strip is inflated (the reference opens the source chip just for ``src.profile``,
+    infer_utils.py:103-113, and ``get_valid_filepaths`` only to see that it opens)."""
+    return _header(path, False).profile()
 
 
 def write(path: str, array: np.ndarray, profile: Optional[Dict[str, Any]] = None, compress: Optional[str] = None) -> None:

@@ -165,3 +165,27 @@ def test_single_process_is_a_no_op():
     s.wait()
     assert torch.equal(g, torch.ones(10)) and s.launched == []
     assert D.gather_class_maps(torch.zeros(2, 1, 1, dtype=torch.int8), [2]) is not None
+
+
+def test_bench_self_launches_its_ranks_dry_run():
+    """`python bench.py --gpus 2` without a launcher starts its own ranks (torch.distributed.run child, 127.0.0.1 rendezvous) and
+    rank 0 prints ONE compact JSON line naming 2 ranks.  --dry-run keeps it free of the HIP library (this box has no GPU)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IG_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["dist"]["ranks"] == 2 and out["dist"]["backend"] == "gloo"
+    assert out["dist"]["bucket_checksum"] == 1.0  # mean of the all-reduced ones
+    assert len(lines[0]) < 2000
+    for key in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in out

@@ -69,3 +69,42 @@ def test_rejects_what_it_does_not_support(tmp_path):
         tiff.write(p, np.zeros((2, 2), dtype=np.complex64))
     with pytest.raises(tiff.TiffError):
         tiff.write(p, np.zeros((2, 2), dtype=np.int16), compress="lzw")
+
+
+@pytest.mark.parametrize("mode,dtype", [("L", np.uint8), ("RGB", np.uint8), ("I;16", np.uint16), ("F", np.float32)])
+def test_lzw_read_matches_pillow(tmp_path, mode, dtype):
+    """GDAL's COMPRESS=LZW (common for HLS derivatives): files written by Pillow/libtiff with LZW decode to the source array;
+    smooth + noisy content so that the code width grows through 9..12 bits and the table is cleared several times."""
+    from PIL import Image
+
+    rng = np.random.default_rng(5)
+    H, W = 301, 257
+    base = (np.add.outer(np.arange(H), np.arange(W)) % 251).astype(np.float64)
+    if mode == "RGB":
+        a = np.stack([base, base[::-1], rng.integers(0, 255, (H, W))], -1).astype(dtype)
+    elif mode == "F":
+        a = (base * 0.25 + rng.normal(size=(H, W))).astype(dtype)
+    else:
+        a = (base * (200 if dtype == np.uint16 else 1) + rng.integers(0, 3, (H, W))).astype(dtype)
+    path = str(tmp_path / f"lzw_{mode.replace(';', '')}.tif")
+    Image.fromarray(a, mode=mode).save(path, compression="tiff_lzw")
+    got, prof = tiff.read(path)
+    want = a.transpose(2, 0, 1) if a.ndim == 3 else a[None]
+    assert got.shape == want.shape and got.dtype == want.dtype
+    assert np.array_equal(got, want)
+    assert tiff.read_profile(path) == prof
+
+
+def test_read_profile_is_header_only_and_band_subset(tmp_path):
+    """read_profile parses the IFD without inflating strips (a truncated pixel section still yields the profile); ``bands`` decodes
+    only the requested planes of a band-interleaved file."""
+    a = np.arange(6 * 40 * 50, dtype=np.int16).reshape(6, 40, 50)
+    path = str(tmp_path / "chip.tif")
+    tiff.write(path, a, compress="deflate")
+    full, prof = tiff.read(path)
+    assert np.array_equal(full, a)
+    sub, prof2 = tiff.read(path, bands=[0, 5, 2])
+    assert np.array_equal(sub, a[[0, 5, 2]]) and prof2 == prof and prof["count"] == 6
+    assert tiff.read_profile(path) == prof
+    with pytest.raises(tiff.TiffError):
+        tiff.read(path, bands=[6])

@@ -273,6 +273,52 @@ def test_linear_wgrad_is_deterministic(split, M, N, K):
 
 
 @pytest.mark.parametrize("split", SPLITS)
+@pytest.mark.parametrize("M,shapes", [
+    (21276, [(768, 3072), (3072, 768), (768, 768), (2304, 768)]),  # one Block of Prithvi-100M at the benchmark batch (108 tiles)
+    (3152, [(768, 3072), (3072, 768), (768, 768), (2304, 768)]),   # the YAML's batch 16
+    (197, [(256, 256), (768, 256)]),                               # fewer tokens than one K-tile pair per split
+    (130, [(256, 512)]),                                           # ragged: 2 valid tokens in the second K-tile pair
+    (1, [(256, 256)]),
+    (6304, [(1024, 4096), (4096, 1024), (1024, 1024), (3072, 1024)]),  # Prithvi-300M Block: 192 tiles, no token split
+    (1000, [(2048, 4096), (4096, 2048), (2048, 2048), (6144, 2048)]),  # more tiles (768) than CUs: several tiles per workgroup
+])
+def test_linear_wgrad_group(split, M, shapes):
+    """Grouped weight gradients (ig_linear_wgrad_group -> gemm8w.hip) against float64 dy^T @ x of the values the kernel sees;
+    accumulation into dw; bit-identical repeats (ordered split-K fold: the reference trains with deterministic=True)."""
+    items, refs = [], []
+    for gi, (N, K) in enumerate(shapes):
+        dy, dyr = bt(rnd(M, N, seed=11 + gi), split)
+        x, xr = bt(rnd(M, K, seed=31 + gi), split)
+        dw = torch.full((N, K), 0.5, device=DEV)
+        items.append((dy, x, dw, N, K))
+        refs.append(dyr.t() @ xr)
+    ops.linear_wgrad_group(items, M)
+    for (dy, x, dw, N, K), ref in zip(items, refs):
+        close(dw - 0.5, ref, 3e-5 if split else 2e-5, atol=None, what=f"grouped wgrad {N}x{K}")
+    first = [it[2].clone() for it in items]
+    for _ in range(3):
+        for it in items:
+            it[2].fill_(0.5)
+        ops.linear_wgrad_group(items, M)
+        for it, f in zip(items, first):
+            assert torch.equal(it[2], f), "grouped weight gradient differs between identical launches"
+
+
+def test_linear_wgrad_group_fallback_shapes():
+    """Shapes the 8-phase engine does not cover (N or K not a multiple of 256) run one ig_linear_wgrad per GEMM."""
+    M = 500
+    items, refs = [], []
+    for gi, (N, K) in enumerate([(192, 64), (256, 256), (40, 72)]):
+        dy, dyr = bt(rnd(M, N, seed=3 + gi), False)
+        x, xr = bt(rnd(M, K, seed=9 + gi), False)
+        items.append((dy, x, torch.zeros(N, K, device=DEV), N, K))
+        refs.append(dyr.t() @ xr)
+    ops.linear_wgrad_group(items, M)
+    for it, ref in zip(items, refs):
+        close(it[2], ref, 2e-5, what="grouped wgrad fallback")
+
+
+@pytest.mark.parametrize("split", SPLITS)
 @pytest.mark.parametrize("T", [1, 3])
 def test_patch_embed(split, T):
     B, C, H, W, p, D = 2, 6, 64, 48, 16, 64

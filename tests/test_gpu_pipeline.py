@@ -374,6 +374,43 @@ def test_tile_inference_geotiff_roundtrip(tmp_path):
     assert (po[:500, :500] >= -1).all() and (po[0:40, 0:40] == pred[0, 0:40, 0:40]).all()  # corner pixels: only window (0, 0) is nearest
 
 
+def test_run_train_eval_on_csv_of_geotiffs(tmp_path, capsys):
+    """The reference's own input form through run.py: a CSV of chip / label GeoTIFF paths -> InstaGeoDataset ->
+    mode=train (raw_batch -> on-device crop / flip / normalise), mode=eval (process_test windows) and mode=chip_inference."""
+    from instageo_amd import run, tiff
+
+    rng = np.random.default_rng(3)
+    rows = []
+    for i in range(5):
+        chip = rng.integers(0, 10000, (6, 256, 256)).astype(np.int16)
+        lab = rng.integers(0, 2, (1, 256, 256)).astype(np.int16)
+        lab[0, :16] = -1
+        if i == 4:
+            lab[:] = -1  # no valid pixel: the row is dropped by get_valid_filepaths
+        tiff.write(str(tmp_path / f"chip_{i}.tif"), chip, compress="deflate")
+        tiff.write(str(tmp_path / f"lab_{i}.tif"), lab)
+        rows.append(f"chip_{i}.tif,lab_{i}.tif")
+    (tmp_path / "set.csv").write_text("Input,Label\n" + "\n".join(rows) + "\n")
+    common = ["model.model_name=prithvi_eo_tiny", "model.load_pretrained_weights=False", "train.batch_size=2", "train.ignore_index=-1",
+              "train.class_weights=[1,3]", f"root_dir={tmp_path}", "dataloader.constant_multiplier=0.0001", "dataloader.no_data_value=-9999"]
+    out = str(tmp_path / "out")
+    assert run.main(["--output-dir", out, "mode=train", "train.num_epochs=1", "train_filepath=set.csv", "valid_filepath=set.csv",
+                     "dataloader.img_size=224"] + common) == 0
+    txt = capsys.readouterr().out
+    assert "Dropped a total of 1 rows" in txt
+    line = [json.loads(l) for l in txt.splitlines() if l.startswith("{")][-1]
+    assert {"train_loss", "val_loss", "val_IoU"} <= set(line) and np.isfinite(line["train_loss"])
+    ck = os.path.join(out, "instageo_best_checkpoint.ckpt")
+    assert os.path.exists(ck)
+    assert run.main(["--output-dir", out, "mode=eval", "test_filepath=set.csv", "test.img_size=256", "test.crop_size=224", "test.stride=32",
+                     f"checkpoint_path={ck}"] + common) == 0
+    res = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1]["Evaluation results"]
+    assert {"test_loss", "test_IoU"} <= set(res) and 0 <= res["test_IoU"] <= 1
+    assert run.main(["--output-dir", out, "mode=chip_inference", "test_filepath=set.csv", "test.img_size=256", f"checkpoint_path={ck}"] + common) == 0
+    preds = sorted(os.listdir(tmp_path / "predictions"))
+    assert len(preds) == 4 and tiff.read(str(tmp_path / "predictions" / preds[0]))[0].shape == (1, 256, 256)
+
+
 def test_run_train_eval_chip_inference(tmp_path, capsys):
     from instageo_amd import run
 

@@ -1,5 +1,5 @@
 import os, sys
-sys.path.insert(0, "/root/repo/instageo-e2e-geospatial-ml_amd")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "instageo-e2e-geospatial-ml_amd"))
 import torch
 from instageo_amd import ops
 from instageo_amd.ops import BT

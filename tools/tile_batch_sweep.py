@@ -1,5 +1,6 @@
+import os
 import sys, time
-sys.path.insert(0, "/root/repo/instageo-e2e-geospatial-ml_amd")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "instageo-e2e-geospatial-ml_amd"))
 import torch
 from instageo_amd.segmentation import PrithviSegmentationModule
 from instageo_amd.infer_utils import sliding_window_inference
