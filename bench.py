@@ -295,12 +295,15 @@ def main() -> None:
         dt = max_over_ranks(time.perf_counter() - t0)
         res = {"mod": mod, "dt": dt, "prof": ops.profile_end() if profile else None, "prof_all": None, "graphed": graphed is not None,
                "loss": (stats[0] / stats[1]).item(), "buckets": None}
-        if sync is not None:  # per-bucket all-reduce time of one extra, instrumented step (outside the timed region)
+        res["dp_mode"] = None if sync is None else ("zero1" if isinstance(sync, D.ShardedGradSync) else "allreduce")
+        if isinstance(sync, D.GradSync):  # per-bucket all-reduce time of one extra, instrumented step (outside the timed region)
             sync.time_buckets = True
             train_step(0)
             torch.cuda.synchronize()
             res["buckets"] = [{"mbytes": round((hi - lo) * 4 / 2**20, 1), "ms": round(ms, 3)} for (lo, hi), ms in sync.bucket_times()]
             sync.time_buckets = False
+        elif sync is not None:  # reduce-scatter + all-gather around the sharded optimizer: bucket sizes only (all overlapped)
+            res["buckets"] = [{"mbytes": round((hi - lo) * 4 / 2**20, 1), "ms": 0.0} for (lo, hi, _) in sync.plan]
         if profile:  # every MFMA / HBM entry point, in a separate untimed pass of 3 steps
             ops.profile_begin(GEMM_OPS + HBM_OPS)
             for i in range(3):
@@ -537,7 +540,7 @@ def main() -> None:
         detail["roofline_kernels"] = all_k
     if world > 1:
         bk = main_res["buckets"] or []
-        out["dist"] = {"ranks": world, "backend": dist.get_backend(), "reserved_cus": ops.reserved_cus(), "buckets": len(bk),
+        out["dist"] = {"ranks": world, "backend": dist.get_backend(), "mode": main_res.get("dp_mode"), "reserved_cus": ops.reserved_cus(), "buckets": len(bk),
                        "allreduce_mbytes": round(sum(b["mbytes"] for b in bk), 1), "allreduce_ms_serial": round(sum(b["ms"] for b in bk), 3)}
         detail["allreduce_buckets"] = bk
     if world == 1 and not args.no_cpu_baseline:

@@ -14,7 +14,9 @@ from typing import Dict, List, Tuple
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG_ROOT = os.path.dirname(_HERE)
 _REPO_ROOT = os.path.dirname(_PKG_ROOT)
-LIB_PATH = os.path.join(_HERE, "libinstageo_hip.so")
+# IG_HIP_LIB: another build of the same library (same header revision) -- same-box A/B runs of two builds (tools/); the default
+# is the in-tree library next to this file
+LIB_PATH = os.environ.get("IG_HIP_LIB") or os.path.join(_HERE, "libinstageo_hip.so")
 HEADER_PATH = os.path.join(_REPO_ROOT, "include", "instageo_hip.h")
 
 _SCALARS = {

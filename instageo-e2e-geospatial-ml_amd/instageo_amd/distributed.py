@@ -145,7 +145,179 @@ class GradSync:
         self.ranges.clear()
 
 
-def attach_data_parallel(module, bucket_bytes: int = 32 << 20) -> Optional[GradSync]:
+class ShardedGradSync:
+    """Gradient exchange as bucketed REDUCE-SCATTER + parameter ALL-GATHER around a sharded optimizer step.
+
+    The flat optimizer range ``[lo, hi)`` is cut into the same contiguous buckets as :class:`GradSync` (ranges arrive
+    head-first in descending address order while backward runs), but a bucket's length is kept a multiple of
+    ``world * ALIGN`` elements and each bucket is reduce-scattered: rank r receives the summed gradients of slice r of every
+    bucket into its ``owned`` buffer.  ``step(adam)`` then runs AdamW on the owned slices only -- 1/world of the optimizer
+    work and of the moment buffers per rank -- and all-gathers every bucket's updated fp32 parameters, bucket by bucket, so
+    the gathers of the first buckets overlap the AdamW launches of the later ones.  Bytes on the wire equal one all-reduce
+    (reduce-scatter + all-gather IS the ring all-reduce, split around the optimizer).  The tail of the range that does not
+    fill a multiple of ``world * ALIGN`` (< that many elements) is all-reduced and updated redundantly by every rank.
+
+    ``adam(param, grad, m, v, index0)`` is the optimizer kernel on one contiguous slice (``FusedAdamW`` passes
+    ``ig_adamw_step``; the CPU tests pass a torch restatement): ``param`` fp32 slice of the flat buffer (updated in place),
+    ``grad`` the SUMMED gradient slice (the 1/world factor is the optimizer's grad scale), ``m`` / ``v`` moment slices owned by
+    this object, ``index0`` the slice's offset in the flat buffer.
+    """
+
+    ALIGN = 64
+
+    def __init__(self, get_grad: Callable[[], torch.Tensor], get_flat: Callable[[], torch.Tensor], lo: int, hi: int,
+                 bucket_bytes: int = 32 << 20, group=None):
+        self.get_grad, self.get_flat, self.lo, self.hi = get_grad, get_flat, lo, hi
+        self.bucket_bytes, self.group = bucket_bytes, group
+        self.world = world_size()
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        self.q = self.world * self.ALIGN
+        self.cur: Optional[Tuple[int, int]] = None
+        self.plan: List[Tuple[int, int, int]] = []      # (lo, hi, owned elements before it), fixed after the first step
+        self._step_buckets: List[Tuple[int, int]] = []  # buckets flushed in the current step
+        self._handles: List = []
+        self._own: List[torch.Tensor] = []              # per bucket: this rank's slice of the summed gradient
+        self._m: List[torch.Tensor] = []                # per bucket: AdamW moments of the owned slice
+        self._v: List[torch.Tensor] = []
+        self.tail: Optional[Tuple[int, int]] = None     # replicated remainder (all-reduced)
+        self.m_tail: Optional[torch.Tensor] = None
+        self.v_tail: Optional[torch.Tensor] = None
+        self._tail_handle = None
+        self._frozen = False
+        self.launched: List[Tuple[int, int]] = []
+
+    # ---- during backward -------------------------------------------------------------------------------------------
+    def ready(self, lo: int, hi: int) -> None:
+        lo, hi = max(lo, self.lo), min(hi, self.hi)
+        if hi <= lo:
+            return
+        if self.cur is not None and hi == self.cur[0]:
+            self.cur = (lo, self.cur[1])
+        elif self.cur is None:
+            self.cur = (lo, hi)
+        else:
+            raise RuntimeError("ShardedGradSync: gradient ranges must arrive adjacent, in descending address order")
+        if (self.cur[1] - self.cur[0]) * 4 >= self.bucket_bytes:
+            self._flush(final=False)
+
+    def _flush(self, final: bool) -> None:
+        if self.cur is None:
+            return
+        lo, hi = self.cur
+        span = ((hi - lo) // self.q) * self.q
+        if span > 0:
+            blo = hi - span
+            g = self.get_grad()
+            n = span // self.world
+            i = len(self._step_buckets)
+            if self._frozen:
+                if i >= len(self.plan) or self.plan[i][:2] != (blo, hi):
+                    raise RuntimeError("ShardedGradSync: the bucket sequence changed between steps (moment slices would be misassigned)")
+            else:  # first step: one (gradient slice, m, v) triple per bucket, kept for the life of the object
+                self.plan.append((blo, hi, sum(t.numel() for t in self._own)))
+                self._own.append(torch.zeros(n, dtype=torch.float32, device=g.device))
+                self._m.append(torch.zeros(n, dtype=torch.float32, device=g.device))
+                self._v.append(torch.zeros(n, dtype=torch.float32, device=g.device))
+            self._handles.append(self._reduce_scatter(self._own[i], g[blo:hi], n))
+            self._step_buckets.append((blo, hi))
+            self.launched.append((blo, hi))
+            hi = blo
+        self.cur = (lo, hi) if hi > lo else None
+        if final and self.cur is not None:
+            tlo, thi = self.cur
+            self.cur = None
+            if self.tail is None:
+                g = self.get_grad()
+                self.tail = (tlo, thi)
+                self.m_tail = torch.zeros(thi - tlo, dtype=torch.float32, device=g.device)
+                self.v_tail = torch.zeros_like(self.m_tail)
+            elif self.tail != (tlo, thi):
+                raise RuntimeError("ShardedGradSync: the replicated tail changed between steps")
+            self._tail_handle = dist.all_reduce(self.get_grad()[tlo:thi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    # Backends without a native reduce-scatter / all-gather for the tensor's device (gloo with device tensors on the one-GPU
+    # test box) take an equivalent form: all-reduce of the bucket + copy of the own slice, and one broadcast per slice.  The
+    # probe result is the same on every rank (same backend, same device kind), so the collective sequences stay matched.
+    _native = {"rs": None, "ag": None}
+
+    class _Done:
+        def wait(self):
+            return None
+
+    def _reduce_scatter(self, out: torch.Tensor, bucket: torch.Tensor, n: int):
+        if self._native["rs"] is not False:
+            try:
+                h = dist.reduce_scatter_tensor(out, bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._native["rs"] = True
+                return h
+            except (RuntimeError, NotImplementedError):
+                if self._native["rs"]:
+                    raise
+                self._native["rs"] = False
+        h = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+        class _Copy:
+            def wait(_self):
+                h.wait()
+                out.copy_(bucket[self.rank * n : (self.rank + 1) * n])
+
+        return _Copy()
+
+    def _all_gather(self, full: torch.Tensor, send: torch.Tensor):
+        if self._native["ag"] is not False:
+            try:
+                h = dist.all_gather_into_tensor(full, send, group=self.group, async_op=True)
+                self._native["ag"] = True
+                return h
+            except (RuntimeError, NotImplementedError):
+                if self._native["ag"]:
+                    raise
+                self._native["ag"] = False
+        n = send.numel()
+        hs = [dist.broadcast(full[r * n : (r + 1) * n], src=r, group=self.group, async_op=True) for r in range(self.world)]
+
+        class _All:
+            def wait(_self):
+                for x in hs:
+                    x.wait()
+
+        return _All()
+
+    # ---- after backward --------------------------------------------------------------------------------------------
+    def step(self, adam: Callable[[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, int], None]) -> None:
+        """Finish the exchange, run ``adam`` on the owned slices (and the replicated tail), all-gather the parameters."""
+        self._flush(final=True)
+        flat = self.get_flat()
+        gathers = []
+        for i, (blo, bhi) in enumerate(self._step_buckets):
+            self._handles[i].wait()
+            n = (bhi - blo) // self.world
+            s0 = blo + self.rank * n
+            adam(flat[s0 : s0 + n], self._own[i], self._m[i], self._v[i], s0)
+            send = flat[s0 : s0 + n].clone()  # (not the in-place form: output and input of the gather do not alias)
+            gathers.append(self._all_gather(flat[blo:bhi], send))
+        if self._tail_handle is not None:
+            self._tail_handle.wait()
+            tlo, thi = self.tail
+            adam(flat[tlo:thi], self.get_grad()[tlo:thi], self.m_tail, self.v_tail, tlo)
+            self._tail_handle = None
+        for h in gathers:
+            h.wait()
+        if not self._frozen:
+            covered = sum(b - a for a, b, _ in self.plan) + (0 if self.tail is None else self.tail[1] - self.tail[0])
+            if covered != self.hi - self.lo:
+                raise RuntimeError(f"ShardedGradSync: buckets cover {covered} of {self.hi - self.lo} gradient elements "
+                                   "(every trainable range must be reported through ready())")
+            self._frozen = True
+        self._handles.clear()
+        self._step_buckets.clear()
+
+    def optimizer_elements(self) -> int:
+        """fp32 elements of moment state held by this rank (about 1/world of the replicated optimizer's)."""
+        return sum(t.numel() for t in self._m) + (0 if self.m_tail is None else self.m_tail.numel())
+
+
+def attach_data_parallel(module, bucket_bytes: int = 32 << 20):
     """Wire a :class:`GradSync` into a ``PrithviSegmentationModule`` (fused path) and broadcast rank 0's
     parameters/buffers so all replicas start equal (Lightning/DDP semantics)."""
     if world_size() == 1:
@@ -161,8 +333,18 @@ def attach_data_parallel(module, bucket_bytes: int = 32 << 20) -> Optional[GradS
 
     if net.store.flat.is_cuda and "IG_RESERVED_CUS" not in os.environ and ops.reserved_cus() == 0:
         ops.set_reserved_cus(DEFAULT_RESERVED_CUS)
+    opt = module.optimizer()
+    opt.set_grad_scale(1.0 / world_size())
+    # IG_DP_MODE: "zero1" (default) = reduce-scatter + AdamW on the owned 1/world slices + all-gather of the parameters;
+    # "allreduce" = one all-reduce per bucket and the replicated optimizer (round 1-2 behaviour)
+    mode = os.environ.get("IG_DP_MODE", "zero1")
+    if mode == "zero1" and hasattr(opt, "attach_sharded"):
+        sync = ShardedGradSync(lambda: net.store.ensure_grad(), lambda: net.store.flat, opt.lo, opt.hi, bucket_bytes)
+        opt.attach_sharded(sync)
+        net.engine.on_grad_ready = sync.ready
+        module.grad_sync = None  # the exchange is finished inside the optimizer step
+        return sync
     sync = GradSync(lambda: net.store.ensure_grad(), bucket_bytes, scale_in_optimizer=True)
-    module.optimizer().set_grad_scale(1.0 / world_size())
     net.engine.on_grad_ready = sync.ready
     module.grad_sync = sync.wait
     return sync

@@ -404,6 +404,7 @@ class SegEngine:
             ws["dx"] = f32(M, D)
             ws["dxb"] = BT.empty((M, D), sp, dev)
             ws["dxb2"] = BT.empty((M, D), sp, dev)
+            ws["wgrad_groups"] = {}
             ws["dtmp"] = BT.empty((M, D), sp, dev)
             ws["dh"] = BT.empty((M, 4 * D), sp, dev)
             ws["dqkv"] = BT.empty((M, 3 * D), sp, dev)
@@ -599,12 +600,15 @@ class SegEngine:
             # qkv
             ops.colsum(ws["dqkv"], self.Gd(b + "attn.qkv.bias"), M, 3 * D)
             ops.linear_dgrad(ws["dqkv"], self.W(b + "attn.qkv.weight"), ws["dtmp"], M, 3 * D, D, wt=WT(i, "attn.qkv.weight"))
-            ops.linear_wgrad_group([
-                (dxb, ws["hact"][i], self.Gd(b + "mlp.fc2.weight"), D, 4 * D),
-                (ws["dh"], ws["c"][i], self.Gd(b + "mlp.fc1.weight"), 4 * D, D),
-                (dxb2, ws["o"][i], self.Gd(b + "attn.proj.weight"), D, D),
-                (ws["dqkv"], ws["a"][i], self.Gd(b + "attn.qkv.weight"), 3 * D, D),
-            ], M)
+            grp = ws["wgrad_groups"].get(i)
+            if grp is None or grp.items[0][2].data_ptr() != self.Gd(b + "mlp.fc2.weight").data_ptr():
+                grp = ws["wgrad_groups"][i] = ops.WgradGroup([
+                    (dxb, ws["hact"][i], self.Gd(b + "mlp.fc2.weight"), D, 4 * D),
+                    (ws["dh"], ws["c"][i], self.Gd(b + "mlp.fc1.weight"), 4 * D, D),
+                    (dxb2, ws["o"][i], self.Gd(b + "attn.proj.weight"), D, D),
+                    (ws["dqkv"], ws["a"][i], self.Gd(b + "attn.qkv.weight"), 3 * D, D),
+                ], M)  # prepared once per (workspace, block): pointers of the workspace and of the flat gradient buffer
+            grp.launch()
             prev_bias = self.Gd(f"{e}blocks.{i - 1}.mlp.fc2.bias") if i > 0 else None
             ops.layernorm_bwd(ws["dtmp"], ws["x_in"][i], ws["mean1"][i], ws["rstd1"][i], self.P(b + "norm1.weight"), dx, True, dxb,
                               self.Gd(b + "norm1.weight"), self.Gd(b + "norm1.bias"), prev_bias, M, D)

@@ -354,25 +354,35 @@ def linear_wgrad(dy: BT, x: BT, dw, M: int, N: int, K: int) -> None:
     _call("ig_linear_wgrad", 2.0 * M * N * K, _p(dy.hi), _p(dy.lo), _p(x.hi), _p(x.lo), _p(dw), M, N, K, _stream())
 
 
+class WgradGroup:
+    """Prepared argument block of one grouped weight-gradient launch: ``items`` = [(dy, x, dw, N, K), ...] sharing the token
+    count M.  The ctypes pointer / size arrays are built ONCE (building them per call costs tens of microseconds of Python --
+    at small batches the step is bound by the host's launch rate), the tensors are kept alive by the object."""
+
+    __slots__ = ("items", "M", "work", "_args")
+
+    def __init__(self, items, M: int):
+        import ctypes
+
+        n = len(items)
+        vp, ip = ctypes.c_void_p * n, ctypes.c_int * n
+        split = items[0][0].lo is not None
+        arrs = [vp(*[_p(it[0].hi) for it in items]), vp(*[_p(it[0].lo) for it in items]) if split else None,
+                vp(*[_p(it[1].hi) for it in items]), vp(*[_p(it[1].lo) for it in items]) if split else None,
+                vp(*[_p(it[2]) for it in items]), ip(*[int(it[3]) for it in items]), ip(*[int(it[4]) for it in items])]
+        self.items, self.M = list(items), int(M)
+        self.work = sum(2.0 * M * it[3] * it[4] for it in items)
+        self._args = (n, *[None if a is None else ctypes.cast(a, ctypes.c_void_p) for a in arrs], int(M)), arrs  # arrs: keep-alive
+
+    def launch(self) -> None:
+        _call("ig_linear_wgrad_group", self.work, *self._args[0], _stream())
+
+
 def linear_wgrad_group(items, M: int) -> None:
     """``items`` = [(dy, x, dw, N, K), ...]: dw_g[N_g][K_g] += dy_g[M][N_g]^T @ x_g[M][K_g] for all g in ONE launch (the weight
-    gradients of a Block's linears share the token count; grouped, their output tiles fill the CUs with 2 token splits instead
-    of 7-28 and the split-K fold shrinks accordingly)."""
-    import ctypes
-
-    n = len(items)
-    vp = ctypes.c_void_p * n
-    ip = ctypes.c_int * n
-    split = items[0][0].lo is not None
-    dy_hi = vp(*[_p(it[0].hi) for it in items])
-    x_hi = vp(*[_p(it[1].hi) for it in items])
-    dy_lo = vp(*[_p(it[0].lo) for it in items]) if split else None
-    x_lo = vp(*[_p(it[1].lo) for it in items]) if split else None
-    dw = vp(*[_p(it[2]) for it in items])
-    Ns, Ks = ip(*[int(it[3]) for it in items]), ip(*[int(it[4]) for it in items])
-    work = sum(2.0 * M * it[3] * it[4] for it in items)
-    c = lambda a: None if a is None else ctypes.cast(a, ctypes.c_void_p)  # noqa: E731
-    _call("ig_linear_wgrad_group", work, n, c(dy_hi), c(dy_lo), c(x_hi), c(x_lo), c(dw), c(Ns), c(Ks), M, _stream())
+    gradients of a Block's linears share the token count; grouped, their output tiles fill the CUs with 2-3 token ranges per
+    tile instead of 7-28 and the split-K fold shrinks accordingly).  Hot loops keep a :class:`WgradGroup` instead."""
+    WgradGroup(items, M).launch()
 
 
 def attention_fwd(qkv: BT, out: BT, lse, B: int, N: int, H: int, hd: int = 64) -> None:

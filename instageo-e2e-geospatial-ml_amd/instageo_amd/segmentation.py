@@ -54,6 +54,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self.m = torch.zeros(self.hi - self.lo, dtype=torch.float32, device=dev)
         self.v = torch.zeros_like(self.m)
         self.hyper = torch.zeros(16, dtype=torch.float32, device=dev)
+        self.sharded = None  # distributed.ShardedGradSync when the optimizer state is sharded over the data-parallel ranks
         self._host_step = 0
         self._write_hyper()
 
@@ -65,6 +66,12 @@ class FusedAdamW(torch.optim.Optimizer):
             h[7], h[8], h[9] = float(self.clip_range[0]), float(self.clip_range[1]), 1.0
         self.hyper[: len(h)] = torch.tensor(h, dtype=torch.float32)
         self._lr_written = g["lr"]
+
+    def attach_sharded(self, sync) -> None:
+        """Shard the optimizer over the data-parallel ranks (``distributed.ShardedGradSync``): the replicated moment buffers
+        are released, every rank keeps the moments of its slices only."""
+        self.sharded = sync
+        self.m = self.v = None
 
     def set_grad_scale(self, scale: float) -> None:
         """Multiply gradients by ``scale`` inside the AdamW kernel (1/world_size after a SUM all-reduce)."""
@@ -94,6 +101,19 @@ class FusedAdamW(torch.optim.Optimizer):
         if store.shadow is None or store.shadow_split != eng.split:
             store.refresh_shadow(eng.split)
         sh = store.shadow
+        if self.sharded is not None:
+            # data parallel, "zero1": the gradient buckets were reduce-scattered during backward; AdamW runs on this rank's slice
+            # of every bucket (moments live in the ShardedGradSync), the updated fp32 parameters are all-gathered, and the bf16
+            # operand copy of the slices other ranks updated is refreshed by one streaming pass
+            def adam(param, grad, m, v, index0):
+                shw = ops.BT(sh.hi[index0 : index0 + param.numel()], None if sh.lo is None else sh.lo[index0 : index0 + param.numel()])
+                ops.adamw_step(param, grad, m, v, shw, self.hyper, param.numel())
+
+            self.sharded.step(adam)
+            store.refresh_shadow(eng.split)
+            eng.shadow_dirty = False
+            eng.shadow_t_dirty = True
+            return loss
         shadow = ops.BT(sh.hi[self.lo : self.hi], None if sh.lo is None else sh.lo[self.lo : self.hi])
         ops.adamw_step(store.flat[self.lo : self.hi], store.grad[self.lo : self.hi], self.m, self.v, shadow, self.hyper, self.hi - self.lo)
         eng.shadow_dirty = False
@@ -349,7 +369,7 @@ class PrithviSegmentationModule(_Base):
         kernel launches with one host call.  Everything the step needs is device resident (AdamW step counter and
         bias corrections, dropout seed counter, loss statistics), so replays need no host-side scalars.
         """
-        assert self.grad_sync is None, "graph capture is for the single-GPU path (RCCL calls are not captured)"
+        assert self.grad_sync is None and self.optimizer().sharded is None, "graph capture is for the single-GPU path (RCCL calls are not captured)"
         static_x = inputs.clone()
         static_y = labels.clone()
         stats = torch.zeros(2, dtype=torch.float64, device=inputs.device)

@@ -189,3 +189,128 @@ def test_bench_self_launches_its_ranks_dry_run():
     assert len(lines[0]) < 2000
     for key in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert key in out
+
+
+def _adam_ref(param, grad, m, v, step, lr=1e-2, b1=0.9, b2=0.999, eps=1e-8, wd=1e-2, scale=1.0):
+    """torch.optim.AdamW on one contiguous slice (the CPU stand-in for ig_adamw_step: the sharding logic is device-agnostic)."""
+    g = grad * scale
+    param.mul_(1 - lr * wd)
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    mh, vh = m / (1 - b1**step), v / (1 - b2**step)
+    param.addcdiv_(mh, vh.sqrt().add_(eps), value=-lr)
+
+
+def _sharded_worker(rank: int, world: int, port: int, q, n: int) -> None:
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "instageo-e2e-geospatial-ml_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from instageo_amd import distributed as D
+
+    D.init_from_env(backend="gloo")
+    try:
+        lo = 40  # a frozen prefix that the optimizer must not touch
+        flat = torch.linspace(-1, 1, n)
+        flat0 = flat.clone()
+        grad = torch.zeros(n)
+        sync = D.ShardedGradSync(lambda: grad, lambda: flat, lo, n, bucket_bytes=4 * 3000)
+        # ranges arrive head-first, adjacent, in descending address order, like SegEngine._grad_ready
+        cuts = [n, n - 1234, n - 5000, n - 5001, 7000, 4096, 100, 0]
+        for step in range(1, 4):
+            gen = torch.Generator().manual_seed(1000 * step + rank)
+            grad.copy_(torch.randn(n, generator=gen))
+            for hi, lo_r in zip(cuts[:-1], cuts[1:]):
+                sync.ready(lo_r, hi)
+            sync.step(lambda p, g, m, v, i0, step=step: _adam_ref(p, g, m, v, step, scale=1.0 / world))
+        q.put((rank, flat.numpy().copy(), sync.optimizer_elements(), list(sync.plan), sync.tail))
+        assert torch.equal(flat[:lo], flat0[:lo])
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, traceback.format_exc(), 0, [], None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_optimizer_equals_the_one_rank_step(world):
+    """reduce-scatter -> AdamW on the owned 1/world slices -> all-gather (distributed.ShardedGradSync) gives
+    every rank the parameters of ONE process that averages the per-rank gradients and runs the full AdamW step; the moment
+    state per rank is ~1/world of the replicated optimizer's; the unaligned tail of the range is handled redundantly."""
+    n = 20_011  # not a multiple of world * 64: a replicated tail exists
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q, n)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert not isinstance(r[1], str), r[1]
+    lo = 40
+    ref = torch.linspace(-1, 1, n)
+    m, v = torch.zeros(n - lo), torch.zeros(n - lo)
+    for step in range(1, 4):
+        g = sum(torch.randn(n, generator=torch.Generator().manual_seed(1000 * step + r)) for r in range(world)) / world
+        _adam_ref(ref[lo:], g[lo:], m, v, step)
+    for r in res:
+        got = torch.from_numpy(r[1])
+        assert torch.allclose(got, ref, rtol=0, atol=2e-6), (got - ref).abs().max()
+        assert torch.equal(got, torch.from_numpy(res[0][1])), "replicas diverged"
+        owned = r[2]
+        assert owned <= (n - lo) // world + world * 64, "moment state is not sharded"
+        plan, tail = r[3], r[4]
+        assert all((b - a) % (world * 64) == 0 for a, b, _ in plan) and len(plan) >= 2
+        assert tail is not None and tail[0] == lo and 0 < tail[1] - tail[0] < world * 64
+        assert sum(b - a for a, b, _ in plan) + tail[1] - tail[0] == n - lo
+
+
+def _gather_worker(rank: int, world: int, port: int, q) -> None:
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "instageo-e2e-geospatial-ml_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from instageo_amd import distributed as D
+
+    D.init_from_env(backend="gloo")
+    try:
+        # BASELINE.json configs[3]: 49 x 49 = 2401 windows; every rank "predicts" its contiguous block (class = window id mod 100)
+        lo, hi = D.shard_range(2401, rank, world)
+        counts = [D.shard_range(2401, k, world)[1] - D.shard_range(2401, k, world)[0] for k in range(world)]
+        local = (torch.arange(lo, hi) % 100).to(torch.int8).view(-1, 1, 1).expand(-1, 3, 3).contiguous()
+        out = D.gather_class_maps(local, counts, dst=0)
+        q.put((rank, hi - lo, None if out is None else out[:, 0, 0].numpy().copy()))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, traceback.format_exc(), None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_window_sharding_and_gather_order(world):
+    """The N>1 tile path without the network: contiguous window blocks per rank (8 ranks: 1 x 301 + 7 x 300), ragged gather to
+    rank 0 in window order."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert not isinstance(r[1], str), r[1]
+    sizes = [r[1] for r in res]
+    assert sum(sizes) == 2401 and max(sizes) - min(sizes) <= 1
+    if world == 8:
+        assert sorted(sizes) == [300] * 7 + [301]
+    assert all(r[2] is None for r in res[1:])
+    assert np.array_equal(res[0][2], (np.arange(2401) % 100).astype(np.int8))

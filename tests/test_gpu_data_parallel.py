@@ -43,8 +43,10 @@ def _batch(cfg, rank):
     return x, y.cuda()
 
 
-def _worker(rank, world, port, q, backend="gloo"):
+def _worker(rank, world, port, q, backend="gloo", mode="zero1"):
     import sys
+
+    os.environ["IG_DP_MODE"] = mode
 
     sys.path[:0] = [ROOT, os.path.join(ROOT, "instageo-e2e-geospatial-ml_amd")]
     local = str(rank) if backend == "nccl" else "0"  # RCCL: one rank per GPU; gloo: both ranks share cuda:0
@@ -61,6 +63,8 @@ def _worker(rank, world, port, q, backend="gloo"):
         if rank == 1:  # replicas start different: attach_data_parallel must broadcast rank 0's weights
             mod.net.store.flat.mul_(1.01)
         sync = D.attach_data_parallel(mod, bucket_bytes=1 << 20)
+        assert isinstance(sync, D.ShardedGradSync if mode == "zero1" else D.GradSync)
+        assert (mod.optimizer().m is None) == (mode == "zero1")  # sharded: no replicated moment buffers
         x, y = _batch(cfg, rank)
         for _ in range(2):
             mod.fused_train_step(x, y)
@@ -79,16 +83,17 @@ def _worker(rank, world, port, q, backend="gloo"):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("backend", ["gloo", "nccl"])
-def test_two_rank_fused_training_equals_manual_gradient_mean(backend):
+@pytest.mark.parametrize("backend,mode", [("gloo", "zero1"), ("gloo", "allreduce"), ("nccl", "zero1")])
+def test_two_rank_fused_training_equals_manual_gradient_mean(backend, mode):
     """backend "nccl" (= RCCL, one rank per GPU) runs where the box has >= 2 devices and is skipped on the 1-GPU test box; the
-    gloo variant exercises the same bucketing / hook / AdamW-scale code with both ranks on cuda:0."""
+    gloo variants exercise the same bucketing / hook / AdamW-scale code with both ranks on cuda:0.  mode "zero1" (the default):
+    reduce-scatter + AdamW on the owned half of every bucket + all-gather; "allreduce": the replicated optimizer."""
     if backend == "nccl" and torch.cuda.device_count() < 2:
         pytest.skip("RCCL variant needs two GPUs")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend, mode)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])

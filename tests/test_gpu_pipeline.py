@@ -392,7 +392,8 @@ def test_run_train_eval_on_csv_of_geotiffs(tmp_path, capsys):
         rows.append(f"chip_{i}.tif,lab_{i}.tif")
     (tmp_path / "set.csv").write_text("Input,Label\n" + "\n".join(rows) + "\n")
     common = ["model.model_name=prithvi_eo_tiny", "model.load_pretrained_weights=False", "train.batch_size=2", "train.ignore_index=-1",
-              "train.class_weights=[1,3]", f"root_dir={tmp_path}", "dataloader.constant_multiplier=0.0001", "dataloader.no_data_value=-9999"]
+              "train.class_weights=[1,3]", f"root_dir={tmp_path}", "dataloader.constant_multiplier=0.0001", "dataloader.no_data_value=-9999",
+              "dataloader.bands=[0,1,2,3,4,5]"]
     out = str(tmp_path / "out")
     assert run.main(["--output-dir", out, "mode=train", "train.num_epochs=1", "train_filepath=set.csv", "valid_filepath=set.csv",
                      "dataloader.img_size=224"] + common) == 0
