@@ -29,10 +29,22 @@
 
 namespace {
 
-constexpr int G8_HALF = 16384;    // one half-tile: 128 rows x 64 k
-constexpr int G8_BUF = 65536;     // A0 A1 B0 B1
-constexpr int G8_STAGE = 131072;  // epilogue staging: 8 waves x 4 KiB
-constexpr int G8_SMEM = 163840;
+// Geometry: WC column waves x 2 row groups; a wave owns (2 MT 16) x 64 of the (MT 64) x (WC 64) tile.  Two instances:
+//   MT = 4, WC = 4: 256 x 256, 8 waves, 160 KiB of LDS, one workgroup per CU            (the shapes with >= 128 such tiles)
+//   MT = 2, WC = 2: 128 x 128, 4 waves,  80 KiB of LDS, TWO workgroups per CU           (small batches: M = 16 x 197 rows leave
+//                   39-156 tiles of 256 x 256 for 256 CUs; the 128 x 128 tiles are 4 x as many and two workgroups share a CU)
+// In both, a half-tile is (MT WR 16 = WC 32) rows x 128 B and every wave issues TWO LDS-DMA instructions per half-tile, so the
+// barrier / vmcnt protocol is identical.
+template <int MT, int WC>
+struct G8Geo {
+    static_assert((MT == 4 && WC == 4) || (MT == 2 && WC == 2), "gemm8: 256 x 256 (MT 4, WC 4) or 128 x 128 (MT 2, WC 2)");
+    static constexpr int NW = 2 * WC, NTHR = 64 * NW;
+    static constexpr int BM = 2 * 2 * MT * 16, BN = WC * 64;
+    static constexpr int HALF = MT * 2 * 16 * 128;  // one half-tile: (BM / 2) rows x 64 k  ( == (BN / 2) x 64 k )
+    static constexpr int BUF = 4 * HALF;            // A0 A1 B0 B1
+    static constexpr int STAGE = 2 * BUF;           // epilogue staging: NW waves x 4 KiB
+    static constexpr int SMEM = STAGE + NW * 4096;
+};
 typedef __attribute__((address_space(3))) char* lds_char_ptr;
 
 // LDS-DMA with a scalar base + 32-bit per-lane offset (the K advance is one scalar add per issue)
@@ -56,13 +68,15 @@ struct Cur {  // issue cursor of one half-tile type (all wave-uniform)
 // reads, 3 = + no barriers, 4 = everything but the epilogue stores.  profiles/r02_v8_ablation_qkv.log: of 71 us (qkv, B = 108)
 // the epilogue is 13.7 (its 33 MB store burst per round sits in front of the next loads in the in-order vmcnt), LDS-DMA 10.2,
 // fragment reads 2.5, barriers 1.7 and the MFMAs themselves 43 us.
-template <int KIND, int NSEG, int ACT, bool DACT, bool SPLIT_OUT, int SCHED = 2, int DBG = 0>
-__global__ __launch_bounds__(512, 2) void gemm8_kernel(G8Params p) {
+template <int KIND, int NSEG, int ACT, bool DACT, bool SPLIT_OUT, int SCHED = 2, int DBG = 0, int MT = 4, int WC = 4>
+__global__ __launch_bounds__(128 * WC, 2) void gemm8_kernel(G8Params p) {
+    using Geo = G8Geo<MT, WC>;
+    constexpr int G8_HALF = Geo::HALF, G8_BUF = Geo::BUF, G8_STAGE = Geo::STAGE, BM = Geo::BM, BN = Geo::BN;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    const int tiles_n = p.N >> 8, tiles_m = (p.M + 255) >> 8, ntiles = tiles_m * tiles_n;
+    const int wr = wave / WC, wc = wave % WC;
+    const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM, ntiles = tiles_m * tiles_n;
     // persistent, XCD-aware: workgroups are dealt round-robin over the 8 XCDs; XCD x owns a contiguous tile range
     const int nb = gridDim.x, xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
     const int nbx = (nb >> 3) + (xcd < (nb & 7) ? 1 : 0);
@@ -78,10 +92,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(G8Params p) {
 
     // fragment read offsets inside a half-tile (k-substep 1: ^ 64)
     const int sw = ((lane >> 4) ^ (lane & 7)) << 4;
-    const int aoff = (wr * 64 + (lane & 15)) * 128 + sw;
+    const int aoff = (wr * (MT * 16) + (lane & 15)) * 128 + sw;
     const int boff = 2 * G8_HALF + (wc * 32 + (lane & 15)) * 128 + sw;
     // LDS-DMA lane constants: LDS row of instruction i of this wave = wave*16 + i*8 + (lane >> 3)
-    const int rbaseA = (wave >> 2) * 128 + (wave & 3) * 16 + (lane >> 3);  // + h*64 + i*8  -> tile row
+    const int rbaseA = ((16 * wave) / (MT * 16)) * (2 * MT * 16) + (16 * wave) % (MT * 16) + (lane >> 3);  // + h*MT*16 + i*8  -> tile row
     const int rbaseB = (wave >> 1) * 64 + (wave & 1) * 16 + (lane >> 3);   // + g*32 + i*8  -> tile column
     const int c16 = ((lane & 7) ^ (lane >> 3)) << 4;
     const unsigned ldsw = lds_base + wave * 2048;
@@ -94,12 +108,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(G8Params p) {
         const int s_ = NSEG == 1 ? 0 : (C).seg;                                             \
         if (ISA) {                                                                          \
             const bf16_t* b_ = s_ == 0 ? p.a[0] : s_ == 1 ? p.a[1] : p.a[2];                \
-            (C).base = (const char*)b_ + (long)bm_ * 256 * lda2;                            \
-            (C).vr = min(256, p.M - bm_ * 256);                                             \
+            (C).base = (const char*)b_ + (long)bm_ * BM * lda2;                             \
+            (C).vr = min(BM, p.M - bm_ * BM);                                               \
         } else {                                                                            \
             const bf16_t* b_ = s_ == 0 ? p.b[0] : s_ == 1 ? p.b[1] : p.b[2];                \
-            (C).base = (const char*)b_ + (long)bn_ * 256 * ldb2;                            \
-            (C).vr = 256;                                                                   \
+            (C).base = (const char*)b_ + (long)bn_ * BN * ldb2;                             \
+            (C).vr = BN;                                                                    \
         }                                                                                   \
     }
 #define G8_INIT(C, ISA)                                        \
@@ -111,7 +125,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(G8Params p) {
 #define G8_ISSUE(C, ISA, HG, BUF)                                                                              \
     if ((DBG == 0 || DBG == 4 || !in_loop) && (C).left > 0) {                                                                                        \
         _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                     \
-            int row_ = ((ISA) ? rbaseA + (HG)*64 : rbaseB + (HG)*32) + i_ * 8;                                 \
+            int row_ = ((ISA) ? rbaseA + (HG)*(MT * 16) : rbaseB + (HG)*32) + i_ * 8;                          \
             row_ = min(row_, (C).vr - 1);                                                                      \
             const unsigned voff_ = (unsigned)(__mul24(row_, (ISA) ? lda2 : ldb2) + c16);                       \
             glds16_s(voff_, (C).base, ldsw + (BUF)*G8_BUF + ((ISA) ? 0 : 2 * G8_HALF) + (HG)*G8_HALF + i_ * 1024); \
@@ -128,7 +142,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(G8Params p) {
         }                                                                                                      \
     }
 
-    f32x4 acc[2][2][2][4];  // [h][g][nt][mt]
+    f32x4 acc[2][2][2][MT];  // [h][g][nt][mt]
     f32x4 binit[2][2];      // accumulator init = bias in MFMA layout (4 consecutive n per lane)
     int tile_c = tlo + jx;
 #define G8_LOAD_BIAS(TILE)                                                                                       \
@@ -136,7 +150,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(G8Params p) {
         const int bn_ = (TILE) % tiles_n;                                                                        \
         _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_) _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_) {   \
             if (p.bias) {                                                                                        \
-                const float4 b4_ = *reinterpret_cast<const float4*>(p.bias + bn_ * 256 + wc * 64 + g_ * 32 + nt_ * 16 + 4 * (lane >> 4)); \
+                const float4 b4_ = *reinterpret_cast<const float4*>(p.bias + bn_ * BN + wc * 64 + g_ * 32 + nt_ * 16 + 4 * (lane >> 4)); \
                 binit[g_][nt_] = f32x4{b4_.x, b4_.y, b4_.z, b4_.w};                                              \
             } else {                                                                                             \
                 binit[g_][nt_] = f32x4{0.f, 0.f, 0.f, 0.f};                                                      \
@@ -145,7 +159,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(G8Params p) {
     }
 #define G8_INIT_ACC()                                                                                            \
     _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_)            \
-        _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_) _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_)  \
+        _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_) _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_) \
             acc[h_][g_][nt_][mt_] = binit[g_][nt_];
     G8_LOAD_BIAS(tile_c)
     G8_INIT_ACC()
@@ -165,9 +179,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(G8Params p) {
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
 
-    bf16x8_t af[4][2], bf0[2][2], bf1[2][2];
+    bf16x8_t af[MT][2], bf0[2][2], bf1[2][2];
 #define G8_READ_A(BUF, H)                                                                                          \
-    if (DBG < 2 || DBG == 4 || !in_loop) _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) \
+    if (DBG < 2 || DBG == 4 || !in_loop) _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) \
         af[mt_][s_] = *reinterpret_cast<const bf16x8_t*>(smem + (BUF)*G8_BUF + (H)*G8_HALF + mt_ * 2048 + (aoff ^ (s_ * 64)));
 #define G8_READ_B(BUF, G, DST)                                                                                     \
     if (DBG < 2 || DBG == 4 || !in_loop) _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) \
@@ -177,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(G8Params p) {
         asm volatile("s_barrier" ::: "memory");                                                                    \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
         __builtin_amdgcn_s_setprio(1);                                                                             \
-        _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_) _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_)    \
+        _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_) _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_)   \
             _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                       \
                 acc[H][G][nt_][mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BSRC[nt_][s_], af[mt_][s_], acc[H][G][nt_][mt_], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                             \
@@ -191,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(G8Params p) {
         if (DBG != 3) asm volatile("s_barrier" ::: "memory");                                                      \
         __builtin_amdgcn_s_setprio(1);                                                                             \
         _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_) _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_)       \
-            _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)   \
+            _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)  \
                 acc[H][g_][nt_][mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g_ ? bf1[nt_][s_] : bf0[nt_][s_], af[mt_][s_], acc[H][g_][nt_][mt_], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                             \
         if (DBG != 3) asm volatile("s_barrier" ::: "memory");                                                      \
@@ -288,7 +302,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(G8Params p) {
         if (!last) G8_LOAD_BIAS(tile_c)  // next tile's accumulator init: in flight during the epilogue
         char* st = smem + G8_STAGE + wave * 4096;
         const int erow = lane & 15, eq = lane >> 4;
-        const int n0 = bn * 256 + wc * 64;
+        const int n0 = bn * BN + wc * 64;
         if constexpr (DBG == 4) {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -297,15 +311,15 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(G8Params p) {
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                        for (int mt = 0; mt < 4; ++mt) asm volatile("" ::"v"(acc[h][g][nt][mt]));
+                        for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(acc[h][g][nt][mt]));
         } else if constexpr (KIND == 0) {
             // bf16 (split) store of act(acc): two 2 KiB staging slots (16 rows x 64 bf16, chunk ^= row & 7)
             const int rrow = lane >> 3, rch = ((lane & 7) ^ (lane >> 3)) << 4, rcol = (lane & 7) * 8;
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    const int m0 = bm * 256 + wr * 128 + h * 64 + mt * 16;
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int m0 = bm * BM + wr * (2 * MT * 16) + h * (MT * 16) + mt * 16;
                     uint2 po[2][2], pd[2][2], pol[2][2], pdl[2][2];
 #pragma unroll
                     for (int g = 0; g < 2; ++g)
@@ -373,8 +387,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(G8Params p) {
             const int rrow = lane >> 3, rcol = (lane & 7) * 8;
             float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             constexpr int PF = SPLIT_OUT ? 2 : 4;  // row tiles per batch of factor loads (16 / 32 registers of hi [+ lo] words)
+            constexpr int NRT = 2 * MT;            // row tiles of a wave: t -> (h, mt) = (t / MT, t % MT)
 #pragma unroll
-            for (int bt = 0; bt < 8 / PF; ++bt) {
+            for (int bt = 0; bt < NRT / PF; ++bt) {
                 // the factor loads of a batch go out FIRST: interleaved with the stores below, every load sat behind the previous
                 // row tile's stores in the in-order vmcnt and its latency was paid 16 times per tile
                 uint4 fh[PF][2], fl[PF][2];
@@ -383,15 +398,15 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(G8Params p) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         const int t = bt * PF + j;
-                        const int m = min(bm * 256 + wr * 128 + (t >> 2) * 64 + (t & 3) * 16 + i * 8 + rrow, p.M - 1);
+                        const int m = min(bm * BM + wr * (2 * MT * 16) + (t / MT) * (MT * 16) + (t % MT) * 16 + i * 8 + rrow, p.M - 1);
                         const size_t o = (size_t)m * p.ldo + n0 + rcol;
                         fh[j][i] = *reinterpret_cast<const uint4*>(p.dact_hi + o);
                         if constexpr (SPLIT_OUT) fl[j][i] = *reinterpret_cast<const uint4*>(p.dact_lo + o);
                     }
 #pragma unroll
                 for (int j = 0; j < PF; ++j) {
-                    const int t = bt * PF + j, h = t >> 2, mt = t & 3;
-                    const int m0 = bm * 256 + wr * 128 + h * 64 + mt * 16;
+                    const int t = bt * PF + j, h = t / MT, mt = t % MT;
+                    const int m0 = bm * BM + wr * (2 * MT * 16) + h * (MT * 16) + mt * 16;
 #pragma unroll
                     for (int g = 0; g < 2; ++g)
 #pragma unroll
@@ -449,15 +464,15 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(G8Params p) {
             float4 rs[2][4];
 #define G8_RESID_LOAD(T, DST)                                                                                              \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                                     \
-        const int m_ = min(bm * 256 + wr * 128 + ((T) >> 2) * 64 + ((T)&3) * 16 + i_ * 4 + rrow, p.M - 1);                 \
+        const int m_ = min(bm * BM + wr * (2 * MT * 16) + ((T) / MT) * (MT * 16) + ((T) % MT) * 16 + i_ * 4 + rrow, p.M - 1); \
         DST[i_] = *reinterpret_cast<const float4*>(p.resid + (size_t)m_ * p.ldo + n0 + rc * 4);                            \
     }
             G8_RESID_LOAD(0, rs[0])
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int h = t >> 2, mt = t & 3;
-                const int m0 = bm * 256 + wr * 128 + h * 64 + mt * 16;
-                if (t + 1 < 8) G8_RESID_LOAD(t + 1, rs[(t + 1) & 1])
+            for (int t = 0; t < 2 * MT; ++t) {
+                const int h = t / MT, mt = t % MT;
+                const int m0 = bm * BM + wr * (2 * MT * 16) + h * (MT * 16) + mt * 16;
+                if (t + 1 < 2 * MT) G8_RESID_LOAD(t + 1, rs[(t + 1) & 1])
 #pragma unroll
                 for (int g = 0; g < 2; ++g)
 #pragma unroll
@@ -499,26 +514,30 @@ inline int g8_env() {
     return e ? atoi(e) : 1;
 }
 
-template <int KIND, int NSEG, int ACT, bool DACT, bool SPLIT_OUT, int SCHED = 1, int DBG = 0>
+template <int KIND, int NSEG, int ACT, bool DACT, bool SPLIT_OUT, int SCHED = 1, int DBG = 0, int MT = 4, int WC = 4>
 int g8_launch_v(const G8Params& p, int grid, hipStream_t st) {
-    auto kern = gemm8_kernel<KIND, NSEG, ACT, DACT, SPLIT_OUT, SCHED, DBG>;
+    using Geo = G8Geo<MT, WC>;
+    auto kern = gemm8_kernel<KIND, NSEG, ACT, DACT, SPLIT_OUT, SCHED, DBG, MT, WC>;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G8_SMEM) != hipSuccess) {
-            ig_set_error("gemm8: could not reserve %d bytes of LDS", G8_SMEM);
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Geo::SMEM) != hipSuccess) {
+            ig_set_error("gemm8: could not reserve %d bytes of LDS", Geo::SMEM);
             return IG_ERR_HIP;
         }
         attr_done = true;
     }
-    ig_note_kernel("gemm8_kernel<%d,%d,%d,%s,%s,%d,%d>", KIND, NSEG, ACT, DACT ? "true" : "false", SPLIT_OUT ? "true" : "false", SCHED, DBG);
+    if (MT == 4) ig_note_kernel("gemm8_kernel<%d,%d,%d,%s,%s,%d,%d>", KIND, NSEG, ACT, DACT ? "true" : "false", SPLIT_OUT ? "true" : "false", SCHED, DBG);
+    else ig_note_kernel("gemm8_kernel<%d,%d,%d,%s,%s,%d,%d,%d,%d>", KIND, NSEG, ACT, DACT ? "true" : "false", SPLIT_OUT ? "true" : "false", SCHED, DBG, MT, WC);
     ig_note_grid(grid);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), G8_SMEM, st, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(Geo::NTHR), Geo::SMEM, st, p);
     return ig_check_launch("gemm8");
 }
 
-// IG_G8_SCHED = 0 selects the 16-MFMA-phase schedule (A/B runs); with -DIG_G8_ABLATE, IG_G8_DBG = 1..4 the timing ablations
+// small = the 128 x 128 instance (two workgroups per CU).  IG_G8_SCHED = 0 selects the 16-MFMA-phase schedule of the 256 x 256
+// instance (A/B runs); with -DIG_G8_ABLATE, IG_G8_DBG = 1..4 the timing ablations
 template <int KIND, int NSEG, int ACT, bool DACT, bool SPLIT_OUT>
-int g8_launch(const G8Params& p, int grid, hipStream_t st) {
+int g8_launch(const G8Params& p, int grid, hipStream_t st, bool small) {
+    if (small) return g8_launch_v<KIND, NSEG, ACT, DACT, SPLIT_OUT, 2, 0, 2, 2>(p, grid, st);
     const char* e = getenv("IG_G8_SCHED");
     const int sched = e ? atoi(e) : 2;
 #ifdef IG_G8_ABLATE
@@ -541,15 +560,22 @@ int g8_launch(const G8Params& p, int grid, hipStream_t st) {
 int ig_gemm8_nt(const G8Params& p, void* stream) {
     if (!g8_env()) return IG_ERR_UNSUPPORTED;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return IG_ERR_UNSUPPORTED;
-    if ((p.K & 127) || (p.N & 255)) return IG_ERR_UNSUPPORTED;
+    if ((p.K & 127) || (p.N & 127)) return IG_ERR_UNSUPPORTED;
     if (p.lda * 2 * 256 >= (1L << 24) || p.ldb * 2 * 256 >= (1L << 24)) return IG_ERR_UNSUPPORTED;  // 24-bit offset multiply
-    const int ntiles = ((p.M + 255) >> 8) * (p.N >> 8);
+    const int ntiles256 = (p.N & 255) ? 0 : ((p.M + 255) >> 8) * (p.N >> 8);
     const int min_tiles = getenv("IG_GEMM8_MIN_TILES") ? atoi(getenv("IG_GEMM8_MIN_TILES")) : 128;
-    // small problems: the 256 x 256 tile leaves CUs idle.  Threshold swept on the whole step: 128 beats 192 at the YAML's batch 16
-    // (117-156 tiles: 1707 -> 1770 chips/s) and for the 300M model at B = 54 (168 tiles: 1200 -> 1279), neutral at B = 32 / 48 / 108;
-    // 96 starts to lose at B = 48
-    if (ntiles < min_tiles && g8_env() != 2) return IG_ERR_UNSUPPORTED;
-    const int grid = ig_tile_grid(ntiles, 1);
+    // The 256 x 256 instance needs enough tiles for one workgroup per CU.  Threshold swept on the whole step: 128 beats 192 at the
+    // YAML's batch 16 (117-156 tiles: 1707 -> 1770 chips/s) and for the 300M model at B = 54 (168 tiles: 1200 -> 1279), neutral at
+    // B = 32 / 48 / 108; 96 starts to lose at B = 48.  Below it (and for N = 128 mod 256) the 128 x 128 instance takes over: four
+    // times the tiles, two workgroups per CU (IG_GEMM8_SMALL=0: back to the round-1 engines for those shapes).
+    bool small = false;
+    if (ntiles256 < min_tiles && g8_env() != 2) {
+        const char* e = getenv("IG_GEMM8_SMALL");
+        if (e && atoi(e) == 0) return IG_ERR_UNSUPPORTED;
+        small = true;
+    }
+    const int ntiles = small ? ((p.M + 127) >> 7) * (p.N >> 7) : ntiles256;
+    const int grid = ig_tile_grid(ntiles, small ? 2 : 1);
     hipStream_t st = (hipStream_t)stream;
     const bool split_in = p.nseg == 3;
     if (p.kind == 0) {
@@ -558,22 +584,22 @@ int ig_gemm8_nt(const G8Params& p, void* stream) {
         if (split_in != split_out) return IG_ERR_UNSUPPORTED;
         if (p.act == 0 && dact) return IG_ERR_UNSUPPORTED;
         if (!split_in) {
-            if (p.act == 0) return g8_launch<0, 1, 0, false, false>(p, grid, st);
-            if (!dact) return g8_launch<0, 1, 1, false, false>(p, grid, st);
-            return g8_launch<0, 1, 1, true, false>(p, grid, st);
+            if (p.act == 0) return g8_launch<0, 1, 0, false, false>(p, grid, st, small);
+            if (!dact) return g8_launch<0, 1, 1, false, false>(p, grid, st, small);
+            return g8_launch<0, 1, 1, true, false>(p, grid, st, small);
         }
-        if (p.act == 0) return g8_launch<0, 3, 0, false, true>(p, grid, st);
-        if (!dact) return g8_launch<0, 3, 1, false, true>(p, grid, st);
-        return g8_launch<0, 3, 1, true, true>(p, grid, st);
+        if (p.act == 0) return g8_launch<0, 3, 0, false, true>(p, grid, st, small);
+        if (!dact) return g8_launch<0, 3, 1, false, true>(p, grid, st, small);
+        return g8_launch<0, 3, 1, true, true>(p, grid, st, small);
     }
     if (p.kind == 1) {
-        if (!split_in) return g8_launch<1, 1, 0, false, false>(p, grid, st);
-        return g8_launch<1, 3, 0, false, false>(p, grid, st);
+        if (!split_in) return g8_launch<1, 1, 0, false, false>(p, grid, st, small);
+        return g8_launch<1, 3, 0, false, false>(p, grid, st, small);
     }
     if (p.kind == 2) {
         if (!p.dact_hi || (split_in != (p.out_lo != nullptr)) || (split_in != (p.dact_lo != nullptr))) return IG_ERR_UNSUPPORTED;
-        if (!split_in) return g8_launch<2, 1, 0, false, false>(p, grid, st);
-        return g8_launch<2, 3, 0, false, true>(p, grid, st);
+        if (!split_in) return g8_launch<2, 1, 0, false, false>(p, grid, st, small);
+        return g8_launch<2, 3, 0, false, true>(p, grid, st, small);
     }
     return IG_ERR_UNSUPPORTED;
 }
