@@ -161,6 +161,16 @@ int ig_conv3x3_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, con
  * input channels: an all-ones MFMA operand against the dy fragments), one column-sum pass otherwise */
 int ig_conv3x3_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const void* x_lo, float* dw, float* dbias, int B, int H,
                      int W, int Cin, int Cout, void* stream);
+/* nn.Conv2d(kernel_size=KS, padding=1) for odd KS in 3..9: the 5 x 5 / 7 x 7 convolutions of the 600M variants' decode head
+ * (model.py:169-177 seg_head_kernel_sizes, :370-375).  NHWC, weights Wc[Cout][KS*KS][Cin]; x is (B,H,W,Cin), y / dy are
+ * (B,Ho,Wo,Cout) with Ho = H + 3 - KS, Wo = W + 3 - KS.  bn_scale / bn_shift as in ig_conv3x3_fwd. */
+int ig_convk_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias, const float* bn_scale,
+                 const float* bn_shift, void* y_hi, void* y_lo, int B, int H, int W, int Cin, int Cout, int KS, void* stream);
+int ig_convk_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, const void* w_lo, void* dx_hi, void* dx_lo, int B,
+                   int H, int W, int Cin, int Cout, int KS, unsigned drop_seed, const unsigned* drop_seed_dev, float drop_p,
+                   void* stream);
+int ig_convk_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const void* x_lo, float* dw, float* dbias, int B, int H,
+                   int W, int Cin, int Cout, int KS, void* stream);
 /* nn.BatchNorm2d + nn.ReLU on [M][C] (M = B*H*W)                                                      :376-377 */
 int ig_bn_relu_fwd(const void* x_hi, const void* x_lo, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, void* y_hi, void* y_lo, float* scale, float* shift, float* mean, float* rstd,

@@ -9,6 +9,8 @@
 // trip); the transposed operands (V^T, K^T, dO^T, Q^T) come from ds_read_b64_tr_b16 on the row-major LDS tile.
 // N = 197 / 589 tokens are handled by zero-filled tails and -inf / +inf masks.
 // SPLIT=true is the bf16x3 precision mode (hi*hi + hi*lo + lo*hi).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -486,6 +488,11 @@ inline void wave_geometry(int N, int& nblk, int& nw) {
     nw = (tiles + nblk - 1) / nblk;
 }
 
+inline bool attn_generic_env() {  // read per call (tests flip it)
+    const char* e = getenv("IG_ATTN_GENERIC");
+    return e && atoi(e) != 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -494,9 +501,11 @@ extern "C" {
 int ig_attention_fwd(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, float* lse, int B, int N, int H,
                      int head_dim, void* stream) {
     IG_REQUIRE(qkv_hi && out_hi, "ig_attention_fwd: null pointer");
-    IG_REQUIRE(head_dim == HD, "ig_attention_fwd: head_dim must be 64 (got %d)", head_dim);
+    IG_REQUIRE(head_dim == HD || head_dim == 80, "ig_attention_fwd: head_dim must be 64 or 80 (got %d)", head_dim);
     IG_REQUIRE((qkv_lo == nullptr) == (out_lo == nullptr), "ig_attention_fwd: split pointers must be given for all tensors or none");
     if (B == 0 || N == 0) return IG_OK;
+    if (head_dim != HD || attn_generic_env())  // 600M variants (16 heads of 80), or IG_ATTN_GENERIC=1 (tests, A/B)
+        return ig_attention_generic_fwd(qkv_hi, qkv_lo, out_hi, out_lo, lse, B, N, H, head_dim, stream);
     {
         const int rc = ig_attention2_fwd(qkv_hi, qkv_lo, out_hi, out_lo, lse, B, N, H, stream);
         if (rc != IG_ERR_UNSUPPORTED) return rc;
@@ -522,11 +531,13 @@ int ig_attention_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi,
                      const void* dout_lo, const float* lse, float* delta, void* dqkv_hi, void* dqkv_lo, int B, int N, int H,
                      int head_dim, void* stream) {
     IG_REQUIRE(qkv_hi && out_hi && dout_hi && lse && delta && dqkv_hi, "ig_attention_bwd: null pointer");
-    IG_REQUIRE(head_dim == HD, "ig_attention_bwd: head_dim must be 64 (got %d)", head_dim);
+    IG_REQUIRE(head_dim == HD || head_dim == 80, "ig_attention_bwd: head_dim must be 64 or 80 (got %d)", head_dim);
     bool split = qkv_lo != nullptr;
     IG_REQUIRE(split == (out_lo != nullptr) && split == (dout_lo != nullptr) && split == (dqkv_lo != nullptr),
                "ig_attention_bwd: split pointers must be given for all tensors or none");
     if (B == 0 || N == 0) return IG_OK;
+    if (head_dim != HD || attn_generic_env())
+        return ig_attention_generic_bwd(qkv_hi, qkv_lo, out_hi, out_lo, dout_hi, dout_lo, lse, delta, dqkv_hi, dqkv_lo, B, N, H, head_dim, stream);
     {
         const int rc = ig_attention2_bwd(qkv_hi, qkv_lo, out_hi, out_lo, dout_hi, dout_lo, lse, delta, dqkv_hi, dqkv_lo, B, N, H, stream);
         if (rc != IG_ERR_UNSUPPORTED) return rc;

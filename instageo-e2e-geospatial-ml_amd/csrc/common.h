@@ -60,6 +60,12 @@ int ig_wgrad8_group(int n, const void* const* dy_hi, const void* const* dy_lo, c
 int ig_attention2_fwd(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, float* lse, int B, int N, int H, void* stream);
 int ig_attention2_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi, const void* out_lo, const void* dout_hi,
                       const void* dout_lo, const float* lse, float* delta, void* dqkv_hi, void* dqkv_lo, int B, int N, int H, void* stream);
+// attention_g.hip: any head dimension that is a multiple of 16 (instantiated: 80 for the 600M variants, 64 for A/B runs)
+int ig_attention_generic_fwd(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, float* lse, int B, int N, int H,
+                             int head_dim, void* stream);
+int ig_attention_generic_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi, const void* out_lo, const void* dout_hi,
+                             const void* dout_lo, const float* lse, float* delta, void* dqkv_hi, void* dqkv_lo, int B, int N, int H,
+                             int head_dim, void* stream);
 // runtime.hip: name of the kernel an entry point launched last on this thread (rocprofv3's demangled name without namespaces and
 // spaces), so bench.py can key its per-kernel roofline table by the names the rocprof summaries under profiles/ use
 void ig_note_kernel(const char* fmt, ...);

@@ -202,6 +202,33 @@ __global__ void patchify_kernel(const float* __restrict__ img, bf16_t* __restric
     }
 }
 
+// any patch size with C p p a multiple of 8 (the 600M variants' patch 14: 8-element units straddle image rows): per-element decode
+__global__ void patchify_generic_kernel(const float* __restrict__ img, bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo,
+                                        int C, int T, int H, int W, int p, int gh, int gw, long units) {
+    const int Kp = C * p * p;
+    for (long u = blockIdx.x * (long)blockDim.x + threadIdx.x; u < units; u += (long)gridDim.x * blockDim.x) {
+        const long e = u * 8;
+        const long row = e / Kp;
+        const int k0 = (int)(e - row * Kp);
+        long tok = row;
+        const int px = (int)(tok % gw);
+        tok /= gw;
+        const int py = (int)(tok % gh);
+        tok /= gh;
+        const int t = (int)(tok % T);
+        const long b = tok / T;
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + j;
+            const int c = k / (p * p), rem = k - c * p * p;
+            const int iy = rem / p, ix = rem - iy * p;
+            f[j] = img[(((b * C + c) * T + t) * H + (py * p + iy)) * (long)W + px * p + ix];
+        }
+        store8_split(out_hi, out_lo, (size_t)e, f);
+    }
+}
+
 // cls rows: x[b][0][:] = cls + pos[0]   (pritvhi.py:520-522)
 __global__ void cls_rows_kernel(float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos, int B,
                                 long row_stride, int D) {
@@ -1062,12 +1089,16 @@ int ig_label_hist(const float* labels, unsigned long long* counts, long n, int l
 
 int ig_patchify(const float* img, void* out_hi, void* out_lo, int B, int C, int T, int H, int W, int p, void* stream) {
     IG_REQUIRE(img && out_hi, "ig_patchify: null pointer");
-    IG_REQUIRE(p % 8 == 0 && W % 4 == 0, "ig_patchify: patch size must be a multiple of 8 and W of 4 (p=%d W=%d)", p, W);
+    IG_REQUIRE(p > 0 && (C * p * p) % 8 == 0, "ig_patchify: C * p * p must be a multiple of 8 (C=%d p=%d)", C, p);
     int gh = H / p, gw = W / p;
     long units = (long)B * T * gh * gw * C * p * p / 8;
     if (units == 0) return IG_OK;
-    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(units, TPB, 16384)), dim3(TPB), 0, ST(stream), img, (bf16_t*)out_hi,
-                       (bf16_t*)out_lo, C, T, H, W, p, gh, gw, units);
+    if (p % 8 == 0 && W % 4 == 0)
+        hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(units, TPB, 16384)), dim3(TPB), 0, ST(stream), img, (bf16_t*)out_hi,
+                           (bf16_t*)out_lo, C, T, H, W, p, gh, gw, units);
+    else  // patch 14 (600M variants): 8-element units straddle image rows
+        hipLaunchKernelGGL(patchify_generic_kernel, dim3(grid_for(units, TPB, 16384)), dim3(TPB), 0, ST(stream), img, (bf16_t*)out_hi,
+                           (bf16_t*)out_lo, C, T, H, W, p, gh, gw, units);
     return ig_check_launch("ig_patchify");
 }
 

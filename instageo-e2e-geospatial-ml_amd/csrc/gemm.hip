@@ -1006,6 +1006,43 @@ struct Conv3Loader {
     __device__ const bf16_t* ptr(int seg, int r, int c8, bool& ok) const { return ptr_tr(seg, r, col(c8), ok); }
 };
 
+// NHWC KS x KS convolution with padding 1 (nn.Conv2d(kernel_size=KS, padding=1), model.py:370-375 with the 600M variants'
+// kernel sizes 5 / 7, model.py:169-177): the output grid is (H + 3 - KS)^2, so rows and source live on DIFFERENT grids.
+//   sign = +1: row = output pixel (b, yo, xo) on (Hr, Wr), reads x(yo + ky - 1, xo + kx - 1) on (Hs, Ws)   (forward, wgrad input)
+//   sign = -1: row = input pixel (b, yi, xi) on (Hr, Wr), reads dy(yi + 1 - ky, xi + 1 - kx) on (Hs, Ws)   (dgrad)
+// Column unit -> (tap = ky KS + kx, channel).  Validity is tested per unit from the row's (y, x) (no tap mask: 49 taps).
+struct ConvKLoader {
+    static constexpr const char* kName = "ConvKLoader";
+    static constexpr bool kLinearK = false;
+    __device__ long kstride() const { return 0; }
+    const bf16_t* base[3];
+    int Mtot, Hr, Wr, Hs, Ws, C, KS, sign;
+    FDiv f_hw, f_w, f_c, f_ks;
+    void finish() { f_hw = make_fdiv(Hr * Wr), f_w = make_fdiv(Wr), f_c = make_fdiv(C), f_ks = make_fdiv(KS); }
+    __device__ void init(int) {}
+    __device__ int kdim() const { return -1; }
+    struct Row { long off; int y, x; bool ok; };
+    struct Col { int dy, dx, c; bool ok; };
+    __device__ Row row(int r) const {
+        const int b = f_hw.div(r), rem = r - b * (Hr * Wr);
+        const int y = f_w.div(rem), x = rem - y * Wr;
+        return Row{(long)b * Hs * Ws * C, y, x, r < Mtot};
+    }
+    __device__ Col col(int c8) const {
+        const int k = c8 * 8;
+        const int tap = f_c.div(k), c = k - tap * C;
+        const int ky = f_ks.div(tap), kx = tap - ky * KS;
+        return Col{sign * (ky - 1), sign * (kx - 1), c, k < KS * KS * C};
+    }
+    __device__ const bf16_t* at(int seg, const Row& rw, const Col& cl, bool& ok) const {
+        const int ys = rw.y + cl.dy, xs = rw.x + cl.dx;
+        ok = rw.ok & cl.ok & ((unsigned)ys < (unsigned)Hs) & ((unsigned)xs < (unsigned)Ws);
+        return bsel(base, seg) + (ok ? rw.off + ((long)ys * Ws + xs) * C + cl.c : 0L);
+    }
+    __device__ const bf16_t* ptr_tr(int seg, int r, const Col& cl, bool& ok) const { return at(seg, row(r), cl, ok); }
+    __device__ const bf16_t* ptr(int seg, int r, int c8, bool& ok) const { return at(seg, row(r), col(c8), ok); }
+};
+
 // ConvTranspose2d(k3,s2,p1,op1) forward, sub-pixel phase z=(py,px): output (2iy+py, 2ix+px) reads taps
 // ky in {1} (py=0) or {0,2} (py=1); tap ky==0 reads input row iy+1, otherwise iy (same for x).
 struct ConvTFwdALoader {
@@ -1090,6 +1127,7 @@ struct ConvWgtTRLoader {
     __device__ long kstride() const { return 0; }
     const bf16_t* base[3];
     int Cout, Cin;
+    int ntaps = 9;  // 3 x 3; 25 / 49 for the 5 x 5 / 7 x 7 convolutions of the 600M head (ig_convk_*)
     FDiv f_co;  // set by finish()
     void finish() { f_co = make_fdiv(Cout); }
     __device__ void init(int) {}
@@ -1097,8 +1135,8 @@ struct ConvWgtTRLoader {
     __device__ const bf16_t* ptr(int seg, int r, int c8, bool& ok) const {
         int c = c8 * 8;
         int tap = f_co.div(r), co = r - tap * Cout;
-        ok = (tap < 9) & (c < Cin);
-        return bsel(base, seg) + (ok ? ((long)co * 9 + tap) * Cin + c : 0L);
+        ok = (tap < ntaps) & (c < Cin);
+        return bsel(base, seg) + (ok ? ((long)co * ntaps + tap) * Cin + c : 0L);
     }
     // (row, column) decode split: the K loop re-uses a row decode across K-steps and a column decode across rows
     struct Row { int r; };
@@ -1933,6 +1971,77 @@ int ig_conv3x3_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, con
     return launch_gemm<PlainLoader, Conv3Loader, EpAtomic, true, true>(
         plain_a(dy_hi, dy_lo, Mtot, Cout, Cout), bl, ep, Cout, 9 * Cin, Mtot, 1, dy_lo != nullptr, (hipStream_t)stream,
         "ig_conv3x3_wgrad", true, 1);
+}
+
+// ---- nn.Conv2d(kernel_size=KS, padding=1), KS odd >= 3, NHWC, weight storage Wc[Cout][KS*KS][Cin]: the 5 x 5 / 7 x 7 convolutions of
+// the 600M variants' decode head (model.py:169-177, 370-375).  x (B,H,W,Cin) -> y (B,Ho,Wo,Cout), Ho = H + 3 - KS. ----
+int ig_convk_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias, const float* bn_scale,
+                 const float* bn_shift, void* y_hi, void* y_lo, int B, int H, int W, int Cin, int Cout, int KS, void* stream) {
+    IG_REQUIRE(x_hi && w_hi && y_hi, "ig_convk_fwd: null pointer");
+    IG_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, "ig_convk_fwd: channels must be multiples of 8");
+    IG_REQUIRE(KS >= 3 && (KS & 1) && KS <= 9 && H + 3 - KS > 0 && W + 3 - KS > 0, "ig_convk_fwd: kernel size %d does not fit a %d x %d input", KS, H, W);
+    IG_SPLIT_CONSISTENT(x_lo, w_lo);
+    IG_REQUIRE((x_lo == nullptr) == (y_lo == nullptr), "ig_convk_fwd: input and output must both be split or both plain");
+    IG_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "ig_convk_fwd: bn_scale and bn_shift go together");
+    const int Ho = H + 3 - KS, Wo = W + 3 - KS;
+    ConvKLoader al{};
+    seg_a(al.base, x_hi, x_lo);
+    al.Mtot = B * Ho * Wo, al.Hr = Ho, al.Wr = Wo, al.Hs = H, al.Ws = W, al.C = Cin, al.KS = KS, al.sign = 1;
+    al.finish();
+    EpStore ep{};
+    ep.out_hi = (bf16_t*)y_hi, ep.out_lo = (bf16_t*)y_lo, ep.bias = bias, ep.ldo = Cout;
+    ep.col_scale = bn_scale, ep.col_shift = bn_shift;
+    return launch_gemm<ConvKLoader, PlainLoader, EpStore, false, false>(
+        al, plain_b(w_hi, w_lo, Cout, KS * KS * Cin, (long)KS * KS * Cin), ep, al.Mtot, Cout, KS * KS * Cin, 1, x_lo != nullptr,
+        (hipStream_t)stream, "ig_convk_fwd", false, 1);
+}
+
+// dx (B,H,W,Cin) = conv_dgrad(dy (B,Ho,Wo,Cout), w) [* dropout mask of the conv input when drop_p > 0]
+int ig_convk_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, const void* w_lo, void* dx_hi, void* dx_lo, int B, int H,
+                   int W, int Cin, int Cout, int KS, unsigned drop_seed, const unsigned* drop_seed_dev, float drop_p, void* stream) {
+    IG_REQUIRE(dy_hi && w_hi && dx_hi, "ig_convk_dgrad: null pointer");
+    IG_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, "ig_convk_dgrad: channels must be multiples of 8");
+    IG_REQUIRE(KS >= 3 && (KS & 1) && KS <= 9 && H + 3 - KS > 0 && W + 3 - KS > 0, "ig_convk_dgrad: kernel size %d does not fit a %d x %d input", KS, H, W);
+    IG_SPLIT_CONSISTENT(dy_lo, w_lo);
+    IG_REQUIRE(drop_p <= 0.f || (double)B * H * W * Cin < 4294967296.0, "ig_convk_dgrad: dropout needs < 2^32 elements");
+    const int Ho = H + 3 - KS, Wo = W + 3 - KS;
+    ConvKLoader al{};
+    seg_a(al.base, dy_hi, dy_lo);
+    al.Mtot = B * H * W, al.Hr = H, al.Wr = W, al.Hs = Ho, al.Ws = Wo, al.C = Cout, al.KS = KS, al.sign = -1;
+    al.finish();
+    ConvWgtTRLoader bl{};
+    seg_b(bl.base, w_hi, w_lo);
+    bl.Cout = Cout, bl.Cin = Cin, bl.ntaps = KS * KS;
+    bl.finish();
+    EpGradStore ep{};
+    ep.out_hi = (bf16_t*)dx_hi, ep.out_lo = (bf16_t*)dx_lo, ep.ldo = Cin, ep.mode = 2;
+    ep.drop_seed = drop_seed, ep.drop_seed_dev = drop_seed_dev;
+    ep.drop_thresh = ig_drop_thresh16(drop_p);
+    ep.drop_inv = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    return launch_gemm<ConvKLoader, ConvWgtTRLoader, EpGradStore, false, true>(
+        al, bl, ep, al.Mtot, Cin, KS * KS * Cout, 1, dy_lo != nullptr, (hipStream_t)stream, "ig_convk_dgrad", false, 1);
+}
+
+// dWc[Cout][KS*KS][Cin] += sum over output pixels of dy[p][co] * x[shift_tap(p)][ci];  dbias[co] += sum_p dy[p][co] (optional)
+int ig_convk_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const void* x_lo, float* dw, float* dbias, int B, int H,
+                   int W, int Cin, int Cout, int KS, void* stream) {
+    IG_REQUIRE(dy_hi && x_hi && dw, "ig_convk_wgrad: null pointer");
+    IG_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, "ig_convk_wgrad: channels must be multiples of 8");
+    IG_REQUIRE(KS >= 3 && (KS & 1) && KS <= 9 && H + 3 - KS > 0 && W + 3 - KS > 0, "ig_convk_wgrad: kernel size %d does not fit a %d x %d input", KS, H, W);
+    IG_SPLIT_CONSISTENT(dy_lo, x_lo);
+    const int Ho = H + 3 - KS, Wo = W + 3 - KS, Mo = B * Ho * Wo;
+    if (dbias) {
+        const int rc = ig_colsum(dy_hi, dy_lo, dbias, (long)Mo, Cout, stream);
+        if (rc != IG_OK) return rc;
+    }
+    ConvKLoader bl{};
+    seg_b(bl.base, x_hi, x_lo);
+    bl.Mtot = Mo, bl.Hr = Ho, bl.Wr = Wo, bl.Hs = H, bl.Ws = W, bl.C = Cin, bl.KS = KS, bl.sign = 1;
+    bl.finish();
+    EpAtomic ep{dw, (long)KS * KS * Cin, 0, 0, nullptr, 0};
+    return launch_gemm<PlainLoader, ConvKLoader, EpAtomic, true, true>(
+        plain_a(dy_hi, dy_lo, Mo, Cout, Cout), bl, ep, Cout, KS * KS * Cin, Mo, 1, dy_lo != nullptr, (hipStream_t)stream,
+        "ig_convk_wgrad", true, 1);
 }
 
 // ---- ConvTranspose2d(k=3,s=2,p=1,op=1), NHWC, weight storage Wc[Cout][9][Cin]  (model.py:361-368) ----

@@ -42,10 +42,14 @@ PRITHVI_VARIANTS = {
     # PrithviViT.forward (pritvhi.py:498-530) takes no coordinates.  The variant therefore computes exactly what prithvi_eo_v2_300
     # computes and carries two extra state_dict entries that receive no gradient.
     "prithvi_eo_v2_300_tl": (1024, 24, 16, 16, 4),
+    # model.py:154-167: 16 heads of 80 (attention_g.hip), patch 14 (16 x 16 tokens of a 224 chip), and -- model.py:169-177 -- decode-head
+    # convolutions of kernel size [5, 5, 5, 7] with padding 1, which shrink every upsampled map (32 -> 30, 60 -> 58, 116 -> 114, 228 -> 224)
+    "prithvi_eo_v2_600": (1280, 32, 16, 14, 4),
+    "prithvi_eo_v2_600_tl": (1280, 32, 16, 14, 4),
 }
 HEAD_KERNELS = {k: (3, 3, 3, 3) for k in PRITHVI_VARIANTS}
-TL_VARIANTS = ("prithvi_eo_v2_300_tl",)
-UNSUPPORTED_VARIANTS = ("prithvi_eo_v2_600", "prithvi_eo_v2_600_tl")
+HEAD_KERNELS.update({"prithvi_eo_v2_600": (5, 5, 5, 7), "prithvi_eo_v2_600_tl": (5, 5, 5, 7)})
+TL_VARIANTS = ("prithvi_eo_v2_300_tl", "prithvi_eo_v2_600_tl")
 
 
 @dataclass
@@ -61,6 +65,7 @@ class SegConfig:
     num_classes: int = 2
     mlp_ratio: int = 4
     drop_p: float = 0.1  # nn.Dropout(0.1) x5 in the head (model.py:369,388)
+    head_kernels: Tuple[int, int, int, int] = (3, 3, 3, 3)  # nn.Conv2d kernel sizes of the four upscaling blocks (model.py:169-177)
 
     @property
     def grid(self) -> int:
@@ -82,22 +87,35 @@ class SegConfig:
     def patch_k(self) -> int:
         return self.in_chans * self.patch * self.patch
 
+    @property
+    def head_dim(self) -> int:
+        return self.embed_dim // self.num_heads
+
+    @property
+    def head_sizes(self) -> List[Tuple[int, int, int]]:
+        """Per upscaling block (input side, ConvTranspose output side = 2 x, Conv2d(k, padding=1) output side = 2 x + 3 - k):
+        (14, 28, 28) ... (112, 224, 224) for 3 x 3 kernels; (16, 32, 30), (30, 60, 58), (58, 116, 114), (114, 228, 224) for the 600M head."""
+        out, h = [], self.grid
+        for k in self.head_kernels:
+            out.append((h, 2 * h, 2 * h + 3 - k))
+            h = 2 * h + 3 - k
+        return out
+
+    @property
+    def out_size(self) -> int:
+        return self.head_sizes[-1][2]
+
 
 def make_seg_config(variant: str, temporal_step: int, image_size: int, num_classes: int, depth: int = -1,
                     in_chans: int = 6) -> SegConfig:
-    if variant in UNSUPPORTED_VARIANTS:
-        raise NotImplementedError(
-            f"variant {variant}: patch 14, head_dim 80 and the 5x5 / 7x7 head kernels (model.py:154-176) are not built "
-            "(the attention kernels are head_dim 64; SURVEY.md section 8f item 4)"
-        )
     if variant not in PRITHVI_VARIANTS:
         raise KeyError(f"unknown Prithvi variant {variant!r}")
     d, l, h, p, _ = PRITHVI_VARIANTS[variant]
     if depth != -1:  # model.py:208-209
         l = depth
     assert image_size % p == 0, "image_size must be divisible by the patch size"
-    assert d // h == 64, "head_dim must be 64"
-    return SegConfig(variant, d, l, h, p, in_chans, temporal_step, image_size, num_classes)
+    assert d % h == 0 and d // h in (64, 80), "head_dim must be 64 or 80 (attention2.hip / attention_g.hip)"
+    return SegConfig(variant, d, l, h, p, in_chans, temporal_step, image_size, num_classes, head_kernels=HEAD_KERNELS[variant])
 
 
 # --------------------------------------------------------------------------------------------------
@@ -163,15 +181,15 @@ class _Entry:
     shape: Tuple[int, ...]  # API (PyTorch) shape
     offset: int
     numel: int
-    kind: str  # "plain" | "conv" (Cout,Cin,3,3 stored [Cout][9][Cin]) | "convT" (Cin,Cout,3,3 stored [Cout][9][Cin])
+    kind: str  # "plain" | "conv" (Cout,Cin,k,k stored [Cout][k*k][Cin]) | "convT" (Cin,Cout,3,3 stored [Cout][9][Cin])
 
     def api_view(self, flat: torch.Tensor) -> torch.Tensor:
         seg = flat[self.offset : self.offset + self.numel]
         if self.kind == "plain":
             return seg.view(self.shape)
         if self.kind == "conv":
-            co, ci = self.shape[0], self.shape[1]
-            return seg.view(co, 3, 3, ci).permute(0, 3, 1, 2)
+            co, ci, k = self.shape[0], self.shape[1], self.shape[2]
+            return seg.view(co, k, k, ci).permute(0, 3, 1, 2)
         ci, co = self.shape[0], self.shape[1]
         return seg.view(co, 3, 3, ci).permute(3, 0, 1, 2)
 
@@ -200,7 +218,7 @@ def _param_specs(cfg: SegConfig) -> List[Tuple[str, Tuple[int, ...], str]]:
     for i in range(4):
         s += [
             (f"{h}{i}.0.weight", (dims[i], dims[i + 1], 3, 3), "convT"), (f"{h}{i}.0.bias", (dims[i + 1],), "plain"),
-            (f"{h}{i}.2.weight", (dims[i + 1], dims[i + 1], 3, 3), "conv"), (f"{h}{i}.2.bias", (dims[i + 1],), "plain"),
+            (f"{h}{i}.2.weight", (dims[i + 1], dims[i + 1], cfg.head_kernels[i], cfg.head_kernels[i]), "conv"), (f"{h}{i}.2.bias", (dims[i + 1],), "plain"),
             (f"{h}{i}.3.weight", (dims[i + 1],), "plain"), (f"{h}{i}.3.bias", (dims[i + 1],), "plain"),
         ]  # fmt: skip
     s += [(h + "5.weight", (cfg.num_classes, dims[4], 1, 1), "plain"), (h + "5.bias", (cfg.num_classes,), "plain")]
@@ -390,10 +408,10 @@ class SegEngine:
         ws["rstd2"] = [f32(M) for _ in range(nsave)]
         ws["meanF"], ws["rstdF"] = f32(M), f32(M)
         dims = cfg.head_dims
-        g = cfg.grid
-        ws["f"] = [BT.empty((B, g << i, g << i, dims[i]), sp, dev) for i in range(5)]
-        ws["u"] = [BT.empty((B, g << (i + 1), g << (i + 1), dims[i + 1]), sp, dev) for i in range(4)]
-        ws["cv"] = [BT.empty((B, g << (i + 1), g << (i + 1), dims[i + 1]), sp, dev) for i in range(4)]
+        hs = cfg.head_sizes  # (input side, ConvTranspose output side, Conv2d output side) per upscaling block
+        ws["f"] = [BT.empty((B, cfg.grid, cfg.grid, dims[0]), sp, dev)] + [BT.empty((B, hs[i][2], hs[i][2], dims[i + 1]), sp, dev) for i in range(4)]
+        ws["u"] = [BT.empty((B, hs[i][1], hs[i][1], dims[i + 1]), sp, dev) for i in range(4)]
+        ws["cv"] = [BT.empty((B, hs[i][2], hs[i][2], dims[i + 1]), sp, dev) for i in range(4)]
         ws["bn_scale"] = [f32(dims[i + 1]) for i in range(4)]
         ws["bn_shift"] = [f32(dims[i + 1]) for i in range(4)]
         ws["bn_mean"] = [f32(dims[i + 1]) for i in range(4)]
@@ -437,7 +455,7 @@ class SegEngine:
         img = img.contiguous().float()
         B = img.shape[0]
         if B == 0:  # empty batch: nothing to launch
-            return torch.empty((0, cfg.num_classes, cfg.img_size, cfg.img_size), dtype=torch.float32, device=img.device)
+            return torch.empty((0, cfg.num_classes, cfg.out_size, cfg.out_size), dtype=torch.float32, device=img.device)
         ws = self.encoder_forward(img, save)
         logits = self._head_forward(ws, B, training, out, update_running, cfg)
         if save:
@@ -470,7 +488,7 @@ class SegEngine:
             x_mid = ws["x_mid"][s]
             ops.layernorm_fwd(x_in, self.P(b + "norm1.weight"), self.P(b + "norm1.bias"), ws["a"][s], ws["mean1"][s], ws["rstd1"][s], M, D)
             ops.linear_fwd(ws["a"][s], self.W(b + "attn.qkv.weight"), self.P(b + "attn.qkv.bias"), ws["qkv"][s], M, 3 * D, D)
-            ops.attention_fwd(ws["qkv"][s], ws["o"][s], ws["lse"][s] if save else None, B, N, H)
+            ops.attention_fwd(ws["qkv"][s], ws["o"][s], ws["lse"][s] if save else None, B, N, H, cfg.head_dim)
             ops.linear_residual_fwd(ws["o"][s], self.W(b + "attn.proj.weight"), self.P(b + "attn.proj.bias"), x_in, x_mid, M, D, D)
             ops.layernorm_fwd(x_mid, self.P(b + "norm2.weight"), self.P(b + "norm2.bias"), ws["c"][s], ws["mean2"][s], ws["rstd2"][s], M, D)
             ops.linear_fwd(ws["c"][s], self.W(b + "mlp.fc1.weight"), self.P(b + "mlp.fc1.bias"), ws["hact"][s], M, 4 * D, D, act=1,
@@ -492,29 +510,29 @@ class SegEngine:
 
     def _head_forward(self, ws, B: int, training: bool, out, update_running: bool, cfg: Optional[SegConfig] = None) -> torch.Tensor:
         cfg = cfg or self.cfg
-        dims, g = cfg.head_dims, cfg.grid
+        dims, hs, ks = cfg.head_dims, cfg.head_sizes, cfg.head_kernels
         p = cfg.drop_p if training else 0.0
         sd = self._drop_counter(advance=True) if p > 0 else None
         h = "segmentation_head."
         for i in range(4):
-            Hs = g << i
+            Hs, Hu, Ho = hs[i]  # ConvTranspose2d: Hs -> Hu = 2 Hs; Conv2d(k, padding=1): Hu -> Ho = Hu + 3 - k (model.py:349-378)
             ops.convT_fwd(ws["f"][i], self.W(f"{h}{i}.0.weight"), self.P(f"{h}{i}.0.bias"), ws["u"][i], B, Hs, Hs, dims[i], dims[i + 1],
                           seed=self.drop_seed + i, p=p, seed_dev=sd)
             if not training:
                 # eval mode: BatchNorm(running stats)+ReLU is a per-channel affine folded into the conv epilogue (one HBM pass less)
                 ops.bn_eval_affine(self.P(f"{h}{i}.3.weight"), self.P(f"{h}{i}.3.bias"), self.buffers[f"{h}{i}.3.running_mean"],
                                    self.buffers[f"{h}{i}.3.running_var"], ws["bn_scale"][i], ws["bn_shift"][i], dims[i + 1])
-                ops.conv3x3_fwd(ws["u"][i], self.W(f"{h}{i}.2.weight"), self.P(f"{h}{i}.2.bias"), ws["f"][i + 1], B, 2 * Hs, 2 * Hs,
-                                dims[i + 1], dims[i + 1], bn_scale=ws["bn_scale"][i], bn_shift=ws["bn_shift"][i])
+                ops.conv_fwd(ws["u"][i], self.W(f"{h}{i}.2.weight"), self.P(f"{h}{i}.2.bias"), ws["f"][i + 1], B, Hu, Hu,
+                             dims[i + 1], dims[i + 1], ks[i], bn_scale=ws["bn_scale"][i], bn_shift=ws["bn_shift"][i])
                 continue
-            ops.conv3x3_fwd(ws["u"][i], self.W(f"{h}{i}.2.weight"), self.P(f"{h}{i}.2.bias"), ws["cv"][i], B, 2 * Hs, 2 * Hs, dims[i + 1],
-                            dims[i + 1])
+            ops.conv_fwd(ws["u"][i], self.W(f"{h}{i}.2.weight"), self.P(f"{h}{i}.2.bias"), ws["cv"][i], B, Hu, Hu, dims[i + 1],
+                         dims[i + 1], ks[i])
             ops.bn_relu_fwd(ws["cv"][i], self.P(f"{h}{i}.3.weight"), self.P(f"{h}{i}.3.bias"), self.buffers[f"{h}{i}.3.running_mean"],
                             self.buffers[f"{h}{i}.3.running_var"], ws["f"][i + 1], ws["bn_scale"][i], ws["bn_shift"][i], ws["bn_mean"][i],
-                            ws["bn_rstd"][i], ws["bn_sums"], B * 4 * Hs * Hs, dims[i + 1], training, training and update_running)
+                            ws["bn_rstd"][i], ws["bn_sums"], B * Ho * Ho, dims[i + 1], training, training and update_running)
             if training and update_running:
                 self.buffers[f"{h}{i}.3.num_batches_tracked"] += 1
-        S = cfg.img_size
+        S = cfg.out_size  # = img_size for every variant at its native chip size (3 x 3 kernels keep 2 x; 600M: 228 -> 224)
         if out is None:
             out = torch.empty((B, cfg.num_classes, S, S), dtype=torch.float32, device=ws["f"][4].hi.device)
         ops.classifier_fwd(ws["f"][4], self.P(h + "5.weight"), self.P(h + "5.bias"), out, B, S * S, dims[4], cfg.num_classes,
@@ -544,24 +562,24 @@ class SegEngine:
         self.store.ensure_grad()
         D, L, N, T, G, H = cfg.embed_dim, cfg.depth, cfg.tokens, cfg.num_frames, cfg.G, cfg.num_heads
         M = B * N
-        dims, g = cfg.head_dims, cfg.grid
+        dims, hs, ks = cfg.head_dims, cfg.head_sizes, cfg.head_kernels
         p = cfg.drop_p if training else 0.0
         sd = self._drop_counter(advance=False) if p > 0 else None
         h = "segmentation_head."
-        S = cfg.img_size
+        S = cfg.out_size
         ops.classifier_bwd(dlogits.contiguous(), ws["f"][4], self.P(h + "5.weight"), ws["df"][4], self.Gd(h + "5.weight"),
                            self.Gd(h + "5.bias"), count, B, S * S, dims[4], cfg.num_classes, seed=self.drop_seed + 4, p=p, seed_dev=sd)
         for i in range(3, -1, -1):
-            Hs = g << i
-            Mo = B * 4 * Hs * Hs
+            Hs, Hu, Ho = hs[i]
+            Mo = B * Ho * Ho
             C1 = dims[i + 1]
             if not training:
                 raise RuntimeError("backward through eval-mode BatchNorm is not supported (reference trains in train mode)")
             ops.bn_relu_bwd(ws["cv"][i], ws["df"][i + 1], ws["bn_scale"][i], ws["bn_shift"][i], ws["bn_mean"][i], ws["bn_rstd"][i],
                             ws["dcv"][i], self.Gd(f"{h}{i}.3.weight"), self.Gd(f"{h}{i}.3.bias"), ws["bn_sums"], Mo, C1)
             # (the bias gradients ride on the weight-gradient kernels' dy fragments where those are the direct kernels)
-            ops.conv3x3_wgrad(ws["dcv"][i], ws["u"][i], self.Gd(f"{h}{i}.2.weight"), B, 2 * Hs, 2 * Hs, C1, C1, dbias=self.Gd(f"{h}{i}.2.bias"))
-            ops.conv3x3_dgrad(ws["dcv"][i], self.W(f"{h}{i}.2.weight"), ws["du"][i], B, 2 * Hs, 2 * Hs, C1, C1, seed=self.drop_seed + i, p=p, seed_dev=sd)
+            ops.conv_wgrad(ws["dcv"][i], ws["u"][i], self.Gd(f"{h}{i}.2.weight"), B, Hu, Hu, C1, C1, ks[i], dbias=self.Gd(f"{h}{i}.2.bias"))
+            ops.conv_dgrad(ws["dcv"][i], self.W(f"{h}{i}.2.weight"), ws["du"][i], B, Hu, Hu, C1, C1, ks[i], seed=self.drop_seed + i, p=p, seed_dev=sd)
             ops.convT_wgrad(ws["du"][i], ws["f"][i], self.Gd(f"{h}{i}.0.weight"), B, Hs, Hs, dims[i], C1, dbias=self.Gd(f"{h}{i}.0.bias"))
             if i > 0 or not self.freeze_backbone:
                 ops.convT_dgrad(ws["du"][i], self.W(f"{h}{i}.0.weight"), ws["df"][i], B, Hs, Hs, dims[i], C1)
@@ -596,7 +614,7 @@ class SegEngine:
                               self.Gd(b + "norm2.weight"), self.Gd(b + "norm2.bias"), self.Gd(b + "attn.proj.bias"), M, D)
             # proj
             ops.linear_dgrad(dxb2, self.W(b + "attn.proj.weight"), ws["dtmp"], M, D, D, wt=WT(i, "attn.proj.weight"))
-            ops.attention_bwd(ws["qkv"][i], ws["o"][i], ws["dtmp"], ws["lse"][i], ws["delta"], ws["dqkv"], B, N, H)
+            ops.attention_bwd(ws["qkv"][i], ws["o"][i], ws["dtmp"], ws["lse"][i], ws["delta"], ws["dqkv"], B, N, H, cfg.head_dim)
             # qkv
             ops.colsum(ws["dqkv"], self.Gd(b + "attn.qkv.bias"), M, 3 * D)
             ops.linear_dgrad(ws["dqkv"], self.W(b + "attn.qkv.weight"), ws["dtmp"], M, 3 * D, D, wt=WT(i, "attn.qkv.weight"))

@@ -422,6 +422,31 @@ def conv3x3_fwd(x: BT, w: BT, bias, y: BT, B, H, W, Cin, Cout, bn_scale=None, bn
           _p(y.hi), _p(y.lo), B, H, W, Cin, Cout, _stream())
 
 
+def conv_fwd(x: BT, w: BT, bias, y: BT, B, H, W, Cin, Cout, ks: int = 3, bn_scale=None, bn_shift=None) -> None:
+    """nn.Conv2d(kernel_size=ks, padding=1): ks = 3 is :func:`conv3x3_fwd`; 5 / 7 (the 600M head) shrink the map to H + 3 - ks."""
+    if ks == 3:
+        return conv3x3_fwd(x, w, bias, y, B, H, W, Cin, Cout, bn_scale, bn_shift)
+    Ho, Wo = H + 3 - ks, W + 3 - ks
+    _call("ig_conv3x3_fwd", 2.0 * B * Ho * Wo * Cin * Cout * ks * ks, _p(x.hi), _p(x.lo), _p(w.hi), _p(w.lo), _p(bias), _p(bn_scale), _p(bn_shift),
+          _p(y.hi), _p(y.lo), B, H, W, Cin, Cout, ks, _stream(), entry="ig_convk_fwd")
+
+
+def conv_dgrad(dy: BT, w: BT, dx: BT, B, H, W, Cin, Cout, ks: int = 3, seed: int = 0, p: float = 0.0, seed_dev=None) -> None:
+    if ks == 3:
+        return conv3x3_dgrad(dy, w, dx, B, H, W, Cin, Cout, seed, p, seed_dev)
+    Ho, Wo = H + 3 - ks, W + 3 - ks
+    _call("ig_conv3x3_dgrad", 2.0 * B * Ho * Wo * Cin * Cout * ks * ks, _p(dy.hi), _p(dy.lo), _p(w.hi), _p(w.lo), _p(dx.hi), _p(dx.lo), B, H, W, Cin,
+          Cout, ks, seed, _p(seed_dev), p, _stream(), entry="ig_convk_dgrad")
+
+
+def conv_wgrad(dy: BT, x: BT, dw, B, H, W, Cin, Cout, ks: int = 3, dbias=None) -> None:
+    if ks == 3:
+        return conv3x3_wgrad(dy, x, dw, B, H, W, Cin, Cout, dbias)
+    Ho, Wo = H + 3 - ks, W + 3 - ks
+    _call("ig_conv3x3_wgrad", 2.0 * B * Ho * Wo * Cin * Cout * ks * ks, _p(dy.hi), _p(dy.lo), _p(x.hi), _p(x.lo), _p(dw), _p(dbias), B, H, W, Cin, Cout,
+          ks, _stream(), entry="ig_convk_wgrad")
+
+
 def bn_eval_affine(gamma, beta, rmean, rvar, scale, shift, C: int, eps: float = 1e-5) -> None:
     _lib.call("ig_bn_eval_affine", _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(scale), _p(shift), C, eps, _stream())
 

@@ -76,7 +76,11 @@ _VARIANTS = {
     # model.py:147-153: coords_encoding time + location, coords_scale_learn=True.  The encoders (pritvhi.py:273-367) are built but
     # PrithviViT.forward (pritvhi.py:498-530) never calls them: same arithmetic as prithvi_eo_v2_300, two extra (1,) parameters.
     "prithvi_eo_v2_300_tl": (1024, 24, 16, 16),
+    # model.py:154-167: 16 heads of 80, patch 14 (16 x 16 tokens of a 224 chip); head kernels [5, 5, 5, 7] (model.py:169-177)
+    "prithvi_eo_v2_600": (1280, 32, 16, 14),
+    "prithvi_eo_v2_600_tl": (1280, 32, 16, 14),
 }
+_HEAD_KERNELS = {"prithvi_eo_v2_600": (5, 5, 5, 7), "prithvi_eo_v2_600_tl": (5, 5, 5, 7)}  # model.py:169-177; (3, 3, 3, 3) otherwise
 
 
 def make_config(
@@ -98,6 +102,7 @@ def make_config(
         num_frames=temporal_step,
         img_size=image_size,
         num_classes=num_classes,
+        head_kernels=_HEAD_KERNELS.get(variant, (3, 3, 3, 3)),
     )
 
 

@@ -43,7 +43,7 @@ def report(tag, got, ref):
     return d.max().item(), d.mean().item()
 
 
-@pytest.mark.parametrize("name", ["tiny_t1_c2", "tiny_t3_c13", "v1_100_t1_c2", "v1_100_t3_c13", "v2_300_t1_c2"])
+@pytest.mark.parametrize("name", ["tiny_t1_c2", "tiny_t3_c13", "v1_100_t1_c2", "v1_100_t3_c13", "v2_300_t1_c2", "v2_600_t1_c2"])
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
 def test_eval_logits_parity(name, precision):
     cfg, sd, net, img, lab = build(name, precision)
@@ -121,13 +121,14 @@ def rel_l2(a, b):
     return ((a - b).norm() / (b.norm() + 1e-300)).item()
 
 
-@pytest.mark.parametrize("name", ["tiny_t1_c2", "tiny_t3_c13", "v1_100_t1_c2", "v1_100_t3_c13", "v2_300_t1_c2"])
+@pytest.mark.parametrize("name", ["tiny_t1_c2", "tiny_t3_c13", "v1_100_t1_c2", "v1_100_t3_c13", "v2_300_t1_c2", "v2_600_t1_c2"])
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
 def test_train_step_gradients(name, precision):
     """forward(train-mode BN, dropout p=0) + loss + backward: loss, logits and gradients vs the fp64 fixture that
     oracle/gen_golden.py computed with the REFERENCE network (tiny, the model-size Prithvi-100M cases -- D = 768 runs the
-    8-phase / ping-pong / dual-K GEMM engines end to end against reference-generated gradients -- and Prithvi-V2-300M:
-    D = 1024, 24 blocks, 16 heads, the 64-channel head of BASELINE configs[4])."""
+    8-phase / ping-pong / dual-K GEMM engines end to end against reference-generated gradients -- Prithvi-V2-300M:
+    D = 1024, 24 blocks, 16 heads, the 64-channel head of BASELINE configs[4] -- and the 600M shape family at depth 2:
+    D = 1280, 16 heads of 80, patch 14 / 257 tokens, head kernels [5, 5, 5, 7], model.py:154-177)."""
     cfg, sd, net, img, lab = build(name, precision)
     net.cfg.drop_p = 0.0
     net.train()
@@ -307,8 +308,8 @@ def test_input_validation():
             net(torch.zeros(1, 5, 1, 224, 224, device=DEV))
         with pytest.raises(Exception):
             net(torch.zeros(1, 6, 1, 224, 224))  # CPU tensor: no CPU fallback
-    with pytest.raises(NotImplementedError):
-        PrithviSeg(variant="prithvi_eo_v2_600", load_pretrained_weights=False, device=DEV)
+    with pytest.raises(KeyError):
+        PrithviSeg(variant="prithvi_eo_v3_900", load_pretrained_weights=False, device=DEV)
     with pytest.raises(RuntimeError):
         PrithviSeg(variant="prithvi_eo_tiny", load_pretrained_weights=True, device=DEV)
 

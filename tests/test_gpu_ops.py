@@ -403,8 +403,7 @@ def test_layernorm_feature_layout(split, T):
     close(dx, gx, 2e-5, what="feature layout bwd")
 
 
-def attn_ref(qkv, B, N, H):
-    hd = 64
+def attn_ref(qkv, B, N, H, hd=64):
     q, k, v = qkv.reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
     att = ((q * hd**-0.5) @ k.transpose(-2, -1)).softmax(-1)
     return (att @ v).transpose(1, 2).reshape(B, N, H * hd)
@@ -429,6 +428,36 @@ def test_attention_fwd_bwd(split, N):
     delta = torch.empty(B * H * N, device=DEV)
     ops.attention_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H)
     close(dqkv.float(), gref, 1e-4 if split else 2e-2, what="attn bwd")
+
+
+@pytest.mark.parametrize("split", SPLITS)
+@pytest.mark.parametrize("N,hd", [(257, 80), (769, 80), (1, 80), (16, 80), (33, 80), (197, 64)])
+def test_attention_generic_head_dim(split, N, hd, monkeypatch):
+    """Head dimensions other than 64 (attention_g.hip): the Prithvi-EO-2.0 600M variants run 16 heads of 80 over 257 (T = 1) or
+    769 (T = 3) tokens (model.py:154-167).  hd = 64 is forced onto the same kernels (IG_ATTN_GENERIC=1) as a cross-check against
+    the case the tuned kernels are tested on."""
+    if hd == 64:
+        monkeypatch.setenv("IG_ATTN_GENERIC", "1")
+    B, H = 2, 3
+    x = rnd(B, N, 3 * H * hd, seed=23)
+    if N > 70:
+        x[0, 70, H * hd : H * hd + hd] *= 10.0  # a spiking key in a late tile: the running maximum moves
+    qkv, qr = bt(x, split)
+    out = BT.empty((B, N, H * hd), split, DEV)
+    lse = torch.empty(B, H, N, device=DEV)
+    ops.attention_fwd(qkv, out, lse, B, N, H, hd=hd)
+    qd = qr.clone().requires_grad_(True)
+    ref = attn_ref(qd, B, N, H, hd)
+    close(out.float(), ref.detach(), 3e-5 if split else 1e-2, what="generic attn fwd")
+    q, k, _ = qr.reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    lse_ref = torch.logsumexp((q * hd**-0.5) @ k.transpose(-2, -1), -1)
+    close(lse, lse_ref, 1e-5 if split else 2e-3, what="generic attn lse")
+    dout, dor = bt(rnd(B, N, H * hd, seed=24), split)
+    (gref,) = torch.autograd.grad((ref * dor).sum(), qd)
+    dqkv = BT.empty((B, N, 3 * H * hd), split, DEV)
+    delta = torch.empty(B * H * N, device=DEV)
+    ops.attention_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, hd=hd)
+    close(dqkv.float(), gref, 1e-4 if split else 2e-2, what="generic attn bwd")
 
 
 @pytest.mark.parametrize("split", SPLITS)
@@ -473,6 +502,37 @@ def test_conv3x3(split, B, H, Cin, Cout):  # unsplit 48 -> 48 (fwd, dgrad) and C
     ops.conv3x3_wgrad(dy, x, dw, B, H, W, Cin, Cout, dbias=db)
     close(dw, gw.permute(0, 2, 3, 1).reshape(Cout, 9, Cin), 3e-5, what="conv wgrad")
     close(db - 0.25, dyr.sum((0, 1, 2)), 3e-5, what="conv bias gradient (fused into the direct kernels / column-sum fallback)")
+
+
+@pytest.mark.parametrize("split", SPLITS)
+@pytest.mark.parametrize("B,H,Cin,Cout,ks", [(2, 16, 64, 32, 5), (1, 30, 80, 80, 7), (2, 9, 160, 160, 5), (1, 5, 16, 8, 7), (3, 7, 24, 40, 5),
+                                             (1, 32, 640, 640, 5)])
+def test_conv_kxk_padding1(split, B, H, Cin, Cout, ks):
+    """nn.Conv2d(kernel_size=5 | 7, padding=1) of the 600M variants' decode head (model.py:169-177): the map shrinks to H + 3 - ks;
+    forward (bias), data gradient and weight / bias gradients against float64 F.conv2d."""
+    W = H + 2
+    Ho, Wo = H + 3 - ks, W + 3 - ks
+    x, xr = bt(nhwc(rnd(B, Cin, H, W, seed=40)), split)
+    wt = rnd(Cout, Cin, ks, ks, seed=41, scale=(ks * ks * Cin) ** -0.5)
+    w, wr = bt(wt.permute(0, 2, 3, 1).reshape(Cout, ks * ks, Cin).contiguous(), split)
+    wr_t = wr.reshape(Cout, ks, ks, Cin).permute(0, 3, 1, 2)
+    bias = rnd(Cout, seed=42)
+    y = BT.empty((B, Ho, Wo, Cout), split, DEV)
+    ops.conv_fwd(x, w, bias.to(DEV), y, B, H, W, Cin, Cout, ks)
+    xin = xr.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    wv = wr_t.clone().requires_grad_(True)
+    ref = F.conv2d(xin, wv, bias.double(), padding=1)
+    assert ref.shape[-2:] == (Ho, Wo)
+    close(y.float(), nhwc(ref.detach()), tol_out(split), what="conv kxk fwd")
+    dy, dyr = bt(nhwc(rnd(B, Cout, Ho, Wo, seed=43)), split)
+    gx, gw = torch.autograd.grad((ref * dyr.permute(0, 3, 1, 2)).sum(), [xin, wv])
+    dx = BT.empty((B, H, W, Cin), split, DEV)
+    ops.conv_dgrad(dy, w, dx, B, H, W, Cin, Cout, ks)
+    close(dx.float(), nhwc(gx), tol_out(split), what="conv kxk dgrad")
+    dw, db = torch.zeros(Cout, ks * ks, Cin, device=DEV), torch.full((Cout,), 0.25, device=DEV)
+    ops.conv_wgrad(dy, x, dw, B, H, W, Cin, Cout, ks, dbias=db)
+    close(dw, gw.permute(0, 2, 3, 1).reshape(Cout, ks * ks, Cin), 3e-5, what="conv kxk wgrad")
+    close(db - 0.25, dyr.sum((0, 1, 2)), 3e-5, what="conv kxk bias gradient")
 
 
 @pytest.mark.parametrize("split", SPLITS)
