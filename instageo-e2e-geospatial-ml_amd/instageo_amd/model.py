@@ -66,6 +66,7 @@ class SegConfig:
     mlp_ratio: int = 4
     drop_p: float = 0.1  # nn.Dropout(0.1) x5 in the head (model.py:369,388)
     head_kernels: Tuple[int, int, int, int] = (3, 3, 3, 3)  # nn.Conv2d kernel sizes of the four upscaling blocks (model.py:169-177)
+    embed_dims: Optional[Tuple[int, int, int, int, int]] = None  # custom decode-head widths (PrithviSeg(embed_dims=...), model.py:304,380-389)
 
     @property
     def grid(self) -> int:
@@ -81,6 +82,8 @@ class SegConfig:
 
     @property
     def head_dims(self) -> List[int]:
+        if self.embed_dims is not None:
+            return list(self.embed_dims)
         return [(self.embed_dim * self.num_frames) // (2**i) for i in range(5)]  # model.py:380-383
 
     @property
@@ -107,7 +110,7 @@ class SegConfig:
 
 
 def make_seg_config(variant: str, temporal_step: int, image_size: int, num_classes: int, depth: int = -1,
-                    in_chans: int = 6) -> SegConfig:
+                    in_chans: int = 6, embed_dims: Optional[List[int]] = None) -> SegConfig:
     if variant not in PRITHVI_VARIANTS:
         raise KeyError(f"unknown Prithvi variant {variant!r}")
     d, l, h, p, _ = PRITHVI_VARIANTS[variant]
@@ -115,7 +118,14 @@ def make_seg_config(variant: str, temporal_step: int, image_size: int, num_class
         l = depth
     assert image_size % p == 0, "image_size must be divisible by the patch size"
     assert d % h == 0 and d // h in (64, 80), "head_dim must be 64 or 80 (attention2.hip / attention_g.hip)"
-    return SegConfig(variant, d, l, h, p, in_chans, temporal_step, image_size, num_classes, head_kernels=HEAD_KERNELS[variant])
+    if embed_dims is not None:
+        # model.py:380-389: the first width is the ConvTranspose's input = the encoder's feature channels D * T; the kernels move
+        # 16-byte (8-channel) units
+        embed_dims = tuple(int(x) for x in embed_dims)
+        if len(embed_dims) != 5 or embed_dims[0] != d * temporal_step or any(x <= 0 or x % 8 for x in embed_dims):
+            raise ValueError(f"embed_dims must be five positive multiples of 8 starting with embed_dim * temporal_step = {d * temporal_step}, got {list(embed_dims)}")
+    return SegConfig(variant, d, l, h, p, in_chans, temporal_step, image_size, num_classes, head_kernels=HEAD_KERNELS[variant],
+                     embed_dims=embed_dims)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -704,12 +714,10 @@ class PrithviSeg(nn.Module):
         **kwargs: Any,
     ) -> None:
         super().__init__()
-        if embed_dims is not None:
-            raise NotImplementedError("custom embed_dims for the head are not supported (reference default: D*T / 2^i)")
         if kwargs:
             raise TypeError(f"unsupported PrithviSeg arguments: {sorted(kwargs)}")
         in_chans = 6 * max(1, len(model_bands) // 6)  # model.py:330 PRETRAINED_BANDS * (len(model_bands)//6)
-        cfg = make_seg_config(variant, temporal_step, image_size, num_classes, depth, in_chans)
+        cfg = make_seg_config(variant, temporal_step, image_size, num_classes, depth, in_chans, embed_dims)
         self.cfg = cfg
         if device is None:
             device = "cuda" if torch.cuda.is_available() else "cpu"

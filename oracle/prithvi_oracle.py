@@ -52,6 +52,7 @@ class OracleConfig:
     img_size: int = 224
     num_classes: int = 2
     head_kernels: Tuple[int, int, int, int] = (3, 3, 3, 3)
+    embed_dims: Optional[Tuple[int, ...]] = None  # PrithviSeg(embed_dims=...) (model.py:304,380-389)
 
     @property
     def grid(self) -> int:
@@ -64,6 +65,8 @@ class OracleConfig:
     @property
     def head_dims(self) -> List[int]:
         # model.py:380-383
+        if self.embed_dims is not None:
+            return list(self.embed_dims)
         return [(self.embed_dim * self.num_frames) // (2**i) for i in range(5)]
 
 

@@ -61,7 +61,51 @@ def test_eval_logits_parity(name, precision):
         assert gmx <= 1e-3
         assert agree >= 0.9995
     else:
-        assert mx <= 8e-2 and mean <= 1e-2 and agree >= 0.99
+        # bf16 operands: measured on MI355X over the six cases max 2.5-3.9e-2, mean 3.4-5.4e-3, argmax agreement 0.991-0.998 on
+        # random-init logits (std ~0.05: maximally fragile argmax); bounds = 1.5 x the worst measured value
+        assert mx <= 6e-2 and mean <= 8e-3 and agree >= 0.99
+
+
+def test_custom_head_widths_embed_dims():
+    """PrithviSeg(embed_dims=[...]) (model.py:304,380-389): a decode head whose widths are not D / 2^i -- eval logits and one
+    train-mode backward against the oracle network with the same widths (bf16x3: 1e-3 on logits, 1e-2 rel-L2 on gradients)."""
+    import dataclasses
+
+    dims = [256, 96, 64, 40, 24]
+    cfg = dataclasses.replace(O.make_config("prithvi_eo_tiny", 1, 2, 224), embed_dims=tuple(dims))
+    sd = O.make_state_dict(cfg, seed=7)
+    net = PrithviSeg(temporal_step=1, image_size=224, num_classes=2, load_pretrained_weights=False, freeze_backbone=False,
+                     variant="prithvi_eo_tiny", embed_dims=dims, precision="bf16x3", device=DEV)
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == O.state_dict_shapes(cfg)
+    net.load_state_dict(sd, strict=True)
+    img, lab = make_inputs("tiny_t1_c2", cfg, 2)
+    net.eval()
+    with torch.no_grad():
+        mx, _ = report("embed_dims eval logits", net(img.to(DEV)), O.prithvi_seg_forward(cfg, sd, img, training=False))
+    assert mx <= 1e-3
+    net.cfg.drop_p = 0.0
+    net.train()
+    eng = net.engine
+    logits = eng.forward(img.to(DEV), training=True, save=True)
+    stats = torch.zeros(2, dtype=torch.float64, device=DEV)
+    dlog = torch.empty_like(logits)
+    cw = class_weights_for(2).to(DEV)
+    ops.ce_loss(logits, lab.to(DEV), cw, -1, stats, dlog)
+    net.store.ensure_grad().zero_()
+    eng.backward(dlog, count=stats)
+    sd64 = {k: (v.double().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k and not k.endswith("pos_embed") else v.double() if v.dtype.is_floating_point else v)
+            for k, v in sd.items()}
+    loss = O.seg_loss(O.prithvi_seg_forward(cfg, sd64, img.double(), training=True), lab, cw.cpu().double(), -1)
+    keys = ["segmentation_head.0.0.weight", "segmentation_head.1.2.weight", "segmentation_head.3.0.bias", "segmentation_head.5.weight",
+            "prithvi_encoder.blocks.0.attn.qkv.weight"]
+    grads = torch.autograd.grad(loss, [sd64[k] for k in keys])
+    for k, g in zip(keys, grads):
+        got = net.store.entries[k].api_view(net.store.grad).double().cpu()
+        err = ((got - g).norm() / g.norm()).item()
+        print(f"   embed_dims grad {k:44s} rel-L2 {err:.3e}")
+        assert err <= 1e-2, k
+    with pytest.raises(ValueError):
+        PrithviSeg(variant="prithvi_eo_tiny", load_pretrained_weights=False, embed_dims=[128, 96, 64, 40, 24], device=DEV)  # dims[0] != D * T
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
@@ -155,7 +199,7 @@ def test_train_step_gradients(name, precision):
         nrm = g.double().norm().item() / float(gold["grad_norm__" + k])
         worst = max(worst, err)
         print(f"   grad {k:48s} rel-L2 {err:.3e}  norm ratio {nrm:.5f}  (fp32 ref noise {float(gold['grad_fp32_noise__' + k]):.1e})")
-        tol = 1e-2 if precision == "bf16x3" else 0.25
+        tol = 1e-2 if precision == "bf16x3" else 0.25  # measured worst key: 4.3-8.4e-3 (bf16x3), 0.145-0.165 (bf16: 1.5 x headroom)
         assert err <= tol, f"{k}: rel L2 {err}"
     # mIoU / confusion (metrics.py semantics) from the device histogram
     from instageo_amd.metrics import metrics_from_matrix
@@ -167,7 +211,10 @@ def test_train_step_gradients(name, precision):
         assert abs(m["jaccard"] - float(gold["miou"])) <= 1e-3 and abs(m["accuracy"] - float(gold["acc"])) <= 1e-3
         assert int(conf.sum().item()) == int(gold["confusion"].sum())
     else:
-        assert lerr <= 8e-2 and abs(loss - float(gold["train_loss"])) <= 2e-2
+        # bf16: train-mode BatchNorm amplifies the operand rounding on the logits (measured 4.3-6.6e-2), but loss and mIoU -- the
+        # quantities north_star bounds at 1e-3 -- stay within 3.4e-4 / 2.5e-4 of the fp64 reference on all six cases
+        assert lerr <= 9e-2 and abs(loss - float(gold["train_loss"])) <= 1e-3
+        assert abs(m["jaccard"] - float(gold["miou"])) <= 1e-3
     # BatchNorm running statistics (momentum 0.1, unbiased variance) vs the oracle
     upd = {}
     with torch.no_grad():
@@ -314,18 +361,21 @@ def test_input_validation():
         PrithviSeg(variant="prithvi_eo_tiny", load_pretrained_weights=True, device=DEV)
 
 
-def test_trained_weights_bf16_miou_and_loss_vs_oracle():
+@pytest.mark.parametrize("variant,freeze,steps,B", [("prithvi_eo_tiny", False, 60, 8), ("prithvi_eo_v1_100", True, 240, 4)])
+def test_trained_weights_bf16_miou_and_loss_vs_oracle(variant, freeze, steps, B):
     """north_star: "outputs (logits, mIoU) must match the reference CPU path within 1e-3".  Random-init logits have std ~0.05,
-    so their argmax is maximally fragile; this test first TRAINS Prithvi-tiny for 60 fused steps (bf16 kernels, lr 1e-3) on a
-    learnable synthetic task (label = sign of a low-frequency field in band 0), then evaluates the trained weights on held-out
-    chips three ways: CPU oracle fp32, the bf16x3 parity mode and the bf16 bench mode.  bf16x3 is held to the 1e-3 bar; the
-    bf16 deltas are MEASURED and printed (and bounded loosely) -- see README "precision modes"."""
+    so their argmax is maximally fragile; this test first TRAINS for 60 fused steps (bf16 kernels, lr 1e-3) on a learnable
+    synthetic task (label = sign of a low-frequency field in band 0) -- Prithvi-tiny end to end, and Prithvi-100M with a frozen
+    random backbone (the reference's default freeze_backbone=True: only the decode head trains) -- then evaluates the trained
+    weights on held-out chips three ways: CPU oracle fp32, the bf16x3 parity mode and the bf16 bench mode.  bf16x3 is held to the
+    1e-3 bar on logits, loss and mIoU in both cases; bf16 meets the loss / mIoU bar on the tiny model and misses it on the 100M case
+    (asserted at twice the measured deviation)."""
     from instageo_amd.metrics import metrics_from_matrix
 
-    cfg = O.make_config("prithvi_eo_tiny", 1, 2)
+    cfg = O.make_config(variant, 1, 2)
     cw = class_weights_for(2)
 
-    def batch(seed, B=8):
+    def batch(seed, B=B):
         g = torch.Generator().manual_seed(seed)
         blocks = torch.randn(B, 6, 1, 14, 14, generator=g)
         x = blocks.repeat_interleave(16, 3).repeat_interleave(16, 4) + 0.3 * torch.randn(B, 6, 1, 224, 224, generator=g)
@@ -333,29 +383,30 @@ def test_trained_weights_bf16_miou_and_loss_vs_oracle():
         y[torch.rand(B, 224, 224, generator=g) < 0.05] = -1
         return x, y
 
-    mod = PrithviSegmentationModule(freeze_backbone=False, load_pretrained_weights=False, num_classes=2, model_name="prithvi_eo_tiny",
-                                    class_weights=[1, 3], ignore_index=-1, learning_rate=1e-3, scheduler=False, precision="bf16", device=DEV)
+    mod = PrithviSegmentationModule(freeze_backbone=freeze, load_pretrained_weights=False, num_classes=2, model_name=variant,
+                                    class_weights=[1, 3], ignore_index=-1, learning_rate=2e-3 if freeze else 1e-3, scheduler=False,
+                                    precision="bf16", device=DEV)
     mod.net.load_state_dict(O.make_state_dict(cfg, seed=1042))
     first = last = None
-    for step in range(60):
+    for step in range(steps):
         x, y = batch(100 + step % 12)
         st = mod.fused_train_step(x.to(DEV), y.to(DEV))
         loss = (st[0] / st[1]).item()
         first = loss if first is None else first
         last = loss
-    assert last < 0.6 * first, f"the task did not train: loss {first:.4f} -> {last:.4f}"
+    assert last < (0.75 if freeze else 0.6) * first, f"the task did not train: loss {first:.4f} -> {last:.4f}"
     sd = {k: v.detach().cpu().clone() for k, v in mod.net.state_dict().items()}
-    xv, yv = batch(999, B=8)
+    xv, yv = batch(999)
     with torch.no_grad():
         ref = O.prithvi_seg_forward(cfg, sd, xv, training=False)
     ref_loss = O.seg_loss(ref, yv, cw, -1).item()
     ref_m = O.confusion_metrics(O.confusion_matrix(yv.numpy(), ref.argmax(1).numpy(), 2, -1))
     conf_ref = ref.softmax(1).max(1).values.mean().item()
-    print(f"[trained tiny] train loss {first:.4f} -> {last:.4f}; oracle eval loss {ref_loss:.5f} mIoU {ref_m['jaccard']:.5f} acc {ref_m['accuracy']:.5f} mean max-prob {conf_ref:.3f}")
-    assert ref_m["jaccard"] > 0.6  # a trained, confident model (random init: ~0.33)
+    print(f"[trained {variant}] train loss {first:.4f} -> {last:.4f}; oracle eval loss {ref_loss:.5f} mIoU {ref_m['jaccard']:.5f} acc {ref_m['accuracy']:.5f} mean max-prob {conf_ref:.3f}")
+    assert ref_m["jaccard"] > (0.5 if freeze else 0.6)  # a trained, confident model (random init: ~0.33)
     out = {}
     for precision in ("bf16x3", "bf16"):
-        net = PrithviSeg(temporal_step=1, num_classes=2, load_pretrained_weights=False, freeze_backbone=False, variant="prithvi_eo_tiny",
+        net = PrithviSeg(temporal_step=1, num_classes=2, load_pretrained_weights=False, freeze_backbone=freeze, variant=variant,
                          precision=precision, device=DEV)
         net.load_state_dict(sd)
         net.eval()
@@ -368,10 +419,17 @@ def test_trained_weights_bf16_miou_and_loss_vs_oracle():
         agree = (logits.argmax(1).cpu() == ref.argmax(1)).float().mean().item()
         print(f"   {precision:7s}: |dloss| {dl:.2e}  |dmIoU| {dm:.2e}  max|dlogits| {dx:.2e}  argmax agreement {agree:.6f}")
         out[precision] = (dl, dm, dx, agree)
+        del net
     dl, dm, dx, agree = out["bf16x3"]
     assert dl <= 1e-3 and dm <= 1e-3 and dx <= 1e-3, "bf16x3 misses the 1e-3 bar on trained weights"
     dl, dm, dx, agree = out["bf16"]
-    assert dl <= 1e-2 and dm <= 5e-3 and agree >= 0.995, f"bf16 on trained weights: dloss {dl} dmIoU {dm} agreement {agree}"
+    if not freeze:  # Prithvi-tiny trained end to end: bf16 also meets the bar on loss and mIoU (measured 2e-5 / 2e-5)
+        assert dl <= 1e-3 and dm <= 1e-3 and agree >= 0.999, f"bf16 on trained weights: dloss {dl} dmIoU {dm} agreement {agree}"
+    else:
+        # Prithvi-100M, random frozen backbone + trained head: the head reads O(1) features through 12 un-trained blocks and the
+        # bf16 operand rounding reaches the loss (measured |dloss| 2.0e-2, |dmIoU| 6.3e-3, argmax agreement 0.9959): on this case
+        # the 1e-3 bar is met by bf16x3 ONLY.  Bounds = 2 x measured.
+        assert dl <= 4e-2 and dm <= 1.3e-2 and agree >= 0.99, f"bf16 on trained weights: dloss {dl} dmIoU {dm} agreement {agree}"
 
 
 def test_tl_variant_matches_the_oracle_and_its_scales_stay_put():
