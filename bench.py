@@ -126,16 +126,27 @@ def cpu_baseline(target_s: float = 10.0) -> dict:
                      f"{host_cores} host cores (torch intra-op threads)",
            "forward_configs0": fwd}  # fmt: skip
     if host_cores > threads:
-        # BASELINE.md section 4 asks for all physical cores with the count stated: the same step with every host core as an
-        # intra-op thread, reported BESIDE the 32-thread figure (at batch 4 the all-core run is the slower one: oversubscription)
-        torch.set_num_threads(host_cores)
-        step()
-        t0 = time.time()
-        m = 0
-        while m < 2 or time.time() - t0 < 0.3 * target_s:
-            step()
-            m += 1
-        out["all_cores"] = {"value": round(B * m / (time.time() - t0), 3), "cores": host_cores, "steps": m}
+        # BASELINE.md section 4 asks for all physical cores with the count stated: the configs[0] forward (B = 4) with EVERY host core as
+        # an intra-op thread, reported BESIDE the 32-thread figures.  At batch 4 the all-core run is pathologically slow (256 threads
+        # oversubscribe 4 chips: a train step took ~150 s on the bench box), so it runs in a child process under a 75 s watchdog and
+        # covers the forward only; a timeout is reported as such.
+        import subprocess
+
+        code = ("import sys, time, torch; sys.path[:0] = %r; from oracle import prithvi_oracle as O; torch.set_num_threads(%d);"
+                "cfg = O.make_config('prithvi_eo_v1_100', 1, 2); sd = O.make_state_dict(cfg, seed=1042);"
+                "img = torch.randn(4, 6, 1, 224, 224, generator=torch.Generator().manual_seed(1042));\n"
+                "with torch.no_grad():\n"
+                "    O.prithvi_seg_forward(cfg, sd, img, training=False); t0 = time.time(); n = 0\n"
+                "    while n < 2 or time.time() - t0 < 5: O.prithvi_seg_forward(cfg, sd, img, training=False); n += 1\n"
+                "print('ALLCORE', 4 * n / (time.time() - t0), n)") % ([ROOT, os.path.join(ROOT, "instageo-e2e-geospatial-ml_amd")], host_cores)
+        try:
+            r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=75, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+            tok = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("ALLCORE")]
+            out["all_cores"] = {"forward_configs0_chips_per_s": round(float(tok[0][1]), 3), "runs": int(tok[0][2]), "cores": host_cores} if tok else \
+                               {"forward_configs0_chips_per_s": None, "cores": host_cores, "error": (r.stderr or "no output")[-200:]}
+        except subprocess.TimeoutExpired:
+            out["all_cores"] = {"forward_configs0_chips_per_s": None, "cores": host_cores, "timeout_s": 75,
+                                "note": "all-core forward of 4 chips did not finish 3 passes in 75 s (< 0.16 chips/s)"}
         torch.set_num_threads(threads)
     return out
 
@@ -548,8 +559,8 @@ def main() -> None:
         detail["cpu_baseline"] = cb
         out["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
                                "sample": f"oracle train steps (fwd+CE+bwd+AdamW), batch 4, Prithvi-100M T=1 fp32, {cb['cores']} of {cb['host_cores']} host cores",
-                               "host_cores": cb["host_cores"], "all_cores_value": (cb.get("all_cores") or {}).get("value"),
-                               "forward_configs0_chips_per_s": cb["forward_configs0"]["value"]}  # fmt: skip
+                               "host_cores": cb["host_cores"], "forward_configs0_chips_per_s": cb["forward_configs0"]["value"],
+                               "forward_configs0_all_cores": (cb.get("all_cores") or {}).get("forward_configs0_chips_per_s")}  # fmt: skip
     path = args.detail_file or os.path.join(ROOT, "profiles", f"bench_detail_n{world}_b{B}_{args.model}_t{T}.json")
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)

@@ -2,7 +2,7 @@
 # SQ / LDS counter passes for a GEMM microbench: tools/pmc_gemm8.sh OUTDIR [bench script + args]
 # default bench: tools/gemm8_bench.py --v8-only; e.g. tools/pmc_gemm8.sh gpurun_out/pmc_w tools/wgrad_bench.py --group-only
 # (separate --pmc passes with --kernel-trace only, as MI355X_MICROARCH.md prescribes; at most 5 SQ counters per pass, and every
-# pass is checked: a rejected counter set must not produce a silently empty table).  Prints per-kernel averages with
+# pass is checked and bounded by `timeout 300`: a rejected counter set must not produce a silently empty table or a hung box).  Prints per-kernel averages with
 #   mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x CUs x GRBM_GUI_ACTIVE / 8 XCDs)      (cycles / cycles)
 #   wait fractions = SQ_WAIT_* / SQ_WAVE_CYCLES                                           (quad-cycles / quad-cycles)
 OUT=$1; shift
@@ -14,7 +14,7 @@ SCRIPT=$R/$1; shift
 cd /tmp && export TMPDIR=/tmp
 pass() {  # name counters...
     local name=$1; shift
-    rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/pmc_$name -o pmc -- python3 $SCRIPT "${ARGS[@]}" > $OUT/pmc_$name.log 2>&1
+    timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/pmc_$name -o pmc -- python3 $SCRIPT "${ARGS[@]}" > $OUT/pmc_$name.log 2>&1
     local rc=$?
     local n=$(find $OUT/pmc_$name -name '*counter_collection.csv' -size +0 | wc -l)
     if [ $rc -ne 0 ] || [ "$n" -eq 0 ]; then echo "PMC pass $name FAILED (rc=$rc, csv files=$n): see $OUT/pmc_$name.log"; tail -5 $OUT/pmc_$name.log; fi
@@ -24,7 +24,8 @@ pass sq1 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI
 pass sq2 SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
 pass lds1 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS
 pass lds2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INST_CYCLES_VMEM SQ_INSTS_VALU_MFMA_MOPS_BF16
-pass mem FETCH_SIZE WRITE_SIZE
+pass fetch FETCH_SIZE   # FETCH_SIZE and WRITE_SIZE in SEPARATE passes: together rocprofv3 aborts (signal 6) and hangs on this pool
+pass write WRITE_SIZE
 python3 - <<PY
 import csv,glob,collections
 agg=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.defaultdict(collections.Counter)
