@@ -96,9 +96,13 @@ def sliding_window_inference(tile: torch.Tensor, model, mean: Sequence[float], s
     n = hi - lo
     out = torch.empty((n, crop_size, crop_size), dtype=torch.int8, device=tile.device)
     C = tile.shape[0] // temporal_size
-    xbuf = torch.empty((min(batch_size, max(n, 1)), C, temporal_size, crop_size, crop_size), dtype=torch.float32, device=tile.device)
-    for i in range(0, n, batch_size):
-        k = min(batch_size, n - i)
+    # balanced batches: ceil(n / batch_size) batches of nearly equal size (2401 windows at 108 per batch = 23 x 104-105, not 22 x 108 + 25:
+    # a small ragged batch runs the persistent GEMM grids mostly empty and allocates a workspace of its own)
+    nbatch = max(1, -(-n // batch_size))
+    bs = -(-n // nbatch) if n else 1
+    xbuf = torch.empty((max(bs, 1), C, temporal_size, crop_size, crop_size), dtype=torch.float32, device=tile.device)
+    for i in range(0, n, bs):
+        k = min(bs, n - i)
         x, _ = gather_windows(tile, mine[i : i + k], mean, std, temporal_size, crop_size, constant_multiplier, out=xbuf[:k])
         logits = eng.forward(x, training=False, save=False)
         ops.argmax_i8(logits, out[i : i + k])
