@@ -125,12 +125,14 @@ int ig_linear_dgrad_wt(const void* dy_hi, const void* dy_lo, const void* wt_hi, 
  * keeps a transposed operand copy of the Block linears' weights next to the bf16 shadow and refreshes it once per step. */
 int ig_transpose_bf16(const void* src_hi, const void* src_lo, void* dst_hi, void* dst_lo, int R, int C, int batch, long src_stride,
                       long dst_stride, void* stream);
-/* F.scaled_dot_product_attention of timm Attention: qkv [B][N][3][H][64] -> out [B][N][H*64], lse [B][H][N] */
+/* F.scaled_dot_product_attention of timm Attention: qkv [B][N][3][H][hd] -> out [B][N][H*hd], lse [B][H][N]; head_dim 64 or 80.
+ * ig_attention_bwd: dqkv_colsum (optional, fp32 [3*H*hd]) += column sums of dqkv over the B*N tokens = the bias gradient of the
+ * fused qkv Linear (pritvhi.py:446-456 -> timm Attention.qkv); fused into the single-pass backward kernel where that runs. */
 int ig_attention_fwd(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, float* lse, int B, int N, int H,
                      int head_dim, void* stream);
 int ig_attention_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi, const void* out_lo, const void* dout_hi,
-                     const void* dout_lo, const float* lse, float* delta, void* dqkv_hi, void* dqkv_lo, int B, int N, int H,
-                     int head_dim, void* stream);
+                     const void* dout_lo, const float* lse, float* delta, void* dqkv_hi, void* dqkv_lo, float* dqkv_colsum, int B,
+                     int N, int H, int head_dim, void* stream);
 /* gradient plumbing: column sums (bias grads), patch-embed grad prep (cls_token / conv bias grads) */
 int ig_colsum(const void* hi, const void* lo, float* out, long M, int C, void* stream);
 int ig_patch_grad_prep(const float* dx, void* hi, void* lo, float* dcls, float* dbias, int B, int ntok, int D, void* stream);

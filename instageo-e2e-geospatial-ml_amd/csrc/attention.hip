@@ -528,18 +528,21 @@ int ig_attention_fwd(const void* qkv_hi, const void* qkv_lo, void* out_hi, void*
 
 // dqkv[B][N][3][H][64] from dout, qkv, out, lse ; delta: device scratch float[B*H*N]
 int ig_attention_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi, const void* out_lo, const void* dout_hi,
-                     const void* dout_lo, const float* lse, float* delta, void* dqkv_hi, void* dqkv_lo, int B, int N, int H,
-                     int head_dim, void* stream) {
+                     const void* dout_lo, const float* lse, float* delta, void* dqkv_hi, void* dqkv_lo, float* dqkv_colsum, int B, int N,
+                     int H, int head_dim, void* stream) {
     IG_REQUIRE(qkv_hi && out_hi && dout_hi && lse && delta && dqkv_hi, "ig_attention_bwd: null pointer");
     IG_REQUIRE(head_dim == HD || head_dim == 80, "ig_attention_bwd: head_dim must be 64 or 80 (got %d)", head_dim);
     bool split = qkv_lo != nullptr;
     IG_REQUIRE(split == (out_lo != nullptr) && split == (dout_lo != nullptr) && split == (dqkv_lo != nullptr),
                "ig_attention_bwd: split pointers must be given for all tensors or none");
     if (B == 0 || N == 0) return IG_OK;
-    if (head_dim != HD || attn_generic_env())
-        return ig_attention_generic_bwd(qkv_hi, qkv_lo, out_hi, out_lo, dout_hi, dout_lo, lse, delta, dqkv_hi, dqkv_lo, B, N, H, head_dim, stream);
+    if (head_dim != HD || attn_generic_env()) {
+        const int rc = ig_attention_generic_bwd(qkv_hi, qkv_lo, out_hi, out_lo, dout_hi, dout_lo, lse, delta, dqkv_hi, dqkv_lo, B, N, H, head_dim, stream);
+        if (rc != IG_OK || !dqkv_colsum) return rc;
+        return ig_colsum(dqkv_hi, dqkv_lo, dqkv_colsum, (long)B * N, 3 * H * head_dim, stream);
+    }
     {
-        const int rc = ig_attention2_bwd(qkv_hi, qkv_lo, out_hi, out_lo, dout_hi, dout_lo, lse, delta, dqkv_hi, dqkv_lo, B, N, H, stream);
+        const int rc = ig_attention2_bwd(qkv_hi, qkv_lo, out_hi, out_lo, dout_hi, dout_lo, lse, delta, dqkv_hi, dqkv_lo, dqkv_colsum, B, N, H, stream);
         if (rc != IG_ERR_UNSUPPORTED) return rc;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -562,6 +565,10 @@ int ig_attention_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi,
     if (split) IG_ATTN_BWD(true, 2, 1024)
     else IG_ATTN_BWD(false, 4, 1024)
 #undef IG_ATTN_BWD
+    if (dqkv_colsum) {
+        const int rc = ig_colsum(dqkv_hi, dqkv_lo, dqkv_colsum, (long)B * N, 3 * H * head_dim, stream);
+        if (rc != IG_OK) return rc;
+    }
     return ig_check_launch("ig_attention_bwd");
 }
 

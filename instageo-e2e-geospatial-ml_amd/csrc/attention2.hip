@@ -557,7 +557,7 @@ __device__ __forceinline__ bf16x8_t tr_slab(const char* slab, int s, int lane) {
 __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_fused_kernel(const bf16_t* __restrict__ qkv_hi, const bf16_t* __restrict__ do_hi,
                                                                      const bf16_t* __restrict__ o_hi, const float* __restrict__ lse,
                                                                      float* __restrict__ delta, bf16_t* __restrict__ dqkv_hi, int N, int H,
-                                                                     float scale) {
+                                                                     float scale, float* __restrict__ dbias) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* q_img = smem;
     char* d_img = smem + A2_TILE;
@@ -684,12 +684,48 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_fused_kernel(const bf16_
         }
         __syncthreads();
     }
-    // dQ write-out: item = (query, 8-column chunk); 8 lanes cover one 128-byte row segment of dqkv's Q slot
+    // dQ write-out: item = (query, 8-column chunk); 8 lanes cover one 128-byte row segment of dqkv's Q slot.  A thread's chunk is
+    // always c = tid & 7 (the stride is a multiple of 8), so its partial column sums stay in eight registers: the qkv BIAS gradient.
+    float cbq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, cbv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int it = tid; it < N * 8; it += A2_THREADS) {
         const int q = it >> 3, c = it & 7;
         const float4 v0 = *reinterpret_cast<const float4*>(s_dq + q * A2F_DQP + 8 * c), v1 = *reinterpret_cast<const float4*>(s_dq + q * A2F_DQP + 8 * c + 4);
         const float f[8] = {v0.x * scale, v0.y * scale, v0.z * scale, v0.w * scale, v1.x * scale, v1.y * scale, v1.z * scale, v1.w * scale};
         *reinterpret_cast<uint4*>(dqkv_hi + ((size_t)b * N + q) * RS + h * 64 + 8 * c) = pack8(f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cbq[e] += f[e];
+    }
+    if (dbias) {  // wave-uniform
+        // Bias gradient of the fused qkv Linear = column sums of dqkv over the tokens.  Its three parts for this (batch, head):
+        //   Q: sum_q dQ[q][d]                      -- the partial sums above;
+        //   K: sum_key dK[key][d] = sum_q Q[q][d] * (sum_key dS[q][key]) = 0 EXACTLY: the rows of dS sum to zero (softmax Jacobian;
+        //      a key bias shifts every logit of a row by the same amount) -- nothing to add;
+        //   V: sum_key dV[key][d] = sum_q dO[q][d] * (sum_key P[q][key]) = sum_q dO[q][d]: column sums of the dO image in LDS.
+        for (int it = tid; it < N * 8; it += A2_THREADS) {
+            const int q = it >> 3, c = it & 7;
+            float f[8];
+            unpack8(*reinterpret_cast<const uint4*>(d_img + q * 128 + ((c ^ sw2(q)) << 4)), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cbv[e] += f[e];
+        }
+        // lanes with equal (lane & 7) of a wave own the same chunk: fold over lane >> 3, then over the 7 waves through the dead dS slabs
+        float* scr = reinterpret_cast<float*>(smem + A2F_OFF_SLAB);  // [wave][chunk][16]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float a = cbq[e], v = cbv[e];
+            a += __shfl_xor(a, 8, 64), v += __shfl_xor(v, 8, 64);
+            a += __shfl_xor(a, 16, 64), v += __shfl_xor(v, 16, 64);
+            a += __shfl_xor(a, 32, 64), v += __shfl_xor(v, 32, 64);
+            if (lane < 8) scr[(wave * 8 + lane) * 16 + e] = a, scr[(wave * 8 + lane) * 16 + 8 + e] = v;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int part = tid >> 6, col = tid & 63;  // part 0 = Q, 1 = V
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < A2_WAVES; ++w) t += scr[(w * 8 + (col >> 3)) * 16 + part * 8 + (col & 7)];
+            atomicAdd(dbias + (size_t)(part * 2) * H * 64 + h * 64 + col, t);
+        }
     }
     if (!active || key >= N) return;
     const size_t orow = ((size_t)b * N + key) * RS + h * 64;
@@ -739,8 +775,11 @@ int ig_attention2_fwd(const void* qkv_hi, const void* qkv_lo, void* out_hi, void
     return ig_check_launch("ig_attention_fwd(attn2)");
 }
 
+// dbias (optional): the qkv bias gradient, dbias[3][H][64] += column sums of dqkv over the B * N tokens -- fused into the single-pass
+// kernel (the K third is identically zero there), one ig_colsum pass over dqkv behind the two-pass kernels
 int ig_attention2_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi, const void* out_lo, const void* dout_hi,
-                      const void* dout_lo, const float* lse, float* delta, void* dqkv_hi, void* dqkv_lo, int B, int N, int H, void* stream) {
+                      const void* dout_lo, const float* lse, float* delta, void* dqkv_hi, void* dqkv_lo, float* dbias, int B, int N, int H,
+                      void* stream) {
     const char* e = getenv("IG_ATTN2");
     if (e && (atoi(e) == 0 || atoi(e) == 2)) return IG_ERR_UNSUPPORTED;  // 2 = second generation for the forward only
     if (N < 1 || H > 65535 || B > 65535) return IG_ERR_UNSUPPORTED;
@@ -759,7 +798,7 @@ int ig_attention2_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi
         }
         ig_note_kernel("attn2_bwd_fused_kernel");
         hipLaunchKernelGGL(attn2_bwd_fused_kernel, dim3(1, H, B), dim3(A2_THREADS), A2F_SMEM, st, (const bf16_t*)qkv_hi, (const bf16_t*)dout_hi,
-                           (const bf16_t*)out_hi, lse, delta, (bf16_t*)dqkv_hi, N, H, scale);
+                           (const bf16_t*)out_hi, lse, delta, (bf16_t*)dqkv_hi, N, H, scale, dbias);
         return ig_check_launch("ig_attention_bwd(attn2 fused)");
     }
     const char* lb = getenv("IG_ATTN2_DQLB");  // 4 (default): two dQ workgroups per CU at 128 registers (56 B of scratch); 2: one at 143 -- measured 75 vs 85 us
@@ -788,5 +827,9 @@ int ig_attention2_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi
     }
     if (split) IG_A2_BWD(true) else IG_A2_BWD(false)
 #undef IG_A2_BWD
+    if (dbias) {
+        const int rc = ig_colsum(dqkv_hi, dqkv_lo, dbias, (long)B * N, 3 * H * 64, stream);
+        if (rc != IG_OK) return rc;
+    }
     return ig_check_launch("ig_attention_bwd(attn2)");
 }

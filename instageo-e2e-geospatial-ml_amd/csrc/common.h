@@ -59,7 +59,8 @@ int ig_wgrad8_group(int n, const void* const* dy_hi, const void* const* dy_lo, c
 // attention2.hip: second-generation attention forward (32x32x16 MFMA, whole-head K/V in LDS); IG_ERR_UNSUPPORTED -> first generation
 int ig_attention2_fwd(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, float* lse, int B, int N, int H, void* stream);
 int ig_attention2_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi, const void* out_lo, const void* dout_hi,
-                      const void* dout_lo, const float* lse, float* delta, void* dqkv_hi, void* dqkv_lo, int B, int N, int H, void* stream);
+                      const void* dout_lo, const float* lse, float* delta, void* dqkv_hi, void* dqkv_lo, float* dbias, int B, int N, int H,
+                      void* stream);
 // attention_g.hip: any head dimension that is a multiple of 16 (instantiated: 80 for the 600M variants, 64 for A/B runs)
 int ig_attention_generic_fwd(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, float* lse, int B, int N, int H,
                              int head_dim, void* stream);

@@ -624,10 +624,11 @@ class SegEngine:
                               self.Gd(b + "norm2.weight"), self.Gd(b + "norm2.bias"), self.Gd(b + "attn.proj.bias"), M, D)
             # proj
             ops.linear_dgrad(dxb2, self.W(b + "attn.proj.weight"), ws["dtmp"], M, D, D, wt=WT(i, "attn.proj.weight"))
-            ops.attention_bwd(ws["qkv"][i], ws["o"][i], ws["dtmp"], ws["lse"][i], ws["delta"], ws["dqkv"], B, N, H, cfg.head_dim)
+            # (the qkv bias gradient = column sums of dqkv rides on the attention backward: fused into the single-pass kernel)
+            ops.attention_bwd(ws["qkv"][i], ws["o"][i], ws["dtmp"], ws["lse"][i], ws["delta"], ws["dqkv"], B, N, H, cfg.head_dim,
+                              dbias=self.Gd(b + "attn.qkv.bias"))
             # qkv
             ops.linear_dgrad(ws["dqkv"], self.W(b + "attn.qkv.weight"), ws["dtmp"], M, 3 * D, D, wt=WT(i, "attn.qkv.weight"))
-            ops.colsum(ws["dqkv"], self.Gd(b + "attn.qkv.bias"), M, 3 * D)  # after the dgrad has pulled dqkv through the caches
             grp = ws["wgrad_groups"].get(i)
             if grp is None or grp.items[0][2].data_ptr() != self.Gd(b + "mlp.fc2.weight").data_ptr():
                 grp = ws["wgrad_groups"][i] = ops.WgradGroup([

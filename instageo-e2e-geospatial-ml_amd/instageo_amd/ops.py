@@ -389,9 +389,10 @@ def attention_fwd(qkv: BT, out: BT, lse, B: int, N: int, H: int, hd: int = 64) -
     _call("ig_attention_fwd", 4.0 * B * H * N * N * hd, _p(qkv.hi), _p(qkv.lo), _p(out.hi), _p(out.lo), _p(lse), B, N, H, hd, _stream())
 
 
-def attention_bwd(qkv: BT, out: BT, dout: BT, lse, delta, dqkv: BT, B: int, N: int, H: int, hd: int = 64) -> None:
+def attention_bwd(qkv: BT, out: BT, dout: BT, lse, delta, dqkv: BT, B: int, N: int, H: int, hd: int = 64, dbias=None) -> None:
+    """``dbias`` (fp32 [3*H*hd], optional) += column sums of dqkv over the tokens: the bias gradient of the fused qkv Linear."""
     _call("ig_attention_bwd", 10.0 * B * H * N * N * hd, _p(qkv.hi), _p(qkv.lo), _p(out.hi), _p(out.lo), _p(dout.hi), _p(dout.lo), _p(lse), _p(delta),
-              _p(dqkv.hi), _p(dqkv.lo), B, N, H, hd, _stream())
+              _p(dqkv.hi), _p(dqkv.lo), _p(dbias), B, N, H, hd, _stream())
 
 
 def colsum(x: BT, out, M: int, C: int) -> None:

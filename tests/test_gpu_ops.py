@@ -428,6 +428,17 @@ def test_attention_fwd_bwd(split, N):
     delta = torch.empty(B * H * N, device=DEV)
     ops.attention_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H)
     close(dqkv.float(), gref, 1e-4 if split else 2e-2, what="attn bwd")
+    # bias gradient of the fused qkv Linear = column sums of dqkv over the tokens: fused into the single-pass backward (bf16, N <= 224:
+    # Q part from the dQ image, V part = column sums of dO, K part identically zero -- the rows of dS sum to zero), one column-sum
+    # pass behind the other kernels.  It ACCUMULATES into the buffer.
+    dbias = torch.full((3 * H * 64,), 0.5, device=DEV)
+    dq2 = BT.empty((B, N, 3 * H * 64), split, DEV)
+    ops.attention_bwd(qkv, out, dout, lse, delta, dq2, B, N, H, dbias=dbias)
+    assert torch.equal(dq2.hi, dqkv.hi)
+    bref = gref.reshape(B * N, 3 * H * 64).sum(0)
+    close(dbias - 0.5, bref, 2e-5 if split else 6e-3, what="qkv bias gradient")
+    kpart = (dbias - 0.5)[H * 64 : 2 * H * 64].abs().max().item()
+    assert kpart <= (1e-4 if split else 2e-2) * bref.abs().max().item(), f"K third of the qkv bias gradient should vanish, got {kpart}"
 
 
 @pytest.mark.parametrize("split", SPLITS)
