@@ -75,7 +75,7 @@ __device__ __forceinline__ int kc32_off(int r, int c) { return r * 64 + ((c ^ ((
 // 64-wide tiles avoid the 25-60 % of wasted MFMA columns (or rows, for the weight gradients) a fixed 128 x 128 tile
 // would spend on them, and the smaller LDS footprint lets a third workgroup share the CU.
 template <class AL, class BL, class EP, bool A_TR, bool B_TR, int NSEG, int MT, int NT, int WM, int BKT = 64>
-__global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, int N, int K, int tiles_n, int kchunk, int zser) {
+__global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, int N, int K, int tiles_n, int kchunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int WN = 4 / WM;
@@ -109,22 +109,15 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
         }
     }
     const int bm = bid / tiles_n, bn = bid - bm * tiles_n;
-    // zser > 1 (ConvTranspose forward): the workgroup runs the launch's z slices -- the four sub-pixel phases -- ONE AFTER THE OTHER on
-    // its row tile instead of one slice per workgroup: every workgroup then does the same 1 + 2 + 2 + 4 taps of work (the phases are
-    // of very different length) and the input tile is fetched once per workgroup instead of once per phase (8 x over-fetch before)
-    const int zlo = zser > 1 ? 0 : (int)blockIdx.z, zhi = zser > 1 ? zser : zlo + 1;
-    const EP ep0 = ep;
-    for (int z = zlo; z < zhi; ++z) {
-    ep = ep0;  // (init() accumulates the device-side dropout seed offset)
-    al.init(z);
-    bl.init(z);
-    ep.init(z);
+    al.init(blockIdx.z);
+    bl.init(blockIdx.z);
+    ep.init(blockIdx.z);
     if (al.kdim() >= 0) K = al.kdim();
     // split-K (wgrad): split ysplit owns k-tiles [kt0, kt0+nk) of every segment
     const int nk_all = (K + BKT - 1) / BKT;
     const int kt0 = ysplit * kchunk;
     const int nk = min(kchunk, nk_all - kt0);
-    if (nk <= 0) continue;
+    if (nk <= 0) return;
     const int total = nk * NSEG;
 
     f32x4 acc[NT][MT];
@@ -274,7 +267,6 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(AL al, BL bl, EP ep, int M, 
             if (n < N) ep.store(m, n, acc[tn][tm]);
         }
     }
-    }  // z
 }
 
 // ==============================================================================================
@@ -1454,14 +1446,6 @@ inline int conv_version(int n_out) {
     if (mode == 2 && n_out >= 128) return 2;
     return 1;
 }
-// IG_CONVT_SERIAL=1: every workgroup runs the four sub-pixel phases of its row tile one after the other (equal work per workgroup,
-// the input tile fetched once per workgroup instead of once per phase).  Measured (round 3, same box): SLOWER than one phase per
-// workgroup -- 192 -> 96 at 56^2 328 -> 358 us, 384 -> 192 at 28^2 255 -> 283 us, inference -1.4 % -- so it stays off: the phases'
-// re-reads hit the MALL, and a workgroup that walks 9 taps serially exposes four prologue / epilogue bubbles instead of one.
-inline bool convt_serial() {
-    const char* e = getenv("IG_CONVT_SERIAL");
-    return e && atoi(e) != 0;
-}
 inline const bf16_t* zero_page() {
     static void* z = nullptr;
     if (!z) {
@@ -1477,8 +1461,6 @@ template <class AL, class BL, class EP, bool A_TR, bool B_TR>
 int launch_gemm(const AL& al, const BL& bl, const EP& ep_in, int M, int N, int K, int Z, bool split, hipStream_t st,
                 const char* what, bool allow_ksplit = false, int force_ver = 0) {
     if (M <= 0 || N <= 0 || K <= 0) return IG_OK;
-    int zser = 1;
-    if (Z < 0) zser = -Z, Z = 1;  // Z = -n: the n z slices run one after the other inside every workgroup (v1 engine only)
     EP ep = ep_in;
     // Split-K weight gradients (atomic epilogue): `ks` splits store their tiles into workspace slabs and one reduce launch adds them
     // to the gradient in a fixed order (deterministic; the split-K float atomics were ~25 us of each ~100 us launch).
@@ -1682,7 +1664,7 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep_in, int M, int N, int K
             attr_done = true;                                                                                          \
         }                                                                                                              \
         ig_note_kernel("gemm_kernel<%s,%s,%s,%s,%s,%d,%d,%d,%d,%d>", AL::kName, BL::kName, EP::kName, A_TR ? "true" : "false", B_TR ? "true" : "false", NSEG_, MT_, NT_, WM_, BKT_); \
-        hipLaunchKernelGGL(kern, grid, block, lds_, st, al, bl, ep, M, N, K, tn, kchunk, zser);                        \
+        hipLaunchKernelGGL(kern, grid, block, lds_, st, al, bl, ep, M, N, K, tn, kchunk);                              \
     }
 #define IG_LAUNCH_V1(NSEG_, MT_, NT_, WM_) IG_LAUNCH_V1K(NSEG_, MT_, NT_, WM_, 64)
     if constexpr (EP::kStagedAtomic) {
@@ -2092,8 +2074,7 @@ int ig_convT_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const voi
     ep.drop_thresh = ig_drop_thresh16(drop_p);
     ep.drop_inv = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     return launch_gemm<ConvTFwdALoader, ConvTFwdBLoader, EpStore, false, false>(
-        al, bl, ep, al.Mtot, Cout, 4 * Cin, convt_serial() ? -4 : 4, x_lo != nullptr, (hipStream_t)stream, "ig_convT_fwd", false,
-        convt_serial() ? 1 : conv_version(Cout));
+        al, bl, ep, al.Mtot, Cout, 4 * Cin, 4, x_lo != nullptr, (hipStream_t)stream, "ig_convT_fwd", false, conv_version(Cout));
 }
 
 // dx (H,W,Cin) = stride-2 gather of dy (2H,2W,Cout) against Wc
