@@ -1,7 +1,11 @@
 """The direct head-stage kernels (conv_direct.hip) against the implicit-GEMM path on the same inputs at the BASELINE image size
 (224 x 224 x 48, 112 x 112 x 96): both paths consume identical bf16 operands and accumulate in fp32, so they may differ only by
 fp32 summation order -- and by one bf16 ulp where a rounding boundary is crossed.  The library reads IG_CONV_DIRECT once per
-process, hence the two subprocesses."""
+process, hence the two subprocesses.
+
+This is a CONSISTENCY check between two HIP paths of this repo (same dropout masks, same zero pattern, same digests at the full image
+size), not parity evidence: parity of both paths against float64 ``F.conv2d`` / ``F.conv_transpose2d`` is
+``tests/test_gpu_ops.py::test_conv3x3 / test_convT / test_direct_head_kernels_at_model_size_vs_float64``."""
 import json
 import os
 import subprocess
