@@ -480,7 +480,9 @@ def main() -> None:
                            "224x224, 2 classes, class_weights [1,3], ignore -1, dropout 0.1), random init" if headline else
                            f"{args.model} T={T} {NCLS} classes, synthetic int16 chips, dropout 0.1, random init",
                "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-               "launch": "hipGraph" if main_res["graphed"] else "eager", "final_loss": round(main_res["loss"], 5),
+               "launch": "hipGraph" if main_res["graphed"] else "eager",
+               "deterministic": os.environ.get("IG_DETERMINISTIC", "1") != "0",  # bit-reproducible reductions (reference: Trainer(deterministic=True))
+               "final_loss": round(main_res["loss"], 5),
                "whole_step_mfma_frac": round(value / world * 3 * fpc / (PEAK_BF16_TFLOPS * 1e12), 4),
                "encoder_fwd_ms": round(main_res["enc_ms"], 3), "encoder_fwd_tflops": round(enc_tflops, 1),
                "encoder_fwd_mfma_frac": round(enc_tflops / PEAK_BF16_TFLOPS, 4),

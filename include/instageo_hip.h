@@ -43,6 +43,19 @@ int ig_device_info(int device, char* name, int name_len, int* cu_count, int* lds
  * 256 CUs serialises them behind a whole GEMM.  Default 0, or the IG_RESERVED_CUS environment variable. */
 int ig_set_reserved_cus(int n);
 int ig_get_reserved_cus(void);
+/* Run-to-run deterministic reductions (the reference's Trainer runs with deterministic=True, pipeline_utils.py:373; float atomics
+ * make the bias / norm / head gradients depend on arrival order).  shadow: zeroed int64[n] on the device, paralleling the flat fp32
+ * gradient buffer grad_base[n]; while registered, every multi-contributor reduction into that buffer is an INTEGER add of the
+ * 2^44-scaled contribution into the shadow (order-independent; one gradient element must stay below 5.2e5 in magnitude), and the
+ * BatchNorm statistics are folded from per-workgroup partials in index order; call ig_det_fold(lo, hi) once the gradients of flat
+ * range [lo, hi) are complete to add the shadow into them (and clear it).  shadow = NULL switches the mode off.  Not
+ * stream-concurrent: call with no kernel of the library in flight, outside captures.  The cross-entropy statistics of ig_ce_loss
+ * and the weight gradients of the linears (ordered split-K folds) are order-independent in both modes. */
+int ig_set_deterministic(void* shadow, const void* grad_base, long n, void* stream);
+int ig_get_deterministic(void);
+int ig_det_fold(long lo, long hi, void* stream);
+/* the same over n ranges in ONE launch: ranges_dev = DEVICE int64 [n][2] (lo, hi), longest = the longest range (sizes the grid) */
+int ig_det_fold_ranges(int n, const long* ranges_dev, long longest, void* stream);
 
 /* ---- dataset side: normalise + layout (instageo/model/dataloader.py:495-524, 707-750) ---------------- */
 /* src (B, T*C, H, W) band = t*C+c, src_dtype 0=int16 1=float32 -> dst (B, C, T, H, W) f32 = (src*mult-mean_c)/std_c */

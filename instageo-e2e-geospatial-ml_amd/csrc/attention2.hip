@@ -724,7 +724,7 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_fused_kernel(const bf16_
             float t = 0.f;
 #pragma unroll
             for (int w = 0; w < A2_WAVES; ++w) t += scr[(w * 8 + (col >> 3)) * 16 + part * 8 + (col & 7)];
-            atomicAdd(dbias + (size_t)(part * 2) * H * 64 + h * 64 + col, t);
+            ig_red_add(dbias + (size_t)(part * 2) * H * 64 + h * 64 + col, t);
         }
     }
     if (!active || key >= N) return;
@@ -741,6 +741,7 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_fused_kernel(const bf16_
 }
 
 }  // namespace
+IG_DET_TU(attention2)  // constant-memory descriptor of the deterministic-reduction mode (common.h)
 
 // IG_ERR_UNSUPPORTED (no error string): the caller runs the first-generation kernel.  IG_ATTN2=0 disables (A/B runs).
 int ig_attention2_fwd(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, float* lse, int B, int N, int H, void* stream) {

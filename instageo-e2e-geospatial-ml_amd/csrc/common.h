@@ -85,8 +85,43 @@ int ig_tile_grid(int ntiles, int per_cu);
 
 static inline int ig_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// ---- run-to-run deterministic reductions (opt-in: ig_set_deterministic) -------------------------------------------------------
+// Floating-point atomics make a sum depend on the order its contributors arrive in.  In deterministic mode every multi-contributor
+// reduction into the flat gradient buffer goes to a parallel int64 "shadow" of that buffer as a FIXED-POINT integer add (integer
+// addition is associative, so any arrival order gives the same bits); ig_det_fold() then adds shadow * 2^-44 into the gradients and
+// clears the shadow.  2^-44 = 5.7e-14 is the rounding step of one contribution, +-5.2e5 the range of one gradient element.
+// Grid-wide statistics (BatchNorm sums) go through per-workgroup partials and an ordered fold instead (their magnitudes span too
+// many decades for one fixed-point scale).  Targets outside the registered buffer keep the float atomic.  Each translation unit holds its own __constant__ copy of the descriptor (no relocatable device code);
+// IG_DET_TU(name) defines the function runtime.hip calls to update that copy.
+struct IgDet {
+    long long* shadow;  // NULL: mode off
+    const float* base;  // flat gradient buffer the shadow parallels
+    long n;
+};
+static __constant__ IgDet g_igdet;
+#define IG_DET_TU(name)                                                                                      \
+    int ig_det_sync_##name(const IgDet* d, hipStream_t st) {                                                 \
+        return hipMemcpyToSymbolAsync(HIP_SYMBOL(g_igdet), d, sizeof(IgDet), 0, hipMemcpyHostToDevice, st) == hipSuccess ? IG_OK : IG_ERR_HIP; \
+    }
+bool ig_deterministic();  // host-side view of the mode (runtime.hip)
+// per-device grow-only scratch buffers (slot 0: BatchNorm partial sums); never freed, a superseded buffer stays allocated because
+// launches in flight may still use it; NULL on allocation failure.  Not to be grown during a graph capture (first calls are warm-ups).
+void* ig_scratch(int slot, size_t bytes);
+
 // device side ----------------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// out-of-order-safe reduction adds (see IgDet above).  The branch is wave-uniform (a constant-memory flag).
+__device__ __forceinline__ void ig_red_add(float* p, float v) {
+    if (g_igdet.shadow) {
+        const long i = p - g_igdet.base;
+        if ((unsigned long)i < (unsigned long)g_igdet.n) {
+            atomicAdd(reinterpret_cast<unsigned long long*>(g_igdet.shadow + i), (unsigned long long)__float2ll_rn(v * 17592186044416.f));
+            return;
+        }
+    }
+    atomicAdd(p, v);
+}
 
 __device__ __forceinline__ bf16_t f2bf(float f) {
     __bf16 b = (__bf16)f;  // round-to-nearest-even, NaN preserving (v_cvt_pk_bf16_f32)

@@ -453,7 +453,7 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES == 4 ? 2 : 1) void conv3x3_wgra
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) atomicAdd(p.dw + (size_t)(co0 + cb * 16 + 4 * g + r) * (9 * CIN) + nb * 16 + i16, acc[cb][b][r]);
+                for (int r = 0; r < 4; ++r) ig_red_add(p.dw + (size_t)(co0 + cb * 16 + 4 * g + r) * (9 * CIN) + nb * 16 + i16, acc[cb][b][r]);
         }
     }
 }
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(TW_TPB, 1) void convT_wgrad_direct_kernel(CTWParams
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                atomicAdd(p.dw + (size_t)(cb * 16 + 4 * g + r) * (9 * CIN) + tap * CIN + wave * 16 + i16, acc[tap][cb][r]);
+                ig_red_add(p.dw + (size_t)(cb * 16 + 4 * g + r) * (9 * CIN) + tap * CIN + wave * 16 + i16, acc[tap][cb][r]);
 }
 
 // ---- LDS-DMA variant of the ConvTranspose weight gradient ------------------------------------------------------
@@ -931,7 +931,7 @@ __global__ __launch_bounds__(TW_TPB, 1) void convT_wgrad_dma_kernel(CTWParams p,
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                atomicAdd(p.dw + (size_t)(cb * 16 + 4 * g + r) * (9 * CIN) + tap * CIN + wave * 16 + i16, acc[tap][cb][r]);
+                ig_red_add(p.dw + (size_t)(cb * 16 + 4 * g + r) * (9 * CIN) + tap * CIN + wave * 16 + i16, acc[tap][cb][r]);
     if (p.dbias != nullptr) {
         // the four phase waves' partial sums are folded through LDS first: 4 x 48 same-address atomics per workgroup, issued
         // by all 256 workgroups as they finish together, were 60 us of serialised atomics at the tail of a 200 us kernel
@@ -944,7 +944,7 @@ __global__ __launch_bounds__(TW_TPB, 1) void convT_wgrad_dma_kernel(CTWParams p,
                 for (int r = 0; r < 4; ++r) red[wave * COUT + cb * 16 + 4 * g + r] = rs[cb][r];
         }
         __syncthreads();
-        if (tid < COUT) atomicAdd(p.dbias + tid, red[tid] + red[COUT + tid] + red[2 * COUT + tid] + red[3 * COUT + tid]);
+        if (tid < COUT) ig_red_add(p.dbias + tid, red[tid] + red[COUT + tid] + red[2 * COUT + tid] + red[3 * COUT + tid]);
     }
 }
 
@@ -1093,12 +1093,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_dma_kernel(CWParams p, c
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) atomicAdd(p.dw + (size_t)(co0 + cb * 16 + 4 * g + r) * (9 * CIN) + nb * 16 + i16, acc[cb][b][r]);
+                for (int r = 0; r < 4; ++r) ig_red_add(p.dw + (size_t)(co0 + cb * 16 + 4 * g + r) * (9 * CIN) + nb * 16 + i16, acc[cb][b][r]);
         }
     }
     if (do_rs && i16 == 0) {  // every column of the ones-product holds the row sum: lanes with column 0 own rows 4g .. 4g+3
 #pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(p.dbias + co0 + wave * 16 + 4 * g + r, rs[r]);
+        for (int r = 0; r < 4; ++r) ig_red_add(p.dbias + co0 + wave * 16 + 4 * g + r, rs[r]);
     }
 }
 
@@ -1561,6 +1561,7 @@ __global__ __launch_bounds__(576, 1) void convT_dgrad_direct_kernel(CTDParams p,
 }
 
 }  // namespace
+IG_DET_TU(conv_direct)  // constant-memory descriptor of the deterministic-reduction mode (common.h)
 
 static const bf16_t* cd_zero_page() {
     static void* z = nullptr;

@@ -407,26 +407,33 @@ __global__ __launch_bounds__(LNB_TPB) void layernorm_bwd_kernel(const bf16_t* __
             }
         }
     }
-    // cross-wave column reduction
+    // cross-wave column reduction: the waves add their partials into the LDS image one after the other (plain read-modify-write in
+    // wave order, so the sum does not depend on which wave gets there first; this variant only serves the small / odd widths)
     for (int i = threadIdx.x; i < 3 * D; i += LNB_TPB) red[i] = 0.f;
     __syncthreads();
+    for (int w = 0; w < LNB_TPB / 64; ++w) {
+        if (wave == w) {
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        int c = lane + i * 64;
-        if (c < nv) {
-            float* r0 = red + c * 4;
-            atomicAdd(r0 + 0, ag[i].x), atomicAdd(r0 + 1, ag[i].y), atomicAdd(r0 + 2, ag[i].z), atomicAdd(r0 + 3, ag[i].w);
-            float* r1 = red + D + c * 4;
-            atomicAdd(r1 + 0, ab[i].x), atomicAdd(r1 + 1, ab[i].y), atomicAdd(r1 + 2, ab[i].z), atomicAdd(r1 + 3, ab[i].w);
-            float* r2 = red + 2 * D + c * 4;
-            atomicAdd(r2 + 0, ac[i].x), atomicAdd(r2 + 1, ac[i].y), atomicAdd(r2 + 2, ac[i].z), atomicAdd(r2 + 3, ac[i].w);
+            for (int i = 0; i < MAXV; ++i) {
+                int c = lane + i * 64;
+                if (c < nv) {
+                    float4* r0 = reinterpret_cast<float4*>(red + c * 4);
+                    float4* r1 = reinterpret_cast<float4*>(red + D + c * 4);
+                    float4* r2 = reinterpret_cast<float4*>(red + 2 * D + c * 4);
+                    float4 t0 = *r0, t1 = *r1, t2 = *r2;
+                    t0.x += ag[i].x, t0.y += ag[i].y, t0.z += ag[i].z, t0.w += ag[i].w;
+                    t1.x += ab[i].x, t1.y += ab[i].y, t1.z += ab[i].z, t1.w += ab[i].w;
+                    t2.x += ac[i].x, t2.y += ac[i].y, t2.z += ac[i].z, t2.w += ac[i].w;
+                    *r0 = t0, *r1 = t1, *r2 = t2;
+                }
+            }
         }
+        __syncthreads();
     }
-    __syncthreads();
     for (int i = threadIdx.x; i < D; i += LNB_TPB) {
-        if (dgamma) atomicAdd(dgamma + i, red[i]);
-        if (dbeta) atomicAdd(dbeta + i, red[D + i]);
-        if (dcol) atomicAdd(dcol + i, red[2 * D + i]);
+        if (dgamma) ig_red_add(dgamma + i, red[i]);
+        if (dbeta) ig_red_add(dbeta + i, red[D + i]);
+        if (dcol) ig_red_add(dcol + i, red[2 * D + i]);
     }
 }
 
@@ -555,7 +562,7 @@ __global__ __launch_bounds__(LNB_TPB) void layernorm_bwd_exact_kernel(const bf16
 #pragma unroll
         for (int w = 0; w < NWV; ++w) t += red[(size_t)w * 3 * D + i];
         float* dst = i < D ? dgamma : i < 2 * D ? dbeta : dcol;
-        if (dst) atomicAdd(dst + (i < D ? i : i < 2 * D ? i - D : i - 2 * D), t);
+        if (dst) ig_red_add(dst + (i < D ? i : i < 2 * D ? i - D : i - 2 * D), t);
     }
 }
 
@@ -600,7 +607,7 @@ __global__ __launch_bounds__(TPB) void colsum_kernel(const bf16_t* __restrict__ 
     for (int i = threadIdx.x; i < cw; i += TPB) {
         float t = 0.f;
         for (int q = 0; q < nslice; ++q) t += red[(size_t)q * cw + i];
-        atomicAdd(out + c0 + i, t);
+        ig_red_add(out + c0 + i, t);
     }
 }
 
@@ -630,16 +637,16 @@ __global__ __launch_bounds__(TPB) void patch_grad_prep_kernel(const float* __res
         for (int t = t0; t < t1; ++t) {
             float4 v = *reinterpret_cast<const float4*>(dx + ((size_t)b * ntok + t) * D + c * 4);
             if (t == 0) {
-                atomicAdd(dcls + c * 4 + 0, v.x), atomicAdd(dcls + c * 4 + 1, v.y);
-                atomicAdd(dcls + c * 4 + 2, v.z), atomicAdd(dcls + c * 4 + 3, v.w);
+                ig_red_add(dcls + c * 4 + 0, v.x), ig_red_add(dcls + c * 4 + 1, v.y);
+                ig_red_add(dcls + c * 4 + 2, v.z), ig_red_add(dcls + c * 4 + 3, v.w);
             } else {
                 float f[4] = {v.x, v.y, v.z, v.w};
                 store4_split(hi, lo, ((size_t)b * (ntok - 1) + (t - 1)) * D + c * 4, f);
                 acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
             }
         }
-        atomicAdd(dbias + c * 4 + 0, acc.x), atomicAdd(dbias + c * 4 + 1, acc.y);
-        atomicAdd(dbias + c * 4 + 2, acc.z), atomicAdd(dbias + c * 4 + 3, acc.w);
+        ig_red_add(dbias + c * 4 + 0, acc.x), ig_red_add(dbias + c * 4 + 1, acc.y);
+        ig_red_add(dbias + c * 4 + 2, acc.z), ig_red_add(dbias + c * 4 + 3, acc.w);
     }
 }
 
@@ -649,7 +656,7 @@ __global__ __launch_bounds__(TPB) void patch_grad_prep_kernel(const float* __res
 // pass 1: per-channel sum / sum of squares: fp32 partials per thread, LDS reduction per block, one fp64
 // atomic per (block, channel, statistic)
 __global__ __launch_bounds__(TPB) void bn_stats_kernel(const bf16_t* __restrict__ hi, const bf16_t* __restrict__ lo,
-                                                       double* __restrict__ sums, long M, int C, int rows_per_block) {
+                                                       double* __restrict__ sums, long M, int C, int rows_per_block, float* __restrict__ part) {
     extern __shared__ float red[];  // [2C]
     const int units = C / 8;
     const int tu = min(units, TPB), nslice = TPB / tu;
@@ -697,7 +704,8 @@ __global__ __launch_bounds__(TPB) void bn_stats_kernel(const bf16_t* __restrict_
         float t = red[i];
         if (direct)
             for (int q2 = 1; q2 < nslice; ++q2) t += red[(size_t)q2 * 2 * C + i];
-        atomicAdd(sums + i, (double)t);
+        if (part) part[(size_t)blockIdx.x * 2 * C + i] = t;  // deterministic mode: bn_part_fold_kernel sums the workgroups in index order
+        else atomicAdd(sums + i, (double)t);
     }
 }
 // finalize: train -> batch statistics (+ running update), eval -> running statistics
@@ -772,7 +780,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const bf16_t* __rest
                                                             const bf16_t* __restrict__ dyh, const bf16_t* __restrict__ dyl,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                            double* __restrict__ sums, long M, int C, int rows_per_block) {
+                                                            double* __restrict__ sums, long M, int C, int rows_per_block, float* __restrict__ part) {
     extern __shared__ float red[];  // [2C]
     const int units = C / 8;
     const int tu = min(units, TPB), nslice = TPB / tu;
@@ -835,7 +843,33 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const bf16_t* __rest
         float t = red[i];
         if (direct)
             for (int q2 = 1; q2 < nslice; ++q2) t += red[(size_t)q2 * 2 * C + i];
-        atomicAdd(sums + i, (double)t);
+        if (part) part[(size_t)blockIdx.x * 2 * C + i] = t;  // deterministic mode: bn_part_fold_kernel sums the workgroups in index order
+        else atomicAdd(sums + i, (double)t);
+    }
+}
+// deterministic mode: sums[i] = sum over the workgroups of the reduce pass of part[wg][i], in a fixed order (strided subsets
+// per column in wg order, folded in subset order) -- the float atomics of the default mode arrive in any order, and a fixed-point
+// integer sum has no range for both the forward moments (up to 1e10) and the backward ones (down to 1e-9)
+__global__ __launch_bounds__(1024) void bn_part_fold_kernel(const float* __restrict__ part, double* __restrict__ sums, int nwg, int n) {
+    // 64 columns x 16 row subsets per workgroup; every thread keeps four independent partial sums so that its loads overlap
+    __shared__ double sub[16][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+    if (c < n) {
+        int w = g;
+        for (; w + 48 < nwg; w += 64) {
+            t0 += (double)part[(size_t)w * n + c], t1 += (double)part[(size_t)(w + 16) * n + c];
+            t2 += (double)part[(size_t)(w + 32) * n + c], t3 += (double)part[(size_t)(w + 48) * n + c];
+        }
+        for (; w < nwg; w += 16) t0 += (double)part[(size_t)w * n + c];
+    }
+    sub[g][threadIdx.x & 63] = (t0 + t1) + (t2 + t3);
+    __syncthreads();
+    if (g == 0 && c < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += sub[q][threadIdx.x];
+        sums[c] = t;
     }
 }
 // backward pass 2: dx = scale*(dyr - sum_dy/n - xhat*sum_dyxhat/n); also emits dgamma/dbeta once (block 0).
@@ -849,7 +883,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const bf16_t* __restr
                                                            float* __restrict__ dbeta, long M, int C, double n, int rows_per_block) {
     if (blockIdx.x == 0) {
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
-            if (dbeta) atomicAdd(dbeta + c, (float)sums[c]);
+            if (dbeta) atomicAdd(dbeta + c, (float)sums[c]);  // one contributor per element: order-independent
             if (dgamma) atomicAdd(dgamma + c, (float)sums[C + c]);
         }
     }
@@ -985,6 +1019,7 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
 
 
 }  // namespace
+IG_DET_TU(elementwise)  // constant-memory descriptor of the deterministic-reduction mode (common.h)
 
 #define ST(s) ((hipStream_t)(s))
 
@@ -1248,10 +1283,17 @@ int ig_bn_relu_fwd(const void* x_hi, const void* x_lo, const float* gamma, const
     IG_REQUIRE(C % 8 == 0 && C <= 4096, "ig_bn_relu_fwd: C must be a multiple of 8 and <= 4096 (got %d)", C);
     if (M == 0) return IG_OK;
     if (training) {
-        (void)hipMemsetAsync(sums, 0, 2 * (size_t)C * sizeof(double), ST(stream));
-        const int rpb = bn_reduce_rows(M);
-        hipLaunchKernelGGL(bn_stats_kernel, dim3(ig_cdiv(M, rpb)), dim3(TPB), bn_red_bytes(C), ST(stream), (const bf16_t*)x_hi, (const bf16_t*)x_lo,
-                           sums, M, C, rpb);
+        const int rpb = bn_reduce_rows(M), nwg = ig_cdiv(M, rpb);
+        float* part = nullptr;
+        if (ig_deterministic()) {
+            part = (float*)ig_scratch(0, (size_t)nwg * 2 * C * sizeof(float));
+            IG_REQUIRE(part, "ig_bn_relu_fwd: scratch allocation failed");
+        } else {
+            (void)hipMemsetAsync(sums, 0, 2 * (size_t)C * sizeof(double), ST(stream));
+        }
+        hipLaunchKernelGGL(bn_stats_kernel, dim3(nwg), dim3(TPB), bn_red_bytes(C), ST(stream), (const bf16_t*)x_hi, (const bf16_t*)x_lo,
+                           sums, M, C, rpb, part);
+        if (part) hipLaunchKernelGGL(bn_part_fold_kernel, dim3(ig_cdiv(2 * C, 64)), dim3(1024), 0, ST(stream), part, sums, nwg, 2 * C);
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(ig_cdiv(C, TPB)), dim3(TPB), 0, ST(stream), sums, gamma, beta, running_mean,
                        running_var, scale, shift, mean, rstd, (double)M, C, eps, momentum, training, update_running);
@@ -1268,10 +1310,17 @@ int ig_bn_relu_bwd(const void* x_hi, const void* x_lo, const void* dy_hi, const 
     IG_REQUIRE(x_hi && dy_hi && scale && shift && mean && rstd && dx_hi && sums, "ig_bn_relu_bwd: null pointer");
     IG_REQUIRE(C % 8 == 0 && C <= 4096, "ig_bn_relu_bwd: C must be a multiple of 8 and <= 4096 (got %d)", C);
     if (M == 0) return IG_OK;
-    (void)hipMemsetAsync(sums, 0, 2 * (size_t)C * sizeof(double), ST(stream));
-    const int rpb = bn_reduce_rows(M);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ig_cdiv(M, rpb)), dim3(TPB), bn_red_bytes(C), ST(stream), (const bf16_t*)x_hi, (const bf16_t*)x_lo,
-                       (const bf16_t*)dy_hi, (const bf16_t*)dy_lo, scale, shift, mean, rstd, sums, M, C, rpb);
+    const int rpb = bn_reduce_rows(M), nwg = ig_cdiv(M, rpb);
+    float* part = nullptr;
+    if (ig_deterministic()) {
+        part = (float*)ig_scratch(0, (size_t)nwg * 2 * C * sizeof(float));
+        IG_REQUIRE(part, "ig_bn_relu_bwd: scratch allocation failed");
+    } else {
+        (void)hipMemsetAsync(sums, 0, 2 * (size_t)C * sizeof(double), ST(stream));
+    }
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nwg), dim3(TPB), bn_red_bytes(C), ST(stream), (const bf16_t*)x_hi, (const bf16_t*)x_lo,
+                       (const bf16_t*)dy_hi, (const bf16_t*)dy_lo, scale, shift, mean, rstd, sums, M, C, rpb, part);
+    if (part) hipLaunchKernelGGL(bn_part_fold_kernel, dim3(ig_cdiv(2 * C, 64)), dim3(1024), 0, ST(stream), part, sums, nwg, 2 * C);
     const int arpb = bn_apply_rows(C);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ig_cdiv(M, arpb)), dim3(TPB), 0, ST(stream), (const bf16_t*)x_hi,
                        (const bf16_t*)x_lo, (const bf16_t*)dy_hi, (const bf16_t*)dy_lo, scale, shift, mean, rstd, sums, (bf16_t*)dx_hi,

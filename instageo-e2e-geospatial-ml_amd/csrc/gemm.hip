@@ -606,7 +606,7 @@ __global__ __launch_bounds__(NTHR2 * DUALK, (BKT == 32 ? 4 : 2)) void gemm2_kern
                             v += __shfl_xor(v, 2, 64);
                             v += __shfl_xor(v, 4, 64);
                             v += __shfl_xor(v, 8, 64);
-                            if ((lane & 15) == 0 && n + c < N) atomicAdd(ep.colsum + n + c, v);
+                            if ((lane & 15) == 0 && n + c < N) ig_red_add(ep.colsum + n + c, v);
                         }
                     }
                 }
@@ -855,7 +855,7 @@ __global__ __launch_bounds__(NTHR5, 2) void gemm5_kernel(AL al, BL bl, EP ep, in
                         v += __shfl_xor(v, 2, 64);
                         v += __shfl_xor(v, 4, 64);
                         v += __shfl_xor(v, 8, 64);
-                        if ((lane & 15) == 0 && n + c < N) atomicAdd(ep.colsum + n + c, v);
+                        if ((lane & 15) == 0 && n + c < N) ig_red_add(ep.colsum + n + c, v);
                     }
                 }
             }
@@ -1373,14 +1373,14 @@ struct EpAtomic {
     __device__ void init(int z) { zoff = (long)z * zstride; }
     __device__ void add(int m, int n, float v) const {
         if (partial) partial[(size_t)(split >= 0 ? split : (int)blockIdx.y) * slab + (size_t)m * ldo + n] = v;
-        else atomicAdd(out + (size_t)m * ldo + zoff + n, v);
+        else ig_red_add(out + (size_t)m * ldo + zoff + n, v);
     }
     __device__ void store(int m, int n, f32x4 a) const {
         float* p = out + (size_t)m * ldo + zoff + n;
-        atomicAdd(p + 0, a[0]);
-        atomicAdd(p + 1, a[1]);
-        atomicAdd(p + 2, a[2]);
-        atomicAdd(p + 3, a[3]);
+        ig_red_add(p + 0, a[0]);
+        ig_red_add(p + 1, a[1]);
+        ig_red_add(p + 2, a[2]);
+        ig_red_add(p + 3, a[3]);
     }
 };
 
@@ -1729,6 +1729,7 @@ inline PlainLoader plain_b(const void* hi, const void* lo, int R, int C, long ld
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 }  // namespace
+IG_DET_TU(gemm)  // constant-memory descriptor of the deterministic-reduction mode (common.h)
 
 #define IG_SPLIT_CONSISTENT(a_lo, b_lo) \
     IG_REQUIRE(((a_lo) == nullptr) == ((b_lo) == nullptr), "split (lo) pointers must be given for all bf16 operands or none")

@@ -453,7 +453,7 @@ __global__ __launch_bounds__(128 * WC, 2) void gemm8_kernel(G8Params p) {
                     v += __shfl_xor(v, 8, 64);
                     v += __shfl_xor(v, 16, 64);
                     v += __shfl_xor(v, 32, 64);
-                    if (lane < 8) atomicAdd(p.colsum + n0 + rcol + j, v);
+                    if (lane < 8) ig_red_add(p.colsum + n0 + rcol + j, v);
                 }
             }
         } else {
@@ -555,6 +555,7 @@ int g8_launch(const G8Params& p, int grid, hipStream_t st, bool small) {
 }
 
 }  // namespace
+IG_DET_TU(gemm8)  // constant-memory descriptor of the deterministic-reduction mode (common.h)
 
 // IG_ERR_UNSUPPORTED (no error string) when the shape is not covered: the caller falls back to the generic engines.
 int ig_gemm8_nt(const G8Params& p, void* stream) {

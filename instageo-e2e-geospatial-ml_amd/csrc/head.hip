@@ -135,30 +135,31 @@ __global__ __launch_bounds__(TPB) void classifier_bwd_kernel(const float* __rest
                                                              long M, long HW, int C, int ncls, uint32_t drop_seed,
                                                              const uint32_t* drop_seed_dev, uint32_t drop_thresh, float drop_inv,
                                                              int iters, int slab) {
-    // w[ncls*C] | dbacc[ncls] (padded to 4) | dW partials: one [ncls*C] slab per pixel slice when `slab` (plain stores; LDS
+    // w[ncls*C] | dbacc[ncls] (padded to 4, 64-bit fixed point) | dW partials: one [ncls*C] slab per pixel slice when `slab` (plain stores; LDS
     // float atomics retire only a few lanes per cycle), else a single [ncls*C] accumulated with atomics
     extern __shared__ __attribute__((aligned(16))) float sm[];
     if (drop_seed_dev) drop_seed += *drop_seed_dev;
     float* sw = sm;
-    float* sdb = sm + ncls * C;
-    float* sdw = sdb + ((ncls + 3) & ~3);
+    unsigned long long* sdbq = reinterpret_cast<unsigned long long*>(sm + ncls * C);  // [ncls] padded to 4 (C % 8 == 0: 8-byte aligned)
+    float* sdw = sm + ncls * C + 2 * ((ncls + 3) & ~3);
     for (int i = threadIdx.x; i < ncls * C; i += TPB) {
         sw[i] = w[i];
         if (!slab) sdw[i] = 0.f;
     }
-    for (int i = threadIdx.x; i < ncls; i += TPB) sdb[i] = 0.f;
+    // bias-gradient partials of the pixel slices: 2^44 fixed point, so the LDS adds commute (run-to-run identical bits)
+    for (int i = threadIdx.x; i < ncls; i += TPB) sdbq[i] = 0ull;
     __syncthreads();
     const float gscale = count ? (float)(1.0 / fmax(count[1], 1.0)) : 1.f;
     const int nu = C / 8, nsl = TPB / nu;
     const int u = threadIdx.x % nu, sl = threadIdx.x / nu;
+    float dwa[NC][8], dba[NC];
+#pragma unroll
+    for (int n = 0; n < NC; ++n) {
+        dba[n] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dwa[n][j] = 0.f;
+    }
     if (sl < nsl) {
-        float dwa[NC][8], dba[NC];
-#pragma unroll
-        for (int n = 0; n < NC; ++n) {
-            dba[n] = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) dwa[n][j] = 0.f;
-        }
         const long m0 = (long)blockIdx.x * nsl * iters + sl;
         for (int it = 0; it < iters; ++it) {
             const long m = m0 + (long)it * nsl;
@@ -205,12 +206,23 @@ __global__ __launch_bounds__(TPB) void classifier_bwd_kernel(const float* __rest
                     float* dst = sdw + (size_t)sl * ncls * C + n * C + u * 8;
                     *reinterpret_cast<float4*>(dst) = make_float4(dwa[n][0], dwa[n][1], dwa[n][2], dwa[n][3]);
                     *reinterpret_cast<float4*>(dst + 4) = make_float4(dwa[n][4], dwa[n][5], dwa[n][6], dwa[n][7]);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) atomicAdd(sdw + n * C + u * 8 + j, dwa[n][j]);
                 }
-                if (u == 0) atomicAdd(sdb + n, dba[n]);
+                if (u == 0) atomicAdd(sdbq + n, (unsigned long long)__float2ll_rn(dba[n] * 17592186044416.f));
             }
+        }
+    }
+    if (!slab) {  // no room for a slab per pixel slice: the slices add into the single image one after the other (fixed order)
+        for (int s2 = 0; s2 < nsl; ++s2) {
+            if (sl == s2) {
+#pragma unroll
+                for (int n = 0; n < NC; ++n) {
+                    if (n < ncls) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) sdw[n * C + u * 8 + j] += dwa[n][j];
+                    }
+                }
+            }
+            __syncthreads();
         }
     }
     __syncthreads();
@@ -218,9 +230,9 @@ __global__ __launch_bounds__(TPB) void classifier_bwd_kernel(const float* __rest
         float t = sdw[i];
         if (slab)
             for (int q = 1; q < nsl; ++q) t += sdw[(size_t)q * ncls * C + i];
-        atomicAdd(dw + i, t);
+        ig_red_add(dw + i, t);
     }
-    for (int i = threadIdx.x; i < ncls; i += TPB) atomicAdd(db + i, sdb[i]);
+    for (int i = threadIdx.x; i < ncls; i += TPB) ig_red_add(db + i, (float)((double)(long long)sdbq[i] * 5.684341886080802e-14));
 }
 
 // Wide variant (ncls x C too large for the per-slice dW slabs above, e.g. 13 classes x 144 channels of the multi-temporal
@@ -241,11 +253,11 @@ __global__ __launch_bounds__(TPB) void classifier_bwd_wide_kernel(const float* _
     const int cw = min(CLS_CHUNK, C - c0);            // channels in the chunk
     const int nu = cw / 8, nsl = TPB / nu;
     float* sw = sm;                                   // [ncls][cw]
-    float* sdb = sw + ncls * CLS_CHUNK;               // [ncls] (padded to 16)
-    float* slab = sdb + 16;                           // [nsl][4][cw]  (<= 8192 floats)
+    unsigned long long* sdbq = reinterpret_cast<unsigned long long*>(sw + ncls * CLS_CHUNK);  // [ncls] (padded to 16), 2^44 fixed point
+    float* slab = sw + ncls * CLS_CHUNK + 32;         // [nsl][4][cw]  (<= 8192 floats)
     float* sdl = slab + TPB * 32;                     // [ncls][CLS_IG * nsl] dlogits of a group of CLS_IG iterations, pre-scaled
     for (int i = threadIdx.x; i < ncls * cw; i += TPB) sw[i] = w[(i / cw) * C + c0 + (i % cw)];
-    for (int i = threadIdx.x; i < 16; i += TPB) sdb[i] = 0.f;
+    for (int i = threadIdx.x; i < 16; i += TPB) sdbq[i] = 0ull;
     __syncthreads();
     const float gscale = count ? (float)(1.0 / fmax(count[1], 1.0)) : 1.f;
     const int u = threadIdx.x % nu, sl = threadIdx.x / nu;
@@ -319,7 +331,7 @@ __global__ __launch_bounds__(TPB) void classifier_bwd_wide_kernel(const float* _
     if (live && blockIdx.y == 0 && u == 0) {
 #pragma unroll
         for (int n = 0; n < NC; ++n)
-            if (n < ncls) atomicAdd(sdb + n, dba[n]);
+            if (n < ncls) atomicAdd(sdbq + n, (unsigned long long)__float2ll_rn(dba[n] * 17592186044416.f));
     }
     __syncthreads();
     // fold the dW partials of the pixel slices, four classes per pass
@@ -341,13 +353,13 @@ __global__ __launch_bounds__(TPB) void classifier_bwd_wide_kernel(const float* _
             if (n < ncls) {
                 float t = 0.f;
                 for (int s2 = 0; s2 < nsl; ++s2) t += slab[((size_t)s2 * 4 + k) * cw + c];
-                atomicAdd(dw + (size_t)n * C + c0 + c, t);
+                ig_red_add(dw + (size_t)n * C + c0 + c, t);
             }
         }
     }
     __syncthreads();
     if (blockIdx.y == 0)
-        for (int i = threadIdx.x; i < ncls; i += TPB) atomicAdd(db + i, sdb[i]);
+        for (int i = threadIdx.x; i < ncls; i += TPB) ig_red_add(db + i, (float)((double)(long long)sdbq[i] * 5.684341886080802e-14));
 }
 
 // stats[0] += sum w_y*nll over valid pixels ; stats[1] += #valid.  dlogits (optional) is left UN-normalised:
@@ -358,11 +370,9 @@ __global__ __launch_bounds__(TPB) void ce_loss_kernel(const float* __restrict__ 
                                                       const float* __restrict__ cw, long ignore_index, double* __restrict__ stats,
                                                       float* __restrict__ dlogits, long long* __restrict__ preds,
                                                       signed char* __restrict__ preds_i8, unsigned long long* __restrict__ confusion,
-                                                      long M, long HW, int ncls) {
-    extern __shared__ unsigned int hist[];  // [ncls*ncls] + 2 floats for loss/count
-    float* red = reinterpret_cast<float*>(hist + ncls * ncls);
+                                                      long M, long HW, int ncls, unsigned long long* __restrict__ acc, unsigned* __restrict__ arrived) {
+    extern __shared__ unsigned int hist[];  // [ncls*ncls]
     for (int i = threadIdx.x; i < ncls * ncls; i += TPB) hist[i] = 0u;
-    if (threadIdx.x < 2) red[threadIdx.x] = 0.f;
     __syncthreads();
     // grid-stride over pixels: ~1k workgroups end in one round of global atomics each (a workgroup per 256 pixels made
     // the 21k same-address double atomics the whole cost of the kernel).  VEC = 4 (HW % 4 == 0): a thread takes four
@@ -444,11 +454,27 @@ __global__ __launch_bounds__(TPB) void ce_loss_kernel(const float* __restrict__ 
                 preds_i8[m0] = (signed char)amv[0];
         }
     }
+    // (loss, count) of the launch as INTEGER atomics (the loss partial of a workgroup in 2^28 fixed point, the count exactly), so
+    // the reported loss is bit-identical from run to run whatever order the workgroups finish in; the workgroup that arrives last
+    // converts the totals, adds them to stats and re-arms the scratch.  Waves are folded in index order.
+    __shared__ float wred[TPB / 64][2];
     my_loss = wave_sum(my_loss);
     my_cnt = wave_sum(my_cnt);
-    if ((threadIdx.x & 63) == 0) atomicAdd(red, my_loss), atomicAdd(red + 1, my_cnt);
+    if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6][0] = my_loss, wred[threadIdx.x >> 6][1] = my_cnt;
     __syncthreads();
-    if (threadIdx.x == 0 && stats) atomicAdd(stats, (double)red[0]), atomicAdd(stats + 1, (double)red[1]);
+    if (stats && threadIdx.x == 0) {
+        float l = 0.f, c = 0.f;
+        for (int w = 0; w < TPB / 64; ++w) l += wred[w][0], c += wred[w][1];
+        const unsigned long long r0 = atomicAdd(acc, (unsigned long long)__double2ll_rn((double)l * 268435456.0));
+        const unsigned long long r1 = atomicAdd(acc + 1, (unsigned long long)c);
+        asm volatile("" ::"v"(r0), "v"(r1));  // both adds have been performed before this workgroup counts itself in
+        if (atomicAdd(arrived, 1u) == gridDim.x - 1) {
+            const long long tl = (long long)atomicExch(acc, 0ull);
+            const unsigned long long tc = atomicExch(acc + 1, 0ull);
+            atomicExch(arrived, 0u);  // launches that share the scratch are ordered on one stream
+            stats[0] += (double)tl * (1.0 / 268435456.0), stats[1] += (double)tc;
+        }
+    }
     if (confusion)
         for (int i = threadIdx.x; i < ncls * ncls; i += TPB)
             if (hist[i]) atomicAdd(confusion + i, (unsigned long long)hist[i]);
@@ -683,6 +709,7 @@ __global__ __launch_bounds__(TPB) void confusion_kernel(const long long* __restr
 inline uint32_t thresh_of(float p) { return ig_drop_thresh16(p); }
 
 }  // namespace
+IG_DET_TU(head)  // constant-memory descriptor of the deterministic-reduction mode (common.h)
 
 extern "C" {
 
@@ -728,7 +755,7 @@ int ig_classifier_bwd(const float* dlogits, const void* f_hi, const void* f_lo, 
         // weights | db | slab (<= 256 threads x 4 classes x 8 channels) | dlogits group (ncls x CLS_IG x <= 128 pixel slices)
         const int rem_units = (C % CLS_CHUNK) / 8;                                  // units of the last (narrower) chunk, 0 = none
         const int nsl_max = TPB / (rem_units ? rem_units : CLS_CHUNK / 8);        // its pixel slices
-        const size_t smw = ((size_t)ncls * CLS_CHUNK + 16 + (size_t)TPB * 32 + (size_t)ncls * CLS_IG * nsl_max) * sizeof(float);
+        const size_t smw = ((size_t)ncls * CLS_CHUNK + 32 + (size_t)TPB * 32 + (size_t)ncls * CLS_IG * nsl_max) * sizeof(float);
         IG_REQUIRE(smw <= 160 * 1024, "ig_classifier_bwd: ncls x C = %d x %d does not fit the LDS", ncls, C);
         static bool attrw = false;
         if (!attrw) {
@@ -745,7 +772,7 @@ int ig_classifier_bwd(const float* dlogits, const void* f_hi, const void* f_lo, 
 #undef IG_CLS_BWDW
         return ig_check_launch("ig_classifier_bwd");
     }
-    size_t sm = ((size_t)ncls * C + ((ncls + 3) & ~3) + (slab ? slab_floats : (size_t)ncls * C)) * sizeof(float);
+    size_t sm = ((size_t)ncls * C + 2 * ((ncls + 3) & ~3) + (slab ? slab_floats : (size_t)ncls * C)) * sizeof(float);
     long iters = (M + nsl * 1024 - 1) / (nsl * 1024);  // ~1k workgroups: one round of dW/db atomics each
     if (iters < 8) iters = 8;
     const long ppb = nsl * iters;  // pixels per block
@@ -770,7 +797,23 @@ int ig_ce_loss(const float* logits, const void* labels, int label_dtype, const f
     IG_REQUIRE(ncls >= 1 && ncls <= MAXC, "ig_ce_loss: 1 <= ncls <= %d (got %d)", MAXC, ncls);
     long M = (long)B * HW;
     if (M == 0) return IG_OK;
-    size_t sm = (size_t)ncls * ncls * sizeof(unsigned) + 2 * sizeof(float);
+    size_t sm = (size_t)ncls * ncls * sizeof(unsigned);
+    // per-device scratch of the order-independent (loss, count) sums: two 64-bit accumulators + the arrival counter; allocated once,
+    // never freed, never during a graph capture (the first call of a process is a warm-up call)
+    static unsigned long long* acc_dev[16] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    IG_REQUIRE(dev >= 0 && dev < 16, "ig_ce_loss: device index %d", dev);
+    if (stats && !acc_dev[dev]) {
+        if (hipMalloc((void**)&acc_dev[dev], 4 * sizeof(unsigned long long)) != hipSuccess ||
+            hipMemset(acc_dev[dev], 0, 4 * sizeof(unsigned long long)) != hipSuccess) {
+            ig_set_error("ig_ce_loss: scratch allocation failed");
+            acc_dev[dev] = nullptr;
+            return IG_ERR_HIP;
+        }
+    }
+    unsigned long long* acc = acc_dev[dev];
+    unsigned* arrived = acc ? reinterpret_cast<unsigned*>(acc + 2) : nullptr;
     const bool vec4 = HW % 4 == 0 && (reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits) |
                                       reinterpret_cast<uintptr_t>(preds) | reinterpret_cast<uintptr_t>(preds_i8)) % 16 == 0;
     const int vec = vec4 ? 4 : 1;
@@ -782,10 +825,10 @@ int ig_ce_loss(const float* logits, const void* labels, int label_dtype, const f
     {                                                                                                                          \
         if (vec4)                                                                                                              \
             hipLaunchKernelGGL((ce_loss_kernel<LT, 4>), grid, block, sm, st, logits, (const LT*)labels, class_weights,         \
-                               ignore_index, stats, dlogits, preds, preds_i8, confusion, M, HW, ncls);                         \
+                               ignore_index, stats, dlogits, preds, preds_i8, confusion, M, HW, ncls, acc, arrived); \
         else                                                                                                                   \
             hipLaunchKernelGGL((ce_loss_kernel<LT, 1>), grid, block, sm, st, logits, (const LT*)labels, class_weights,         \
-                               ignore_index, stats, dlogits, preds, preds_i8, confusion, M, HW, ncls);                         \
+                               ignore_index, stats, dlogits, preds, preds_i8, confusion, M, HW, ncls, acc, arrived); \
     }
     if (label_dtype == 0)
         IG_CE(long long)

@@ -4,6 +4,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -74,7 +76,102 @@ int ig_cu_count() {
     return cus;
 }
 
+// ---- deterministic reduction mode (common.h: IgDet) -----------------------------------------------------------------------------
+int ig_det_sync_elementwise(const IgDet*, hipStream_t);
+int ig_det_sync_head(const IgDet*, hipStream_t);
+int ig_det_sync_conv_direct(const IgDet*, hipStream_t);
+int ig_det_sync_gemm(const IgDet*, hipStream_t);
+int ig_det_sync_gemm8(const IgDet*, hipStream_t);
+int ig_det_sync_attention2(const IgDet*, hipStream_t);
+IG_DET_TU(runtime)
+static IgDet g_det_host = {nullptr, nullptr, 0};
+bool ig_deterministic() { return g_det_host.shadow != nullptr; }
+void* ig_scratch(int slot, size_t bytes) {
+    static void* buf[16][4] = {};
+    static size_t cap[16][4] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || slot < 0 || slot >= 4) return nullptr;
+    if (cap[dev][slot] < bytes) {
+        void* p = nullptr;
+        const size_t want = bytes + bytes / 2;
+        if (hipMalloc(&p, want) != hipSuccess) return nullptr;
+        buf[dev][slot] = p, cap[dev][slot] = want;
+    }
+    return buf[dev][slot];
+}
+
+namespace {
+// grad[i] += shadow[i] * 2^-44 ; shadow[i] = 0 over a table of flat ranges (blockIdx.y = range; two elements per thread where the
+// range start is even: 16-byte shadow loads)
+__global__ __launch_bounds__(256) void det_fold_kernel(float* __restrict__ grad, long long* __restrict__ shadow, const long* __restrict__ ranges,
+                                                       long lo1, long hi1) {
+    const long lo = ranges ? ranges[2 * blockIdx.y] : lo1, hi = ranges ? ranges[2 * blockIdx.y + 1] : hi1;
+    for (long i = lo + (blockIdx.x * 256L + threadIdx.x) * 2; i < hi; i += (long)gridDim.x * 512) {
+        if (i + 1 < hi && ((i & 1) == 0)) {
+            longlong2 s = *reinterpret_cast<const longlong2*>(shadow + i);
+            if (s.x | s.y) {
+                if (s.x) grad[i] += (float)((double)s.x * 5.684341886080802e-14);
+                if (s.y) grad[i + 1] += (float)((double)s.y * 5.684341886080802e-14);
+                *reinterpret_cast<longlong2*>(shadow + i) = make_longlong2(0, 0);
+            }
+        } else {
+            for (long j = i; j < min(i + 2, hi); ++j) {
+                const long long s = shadow[j];
+                if (s) grad[j] += (float)((double)s * 5.684341886080802e-14), shadow[j] = 0;
+            }
+        }
+    }
+}
+}  // namespace
+
 extern "C" {
+
+// shadow: zero-initialised int64[n] on the device that parallels the flat fp32 gradient buffer grad_base[n]; NULL turns the mode
+// off.  The descriptor lives in constant memory of every kernel module: call it when no kernel of the library is in flight
+// (it is stream-ordered on `stream`), before any graph capture.
+int ig_set_deterministic(void* shadow, const void* grad_base, long n, void* stream) {
+    IG_REQUIRE(shadow == nullptr || (grad_base != nullptr && n > 0), "ig_set_deterministic: shadow without a gradient buffer");
+    IG_REQUIRE(((uintptr_t)shadow & 15) == 0, "ig_set_deterministic: shadow must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    g_det_host.shadow = (long long*)shadow;
+    g_det_host.base = shadow ? (const float*)grad_base : nullptr;
+    g_det_host.n = shadow ? n : 0;
+    int rc = ig_det_sync_runtime(&g_det_host, st);
+    rc |= ig_det_sync_elementwise(&g_det_host, st);
+    rc |= ig_det_sync_head(&g_det_host, st);
+    rc |= ig_det_sync_conv_direct(&g_det_host, st);
+    rc |= ig_det_sync_gemm(&g_det_host, st);
+    rc |= ig_det_sync_gemm8(&g_det_host, st);
+    rc |= ig_det_sync_attention2(&g_det_host, st);
+    if (rc != IG_OK) {
+        ig_set_error("ig_set_deterministic: hipMemcpyToSymbol failed: %s", hipGetErrorString(hipGetLastError()));
+        return IG_ERR_HIP;
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) return IG_ERR_HIP;
+    return IG_OK;
+}
+int ig_get_deterministic(void) { return ig_deterministic() ? 1 : 0; }
+
+// Adds the fixed-point shadow sums of gradient elements [lo, hi) into the gradient buffer and clears them (no-op when the mode is off).
+int ig_det_fold(long lo, long hi, void* stream) {
+    if (!ig_deterministic() || hi <= lo) return IG_OK;
+    IG_REQUIRE(lo >= 0 && hi <= g_det_host.n, "ig_det_fold: range [%ld, %ld) outside the registered buffer of %ld", lo, hi, g_det_host.n);
+    const int gx = (int)std::min<long>(((hi - lo + 1) / 2 + 255) / 256, 2048);
+    ig_note_kernel("det_fold_kernel");
+    det_fold_kernel<<<dim3(gx, 1), 256, 0, (hipStream_t)stream>>>(const_cast<float*>(g_det_host.base), g_det_host.shadow, nullptr, lo, hi);
+    return ig_check_launch("ig_det_fold");
+}
+// The same over a table of n ranges in DEVICE memory (int64 [n][2] = lo, hi; inside the registered buffer -- not checked) in ONE
+// launch; `longest` = the longest range (sizes the grid).  A caller that knows which elements only ever receive ordered writes
+// (the weights of the linears on the grouped 8-phase weight-gradient path) leaves them out of the table.
+int ig_det_fold_ranges(int n, const long* ranges_dev, long longest, void* stream) {
+    if (!ig_deterministic() || n <= 0 || longest <= 0) return IG_OK;
+    IG_REQUIRE(ranges_dev && n <= 65535, "ig_det_fold_ranges: null table or more than 65535 ranges");
+    const int gx = (int)std::min<long>(((longest + 1) / 2 + 255) / 256, 2048);
+    ig_note_kernel("det_fold_kernel");
+    det_fold_kernel<<<dim3(gx, n), 256, 0, (hipStream_t)stream>>>(const_cast<float*>(g_det_host.base), g_det_host.shadow, ranges_dev, 0, 0);
+    return ig_check_launch("ig_det_fold_ranges");
+}
 
 int ig_set_reserved_cus(int n) {
     IG_REQUIRE(n >= 0 && n < 128, "ig_set_reserved_cus: n must be in [0, 128) (got %d)", n);

@@ -18,6 +18,7 @@ Design
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Any, Callable, Dict, List, Optional, Tuple
 
@@ -330,6 +331,11 @@ class SegEngine:
         self._drop_step: Optional[torch.Tensor] = None  # device uint32 counter mixed into the dropout hash each step
         self.freeze_backbone = False
         self.on_grad_ready: Optional[Callable[[int, int], None]] = None
+        # run-to-run bit-identical training (the reference's Trainer runs with deterministic=True, pipeline_utils.py:373): the
+        # multi-contributor reductions go through the fixed-point shadow of the gradient buffer (ops.set_deterministic).  On by
+        # default (0.15-0.2 ms per step); IG_DETERMINISTIC=0 or ``engine.deterministic = False`` selects the float atomics.
+        self.deterministic = os.environ.get("IG_DETERMINISTIC", "1") != "0"
+        self._det_pending: List[Tuple[int, int]] = []
         self._pos_cache: Dict[int, Any] = {}
         self._last: Optional[Dict[str, Any]] = None
         self._generation = 0  # bumped by every forward(save=True): the saved activations belong to exactly one forward
@@ -433,6 +439,7 @@ class SegEngine:
             ws["dxb"] = BT.empty((M, D), sp, dev)
             ws["dxb2"] = BT.empty((M, D), sp, dev)
             ws["wgrad_groups"] = {}
+            ws["det_folds"] = {}  # deterministic mode: prepared per-block fold ranges (ops.DetFoldRanges)
             ws["dtmp"] = BT.empty((M, D), sp, dev)
             ws["dh"] = BT.empty((M, 4 * D), sp, dev)
             ws["dqkv"] = BT.empty((M, 3 * D), sp, dev)
@@ -466,6 +473,8 @@ class SegEngine:
         B = img.shape[0]
         if B == 0:  # empty batch: nothing to launch
             return torch.empty((0, cfg.num_classes, cfg.out_size, cfg.out_size), dtype=torch.float32, device=img.device)
+        if training:  # BatchNorm batch statistics are a grid-wide reduction: the mode must be in place before the first forward
+            self._sync_deterministic()
         ws = self.encoder_forward(img, save)
         logits = self._head_forward(ws, B, training, out, update_running, cfg)
         if save:
@@ -554,6 +563,14 @@ class SegEngine:
         assert self._last is not None
         return self._last["ws"]["f"][0].float().permute(0, 3, 1, 2).contiguous()
 
+    def _sync_deterministic(self) -> None:
+        """Register / unregister this engine's gradient buffer with the library's deterministic-reduction mode (no-op when
+        nothing changed; a change synchronises the device)."""
+        if self.deterministic:
+            ops.set_deterministic(self.store.ensure_grad())
+        elif self.store.grad is not None and ops._DET["grad"] is self.store.grad:
+            ops.set_deterministic(None)
+
     # ---- backward ------------------------------------------------------------------------------
     def backward(self, dlogits: torch.Tensor, count: Optional[torch.Tensor] = None, generation: Optional[int] = None) -> None:
         """Accumulate d loss / d params into the flat grad buffer from d loss / d logits.
@@ -570,6 +587,8 @@ class SegEngine:
                 "(one set of activations per engine: run backward before the next training forward, or use a second module)")
         ws, B, training = self._last["ws"], self._last["B"], self._last["training"]
         self.store.ensure_grad()
+        self._sync_deterministic()
+        self._det_pending = []
         D, L, N, T, G, H = cfg.embed_dim, cfg.depth, cfg.tokens, cfg.num_frames, cfg.G, cfg.num_heads
         M = B * N
         dims, hs, ks = cfg.head_dims, cfg.head_sizes, cfg.head_kernels
@@ -594,7 +613,7 @@ class SegEngine:
             if i > 0 or not self.freeze_backbone:
                 ops.convT_dgrad(ws["du"][i], self.W(f"{h}{i}.0.weight"), ws["df"][i], B, Hs, Hs, dims[i], C1)
         head0 = "segmentation_head.0.0.weight"
-        self._grad_ready(head0, None)
+        self._grad_ready(head0, None, last=self.freeze_backbone)
         if self.freeze_backbone:
             return
         e = "prithvi_encoder."
@@ -638,22 +657,50 @@ class SegEngine:
                     (ws["dqkv"], ws["a"][i], self.Gd(b + "attn.qkv.weight"), 3 * D, D),
                 ], M)  # prepared once per (workspace, block): pointers of the workspace and of the flat gradient buffer
             grp.launch()
+            if self.deterministic and i not in ws["det_folds"]:
+                # the grouped 8-phase kernel writes the four weight gradients through its ordered fold, never through the shadow: the
+                # fold then only visits the small vectors between them (the whole block otherwise)
+                lo_b, hi_b = self.store.entries[block_start(i)].offset, self.store.entries[block_start(i + 1)].offset
+                ranges = [(lo_b, hi_b)]
+                if ops.last_kernel().startswith("gemm8w_kernel"):
+                    ranges, at = [], lo_b
+                    for wname in sorted((b + n for n in ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight")),
+                                        key=lambda k: self.store.entries[k].offset):
+                        ent = self.store.entries[wname]
+                        ranges.append((at, ent.offset))
+                        at = ent.offset + ent.numel
+                    ranges.append((at, hi_b))
+                ws["det_folds"][i] = [r for r in ranges if r[1] > r[0]]
             prev_bias = self.Gd(f"{e}blocks.{i - 1}.mlp.fc2.bias") if i > 0 else None
             ops.layernorm_bwd(ws["dtmp"], ws["x_in"][i], ws["mean1"][i], ws["rstd1"][i], self.P(b + "norm1.weight"), dx, True, dxb,
                               self.Gd(b + "norm1.weight"), self.Gd(b + "norm1.bias"), prev_bias, M, D)
-            self._grad_ready(block_start(i), block_start(i + 1))  # all grads of block i are final
+            self._grad_ready(block_start(i), block_start(i + 1), block=i)  # all grads of block i are final
         # patch embedding + cls token
         ops.patch_grad_prep(dx, ws["dpe"], self.Gd(e + "cls_token"), self.Gd(e + "patch_embed.proj.bias"), B, N, D)
         ops.linear_wgrad(ws["dpe"], ws["patches"], self.Gd(e + "patch_embed.proj.weight"), B * T * G, D, cfg.patch_k)
-        self._grad_ready(e + "cls_token", block_start(0))
+        self._grad_ready(e + "cls_token", block_start(0), last=True)
 
-    def _grad_ready(self, first: str, until: Optional[str]) -> None:
+    def _grad_ready(self, first: str, until: Optional[str], block: Optional[int] = None, last: bool = False) -> None:
         """Tell the data-parallel layer that grads of flat range [offset(first), offset(until)) are final."""
-        if self.on_grad_ready is None:
-            return
         lo = self.store.entries[first].offset
         hi = self.store.total if until is None else self.store.entries[until].offset
-        if hi > lo:
+        if self.deterministic:  # the shadow sums of the range become part of the gradients before anyone reads them
+            ws = self._last["ws"]
+            ranges = (ws["det_folds"].get(block) if block is not None else None) or [(lo, hi)]
+            small = [r for r in ranges if r[1] - r[0] <= 65536]
+            for r in ranges:
+                if r[1] - r[0] > 65536:
+                    ops.det_fold(*r)
+            if self.on_grad_ready is None and not last:
+                self._det_pending.extend(small)  # one process: a single table launch at the end of the backward pass
+            else:
+                key = ("table", tuple(self._det_pending + small))
+                self._det_pending = []
+                table = ws["det_folds"].get(key)
+                if table is None:
+                    table = ws["det_folds"][key] = ops.DetFoldRanges(key[1], self.store.flat.device)
+                table.launch()
+        if self.on_grad_ready is not None and hi > lo:
             self.on_grad_ready(lo, hi)
 
 

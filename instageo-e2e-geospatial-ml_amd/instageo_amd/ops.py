@@ -153,6 +153,62 @@ def set_reserved_cus(n: int) -> None:
     _lib.call("ig_set_reserved_cus", int(n))
 
 
+# ---- run-to-run deterministic reductions (include/instageo_hip.h: ig_set_deterministic) --------------------------------
+_DET = {"grad": None, "shadow": None}
+
+
+def set_deterministic(grad_flat: Optional[torch.Tensor]) -> None:
+    """Register ``grad_flat`` (the flat fp32 gradient buffer) for order-independent reductions, or switch the mode off (None).
+
+    While registered, the kernels add their bias / norm / head gradient contributions as 2^44 fixed-point integers into an int64
+    shadow of the buffer; ``det_fold(lo, hi)`` adds the shadow into the gradients.  One buffer per process at a time.
+    """
+    if grad_flat is None:
+        if _DET["grad"] is not None:
+            torch.cuda.synchronize()
+            _lib.call("ig_set_deterministic", None, None, 0, _stream())
+        _DET["grad"] = _DET["shadow"] = None
+        return
+    g = _f32(grad_flat)
+    if _DET["grad"] is not None and _DET["grad"].data_ptr() == g.data_ptr() and _DET["grad"].numel() == g.numel():
+        return
+    torch.cuda.synchronize()
+    shadow = torch.zeros(g.numel(), dtype=torch.int64, device=g.device)
+    _lib.call("ig_set_deterministic", _p(shadow), _p(g), g.numel(), _stream())
+    _DET["grad"], _DET["shadow"] = g, shadow
+
+
+def last_kernel() -> str:
+    """Name of the kernel the most recent MFMA entry point of this thread launched (``ig_last_kernel``)."""
+    return (_lib.load().ig_last_kernel() or b"").decode()
+
+
+def deterministic() -> bool:
+    return bool(_lib.load().ig_get_deterministic())
+
+
+def det_fold(lo: int, hi: int) -> None:
+    """Add the fixed-point shadow sums of flat gradient range [lo, hi) into the gradients and clear them (no-op when off)."""
+    if _DET["grad"] is not None and hi > lo:
+        _lib.call("ig_det_fold", int(lo), int(hi), _stream())
+
+
+class DetFoldRanges:
+    """Prepared argument block of one ``ig_det_fold_ranges`` launch: a device table of flat ranges [(lo, hi), ...]."""
+
+    __slots__ = ("n", "ranges", "_table", "_longest")
+
+    def __init__(self, ranges, device):
+        self.ranges = [(int(a), int(b)) for a, b in ranges if b > a]
+        self.n = len(self.ranges)
+        self._table = torch.tensor(self.ranges or [(0, 0)], dtype=torch.int64).to(device)
+        self._longest = max([b - a for a, b in self.ranges], default=0)
+
+    def launch(self) -> None:
+        if _DET["grad"] is not None and self.n:
+            _lib.call("ig_det_fold_ranges", self.n, _p(self._table), self._longest, _stream())
+
+
 def _f32(t: torch.Tensor) -> torch.Tensor:
     assert t.dtype == torch.float32, t.dtype
     return t

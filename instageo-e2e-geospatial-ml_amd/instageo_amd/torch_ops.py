@@ -29,7 +29,7 @@ from . import _lib
 NAMESPACE = "instageo_mi355x"
 _SCALAR_SCHEMA = {"int": "int", "long": "int", "unsigned": "int", "float": "float", "double": "float"}
 _SKIP = {"ig_last_error", "ig_last_kernel", "ig_note_reset", "ig_last_grid", "ig_version", "ig_header_stamp", "ig_device_info",
-         "ig_set_reserved_cus", "ig_get_reserved_cus",
+         "ig_set_reserved_cus", "ig_get_reserved_cus", "ig_set_deterministic", "ig_get_deterministic", "ig_det_fold", "ig_det_fold_ranges",
          "ig_linear_wgrad_group"}  # host-side queries: no tensors; the grouped launch takes HOST arrays of device pointers
 
 

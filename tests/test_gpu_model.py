@@ -483,3 +483,86 @@ def test_other_input_sizes_interpolate_the_position_table():
         assert rel_l2(got[k].grad, rg) <= 1e-2, k
     with pytest.raises(ValueError):
         net(torch.zeros(1, 6, 1, 100, 100, device=DEV))  # not a multiple of the patch size
+
+
+def _train_steps(name, precision, deterministic, B, steps=3):
+    variant, T, ncls, _, depth = CASES[name]
+    cfg = case_config(name)
+    sd = O.make_state_dict(cfg, seed=1042)
+    img, lab = make_inputs(name, cfg, B)
+    mod = PrithviSegmentationModule(freeze_backbone=False, load_pretrained_weights=False, num_classes=ncls, model_name=variant,
+                                    temporal_step=T, depth=depth, class_weights=class_weights_for(ncls).tolist(), ignore_index=-1,
+                                    learning_rate=1e-3, precision=precision, device=DEV)
+    mod.net.load_state_dict(sd)
+    mod.net.engine.deterministic = deterministic
+    stats = []
+    for _ in range(steps):  # dropout stays ON: its mask is a hash of (seed, step counter, element), not a random stream
+        st = mod.fused_train_step(img.to(DEV), lab.to(DEV))
+        stats.append(st.clone())
+    torch.cuda.synchronize()
+    return mod.net.store.flat.clone(), mod.net.store.grad.clone(), torch.stack(stats)
+
+
+@pytest.mark.parametrize("name,precision,B", [("tiny_t3_c13", "bf16x3", 3), ("v1_100_t1_c2", "bf16", 6), ("v1_100_t3_c13", "bf16", 2)])
+def test_deterministic_mode_is_bit_reproducible(name, precision, B):
+    """engine.deterministic (the reference's Trainer(deterministic=True), pipeline_utils.py:373): two runs of three full training
+    steps from the same weights and batch end in bit-identical parameters, gradients and loss statistics.  Every
+    multi-contributor float reduction of the step (bias / norm / head gradients, BatchNorm and loss sums) takes an
+    order-independent route in this mode; the weight gradients of the linears are ordered folds in both modes."""
+    try:
+        p1, g1, s1 = _train_steps(name, precision, True, B)
+        p2, g2, s2 = _train_steps(name, precision, True, B)
+        assert ops.deterministic()
+        assert torch.equal(s1, s2), (s1, s2)
+        assert torch.equal(g1, g2), f"{(g1 != g2).sum().item()} gradient elements differ"
+        assert torch.equal(p1, p2), f"{(p1 != p2).sum().item()} parameters differ"
+        # and it is the same training: the gradients of ONE step agree with the default (float-atomic) mode to summation-order
+        # rounding (later steps are not comparable element by element: AdamW's first updates are +-lr whatever the gradient's size,
+        # so a last-bit difference in a near-zero gradient moves that weight by 2 lr -- the default mode does that to itself)
+        _, g1s, s1s = _train_steps(name, precision, True, B, steps=1)
+        ops.set_deterministic(None)  # the registration is per process: it stays with the last deterministic engine until cleared
+        assert not ops.deterministic()
+        _, g0s, s0s = _train_steps(name, precision, False, B, steps=1)
+        rel = ((g1s.double() - g0s.double()).norm() / g0s.double().norm()).item()
+        dl = ((s1s[:, 0] / s1s[:, 1]) - (s0s[:, 0] / s0s[:, 1])).abs().max().item()
+        _, g0, _ = _train_steps(name, precision, False, B)
+        _, g0b, _ = _train_steps(name, precision, False, B)
+        print(f"[{name}/{precision}] deterministic vs default, one step: grad rel-L2 {rel:.3e}, |dloss| {dl:.3e}; default mode, two runs "
+              f"of three steps: {(g0 != g0b).sum().item()} of {g0.numel()} gradient elements differ, rel-L2 "
+              f"{((g0.double() - g0b.double()).norm() / g0.double().norm()).item():.3e}")
+        assert rel <= 1e-5 and dl <= 1e-6
+    finally:
+        ops.set_deterministic(None)
+
+
+def test_det_fold_adds_fixed_point_shadow():
+    """ig_set_deterministic / ig_det_fold: colsum into a registered buffer lands in the int64 shadow (2^44 fixed point), the fold
+    moves it into the buffer and clears the shadow; a target outside the buffer keeps the float atomic."""
+    torch.manual_seed(0)
+    M, C = 5000, 96
+    x = torch.randn(M, C, device=DEV)
+    xb = ops.BT.from_float(x, False)
+    ref = xb.float().double().sum(0).float()
+    buf = torch.zeros(4 * C, device=DEV)
+    other = torch.zeros(C, device=DEV)
+    try:
+        ops.set_deterministic(buf)
+        ops.colsum(xb, buf[C : 2 * C], M, C)
+        ops.colsum(xb, other, M, C)
+        torch.cuda.synchronize()
+        assert buf.abs().max().item() == 0.0  # still in the shadow
+        sh = ops._DET["shadow"]
+        assert (sh[C : 2 * C] != 0).all() and (sh[:C] == 0).all() and (sh[2 * C :] == 0).all()
+        got1 = (sh[C : 2 * C].double() * 2.0 ** -44).float()
+        ops.det_fold(C, 2 * C)
+        torch.cuda.synchronize()
+        assert (sh == 0).all()
+        assert torch.equal(buf[C : 2 * C], got1) and buf[:C].abs().max().item() == 0.0
+        assert torch.allclose(buf[C : 2 * C], ref, rtol=1e-5, atol=1e-4) and torch.allclose(other, ref, rtol=1e-5, atol=1e-4)
+        # two shadow runs give the same bits
+        ops.colsum(xb, buf[2 * C : 3 * C], M, C)
+        ops.det_fold(2 * C, 3 * C)
+        assert torch.equal(buf[2 * C : 3 * C], buf[C : 2 * C])
+    finally:
+        ops.set_deterministic(None)
+    assert not ops.deterministic()
