@@ -209,7 +209,8 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=108, help="chips per GPU per step")
+    ap.add_argument("--batch", type=int, default=216, help="chips per GPU per step (216 x 197 tokens = 167 row tiles of 256: the N = 768 "
+                    "GEMMs fill 2 rounds of 256 CUs to 98 %%, attention 10.1 rounds; 108 = one round was the default of rounds 1-3)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
     ap.add_argument("--model", default="prithvi_eo_v1_100", help="variant (other BASELINE configs: prithvi_eo_v2_300)")
     ap.add_argument("--temporal", type=int, default=1, help="T: 1 = configs[1] (default), 3 = configs[2] multi-temporal crop")
@@ -547,8 +548,8 @@ def main() -> None:
                            "frac": d["frac"], "traffic": None, "launches_per_step": d["launches_per_step"], "avg_launch_us": d["avg_us"],
                            "ms_per_step": d["ms_per_step"], "gflop_per_launch": d["gflop_per_launch"], "timed_launches": d["timed_launches"],
                            "event_stride": args.event_stride}  # fmt: skip
-        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_bench_b108.json")))
-        if pmc_files and B == 108 and headline:
+        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_bench_b{B}.json")))
+        if pmc_files and headline:
             # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
             # (tools/pmc_bench.sh); FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md
             pmc = json.load(open(pmc_files[-1]))

@@ -11,7 +11,11 @@ run b16 --batch 16
 run b32 --batch 32
 run b108 --batch 108
 run b112 --batch 112
+run b216 --batch 216
 run t3_c13_b36 --temporal 3 --classes 13 --batch 36
+run t3_c13_b72 --temporal 3 --classes 13 --batch 72
 run t3_c13_b8 --temporal 3 --classes 13 --batch 8
 run 300m_b32 --model prithvi_eo_v2_300 --batch 32
 run 300m_b54 --model prithvi_eo_v2_300 --batch 54
+run 300m_b80 --model prithvi_eo_v2_300 --batch 80
+run 300m_b160 --model prithvi_eo_v2_300 --batch 160
