@@ -126,9 +126,12 @@ int ig_linear_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, cons
                     void* stream);
 /* n weight gradients sharing the token count M in ONE launch (the four linears of a timm Block, pritvhi.py:446-456:
  * autograd's grad_weight of F.linear for qkv / proj / fc1 / fc2): dw[g] += dy[g]^T @ x[g].  All array arguments are HOST arrays
- * of n entries; dy_lo / x_lo may be NULL (plain bf16).  Bit-reproducible (ordered split-K fold). */
+ * of n entries; dy_lo / x_lo may be NULL (plain bf16).  Bit-reproducible (ordered split-K fold).  overwrite != 0: dw[g] = dy[g]^T @
+ * x[g] -- the first backward of a step then needs neither a zeroed dw nor reads its old contents (4 + 4 bytes per weight less). */
 int ig_linear_wgrad_group(int n, const void* const* dy_hi, const void* const* dy_lo, const void* const* x_hi,
-                          const void* const* x_lo, float* const* dw, const int* N, const int* K, int M, void* stream);
+                          const void* const* x_lo, float* const* dw, const int* N, const int* K, int M, int overwrite, void* stream);
+/* base[lo .. hi) = 0 for n flat ranges in ONE launch: ranges_dev = DEVICE int64 [n][2], longest = the longest range */
+int ig_zero_ranges(float* base, int n, const long* ranges_dev, long longest, void* stream);
 /* ig_linear_dgrad with the weight handed over TRANSPOSED (wt [K][N] = w^T, see ig_transpose_bf16): same result, but both
  * operands are contiguous in the reduce dimension, the form of the forward linears (dx = dy @ w is autograd's grad_input of
  * F.linear, pritvhi.py:446-456) */

@@ -54,7 +54,7 @@ int ig_gemm8_nt(const G8Params& p, void* stream);  // IG_ERR_UNSUPPORTED (no err
 // gemm8w.hip: grouped linear weight gradients dW_g += dy_g^T x_g (shared token count M) on the 8-phase schedule with transposed
 // fragment reads; IG_ERR_UNSUPPORTED (no error string) when a shape is not covered (N, K multiples of 256)
 int ig_wgrad8_group(int n, const void* const* dy_hi, const void* const* dy_lo, const void* const* x_hi, const void* const* x_lo,
-                    float* const* dw, const int* N, const int* K, int M, void* stream);
+                    float* const* dw, const int* N, const int* K, int M, int overwrite, void* stream);
 // runtime.hip: compute units the persistent kernels leave free (for RCCL's kernels when world > 1); ig_set_reserved_cus()
 // attention2.hip: second-generation attention forward (32x32x16 MFMA, whole-head K/V in LDS); IG_ERR_UNSUPPORTED -> first generation
 int ig_attention2_fwd(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, float* lse, int B, int N, int H, void* stream);

@@ -1833,7 +1833,7 @@ int ig_linear_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, cons
     IG_REQUIRE(N % 8 == 0 && K % 8 == 0, "ig_linear_wgrad: N and K must be multiples of 8");
     IG_SPLIT_CONSISTENT(dy_lo, x_lo);
     if (!gemm_env()) {  // 8-phase engine with transposed fragment reads (gemm8w.hip) for the shapes it covers
-        const int rc = ig_wgrad8_group(1, &dy_hi, &dy_lo, &x_hi, &x_lo, &dw, &N, &K, M, stream);
+        const int rc = ig_wgrad8_group(1, &dy_hi, &dy_lo, &x_hi, &x_lo, &dw, &N, &K, M, 0, stream);
         if (rc != IG_ERR_UNSUPPORTED) return rc;
     }
     EpAtomic ep{dw, (long)K, 0, 0, nullptr, 0};
@@ -1858,15 +1858,21 @@ int ig_linear_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, cons
 // n weight gradients that share the token count M in ONE launch: dw[g][N[g]][K[g]] += dy[g][M][N[g]]^T @ x[g][M][K[g]].  The pointer
 // and size arrays are HOST arrays of n entries (dy_lo / x_lo: NULL or arrays whose entries are all NULL or all set).
 int ig_linear_wgrad_group(int n, const void* const* dy_hi, const void* const* dy_lo, const void* const* x_hi, const void* const* x_lo,
-                          float* const* dw, const int* N, const int* K, int M, void* stream) {
+                          float* const* dw, const int* N, const int* K, int M, int overwrite, void* stream) {
     IG_REQUIRE(n > 0 && n <= 16 && dy_hi && x_hi && dw && N && K, "ig_linear_wgrad_group: 1..16 GEMMs and non-null arrays");
     for (int g = 0; g < n; ++g) IG_REQUIRE(dy_hi[g] && x_hi[g] && dw[g], "ig_linear_wgrad_group: null pointer in GEMM %d", g);
-    if (M <= 0) return IG_OK;
-    if (!gemm_env()) {
-        const int rc = ig_wgrad8_group(n, dy_hi, dy_lo, x_hi, x_lo, dw, N, K, M, stream);
+    if (M <= 0 && !overwrite) return IG_OK;
+    if (!gemm_env() && M > 0) {
+        const int rc = ig_wgrad8_group(n, dy_hi, dy_lo, x_hi, x_lo, dw, N, K, M, overwrite, stream);
         if (rc != IG_ERR_UNSUPPORTED) return rc;
     }
     for (int g = 0; g < n; ++g) {
+        // the per-GEMM engines accumulate: "overwrite" = clear first
+        if (overwrite && hipMemsetAsync(dw[g], 0, (size_t)N[g] * K[g] * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+            ig_set_error("ig_linear_wgrad_group: hipMemsetAsync failed");
+            return IG_ERR_HIP;
+        }
+        if (M <= 0) continue;
         const int rc = ig_linear_wgrad(dy_hi[g], dy_lo ? dy_lo[g] : nullptr, x_hi[g], x_lo ? x_lo[g] : nullptr, dw[g], M, N[g], K[g], stream);
         if (rc != IG_OK) return rc;
     }

@@ -265,9 +265,9 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
 #undef W_ZERO_ACC
 }
 
-// dW tile += sum of its slabs, in slab (= token) order.  Slab element e = a * 512 + tid holds accumulator a = ((h*2+g)*2+nt)*4+mt
+// dW tile (+)= sum of its slabs, in slab (= token) order.  Slab element e = a * 512 + tid holds accumulator a = ((h*2+g)*2+nt)*4+mt
 // of thread tid: dW rows h*128 + wr*64 + mt*16 + (lane & 15), columns g*128 + wc*32 + nt*16 + 4 (lane >> 4) .. +3.
-__global__ __launch_bounds__(256) void wgrad8_reduce_kernel(const WTile* __restrict__ tiles, const float4* __restrict__ slabs) {
+__global__ __launch_bounds__(256) void wgrad8_reduce_kernel(const WTile* __restrict__ tiles, const float4* __restrict__ slabs, int overwrite) {
     const WTile T = tiles[blockIdx.y];
     const int e = blockIdx.x * 256 + threadIdx.x;  // 0 .. 16383
     const float4* p = slabs + T.first * 16384L + e;
@@ -280,9 +280,11 @@ __global__ __launch_bounds__(256) void wgrad8_reduce_kernel(const WTile* __restr
     const int row = (a >> 4) * 128 + (wave >> 2) * 64 + (a & 3) * 16 + (lane & 15);
     const int col = ((a >> 3) & 1) * 128 + (wave & 3) * 32 + ((a >> 2) & 1) * 16 + 4 * (lane >> 4);
     float4* o = reinterpret_cast<float4*>(T.out + (long)row * T.ldo + col);
-    float4 v = *o;
-    v.x += s.x, v.y += s.y, v.z += s.z, v.w += s.w;
-    *o = v;
+    if (!overwrite) {  // overwrite: dW = sum (a fresh step: the caller neither zeroed dW nor wants its old contents read)
+        const float4 v = *o;
+        s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+    }
+    *o = s;
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -340,7 +342,7 @@ inline int wg8_rem_env() {  // IG_WGRAD8_REM=0: uniform token splits only (A/B r
 // Grouped weight gradients.  IG_ERR_UNSUPPORTED (no error string) when a shape is not covered: the caller falls back to one
 // ig_linear_wgrad per GEMM.
 int ig_wgrad8_group(int n, const void* const* dy_hi, const void* const* dy_lo, const void* const* x_hi, const void* const* x_lo,
-                    float* const* dw, const int* N, const int* K, int M, void* stream) {
+                    float* const* dw, const int* N, const int* K, int M, int overwrite, void* stream) {
     if (!wg8_env() || n <= 0 || M <= 0) return IG_ERR_UNSUPPORTED;
     const bool split = dy_lo && dy_lo[0];
     long ntiles = 0;
@@ -500,6 +502,6 @@ int ig_wgrad8_group(int n, const void* const* dy_hi, const void* const* dy_lo, c
     ig_note_grid(pl.nwg);
     if (split) hipLaunchKernelGGL(k3, dim3(pl.nwg), dim3(512), W_SMEM, st, (const WSeg*)pl.segs, ws, zp);
     else hipLaunchKernelGGL(k1, dim3(pl.nwg), dim3(512), W_SMEM, st, (const WSeg*)pl.segs, ws, zp);
-    hipLaunchKernelGGL(wgrad8_reduce_kernel, dim3(64, pl.ntiles), dim3(256), 0, st, (const WTile*)pl.tiles, (const float4*)ws);
+    hipLaunchKernelGGL(wgrad8_reduce_kernel, dim3(64, pl.ntiles), dim3(256), 0, st, (const WTile*)pl.tiles, (const float4*)ws, overwrite);
     return ig_check_launch("ig_linear_wgrad_group");
 }

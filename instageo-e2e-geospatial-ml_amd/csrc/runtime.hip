@@ -122,6 +122,14 @@ __global__ __launch_bounds__(256) void det_fold_kernel(float* __restrict__ grad,
         }
     }
 }
+__global__ __launch_bounds__(256) void zero_ranges_kernel(float* __restrict__ base, const long* __restrict__ ranges) {
+    const long lo = ranges[2 * blockIdx.y], hi = ranges[2 * blockIdx.y + 1];
+    for (long i = lo + (blockIdx.x * 256L + threadIdx.x) * 4; i < hi; i += (long)gridDim.x * 1024) {
+        if (i + 3 < hi && ((i & 3) == 0)) *reinterpret_cast<float4*>(base + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        else
+            for (long j = i; j < min(i + 4, hi); ++j) base[j] = 0.f;
+    }
+}
 }  // namespace
 
 extern "C" {
@@ -171,6 +179,14 @@ int ig_det_fold_ranges(int n, const long* ranges_dev, long longest, void* stream
     ig_note_kernel("det_fold_kernel");
     det_fold_kernel<<<dim3(gx, n), 256, 0, (hipStream_t)stream>>>(const_cast<float*>(g_det_host.base), g_det_host.shadow, ranges_dev, 0, 0);
     return ig_check_launch("ig_det_fold_ranges");
+}
+
+int ig_zero_ranges(float* base, int n, const long* ranges_dev, long longest, void* stream) {
+    if (n <= 0 || longest <= 0) return IG_OK;
+    IG_REQUIRE(base && ranges_dev && n <= 65535, "ig_zero_ranges: null pointer or more than 65535 ranges");
+    const int gx = (int)std::min<long>((longest + 1023) / 1024, 2048);
+    zero_ranges_kernel<<<dim3(gx, n), 256, 0, (hipStream_t)stream>>>(base, ranges_dev);
+    return ig_check_launch("ig_zero_ranges");
 }
 
 int ig_set_reserved_cus(int n) {

@@ -193,6 +193,22 @@ def det_fold(lo: int, hi: int) -> None:
         _lib.call("ig_det_fold", int(lo), int(hi), _stream())
 
 
+class ZeroRanges:
+    """Prepared argument block of one ``ig_zero_ranges`` launch: ``base[lo:hi] = 0`` for a device table of flat ranges."""
+
+    __slots__ = ("n", "ranges", "_table", "_longest")
+
+    def __init__(self, ranges, device):
+        self.ranges = [(int(a), int(b)) for a, b in ranges if b > a]
+        self.n = len(self.ranges)
+        self._table = torch.tensor(self.ranges or [(0, 0)], dtype=torch.int64).to(device)
+        self._longest = max([b - a for a, b in self.ranges], default=0)
+
+    def launch(self, base: torch.Tensor) -> None:
+        if self.n:
+            _lib.call("ig_zero_ranges", _p(_f32(base)), self.n, _p(self._table), self._longest, _stream())
+
+
 class DetFoldRanges:
     """Prepared argument block of one ``ig_det_fold_ranges`` launch: a device table of flat ranges [(lo, hi), ...]."""
 
@@ -430,15 +446,16 @@ class WgradGroup:
         self.work = sum(2.0 * M * it[3] * it[4] for it in items)
         self._args = (n, *[None if a is None else ctypes.cast(a, ctypes.c_void_p) for a in arrs], int(M)), arrs  # arrs: keep-alive
 
-    def launch(self) -> None:
-        _call("ig_linear_wgrad_group", self.work, *self._args[0], _stream())
+    def launch(self, overwrite: bool = False) -> None:
+        """``overwrite``: dW = dy^T x instead of dW += (the first backward of a step: no zeroed dW needed, its old contents not read)."""
+        _call("ig_linear_wgrad_group", self.work, *self._args[0], int(overwrite), _stream())
 
 
-def linear_wgrad_group(items, M: int) -> None:
+def linear_wgrad_group(items, M: int, overwrite: bool = False) -> None:
     """``items`` = [(dy, x, dw, N, K), ...]: dw_g[N_g][K_g] += dy_g[M][N_g]^T @ x_g[M][K_g] for all g in ONE launch (the weight
     gradients of a Block's linears share the token count; grouped, their output tiles fill the CUs with 2-3 token ranges per
     tile instead of 7-28 and the split-K fold shrinks accordingly).  Hot loops keep a :class:`WgradGroup` instead."""
-    WgradGroup(items, M).launch()
+    WgradGroup(items, M).launch(overwrite)
 
 
 def attention_fwd(qkv: BT, out: BT, lse, B: int, N: int, H: int, hd: int = 64) -> None:

@@ -12,6 +12,7 @@ and optimiser/scheduler choices.  Two execution paths share the same kernels:
 from __future__ import annotations
 
 import math
+import os
 from typing import Any, Callable, Dict, List, Optional, Tuple
 
 import torch
@@ -33,6 +34,8 @@ except Exception:  # pragma: no cover - Lightning is absent in this image
 # --------------------------------------------------------------------------------------------------
 # AdamW on the flat parameter buffer (base.py:124-126: torch.optim.AdamW defaults)
 # --------------------------------------------------------------------------------------------------
+_FRESH_STEP = os.environ.get("IG_FRESH_STEP", "1") != "0"  # A/B switch: 0 = zero every gradient and accumulate (rounds 1-2)
+
 class FusedAdamW(torch.optim.Optimizer):
     """``torch.optim.AdamW`` semantics, one HIP launch over the flat buffer of a :class:`PrithviSeg`.
 
@@ -349,8 +352,11 @@ class PrithviSegmentationModule(_Base):
             ws["dlogits"] = dlog
         self._fused_loss(logits, labels, stats, dlog, "train")
         g = net.store.ensure_grad()
-        g[opt.lo : opt.hi].zero_()
-        eng.backward(dlog, count=stats)
+        if _FRESH_STEP:  # the Blocks' weight gradients are written, not accumulated: they are neither zeroed nor read (model.py)
+            eng.zero_grads_for_step(opt.lo, opt.hi)
+        else:
+            g[opt.lo : opt.hi].zero_()
+        eng.backward(dlog, count=stats, fresh=_FRESH_STEP)
         if self.grad_sync is not None:
             self.grad_sync()
         opt.step(grads_in_flat=True)

@@ -302,6 +302,16 @@ def test_linear_wgrad_group(split, M, shapes):
         ops.linear_wgrad_group(items, M)
         for it, f in zip(items, first):
             assert torch.equal(it[2], f), "grouped weight gradient differs between identical launches"
+    # overwrite: dW = dy^T x whatever dW held (NaN here), bit-identical to the accumulate form on a zeroed dW
+    for it in items:
+        it[2].zero_()
+    ops.linear_wgrad_group(items, M)
+    acc = [it[2].clone() for it in items]
+    for it in items:
+        it[2].fill_(float("nan"))
+    ops.linear_wgrad_group(items, M, overwrite=True)
+    for it, a in zip(items, acc):
+        assert torch.equal(it[2], a), "overwrite form differs from accumulate-into-zero"
 
 
 def test_linear_wgrad_group_fallback_shapes():
@@ -316,6 +326,23 @@ def test_linear_wgrad_group_fallback_shapes():
     ops.linear_wgrad_group(items, M)
     for it, ref in zip(items, refs):
         close(it[2], ref, 2e-5, what="grouped wgrad fallback")
+    for it in items:  # overwrite on the fallback path: the library clears dW first
+        it[2].fill_(float("nan"))
+    ops.linear_wgrad_group(items, M, overwrite=True)
+    for it, ref in zip(items, refs):
+        close(it[2], ref, 2e-5, what="grouped wgrad fallback, overwrite")
+
+
+def test_zero_ranges_table():
+    """ig_zero_ranges: base[lo:hi] = 0 for a device table of ranges (odd starts and lengths), nothing else touched."""
+    base = torch.arange(1, 20001, dtype=torch.float32, device=DEV)
+    ranges = [(0, 5), (7, 8), (13, 4100), (4101, 4104), (9999, 20000)]
+    ops.ZeroRanges(ranges, DEV).launch(base)
+    ref = torch.arange(1, 20001, dtype=torch.float32)
+    for a, b in ranges:
+        ref[a:b] = 0
+    assert torch.equal(base.cpu(), ref)
+    ops.ZeroRanges([], DEV).launch(base)  # empty table: no launch
 
 
 @pytest.mark.parametrize("split", SPLITS)
