@@ -567,3 +567,37 @@ def test_det_fold_adds_fixed_point_shadow():
     finally:
         ops.set_deterministic(None)
     assert not ops.deterministic()
+
+
+@pytest.mark.parametrize("name,precision,B", [("tiny_t1_c2", "bf16", 4), ("v1_100_t1_c2", "bf16", 6)])
+def test_graphed_train_step_equals_eager_bit_for_bit(name, precision, B):
+    """make_graphed_train_step (one hipGraph replay per step; warm-up and capture leave no trace in the training state) against
+    the eager fused step: with the deterministic reductions three replays and three eager steps from the same weights end in
+    bit-identical parameters and loss statistics -- the capture holds the fixed-point shadow folds, the range tables and the
+    fresh-step zeroing like any other launch."""
+    variant, T, ncls, _, depth = CASES[name]
+    cfg = case_config(name)
+    sd = O.make_state_dict(cfg, seed=1042)
+    img, lab = make_inputs(name, cfg, B)
+    x, y = img.to(DEV), lab.to(DEV)
+
+    def module():
+        mod = PrithviSegmentationModule(freeze_backbone=False, load_pretrained_weights=False, num_classes=ncls, model_name=variant,
+                                        temporal_step=T, depth=depth, class_weights=class_weights_for(ncls).tolist(), ignore_index=-1,
+                                        learning_rate=1e-3, precision=precision, device=DEV)
+        mod.net.load_state_dict(sd)
+        mod.net.engine.deterministic = True
+        return mod
+
+    try:
+        eager = module()
+        s_eager = torch.stack([eager.fused_train_step(x, y).clone() for _ in range(3)])
+        p_eager = eager.net.store.flat.clone()
+        graphed = module()
+        run = graphed.make_graphed_train_step(x, y)
+        s_graph = torch.stack([run(x, y).clone() for _ in range(3)])
+        torch.cuda.synchronize()
+        assert torch.equal(s_graph, s_eager), (s_graph, s_eager)
+        assert torch.equal(graphed.net.store.flat, p_eager), f"{(graphed.net.store.flat != p_eager).sum().item()} parameters differ"
+    finally:
+        ops.set_deterministic(None)
