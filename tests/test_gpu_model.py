@@ -504,7 +504,8 @@ def _train_steps(name, precision, deterministic, B, steps=3):
     return mod.net.store.flat.clone(), mod.net.store.grad.clone(), torch.stack(stats)
 
 
-@pytest.mark.parametrize("name,precision,B", [("tiny_t3_c13", "bf16x3", 3), ("v1_100_t1_c2", "bf16", 6), ("v1_100_t3_c13", "bf16", 2)])
+@pytest.mark.parametrize("name,precision,B", [("tiny_t3_c13", "bf16x3", 3), ("v1_100_t1_c2", "bf16", 6), ("v1_100_t1_c2", "bf16x3", 4),
+                                              ("v1_100_t3_c13", "bf16", 2), ("v2_600_t1_c2", "bf16", 2)])
 def test_deterministic_mode_is_bit_reproducible(name, precision, B):
     """engine.deterministic (the reference's Trainer(deterministic=True), pipeline_utils.py:373): two runs of three full training
     steps from the same weights and batch end in bit-identical parameters, gradients and loss statistics.  Every
