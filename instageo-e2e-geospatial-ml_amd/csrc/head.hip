@@ -8,6 +8,17 @@
 
 namespace {
 
+// m = b * HW + pix.  A 64-bit integer division is ~150 instructions on this hardware and sat in per-pixel loops; the 32-bit form
+// (pixel counts below 2^31: every real batch) is ~30.
+__device__ __forceinline__ void split_pixel(long m, long HW, long& b, long& pix) {
+    if ((unsigned long)(m | HW) < (1ul << 31)) {
+        const unsigned bu = (unsigned)m / (unsigned)HW;
+        b = bu, pix = (long)((unsigned)m - bu * (unsigned)HW);
+    } else {
+        b = m / HW, pix = m - b * HW;
+    }
+}
+
 constexpr int TPB = 256;
 constexpr int MAXC = 16;  // max classes held in registers
 
@@ -117,7 +128,8 @@ __global__ __launch_bounds__(TPB) void classifier_fwd_kernel(const bf16_t* __res
 #pragma unroll
     for (int n = 0; n < MAXC; ++n)
         if (n < ncls) acc[n] += sw[ncls * C + n];
-    long b = m / HW, pix = m - b * HW;
+    long b, pix;
+    split_pixel(m, HW, b, pix);
 #pragma unroll
     for (int n = 0; n < MAXC; ++n)
         if (n < ncls) logits[(b * ncls + n) * HW + pix] = acc[n];
@@ -161,43 +173,62 @@ __global__ __launch_bounds__(TPB) void classifier_bwd_kernel(const float* __rest
     }
     if (sl < nsl) {
         const long m0 = (long)blockIdx.x * nsl * iters + sl;
-        for (int it = 0; it < iters; ++it) {
-            const long m = m0 + (long)it * nsl;
-            if (m >= M) break;
-            const long b = m / HW, pix = m - b * HW;
-            const size_t idx = (size_t)m * C + u * 8;
-            float f[8], o[8], msk[8];
-            load8_split(f_hi, f_lo, idx, f);
-            if (drop_thresh) {
-                dropout_scale4(drop_seed, (uint32_t)idx, drop_thresh, drop_inv, msk);
-                dropout_scale4(drop_seed, (uint32_t)idx + 4u, drop_thresh, drop_inv, msk + 4);
-            } else {
+        // UNR pixels per iteration, every load of all of them (features, dlogits) issued before the first use: with one pixel in
+        // flight per thread the kernel kept ~6 MB of loads in the air over the whole chip -- 3.1 TB/s at the HBM latency
+        constexpr int UNR = NC <= 4 ? 2 : 1;
+        for (int it = 0; it < iters; it += UNR) {
+            if (m0 + (long)it * nsl >= M) break;
+            float f[UNR][8], gq[UNR][NC];
+            size_t idxq[UNR];
+            bool ok[UNR];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) msk[j] = 1.f;
+            for (int q = 0; q < UNR; ++q) {
+                const long mq = m0 + (long)(it + q) * nsl;
+                ok[q] = it + q < iters && mq < M;
+                const long m = ok[q] ? mq : m0 + (long)it * nsl;  // dead slot: harmless duplicate loads, nothing stored or summed
+                long b, pix;
+                split_pixel(m, HW, b, pix);
+                idxq[q] = (size_t)m * C + u * 8;
+                load8_split(f_hi, f_lo, idxq[q], f[q]);
+#pragma unroll
+                for (int n = 0; n < NC; ++n) gq[q][n] = n < ncls ? dl[(b * ncls + n) * HW + pix] * gscale : 0.f;
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                f[j] *= msk[j];
-                o[j] = 0.f;
-            }
+            for (int q = 0; q < UNR; ++q) {
+                if (!ok[q]) continue;
+                const size_t idx = idxq[q];
+                float o[8], msk[8];
+                if (drop_thresh) {
+                    dropout_scale4(drop_seed, (uint32_t)idx, drop_thresh, drop_inv, msk);
+                    dropout_scale4(drop_seed, (uint32_t)idx + 4u, drop_thresh, drop_inv, msk + 4);
+                } else {
 #pragma unroll
-            for (int n = 0; n < NC; ++n) {
-                if (n < ncls) {
-                    const float g = dl[(b * ncls + n) * HW + pix] * gscale;
-                    const float4 w0 = *reinterpret_cast<const float4*>(sw + n * C + u * 8);
-                    const float4 w1 = *reinterpret_cast<const float4*>(sw + n * C + u * 8 + 4);
-                    const float wr[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-                    dba[n] += g;
+                    for (int j = 0; j < 8; ++j) msk[j] = 1.f;
+                }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        o[j] += g * wr[j];
-                        dwa[n][j] += g * f[j];
+                for (int j = 0; j < 8; ++j) {
+                    f[q][j] *= msk[j];
+                    o[j] = 0.f;
+                }
+#pragma unroll
+                for (int n = 0; n < NC; ++n) {
+                    if (n < ncls) {
+                        const float g = gq[q][n];
+                        const float4 w0 = *reinterpret_cast<const float4*>(sw + n * C + u * 8);
+                        const float4 w1 = *reinterpret_cast<const float4*>(sw + n * C + u * 8 + 4);
+                        const float wr[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+                        dba[n] += g;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            o[j] += g * wr[j];
+                            dwa[n][j] += g * f[q][j];
+                        }
                     }
                 }
-            }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] *= msk[j];
-            store8_split(df_hi, df_lo, idx, o);
+                for (int j = 0; j < 8; ++j) o[j] *= msk[j];
+                store8_split(df_hi, df_lo, idx, o);
+            }
         }
 #pragma unroll
         for (int n = 0; n < NC; ++n) {
@@ -281,7 +312,8 @@ __global__ __launch_bounds__(TPB) void classifier_bwd_wide_kernel(const float* _
             const long m = mg + px;
             float g = 0.f;
             if (m < M && px < (iters - it0) * nsl) {
-                const long b = m / HW, pix = m - b * HW;
+                long b, pix;
+                split_pixel(m, HW, b, pix);
                 g = dl[(b * ncls + n) * HW + pix] * gscale;
             }
             sdl[i] = g;
@@ -380,7 +412,8 @@ __global__ __launch_bounds__(TPB) void ce_loss_kernel(const float* __restrict__ 
     // flight per CU to cover the HBM latency.
     float my_loss = 0.f, my_cnt = 0.f;
     for (long m0 = (blockIdx.x * (long)TPB + threadIdx.x) * VEC; m0 < M; m0 += (long)gridDim.x * TPB * VEC) {
-        const long b = m0 / HW, pix = m0 - b * HW;
+        long b, pix;
+        split_pixel(m0, HW, b, pix);
         float z[MAXC][VEC];
         LABEL lab[VEC];
 #pragma unroll
@@ -495,7 +528,8 @@ __global__ __launch_bounds__(TPB) void kd_loss_kernel(const float* __restrict__ 
             const long y = (long)labels[m];
             if (y == ignore_index || y < 0 || y >= ncls) continue;
         }
-        const long b = m / HW, pix = m - b * HW;
+        long b, pix;
+        split_pixel(m, HW, b, pix);
         float zs[MAXC], zt[MAXC];
         float ms = -INFINITY, mt = -INFINITY;
 #pragma unroll
@@ -550,7 +584,8 @@ __global__ __launch_bounds__(TPB) void auc_update_kernel(const float* __restrict
     for (long m = blockIdx.x * (long)TPB + threadIdx.x; m < M; m += (long)gridDim.x * TPB) {
         const long y = (long)labels[m];
         if (y == ignore_index) continue;
-        const long b = m / HW, pix = m - b * HW;
+        long b, pix;
+        split_pixel(m, HW, b, pix);
         float z[MAXC];
         float mx = -INFINITY;
 #pragma unroll
@@ -589,7 +624,8 @@ __global__ __launch_bounds__(TPB) void softmax_prob_kernel(const float* __restri
                                                            int ncls, int cls) {
     const long m = blockIdx.x * (long)TPB + threadIdx.x;
     if (m >= M) return;
-    const long b = m / HW, pix = m - b * HW;
+    long b, pix;
+    split_pixel(m, HW, b, pix);
     float mx = -INFINITY, zc = 0.f;
     for (int n = 0; n < ncls; ++n) mx = fmaxf(mx, logits[(b * ncls + n) * HW + pix]);
     float se = 0.f;
@@ -678,7 +714,8 @@ __global__ __launch_bounds__(TPB) void kd_mse_loss_kernel(const float* __restric
 __global__ void argmax_kernel(const float* __restrict__ logits, signed char* __restrict__ out, long M, long HW, int ncls) {
     long m = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (m >= M) return;
-    long b = m / HW, pix = m - b * HW;
+    long b, pix;
+    split_pixel(m, HW, b, pix);
     float mx = -INFINITY;
     int am = 0;
     for (int n = 0; n < ncls; ++n) {
