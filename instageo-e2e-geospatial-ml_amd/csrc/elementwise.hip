@@ -2,6 +2,8 @@
 // LayerNorm fwd/bwd, BatchNorm(+ReLU) fwd/bwd, column sums, bf16 splitting, AdamW.
 // All are streaming kernels: 16-byte accesses per lane, wave64 shuffles for row reductions, one
 // atomic per (block, column) for column reductions.  Reference call sites are cited per kernel.
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -1171,9 +1173,11 @@ int ig_layernorm_bwd(const void* dy_hi, const void* dy_lo, const float* x, const
     // 48 rows per workgroup (measured best of 16..128 at M = 21168, tools/ln_bench.py).  For small M keep ~200 workgroups
     // (every workgroup ends in 3 D atomics, so more is not better): M = 3152 (the YAML's batch 16) 16 rows -> 21 us against
     // 38 us at 48 and 24 us at 8; M = 10638 stays at 48 (60 us; 32 rows: 75 us)
+    // From M = 21168 up the best grid stays at ~440 workgroups (1.7 per CU): M = 42552 (batch 216) 96 rows 113 us against 119 us at 48
+    // and 147-210 us at 144-240 rows (r03: IG_LNB_RPB sweep)
     int rpb = (int)((((long)M + 209) / 210 + 7) / 8 * 8);
     if (rpb < 8) rpb = 8;
-    if (rpb > 48) rpb = 48;
+    if (rpb > 48) rpb = std::max(48, (int)((((long)M + 443) / 444 + 7) / 8 * 8));
     if (rpb_env > 0) rpb = rpb_env;
     dim3 grid(ig_cdiv(M, rpb));
     size_t sm = 3 * (size_t)D * sizeof(float);
