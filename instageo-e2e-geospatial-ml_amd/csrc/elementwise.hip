@@ -1177,7 +1177,7 @@ int ig_layernorm_bwd(const void* dy_hi, const void* dy_lo, const float* x, const
     // and 147-210 us at 144-240 rows (r03: IG_LNB_RPB sweep)
     int rpb = (int)((((long)M + 209) / 210 + 7) / 8 * 8);
     if (rpb < 8) rpb = 8;
-    if (rpb > 48) rpb = std::max(48, (int)((((long)M + 443) / 444 + 7) / 8 * 8));
+    if (rpb > 48) rpb = std::max(48, (int)(((long)M / 444 + 4) / 8 * 8));  // nearest multiple of 8 to M / 444
     if (rpb_env > 0) rpb = rpb_env;
     dim3 grid(ig_cdiv(M, rpb));
     size_t sm = 3 * (size_t)D * sizeof(float);
