@@ -405,6 +405,34 @@ def test_layernorm_fwd_bwd(split, D):
     close(dx2, gx, 2e-5, what="ln dx (no accumulate)")
 
 
+@pytest.mark.parametrize("M", [21276, 42552, 42555])
+def test_layernorm_bwd_benchmark_token_counts(M):
+    """LayerNorm backward at the token counts of the benchmark batches (108 / 216 chips x 197 tokens, and a ragged count): the
+    rows-per-workgroup rule changes with M (48 -> 96 rows), the result must not -- against float64 autograd on the device."""
+    D = 768
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(M, D, device=DEV, generator=gen) * 2 + 0.5
+    g = 1 + 0.1 * torch.randn(D, device=DEV, generator=gen)
+    b = 0.1 * torch.randn(D, device=DEV, generator=gen)
+    out = BT.empty((M, D), False, DEV)
+    mean = torch.empty(M, device=DEV)
+    rstd = torch.empty(M, device=DEV)
+    ops.layernorm_fwd(x, g, b, out, mean, rstd, M, D)
+    dy = BT.from_float(torch.randn(M, D, device=DEV, generator=gen), False)
+    xd, gd, bd = x.double().requires_grad_(True), g.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = F.layer_norm(xd, (D,), gd, bd, 1e-5)
+    gx, gg, gb = torch.autograd.grad((ref * dy.float().double()).sum(), [xd, gd, bd])
+    dx0 = torch.randn(M, D, device=DEV, generator=gen)
+    dx = dx0.clone()
+    dgam, dbet, dcol = (torch.zeros(D, device=DEV) for _ in range(3))
+    ops.layernorm_bwd(dy, x, mean, rstd, g, dx, True, None, dgam, dbet, dcol, M, D)
+    want = dx0.double() + gx
+    assert (dx.double() - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+    for got, w, what in ((dgam, gg, "dgamma"), (dbet, gb, "dbeta"), (dcol, want.sum(0), "dcol")):
+        err = (got.double() - w).abs().max().item() / max(1.0, w.abs().max().item())
+        assert err <= 5e-5, (what, err)
+
+
 @pytest.mark.parametrize("split", SPLITS)
 @pytest.mark.parametrize("T", [1, 3])
 def test_layernorm_feature_layout(split, T):
