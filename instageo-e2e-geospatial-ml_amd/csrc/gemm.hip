@@ -1372,7 +1372,7 @@ struct EpAtomic {
     int ntiles = 0;  // v1 engine: output tiles of the launch (the kernel is not told otherwise)
     __device__ void init(int z) { zoff = (long)z * zstride; }
     __device__ void add(int m, int n, float v) const {
-        if (partial) partial[(size_t)(split >= 0 ? split : (int)blockIdx.y) * slab + (size_t)m * ldo + n] = v;
+        if (partial) partial[(size_t)(split >= 0 ? split : (int)blockIdx.y) * slab + (size_t)m * ldo + zoff + n] = v;
         else ig_red_add(out + (size_t)m * ldo + zoff + n, v);
     }
     __device__ void store(int m, int n, f32x4 a) const {
@@ -1468,7 +1468,10 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep_in, int M, int N, int K
     auto prep_partial = [&](int ks) -> int {
         if constexpr (EP::kStagedAtomic) {
             partial_ks = 0;
-            if (ks > 1 && Z == 1 && splitk_partial_enabled() && ((long)M * ep.ldo) % 4 == 0 && (((uintptr_t)ep.out) & 15) == 0) {
+            // Z > 1 (the taps of the ConvTranspose weight gradient in blockIdx.z): the z slices must tile the rows of `out` exactly,
+            // because the reduce adds WHOLE slabs -- an element no workgroup stored would be garbage
+            const bool z_ok = Z == 1 || ((long)Z * ep.zstride == ep.ldo && (long)N == ep.zstride);
+            if (ks > 1 && z_ok && splitk_partial_enabled() && ((long)M * ep.ldo) % 4 == 0 && (((uintptr_t)ep.out) & 15) == 0) {
                 float* ws = splitk_workspace((size_t)ks * M * ep.ldo * sizeof(float), st);
                 if (ws) {  // (no workspace -- allocation failed or a capture is active: the atomic form, still correct)
                     ep.partial = ws, ep.slab = (long)M * ep.ldo;
