@@ -254,3 +254,33 @@ def test_torch_library_ops_are_registered_from_the_header():
 
     with pytest.raises(NotImplementedError):  # no CPU backend
         torch.ops.instageo_mi355x.linear(torch.empty(4, 8, dtype=torch.bfloat16), torch.empty(8, 8, dtype=torch.bfloat16), None, 0)
+
+
+@pytest.mark.parametrize("variant", ["prithvi_eo_v1_100", "prithvi_eo_v2_300"])
+def test_block_gradient_range_tables_partition_the_flat_buffer(variant):
+    """Host logic behind the deterministic folds and the fresh-step zeroing (model.py): the "small ranges" of a Block are exactly its
+    flat range minus the four weight matrices the grouped weight-gradient kernel writes -- nothing left out, nothing twice -- and the
+    notification ranges of a backward pass tile [0, total)."""
+    from instageo_amd.model import PrithviSeg
+
+    net = PrithviSeg(variant=variant, load_pretrained_weights=False, device="cpu")
+    eng, ent = net.engine, net.engine.store.entries
+    L = eng.cfg.depth
+    e = "prithvi_encoder."
+    starts = [ent[f"{e}blocks.{i}.norm1.weight"].offset for i in range(L)] + [ent[e + "norm.weight"].offset]
+    for i in (0, L // 2, L - 1):
+        lo, hi = starts[i], starts[i + 1]
+        small = eng._block_small_ranges(i, lo, hi)
+        big = sorted((ent[f"{e}blocks.{i}.{n}"].offset, ent[f"{e}blocks.{i}.{n}"].offset + ent[f"{e}blocks.{i}.{n}"].numel) for n in eng._BLOCK_WEIGHTS)
+        pieces = sorted(small + big)
+        assert pieces[0][0] == lo and pieces[-1][1] == hi
+        assert all(a[1] == b[0] for a, b in zip(pieces, pieces[1:])), "gap or overlap inside a Block"
+        assert all(b > a for a, b in small)
+        D = eng.cfg.embed_dim
+        assert sum(b - a for a, b in small) == 13 * D  # 2 LayerNorms (4 D) + biases of qkv (3 D), proj (D), fc1 (4 D), fc2 (D)
+    # the notification ranges of SegEngine.backward: head | final norm | blocks L-1 .. 0 | cls token + patch embedding
+    head0 = ent["segmentation_head.0.0.weight"].offset
+    tiles = [(head0, eng.store.total), (starts[L], head0)] + [(starts[i], starts[i + 1]) for i in range(L - 1, -1, -1)]
+    tiles.append((ent[e + "cls_token"].offset, starts[0]))
+    tiles.sort()
+    assert tiles[0][0] == 0 and tiles[-1][1] == eng.store.total and all(a[1] == b[0] for a, b in zip(tiles, tiles[1:]))
