@@ -19,6 +19,38 @@ __device__ __forceinline__ void split_pixel(long m, long HW, long& b, long& pix)
     }
 }
 
+// Grid-wide sums in a FIXED order (the reported loss statistics are bit-identical from run to run): thread i < NV of every workgroup
+// hands in its workgroup's partial t; partials go to scratch[workgroup][i]; the workgroup that takes the last ticket adds them up in
+// workgroup order (16 strided subsets per value, folded in subset order) and gets the totals back in t of its threads i < NV.
+// Returns true in that workgroup only.  NV <= 16, blockDim.x == 256.  Launches that share the scratch are ordered on one stream.
+template <int NV>
+__device__ __forceinline__ bool ordered_grid_totals(double& t, double* __restrict__ scratch, unsigned* __restrict__ ticket) {
+    static_assert(NV <= 16, "at most 16 values");
+    __shared__ int s_last;
+    __shared__ double s_sub[16][16];
+    if (threadIdx.x < NV) scratch[(size_t)blockIdx.x * NV + threadIdx.x] = t;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return false;
+    __threadfence();
+    const int i = threadIdx.x & 15, g = threadIdx.x >> 4;
+    double a = 0.0;
+    if (i < NV)
+        for (unsigned b = g; b < gridDim.x; b += 16) a += *reinterpret_cast<volatile double*>(scratch + (size_t)b * NV + i);
+    s_sub[g][i] = a;
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += s_sub[q][threadIdx.x];
+        t = s;
+    }
+    if (threadIdx.x == 0) atomicExch(ticket, 0u);
+    return true;
+}
+
 constexpr int TPB = 256;
 constexpr int MAXC = 16;  // max classes held in registers
 
@@ -520,7 +552,7 @@ __global__ __launch_bounds__(TPB) void ce_loss_kernel(const float* __restrict__ 
 template <typename LABEL>
 __global__ __launch_bounds__(TPB) void kd_loss_kernel(const float* __restrict__ student, const float* __restrict__ teacher,
                                                       const LABEL* __restrict__ labels, long ignore_index, double* __restrict__ kl_sum,
-                                                      float* __restrict__ dlogits, long M, long HW, int ncls) {
+                                                      float* __restrict__ dlogits, long M, long HW, int ncls, double* __restrict__ scratch, unsigned* __restrict__ ticket) {
     __shared__ double red[TPB / 64];
     double my = 0.0;
     for (long m = blockIdx.x * (long)TPB + threadIdx.x; m < M; m += (long)gridDim.x * TPB) {
@@ -559,11 +591,10 @@ __global__ __launch_bounds__(TPB) void kd_loss_kernel(const float* __restrict__ 
     for (int o = 32; o > 0; o >>= 1) my += __shfl_xor(my, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = my;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
+    double t = 0.0;
+    if (threadIdx.x == 0)
         for (int w = 0; w < TPB / 64; ++w) t += red[w];
-        atomicAdd(kl_sum, t);
-    }
+    if (ordered_grid_totals<1>(t, scratch, ticket) && threadIdx.x == 0) *kl_sum += t;
 }
 
 // K16b streaming ROC-AUC histograms (metrics.py:214-256, called with softmax probabilities at segmentation.py:153-156):
@@ -644,7 +675,7 @@ __global__ __launch_bounds__(TPB) void softmax_prob_kernel(const float* __restri
 __global__ __launch_bounds__(TPB) void mse_loss_kernel(const float* __restrict__ pred, const float* __restrict__ labels, float ignore_value,
                                                        int use_log, double* __restrict__ stats, float* __restrict__ dpred,
                                                        double* __restrict__ msums, float ee_bias, float ee_coef, int include_ee,
-                                                       long M) {
+                                                       long M, double* __restrict__ scratch, unsigned* __restrict__ ticket) {
     __shared__ double red[TPB / 64][10];
     double a[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [0] = sum of squared error in the (possibly log) training domain
     for (long m = blockIdx.x * (long)TPB + threadIdx.x; m < M; m += (long)gridDim.x * TPB) {
@@ -673,15 +704,16 @@ __global__ __launch_bounds__(TPB) void mse_loss_kernel(const float* __restrict__
         if (lane == 0) red[wave][i] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 10) {
-        double t = 0.0;
+    double t = 0.0;
+    if (threadIdx.x < 10)
         for (int w = 0; w < TPB / 64; ++w) t += red[w][threadIdx.x];
+    if (ordered_grid_totals<10>(t, scratch, ticket) && threadIdx.x < 10) {
         const int i = threadIdx.x;
-        if (i == 0) atomicAdd(stats + 0, t);
+        if (i == 0) stats[0] += t;
         else if (i == 1) {
-            atomicAdd(stats + 1, t);
-            if (msums) atomicAdd(msums + 0, t);
-        } else if (msums) atomicAdd(msums + (i - 1), t);
+            stats[1] += t;
+            if (msums) msums[0] += t;
+        } else if (msums) msums[i - 1] += t;
     }
 }
 
@@ -689,7 +721,7 @@ __global__ __launch_bounds__(TPB) void mse_loss_kernel(const float* __restrict__
 // (student - teacher')^2 with teacher' = log1p(teacher) under use_log_scale; sum[0] += the numerator, dpred += 2 (s - t').
 __global__ __launch_bounds__(TPB) void kd_mse_loss_kernel(const float* __restrict__ pred, const float* __restrict__ teacher,
                                                           const float* __restrict__ labels, float ignore_value, int use_log,
-                                                          double* __restrict__ sum, float* __restrict__ dpred, long M) {
+                                                          double* __restrict__ sum, float* __restrict__ dpred, long M, double* __restrict__ scratch, unsigned* __restrict__ ticket) {
     __shared__ double red[TPB / 64];
     double a = 0.0;
     for (long m = blockIdx.x * (long)TPB + threadIdx.x; m < M; m += (long)gridDim.x * TPB) {
@@ -703,11 +735,10 @@ __global__ __launch_bounds__(TPB) void kd_mse_loss_kernel(const float* __restric
     for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
+    double t = 0.0;
+    if (threadIdx.x == 0)
         for (int w = 0; w < TPB / 64; ++w) t += red[w];
-        atomicAdd(sum, t);
-    }
+    if (ordered_grid_totals<1>(t, scratch, ticket) && threadIdx.x == 0) *sum += t;
 }
 
 // argmax over classes -> int8 class map (infer_utils.py:99-101)
@@ -826,6 +857,21 @@ int ig_classifier_bwd(const float* dlogits, const void* f_hi, const void* f_lo, 
     return ig_check_launch("ig_classifier_bwd");
 }
 
+// per-device scratch of ordered_grid_totals: 1024 workgroups x 16 partials + the ticket; allocated (zeroed) once, never freed,
+// never during a graph capture (the first call of a process is a warm-up call)
+static double* loss_scratch(unsigned** ticket) {
+    static double* buf[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!buf[dev]) {
+        const size_t bytes = (1024 * 16 + 2) * sizeof(double);
+        if (hipMalloc((void**)&buf[dev], bytes) != hipSuccess) return nullptr;
+        if (hipMemset(buf[dev], 0, bytes) != hipSuccess) return nullptr;
+    }
+    *ticket = reinterpret_cast<unsigned*>(buf[dev] + 1024 * 16);
+    return buf[dev];
+}
+
 // label_dtype: 0 = int64, 1 = int32, 2 = float32 (reference labels are float tensors cast with .long())
 int ig_ce_loss(const float* logits, const void* labels, int label_dtype, const float* class_weights, long ignore_index,
                double* stats, float* dlogits, long long* preds, signed char* preds_i8, unsigned long long* confusion, int B,
@@ -891,15 +937,18 @@ int ig_kd_loss(const float* student_logits, const float* teacher_logits, const v
     long nblk = (M + TPB - 1) / TPB;
     if (nblk > 1024) nblk = 1024;
     hipStream_t st = (hipStream_t)stream;
+    unsigned* ticket = nullptr;
+    double* scratch = loss_scratch(&ticket);
+    IG_REQUIRE(scratch, "ig_kd_loss: scratch allocation failed");
     if (label_dtype == 0)
         hipLaunchKernelGGL(kd_loss_kernel<long long>, dim3((unsigned)nblk), dim3(TPB), 0, st, student_logits, teacher_logits,
-                           (const long long*)labels, ignore_index, kl_sum, dlogits, M, HW, ncls);
+                           (const long long*)labels, ignore_index, kl_sum, dlogits, M, HW, ncls, scratch, ticket);
     else if (label_dtype == 1)
         hipLaunchKernelGGL(kd_loss_kernel<int>, dim3((unsigned)nblk), dim3(TPB), 0, st, student_logits, teacher_logits, (const int*)labels,
-                           ignore_index, kl_sum, dlogits, M, HW, ncls);
+                           ignore_index, kl_sum, dlogits, M, HW, ncls, scratch, ticket);
     else if (label_dtype == 2)
         hipLaunchKernelGGL(kd_loss_kernel<float>, dim3((unsigned)nblk), dim3(TPB), 0, st, student_logits, teacher_logits,
-                           (const float*)labels, ignore_index, kl_sum, dlogits, M, HW, ncls);
+                           (const float*)labels, ignore_index, kl_sum, dlogits, M, HW, ncls, scratch, ticket);
     else {
         ig_set_error("ig_kd_loss: unsupported label dtype %d", label_dtype);
         return IG_ERR_UNSUPPORTED;
@@ -957,8 +1006,11 @@ int ig_mse_loss(const float* pred, const float* labels, float ignore_value, int 
     if (n == 0) return IG_OK;
     long nblk = (n + TPB - 1) / TPB;
     if (nblk > 1024) nblk = 1024;
+    unsigned* ticket = nullptr;
+    double* scratch = loss_scratch(&ticket);
+    IG_REQUIRE(scratch, "ig_mse_loss: scratch allocation failed");
     hipLaunchKernelGGL(mse_loss_kernel, dim3((unsigned)nblk), dim3(TPB), 0, (hipStream_t)stream, pred, labels, ignore_value, use_log_scale,
-                       stats, dpred, msums, ee_bias, ee_coef, include_ee, n);
+                       stats, dpred, msums, ee_bias, ee_coef, include_ee, n, scratch, ticket);
     return ig_check_launch("ig_mse_loss");
 }
 
@@ -968,8 +1020,11 @@ int ig_kd_mse_loss(const float* pred, const float* teacher, const float* labels,
     if (n == 0) return IG_OK;
     long nblk = (n + TPB - 1) / TPB;
     if (nblk > 1024) nblk = 1024;
+    unsigned* ticket = nullptr;
+    double* scratch = loss_scratch(&ticket);
+    IG_REQUIRE(scratch, "ig_kd_mse_loss: scratch allocation failed");
     hipLaunchKernelGGL(kd_mse_loss_kernel, dim3((unsigned)nblk), dim3(TPB), 0, (hipStream_t)stream, pred, teacher, labels, ignore_value,
-                       use_log_scale, sum, dpred, n);
+                       use_log_scale, sum, dpred, n, scratch, ticket);
     return ig_check_launch("ig_kd_mse_loss");
 }
 

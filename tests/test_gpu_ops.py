@@ -1000,3 +1000,36 @@ def test_torch_library_functional_ops_autograd():
     yy = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
     torch.library.opcheck(ns.linear_fwd.default, (x.detach(), None, w.detach(), None, b.detach(), yy, None, None, None, M, N, K, 0),
                           test_utils=("test_schema", "test_faketensor"))
+
+
+def test_loss_statistics_are_bit_reproducible():
+    """The grid-wide sums of ig_mse_loss / ig_kd_mse_loss / ig_kd_loss / ig_ce_loss are added in a fixed order (workgroup partials
+    folded by the workgroup that arrives last): repeated launches on the same inputs give bit-identical statistics -- many workgroups
+    (the 1024-workgroup cap) and a launch with a single one."""
+    g = torch.Generator(device=DEV).manual_seed(11)
+    for n_img in (40, 1):
+        B, H, W, ncls = n_img, 224, 224, 5
+        pred = torch.randn(B, 1, H, W, device=DEV, generator=g) * 3
+        teach = torch.randn(B, 1, H, W, device=DEV, generator=g) * 3
+        lab = torch.rand(B, H, W, device=DEV, generator=g) * 10
+        lab[torch.rand(B, H, W, device=DEV, generator=g) < 0.1] = -1.0
+        s_log = torch.randn(B, ncls, H, W, device=DEV, generator=g)
+        t_log = torch.randn(B, ncls, H, W, device=DEV, generator=g)
+        lab_c = torch.randint(-1, ncls, (B, H, W), device=DEV, generator=g)
+        runs = []
+        for _ in range(4):
+            st = torch.zeros(2, dtype=torch.float64, device=DEV)
+            ms = torch.zeros(9, dtype=torch.float64, device=DEV)
+            kd = torch.zeros(1, dtype=torch.float64, device=DEV)
+            kl = torch.zeros(1, dtype=torch.float64, device=DEV)
+            ce = torch.zeros(2, dtype=torch.float64, device=DEV)
+            ops.mse_loss(pred, lab, -1.0, False, st, None, ms, 0.1, 0.15, True)
+            ops.kd_mse_loss(pred, teach, lab, -1.0, False, kd)
+            ops.kd_loss(s_log, t_log, lab_c, -1, kl, None)
+            ops.ce_loss(s_log, lab_c, None, -1, ce)
+            runs.append(torch.cat([st, ms, kd, kl, ce]))
+        for r in runs[1:]:
+            assert torch.equal(r, runs[0]), (r, runs[0])
+        valid = lab != -1.0
+        want = ((pred[:, 0] - lab)[valid].double() ** 2).sum().item()
+        assert abs(runs[0][0].item() - want) <= 1e-9 * want and runs[0][1].item() == valid.sum().item()
