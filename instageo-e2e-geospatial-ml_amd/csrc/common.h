@@ -35,6 +35,13 @@ int ig_convT_wgrad_direct(const void* dy, const void* x, float* dw, float* dbias
 int ig_conv3x3_wgrad_direct(const void* dy, const void* x, float* dw, float* dbias, int* bias_fused, int B, int H, int W, int Cin,
                             int Cout, void* stream);
 
+// conv8.hip: the decode head's wide ConvTranspose / Conv2d 3x3 forward and data-gradient passes as implicit GEMMs on the 8-phase
+// schedule with gathering LDS-DMA.  kind 0: Conv2d 3x3 pad 1 (sign +1 forward, -1 data gradient), 1: ConvTranspose forward,
+// 2: ConvTranspose data gradient.  (H, W) = row grid, C = channels of the gathered tensor, N = output channels.
+// IG_ERR_UNSUPPORTED (no error string) when the shape is not covered.
+int ig_conv8(int kind, int sign, const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
+             const float* scale, const float* shift, void* y_hi, void* y_lo, int B, int H, int W, int C, int N, unsigned drop_seed,
+             const unsigned* drop_seed_dev, float drop_p, void* stream);
 // gemm8.hip: the 256 x 256 x 64 8-phase engine for the K-contiguous ("NT") linear GEMMs.  kind 0: bf16 (split) store of
 // act(acc + bias) [+ gelu' copy]; kind 1: fp32 out = resid + acc + bias; kind 2: bf16 (split) store of acc * dact (dact_hi /
 // dact_lo are INPUTS here) with optional fused column sums.  a / b: segment pointer sets (nseg 1 or 3).
@@ -85,6 +92,24 @@ int ig_tile_grid(int ntiles, int per_cu);
 
 static inline int ig_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Division by a launch-time constant as multiply-high + shift (dividends < 2^31): the pixel -> (b, y, x) and
+// k -> (tap, channel) decodes of the convolution gathers were integer divisions per 16-byte unit.
+struct FDiv {
+    unsigned mul, shr, d;
+    __device__ __forceinline__ int div(int n) const { return d == 1 ? n : (int)(__umulhi((unsigned)n, mul) >> shr); }
+};
+static inline FDiv make_fdiv(int d) {
+    FDiv f{0u, 0u, (unsigned)d};
+    if (d > 1) {
+        unsigned lg = 0;
+        while ((1u << lg) < (unsigned)d) ++lg;  // ceil(log2 d)
+        const unsigned p = 31 + lg;
+        f.mul = (unsigned)((((unsigned long long)1 << p) + (unsigned)d - 1) / (unsigned)d);
+        f.shr = p - 32;
+    }
+    return f;
+}
+
 // ---- run-to-run deterministic reductions (opt-in: ig_set_deterministic) -------------------------------------------------------
 // Floating-point atomics make a sum depend on the order its contributors arrive in.  In deterministic mode every multi-contributor
 // reduction into the flat gradient buffer goes to a parallel int64 "shadow" of that buffer as a FIXED-POINT integer add (integer
@@ -107,6 +132,7 @@ bool ig_deterministic();  // host-side view of the mode (runtime.hip)
 // per-device grow-only scratch buffers (slot 0: BatchNorm partial sums); never freed, a superseded buffer stays allocated because
 // launches in flight may still use it; NULL on allocation failure.  Not to be grown during a graph capture (first calls are warm-ups).
 void* ig_scratch(int slot, size_t bytes);
+void* ig_scratch2(int slot, size_t bytes, bool may_grow);  // may_grow = false: NULL instead of an allocation (stream captures)
 
 // device side ----------------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }

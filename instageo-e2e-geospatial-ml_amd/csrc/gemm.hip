@@ -898,23 +898,7 @@ __global__ __launch_bounds__(NTHR5, 2) void gemm5_kernel(AL al, BL bl, EP ep, in
 #undef GEMM5_SETUP
 }
 
-// Division by a launch-time constant as multiply-high + shift (dividends < 2^31): the pixel -> (b, y, x) and
-// k -> (tap, channel) decodes of the convolution gathers were integer divisions per 16-byte unit.
-struct FDiv {
-    unsigned mul, shr, d;
-    __device__ __forceinline__ int div(int n) const { return d == 1 ? n : (int)(__umulhi((unsigned)n, mul) >> shr); }
-};
-static inline FDiv make_fdiv(int d) {
-    FDiv f{0u, 0u, (unsigned)d};
-    if (d > 1) {
-        unsigned lg = 0;
-        while ((1u << lg) < (unsigned)d) ++lg;  // ceil(log2 d)
-        const unsigned p = 31 + lg;
-        f.mul = (unsigned)((((unsigned long long)1 << p) + (unsigned)d - 1) / (unsigned)d);
-        f.shr = p - 32;
-    }
-    return f;
-}
+// FDiv / make_fdiv (division by a launch-time constant as multiply-high + shift): common.h
 
 // ------------------------------------------------------------------------------------ loaders
 // segment base pointer by compare/select: a dynamically indexed base[seg] of a by-value loader that init() has modified
@@ -1908,6 +1892,10 @@ int ig_conv3x3_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const v
         const int rc = ig_conv3x3_direct(x_hi, w_hi, bias, bn_scale, bn_shift, y_hi, B, H, W, Cin, Cout, 0, 0, nullptr, 0.f, stream);
         if (rc != IG_ERR_UNSUPPORTED) return rc;
     }
+    {  // wide stages: implicit GEMM on the 8-phase schedule with gathering LDS-DMA (conv8.hip)
+        const int rc = ig_conv8(0, 1, x_hi, x_lo, w_hi, w_lo, bias, bn_scale, bn_shift, y_hi, y_lo, B, H, W, Cin, Cout, 0, nullptr, 0.f, stream);
+        if (rc != IG_ERR_UNSUPPORTED) return rc;
+    }
     Conv3Loader al{};
     seg_a(al.base, x_hi, x_lo);
     al.Mtot = B * H * W, al.H = H, al.W = W, al.C = Cin, al.sign = 1;
@@ -1932,6 +1920,11 @@ int ig_conv3x3_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, con
     if (!dy_lo && !dx_lo) {
         const int rc = ig_conv3x3_direct(dy_hi, w_hi, nullptr, nullptr, nullptr, dx_hi, B, H, W, Cin, Cout, 1, drop_seed, drop_seed_dev,
                                          drop_p, stream);
+        if (rc != IG_ERR_UNSUPPORTED) return rc;
+    }
+    {
+        const int rc = ig_conv8(0, -1, dy_hi, dy_lo, w_hi, w_lo, nullptr, nullptr, nullptr, dx_hi, dx_lo, B, H, W, Cout, Cin, drop_seed,
+                                drop_seed_dev, drop_p, stream);
         if (rc != IG_ERR_UNSUPPORTED) return rc;
     }
     Conv3Loader al{};
@@ -2067,6 +2060,11 @@ int ig_convT_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const voi
         const int rc = ig_convT_fwd_direct(x_hi, w_hi, bias, y_hi, B, H, W, Cin, Cout, drop_seed, drop_seed_dev, drop_p, stream);
         if (rc != IG_ERR_UNSUPPORTED) return rc;
     }
+    {
+        const int rc = ig_conv8(1, 1, x_hi, x_lo, w_hi, w_lo, bias, nullptr, nullptr, y_hi, y_lo, B, H, W, Cin, Cout, drop_seed, drop_seed_dev,
+                                drop_p, stream);
+        if (rc != IG_ERR_UNSUPPORTED) return rc;
+    }
     ConvTFwdALoader al{};
     seg_a(al.base, x_hi, x_lo);
     al.Mtot = B * H * W, al.H = H, al.W = W, al.C = Cin;
@@ -2095,6 +2093,10 @@ int ig_convT_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, const
     IG_SPLIT_CONSISTENT(dy_lo, w_lo);
     if (!dy_lo && !dx_lo) {  // last stage (96 -> 48): direct stride-2 gather over phase planes (conv_direct.hip)
         const int rc = ig_convT_dgrad_direct(dy_hi, w_hi, dx_hi, B, H, W, Cin, Cout, stream);
+        if (rc != IG_ERR_UNSUPPORTED) return rc;
+    }
+    {
+        const int rc = ig_conv8(2, 1, dy_hi, dy_lo, w_hi, w_lo, nullptr, nullptr, nullptr, dx_hi, dx_lo, B, H, W, Cout, Cin, 0, nullptr, 0.f, stream);
         if (rc != IG_ERR_UNSUPPORTED) return rc;
     }
     ConvTGradLoader al{};

@@ -86,12 +86,14 @@ int ig_det_sync_attention2(const IgDet*, hipStream_t);
 IG_DET_TU(runtime)
 static IgDet g_det_host = {nullptr, nullptr, 0};
 bool ig_deterministic() { return g_det_host.shadow != nullptr; }
-void* ig_scratch(int slot, size_t bytes) {
+void* ig_scratch(int slot, size_t bytes) { return ig_scratch2(slot, bytes, true); }
+void* ig_scratch2(int slot, size_t bytes, bool may_grow) {
     static void* buf[16][4] = {};
     static size_t cap[16][4] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || slot < 0 || slot >= 4) return nullptr;
     if (cap[dev][slot] < bytes) {
+        if (!may_grow) return nullptr;  // e.g. during a stream capture: nothing may be allocated
         void* p = nullptr;
         const size_t want = bytes + bytes / 2;
         if (hipMalloc(&p, want) != hipSuccess) return nullptr;

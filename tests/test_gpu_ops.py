@@ -627,6 +627,118 @@ def test_convT(split, B, H, Cin, Cout):  # 96 -> 48 unsplit runs the direct sub-
     close(db - 0.25, dyr.sum((0, 1, 2)), 3e-5, what="convT bias gradient")
 
 
+@pytest.mark.parametrize("split", SPLITS)
+@pytest.mark.parametrize("B,H,Cin,Cout", [
+    (3, 14, 384, 384),   # 256 x 192 instance (N = 384 = 2 x 192), ragged last row tile
+    (2, 9, 192, 192),    # N = 192, K = 27 K-tiles padded to 28
+    (1, 12, 128, 256),   # 256 x 256 instance, K = 9 x 128
+    (2, 10, 128, 128),   # 256 x 128 instance
+    (1, 20, 144, 144),   # 192 x 144 instance (T = 3 widths: 2.25 K-tiles per tap, chunk-level tap decode)
+    (1, 14, 288, 288),   # 2 x 144
+    (2, 11, 96, 96),     # 192 x 96 instance (1.5 K-tiles per tap)
+    (1, 7, 576, 576),    # 3 x 192
+    (1, 5, 1152, 1152),  # 6 x 192, K = 162 K-tiles, 1296-entry chunk table
+    (1, 1, 192, 192), (1, 2, 384, 192),
+])
+def test_conv8_engine_conv3x3(split, B, H, Cin, Cout, monkeypatch):
+    """The 8-phase implicit-GEMM engine with gathering LDS-DMA (conv8.hip), forced for every covered shape: nn.Conv2d(k=3, padding=1)
+    forward (+ bias, + eval-mode BatchNorm/ReLU fold) and data gradient (+ the dropout mask of its input) against float64 torch on the
+    same rounded operands; every tile instance; repeated launches bit-identical (LDS-DMA / barrier race screen)."""
+    monkeypatch.setenv("IG_CONV8", "2")
+    monkeypatch.setenv("IG_CONV_DIRECT", "0")  # the 96-channel stage has a direct kernel that would be tried first
+    W = H + 3
+    x, xr = bt(nhwc(rnd(B, Cin, H, W, seed=26)), split)
+    wt = rnd(Cout, Cin, 3, 3, seed=27, scale=(9 * Cin) ** -0.5)
+    w, wr = bt(wt.permute(0, 2, 3, 1).reshape(Cout, 9, Cin).contiguous(), split)
+    wr_t = wr.reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+    bias = rnd(Cout, seed=28)
+    y = BT.zeros((B, H, W, Cout), split, DEV)
+    ops.conv3x3_fwd(x, w, bias.to(DEV), y, B, H, W, Cin, Cout)
+    assert ops.last_kernel().startswith("conv8_kernel"), ops.last_kernel()
+    xin = xr.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    wv = wr_t.clone().requires_grad_(True)
+    ref = F.conv2d(xin, wv, bias.double(), padding=1)
+    close(y.float(), nhwc(ref.detach()), tol_out(split), what="conv8 fwd")
+    first = y.hi.clone()
+    for _ in range(5):
+        y.hi.zero_()
+        ops.conv3x3_fwd(x, w, bias.to(DEV), y, B, H, W, Cin, Cout)
+        assert torch.equal(y.hi, first), "conv8 forward differs between identical launches"
+    # eval-mode BatchNorm + ReLU folded into the epilogue
+    sc, sh = (rnd(Cout, seed=61).abs() + 0.5), rnd(Cout, seed=62)
+    ops.conv3x3_fwd(x, w, bias.to(DEV), y, B, H, W, Cin, Cout, bn_scale=sc.to(DEV), bn_shift=sh.to(DEV))
+    assert ops.last_kernel().startswith("conv8_kernel")
+    refbn = torch.relu(ref.detach() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+    close(y.float(), nhwc(refbn), tol_out(split), what="conv8 fwd + BN/ReLU fold")
+    dy, dyr = bt(nhwc(rnd(B, Cout, H, W, seed=29)), split)
+    (gx,) = torch.autograd.grad((ref * dyr.permute(0, 3, 1, 2)).sum(), [xin])
+    dx = BT.zeros((B, H, W, Cin), split, DEV)
+    ops.conv3x3_dgrad(dy, w, dx, B, H, W, Cin, Cout)
+    assert ops.last_kernel().startswith("conv8_kernel"), ops.last_kernel()
+    close(dx.float(), nhwc(gx), tol_out(split), what="conv8 dgrad")
+    # dropout mask of the conv input: the same counter hash as the round-1 engine (zero pattern identical, kept values scaled)
+    dxd = BT.zeros((B, H, W, Cin), split, DEV)
+    ops.conv3x3_dgrad(dy, w, dxd, B, H, W, Cin, Cout, seed=1234, p=0.1)
+    assert ops.last_kernel().startswith("conv8_kernel")
+    monkeypatch.setenv("IG_CONV8", "0")
+    monkeypatch.setenv("IG_CONV_DIRECT", "0")
+    dxo = BT.zeros((B, H, W, Cin), split, DEV)
+    ops.conv3x3_dgrad(dy, w, dxo, B, H, W, Cin, Cout, seed=1234, p=0.1)
+    assert not ops.last_kernel().startswith("conv8_kernel")
+    assert torch.equal(dxd.float() == 0, dxo.float() == 0), "dropout masks of the two engines differ"
+    close(dxd.float(), dxo.float().double().cpu(), tol_out(split), what="conv8 dgrad with dropout vs the gather GEMM")
+
+
+@pytest.mark.parametrize("split", SPLITS)
+@pytest.mark.parametrize("B,H,Cin,Cout", [
+    (3, 14, 768, 384),   # stage 0 of the 100M head: N = 384 (fwd), 768 (dgrad = 3 x 256)
+    (2, 9, 384, 192),    # stage 1
+    (1, 13, 192, 96),    # stage 2: 1-tap phase = 3 K-tiles padded to 4; N = 96 instance
+    (1, 7, 288, 144),    # T = 3 widths
+    (1, 6, 2304, 1152),  # T = 3 stage 0
+    (2, 5, 128, 128), (1, 1, 384, 192), (1, 2, 128, 256),
+])
+def test_conv8_engine_convT(split, B, H, Cin, Cout, monkeypatch):
+    """nn.ConvTranspose2d(k3, s2, p1, op1) forward (four sub-pixel phases as tiles of one persistent launch, + bias, + dropout)
+    and data gradient (stride-2 gather) on the conv8 engine against float64 torch."""
+    monkeypatch.setenv("IG_CONV8", "2")
+    monkeypatch.setenv("IG_CONV_DIRECT", "0")
+    W = H + 1
+    x, xr = bt(nhwc(rnd(B, Cin, H, W, seed=30)), split)
+    wt = rnd(Cin, Cout, 3, 3, seed=31, scale=(2.25 * Cin) ** -0.5)
+    w, wr = bt(wt.permute(1, 2, 3, 0).reshape(Cout, 9, Cin).contiguous(), split)
+    wr_t = wr.reshape(Cout, 3, 3, Cin).permute(3, 0, 1, 2)
+    bias = rnd(Cout, seed=32)
+    y = BT.zeros((B, 2 * H, 2 * W, Cout), split, DEV)
+    ops.convT_fwd(x, w, bias.to(DEV), y, B, H, W, Cin, Cout)
+    assert ops.last_kernel().startswith("conv8_kernel"), ops.last_kernel()
+    xin = xr.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    wv = wr_t.clone().requires_grad_(True)
+    ref = F.conv_transpose2d(xin, wv, bias.double(), stride=2, padding=1, output_padding=1)
+    close(y.float(), nhwc(ref.detach()), tol_out(split), what="conv8 convT fwd")
+    first = y.hi.clone()
+    for _ in range(5):
+        y.hi.zero_()
+        ops.convT_fwd(x, w, bias.to(DEV), y, B, H, W, Cin, Cout)
+        assert torch.equal(y.hi, first), "conv8 convT forward differs between identical launches"
+    dy, dyr = bt(nhwc(rnd(B, Cout, 2 * H, 2 * W, seed=33)), split)
+    (gx,) = torch.autograd.grad((ref * dyr.permute(0, 3, 1, 2)).sum(), [xin])
+    dx = BT.zeros((B, H, W, Cin), split, DEV)
+    ops.convT_dgrad(dy, w, dx, B, H, W, Cin, Cout)
+    assert ops.last_kernel().startswith("conv8_kernel"), ops.last_kernel()
+    close(dx.float(), nhwc(gx), tol_out(split), what="conv8 convT dgrad")
+    # forward dropout: same mask as the round-1 engine
+    yd = BT.zeros((B, 2 * H, 2 * W, Cout), split, DEV)
+    ops.convT_fwd(x, w, bias.to(DEV), yd, B, H, W, Cin, Cout, seed=77, p=0.1)
+    monkeypatch.setenv("IG_CONV8", "0")
+    monkeypatch.setenv("IG_CONV_DIRECT", "0")
+    yo = BT.zeros((B, 2 * H, 2 * W, Cout), split, DEV)
+    ops.convT_fwd(x, w, bias.to(DEV), yo, B, H, W, Cin, Cout, seed=77, p=0.1)
+    assert not ops.last_kernel().startswith("conv8_kernel")
+    assert torch.equal(yd.float() == 0, yo.float() == 0), "dropout masks of the two engines differ"
+    close(yd.float(), yo.float().double().cpu(), tol_out(split), what="conv8 convT fwd with dropout vs the gather GEMM")
+
+
 @pytest.mark.parametrize("kind,C,H", [("conv", 48, 224), ("conv", 96, 112), ("convT", 96, 112)])
 def test_direct_head_kernels_at_model_size_vs_float64(kind, C, H):
     """The direct (halo-tile / sub-pixel) head kernels at the BASELINE image sizes -- 224 x 224 x 48, 112 x 112 x 96 and the
