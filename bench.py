@@ -218,6 +218,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-leg", action="store_true", help="skip the bf16x3 (1e-3-parity) leg")
     ap.add_argument("--no-tile", action="store_true", help="skip the configs[3] sliding-window leg")
+    ap.add_argument("--no-t3-leg", action="store_true", help="N > 1: skip the T = 3 / 13-class leg (the shape the scaling target is stated on)")
+    ap.add_argument("--t3-batch", type=int, default=36, help="per-GPU batch of the T = 3 leg")
     ap.add_argument("--tile-size", type=int, default=10980)
     ap.add_argument("--event-stride", type=int, default=7, help="bracket every n-th launch of the timed entry points with HIP events")
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP events (roofline objects become null)")
@@ -255,21 +257,28 @@ def main() -> None:
     torch.cuda.set_device(dev)
     torch.manual_seed(1042 + rank)
 
-    B = args.batch
-    T, NCLS = args.temporal, args.classes
     crop_w = PRESETS["multitemporal_crop_classification"]["train"]["class_weights"]  # multitemporal_crop_classification.yaml:15-30
-    cw = [1, 3] if NCLS == 2 else (crop_w if NCLS == len(crop_w) else [1.0] * NCLS)
     mean = torch.tensor(MEAN, device=dev)
     std = torch.tensor(STD, device=dev)
     nb = 4  # resident synthetic batches (raw int16 HLS domain), cycled
-    g = torch.Generator(device=dev).manual_seed(1042 + rank)
-    raws = [torch.randint(0, 10000, (B, 6 * T, 224, 224), generator=g, device=dev, dtype=torch.int16) for _ in range(nb)]
-    labels = []
-    for _ in range(nb):
-        y = torch.randint(0, NCLS, (B, 224, 224), generator=g, device=dev)
-        y[torch.rand((B, 224, 224), generator=g, device=dev) < 0.05] = -1
-        labels.append(y)
-    xbuf = torch.empty((B, 6, T, 224, 224), dtype=torch.float32, device=dev)
+
+    def make_workload(B: int, T: int, NCLS: int) -> dict:
+        """Resident synthetic batches of one configuration (per rank: its own shard of the global batch)."""
+        g = torch.Generator(device=dev).manual_seed(1042 + rank)
+        raws = [torch.randint(0, 10000, (B, 6 * T, 224, 224), generator=g, device=dev, dtype=torch.int16) for _ in range(nb)]
+        labels = []
+        for _ in range(nb):
+            y = torch.randint(0, NCLS, (B, 224, 224), generator=g, device=dev)
+            y[torch.rand((B, 224, 224), generator=g, device=dev) < 0.05] = -1
+            labels.append(y)
+        return {"B": B, "T": T, "NCLS": NCLS, "raws": raws, "labels": labels,
+                "cw": [1, 3] if NCLS == 2 else (crop_w if NCLS == len(crop_w) else [1.0] * NCLS),
+                "xbuf": torch.empty((B, 6, T, 224, 224), dtype=torch.float32, device=dev)}
+
+    B = args.batch
+    T, NCLS = args.temporal, args.classes
+    main_wl = make_workload(B, T, NCLS)
+    raws, labels, xbuf = main_wl["raws"], main_wl["labels"], main_wl["xbuf"]
 
     def barrier() -> None:
         if world > 1:
@@ -282,8 +291,10 @@ def main() -> None:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return t.item()
 
-    def run_mode(precision: str, profile: bool, graph: bool):
-        """Train + inference (+ encoder-forward) legs of one precision mode; returns a dict of raw measurements."""
+    def run_mode(precision: str, profile: bool, graph: bool, wl: dict = None):
+        """Train + inference (+ encoder-forward) legs of one precision mode on workload ``wl``; returns a dict of raw measurements."""
+        wl = wl or main_wl
+        B, T, NCLS, raws, labels, xbuf, cw = wl["B"], wl["T"], wl["NCLS"], wl["raws"], wl["labels"], wl["xbuf"], wl["cw"]
         mod = PrithviSegmentationModule(image_size=224, learning_rate=1e-4, freeze_backbone=False, load_pretrained_weights=False,
                                         num_classes=NCLS, temporal_step=T, class_weights=cw, ignore_index=-1, weight_decay=0.01,
                                         scheduler=False, model_name=args.model, precision=precision, device=dev)  # fmt: skip
@@ -323,8 +334,14 @@ def main() -> None:
             torch.cuda.synchronize()
             res["buckets"] = [{"mbytes": round((hi - lo) * 4 / 2**20, 1), "ms": round(ms, 3)} for (lo, hi), ms in sync.bucket_times()]
             sync.time_buckets = False
-        elif sync is not None:  # reduce-scatter + all-gather around the sharded optimizer: bucket sizes only (all overlapped)
+        elif sync is not None:
+            # reduce-scatter + all-gather around the sharded optimizer: bucket sizes, and the EXPOSED communication of one extra,
+            # instrumented step (events around every wait on the compute stream: the time it stands still for the exchange)
             res["buckets"] = [{"mbytes": round((hi - lo) * 4 / 2**20, 1), "ms": 0.0} for (lo, hi, _) in sync.plan]
+            sync.time_exposed = True
+            train_step(0)
+            res["exposed"] = sync.exposed_ms()
+            sync.time_exposed = False
         if profile:  # every MFMA / HBM entry point, in a separate untimed pass of 3 steps
             ops.profile_begin(GEMM_OPS + HBM_OPS)
             for i in range(3):
@@ -468,6 +485,22 @@ def main() -> None:
         parity.pop("mod")
         torch.cuda.empty_cache()
 
+    t3_leg = None
+    if world > 1 and (T, NCLS, args.model) == (1, 2, "prithvi_eo_v1_100") and not args.no_t3_leg and not args.graph:
+        # the shape north_star's >= 7x scaling target is stated on (BASELINE configs[2]: 224x224x6x3 chips, 13 classes), beside the
+        # default line: same data-parallel step, per-GPU batch --t3-batch
+        main_res.pop("mod", None)
+        mod = None
+        torch.cuda.empty_cache()
+        wl3 = make_workload(args.t3_batch, 3, 13)
+        r3 = run_mode(args.precision, False, False, wl3)
+        r3.pop("mod")
+        t3_leg = {"workload": "prithvi_eo_v1_100 T=3 13 classes (BASELINE configs[2] shape), synthetic int16 chips", "per_gpu_batch": args.t3_batch,
+                  "value": round(world * args.t3_batch * args.steps / r3["dt"], 2), "unit": "chips/s", "ms_per_step": round(1e3 * r3["dt"] / args.steps, 3),
+                  "inference_chips_per_s": round(world * args.t3_batch * args.steps / r3["dti"], 1), "exposed_comm_ms": r3.get("exposed")}
+        del wl3
+        torch.cuda.empty_cache()
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -565,6 +598,14 @@ def main() -> None:
         bk = main_res["buckets"] or []
         out["dist"] = {"ranks": world, "backend": dist.get_backend(), "mode": main_res.get("dp_mode"), "reserved_cus": ops.reserved_cus(), "buckets": len(bk),
                        "allreduce_mbytes": round(sum(b["mbytes"] for b in bk), 1), "allreduce_ms_serial": round(sum(b["ms"] for b in bk), 3)}
+        ex = main_res.get("exposed")
+        if ex is not None:  # zero1: time the compute stream stood still for the reduce-scatters / all-gathers of one instrumented step
+            out["dist"].update({"rs_exposed_ms": round(ex["rs"], 3), "ag_exposed_ms": round(ex["ag"], 3), "tail_exposed_ms": round(ex["tail"], 3),
+                                "gather": os.environ.get("IG_DP_GATHER", "shadow")})
+        if t3_leg is not None:
+            out["dist"]["t3_c13_chips_per_s"] = t3_leg["value"]
+            out["dist"]["t3_c13_ms_per_step"] = t3_leg["ms_per_step"]
+            detail["dp_t3_leg"] = t3_leg
         detail["allreduce_buckets"] = bk
     if world == 1 and not args.no_cpu_baseline:
         cb = cpu_baseline()

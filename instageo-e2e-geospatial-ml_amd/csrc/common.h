@@ -62,6 +62,10 @@ int ig_gemm8_nt(const G8Params& p, void* stream);  // IG_ERR_UNSUPPORTED (no err
 // fragment reads; IG_ERR_UNSUPPORTED (no error string) when a shape is not covered (N, K multiples of 256)
 int ig_wgrad8_group(int n, const void* const* dy_hi, const void* const* dy_lo, const void* const* x_hi, const void* const* x_lo,
                     float* const* dw, const int* N, const int* K, int M, int overwrite, void* stream);
+// gemm8w.hip: weight gradient of nn.Conv2d(k=3, padding=1) (kind 0) / nn.ConvTranspose2d(k3,s2,p1,op1) (kind 1) on the same engine
+// (gathering LDS-DMA); dWc[Cout][9][Cin] += ...; IG_ERR_UNSUPPORTED (no error string) when the shape is not covered
+int ig_wgrad8_conv(int kind, const void* dy_hi, const void* dy_lo, const void* x_hi, const void* x_lo, float* dw, int B, int H, int W,
+                   int Cin, int Cout, void* stream);
 // runtime.hip: compute units the persistent kernels leave free (for RCCL's kernels when world > 1); ig_set_reserved_cus()
 // attention2.hip: second-generation attention forward (32x32x16 MFMA, whole-head K/V in LDS); IG_ERR_UNSUPPORTED -> first generation
 int ig_attention2_fwd(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, float* lse, int B, int N, int H, void* stream);
@@ -141,7 +145,9 @@ __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint3
 __device__ __forceinline__ void ig_red_add(float* p, float v) {
     if (g_igdet.shadow) {
         const long i = p - g_igdet.base;
-        if ((unsigned long)i < (unsigned long)g_igdet.n) {
+        // NaN, Inf and |v| >= 5e5 do not fit the fixed-point shadow (the conversion would turn NaN into 0 and saturate the rest: a
+        // diverged step would report finite gradients): they take the float atomic -- NaN / Inf absorb whatever order they arrive in
+        if ((unsigned long)i < (unsigned long)g_igdet.n && fabsf(v) < 5.0e5f) {
             atomicAdd(reinterpret_cast<unsigned long long*>(g_igdet.shadow + i), (unsigned long long)__float2ll_rn(v * 17592186044416.f));
             return;
         }

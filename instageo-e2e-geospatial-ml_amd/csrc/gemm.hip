@@ -1953,6 +1953,13 @@ int ig_conv3x3_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, con
     IG_SPLIT_CONSISTENT(dy_lo, x_lo);
     // dbias (optional): the convolution's bias gradient, dbias[co] += sum_pixels dy[p][co] -- fused into the direct kernels,
     // otherwise one column-sum pass over dy
+    {  // wide stages: the 8-phase weight-gradient engine with a gathering B operand (gemm8w.hip)
+        const int rc = ig_wgrad8_conv(0, dy_hi, dy_lo, x_hi, x_lo, dw, B, H, W, Cin, Cout, stream);
+        if (rc != IG_ERR_UNSUPPORTED) {
+            if (rc == IG_OK && dbias) return ig_colsum(dy_hi, dy_lo, dbias, (long)B * H * W, Cout, stream);
+            return rc;
+        }
+    }
     if (!dy_lo) {  // narrow stages: register-resident partial sums over halo tiles (conv_direct.hip)
         int fused = 0;
         const int rc = ig_conv3x3_wgrad_direct(dy_hi, x_hi, dw, dbias, &fused, B, H, W, Cin, Cout, stream);
@@ -2121,6 +2128,13 @@ int ig_convT_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const
     IG_SPLIT_CONSISTENT(dy_lo, x_lo);
     // dbias (optional): dbias[co] += sum over the (2H, 2W) output pixels of dy -- fused into the direct kernel, otherwise one
     // column-sum pass over dy
+    {  // wide stages: the 8-phase weight-gradient engine with a gathering A operand (gemm8w.hip)
+        const int rc = ig_wgrad8_conv(1, dy_hi, dy_lo, x_hi, x_lo, dw, B, H, W, Cin, Cout, stream);
+        if (rc != IG_ERR_UNSUPPORTED) {
+            if (rc == IG_OK && dbias) return ig_colsum(dy_hi, dy_lo, dbias, 4L * B * H * W, Cout, stream);
+            return rc;
+        }
+    }
     if (!dy_lo) {  // last stage (96 -> 48): register-resident partial sums (conv_direct.hip)
         int fused = 0;
         const int rc = ig_convT_wgrad_direct(dy_hi, x_hi, dw, dbias, &fused, B, H, W, Cin, Cout, stream);

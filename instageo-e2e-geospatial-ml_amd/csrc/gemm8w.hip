@@ -1,24 +1,37 @@
-// v8w: the weight gradients of the timm Block linears (pritvhi.py:446-456: qkv / proj / fc1 / fc2; autograd's grad_weight of
-// F.linear) as ONE grouped launch on the 256 x 256 x 64 "8-phase" schedule of gemm8.hip.
+// v8w: weight gradients on the 256 x 256 x 64 "8-phase" schedule of gemm8.hip, as grouped launches with ordered split-K folds.
 //
-//   dW_g[n][k] += sum_m dy_g[m][n] * x_g[m][k]          g = 0 .. ng-1, all GEMMs of a group share the token count M
+//   mode 0  dW_g[n][k] += sum_m dy_g[m][n] * x_g[m][k]       the linears of a timm Block (pritvhi.py:446-456: qkv / proj / fc1 / fc2;
+//                                                            autograd's grad_weight of F.linear), g = 0 .. ng-1 share the token count
+//   mode 1  dWc[co][tap][ci] += sum_p dy[p][co] * x[p + shift(tap)][ci]        nn.Conv2d(k=3, padding=1)      (model.py:370-375)
+//   mode 2  dWc[co][tap][ci] += sum_p dy[up(p) + shift(tap)][co] * x[p][ci]    nn.ConvTranspose2d(k3,s2,p1,op1) (model.py:361-368)
 //
-// * The reduction runs over tokens, so BOTH operands are reduce-strided ("TR"): an operand half-tile in LDS is
+// * The reduction runs over tokens / pixels, so BOTH operands are reduce-strided ("TR"): an operand half-tile in LDS is
 //   [64 tokens][128 columns] (256-byte rows, 16 KiB), filled by LDS-DMA in full 256-byte source rows (two cache lines per
 //   token and half-tile), and the MFMA fragments come from ds_read_b64_tr_b16 (hardware transpose).  The bank swizzle is the
 //   chunk-pair key of gemm.hip's TR image (lds_trw<16>), applied on the DMA source chunk and on the fragment reads.
+// * Tile shapes: the kernel body is a template on MT (16-row blocks of dW per wave and half: 4 -> 256 rows, 3 -> 192) and NT1 (16-column
+//   blocks per wave in the second B half: 2 -> 256 columns, 1 -> 192).  The LDS image and the number of LDS-DMA instructions per wave and
+//   half-tile are the same for all of them (the lanes of the unused columns are masked), so the barrier / vmcnt protocol is shared.
+//   The linears use 256 x 256; the head's channel counts (multiples of 48 / 144) use 192-row tiles.
+// * Convolutions: the shifted operand is GATHERED by the LDS-DMA through a buffer descriptor (`buffer_load_dwordx4 ... offen lds`:
+//   border taps get an out-of-range offset and the hardware writes zeros, see conv8.hip): per lane a 32-bit byte offset = pixel row
+//   (kept incrementally per K-tile: p, y, x advance by 64 tokens) + the tap's displacement and the lane's channel chunk (per segment).
+//   mode 1 gathers x (the lane's tap follows from its output column), mode 2 gathers dy (one tap per tile).
 // * Work = (output tile, token range) SEGMENTS from a host-built table: the tiles of all GEMMs of the group form one list, so
 //   a group of four GEMMs (108 tiles at D = 768) runs with 2 token splits on 216 CUs where four separate launches needed
 //   7-28 splits each -- the split-K fold (slab stores + ordered reduce) shrinks from 4 x 32 MB to 54 MB per block and every
-//   workgroup runs a 160-K-tile main loop instead of 12-48.
+//   workgroup runs a 160-K-tile main loop instead of 12-48.  The table holds OFFSETS; the operand pointers travel as kernel
+//   arguments, so a plan depends on shapes only (bounded cache, no device allocation per pointer set).
 // * Deterministic: every segment stores its fp32 partial tile to its own slab in the accumulator's own (lane-linear) layout
 //   -- 16-byte coalesced stores, no LDS staging -- and wgrad8_reduce_kernel adds a tile's slabs in slab order.
-// * Same barrier / vmcnt protocol as gemm8_kernel (SCHED 2): two big phases of 32 MFMAs per K-tile, the two row groups one
+// * Same barrier / vmcnt protocol as gemm8_kernel (SCHED 2): two big phases per K-tile, the two row groups one
 //   barrier apart, counted vmcnt(8), a half-tile refilled the phase after its last read was retired.
 #include <stdlib.h>
 #include <string.h>
 
+#include <list>
 #include <map>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -29,27 +42,47 @@ constexpr int W_HALF = 16384;  // one half-tile: 64 tokens x 128 columns
 constexpr int W_BUF = 65536;   // A0 A1 B0 B1
 constexpr int W_SMEM = 131072;
 constexpr int W_MAXSEG = 6;    // segments per workgroup
+constexpr int W_MAXG = 4;      // GEMMs per group
+constexpr long W_SLAB = 65536;  // floats per slab slot (the 256 x 256 tile; smaller tiles use a prefix)
 typedef __attribute__((address_space(3))) char* lds_char_ptr;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 struct WSeg {  // one (workgroup, output tile, token range); 64 bytes
-    const char* a[2];  // dy hi / lo at (first token, tile row block): the columns of dy are the ROWS of dW
-    const char* b[2];  // x hi / lo at (first token, tile column block)
-    long slab;         // index of the segment's 256 x 256 fp32 partial tile in the slab workspace
-    int lda2, ldb2;    // row pitch of dy / x in bytes
-    int nkt;           // K-tiles (64 tokens) of this segment, even; 0 = end of this workgroup's list
-    int rows;          // valid tokens from the first one (< 64 nkt on the ragged tail: the rest reads the zero page)
-    long pad;
+    long aoff, boff;  // byte offset of the tile's column block in a row of dy / x; for a plain operand plus the first token's row
+    long slab;        // index of the segment's partial tile in the slab workspace
+    int lda2, ldb2;   // row pitch of dy / x in bytes
+    int nkt;          // K-tiles (64 tokens) of this segment, even; 0 = end of this workgroup's list
+    int rows;         // valid tokens from the first one (< 64 nkt on the ragged tail)
+    int tok0;         // first token (gathered operands decode their pixel from it)
+    short g, tap;     // GEMM of the group (pointer set); mode 2: tap of the tile
+    int jcol0;        // mode 1: first column of the tile in (tap, ci) space
+    int acols, bcols;  // valid columns of the tile's A / B block (multiples of 8): lanes beyond them are masked
+    int pad;
 };
 static_assert(sizeof(WSeg) == 64, "WSeg layout");
 
-struct WTile {  // reduce table
-    float* out;  // dW at the tile origin
-    long first;  // first slab of this tile (its slabs are consecutive, in token order)
+struct WTile {  // reduce table; 32 bytes
+    long out_off;  // element offset of the tile origin inside dW of GEMM g
+    long first;    // first slab of this tile (its slabs are consecutive, in token order)
     int ldo, nslab;
-    long pad;
+    short g, rows, cols, pad;  // valid rows / columns of the tile
 };
 static_assert(sizeof(WTile) == 32, "WTile layout");
+
+struct WArgs {  // operand pointers of the launch (the tables hold offsets)
+    const char* a[W_MAXG][2];  // dy hi / lo
+    const char* b[W_MAXG][2];  // x hi / lo
+};
+struct WConv {  // modes 1 / 2: geometry of the pixel grid the tokens run over
+    int M, H, W;            // tokens, grid of one image
+    int Cg;                 // channels of the gathered operand (mode 1: Cin of x; mode 2: Cout of dy)
+    unsigned g_bytes;       // bytes of the gathered tensor (buffer descriptor bound, < 2^31)
+    FDiv f_hw, f_w, f_c;    // division by H W, W, Cg
+};
+struct WDw {
+    float* dw[W_MAXG];
+};
 
 __device__ __forceinline__ void w_glds_s(unsigned voff, const void* sbase, unsigned lds_dst) {
     unsigned keep;
@@ -65,15 +98,40 @@ __device__ __forceinline__ void w_glds_v(const void* gsrc, unsigned lds_dst) {
                  : "v"(gsrc), "s"(lds_dst)
                  : "memory");
 }
+__device__ __forceinline__ void w_blds(unsigned voff, i32x4 rsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rsrc), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ i32x4 w_rsrc(const void* base, unsigned bytes) {
+    const uint64_t a = (uint64_t)base;
+    i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
+    r.y = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000;
+    return r;
+}
 
-struct WCur {  // issue cursor of one half-tile type (all wave-uniform)
+struct WCur {  // issue cursor of one operand (wave-uniform part)
     const char* base;
     int kt, rows, ld2, seg, pseg, left;
 };
+struct WRows {  // gathered operand: the two token rows this lane fetches per K-tile (rows krow, krow + 4 of the K-tile)
+    int p[2], y[2], x[2], b[2];
+};
 
-template <int NSEG>
+// MODE 0: plain x plain (linears), 1: B gathered (Conv2d 3x3), 2: A gathered (ConvTranspose).  MT: 16-row blocks per wave and A half
+// (4: 256-row tile, 3: 192); NT1: 16-column blocks per wave in the second B half (2: 256-column tile, 1: 192).
+template <int NSEG, int MODE, int MT, int NT1>
 __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__ segs, float* __restrict__ slabs,
-                                                        const bf16_t* __restrict__ zero_page) {
+                                                        const bf16_t* __restrict__ zero_page, WArgs args, WConv cv) {
+    constexpr int NTW = 2 + NT1;        // 16-column blocks per wave
+    constexpr int ACOLS = 2 * MT * 16;  // columns of an A half actually used (of the 128 in the image)
+    constexpr int B1COLS = NT1 * 64;    // columns of the second B half actually used
+    constexpr bool MASKED = MODE != 0 || MT != 4 || NT1 != 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -91,84 +149,185 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
     const int rkey = qq | ((g4 & 1) << 2);  // key of token rows 8 g4 + qq (+4, +32)
     const int rlow = ((pp >> 1) << 4) | ((pp & 1) << 3);
     const int k0off = (8 * g4 + qq) * 256;
-    // A: column wr*64 + mt*16 + 4pp of the half -> 16-byte chunk wr*8 + mt*2 + (pp>>1); chunk pair index (wr<<2 | mt) ^ key
-    const int aoff = k0off + ((((wr << 2) ^ rkey) << 5) | rlow);              // ^ (mt << 5)
-    // B: column wc*32 + nt*16 + 4pp -> chunk wc*4 + nt*2 + (pp>>1); chunk pair index (wc<<1 | nt) ^ key
-    const int boff = 2 * W_HALF + k0off + ((((wc << 1) ^ rkey) << 5) | rlow);  // ^ (nt << 5)
+    // A: column wr*MT*16 + mt*16 + 4pp of the half -> 16-byte chunk pair index (wr MT + mt) ^ key
+    // B: half 0: column wc*32 + nt*16 + 4pp -> pair (wc 2 + nt);  half 1: column wc*NT1*16 + nt*16 + 4pp -> pair (wc NT1 + nt)
+#define W_AOFF(mt_) (k0off + (((((wr * MT) + (mt_)) ^ rkey) << 5) | rlow))
+#define W_BOFF(nt_) (2 * W_HALF + ((nt_) < 2 ? 0 : W_HALF) + k0off + (((((nt_) < 2 ? wc * 2 + (nt_) : wc * NT1 + (nt_)-2) ^ rkey) << 5) | rlow))
     // ---- LDS-DMA lane constants: instruction i of this wave fills token rows wave*8 + i*4 + (lane >> 4) ----
     const int krow = wave * 8 + (lane >> 4);
     const int dkey = (lane >> 4) | ((wave & 1) << 2);
-    const int lch16 = ((lane & 15) ^ (dkey << 1)) << 4;  // logical source chunk of this lane's physical chunk
+    const int lch = (lane & 15) ^ (dkey << 1);  // logical source chunk (8 columns) of this lane's physical chunk
+    const int lch16 = lch << 4;
     const unsigned ldsw = lds_base + wave * 2048;
 
-    WCur cA0, cA1, cB0, cB1;
-#define W_REBASE(C, ISA)                                                                      \
-    {                                                                                         \
-        const WSeg* s_ = my + (C).seg;                                                        \
-        const int pa_ = NSEG == 1 ? 0 : ((C).pseg == 2 ? 1 : 0);                              \
-        const int pb_ = NSEG == 1 ? 0 : ((C).pseg == 1 ? 1 : 0);                              \
-        (C).base = (ISA) ? (pa_ ? s_->a[1] : s_->a[0]) : (pb_ ? s_->b[1] : s_->b[0]);         \
-        (C).ld2 = (ISA) ? s_->lda2 : s_->ldb2;                                                \
-        (C).kt = s_->nkt;                                                                     \
-        (C).rows = s_->rows;                                                                  \
+    WCur cA0, cA1, cB;  // the two B halves of a K-tile are always issued together: one cursor
+    WRows rA0, rA1, rB;  // MODE 2: rA0 / rA1; MODE 1: rB
+    // per-segment lane constants of the gathered operand
+    bool okA[2] = {true, true}, okB[2] = {true, true};  // this lane's column exists in half 0 / 1 of the tile
+    int shB[2] = {0, 0}, dyB[2] = {0, 0}, dxB[2] = {0, 0};  // MODE 1: byte displacement (tap shift + channel), tap displacement per B half
+    int shA[2] = {0, 0}, kyA[2] = {1, 1}, kxA[2] = {1, 1};  // MODE 2: byte displacement of the tile's tap, the tap (per A cursor = half)
+    int colA[2] = {0, 0};                                   // MODE 2: byte offset of this lane's column chunk in half 0 / 1
+    i32x4 rs_hi = {0, 0, 0, 0}, rs_lo = {0, 0, 0, 0};
+    if constexpr (MODE != 0) {  // one gathered tensor per launch (the group holds ONE convolution)
+        rs_hi = w_rsrc(MODE == 1 ? args.b[0][0] : args.a[0][0], cv.g_bytes);
+        rs_lo = w_rsrc(MODE == 1 ? args.b[0][1] : args.a[0][1], cv.g_bytes);
     }
-#define W_INIT(C, ISA)                                    \
-    {                                                     \
-        (C).seg = 0, (C).pseg = 0, (C).left = Gtot;       \
-        W_REBASE(C, ISA)                                  \
-    }
-    // the two wave-instructions of this wave for half-tile (ISA ? A : B, HG) of the cursor's K-tile into buffer BUF
-#define W_ISSUE(C, ISA, HG, BUF)                                                                                  \
-    if ((C).left > 0) {                                                                                           \
-        const unsigned dst_ = ldsw + (BUF)*W_BUF + ((ISA) ? 0 : 2 * W_HALF) + (HG)*W_HALF;                        \
-        if ((C).rows >= 64) {                                                                                     \
-            _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                    \
-                const unsigned voff_ = (unsigned)(__mul24(krow + i_ * 4, (C).ld2) + (HG)*256 + lch16);            \
-                w_glds_s(voff_, (C).base, dst_ + i_ * 1024);                                                      \
-            }                                                                                                     \
-        } else { /* ragged tail of the token range: rows past the end come from the zero page */                  \
-            _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                    \
-                const int r_ = krow + i_ * 4;                                                                     \
-                const char* p_ = r_ < (C).rows ? (C).base + (unsigned)(__mul24(r_, (C).ld2) + (HG)*256 + lch16)   \
-                                               : (const char*)zero_page + ((lane & 15) << 4);                     \
-                w_glds_v(p_, dst_ + i_ * 1024);                                                                   \
-            }                                                                                                     \
-        }                                                                                                         \
-        (C).left--;                                                                                               \
-        (C).base += (long)(C).ld2 << 6;                                                                           \
-        (C).rows -= 64;                                                                                           \
-        if (--(C).kt == 0) {                                                                                      \
-            if (NSEG == 1 || ++(C).pseg == NSEG) {                                                                \
-                (C).pseg = 0;                                                                                     \
-                (C).seg++;                                                                                        \
-            }                                                                                                     \
-            if ((C).left > 0) W_REBASE(C, ISA)                                                                    \
-        }                                                                                                         \
-    }
+    const int C2g = cv.Cg * 2;
 
-    f32x4 acc[2][2][2][4];  // [h][g][nt][mt]
+#define W_DECODE_ROWS(R, TOK0)                                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                       \
+        const int p_ = (TOK0) + krow + i_ * 4;                                               \
+        const int b_ = cv.f_hw.div(p_), rem_ = p_ - b_ * (cv.H * cv.W);                      \
+        (R).p[i_] = p_, (R).b[i_] = b_;                                                      \
+        (R).y[i_] = cv.f_w.div(rem_), (R).x[i_] = rem_ - (R).y[i_] * cv.W;                   \
+    }
+#define W_ADVANCE_ROWS(R)                                                                    \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                       \
+        (R).p[i_] += 64;                                                                     \
+        const int xs_ = (R).x[i_] + 64, q_ = cv.f_w.div(xs_);                                \
+        (R).x[i_] = xs_ - q_ * cv.W;                                                         \
+        int y_ = (R).y[i_] + q_;                                                             \
+        while (y_ >= cv.H) y_ -= cv.H, (R).b[i_]++;                                          \
+        (R).y[i_] = y_;                                                                      \
+    }
+    int psegA0 = 0, psegA1 = 0, psegB = 0;  // split-precision pass of each cursor's current segment: 0 hi*hi, 1 hi*lo, 2 lo*hi
+
+    auto rebaseA = [&](WCur& C, WRows& R, int hg, int& pseg) {
+        const WSeg* s_ = my + C.seg;
+        const int g_ = s_->g;
+        const int pa_ = NSEG == 1 ? 0 : (C.pseg == 2 ? 1 : 0);
+        C.ld2 = s_->lda2, C.kt = s_->nkt, C.rows = s_->rows;
+        pseg = pa_;
+        if constexpr (MODE == 2) {
+            C.base = nullptr;
+            W_DECODE_ROWS(R, s_->tok0)
+            const int tap = s_->tap;
+            kyA[hg] = (tap * 11) >> 5, kxA[hg] = tap - kyA[hg] * 3;
+            shA[hg] = ((kyA[hg] - 1) * 2 * cv.W + (kxA[hg] - 1)) * C2g;
+            colA[hg] = (int)s_->aoff + hg * (ACOLS * 2) + lch16;
+            okA[hg] = lch * 8 < ACOLS && hg * ACOLS + lch * 8 < s_->acols;
+        } else {
+            C.base = args.a[g_][pa_] + s_->aoff;
+            if constexpr (MASKED) okA[hg] = lch * 8 < ACOLS && hg * ACOLS + lch * 8 < s_->acols;
+        }
+    };
+    auto rebaseB = [&](WCur& C, WRows& R, int& pseg) {
+        const WSeg* s_ = my + C.seg;
+        const int g_ = s_->g;
+        const int pb_ = NSEG == 1 ? 0 : (C.pseg == 1 ? 1 : 0);
+        C.ld2 = s_->ldb2, C.kt = s_->nkt, C.rows = s_->rows;
+        pseg = pb_;
+        if constexpr (MODE == 1) {
+            C.base = nullptr;
+            W_DECODE_ROWS(R, s_->tok0)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int j = s_->jcol0 + g * 128 + lch * 8;  // column in (tap, ci) space
+                const int tap = cv.f_c.div(j), ci = j - tap * cv.Cg;
+                const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
+                dyB[g] = ky - 1, dxB[g] = kx - 1;
+                shB[g] = ((dyB[g] * cv.W + dxB[g]) * cv.Cg + ci) * 2;
+                okB[g] = lch * 8 < (g ? B1COLS : 128) && g * 128 + lch * 8 < s_->bcols && tap < 9;
+            }
+        } else {
+            C.base = args.b[g_][pb_] + s_->boff;
+            if constexpr (MASKED) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g) okB[g] = lch * 8 < (g ? B1COLS : 128) && g * 128 + lch * 8 < s_->bcols;
+            }
+        }
+    };
+    auto advance = [&](WCur& C) -> bool {  // one K-tile issued; true: the cursor moved to its next segment (rebase)
+        C.left--;
+        if (C.base) C.base += (long)C.ld2 << 6;
+        C.rows -= 64;
+        if (--C.kt == 0) {
+            if (NSEG == 1 || ++C.pseg == NSEG) C.pseg = 0, C.seg++;
+            return C.left > 0;
+        }
+        return false;
+    };
+    // plain operand: the two wave-instructions of this wave for one half-tile
+    auto issue_plain = [&](const WCur& C, unsigned dst, int colbyte, bool ok) {
+        // a masked lane (column outside the tile / the half) re-reads the first chunk of the tile's block: every wave must issue both
+        // instructions (the counted vmcnt waits rely on it), the address stays inside the tensor, the LDS columns it fills are never used
+        const int cb = (!MASKED || ok) ? colbyte + lch16 : 0;
+        if (C.rows >= 64) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) w_glds_s((unsigned)(__mul24(krow + i * 4, C.ld2) + cb), C.base, dst + i * 1024);
+        } else {  // ragged tail of the token range: rows past the end come from the zero page
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = krow + i * 4;
+                const char* p_ = r < C.rows ? C.base + (unsigned)(__mul24(r, C.ld2) + cb) : (const char*)zero_page + ((lane & 15) << 4);
+                w_glds_v(p_, dst + i * 1024);
+            }
+        }
+    };
+    // A half hg of the cursor's K-tile into buffer buf
+    auto issueA = [&](WCur& C, WRows& R, int hg, int buf, int& pseg) {
+        if (C.left <= 0) return;
+        const unsigned dst = ldsw + buf * W_BUF + hg * W_HALF;
+        if constexpr (MODE == 2) {
+            const i32x4 rs = (NSEG == 3 && pseg) ? rs_lo : rs_hi;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bool v = okA[hg] & (R.p[i] < cv.M) & ((R.y[i] > 0) | (kyA[hg] > 0)) & ((R.x[i] > 0) | (kxA[hg] > 0));
+                const int pix = (R.b[i] * 2 * cv.H + 2 * R.y[i]) * (2 * cv.W) + 2 * R.x[i];
+                const unsigned voff = v ? (unsigned)(pix * C2g + shA[hg] + colA[hg]) : 0x80000000u;
+                w_blds(voff, rs, dst + i * 1024);
+            }
+            W_ADVANCE_ROWS(R)
+        } else {
+            issue_plain(C, dst, hg * (ACOLS * 2), okA[hg]);
+        }
+        if (advance(C)) rebaseA(C, R, hg, pseg);
+    };
+    // both B halves of the cursor's K-tile into buffer buf
+    auto issueB = [&](WCur& C, WRows& R, int buf, int& pseg) {
+        if (C.left <= 0) return;
+        const unsigned dst = ldsw + buf * W_BUF + 2 * W_HALF;
+        if constexpr (MODE == 1) {
+            const i32x4 rs = (NSEG == 3 && pseg) ? rs_lo : rs_hi;
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const bool v = okB[g] & (R.p[i] < cv.M) & ((unsigned)(R.y[i] + dyB[g]) < (unsigned)cv.H) &
+                                   ((unsigned)(R.x[i] + dxB[g]) < (unsigned)cv.W);
+                    const unsigned voff = v ? (unsigned)(R.p[i] * C2g + shB[g]) : 0x80000000u;
+                    w_blds(voff, rs, dst + g * W_HALF + i * 1024);
+                }
+            W_ADVANCE_ROWS(R)
+        } else {
+            issue_plain(C, dst, 0, okB[0]);
+            issue_plain(C, dst + W_HALF, 256, okB[1]);
+        }
+        if (advance(C)) rebaseB(C, R, pseg);
+    };
+
+    f32x4 acc[2][NTW][MT];  // [h][nt][mt]
 #define W_ZERO_ACC()                                                                                             \
-    _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_)            \
-        _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_) _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_)  \
-            acc[h_][g_][nt_][mt_] = f32x4{0.f, 0.f, 0.f, 0.f};
+    _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) _Pragma("unroll") for (int nt_ = 0; nt_ < NTW; ++nt_)       \
+        _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_) acc[h_][nt_][mt_] = f32x4{0.f, 0.f, 0.f, 0.f};
     W_ZERO_ACC()
 
     // prologue: K-tile 0 complete + A0, B0, B1 of K-tile 1 (the state the steady-state schedule leaves behind)
-    W_INIT(cA0, true)
-    W_INIT(cA1, true)
-    W_INIT(cB0, false)
-    W_INIT(cB1, false)
-    W_ISSUE(cA0, true, 0, 0)
-    W_ISSUE(cB0, false, 0, 0)
-    W_ISSUE(cB1, false, 1, 0)
-    W_ISSUE(cA1, true, 1, 0)
-    W_ISSUE(cA0, true, 0, 1)
-    W_ISSUE(cB0, false, 0, 1)
-    W_ISSUE(cB1, false, 1, 1)
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    cA0.seg = cA1.seg = cB.seg = 0;
+    cA0.pseg = cA1.pseg = cB.pseg = 0;
+    cA0.left = cA1.left = cB.left = Gtot;
+    rebaseA(cA0, rA0, 0, psegA0);
+    rebaseA(cA1, rA1, 1, psegA1);
+    rebaseB(cB, rB, psegB);
+    issueA(cA0, rA0, 0, 0, psegA0);
+    issueB(cB, rB, 0, psegB);
+    issueA(cA1, rA1, 1, 0, psegA1);
+    issueA(cA0, rA0, 0, 1, psegA0);
+    issueB(cB, rB, 1, psegB);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
 
-    bf16x8_t af[4][2], bf0[2][2], bf1[2][2];
+    bf16x8_t af[MT][2], bfr[NTW][2];
 #define W_TR(DST, ADDR)                                                                                           \
     {                                                                                                             \
         const s16x4 v0_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(smem + (ADDR)));                \
@@ -178,20 +337,20 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
         DST = __builtin_bit_cast(bf16x8_t, r_);                                                                   \
     }
 #define W_READ_A(BUF, H)                                                                                          \
-    _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)          \
-        W_TR(af[mt_][s_], (BUF)*W_BUF + (H)*W_HALF + s_ * 8192 + (aoff ^ (mt_ << 5)))
-#define W_READ_B(BUF, G, DST)                                                                                     \
-    _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)          \
-        W_TR(DST[nt_][s_], (BUF)*W_BUF + (G)*W_HALF + s_ * 8192 + (boff ^ (nt_ << 5)))
-    // "big phase": 32 MFMAs (two quadrants) between one barrier pair; reads are retired BEFORE the first barrier
+    _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)          \
+        W_TR(af[mt_][s_], (BUF)*W_BUF + (H)*W_HALF + s_ * 8192 + W_AOFF(mt_))
+#define W_READ_B(BUF)                                                                                             \
+    _Pragma("unroll") for (int nt_ = 0; nt_ < NTW; ++nt_) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)        \
+        W_TR(bfr[nt_][s_], (BUF)*W_BUF + s_ * 8192 + W_BOFF(nt_))
+    // "big phase": all MFMAs of one A half between one barrier pair; reads are retired BEFORE the first barrier
 #define W_MFMA2(H)                                                                                                \
     {                                                                                                             \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
         asm volatile("s_barrier" ::: "memory");                                                                   \
         __builtin_amdgcn_s_setprio(1);                                                                            \
-        _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_) _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_)      \
-            _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)  \
-                acc[H][g_][nt_][mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g_ ? bf1[nt_][s_] : bf0[nt_][s_], af[mt_][s_], acc[H][g_][nt_][mt_], 0, 0, 0); \
+        _Pragma("unroll") for (int nt_ = 0; nt_ < NTW; ++nt_) _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_) \
+            _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                      \
+                acc[H][nt_][mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt_][s_], af[mt_][s_], acc[H][nt_][mt_], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                            \
         asm volatile("s_barrier" ::: "memory");                                                                   \
     }
@@ -211,28 +370,24 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
             if (wr == 1) asm volatile("s_barrier" ::: "memory");
             staggered = true;
         }
-        W_READ_B(0, 0, bf0)
-        W_READ_B(0, 1, bf1)
+        W_READ_B(0)
         W_READ_A(0, 0)
-        W_ISSUE(cA1, true, 1, 1)
+        issueA(cA1, rA1, 1, 1, psegA1);
         W_WAIT(8)
         W_MFMA2(0)
         W_READ_A(0, 1)
-        W_ISSUE(cA0, true, 0, 0)
-        W_ISSUE(cB0, false, 0, 0)
-        W_ISSUE(cB1, false, 1, 0)
+        issueA(cA0, rA0, 0, 0, psegA0);
+        issueB(cB, rB, 0, psegB);
         W_WAIT(2)
         W_MFMA2(1)
-        W_READ_B(1, 0, bf0)
-        W_READ_B(1, 1, bf1)
+        W_READ_B(1)
         W_READ_A(1, 0)
-        W_ISSUE(cA1, true, 1, 0)
+        issueA(cA1, rA1, 1, 0, psegA1);
         W_WAIT(0)
         W_MFMA2(0)
         W_READ_A(1, 1)
-        W_ISSUE(cA0, true, 0, 1)
-        W_ISSUE(cB0, false, 0, 1)
-        W_ISSUE(cB1, false, 1, 1)
+        issueA(cA0, rA0, 0, 1, psegA0);
+        issueB(cB, rB, 1, psegB);
         W_WAIT(0)
         W_MFMA2(1)
         if (++it_c < seg_iters) continue;
@@ -240,15 +395,13 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
         it_c = 0;
         if (wr == 0) asm volatile("s_barrier" ::: "memory");  // re-align the groups: both store bursts run concurrently
         staggered = false;
-        f32x4* sl = reinterpret_cast<f32x4*>(slabs + my[cseg].slab * 65536L) + tid;
+        f32x4* sl = reinterpret_cast<f32x4*>(slabs + my[cseg].slab * W_SLAB) + tid;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int g = 0; g < 2; ++g)
+            for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) sl[(((h * 2 + g) * 2 + nt) * 4 + mt) * 512] = acc[h][g][nt][mt];
+                for (int mt = 0; mt < MT; ++mt) sl[((h * NTW + nt) * MT + mt) * 512] = acc[h][nt][mt];
         W_ZERO_ACC()
         ++cseg;
         if (!last) seg_iters = (my[cseg].nkt * NSEG) >> 1;
@@ -259,27 +412,35 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
 #undef W_READ_A
 #undef W_READ_B
 #undef W_TR
-#undef W_ISSUE
-#undef W_INIT
-#undef W_REBASE
 #undef W_ZERO_ACC
+#undef W_AOFF
+#undef W_BOFF
+#undef W_DECODE_ROWS
+#undef W_ADVANCE_ROWS
 }
 
-// dW tile (+)= sum of its slabs, in slab (= token) order.  Slab element e = a * 512 + tid holds accumulator a = ((h*2+g)*2+nt)*4+mt
-// of thread tid: dW rows h*128 + wr*64 + mt*16 + (lane & 15), columns g*128 + wc*32 + nt*16 + 4 (lane >> 4) .. +3.
-__global__ __launch_bounds__(256) void wgrad8_reduce_kernel(const WTile* __restrict__ tiles, const float4* __restrict__ slabs, int overwrite) {
+// dW tile (+)= sum of its slabs, in slab (= token) order.  Slab element e = a * 512 + tid holds accumulator a = (h NTW + nt) MT + mt
+// of thread tid: dW rows h*2MT16 + wr*MT16 + mt*16 + (lane & 15), columns (nt < 2: wc*32 + nt*16 | 128 + wc*NT1*16 + (nt-2)*16) + 4 (lane >> 4) .. +3.
+template <int MT, int NT1>
+__global__ __launch_bounds__(256) void wgrad8_reduce_kernel(const WTile* __restrict__ tiles, const float4* __restrict__ slabs, WDw dws,
+                                                            int overwrite) {
+    constexpr int NTW = 2 + NT1, NA = 2 * NTW * MT;
     const WTile T = tiles[blockIdx.y];
-    const int e = blockIdx.x * 256 + threadIdx.x;  // 0 .. 16383
-    const float4* p = slabs + T.first * 16384L + e;
+    const int e = blockIdx.x * 256 + threadIdx.x;  // 0 .. NA * 512 - 1
+    if (e >= NA * 512) return;
+    const int a = e >> 9, tid = e & 511, wave = tid >> 6, lane = tid & 63;
+    const int h = a / (NTW * MT), nt = (a / MT) % NTW, mt = a % MT;
+    const int row = h * (2 * MT * 16) + (wave >> 2) * (MT * 16) + mt * 16 + (lane & 15);
+    const int col = (nt < 2 ? (wave & 3) * 32 + nt * 16 : 128 + (wave & 3) * (NT1 * 16) + (nt - 2) * 16) + 4 * (lane >> 4);
+    if (row >= T.rows || col >= T.cols) return;
+    const float4* p = slabs + T.first * (W_SLAB / 4) + e;
     float4 s = p[0];
     for (int k = 1; k < T.nslab; ++k) {
-        const float4 t = p[(long)k * 16384L];
+        const float4 t = p[(long)k * (W_SLAB / 4)];
         s.x += t.x, s.y += t.y, s.z += t.z, s.w += t.w;
     }
-    const int a = e >> 9, tid = e & 511, wave = tid >> 6, lane = tid & 63;
-    const int row = (a >> 4) * 128 + (wave >> 2) * 64 + (a & 3) * 16 + (lane & 15);
-    const int col = ((a >> 3) & 1) * 128 + (wave & 3) * 32 + ((a >> 2) & 1) * 16 + 4 * (lane >> 4);
-    float4* o = reinterpret_cast<float4*>(T.out + (long)row * T.ldo + col);
+    float* dw = T.g == 0 ? dws.dw[0] : T.g == 1 ? dws.dw[1] : T.g == 2 ? dws.dw[2] : dws.dw[3];
+    float4* o = reinterpret_cast<float4*>(dw + T.out_off + (long)row * T.ldo + col);
     if (!overwrite) {  // overwrite: dW = sum (a fresh step: the caller neither zeroed dW nor wants its old contents read)
         const float4 v = *o;
         s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
@@ -295,23 +456,29 @@ struct WPlan {
     long nslab = 0;
 };
 typedef std::vector<long> WKey;
-std::map<WKey, WPlan>& plan_cache() {
-    static std::map<WKey, WPlan> c;
+// Plans depend on shapes only (the tables hold offsets), so the cache is small: bounded, least-recently-used eviction, one lock.
+struct PlanCache {
+    std::mutex mu;
+    std::map<WKey, std::pair<WPlan, std::list<WKey>::iterator>> map;
+    std::list<WKey> lru;  // front = most recent
+    static constexpr size_t kMax = 96;
+};
+PlanCache& plan_cache() {
+    static PlanCache c;
     return c;
 }
 // slab workspace, per device: grown on demand; superseded buffers are kept (a captured graph may still hold their address) and
 // nothing is allocated while a stream capture is active (the first eager step has sized it by then)
-float* slab_workspace(long nslab, hipStream_t st) {
+float* slab_workspace(long nslab, bool capturing) {
     constexpr int kMaxDev = 16;
     static float* ws[kMaxDev] = {};
     static long cap[kMaxDev] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
     if (nslab > cap[dev]) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;
+        if (capturing) return nullptr;
         void* p = nullptr;
-        if (hipMalloc(&p, (size_t)nslab * 65536 * sizeof(float)) != hipSuccess) return nullptr;
+        if (hipMalloc(&p, (size_t)nslab * W_SLAB * sizeof(float)) != hipSuccess) return nullptr;
         ws[dev] = (float*)p, cap[dev] = nslab;
     }
     return ws[dev];
@@ -331,177 +498,298 @@ inline int wg8_env() {  // IG_WGRAD8: 0 = off (the BK = 32 ring engine of gemm.h
     const char* e = getenv("IG_WGRAD8");
     return e ? atoi(e) : 1;
 }
-
 inline int wg8_rem_env() {  // IG_WGRAD8_REM=0: uniform token splits only (A/B runs)
     const char* e = getenv("IG_WGRAD8_REM");
     return e ? atoi(e) : 1;
 }
 
+struct TileRef {  // one output tile of the launch
+    int g;         // GEMM (pointer set)
+    long aoff, boff;  // byte offset of its column block in a row of dy / x
+    int acols, bcols;
+    long out_off;
+    int ldo;
+    int tap, jcol0;
+};
+
+template <int NSEG, int MODE, int MT, int NT1>
+int w_launch(const WPlan& pl, float* ws, const bf16_t* zp, const WArgs& args, const WConv& cv, const WDw& dws, int overwrite, hipStream_t st) {
+    auto kern = gemm8w_kernel<NSEG, MODE, MT, NT1>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, W_SMEM) != hipSuccess) {
+            ig_set_error("gemm8w: could not reserve %d bytes of LDS", W_SMEM);
+            return IG_ERR_HIP;
+        }
+        attr_done = true;
+    }
+    ig_note_kernel("gemm8w_kernel<%d,%d,%d,%d>", NSEG, MODE, MT, NT1);
+    ig_note_grid(pl.nwg);
+    hipLaunchKernelGGL(kern, dim3(pl.nwg), dim3(512), W_SMEM, st, (const WSeg*)pl.segs, ws, zp, args, cv);
+    constexpr int NA = 2 * (2 + NT1) * MT;
+    hipLaunchKernelGGL((wgrad8_reduce_kernel<MT, NT1>), dim3(NA * 2, pl.ntiles), dim3(256), 0, st, (const WTile*)pl.tiles, (const float4*)ws, dws,
+                       overwrite);
+    return ig_check_launch("gemm8w");
+}
+
+// Plan (cached by `key`) + launch.  tiles: the output tiles of the launch; every tile reduces over the same M tokens.
+template <int MODE, int MT, int NT1>
+int w_run(const WKey& key, const std::vector<TileRef>& tl, int M, int lda2_of_g[W_MAXG], int ldb2_of_g[W_MAXG], bool split, const WArgs& args,
+          const WConv& cv, const WDw& dws, int overwrite, hipStream_t st, const char* what) {
+    const long ntiles = (long)tl.size();
+    int ncu = ig_cu_count() - ig_reserved_cus();
+    if (ncu < 8) ncu = 8;
+    if (ntiles > (long)ncu * W_MAXSEG || ntiles < 1) return IG_ERR_UNSUPPORTED;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+    PlanCache& cache = plan_cache();
+    WPlan pl;
+    {
+        std::lock_guard<std::mutex> lock(cache.mu);
+        auto it = cache.map.find(key);
+        if (it != cache.map.end()) {
+            cache.lru.splice(cache.lru.begin(), cache.lru, it->second.second);
+            pl = it->second.first;
+        } else {
+            if (capturing) return IG_ERR_UNSUPPORTED;  // a miss allocates and copies synchronously: not inside a stream capture
+            // ---- plan.  P = K-tile pairs (128 tokens) per tile, T tiles, C workgroups (one per CU).
+            // * uniform: every tile is cut into ks = C / T token ranges; the (split, tile) pairs are listed split-major and each XCD
+            //   (workgroup id % 8) takes a contiguous run, so the workgroups that share an L2 stream the SAME token range of
+            //   neighbouring tiles (tiles of one GEMM row share the dy column block).  108 tiles (one Block at D = 768): 216 of 256 CUs.
+            // * with remainder (IG_WGRAD8_REM, default on): the ks main ranges are shortened to c = ceil(T P / C) pairs -- the length
+            //   that balances all C workgroups -- and the last r = P - ks c pairs of every tile go to the R = C - T ks workgroups
+            //   left over, which walk the tiles' remainders in tile order (3-4 short segments each, again in step with one another).
+            //   Makespan 84 -> 71 pairs at T = 108; the price is one more slab per tile in the fold.
+            // * more tiles than CUs: ks = 1 and a workgroup walks several tiles.
+            const int P = (M + 127) >> 7;
+            const int T = (int)ntiles;
+            struct SegRef { int t, p0, np; };
+            std::vector<std::vector<SegRef>> wl;  // logical workgroups, in the order they are dealt to the XCDs
+            int ks = ncu / T;
+            if (ks < 1) ks = 1;
+            if (ks > P) ks = P;
+            bool rem = false;
+            int c = 0, r = 0, R = 0, q = 0;
+            if (T <= ncu && wg8_rem_env()) {
+                c = (int)(((long)T * P + ncu - 1) / ncu);
+                r = P - ks * c, R = ncu - T * ks;
+                if (r > 0 && R > 0) {
+                    q = (int)(((long)T * r + R - 1) / R);
+                    rem = (q + r - 1) / r + 1 <= W_MAXSEG;
+                }
+            }
+            if (rem) {
+                for (int sp = 0; sp < ks; ++sp)
+                    for (int t = 0; t < T; ++t) wl.push_back({SegRef{t, sp * c, c}});
+                for (int j = 0; j < R; ++j) {
+                    std::vector<SegRef> v;
+                    long u = (long)j * q, ue = u + q < (long)T * r ? u + q : (long)T * r;
+                    while (u < ue) {
+                        const int t = (int)(u / r), o = (int)(u - (long)t * r);
+                        const int np = (int)((r - o) < (ue - u) ? (r - o) : (ue - u));
+                        v.push_back(SegRef{t, ks * c + o, np});
+                        u += np;
+                    }
+                    if (!v.empty()) wl.push_back(v);
+                }
+            } else {
+                const int chunk = (P + ks - 1) / ks;
+                ks = (P + chunk - 1) / chunk;
+                const long Q = (long)T * ks;                    // (split, tile) pairs
+                const int per_wg = (int)((Q + ncu - 1) / ncu);  // 1 unless there are more tiles than CUs
+                if (per_wg > W_MAXSEG) return IG_ERR_UNSUPPORTED;
+                for (long q0 = 0; q0 < Q; q0 += per_wg) {
+                    std::vector<SegRef> v;
+                    for (long qi = q0; qi < q0 + per_wg && qi < Q; ++qi) {
+                        const int sp = (int)(qi / T), t = (int)(qi - (long)sp * T);
+                        v.push_back(SegRef{t, sp * chunk, (P - sp * chunk) < chunk ? (P - sp * chunk) : chunk});
+                    }
+                    wl.push_back(v);
+                }
+            }
+            const long nq = (long)wl.size();
+            const int nwg = 8 * (int)((nq + 7) / 8);
+            std::vector<WSeg> hs((size_t)nwg * W_MAXSEG);
+            memset(hs.data(), 0, hs.size() * sizeof(WSeg));
+            const int spt = ks + 2;  // slab slots per tile (a tile's remainder may be cut once by a workgroup boundary)
+            std::vector<int> tcount(T, 0);
+            const long qx = nq >> 3, rx = nq & 7;
+            for (int b = 0; b < nwg; ++b) {
+                const int xcd = b & 7, j = b >> 3;
+                const long lo = xcd * qx + (xcd < rx ? xcd : rx), cnt = qx + (xcd < rx ? 1 : 0);
+                if (j >= cnt) continue;
+                const std::vector<SegRef>& v = wl[lo + j];
+                for (size_t si = 0; si < v.size() && si < (size_t)W_MAXSEG; ++si) {
+                    const TileRef& tr = tl[v[si].t];
+                    const long tok0 = (long)v[si].p0 * 128;
+                    WSeg& d = hs[(size_t)b * W_MAXSEG + si];
+                    d.lda2 = lda2_of_g[tr.g], d.ldb2 = ldb2_of_g[tr.g];
+                    d.aoff = tr.aoff + (MODE == 2 ? 0 : tok0 * d.lda2);
+                    d.boff = tr.boff + (MODE == 1 ? 0 : tok0 * d.ldb2);
+                    d.slab = (long)v[si].t * spt + tcount[v[si].t]++;
+                    d.nkt = v[si].np * 2;
+                    const long left = (long)M - tok0;
+                    d.rows = (int)(left < (long)d.nkt * 64 ? left : (long)d.nkt * 64);
+                    d.tok0 = (int)tok0;
+                    d.g = (short)tr.g, d.tap = (short)tr.tap, d.jcol0 = tr.jcol0;
+                    d.acols = tr.acols, d.bcols = tr.bcols;
+                }
+            }
+            std::vector<WTile> ht(ntiles);
+            for (long t = 0; t < ntiles; ++t) {
+                const TileRef& tr = tl[t];
+                ht[t].out_off = tr.out_off;
+                ht[t].first = t * spt, ht[t].ldo = tr.ldo, ht[t].nslab = tcount[t];
+                ht[t].g = (short)tr.g, ht[t].rows = (short)tr.acols, ht[t].cols = (short)tr.bcols, ht[t].pad = 0;
+                if (tcount[t] > spt || tcount[t] < 1) {
+                    ig_set_error("%s: internal plan error (tile %ld has %d segments)", what, t, tcount[t]);
+                    return IG_ERR_ARG;
+                }
+            }
+            pl.nwg = nwg, pl.ntiles = (int)ntiles, pl.nslab = ntiles * spt;
+            if (hipMalloc((void**)&pl.segs, hs.size() * sizeof(WSeg)) != hipSuccess ||
+                hipMalloc((void**)&pl.tiles, ht.size() * sizeof(WTile)) != hipSuccess) {
+                ig_set_error("%s: could not allocate the segment tables", what);
+                return IG_ERR_HIP;
+            }
+            // synchronous copies from host vectors (first call of a shape only)
+            if (hipMemcpy(pl.segs, hs.data(), hs.size() * sizeof(WSeg), hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(pl.tiles, ht.data(), ht.size() * sizeof(WTile), hipMemcpyHostToDevice) != hipSuccess) {
+                ig_set_error("%s: could not upload the segment tables", what);
+                return IG_ERR_HIP;
+            }
+            if (cache.map.size() >= PlanCache::kMax) {  // evict the least recently used plan (its launches may still be queued: drain first)
+                (void)hipDeviceSynchronize();
+                const WKey old = cache.lru.back();
+                auto ot = cache.map.find(old);
+                (void)hipFree(ot->second.first.segs);
+                (void)hipFree(ot->second.first.tiles);
+                cache.map.erase(ot);
+                cache.lru.pop_back();
+            }
+            cache.lru.push_front(key);
+            cache.map.emplace(key, std::make_pair(pl, cache.lru.begin()));
+        }
+    }
+    float* ws = slab_workspace(pl.nslab, capturing);
+    const bf16_t* zp = w_zero_page();
+    if (!ws || !zp) {
+        if (capturing) return IG_ERR_UNSUPPORTED;
+        ig_set_error("%s: could not allocate the slab workspace (%ld slabs)", what, pl.nslab);
+        return IG_ERR_HIP;
+    }
+    if (split) return w_launch<3, MODE, MT, NT1>(pl, ws, zp, args, cv, dws, overwrite, st);
+    return w_launch<1, MODE, MT, NT1>(pl, ws, zp, args, cv, dws, overwrite, st);
+}
+
 }  // namespace
 
-// Grouped weight gradients.  IG_ERR_UNSUPPORTED (no error string) when a shape is not covered: the caller falls back to one
+// Grouped linear weight gradients.  IG_ERR_UNSUPPORTED (no error string) when a shape is not covered: the caller falls back to one
 // ig_linear_wgrad per GEMM.
 int ig_wgrad8_group(int n, const void* const* dy_hi, const void* const* dy_lo, const void* const* x_hi, const void* const* x_lo,
                     float* const* dw, const int* N, const int* K, int M, int overwrite, void* stream) {
-    if (!wg8_env() || n <= 0 || M <= 0) return IG_ERR_UNSUPPORTED;
+    if (!wg8_env() || n <= 0 || n > W_MAXG || M <= 0) return IG_ERR_UNSUPPORTED;
     const bool split = dy_lo && dy_lo[0];
-    long ntiles = 0;
+    WArgs args{};
+    WDw dws{};
+    int lda2[W_MAXG] = {}, ldb2[W_MAXG] = {};
+    std::vector<TileRef> tl;
     for (int g = 0; g < n; ++g) {
         if (N[g] <= 0 || K[g] <= 0 || (N[g] & 255) || (K[g] & 255)) return IG_ERR_UNSUPPORTED;
         if ((long)N[g] * 2 * 64 >= (1L << 24) || (long)K[g] * 2 * 64 >= (1L << 24)) return IG_ERR_UNSUPPORTED;  // 24-bit offset multiply
         if ((((uintptr_t)dy_hi[g]) | ((uintptr_t)x_hi[g]) | ((uintptr_t)dw[g])) & 15) return IG_ERR_UNSUPPORTED;
         if (split != ((dy_lo && dy_lo[g]) != 0) || split != ((x_lo && x_lo[g]) != 0)) return IG_ERR_UNSUPPORTED;
         if (split && ((((uintptr_t)dy_lo[g]) | ((uintptr_t)x_lo[g])) & 15)) return IG_ERR_UNSUPPORTED;
-        ntiles += (long)(N[g] >> 8) * (K[g] >> 8);
+        args.a[g][0] = (const char*)dy_hi[g], args.a[g][1] = split ? (const char*)dy_lo[g] : (const char*)dy_hi[g];
+        args.b[g][0] = (const char*)x_hi[g], args.b[g][1] = split ? (const char*)x_lo[g] : (const char*)x_hi[g];
+        dws.dw[g] = dw[g];
+        lda2[g] = N[g] * 2, ldb2[g] = K[g] * 2;
+        for (int tm = 0; tm < (N[g] >> 8); ++tm)
+            for (int tn = 0; tn < (K[g] >> 8); ++tn)
+                tl.push_back(TileRef{g, (long)tm * 512, (long)tn * 512, 256, 256, (long)tm * 256 * K[g] + (long)tn * 256, K[g], 0, 0});
     }
     int ncu = ig_cu_count() - ig_reserved_cus();
     if (ncu < 8) ncu = 8;
-    if (ntiles > (long)ncu * W_MAXSEG) return IG_ERR_UNSUPPORTED;
-    WKey key;
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
-    key.push_back(n), key.push_back(M), key.push_back(ncu), key.push_back(split), key.push_back(wg8_rem_env()), key.push_back(dev_);
-    for (int g = 0; g < n; ++g) {
-        key.push_back((long)(uintptr_t)dy_hi[g]), key.push_back((long)(uintptr_t)(split ? dy_lo[g] : nullptr));
-        key.push_back((long)(uintptr_t)x_hi[g]), key.push_back((long)(uintptr_t)(split ? x_lo[g] : nullptr));
-        key.push_back((long)(uintptr_t)dw[g]), key.push_back(N[g]), key.push_back(K[g]);
+    WKey key = {0, n, M, ncu, split, wg8_rem_env(), dev_};
+    for (int g = 0; g < n; ++g) key.push_back(N[g]), key.push_back(K[g]);
+    WConv cv{};
+    return w_run<0, 4, 2>(key, tl, M, lda2, ldb2, split, args, cv, dws, overwrite, (hipStream_t)stream, "ig_linear_wgrad_group");
+}
+
+// Weight gradient of the decode head's convolutions on the same engine.  kind 0: nn.Conv2d(k=3, padding=1): dy (B,H,W,Cout), x (B,H,W,Cin);
+// kind 1: nn.ConvTranspose2d(k3,s2,p1,op1): dy (B,2H,2W,Cout), x (B,H,W,Cin).  dWc[Cout][9][Cin] += ...  IG_ERR_UNSUPPORTED (no error
+// string) when the shape is not covered.
+int ig_wgrad8_conv(int kind, const void* dy_hi, const void* dy_lo, const void* x_hi, const void* x_lo, float* dw, int B, int H, int W,
+                   int Cin, int Cout, void* stream) {
+    const int env = wg8_env();
+    if (!env || B <= 0) return IG_ERR_UNSUPPORTED;
+    const char* ce = getenv("IG_WGRAD8_CONV");  // 0: off, 1: default, 2: every covered shape
+    const int cenv = ce ? atoi(ce) : 1;
+    if (!cenv) return IG_ERR_UNSUPPORTED;
+    if ((Cin % 8) || (Cout % 8)) return IG_ERR_UNSUPPORTED;
+    const bool split = dy_lo != nullptr;
+    if (split != (x_lo != nullptr)) return IG_ERR_UNSUPPORTED;
+    if ((((uintptr_t)dy_hi) | ((uintptr_t)x_hi) | ((uintptr_t)dw) | ((uintptr_t)dy_lo) | ((uintptr_t)x_lo)) & 15) return IG_ERR_UNSUPPORTED;
+    const long M = (long)B * H * W;
+    const double g_bytes = kind == 0 ? (double)M * Cin * 2.0 : (double)M * 4.0 * Cout * 2.0;
+    if (M >= (1L << 30) || g_bytes >= 2147483648.0) return IG_ERR_UNSUPPORTED;
+    if ((long)Cout * 2 * 64 >= (1L << 24) || (long)Cin * 2 * 64 >= (1L << 24)) return IG_ERR_UNSUPPORTED;
+    // tile shape: 192-row tiles (the channel counts are multiples of 48 / 144); 192 or 256 columns by the padding they leave
+    const int BMt = 192;
+    const int ncols = kind == 0 ? 9 * Cin : Cin;  // columns of one GEMM: (tap, ci) for the convolution, ci per tap for the transpose
+    auto waste = [&](int bn) { return (double)((ncols + bn - 1) / bn * bn) / ncols; };
+    const int BNt = waste(256) < waste(192) - 1e-9 ? 256 : 192;
+    const int tiles_m = (Cout + BMt - 1) / BMt, tiles_n = (ncols + BNt - 1) / BNt;
+    const double util = (double)Cout * ncols / ((double)tiles_m * BMt * tiles_n * BNt);
+    int ncu = ig_cu_count() - ig_reserved_cus();
+    if (ncu < 8) ncu = 8;
+    const long ntl = (long)tiles_m * tiles_n * (kind == 0 ? 1 : 9);
+    if (cenv != 2) {
+        // Measured per stage against the round-1 engines / the direct kernels (tools/head_bench.py, B = 216 at T = 1, B = 36 at T = 3): a
+        // 192-row tile carries 36 MFMAs per wave and K-tile against the 64 of the linears' 256 x 256 tile, with the same LDS-DMA and
+        // barrier cost per K-tile (440-700 TFLOP/s where the linears reach 1080), so it only pays where the old engines fit badly:
+        //   Conv2d:  576 -> 576 (992 vs 1199 us), 144 -> 144 (1288 vs 1542), 384 -> 384 (642 vs 652); not 192 (direct kernel: 576 vs 648),
+        //            288 (1310 vs 1084), 1152 (324 tiles on 256 CUs: 1536 vs 1171)
+        //   ConvTranspose: 1152 -> 576 (643 vs 696); the others within 2 %
+        if (M < 8192 || ntl > ncu) return IG_ERR_UNSUPPORTED;
+        const bool pays = kind == 0 ? ((util >= 0.95 && Cin >= 384) || Cout == 144) : (Cin >= 1024 && util >= 0.95);
+        if (!pays) return IG_ERR_UNSUPPORTED;
     }
+    WArgs args{};
+    WDw dws{};
+    args.a[0][0] = (const char*)dy_hi, args.a[0][1] = split ? (const char*)dy_lo : (const char*)dy_hi;
+    args.b[0][0] = (const char*)x_hi, args.b[0][1] = split ? (const char*)x_lo : (const char*)x_hi;
+    dws.dw[0] = dw;
+    int lda2[W_MAXG] = {Cout * 2, 0, 0, 0}, ldb2[W_MAXG] = {Cin * 2, 0, 0, 0};
+    std::vector<TileRef> tl;
+    const int ntap = kind == 0 ? 1 : 9;
+    for (int tap = 0; tap < ntap; ++tap)
+        for (int tm = 0; tm < tiles_m; ++tm)
+            for (int tn = 0; tn < tiles_n; ++tn) {
+                TileRef t{};
+                t.g = 0;
+                t.aoff = (long)tm * BMt * 2, t.boff = kind == 0 ? 0 : (long)tn * BNt * 2;
+                t.acols = Cout - tm * BMt < BMt ? Cout - tm * BMt : BMt;
+                t.bcols = ncols - tn * BNt < BNt ? ncols - tn * BNt : BNt;
+                t.ldo = 9 * Cin;
+                t.out_off = (long)tm * BMt * t.ldo + (kind == 0 ? 0 : (long)tap * Cin) + (long)tn * BNt;
+                t.tap = tap, t.jcol0 = tn * BNt;
+                tl.push_back(t);
+            }
+    WConv cv{};
+    cv.M = (int)M, cv.H = H, cv.W = W, cv.Cg = kind == 0 ? Cin : Cout;
+    cv.g_bytes = (unsigned)g_bytes;
+    cv.f_hw = make_fdiv(H * W), cv.f_w = make_fdiv(W), cv.f_c = make_fdiv(cv.Cg);
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    const WKey key = {1 + kind, (long)M, ncu, split, wg8_rem_env(), dev_, H, W, Cin, Cout, BNt};
     hipStream_t st = (hipStream_t)stream;
-    auto& cache = plan_cache();
-    auto it = cache.find(key);
-    if (it == cache.end()) {
-        // ---- plan.  P = K-tile pairs (128 tokens) per tile, T tiles, C workgroups (one per CU).
-        // * uniform: every tile is cut into ks = C / T token ranges; the (split, tile) pairs are listed split-major and each XCD
-        //   (workgroup id % 8) takes a contiguous run, so the workgroups that share an L2 stream the SAME token range of
-        //   neighbouring tiles (tiles of one GEMM row share the dy column block).  108 tiles (one Block at D = 768): 216 of 256 CUs.
-        // * with remainder (IG_WGRAD8_REM, default on): the ks main ranges are shortened to c = ceil(T P / C) pairs -- the length
-        //   that balances all C workgroups -- and the last r = P - ks c pairs of every tile go to the R = C - T ks workgroups
-        //   left over, which walk the tiles' remainders in tile order (3-4 short segments each, again in step with one another).
-        //   Makespan 84 -> 71 pairs at T = 108; the price is one more slab per tile in the fold.
-        // * more tiles than CUs: ks = 1 and a workgroup walks several tiles.
-        const int P = (M + 127) >> 7;
-        struct TileRef { int g, tm, tn; };
-        std::vector<TileRef> tl;
-        for (int g = 0; g < n; ++g)
-            for (int tm = 0; tm < (N[g] >> 8); ++tm)
-                for (int tn = 0; tn < (K[g] >> 8); ++tn) tl.push_back({g, tm, tn});
-        const int T = (int)ntiles;
-        struct SegRef { int t, p0, np; };
-        std::vector<std::vector<SegRef>> wl;  // logical workgroups, in the order they are dealt to the XCDs
-        int ks = ncu / T;
-        if (ks < 1) ks = 1;
-        if (ks > P) ks = P;
-        bool rem = false;
-        int c = 0, r = 0, R = 0, q = 0;
-        if (T <= ncu && wg8_rem_env()) {
-            c = (int)(((long)T * P + ncu - 1) / ncu);
-            r = P - ks * c, R = ncu - T * ks;
-            if (r > 0 && R > 0) {
-                q = (int)(((long)T * r + R - 1) / R);
-                rem = (q + r - 1) / r + 1 <= W_MAXSEG;
-            }
-        }
-        if (rem) {
-            for (int sp = 0; sp < ks; ++sp)
-                for (int t = 0; t < T; ++t) wl.push_back({SegRef{t, sp * c, c}});
-            for (int j = 0; j < R; ++j) {
-                std::vector<SegRef> v;
-                long u = (long)j * q, ue = u + q < (long)T * r ? u + q : (long)T * r;
-                while (u < ue) {
-                    const int t = (int)(u / r), o = (int)(u - (long)t * r);
-                    const int np = (int)((r - o) < (ue - u) ? (r - o) : (ue - u));
-                    v.push_back(SegRef{t, ks * c + o, np});
-                    u += np;
-                }
-                if (!v.empty()) wl.push_back(v);
-            }
-        } else {
-            const int chunk = (P + ks - 1) / ks;
-            ks = (P + chunk - 1) / chunk;
-            const long Q = (long)T * ks;                    // (split, tile) pairs
-            const int per_wg = (int)((Q + ncu - 1) / ncu);  // 1 unless there are more tiles than CUs
-            for (long q0 = 0; q0 < Q; q0 += per_wg) {
-                std::vector<SegRef> v;
-                for (long qi = q0; qi < q0 + per_wg && qi < Q; ++qi) {
-                    const int sp = (int)(qi / T), t = (int)(qi - (long)sp * T);
-                    v.push_back(SegRef{t, sp * chunk, (P - sp * chunk) < chunk ? (P - sp * chunk) : chunk});
-                }
-                wl.push_back(v);
-            }
-        }
-        const long nq = (long)wl.size();
-        const int nwg = 8 * (int)((nq + 7) / 8);
-        std::vector<WSeg> hs((size_t)nwg * W_MAXSEG);
-        memset(hs.data(), 0, hs.size() * sizeof(WSeg));
-        const int spt = ks + 2;  // slab slots per tile (a tile's remainder may be cut once by a workgroup boundary)
-        std::vector<std::vector<std::pair<int, long>>> tslabs(T);  // per tile: (first pair, slab) of its segments
-        std::vector<int> tcount(T, 0);
-        const long qx = nq >> 3, rx = nq & 7;
-        for (int b = 0; b < nwg; ++b) {
-            const int xcd = b & 7, j = b >> 3;
-            const long lo = xcd * qx + (xcd < rx ? xcd : rx), cnt = qx + (xcd < rx ? 1 : 0);
-            if (j >= cnt) continue;
-            const std::vector<SegRef>& v = wl[lo + j];
-            for (size_t si = 0; si < v.size() && si < (size_t)W_MAXSEG; ++si) {
-                const TileRef& tr = tl[v[si].t];
-                const long tok0 = (long)v[si].p0 * 128;
-                WSeg& d = hs[(size_t)b * W_MAXSEG + si];
-                const long ao = (tok0 * N[tr.g] + (long)tr.tm * 256) * 2, bo = (tok0 * K[tr.g] + (long)tr.tn * 256) * 2;
-                d.a[0] = (const char*)dy_hi[tr.g] + ao, d.a[1] = split ? (const char*)dy_lo[tr.g] + ao : d.a[0];
-                d.b[0] = (const char*)x_hi[tr.g] + bo, d.b[1] = split ? (const char*)x_lo[tr.g] + bo : d.b[0];
-                d.slab = (long)v[si].t * spt + tcount[v[si].t]++;
-                d.lda2 = N[tr.g] * 2, d.ldb2 = K[tr.g] * 2;
-                d.nkt = v[si].np * 2;
-                const long left = (long)M - tok0;
-                d.rows = (int)(left < (long)d.nkt * 64 ? left : (long)d.nkt * 64);
-            }
-        }
-        std::vector<WTile> ht(ntiles);
-        for (long t = 0; t < ntiles; ++t) {
-            const TileRef& tr = tl[t];
-            ht[t].out = dw[tr.g] + (long)tr.tm * 256 * K[tr.g] + (long)tr.tn * 256;
-            ht[t].first = t * spt, ht[t].ldo = K[tr.g], ht[t].nslab = tcount[t], ht[t].pad = 0;
-            if (tcount[t] > spt || tcount[t] < 1) {
-                ig_set_error("ig_linear_wgrad_group: internal plan error (tile %ld has %d segments)", t, tcount[t]);
-                return IG_ERR_ARG;
-            }
-        }
-        WPlan pl;
-        pl.nwg = nwg, pl.ntiles = (int)ntiles, pl.nslab = ntiles * spt;
-        if (hipMalloc((void**)&pl.segs, hs.size() * sizeof(WSeg)) != hipSuccess ||
-            hipMalloc((void**)&pl.tiles, ht.size() * sizeof(WTile)) != hipSuccess) {
-            ig_set_error("ig_linear_wgrad_group: could not allocate the segment tables");
-            return IG_ERR_HIP;
-        }
-        // synchronous copies from host vectors (first call of a configuration only)
-        if (hipMemcpy(pl.segs, hs.data(), hs.size() * sizeof(WSeg), hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(pl.tiles, ht.data(), ht.size() * sizeof(WTile), hipMemcpyHostToDevice) != hipSuccess) {
-            ig_set_error("ig_linear_wgrad_group: could not upload the segment tables");
-            return IG_ERR_HIP;
-        }
-        it = cache.emplace(key, pl).first;
+    if (kind == 0) {
+        if (BNt == 256) return w_run<1, 3, 2>(key, tl, (int)M, lda2, ldb2, split, args, cv, dws, 0, st, "ig_conv3x3_wgrad");
+        return w_run<1, 3, 1>(key, tl, (int)M, lda2, ldb2, split, args, cv, dws, 0, st, "ig_conv3x3_wgrad");
     }
-    const WPlan& pl = it->second;
-    float* ws = slab_workspace(pl.nslab, st);
-    const bf16_t* zp = w_zero_page();
-    if (!ws || !zp) {
-        ig_set_error("ig_linear_wgrad_group: could not allocate the slab workspace (%ld slabs)", pl.nslab);
-        return IG_ERR_HIP;
-    }
-    static bool attr_done[2] = {false, false};
-    auto k1 = gemm8w_kernel<1>;
-    auto k3 = gemm8w_kernel<3>;
-    if (!attr_done[split]) {
-        if (hipFuncSetAttribute(split ? (const void*)k3 : (const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, W_SMEM) != hipSuccess) {
-            ig_set_error("gemm8w: could not reserve %d bytes of LDS", W_SMEM);
-            return IG_ERR_HIP;
-        }
-        attr_done[split] = true;
-    }
-    ig_note_kernel("gemm8w_kernel<%d>", split ? 3 : 1);
-    ig_note_grid(pl.nwg);
-    if (split) hipLaunchKernelGGL(k3, dim3(pl.nwg), dim3(512), W_SMEM, st, (const WSeg*)pl.segs, ws, zp);
-    else hipLaunchKernelGGL(k1, dim3(pl.nwg), dim3(512), W_SMEM, st, (const WSeg*)pl.segs, ws, zp);
-    hipLaunchKernelGGL(wgrad8_reduce_kernel, dim3(64, pl.ntiles), dim3(256), 0, st, (const WTile*)pl.tiles, (const float4*)ws, overwrite);
-    return ig_check_launch("ig_linear_wgrad_group");
+    if (BNt == 256) return w_run<2, 3, 2>(key, tl, (int)M, lda2, ldb2, split, args, cv, dws, 0, st, "ig_convT_wgrad");
+    return w_run<2, 3, 1>(key, tl, (int)M, lda2, ldb2, split, args, cv, dws, 0, st, "ig_convT_wgrad");
 }

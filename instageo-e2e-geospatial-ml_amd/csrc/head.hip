@@ -270,7 +270,10 @@ __global__ __launch_bounds__(TPB) void classifier_bwd_kernel(const float* __rest
                     *reinterpret_cast<float4*>(dst) = make_float4(dwa[n][0], dwa[n][1], dwa[n][2], dwa[n][3]);
                     *reinterpret_cast<float4*>(dst + 4) = make_float4(dwa[n][4], dwa[n][5], dwa[n][6], dwa[n][7]);
                 }
-                if (u == 0) atomicAdd(sdbq + n, (unsigned long long)__float2ll_rn(dba[n] * 17592186044416.f));
+                if (u == 0) {  // non-finite / out-of-range partials bypass the fixed-point slot (ig_red_add keeps them visible)
+                    if (fabsf(dba[n]) < 5.0e5f) atomicAdd(sdbq + n, (unsigned long long)__float2ll_rn(dba[n] * 17592186044416.f));
+                    else ig_red_add(db + n, dba[n]);
+                }
             }
         }
     }
@@ -395,7 +398,10 @@ __global__ __launch_bounds__(TPB) void classifier_bwd_wide_kernel(const float* _
     if (live && blockIdx.y == 0 && u == 0) {
 #pragma unroll
         for (int n = 0; n < NC; ++n)
-            if (n < ncls) atomicAdd(sdbq + n, (unsigned long long)__float2ll_rn(dba[n] * 17592186044416.f));
+            if (n < ncls) {
+                if (fabsf(dba[n]) < 5.0e5f) atomicAdd(sdbq + n, (unsigned long long)__float2ll_rn(dba[n] * 17592186044416.f));
+                else ig_red_add(db + n, dba[n]);
+            }
     }
     __syncthreads();
     // fold the dW partials of the pixel slices, four classes per pass
@@ -530,14 +536,23 @@ __global__ __launch_bounds__(TPB) void ce_loss_kernel(const float* __restrict__ 
     if (stats && threadIdx.x == 0) {
         float l = 0.f, c = 0.f;
         for (int w = 0; w < TPB / 64; ++w) l += wred[w][0], c += wred[w][1];
-        const unsigned long long r0 = atomicAdd(acc, (unsigned long long)__double2ll_rn((double)l * 268435456.0));
+        // a NaN / Inf / absurdly large partial (diverged step) cannot go through the integer sum (NaN would convert to 0): it raises a
+        // poison word instead and the reported loss becomes NaN / +-Inf, as the reference's (Lightning logs the NaN loss)
+        unsigned* poison = reinterpret_cast<unsigned*>(acc + 3);
+        unsigned long long r0 = 0ull;
+        unsigned pz0 = 0u;
+        if (fabsf(l) < 3.0e7f) r0 = atomicAdd(acc, (unsigned long long)__double2ll_rn((double)l * 268435456.0));
+        else pz0 = atomicOr(poison, l != l ? 1u : (l > 0.f ? 2u : 4u));
         const unsigned long long r1 = atomicAdd(acc + 1, (unsigned long long)c);
-        asm volatile("" ::"v"(r0), "v"(r1));  // both adds have been performed before this workgroup counts itself in
+        asm volatile("" ::"v"(r0), "v"(r1), "v"(pz0));  // the adds have been performed before this workgroup counts itself in
         if (atomicAdd(arrived, 1u) == gridDim.x - 1) {
             const long long tl = (long long)atomicExch(acc, 0ull);
             const unsigned long long tc = atomicExch(acc + 1, 0ull);
+            const unsigned pz = atomicExch(poison, 0u);
             atomicExch(arrived, 0u);  // launches that share the scratch are ordered on one stream
-            stats[0] += (double)tl * (1.0 / 268435456.0), stats[1] += (double)tc;
+            double tot = (double)tl * (1.0 / 268435456.0);
+            if (pz) tot = ((pz & 1u) || (pz & 6u) == 6u) ? __longlong_as_double(0x7ff8000000000000LL) : ((pz & 2u) ? 1.0 : -1.0) * __longlong_as_double(0x7ff0000000000000LL);
+            stats[0] += tot, stats[1] += (double)tc;
         }
     }
     if (confusion)

@@ -185,6 +185,10 @@ class ShardedGradSync:
         self._tail_handle = None
         self._frozen = False
         self.launched: List[Tuple[int, int]] = []
+        self.master_complete = True      # False after a step that published only the bf16 operand copy (see step / gather_master)
+        self._small = None               # index tables of the fp32-read parameters (see _sync_small)
+        self.time_exposed = False        # bench.py diagnostics: events around every wait of the step
+        self._exposed: List = []
 
     # ---- during backward -------------------------------------------------------------------------------------------
     def ready(self, lo: int, hi: int) -> None:
@@ -284,37 +288,162 @@ class ShardedGradSync:
         return _All()
 
     # ---- after backward --------------------------------------------------------------------------------------------
-    def step(self, adam: Callable[[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, int], None]) -> None:
-        """Finish the exchange, run ``adam`` on the owned slices (and the replicated tail), all-gather the parameters."""
+    def _timed_wait(self, handle, kind: str) -> None:
+        """``handle.wait()``; in the instrumented step also the time the compute stream stands still in it (two events around
+        the wait on the current stream: nothing else is enqueued between them, so their distance IS the exposed communication)."""
+        if self.time_exposed and torch.cuda.is_available():
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            handle.wait()
+            b.record()
+            self._exposed.append((kind, a, b))
+        else:
+            handle.wait()
+
+    def exposed_ms(self) -> dict:
+        """{"rs": ms, "ag": ms, "tail": ms}: exposed (un-overlapped) communication of the steps run with ``time_exposed`` set;
+        clears the record.  Synchronises the device."""
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        out = {"rs": 0.0, "ag": 0.0, "tail": 0.0}
+        for kind, a, b in self._exposed:
+            out[kind] += a.elapsed_time(b)
+        self._exposed = []
+        return out
+
+    def step(self, adam: Callable[[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, int], None],
+             gather: Optional[Sequence[torch.Tensor]] = None, small_ranges: Optional[Sequence[Tuple[int, int]]] = None) -> None:
+        """Finish the exchange, run ``adam`` on the owned slices (and the replicated tail), publish the result.
+
+        ``gather`` None: the updated fp32 parameters are all-gathered (4 bytes per parameter).  ``gather`` = flat tensors indexed
+        like the parameter buffer (the bf16 operand copy: hi, and lo in the split-precision mode) -- what the other ranks compute
+        with -- : THOSE are all-gathered instead (2 bytes per parameter; ``adam`` has written this rank's slice of them), the fp32
+        masters stay sharded (:meth:`gather_master` completes them, e.g. before a checkpoint), and the parameters the kernels read
+        in fp32 (``small_ranges``: biases, norm affine, classifier -- a few hundred KB) are exchanged by ONE small all-reduce in which
+        every rank contributes the elements it owns."""
         self._flush(final=True)
         flat = self.get_flat()
-        gathers = []
-        for i, (blo, bhi) in enumerate(self._step_buckets):
-            self._handles[i].wait()
-            n = (bhi - blo) // self.world
-            s0 = blo + self.rank * n
-            adam(flat[s0 : s0 + n], self._own[i], self._m[i], self._v[i], s0)
-            send = flat[s0 : s0 + n].clone()  # (not the in-place form: output and input of the gather do not alias)
-            gathers.append(self._all_gather(flat[blo:bhi], send))
-        if self._tail_handle is not None:
-            self._tail_handle.wait()
-            tlo, thi = self.tail
-            adam(flat[tlo:thi], self.get_grad()[tlo:thi], self.m_tail, self.v_tail, tlo)
-            self._tail_handle = None
-        for h in gathers:
-            h.wait()
+        # every step: the bucket sequence must be the planned one BEFORE anything is updated (a missing ready() range would leave
+        # some parameters without their update while the others step)
+        if self._frozen and len(self._step_buckets) != len(self.plan):
+            raise RuntimeError(f"ShardedGradSync: {len(self._step_buckets)} of {len(self.plan)} planned buckets were reported this step")
         if not self._frozen:
             covered = sum(b - a for a, b, _ in self.plan) + (0 if self.tail is None else self.tail[1] - self.tail[0])
             if covered != self.hi - self.lo:
                 raise RuntimeError(f"ShardedGradSync: buckets cover {covered} of {self.hi - self.lo} gradient elements "
                                    "(every trainable range must be reported through ready())")
-            self._frozen = True
+        gathers = []
+        for i, (blo, bhi) in enumerate(self._step_buckets):
+            self._timed_wait(self._handles[i], "rs")
+            n = (bhi - blo) // self.world
+            s0 = blo + self.rank * n
+            adam(flat[s0 : s0 + n], self._own[i], self._m[i], self._v[i], s0)
+            for t in ([flat] if gather is None else gather):
+                send = t[s0 : s0 + n].clone()  # (not the in-place form: output and input of the gather do not alias)
+                gathers.append(self._all_gather(t[blo:bhi], send))
+        if self._tail_handle is not None:
+            self._timed_wait(self._tail_handle, "tail")
+            tlo, thi = self.tail
+            adam(flat[tlo:thi], self.get_grad()[tlo:thi], self.m_tail, self.v_tail, tlo)
+            self._tail_handle = None
+        if gather is not None and small_ranges:
+            self._sync_small(flat, small_ranges)
+        for h in gathers:
+            self._timed_wait(h, "ag")
+        self._frozen = True
+        self.master_complete = gather is None
         self._handles.clear()
         self._step_buckets.clear()
+
+    def _sync_small(self, flat: torch.Tensor, small_ranges: Sequence[Tuple[int, int]]) -> None:
+        """fp32 parameters inside the sharded buckets that the kernels read directly: every rank fills a compact buffer with the
+        elements it owns (zeros elsewhere), one all-reduce (SUM) completes it, the result goes back into the flat buffer."""
+        if self._small is None:
+            idx_all, pos_own, idx_own, at = [], [], [], 0
+            owned = [(blo + self.rank * ((bhi - blo) // self.world), blo + (self.rank + 1) * ((bhi - blo) // self.world)) for blo, bhi, _ in self.plan]
+            for lo, hi in small_ranges:
+                for blo, bhi, _ in self.plan:  # the part of the range inside sharded buckets (the replicated tail needs nothing)
+                    a, b = max(lo, blo), min(hi, bhi)
+                    if b <= a:
+                        continue
+                    idx_all.append(torch.arange(a, b))
+                    for olo, ohi in owned:
+                        c, d = max(a, olo), min(b, ohi)
+                        if d > c:
+                            idx_own.append(torch.arange(c, d))
+                            pos_own.append(torch.arange(at + c - a, at + d - a))
+                    at += b - a
+            dev = flat.device
+            cat = lambda xs: (torch.cat(xs) if xs else torch.zeros(0, dtype=torch.int64)).to(dev)  # noqa: E731
+            self._small = (cat(idx_all), cat(idx_own), cat(pos_own), torch.zeros(at, dtype=torch.float32, device=dev))
+        idx_all, idx_own, pos_own, buf = self._small
+        if buf.numel() == 0:
+            return
+        buf.zero_()
+        buf[pos_own] = flat[idx_own]
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        flat[idx_all] = buf
+
+    def gather_master(self) -> None:
+        """Complete the fp32 master parameters on every rank (after steps that published only the bf16 operand copy): one fp32
+        all-gather per bucket.  Collective -- every rank calls it (e.g. at epoch end, before rank 0 writes a checkpoint)."""
+        if self.world == 1 or self.master_complete or not self.plan:
+            return
+        flat = self.get_flat()
+        hs = []
+        for blo, bhi, _ in self.plan:
+            n = (bhi - blo) // self.world
+            s0 = blo + self.rank * n
+            hs.append(self._all_gather(flat[blo:bhi], flat[s0 : s0 + n].clone()))
+        for h in hs:
+            h.wait()
+        self.master_complete = True
 
     def optimizer_elements(self) -> int:
         """fp32 elements of moment state held by this rank (about 1/world of the replicated optimizer's)."""
         return sum(t.numel() for t in self._m) + (0 if self.m_tail is None else self.m_tail.numel())
+
+    # ---- checkpoint / resume of the sharded moments ----------------------------------------------------------------
+    def state_dict(self) -> dict:
+        """This rank's optimizer state: the bucket plan and the AdamW moments of the owned slices (+ the replicated tail)."""
+        return {"world": self.world, "rank": self.rank, "plan": list(self.plan), "tail": self.tail,
+                "m": [t.detach().cpu().clone() for t in self._m], "v": [t.detach().cpu().clone() for t in self._v],
+                "m_tail": None if self.m_tail is None else self.m_tail.detach().cpu().clone(),
+                "v_tail": None if self.v_tail is None else self.v_tail.detach().cpu().clone()}
+
+    def load_state_dict(self, sd: dict) -> None:
+        """Restore :meth:`state_dict` of the SAME rank / world size / bucket plan (a plan exists after the first step; before it,
+        the saved plan is adopted and checked against the buckets as they arrive)."""
+        if sd["world"] != self.world or sd["rank"] != self.rank:
+            raise RuntimeError(f"ShardedGradSync: state of rank {sd['rank']}/{sd['world']} loaded into rank {self.rank}/{self.world}")
+        if self._frozen and [tuple(p) for p in sd["plan"]] != [tuple(p) for p in self.plan]:
+            raise RuntimeError("ShardedGradSync: the saved bucket plan differs from the current one")
+        dev = self.get_flat().device
+        self.plan = [tuple(p) for p in sd["plan"]]
+        self.tail = None if sd["tail"] is None else tuple(sd["tail"])
+        self._m = [t.to(dev).clone() for t in sd["m"]]
+        self._v = [t.to(dev).clone() for t in sd["v"]]
+        self._own = [torch.zeros_like(t) for t in self._m]
+        self.m_tail = None if sd["m_tail"] is None else sd["m_tail"].to(dev).clone()
+        self.v_tail = None if sd["v_tail"] is None else sd["v_tail"].to(dev).clone()
+        self._frozen = True
+
+    def full_moments(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(m, v) over the whole optimizer range [lo, hi) on EVERY rank (collective: one all-gather per bucket and moment) -- the
+        layout of the replicated optimizer, for a world-size independent checkpoint."""
+        dev = self.get_flat().device
+        m = torch.zeros(self.hi - self.lo, dtype=torch.float32, device=dev)
+        v = torch.zeros_like(m)
+        for i, (blo, bhi, _) in enumerate(self.plan):
+            for full, part in ((m, self._m[i]), (v, self._v[i])):
+                if self.world > 1:
+                    self._all_gather(full[blo - self.lo : bhi - self.lo], part.clone()).wait()
+                else:
+                    full[blo - self.lo : bhi - self.lo] = part
+        if self.tail is not None:
+            m[self.tail[0] - self.lo : self.tail[1] - self.lo] = self.m_tail
+            v[self.tail[0] - self.lo : self.tail[1] - self.lo] = self.v_tail
+        return m, v
 
 
 def attach_data_parallel(module, bucket_bytes: int = 32 << 20):
@@ -342,6 +471,7 @@ def attach_data_parallel(module, bucket_bytes: int = 32 << 20):
         sync = ShardedGradSync(lambda: net.store.ensure_grad(), lambda: net.store.flat, opt.lo, opt.hi, bucket_bytes)
         opt.attach_sharded(sync)
         net.engine.on_grad_ready = sync.ready
+        net.engine.master_sync = sync.gather_master
         module.grad_sync = None  # the exchange is finished inside the optimizer step
         return sync
     sync = GradSync(lambda: net.store.ensure_grad(), bucket_bytes, scale_in_optimizer=True)

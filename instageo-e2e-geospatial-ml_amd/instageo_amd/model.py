@@ -331,6 +331,7 @@ class SegEngine:
         self._drop_step: Optional[torch.Tensor] = None  # device uint32 counter mixed into the dropout hash each step
         self.freeze_backbone = False
         self.on_grad_ready: Optional[Callable[[int, int], None]] = None
+        self.master_sync: Optional[Callable[[], None]] = None  # distributed.ShardedGradSync.gather_master when the fp32 masters are sharded
         # run-to-run bit-identical training (the reference's Trainer runs with deterministic=True, pipeline_utils.py:373): the
         # multi-contributor reductions go through the fixed-point shadow of the gradient buffer (ops.set_deterministic).  On by
         # default (0.15-0.2 ms per step); IG_DETERMINISTIC=0 or ``engine.deterministic = False`` selects the float atomics.
@@ -356,6 +357,8 @@ class SegEngine:
 
     def _prepare_shadow(self) -> None:
         if self.shadow_dirty or self.store.shadow is None or self.store.shadow_split != self.split:
+            if self.master_sync is not None:  # data parallel with sharded fp32 masters: complete them before they are read (collective)
+                self.master_sync()
             self.store.refresh_shadow(self.split)
             self.shadow_dirty = False
             self.shadow_t_dirty = True
@@ -664,8 +667,16 @@ class SegEngine:
                     (ws["dqkv"], ws["a"][i], self.Gd(b + "attn.qkv.weight"), 3 * D, D),
                 ], M)  # prepared once per (workspace, block): pointers of the workspace and of the flat gradient buffer
             grp.launch(overwrite=fresh)
-            if i not in ws["wgrad8"]:  # did the grouped 8-phase kernel take it (ordered fold straight into dW), or the per-GEMM engines?
-                ws["wgrad8"][i] = ops.last_kernel().startswith("gemm8w_kernel")
+            # Did the grouped 8-phase kernel take it (ordered fold straight into dW), or the per-GEMM engines (whose split-K adds go
+            # through the fixed-point shadow)?  The library decides on EVERY call (IG_WGRAD8, reserved CUs, a stream capture meeting an
+            # unplanned shape ...), so the answer is read back every time: a change re-plans this block's fold and the zeroing table.
+            took8 = ops.last_kernel().startswith("gemm8w_kernel")
+            if ws["wgrad8"].get(i) is not took8:
+                ws["wgrad8"][i] = took8
+                ws["det_folds"].pop(i, None)
+                for k in [k for k in ws["det_folds"] if isinstance(k, tuple)]:
+                    del ws["det_folds"][k]
+                ws.pop("zero_small", None)
             if self.deterministic and i not in ws["det_folds"]:
                 # the grouped kernel never writes through the shadow: the fold then only visits the small vectors between the four
                 # weight matrices (the whole block otherwise)

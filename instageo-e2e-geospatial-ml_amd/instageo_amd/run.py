@@ -163,6 +163,7 @@ def train(cfg: Dict[str, Any], model, out_dir: str, rank: int, world: int) -> Di
             sched.step()
         model.log("learning_rate", opt.param_groups[0]["lr"])
         history = {k: (float(v) if not isinstance(v, (list, tuple)) else v) for k, v in model.logged.items()}
+        model.sync_master_params()  # data parallel: the fp32 masters are sharded between checkpoints (collective, every rank)
         if rank == 0:
             print(json.dumps({"epoch": epoch, **{k: round(v, 6) for k, v in history.items() if isinstance(v, float)}}))
             # ModelCheckpoint(monitor = "val_RMSE" (min) for regression else "val_IoU" (max), save_top_k=1)  (run.py:163-164)

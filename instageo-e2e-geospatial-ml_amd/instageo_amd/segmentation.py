@@ -58,6 +58,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self.v = torch.zeros_like(self.m)
         self.hyper = torch.zeros(16, dtype=torch.float32, device=dev)
         self.sharded = None  # distributed.ShardedGradSync when the optimizer state is sharded over the data-parallel ranks
+        self._small_ranges = None  # flat ranges of the parameters the kernels read in fp32 (biases, norm affine, classifier ...)
         self._host_step = 0
         self._write_hyper()
 
@@ -106,14 +107,23 @@ class FusedAdamW(torch.optim.Optimizer):
         sh = store.shadow
         if self.sharded is not None:
             # data parallel, "zero1": the gradient buckets were reduce-scattered during backward; AdamW runs on this rank's slice
-            # of every bucket (moments live in the ShardedGradSync), the updated fp32 parameters are all-gathered, and the bf16
-            # operand copy of the slices other ranks updated is refreshed by one streaming pass
+            # of every bucket (moments live in the ShardedGradSync) and writes the fp32 masters AND the bf16 operand copy of the
+            # slice.  IG_DP_GATHER=shadow (default): the other ranks only compute with the bf16 copy, so THAT is all-gathered
+            # (2 bytes per parameter on the wire instead of 4, and no refresh pass over the slices other ranks updated); the fp32
+            # masters stay sharded until gather_master() (checkpoints), the fp32-read vectors travel in one small all-reduce.
+            # IG_DP_GATHER=fp32: all-gather the fp32 parameters and refresh the whole operand copy (round 3).
             def adam(param, grad, m, v, index0):
                 shw = ops.BT(sh.hi[index0 : index0 + param.numel()], None if sh.lo is None else sh.lo[index0 : index0 + param.numel()])
                 ops.adamw_step(param, grad, m, v, shw, self.hyper, param.numel())
 
-            self.sharded.step(adam)
-            store.refresh_shadow(eng.split)
+            if os.environ.get("IG_DP_GATHER", "shadow") == "fp32":
+                self.sharded.step(adam)
+                store.refresh_shadow(eng.split)
+            else:
+                if self._small_ranges is None:
+                    self._small_ranges = [(e.offset, e.offset + e.numel) for e in store.entries.values()
+                                          if e.numel <= 65536 and e.offset + e.numel > self.lo and e.offset < self.hi]
+                self.sharded.step(adam, gather=[sh.hi] + ([] if sh.lo is None else [sh.lo]), small_ranges=self._small_ranges)
             eng.shadow_dirty = False
             eng.shadow_t_dirty = True
             return loss
@@ -464,6 +474,14 @@ class PrithviSegmentationModule(_Base):
         return ops.softmax_prob(logits, 1)
 
     # ---- checkpoints (pipeline_utils.py:347-355, factory.py:113-115) ----------------------------
+    def sync_master_params(self) -> None:
+        """Data parallel (``zero1``): complete the fp32 master parameters on every rank -- between checkpoints only the bf16 operand
+        copy is exchanged (``distributed.ShardedGradSync.gather_master``).  Collective: every rank calls it; a no-op otherwise."""
+        opt = getattr(self, "_optimizer", None)
+        sync = getattr(opt, "sharded", None) if opt is not None else None
+        if sync is not None:
+            sync.gather_master()
+
     def checkpoint_state_dict(self) -> Dict[str, torch.Tensor]:
         """``{"net.<...>": tensor, "criterion.weight": tensor}`` -- the reference's Lightning key layout."""
         sd = {"net." + k: v.detach().clone().contiguous().cpu() for k, v in self.net.state_dict().items()}

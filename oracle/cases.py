@@ -18,7 +18,10 @@ CASES = {
     "v2_300_t1_c2": ("prithvi_eo_v2_300", 1, 2, 1, -1),  # BASELINE.json configs[4] architecture (D=1024, L=24, 16 heads)
     # the 600M shape family at depth 2 (model.py:154-177): D = 1280, 16 heads of 80, patch 14 (257 tokens), head kernels [5, 5, 5, 7]
     "v2_600_t1_c2": ("prithvi_eo_v2_600", 1, 2, 1, 2),
+    # ... and at FULL depth (32 blocks, 630M parameters): eval logits only (an fp64 backward of it does not fit the build container)
+    "v2_600_full_t1_c2": ("prithvi_eo_v2_600", 1, 2, 1, -1),
 }
+EVAL_ONLY = {"v2_600_full_t1_c2"}  # cases whose fixture holds the eval forward only
 
 # instageo/model/configs/multitemporal_crop_classification.yaml:15-30
 CROP_WEIGHTS = [0.386375, 0.661126, 0.548184, 0.640482, 0.876862, 0.925186, 3.249462,

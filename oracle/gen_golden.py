@@ -107,7 +107,7 @@ def install_shims() -> None:
     sys.path.insert(0, REF)
 
 
-from oracle.cases import CASES, GRAD_KEYS, class_weights_for, make_inputs, sub  # noqa: E402
+from oracle.cases import CASES, EVAL_ONLY, GRAD_KEYS, class_weights_for, make_inputs, sub  # noqa: E402
 
 
 def main() -> None:
@@ -188,7 +188,7 @@ def main() -> None:
         # fp32 autograd noise on these gradients is ~3e-3 relative (train-mode BN backward
         # cancellations), so the restatement is pinned in fp64 (agreement ~1e-15) and the
         # fixture stores the fp64 gradients plus the fp32 run's own distance from them.
-        if True:  # every case, the 300M one included (fp64 backward of 300M parameters at B = 1: a few minutes, ~10 GB)
+        if name not in EVAL_ONLY:  # the 300M one included (fp64 backward of 300M parameters at B = 1: a few minutes, ~10 GB)
             cw = class_weights_for(ncls)
 
             def ref_train(dt):

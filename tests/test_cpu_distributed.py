@@ -269,6 +269,96 @@ def test_sharded_optimizer_equals_the_one_rank_step(world):
         assert sum(b - a for a, b, _ in plan) + tail[1] - tail[0] == n - lo
 
 
+def _shadow_worker(rank: int, world: int, port: int, q, n: int) -> None:
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "instageo-e2e-geospatial-ml_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from instageo_amd import distributed as D
+
+    D.init_from_env(backend="gloo")
+    try:
+        lo = 40
+        flat = torch.linspace(-1, 1, n)
+        shadow = flat.to(torch.bfloat16)  # the operand copy the other ranks compute with
+        grad = torch.zeros(n)
+        small = [(100, 164), (7000, 7003), (n - 5001, n - 4990), (n - 30, n)]  # "biases": read in fp32 on every rank
+        sync = D.ShardedGradSync(lambda: grad, lambda: flat, lo, n, bucket_bytes=4 * 3000)
+        cuts = [n, n - 1234, n - 5000, n - 5001, 7000, 4096, 100, 0]
+
+        def adam(p, g, m, v, i0, step):
+            _adam_ref(p, g, m, v, step, scale=1.0 / world)
+            shadow[i0 : i0 + p.numel()] = p.to(torch.bfloat16)  # ig_adamw_step writes the bf16 copy of its slice too
+
+        stale = False
+        for step in range(1, 4):
+            gen = torch.Generator().manual_seed(1000 * step + rank)
+            grad.copy_(torch.randn(n, generator=gen))
+            for hi, lo_r in zip(cuts[:-1], cuts[1:]):
+                sync.ready(lo_r, hi)
+            sync.step(lambda p, g, m, v, i0, step=step: adam(p, g, m, v, i0, step), gather=[shadow], small_ranges=small)
+            assert not sync.master_complete
+        small_vals = torch.cat([flat[a:b] for a, b in small]).clone()  # before the masters are completed
+        shadow_now = shadow.clone()
+        before = flat.clone()
+        sync.gather_master()
+        stale = not torch.equal(before, flat)  # some rank's masters WERE incomplete before the gather
+        sd = sync.state_dict()
+        m_full, v_full = sync.full_moments()
+        sync2 = D.ShardedGradSync(lambda: grad, lambda: flat, lo, n, bucket_bytes=4 * 3000)
+        sync2.load_state_dict(sd)
+        ok_state = all(torch.equal(a, b) for a, b in zip(sync2._m + sync2._v, sync._m + sync._v)) and sync2.plan == sync.plan
+        q.put((rank, flat.numpy().copy(), shadow_now.float().numpy().copy(), small_vals.numpy().copy(), stale, ok_state,
+               m_full.numpy().copy(), v_full.numpy().copy()))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_optimizer_publishes_the_bf16_operand_copy(world):
+    """``ShardedGradSync.step(adam, gather=[shadow], small_ranges=...)``: only the bf16 operand copy (2 bytes per parameter) is
+    all-gathered after the sharded AdamW; the parameters that are read in fp32 travel in one small all-reduce; the fp32 masters stay
+    sharded until ``gather_master()``.  After three steps on 2 / 4 gloo ranks: every rank's operand copy and fp32-read ranges equal
+    the ONE-process step, the completed masters equal it too, and the exported moments equal the replicated optimizer's."""
+    n = 20_011
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shadow_worker, args=(r, world, port, q, n)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert not isinstance(r[1], str), r[1]
+    lo = 40
+    ref = torch.linspace(-1, 1, n)
+    m, v = torch.zeros(n - lo), torch.zeros(n - lo)
+    for step in range(1, 4):
+        g = sum(torch.randn(n, generator=torch.Generator().manual_seed(1000 * step + r)) for r in range(world)) / world
+        _adam_ref(ref[lo:], g[lo:], m, v, step)
+    small = [(100, 164), (7000, 7003), (n - 5001, n - 4990), (n - 30, n)]
+    ref_small = torch.cat([ref[a:b] for a, b in small])
+    ref_shadow = ref.to(torch.bfloat16).float()
+    for r in res:
+        flat, shadow, small_vals, stale, ok_state, m_full, v_full = (torch.from_numpy(r[1]), torch.from_numpy(r[2]), torch.from_numpy(r[3]), r[4], r[5],
+                                                                     torch.from_numpy(r[6]), torch.from_numpy(r[7]))
+        assert torch.allclose(flat, ref, rtol=0, atol=2e-6), "completed masters differ from the one-process step"
+        # the operand copy: bf16 of the owner's fp32 value (one bf16 ulp of slack where the 2e-6 fp32 noise straddles a rounding edge)
+        assert (shadow[lo:] - ref_shadow[lo:]).abs().max() <= 2.0 ** -7 * ref_shadow.abs().max() and (shadow[lo:] != ref_shadow[lo:]).float().mean() < 1e-3
+        assert torch.allclose(small_vals, ref_small, rtol=0, atol=2e-6), "fp32-read ranges were not exchanged"
+        assert torch.equal(shadow, torch.from_numpy(res[0][2])), "operand copies diverged between ranks"
+        assert ok_state
+        assert torch.allclose(m_full, m, rtol=0, atol=2e-6) and torch.allclose(v_full, v, rtol=0, atol=2e-6)
+    assert any(r[4] for r in res), "no rank had incomplete masters before gather_master(): the test does not exercise the sharded state"
+
+
 def _gather_worker(rank: int, world: int, port: int, q) -> None:
     import sys
 

@@ -69,15 +69,24 @@ def _worker(rank, world, port, q, backend="gloo", mode="zero1"):
         for _ in range(2):
             mod.fused_train_step(x, y)
         torch.cuda.synchronize()
+        sh = mod.net.store.shadow
+        shadow_sum = float(sh.hi.float().double().sum().item() + (0.0 if sh.lo is None else sh.lo.float().double().sum().item()))
+        if mode == "zero1":
+            # between checkpoints only the bf16 operand copy is exchanged: the fp32 masters of the slices the other rank owns are
+            # stale until sync_master_params() (collective) completes them
+            stale = mod.net.store.flat.detach().clone()
+            assert not sync.master_complete
+            mod.sync_master_params()
+            assert sync.master_complete and not torch.equal(stale, mod.net.store.flat)
         flat = mod.net.store.flat.detach().cpu()
         # numpy (pickled by value): a torch tensor would travel as a shared-memory fd that dies with this process
         from instageo_amd import ops
 
-        q.put((rank, flat.numpy().copy(), len(sync.launched), int(mod.train_metrics.matrix.sum()), ops.reserved_cus()))
+        q.put((rank, flat.numpy().copy(), len(sync.launched), int(mod.train_metrics.matrix.sum()), ops.reserved_cus(), shadow_sum))
     except Exception as e:  # pragma: no cover
         import traceback
 
-        q.put((rank, traceback.format_exc(), 0, 0, 0))
+        q.put((rank, traceback.format_exc(), 0, 0, 0, 0.0))
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()
@@ -103,6 +112,7 @@ def test_two_rank_fused_training_equals_manual_gradient_mean(backend, mode):
         assert not isinstance(r[1], str), r[1]
     flat0, flat1 = torch.from_numpy(res[0][1]), torch.from_numpy(res[1][1])
     assert torch.equal(flat0, flat1), "replicas diverged"
+    assert res[0][5] == res[1][5], "the bf16 operand copies of the replicas differ"
     assert res[0][2] >= 2, "expected several gradient buckets per step"
     assert res[0][4] == 8 and res[1][4] == 8, "attach_data_parallel leaves 8 CUs to the collective kernels (distributed.DEFAULT_RESERVED_CUS)"
     # single-process restatement: per-rank grads (rank-local BN), mean, one AdamW step -- twice

@@ -43,7 +43,8 @@ def report(tag, got, ref):
     return d.max().item(), d.mean().item()
 
 
-@pytest.mark.parametrize("name", ["tiny_t1_c2", "tiny_t3_c13", "v1_100_t1_c2", "v1_100_t3_c13", "v2_300_t1_c2", "v2_600_t1_c2"])
+@pytest.mark.parametrize("name", ["tiny_t1_c2", "tiny_t3_c13", "v1_100_t1_c2", "v1_100_t3_c13", "v2_300_t1_c2", "v2_600_t1_c2",
+                                  "v2_600_full_t1_c2"])  # the last one: prithvi_eo_v2_600 at its full 32 blocks (630M parameters)
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
 def test_eval_logits_parity(name, precision):
     cfg, sd, net, img, lab = build(name, precision)
@@ -568,6 +569,51 @@ def test_det_fold_adds_fixed_point_shadow():
     finally:
         ops.set_deterministic(None)
     assert not ops.deterministic()
+
+
+def test_divergence_stays_visible_in_deterministic_mode():
+    """A diverged step must report NaN / Inf, as the reference's autograd does (Lightning logs a NaN loss).  The deterministic mode sums
+    through fixed-point integers, and a float -> integer conversion turns NaN into 0 and saturates Inf: non-finite and
+    out-of-range contributions therefore bypass the integer path -- the column sums into a registered gradient buffer, the loss
+    statistics of ig_ce_loss, and the classifier bias gradient."""
+    torch.manual_seed(0)
+    M, C = 3000, 64
+    x = torch.randn(M, C, device=DEV)
+    x[17, 5] = float("nan")
+    x[99, 9] = float("inf")
+    x[123, 11] = 3.0e38  # finite but far outside the 2^44 fixed-point range
+    xb = ops.BT.from_float(x, False)
+    buf = torch.zeros(2 * C, device=DEV)
+    try:
+        ops.set_deterministic(buf)
+        ops.colsum(xb, buf[:C], M, C)
+        ops.det_fold(0, C)
+        torch.cuda.synchronize()
+        assert torch.isnan(buf[5]) and torch.isinf(buf[9]) and buf[9] > 0 and buf[11] > 1e38
+        ok = torch.ones(C, dtype=torch.bool)
+        ok[[5, 9, 11]] = False
+        ref = xb.float().double().sum(0).float()
+        assert torch.allclose(buf[:C][ok.to(DEV)], ref[ok.to(DEV)], rtol=1e-5, atol=1e-4)
+    finally:
+        ops.set_deterministic(None)
+    # loss statistics: NaN logits -> NaN loss (and NaN dlogits), both label dtypes' kernel
+    B, ncls, HW = 2, 3, 4096
+    logits = torch.randn(B, ncls, HW, device=DEV)
+    labels = torch.randint(0, ncls, (B, HW), device=DEV)
+    cw = torch.ones(ncls, device=DEV)
+    for bad in (float("nan"), float("inf")):
+        lg = logits.clone()
+        lg[1, 2, 77] = bad
+        stats = torch.zeros(2, dtype=torch.float64, device=DEV)
+        dl = torch.empty_like(lg)
+        ops.ce_loss(lg, labels, cw, -1, stats, dl)
+        torch.cuda.synchronize()
+        assert not torch.isfinite(stats[0]), f"loss sum {stats[0].item()} for a {bad} logit"
+        assert stats[1].item() == B * HW
+        assert not torch.isfinite(dl[1, :, 77]).all()
+        stats.zero_()
+        ops.ce_loss(logits, labels, cw, -1, stats, dl)  # the poison word was re-armed: the next launch is clean
+        assert torch.isfinite(stats[0])
 
 
 @pytest.mark.parametrize("name,precision,B", [("tiny_t1_c2", "bf16", 4), ("v1_100_t1_c2", "bf16", 6)])

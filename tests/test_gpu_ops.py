@@ -635,7 +635,7 @@ def test_convT(split, B, H, Cin, Cout):  # 96 -> 48 unsplit runs the direct sub-
     (2, 10, 128, 128),   # 256 x 128 instance
     (1, 20, 144, 144),   # 192 x 144 instance (T = 3 widths: 2.25 K-tiles per tap, chunk-level tap decode)
     (1, 14, 288, 288),   # 2 x 144
-    (2, 11, 96, 96),     # 192 x 96 instance (1.5 K-tiles per tap)
+    (2, 11, 96, 192),    # 1.5 K-tiles per tap; data gradient N = 96 on a ragged 128-wide tile
     (1, 7, 576, 576),    # 3 x 192
     (1, 5, 1152, 1152),  # 6 x 192, K = 162 K-tiles, 1296-entry chunk table
     (1, 1, 192, 192), (1, 2, 384, 192),
@@ -737,6 +737,52 @@ def test_conv8_engine_convT(split, B, H, Cin, Cout, monkeypatch):
     assert not ops.last_kernel().startswith("conv8_kernel")
     assert torch.equal(yd.float() == 0, yo.float() == 0), "dropout masks of the two engines differ"
     close(yd.float(), yo.float().double().cpu(), tol_out(split), what="conv8 convT fwd with dropout vs the gather GEMM")
+
+
+@pytest.mark.parametrize("split", SPLITS)
+@pytest.mark.parametrize("kind,B,H,Cin,Cout", [
+    ("conv", 3, 14, 384, 384),    # 2 x 192 rows, 3456 = 18 x 192 columns; ragged token tail
+    ("conv", 2, 9, 192, 192),     # one row tile, a tap every 1.5 half-tiles (lane-level tap decode)
+    ("conv", 1, 20, 144, 144),    # ragged rows (144 of 192) and a ragged last column tile (1296 = 6.75 x 192)
+    ("conv", 1, 14, 288, 288),    # 1.5 row tiles
+    ("conv", 2, 11, 96, 96),      # half a row tile (forced)
+    ("conv", 1, 7, 576, 576), ("conv", 1, 12, 128, 256), ("conv", 1, 1, 192, 192), ("conv", 1, 3, 48, 192),
+    ("convT", 3, 14, 768, 384),   # 9 taps x 2 x 3 tiles of 192 x 256
+    ("convT", 2, 9, 384, 192), ("convT", 1, 13, 192, 96), ("convT", 1, 7, 288, 144), ("convT", 1, 6, 2304, 1152), ("convT", 2, 5, 128, 128),
+    ("convT", 1, 1, 384, 192),
+])
+def test_wgrad8_conv_engine(split, kind, B, H, Cin, Cout, monkeypatch):
+    """Weight gradients of nn.Conv2d(k=3, padding=1) / nn.ConvTranspose2d(k3, s2, p1, op1) on the grouped 8-phase engine with a
+    gathering LDS-DMA operand (gemm8w.hip modes 1 / 2), forced for every shape: against float64 autograd on the same rounded
+    operands, accumulation into dW, the bias gradient, bit-identical repeats."""
+    monkeypatch.setenv("IG_WGRAD8_CONV", "2")
+    W = H + 2
+    x, xr = bt(nhwc(rnd(B, Cin, H, W, seed=50)), split)
+    xin = xr.permute(0, 3, 1, 2).clone()
+    if kind == "conv":
+        wv = rnd(Cout, Cin, 3, 3, seed=51).double().requires_grad_(True)
+        ref = F.conv2d(xin, wv, None, padding=1)
+        Ho, Wo = H, W
+    else:
+        wv = rnd(Cin, Cout, 3, 3, seed=51).double().requires_grad_(True)
+        ref = F.conv_transpose2d(xin, wv, None, stride=2, padding=1, output_padding=1)
+        Ho, Wo = 2 * H, 2 * W
+    dy, dyr = bt(nhwc(rnd(B, Cout, Ho, Wo, seed=52)), split)
+    (gw,) = torch.autograd.grad((ref * dyr.permute(0, 3, 1, 2)).sum(), [wv])
+    gw_s = (gw.permute(0, 2, 3, 1) if kind == "conv" else gw.permute(1, 2, 3, 0)).reshape(Cout, 9, Cin)
+    dw, db = torch.zeros(Cout, 9, Cin, device=DEV), torch.full((Cout,), 0.25, device=DEV)
+    fn = ops.conv3x3_wgrad if kind == "conv" else ops.convT_wgrad
+    fn(dy, x, dw, B, H, W, Cin, Cout, dbias=db)
+    close(dw, gw_s, 3e-5, what=f"{kind} wgrad8")
+    close(db - 0.25, dyr.sum((0, 1, 2)), 3e-5, what=f"{kind} wgrad8 bias gradient")
+    first = dw.clone()
+    fn(dy, x, dw, B, H, W, Cin, Cout)  # accumulates
+    assert ops.last_kernel().startswith("gemm8w_kernel"), ops.last_kernel()
+    close(dw, 2 * gw_s, 3e-5, what=f"{kind} wgrad8 accumulate")
+    for _ in range(3):
+        dw.zero_()
+        fn(dy, x, dw, B, H, W, Cin, Cout)
+        assert torch.equal(dw, first), "wgrad8 differs between identical launches"
 
 
 @pytest.mark.parametrize("kind,C,H", [("conv", 48, 224), ("conv", 96, 112), ("convT", 96, 112)])
@@ -1068,6 +1114,59 @@ def test_mse_loss_and_regression_metrics(use_log):
         assert m2.n == 3000
         m2.reset()
         assert m2.n == 0 and np.isnan(m2.compute()["mae"])
+
+
+def test_wgrad8_plan_cache_is_pointer_free_and_capture_safe():
+    """gemm8w.hip keys its plans by SHAPE (the tables hold offsets, the operand pointers travel as kernel arguments): 2000 forward +
+    backward passes of ``torch.ops.instageo_mi355x.linear`` on freshly allocated tensors leave the free device memory where it was
+    (round 3 leaked two device tables per pointer set), and a shape the engine has not planned yet, met inside a stream capture,
+    falls back without allocating (the capture stays valid and the replay computes the right gradient)."""
+    from instageo_amd import torch_ops
+
+    torch_ops.register()
+    ns = torch.ops.instageo_mi355x
+    M, N, K = 512, 256, 256
+    w = (rnd(N, K, seed=2) * K**-0.5).to(DEV).bfloat16().requires_grad_(True)
+    b = rnd(N, seed=3).to(DEV).requires_grad_(True)
+
+    def one():
+        x = torch.randn(M, K, device=DEV).bfloat16().requires_grad_(True)  # fresh operand / gradient buffers every pass
+        y, _ = ns.linear(x, w, b, 0)
+        gx, gw, gb = torch.autograd.grad(y, (x, w, b), torch.randn(M, N, device=DEV).bfloat16())
+        return gw
+
+    for _ in range(20):
+        one()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info()[0]
+    keep = []
+    for i in range(2000):
+        g = one()
+        if i % 250 == 0:
+            keep.append(g)  # hold some results so the caching allocator really hands out new addresses
+    torch.cuda.synchronize()
+    del keep, g
+    torch.cuda.empty_cache()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 8 << 20, f"device memory shrank by {(free0 - free1) / 2**20:.1f} MiB over 2000 passes"
+
+    # a cold shape inside a capture: the grouped engine must not allocate or copy synchronously there
+    M2, N2, K2 = 1408, 512, 768  # not used anywhere else in the suite
+    dy, dyr = bt(rnd(M2, N2, seed=5), False)
+    x2, xr2 = bt(rnd(M2, K2, seed=6), False)
+    dw = torch.zeros(N2, K2, device=DEV)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            ops.linear_wgrad(dy, x2, dw, M2, N2, K2)
+    torch.cuda.current_stream().wait_stream(side)
+    dw.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    close(dw, dyr.t() @ xr2, 3e-5, what="linear wgrad captured on a cold shape")
 
 
 def test_torch_library_functional_ops_autograd():

@@ -53,7 +53,7 @@ def main():
     B, sp = a.batch, a.split
     only = set(a.only.split(","))
     dims = [a.dim * a.temporal // 2**i for i in range(5)]
-    modes = [("old", {"IG_CONV8": "0"}), ("new", {"IG_CONV8": "1"})]
+    modes = [("old", {"IG_CONV8": "0", "IG_WGRAD8_CONV": "0"}), ("new", {"IG_CONV8": "1", "IG_WGRAD8_CONV": "1"})]
 
     def mk(*shape):
         return BT.from_float(torch.randn(*shape, device=dev) * 0.5, sp)
