@@ -338,9 +338,12 @@ def main() -> None:
             # reduce-scatter + all-gather around the sharded optimizer: bucket sizes, and the EXPOSED communication of one extra,
             # instrumented step (events around every wait on the compute stream: the time it stands still for the exchange)
             res["buckets"] = [{"mbytes": round((hi - lo) * 4 / 2**20, 1), "ms": 0.0} for (lo, hi, _) in sync.plan]
-            sync.time_exposed = True
-            train_step(0)
-            res["exposed"] = sync.exposed_ms()
+            try:
+                sync.time_exposed = True
+                train_step(0)
+                res["exposed"] = sync.exposed_ms()
+            except Exception:  # noqa: BLE001  (diagnostics only)
+                res["exposed"] = None
             sync.time_exposed = False
         if profile:  # every MFMA / HBM entry point, in a separate untimed pass of 3 steps
             ops.profile_begin(GEMM_OPS + HBM_OPS)
@@ -492,13 +495,16 @@ def main() -> None:
         main_res.pop("mod", None)
         mod = None
         torch.cuda.empty_cache()
-        wl3 = make_workload(args.t3_batch, 3, 13)
-        r3 = run_mode(args.precision, False, False, wl3)
-        r3.pop("mod")
-        t3_leg = {"workload": "prithvi_eo_v1_100 T=3 13 classes (BASELINE configs[2] shape), synthetic int16 chips", "per_gpu_batch": args.t3_batch,
-                  "value": round(world * args.t3_batch * args.steps / r3["dt"], 2), "unit": "chips/s", "ms_per_step": round(1e3 * r3["dt"] / args.steps, 3),
-                  "inference_chips_per_s": round(world * args.t3_batch * args.steps / r3["dti"], 1), "exposed_comm_ms": r3.get("exposed")}
-        del wl3
+        try:  # an extra leg must never cost the headline line (every rank takes the same branch: the failure modes are symmetric)
+            wl3 = make_workload(args.t3_batch, 3, 13)
+            r3 = run_mode(args.precision, False, False, wl3)
+            r3.pop("mod")
+            t3_leg = {"workload": "prithvi_eo_v1_100 T=3 13 classes (BASELINE configs[2] shape), synthetic int16 chips", "per_gpu_batch": args.t3_batch,
+                      "value": round(world * args.t3_batch * args.steps / r3["dt"], 2), "unit": "chips/s", "ms_per_step": round(1e3 * r3["dt"] / args.steps, 3),
+                      "inference_chips_per_s": round(world * args.t3_batch * args.steps / r3["dti"], 1), "exposed_comm_ms": r3.get("exposed")}
+            del wl3
+        except Exception as e:  # noqa: BLE001
+            t3_leg = {"error": f"{e.__class__.__name__}: {e}"[:300], "value": None, "ms_per_step": None}
         torch.cuda.empty_cache()
 
     if rank != 0:

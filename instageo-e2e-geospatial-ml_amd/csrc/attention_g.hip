@@ -1,7 +1,9 @@
 // Attention for head dimensions other than 64 (any multiple of 16 up to 128): the Prithvi-EO-2.0 600M variants run 16 heads of
 // 80 (model.py:154-167; timm Attention called from pritvhi.py:446-456 -> F.scaled_dot_product_attention).
 //
-// Built on v_mfma_f32_16x16x16_bf16 (K = 16: 80 = 5 steps, no padding), without LDS: a wave owns a 16-row tile of one
+// Two sets of kernels.  Round 4 (plain bf16): the streamed side of the head staged in LDS, transposed fragments by
+// ds_read_b64_tr_b16 (attng_*_lds_kernel, further down).  Round 3 (kept for the split-precision mode, whose hi + lo images of a
+// 257-token head do not fit the LDS, and for A/B runs): built on v_mfma_f32_16x16x16_bf16 (K = 16: 80 = 5 steps, no padding), without LDS: a wave owns a 16-row tile of one
 // (batch, head) -- queries in the forward and the dQ pass, keys in the dK / dV pass -- and streams the other side in 16-row
 // tiles.  Products are oriented so that the accumulator tile of the first product is directly the B operand of the second
 // (rows 4 (lane >> 4) + j, column lane & 15 = its k / column layout):
@@ -309,10 +311,276 @@ __global__ __launch_bounds__(AG_WPB * 64) void attng_bwd_dq_kernel(const bf16_t*
     }
 }
 
+// ----------------------------------------------------------------------------------------------------------------------
+// LDS-staged variants (plain bf16): a workgroup = 8 waves = 128 owner rows of one (batch, head); the streamed side of the head is
+// staged ONCE per workgroup and chunk of AGL_CH rows into two row-major LDS images, and every fragment of the inner loop comes from
+// LDS: row operands as 8-byte reads, the transposed A operands (V^T, dO^T, Q^T, K^T) as ds_read_b64_tr_b16 on the same row-major
+// image (16 lanes read a 4-row x 16-column block, lane i receives column i) -- the kernels above fetch them as four 2-byte loads from
+// L2 per fragment.  Image pitches: 2 HD + 16 bytes = 176 for HD = 80 (44 dwords: the sixteen rows of an 8-byte row read fall on
+// disjoint banks) for images read by rows, 2 HD = 160 for an image only read transposed (rows q, q + 4 of a tr block: 40-dword steps).
+constexpr int AGL_WPB = 8;
+constexpr int AGL_CH = 272;  // rows of the streamed side per chunk (17 tiles: the 257 tokens of a 600M chip in one chunk)
+typedef __attribute__((address_space(3))) s16x4v* agl_lds_ptr;
+
+template <int HD>
+__device__ __forceinline__ void agl_fill(char* img, int pitch, const bf16_t* src, long row_stride, int r0, int nrows, int N, int tid, int nthr) {
+    constexpr int UPR = HD / 8;  // 16-byte units per row
+    for (int u = tid; u < nrows * UPR; u += nthr) {
+        const int r = u / UPR, c = u - r * UPR;
+        const uint4 v = *reinterpret_cast<const uint4*>(src + (long)min(r0 + r, N - 1) * row_stride + c * 8);
+        *reinterpret_cast<uint4*>(img + r * pitch + c * 16) = v;
+    }
+}
+__device__ __forceinline__ s16x4v agl_row4(const char* img, int pitch, int row, int col) {
+    return *reinterpret_cast<const s16x4v*>(img + row * pitch + col * 2);
+}
+// transposed fragment: 4 consecutive ROWS r0 + 4 g .. + 3 of column c0 + li  (A operand X^T[m = column][k = row])
+__device__ __forceinline__ s16x4v agl_col4(const char* img, int pitch, int r0, int c0, int li, int g) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((agl_lds_ptr)(img + (r0 + 4 * g + (li >> 2)) * pitch + (c0 + 4 * (li & 3)) * 2));
+}
+
+template <int HD>
+__global__ __launch_bounds__(AGL_WPB * 64) void attng_fwd_lds_kernel(const bf16_t* __restrict__ qkv_hi, bf16_t* __restrict__ out_hi,
+                                                                    float* __restrict__ lse, int N, int H, float scale) {
+    constexpr int NS = HD / 16, PK = 2 * HD + 16, PV = 2 * HD;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* k_img = smem;
+    char* v_img = smem + AGL_CH * PK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = (blockIdx.x * AGL_WPB + wave) * 16;
+    const bool active = q0 < N;
+    const long RS = 3L * H * HD, OS = (long)H * HD;
+    const bf16_t* qh = qkv_hi + (long)b * N * RS + h * HD;
+    const bf16_t *kh = qh + H * HD, *vh = qh + 2 * H * HD;
+    const int qr = min(q0 + li, N - 1);
+    s16x4v bq[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) bq[s] = row4(qh, RS, qr, 16 * s + 4 * g);
+    f32x4 acc[NS];
+#pragma unroll
+    for (int dt = 0; dt < NS; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const float c2 = scale * 1.44269504088896340736f;
+    for (int c0 = 0; c0 < N; c0 += AGL_CH) {
+        const int nr = min(AGL_CH, (N - c0 + 15) / 16 * 16);
+        __syncthreads();
+        agl_fill<HD>(k_img, PK, kh, RS, c0, nr, N, tid, AGL_WPB * 64);
+        agl_fill<HD>(v_img, PV, vh, RS, c0, nr, N, tid, AGL_WPB * 64);
+        __syncthreads();
+        if (!active) continue;
+        for (int kk = 0; kk < nr; kk += 16) {
+            const int k0 = c0 + kk;
+            f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < NS; ++s) st = mfma16(agl_row4(k_img, PK, kk + li, 16 * s + 4 * g), bq[s], st);
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                st[j] = (k0 + 4 * g + j < N) ? st[j] * c2 : -INFINITY;
+                mx = fmaxf(mx, st[j]);
+            }
+            mx = grp_max(mx);
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            float ps = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                st[j] = __builtin_amdgcn_exp2f(st[j] - m_new);
+                ps += st[j];
+            }
+            l_run = l_run * alpha + grp_sum(ps);
+            m_run = m_new;
+            s16x4v bp, bpl;
+            pack4<false>(st, bp, bpl);
+#pragma unroll
+            for (int dt = 0; dt < NS; ++dt) {
+                acc[dt] *= alpha;
+                acc[dt] = mfma16(agl_col4(v_img, PV, kk, 16 * dt, li, g), bp, acc[dt]);
+            }
+        }
+    }
+    if (!active || q0 + li >= N) return;
+    const float inv = 1.0f / l_run;
+    const size_t orow = ((size_t)b * N + q0 + li) * OS + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < NS; ++dt) {
+        const float f[4] = {acc[dt][0] * inv, acc[dt][1] * inv, acc[dt][2] * inv, acc[dt][3] * inv};
+        store4_split(out_hi, nullptr, orow + 16 * dt + 4 * g, f);
+    }
+    if (lse && g == 0) lse[((long)b * H + h) * N + q0 + li] = (m_run + __builtin_amdgcn_logf(l_run)) * 0.69314718055994530942f;
+}
+
+// key-owner pass (dK, dV of 16 keys per wave): Q and dO of the head staged in LDS (both read by rows AND transposed: pitch 2 HD + 16)
+template <int HD>
+__global__ __launch_bounds__(AGL_WPB * 64) void attng_bwd_dkv_lds_kernel(const bf16_t* __restrict__ qkv_hi, const bf16_t* __restrict__ do_hi,
+                                                                        const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                        bf16_t* __restrict__ dqkv_hi, int N, int H, float scale) {
+    constexpr int NS = HD / 16, PQ = 2 * HD + 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* q_img = smem;
+    char* d_img = smem + AGL_CH * PQ;
+    float* s_l = reinterpret_cast<float*>(smem + 2 * AGL_CH * PQ);
+    float* s_d = s_l + AGL_CH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int k0 = (blockIdx.x * AGL_WPB + wave) * 16;
+    const bool active = k0 < N;
+    const long RS = 3L * H * HD, OS = (long)H * HD;
+    const bf16_t* qh = qkv_hi + (long)b * N * RS + h * HD;
+    const bf16_t *kh = qh + H * HD, *vh = qh + 2 * H * HD;
+    const bf16_t* dh = do_hi + (long)b * N * OS + h * HD;
+    const float* lrow = lse + ((long)b * H + h) * N;
+    const float* drow = delta + ((long)b * H + h) * N;
+    const int kr = min(k0 + li, N - 1);
+    const float kvalid = (k0 + li < N) ? 1.f : 0.f;
+    s16x4v bk[NS], bv[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) bk[s] = row4(kh, RS, kr, 16 * s + 4 * g), bv[s] = row4(vh, RS, kr, 16 * s + 4 * g);
+    f32x4 dk[NS], dv[NS];
+#pragma unroll
+    for (int dt = 0; dt < NS; ++dt) dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}, dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float c2 = scale * 1.44269504088896340736f;
+    for (int c0 = 0; c0 < N; c0 += AGL_CH) {
+        const int nr = min(AGL_CH, (N - c0 + 15) / 16 * 16);
+        __syncthreads();
+        agl_fill<HD>(q_img, PQ, qh, RS, c0, nr, N, tid, AGL_WPB * 64);
+        agl_fill<HD>(d_img, PQ, dh, OS, c0, nr, N, tid, AGL_WPB * 64);
+        for (int r = tid; r < nr; r += AGL_WPB * 64) {
+            const bool ok = c0 + r < N;
+            s_l[r] = ok ? lrow[c0 + r] * 1.44269504088896340736f : INFINITY;  // +inf -> P = 0 on padded queries
+            s_d[r] = ok ? drow[c0 + r] : 0.f;
+        }
+        __syncthreads();
+        if (!active) continue;
+        for (int qq = 0; qq < nr; qq += 16) {
+            f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};  // rows q = qq + 4 g + j, column key
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                st = mfma16(agl_row4(q_img, PQ, qq + li, 16 * s + 4 * g), bk[s], st);
+                dp = mfma16(agl_row4(d_img, PQ, qq + li, 16 * s + 4 * g), bv[s], dp);
+            }
+            const float4 l4 = *reinterpret_cast<const float4*>(s_l + qq + 4 * g), d4 = *reinterpret_cast<const float4*>(s_d + qq + 4 * g);
+            const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+            f32x4 ds;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float pv = __builtin_amdgcn_exp2f(fmaf(st[j], c2, -ll[j])) * kvalid;
+                st[j] = pv;
+                ds[j] = pv * (dp[j] - dd[j]);
+            }
+            s16x4v bp, bpl, bs, bsl;
+            pack4<false>(st, bp, bpl);
+            pack4<false>(ds, bs, bsl);
+#pragma unroll
+            for (int dt = 0; dt < NS; ++dt) {
+                dv[dt] = mfma16(agl_col4(d_img, PQ, qq, 16 * dt, li, g), bp, dv[dt]);
+                dk[dt] = mfma16(agl_col4(q_img, PQ, qq, 16 * dt, li, g), bs, dk[dt]);
+            }
+        }
+    }
+    if (!active || k0 + li >= N) return;
+    const size_t orow = ((size_t)b * N + k0 + li) * RS + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < NS; ++dt) {
+        const float fk[4] = {dk[dt][0] * scale, dk[dt][1] * scale, dk[dt][2] * scale, dk[dt][3] * scale};
+        const float fv[4] = {dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]};
+        store4_split(dqkv_hi, nullptr, orow + (size_t)H * HD + 16 * dt + 4 * g, fk);
+        store4_split(dqkv_hi, nullptr, orow + 2 * (size_t)H * HD + 16 * dt + 4 * g, fv);
+    }
+}
+
+// query-owner pass (dQ of 16 queries per wave): K (rows and transposed) and V (rows) of the head staged in LDS
+template <int HD>
+__global__ __launch_bounds__(AGL_WPB * 64) void attng_bwd_dq_lds_kernel(const bf16_t* __restrict__ qkv_hi, const bf16_t* __restrict__ do_hi,
+                                                                       const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                       bf16_t* __restrict__ dqkv_hi, int N, int H, float scale) {
+    constexpr int NS = HD / 16, PK = 2 * HD + 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* k_img = smem;
+    char* v_img = smem + AGL_CH * PK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = (blockIdx.x * AGL_WPB + wave) * 16;
+    const bool active = q0 < N;
+    const long RS = 3L * H * HD, OS = (long)H * HD;
+    const bf16_t* qh = qkv_hi + (long)b * N * RS + h * HD;
+    const bf16_t *kh = qh + H * HD, *vh = qh + 2 * H * HD;
+    const bf16_t* dh = do_hi + (long)b * N * OS + h * HD;
+    const int qr = min(q0 + li, N - 1);
+    const bool qok = q0 + li < N;
+    const float l2 = qok ? lse[((long)b * H + h) * N + q0 + li] * 1.44269504088896340736f : INFINITY;
+    const float de = qok ? delta[((long)b * H + h) * N + q0 + li] : 0.f;
+    s16x4v bq[NS], bd[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) bq[s] = row4(qh, RS, qr, 16 * s + 4 * g), bd[s] = row4(dh, OS, qr, 16 * s + 4 * g);
+    f32x4 dq[NS];
+#pragma unroll
+    for (int dt = 0; dt < NS; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float c2 = scale * 1.44269504088896340736f;
+    for (int c0 = 0; c0 < N; c0 += AGL_CH) {
+        const int nr = min(AGL_CH, (N - c0 + 15) / 16 * 16);
+        __syncthreads();
+        agl_fill<HD>(k_img, PK, kh, RS, c0, nr, N, tid, AGL_WPB * 64);
+        agl_fill<HD>(v_img, PK, vh, RS, c0, nr, N, tid, AGL_WPB * 64);
+        __syncthreads();
+        if (!active) continue;
+        for (int kk = 0; kk < nr; kk += 16) {
+            const int k0 = c0 + kk;
+            f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};  // rows key = k0 + 4 g + j, column q
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                st = mfma16(agl_row4(k_img, PK, kk + li, 16 * s + 4 * g), bq[s], st);
+                dp = mfma16(agl_row4(v_img, PK, kk + li, 16 * s + 4 * g), bd[s], dp);
+            }
+            f32x4 ds;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float pv = (k0 + 4 * g + j < N) ? __builtin_amdgcn_exp2f(fmaf(st[j], c2, -l2)) : 0.f;
+                ds[j] = pv * (dp[j] - de);
+            }
+            s16x4v bs, bsl;
+            pack4<false>(ds, bs, bsl);
+#pragma unroll
+            for (int dt = 0; dt < NS; ++dt) dq[dt] = mfma16(agl_col4(k_img, PK, kk, 16 * dt, li, g), bs, dq[dt]);
+        }
+    }
+    if (!active || !qok) return;
+    const size_t orow = ((size_t)b * N + q0 + li) * RS + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < NS; ++dt) {
+        const float f[4] = {dq[dt][0] * scale, dq[dt][1] * scale, dq[dt][2] * scale, dq[dt][3] * scale};
+        store4_split(dqkv_hi, nullptr, orow + 16 * dt + 4 * g, f);
+    }
+}
+
+inline bool agl_enabled() {  // IG_ATTNG_LDS=0: the register / L2 kernels above for the plain mode too (A/B runs, tests)
+    const char* e = getenv("IG_ATTNG_LDS");
+    return !(e && atoi(e) == 0);
+}
+template <class K>
+inline bool agl_attr(K kern, int bytes) {
+    return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+}
+
 template <int HD>
 int attng_fwd(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, float* lse, int B, int N, int H, hipStream_t st) {
     const dim3 grid(ig_cdiv(ig_cdiv(N, 16), AG_WPB), H, B), block(AG_WPB * 64);
     const float scale = 1.0f / sqrtf((float)HD);
+    if (!qkv_lo && agl_enabled()) {
+        constexpr int smem = AGL_CH * (2 * HD + 16) + AGL_CH * 2 * HD;
+        static bool attr = false;
+        if (!attr) attr = agl_attr(attng_fwd_lds_kernel<HD>, smem);
+        if (attr) {
+            ig_note_kernel("attng_fwd_lds_kernel<%d>", HD);
+            hipLaunchKernelGGL((attng_fwd_lds_kernel<HD>), dim3(ig_cdiv(ig_cdiv(N, 16), AGL_WPB), H, B), dim3(AGL_WPB * 64), smem, st,
+                               (const bf16_t*)qkv_hi, (bf16_t*)out_hi, lse, N, H, scale);
+            return ig_check_launch("ig_attention_fwd");
+        }
+    }
     ig_note_kernel("attng_fwd_kernel<%d,%s>", HD, qkv_lo ? "true" : "false");
     if (qkv_lo)
         hipLaunchKernelGGL((attng_fwd_kernel<HD, true>), grid, block, 0, st, (const bf16_t*)qkv_hi, (const bf16_t*)qkv_lo, (bf16_t*)out_hi,
@@ -329,6 +597,22 @@ int attng_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi, const 
     const dim3 grid(ig_cdiv(ig_cdiv(N, 16), AG_WPB), H, B), block(AG_WPB * 64);
     const float scale = 1.0f / sqrtf((float)HD);
     const long total = (long)B * N * H;
+    if (!qkv_lo && agl_enabled()) {
+        constexpr int smem_kv = 2 * AGL_CH * (2 * HD + 16) + 2 * AGL_CH * 4, smem_q = 2 * AGL_CH * (2 * HD + 16);
+        static bool attr = false;
+        if (!attr) attr = agl_attr(attng_bwd_dkv_lds_kernel<HD>, smem_kv) && agl_attr(attng_bwd_dq_lds_kernel<HD>, smem_q);
+        if (attr) {
+            const dim3 gl(ig_cdiv(ig_cdiv(N, 16), AGL_WPB), H, B), bl(AGL_WPB * 64);
+            ig_note_kernel("attng_bwd_dkv_lds_kernel<%d>+attng_bwd_dq_lds_kernel", HD);
+            hipLaunchKernelGGL((attng_delta_kernel<HD, false>), dim3(ig_cdiv(total, 256)), dim3(256), 0, st, (const bf16_t*)out_hi,
+                               (const bf16_t*)out_lo, (const bf16_t*)dout_hi, (const bf16_t*)dout_lo, delta, N, H, total);
+            hipLaunchKernelGGL((attng_bwd_dkv_lds_kernel<HD>), gl, bl, smem_kv, st, (const bf16_t*)qkv_hi, (const bf16_t*)dout_hi, lse,
+                               (const float*)delta, (bf16_t*)dqkv_hi, N, H, scale);
+            hipLaunchKernelGGL((attng_bwd_dq_lds_kernel<HD>), gl, bl, smem_q, st, (const bf16_t*)qkv_hi, (const bf16_t*)dout_hi, lse,
+                               (const float*)delta, (bf16_t*)dqkv_hi, N, H, scale);
+            return ig_check_launch("ig_attention_bwd");
+        }
+    }
     ig_note_kernel("attng_bwd_dkv_kernel<%d,%s>+attng_bwd_dq_kernel", HD, qkv_lo ? "true" : "false");
 #define AG_BWD(SPLIT_)                                                                                                             \
     {                                                                                                                              \

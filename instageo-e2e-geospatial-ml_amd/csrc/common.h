@@ -29,6 +29,7 @@ int ig_convT_fwd_direct(const void* x, const void* w, const float* bias, void* y
                         unsigned drop_seed, const unsigned* drop_seed_dev, float drop_p, void* stream);
 // elementwise.hip (public C ABI): out[c] += sum_m x[m][c]
 extern "C" int ig_colsum(const void* hi, const void* lo, float* out, long M, int C, void* stream);
+int ig_colsum_ld(const void* hi, const void* lo, float* out, long M, int C, long ld, void* stream);  // first C columns, row pitch ld
 int ig_convT_dgrad_direct(const void* dy, const void* w, void* dx, int B, int H, int W, int Cin, int Cout, void* stream);
 int ig_convT_wgrad_direct(const void* dy, const void* x, float* dw, float* dbias, int* bias_fused, int B, int H, int W, int Cin,
                           int Cout, void* stream);

@@ -637,7 +637,9 @@ int ig_conv8(int kind, int sign, const void* x_hi, const void* x_lo, const void*
         const C8Shape& s = kShapes[i];
         const int tn = (N + s.bn - 1) / s.bn;
         const double util = (double)N / ((double)tn * s.bn);  // ragged last column tile: dead MFMA columns
-        if (util < (env == 2 ? 0.5 : tn == 1 ? 0.74 : 0.80)) continue;  // N = 144 on one 192-wide tile pays (measured); 288 on two does not
+        // ragged last column tile: N = 144 on one 192-wide tile pays (measured); 288 on two does not; the 128-wide instance never does
+        // (N = 96 on it: 3360 vs 2192 us in the split mode, 797 vs 610 us plain)
+        if (util < (env == 2 ? 0.5 : s.bn == 128 ? 1.0 : tn == 1 ? 0.74 : 0.80)) continue;
         if (force_bn && s.bn != force_bn) continue;
         if ((w_lo ? s.lds3 : s.lds) + (tent + 32) * 4 > 160 * 1024) continue;
         const long tiles = (M + s.bm - 1) / s.bm * tn * pl.nphase;

@@ -572,7 +572,7 @@ __global__ __launch_bounds__(LNB_TPB) void layernorm_bwd_exact_kernel(const bf16
 // grid (row chunk, 1024-column chunk); threads tile (row slice, 8-column unit) with 4 independent 16-byte loads in
 // flight; per-block LDS reduction over the row slices (plain stores + loads), then one atomic per (block, column)
 __global__ __launch_bounds__(TPB) void colsum_kernel(const bf16_t* __restrict__ hi, const bf16_t* __restrict__ lo,
-                                                     float* __restrict__ out, long M, int C, int rows_per_block) {
+                                                     float* __restrict__ out, long M, int C, int rows_per_block, long ld) {
     __shared__ float red[TPB * 8];  // [row slice][columns of this block]: plain stores, no LDS float atomics (slow)
     const int c0 = blockIdx.y * 1024;
     const int cw = min(1024, C - c0);  // columns of this block (128 units: two row slices per 256 threads)
@@ -588,16 +588,16 @@ __global__ __launch_bounds__(TPB) void colsum_kernel(const bf16_t* __restrict__ 
         long r = r0 + sl;
         for (; r + 3L * nslice < r1; r += 4L * nslice) {
             float f0[8], f1[8], f2[8], f3[8];
-            load8_split(hi, lo, (size_t)r * C + col, f0);
-            load8_split(hi, lo, (size_t)(r + nslice) * C + col, f1);
-            load8_split(hi, lo, (size_t)(r + 2L * nslice) * C + col, f2);
-            load8_split(hi, lo, (size_t)(r + 3L * nslice) * C + col, f3);
+            load8_split(hi, lo, (size_t)r * ld + col, f0);
+            load8_split(hi, lo, (size_t)(r + nslice) * ld + col, f1);
+            load8_split(hi, lo, (size_t)(r + 2L * nslice) * ld + col, f2);
+            load8_split(hi, lo, (size_t)(r + 3L * nslice) * ld + col, f3);
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] += (f0[j] + f1[j]) + (f2[j] + f3[j]);
         }
         for (; r < r1; r += nslice) {
             float f[8];
-            load8_split(hi, lo, (size_t)r * C + col, f);
+            load8_split(hi, lo, (size_t)r * ld + col, f);
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] += f[j];
         }
@@ -1210,9 +1210,12 @@ int ig_layernorm_bwd(const void* dy_hi, const void* dy_lo, const float* x, const
     return ig_check_launch("ig_layernorm_bwd");
 }
 
-int ig_colsum(const void* hi, const void* lo, float* out, long M, int C, void* stream) {
+int ig_colsum(const void* hi, const void* lo, float* out, long M, int C, void* stream) { return ig_colsum_ld(hi, lo, out, M, C, C, stream); }
+}  // extern "C"
+// internal: column sums of the first C columns of a row-major matrix with row pitch ld (elements)
+int ig_colsum_ld(const void* hi, const void* lo, float* out, long M, int C, long ld, void* stream) {
     IG_REQUIRE(hi && out, "ig_colsum: null pointer");
-    IG_REQUIRE(C % 8 == 0, "ig_colsum: C must be a multiple of 8 (got %d)", C);
+    IG_REQUIRE(C % 8 == 0 && ld % 8 == 0 && ld >= C, "ig_colsum: C and the row pitch must be multiples of 8 (got %d, %ld)", C, ld);
     if (M == 0) return IG_OK;
     // ~768 workgroups in total: fewer leave HBM idle, more are bound by the final global atomics (measured, tools/colsum_bench.py)
     const long cchunks = ig_cdiv(C, 1024);
@@ -1220,9 +1223,10 @@ int ig_colsum(const void* hi, const void* lo, float* out, long M, int C, void* s
     static const int blocks_env = getenv("IG_COLSUM_BLOCKS") ? atoi(getenv("IG_COLSUM_BLOCKS")) : 0;  // tuning knob (tools/colsum_bench.py)
     if (blocks_env > 0) rpb = (int)(((M * cchunks + blocks_env - 1) / blocks_env + 31) / 32 * 32);
     hipLaunchKernelGGL(colsum_kernel, dim3(ig_cdiv(M, rpb), ig_cdiv(C, 1024)), dim3(TPB), 0, ST(stream), (const bf16_t*)hi, (const bf16_t*)lo, out, M,
-                       C, rpb);
+                       C, rpb, ld);
     return ig_check_launch("ig_colsum");
 }
+extern "C" {
 
 int ig_split_bf16(const float* src, void* hi, void* lo, long n, void* stream) {
     IG_REQUIRE(src && hi, "ig_split_bf16: null pointer");

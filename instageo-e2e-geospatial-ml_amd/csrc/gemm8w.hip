@@ -754,7 +754,9 @@ int ig_wgrad8_conv(int kind, const void* dy_hi, const void* dy_lo, const void* x
         //            288 (1310 vs 1084), 1152 (324 tiles on 256 CUs: 1536 vs 1171)
         //   ConvTranspose: 1152 -> 576 (643 vs 696); the others within 2 %
         if (M < 8192 || ntl > ncu) return IG_ERR_UNSUPPORTED;
-        const bool pays = kind == 0 ? ((util >= 0.95 && Cin >= 384) || Cout == 144) : (Cin >= 1024 && util >= 0.95);
+        // split (bf16x3) mode: the direct kernels do not take split operands, so the alternative is the round-1 engine at three passes:
+        // Conv2d 192 -> 192 1900 vs 2820 us, ConvTranspose 384 -> 192 1322 vs 1541 (not 96 / 48 output rows: half / quarter-empty tiles)
+        const bool pays = kind == 0 ? ((util >= 0.95 && Cin >= (split ? 192 : 384)) || Cout == 144) : (Cin >= (split ? 384 : 1024) && util >= 0.95);
         if (!pays) return IG_ERR_UNSUPPORTED;
     }
     WArgs args{};

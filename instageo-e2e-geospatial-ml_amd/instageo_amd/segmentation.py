@@ -35,6 +35,7 @@ except Exception:  # pragma: no cover - Lightning is absent in this image
 # AdamW on the flat parameter buffer (base.py:124-126: torch.optim.AdamW defaults)
 # --------------------------------------------------------------------------------------------------
 _FRESH_STEP = os.environ.get("IG_FRESH_STEP", "1") != "0"  # A/B switch: 0 = zero every gradient and accumulate (rounds 1-2)
+_ADAMW_OVERLAP = os.environ.get("IG_ADAMW_OVERLAP", "1") != "0"  # A/B switch: 0 = one AdamW launch after the backward pass (rounds 1-3)
 
 class FusedAdamW(torch.optim.Optimizer):
     """``torch.optim.AdamW`` semantics, one HIP launch over the flat buffer of a :class:`PrithviSeg`.
@@ -59,6 +60,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self.hyper = torch.zeros(16, dtype=torch.float32, device=dev)
         self.sharded = None  # distributed.ShardedGradSync when the optimizer state is sharded over the data-parallel ranks
         self._small_ranges = None  # flat ranges of the parameters the kernels read in fp32 (biases, norm affine, classifier ...)
+        self._side = None  # side stream of the early (overlapped) optimizer launches
         self._host_step = 0
         self._write_hyper()
 
@@ -89,14 +91,11 @@ class FusedAdamW(torch.optim.Optimizer):
             if p.requires_grad and p.grad is not None:
                 store.entries[name].api_view(g).copy_(p.grad)
 
-    @torch.no_grad()
-    def step(self, closure=None, grads_in_flat: bool = False):
-        loss = closure() if closure is not None else None
+    def _begin(self):
+        """Per-step preamble: learning rate, device step counter / bias corrections, operand copy in the engine's precision."""
         if self.param_groups[0]["lr"] != self._lr_written:
             self.hyper[0] = float(self.param_groups[0]["lr"])
             self._lr_written = self.param_groups[0]["lr"]
-        if not grads_in_flat:
-            self.gather_grads()
         store = self.net.store
         self._host_step += 1
         ops.adamw_advance(self.hyper)
@@ -104,7 +103,21 @@ class FusedAdamW(torch.optim.Optimizer):
         eng = self.net.engine
         if store.shadow is None or store.shadow_split != eng.split:
             store.refresh_shadow(eng.split)
-        sh = store.shadow
+        return store, eng, store.shadow
+
+    def _adam_range(self, lo: int, hi: int) -> None:
+        """AdamW on flat range [lo, hi) (inside [self.lo, self.hi)) with the replicated moments."""
+        store, sh = self.net.store, self.net.store.shadow
+        shadow = ops.BT(sh.hi[lo:hi], None if sh.lo is None else sh.lo[lo:hi])
+        ops.adamw_step(store.flat[lo:hi], store.grad[lo:hi], self.m[lo - self.lo : hi - self.lo], self.v[lo - self.lo : hi - self.lo], shadow,
+                       self.hyper, hi - lo)
+
+    @torch.no_grad()
+    def step(self, closure=None, grads_in_flat: bool = False):
+        loss = closure() if closure is not None else None
+        if not grads_in_flat:
+            self.gather_grads()
+        store, eng, sh = self._begin()
         if self.sharded is not None:
             # data parallel, "zero1": the gradient buckets were reduce-scattered during backward; AdamW runs on this rank's slice
             # of every bucket (moments live in the ShardedGradSync) and writes the fp32 masters AND the bf16 operand copy of the
@@ -127,11 +140,65 @@ class FusedAdamW(torch.optim.Optimizer):
             eng.shadow_dirty = False
             eng.shadow_t_dirty = True
             return loss
-        shadow = ops.BT(sh.hi[self.lo : self.hi], None if sh.lo is None else sh.lo[self.lo : self.hi])
-        ops.adamw_step(store.flat[self.lo : self.hi], store.grad[self.lo : self.hi], self.m, self.v, shadow, self.hyper, self.hi - self.lo)
+        self._adam_range(self.lo, self.hi)
         eng.shadow_dirty = False
         eng.shadow_t_dirty = True  # the transposed weight copy is rebuilt by the next backward
         return loss
+
+    # ---- single process: AdamW of every gradient range as soon as it is final, on a side stream ------------------------------------
+    def early_begin(self) -> Callable[[int, int], None]:
+        """Start a step whose optimizer work rides on the backward pass: returns the ``on_grad_ready(lo, hi)`` hook.  Ranges arrive
+        adjacent, in descending address order (head first); every >= ``EARLY_MIN`` elements the AdamW kernel of the merged range is
+        launched on a SIDE stream behind an event of the launch stream, so it overlaps the backward kernels of the earlier blocks
+        (whose weights it does not touch: a block's parameters are last read by its own backward).  :meth:`early_finish` joins."""
+        self._begin()
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        self._early_cur: Optional[Tuple[int, int]] = None
+        self._early_done: List[Tuple[int, int]] = []
+        return self._early_ready
+
+    EARLY_MIN = 4 << 20
+
+    def _early_ready(self, lo: int, hi: int) -> None:
+        lo, hi = max(lo, self.lo), min(hi, self.hi)
+        if hi <= lo:
+            return
+        if self._early_cur is not None and hi == self._early_cur[0]:
+            self._early_cur = (lo, self._early_cur[1])
+        else:
+            self._early_flush()
+            self._early_cur = (lo, hi)
+        if self._early_cur[1] - self._early_cur[0] >= self.EARLY_MIN:
+            self._early_flush()
+
+    def _early_flush(self) -> None:
+        if self._early_cur is None:
+            return
+        lo, hi = self._early_cur
+        self._early_cur = None
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ev)
+            self._adam_range(lo, hi)
+        self._early_done.append((lo, hi))
+
+    @torch.no_grad()
+    def early_finish(self) -> None:
+        """Launch what is left, make the launch stream wait for the side stream, and update whatever was never reported."""
+        self._early_flush()
+        torch.cuda.current_stream().wait_stream(self._side)
+        at = self.hi
+        for lo, hi in self._early_done:  # descending, adjacent when the whole range was reported
+            if hi < at:
+                self._adam_range(hi, at)
+            at = min(at, lo)
+        if at > self.lo:
+            self._adam_range(self.lo, at)
+        eng = self.net.engine
+        eng.shadow_dirty = False
+        eng.shadow_t_dirty = True
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         super().zero_grad(set_to_none=set_to_none)
@@ -233,6 +300,7 @@ class PrithviSegmentationModule(_Base):
         self.logged: Dict[str, Any] = {}
         self._loss_sums: Dict[str, torch.Tensor] = {}
         self._optimizer: Optional[FusedAdamW] = None
+        self._early_ok = True  # False while a hipGraph of the step is being prepared (make_graphed_train_step)
         self.grad_sync: Optional[Callable[[], None]] = None  # set by the data-parallel wrapper
 
     # ---- reference API -------------------------------------------------------------------------
@@ -366,10 +434,23 @@ class PrithviSegmentationModule(_Base):
             eng.zero_grads_for_step(opt.lo, opt.hi)
         else:
             g[opt.lo : opt.hi].zero_()
-        eng.backward(dlog, count=stats, fresh=_FRESH_STEP)
-        if self.grad_sync is not None:
-            self.grad_sync()
-        opt.step(grads_in_flat=True)
+        # single process, not under a stream capture: the optimizer work rides on the backward pass (IG_ADAMW_OVERLAP=0: afterwards)
+        # (measured, tools/ab_step.sh: +0.5-0.7 % at B = 216; at the YAML's batch 16 the extra fold launches and stream events cost
+        # more than the 0.5 ms they hide -- the step there is bound by the host's launch rate -- so small batches keep the single launch)
+        early = (self.grad_sync is None and opt.sharded is None and eng.on_grad_ready is None and _ADAMW_OVERLAP and self._early_ok
+                 and inputs.shape[0] * net.cfg.tokens >= 10000 and not torch.cuda.is_current_stream_capturing())
+        if early:
+            eng.on_grad_ready = opt.early_begin()
+            try:
+                eng.backward(dlog, count=stats, fresh=_FRESH_STEP)
+            finally:
+                eng.on_grad_ready = None
+            opt.early_finish()
+        else:
+            eng.backward(dlog, count=stats, fresh=_FRESH_STEP)
+            if self.grad_sync is not None:
+                self.grad_sync()
+            opt.step(grads_in_flat=True)
         acc = self._loss_sums.get("train")
         if acc is None:
             acc = torch.zeros(2, dtype=torch.float64, device=logits.device)
@@ -404,14 +485,18 @@ class PrithviSegmentationModule(_Base):
                 "loss": self._loss_sums["train"].clone(), "bufs": {k: t.clone() for k, t in self.net._buffers_flat.items()}}
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):  # warm-up on a side stream: allocates workspaces, sets kernel attributes
-            for _ in range(2):
+        self._early_ok = False  # warm-up and capture run the SAME launch sequence (the overlapped optimizer forks a second stream)
+        try:
+            with torch.cuda.stream(side):  # warm-up on a side stream: allocates workspaces, sets kernel attributes
+                for _ in range(2):
+                    self.fused_train_step(static_x, static_y, stats)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
                 self.fused_train_step(static_x, static_y, stats)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            self.fused_train_step(static_x, static_y, stats)
+        finally:
+            self._early_ok = True
         with torch.no_grad():  # in-place restores: the graph keeps writing into these very tensors
             self.net.store.flat.copy_(snap["flat"])
             opt.m.copy_(snap["m"]), opt.v.copy_(snap["v"]), opt.hyper.copy_(snap["hyper"])

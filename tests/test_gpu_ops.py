@@ -512,6 +512,8 @@ def test_attention_generic_head_dim(split, N, hd, monkeypatch):
     out = BT.empty((B, N, H * hd), split, DEV)
     lse = torch.empty(B, H, N, device=DEV)
     ops.attention_fwd(qkv, out, lse, B, N, H, hd=hd)
+    # plain bf16: the LDS-staged kernels (whole head in two LDS images, three chunks at N = 769); split: the register / L2 kernels
+    assert ("lds" in ops.last_kernel()) == (not split), ops.last_kernel()
     qd = qr.clone().requires_grad_(True)
     ref = attn_ref(qd, B, N, H, hd)
     close(out.float(), ref.detach(), 3e-5 if split else 1e-2, what="generic attn fwd")

@@ -49,11 +49,14 @@ def main():
     ap.add_argument("--only", default="fwd,dgrad,wgrad")
     ap.add_argument("--split", action="store_true")
     ap.add_argument("--stages", default="0,1,2,3")
+    ap.add_argument("--force", action="store_true", help="third column: both engines forced for every covered shape")
     a = ap.parse_args()
     B, sp = a.batch, a.split
     only = set(a.only.split(","))
     dims = [a.dim * a.temporal // 2**i for i in range(5)]
     modes = [("old", {"IG_CONV8": "0", "IG_WGRAD8_CONV": "0"}), ("new", {"IG_CONV8": "1", "IG_WGRAD8_CONV": "1"})]
+    if a.force:
+        modes.append(("forced", {"IG_CONV8": "2", "IG_WGRAD8_CONV": "2"}))
 
     def mk(*shape):
         return BT.from_float(torch.randn(*shape, device=dev) * 0.5, sp)
