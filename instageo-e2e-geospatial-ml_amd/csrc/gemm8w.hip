@@ -4,6 +4,9 @@
 //                                                            autograd's grad_weight of F.linear), g = 0 .. ng-1 share the token count
 //   mode 1  dWc[co][tap][ci] += sum_p dy[p][co] * x[p + shift(tap)][ci]        nn.Conv2d(k=3, padding=1)      (model.py:370-375)
 //   mode 2  dWc[co][tap][ci] += sum_p dy[up(p) + shift(tap)][co] * x[p][ci]    nn.ConvTranspose2d(k3,s2,p1,op1) (model.py:361-368)
+//           round 4b: run as mode 1 with the ROLES SWAPPED -- rows = ci (x, plain: 256-row tiles), columns = (tap, co) (dy, gathered
+//           at the stride-2 positions, the lane's tap from its column), the fold stores the tile transposed into dWc[co][tap][ci];
+//           the per-tap form (A gathered, 192-row tiles) stays for A/B runs (IG_WGRAD8_CONVT_SWAP=0)
 //
 // * The reduction runs over tokens / pixels, so BOTH operands are reduce-strided ("TR"): an operand half-tile in LDS is
 //   [64 tokens][128 columns] (256-byte rows, 16 KiB), filled by LDS-DMA in full 256-byte source rows (two cache lines per
@@ -62,13 +65,14 @@ struct WSeg {  // one (workgroup, output tile, token range); 64 bytes
 };
 static_assert(sizeof(WSeg) == 64, "WSeg layout");
 
-struct WTile {  // reduce table; 32 bytes
-    long out_off;  // element offset of the tile origin inside dW of GEMM g
+struct WTile {  // reduce table; 40 bytes
+    long out_off;  // element offset of the tile origin inside dW of GEMM g (transposed fold: first row = ci of the tile)
     long first;    // first slab of this tile (its slabs are consecutive, in token order)
     int ldo, nslab;
     short g, rows, cols, pad;  // valid rows / columns of the tile
+    int jcol0, pad2;           // transposed fold: first column of the tile in (tap, co) space
 };
-static_assert(sizeof(WTile) == 32, "WTile layout");
+static_assert(sizeof(WTile) == 40, "WTile layout");
 
 struct WArgs {  // operand pointers of the launch (the tables hold offsets)
     const char* a[W_MAXG][2];  // dy hi / lo
@@ -76,7 +80,9 @@ struct WArgs {  // operand pointers of the launch (the tables hold offsets)
 };
 struct WConv {  // modes 1 / 2: geometry of the pixel grid the tokens run over
     int M, H, W;            // tokens, grid of one image
-    int Cg;                 // channels of the gathered operand (mode 1: Cin of x; mode 2: Cout of dy)
+    int Cg;                 // channels of the gathered operand (mode 1: Cin of x, or Cout of dy with sm = 2; mode 2: Cout of dy)
+    int sm;                 // mode 1: the gathered tensor lives on the (sm H, sm W) grid, token (y, x) sits at (sm y, sm x) (2: ConvTranspose)
+    int Cout_t, Cin_t;      // transposed fold (ConvTranspose with swapped roles): dWc[co][tap][ci], row pitch 9 Cin_t
     unsigned g_bytes;       // bytes of the gathered tensor (buffer descriptor bound, < 2^31)
     FDiv f_hw, f_w, f_c;    // division by H W, W, Cg
 };
@@ -185,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
     _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                       \
         (R).p[i_] += 64;                                                                     \
         const int xs_ = (R).x[i_] + 64, q_ = cv.f_w.div(xs_);                                \
-        (R).x[i_] = xs_ - q_ * cv.W;                                                         \
+        (R).x[i_] = xs_ - __mul24(q_, cv.W);                                                 \
         int y_ = (R).y[i_] + q_;                                                             \
         while (y_ >= cv.H) y_ -= cv.H, (R).b[i_]++;                                          \
         (R).y[i_] = y_;                                                                      \
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
                 const int tap = cv.f_c.div(j), ci = j - tap * cv.Cg;
                 const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
                 dyB[g] = ky - 1, dxB[g] = kx - 1;
-                shB[g] = ((dyB[g] * cv.W + dxB[g]) * cv.Cg + ci) * 2;
+                shB[g] = ((dyB[g] * cv.sm * cv.W + dxB[g]) * cv.Cg + ci) * 2;
                 okB[g] = lch * 8 < (g ? B1COLS : 128) && g * 128 + lch * 8 < s_->bcols && tap < 9;
             }
         } else {
@@ -289,13 +295,22 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
         const unsigned dst = ldsw + buf * W_BUF + 2 * W_HALF;
         if constexpr (MODE == 1) {
             const i32x4 rs = (NSEG == 3 && pseg) ? rs_lo : rs_hi;
+            // source pixel of token p = (b, y, x): p itself (sm = 1), or (b, 2y, 2x) of the (2H, 2W) image = 4 p - 2 x (ConvTranspose, sm = 2):
+            // shifts and one 32-bit multiply per row (the per-half work is two adds, two compares, a select)
+            const int sh = cv.sm - 1, Hs = cv.H << sh, Ws = cv.W << sh;
+            unsigned rowb[2];
+            int ysh[2], xsh[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ysh[i] = R.y[i] << sh, xsh[i] = R.x[i] << sh;
+                rowb[i] = (unsigned)(((R.p[i] << (2 * sh)) - (xsh[i] & -sh)) * C2g);
+            }
 #pragma unroll
             for (int g = 0; g < 2; ++g)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const bool v = okB[g] & (R.p[i] < cv.M) & ((unsigned)(R.y[i] + dyB[g]) < (unsigned)cv.H) &
-                                   ((unsigned)(R.x[i] + dxB[g]) < (unsigned)cv.W);
-                    const unsigned voff = v ? (unsigned)(R.p[i] * C2g + shB[g]) : 0x80000000u;
+                    const bool v = okB[g] & (R.p[i] < cv.M) & ((unsigned)(ysh[i] + dyB[g]) < (unsigned)Hs) & ((unsigned)(xsh[i] + dxB[g]) < (unsigned)Ws);
+                    const unsigned voff = v ? rowb[i] + (unsigned)shB[g] : 0x80000000u;
                     w_blds(voff, rs, dst + g * W_HALF + i * 1024);
                 }
             W_ADVANCE_ROWS(R)
@@ -421,9 +436,9 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
 
 // dW tile (+)= sum of its slabs, in slab (= token) order.  Slab element e = a * 512 + tid holds accumulator a = (h NTW + nt) MT + mt
 // of thread tid: dW rows h*2MT16 + wr*MT16 + mt*16 + (lane & 15), columns (nt < 2: wc*32 + nt*16 | 128 + wc*NT1*16 + (nt-2)*16) + 4 (lane >> 4) .. +3.
-template <int MT, int NT1>
+template <int MT, int NT1, bool TRANS>
 __global__ __launch_bounds__(256) void wgrad8_reduce_kernel(const WTile* __restrict__ tiles, const float4* __restrict__ slabs, WDw dws,
-                                                            int overwrite) {
+                                                            int overwrite, int cout_t, int cin_t) {
     constexpr int NTW = 2 + NT1, NA = 2 * NTW * MT;
     const WTile T = tiles[blockIdx.y];
     const int e = blockIdx.x * 256 + threadIdx.x;  // 0 .. NA * 512 - 1
@@ -440,6 +455,17 @@ __global__ __launch_bounds__(256) void wgrad8_reduce_kernel(const WTile* __restr
         s.x += t.x, s.y += t.y, s.z += t.z, s.w += t.w;
     }
     float* dw = T.g == 0 ? dws.dw[0] : T.g == 1 ? dws.dw[1] : T.g == 2 ? dws.dw[2] : dws.dw[3];
+    if constexpr (TRANS) {  // tile rows = ci, columns = (tap, co): dWc[co][tap][ci] (4 consecutive co per thread: scalar stores)
+        const int j = T.jcol0 + col, tap = j / cout_t, co = j - tap * cout_t;
+        float* o = dw + ((long)co * 9 + tap) * cin_t + T.out_off + row;
+        const float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float* oe = o + (long)e * 9 * cin_t;
+            *oe = overwrite ? v[e] : *oe + v[e];
+        }
+        return;
+    }
     float4* o = reinterpret_cast<float4*>(dw + T.out_off + (long)row * T.ldo + col);
     if (!overwrite) {  // overwrite: dW = sum (a fresh step: the caller neither zeroed dW nor wants its old contents read)
         const float4 v = *o;
@@ -512,7 +538,7 @@ struct TileRef {  // one output tile of the launch
     int tap, jcol0;
 };
 
-template <int NSEG, int MODE, int MT, int NT1>
+template <int NSEG, int MODE, int MT, int NT1, bool TRANS>
 int w_launch(const WPlan& pl, float* ws, const bf16_t* zp, const WArgs& args, const WConv& cv, const WDw& dws, int overwrite, hipStream_t st) {
     auto kern = gemm8w_kernel<NSEG, MODE, MT, NT1>;
     static bool attr_done = false;
@@ -527,13 +553,13 @@ int w_launch(const WPlan& pl, float* ws, const bf16_t* zp, const WArgs& args, co
     ig_note_grid(pl.nwg);
     hipLaunchKernelGGL(kern, dim3(pl.nwg), dim3(512), W_SMEM, st, (const WSeg*)pl.segs, ws, zp, args, cv);
     constexpr int NA = 2 * (2 + NT1) * MT;
-    hipLaunchKernelGGL((wgrad8_reduce_kernel<MT, NT1>), dim3(NA * 2, pl.ntiles), dim3(256), 0, st, (const WTile*)pl.tiles, (const float4*)ws, dws,
-                       overwrite);
+    hipLaunchKernelGGL((wgrad8_reduce_kernel<MT, NT1, TRANS>), dim3(NA * 2, pl.ntiles), dim3(256), 0, st, (const WTile*)pl.tiles, (const float4*)ws,
+                       dws, overwrite, cv.Cout_t, cv.Cin_t);
     return ig_check_launch("gemm8w");
 }
 
 // Plan (cached by `key`) + launch.  tiles: the output tiles of the launch; every tile reduces over the same M tokens.
-template <int MODE, int MT, int NT1>
+template <int MODE, int MT, int NT1, bool TRANS = false>
 int w_run(const WKey& key, const std::vector<TileRef>& tl, int M, int lda2_of_g[W_MAXG], int ldb2_of_g[W_MAXG], bool split, const WArgs& args,
           const WConv& cv, const WDw& dws, int overwrite, hipStream_t st, const char* what) {
     const long ntiles = (long)tl.size();
@@ -641,6 +667,7 @@ int w_run(const WKey& key, const std::vector<TileRef>& tl, int M, int lda2_of_g[
                 ht[t].out_off = tr.out_off;
                 ht[t].first = t * spt, ht[t].ldo = tr.ldo, ht[t].nslab = tcount[t];
                 ht[t].g = (short)tr.g, ht[t].rows = (short)tr.acols, ht[t].cols = (short)tr.bcols, ht[t].pad = 0;
+                ht[t].jcol0 = tr.jcol0, ht[t].pad2 = 0;
                 if (tcount[t] > spt || tcount[t] < 1) {
                     ig_set_error("%s: internal plan error (tile %ld has %d segments)", what, t, tcount[t]);
                     return IG_ERR_ARG;
@@ -678,8 +705,8 @@ int w_run(const WKey& key, const std::vector<TileRef>& tl, int M, int lda2_of_g[
         ig_set_error("%s: could not allocate the slab workspace (%ld slabs)", what, pl.nslab);
         return IG_ERR_HIP;
     }
-    if (split) return w_launch<3, MODE, MT, NT1>(pl, ws, zp, args, cv, dws, overwrite, st);
-    return w_launch<1, MODE, MT, NT1>(pl, ws, zp, args, cv, dws, overwrite, st);
+    if (split) return w_launch<3, MODE, MT, NT1, TRANS>(pl, ws, zp, args, cv, dws, overwrite, st);
+    return w_launch<1, MODE, MT, NT1, TRANS>(pl, ws, zp, args, cv, dws, overwrite, st);
 }
 
 }  // namespace
@@ -718,6 +745,20 @@ int ig_wgrad8_group(int n, const void* const* dy_hi, const void* const* dy_lo, c
     return w_run<0, 4, 2>(key, tl, M, lda2, ldb2, split, args, cv, dws, overwrite, (hipStream_t)stream, "ig_linear_wgrad_group");
 }
 
+// Default routing of the convolution weight gradients (IG_WGRAD8_CONV=1), by measurement against the round-1 engines / the direct
+// kernels (tools/head_bench.py, microseconds old -> new; IG_WGRAD8_CONV=2 forces every covered shape):
+//   B = 216, T = 1   Conv2d 384: 673 -> 575 (192 x 256 tiles); 192: the direct kernel stays (573 vs 569); 96 / 48: direct kernels (1306 / 2559 forced)
+//                    ConvTranspose (roles swapped) 768 -> 384: 455 -> 325 (256 x 256 tiles, 692 TFLOP/s), 384 -> 192: 490 -> 381, 192 -> 96: 646 -> 462;
+//                    96 -> 48: the direct kernel stays (373 vs 960)
+//   B = 36, T = 3    Conv2d 1152: 1152 -> 940, 576: 1193 -> 839, 144: 1551 -> 1378; 288 (1.5 row tiles): 1088 vs 1165 forced -> stays
+//                    ConvTranspose 1152 -> 576: 698 -> 482, 576 -> 288: 841 -> 515, 288 -> 144: 1163 -> 817; 2304 -> 1152 (M = 7056): 652 vs 717 forced -> stays
+//   bf16x3           Conv2d 192: 2820 -> 1900 (the direct kernels do not take split operands)
+static bool c8w_pays(int kind, bool swap, bool split, int Cin, int Cout, double util, long ntl, int ncu) {
+    if (kind == 0) return (util >= 0.90 && Cin >= (split ? 192 : 384)) || Cout == 144;
+    if (swap) return util >= 0.70 && Cin >= 192 && Cout >= 96;
+    return Cin >= (split ? 384 : 1024) && util >= 0.95 && ntl <= ncu;
+}
+
 // Weight gradient of the decode head's convolutions on the same engine.  kind 0: nn.Conv2d(k=3, padding=1): dy (B,H,W,Cout), x (B,H,W,Cin);
 // kind 1: nn.ConvTranspose2d(k3,s2,p1,op1): dy (B,2H,2W,Cout), x (B,H,W,Cin).  dWc[Cout][9][Cin] += ...  IG_ERR_UNSUPPORTED (no error
 // string) when the shape is not covered.
@@ -736,62 +777,70 @@ int ig_wgrad8_conv(int kind, const void* dy_hi, const void* dy_lo, const void* x
     const double g_bytes = kind == 0 ? (double)M * Cin * 2.0 : (double)M * 4.0 * Cout * 2.0;
     if (M >= (1L << 30) || g_bytes >= 2147483648.0) return IG_ERR_UNSUPPORTED;
     if ((long)Cout * 2 * 64 >= (1L << 24) || (long)Cin * 2 * 64 >= (1L << 24)) return IG_ERR_UNSUPPORTED;
-    // tile shape: 192-row tiles (the channel counts are multiples of 48 / 144); 192 or 256 columns by the padding they leave
-    const int BMt = 192;
-    const int ncols = kind == 0 ? 9 * Cin : Cin;  // columns of one GEMM: (tap, ci) for the convolution, ci per tap for the transpose
-    auto waste = [&](int bn) { return (double)((ncols + bn - 1) / bn * bn) / ncols; };
-    const int BNt = waste(256) < waste(192) - 1e-9 ? 256 : 192;
-    const int tiles_m = (Cout + BMt - 1) / BMt, tiles_n = (ncols + BNt - 1) / BNt;
-    const double util = (double)Cout * ncols / ((double)tiles_m * BMt * tiles_n * BNt);
+    // ConvTranspose: roles swapped by default (rows = ci from x, columns = (tap, co) from dy gathered at the stride-2 positions, transposed
+    // fold): one GEMM with 256- or 192-row tiles instead of nine with 192-row tiles of a gathered A.  IG_WGRAD8_CONVT_SWAP=0: the per-tap form.
+    const char* se = getenv("IG_WGRAD8_CONVT_SWAP");
+    const bool swap = kind == 1 && !(se && atoi(se) == 0);
+    const int nrows = swap ? Cin : Cout;                                  // rows of the GEMM's output
+    const int ncols = kind == 0 ? 9 * Cin : (swap ? 9 * Cout : Cin);      // its columns
+    auto waste = [](int n, int b) { return (double)((n + b - 1) / b * b) / n; };
+    // tile shape: 256 x 256 carries 64 MFMAs per wave and K-tile, 192 x 256 48, 192 x 192 36 at the same LDS-DMA / barrier cost: the larger
+    // tile wins unless it leaves more than ~12 % of itself empty
+    const int BMt = (swap || kind == 0) && waste(nrows, 256) <= waste(nrows, 192) + 1e-9 ? 256 : (waste(nrows, 256) < waste(nrows, 192) - 0.12 ? 256 : 192);
+    const int BNt = waste(ncols, 256) <= waste(ncols, 192) + 0.12 ? 256 : 192;
+    if (!swap && kind == 1 && BMt != 192) return IG_ERR_UNSUPPORTED;  // (the per-tap form is instantiated for 192-row tiles only)
+    const int tiles_m = (nrows + BMt - 1) / BMt, tiles_n = (ncols + BNt - 1) / BNt;
+    const double util = (double)nrows * ncols / ((double)tiles_m * BMt * tiles_n * BNt);
     int ncu = ig_cu_count() - ig_reserved_cus();
     if (ncu < 8) ncu = 8;
-    const long ntl = (long)tiles_m * tiles_n * (kind == 0 ? 1 : 9);
+    const long ntl = (long)tiles_m * tiles_n * ((kind == 0 || swap) ? 1 : 9);
     if (cenv != 2) {
-        // Measured per stage against the round-1 engines / the direct kernels (tools/head_bench.py, B = 216 at T = 1, B = 36 at T = 3): a
-        // 192-row tile carries 36 MFMAs per wave and K-tile against the 64 of the linears' 256 x 256 tile, with the same LDS-DMA and
-        // barrier cost per K-tile (440-700 TFLOP/s where the linears reach 1080), so it only pays where the old engines fit badly:
-        //   Conv2d:  576 -> 576 (992 vs 1199 us), 144 -> 144 (1288 vs 1542), 384 -> 384 (642 vs 652); not 192 (direct kernel: 576 vs 648),
-        //            288 (1310 vs 1084), 1152 (324 tiles on 256 CUs: 1536 vs 1171)
-        //   ConvTranspose: 1152 -> 576 (643 vs 696); the others within 2 %
-        if (M < 8192 || ntl > ncu) return IG_ERR_UNSUPPORTED;
-        // split (bf16x3) mode: the direct kernels do not take split operands, so the alternative is the round-1 engine at three passes:
-        // Conv2d 192 -> 192 1900 vs 2820 us, ConvTranspose 384 -> 192 1322 vs 1541 (not 96 / 48 output rows: half / quarter-empty tiles)
-        const bool pays = kind == 0 ? ((util >= 0.95 && Cin >= (split ? 192 : 384)) || Cout == 144) : (Cin >= (split ? 384 : 1024) && util >= 0.95);
-        if (!pays) return IG_ERR_UNSUPPORTED;
+        if (M < 8192 || ntl > (long)ncu * W_MAXSEG) return IG_ERR_UNSUPPORTED;
+        if (!c8w_pays(kind, swap, split, Cin, Cout, util, ntl, ncu)) return IG_ERR_UNSUPPORTED;
     }
     WArgs args{};
     WDw dws{};
-    args.a[0][0] = (const char*)dy_hi, args.a[0][1] = split ? (const char*)dy_lo : (const char*)dy_hi;
-    args.b[0][0] = (const char*)x_hi, args.b[0][1] = split ? (const char*)x_lo : (const char*)x_hi;
+    // operand A = the plain matrix whose columns are the ROWS of the output, operand B = the other one
+    const void *ah = swap ? x_hi : dy_hi, *al = swap ? x_lo : dy_lo, *bh = swap ? dy_hi : x_hi, *bl = swap ? dy_lo : x_lo;
+    args.a[0][0] = (const char*)ah, args.a[0][1] = split ? (const char*)al : (const char*)ah;
+    args.b[0][0] = (const char*)bh, args.b[0][1] = split ? (const char*)bl : (const char*)bh;
     dws.dw[0] = dw;
-    int lda2[W_MAXG] = {Cout * 2, 0, 0, 0}, ldb2[W_MAXG] = {Cin * 2, 0, 0, 0};
+    int lda2[W_MAXG] = {(swap ? Cin : Cout) * 2, 0, 0, 0}, ldb2[W_MAXG] = {(swap ? Cout : Cin) * 2, 0, 0, 0};
     std::vector<TileRef> tl;
-    const int ntap = kind == 0 ? 1 : 9;
+    const int ntap = (kind == 0 || swap) ? 1 : 9;
     for (int tap = 0; tap < ntap; ++tap)
         for (int tm = 0; tm < tiles_m; ++tm)
             for (int tn = 0; tn < tiles_n; ++tn) {
                 TileRef t{};
                 t.g = 0;
-                t.aoff = (long)tm * BMt * 2, t.boff = kind == 0 ? 0 : (long)tn * BNt * 2;
-                t.acols = Cout - tm * BMt < BMt ? Cout - tm * BMt : BMt;
+                t.aoff = (long)tm * BMt * 2, t.boff = (kind == 0 || swap) ? 0 : (long)tn * BNt * 2;
+                t.acols = nrows - tm * BMt < BMt ? nrows - tm * BMt : BMt;
                 t.bcols = ncols - tn * BNt < BNt ? ncols - tn * BNt : BNt;
                 t.ldo = 9 * Cin;
-                t.out_off = (long)tm * BMt * t.ldo + (kind == 0 ? 0 : (long)tap * Cin) + (long)tn * BNt;
+                t.out_off = swap ? (long)tm * BMt : (long)tm * BMt * t.ldo + (kind == 0 ? 0 : (long)tap * Cin) + (long)tn * BNt;
                 t.tap = tap, t.jcol0 = tn * BNt;
                 tl.push_back(t);
             }
     WConv cv{};
     cv.M = (int)M, cv.H = H, cv.W = W, cv.Cg = kind == 0 ? Cin : Cout;
+    cv.sm = swap ? 2 : 1, cv.Cout_t = Cout, cv.Cin_t = Cin;
     cv.g_bytes = (unsigned)g_bytes;
     cv.f_hw = make_fdiv(H * W), cv.f_w = make_fdiv(W), cv.f_c = make_fdiv(cv.Cg);
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
-    const WKey key = {1 + kind, (long)M, ncu, split, wg8_rem_env(), dev_, H, W, Cin, Cout, BNt};
+    const WKey key = {1 + kind + (swap ? 2 : 0), (long)M, ncu, split, wg8_rem_env(), dev_, H, W, Cin, Cout, BMt, BNt};
     hipStream_t st = (hipStream_t)stream;
-    if (kind == 0) {
-        if (BNt == 256) return w_run<1, 3, 2>(key, tl, (int)M, lda2, ldb2, split, args, cv, dws, 0, st, "ig_conv3x3_wgrad");
-        return w_run<1, 3, 1>(key, tl, (int)M, lda2, ldb2, split, args, cv, dws, 0, st, "ig_conv3x3_wgrad");
+    const int M_ = (int)M;
+#define IG_W8C(MODE, TRANS, WHAT)                                                                                                  \
+    {                                                                                                                              \
+        if (BMt == 256 && BNt == 256) return w_run<MODE, 4, 2, TRANS>(key, tl, M_, lda2, ldb2, split, args, cv, dws, 0, st, WHAT);  \
+        if (BMt == 256) return w_run<MODE, 4, 1, TRANS>(key, tl, M_, lda2, ldb2, split, args, cv, dws, 0, st, WHAT);                \
+        if (BNt == 256) return w_run<MODE, 3, 2, TRANS>(key, tl, M_, lda2, ldb2, split, args, cv, dws, 0, st, WHAT);                \
+        return w_run<MODE, 3, 1, TRANS>(key, tl, M_, lda2, ldb2, split, args, cv, dws, 0, st, WHAT);                                \
     }
-    if (BNt == 256) return w_run<2, 3, 2>(key, tl, (int)M, lda2, ldb2, split, args, cv, dws, 0, st, "ig_convT_wgrad");
-    return w_run<2, 3, 1>(key, tl, (int)M, lda2, ldb2, split, args, cv, dws, 0, st, "ig_convT_wgrad");
+    if (kind == 0) IG_W8C(1, false, "ig_conv3x3_wgrad")
+    if (swap) IG_W8C(1, true, "ig_convT_wgrad")
+#undef IG_W8C
+    if (BNt == 256) return w_run<2, 3, 2>(key, tl, M_, lda2, ldb2, split, args, cv, dws, 0, st, "ig_convT_wgrad");
+    return w_run<2, 3, 1>(key, tl, M_, lda2, ldb2, split, args, cv, dws, 0, st, "ig_convT_wgrad");
 }
