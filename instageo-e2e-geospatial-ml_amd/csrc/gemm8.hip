@@ -575,6 +575,9 @@ int ig_gemm8_nt(const G8Params& p, void* stream) {
         if (e && atoi(e) == 0) return IG_ERR_UNSUPPORTED;
         small = true;
     }
+    // (Round 4, measured and not kept: taking the 128 x 128 instance whenever its round count beats the big one's by a cost model --
+    // 261 tiles of 256 x 256 on 256 CUs are two rounds for 1.02 rounds of work at B = 112, 1044 quarter-tiles are three rounds of 512 --
+    // made the cliff WORSE: 4142 -> 4005 chips/s at B = 112, 4599 -> 4343 at B = 221; a small-instance round costs more than half a big one.)
     const int ntiles = small ? ((p.M + 127) >> 7) * (p.N >> 7) : ntiles256;
     const int grid = ig_tile_grid(ntiles, small ? 2 : 1);
     hipStream_t st = (hipStream_t)stream;

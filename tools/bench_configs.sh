@@ -19,3 +19,4 @@ run 300m_b32 --model prithvi_eo_v2_300 --batch 32
 run 300m_b54 --model prithvi_eo_v2_300 --batch 54
 run 300m_b80 --model prithvi_eo_v2_300 --batch 80
 run 300m_b160 --model prithvi_eo_v2_300 --batch 160
+run 600m_b32 --model prithvi_eo_v2_600 --batch 32 --steps 10 --warmup 3

@@ -5,7 +5,7 @@
 #   3. HBM-traffic PMC passes of the same command        -> pmc_bench.json
 #   4. the other BASELINE configs / batch sizes          -> configs/*.json
 # every profiler invocation is bounded by `timeout`.
-TAG=${1:-r03}; R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
+TAG=${1:-r04}; R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd $R
 timeout 600 python bench.py --detail-file $OUT/bench_detail.json > $OUT/bench.log 2>&1; tail -c 2200 $OUT/bench.log
 (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o b -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity-leg --no-tile --no-profile --detail-file /tmp/d.json > $OUT/prof.log 2>&1)
