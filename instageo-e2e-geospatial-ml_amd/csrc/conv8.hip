@@ -650,7 +650,9 @@ int ig_conv8(int kind, int sign, const void* x_hi, const void* x_lo, const void*
     if (best < 0) return IG_ERR_UNSUPPORTED;
     const C8Shape& sh = kShapes[best];
     const long ntiles = (M + sh.bm - 1) / sh.bm * ((N + sh.bn - 1) / sh.bn) * pl.nphase;
-    if (env != 2 && ntiles < slots) return IG_ERR_UNSUPPORTED;  // less than one tile per CU: the round-1 engine's finer tiles (B = 16: -0.9 % with conv8)
+    // (nearly) one tile per CU or more: 252 tiles pay (ConvTranspose dgrad 2304 -> 1152 at B = 36: 477 -> 319 us), 196 do not (B = 16: -0.9 %
+    // of the step): below that the round-1 engine's finer tiles
+    if (env != 2 && ntiles < slots - slots / 8) return IG_ERR_UNSUPPORTED;
     // ConvTranspose forward: the statically dealt 1- / 2- / 4-tap phase tiles leave the workgroups 10-25 % out of balance (the
     // round-1 engine's phases are dispatched heaviest-first by the hardware).  Measured per stage (tools/head_bench.py): it pays with
     // long reductions and many tiles (768 -> 384 at B = 216, 1152 -> 576, 576 -> 288) and at the widths the round-1 tiles fit badly

@@ -1153,6 +1153,22 @@ def test_wgrad8_plan_cache_is_pointer_free_and_capture_safe():
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 8 << 20, f"device memory shrank by {(free0 - free1) / 2**20:.1f} MiB over 2000 passes"
 
+    # more distinct shapes than the cache holds (96): least-recently-used plans are evicted (their tables freed), results stay right,
+    # and an evicted shape is simply planned again
+    xe, xer = bt(rnd(256 + 110 * 64, 256, seed=8), False)
+    dye, dyer = bt(rnd(256 + 110 * 64, 256, seed=9), False)
+    dwe = torch.zeros(256, 256, device=DEV)
+    for rep in range(2):
+        for j in range(0, 110, 1 if rep == 0 else 37):
+            Me = 256 + 64 * j
+            dwe.zero_()
+            ops.linear_wgrad(BT(dye.hi[:Me], None), BT(xe.hi[:Me], None), dwe, Me, 256, 256)
+            if j % 27 == 0:
+                assert ops.last_kernel().startswith("gemm8w_kernel"), ops.last_kernel()
+                close(dwe, dyer[:Me].t() @ xer[:Me], 3e-5, what=f"linear wgrad M={Me} (plan cache eviction)")
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] > free1 - (96 << 20)  # (the slab workspace of the widest token split: grown geometrically, kept)
+
     # a cold shape inside a capture: the grouped engine must not allocate or copy synchronously there
     M2, N2, K2 = 1408, 512, 768  # not used anywhere else in the suite
     dy, dyr = bt(rnd(M2, N2, seed=5), False)
