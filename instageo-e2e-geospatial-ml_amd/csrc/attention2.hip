@@ -829,13 +829,10 @@ int ig_attention2_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi
     if (split) IG_A2_BWD(true) else IG_A2_BWD(false)
 #undef IG_A2_BWD
     if (dbias) {
-        // bias gradient of the fused qkv Linear = column sums of dqkv over the tokens, in three parts (see the fused kernel): Q = column
-        // sums of the dQ third of dqkv; K = 0 exactly (the rows of dS sum to zero); V = sum_q dO[q] (the rows of P sum to one) --
-        // two passes over M x D instead of one over M x 3D
-        const int D = H * 64;
-        int rc = ig_colsum_ld(dqkv_hi, dqkv_lo, dbias, (long)B * N, D, 3L * D, stream);
-        if (rc != IG_OK) return rc;
-        rc = ig_colsum_ld(dout_hi, dout_lo, dbias + 2 * D, (long)B * N, D, D, stream);
+        // (round 4, measured and not kept: Q part = column sums of the dQ third, K part = 0, V part = column sums of dO -- two passes over
+        // M x D instead of one over M x 3D -- is SLOWER at T = 3 / B = 36: 2 x 30.8 us against 41.9 us, the pass is bound by its launch and
+        // its final atomics at this size, not by the bytes)
+        const int rc = ig_colsum(dqkv_hi, dqkv_lo, dbias, (long)B * N, 3 * H * 64, stream);
         if (rc != IG_OK) return rc;
     }
     return ig_check_launch("ig_attention_bwd(attn2)");

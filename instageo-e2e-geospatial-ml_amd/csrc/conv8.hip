@@ -444,32 +444,34 @@ struct C8Plan {
     int ktab_n;
 };
 
+// chunk table behind its 32-word header of per-phase constants (one workgroup)
+__device__ void conv8_build_table(int* __restrict__ ktab, const C8Plan& pl) {
+    if (threadIdx.x < 32) {
+        const int ph = threadIdx.x >> 3, f = threadIdx.x & 7, q = ph < pl.nphase ? ph : 0;
+        const int v = f == 0 ? pl.kpad[q] / 64 : f == 1 ? pl.toff[q] : f == 2 ? pl.kpad[q] : f == 3 ? (int)(pl.boff[q] & 0xffffffffL)
+                      : f == 4 ? (int)(pl.boff[q] >> 32) : 0;
+        ktab[threadIdx.x] = v;
+    }
+    for (int ph = 0; ph < pl.nphase; ++ph)
+        for (int j = threadIdx.x; j < pl.kpad[ph] / 8; j += blockDim.x) {
+            const int k = j * 8, tl = k / pl.C;
+            int e = 31;
+            if (tl < pl.ntaps[ph]) {
+                const int b = pl.bit[ph][tl], c = k - tl * pl.C;
+                const int d16 = ((pl.ddy[b] * pl.Ws + pl.ddx[b]) * pl.C + c) / 8;  // 16-byte units (C % 8 == 0)
+                e = (int)((unsigned)d16 << 8) | b;
+            }
+            ktab[32 + pl.toff[ph] + j] = e;
+        }
+}
 // straight pack: one workgroup per (phase, n) row; 16-byte units.  Also builds the table (blockIdx.x == rows_total).
 __global__ __launch_bounds__(256) void conv8_pack_rows_kernel(const bf16_t* __restrict__ w_hi, const bf16_t* __restrict__ w_lo,
                                                               bf16_t* __restrict__ d_hi, bf16_t* __restrict__ d_lo, int* __restrict__ ktab, C8Plan pl) {
     const int row = blockIdx.x;
     if (row == pl.rows_total) {  // chunk table behind its 32-word header of per-phase constants
-        if (blockIdx.y) return;
-        if (threadIdx.x < 32) {
-            const int ph = threadIdx.x >> 3, f = threadIdx.x & 7, q = ph < pl.nphase ? ph : 0;
-            const int v = f == 0 ? pl.kpad[q] / 64 : f == 1 ? pl.toff[q] : f == 2 ? pl.kpad[q] : f == 3 ? (int)(pl.boff[q] & 0xffffffffL)
-                          : f == 4 ? (int)(pl.boff[q] >> 32) : 0;
-            ktab[threadIdx.x] = v;
-        }
-        for (int ph = 0; ph < pl.nphase; ++ph)
-            for (int j = threadIdx.x; j < pl.kpad[ph] / 8; j += blockDim.x) {
-                const int k = j * 8, tl = k / pl.C;
-                int e = 31;
-                if (tl < pl.ntaps[ph]) {
-                    const int b = pl.bit[ph][tl], c = k - tl * pl.C;
-                    const int d16 = ((pl.ddy[b] * pl.Ws + pl.ddx[b]) * pl.C + c) / 8;  // 16-byte units (C % 8 == 0)
-                    e = (int)((unsigned)d16 << 8) | b;
-                }
-                ktab[32 + pl.toff[ph] + j] = e;
-            }
+        if (blockIdx.y == 0) conv8_build_table(ktab, pl);
         return;
     }
-    if (pl.transposed) return;
     const int ph = row / pl.N, n = row - ph * pl.N;
     const bf16_t* src = blockIdx.y ? w_lo : w_hi;
     bf16_t* dst = (blockIdx.y ? d_lo : d_hi) + pl.boff[ph] + (long)n * pl.kpad[ph];
@@ -483,9 +485,13 @@ __global__ __launch_bounds__(256) void conv8_pack_rows_kernel(const bf16_t* __re
 // transposed pack (data gradients): per tap a [C = Cout][N = Cin] -> [N][C] tile transpose through LDS; blockIdx.z = tap (9: the
 // zero padding of the rows' tails)
 __global__ __launch_bounds__(256) void conv8_pack_tr_kernel(const bf16_t* __restrict__ w_hi, const bf16_t* __restrict__ w_lo,
-                                                            bf16_t* __restrict__ d_hi, bf16_t* __restrict__ d_lo, C8Plan pl) {
+                                                            bf16_t* __restrict__ d_hi, bf16_t* __restrict__ d_lo, int* __restrict__ ktab, C8Plan pl) {
     __shared__ bf16_t tile[64][66];
     const int t = threadIdx.x;
+    if (blockIdx.z == gridDim.z - 1) {  // last z slice: the chunk table behind its header (one launch instead of two per data gradient)
+        if (blockIdx.x == 0 && blockIdx.y == 0) conv8_build_table(ktab, pl);
+        return;
+    }
     const int split = blockIdx.z / 10, tap = blockIdx.z - split * 10;
     const bf16_t* src = split ? w_lo : w_hi;
     bf16_t* dst = split ? d_lo : d_hi;
@@ -678,13 +684,12 @@ int ig_conv8(int kind, int sign, const void* x_hi, const void* x_lo, const void*
     bf16_t* p_lo = w_lo ? (bf16_t*)(scratch + wbytes) : nullptr;
     int* ktab = (int*)(scratch + wbytes * (w_lo ? 2 : 1));
 
-    C8Plan q = pl;
-    if (pl.transposed) q.rows_total = 0;  // the rows come from the transposing kernel; this launch only builds the table
-    hipLaunchKernelGGL(conv8_pack_rows_kernel, dim3(q.rows_total + 1, (w_lo && !pl.transposed) ? 2 : 1), dim3(256), 0, st, (const bf16_t*)w_hi,
-                       (const bf16_t*)w_lo, p_hi, p_lo, ktab, q);
-    if (pl.transposed)
-        hipLaunchKernelGGL(conv8_pack_tr_kernel, dim3((N + 63) / 64, (C + 63) / 64, 10 * (w_lo ? 2 : 1)), dim3(256), 0, st, (const bf16_t*)w_hi,
-                           (const bf16_t*)w_lo, p_hi, p_lo, pl);
+    if (pl.transposed)  // (z: 10 slices per precision half -- 9 taps + the zero padding -- and one more for the chunk table)
+        hipLaunchKernelGGL(conv8_pack_tr_kernel, dim3((N + 63) / 64, (C + 63) / 64, 10 * (w_lo ? 2 : 1) + 1), dim3(256), 0, st, (const bf16_t*)w_hi,
+                           (const bf16_t*)w_lo, p_hi, p_lo, ktab, pl);
+    else
+        hipLaunchKernelGGL(conv8_pack_rows_kernel, dim3(pl.rows_total + 1, w_lo ? 2 : 1), dim3(256), 0, st, (const bf16_t*)w_hi, (const bf16_t*)w_lo,
+                           p_hi, p_lo, ktab, pl);
 
     C8Params p{};
     p.a[0] = (const bf16_t*)x_hi, p.a[1] = (const bf16_t*)x_lo;

@@ -158,7 +158,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._early_done: List[Tuple[int, int]] = []
         return self._early_ready
 
-    EARLY_MIN = 4 << 20
+    EARLY_MIN = 12 << 20  # elements per launch: a handful of launches per step (each notification below it only extends the pending range)
 
     def _early_ready(self, lo: int, hi: int) -> None:
         lo, hi = max(lo, self.lo), min(hi, self.hi)
