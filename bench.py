@@ -66,7 +66,7 @@ GEMM_OPS = ["ig_linear_fwd", "ig_linear_residual_fwd", "ig_linear_dgrad", "ig_li
             "ig_convT_fwd", "ig_convT_dgrad", "ig_convT_wgrad", "ig_conv3x3_fwd", "ig_conv3x3_dgrad", "ig_conv3x3_wgrad",
             "ig_patch_embed_fwd"]  # fmt: skip
 HBM_OPS = ["ig_normalize_chips", "ig_layernorm_fwd", "ig_layernorm_bwd", "ig_colsum", "ig_bn_relu_fwd", "ig_bn_relu_bwd",
-           "ig_classifier_fwd", "ig_classifier_bwd", "ig_ce_loss", "ig_adamw_step"]
+           "ig_classifier_fwd", "ig_classifier_bwd", "ig_classifier_bn_fwd", "ig_classifier_bn_bwd", "ig_ce_loss", "ig_adamw_step"]
 GEMM_OPS.append("ig_linear_wgrad_group")
 TIMED_OPS = ["ig_linear_fwd", "ig_linear_residual_fwd", "ig_linear_dgrad", "ig_linear_wgrad", "ig_linear_wgrad_group"]
 

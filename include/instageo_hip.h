@@ -171,6 +171,13 @@ int ig_convT_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const
 int ig_conv3x3_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
                    const float* bn_scale, const float* bn_shift, void* y_hi, void* y_lo, int B, int H, int W, int Cin, int Cout,
                    void* stream);
+/* the same in front of a training-mode nn.BatchNorm2d (:376): where the direct 48-channel kernel runs, the convolution also leaves
+ * sums[2 Cout] (per-channel sum / sum of squares of the stored outputs) and sets *fused = 1 (HOST int); else *fused = 0 */
+int ig_conv3x3_fwd_stats(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias, void* y_hi,
+                         void* y_lo, double* sums, int* fused, int B, int H, int W, int Cin, int Cout, void* stream);
+/* batch statistics -> scale / shift / mean / rstd (+ running update) from sums a producer filled (finalize step of ig_bn_relu_fwd) */
+int ig_bn_finalize(const double* sums, const float* gamma, const float* beta, float* running_mean, float* running_var, float* scale,
+                   float* shift, float* mean, float* rstd, long M, int C, float eps, float momentum, int update_running, void* stream);
 int ig_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float* scale,
                       float* shift, int C, float eps, void* stream);
 int ig_conv3x3_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, const void* w_lo, void* dx_hi, void* dx_lo, int B,
@@ -196,12 +203,23 @@ int ig_bn_relu_fwd(const void* x_hi, const void* x_lo, const float* gamma, const
 int ig_bn_relu_bwd(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, const float* scale,
                    const float* shift, const float* mean, const float* rstd, void* dx_hi, void* dx_lo, float* dgamma,
                    float* dbeta, double* sums, long M, int C, void* stream);
+/* y_hi == NULL: batch statistics + scale / shift / mean / rstd (+ running update) only, no apply pass (ig_classifier_bn_fwd applies) */
 /* nn.Dropout(p) + nn.Conv2d(k=1): f (B,HW,C) -> logits (B,ncls,HW) f32                                 :388-389 */
 int ig_classifier_fwd(const void* f_hi, const void* f_lo, const float* w, const float* bias, float* logits, int B, long HW, int C,
                       int ncls, unsigned drop_seed, const unsigned* drop_seed_dev, float drop_p, void* stream);
 int ig_classifier_bwd(const float* dlogits, const void* f_hi, const void* f_lo, const float* w, void* df_hi, void* df_lo,
                       float* dw, float* db, const double* count, int B, long HW, int C, int ncls, unsigned drop_seed,
                       const unsigned* drop_seed_dev, float drop_p, void* stream);
+/* training-mode tail of the head in fused passes: the last stage's nn.BatchNorm2d + nn.ReLU (:376-377) applied inside the
+ * nn.Dropout + nn.Conv2d(k=1) kernels (:388-389); x = that stage's Conv2d output.  The activation between them and its gradient
+ * are recomputed, never stored.  Backward: classifier dW / db + the BatchNorm sums in one pass over x, dx + dgamma / dbeta in a second. */
+int ig_classifier_bn_fwd(const void* x_hi, const void* x_lo, const float* scale, const float* shift, const float* w, const float* bias,
+                         float* logits, int B, long HW, int C, int ncls, unsigned drop_seed, const unsigned* drop_seed_dev, float drop_p,
+                         void* stream);
+int ig_classifier_bn_bwd(const float* dlogits, const void* x_hi, const void* x_lo, const float* scale, const float* shift,
+                         const float* mean, const float* rstd, const float* w, void* dx_hi, void* dx_lo, float* dw, float* db,
+                         float* dgamma, float* dbeta, double* sums, const double* count, int B, long HW, int C, int ncls,
+                         unsigned drop_seed, const unsigned* drop_seed_dev, float drop_p, void* stream);
 
 /* ---- task module (instageo/model/segmentation.py, metrics.py, infer_utils.py, base.py) --------------- */
 /* CE(weight, ignore_index,'none') + masked mean pieces, argmax, int64 confusion matrix   segmentation.py:85-87,117-151 */

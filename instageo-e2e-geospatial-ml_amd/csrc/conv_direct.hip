@@ -24,6 +24,7 @@
 // The data gradient is the same kernel over dy with the weights gathered as W'[ci][8 - tap][co] at LDS-fill time.
 // Results are those of the implicit-GEMM path up to fp32 summation order (same bf16 operands, fp32 accumulation).
 #include "common.h"
+#include "bn_fold.h"
 
 namespace {
 
@@ -78,6 +79,9 @@ struct CDParams {
     uint32_t drop_seed, drop_thresh;
     const uint32_t* drop_seed_dev;
     float drop_inv;
+    // optional (conv3x3_direct_kernel): per-workgroup partial sums [gridDim.x][2C] of the STORED (bf16-rounded) outputs and their
+    // squares -- the statistics pass of the training-mode BatchNorm that follows, without its read of the tensor
+    float* stats_part;
 };
 
 template <int C>
@@ -202,6 +206,12 @@ __global__ __launch_bounds__(CD_TPB, 2) void conv3x3_direct_kernel(CDParams p) {
         }
     };
 
+    // BatchNorm statistics of this lane's channels (fixed over the tiles: 8 per block pair + 4 of an unpaired last block)
+    constexpr int NS = G::NPAIR * 8 + (G::NB & 1) * 4;
+    float st_s[NS], st_q[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) st_s[k] = 0.f, st_q[k] = 0.f;
+    const bool want_stats = p.stats_part != nullptr;
     // output element offset of this lane's pixel (row 4*wave of the tile, column j) relative to the tile origin, + channel 8g
     const int e_lane = ((wave * 4) * p.W + j) * C;
     const int nt = (int)p.ntiles, gstep = (int)gridDim.x;
@@ -262,7 +272,14 @@ __global__ __launch_bounds__(CD_TPB, 2) void conv3x3_direct_kernel(CDParams p) {
                     float v[8];
                     finish4(acc[2 * pr][mb], n, idx, v);
                     finish4(acc[2 * pr + 1][mb], n + 4, idx + 4, v + 4);
-                    *reinterpret_cast<uint4*>(p.y + idx) = pack8(v);
+                    const uint4 pk = pack8(v);
+                    *reinterpret_cast<uint4*>(p.y + idx) = pk;
+                    if (want_stats) {
+                        float r[8];
+                        unpack8(pk, r);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) st_s[pr * 8 + i] += r[i], st_q[pr * 8 + i] = fmaf(r[i], r[i], st_q[pr * 8 + i]);
+                    }
                 }
                 if (G::NB & 1) {
                     const int n = (G::NB - 1) * 16 + 4 * g;
@@ -270,14 +287,44 @@ __global__ __launch_bounds__(CD_TPB, 2) void conv3x3_direct_kernel(CDParams p) {
                     float v[4];
                     finish4(acc[G::NB - 1][mb], n, idx, v);
                     store4_split(p.y, nullptr, idx, v);
+                    if (want_stats) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float r = bf2f(f2bf(v[i]));
+                            st_s[G::NPAIR * 8 + i] += r, st_q[G::NPAIR * 8 + i] = fmaf(r, r, st_q[G::NPAIR * 8 + i]);
+                        }
+                    }
                 }
             }
+        }
+    }
+    if (want_stats) {  // lanes j of a k-group -> wave -> workgroup, all in a fixed order (the tile schedule is static too)
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) st_s[k] += __shfl_xor(st_s[k], o, 64), st_q[k] += __shfl_xor(st_q[k], o, 64);
+        }
+        __syncthreads();  // the halo buffer is dead
+        float* red = reinterpret_cast<float*>(hal);  // [wave][g][NS][2]
+        if (j == 0) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) red[((wave * 4 + g) * NS + k) * 2] = st_s[k], red[((wave * 4 + g) * NS + k) * 2 + 1] = st_q[k];
+        }
+        __syncthreads();
+        for (int c = tid; c < C; c += CD_TPB) {
+            int gg, k;
+            if (c < G::NPAIR * 32) gg = (c % 32) / 8, k = (c / 32) * 8 + c % 8;
+            else gg = (c - (G::NB - 1) * 16) / 4, k = G::NPAIR * 8 + (c - (G::NB - 1) * 16) % 4;
+            float ss = 0.f, qq = 0.f;
+            for (int w = 0; w < CD_TPB / 64; ++w) ss += red[((w * 4 + gg) * NS + k) * 2], qq += red[((w * 4 + gg) * NS + k) * 2 + 1];
+            p.stats_part[(size_t)blockIdx.x * 2 * C + c] = ss;
+            p.stats_part[(size_t)blockIdx.x * 2 * C + C + c] = qq;
         }
     }
 }
 
 template <int C>
-int launch_direct(const CDParams& p, hipStream_t st, const char* what) {
+int launch_direct(CDParams p, hipStream_t st, const char* what, double* stat_sums = nullptr) {
     using G = CDCfg<C>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -287,8 +334,16 @@ int launch_direct(const CDParams& p, hipStream_t st, const char* what) {
     static const int nwg_env = getenv("IG_CONV_DIRECT_WGS") ? atoi(getenv("IG_CONV_DIRECT_WGS")) : 0;
     long nwg = nwg_env > 0 ? nwg_env : 512;  // two persistent workgroups per CU
     if (nwg > p.ntiles) nwg = p.ntiles;
+    if (stat_sums) {
+        p.stats_part = (float*)ig_scratch(0, (size_t)nwg * 2 * C * sizeof(float));
+        if (!p.stats_part) {
+            ig_set_error("%s: scratch allocation failed", what);
+            return IG_ERR_HIP;
+        }
+    }
     ig_note_kernel("conv3x3_direct_kernel<%d>", C);
     hipLaunchKernelGGL(conv3x3_direct_kernel<C>, dim3((unsigned)nwg), dim3(CD_TPB), G::SMEM, st, p);
+    if (stat_sums) hipLaunchKernelGGL(bn_part_fold_kernel, dim3(ig_cdiv(2 * C, 64)), dim3(1024), 0, st, p.stats_part, stat_sums, (int)nwg, 2 * C);
     return ig_check_launch(what);
 }
 
@@ -1576,7 +1631,8 @@ static const bf16_t* cd_zero_page() {
 // (without setting the error string) when it does not, and the caller falls through to the implicit GEMM.
 int ig_conv3x3_direct(const void* x, const void* w, const float* bias, const float* bn_scale, const float* bn_shift, void* y,
                       int B, int H, int W, int Cin, int Cout, int dgrad, unsigned drop_seed, const unsigned* drop_seed_dev,
-                      float drop_p, void* stream) {
+                      float drop_p, void* stream, double* stat_sums, int* stats_fused) {
+    if (stats_fused) *stats_fused = 0;
     static const int enabled = getenv("IG_CONV_DIRECT") ? atoi(getenv("IG_CONV_DIRECT")) : 1;
     static const int use96 = getenv("IG_CD_96") ? atoi(getenv("IG_CD_96")) : 1;
     if (!enabled || Cin != Cout || (Cin != 48 && !(Cin == 96 && use96))) return IG_ERR_UNSUPPORTED;
@@ -1611,7 +1667,10 @@ int ig_conv3x3_direct(const void* x, const void* w, const float* bias, const flo
         hipLaunchKernelGGL(conv3x3_direct_slice_kernel<96>, dim3((unsigned)nwg, 2), dim3(576), smem96, (hipStream_t)stream, p, zp);
         return ig_check_launch(dgrad ? "ig_conv3x3_dgrad(direct, slices)" : "ig_conv3x3_fwd(direct, slices)");
     }
-    return launch_direct<48>(p, (hipStream_t)stream, dgrad ? "ig_conv3x3_dgrad(direct)" : "ig_conv3x3_fwd(direct)");
+    static const int fuse_stats = getenv("IG_CONV_STATS") ? atoi(getenv("IG_CONV_STATS")) : 1;
+    const bool st = stat_sums && stats_fused && fuse_stats && !dgrad;
+    if (st) *stats_fused = 1;
+    return launch_direct<48>(p, (hipStream_t)stream, dgrad ? "ig_conv3x3_dgrad(direct)" : "ig_conv3x3_fwd(direct)", st ? stat_sums : nullptr);
 }
 
 // Called by ig_conv3x3_wgrad (gemm.hip); IG_ERR_UNSUPPORTED when the shape is not covered.

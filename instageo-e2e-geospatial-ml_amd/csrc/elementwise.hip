@@ -5,6 +5,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "bn_fold.h"
 
 namespace {
 
@@ -849,31 +850,6 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const bf16_t* __rest
         else atomicAdd(sums + i, (double)t);
     }
 }
-// deterministic mode: sums[i] = sum over the workgroups of the reduce pass of part[wg][i], in a fixed order (strided subsets
-// per column in wg order, folded in subset order) -- the float atomics of the default mode arrive in any order, and a fixed-point
-// integer sum has no range for both the forward moments (up to 1e10) and the backward ones (down to 1e-9)
-__global__ __launch_bounds__(1024) void bn_part_fold_kernel(const float* __restrict__ part, double* __restrict__ sums, int nwg, int n) {
-    // 64 columns x 16 row subsets per workgroup; every thread keeps four independent partial sums so that its loads overlap
-    __shared__ double sub[16][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
-    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-    if (c < n) {
-        int w = g;
-        for (; w + 48 < nwg; w += 64) {
-            t0 += (double)part[(size_t)w * n + c], t1 += (double)part[(size_t)(w + 16) * n + c];
-            t2 += (double)part[(size_t)(w + 32) * n + c], t3 += (double)part[(size_t)(w + 48) * n + c];
-        }
-        for (; w < nwg; w += 16) t0 += (double)part[(size_t)w * n + c];
-    }
-    sub[g][threadIdx.x & 63] = (t0 + t1) + (t2 + t3);
-    __syncthreads();
-    if (g == 0 && c < n) {
-        double t = 0.0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) t += sub[q][threadIdx.x];
-        sums[c] = t;
-    }
-}
 // backward pass 2: dx = scale*(dyr - sum_dy/n - xhat*sum_dyxhat/n); also emits dgamma/dbeta once (block 0).
 // Same thread -> fixed-channel-unit walk as the forward apply: six per-channel constants live in registers.
 __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const bf16_t* __restrict__ xh, const bf16_t* __restrict__ xl,
@@ -1287,7 +1263,7 @@ static inline int bn_apply_rows(int C) {
 int ig_bn_relu_fwd(const void* x_hi, const void* x_lo, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, void* y_hi, void* y_lo, float* scale, float* shift, float* mean, float* rstd,
                    double* sums, long M, int C, float eps, float momentum, int training, int update_running, void* stream) {
-    IG_REQUIRE(x_hi && gamma && beta && running_mean && running_var && y_hi && scale && shift && sums, "ig_bn_relu_fwd: null pointer");
+    IG_REQUIRE(x_hi && gamma && beta && running_mean && running_var && scale && shift && sums, "ig_bn_relu_fwd: null pointer");
     IG_REQUIRE(C % 8 == 0 && C <= 4096, "ig_bn_relu_fwd: C must be a multiple of 8 and <= 4096 (got %d)", C);
     if (M == 0) return IG_OK;
     if (training) {
@@ -1305,10 +1281,22 @@ int ig_bn_relu_fwd(const void* x_hi, const void* x_lo, const float* gamma, const
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(ig_cdiv(C, TPB)), dim3(TPB), 0, ST(stream), sums, gamma, beta, running_mean,
                        running_var, scale, shift, mean, rstd, (double)M, C, eps, momentum, training, update_running);
+    if (!y_hi) return ig_check_launch("ig_bn_relu_fwd");  // statistics only: the consumer applies scale / shift itself (ig_classifier_bn_fwd)
     const int arpb = bn_apply_rows(C);
     hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(ig_cdiv(M, arpb)), dim3(TPB), 0, ST(stream), (const bf16_t*)x_hi,
                        (const bf16_t*)x_lo, scale, shift, (bf16_t*)y_hi, (bf16_t*)y_lo, M, C, arpb);
     return ig_check_launch("ig_bn_relu_fwd");
+}
+
+// Training-mode statistics -> scale / shift / mean / rstd (+ running update) from sums[2C] that a producer has already filled
+// (ig_conv3x3_fwd_stats): the finalize step of ig_bn_relu_fwd alone.
+int ig_bn_finalize(const double* sums, const float* gamma, const float* beta, float* running_mean, float* running_var, float* scale,
+                   float* shift, float* mean, float* rstd, long M, int C, float eps, float momentum, int update_running, void* stream) {
+    IG_REQUIRE(sums && gamma && beta && running_mean && running_var && scale && shift, "ig_bn_finalize: null pointer");
+    if (M == 0 || C == 0) return IG_OK;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ig_cdiv(C, TPB)), dim3(TPB), 0, ST(stream), sums, gamma, beta, running_mean, running_var,
+                       scale, shift, mean, rstd, (double)M, C, eps, momentum, 1, update_running);
+    return ig_check_launch("ig_bn_finalize");
 }
 
 // BatchNorm(+ReLU) backward (training statistics): x = saved conv output, dy = grad of the ReLU output

@@ -1909,6 +1909,21 @@ int ig_conv3x3_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const v
         (hipStream_t)stream, "ig_conv3x3_fwd", false, conv_version(Cout));
 }
 
+// The same convolution in front of a training-mode BatchNorm: where the direct kernel runs (the 48-channel last stage) it also
+// leaves sums[2 Cout] = per-channel sum and sum of squares of the stored outputs and sets *fused = 1 (host int); otherwise
+// *fused = 0 and the caller runs the statistics pass (ig_bn_relu_fwd with y == NULL).
+int ig_conv3x3_fwd_stats(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias, void* y_hi,
+                         void* y_lo, double* sums, int* fused, int B, int H, int W, int Cin, int Cout, void* stream) {
+    IG_REQUIRE(x_hi && w_hi && y_hi && sums && fused, "ig_conv3x3_fwd_stats: null pointer");
+    *fused = 0;
+    if (!x_lo && !y_lo && Cin % 8 == 0 && Cout % 8 == 0 && (x_lo == nullptr) == (w_lo == nullptr)) {
+        const int rc = ig_conv3x3_direct(x_hi, w_hi, bias, nullptr, nullptr, y_hi, B, H, W, Cin, Cout, 0, 0, nullptr, 0.f, stream, sums, fused);
+        if (rc != IG_ERR_UNSUPPORTED) return rc;
+    }
+    *fused = 0;
+    return ig_conv3x3_fwd(x_hi, x_lo, w_hi, w_lo, bias, nullptr, nullptr, y_hi, y_lo, B, H, W, Cin, Cout, stream);
+}
+
 // dx = conv_dgrad(dy, w) [* dropout mask of the conv input when drop_p > 0]
 int ig_conv3x3_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, const void* w_lo, void* dx_hi, void* dx_lo,
                      int B, int H, int W, int Cin, int Cout, unsigned drop_seed, const unsigned* drop_seed_dev, float drop_p,

@@ -5,6 +5,7 @@
 //   K16 argmax / softmax                                              segmentation.py:125-126, infer_utils.py:99-101
 //   K17 np.bincount(y_true*k + y_pred) confusion matrix (int64)       metrics.py:86-108
 #include "common.h"
+#include "bn_fold.h"
 
 namespace {
 
@@ -102,14 +103,22 @@ __global__ __launch_bounds__(TPB) void classifier_fwd_kernel(const bf16_t* __res
                                                              const float* __restrict__ w, const float* __restrict__ bias,
                                                              float* __restrict__ logits, long M, long HW, int C, int ncls,
                                                              uint32_t drop_seed, const uint32_t* drop_seed_dev, uint32_t drop_thresh,
-                                                             float drop_inv) {
-    extern __shared__ __attribute__((aligned(16))) float sw[];  // [ncls][C] + [ncls] (padded to 4) | staged pixel chunk (hi [, lo])
+                                                             float drop_inv, const float* __restrict__ bn_scale,
+                                                             const float* __restrict__ bn_shift) {
+    // [ncls][C] + [ncls] (padded to 4) [+ BatchNorm scale [C], shift [C]] | staged pixel chunk (hi [, lo])
+    extern __shared__ __attribute__((aligned(16))) float sw[];
     if (drop_seed_dev) drop_seed += *drop_seed_dev;
     const int units = C / 8;
     const int cmax = min(units, CLS_CHUNK / 8), pitch = cmax * 16 + 16;  // bytes per staged pixel row
-    char* stage = reinterpret_cast<char*>(sw + ncls * C + ((ncls + 3) & ~3));
+    const float* sbn = sw + ncls * C + ((ncls + 3) & ~3);
+    char* stage = reinterpret_cast<char*>(sw + ncls * C + ((ncls + 3) & ~3) + (bn_scale ? 2 * C : 0));
     for (int i = threadIdx.x; i < ncls * C; i += TPB) sw[i] = w[i];
     for (int i = threadIdx.x; i < ncls; i += TPB) sw[ncls * C + i] = bias[i];
+    if (bn_scale)
+        for (int i = threadIdx.x; i < C; i += TPB) {
+            sw[ncls * C + ((ncls + 3) & ~3) + i] = bn_scale[i];
+            sw[ncls * C + ((ncls + 3) & ~3) + C + i] = bn_shift[i];
+        }
     const long m0 = blockIdx.x * (long)TPB;
     const int npix = (int)min((long)TPB, M - m0);
     const long m = m0 + threadIdx.x;
@@ -137,6 +146,11 @@ __global__ __launch_bounds__(TPB) void classifier_fwd_kernel(const bf16_t* __res
                 unpack8(*reinterpret_cast<const uint4*>(row + (size_t)TPB * pitch + c8 * 16), g);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) f[j] += g[j];
+            }
+            if (bn_scale) {  // the operand is the last Conv2d's output: training-mode BatchNorm + ReLU applied here, not in a pass of its own
+                const float* sc = sbn + (c0 + c8) * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = fmaxf(fmaf(f[j], sc[j], sc[C + j]), 0.f);
             }
             if (drop_thresh) {
                 const size_t idx = (size_t)m * C + (c0 + c8) * 8;
@@ -167,269 +181,316 @@ __global__ __launch_bounds__(TPB) void classifier_fwd_kernel(const bf16_t* __res
         if (n < ncls) logits[(b * ncls + n) * HW + pix] = acc[n];
 }
 
+// Training-mode BatchNorm2d + ReLU in front of the classifier, fused into its kernels (MODE template argument of the backward kernels):
+//   MODE 0  plain classifier backward (f = the classifier's input, df = its gradient)
+//   MODE 1  f = x, the last Conv2d's output: a = relu(x*scale + shift) is recomputed, dW / db are accumulated from it, and the
+//           BatchNorm backward's two per-channel sums (dyr, dyr * xhat; dyr = d a * [a > 0]) leave as per-workgroup partials (or double
+//           atomics) -- nothing of pixel size is written
+//   MODE 2  the same recomputation, writes dx = scale*(dyr - k1 - xhat*k2) (k = sums / n) to df; no dW / db
+// so the activation between BatchNorm and the classifier and its gradient never exist in HBM (7 passes over the largest tensor of the
+// head instead of 11 with the separate BatchNorm kernels).
+struct ClsBn {
+    const float *scale, *shift, *mean, *rstd;
+    double* sums;   // [2C]: MODE 1 adds to it when part == NULL, MODE 2 reads it
+    float* part;    // MODE 1, deterministic mode: [workgroups][2C] partials (bn_part_fold_kernel sums them in index order)
+    float *dgamma, *dbeta;
+    double inv_n;
+};
+
 // df[m][c] = drop_mask * sum_n dl[b][n][pix] * w[n][c] * gscale ; dW[n][c] += sum_m dl*f_dropped ; db[n] += sum_m dl
 // gscale = 1/(*count) when count != NULL (fused trainer: dlogits left un-normalised by the loss kernel).
-// A thread owns ONE 8-channel unit and walks `iters` pixels (stride = pixel slices per block), so dW partials stay in
-// registers and are reduced once per block (a thread-per-pixel version spent its time in 96 wave reductions per pixel).
-template <int NC>  // class-count bucket (register accumulators are NC x 8)
-__global__ __launch_bounds__(TPB) void classifier_bwd_kernel(const float* __restrict__ dl, const bf16_t* __restrict__ f_hi,
-                                                             const bf16_t* __restrict__ f_lo, const float* __restrict__ w,
-                                                             bf16_t* __restrict__ df_hi, bf16_t* __restrict__ df_lo,
-                                                             float* __restrict__ dw, float* __restrict__ db, const double* count,
-                                                             long M, long HW, int C, int ncls, uint32_t drop_seed,
-                                                             const uint32_t* drop_seed_dev, uint32_t drop_thresh, float drop_inv,
-                                                             int iters, int slab) {
-    // w[ncls*C] | dbacc[ncls] (padded to 4, 64-bit fixed point) | dW partials: one [ncls*C] slab per pixel slice when `slab` (plain stores; LDS
-    // float atomics retire only a few lanes per cycle), else a single [ncls*C] accumulated with atomics
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    if (drop_seed_dev) drop_seed += *drop_seed_dev;
-    float* sw = sm;
-    unsigned long long* sdbq = reinterpret_cast<unsigned long long*>(sm + ncls * C);  // [ncls] padded to 4 (C % 8 == 0: 8-byte aligned)
-    float* sdw = sm + ncls * C + 2 * ((ncls + 3) & ~3);
-    for (int i = threadIdx.x; i < ncls * C; i += TPB) {
-        sw[i] = w[i];
-        if (!slab) sdw[i] = 0.f;
+//
+// These kernels look HBM-bound (one pass over the head's largest tensor) but are VALU-issue-bound unless the per-pixel overhead is
+// kept out of the loop (round 4: the previous pair of kernels spent ~40 instructions per element on 64-bit index arithmetic, pixel
+// -> (image, offset) divisions and per-class branches, and ran at 1.1-3.3 TB/s).  Structure:
+//   * a thread owns ONE unit of VEC channels (8, or 4 when 16 classes would not leave room for the NC x VEC weights AND the NC x VEC
+//     dW accumulators in registers) and walks pixels with stride nsl = 256 / (C / VEC): loads stay fully coalesced, the class weights,
+//     the BatchNorm constants and the dW partials never leave registers, the element index advances by one add per pixel;
+//   * the dlogits of IG iterations (IG * nsl consecutive pixels) are staged through LDS with coalesced loads, pre-scaled and padded to
+//     NC classes (the C / VEC threads of a pixel would each have loaded all of them, from NCHW planes); the (image, offset) split is one
+//     scalar division per group;
+//   * NC is a compile-time class bucket: the class loops are straight-line packed FMAs (padded classes multiply zeros);
+//   * at the end the dW partials of the pixel slices are folded through a 32 KiB slab, G classes per round, then leave as one
+//     order-independent add per element and workgroup (ig_red_add); db through 2^44 fixed point (NaN / Inf / huge bypass it).
+constexpr int CLS_SLAB = 8192;  // floats
+template <int VEC>
+__device__ __forceinline__ void cls_load(const bf16_t* hi, const bf16_t* lo, size_t idx, float* f) {
+    if constexpr (VEC == 8) {
+        load8_split(hi, lo, idx, f);
+    } else {
+        const uint2 u = *reinterpret_cast<const uint2*>(hi + idx);
+        f[0] = __uint_as_float(u.x << 16), f[1] = __uint_as_float(u.x & 0xffff0000u);
+        f[2] = __uint_as_float(u.y << 16), f[3] = __uint_as_float(u.y & 0xffff0000u);
+        if (lo) {
+            const uint2 v = *reinterpret_cast<const uint2*>(lo + idx);
+            f[0] += __uint_as_float(v.x << 16), f[1] += __uint_as_float(v.x & 0xffff0000u);
+            f[2] += __uint_as_float(v.y << 16), f[3] += __uint_as_float(v.y & 0xffff0000u);
+        }
     }
-    // bias-gradient partials of the pixel slices: 2^44 fixed point, so the LDS adds commute (run-to-run identical bits)
-    for (int i = threadIdx.x; i < ncls; i += TPB) sdbq[i] = 0ull;
-    __syncthreads();
-    const float gscale = count ? (float)(1.0 / fmax(count[1], 1.0)) : 1.f;
-    const int nu = C / 8, nsl = TPB / nu;
+}
+template <int VEC>
+__device__ __forceinline__ void cls_store(bf16_t* hi, bf16_t* lo, size_t idx, const float* f) {
+    if constexpr (VEC == 8) store8_split(hi, lo, idx, f);
+    else store4_split(hi, lo, idx, f);
+}
+
+// MODE: 0 plain (df + dW + db)                 1 BatchNorm reduce pass (dW + db + BatchNorm sums; ClsBn above)
+//       2 BatchNorm apply pass (dx only)         3 plain, df only            4 plain, dW + db only
+//       5 BatchNorm reduce pass in "S form" (below)
+// Modes 4 / 5 take NC classes per workgroup, blockIdx.y selects the class group (more than 8 classes: NC x VEC weights AND NC x VEC
+// accumulators do not fit the registers at a useful occupancy; a 16-class instance ran at one wave per SIMD, 0.6 TB/s).
+// S form: with pm = dropout mask * [a > 0] the per-class sums S1[n][c] = sum_m g[m][n] pm[m][c] and S2[n][c] = sum_m g[m][n] pm[m][c]
+// (x[m][c] - mu[c]) give everything the reduce pass owes WITHOUT forming d a = sum_n g w (needs all classes in one thread):
+//   dW[n][c] = sum_m g a msk = scale[c] S2[n][c] + beta[c] S1[n][c]          (a = scale (x - mu) + beta where a > 0)
+//   sum_m dyr[c] = sum_n w[n][c] S1[n][c],   sum_m dyr x_hat[c] = rstd[c] sum_n w[n][c] S2[n][c]
+// so each class group adds its part to dW, db and the BatchNorm partials independently.
+template <int NC, int VEC, int MODE>
+__global__ __launch_bounds__(TPB, VEC == 8 ? 1 : 2) void cls_bwd_kernel(const float* __restrict__ dl, const bf16_t* __restrict__ f_hi,
+                                                         const bf16_t* __restrict__ f_lo, const float* __restrict__ w,
+                                                         bf16_t* __restrict__ df_hi, bf16_t* __restrict__ df_lo, float* __restrict__ dw,
+                                                         float* __restrict__ db, const double* count, long M, long HW, int C, int ncls,
+                                                         uint32_t drop_seed, const uint32_t* drop_seed_dev, uint32_t drop_thresh,
+                                                         float drop_inv, int iters, int ig, ClsBn bn) {
+    constexpr bool HAS_BN = MODE == 1 || MODE == 2 || MODE == 5;
+    constexpr bool WANT_O = MODE <= 3;                            // d(classifier input) is formed
+    constexpr bool WANT_DW = MODE == 0 || MODE == 1 || MODE >= 4; // dW / db are accumulated
+    constexpr bool SFORM = MODE == 5;
+    // sdbq[16] (64-bit fixed point) | slab[CLS_SLAB] | sdl[NC][ig * nsl]
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    unsigned long long* sdbq = reinterpret_cast<unsigned long long*>(sm);
+    float* slab = sm + 32;
+    float* sdl = slab + CLS_SLAB;
+    if (drop_seed_dev) drop_seed += *drop_seed_dev;
+    const int nu = C / VEC, nsl = TPB / nu;
     const int u = threadIdx.x % nu, sl = threadIdx.x / nu;
-    float dwa[NC][8], dba[NC];
+    const bool live = sl < nsl;
+    const int c0 = u * VEC;
+    const int n0 = blockIdx.y * NC;          // first class of this workgroup's group (modes 4 / 5; otherwise 0)
+    const int ncl = min(NC, ncls - n0);      // classes of the group
+    if (threadIdx.x < 16) sdbq[threadIdx.x] = 0ull;
+    const float gscale = count ? (float)(1.0 / fmax(count[1], 1.0)) : 1.f;
+    float wr[WANT_O ? NC : 1][VEC], dwa[WANT_DW ? NC : 1][VEC], s1[SFORM ? NC : 1][VEC], dba[NC];
 #pragma unroll
     for (int n = 0; n < NC; ++n) {
         dba[n] = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dwa[n][j] = 0.f;
+        for (int j = 0; j < VEC; ++j) {
+            if constexpr (WANT_O) wr[n][j] = n < ncl ? w[(size_t)(n0 + n) * C + c0 + j] : 0.f;
+            if constexpr (WANT_DW) dwa[n][j] = 0.f;
+            if constexpr (SFORM) s1[n][j] = 0.f;
+        }
     }
-    if (sl < nsl) {
-        const long m0 = (long)blockIdx.x * nsl * iters + sl;
-        // UNR pixels per iteration, every load of all of them (features, dlogits) issued before the first use: with one pixel in
-        // flight per thread the kernel kept ~6 MB of loads in the air over the whole chip -- 3.1 TB/s at the HBM latency
-        constexpr int UNR = NC <= 4 ? 2 : 1;
-        for (int it = 0; it < iters; it += UNR) {
-            if (m0 + (long)it * nsl >= M) break;
-            float f[UNR][8], gq[UNR][NC];
-            size_t idxq[UNR];
-            bool ok[UNR];
+    float bsc[VEC], bsh[VEC], bmu[VEC], brs[VEC], bs[VEC], bq[VEC];  // BatchNorm constants of this unit; MODE 2: bmu = ca, brs = cb
+    if constexpr (HAS_BN) {
 #pragma unroll
-            for (int q = 0; q < UNR; ++q) {
-                const long mq = m0 + (long)(it + q) * nsl;
-                ok[q] = it + q < iters && mq < M;
-                const long m = ok[q] ? mq : m0 + (long)it * nsl;  // dead slot: harmless duplicate loads, nothing stored or summed
-                long b, pix;
-                split_pixel(m, HW, b, pix);
-                idxq[q] = (size_t)m * C + u * 8;
-                load8_split(f_hi, f_lo, idxq[q], f[q]);
-#pragma unroll
-                for (int n = 0; n < NC; ++n) gq[q][n] = n < ncls ? dl[(b * ncls + n) * HW + pix] * gscale : 0.f;
+        for (int j = 0; j < VEC; ++j) {
+            const int c = c0 + j;
+            bsc[j] = bn.scale[c], bsh[j] = bn.shift[c], bmu[j] = bn.mean[c], brs[j] = bn.rstd[c], bs[j] = 0.f, bq[j] = 0.f;
+            if constexpr (MODE == 2) {  // dx = sc*dyr - ca - cb*x  with  ca = sc*k1 - mu*cb,  cb = sc*rs*k2
+                const float k1 = (float)(bn.sums[c] * bn.inv_n), k2 = (float)(bn.sums[C + c] * bn.inv_n);
+                brs[j] = bsc[j] * brs[j] * k2;
+                bmu[j] = bsc[j] * k1 - bmu[j] * brs[j];
             }
+        }
+        if (MODE == 2 && blockIdx.x == 0)
+            for (int c = threadIdx.x; c < C; c += TPB) {
+                if (bn.dbeta) atomicAdd(bn.dbeta + c, (float)bn.sums[c]);  // one contributor per element: order-independent
+                if (bn.dgamma) atomicAdd(bn.dgamma + c, (float)bn.sums[C + c]);
+            }
+    }
+    const long mb = (long)blockIdx.x * nsl * iters;
+    const int gpx = ig * nsl;
+    const size_t estep = (size_t)nsl * C;
+    constexpr bool PIPE = VEC == 4;
+    constexpr int PF = PIPE ? 4 : 2;  // pixels per trip
+    auto process = [&](float* f, const size_t idx, const int px) __attribute__((always_inline)) {
+            float o[VEC], msk[VEC], x[VEC];
+            if (drop_thresh) {
+                dropout_scale4(drop_seed, (uint32_t)idx, drop_thresh, drop_inv, msk);
+                if constexpr (VEC == 8) dropout_scale4(drop_seed, (uint32_t)idx + 4u, drop_thresh, drop_inv, msk + 4);
+            } else {
 #pragma unroll
-            for (int q = 0; q < UNR; ++q) {
-                if (!ok[q]) continue;
-                const size_t idx = idxq[q];
-                float o[8], msk[8];
-                if (drop_thresh) {
-                    dropout_scale4(drop_seed, (uint32_t)idx, drop_thresh, drop_inv, msk);
-                    dropout_scale4(drop_seed, (uint32_t)idx + 4u, drop_thresh, drop_inv, msk + 4);
-                } else {
+                for (int j = 0; j < VEC; ++j) msk[j] = 1.f;
+            }
+            if constexpr (SFORM) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) msk[j] = 1.f;
+                for (int j = 0; j < VEC; ++j) {
+                    x[j] = f[j];
+                    msk[j] = fmaf(x[j], bsc[j], bsh[j]) > 0.f ? msk[j] : 0.f;  // pm
+                    f[j] = msk[j] * (x[j] - bmu[j]);                         // pm (x - mu)
                 }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    f[q][j] *= msk[j];
+                for (int n = 0; n < NC; ++n) {
+                    const float g = sdl[n * gpx + px];
+                    dba[n] += g;
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) s1[n][j] = fmaf(g, msk[j], s1[n][j]), dwa[n][j] = fmaf(g, f[j], dwa[n][j]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    if constexpr (HAS_BN) x[j] = f[j], f[j] = fmaxf(fmaf(x[j], bsc[j], bsh[j]), 0.f);
+                    f[j] *= msk[j];
                     o[j] = 0.f;
                 }
 #pragma unroll
                 for (int n = 0; n < NC; ++n) {
-                    if (n < ncls) {
-                        const float g = gq[q][n];
-                        const float4 w0 = *reinterpret_cast<const float4*>(sw + n * C + u * 8);
-                        const float4 w1 = *reinterpret_cast<const float4*>(sw + n * C + u * 8 + 4);
-                        const float wr[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-                        dba[n] += g;
+                    const float g = sdl[n * gpx + px];
+                    if constexpr (WANT_DW) dba[n] += g;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            o[j] += g * wr[j];
-                            dwa[n][j] += g * f[q][j];
-                        }
+                    for (int j = 0; j < VEC; ++j) {
+                        if constexpr (WANT_O) o[j] = fmaf(g, wr[n][j], o[j]);
+                        if constexpr (WANT_DW) dwa[n][j] = fmaf(g, f[j], dwa[n][j]);
                     }
                 }
+                if constexpr (WANT_O) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] *= msk[j];
-                store8_split(df_hi, df_lo, idx, o);
-            }
-        }
-#pragma unroll
-        for (int n = 0; n < NC; ++n) {
-            if (n < ncls) {
-                if (slab) {
-                    float* dst = sdw + (size_t)sl * ncls * C + n * C + u * 8;
-                    *reinterpret_cast<float4*>(dst) = make_float4(dwa[n][0], dwa[n][1], dwa[n][2], dwa[n][3]);
-                    *reinterpret_cast<float4*>(dst + 4) = make_float4(dwa[n][4], dwa[n][5], dwa[n][6], dwa[n][7]);
+                    for (int j = 0; j < VEC; ++j) o[j] *= msk[j];
                 }
-                if (u == 0) {  // non-finite / out-of-range partials bypass the fixed-point slot (ig_red_add keeps them visible)
-                    if (fabsf(dba[n]) < 5.0e5f) atomicAdd(sdbq + n, (unsigned long long)__float2ll_rn(dba[n] * 17592186044416.f));
-                    else ig_red_add(db + n, dba[n]);
+                if constexpr (MODE == 0 || MODE == 3) cls_store<VEC>(df_hi, df_lo, idx, o);
+                if constexpr (MODE == 1) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        const float dyr = fmaf(x[j], bsc[j], bsh[j]) > 0.f ? o[j] : 0.f;
+                        bs[j] += dyr;
+                        bq[j] = fmaf(dyr, x[j] - bmu[j], bq[j]);  // x_hat = (x - mu) * rstd: the factor rstd is applied once, below
+                    }
+                }
+                if constexpr (MODE == 2) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        const float dyr = fmaf(x[j], bsc[j], bsh[j]) > 0.f ? o[j] : 0.f;
+                        o[j] = fmaf(bsc[j], dyr, -fmaf(brs[j], x[j], bmu[j]));
+                    }
+                    cls_store<VEC>(df_hi, df_lo, idx, o);
+                }
+            }
+
+    };
+    for (int it0 = 0; it0 < iters; it0 += ig) {
+        const long mg = mb + (long)it0 * nsl;
+        if (mg >= M) break;  // uniform
+        const int itn = min(ig, iters - it0);
+        const int npx = (int)min((long)itn * nsl, M - mg);
+        size_t e = (size_t)(mg + sl) * C + c0;
+        float fa[PF][VEC];
+        if (PIPE && live && sl < npx) {  // first trip of the group: in flight across the dlogits staging below
+            const int nv0 = min(itn, (npx - sl + nsl - 1) / nsl);
+#pragma unroll
+            for (int k = 0; k < PF; ++k) cls_load<VEC>(f_hi, f_lo, k < nv0 ? e + (size_t)k * estep : e, fa[k]);
+        }
+        __syncthreads();  // the previous group's dlogits have been consumed (first group: sdbq is zero)
+        {
+            const long b0 = mg / HW, pix0 = mg - b0 * HW;
+#pragma unroll
+            for (int n = 0; n < NC; ++n)
+                for (int px = threadIdx.x; px < gpx; px += TPB) {
+                    float g = 0.f;
+                    if (n < ncl && px < npx) {
+                        long b = b0, pix = pix0 + px;
+                        while (pix >= HW) pix -= HW, ++b;
+                        g = dl[(b * ncls + n0 + n) * HW + pix] * gscale;
+                    }
+                    sdl[n * gpx + px] = g;
+                }
+        }
+        __syncthreads();
+        if (live) {
+            const int nv = min(itn, (npx - sl + nsl - 1) / nsl);  // this thread's pixels in the group
+            if constexpr (PIPE) {
+                // trips of PF pixels; the loads of trip t + 1 are issued before trip t is computed: the 8-byte loads of the 4-channel form
+                // left too little in flight (16-class df pass 709 -> 381 us); the 8-channel form at <= 4 classes is at the HBM rate with
+                // two pixels per step and lost occupancy to the second buffer (462 -> 708 us)
+                for (int t = 0; t < nv; t += PF) {
+                    float fb[PF][VEC];
+                    if (t + PF < nv) {
+#pragma unroll
+                        for (int k = 0; k < PF; ++k) cls_load<VEC>(f_hi, f_lo, t + PF + k < nv ? e + (size_t)(PF + k) * estep : e, fb[k]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < PF; ++k) {
+                        if (t + k < nv) process(fa[k], e + (size_t)k * estep, (t + k) * nsl + sl);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int k = 0; k < PF; ++k)
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) fa[k][j] = fb[k][j];
+                    e += (size_t)PF * estep;
+                }
+            } else {
+                for (int t = 0; t < nv; t += 2, e += 2 * estep) {  // two pixels in flight per thread
+                    const bool two = t + 1 < nv;
+                    float f[2][VEC];
+                    cls_load<VEC>(f_hi, f_lo, e, f[0]);
+                    cls_load<VEC>(f_hi, f_lo, two ? e + estep : e, f[1]);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        if (q == 1 && !two) break;
+                        process(f[q], e + q * estep, (t + q) * nsl + sl);
+                    }
                 }
             }
         }
     }
-    if (!slab) {  // no room for a slab per pixel slice: the slices add into the single image one after the other (fixed order)
-        for (int s2 = 0; s2 < nsl; ++s2) {
-            if (sl == s2) {
+    if constexpr (WANT_DW) {  // (nothing is reduced in the passes that only write df / dx)
+        if constexpr (SFORM) {  // S1, S2 -> dW and this class group's part of the BatchNorm sums
 #pragma unroll
-                for (int n = 0; n < NC; ++n) {
-                    if (n < ncls) {
+            for (int n = 0; n < NC; ++n)
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) sdw[n * C + u * 8 + j] += dwa[n][j];
-                    }
+                for (int j = 0; j < VEC; ++j) {
+                    const float wn = n < ncl ? w[(size_t)(n0 + n) * C + c0 + j] : 0.f;
+                    bs[j] = fmaf(wn, s1[n][j], bs[j]);
+                    bq[j] = fmaf(wn, dwa[n][j], bq[j]);
+                    dwa[n][j] = fmaf(bsc[j], dwa[n][j], fmaf(bmu[j], bsc[j], bsh[j]) * s1[n][j]);  // beta = shift + mu * scale
                 }
+        }
+        // ---- fold the dW partials of the pixel slices, G classes per round through the slab [nsl][G][C]
+        const int G = max(1, min(NC, CLS_SLAB / (nsl * C)));
+        for (int g0 = 0; g0 < ncl; g0 += G) {
+            __syncthreads();
+            if (live) {
+#pragma unroll
+                for (int n = 0; n < NC; ++n)
+                    if (n >= g0 && n < g0 + G) {
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) slab[((size_t)sl * G + (n - g0)) * C + c0 + j] = dwa[n][j];
+                    }
             }
             __syncthreads();
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < ncls * C; i += TPB) {
-        float t = sdw[i];
-        if (slab)
-            for (int q = 1; q < nsl; ++q) t += sdw[(size_t)q * ncls * C + i];
-        ig_red_add(dw + i, t);
-    }
-    for (int i = threadIdx.x; i < ncls; i += TPB) ig_red_add(db + i, (float)((double)(long long)sdbq[i] * 5.684341886080802e-14));
-}
-
-// Wide variant (ncls x C too large for the per-slice dW slabs above, e.g. 13 classes x 144 channels of the multi-temporal
-// head, where the fallback -- LDS float atomics -- ran at 0.76 TB/s): blockIdx.y selects a chunk of <= 48 channels, so a thread
-// still owns one 8-channel unit but there are 42 pixel slices per workgroup, and the dW partials are folded through a 32 KiB
-// slab FOUR classes at a time.  dlogits are re-read once per channel chunk (13 floats per pixel against 288 bytes of features).
-template <int NC>
-__global__ __launch_bounds__(TPB) void classifier_bwd_wide_kernel(const float* __restrict__ dl, const bf16_t* __restrict__ f_hi,
-                                                                  const bf16_t* __restrict__ f_lo, const float* __restrict__ w,
-                                                                  bf16_t* __restrict__ df_hi, bf16_t* __restrict__ df_lo,
-                                                                  float* __restrict__ dw, float* __restrict__ db, const double* count,
-                                                                  long M, long HW, int C, int ncls, uint32_t drop_seed,
-                                                                  const uint32_t* drop_seed_dev, uint32_t drop_thresh, float drop_inv,
-                                                                  int iters) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    if (drop_seed_dev) drop_seed += *drop_seed_dev;
-    const int c0 = blockIdx.y * CLS_CHUNK;            // first channel of this chunk
-    const int cw = min(CLS_CHUNK, C - c0);            // channels in the chunk
-    const int nu = cw / 8, nsl = TPB / nu;
-    float* sw = sm;                                   // [ncls][cw]
-    unsigned long long* sdbq = reinterpret_cast<unsigned long long*>(sw + ncls * CLS_CHUNK);  // [ncls] (padded to 16), 2^44 fixed point
-    float* slab = sw + ncls * CLS_CHUNK + 32;         // [nsl][4][cw]  (<= 8192 floats)
-    float* sdl = slab + TPB * 32;                     // [ncls][CLS_IG * nsl] dlogits of a group of CLS_IG iterations, pre-scaled
-    for (int i = threadIdx.x; i < ncls * cw; i += TPB) sw[i] = w[(i / cw) * C + c0 + (i % cw)];
-    for (int i = threadIdx.x; i < 16; i += TPB) sdbq[i] = 0ull;
-    __syncthreads();
-    const float gscale = count ? (float)(1.0 / fmax(count[1], 1.0)) : 1.f;
-    const int u = threadIdx.x % nu, sl = threadIdx.x / nu;
-    const bool live = sl < nsl;
-    float dwa[NC][8], dba[NC];
-#pragma unroll
-    for (int n = 0; n < NC; ++n) {
-        dba[n] = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) dwa[n][j] = 0.f;
-    }
-    // the dlogits of CLS_IG iterations (= CLS_IG * nsl consecutive pixels) are staged once per group with coalesced loads: read
-    // straight from global they were 13 loads per pixel and thread, shared by the `nu` threads of a slice and repeated per chunk
-    const long mb = (long)blockIdx.x * nsl * iters;
-    const int gpx = CLS_IG * nsl;
-    for (int it0 = 0; it0 < iters; it0 += CLS_IG) {
-        if (it0) __syncthreads();
-        const long mg = mb + (long)it0 * nsl;
-        for (int i = threadIdx.x; i < ncls * gpx; i += TPB) {
-            const int n = i / gpx, px = i - n * gpx;
-            const long m = mg + px;
-            float g = 0.f;
-            if (m < M && px < (iters - it0) * nsl) {
-                long b, pix;
-                split_pixel(m, HW, b, pix);
-                g = dl[(b * ncls + n) * HW + pix] * gscale;
-            }
-            sdl[i] = g;
-        }
-        __syncthreads();
-        if (!live) continue;
-        const int itn = min(CLS_IG, iters - it0);
-        for (int it = 0; it < itn; ++it) {
-            const int px = it * nsl + sl;
-            const long m = mg + px;
-            if (m >= M) break;
-            const size_t idx = (size_t)m * C + c0 + u * 8;
-            float f[8], o[8], msk[8];
-            load8_split(f_hi, f_lo, idx, f);
-            if (drop_thresh) {
-                dropout_scale4(drop_seed, (uint32_t)idx, drop_thresh, drop_inv, msk);
-                dropout_scale4(drop_seed, (uint32_t)idx + 4u, drop_thresh, drop_inv, msk + 4);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) msk[j] = 1.f;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                f[j] *= msk[j];
-                o[j] = 0.f;
-            }
-#pragma unroll
-            for (int n = 0; n < NC; ++n) {
-                if (n < ncls) {
-                    const float g = sdl[n * gpx + px];
-                    const float4 w0 = *reinterpret_cast<const float4*>(sw + n * cw + u * 8);
-                    const float4 w1 = *reinterpret_cast<const float4*>(sw + n * cw + u * 8 + 4);
-                    const float wr[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-                    dba[n] += g;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        o[j] += g * wr[j];
-                        dwa[n][j] += g * f[j];
-                    }
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] *= msk[j];
-            store8_split(df_hi, df_lo, idx, o);
-        }
-    }
-    if (live && blockIdx.y == 0 && u == 0) {
-#pragma unroll
-        for (int n = 0; n < NC; ++n)
-            if (n < ncls) {
-                if (fabsf(dba[n]) < 5.0e5f) atomicAdd(sdbq + n, (unsigned long long)__float2ll_rn(dba[n] * 17592186044416.f));
-                else ig_red_add(db + n, dba[n]);
-            }
-    }
-    __syncthreads();
-    // fold the dW partials of the pixel slices, four classes per pass
-#pragma unroll
-    for (int q = 0; q < NC / 4; ++q) {
-        if (4 * q >= ncls) break;
-        if (q) __syncthreads();
-        if (live) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float* dst = slab + ((size_t)sl * 4 + k) * cw + u * 8;
-                *reinterpret_cast<float4*>(dst) = make_float4(dwa[4 * q + k][0], dwa[4 * q + k][1], dwa[4 * q + k][2], dwa[4 * q + k][3]);
-                *reinterpret_cast<float4*>(dst + 4) = make_float4(dwa[4 * q + k][4], dwa[4 * q + k][5], dwa[4 * q + k][6], dwa[4 * q + k][7]);
-            }
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < 4 * cw; i += TPB) {
-            const int k = i / cw, c = i - k * cw, n = 4 * q + k;
-            if (n < ncls) {
+            const int nn = min(G, ncl - g0);
+            for (int i = threadIdx.x; i < nn * C; i += TPB) {
+                const int k = i / C, c = i - k * C;
                 float t = 0.f;
-                for (int s2 = 0; s2 < nsl; ++s2) t += slab[((size_t)s2 * 4 + k) * cw + c];
-                ig_red_add(dw + (size_t)n * C + c0 + c, t);
+                for (int s2 = 0; s2 < nsl; ++s2) t += slab[((size_t)s2 * G + k) * C + c];
+                ig_red_add(dw + (size_t)(n0 + g0 + k) * C + c, t);
+            }
+        }
+        if (live && u == 0) {  // non-finite / out-of-range partials bypass the fixed-point slot (ig_red_add keeps them visible)
+#pragma unroll
+            for (int n = 0; n < NC; ++n)
+                if (n < ncl) {
+                    if (fabsf(dba[n]) < 5.0e5f) atomicAdd(sdbq + n, (unsigned long long)__float2ll_rn(dba[n] * 17592186044416.f));
+                    else ig_red_add(db + n0 + n, dba[n]);
+                }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < ncl; i += TPB) ig_red_add(db + n0 + i, (float)((double)(long long)sdbq[i] * 5.684341886080802e-14));
+        if constexpr (MODE == 1 || SFORM) {  // BatchNorm sums of this workgroup: slab per pixel slice [nsl][2][C], folded in slice order
+            if (live) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) slab[(size_t)sl * 2 * C + c0 + j] = bs[j], slab[(size_t)sl * 2 * C + C + c0 + j] = bq[j] * brs[j];
+            }
+            __syncthreads();
+            const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+            for (int i = threadIdx.x; i < 2 * C; i += TPB) {
+                float t = 0.f;
+                for (int q = 0; q < nsl; ++q) t += slab[(size_t)q * 2 * C + i];
+                if (bn.part) bn.part[wg * 2 * C + i] = t;
+                else atomicAdd(bn.sums + i, (double)t);
             }
         }
     }
-    __syncthreads();
-    if (blockIdx.y == 0)
-        for (int i = threadIdx.x; i < ncls; i += TPB) ig_red_add(db + i, (float)((double)(long long)sdbq[i] * 5.684341886080802e-14));
 }
 
 // stats[0] += sum w_y*nll over valid pixels ; stats[1] += #valid.  dlogits (optional) is left UN-normalised:
@@ -796,14 +857,15 @@ IG_DET_TU(head)  // constant-memory descriptor of the deterministic-reduction mo
 
 extern "C" {
 
-int ig_classifier_fwd(const void* f_hi, const void* f_lo, const float* w, const float* bias, float* logits, int B, long HW, int C,
-                      int ncls, unsigned drop_seed, const unsigned* drop_seed_dev, float drop_p, void* stream) {
+static int classifier_fwd_impl(const void* f_hi, const void* f_lo, const float* bn_scale, const float* bn_shift, const float* w,
+                               const float* bias, float* logits, int B, long HW, int C, int ncls, unsigned drop_seed,
+                               const unsigned* drop_seed_dev, float drop_p, void* stream) {
     IG_REQUIRE(f_hi && w && bias && logits, "ig_classifier_fwd: null pointer");
     IG_REQUIRE(C % 8 == 0 && ncls >= 1 && ncls <= MAXC, "ig_classifier_fwd: need C %% 8 == 0 and 1 <= ncls <= %d (C=%d ncls=%d)", MAXC, C, ncls);
     long M = (long)B * HW;
     if (M == 0) return IG_OK;
     const int cmax = C / 8 < CLS_CHUNK / 8 ? C / 8 : CLS_CHUNK / 8;
-    size_t sm = ((size_t)ncls * C + ((ncls + 3) & ~3)) * sizeof(float) + (size_t)TPB * (cmax * 16 + 16) * (f_lo ? 2 : 1);
+    size_t sm = ((size_t)ncls * C + ((ncls + 3) & ~3) + (bn_scale ? 2 * (size_t)C : 0)) * sizeof(float) + (size_t)TPB * (cmax * 16 + 16) * (f_lo ? 2 : 1);
     IG_REQUIRE(sm <= 160 * 1024, "ig_classifier_fwd: ncls x C = %d x %d weights do not fit the LDS", ncls, C);
     static bool attr_done = false;
     if (!attr_done) {
@@ -812,64 +874,119 @@ int ig_classifier_fwd(const void* f_hi, const void* f_lo, const float* w, const 
     }
     hipLaunchKernelGGL(classifier_fwd_kernel, dim3((unsigned)((M + TPB - 1) / TPB)), dim3(TPB), sm, (hipStream_t)stream,
                        (const bf16_t*)f_hi, (const bf16_t*)f_lo, w, bias, logits, M, HW, C, ncls, drop_seed, drop_seed_dev, thresh_of(drop_p),
-                       drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f);
+                       drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, bn_scale, bn_shift);
     return ig_check_launch("ig_classifier_fwd");
 }
 
+int ig_classifier_fwd(const void* f_hi, const void* f_lo, const float* w, const float* bias, float* logits, int B, long HW, int C,
+                      int ncls, unsigned drop_seed, const unsigned* drop_seed_dev, float drop_p, void* stream) {
+    return classifier_fwd_impl(f_hi, f_lo, nullptr, nullptr, w, bias, logits, B, HW, C, ncls, drop_seed, drop_seed_dev, drop_p, stream);
+}
+
+// The training-mode tail of the head in one pass: logits = bias + w . drop(relu(x*scale + shift)), x = the last Conv2d's output,
+// scale / shift = the batch statistics' affine (ig_bn_relu_fwd with y == NULL computes them without an apply pass).
+int ig_classifier_bn_fwd(const void* x_hi, const void* x_lo, const float* scale, const float* shift, const float* w, const float* bias,
+                         float* logits, int B, long HW, int C, int ncls, unsigned drop_seed, const unsigned* drop_seed_dev, float drop_p,
+                         void* stream) {
+    IG_REQUIRE(scale && shift, "ig_classifier_bn_fwd: null pointer");
+    return classifier_fwd_impl(x_hi, x_lo, scale, shift, w, bias, logits, B, HW, C, ncls, drop_seed, drop_seed_dev, drop_p, stream);
+}
+
 // count: NULL, or the loss kernel's stats buffer (uses stats[1] = #valid pixels to normalise dlogits)
-int ig_classifier_bwd(const float* dlogits, const void* f_hi, const void* f_lo, const float* w, void* df_hi, void* df_lo, float* dw,
-                      float* db, const double* count, int B, long HW, int C, int ncls, unsigned drop_seed,
-                      const unsigned* drop_seed_dev, float drop_p, void* stream) {
-    IG_REQUIRE(dlogits && f_hi && w && df_hi && dw && db, "ig_classifier_bwd: null pointer");
+// mode 0: plain; 1 / 2: the reduce / apply passes of the fused BatchNorm + classifier backward (ClsBn)
+static int classifier_bwd_impl(int mode, ClsBn bn, int* nwg_out, const float* dlogits, const void* f_hi, const void* f_lo, const float* w,
+                               void* df_hi, void* df_lo, float* dw, float* db, const double* count, int B, long HW, int C, int ncls,
+                               unsigned drop_seed, const unsigned* drop_seed_dev, float drop_p, void* stream) {
+    IG_REQUIRE(dlogits && f_hi && w && (df_hi || mode == 1) && ((dw && db) || mode == 2), "ig_classifier_bwd: null pointer");
     IG_REQUIRE(C % 8 == 0 && ncls >= 1 && ncls <= MAXC, "ig_classifier_bwd: need C %% 8 == 0 and 1 <= ncls <= %d", MAXC);
     long M = (long)B * HW;
     if (M == 0) return IG_OK;
-    IG_REQUIRE(C / 8 <= TPB, "ig_classifier_bwd: C must be <= %d", TPB * 8);
-    const long nsl = TPB / (C / 8);
-    const size_t slab_floats = (size_t)nsl * ncls * C;
-    const int slab = slab_floats * sizeof(float) <= 32768;
-    static const int wide_env = getenv("IG_CLS_WIDE") ? atoi(getenv("IG_CLS_WIDE")) : 1;  // 0: LDS-atomic fallback (A/B runs)
-    if (!slab && ncls > 4 && C % 8 == 0 && wide_env) {  // wide head: channel-chunked workgroups, class-grouped dW fold
-        const int nslw = TPB / (CLS_CHUNK / 8);  // 42 slices of 6 units
-        long it = (M + (long)nslw * 1024 - 1) / ((long)nslw * 1024);
-        if (it < 8) it = 8;
-        const long ppbw = (long)nslw * it;
-        const dim3 gridw((unsigned)((M + ppbw - 1) / ppbw), (unsigned)((C + CLS_CHUNK - 1) / CLS_CHUNK));
-        // weights | db | slab (<= 256 threads x 4 classes x 8 channels) | dlogits group (ncls x CLS_IG x <= 128 pixel slices)
-        const int rem_units = (C % CLS_CHUNK) / 8;                                  // units of the last (narrower) chunk, 0 = none
-        const int nsl_max = TPB / (rem_units ? rem_units : CLS_CHUNK / 8);        // its pixel slices
-        const size_t smw = ((size_t)ncls * CLS_CHUNK + 32 + (size_t)TPB * 32 + (size_t)ncls * CLS_IG * nsl_max) * sizeof(float);
-        IG_REQUIRE(smw <= 160 * 1024, "ig_classifier_bwd: ncls x C = %d x %d does not fit the LDS", ncls, C);
-        static bool attrw = false;
-        if (!attrw) {
-            (void)hipFuncSetAttribute((const void*)classifier_bwd_wide_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)classifier_bwd_wide_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attrw = true;
-        }
-#define IG_CLS_BWDW(NC)                                                                                                         \
-    hipLaunchKernelGGL(classifier_bwd_wide_kernel<NC>, gridw, dim3(TPB), smw, (hipStream_t)stream, dlogits, (const bf16_t*)f_hi, \
-                       (const bf16_t*)f_lo, w, (bf16_t*)df_hi, (bf16_t*)df_lo, dw, db, count, M, HW, C, ncls, drop_seed,        \
-                       drop_seed_dev, thresh_of(drop_p), drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, (int)it)
-        if (ncls <= 8) IG_CLS_BWDW(8);
-        else IG_CLS_BWDW(16);
-#undef IG_CLS_BWDW
-        return ig_check_launch("ig_classifier_bwd");
-    }
-    size_t sm = ((size_t)ncls * C + 2 * ((ncls + 3) & ~3) + (slab ? slab_floats : (size_t)ncls * C)) * sizeof(float);
-    long iters = (M + nsl * 1024 - 1) / (nsl * 1024);  // ~1k workgroups: one round of dW/db atomics each
+    const int nc = ncls <= 2 ? 2 : ncls <= 4 ? 4 : ncls <= 8 ? 8 : 16;  // class bucket (padded classes multiply zeros)
+    const bool wide = ncls > 4;          // dW passes split the classes into groups of 8 (blockIdx.y), 4 channels per thread
+    const int vec = wide ? 4 : 8;
+    IG_REQUIRE(C / vec <= TPB, "ig_classifier_bwd: C must be <= %d", TPB * vec);
+    const long nsl = TPB / (C / vec);
+    long iters = (M + nsl * 1024 - 1) / (nsl * 1024);  // ~1k workgroups: one round of dW / db adds each
     if (iters < 8) iters = 8;
-    const long ppb = nsl * iters;  // pixels per block
-    const dim3 grid((unsigned)((M + ppb - 1) / ppb));
-#define IG_CLS_BWD(NC)                                                                                                          \
-    hipLaunchKernelGGL(classifier_bwd_kernel<NC>, grid, dim3(TPB), sm, (hipStream_t)stream, dlogits, (const bf16_t*)f_hi,       \
-                       (const bf16_t*)f_lo, w, (bf16_t*)df_hi, (bf16_t*)df_lo, dw, db, count, M, HW, C, ncls, drop_seed,        \
-                       drop_seed_dev, thresh_of(drop_p), drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, (int)iters, slab)
-    if (ncls <= 2) IG_CLS_BWD(2);
-    else if (ncls <= 4) IG_CLS_BWD(4);
-    else if (ncls <= 8) IG_CLS_BWD(8);
-    else IG_CLS_BWD(16);
+    const long ppb = nsl * iters;  // pixels per workgroup
+    const unsigned gx = (unsigned)((M + ppb - 1) / ppb);
+    const unsigned gy_split = wide ? (unsigned)((ncls + 7) / 8) : 1u;  // class groups of the dW passes
+    if (nwg_out) {  // geometry query (the caller sizes the partial-sum scratch before the launch)
+        *nwg_out = (int)(gx * gy_split);
+        return IG_OK;
+    }
+    long ig = 4096 / (nc * nsl);  // iterations per staged dlogits group: ~16 KiB of LDS (at most 8 x 16 x 128 floats = 64 KiB)
+    const long ig_max = wide ? 32 : 8;
+    ig = ig < 8 ? 8 : ig > ig_max ? ig_max : ig & ~7L;  // whole trips of the prefetching loop (4 pixels)
+    const size_t sm = (32 + (size_t)CLS_SLAB + (size_t)nc * ig * nsl) * sizeof(float);
+    const float inv = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    static const bool sform = !getenv("IG_CLS_SFORM") || atoi(getenv("IG_CLS_SFORM"));  // reduce pass in S form also at <= 4 classes (A/B switch)
+#define IG_CLS_BWD(NC, VEC, MD, GY)                                                                                                  \
+    hipLaunchKernelGGL((cls_bwd_kernel<NC, VEC, MD>), dim3(gx, GY), dim3(TPB), sm, (hipStream_t)stream, dlogits, (const bf16_t*)f_hi, \
+                       (const bf16_t*)f_lo, w, (bf16_t*)df_hi, (bf16_t*)df_lo, dw, db, count, M, HW, C, ncls, drop_seed,             \
+                       drop_seed_dev, thresh_of(drop_p), inv, (int)iters, (int)ig, bn)
+#define IG_CLS_BWD_M(NC)                             \
+    do {                                             \
+        if (mode == 0) IG_CLS_BWD(NC, 8, 0, 1);      \
+        else if (mode == 1) {                        \
+            if (sform) IG_CLS_BWD(NC, 8, 5, 1);      \
+            else IG_CLS_BWD(NC, 8, 1, 1);            \
+        }                                            \
+        else IG_CLS_BWD(NC, 8, 2, 1);                \
+    } while (0)
+#define IG_CLS_BWD_W(NC)                                      \
+    do {                                                      \
+        if (mode == 0) {                                      \
+            IG_CLS_BWD(NC, 4, 3, 1);                          \
+            IG_CLS_BWD(8, 4, 4, gy_split);                    \
+        } else if (mode == 1) IG_CLS_BWD(8, 4, 5, gy_split);  \
+        else IG_CLS_BWD(NC, 4, 2, 1);                         \
+    } while (0)
+    if (nc == 2) IG_CLS_BWD_M(2);
+    else if (nc == 4) IG_CLS_BWD_M(4);
+    else if (nc == 8) IG_CLS_BWD_W(8);
+    else IG_CLS_BWD_W(16);
+#undef IG_CLS_BWD_W
+#undef IG_CLS_BWD_M
 #undef IG_CLS_BWD
     return ig_check_launch("ig_classifier_bwd");
+}
+
+int ig_classifier_bwd(const float* dlogits, const void* f_hi, const void* f_lo, const float* w, void* df_hi, void* df_lo, float* dw,
+                      float* db, const double* count, int B, long HW, int C, int ncls, unsigned drop_seed,
+                      const unsigned* drop_seed_dev, float drop_p, void* stream) {
+    return classifier_bwd_impl(0, ClsBn{}, nullptr, dlogits, f_hi, f_lo, w, df_hi, df_lo, dw, db, count, B, HW, C, ncls, drop_seed,
+                               drop_seed_dev, drop_p, stream);
+}
+
+// Backward of the fused tail (ig_classifier_bn_fwd): x = the last Conv2d's output (saved), scale / shift / mean / rstd from the forward's
+// statistics.  Pass 1 recomputes the activation, accumulates dW / db of the classifier and the BatchNorm backward's per-channel sums;
+// pass 2 recomputes it again and writes dx; dgamma / dbeta are added once.  sums: device scratch double[2C].
+int ig_classifier_bn_bwd(const float* dlogits, const void* x_hi, const void* x_lo, const float* scale, const float* shift,
+                         const float* mean, const float* rstd, const float* w, void* dx_hi, void* dx_lo, float* dw, float* db,
+                         float* dgamma, float* dbeta, double* sums, const double* count, int B, long HW, int C, int ncls,
+                         unsigned drop_seed, const unsigned* drop_seed_dev, float drop_p, void* stream) {
+    IG_REQUIRE(scale && shift && mean && rstd && sums && dx_hi, "ig_classifier_bn_bwd: null pointer");
+    const long M = (long)B * HW;
+    if (M == 0) return IG_OK;
+    int nwg = 0;
+    int rc = classifier_bwd_impl(1, ClsBn{}, &nwg, dlogits, x_hi, x_lo, w, nullptr, nullptr, dw, db, count, B, HW, C, ncls, drop_seed,
+                                 drop_seed_dev, drop_p, stream);
+    if (rc != IG_OK) return rc;
+    ClsBn bn{scale, shift, mean, rstd, sums, nullptr, dgamma, dbeta, 1.0 / (double)M};
+    if (ig_deterministic()) {
+        bn.part = (float*)ig_scratch(0, (size_t)nwg * 2 * C * sizeof(float));
+        IG_REQUIRE(bn.part, "ig_classifier_bn_bwd: scratch allocation failed");
+    } else {
+        (void)hipMemsetAsync(sums, 0, 2 * (size_t)C * sizeof(double), (hipStream_t)stream);
+    }
+    rc = classifier_bwd_impl(1, bn, nullptr, dlogits, x_hi, x_lo, w, nullptr, nullptr, dw, db, count, B, HW, C, ncls, drop_seed,
+                             drop_seed_dev, drop_p, stream);
+    if (rc != IG_OK) return rc;
+    if (bn.part)
+        hipLaunchKernelGGL(bn_part_fold_kernel, dim3(ig_cdiv(2 * C, 64)), dim3(1024), 0, (hipStream_t)stream, bn.part, sums, nwg, 2 * C);
+    return classifier_bwd_impl(2, bn, nullptr, dlogits, x_hi, x_lo, w, dx_hi, dx_lo, nullptr, nullptr, count, B, HW, C, ncls, drop_seed,
+                               drop_seed_dev, drop_p, stream);
 }
 
 // per-device scratch of ordered_grid_totals: 1024 workgroups x 16 partials + the ticket; allocated (zeroed) once, never freed,

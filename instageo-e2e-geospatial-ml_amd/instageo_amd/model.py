@@ -336,6 +336,8 @@ class SegEngine:
         # multi-contributor reductions go through the fixed-point shadow of the gradient buffer (ops.set_deterministic).  On by
         # default (0.15-0.2 ms per step); IG_DETERMINISTIC=0 or ``engine.deterministic = False`` selects the float atomics.
         self.deterministic = os.environ.get("IG_DETERMINISTIC", "1") != "0"
+        # training: the last stage's BatchNorm + ReLU run inside the classifier kernels (IG_FUSE_TAIL=0: the separate passes, for A/B runs)
+        self.fuse_tail = os.environ.get("IG_FUSE_TAIL", "1") != "0"
         self._det_pending: List[Tuple[int, int]] = []
         self._pos_cache: Dict[int, Any] = {}
         self._last: Optional[Dict[str, Any]] = None
@@ -548,6 +550,23 @@ class SegEngine:
                 ops.conv_fwd(ws["u"][i], self.W(f"{h}{i}.2.weight"), self.P(f"{h}{i}.2.bias"), ws["f"][i + 1], B, Hu, Hu,
                              dims[i + 1], dims[i + 1], ks[i], bn_scale=ws["bn_scale"][i], bn_shift=ws["bn_shift"][i])
                 continue
+            if i == 3 and self.fuse_tail:
+                # last stage: statistics only -- from the convolution's epilogue where the direct kernel runs -- and BatchNorm + ReLU are
+                # applied inside the classifier kernels (the activation between them, the largest tensor of the head, is never written:
+                # ig_classifier_bn_fwd / _bwd)
+                bn_args = (self.P(f"{h}{i}.3.weight"), self.P(f"{h}{i}.3.bias"), self.buffers[f"{h}{i}.3.running_mean"],
+                           self.buffers[f"{h}{i}.3.running_var"], ws["bn_scale"][i], ws["bn_shift"][i], ws["bn_mean"][i], ws["bn_rstd"][i])
+                if ks[i] == 3 and ops.conv3x3_fwd_stats(ws["u"][i], self.W(f"{h}{i}.2.weight"), self.P(f"{h}{i}.2.bias"), ws["cv"][i], ws["bn_sums"],
+                                                        B, Hu, Hu, dims[i + 1], dims[i + 1]):
+                    ops.bn_finalize(ws["bn_sums"], *bn_args, B * Ho * Ho, dims[i + 1], training and update_running)
+                else:
+                    if ks[i] != 3:
+                        ops.conv_fwd(ws["u"][i], self.W(f"{h}{i}.2.weight"), self.P(f"{h}{i}.2.bias"), ws["cv"][i], B, Hu, Hu, dims[i + 1],
+                                     dims[i + 1], ks[i])
+                    ops.bn_stats(ws["cv"][i], *bn_args, ws["bn_sums"], B * Ho * Ho, dims[i + 1], training and update_running)
+                if training and update_running:
+                    self.buffers[f"{h}{i}.3.num_batches_tracked"] += 1
+                continue
             ops.conv_fwd(ws["u"][i], self.W(f"{h}{i}.2.weight"), self.P(f"{h}{i}.2.bias"), ws["cv"][i], B, Hu, Hu, dims[i + 1],
                          dims[i + 1], ks[i])
             ops.bn_relu_fwd(ws["cv"][i], self.P(f"{h}{i}.3.weight"), self.P(f"{h}{i}.3.bias"), self.buffers[f"{h}{i}.3.running_mean"],
@@ -558,8 +577,13 @@ class SegEngine:
         S = cfg.out_size  # = img_size for every variant at its native chip size (3 x 3 kernels keep 2 x; 600M: 228 -> 224)
         if out is None:
             out = torch.empty((B, cfg.num_classes, S, S), dtype=torch.float32, device=ws["f"][4].hi.device)
-        ops.classifier_fwd(ws["f"][4], self.P(h + "5.weight"), self.P(h + "5.bias"), out, B, S * S, dims[4], cfg.num_classes,
-                           seed=self.drop_seed + 4, p=p, seed_dev=sd)
+        if training and self.fuse_tail:
+            ops.classifier_bn_fwd(ws["cv"][3], ws["bn_scale"][3], ws["bn_shift"][3], self.P(h + "5.weight"), self.P(h + "5.bias"), out, B, S * S,
+                                  dims[4], cfg.num_classes, seed=self.drop_seed + 4, p=p, seed_dev=sd)
+        else:
+            ops.classifier_fwd(ws["f"][4], self.P(h + "5.weight"), self.P(h + "5.bias"), out, B, S * S, dims[4], cfg.num_classes,
+                               seed=self.drop_seed + 4, p=p, seed_dev=sd)
+        ws["tail_fused"] = bool(training and self.fuse_tail)
         return out
 
     def features_nchw(self) -> torch.Tensor:
@@ -603,16 +627,24 @@ class SegEngine:
         sd = self._drop_counter(advance=False) if p > 0 else None
         h = "segmentation_head."
         S = cfg.out_size
-        ops.classifier_bwd(dlogits.contiguous(), ws["f"][4], self.P(h + "5.weight"), ws["df"][4], self.Gd(h + "5.weight"),
-                           self.Gd(h + "5.bias"), count, B, S * S, dims[4], cfg.num_classes, seed=self.drop_seed + 4, p=p, seed_dev=sd)
+        if not training:
+            raise RuntimeError("backward through eval-mode BatchNorm is not supported (reference trains in train mode)")
+        fused = ws.get("tail_fused", False)
+        if fused:
+            ops.classifier_bn_bwd(dlogits.contiguous(), ws["cv"][3], ws["bn_scale"][3], ws["bn_shift"][3], ws["bn_mean"][3], ws["bn_rstd"][3],
+                                  self.P(h + "5.weight"), ws["dcv"][3], self.Gd(h + "5.weight"), self.Gd(h + "5.bias"),
+                                  self.Gd(f"{h}3.3.weight"), self.Gd(f"{h}3.3.bias"), ws["bn_sums"], count, B, S * S, dims[4], cfg.num_classes,
+                                  seed=self.drop_seed + 4, p=p, seed_dev=sd)
+        else:
+            ops.classifier_bwd(dlogits.contiguous(), ws["f"][4], self.P(h + "5.weight"), ws["df"][4], self.Gd(h + "5.weight"),
+                               self.Gd(h + "5.bias"), count, B, S * S, dims[4], cfg.num_classes, seed=self.drop_seed + 4, p=p, seed_dev=sd)
         for i in range(3, -1, -1):
             Hs, Hu, Ho = hs[i]
             Mo = B * Ho * Ho
             C1 = dims[i + 1]
-            if not training:
-                raise RuntimeError("backward through eval-mode BatchNorm is not supported (reference trains in train mode)")
-            ops.bn_relu_bwd(ws["cv"][i], ws["df"][i + 1], ws["bn_scale"][i], ws["bn_shift"][i], ws["bn_mean"][i], ws["bn_rstd"][i],
-                            ws["dcv"][i], self.Gd(f"{h}{i}.3.weight"), self.Gd(f"{h}{i}.3.bias"), ws["bn_sums"], Mo, C1)
+            if not (fused and i == 3):
+                ops.bn_relu_bwd(ws["cv"][i], ws["df"][i + 1], ws["bn_scale"][i], ws["bn_shift"][i], ws["bn_mean"][i], ws["bn_rstd"][i],
+                                ws["dcv"][i], self.Gd(f"{h}{i}.3.weight"), self.Gd(f"{h}{i}.3.bias"), ws["bn_sums"], Mo, C1)
             # The Conv2d bias sits in front of a training-mode BatchNorm: its gradient, the pixel sum of the BatchNorm backward's
             # output, is ZERO by construction (sum(dy - mean(dy)) = 0 and sum(x_hat) = 0); the reference's autograd returns the
             # fp32 rounding noise of that sum (1e-8 here).  It is left at exactly 0: no column-sum pass over dcv (two launches per

@@ -560,6 +560,43 @@ def classifier_bwd(dlogits, f: BT, w, df: BT, dw, db, count, B: int, HW: int, C:
           _p(df.hi), _p(df.lo), _p(dw), _p(db), _p(count), B, HW, C, ncls, seed, _p(seed_dev), p, _stream())
 
 
+def bn_stats(x: BT, gamma, beta, rmean, rvar, scale, shift, mean, rstd, sums, M: int, C: int, update_running: bool, eps: float = 1e-5,
+             momentum: float = 0.1) -> None:
+    """Training-mode BatchNorm statistics only (scale / shift / mean / rstd, running update): the consumer applies them."""
+    _call("ig_bn_relu_fwd", float(M) * C * (2 if x.lo is None else 4), _p(x.hi), _p(x.lo), _p(gamma), _p(beta), _p(rmean), _p(rvar), None, None,
+          _p(scale), _p(shift), _p(mean), _p(rstd), _p(sums), M, C, eps, momentum, 1, int(update_running), _stream())
+
+
+def conv3x3_fwd_stats(x: BT, w: BT, bias, y: BT, sums, B, H, W, Cin, Cout) -> bool:
+    """nn.Conv2d(k=3, padding=1) in front of a training-mode BatchNorm; True when the kernel also left the per-channel sum / sum of squares
+    of its outputs in ``sums`` (f64 [2 Cout]): the BatchNorm then needs :func:`bn_finalize` only, not a statistics pass."""
+    import ctypes
+
+    fused = ctypes.c_int(0)
+    _call("ig_conv3x3_fwd", 2.0 * B * H * W * Cin * Cout * 9, _p(x.hi), _p(x.lo), _p(w.hi), _p(w.lo), _p(bias), _p(y.hi), _p(y.lo), _p(sums),
+          ctypes.cast(ctypes.byref(fused), ctypes.c_void_p), B, H, W, Cin, Cout, _stream(), entry="ig_conv3x3_fwd_stats")
+    return bool(fused.value)
+
+
+def bn_finalize(sums, gamma, beta, rmean, rvar, scale, shift, mean, rstd, M: int, C: int, update_running: bool, eps: float = 1e-5,
+                momentum: float = 0.1) -> None:
+    _lib.call("ig_bn_finalize", _p(sums), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(scale), _p(shift), _p(mean), _p(rstd), M, C, eps, momentum,
+              int(update_running), _stream())
+
+
+def classifier_bn_fwd(x: BT, scale, shift, w, bias, logits, B: int, HW: int, C: int, ncls: int, seed: int = 0, p: float = 0.0, seed_dev=None) -> None:
+    _call("ig_classifier_bn_fwd", float(B) * HW * (C * (2 if x.lo is None else 4) + ncls * 4), _p(x.hi), _p(x.lo), _p(scale), _p(shift), _p(w),
+          _p(bias), _p(logits), B, HW, C, ncls, seed, _p(seed_dev), p, _stream())
+
+
+def classifier_bn_bwd(dlogits, x: BT, scale, shift, mean, rstd, w, dx: BT, dw, db, dgamma, dbeta, sums, count, B: int, HW: int, C: int,
+                      ncls: int, seed: int = 0, p: float = 0.0, seed_dev=None) -> None:
+    # two passes over x (+ dlogits), one write of dx
+    _call("ig_classifier_bn_bwd", float(B) * HW * (3 * C * (2 if x.lo is None else 4) + 2 * ncls * 4), _p(dlogits), _p(x.hi), _p(x.lo), _p(scale),
+          _p(shift), _p(mean), _p(rstd), _p(w), _p(dx.hi), _p(dx.lo), _p(dw), _p(db), _p(dgamma), _p(dbeta), _p(sums), _p(count), B, HW, C, ncls,
+          seed, _p(seed_dev), p, _stream())
+
+
 _LABEL_DT = {torch.int64: 0, torch.int32: 1, torch.float32: 2}
 
 

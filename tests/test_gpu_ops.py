@@ -906,7 +906,7 @@ def test_bn_relu(split, M, C):
 
 
 @pytest.mark.parametrize("split", SPLITS)
-@pytest.mark.parametrize("ncls,C", [(2, 48), (13, 144)])
+@pytest.mark.parametrize("ncls,C", [(2, 48), (13, 144), (7, 96), (3, 48)])
 def test_classifier_and_loss(split, ncls, C):
     B, H, W = 2, 24, 20
     HW = H * W
@@ -956,6 +956,122 @@ def test_classifier_and_loss(split, ncls, C):
     close(df.float(), gf, tol_out(split), what="classifier df")
     close(dw, gw, 3e-5, what="classifier dw")
     close(db, gb, 3e-5, what="classifier db")
+
+
+@pytest.mark.parametrize("C,B,H,W,expect", [(48, 3, 40, 40, True), (48, 2, 23, 37, True), (48, 70, 32, 32, True), (192, 1, 16, 16, False)])
+def test_conv3x3_fwd_stats(C, B, H, W, expect):
+    """nn.Conv2d(k=3, padding=1) in front of a training-mode BatchNorm (model.py:370-377): where the direct 48-channel kernel runs, its
+    epilogue also leaves the per-channel sum / sum of squares of the STORED outputs (the statistics pass without its read of the tensor);
+    elsewhere the call is the plain convolution and reports that the statistics pass is still owed."""
+    x, xr = bt(rnd(B, H, W, C, seed=61), False)
+    w, wr = bt(rnd(C, 9, C, seed=62, scale=(9 * C) ** -0.5), False)
+    bias = rnd(C, seed=63)
+    y, y2 = BT.empty((B, H, W, C), False, DEV), BT.empty((B, H, W, C), False, DEV)
+    sums = torch.full((2 * C,), -1.0, dtype=torch.float64, device=DEV)
+    fused = ops.conv3x3_fwd_stats(x, w, bias.to(DEV), y, sums, B, H, W, C, C)
+    assert fused == expect
+    ops.conv3x3_fwd(x, w, bias.to(DEV), y2, B, H, W, C, C)
+    assert torch.equal(y.hi, y2.hi)  # the same kernel with the statistics switched on
+    ref = F.conv2d(xr.permute(0, 3, 1, 2), wr.view(C, 3, 3, C).permute(0, 3, 1, 2), bias.double(), padding=1).permute(0, 2, 3, 1)
+    close(y.float(), ref, tol_out(False), what="conv fwd")
+    if fused:
+        yd = y.float().double().cpu().reshape(-1, C)
+        close(sums[:C], yd.sum(0), 2e-6, what="sum")
+        close(sums[C:], (yd * yd).sum(0), 2e-6, what="sum of squares")
+        sums2 = torch.empty_like(sums)
+        ops.conv3x3_fwd_stats(x, w, bias.to(DEV), y, sums2, B, H, W, C, C)
+        assert torch.equal(sums, sums2)  # ordered partial sums: bit-identical from run to run
+        # BatchNorm from these sums == the statistics pass over the stored tensor
+        g, b = 1 + 0.1 * rnd(C, seed=64), 0.1 * rnd(C, seed=65)
+        out = []
+        for mode in (0, 1):
+            rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+            scale, shift, mean, rstd = (torch.empty(C, device=DEV) for _ in range(4))
+            if mode:
+                ops.bn_finalize(sums, g.to(DEV), b.to(DEV), rm, rv, scale, shift, mean, rstd, B * H * W, C, True)
+            else:
+                s3 = torch.empty_like(sums)
+                ops.bn_stats(y, g.to(DEV), b.to(DEV), rm, rv, scale, shift, mean, rstd, s3, B * H * W, C, True)
+            out.append((rm, rv, scale, shift, mean, rstd))
+        for a_, b_, nm in zip(out[0], out[1], ("running mean", "running var", "scale", "shift", "mean", "rstd")):
+            close(b_, a_.double().cpu(), 2e-6, what=nm)
+
+
+@pytest.mark.parametrize("det", [False, True])
+@pytest.mark.parametrize("split", SPLITS)
+@pytest.mark.parametrize("ncls,C,B,H,W", [(2, 48, 2, 24, 20), (13, 144, 2, 24, 20), (1, 48, 1, 30, 30), (4, 144, 3, 56, 56), (2, 96, 1, 17, 9), (6, 48, 2, 24, 20), (16, 80, 1, 40, 33)])
+def test_classifier_bn_fused_tail(det, split, ncls, C, B, H, W):
+    """The training-mode tail of the head in fused passes (model.py:376-377 + 388-389): BatchNorm2d (batch statistics) + ReLU applied inside
+    the Dropout + Conv2d(k=1) kernels, forward and backward, against float64 autograd; with dropout on, against the separate kernels
+    (same counter-hash mask)."""
+    HW, M = H * W, B * H * W
+    x, xr = bt(rnd(M, C, seed=51) * 1.5 + 0.3, split)
+    g, b = 1 + 0.1 * rnd(C, seed=52), 0.1 * rnd(C, seed=53)
+    w, cb = rnd(ncls, C, seed=54, scale=C**-0.5), rnd(ncls, seed=55)
+    rm0, rv0 = 0.1 * rnd(C, seed=56), 1 + 0.2 * torch.rand(C)
+    rm, rv = rm0.clone().to(DEV), rv0.clone().to(DEV)
+    scale, shift, mean, rstd = (torch.empty(C, device=DEV) for _ in range(4))
+    sums = torch.empty(2 * C, dtype=torch.float64, device=DEV)
+    logits = torch.empty(B, ncls, H, W, device=DEV)
+    # flat "gradient buffer": dw | db | dgamma | dbeta (registered in the deterministic mode: fixed-point shadow + ordered partial folds)
+    nw = ncls * C
+    flat = torch.zeros(nw + ncls + 2 * C + 8, device=DEV)
+    dw, db, dgam, dbet = flat[:nw].view(ncls, C), flat[nw : nw + ncls], flat[nw + ncls : nw + ncls + C], flat[nw + ncls + C : nw + ncls + 2 * C]
+    xd = xr.clone().requires_grad_(True)
+    gd, bd = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    wd, cbd = w.double().requires_grad_(True), cb.double().requires_grad_(True)
+    rmd, rvd = rm0.double().clone(), rv0.double().clone()
+    act = F.relu(F.batch_norm(xd, rmd, rvd, gd, bd, True, 0.1, 1e-5))
+    ref = (act.view(B, HW, C) @ wd.t() + cbd).permute(0, 2, 1).reshape(B, ncls, H, W)
+    dl = rnd(B, ncls, H, W, seed=57)
+    gx, gg, gb, gw, gcb = torch.autograd.grad((ref * dl.double()).sum(), [xd, gd, bd, wd, cbd])
+    try:
+        if det:
+            ops.set_deterministic(flat)
+        ops.bn_stats(x, g.to(DEV), b.to(DEV), rm, rv, scale, shift, mean, rstd, sums, M, C, True)
+        close(rm, rmd, 1e-5, what="running mean")
+        close(rv, rvd, 1e-5, what="running var")
+        ops.classifier_bn_fwd(x, scale, shift, w.to(DEV), cb.to(DEV), logits, B, HW, C, ncls)
+        close(logits, ref.detach(), 3e-5, what="fused logits")
+        dx = BT.empty((M, C), split, DEV)
+        ops.classifier_bn_bwd(dl.to(DEV), x, scale, shift, mean, rstd, w.to(DEV), dx, dw, db, dgam, dbet, sums, None, B, HW, C, ncls)
+        ops.det_fold(0, flat.numel())
+        close(dx.float(), gx, tol_out(split), what="fused dx")
+        close(dw, gw, 3e-5, what="fused dw")
+        close(db, gcb, 3e-5, what="fused db")
+        close(dgam, gg, 3e-5, what="fused dgamma")
+        close(dbet, gb, 3e-5, what="fused dbeta")
+        if det:  # a second run gives the same bits
+            first = (dx.float().clone(), flat.clone())
+            flat.zero_()
+            ops.classifier_bn_bwd(dl.to(DEV), x, scale, shift, mean, rstd, w.to(DEV), dx, dw, db, dgam, dbet, sums, None, B, HW, C, ncls)
+            ops.det_fold(0, flat.numel())
+            assert torch.equal(dx.float(), first[0]) and torch.equal(flat, first[1])
+        # dropout on: the separate kernels (BatchNorm apply -> classifier) regenerate the same mask from the same seed
+        y = BT.empty((M, C), split, DEV)
+        ops.bn_relu_fwd(x, g.to(DEV), b.to(DEV), rm, rv, y, scale, shift, mean, rstd, sums, M, C, True, False)
+        lg_sep, lg_fus = torch.empty_like(logits), torch.empty_like(logits)
+        ops.classifier_fwd(y, w.to(DEV), cb.to(DEV), lg_sep, B, HW, C, ncls, seed=77, p=0.1)
+        ops.classifier_bn_fwd(x, scale, shift, w.to(DEV), cb.to(DEV), lg_fus, B, HW, C, ncls, seed=77, p=0.1)
+        assert (lg_fus - logits).abs().max().item() > 1e-3  # the mask does something
+        close(lg_fus, lg_sep.double().cpu(), 3e-5 if split else 4e-3, what="fused vs separate logits with dropout")
+        flat2 = torch.zeros_like(flat)
+        dw2, db2, dgam2, dbet2 = flat2[:nw].view(ncls, C), flat2[nw : nw + ncls], flat2[nw + ncls : nw + ncls + C], flat2[nw + ncls + C : nw + ncls + 2 * C]
+        if det:
+            ops.set_deterministic(None)
+        df, dx2, dx3 = BT.empty((M, C), split, DEV), BT.empty((M, C), split, DEV), BT.empty((M, C), split, DEV)
+        ops.classifier_bwd(dl.to(DEV), y, w.to(DEV), df, dw2, db2, None, B, HW, C, ncls, seed=77, p=0.1)
+        ops.bn_relu_bwd(x, df, scale, shift, mean, rstd, dx2, dgam2, dbet2, sums, M, C)
+        flat.zero_()
+        ops.classifier_bn_bwd(dl.to(DEV), x, scale, shift, mean, rstd, w.to(DEV), dx3, dw, db, dgam, dbet, sums, None, B, HW, C, ncls, seed=77, p=0.1)
+        t = 3e-5 if split else 1.2e-2
+        close(dx3.float(), dx2.float().double().cpu(), t, what="fused vs separate dx with dropout")
+        close(dw, dw2.double().cpu(), t, what="fused vs separate dw with dropout")
+        close(db, db2.double().cpu(), 3e-5, what="fused vs separate db with dropout")
+        close(dgam, dgam2.double().cpu(), t, what="fused vs separate dgamma with dropout")
+        close(dbet, dbet2.double().cpu(), t, what="fused vs separate dbeta with dropout")
+    finally:
+        ops.set_deterministic(None)
 
 
 def test_ce_loss_all_ignored_and_float_labels():
