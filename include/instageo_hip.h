@@ -171,7 +171,7 @@ int ig_convT_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const
 int ig_conv3x3_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
                    const float* bn_scale, const float* bn_shift, void* y_hi, void* y_lo, int B, int H, int W, int Cin, int Cout,
                    void* stream);
-/* the same in front of a training-mode nn.BatchNorm2d (:376): where the direct 48-channel kernel runs, the convolution also leaves
+/* the same in front of a training-mode nn.BatchNorm2d (:376): where a direct kernel runs (48 / 96 channels), the convolution also leaves
  * sums[2 Cout] (per-channel sum / sum of squares of the stored outputs) and sets *fused = 1 (HOST int); else *fused = 0 */
 int ig_conv3x3_fwd_stats(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias, void* y_hi,
                          void* y_lo, double* sums, int* fused, int B, int H, int W, int Cin, int Cout, void* stream);
@@ -203,7 +203,8 @@ int ig_bn_relu_fwd(const void* x_hi, const void* x_lo, const float* gamma, const
 int ig_bn_relu_bwd(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, const float* scale,
                    const float* shift, const float* mean, const float* rstd, void* dx_hi, void* dx_lo, float* dgamma,
                    float* dbeta, double* sums, long M, int C, void* stream);
-/* y_hi == NULL: batch statistics + scale / shift / mean / rstd (+ running update) only, no apply pass (ig_classifier_bn_fwd applies) */
+/* y_hi == NULL: batch statistics + scale / shift / mean / rstd (+ running update) only, no apply pass (ig_classifier_bn_fwd applies);
+ * training == 2: batch statistics that a producer has already left in sums (ig_conv3x3_fwd_stats with *fused == 1): no statistics pass */
 /* nn.Dropout(p) + nn.Conv2d(k=1): f (B,HW,C) -> logits (B,ncls,HW) f32                                 :388-389 */
 int ig_classifier_fwd(const void* f_hi, const void* f_lo, const float* w, const float* bias, float* logits, int B, long HW, int C,
                       int ncls, unsigned drop_seed, const unsigned* drop_seed_dev, float drop_p, void* stream);

@@ -1426,6 +1426,12 @@ __global__ __launch_bounds__(576, 1) void conv3x3_direct_slice_kernel(CDParams p
             for (int i = 0; i < 4; ++i) v[i] *= mk[i];
         }
     };
+    // BatchNorm statistics of this lane's 12 channels of the slice (see conv3x3_direct_kernel)
+    constexpr int NS = NPAIR * 8 + (NB & 1) * 4;
+    float st_s[NS], st_q[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) st_s[k] = 0.f, st_q[k] = 0.f;
+    const bool want_stats = p.stats_part != nullptr;
     for (int n = 0; n < mine; ++n) {
         asm volatile("s_barrier" ::: "memory");
         int b, ty0, tx0;
@@ -1454,7 +1460,14 @@ __global__ __launch_bounds__(576, 1) void conv3x3_direct_slice_kernel(CDParams p
                 float v[8];
                 finish4(acc[2 * pr], nn, idx, v);
                 finish4(acc[2 * pr + 1], nn + 4, idx + 4, v + 4);
-                *reinterpret_cast<uint4*>(p.y + idx) = pack8(v);
+                const uint4 pk = pack8(v);
+                *reinterpret_cast<uint4*>(p.y + idx) = pk;
+                if (want_stats) {
+                    float r[8];
+                    unpack8(pk, r);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) st_s[pr * 8 + i] += r[i], st_q[pr * 8 + i] = fmaf(r[i], r[i], st_q[pr * 8 + i]);
+                }
             }
             if (NB & 1) {
                 const int nn = (NB - 1) * 16 + 4 * g;
@@ -1462,7 +1475,38 @@ __global__ __launch_bounds__(576, 1) void conv3x3_direct_slice_kernel(CDParams p
                 float v[4];
                 finish4(acc[NB - 1], nn, idx, v);
                 store4_split(p.y, nullptr, idx, v);
+                if (want_stats) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float r = bf2f(f2bf(v[i]));
+                        st_s[NPAIR * 8 + i] += r, st_q[NPAIR * 8 + i] = fmaf(r, r, st_q[NPAIR * 8 + i]);
+                    }
+                }
             }
+        }
+    }
+    if (want_stats) {  // the loader wave has left: the barriers below count the eight MFMA waves
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) st_s[k] += __shfl_xor(st_s[k], o, 64), st_q[k] += __shfl_xor(st_q[k], o, 64);
+        }
+        asm volatile("s_barrier" ::: "memory");  // every wave has finished reading the halo stages
+        float* red = reinterpret_cast<float*>(smem + W_BYTES);  // [wave][g][NS][2]
+        if (j == 0) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) red[((wave * 4 + g) * NS + k) * 2] = st_s[k], red[((wave * 4 + g) * NS + k) * 2 + 1] = st_q[k];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        for (int c = tid; c < COB; c += NCW * 64) {
+            int gg, k;
+            if (c < NPAIR * 32) gg = (c % 32) / 8, k = (c / 32) * 8 + c % 8;
+            else gg = (c - (NB - 1) * 16) / 4, k = NPAIR * 8 + (c - (NB - 1) * 16) % 4;
+            float ss = 0.f, qq = 0.f;
+            for (int w = 0; w < NCW; ++w) ss += red[((w * 4 + gg) * NS + k) * 2], qq += red[((w * 4 + gg) * NS + k) * 2 + 1];
+            p.stats_part[(size_t)blockIdx.x * 2 * C + co0 + c] = ss;
+            p.stats_part[(size_t)blockIdx.x * 2 * C + C + co0 + c] = qq;
         }
     }
 }
@@ -1663,8 +1707,19 @@ int ig_conv3x3_direct(const void* x, const void* w, const float* bias, const flo
             attr96 = true;
         }
         const long nwg = p.ntiles < 128 ? p.ntiles : 128;
+        const bool st96 = stat_sums && stats_fused && !dgrad && (!getenv("IG_CONV_STATS") || atoi(getenv("IG_CONV_STATS")));
+        if (st96) {
+            p.stats_part = (float*)ig_scratch(0, (size_t)nwg * 2 * 96 * sizeof(float));
+            if (!p.stats_part) {
+                ig_set_error("ig_conv3x3_fwd: scratch allocation failed");
+                return IG_ERR_HIP;
+            }
+            *stats_fused = 1;
+        }
         ig_note_kernel("conv3x3_direct_slice_kernel<96>");
         hipLaunchKernelGGL(conv3x3_direct_slice_kernel<96>, dim3((unsigned)nwg, 2), dim3(576), smem96, (hipStream_t)stream, p, zp);
+        if (st96)
+            hipLaunchKernelGGL(bn_part_fold_kernel, dim3(ig_cdiv(2 * 96, 64)), dim3(1024), 0, (hipStream_t)stream, p.stats_part, stat_sums, (int)nwg, 2 * 96);
         return ig_check_launch(dgrad ? "ig_conv3x3_dgrad(direct, slices)" : "ig_conv3x3_fwd(direct, slices)");
     }
     static const int fuse_stats = getenv("IG_CONV_STATS") ? atoi(getenv("IG_CONV_STATS")) : 1;

@@ -1266,7 +1266,7 @@ int ig_bn_relu_fwd(const void* x_hi, const void* x_lo, const float* gamma, const
     IG_REQUIRE(x_hi && gamma && beta && running_mean && running_var && scale && shift && sums, "ig_bn_relu_fwd: null pointer");
     IG_REQUIRE(C % 8 == 0 && C <= 4096, "ig_bn_relu_fwd: C must be a multiple of 8 and <= 4096 (got %d)", C);
     if (M == 0) return IG_OK;
-    if (training) {
+    if (training == 1) {  // (training == 2: a producer has already left the statistics in sums -- ig_conv3x3_fwd_stats)
         const int rpb = bn_reduce_rows(M), nwg = ig_cdiv(M, rpb);
         float* part = nullptr;
         if (ig_deterministic()) {

@@ -269,10 +269,9 @@ __global__ __launch_bounds__(TPB, VEC == 8 ? 1 : 2) void cls_bwd_kernel(const fl
     const int ncl = min(NC, ncls - n0);      // classes of the group
     if (threadIdx.x < 16) sdbq[threadIdx.x] = 0ull;
     const float gscale = count ? (float)(1.0 / fmax(count[1], 1.0)) : 1.f;
-    float wr[WANT_O ? NC : 1][VEC], dwa[WANT_DW ? NC : 1][VEC], s1[SFORM ? NC : 1][VEC], dba[NC];
+    float wr[WANT_O ? NC : 1][VEC], dwa[WANT_DW ? NC : 1][VEC], s1[SFORM ? NC : 1][VEC];
 #pragma unroll
     for (int n = 0; n < NC; ++n) {
-        dba[n] = 0.f;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             if constexpr (WANT_O) wr[n][j] = n < ncl ? w[(size_t)(n0 + n) * C + c0 + j] : 0.f;
@@ -301,7 +300,7 @@ __global__ __launch_bounds__(TPB, VEC == 8 ? 1 : 2) void cls_bwd_kernel(const fl
     const long mb = (long)blockIdx.x * nsl * iters;
     const int gpx = ig * nsl;
     const size_t estep = (size_t)nsl * C;
-    constexpr bool PIPE = VEC == 4;
+    constexpr bool PIPE = VEC == 4 && !(MODE == 5 && NC == 16);
     constexpr int PF = PIPE ? 4 : 2;  // pixels per trip
     auto process = [&](float* f, const size_t idx, const int px) __attribute__((always_inline)) {
             float o[VEC], msk[VEC], x[VEC];
@@ -322,7 +321,6 @@ __global__ __launch_bounds__(TPB, VEC == 8 ? 1 : 2) void cls_bwd_kernel(const fl
 #pragma unroll
                 for (int n = 0; n < NC; ++n) {
                     const float g = sdl[n * gpx + px];
-                    dba[n] += g;
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) s1[n][j] = fmaf(g, msk[j], s1[n][j]), dwa[n][j] = fmaf(g, f[j], dwa[n][j]);
                 }
@@ -336,7 +334,6 @@ __global__ __launch_bounds__(TPB, VEC == 8 ? 1 : 2) void cls_bwd_kernel(const fl
 #pragma unroll
                 for (int n = 0; n < NC; ++n) {
                     const float g = sdl[n * gpx + px];
-                    if constexpr (WANT_DW) dba[n] += g;
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) {
                         if constexpr (WANT_O) o[j] = fmaf(g, wr[n][j], o[j]);
@@ -383,7 +380,8 @@ __global__ __launch_bounds__(TPB, VEC == 8 ? 1 : 2) void cls_bwd_kernel(const fl
         {
             const long b0 = mg / HW, pix0 = mg - b0 * HW;
 #pragma unroll
-            for (int n = 0; n < NC; ++n)
+            for (int n = 0; n < NC; ++n) {
+                float part = 0.f;
                 for (int px = threadIdx.x; px < gpx; px += TPB) {
                     float g = 0.f;
                     if (n < ncl && px < npx) {
@@ -392,7 +390,18 @@ __global__ __launch_bounds__(TPB, VEC == 8 ? 1 : 2) void cls_bwd_kernel(const fl
                         g = dl[(b * ncls + n0 + n) * HW + pix] * gscale;
                     }
                     sdl[n * gpx + px] = g;
+                    part += g;
                 }
+                if constexpr (WANT_DW) {  // db: the staged values are summed here (per wave, then 2^44 fixed point: any order, same bits)
+                    if (n < ncl) {        // -- not per pixel and thread in the loop below (NC adds and NC registers less)
+                        part = wave_sum(part);
+                        if ((threadIdx.x & 63) == 0) {  // non-finite / out-of-range partials bypass the fixed-point slot (ig_red_add keeps them visible)
+                            if (fabsf(part) < 5.0e5f) atomicAdd(sdbq + n, (unsigned long long)__float2ll_rn(part * 17592186044416.f));
+                            else ig_red_add(db + n0 + n, part);
+                        }
+                    }
+                }
+            }
         }
         __syncthreads();
         if (live) {
@@ -465,14 +474,6 @@ __global__ __launch_bounds__(TPB, VEC == 8 ? 1 : 2) void cls_bwd_kernel(const fl
                 for (int s2 = 0; s2 < nsl; ++s2) t += slab[((size_t)s2 * G + k) * C + c];
                 ig_red_add(dw + (size_t)(n0 + g0 + k) * C + c, t);
             }
-        }
-        if (live && u == 0) {  // non-finite / out-of-range partials bypass the fixed-point slot (ig_red_add keeps them visible)
-#pragma unroll
-            for (int n = 0; n < NC; ++n)
-                if (n < ncl) {
-                    if (fabsf(dba[n]) < 5.0e5f) atomicAdd(sdbq + n, (unsigned long long)__float2ll_rn(dba[n] * 17592186044416.f));
-                    else ig_red_add(db + n0 + n, dba[n]);
-                }
         }
         __syncthreads();
         for (int i = threadIdx.x; i < ncl; i += TPB) ig_red_add(db + n0 + i, (float)((double)(long long)sdbq[i] * 5.684341886080802e-14));
@@ -911,8 +912,11 @@ static int classifier_bwd_impl(int mode, ClsBn bn, int* nwg_out, const float* dl
     const long ppb = nsl * iters;  // pixels per workgroup
     const unsigned gx = (unsigned)((M + ppb - 1) / ppb);
     const unsigned gy_split = wide ? (unsigned)((ncls + 7) / 8) : 1u;  // class groups of the dW passes
-    if (nwg_out) {  // geometry query (the caller sizes the partial-sum scratch before the launch)
-        *nwg_out = (int)(gx * gy_split);
+    // > 8 classes: the dW passes take all 16 class slots in one group (default: 13 classes, S form: 722 against 1040 us for two groups of 8, each of
+    // which repeats the loads, the dropout hash and the mask; IG_CLS_ONE_GROUP=0 for A/B runs)
+    static const bool one_group = !getenv("IG_CLS_ONE_GROUP") || atoi(getenv("IG_CLS_ONE_GROUP"));
+    if (nwg_out) {  // geometry query of the reduce pass (the caller sizes the partial-sum scratch before the launch)
+        *nwg_out = (int)(gx * (nc == 16 && one_group ? 1u : gy_split));
         return IG_OK;
     }
     long ig = 4096 / (nc * nsl);  // iterations per staged dlogits group: ~16 KiB of LDS (at most 8 x 16 x 128 floats = 64 KiB)
@@ -938,8 +942,12 @@ static int classifier_bwd_impl(int mode, ClsBn bn, int* nwg_out, const float* dl
     do {                                                      \
         if (mode == 0) {                                      \
             IG_CLS_BWD(NC, 4, 3, 1);                          \
-            IG_CLS_BWD(8, 4, 4, gy_split);                    \
-        } else if (mode == 1) IG_CLS_BWD(8, 4, 5, gy_split);  \
+            if (NC == 16 && one_group) IG_CLS_BWD(NC, 4, 4, 1); \
+            else IG_CLS_BWD(8, 4, 4, gy_split);               \
+        } else if (mode == 1) {                               \
+            if (NC == 16 && one_group) IG_CLS_BWD(NC, 4, 5, 1); \
+            else IG_CLS_BWD(8, 4, 5, gy_split);               \
+        }                                                     \
         else IG_CLS_BWD(NC, 4, 2, 1);                         \
     } while (0)
     if (nc == 2) IG_CLS_BWD_M(2);

@@ -567,11 +567,16 @@ class SegEngine:
                 if training and update_running:
                     self.buffers[f"{h}{i}.3.num_batches_tracked"] += 1
                 continue
-            ops.conv_fwd(ws["u"][i], self.W(f"{h}{i}.2.weight"), self.P(f"{h}{i}.2.bias"), ws["cv"][i], B, Hu, Hu, dims[i + 1],
-                         dims[i + 1], ks[i])
+            stats_ready = False  # the direct convolutions (48 / 96 channels) leave the BatchNorm statistics: no statistics pass
+            if ks[i] == 3 and training:
+                stats_ready = ops.conv3x3_fwd_stats(ws["u"][i], self.W(f"{h}{i}.2.weight"), self.P(f"{h}{i}.2.bias"), ws["cv"][i], ws["bn_sums"], B, Hu, Hu,
+                                                    dims[i + 1], dims[i + 1])
+            else:
+                ops.conv_fwd(ws["u"][i], self.W(f"{h}{i}.2.weight"), self.P(f"{h}{i}.2.bias"), ws["cv"][i], B, Hu, Hu, dims[i + 1],
+                             dims[i + 1], ks[i])
             ops.bn_relu_fwd(ws["cv"][i], self.P(f"{h}{i}.3.weight"), self.P(f"{h}{i}.3.bias"), self.buffers[f"{h}{i}.3.running_mean"],
                             self.buffers[f"{h}{i}.3.running_var"], ws["f"][i + 1], ws["bn_scale"][i], ws["bn_shift"][i], ws["bn_mean"][i],
-                            ws["bn_rstd"][i], ws["bn_sums"], B * Ho * Ho, dims[i + 1], training, training and update_running)
+                            ws["bn_rstd"][i], ws["bn_sums"], B * Ho * Ho, dims[i + 1], training, training and update_running, stats_ready=stats_ready)
             if training and update_running:
                 self.buffers[f"{h}{i}.3.num_batches_tracked"] += 1
         S = cfg.out_size  # = img_size for every variant at its native chip size (3 x 3 kernels keep 2 x; 600M: 228 -> 224)

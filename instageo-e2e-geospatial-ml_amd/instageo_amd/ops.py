@@ -536,11 +536,13 @@ def conv3x3_wgrad(dy: BT, x: BT, dw, B, H, W, Cin, Cout, dbias=None) -> None:
 
 
 def bn_relu_fwd(x: BT, gamma, beta, rmean, rvar, y: BT, scale, shift, mean, rstd, sums, M: int, C: int, training: bool,
-                update_running: bool, eps: float = 1e-5, momentum: float = 0.1) -> None:
+                update_running: bool, eps: float = 1e-5, momentum: float = 0.1, stats_ready: bool = False) -> None:
+    """``stats_ready``: ``sums`` already holds the batch statistics (:func:`conv3x3_fwd_stats` returned True): no statistics pass."""
     nb = 2 if x.lo is None else 4
     # training: statistics pass (read) + apply pass (read + write); eval: one read + write pass
-    _call("ig_bn_relu_fwd", float(M) * C * nb * (3 if training else 2), _p(x.hi), _p(x.lo), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(y.hi), _p(y.lo), _p(scale), _p(shift),
-          _p(mean), _p(rstd), _p(sums), M, C, eps, momentum, int(training), int(update_running), _stream())
+    mode = (2 if stats_ready else 1) if training else 0
+    _call("ig_bn_relu_fwd", float(M) * C * nb * (3 if mode == 1 else 2), _p(x.hi), _p(x.lo), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(y.hi), _p(y.lo), _p(scale), _p(shift),
+          _p(mean), _p(rstd), _p(sums), M, C, eps, momentum, mode, int(update_running), _stream())
 
 
 def bn_relu_bwd(x: BT, dy: BT, scale, shift, mean, rstd, dx: BT, dgamma, dbeta, sums, M: int, C: int) -> None:

@@ -958,7 +958,8 @@ def test_classifier_and_loss(split, ncls, C):
     close(db, gb, 3e-5, what="classifier db")
 
 
-@pytest.mark.parametrize("C,B,H,W,expect", [(48, 3, 40, 40, True), (48, 2, 23, 37, True), (48, 70, 32, 32, True), (192, 1, 16, 16, False)])
+@pytest.mark.parametrize("C,B,H,W,expect", [(48, 3, 40, 40, True), (48, 2, 23, 37, True), (48, 70, 32, 32, True), (192, 1, 16, 16, False),
+                                            (96, 2, 40, 40, True), (96, 3, 21, 35, True), (96, 40, 32, 32, True)])
 def test_conv3x3_fwd_stats(C, B, H, W, expect):
     """nn.Conv2d(k=3, padding=1) in front of a training-mode BatchNorm (model.py:370-377): where the direct 48-channel kernel runs, its
     epilogue also leaves the per-channel sum / sum of squares of the STORED outputs (the statistics pass without its read of the tensor);
@@ -989,6 +990,14 @@ def test_conv3x3_fwd_stats(C, B, H, W, expect):
             scale, shift, mean, rstd = (torch.empty(C, device=DEV) for _ in range(4))
             if mode:
                 ops.bn_finalize(sums, g.to(DEV), b.to(DEV), rm, rv, scale, shift, mean, rstd, B * H * W, C, True)
+                # ... and the apply pass from ready statistics == statistics + apply
+                ya, yb = BT.empty((B, H, W, C), False, DEV), BT.empty((B, H, W, C), False, DEV)
+                r2, v2 = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+                ops.bn_relu_fwd(y, g.to(DEV), b.to(DEV), r2, v2, ya, scale, shift, mean, rstd, sums.clone(), B * H * W, C, True, True, stats_ready=True)
+                r3, v3 = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+                ops.bn_relu_fwd(y, g.to(DEV), b.to(DEV), r3, v3, yb, scale, shift, mean, rstd, torch.empty_like(sums), B * H * W, C, True, True)
+                close(ya.float(), yb.float().double().cpu(), 1e-2, what="apply from ready statistics")
+                close(r2, r3.double().cpu(), 2e-6, what="running mean (ready statistics)")
             else:
                 s3 = torch.empty_like(sums)
                 ops.bn_stats(y, g.to(DEV), b.to(DEV), rm, rv, scale, shift, mean, rstd, s3, B * H * W, C, True)
