@@ -45,7 +45,13 @@ def _read_ifd(buf: bytes, bo: str, off: int) -> Dict[int, Tuple[int, Any]]:
             continue
         fmt, size = _TYPES[typ]
         nbytes = size * cnt
-        data = val[:nbytes] if nbytes <= 4 else buf[struct.unpack(bo + "I", val)[0] :][:nbytes]
+        if nbytes <= 4:
+            data = val[:nbytes]
+        else:
+            voff = struct.unpack(bo + "I", val)[0]
+            if voff + nbytes > len(buf):  # beyond what was read (header-only reads take the first 64 KiB): the caller re-reads the whole file
+                raise struct.error(f"tag {tag}: {nbytes} bytes at offset {voff} lie beyond the {len(buf)} bytes read")
+            data = buf[voff : voff + nbytes]
         if typ == 2:
             tags[tag] = (typ, data.rstrip(b"\x00").decode("latin-1"))
         elif typ in (5, 10):
@@ -162,7 +168,10 @@ class _Header:
 def _header(path: str, whole: bool) -> _Header:
     with open(path, "rb") as f:
         if whole:
-            return _Header(path, f.read())
+            try:
+                return _Header(path, f.read())
+            except (struct.error, IndexError) as e:
+                raise TiffError(f"{path}: truncated or corrupt TIFF ({e})") from e
         # header only: the IFD and its out-of-line values normally sit in the first or the last kilobytes; fall back to the whole
         # file when an offset points outside what was read
         head = f.read(1 << 16)
@@ -170,7 +179,10 @@ def _header(path: str, whole: bool) -> _Header:
             return _Header(path, head)
         except (struct.error, IndexError):
             f.seek(0)
-            return _Header(path, f.read())
+            try:
+                return _Header(path, f.read())
+            except (struct.error, IndexError) as e:
+                raise TiffError(f"{path}: truncated or corrupt TIFF ({e})") from e
 
 
 def read(path: str, bands: Optional[List[int]] = None) -> Tuple[np.ndarray, Dict[str, Any]]:

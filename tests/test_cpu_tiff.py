@@ -108,3 +108,34 @@ def test_read_profile_is_header_only_and_band_subset(tmp_path):
     assert tiff.read_profile(path) == prof
     with pytest.raises(tiff.TiffError):
         tiff.read(path, bands=[6])
+
+
+def test_read_profile_falls_back_when_tag_values_lie_beyond_the_header_read(tmp_path):
+    """read_profile reads the first 64 KiB; an out-of-line ASCII value (GDAL_NODATA) stored beyond them must trigger the
+    whole-file fallback instead of coming back truncated; a value beyond the end of the file is an error, not an empty string."""
+    import struct
+
+    W = H = 4
+    pix = bytes(range(W * H))
+    nodata = b"-9999\x00"
+    nd_off = 70000  # beyond the 64 KiB header read
+    entries = [(256, 3, 1, W), (257, 3, 1, H), (258, 3, 1, 8), (259, 3, 1, 1), (262, 3, 1, 1), (273, 4, 1, 200), (277, 3, 1, 1), (278, 3, 1, H),
+               (279, 4, 1, W * H), (339, 3, 1, 1), (42113, 2, len(nodata), nd_off)]
+    ifd = struct.pack("<H", len(entries))
+    for tag, typ, cnt, val in entries:
+        ifd += struct.pack("<HHI", tag, typ, cnt) + (struct.pack("<HH", val, 0) if typ == 3 else struct.pack("<I", val))
+    ifd += struct.pack("<I", 0)
+    buf = bytearray(nd_off + len(nodata))
+    buf[0:8] = b"II" + struct.pack("<HI", 42, 8)
+    buf[8 : 8 + len(ifd)] = ifd
+    buf[200 : 200 + len(pix)] = pix
+    buf[nd_off:] = nodata
+    path = str(tmp_path / "far_tag.tif")
+    open(path, "wb").write(bytes(buf))
+    prof = tiff.read_profile(path)
+    assert prof["nodata"] == -9999.0 and prof["width"] == W and prof["height"] == H
+    arr, prof2 = tiff.read(path)
+    assert prof2 == prof and arr.reshape(-1).tolist() == list(pix)
+    open(path, "wb").write(bytes(buf[: nd_off + 2]))  # the value now runs past the end of the file
+    with pytest.raises(tiff.TiffError):
+        tiff.read_profile(path)
