@@ -294,7 +294,7 @@ __global__ __launch_bounds__(A2_THREADS, LB) void attn2_bwd_dq_kernel(const bf16
                                                                   const bf16_t* __restrict__ o_hi, const bf16_t* __restrict__ o_lo,
                                                                   const float* __restrict__ lse, float* __restrict__ delta,
                                                                   bf16_t* __restrict__ dqkv_hi, bf16_t* __restrict__ dqkv_lo, int N, int H,
-                                                                  float scale) {
+                                                                  float scale, float* __restrict__ dbias) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* k_hi = smem;
     char* v_hi = smem + A2_TILE;
@@ -395,15 +395,70 @@ __global__ __launch_bounds__(A2_THREADS, LB) void attn2_bwd_dq_kernel(const bf16
             }
         }
     }
-    if (!active || q >= N) return;
-    const size_t orow = ((size_t)b * N + q) * RS + h * 64;
+    const bool valid = active && q < N;
+    if (valid) {
+        const size_t orow = ((size_t)b * N + q) * RS + h * 64;
 #pragma unroll
-    for (int dhf = 0; dhf < 2; ++dhf)
+        for (int dhf = 0; dhf < 2; ++dhf)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float f[4] = {dq[dhf][4 * g] * scale, dq[dhf][4 * g + 1] * scale, dq[dhf][4 * g + 2] * scale, dq[dhf][4 * g + 3] * scale};
-            store4_split(dqkv_hi, dqkv_lo, orow + 32 * dhf + 8 * g + 4 * lh, f);
+            for (int g = 0; g < 4; ++g) {
+                const float f[4] = {dq[dhf][4 * g] * scale, dq[dhf][4 * g + 1] * scale, dq[dhf][4 * g + 2] * scale, dq[dhf][4 * g + 3] * scale};
+                store4_split(dqkv_hi, dqkv_lo, orow + 32 * dhf + 8 * g + 4 * lh, f);
+            }
+    }
+    if (!dbias) return;  // wave-uniform
+    // Bias gradient of the fused qkv Linear (column sums of dqkv over the tokens) from what this workgroup already holds, as in the
+    // single-pass kernel: Q part = sum over its queries of dQ; V part = sum_key dV = sum_q dO (the rows of P sum to one) -> the dO
+    // rows of its queries; K part = 0 exactly (the rows of dS sum to zero).  This replaces an ig_colsum pass over all of dqkv per Block
+    // (T = 3, B = 36: 12 x 43 us; bf16x3 at B = 216: 12 x 145 us).  Lanes = queries: a transposing butterfly over the 32 lanes of a
+    // half-wave (31 shuffles per 32 values) leaves value index lr in lane lr; waves are folded through the (dead) K image.
+    __syncthreads();  // every wave has left the key loop: the K image is dead
+    float* scr = reinterpret_cast<float*>(smem);  // [wave][part][64]
+    // value index lr -> column: dQ register (dhf, 4 g + e) = index 16 dhf + 4 g + e holds column 32 dhf + 8 g + 4 lh + e;
+    // dO fragment (s, e) = index 8 s + e holds column 16 s + 8 lh + e.  (One set of 32 values at a time: registers.)
+    {
+        float v[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) v[i] = valid ? dq[i >> 4][i & 15] * scale : 0.f;
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) {
+            const bool up = (lr & o) != 0;
+#pragma unroll
+            for (int i = 0; i < o; ++i) {
+                const float snd = up ? v[i] : v[i + o], kp = up ? v[i + o] : v[i];
+                v[i] = kp + __shfl_xor(snd, o, 64);
+            }
         }
+        scr[(wave * 2 + 0) * 64 + 32 * (lr >> 4) + 8 * ((lr >> 2) & 3) + 4 * lh + (lr & 3)] = v[0];
+    }
+    {
+        float v[32];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float dv = SPLIT ? (float)dh[s][e] + (float)dl[s][e] : (float)dh[s][e];
+                v[s * 8 + e] = valid ? dv : 0.f;
+            }
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) {
+            const bool up = (lr & o) != 0;
+#pragma unroll
+            for (int i = 0; i < o; ++i) {
+                const float snd = up ? v[i] : v[i + o], kp = up ? v[i + o] : v[i];
+                v[i] = kp + __shfl_xor(snd, o, 64);
+            }
+        }
+        scr[(wave * 2 + 1) * 64 + 16 * (lr >> 3) + 8 * lh + (lr & 7)] = v[0];
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int part = tid >> 6, col = tid & 63;  // part 0 = Q, 1 = V
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < A2_WAVES; ++w) t += scr[(w * 2 + part) * 64 + col];
+        ig_red_add(dbias + (size_t)(part * 2) * H * 64 + h * 64 + col, t);
+    }
 }
 
 template <bool SPLIT>
@@ -777,7 +832,7 @@ int ig_attention2_fwd(const void* qkv_hi, const void* qkv_lo, void* out_hi, void
 }
 
 // dbias (optional): the qkv bias gradient, dbias[3][H][64] += column sums of dqkv over the B * N tokens -- fused into the single-pass
-// kernel (the K third is identically zero there), one ig_colsum pass over dqkv behind the two-pass kernels
+// kernel and into the dQ kernel of the two-pass form (the K third is identically zero; IG_ATTN2_DQ_BIAS=0: one ig_colsum pass over dqkv)
 int ig_attention2_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi, const void* out_lo, const void* dout_hi,
                       const void* dout_lo, const float* lse, float* delta, void* dqkv_hi, void* dqkv_lo, float* dbias, int B, int N, int H,
                       void* stream) {
@@ -804,6 +859,9 @@ int ig_attention2_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi
     }
     const char* lb = getenv("IG_ATTN2_DQLB");  // 4 (default): two dQ workgroups per CU at 128 registers (56 B of scratch); 2: one at 143 -- measured 75 vs 85 us
     const int dqlb = lb ? atoi(lb) : 4;
+    const char* be = getenv("IG_ATTN2_DQ_BIAS");  // 0: the qkv bias gradient by a column-sum pass over dqkv (A/B runs)
+    const bool kbias = dbias && !(be && atoi(be) == 0);
+    float* dbias_k = kbias ? dbias : nullptr;
 #define IG_A2_BWD(SPLIT_)                                                                                                          \
     {                                                                                                                              \
         static bool attr = false;                                                                                                  \
@@ -816,11 +874,11 @@ int ig_attention2_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi
         if (dqlb == 4 && !SPLIT_)                                                                                                  \
             hipLaunchKernelGGL((attn2_bwd_dq_kernel<SPLIT_, 4>), grid, dim3(A2_THREADS), lds_q, st, (const bf16_t*)qkv_hi,          \
                                (const bf16_t*)qkv_lo, (const bf16_t*)dout_hi, (const bf16_t*)dout_lo, (const bf16_t*)out_hi,       \
-                               (const bf16_t*)out_lo, lse, delta, (bf16_t*)dqkv_hi, (bf16_t*)dqkv_lo, N, H, scale);                \
+                               (const bf16_t*)out_lo, lse, delta, (bf16_t*)dqkv_hi, (bf16_t*)dqkv_lo, N, H, scale, dbias_k);       \
         else                                                                                                                       \
             hipLaunchKernelGGL((attn2_bwd_dq_kernel<SPLIT_, 2>), grid, dim3(A2_THREADS), lds_q, st, (const bf16_t*)qkv_hi,          \
                                (const bf16_t*)qkv_lo, (const bf16_t*)dout_hi, (const bf16_t*)dout_lo, (const bf16_t*)out_hi,       \
-                               (const bf16_t*)out_lo, lse, delta, (bf16_t*)dqkv_hi, (bf16_t*)dqkv_lo, N, H, scale);                \
+                               (const bf16_t*)out_lo, lse, delta, (bf16_t*)dqkv_hi, (bf16_t*)dqkv_lo, N, H, scale, dbias_k);       \
         ig_note_kernel("attn2_bwd_dq_kernel<%s>+attn2_bwd_dkv_kernel<%s>", SPLIT_ ? "true" : "false", SPLIT_ ? "true" : "false");  \
         hipLaunchKernelGGL(attn2_bwd_dkv_kernel<SPLIT_>, grid, dim3(A2_THREADS), lds_kv, st, (const bf16_t*)qkv_hi,                   \
                            (const bf16_t*)qkv_lo, (const bf16_t*)dout_hi, (const bf16_t*)dout_lo, lse, delta, (bf16_t*)dqkv_hi,     \
@@ -828,10 +886,10 @@ int ig_attention2_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi
     }
     if (split) IG_A2_BWD(true) else IG_A2_BWD(false)
 #undef IG_A2_BWD
-    if (dbias) {
+    if (dbias && !kbias) {
         // (round 4, measured and not kept: Q part = column sums of the dQ third, K part = 0, V part = column sums of dO -- two passes over
         // M x D instead of one over M x 3D -- is SLOWER at T = 3 / B = 36: 2 x 30.8 us against 41.9 us, the pass is bound by its launch and
-        // its final atomics at this size, not by the bytes)
+        // its final atomics at this size, not by the bytes; kept: the same sums from INSIDE the dQ kernel, above)
         const int rc = ig_colsum(dqkv_hi, dqkv_lo, dbias, (long)B * N, 3 * H * 64, stream);
         if (rc != IG_OK) return rc;
     }
