@@ -175,6 +175,12 @@ int ig_conv3x3_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const v
  * sums[2 Cout] (per-channel sum / sum of squares of the stored outputs) and sets *fused = 1 (HOST int); else *fused = 0 */
 int ig_conv3x3_fwd_stats(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias, void* y_hi,
                          void* y_lo, double* sums, int* fused, int B, int H, int W, int Cin, int Cout, void* stream);
+/* inference tail: the last nn.Conv2d(k=3, padding=1) (:370-375, + eval-mode BatchNorm + ReLU) and the nn.Conv2d(k=1) classifier (:389;
+ * dropout is the identity in eval mode) in ONE kernel where the direct 48-channel kernel runs and ncls <= 2: *fused = 1 (HOST int), y_hi
+ * may be NULL (the activation is then not stored).  *fused = 0: nothing was computed, run ig_conv3x3_fwd + ig_classifier_fwd. */
+int ig_conv3x3_cls_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias, const float* bn_scale,
+                       const float* bn_shift, void* y_hi, const float* cls_w, const float* cls_b, float* logits, int* fused, int B, int H,
+                       int W, int Cin, int Cout, int ncls, void* stream);
 /* batch statistics -> scale / shift / mean / rstd (+ running update) from sums a producer filled (finalize step of ig_bn_relu_fwd) */
 int ig_bn_finalize(const double* sums, const float* gamma, const float* beta, float* running_mean, float* running_var, float* scale,
                    float* shift, float* mean, float* rstd, long M, int C, float eps, float momentum, int update_running, void* stream);

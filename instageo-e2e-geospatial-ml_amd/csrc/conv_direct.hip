@@ -82,9 +82,13 @@ struct CDParams {
     // optional (conv3x3_direct_kernel): per-workgroup partial sums [gridDim.x][2C] of the STORED (bf16-rounded) outputs and their
     // squares -- the statistics pass of the training-mode BatchNorm that follows, without its read of the tensor
     float* stats_part;
+    // optional (conv3x3_direct_kernel<C, NCLS > 0>, inference): the 1 x 1 classifier on top of the finished pixels (eval-mode BatchNorm +
+    // ReLU already folded in): logits[b][n][oy][ox] = cls_b[n] + sum_c cls_w[n][c] * v[c]; y may then be NULL (the activation is not stored)
+    const float *cls_w, *cls_b;
+    float* logits;
 };
 
-template <int C>
+template <int C, int NCLS = 0>
 __global__ __launch_bounds__(CD_TPB, 2) void conv3x3_direct_kernel(CDParams p) {
     using G = CDCfg<C>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -212,6 +216,17 @@ __global__ __launch_bounds__(CD_TPB, 2) void conv3x3_direct_kernel(CDParams p) {
 #pragma unroll
     for (int k = 0; k < NS; ++k) st_s[k] = 0.f, st_q[k] = 0.f;
     const bool want_stats = p.stats_part != nullptr;
+    // classifier weights of this lane's channels (registers: NCLS <= 2)
+    float cw[NCLS > 0 ? NCLS : 1][NS];
+    if constexpr (NCLS > 0) {
+#pragma unroll
+        for (int n = 0; n < NCLS; ++n)
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int c = k < G::NPAIR * 8 ? (k / 8) * 32 + 8 * g + k % 8 : (G::NB - 1) * 16 + 4 * g + (k - G::NPAIR * 8);
+                cw[n][k] = p.cls_w[n * C + c];
+            }
+    }
     // output element offset of this lane's pixel (row 4*wave of the tile, column j) relative to the tile origin, + channel 8g
     const int e_lane = ((wave * 4) * p.W + j) * C;
     const int nt = (int)p.ntiles, gstep = (int)gridDim.x;
@@ -263,7 +278,11 @@ __global__ __launch_bounds__(CD_TPB, 2) void conv3x3_direct_kernel(CDParams p) {
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             const int oy = ty0 + wave * 4 + mb;
-            if (oy < p.H && ox < p.W) {
+            const bool inside = oy < p.H && ox < p.W;
+            float lg[NCLS > 0 ? NCLS : 1];
+#pragma unroll
+            for (int n = 0; n < (NCLS > 0 ? NCLS : 1); ++n) lg[n] = 0.f;
+            if (inside) {
                 const size_t pixc = origin + (unsigned)(e_lane + mb * p.W * C);  // element index of channel 0 of the pixel
 #pragma unroll
                 for (int pr = 0; pr < G::NPAIR; ++pr) {
@@ -273,12 +292,18 @@ __global__ __launch_bounds__(CD_TPB, 2) void conv3x3_direct_kernel(CDParams p) {
                     finish4(acc[2 * pr][mb], n, idx, v);
                     finish4(acc[2 * pr + 1][mb], n + 4, idx + 4, v + 4);
                     const uint4 pk = pack8(v);
-                    *reinterpret_cast<uint4*>(p.y + idx) = pk;
+                    if (NCLS == 0 || p.y) *reinterpret_cast<uint4*>(p.y + idx) = pk;
                     if (want_stats) {
                         float r[8];
                         unpack8(pk, r);
 #pragma unroll
                         for (int i = 0; i < 8; ++i) st_s[pr * 8 + i] += r[i], st_q[pr * 8 + i] = fmaf(r[i], r[i], st_q[pr * 8 + i]);
+                    }
+                    if constexpr (NCLS > 0) {
+#pragma unroll
+                        for (int n2 = 0; n2 < NCLS; ++n2)
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) lg[n2] = fmaf(v[i], cw[n2][pr * 8 + i], lg[n2]);
                     }
                 }
                 if (G::NB & 1) {
@@ -286,7 +311,7 @@ __global__ __launch_bounds__(CD_TPB, 2) void conv3x3_direct_kernel(CDParams p) {
                     const size_t idx = pixc + n;
                     float v[4];
                     finish4(acc[G::NB - 1][mb], n, idx, v);
-                    store4_split(p.y, nullptr, idx, v);
+                    if (NCLS == 0 || p.y) store4_split(p.y, nullptr, idx, v);
                     if (want_stats) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
@@ -294,6 +319,21 @@ __global__ __launch_bounds__(CD_TPB, 2) void conv3x3_direct_kernel(CDParams p) {
                             st_s[G::NPAIR * 8 + i] += r, st_q[G::NPAIR * 8 + i] = fmaf(r, r, st_q[G::NPAIR * 8 + i]);
                         }
                     }
+                    if constexpr (NCLS > 0) {
+#pragma unroll
+                        for (int n2 = 0; n2 < NCLS; ++n2)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) lg[n2] = fmaf(v[i], cw[n2][G::NPAIR * 8 + i], lg[n2]);
+                    }
+                }
+            }
+            if constexpr (NCLS > 0) {  // the four k-group lanes of a pixel (lane = 16 g + j) hold its 48 channels: fold, g == 0 stores
+#pragma unroll
+                for (int n2 = 0; n2 < NCLS; ++n2) {
+                    float t = lg[n2];
+                    t += __shfl_xor(t, 16, 64);
+                    t += __shfl_xor(t, 32, 64);
+                    if (g == 0 && inside) p.logits[((size_t)b * NCLS + n2) * p.H * p.W + (size_t)oy * p.W + ox] = t + p.cls_b[n2];
                 }
             }
         }
@@ -323,12 +363,12 @@ __global__ __launch_bounds__(CD_TPB, 2) void conv3x3_direct_kernel(CDParams p) {
     }
 }
 
-template <int C>
+template <int C, int NCLS = 0>
 int launch_direct(CDParams p, hipStream_t st, const char* what, double* stat_sums = nullptr) {
     using G = CDCfg<C>;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_direct_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
+        (void)hipFuncSetAttribute((const void*)conv3x3_direct_kernel<C, NCLS>, hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
         attr_done = true;
     }
     static const int nwg_env = getenv("IG_CONV_DIRECT_WGS") ? atoi(getenv("IG_CONV_DIRECT_WGS")) : 0;
@@ -341,13 +381,15 @@ int launch_direct(CDParams p, hipStream_t st, const char* what, double* stat_sum
             return IG_ERR_HIP;
         }
     }
-    ig_note_kernel("conv3x3_direct_kernel<%d>", C);
-    hipLaunchKernelGGL(conv3x3_direct_kernel<C>, dim3((unsigned)nwg), dim3(CD_TPB), G::SMEM, st, p);
+    if (NCLS) ig_note_kernel("conv3x3_direct_kernel<%d,%d>", C, NCLS);
+    else ig_note_kernel("conv3x3_direct_kernel<%d>", C);
+    hipLaunchKernelGGL((conv3x3_direct_kernel<C, NCLS>), dim3((unsigned)nwg), dim3(CD_TPB), G::SMEM, st, p);
     if (stat_sums) hipLaunchKernelGGL(bn_part_fold_kernel, dim3(ig_cdiv(2 * C, 64)), dim3(1024), 0, st, p.stats_part, stat_sums, (int)nwg, 2 * C);
     return ig_check_launch(what);
 }
 
 // ---------------------------------------------------------------------------------------------- weight gradient
+
 // dWc[co][tap][ci] += sum_pixels dy[p][co] * x[p + off(tap)][ci] for the 48- and 96-channel stages.  The implicit GEMM needs
 // a split-K grid with an atomic pass per split and gathers x nine times (843 us at 108 x 224 x 224 x 48); here a persistent
 // workgroup keeps a 48 x 9*CIN partial sum in registers (3 x 7 MFMA accumulators per wave; 4 waves for CIN = 48, 8 for 96)
@@ -1673,6 +1715,26 @@ static const bf16_t* cd_zero_page() {
 
 // Called by ig_conv3x3_fwd / ig_conv3x3_dgrad (gemm.hip) for the shapes this kernel covers; returns IG_ERR_UNSUPPORTED
 // (without setting the error string) when it does not, and the caller falls through to the implicit GEMM.
+// Inference tail: the 48-channel last Conv2d (+ bias, + eval-mode BatchNorm + ReLU) with the 1 x 1 classifier applied to the finished
+// pixels in the same epilogue: the head's largest activation is neither written nor read again.  y may be NULL.  IG_ERR_UNSUPPORTED
+// (no error string) when the shape is not covered (C != 48, more than 2 classes): the caller runs the two kernels.
+int ig_conv3x3_cls_direct(const void* x, const void* w, const float* bias, const float* bn_scale, const float* bn_shift, void* y,
+                          const float* cls_w, const float* cls_b, float* logits, int B, int H, int W, int C, int ncls, void* stream) {
+    static const int enabled = getenv("IG_CONV_CLS") ? atoi(getenv("IG_CONV_CLS")) : 1;
+    if (!enabled || C != 48 || ncls < 1 || ncls > 2 || (long)B * H * W * C >= (1L << 31)) return IG_ERR_UNSUPPORTED;
+    CDParams p{};
+    p.x = (const bf16_t*)x, p.w = (const bf16_t*)w, p.y = (bf16_t*)y;
+    p.bias = bias, p.col_scale = bn_scale, p.col_shift = bn_shift;
+    p.B = B, p.H = H, p.W = W;
+    p.tiles_x = (W + TW - 1) / TW, p.tiles_y = (H + TH - 1) / TH;
+    p.ntiles = (long)B * p.tiles_x * p.tiles_y;
+    p.drop_inv = 1.f;
+    p.cls_w = cls_w, p.cls_b = cls_b, p.logits = logits;
+    if (p.ntiles == 0) return IG_OK;
+    if (ncls == 1) return launch_direct<48, 1>(p, (hipStream_t)stream, "ig_conv3x3_cls_fwd(direct)");
+    return launch_direct<48, 2>(p, (hipStream_t)stream, "ig_conv3x3_cls_fwd(direct)");
+}
+
 int ig_conv3x3_direct(const void* x, const void* w, const float* bias, const float* bn_scale, const float* bn_shift, void* y,
                       int B, int H, int W, int Cin, int Cout, int dgrad, unsigned drop_seed, const unsigned* drop_seed_dev,
                       float drop_p, void* stream, double* stat_sums, int* stats_fused) {

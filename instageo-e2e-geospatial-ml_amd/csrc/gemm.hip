@@ -1924,6 +1924,22 @@ int ig_conv3x3_fwd_stats(const void* x_hi, const void* x_lo, const void* w_hi, c
     return ig_conv3x3_fwd(x_hi, x_lo, w_hi, w_lo, bias, nullptr, nullptr, y_hi, y_lo, B, H, W, Cin, Cout, stream);
 }
 
+// Inference: the last Conv2d(k=3, padding=1) (+ eval-mode BatchNorm + ReLU) and the Conv2d(k=1) classifier on top of it.  Where the direct
+// 48-channel kernel runs and ncls <= 2 the classifier is applied in the convolution's epilogue (*fused = 1, HOST int; y may be NULL and
+// is then not written); otherwise *fused = 0 and NOTHING has been computed: the caller runs ig_conv3x3_fwd and ig_classifier_fwd.
+int ig_conv3x3_cls_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias, const float* bn_scale,
+                       const float* bn_shift, void* y_hi, const float* cls_w, const float* cls_b, float* logits, int* fused, int B, int H,
+                       int W, int Cin, int Cout, int ncls, void* stream) {
+    IG_REQUIRE(x_hi && w_hi && cls_w && cls_b && logits && fused, "ig_conv3x3_cls_fwd: null pointer");
+    IG_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "ig_conv3x3_cls_fwd: bn_scale and bn_shift go together");
+    *fused = 0;
+    if (x_lo || w_lo || Cin != Cout) return IG_OK;
+    const int rc = ig_conv3x3_cls_direct(x_hi, w_hi, bias, bn_scale, bn_shift, y_hi, cls_w, cls_b, logits, B, H, W, Cin, ncls, stream);
+    if (rc == IG_ERR_UNSUPPORTED) return IG_OK;
+    if (rc == IG_OK) *fused = 1;
+    return rc;
+}
+
 // dx = conv_dgrad(dy, w) [* dropout mask of the conv input when drop_p > 0]
 int ig_conv3x3_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, const void* w_lo, void* dx_hi, void* dx_lo,
                      int B, int H, int W, int Cin, int Cout, unsigned drop_seed, const unsigned* drop_seed_dev, float drop_p,

@@ -539,6 +539,7 @@ class SegEngine:
         p = cfg.drop_p if training else 0.0
         sd = self._drop_counter(advance=True) if p > 0 else None
         h = "segmentation_head."
+        eval_tail_fused = False
         for i in range(4):
             Hs, Hu, Ho = hs[i]  # ConvTranspose2d: Hs -> Hu = 2 Hs; Conv2d(k, padding=1): Hu -> Ho = Hu + 3 - k (model.py:349-378)
             ops.convT_fwd(ws["f"][i], self.W(f"{h}{i}.0.weight"), self.P(f"{h}{i}.0.bias"), ws["u"][i], B, Hs, Hs, dims[i], dims[i + 1],
@@ -547,6 +548,16 @@ class SegEngine:
                 # eval mode: BatchNorm(running stats)+ReLU is a per-channel affine folded into the conv epilogue (one HBM pass less)
                 ops.bn_eval_affine(self.P(f"{h}{i}.3.weight"), self.P(f"{h}{i}.3.bias"), self.buffers[f"{h}{i}.3.running_mean"],
                                    self.buffers[f"{h}{i}.3.running_var"], ws["bn_scale"][i], ws["bn_shift"][i], dims[i + 1])
+                if i == 3 and ks[i] == 3 and self.fuse_tail:
+                    # inference tail: where the direct 48-channel kernel runs, the classifier is applied in the last convolution's epilogue
+                    # and the head's largest activation is neither written nor read again
+                    if out is None:
+                        out = torch.empty((B, cfg.num_classes, cfg.out_size, cfg.out_size), dtype=torch.float32, device=ws["f"][4].hi.device)
+                    eval_tail_fused = ops.conv3x3_cls_fwd(ws["u"][i], self.W(f"{h}{i}.2.weight"), self.P(f"{h}{i}.2.bias"), ws["bn_scale"][i],
+                                                          ws["bn_shift"][i], None, self.P(h + "5.weight"), self.P(h + "5.bias"), out, B, Hu, Hu,
+                                                          dims[i + 1], cfg.num_classes)
+                    if eval_tail_fused:
+                        continue
                 ops.conv_fwd(ws["u"][i], self.W(f"{h}{i}.2.weight"), self.P(f"{h}{i}.2.bias"), ws["f"][i + 1], B, Hu, Hu,
                              dims[i + 1], dims[i + 1], ks[i], bn_scale=ws["bn_scale"][i], bn_shift=ws["bn_shift"][i])
                 continue
@@ -582,7 +593,9 @@ class SegEngine:
         S = cfg.out_size  # = img_size for every variant at its native chip size (3 x 3 kernels keep 2 x; 600M: 228 -> 224)
         if out is None:
             out = torch.empty((B, cfg.num_classes, S, S), dtype=torch.float32, device=ws["f"][4].hi.device)
-        if training and self.fuse_tail:
+        if eval_tail_fused:
+            pass
+        elif training and self.fuse_tail:
             ops.classifier_bn_fwd(ws["cv"][3], ws["bn_scale"][3], ws["bn_shift"][3], self.P(h + "5.weight"), self.P(h + "5.bias"), out, B, S * S,
                                   dims[4], cfg.num_classes, seed=self.drop_seed + 4, p=p, seed_dev=sd)
         else:

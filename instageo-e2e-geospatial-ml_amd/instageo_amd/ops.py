@@ -580,6 +580,20 @@ def conv3x3_fwd_stats(x: BT, w: BT, bias, y: BT, sums, B, H, W, Cin, Cout) -> bo
     return bool(fused.value)
 
 
+def conv3x3_cls_fwd(x: BT, w: BT, bias, bn_scale, bn_shift, y: Optional[BT], cls_w, cls_b, logits, B, H, W, C, ncls) -> bool:
+    """Inference tail in one kernel: the last 3 x 3 convolution (+ eval-mode BatchNorm + ReLU) and the 1 x 1 classifier.  True when it ran
+    (direct 48-channel kernel, <= 2 classes, plain bf16); False: nothing was computed, run :func:`conv3x3_fwd` + :func:`classifier_fwd`.
+    ``y`` may be None: the activation is then not stored."""
+    import ctypes
+
+    if x.lo is not None:
+        return False
+    fused = ctypes.c_int(0)
+    _call("ig_conv3x3_fwd", 2.0 * B * H * W * C * C * 9, _p(x.hi), None, _p(w.hi), None, _p(bias), _p(bn_scale), _p(bn_shift), _p(y.hi) if y is not None else None,
+          _p(cls_w), _p(cls_b), _p(logits), ctypes.cast(ctypes.byref(fused), ctypes.c_void_p), B, H, W, C, C, ncls, _stream(), entry="ig_conv3x3_cls_fwd")
+    return bool(fused.value)
+
+
 def bn_finalize(sums, gamma, beta, rmean, rvar, scale, shift, mean, rstd, M: int, C: int, update_running: bool, eps: float = 1e-5,
                 momentum: float = 0.1) -> None:
     _lib.call("ig_bn_finalize", _p(sums), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(scale), _p(shift), _p(mean), _p(rstd), M, C, eps, momentum,

@@ -30,8 +30,9 @@ NAMESPACE = "instageo_mi355x"
 _SCALAR_SCHEMA = {"int": "int", "long": "int", "unsigned": "int", "float": "float", "double": "float"}
 _SKIP = {"ig_last_error", "ig_last_kernel", "ig_note_reset", "ig_last_grid", "ig_version", "ig_header_stamp", "ig_device_info",
          "ig_set_reserved_cus", "ig_get_reserved_cus", "ig_set_deterministic", "ig_get_deterministic", "ig_det_fold", "ig_det_fold_ranges",
-         "ig_linear_wgrad_group", "ig_conv3x3_fwd_stats"}  # host-side queries: no tensors; the grouped launch takes HOST arrays of device
-# pointers; ig_conv3x3_fwd_stats reports through a HOST int (ig_conv3x3_fwd + ig_bn_relu_fwd are the op-level equivalents)
+         "ig_linear_wgrad_group", "ig_conv3x3_fwd_stats", "ig_conv3x3_cls_fwd"}  # host-side queries: no tensors; the grouped launch takes HOST arrays of device
+# pointers; ig_conv3x3_fwd_stats / ig_conv3x3_cls_fwd report through a HOST int (ig_conv3x3_fwd + ig_bn_relu_fwd / ig_classifier_fwd are the
+# op-level equivalents)
 
 
 def parse_prototypes(path: str = _lib.HEADER_PATH) -> Dict[str, List[Tuple[str, str]]]:

@@ -1006,6 +1006,35 @@ def test_conv3x3_fwd_stats(C, B, H, W, expect):
             close(b_, a_.double().cpu(), 2e-6, what=nm)
 
 
+@pytest.mark.parametrize("ncls,C,B,H,W,expect", [(2, 48, 3, 40, 40, True), (1, 48, 2, 23, 37, True), (2, 48, 30, 48, 32, True), (3, 48, 1, 16, 16, False),
+                                                 (2, 96, 1, 16, 16, False)])
+def test_conv3x3_cls_fwd_inference_tail(ncls, C, B, H, W, expect):
+    """Inference tail (model.py:370-377 in eval mode + :389): last Conv2d + folded BatchNorm + ReLU with the 1 x 1 classifier applied in the
+    same epilogue, against float64 torch and against the two separate kernels; uncovered shapes report that nothing was computed."""
+    x, xr = bt(rnd(B, H, W, C, seed=71), False)
+    w, wr = bt(rnd(C, 9, C, seed=72, scale=(9 * C) ** -0.5), False)
+    bias, sc, sh = rnd(C, seed=73), 1 + 0.2 * rnd(C, seed=74), 0.3 * rnd(C, seed=75)
+    cw, cb = rnd(ncls, C, seed=76, scale=C**-0.5), rnd(ncls, seed=77)
+    logits = torch.full((B, ncls, H, W), 7.0, device=DEV)
+    fused = ops.conv3x3_cls_fwd(x, w, bias.to(DEV), sc.to(DEV), sh.to(DEV), None, cw.to(DEV), cb.to(DEV), logits, B, H, W, C, ncls)
+    assert fused == expect
+    if not fused:
+        assert (logits == 7.0).all()  # nothing was computed
+        return
+    conv = F.conv2d(xr.permute(0, 3, 1, 2), wr.view(C, 3, 3, C).permute(0, 3, 1, 2), bias.double(), padding=1)
+    act = F.relu(conv * sc.double().view(1, C, 1, 1) + sh.double().view(1, C, 1, 1))
+    ref = F.conv2d(act, cw.double().view(ncls, C, 1, 1), cb.double())
+    close(logits, ref, 1e-4, what="fused inference tail vs float64")
+    # the separate kernels round the activation to bf16 in between; with y given the fused call also stores it, identically
+    y, y2 = BT.empty((B, H, W, C), False, DEV), BT.empty((B, H, W, C), False, DEV)
+    lg2, lg3 = torch.empty_like(logits), torch.empty_like(logits)
+    ops.conv3x3_fwd(x, w, bias.to(DEV), y, B, H, W, C, C, sc.to(DEV), sh.to(DEV))
+    ops.classifier_fwd(y, cw.to(DEV), cb.to(DEV), lg2, B, H * W, C, ncls)
+    close(logits, lg2.double().cpu(), 4e-3, what="fused vs separate kernels")
+    assert ops.conv3x3_cls_fwd(x, w, bias.to(DEV), sc.to(DEV), sh.to(DEV), y2, cw.to(DEV), cb.to(DEV), lg3, B, H, W, C, ncls)
+    assert torch.equal(y2.hi, y.hi) and torch.equal(lg3, logits)
+
+
 @pytest.mark.parametrize("det", [False, True])
 @pytest.mark.parametrize("split", SPLITS)
 @pytest.mark.parametrize("ncls,C,B,H,W", [(2, 48, 2, 24, 20), (13, 144, 2, 24, 20), (1, 48, 1, 30, 30), (4, 144, 3, 56, 56), (2, 96, 1, 17, 9), (6, 48, 2, 24, 20), (16, 80, 1, 40, 33)])
