@@ -381,8 +381,7 @@ int launch_direct(CDParams p, hipStream_t st, const char* what, double* stat_sum
             return IG_ERR_HIP;
         }
     }
-    if (NCLS) ig_note_kernel("conv3x3_direct_kernel<%d,%d>", C, NCLS);
-    else ig_note_kernel("conv3x3_direct_kernel<%d>", C);
+    ig_note_kernel("conv3x3_direct_kernel<%d,%d>", C, NCLS);
     hipLaunchKernelGGL((conv3x3_direct_kernel<C, NCLS>), dim3((unsigned)nwg), dim3(CD_TPB), G::SMEM, st, p);
     if (stat_sums) hipLaunchKernelGGL(bn_part_fold_kernel, dim3(ig_cdiv(2 * C, 64)), dim3(1024), 0, st, p.stats_part, stat_sums, (int)nwg, 2 * C);
     return ig_check_launch(what);
