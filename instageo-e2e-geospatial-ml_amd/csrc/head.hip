@@ -497,7 +497,10 @@ __global__ __launch_bounds__(TPB, VEC == 8 ? 1 : 2) void cls_bwd_kernel(const fl
 // stats[0] += sum w_y*nll over valid pixels ; stats[1] += #valid.  dlogits (optional) is left UN-normalised:
 // dl[n] = w_y*(softmax_n - [n==y]) (0 on ignored pixels); divide by stats[1] downstream.
 // preds (optional): int64 argmax (first maximal index, as torch.argmax); confusion (optional): int64 [k][k].
-template <typename LABEL, int VEC>
+// NCB: class bucket (2: the two-class flood task -- straight-line class loops and the confusion counts in four registers per thread:
+// the LDS histogram has only four counters there, and 256 threads x 4 pixels of same-address LDS atomics per iteration were the kernel;
+// 16: everything else)
+template <typename LABEL, int VEC, int NCB>
 __global__ __launch_bounds__(TPB) void ce_loss_kernel(const float* __restrict__ logits, const LABEL* __restrict__ labels,
                                                       const float* __restrict__ cw, long ignore_index, double* __restrict__ stats,
                                                       float* __restrict__ dlogits, long long* __restrict__ preds,
@@ -511,13 +514,14 @@ __global__ __launch_bounds__(TPB) void ce_loss_kernel(const float* __restrict__ 
     // consecutive pixels of one image per iteration with 16-byte loads/stores -- the scalar loop had too few bytes in
     // flight per CU to cover the HBM latency.
     float my_loss = 0.f, my_cnt = 0.f;
+    unsigned cnt4[4] = {0u, 0u, 0u, 0u};  // NCB == 2: confusion counts [y][argmax] of this thread
     for (long m0 = (blockIdx.x * (long)TPB + threadIdx.x) * VEC; m0 < M; m0 += (long)gridDim.x * TPB * VEC) {
         long b, pix;
         split_pixel(m0, HW, b, pix);
-        float z[MAXC][VEC];
+        float z[NCB][VEC];
         LABEL lab[VEC];
 #pragma unroll
-        for (int n = 0; n < MAXC; ++n) {
+        for (int n = 0; n < NCB; ++n) {
             if (n < ncls) {
                 const float* src = logits + (b * ncls + n) * HW + pix;
                 if constexpr (VEC == 4) {
@@ -536,11 +540,11 @@ __global__ __launch_bounds__(TPB) void ce_loss_kernel(const float* __restrict__ 
             float mx = -INFINITY;
             int am = 0;
 #pragma unroll
-            for (int n = 0; n < MAXC; ++n)
+            for (int n = 0; n < NCB; ++n)
                 if (n < ncls && z[n][e] > mx) mx = z[n][e], am = n;
             float se = 0.f;
 #pragma unroll
-            for (int n = 0; n < MAXC; ++n)
+            for (int n = 0; n < NCB; ++n)
                 if (n < ncls) se += __expf(z[n][e] - mx);
             const float lse = mx + __logf(se);
             const long y = (long)lab[e];
@@ -549,20 +553,26 @@ __global__ __launch_bounds__(TPB) void ce_loss_kernel(const float* __restrict__ 
             if (valid) {
                 float zy = 0.f;
 #pragma unroll
-                for (int n = 0; n < MAXC; ++n)
+                for (int n = 0; n < NCB; ++n)
                     if (n == (int)y) zy = z[n][e];
                 my_loss += wy * (lse - zy);
                 my_cnt += 1.f;
-                if (confusion) atomicAdd(hist + (int)y * ncls + am, 1u);
+                if constexpr (NCB == 2) {
+                    const int ci = (int)y * ncls + am;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) cnt4[q] += ci == q ? 1u : 0u;
+                } else {
+                    if (confusion) atomicAdd(hist + (int)y * ncls + am, 1u);
+                }
             }
 #pragma unroll
-            for (int n = 0; n < MAXC; ++n)
+            for (int n = 0; n < NCB; ++n)
                 if (n < ncls) z[n][e] = wy * (__expf(z[n][e] - lse) - (n == (int)y ? 1.f : 0.f));  // z now holds dlogits
             amv[e] = am;
         }
         if (dlogits) {
 #pragma unroll
-            for (int n = 0; n < MAXC; ++n) {
+            for (int n = 0; n < NCB; ++n) {
                 if (n < ncls) {
                     float* dst = dlogits + (b * ncls + n) * HW + pix;
                     if constexpr (VEC == 4)
@@ -590,6 +600,17 @@ __global__ __launch_bounds__(TPB) void ce_loss_kernel(const float* __restrict__ 
     // (loss, count) of the launch as INTEGER atomics (the loss partial of a workgroup in 2^28 fixed point, the count exactly), so
     // the reported loss is bit-identical from run to run whatever order the workgroups finish in; the workgroup that arrives last
     // converts the totals, adds them to stats and re-arms the scratch.  Waves are folded in index order.
+    if constexpr (NCB == 2) {
+        if (confusion) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned c = cnt4[q];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+                if ((threadIdx.x & 63) == 0 && q < ncls * ncls && c) atomicAdd(hist + q, c);
+            }
+        }
+    }
     __shared__ float wred[TPB / 64][2];
     my_loss = wave_sum(my_loss);
     my_cnt = wave_sum(my_cnt);
@@ -1046,11 +1067,14 @@ int ig_ce_loss(const float* logits, const void* labels, int label_dtype, const f
     hipStream_t st = (hipStream_t)stream;
 #define IG_CE(LT)                                                                                                              \
     {                                                                                                                          \
-        if (vec4)                                                                                                              \
-            hipLaunchKernelGGL((ce_loss_kernel<LT, 4>), grid, block, sm, st, logits, (const LT*)labels, class_weights,         \
+        if (vec4 && ncls <= 2)                                                                                                 \
+            hipLaunchKernelGGL((ce_loss_kernel<LT, 4, 2>), grid, block, sm, st, logits, (const LT*)labels, class_weights,      \
+                               ignore_index, stats, dlogits, preds, preds_i8, confusion, M, HW, ncls, acc, arrived); \
+        else if (vec4)                                                                                                         \
+            hipLaunchKernelGGL((ce_loss_kernel<LT, 4, 16>), grid, block, sm, st, logits, (const LT*)labels, class_weights,     \
                                ignore_index, stats, dlogits, preds, preds_i8, confusion, M, HW, ncls, acc, arrived); \
         else                                                                                                                   \
-            hipLaunchKernelGGL((ce_loss_kernel<LT, 1>), grid, block, sm, st, logits, (const LT*)labels, class_weights,         \
+            hipLaunchKernelGGL((ce_loss_kernel<LT, 1, 16>), grid, block, sm, st, logits, (const LT*)labels, class_weights,     \
                                ignore_index, stats, dlogits, preds, preds_i8, confusion, M, HW, ncls, acc, arrived); \
     }
     if (label_dtype == 0)
