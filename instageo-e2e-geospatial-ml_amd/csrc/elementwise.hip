@@ -958,10 +958,14 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     const bool clip = hyper[9] != 0.f;
     const float step_size = lr / bc1;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        float4 P = reinterpret_cast<float4*>(p)[i];
-        float4 G = reinterpret_cast<const float4*>(g)[i];
-        float4 Mv = reinterpret_cast<float4*>(m)[i];
-        float4 V = reinterpret_cast<float4*>(v)[i];
+        // streaming accesses (non-temporal): 30 bytes per parameter that nobody reads again before the next optimizer step -- kept out of
+        // the L2 / MALL that the backward kernels running beside the overlapped launches live in
+        const f32x4 P4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p) + i);
+        const f32x4 G4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g) + i);
+        const f32x4 M4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(m) + i);
+        const f32x4 V4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(v) + i);
+        const float4 P = make_float4(P4[0], P4[1], P4[2], P4[3]), G = make_float4(G4[0], G4[1], G4[2], G4[3]);
+        const float4 Mv = make_float4(M4[0], M4[1], M4[2], M4[3]), V = make_float4(V4[0], V4[1], V4[2], V4[3]);
         float pp[4] = {P.x, P.y, P.z, P.w}, gg[4] = {G.x * gscale, G.y * gscale, G.z * gscale, G.w * gscale}, mm[4] = {Mv.x, Mv.y, Mv.z, Mv.w},
               vv[4] = {V.x, V.y, V.z, V.w};
 #pragma unroll
@@ -973,9 +977,9 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
             pp[j] = pp[j] - step_size * (mm[j] / denom);
             if (clip) pp[j] = fminf(fmaxf(pp[j], clo), chi);
         }
-        reinterpret_cast<float4*>(p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
-        reinterpret_cast<float4*>(m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
-        reinterpret_cast<float4*>(v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        __builtin_nontemporal_store(f32x4{pp[0], pp[1], pp[2], pp[3]}, reinterpret_cast<f32x4*>(p) + i);
+        __builtin_nontemporal_store(f32x4{mm[0], mm[1], mm[2], mm[3]}, reinterpret_cast<f32x4*>(m) + i);
+        __builtin_nontemporal_store(f32x4{vv[0], vv[1], vv[2], vv[3]}, reinterpret_cast<f32x4*>(v) + i);
         if (sh) store4_split(sh, sl, (size_t)i * 4, pp);
     }
 }

@@ -29,6 +29,26 @@
 
 namespace {
 
+// Epilogue stores.  Non-temporal stores drain the write burst of 256 CUs faster in isolation (round 4, same-box A/B of two builds at
+// M = 42552: proj 87 -> 72 us, fc1 + gelu' 256 -> 239, d_fc1 164 -> 157, qkv / fc2 unchanged) but over the whole step the gain is gone
+// (44.36 -> 44.28 ms): the consumer of the tile then misses in L2 / MALL.  -DIG_G8_NT builds them all non-temporal (A/B builds); by
+// default only the tensor nobody reads before the backward pass -- gelu' saved by fc1 -- takes the non-temporal path.
+template <bool NT = false, typename T>
+__device__ __forceinline__ void g8_store(T* ptr, const T& v) {
+#ifdef IG_G8_NT
+    constexpr bool nt = true;
+#else
+    constexpr bool nt = NT;
+#endif
+    if constexpr (nt) {
+        static_assert(sizeof(T) == 16, "16-byte stores");
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+        __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, v), reinterpret_cast<u32x4_t*>(ptr));
+    } else {
+        *ptr = v;
+    }
+}
+
 // Geometry: WC column waves x 2 row groups; a wave owns (2 MT 16) x 64 of the (MT 64) x (WC 64) tile.  Two instances:
 //   MT = 4, WC = 4: 256 x 256, 8 waves, 160 KiB of LDS, one workgroup per CU            (the shapes with >= 128 such tiles)
 //   MT = 2, WC = 2: 128 x 128, 4 waves,  80 KiB of LDS, TWO workgroups per CU           (small batches: M = 16 x 197 rows leave
@@ -348,7 +368,7 @@ __global__ __launch_bounds__(128 * WC, 2) void gemm8_kernel(G8Params p) {
                             }
                         }
                         // one pass = two staged arrays (X -> slot 0, Y -> slot 1) written in MFMA layout, read back row-contiguous
-#define G8_STAGE_PASS(PX, PY, HAVE_Y, DSTX, DSTY)                                                                      \
+#define G8_STAGE_PASS(PX, PY, HAVE_Y, DSTX, DSTY, NTY)                                                                    \
     {                                                                                                                  \
         _Pragma("unroll") for (int g = 0; g < 2; ++g) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {               \
             const int chunk_ = g * 4 + nt * 2 + (eq >> 1);                                                             \
@@ -364,18 +384,18 @@ __global__ __launch_bounds__(128 * WC, 2) void gemm8_kernel(G8Params p) {
             const int m_ = m0 + r_;                                                                                    \
             if (m_ < p.M) {                                                                                            \
                 const size_t o_ = (size_t)m_ * p.ldo + n0 + rcol;                                                      \
-                *reinterpret_cast<uint4*>((DSTX) + o_) = ux_;                                                          \
-                if (HAVE_Y) *reinterpret_cast<uint4*>((DSTY) + o_) = uy_;                                              \
+                g8_store(reinterpret_cast<uint4*>((DSTX) + o_), ux_);                                                  \
+                if (HAVE_Y) g8_store<NTY>(reinterpret_cast<uint4*>((DSTY) + o_), uy_);                                 \
             }                                                                                                          \
         }                                                                                                              \
     }
                     if constexpr (SPLIT_OUT) {
-                        G8_STAGE_PASS(po, pol, true, p.out_hi, p.out_lo)
-                        if constexpr (DACT) G8_STAGE_PASS(pd, pdl, true, p.dact_hi, p.dact_lo)
+                        G8_STAGE_PASS(po, pol, true, p.out_hi, p.out_lo, false)
+                        if constexpr (DACT) G8_STAGE_PASS(pd, pdl, true, p.dact_hi, p.dact_lo, false)
                     } else if constexpr (DACT) {
-                        G8_STAGE_PASS(po, pd, true, p.out_hi, p.dact_hi)
+                        G8_STAGE_PASS(po, pd, true, p.out_hi, p.dact_hi, true)
                     } else {
-                        G8_STAGE_PASS(po, po, false, p.out_hi, p.out_hi)
+                        G8_STAGE_PASS(po, po, false, p.out_hi, p.out_hi, false)
                     }
 #undef G8_STAGE_PASS
                 }
@@ -434,13 +454,13 @@ __global__ __launch_bounds__(128 * WC, 2) void gemm8_kernel(G8Params p) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) v[e] *= f[e], cs[e] += v[e];
                             const uint4 u = pack8(v);
-                            *reinterpret_cast<uint4*>(p.out_hi + o) = u;
+                            g8_store(reinterpret_cast<uint4*>(p.out_hi + o), u);
                             if constexpr (SPLIT_OUT) {
                                 float hv[8], rv[8];
                                 unpack8(u, hv);
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) rv[e] = v[e] - hv[e];
-                                *reinterpret_cast<uint4*>(p.out_lo + o) = pack8(rv);
+                                g8_store(reinterpret_cast<uint4*>(p.out_lo + o), pack8(rv));
                             }
                         }
                     }
@@ -487,7 +507,7 @@ __global__ __launch_bounds__(128 * WC, 2) void gemm8_kernel(G8Params p) {
                     const int m = m0 + r;
                     if (m < p.M) {
                         const float4 rv = rs[t & 1][i];
-                        *reinterpret_cast<float4*>(p.outf + (size_t)m * p.ldo + n0 + rc * 4) = make_float4(rv.x + a[0], rv.y + a[1], rv.z + a[2], rv.w + a[3]);
+                        g8_store(reinterpret_cast<float4*>(p.outf + (size_t)m * p.ldo + n0 + rc * 4), make_float4(rv.x + a[0], rv.y + a[1], rv.z + a[2], rv.w + a[3]));
                     }
                 }
             }
