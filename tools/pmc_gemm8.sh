@@ -32,7 +32,7 @@ agg=collections.defaultdict(lambda: collections.defaultdict(float)); n=collectio
 for fn in glob.glob("$OUT/pmc_*/**/*counter_collection.csv",recursive=True):
     for r in csv.DictReader(open(fn)):
         k=r["Kernel_Name"].replace("(anonymous namespace)::","").split("(")[0].replace("void ","").replace(" ","")
-        if not any(t in k for t in ("gemm", "wgrad", "cls_", "classifier", "bn_")): continue
+        if not any(t in k for t in ("gemm", "wgrad", "cls_", "classifier", "bn_", "attn")): continue
         agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); n[k][r["Counter_Name"]]+=1
 for k,v in agg.items():
     print(k)
