@@ -406,7 +406,8 @@ def test_trained_weights_bf16_miou_and_loss_vs_oracle(variant, freeze, steps, B)
     conf_ref = ref.softmax(1).max(1).values.mean().item()
     print(f"[trained {variant}] train loss {first:.4f} -> {last:.4f}; oracle eval loss {ref_loss:.5f} mIoU {ref_m['jaccard']:.5f} acc {ref_m['accuracy']:.5f} mean max-prob {conf_ref:.3f}")
     # a trained, confident model (random init: ~0.33).  The frozen-backbone case over-fits its 48 training chips (held-out loss ~1.8 at 0.98
-    # mean confidence) and its held-out mIoU moves with rounding-level changes of the training trajectory (0.48-0.56 seen): the bar only
+    # mean confidence) and its held-out mIoU moves with rounding-level changes of the training trajectory (same build, same box: 0.505 with every fusion switched off, 0.565 /
+    # 0.484 with the BatchNorm statistics taken by the separate pass / from the convolution's epilogue -- identical sums up to order): the bar only
     # makes sure the weights are far from initialisation; the assertions that matter are the mode-vs-oracle differences below
     assert ref_m["jaccard"] > (0.42 if freeze else 0.6)
     out = {}
