@@ -18,6 +18,20 @@
 
 #include "common.h"
 
+#ifdef IG_A2_PROF
+// timing instrumentation of attn2_bwd_fused_kernel (debug builds only: tools/attn_phase_prof.py): s_memtime at phase boundaries of the
+// waves of workgroup (0, 0, 0); MARKV makes the clock read wait for a value (an MFMA result), so the phase includes the pipeline drain
+__device__ unsigned long long g_a2prof[8 * 48];
+#define A2P_INIT_X const bool a2p_on = blockIdx.x == 0 && blockIdx.y == 1 && blockIdx.z == 1 && (threadIdx.x & 63) == 0;
+#define A2P_MARK(I) { if (a2p_on) g_a2prof[(threadIdx.x >> 6) * 48 + (I)] = __builtin_readcyclecounter(); }
+#define A2P_MARKV(I, V) { float a2p_v = (V); asm volatile("" ::"v"(a2p_v)); if (a2p_on) g_a2prof[(threadIdx.x >> 6) * 48 + (I)] = __builtin_readcyclecounter(); }
+extern "C" int ig_debug_a2prof(unsigned long long* dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_a2prof), sizeof(g_a2prof)) == hipSuccess ? 0 : -1; }
+#else
+#define A2P_INIT_X
+#define A2P_MARK(I)
+#define A2P_MARKV(I, V)
+#endif
+
 namespace {
 
 constexpr int A2_WAVES = 7, A2_THREADS = 448, A2_QB = 224, A2_CH = 224;
@@ -614,6 +628,7 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_fused_kernel(const bf16_
                                                                      float* __restrict__ delta, bf16_t* __restrict__ dqkv_hi, int N, int H,
                                                                      float scale, float* __restrict__ dbias) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    A2P_INIT_X
     char* q_img = smem;
     char* d_img = smem + A2_TILE;
     char* k_img = smem + A2F_OFF_K;
@@ -624,8 +639,11 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_fused_kernel(const bf16_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     char* slab = smem + A2F_OFF_SLAB + wave * A2F_SLAB;
     const int lr = lane & 31, lh = lane >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
     const long RS = 3L * H * 64, OS = (long)H * 64;
+    // (A persistent loop over the (batch, head) items saves the dispatch of a workgroup and the launch skew of its seven waves per head --
+    // 138 -> 135.5 us at B = 108 -- but costs ~40 registers: together with the prefetched fragments below the body spills (289 us at
+    // B = 216 against 276 us either way alone); as a non-inlined item function 352 us.  One workgroup per item it stays.)
+    const int h = blockIdx.y, b = blockIdx.z;
     const bf16_t* base = qkv_hi + (long)b * N * RS + h * 64;
     const bf16_t* dob = do_hi + (long)b * N * OS + h * 64;
     const bf16_t* ob = o_hi + (long)b * N * OS + h * 64;
@@ -667,8 +685,11 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_fused_kernel(const bf16_
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dk[i][r] = 0.f, dv[i][r] = 0.f;
+    A2P_MARK(0)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    A2P_MARK(1)
     __syncthreads();
+    A2P_MARK(2)
     const int ntile = (N + 31) >> 5;  // = number of active waves: tile qt is first touched by wave qt in step 0
     bf16x8_t kt[2][2];                // K^T A operands of the wave's 32 keys: [k-step][d half]
 #pragma unroll
@@ -677,8 +698,10 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_fused_kernel(const bf16_
         for (int dhf = 0; dhf < 2; ++dhf) kt[s][dhf] = tr_frag(k_img, k0, s, 32 * dhf, lane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();  // the dQ image takes the K image's place
+    A2P_MARK(3)
     for (int step = 0; step < A2_WAVES; ++step) {
         const int qt = (wave + step) % A2_WAVES;
+        A2P_MARK(4 + step * 6)
         if (active && qt < ntile) {
             f32x16 st, dp;
 #pragma unroll
@@ -687,6 +710,18 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_fused_kernel(const bf16_
             for (int s = 0; s < 4; ++s) st = mfma32(rows_frag(q_img, qt * 32, s, lr, lh), kh[s], st);  // S[q][key]
 #pragma unroll
             for (int s = 0; s < 4; ++s) dp = mfma32(rows_frag(d_img, qt * 32, s, lr, lh), vh[s], dp);  // dP[q][key]
+            // the transposed Q / dO fragments of the dV / dK products do not depend on the softmax: their LDS reads are issued HERE, so
+            // that their latency runs under the exp / dS arithmetic instead of in front of every MFMA pair (phase timing, tools/
+            // attn_phase_prof.py: "pack + dV, dK" was 1325 cycles per step and wave for 256 cycles of MFMAs)
+            bf16x8_t tdo[2][2], tq[2][2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int dhf = 0; dhf < 2; ++dhf) {
+                    tdo[s][dhf] = tr_frag(d_img, qt * 32, s, 32 * dhf, lane);
+                    tq[s][dhf] = tr_frag(q_img, qt * 32, s, 32 * dhf, lane);
+                }
+            A2P_MARKV(5 + step * 6, st[0] + dp[0])
             f32x16 ds;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {  // accumulator rows 8 g + 4 lh + (0..3) = four consecutive queries
@@ -700,6 +735,7 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_fused_kernel(const bf16_
                     ds[4 * g + e] = pv * (dp[4 * g + e] - dd[e]);
                 }
             }
+            A2P_MARKV(6 + step * 6, ds[0] + ds[15])
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 bf16x8_t ph, pl, sh, sl;
@@ -711,33 +747,43 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_fused_kernel(const bf16_
                 *reinterpret_cast<uint2*>(slab + lr * 72 + (16 * s + 8 + 4 * lh) * 2) = make_uint2(su.z, su.w);
 #pragma unroll
                 for (int dhf = 0; dhf < 2; ++dhf) {
-                    dv[dhf] = mfma32(tr_frag(d_img, qt * 32, s, 32 * dhf, lane), ph, dv[dhf]);  // dV^T += dO^T P
-                    dk[dhf] = mfma32(tr_frag(q_img, qt * 32, s, 32 * dhf, lane), sh, dk[dhf]);  // dK^T += Q^T dS
+                    dv[dhf] = mfma32(tdo[s][dhf], ph, dv[dhf]);  // dV^T += dO^T P
+                    dk[dhf] = mfma32(tq[s][dhf], sh, dk[dhf]);   // dK^T += Q^T dS
                 }
             }
+            A2P_MARKV(7 + step * 6, dv[0][0] + dk[0][0] + dv[1][15] + dk[1][15])
             // dQ^T[d][q tile] partial of this key block, folded into the workgroup's fp32 image (this wave owns tile qt in this step)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const bf16x8_t b0 = tr_slab(slab, 0, lane), b1 = tr_slab(slab, 1, lane);
-#pragma unroll
-            for (int dhf = 0; dhf < 2; ++dhf) {
-                f32x16 dq;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dq[r] = 0.f;
-                dq = mfma32(kt[0][dhf], b0, dq);
-                dq = mfma32(kt[1][dhf], b1, dq);
-                float* row = s_dq + (qt * 32 + lr) * A2F_DQP + 32 * dhf + 4 * lh;  // lane = query; registers 4 g .. 4 g + 3 = columns 8 g + 4 lh + (0..3)
+            // the dQ partials of the earlier steps for this query tile (final since the last barrier) become the accumulator INIT of this
+            // step's dQ product: their LDS reads run under the dV / dK MFMAs, and the read-add-write after the product is a plain write
+            f32x16 dq0, dq1;  // (loaded behind the dV / dK MFMAs: their issue covers the LDS latency; earlier, the 32 registers spill)
+            {
+                const float* row = s_dq + (qt * 32 + lr) * A2F_DQP + 4 * lh;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    float4 v = make_float4(dq[4 * g], dq[4 * g + 1], dq[4 * g + 2], dq[4 * g + 3]);
-                    if (step > 0) {
-                        const float4 o = *reinterpret_cast<const float4*>(row + 8 * g);
-                        v.x += o.x, v.y += o.y, v.z += o.z, v.w += o.w;
-                    }
-                    *reinterpret_cast<float4*>(row + 8 * g) = v;
+                    float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0;
+                    if (step > 0) o0 = *reinterpret_cast<const float4*>(row + 8 * g), o1 = *reinterpret_cast<const float4*>(row + 32 + 8 * g);
+                    dq0[4 * g] = o0.x, dq0[4 * g + 1] = o0.y, dq0[4 * g + 2] = o0.z, dq0[4 * g + 3] = o0.w;
+                    dq1[4 * g] = o1.x, dq1[4 * g + 1] = o1.y, dq1[4 * g + 2] = o1.z, dq1[4 * g + 3] = o1.w;
                 }
             }
+            const bf16x8_t b0 = tr_slab(slab, 0, lane), b1 = tr_slab(slab, 1, lane);
+            dq0 = mfma32(kt[0][0], b0, dq0);
+            dq1 = mfma32(kt[0][1], b0, dq1);
+            dq0 = mfma32(kt[1][0], b1, dq0);
+            dq1 = mfma32(kt[1][1], b1, dq1);
+            {
+                float* row = s_dq + (qt * 32 + lr) * A2F_DQP + 4 * lh;  // lane = query; registers 4 g .. 4 g + 3 = columns 8 g + 4 lh + (0..3)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    *reinterpret_cast<float4*>(row + 8 * g) = make_float4(dq0[4 * g], dq0[4 * g + 1], dq0[4 * g + 2], dq0[4 * g + 3]);
+                    *reinterpret_cast<float4*>(row + 32 + 8 * g) = make_float4(dq1[4 * g], dq1[4 * g + 1], dq1[4 * g + 2], dq1[4 * g + 3]);
+                }
+            }
+            A2P_MARK(8 + step * 6)
         }
         __syncthreads();
+        A2P_MARK(9 + step * 6)
     }
     // dQ write-out: item = (query, 8-column chunk); 8 lanes cover one 128-byte row segment of dqkv's Q slot.  A thread's chunk is
     // always c = tid & 7 (the stride is a multiple of 8), so its partial column sums stay in eight registers: the qkv BIAS gradient.
@@ -750,6 +796,7 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_fused_kernel(const bf16_
 #pragma unroll
         for (int e = 0; e < 8; ++e) cbq[e] += f[e];
     }
+    A2P_MARK(46)
     if (dbias) {  // wave-uniform
         // Bias gradient of the fused qkv Linear = column sums of dqkv over the tokens.  Its three parts for this (batch, head):
         //   Q: sum_q dQ[q][d]                      -- the partial sums above;
@@ -763,36 +810,38 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_fused_kernel(const bf16_
 #pragma unroll
             for (int e = 0; e < 8; ++e) cbv[e] += f[e];
         }
-        // lanes with equal (lane & 7) of a wave own the same chunk: fold over lane >> 3, then over the 7 waves through the dead dS slabs
-        float* scr = reinterpret_cast<float*>(smem + A2F_OFF_SLAB);  // [wave][chunk][16]
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float a = cbq[e], v = cbv[e];
-            a += __shfl_xor(a, 8, 64), v += __shfl_xor(v, 8, 64);
-            a += __shfl_xor(a, 16, 64), v += __shfl_xor(v, 16, 64);
-            a += __shfl_xor(a, 32, 64), v += __shfl_xor(v, 32, 64);
-            if (lane < 8) scr[(wave * 8 + lane) * 16 + e] = a, scr[(wave * 8 + lane) * 16 + 8 + e] = v;
-        }
+        A2P_MARKV(40, cbv[0] + cbv[7])
+        // Every thread's 8 + 8 partial sums go to LDS as they are (the Q image is dead: [thread][16] floats = exactly its 28 KB) and 128
+        // threads add the 56 partials of their column (7 waves x 8 lane groups own the same 8-column chunk) in a fixed order.  (Folding over
+        // the lanes with 48 __shfl_xor first cost 2.7 k of the workgroup's 41 k cycles: each is a ds_bpermute round trip.)
+        float* scr = reinterpret_cast<float*>(q_img);  // [tid][16]: 0..7 = dQ sums, 8..15 = dO sums of chunk tid & 7
+        *reinterpret_cast<float4*>(scr + tid * 16) = make_float4(cbq[0], cbq[1], cbq[2], cbq[3]);
+        *reinterpret_cast<float4*>(scr + tid * 16 + 4) = make_float4(cbq[4], cbq[5], cbq[6], cbq[7]);
+        *reinterpret_cast<float4*>(scr + tid * 16 + 8) = make_float4(cbv[0], cbv[1], cbv[2], cbv[3]);
+        *reinterpret_cast<float4*>(scr + tid * 16 + 12) = make_float4(cbv[4], cbv[5], cbv[6], cbv[7]);
+        A2P_MARK(41)
         __syncthreads();
+        A2P_MARK(42)
         if (tid < 128) {
             const int part = tid >> 6, col = tid & 63;  // part 0 = Q, 1 = V
             float t = 0.f;
-#pragma unroll
-            for (int w = 0; w < A2_WAVES; ++w) t += scr[(w * 8 + (col >> 3)) * 16 + part * 8 + (col & 7)];
+            for (int g = 0; g < A2_THREADS / 8; ++g) t += scr[(g * 8 + (col >> 3)) * 16 + part * 8 + (col & 7)];
             ig_red_add(dbias + (size_t)(part * 2) * H * 64 + h * 64 + col, t);
         }
     }
-    if (!active || key >= N) return;
-    const size_t orow = ((size_t)b * N + key) * RS + h * 64;
+    A2P_MARK(47)
+    if (active && key < N) {
+        const size_t orow = ((size_t)b * N + key) * RS + h * 64;
 #pragma unroll
-    for (int dhf = 0; dhf < 2; ++dhf)
+        for (int dhf = 0; dhf < 2; ++dhf)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float fk[4] = {dk[dhf][4 * g] * scale, dk[dhf][4 * g + 1] * scale, dk[dhf][4 * g + 2] * scale, dk[dhf][4 * g + 3] * scale};
-            const float fv[4] = {dv[dhf][4 * g], dv[dhf][4 * g + 1], dv[dhf][4 * g + 2], dv[dhf][4 * g + 3]};
-            store4_split(dqkv_hi, nullptr, orow + (size_t)H * 64 + 32 * dhf + 8 * g + 4 * lh, fk);
-            store4_split(dqkv_hi, nullptr, orow + 2 * (size_t)H * 64 + 32 * dhf + 8 * g + 4 * lh, fv);
-        }
+            for (int g = 0; g < 4; ++g) {
+                const float fk[4] = {dk[dhf][4 * g] * scale, dk[dhf][4 * g + 1] * scale, dk[dhf][4 * g + 2] * scale, dk[dhf][4 * g + 3] * scale};
+                const float fv[4] = {dv[dhf][4 * g], dv[dhf][4 * g + 1], dv[dhf][4 * g + 2], dv[dhf][4 * g + 3]};
+                store4_split(dqkv_hi, nullptr, orow + (size_t)H * 64 + 32 * dhf + 8 * g + 4 * lh, fk);
+                store4_split(dqkv_hi, nullptr, orow + 2 * (size_t)H * 64 + 32 * dhf + 8 * g + 4 * lh, fv);
+            }
+    }
 }
 
 // Second form of the single-pass backward (round 4): the waves EXCHANGE their bf16 dS^T tiles instead of folding fp32 dQ partials into an
