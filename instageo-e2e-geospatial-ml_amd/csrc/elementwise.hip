@@ -486,7 +486,11 @@ __global__ __launch_bounds__(LNB_TPB) void layernorm_bwd_exact_kernel(const bf16
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
                 const int c = lane + i * 64;
-                xh[q][i] = *reinterpret_cast<const float4*>(x + (size_t)row * D + c * 4);
+                {   // the saved forward input is read exactly once: streaming (non-temporal) load, it should not displace the gradients that
+                    // the neighbouring kernels hand to each other through L2 / MALL
+                    const f32x4 xv4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x + (size_t)row * D + c * 4));
+                    xh[q][i] = make_float4(xv4[0], xv4[1], xv4[2], xv4[3]);
+                }
                 old[q][i] = accumulate ? *reinterpret_cast<const float4*>(dx + (size_t)row * D + c * 4) : make_float4(0, 0, 0, 0);
                 float d[4] = {0.f, 0.f, 0.f, 0.f};
                 if (!zero_dy) {

@@ -420,8 +420,10 @@ __global__ __launch_bounds__(128 * WC, 2) void gemm8_kernel(G8Params p) {
                         const int t = bt * PF + j;
                         const int m = min(bm * BM + wr * (2 * MT * 16) + (t / MT) * (MT * 16) + (t % MT) * 16 + i * 8 + rrow, p.M - 1);
                         const size_t o = (size_t)m * p.ldo + n0 + rcol;
-                        fh[j][i] = *reinterpret_cast<const uint4*>(p.dact_hi + o);
-                        if constexpr (SPLIT_OUT) fl[j][i] = *reinterpret_cast<const uint4*>(p.dact_lo + o);
+                        // gelu' was saved by the forward pass and is read exactly once: streaming (non-temporal) loads
+                        typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+                        fh[j][i] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p.dact_hi + o)));
+                        if constexpr (SPLIT_OUT) fl[j][i] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p.dact_lo + o)));
                     }
 #pragma unroll
                 for (int j = 0; j < PF; ++j) {
