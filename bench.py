@@ -257,6 +257,7 @@ def main() -> None:
     from instageo_amd.segmentation import PrithviSegmentationModule
 
     rank, local_rank, world = D.init_from_env()
+    dp = D.dp_active()  # more than one rank -- or ONE rank under IG_DIST_FORCE=1 (pre-flight of the RCCL path on a one-GPU box)
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     dev = torch.device("cuda", local_rank)
@@ -287,13 +288,13 @@ def main() -> None:
     raws, labels, xbuf = main_wl["raws"], main_wl["labels"], main_wl["xbuf"]
 
     def barrier() -> None:
-        if world > 1:
+        if dp:
             dist.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(x: float) -> float:
         t = torch.tensor([x], dtype=torch.float64, device=dev)
-        if world > 1:
+        if dp:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return t.item()
 
@@ -472,7 +473,7 @@ def main() -> None:
         torch.cuda.synchronize()
         dt_local = time.perf_counter() - t0  # this rank's windows, no collective
         n_local = int(local_maps.shape[0])
-        if world > 1:
+        if dp:
             counts = [D.shard_range(len(origins), r, world)[1] - D.shard_range(len(origins), r, world)[0] for r in range(world)]
             maps = D.gather_class_maps(local_maps, counts, dst=0)
         else:
@@ -499,7 +500,7 @@ def main() -> None:
         torch.cuda.empty_cache()
 
     t3_leg = None
-    if world > 1 and (T, NCLS, args.model) == (1, 2, "prithvi_eo_v1_100") and not args.no_t3_leg and not args.graph:
+    if dp and (T, NCLS, args.model) == (1, 2, "prithvi_eo_v1_100") and not args.no_t3_leg and not args.graph:
         # the shape north_star's >= 7x scaling target is stated on (BASELINE configs[2]: 224x224x6x3 chips, 13 classes), beside the
         # default line: same data-parallel step, per-GPU batch --t3-batch
         main_res.pop("mod", None)
@@ -518,7 +519,7 @@ def main() -> None:
         torch.cuda.empty_cache()
 
     if rank != 0:
-        if world > 1:
+        if dp:
             dist.destroy_process_group()
         return
 
@@ -610,7 +611,7 @@ def main() -> None:
                                    f"every {args.event_stride}-th launch of the linear-GEMM entry points")
         detail["roofline_timed_region"] = timed_k
         detail["roofline_kernels"] = all_k
-    if world > 1:
+    if dp:
         bk = main_res["buckets"] or []
         out["dist"] = {"ranks": world, "backend": dist.get_backend(), "mode": main_res.get("dp_mode"), "reserved_cus": ops.reserved_cus(), "buckets": len(bk),
                        "allreduce_mbytes": round(sum(b["mbytes"] for b in bk), 1), "allreduce_ms_serial": round(sum(b["ms"] for b in bk), 3)}
@@ -652,7 +653,7 @@ def main() -> None:
         out["config"].pop("train_chips_per_s_pcie_overlapped", None)
         line = json.dumps(out)
     print(line)
-    if world > 1:
+    if dp:
         dist.destroy_process_group()
 
 

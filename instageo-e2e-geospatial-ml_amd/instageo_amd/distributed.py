@@ -42,7 +42,10 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     backend = backend or os.environ.get("IG_DIST_BACKEND") or None
     if os.environ.get("IG_SINGLE_DEVICE") == "1":
         local_rank = 0
-    if world > 1 and not dist.is_initialized():
+    # IG_DIST_FORCE=1: initialise the process group (and run every collective of the data-parallel path) with ONE rank too -- the
+    # pre-flight of the RCCL code path on a one-GPU box, where every collective degenerates to a copy (tests/test_gpu_data_parallel.py,
+    # `IG_DIST_FORCE=1 python bench.py`)
+    if (world > 1 or os.environ.get("IG_DIST_FORCE") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         # this image's host driver only supports dmabuf IPC: without it RCCL's (and torch's) cross-process device-memory
@@ -61,6 +64,14 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
 
 def world_size() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def dp_active() -> bool:
+    """True when the collectives of the data-parallel path have to run: more than one rank, or a process group of ONE rank that
+    was initialised with ``IG_DIST_FORCE=1`` (see :func:`init_from_env`)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("IG_DIST_FORCE") == "1"
 
 
 def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
@@ -94,7 +105,7 @@ class GradSync:
         self._bucket_ms: List[Tuple[Tuple[int, int], float]] = []
 
     def ready(self, lo: int, hi: int) -> None:
-        if world_size() == 1 or hi <= lo:
+        if not dp_active() or hi <= lo:
             return
         if self.cur is not None and hi == self.cur[0]:
             self.cur = (lo, self.cur[1])
@@ -131,7 +142,7 @@ class GradSync:
         return out
 
     def wait(self) -> None:
-        if world_size() == 1:
+        if not dp_active():
             return
         self._flush()
         for h in self.handles:
@@ -170,7 +181,7 @@ class ShardedGradSync:
         self.get_grad, self.get_flat, self.lo, self.hi = get_grad, get_flat, lo, hi
         self.bucket_bytes, self.group = bucket_bytes, group
         self.world = world_size()
-        self.rank = dist.get_rank() if self.world > 1 else 0
+        self.rank = dist.get_rank() if dp_active() else 0
         self.q = self.world * self.ALIGN
         self.cur: Optional[Tuple[int, int]] = None
         self.plan: List[Tuple[int, int, int]] = []      # (lo, hi, owned elements before it), fixed after the first step
@@ -387,7 +398,7 @@ class ShardedGradSync:
     def gather_master(self) -> None:
         """Complete the fp32 master parameters on every rank (after steps that published only the bf16 operand copy): one fp32
         all-gather per bucket.  Collective -- every rank calls it (e.g. at epoch end, before rank 0 writes a checkpoint)."""
-        if self.world == 1 or self.master_complete or not self.plan:
+        if not dp_active() or self.master_complete or not self.plan:
             return
         flat = self.get_flat()
         hs = []
@@ -436,7 +447,7 @@ class ShardedGradSync:
         v = torch.zeros_like(m)
         for i, (blo, bhi, _) in enumerate(self.plan):
             for full, part in ((m, self._m[i]), (v, self._v[i])):
-                if self.world > 1:
+                if dp_active():
                     self._all_gather(full[blo - self.lo : bhi - self.lo], part.clone()).wait()
                 else:
                     full[blo - self.lo : bhi - self.lo] = part
@@ -449,7 +460,7 @@ class ShardedGradSync:
 def attach_data_parallel(module, bucket_bytes: int = 32 << 20):
     """Wire a :class:`GradSync` into a ``PrithviSegmentationModule`` (fused path) and broadcast rank 0's
     parameters/buffers so all replicas start equal (Lightning/DDP semantics)."""
-    if world_size() == 1:
+    if not dp_active():
         return None
     net = module.net
     dist.broadcast(net.store.flat, src=0)
@@ -482,14 +493,14 @@ def attach_data_parallel(module, bucket_bytes: int = 32 << 20):
 
 def reduce_confusion(matrix: torch.Tensor) -> torch.Tensor:
     """Sum the k x k int64 confusion matrix over ranks (C2 of SURVEY.md 2.2)."""
-    if world_size() > 1:
+    if dp_active():
         dist.all_reduce(matrix, op=dist.ReduceOp.SUM)
     return matrix
 
 
 def reduce_loss_stats(stats: torch.Tensor) -> torch.Tensor:
     """Sum (loss_sum, count) over ranks."""
-    if world_size() > 1:
+    if dp_active():
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
     return stats
 
@@ -497,7 +508,7 @@ def reduce_loss_stats(stats: torch.Tensor) -> torch.Tensor:
 def gather_class_maps(local: torch.Tensor, counts: Sequence[int], dst: int = 0) -> Optional[torch.Tensor]:
     """Gather per-rank int8 class maps (n_r, H, W) to ``dst`` (C3 of SURVEY.md 2.2).  ``counts[r]`` = n_r."""
     world = world_size()
-    if world == 1:
+    if not dp_active():
         return local
     rank = dist.get_rank()
     nmax = max(counts)

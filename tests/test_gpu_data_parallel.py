@@ -43,10 +43,12 @@ def _batch(cfg, rank):
     return x, y.cuda()
 
 
-def _worker(rank, world, port, q, backend="gloo", mode="zero1"):
+def _worker(rank, world, port, q, backend="gloo", mode="zero1", force=False):
     import sys
 
     os.environ["IG_DP_MODE"] = mode
+    if force:
+        os.environ["IG_DIST_FORCE"] = "1"
 
     sys.path[:0] = [ROOT, os.path.join(ROOT, "instageo-e2e-geospatial-ml_amd")]
     local = str(rank) if backend == "nccl" else "0"  # RCCL: one rank per GPU; gloo: both ranks share cuda:0
@@ -77,7 +79,7 @@ def _worker(rank, world, port, q, backend="gloo", mode="zero1"):
             stale = mod.net.store.flat.detach().clone()
             assert not sync.master_complete
             mod.sync_master_params()
-            assert sync.master_complete and not torch.equal(stale, mod.net.store.flat)
+            assert sync.master_complete and (world == 1 or not torch.equal(stale, mod.net.store.flat))  # (one rank owns every slice)
         flat = mod.net.store.flat.detach().cpu()
         # numpy (pickled by value): a torch tensor would travel as a shared-memory fd that dies with this process
         from instageo_amd import ops
@@ -149,5 +151,35 @@ def test_two_rank_fused_training_equals_manual_gradient_mean(backend, mode):
     d_dp, d_ref = flat0 - init, ref - init
     cos = torch.nn.functional.cosine_similarity(d_dp.reshape(1, -1), d_ref.reshape(1, -1)).item()
     diff = (flat0 - ref).abs()
+    print(f"update cosine {cos:.6f}; max diff {diff.max().item():.2e}; mean diff {diff.mean().item():.2e}")
+    assert cos >= 0.999 and diff.max().item() <= 4.5e-3 and diff.mean().item() <= 2e-5
+
+
+@pytest.mark.parametrize("mode", ["zero1", "allreduce"])
+def test_single_rank_rccl_preflight(mode):
+    """The collectives of the data-parallel step on RCCL itself (backend "nccl"), with the ONE device this box has: ``IG_DIST_FORCE=1``
+    initialises a one-rank process group and keeps every collective of the path in place (parameter broadcast, bucketed reduce-scatter /
+    all-reduce launched from backward, sharded AdamW, all-gather of the bf16 operand copy, the compact all-reduce of the small fp32
+    parameters, ``sync_master_params``) -- each degenerates to a copy, so the result must equal the plain single-process step.  What this
+    screens is what two gloo ranks cannot: dtypes, alignment and stream semantics RCCL accepts for exactly our call pattern."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker, args=(0, 1, _free_port(), q, "nccl", mode, True))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(timeout=60)
+    assert not isinstance(res[1], str), res[1]
+    assert res[2] >= 2, "expected several gradient buckets per step"
+    cfg, mod = _make_module()
+    x, y = _batch(cfg, 0)
+    for _ in range(2):
+        mod.fused_train_step(x, y)
+    torch.cuda.synchronize()
+    ref = mod.net.store.flat.detach().cpu()
+    got = torch.from_numpy(res[1])
+    _, fresh = _make_module()
+    init = fresh.net.store.flat.detach().cpu()
+    cos = torch.nn.functional.cosine_similarity((got - init).reshape(1, -1), (ref - init).reshape(1, -1)).item()
+    diff = (got - ref).abs()
     print(f"update cosine {cos:.6f}; max diff {diff.max().item():.2e}; mean diff {diff.mean().item():.2e}")
     assert cos >= 0.999 and diff.max().item() <= 4.5e-3 and diff.mean().item() <= 2e-5
