@@ -225,7 +225,8 @@ def main() -> None:
     ap.add_argument("--no-parity-leg", action="store_true", help="skip the bf16x3 (1e-3-parity) leg")
     ap.add_argument("--no-tile", action="store_true", help="skip the configs[3] sliding-window leg")
     ap.add_argument("--no-t3-leg", action="store_true", help="N > 1: skip the T = 3 / 13-class leg (the shape the scaling target is stated on)")
-    ap.add_argument("--t3-batch", type=int, default=36, help="per-GPU batch of the T = 3 leg")
+    ap.add_argument("--t3-batch", type=int, default=72, help="per-GPU batch of the T = 3 leg (72 x 589 tokens = 166 row tiles of 256, the same fill "
+                    "of the tile rounds as the default T = 1 batch: +5.7 %% chips/s over 36 on the same box)")
     ap.add_argument("--tile-size", type=int, default=10980)
     ap.add_argument("--event-stride", type=int, default=7, help="bracket every n-th launch of the timed entry points with HIP events")
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP events (roofline objects become null)")
