@@ -106,7 +106,7 @@ def sliding_window_inference(tile: torch.Tensor, model, mean: Sequence[float], s
         x, _ = gather_windows(tile, mine[i : i + k], mean, std, temporal_size, crop_size, constant_multiplier, out=xbuf[:k])
         logits = eng.forward(x, training=False, save=False)
         ops.argmax_i8(logits, out[i : i + k])
-    if gather and world > 1:
+    if gather and D.dp_active():
         counts = [D.shard_range(len(origins), r, world)[1] - D.shard_range(len(origins), r, world)[0] for r in range(world)]
         return D.gather_class_maps(out, counts, dst=0), origins
     return out, origins

@@ -114,7 +114,7 @@ def _reduce_metrics(metrics, dev, model=None, step_type: Optional[str] = None) -
     """Sum the rank-local streaming state over ranks before the epoch-end hooks: the confusion matrix (or the regression
     sums), the (sum of batch losses, #batches) pair behind ``<step>_loss`` and, for the test epoch, the ROC-AUC histograms."""
     D.reduce_confusion(metrics.device_matrix(dev) if hasattr(metrics, "device_matrix") else metrics.device_sums(dev))
-    if model is None or D.world_size() == 1:
+    if model is None or not D.dp_active():
         return
     acc = model._loss_sums.get(step_type)
     if acc is None:  # a rank whose shard was empty still has to take part in the collective
@@ -253,7 +253,7 @@ def main(argv: Optional[List[str]] = None) -> int:
             print(f"Carbon tracking information: {info}")
     else:
         raise ValueError(f"unknown mode {cfg['mode']!r}")
-    if world > 1:
+    if D.dp_active():
         torch.distributed.destroy_process_group()
     return 0
 
