@@ -946,10 +946,21 @@ static int classifier_bwd_impl(int mode, ClsBn bn, int* nwg_out, const float* dl
     const size_t sm = (32 + (size_t)CLS_SLAB + (size_t)nc * ig * nsl) * sizeof(float);
     const float inv = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     static const bool sform = !getenv("IG_CLS_SFORM") || atoi(getenv("IG_CLS_SFORM"));  // reduce pass in S form also at <= 4 classes (A/B switch)
-#define IG_CLS_BWD(NC, VEC, MD, GY)                                                                                                  \
-    hipLaunchKernelGGL((cls_bwd_kernel<NC, VEC, MD>), dim3(gx, GY), dim3(TPB), sm, (hipStream_t)stream, dlogits, (const bf16_t*)f_hi, \
-                       (const bf16_t*)f_lo, w, (bf16_t*)df_hi, (bf16_t*)df_lo, dw, db, count, M, HW, C, ncls, drop_seed,             \
-                       drop_seed_dev, thresh_of(drop_p), inv, (int)iters, (int)ig, bn)
+    // narrow heads (C = 16 with > 8 classes, C = 8 with > 4) stage more than the default 64 KiB limit of dynamic LDS: 32 KiB slab + ig >= 8
+    // groups of nc x nsl floats; every instantiation raises its limit once (as classifier_fwd_kernel does)
+#define IG_CLS_BWD(NC, VEC, MD, GY)                                                                                                      \
+    do {                                                                                                                                 \
+        auto kern_ = cls_bwd_kernel<NC, VEC, MD>;                                                                                        \
+        static bool attr_done_ = false;                                                                                                  \
+        if (!attr_done_) {                                                                                                               \
+            IG_REQUIRE(hipFuncSetAttribute((const void*)kern_, hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10) == hipSuccess,     \
+                       "ig_classifier_bwd: could not raise the dynamic LDS limit%s", "");                                               \
+            attr_done_ = true;                                                                                                           \
+        }                                                                                                                                \
+        hipLaunchKernelGGL(kern_, dim3(gx, GY), dim3(TPB), sm, (hipStream_t)stream, dlogits, (const bf16_t*)f_hi,                        \
+                           (const bf16_t*)f_lo, w, (bf16_t*)df_hi, (bf16_t*)df_lo, dw, db, count, M, HW, C, ncls, drop_seed,             \
+                           drop_seed_dev, thresh_of(drop_p), inv, (int)iters, (int)ig, bn);                                              \
+    } while (0)
 #define IG_CLS_BWD_M(NC)                             \
     do {                                             \
         if (mode == 0) IG_CLS_BWD(NC, 8, 0, 1);      \

@@ -200,6 +200,7 @@ class ShardedGradSync:
         self._small = None               # index tables of the fp32-read parameters (see _sync_small)
         self.time_exposed = False        # bench.py diagnostics: events around every wait of the step
         self._exposed: List = []
+        self._pending: List = []         # (bucket lo, handle) of all-gathers whose wait was deferred to the next reader (wait_params)
 
     # ---- during backward -------------------------------------------------------------------------------------------
     def ready(self, lo: int, hi: int) -> None:
@@ -323,7 +324,8 @@ class ShardedGradSync:
         return out
 
     def step(self, adam: Callable[[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, int], None],
-             gather: Optional[Sequence[torch.Tensor]] = None, small_ranges: Optional[Sequence[Tuple[int, int]]] = None) -> None:
+             gather: Optional[Sequence[torch.Tensor]] = None, small_ranges: Optional[Sequence[Tuple[int, int]]] = None,
+             defer: bool = False) -> None:
         """Finish the exchange, run ``adam`` on the owned slices (and the replicated tail), publish the result.
 
         ``gather`` None: the updated fp32 parameters are all-gathered (4 bytes per parameter).  ``gather`` = flat tensors indexed
@@ -331,7 +333,8 @@ class ShardedGradSync:
         with -- : THOSE are all-gathered instead (2 bytes per parameter; ``adam`` has written this rank's slice of them), the fp32
         masters stay sharded (:meth:`gather_master` completes them, e.g. before a checkpoint), and the parameters the kernels read
         in fp32 (``small_ranges``: biases, norm affine, classifier -- a few hundred KB) are exchanged by ONE small all-reduce in which
-        every rank contributes the elements it owns."""
+        every rank contributes the elements it owns.  ``defer`` (with ``gather``): return without waiting for the all-gathers;
+        :meth:`wait_params` must then run in front of every reader of the gathered tensors."""
         self._flush(final=True)
         flat = self.get_flat()
         # every step: the bucket sequence must be the planned one BEFORE anything is updated (a missing ready() range would leave
@@ -343,28 +346,46 @@ class ShardedGradSync:
             if covered != self.hi - self.lo:
                 raise RuntimeError(f"ShardedGradSync: buckets cover {covered} of {self.hi - self.lo} gradient elements "
                                    "(every trainable range must be reported through ready())")
-        gathers = []
+        self.wait_params()  # (a step without a forward in between: nothing of the previous publication may still be in flight)
         for i, (blo, bhi) in enumerate(self._step_buckets):
             self._timed_wait(self._handles[i], "rs")
             n = (bhi - blo) // self.world
             s0 = blo + self.rank * n
             adam(flat[s0 : s0 + n], self._own[i], self._m[i], self._v[i], s0)
-            for t in ([flat] if gather is None else gather):
-                send = t[s0 : s0 + n].clone()  # (not the in-place form: output and input of the gather do not alias)
-                gathers.append(self._all_gather(t[blo:bhi], send))
         if self._tail_handle is not None:
             self._timed_wait(self._tail_handle, "tail")
             tlo, thi = self.tail
             adam(flat[tlo:thi], self.get_grad()[tlo:thi], self.m_tail, self.v_tail, tlo)
             self._tail_handle = None
-        if gather is not None and small_ranges:
+        if gather is not None and small_ranges:  # before the all-gathers: a collective queued behind them would wait for all of them
             self._sync_small(flat, small_ranges)
-        for h in gathers:
-            self._timed_wait(h, "ag")
+        # The all-gathers go out in ASCENDING address order -- the order in which the next forward pass reads the parameters
+        # (patch embed, block 0, 1, ...): with ``defer`` the wait for a bucket is left to the first kernel that reads it
+        # (wait_params, called by the engine in front of every Block), so the exchange rides under the next step's normalise, patch
+        # embed and earlier blocks instead of standing between two steps.
+        gathers = []
+        for blo, bhi in sorted(self._step_buckets):
+            n = (bhi - blo) // self.world
+            s0 = blo + self.rank * n
+            for t in ([flat] if gather is None else gather):
+                send = t[s0 : s0 + n].clone()  # (not the in-place form: output and input of the gather do not alias)
+                gathers.append((blo, self._all_gather(t[blo:bhi], send)))
+        if defer and gather is not None:
+            self._pending = gathers
+        else:
+            for _, h in gathers:
+                self._timed_wait(h, "ag")
         self._frozen = True
         self.master_complete = gather is None
         self._handles.clear()
         self._step_buckets.clear()
+
+    def wait_params(self, upto: Optional[int] = None) -> None:
+        """Wait (on the current stream) for the deferred all-gathers of every bucket that starts below flat offset ``upto`` (None:
+        all of them).  The engine calls it with the end offset of the parameters it is about to read (``SegEngine.param_wait``)."""
+        while self._pending and (upto is None or self._pending[0][0] < upto):
+            _, h = self._pending.pop(0)
+            self._timed_wait(h, "ag")
 
     def _sync_small(self, flat: torch.Tensor, small_ranges: Sequence[Tuple[int, int]]) -> None:
         """fp32 parameters inside the sharded buckets that the kernels read directly: every rank fills a compact buffer with the
@@ -398,6 +419,7 @@ class ShardedGradSync:
     def gather_master(self) -> None:
         """Complete the fp32 master parameters on every rank (after steps that published only the bf16 operand copy): one fp32
         all-gather per bucket.  Collective -- every rank calls it (e.g. at epoch end, before rank 0 writes a checkpoint)."""
+        self.wait_params()
         if not dp_active() or self.master_complete or not self.plan:
             return
         flat = self.get_flat()
@@ -483,6 +505,8 @@ def attach_data_parallel(module, bucket_bytes: int = 32 << 20):
         opt.attach_sharded(sync)
         net.engine.on_grad_ready = sync.ready
         net.engine.master_sync = sync.gather_master
+        net.engine.master_complete = lambda: sync.master_complete  # state_dict() refuses to read sharded masters (see PrithviSeg.state_dict)
+        net.engine.param_wait = sync.wait_params                   # deferred all-gather waits, in front of each Block of the next forward
         module.grad_sync = None  # the exchange is finished inside the optimizer step
         return sync
     sync = GradSync(lambda: net.store.ensure_grad(), bucket_bytes, scale_in_optimizer=True)

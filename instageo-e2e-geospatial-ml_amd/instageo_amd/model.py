@@ -332,6 +332,9 @@ class SegEngine:
         self.freeze_backbone = False
         self.on_grad_ready: Optional[Callable[[int, int], None]] = None
         self.master_sync: Optional[Callable[[], None]] = None  # distributed.ShardedGradSync.gather_master when the fp32 masters are sharded
+        self.master_complete: Optional[Callable[[], bool]] = None  # ... and whether they are complete on this rank right now
+        # data parallel: wait for the deferred all-gather of the parameters below a flat offset (ShardedGradSync.wait_params)
+        self.param_wait: Optional[Callable[[Optional[int]], None]] = None
         # run-to-run bit-identical training (the reference's Trainer runs with deterministic=True, pipeline_utils.py:373): the
         # multi-contributor reductions go through the fixed-point shadow of the gradient buffer (ops.set_deterministic).  On by
         # default (0.15-0.2 ms per step); IG_DETERMINISTIC=0 or ``engine.deterministic = False`` selects the float atomics.
@@ -352,6 +355,15 @@ class SegEngine:
 
     def W(self, name: str) -> BT:
         return self.store.w(name)
+
+    def _need(self, last_name: Optional[str]) -> None:
+        """The parameters up to and including ``last_name`` (flat = forward order; None: all) are about to be read."""
+        if self.param_wait is not None:
+            if last_name is None:
+                self.param_wait(None)
+            else:
+                ent = self.store.entries[last_name]
+                self.param_wait(ent.offset + ent.numel)
 
     def mark_params_changed(self) -> None:
         self.shadow_dirty = True
@@ -502,6 +514,7 @@ class SegEngine:
         pos = self.pos_embed_for(cfg)
         ops.patchify(img, cfg.patch, ws["patches"])
         x = ws["x_in"][0]
+        self._need(e + "patch_embed.proj.bias")
         ops.cls_rows(x, self.P(e + "cls_token"), pos, B, N, D)
         ops.patch_embed_fwd(ws["patches"], self.W(e + "patch_embed.proj.weight"), self.P(e + "patch_embed.proj.bias"), pos, x, B,
                             T * G, D, cfg.patch_k)
@@ -511,6 +524,7 @@ class SegEngine:
             x_in = ws["x_in"][i if save else i % 2]
             x_out = ws["x_in"][i + 1 if save else (i + 1) % 2]
             x_mid = ws["x_mid"][s]
+            self._need(b + "mlp.fc2.bias")
             ops.layernorm_fwd(x_in, self.P(b + "norm1.weight"), self.P(b + "norm1.bias"), ws["a"][s], ws["mean1"][s], ws["rstd1"][s], M, D)
             ops.linear_fwd(ws["a"][s], self.W(b + "attn.qkv.weight"), self.P(b + "attn.qkv.bias"), ws["qkv"][s], M, 3 * D, D)
             ops.attention_fwd(ws["qkv"][s], ws["o"][s], ws["lse"][s] if save else None, B, N, H, cfg.head_dim)
@@ -520,6 +534,7 @@ class SegEngine:
                            pre=ws["hpre"][s] if save else None)
             ops.linear_residual_fwd(ws["hact"][s], self.W(b + "mlp.fc2.weight"), self.P(b + "mlp.fc2.bias"), x_mid, x_out, M, D, 4 * D)
         x_fin = ws["x_in"][L if save else L % 2]
+        self._need(None)  # final norm + decode head
         # final LayerNorm writes the (B, 14, 14, D*T) feature image directly (model.py:406-413, c = d*T + t)
         ops.layernorm_fwd(x_fin, self.P(e + "norm.weight"), self.P(e + "norm.bias"), ws["f"][0], ws["meanF"], ws["rstdF"], M, D,
                           feat_T=T, feat_G=G, ntok=N)
@@ -1016,6 +1031,16 @@ class PrithviSeg(nn.Module):
                     bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
                     p.copy_(torch.empty(p.shape).uniform_(-bound, bound))
         self.engine.mark_params_changed() if hasattr(self, "engine") else None
+
+    def state_dict(self, *args, **kwargs):
+        """``nn.Module.state_dict`` with the reference's keys.  Under sharded data parallelism (``zero1`` publishing the bf16 operand
+        copy) a rank holds CURRENT fp32 masters only for the slices it owns between two ``sync_master_params()`` calls: reading them
+        then would save mixed-age weights, and completing them is a collective that one rank cannot run alone -- so this raises."""
+        mc = getattr(self.engine, "master_complete", None) if hasattr(self, "engine") else None
+        if mc is not None and not mc():
+            raise RuntimeError("PrithviSeg.state_dict(): the fp32 master parameters are sharded over the data-parallel ranks and this "
+                               "rank's copy is incomplete; call PrithviSegmentationModule.sync_master_params() on EVERY rank first")
+        return super().state_dict(*args, **kwargs)
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
         out = super().load_state_dict(state_dict, strict=strict, assign=False)

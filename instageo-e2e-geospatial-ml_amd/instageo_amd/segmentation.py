@@ -102,6 +102,8 @@ class FusedAdamW(torch.optim.Optimizer):
         # the kernel also refreshes the bf16 (hi/lo) operand copy used by the MFMA kernels
         eng = self.net.engine
         if store.shadow is None or store.shadow_split != eng.split:
+            if eng.master_sync is not None:  # sharded fp32 masters: complete them before the operand copy is rebuilt from them (collective)
+                eng.master_sync()
             store.refresh_shadow(eng.split)
         return store, eng, store.shadow
 
@@ -136,7 +138,9 @@ class FusedAdamW(torch.optim.Optimizer):
                 if self._small_ranges is None:
                     self._small_ranges = [(e.offset, e.offset + e.numel) for e in store.entries.values()
                                           if e.numel <= 65536 and e.offset + e.numel > self.lo and e.offset < self.hi]
-                self.sharded.step(adam, gather=[sh.hi] + ([] if sh.lo is None else [sh.lo]), small_ranges=self._small_ranges)
+                # the waits for the all-gathers are left to the next forward pass (engine.param_wait, one per Block): IG_DP_DEFER=0 waits here
+                self.sharded.step(adam, gather=[sh.hi] + ([] if sh.lo is None else [sh.lo]), small_ranges=self._small_ranges,
+                                  defer=os.environ.get("IG_DP_DEFER", "1") != "0" and eng.param_wait is not None)
             eng.shadow_dirty = False
             eng.shadow_t_dirty = True
             return loss
@@ -151,6 +155,8 @@ class FusedAdamW(torch.optim.Optimizer):
         adjacent, in descending address order (head first); every >= ``EARLY_MIN`` elements the AdamW kernel of the merged range is
         launched on a SIDE stream behind an event of the launch stream, so it overlaps the backward kernels of the earlier blocks
         (whose weights it does not touch: a block's parameters are last read by its own backward).  :meth:`early_finish` joins."""
+        for hook in list(getattr(self, "_optimizer_step_pre_hooks", {}).values()):  # this path IS optimizer.step(): same hooks
+            hook(self, (), {})
         self._begin()
         if self._side is None:
             self._side = torch.cuda.Stream()
@@ -199,6 +205,21 @@ class FusedAdamW(torch.optim.Optimizer):
         eng = self.net.engine
         eng.shadow_dirty = False
         eng.shadow_t_dirty = True
+        # what torch.optim.Optimizer.step()'s wrappers would have done: LR schedulers check _opt_called ("lr_scheduler.step() before
+        # optimizer.step()"), step post hooks run after the update
+        self._opt_called = True
+        for hook in list(getattr(self, "_optimizer_step_post_hooks", {}).values()):
+            hook(self, (), {})
+
+    def early_abort(self) -> None:
+        """The backward pass raised in the middle of an overlapped step: join the side stream (its launches read the gradient
+        buffer) and take back the step counter the preamble advanced, so that the failed step leaves no half-applied bookkeeping."""
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+        self._early_cur, self._early_done = None, []
+        self._host_step -= 1
+        self._write_hyper()
+        self.net.engine.mark_params_changed()  # some ranges may already be updated: rebuild the operand copy from the masters
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         super().zero_grad(set_to_none=set_to_none)
@@ -443,8 +464,11 @@ class PrithviSegmentationModule(_Base):
             eng.on_grad_ready = opt.early_begin()
             try:
                 eng.backward(dlog, count=stats, fresh=_FRESH_STEP)
-            finally:
+            except BaseException:
                 eng.on_grad_ready = None
+                opt.early_abort()
+                raise
+            eng.on_grad_ready = None
             opt.early_finish()
         else:
             eng.backward(dlog, count=stats, fresh=_FRESH_STEP)

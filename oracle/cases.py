@@ -15,6 +15,9 @@ CASES = {
     "tiny_t3_c13": ("prithvi_eo_tiny", 3, 13, 2, -1),
     "v1_100_t1_c2": ("prithvi_eo_v1_100", 1, 2, 4, -1),  # BASELINE.json configs[0]
     "v1_100_t3_c13": ("prithvi_eo_v1_100", 3, 13, 1, -1),
+    # the reference YAMLs' own per-GPU batches (train-mode BatchNorm couples the batch, so B = 4 / 1 do not cover them):
+    "v1_100_t1_c2_b16": ("prithvi_eo_v1_100", 1, 2, 16, -1),  # configs/sen1floods11.yaml:13 (batch_size: 16)
+    "v1_100_t3_c13_b8": ("prithvi_eo_v1_100", 3, 13, 8, -1),  # configs/multitemporal_crop_classification.yaml:14 (batch_size: 8)
     "v2_300_t1_c2": ("prithvi_eo_v2_300", 1, 2, 1, -1),  # BASELINE.json configs[4] architecture (D=1024, L=24, 16 heads)
     # the 600M shape family at depth 2 (model.py:154-177): D = 1280, 16 heads of 80, patch 14 (257 tokens), head kernels [5, 5, 5, 7]
     "v2_600_t1_c2": ("prithvi_eo_v2_600", 1, 2, 1, 2),

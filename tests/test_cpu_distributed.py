@@ -363,6 +363,107 @@ def test_sharded_optimizer_publishes_the_bf16_operand_copy(world):
     assert any(r[4] for r in res), "no rank had incomplete masters before gather_master(): the test does not exercise the sharded state"
 
 
+def _checkpoint_guard_worker(rank: int, world: int, port: int, q) -> None:
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "instageo-e2e-geospatial-ml_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from instageo_amd import distributed as D
+    from instageo_amd.segmentation import PrithviSegmentationModule
+
+    D.init_from_env(backend="gloo")
+    try:
+        torch.manual_seed(3 + rank)  # different initial weights per rank: attach_data_parallel broadcasts rank 0's
+        mod = PrithviSegmentationModule(model_name="prithvi_eo_tiny", load_pretrained_weights=False, freeze_backbone=False, device="cpu",
+                                        class_weights=[1, 3], ignore_index=-1)
+        sync = D.attach_data_parallel(mod, bucket_bytes=4 << 20)
+        net, opt = mod.net, mod.optimizer()
+        store, eng = net.store, net.engine
+        assert isinstance(sync, D.ShardedGradSync) and opt.sharded is sync and eng.param_wait is not None
+        flat0 = store.flat.clone()
+        n = store.flat.numel()
+        shadow = store.flat.to(torch.bfloat16)  # stand-in for the device operand copy (ig_adamw_step writes it on the GPU)
+        grad = store.ensure_grad()
+        sd_before = mod.checkpoint_state_dict()  # masters complete: allowed
+        # the engine reports gradient ranges per Block, head first (descending addresses); here: the parameter entries in reverse
+        ents = sorted(store.entries.values(), key=lambda e: -e.offset)
+        bounds = [n] + [e.offset for e in ents]
+
+        def adam(p, g, m, v, i0, step):
+            _adam_ref(p, g, m, v, step, scale=1.0 / world)
+            shadow[i0 : i0 + p.numel()] = p.to(torch.bfloat16)
+
+        raised, popped = [], []
+        for step in (1, 2):
+            grad.copy_(torch.randn(n, generator=torch.Generator().manual_seed(1000 * step + rank)))
+            for hi, lo_r in zip(bounds[:-1], bounds[1:]):
+                sync.ready(lo_r, hi)
+            sync.step(lambda p, g, m, v, i0, step=step: adam(p, g, m, v, i0, step), gather=[shadow], small_ranges=[(n - 64, n)], defer=True)
+            try:
+                mod.checkpoint_state_dict()
+                raised.append(False)
+            except RuntimeError as e:
+                raised.append("sync_master_params" in str(e))
+            # the next forward pass: the engine's hooks wait bucket by bucket, in address order
+            pend0 = len(sync._pending)
+            first_block_end = store.entries["prithvi_encoder.blocks.0.mlp.fc2.bias"]
+            eng._need("prithvi_encoder.blocks.0.mlp.fc2.bias")
+            pend1 = len(sync._pending)
+            own_lo = sync.plan[-1][0]  # lowest bucket
+            eng._need(None)
+            popped.append((pend0, pend1, len(sync._pending), own_lo < first_block_end.offset + first_block_end.numel))
+        mod.sync_master_params()  # collective: every rank
+        sd_after = mod.checkpoint_state_dict()
+        q.put((rank, raised, popped, flat0.numpy().copy(), {k: v.numpy().copy() for k, v in sd_after.items() if k.startswith("net.segmentation_head.5")},
+               store.flat.numpy().copy(), shadow.float().numpy().copy(), opt.lo, opt.hi, len(sd_before)))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_checkpoint_refuses_sharded_masters_and_the_gather_wait_is_deferred():
+    """zero1 publishing the bf16 operand copy (the default): between ``sync_master_params()`` calls a rank's fp32 masters are
+    current only for its own slices.  ``checkpoint_state_dict()`` / ``PrithviSeg.state_dict()`` on such a rank must RAISE (a
+    collective cannot run on rank 0 alone, and a silent read saves (N - 1)/N stale weights); after ``sync_master_params()`` on
+    every rank the checkpoint equals the one-process optimizer.  The same run checks the deferred all-gather: ``step(defer=True)``
+    returns with the gathers in flight and the engine's per-Block hook waits for them in address order."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_checkpoint_guard_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert not isinstance(r[1], str), r[1]
+    flat0, lo, hi = torch.from_numpy(res[0][3]), res[0][7], res[0][8]
+    assert np.array_equal(res[0][3], res[1][3]), "attach_data_parallel did not broadcast rank 0's parameters"
+    n = flat0.numel()
+    ref = flat0.clone()
+    m, v = torch.zeros(hi - lo), torch.zeros(hi - lo)
+    for step in (1, 2):
+        g = sum(torch.randn(n, generator=torch.Generator().manual_seed(1000 * step + r)) for r in range(world)) / world
+        _adam_ref(ref[lo:hi], g[lo:hi], m, v, step)
+    for r in res:
+        assert r[1] == [True, True], "checkpoint_state_dict() did not refuse the incomplete masters"
+        for pend0, pend1, pend2, first_in_block0 in r[2]:
+            assert pend0 >= 2 and pend2 == 0, "the all-gathers were not left in flight by step(defer=True)"
+            assert pend1 < pend0 if first_in_block0 else pend1 == pend0
+            assert pend1 > 0, "waiting for Block 0 drained buckets that only the later blocks read"
+        assert torch.allclose(torch.from_numpy(r[5]), ref, rtol=0, atol=2e-6), "completed masters differ from the one-process optimizer"
+        assert np.array_equal(r[5], res[0][5]) and np.array_equal(r[6], res[0][6]), "ranks diverged"
+        for k, val in r[4].items():
+            assert np.array_equal(val, res[0][4][k])
+        assert r[9] >= 90
+
+
 def _gather_worker(rank: int, world: int, port: int, q) -> None:
     import sys
 

@@ -4,7 +4,7 @@ Tolerances (stated per north_star):
 * precision "bf16x3" (split-bf16 MFMA): logits within 1e-3 abs of the fp32 reference -- the north-star bar.
 * precision "bf16" (the fast/bench mode): bf16 has 8 mantissa bits; through 12+ residual blocks a 1e-3 abs
   bound on O(1) logits is not attainable (a CPU emulation of the same roundings gives ~3e-2 max).  Its
-  deviation is *measured* here and bounded by max-abs <= 8e-2, mean-abs <= 1e-2, argmax agreement >= 99 %.
+  deviation is *measured* here and bounded by max-abs <= 6e-2, mean-abs <= 8e-3, argmax agreement >= 99 %.
 * gradients: the fp32 reference's own autograd noise on these cases is ~3e-3 relative (fixture key
   grad_fp32_noise__*), so bf16x3 gradients are held to 1e-2 relative L2 against the fp64 fixture.
 """
@@ -143,6 +143,43 @@ def test_benchmark_batch_ties_to_the_golden_fixture_and_is_permutation_equivaria
         assert gmx <= 8e-2 and d <= 8e-2
 
 
+@pytest.mark.parametrize("B", [36, 72])
+def test_multitemporal_benchmark_batch_ties_to_the_golden_fixture(B):
+    """BASELINE configs[2] (T = 3, 13 classes: configs/multitemporal_crop_classification.yaml:14-30) at the batches bench.py times it
+    at (36 / 72 chips per GPU).  At one chip the head's row counts (196 ... 50 176) keep most stages off the wide-convolution
+    engines (conv8.hip, gemm8w.hip modes 1 / 2), so the B = 1 fixture does not exercise the benchmarked path.  Here the fixture's
+    chip sits at scattered positions of a random batch; eval mode has no cross-sample coupling, so
+    (i) its logits equal the reference-generated golden vector (tests/golden/v1_100_t3_c13.npz) within 1e-3 (bf16x3),
+    (ii) a batch permutation permutes the logits bit for bit, and
+    (iii) the launch log shows that the 8-phase convolution engine served the head (kernel names as rocprofv3 prints them)."""
+    name = "v1_100_t3_c13"
+    cfg, sd, net, img1, _ = build(name, "bf16x3")
+    net.eval()
+    g = torch.Generator().manual_seed(11)
+    img = torch.randn((B, *img1.shape[1:]), generator=g)
+    pos = [0, 17, B - 1]
+    for q in pos:
+        img[q] = img1[0]
+    ops.profile_begin(["ig_conv3x3_fwd", "ig_convT_fwd", "ig_linear_fwd", "ig_attention_fwd"])
+    with torch.no_grad():
+        logits = net(img.to(DEV))
+    kern = ops.profile_end()["kernels"]
+    names = sorted(kern)
+    print("   kernels:", names)
+    assert any(k.startswith("conv8_kernel") for k in names), f"the wide-convolution engine did not run at B = {B}: {names}"
+    assert any(k.startswith("gemm8_kernel") for k in names) and any(k.startswith("attn2_") for k in names)
+    with torch.no_grad():
+        perm = torch.randperm(B, generator=g)
+        logits_p = net(img[perm].to(DEV))
+    assert torch.equal(logits_p.cpu(), logits.cpu()[perm]), "eval logits depend on the batch position of a chip"
+    gold = np.load(os.path.join(GOLD, f"{name}.npz"))
+    for q in pos:
+        gmx = np.abs(sub(logits[q:q + 1].cpu()) - gold["eval_logits_sub"]).max()
+        print(f"   B={B} chip at {q}: vs golden {gmx:.3e}")
+        assert gmx <= 1e-3
+    assert torch.equal(logits[pos[0]].cpu(), logits[pos[1]].cpu()) and torch.equal(logits[pos[0]].cpu(), logits[pos[2]].cpu())
+
+
 @pytest.mark.parametrize("name", ["tiny_t1_c2", "tiny_t3_c13"])
 def test_stage_activations_bf16x3(name):
     """Per-stage check (features image layout c = d*T+t, head stages) against the golden sub-samples."""
@@ -167,7 +204,8 @@ def rel_l2(a, b):
     return ((a - b).norm() / (b.norm() + 1e-300)).item()
 
 
-@pytest.mark.parametrize("name", ["tiny_t1_c2", "tiny_t3_c13", "v1_100_t1_c2", "v1_100_t3_c13", "v2_300_t1_c2", "v2_600_t1_c2"])
+@pytest.mark.parametrize("name", ["tiny_t1_c2", "tiny_t3_c13", "v1_100_t1_c2", "v1_100_t3_c13", "v2_300_t1_c2", "v2_600_t1_c2",
+                                  "v1_100_t1_c2_b16", "v1_100_t3_c13_b8"])  # the last two: the reference YAMLs' own batch sizes
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
 def test_train_step_gradients(name, precision):
     """forward(train-mode BN, dropout p=0) + loss + backward: loss, logits and gradients vs the fp64 fixture that

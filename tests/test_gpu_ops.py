@@ -931,7 +931,7 @@ def test_bn_relu(split, M, C):
 
 
 @pytest.mark.parametrize("split", SPLITS)
-@pytest.mark.parametrize("ncls,C", [(2, 48), (13, 144), (7, 96), (3, 48)])
+@pytest.mark.parametrize("ncls,C", [(2, 48), (13, 144), (7, 96), (3, 48), (13, 16), (7, 8)])  # the last two: narrow heads, > 64 KiB of staged dlogits
 def test_classifier_and_loss(split, ncls, C):
     B, H, W = 2, 24, 20
     HW = H * W
