@@ -27,6 +27,16 @@
 
 #include "common.h"
 
+#ifdef IG_G8_PROF
+// Diagnostic builds only (csrc: `make prof` -> libinstageo_hip_g8prof{1,2}.so, tools/gemm8_phase_prof.py): s_memtime stamps at the phase
+// boundaries around one tile transition of workgroup 0; they go to a buffer nothing else reads.  IG_G8_PROF=1 also drains the stores
+// behind the epilogue (how long until they are acknowledged), 2 leaves the kernel's own waits alone.
+__device__ unsigned long long g_g8prof[8 * 64];
+#define G8P_MARK(I) { if (g8p_on) g_g8prof[wave * 64 + (I)] = __builtin_readcyclecounter(); }
+extern "C" int ig_debug_g8prof(unsigned long long* dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_g8prof), sizeof(g_g8prof)) == hipSuccess ? 0 : -1; }
+#else
+#define G8P_MARK(I)
+#endif
 namespace {
 
 // Epilogue stores.  Non-temporal stores drain the write burst of 256 CUs faster in isolation (round 4, same-box A/B of two builds at
@@ -81,14 +91,21 @@ struct Cur {  // issue cursor of one half-tile type (all wave-uniform)
     int kt, seg, tile, vr, left;
 };
 
-// SCHED 2 (default): two "big phases" of 32 MFMAs per K-tile (4 barriers per K-tile instead of 8; +2-4 %); SCHED 0: the four
-// 16-MFMA phases of the header comment (kept for A/B runs, IG_G8_SCHED=0).  A third schedule that balanced the LDS reads over the
-// four phases (8/4/8/4 instead of 12/4/8/0) measured no gain and was removed.
+// SCHED 2: two "big phases" of 32 MFMAs per K-tile (4 barriers per K-tile instead of the 8 of the header comment's 16-MFMA phases:
+// +2-4 %, round 2; that four-phase schedule and one that balanced its LDS reads were removed).  SCHED 4 (default, round 5): the same
+// big phases with (i) every counted wait BEFORE its phase's issues and (ii) the B1 half-tile of K-tile t + 2 issued BEHIND the MFMAs of
+// big phase 2 instead of in its read phase.  In-kernel stamps (profiles/r05_gemm8_phase_*.txt): a read phase -- 8-16 fragment reads,
+// 2-6 LDS-DMA issues at ~95 cycles each, the wait -- takes 760-970 cycles, the other group's 32 MFMAs 640, so every interval is as long
+// as its READ side and a wave waits ~500 cycles at the closing barrier behind its MFMAs: that is where two of the six issues of the
+// long read phase go.  WAR: the slot was last read two intervals earlier, by both groups.  The DMA stream of a wave in program order:
+// [R1: A1(t+1)] [R2: A0 B0 (t+2)] [M2: B1(t+2)]; R1's wait retires A1(t) with 6 younger operations in flight, R2's retires
+// A0 B0 B1 (t+1) with 2 (last iteration: 6 2 0 0).  qkv 142.0 -> 135.4 us, fc2 193.8 -> 190.4 at M = 42552 (same box, tools/gemm8_bench.py
+// --sched); also measured, not kept: A1 behind the MFMAs of big phase 1 as well (140.1), the waits moved alone (141.9).
 // DBG (timing ablations, built with -DIG_G8_ABLATE only; results are garbage): 1 = no LDS-DMA inside the loop, 2 = + no fragment
 // reads, 3 = + no barriers, 4 = everything but the epilogue stores.  profiles/r02_v8_ablation_qkv.log: of 71 us (qkv, B = 108)
 // the epilogue is 13.7 (its 33 MB store burst per round sits in front of the next loads in the in-order vmcnt), LDS-DMA 10.2,
 // fragment reads 2.5, barriers 1.7 and the MFMAs themselves 43 us.
-template <int KIND, int NSEG, int ACT, bool DACT, bool SPLIT_OUT, int SCHED = 2, int DBG = 0, int MT = 4, int WC = 4>
+template <int KIND, int NSEG, int ACT, bool DACT, bool SPLIT_OUT, int SCHED = 4, int DBG = 0, int MT = 4, int WC = 4>
 __global__ __launch_bounds__(128 * WC, 2) void gemm8_kernel(G8Params p) {
     using Geo = G8Geo<MT, WC>;
     constexpr int G8_HALF = Geo::HALF, G8_BUF = Geo::BUF, G8_STAGE = Geo::STAGE, BM = Geo::BM, BN = Geo::BN;
@@ -195,7 +212,7 @@ __global__ __launch_bounds__(128 * WC, 2) void gemm8_kernel(G8Params p) {
     G8_ISSUE(cA1, true, 1, 0)
     G8_ISSUE(cA0, true, 0, 1)
     G8_ISSUE(cB0, false, 0, 1)
-    if constexpr (SCHED == 2) G8_ISSUE(cB1, false, 1, 1)
+    if constexpr (SCHED >= 2) G8_ISSUE(cB1, false, 1, 1)
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
 
@@ -206,29 +223,29 @@ __global__ __launch_bounds__(128 * WC, 2) void gemm8_kernel(G8Params p) {
 #define G8_READ_B(BUF, G, DST)                                                                                     \
     if (DBG < 2 || DBG == 4 || !in_loop) _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) \
         DST[nt_][s_] = *reinterpret_cast<const bf16x8_t*>(smem + (BUF)*G8_BUF + (G)*G8_HALF + nt_ * 2048 + (boff ^ (s_ * 64)));
-#define G8_MFMA(H, G, BSRC)                                                                                        \
-    {                                                                                                              \
-        asm volatile("s_barrier" ::: "memory");                                                                    \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
-        __builtin_amdgcn_s_setprio(1);                                                                             \
-        _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_) _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_)   \
-            _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                       \
-                acc[H][G][nt_][mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BSRC[nt_][s_], af[mt_][s_], acc[H][G][nt_][mt_], 0, 0, 0); \
-        __builtin_amdgcn_s_setprio(0);                                                                             \
-        asm volatile("s_barrier" ::: "memory");                                                                    \
-    }
-    // SCHED 2 "big phase": 32 MFMAs (two quadrants) between one barrier pair; reads are retired BEFORE the first barrier
+// SCHED 2 "big phase": 32 MFMAs (two quadrants) between one barrier pair; reads are retired BEFORE the first barrier
     // (lgkmcnt(0)), so a half-tile may be refilled in the very next phase
-#define G8_MFMA2(H)                                                                                                \
+#define G8_MFMA2(H) G8_MFMA2T(H, 60, )
+    // PM: first of three stamp slots of the diagnostic build; TAIL: LDS-DMA issues of this wave placed behind its MFMAs (SCHED 4)
+#define G8_MFMA2T(H, PM, TAIL)                                                                                     \
     {                                                                                                              \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
+        G8P_MARK(PM)                                                                                               \
         if (DBG != 3) asm volatile("s_barrier" ::: "memory");                                                      \
+        G8P_MARK(PM + 1)                                                                                           \
         __builtin_amdgcn_s_setprio(1);                                                                             \
         _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_) _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_)       \
             _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)  \
                 acc[H][g_][nt_][mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g_ ? bf1[nt_][s_] : bf0[nt_][s_], af[mt_][s_], acc[H][g_][nt_][mt_], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                             \
+        G8P_MARK(PM + 2)                                                                                           \
+        TAIL                                                                                                       \
         if (DBG != 3) asm volatile("s_barrier" ::: "memory");                                                      \
+    }
+#define G8_WAITN(CNT, LASTCNT)                                                               \
+    {                                                                                        \
+        if (last) asm volatile("s_waitcnt vmcnt(" #LASTCNT ")" ::: "memory");                \
+        else asm volatile("s_waitcnt vmcnt(" #CNT ")" ::: "memory");                         \
     }
 #define G8_WAIT(LASTCNT)                                                                     \
     {                                                                                        \
@@ -236,6 +253,11 @@ __global__ __launch_bounds__(128 * WC, 2) void gemm8_kernel(G8Params p) {
         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                \
     }
 
+#ifdef IG_G8_PROF
+    int g8p_tiles = 0;    // tiles finished by this workgroup
+    bool g8p_on = false;  // the stamps of this iteration are recorded
+    int g8p_base = 0;
+#endif
     int it_c = 0;  // iterations (K-tile pairs) done of the current tile
     const int iters = Gtot >> 1, per_tile2 = per_tile >> 1;
     bool staggered = false;
@@ -247,44 +269,17 @@ __global__ __launch_bounds__(128 * WC, 2) void gemm8_kernel(G8Params p) {
     in_loop = true;
     for (int it = 0; it < iters; ++it) {
         const bool last = it == iters - 1;
+#ifdef IG_G8_PROF
+        // recorded: the first iteration behind the 2nd tile's epilogue (slots 2-14) and the 2nd iteration of the 3rd tile (18-30, a plain one)
+        g8p_on = blockIdx.x == 0 && g8p_tiles == 2 && it_c <= 1;
+        g8p_base = it_c == 0 ? 0 : 16;
+        G8P_MARK(g8p_base + 2)
+#endif
         if (!staggered) {  // (re-)establish the stagger: group 1 runs one barrier behind group 0
             if (wr == 1) asm volatile("s_barrier" ::: "memory");
             staggered = true;
         }
-        if constexpr (SCHED == 0) {
-            // ---- even K-tile (buffer 0) ----
-            G8_READ_B(0, 0, bf0)
-            G8_READ_A(0, 0)
-            G8_ISSUE(cB1, false, 1, 1)
-            G8_WAIT(8)
-            G8_MFMA(0, 0, bf0)
-            G8_READ_B(0, 1, bf1)
-            G8_ISSUE(cA1, true, 1, 1)
-            G8_WAIT(8)
-            G8_MFMA(0, 1, bf1)
-            G8_READ_A(0, 1)
-            G8_ISSUE(cA0, true, 0, 0)
-            G8_MFMA(1, 1, bf1)
-            G8_ISSUE(cB0, false, 0, 0)
-            G8_WAIT(4)
-            G8_MFMA(1, 0, bf0)
-            // ---- odd K-tile (buffer 1) ----
-            G8_READ_B(1, 0, bf0)
-            G8_READ_A(1, 0)
-            G8_ISSUE(cB1, false, 1, 0)
-            G8_WAIT(2)
-            G8_MFMA(0, 0, bf0)
-            G8_READ_B(1, 1, bf1)
-            G8_ISSUE(cA1, true, 1, 0)
-            G8_WAIT(0)
-            G8_MFMA(0, 1, bf1)
-            G8_READ_A(1, 1)
-            G8_ISSUE(cA0, true, 0, 1)
-            G8_MFMA(1, 1, bf1)
-            G8_ISSUE(cB0, false, 0, 1)
-            G8_WAIT(0)
-            G8_MFMA(1, 0, bf0)
-        } else if constexpr (SCHED == 2) {
+        if constexpr (SCHED == 2) {
             // two big phases per K-tile: BP1 reads A0 B0 B1 + issues A1 of the next K-tile; BP2 reads A1 + issues A0 B0 B1 of
             // K-tile + 2 into the slots BP1 has just retired.  Every wait is vmcnt(8) (see the header comment).
             G8_READ_B(0, 0, bf0)
@@ -312,11 +307,52 @@ __global__ __launch_bounds__(128 * WC, 2) void gemm8_kernel(G8Params p) {
             G8_WAIT(0)
             G8_MFMA2(1)
         }
+        else if constexpr (SCHED == 4) {
+            G8_READ_B(0, 0, bf0)
+            G8_READ_B(0, 1, bf1)
+            G8_READ_A(0, 0)
+            G8P_MARK(g8p_base + 3)
+            G8_WAITN(6, 6)
+            G8_ISSUE(cA1, true, 1, 1)
+            G8P_MARK(g8p_base + 4)
+            G8_MFMA2T(0, (g8p_base ? 40 : 60), )
+            G8P_MARK(g8p_base + 5)
+            G8_READ_A(0, 1)
+            G8P_MARK(g8p_base + 6)
+            G8_WAITN(2, 2)
+            G8_ISSUE(cA0, true, 0, 0)
+            G8_ISSUE(cB0, false, 0, 0)
+            G8P_MARK(g8p_base + 7)
+            G8_MFMA2T(1, (g8p_base ? 44 : 60), G8_ISSUE(cB1, false, 1, 0))
+            G8P_MARK(g8p_base + 8)
+            G8_READ_B(1, 0, bf0)
+            G8_READ_B(1, 1, bf1)
+            G8_READ_A(1, 0)
+            G8P_MARK(g8p_base + 9)
+            G8_WAITN(6, 0)
+            G8_ISSUE(cA1, true, 1, 0)
+            G8P_MARK(g8p_base + 10)
+            G8_MFMA2T(0, (g8p_base ? 48 : 60), )
+            G8P_MARK(g8p_base + 11)
+            G8_READ_A(1, 1)
+            G8P_MARK(g8p_base + 12)
+            G8_WAITN(2, 0)
+            G8_ISSUE(cA0, true, 0, 1)
+            G8_ISSUE(cB0, false, 0, 1)
+            G8P_MARK(g8p_base + 13)
+            G8_MFMA2T(1, (g8p_base ? 52 : 60), G8_ISSUE(cB1, false, 1, 1))
+            G8P_MARK(g8p_base + 14)
+        }
         if (++it_c < per_tile2) continue;
         // ================= tile finished: epilogue (the next tile's first K-tiles are in flight) =================
         it_c = 0;
+#ifdef IG_G8_PROF
+        g8p_on = blockIdx.x == 0 && g8p_tiles == 1;
+        G8P_MARK(32)
+#endif
         if (wr == 0) asm volatile("s_barrier" ::: "memory");  // re-align the groups: both epilogues run concurrently
         staggered = false;
+        G8P_MARK(33)
         const int bm = tile_c / tiles_n, bn = tile_c - bm * tiles_n;
         tile_c += nbx;
         if (!last) G8_LOAD_BIAS(tile_c)  // next tile's accumulator init: in flight during the epilogue
@@ -515,12 +551,21 @@ __global__ __launch_bounds__(128 * WC, 2) void gemm8_kernel(G8Params p) {
             }
 #undef G8_RESID_LOAD
         }
+#ifdef IG_G8_PROF
+        G8P_MARK(34)
+#if IG_G8_PROF == 1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        G8P_MARK(35)
+#endif
+        ++g8p_tiles;
+#endif
         G8_INIT_ACC()
     }
     if (staggered && wr == 0) asm volatile("s_barrier" ::: "memory");  // (unreachable in practice: every tile ends re-aligned)
 #undef G8_WAIT
 #undef G8_MFMA2
-#undef G8_MFMA
+#undef G8_MFMA2T
+#undef G8_WAITN
 #undef G8_READ_A
 #undef G8_READ_B
 #undef G8_ISSUE
@@ -555,13 +600,16 @@ int g8_launch_v(const G8Params& p, int grid, hipStream_t st) {
     return ig_check_launch("gemm8");
 }
 
-// small = the 128 x 128 instance (two workgroups per CU).  IG_G8_SCHED = 0 selects the 16-MFMA-phase schedule of the 256 x 256
-// instance (A/B runs); with -DIG_G8_ABLATE, IG_G8_DBG = 1..4 the timing ablations
+// small = the 128 x 128 instance (two workgroups per CU).  IG_G8_SCHED = 2 selects the round-2 placement of the LDS-DMA issues (A/B
+// runs); with -DIG_G8_ABLATE, IG_G8_DBG = 1..4 the timing ablations
 template <int KIND, int NSEG, int ACT, bool DACT, bool SPLIT_OUT>
 int g8_launch(const G8Params& p, int grid, hipStream_t st, bool small) {
-    if (small) return g8_launch_v<KIND, NSEG, ACT, DACT, SPLIT_OUT, 2, 0, 2, 2>(p, grid, st);
     const char* e = getenv("IG_G8_SCHED");
-    const int sched = e ? atoi(e) : 2;
+    const int sched = e ? atoi(e) : 4;
+    if (small) {
+        if (sched == 2) return g8_launch_v<KIND, NSEG, ACT, DACT, SPLIT_OUT, 2, 0, 2, 2>(p, grid, st);
+        return g8_launch_v<KIND, NSEG, ACT, DACT, SPLIT_OUT, 4, 0, 2, 2>(p, grid, st);
+    }
 #ifdef IG_G8_ABLATE
     if constexpr (KIND == 0 && NSEG == 1 && ACT == 0) {
         const char* d = getenv("IG_G8_DBG");
@@ -572,8 +620,8 @@ int g8_launch(const G8Params& p, int grid, hipStream_t st, bool small) {
         if (dbg == 4) return g8_launch_v<KIND, NSEG, ACT, DACT, SPLIT_OUT, 2, 4>(p, grid, st);
     }
 #endif
-    if (sched == 0) return g8_launch_v<KIND, NSEG, ACT, DACT, SPLIT_OUT, 0, 0>(p, grid, st);
-    return g8_launch_v<KIND, NSEG, ACT, DACT, SPLIT_OUT, 2, 0>(p, grid, st);
+    if (sched == 2) return g8_launch_v<KIND, NSEG, ACT, DACT, SPLIT_OUT, 2, 0>(p, grid, st);
+    return g8_launch_v<KIND, NSEG, ACT, DACT, SPLIT_OUT, 4, 0>(p, grid, st);
 }
 
 }  // namespace

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of the forward linear GEMM engines in ONE process (interleaved rounds, random data, HIP events):
-IG_GEMM8=0 (gemm2 / gemm5) vs IG_GEMM8=1 (gemm8.hip).  Usage: python tools/gemm8_bench.py [M] [--x3]"""
+the two placements of the LDS-DMA issues in gemm8.hip (IG_G8_SCHED=2 / 4; --old adds the round-1 engines).  Usage: python tools/gemm8_bench.py [M] [--x3]"""
 import os
 import statistics
 import sys
@@ -88,15 +88,18 @@ if "--v8-only" in sys.argv:  # profiling passes: a few launches of each case on 
             fn()
     torch.cuda.synchronize()
     sys.exit(0)
-VARIANTS = [("old", {"IG_GEMM8": "0"}), ("v8 s0", {"IG_GEMM8": "1", "IG_G8_SCHED": "0"}), ("v8 s2", {"IG_GEMM8": "1", "IG_G8_SCHED": "2"})]
-ABL = [("s2 noDMA", {"IG_GEMM8": "1", "IG_G8_DBG": "1"}), ("s2 noDMA noLDS", {"IG_GEMM8": "1", "IG_G8_DBG": "2"}),
-       ("s2 noDMA noLDS noBAR", {"IG_GEMM8": "1", "IG_G8_DBG": "3"}), ("s2 noEPI", {"IG_GEMM8": "1", "IG_G8_DBG": "4"})]
+VARIANTS = [("sched 2", {"IG_GEMM8": "1", "IG_G8_SCHED": "2"}), ("sched 4", {"IG_GEMM8": "1", "IG_G8_SCHED": "4"})]
+if "--old" in sys.argv:
+    VARIANTS = [("old", {"IG_GEMM8": "0"})] + VARIANTS
+KEYS = ("IG_GEMM8", "IG_G8_SCHED", "IG_G8_DBG")
+ABL = [("s2 noDMA", {"IG_GEMM8": "1", "IG_G8_SCHED": "2", "IG_G8_DBG": "1"}), ("s2 noDMA noLDS", {"IG_GEMM8": "1", "IG_G8_SCHED": "2", "IG_G8_DBG": "2"}),
+       ("s2 noDMA noLDS noBAR", {"IG_GEMM8": "1", "IG_G8_SCHED": "2", "IG_G8_DBG": "3"}), ("s2 noEPI", {"IG_GEMM8": "1", "IG_G8_SCHED": "2", "IG_G8_DBG": "4"})]
 for ci, (name, N, K, fn) in enumerate(cases):
     variants = VARIANTS + (ABL if (ci == 0 and not split and "--ablate" in sys.argv) else [])
     res = {v: [] for v, _ in variants}
     for rnd_i in range(5):
         for v, env in variants:
-            for k in ("IG_GEMM8", "IG_G8_SCHED", "IG_G8_DBG"):
+            for k in KEYS:
                 os.environ.pop(k, None)
             os.environ.update(env)
             if rnd_i == 0:
@@ -106,5 +109,5 @@ for ci, (name, N, K, fn) in enumerate(cases):
     fl = 2.0 * M * N * K * (3 if split else 1)
     line = f"{name:28s} N={N:5d} K={K:5d}: " + "   ".join(f"{v} {statistics.median(t):7.1f} us ({fl/statistics.median(t)/1e6:5.0f} TF/s)" for v, t in res.items())
     print(line)
-for k in ("IG_GEMM8", "IG_G8_SCHED", "IG_G8_DBG"):
+for k in KEYS:
     os.environ.pop(k, None)
