@@ -232,14 +232,23 @@ __global__ __launch_bounds__(128 * WC, 2) void conv8_kernel(C8Params p) {
         C8_ADVANCE(CUR, C8_REBASE_A(CUR, HF))                                                                       \
         (CUR).e = tab[(CUR).toff + (CUR).kt * 8 + sc];                                                               \
     }
-#define C8_ISSUE_B(CUR, BUFI)                                                                                  \
+    // B pieces of the cursor's K-tile into buffer BUFI in two parts (as gemm8.hip, schedule 4): part 0 in the read phase of big phase 2,
+    // part 1 behind that phase's MFMAs.  Only the 256-wide instances (two column halves of two pieces each) move their second half
+    // there: convT dgrad 768 -> 384 244 -> 217 us; with one piece to move (256 x 192: 24 MFMAs per phase) the tail made the instances
+    // 1-3 % slower, so they keep all of B in the read phase (same-box A/B of two builds, tools/head_bench.py).
+    constexpr bool B_TAIL = NT1 >= 2;
+#define C8_ISSUE_B(CUR, BUFI, PART)                                                                            \
     if ((CUR).i < my_tiles) {                                                                                  \
-        _Pragma("unroll") for (int i_ = 0; i_ < NT0; ++i_)                                                     \
-            c8_glds16_s((unsigned)(__mul24(min(bcol0[i_], (CUR).vr - 1), (CUR).ldb2) + c16), (CUR).base, ldsw_b0 + (BUFI)*BUF + i_ * 1024); \
-        _Pragma("unroll") for (int i_ = 0; i_ < NT1; ++i_)                                                     \
-            c8_glds16_s((unsigned)(__mul24(min(bcol1[i_], (CUR).vr - 1), (CUR).ldb2) + c16), (CUR).base, ldsw_b1 + (BUFI)*BUF + i_ * 1024); \
-        (CUR).base += 128;                                                                                     \
-        C8_ADVANCE(CUR, C8_REBASE_B(CUR))                                                                      \
+        if ((PART) == 0) {                                                                                     \
+            _Pragma("unroll") for (int i_ = 0; i_ < NT0; ++i_)                                                 \
+                c8_glds16_s((unsigned)(__mul24(min(bcol0[i_], (CUR).vr - 1), (CUR).ldb2) + c16), (CUR).base, ldsw_b0 + (BUFI)*BUF + i_ * 1024); \
+        }                                                                                                      \
+        if ((PART) == (B_TAIL ? 1 : 0)) {                                                                      \
+            _Pragma("unroll") for (int i_ = 0; i_ < NT1; ++i_)                                                 \
+                c8_glds16_s((unsigned)(__mul24(min(bcol1[i_], (CUR).vr - 1), (CUR).ldb2) + c16), (CUR).base, ldsw_b1 + (BUFI)*BUF + i_ * 1024); \
+            (CUR).base += 128;                                                                                 \
+            C8_ADVANCE(CUR, C8_REBASE_B(CUR))                                                                  \
+        }                                                                                                      \
     }
 
     f32x4 acc[2][NTW][MT];  // [h][nt][mt]
@@ -263,10 +272,12 @@ __global__ __launch_bounds__(128 * WC, 2) void conv8_kernel(C8Params p) {
     cA0.e = tab[cA0.toff + sc];
     cA1.e = cA0.e;
     C8_ISSUE_A(cA0, 0, 0)
-    C8_ISSUE_B(cB, 0)
+    C8_ISSUE_B(cB, 0, 0)
+    C8_ISSUE_B(cB, 0, 1)
     C8_ISSUE_A(cA1, 1, 0)
     C8_ISSUE_A(cA0, 0, 1)
-    C8_ISSUE_B(cB, 1)
+    C8_ISSUE_B(cB, 1, 0)
+    C8_ISSUE_B(cB, 1, 1)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW - AI) : "memory");
     asm volatile("s_barrier" ::: "memory");
 
@@ -280,7 +291,7 @@ __global__ __launch_bounds__(128 * WC, 2) void conv8_kernel(C8Params p) {
             smem + (BUFI)*BUF + (nt_ < NT0 ? nt_ * 2048 + (boff0 ^ (s_ * 64)) : (nt_ - NT0) * 2048 + (boff1 ^ (s_ * 64))));
     // one "big phase": all MFMAs of A half H between one barrier pair; the reads were retired BEFORE the first barrier
     // (lgkmcnt(0)), so a half-tile may be refilled in the very next phase
-#define C8_MFMA(HF)                                                                                             \
+#define C8_MFMA(HF, TAIL)                                                                                       \
     {                                                                                                           \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
         asm volatile("s_barrier" ::: "memory");                                                                 \
@@ -289,12 +300,16 @@ __global__ __launch_bounds__(128 * WC, 2) void conv8_kernel(C8Params p) {
             _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                    \
                 acc[HF][nt_][mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt_][s_], af[mt_][s_], acc[HF][nt_][mt_], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                          \
+        TAIL                                                                                                    \
         asm volatile("s_barrier" ::: "memory");                                                                 \
     }
-#define C8_WAIT(LASTCNT)                                                                     \
+    // B_TAIL instances: the wait stands BEFORE its phase's issues: R1 retires A1(t) with the AI + NT0 + NT1 younger operations of
+    // A0 B (t + 1) in flight, R2 retires A0 B (t + 1) with the AI of A1(t + 1); last iteration: VMW - AI, AI, 0, 0.  The others keep the
+    // round-4 order (issue, then wait with VMW operations in flight; last iteration: VMW, AI, 0, 0).
+#define C8_WAIT(CNT, LASTCNT)                                                                \
     {                                                                                        \
         if (last) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LASTCNT) : "memory");             \
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");                      \
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory");                      \
     }
 
     int it_c = 0;  // iterations (K-tile pairs) done of the current tile
@@ -308,28 +323,32 @@ __global__ __launch_bounds__(128 * WC, 2) void conv8_kernel(C8Params p) {
             if (wr == 1) asm volatile("s_barrier" ::: "memory");
             staggered = true;
         }
-        // two big phases per K-tile: BP1 reads A0 B0 B1 + issues A1 of the next K-tile; BP2 reads A1 + issues A0 B0 B1 of
-        // K-tile + 2 into the slots BP1 has just retired
+        // two big phases per K-tile: BP1 reads A0 B0 B1 + issues A1 of the next K-tile; BP2 reads A1 + issues A0 and the first part of B of
+        // K-tile + 2 into the slots BP1 has just retired, the second part of B behind its MFMAs (the read phases bound the intervals)
         C8_READ_B(0)
         C8_READ_A(0, 0)
+        if constexpr (B_TAIL) C8_WAIT(VMW - AI, VMW - AI)
         C8_ISSUE_A(cA1, 1, 1)
-        C8_WAIT(VMW)
-        C8_MFMA(0)
+        if constexpr (!B_TAIL) C8_WAIT(VMW, VMW)
+        C8_MFMA(0, )
         C8_READ_A(0, 1)
+        if constexpr (B_TAIL) C8_WAIT(AI, AI)
         C8_ISSUE_A(cA0, 0, 0)
-        C8_ISSUE_B(cB, 0)
-        C8_WAIT(AI)
-        C8_MFMA(1)
+        C8_ISSUE_B(cB, 0, 0)
+        if constexpr (!B_TAIL) C8_WAIT(VMW, AI)
+        C8_MFMA(1, C8_ISSUE_B(cB, 0, 1))
         C8_READ_B(1)
         C8_READ_A(1, 0)
+        if constexpr (B_TAIL) C8_WAIT(VMW - AI, 0)
         C8_ISSUE_A(cA1, 1, 0)
-        C8_WAIT(0)
-        C8_MFMA(0)
+        if constexpr (!B_TAIL) C8_WAIT(VMW, 0)
+        C8_MFMA(0, )
         C8_READ_A(1, 1)
+        if constexpr (B_TAIL) C8_WAIT(AI, 0)
         C8_ISSUE_A(cA0, 0, 1)
-        C8_ISSUE_B(cB, 1)
-        C8_WAIT(0)
-        C8_MFMA(1)
+        C8_ISSUE_B(cB, 1, 0)
+        if constexpr (!B_TAIL) C8_WAIT(VMW, 0)
+        C8_MFMA(1, C8_ISSUE_B(cB, 1, 1))
         if (++it_c < per_tile2) continue;
         // ================= tile finished: epilogue (the next tile's first K-tiles are in flight) =================
         it_c = 0;

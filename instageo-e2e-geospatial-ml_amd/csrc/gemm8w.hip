@@ -27,8 +27,8 @@
 //   arguments, so a plan depends on shapes only (bounded cache, no device allocation per pointer set).
 // * Deterministic: every segment stores its fp32 partial tile to its own slab in the accumulator's own (lane-linear) layout
 //   -- 16-byte coalesced stores, no LDS staging -- and wgrad8_reduce_kernel adds a tile's slabs in slab order.
-// * Same barrier / vmcnt protocol as gemm8_kernel (SCHED 2): two big phases per K-tile, the two row groups one
-//   barrier apart, counted vmcnt(8), a half-tile refilled the phase after its last read was retired.
+// * Same barrier / vmcnt protocol as gemm8_kernel (SCHED 4): two big phases per K-tile, the two row groups one
+//   barrier apart, counted vmcnt(6) / vmcnt(2) in front of the issues, the second B half issued behind the MFMAs of big phase 2.
 #include <stdlib.h>
 #include <string.h>
 
@@ -289,36 +289,29 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
         }
         if (advance(C)) rebaseA(C, R, hg, pseg);
     };
-    // both B halves of the cursor's K-tile into buffer buf
-    auto issueB = [&](WCur& C, WRows& R, int buf, int& pseg) {
+    // B half g of the cursor's K-tile into buffer buf; the cursor advances behind half 1 (the halves of a K-tile are issued in two
+    // different phases: half 0 in the read phase of big phase 2, half 1 behind that phase's MFMAs -- see the main loop)
+    auto issueB = [&](WCur& C, WRows& R, int buf, int& pseg, int g) {
         if (C.left <= 0) return;
-        const unsigned dst = ldsw + buf * W_BUF + 2 * W_HALF;
+        const unsigned dst = ldsw + buf * W_BUF + 2 * W_HALF + g * W_HALF;
         if constexpr (MODE == 1) {
             const i32x4 rs = (NSEG == 3 && pseg) ? rs_lo : rs_hi;
             // source pixel of token p = (b, y, x): p itself (sm = 1), or (b, 2y, 2x) of the (2H, 2W) image = 4 p - 2 x (ConvTranspose, sm = 2):
             // shifts and one 32-bit multiply per row (the per-half work is two adds, two compares, a select)
             const int sh = cv.sm - 1, Hs = cv.H << sh, Ws = cv.W << sh;
-            unsigned rowb[2];
-            int ysh[2], xsh[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                ysh[i] = R.y[i] << sh, xsh[i] = R.x[i] << sh;
-                rowb[i] = (unsigned)(((R.p[i] << (2 * sh)) - (xsh[i] & -sh)) * C2g);
+                const int ysh = R.y[i] << sh, xsh = R.x[i] << sh;
+                const unsigned rowb = (unsigned)(((R.p[i] << (2 * sh)) - (xsh & -sh)) * C2g);
+                const bool v = okB[g] & (R.p[i] < cv.M) & ((unsigned)(ysh + dyB[g]) < (unsigned)Hs) & ((unsigned)(xsh + dxB[g]) < (unsigned)Ws);
+                const unsigned voff = v ? rowb + (unsigned)shB[g] : 0x80000000u;
+                w_blds(voff, rs, dst + i * 1024);
             }
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const bool v = okB[g] & (R.p[i] < cv.M) & ((unsigned)(ysh[i] + dyB[g]) < (unsigned)Hs) & ((unsigned)(xsh[i] + dxB[g]) < (unsigned)Ws);
-                    const unsigned voff = v ? rowb[i] + (unsigned)shB[g] : 0x80000000u;
-                    w_blds(voff, rs, dst + g * W_HALF + i * 1024);
-                }
-            W_ADVANCE_ROWS(R)
+            if (g == 1) W_ADVANCE_ROWS(R)
         } else {
-            issue_plain(C, dst, 0, okB[0]);
-            issue_plain(C, dst + W_HALF, 256, okB[1]);
+            issue_plain(C, dst, g * 256, okB[g]);
         }
-        if (advance(C)) rebaseB(C, R, pseg);
+        if (g == 1 && advance(C)) rebaseB(C, R, pseg);
     };
 
     f32x4 acc[2][NTW][MT];  // [h][nt][mt]
@@ -335,10 +328,12 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
     rebaseA(cA1, rA1, 1, psegA1);
     rebaseB(cB, rB, psegB);
     issueA(cA0, rA0, 0, 0, psegA0);
-    issueB(cB, rB, 0, psegB);
+    issueB(cB, rB, 0, psegB, 0);
+    issueB(cB, rB, 0, psegB, 1);
     issueA(cA1, rA1, 1, 0, psegA1);
     issueA(cA0, rA0, 0, 1, psegA0);
-    issueB(cB, rB, 1, psegB);
+    issueB(cB, rB, 1, psegB, 0);
+    issueB(cB, rB, 1, psegB, 1);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
 
@@ -358,7 +353,8 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
     _Pragma("unroll") for (int nt_ = 0; nt_ < NTW; ++nt_) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)        \
         W_TR(bfr[nt_][s_], (BUF)*W_BUF + s_ * 8192 + W_BOFF(nt_))
     // "big phase": all MFMAs of one A half between one barrier pair; reads are retired BEFORE the first barrier
-#define W_MFMA2(H)                                                                                                \
+    // TAIL: LDS-DMA issues of this wave placed behind its MFMAs (as gemm8.hip, schedule 4: the read phases bound the intervals)
+#define W_MFMA2(H, TAIL)                                                                                          \
     {                                                                                                             \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
         asm volatile("s_barrier" ::: "memory");                                                                   \
@@ -367,12 +363,15 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
             _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                      \
                 acc[H][nt_][mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt_][s_], af[mt_][s_], acc[H][nt_][mt_], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                            \
+        TAIL                                                                                                      \
         asm volatile("s_barrier" ::: "memory");                                                                   \
     }
-#define W_WAIT(LASTCNT)                                                          \
+    // the wait stands BEFORE its phase's issues: R1 retires A1(t) with the 6 younger operations A0 B.0 (R2) B.1 (M2 tail) of K-tile t + 1
+    // in flight, R2 retires A0 B (t + 1) with the 2 of A1(t + 1); last iteration: 6 2 0 0
+#define W_WAIT(CNT, LASTCNT)                                                     \
     {                                                                            \
         if (last) asm volatile("s_waitcnt vmcnt(" #LASTCNT ")" ::: "memory");    \
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                    \
+        else asm volatile("s_waitcnt vmcnt(" #CNT ")" ::: "memory");             \
     }
 
     int cseg = 0, it_c = 0;
@@ -387,24 +386,24 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
         }
         W_READ_B(0)
         W_READ_A(0, 0)
+        W_WAIT(6, 6)
         issueA(cA1, rA1, 1, 1, psegA1);
-        W_WAIT(8)
-        W_MFMA2(0)
+        W_MFMA2(0, )
         W_READ_A(0, 1)
+        W_WAIT(2, 2)
         issueA(cA0, rA0, 0, 0, psegA0);
-        issueB(cB, rB, 0, psegB);
-        W_WAIT(2)
-        W_MFMA2(1)
+        issueB(cB, rB, 0, psegB, 0);
+        W_MFMA2(1, issueB(cB, rB, 0, psegB, 1);)
         W_READ_B(1)
         W_READ_A(1, 0)
+        W_WAIT(6, 0)
         issueA(cA1, rA1, 1, 0, psegA1);
-        W_WAIT(0)
-        W_MFMA2(0)
+        W_MFMA2(0, )
         W_READ_A(1, 1)
+        W_WAIT(2, 0)
         issueA(cA0, rA0, 0, 1, psegA0);
-        issueB(cB, rB, 1, psegB);
-        W_WAIT(0)
-        W_MFMA2(1)
+        issueB(cB, rB, 1, psegB, 0);
+        W_MFMA2(1, issueB(cB, rB, 1, psegB, 1);)
         if (++it_c < seg_iters) continue;
         // ===== segment finished: store the partial tile (the next segment's first K-tiles are in flight) =====
         it_c = 0;

@@ -17,8 +17,10 @@ Design
 """
 from __future__ import annotations
 
+import itertools
 import math
 import os
+import weakref
 from dataclasses import dataclass
 from typing import Any, Callable, Dict, List, Optional, Tuple
 
@@ -825,31 +827,17 @@ class SegEngine:
 # --------------------------------------------------------------------------------------------------
 # autograd bridge + nn.Module with the reference's contract
 # --------------------------------------------------------------------------------------------------
-class _SegFunction(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, img, module, *params):
-        ctx.module = module
-        eng = module.engine
-        logits = eng.forward(img, module.training, save=True)
-        ctx.n = len(params)
-        ctx.generation = eng._generation
-        return logits
+# ``torch.ops.instageo_mi355x.prithvi_seg`` (torch_ops.py) finds the network behind an integer handle: a custom op takes tensors and
+# scalars only.  Weak references: a handle dies with its module.
+_NETWORKS: "weakref.WeakValueDictionary[int, PrithviSeg]" = weakref.WeakValueDictionary()
+_HANDLES = itertools.count(1)
 
-    @staticmethod
-    def backward(ctx, dlogits):
-        module = ctx.module
-        eng = module.engine
-        store = module.store
-        g = store.ensure_grad()
-        g.zero_()
-        eng.backward(dlogits.contiguous().float(), generation=ctx.generation)
-        grads = []
-        for name, p in module._flat_params():
-            if p.requires_grad:
-                grads.append(store.entries[name].api_view(g).clone())
-            else:
-                grads.append(None)
-        return (None, None, *grads)
+
+def network_of(handle: int) -> "PrithviSeg":
+    net = _NETWORKS.get(int(handle))
+    if net is None:
+        raise RuntimeError(f"instageo_mi355x::prithvi_seg: no live PrithviSeg behind handle {handle}")
+    return net
 
 
 class _Holder(nn.Module):
@@ -896,6 +884,8 @@ class PrithviSeg(nn.Module):
         }  # fmt: skip
         self._build_tree()
         self.engine = SegEngine(cfg, self.store, self._buffers_flat, precision)
+        self._handle = next(_HANDLES)
+        _NETWORKS[self._handle] = self
         self.reset_parameters()
         if load_pretrained_weights:
             raise RuntimeError(
@@ -1053,19 +1043,24 @@ class PrithviSeg(nn.Module):
 
     # ---- forward -------------------------------------------------------------------------------
     def forward(self, img: torch.Tensor, return_features: bool = False):
-        """(B,C,T,H,W) [or (B,C,H,W) if T==1] -> logits (B,num_classes,H,W) [, features (B,D*T,14,14)]."""
+        """(B,C,T,H,W) [or (B,C,H,W) if T==1] -> logits (B,num_classes,H,W) [, features (B,D*T,14,14)].
+
+        The whole network is ONE dispatcher op, ``torch.ops.instageo_mi355x.prithvi_seg`` (torch_ops.py: CUDA/HIP implementation = the
+        engine's forward, ``register_autograd`` backward = the engine's backward through ``prithvi_seg_backward``, a fake
+        implementation for tracing), so the module sits behind a PyTorch custom op (north_star; base.py:28,69-77, model.py:392-419) and
+        ``torch.compile(net, fullgraph=True)`` captures one node.  The parameters are passed as a tensor list -- autograd sees the
+        dependence and ``loss.backward()`` fills ``p.grad`` -- and the activations stay in the engine's workspaces."""
+        if not img.is_cuda:
+            raise ops._lib.HipLibraryError("PrithviSeg.forward needs a HIP device tensor: instageo_amd has no CPU path")
+        from . import torch_ops
+
+        torch_ops.register()
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        if needs_grad:
-            # foreign optimizers write into the fp32 views directly: always refresh the bf16 operands
-            self.engine.mark_params_changed()
-            params = [p for _, p in self._flat_params()]
-            out = _SegFunction.apply(img, self, *params)
-        else:
-            self.engine.mark_params_changed()
-            out = self.engine.forward(img, self.training, save=return_features, update_running=True)
+        params = [p for _, p in self._flat_params()]
+        logits, feats = torch.ops.instageo_mi355x.prithvi_seg(img, params, self._handle, self.training, needs_grad, return_features)
         if return_features:
-            return out, self.engine.features_nchw()
-        return out
+            return logits, feats
+        return logits
 
 
 def load_prithvi_checkpoint(model: PrithviSeg, state_dict: Dict[str, torch.Tensor], pretrained_bands: Optional[List[int]] = None,

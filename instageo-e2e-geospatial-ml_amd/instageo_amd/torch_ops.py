@@ -11,9 +11,11 @@ source of truth -- the schemas below are GENERATED from its prototypes):
   the dispatcher, ``torch.compile`` graphs (as opaque mutating calls) and ``torch.library.opcheck``.
 * **functional, differentiable ops** for the Block linears and LayerNorm with ``torch.library.register_autograd``:
   ``linear(x, w, bias, act)``, ``layer_norm(x, gamma, beta, eps)`` -- bf16 activations/weights, fp32 residual-stream input for
-  LayerNorm -- whose backward formulas call the dgrad / wgrad / layernorm_bwd raw ops.  The whole-network autograd bridge of
-  ``PrithviSeg.forward`` (:class:`instageo_amd.model._SegFunction`) stays the product path: it keeps activations in the
-  engine's workspaces instead of autograd-saved tensors.
+  LayerNorm -- whose backward formulas call the dgrad / wgrad / layernorm_bwd raw ops.
+* **the whole network as one op**: ``prithvi_seg(img, params[], handle, training, save, features) -> (logits, features)`` with
+  ``prithvi_seg_backward`` behind ``register_autograd`` -- what ``PrithviSeg.forward`` dispatches through (model.py).  The engine
+  (workspaces, saved activations, BatchNorm running statistics) is found through the integer ``handle``; the parameters travel as a
+  tensor list so that autograd sees the dependence.
 
 There is no CPU implementation: the ops are registered for the CUDA (HIP) dispatch key only.
 """
@@ -108,6 +110,7 @@ def register() -> Dict[str, str]:
         torch.library.register_fake(f"{NAMESPACE}::{op}", lambda *a, **k: None, lib=lib)
         RAW_OPS[op] = schema
     _register_functional(lib)
+    _register_network(lib)
     _LIBRARY = lib
     return RAW_OPS
 
@@ -215,3 +218,67 @@ def _register_functional(lib: torch.library.Library) -> None:
         return dx, dg, db, None
 
     torch.library.register_autograd(f"{NAMESPACE}::layer_norm", ln_bwd, setup_context=ln_setup, lib=lib)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the whole network as one op (PrithviSeg.forward dispatches through it)
+# ---------------------------------------------------------------------------------------------------------------------
+def _register_network(lib: torch.library.Library) -> None:
+    from . import model as M
+
+    ns = torch.ops.instageo_mi355x
+    # img (B, C, T, H, W) f32 [or (B, C, H, W) when T == 1]; params: the module's parameters in flat (= forward) order -- read through
+    # the engine's own flat buffer, listed here for autograd; handle: model.network_of; training: BatchNorm batch statistics + dropout
+    # (nn.Module.train()); save: keep the activations for prithvi_seg_backward; features: also return reshaped_features (B, D*T, 14, 14)
+    # (an empty tensor otherwise).  Hidden state behind the handle: workspaces, the saved activations of the latest save=True call,
+    # the BatchNorm running statistics (updated when training), the dropout counter.
+    lib.define("prithvi_seg(Tensor img, Tensor[] params, int handle, bool training, bool save, bool features) -> (Tensor, Tensor)")
+
+    def seg_impl(img, params, handle, training, save, features):
+        net = M.network_of(handle)
+        eng = net.engine
+        eng.mark_params_changed()  # foreign optimizers write into the fp32 views directly: always refresh the bf16 operands
+        logits = eng.forward(img, training, save=save or features, update_running=True)
+        feats = eng.features_nchw() if features else logits.new_empty((0,))
+        return logits, feats
+
+    lib.impl("prithvi_seg", seg_impl, "CUDA")
+
+    def seg_fake(img, params, handle, training, save, features):
+        net = M.network_of(handle)
+        cfg = net.engine.geometry(int(img.shape[-1]))
+        B = img.shape[0]
+        logits = img.new_empty((B, cfg.num_classes, cfg.out_size, cfg.out_size), dtype=torch.float32)
+        shape = (B, cfg.embed_dim * cfg.num_frames, cfg.grid, cfg.grid) if features else (0,)
+        return logits, img.new_empty(shape, dtype=torch.float32)
+
+    torch.library.register_fake(f"{NAMESPACE}::prithvi_seg", seg_fake, lib=lib)
+
+    # gradients of the parameters for an upstream dlogits, from the activations the forward call of ``generation`` saved; an empty
+    # tensor for a parameter that does not require a gradient
+    lib.define("prithvi_seg_backward(Tensor dlogits, Tensor[] params, int handle, int generation) -> Tensor[]")
+
+    def seg_bwd_impl(dlogits, params, handle, generation):
+        net = M.network_of(handle)
+        eng, store = net.engine, net.store
+        g = store.ensure_grad()
+        g.zero_()
+        eng.backward(dlogits.contiguous().float(), generation=generation)
+        return [store.entries[name].api_view(g).clone() if p.requires_grad else p.new_empty((0,)) for name, p in net._flat_params()]
+
+    lib.impl("prithvi_seg_backward", seg_bwd_impl, "CUDA")
+    torch.library.register_fake(
+        f"{NAMESPACE}::prithvi_seg_backward",
+        lambda dlogits, params, handle, generation: [p.new_empty(p.shape if p.requires_grad else (0,)) for p in params], lib=lib)
+
+    def seg_setup(ctx, inputs, output):
+        img, params, handle, training, save, features = inputs
+        ctx.handle, ctx.generation = handle, M.network_of(handle).engine._generation
+        ctx.req = [p.requires_grad for p in params]
+        ctx.save_for_backward(*params)
+
+    def seg_bwd(ctx, dlogits, _dfeats):
+        grads = ns.prithvi_seg_backward(dlogits, list(ctx.saved_tensors), ctx.handle, ctx.generation)
+        return None, [g if r else None for g, r in zip(grads, ctx.req)], None, None, None, None
+
+    torch.library.register_autograd(f"{NAMESPACE}::prithvi_seg", seg_bwd, setup_context=seg_setup, lib=lib)

@@ -284,3 +284,35 @@ def test_block_gradient_range_tables_partition_the_flat_buffer(variant):
     tiles.append((ent[e + "cls_token"].offset, starts[0]))
     tiles.sort()
     assert tiles[0][0] == 0 and tiles[-1][1] == eng.store.total and all(a[1] == b[0] for a, b in zip(tiles, tiles[1:]))
+
+
+def test_whole_network_custom_op_is_registered_with_a_fake_implementation():
+    """``instageo_mi355x::prithvi_seg`` (torch_ops.py): schema, fake (meta) shapes of logits / features, and no CPU kernel --
+    ``PrithviSeg.forward`` dispatches through it (checked on the GPU by tests/test_gpu_model.py)."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+
+    from instageo_amd import torch_ops
+    from instageo_amd.model import PrithviSeg
+
+    torch_ops.register()
+    op = torch.ops.instageo_mi355x.prithvi_seg
+    assert "Tensor[] params" in str(op.default._schema) and "int handle" in str(op.default._schema)
+    net = PrithviSeg(variant="prithvi_eo_tiny", temporal_step=3, num_classes=13, load_pretrained_weights=False, device="cpu")
+    with FakeTensorMode():
+        img = torch.empty(2, 6, 3, 224, 224)
+        ps = [torch.empty(p.shape) for _, p in net._flat_params()]
+        logits, feats = op(img, ps, net._handle, False, False, True)
+        assert logits.shape == (2, 13, 224, 224) and feats.shape == (2, 256 * 3, 14, 14)
+        grads = torch.ops.instageo_mi355x.prithvi_seg_backward(logits, ps, net._handle, 1)
+        assert len(grads) == len(ps)
+    with pytest.raises(NotImplementedError):  # no CPU backend
+        op(torch.zeros(1, 6, 3, 224, 224), [p.detach() for _, p in net._flat_params()], net._handle, False, False, False)
+    handle = net._handle
+    del net
+    import gc
+
+    gc.collect()
+    with pytest.raises(RuntimeError):
+        from instageo_amd.model import network_of
+
+        network_of(handle)
