@@ -606,10 +606,9 @@ template <int KIND, int NSEG, int ACT, bool DACT, bool SPLIT_OUT>
 int g8_launch(const G8Params& p, int grid, hipStream_t st, bool small) {
     const char* e = getenv("IG_G8_SCHED");
     const int sched = e ? atoi(e) : 4;
-    if (small) {
-        if (sched == 2) return g8_launch_v<KIND, NSEG, ACT, DACT, SPLIT_OUT, 2, 0, 2, 2>(p, grid, st);
-        return g8_launch_v<KIND, NSEG, ACT, DACT, SPLIT_OUT, 4, 0, 2, 2>(p, grid, st);
-    }
+    // the 128 x 128 instance (16 MFMAs per big phase, two workgroups per CU) keeps the round-2 placement: with schedule 4 its launches
+    // were 9-10 % slower in the B = 16 step (profiles/r05_configs/step_b16_sched4_small_instance.txt: 24.8 -> 27.2 us)
+    if (small) return g8_launch_v<KIND, NSEG, ACT, DACT, SPLIT_OUT, 2, 0, 2, 2>(p, grid, st);
 #ifdef IG_G8_ABLATE
     if constexpr (KIND == 0 && NSEG == 1 && ACT == 0) {
         const char* d = getenv("IG_G8_DBG");

@@ -71,6 +71,12 @@ def _worker(rank, world, port, q, backend="gloo", mode="zero1", force=False):
         for _ in range(2):
             mod.fused_train_step(x, y)
         torch.cuda.synchronize()
+        if mode == "zero1":
+            # the all-gathers of the operand copy are left in flight for the next forward pass to wait for, Block by Block
+            # (engine.param_wait); a reader of the copy outside the engine waits for them itself
+            deferred = len(sync._pending)
+            assert world == 1 or os.environ.get("IG_DP_DEFER") == "0" or deferred > 0
+            sync.wait_params()
         sh = mod.net.store.shadow
         shadow_sum = float(sh.hi.float().double().sum().item() + (0.0 if sh.lo is None else sh.lo.float().double().sum().item()))
         if mode == "zero1":
