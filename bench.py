@@ -224,6 +224,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-leg", action="store_true", help="skip the bf16x3 (1e-3-parity) leg")
     ap.add_argument("--no-tile", action="store_true", help="skip the configs[3] sliding-window leg")
+    ap.add_argument("--no-yaml-legs", action="store_true", help="N = 1: skip the legs at the reference YAMLs' batches (16; T = 3: 8) and the T = 3 / batch 72 leg")
     ap.add_argument("--no-t3-leg", action="store_true", help="N > 1: skip the T = 3 / 13-class leg (the shape the scaling target is stated on)")
     ap.add_argument("--t3-batch", type=int, default=72, help="per-GPU batch of the T = 3 leg (72 x 589 tokens = 166 row tiles of 256, the same fill "
                     "of the tile rounds as the default T = 1 batch: +5.7 %% chips/s over 36 on the same box)")
@@ -519,6 +520,28 @@ def main() -> None:
             t3_leg = {"error": f"{e.__class__.__name__}: {e}"[:300], "value": None, "ms_per_step": None}
         torch.cuda.empty_cache()
 
+    # N = 1, headline configuration: the reference YAMLs' own per-GPU batches (configs/sen1floods11.yaml:13 batch_size 16;
+    # multitemporal_crop_classification.yaml:14 batch_size 8, T = 3 / 13 classes) and configs[2]'s shape at the batch that fills the
+    # tile rounds (72) as extra, short legs -- SURVEY 8(d) cfg 2: "bs 16 and the largest B that fits" -- so that the small-batch numbers
+    # are driver-observed
+    yaml_legs = {}
+    if not dp and (T, NCLS, args.model) == (1, 2, "prithvi_eo_v1_100") and args.precision == "bf16" and not args.no_yaml_legs and not args.graph:
+        main_res.pop("mod", None)
+        mod = None
+        torch.cuda.empty_cache()
+        for key, (b_, t_, c_) in {"yaml_b16": (16, 1, 2), "yaml_t3_b8": (8, 3, 13), "t3_b72": (args.t3_batch, 3, 13)}.items():
+            try:  # an extra leg must never cost the headline line
+                wl_ = make_workload(b_, t_, c_)
+                r_ = run_mode(args.precision, False, False, wl_)
+                r_.pop("mod")
+                yaml_legs[key] = {"per_gpu_batch": b_, "temporal": t_, "classes": c_, "value": round(b_ * args.steps / r_["dt"], 1), "unit": "chips/s",
+                                  "ms_per_step": round(1e3 * r_["dt"] / args.steps, 3), "inference_chips_per_s": round(b_ * args.steps / r_["dti"], 1),
+                                  "encoder_fwd_ms": round(r_["enc_ms"], 3)}
+                del wl_, r_
+            except Exception as e:  # noqa: BLE001
+                yaml_legs[key] = {"error": f"{e.__class__.__name__}: {e}"[:300], "value": None}
+            torch.cuda.empty_cache()
+
     if rank != 0:
         if dp:
             dist.destroy_process_group()
@@ -529,7 +552,7 @@ def main() -> None:
     headline = (T, NCLS, args.model) == (1, 2, "prithvi_eo_v1_100")
     enc_tflops = B * fpc_enc / (main_res["enc_ms"] * 1e-3) / 1e12
     cfg_out = {"workload": "BASELINE.json configs[1]: Prithvi-100M fine-tune, Sen1Floods11-shaped synthetic int16 chips (6 bands, T=1, "
-                           "224x224, 2 classes, class_weights [1,3], ignore -1, dropout 0.1), random init" if headline else
+                           "224x224, 2 classes, weights [1,3], ignore -1, dropout 0.1)" if headline else
                            f"{args.model} T={T} {NCLS} classes, synthetic int16 chips, dropout 0.1, random init",
                "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                "launch": "hipGraph" if main_res["graphed"] else "eager",
@@ -554,6 +577,10 @@ def main() -> None:
             "encoder_fwd_ms": round(parity["enc_ms"], 3), "final_loss": round(parity["loss"], 5),
             "note": "same workload, batch and step; split-bf16 operands (hi*hi + hi*lo + lo*hi, 3 MFMAs per product: ceiling = "
                     "peak / 3); this mode meets the north-star 1e-3 logits / mIoU tolerance (tests/test_gpu_model.py)"}  # fmt: skip
+    for key, leg in yaml_legs.items():
+        cfg_out[key + "_chips_per_s"] = leg["value"]
+    if yaml_legs:
+        detail["yaml_batch_legs"] = yaml_legs
     if tile_leg is not None:
         cfg_out["tile_windows_per_s"] = tile_leg["value"]
         cfg_out["tile_windows_per_s_per_gpu"] = tile_leg["per_gpu_windows_per_s"]
@@ -632,9 +659,7 @@ def main() -> None:
                                "sample": f"oracle train steps (fwd+CE+bwd+AdamW), batch 4, Prithvi-100M T=1 fp32, {cb['cores']} of {cb['host_cores']} host cores",
                                "host_cores": cb["host_cores"], "forward_configs0_chips_per_s": cb["forward_configs0"]["value"],
                                "forward_configs0_all_cores": (cb.get("all_cores") or {}).get("forward_configs0_chips_per_s"),
-                               "all_cores_upper_bound": (cb.get("all_cores") or {}).get("upper_bound_chips_per_s"),
-                               "forward_configs0_thread_sweep": {str(cb["cores"]): cb["forward_configs0"]["value"],
-                                                                 **{k[8:]: (cb.get(k) or {}).get("forward_configs0_chips_per_s") for k in ("threads_8", "threads_32", "threads_64")}}}  # fmt: skip
+                               "all_cores_upper_bound": (cb.get("all_cores") or {}).get("upper_bound_chips_per_s")}  # (thread sweep: detail file)
     path = args.detail_file or os.path.join(ROOT, "profiles", f"bench_detail_n{world}_b{B}_{args.model}_t{T}.json")
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)

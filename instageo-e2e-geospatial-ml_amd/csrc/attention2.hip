@@ -844,218 +844,12 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_fused_kernel(const bf16_
     }
 }
 
-// Second form of the single-pass backward (round 4): the waves EXCHANGE their bf16 dS^T tiles instead of folding fp32 dQ partials into an
-// LDS image.  A wave still owns 32 keys (dK, dV in registers) and in step s works on query tile (wave + s) mod 7; its dS^T tile goes to a
-// double-buffered slab, and after the step's barrier wave w -- the owner of QUERY tile w -- multiplies the tile that key block
-// (w - s) mod 7 has just produced for it with that block's K^T fragments (read from the K image, which now stays resident) into dQ
-// accumulators that live in its registers.  Per wave and step the LDS traffic drops from ~60 KB to ~34 KB (the read-modify-write of an
-// 8 KB fp32 dQ tile was half of it), the 57 KB fp32 image and the final image -> bf16 pass are gone (LDS 135 -> 117 KB).
-// MEASURED: no faster than the image form (same box, B = 108: 135-137 us against 134-139 us; whole step at B = 216 45.32 against 45.40
-// ms) -- the step is not bound by LDS bandwidth but by the dependent chain MFMA -> exp -> pack -> MFMA of a wave's tile at two waves per
-// SIMD; two workgroups per CU would need <= 80 KB and the three images alone are 84 KB.  Kept as an A/B variant (IG_ATTN2_FUSED=2).
-constexpr int A2G_OFF_SLAB = 3 * A2_TILE;                                 // [2 buffers][7 waves] dS slabs behind the Q, dO, K images
-constexpr int A2G_OFF_LSE = A2G_OFF_SLAB + 2 * A2_WAVES * A2F_SLAB;
-constexpr int A2G_SMEM = A2G_OFF_LSE + 2 * A2_CH * 4;
-__global__ __launch_bounds__(A2_THREADS) void attn2_bwd_fused2_kernel(const bf16_t* __restrict__ qkv_hi, const bf16_t* __restrict__ do_hi,
-                                                                     const bf16_t* __restrict__ o_hi, const float* __restrict__ lse,
-                                                                     float* __restrict__ delta, bf16_t* __restrict__ dqkv_hi, int N, int H,
-                                                                     float scale, float* __restrict__ dbias) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* q_img = smem;
-    char* d_img = smem + A2_TILE;
-    char* k_img = smem + A2F_OFF_K;
-    float* s_lse = reinterpret_cast<float*>(smem + A2G_OFF_LSE);
-    float* s_del = s_lse + A2_CH;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    char* slabs = smem + A2G_OFF_SLAB;  // [buffer][wave]: dS^T tiles, exchanged between the waves
-    const int lr = lane & 31, lh = lane >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const long RS = 3L * H * 64, OS = (long)H * 64;
-    const bf16_t* base = qkv_hi + (long)b * N * RS + h * 64;
-    const bf16_t* dob = do_hi + (long)b * N * OS + h * 64;
-    const bf16_t* ob = o_hi + (long)b * N * OS + h * 64;
-    const int k0 = wave * 32;
-    const bool active = k0 < N;
-    const int key = k0 + lr, kr = min(key, N - 1);
-    const unsigned lds_base = (unsigned)(uintptr_t)(lds_char_ptr)smem;
-
-    dma_image(lds_base, base, RS, 0, N, wave, lane);
-    dma_image(lds_base + A2_TILE, dob, OS, 0, N, wave, lane);
-    dma_image(lds_base + A2F_OFF_K, base + H * 64, RS, 0, N, wave, lane);
-    bf16x8_t kh[4], vh[4];  // K^T / V^T B operands of this lane's key
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        kh[s] = own_frag(base + H * 64, RS, kr, s, lh);
-        vh[s] = own_frag(base + 2 * H * 64, RS, kr, s, lh);
-    }
-    {   // delta = rowsum(dO o O) and lse of the wave's own 32 QUERY rows (same row numbers as its keys): 8 + 8 coalesced 16-byte
-        // loads per lane issued behind the DMAs, two half-row partial sums folded with one permlane swap
-        float dl = 0.f;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const bf16x8_t oh = own_frag(ob, OS, kr, s, lh), dh = own_frag(dob, OS, kr, s, lh);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) dl = fmaf((float)oh[e], (float)dh[e], dl);
-        }
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(dl), __float_as_uint(dl), false, false);
-        dl = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-        if (lh == 0) {
-            if (key < N) delta[((long)b * H + h) * N + key] = dl;
-            s_lse[key] = key < N ? lse[((long)b * H + h) * N + key] * 1.44269504088896340736f : INFINITY;  // +inf -> P = 0 on padded queries
-            s_del[key] = key < N ? dl : 0.f;
-        }
-    }
-    const float c2 = scale * 1.44269504088896340736f;
-    const float kmask = key < N ? 1.f : 0.f;  // padded keys must not reach dQ
-    f32x16 dk[2], dv[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dk[i][r] = 0.f, dv[i][r] = 0.f;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const int ntile = (N + 31) >> 5;  // = number of active waves: tile qt is first touched by wave qt in step 0
-    f32x16 dq[2];  // dQ^T of the wave's OWN query tile (tile index = wave), accumulated over the key blocks in registers
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
-    for (int step = 0; step < A2_WAVES; ++step) {
-        const int qt = (wave + step) % A2_WAVES;
-        char* slab = slabs + ((step & 1) * A2_WAVES + wave) * A2F_SLAB;
-        if (active && qt < ntile) {
-            f32x16 st, dp;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) st[r] = 0.f, dp[r] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) st = mfma32(rows_frag(q_img, qt * 32, s, lr, lh), kh[s], st);  // S[q][key]
-#pragma unroll
-            for (int s = 0; s < 4; ++s) dp = mfma32(rows_frag(d_img, qt * 32, s, lr, lh), vh[s], dp);  // dP[q][key]
-            f32x16 ds;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {  // accumulator rows 8 g + 4 lh + (0..3) = four consecutive queries
-                const float4 l4 = *reinterpret_cast<const float4*>(s_lse + qt * 32 + 8 * g + 4 * lh);
-                const float4 d4 = *reinterpret_cast<const float4*>(s_del + qt * 32 + 8 * g + 4 * lh);
-                const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float pv = __builtin_amdgcn_exp2f(fmaf(st[4 * g + e], c2, -ll[e])) * kmask;
-                    st[4 * g + e] = pv;
-                    ds[4 * g + e] = pv * (dp[4 * g + e] - dd[e]);
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                bf16x8_t ph, pl, sh, sl;
-                pack_step<false>(st, s, ph, pl);
-                pack_step<false>(ds, s, sh, sl);
-                // dS rows of this lane's key: queries 16 s + 4 lh + (0..3) and 16 s + 8 + 4 lh + (0..3)
-                const uint4 su = __builtin_bit_cast(uint4, sh);
-                *reinterpret_cast<uint2*>(slab + lr * 72 + (16 * s + 4 * lh) * 2) = make_uint2(su.x, su.y);
-                *reinterpret_cast<uint2*>(slab + lr * 72 + (16 * s + 8 + 4 * lh) * 2) = make_uint2(su.z, su.w);
-#pragma unroll
-                for (int dhf = 0; dhf < 2; ++dhf) {
-                    dv[dhf] = mfma32(tr_frag(d_img, qt * 32, s, 32 * dhf, lane), ph, dv[dhf]);  // dV^T += dO^T P
-                    dk[dhf] = mfma32(tr_frag(q_img, qt * 32, s, 32 * dhf, lane), sh, dk[dhf]);  // dK^T += Q^T dS
-                }
-            }
-        }
-        __syncthreads();  // the dS tiles of this step are visible (the other buffer is being read until the next barrier)
-        {
-            // dQ of the wave's own query tile: in this step key block kb = wave - step (mod 7) has produced dS[tile wave][keys of kb]
-            const int kb = (wave + A2_WAVES - step) % A2_WAVES;
-            if (wave < ntile && kb * 32 < N) {
-                const char* ks = slabs + ((step & 1) * A2_WAVES + kb) * A2F_SLAB;
-                const bf16x8_t b0 = tr_slab(ks, 0, lane), b1 = tr_slab(ks, 1, lane);
-#pragma unroll
-                for (int dhf = 0; dhf < 2; ++dhf) {
-                    dq[dhf] = mfma32(tr_frag(k_img, kb * 32, 0, 32 * dhf, lane), b0, dq[dhf]);
-                    dq[dhf] = mfma32(tr_frag(k_img, kb * 32, 1, 32 * dhf, lane), b1, dq[dhf]);
-                }
-            }
-        }
-    }
-    __syncthreads();  // the slabs are dead: they carry the bias-gradient partials below
-    // dQ write-out from registers (lane = query wave * 32 + lr; registers 4 g .. 4 g + 3 of half dhf = columns 32 dhf + 8 g + 4 lh + (0..3))
-    const int myq = wave * 32 + lr;
-    if (myq < N) {
-        const size_t qrow = ((size_t)b * N + myq) * RS + h * 64;
-#pragma unroll
-        for (int dhf = 0; dhf < 2; ++dhf)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float f[4] = {dq[dhf][4 * g] * scale, dq[dhf][4 * g + 1] * scale, dq[dhf][4 * g + 2] * scale, dq[dhf][4 * g + 3] * scale};
-                store4_split(dqkv_hi, nullptr, qrow + 32 * dhf + 8 * g + 4 * lh, f);
-            }
-    }
-    if (dbias) {  // wave-uniform
-        // Bias gradient of the fused qkv Linear = column sums of dqkv over the tokens.  Q: sum over the queries of dQ (a transposing
-        // butterfly over the 32 query lanes leaves value index lr in lane lr); K: 0 EXACTLY (the rows of dS sum to zero); V: sum_key dV =
-        // sum_q dO (the rows of P sum to one): column sums of the dO image in LDS.
-        float cbv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int it = tid; it < N * 8; it += A2_THREADS) {
-            const int q = it >> 3, c = it & 7;
-            float f[8];
-            unpack8(*reinterpret_cast<const uint4*>(d_img + q * 128 + ((c ^ sw2(q)) << 4)), f);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) cbv[e] += f[e];
-        }
-        float* scr = reinterpret_cast<float*>(smem + A2G_OFF_SLAB);  // [wave][part][64]
-        {
-            float v[32];
-#pragma unroll
-            for (int i = 0; i < 32; ++i) v[i] = myq < N ? dq[i >> 4][i & 15] * scale : 0.f;
-#pragma unroll
-            for (int o = 16; o >= 1; o >>= 1) {
-                const bool up = (lr & o) != 0;
-#pragma unroll
-                for (int i = 0; i < o; ++i) {
-                    const float snd = up ? v[i] : v[i + o], kp = up ? v[i + o] : v[i];
-                    v[i] = kp + __shfl_xor(snd, o, 64);
-                }
-            }
-            scr[(wave * 2 + 0) * 64 + 32 * (lr >> 4) + 8 * ((lr >> 2) & 3) + 4 * lh + (lr & 3)] = v[0];
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {  // lanes with equal (lane & 7) own the same 8-column chunk of dO
-            float v = cbv[e];
-            v += __shfl_xor(v, 8, 64);
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            if (lane < 8) scr[(wave * 2 + 1) * 64 + lane * 8 + e] = v;
-        }
-        __syncthreads();
-        if (tid < 128) {
-            const int part = tid >> 6, col = tid & 63;  // part 0 = Q, 1 = V
-            float t = 0.f;
-#pragma unroll
-            for (int w = 0; w < A2_WAVES; ++w) t += scr[(w * 2 + part) * 64 + col];
-            ig_red_add(dbias + (size_t)(part * 2) * H * 64 + h * 64 + col, t);
-        }
-    }
-    if (!active || key >= N) return;
-    const size_t orow = ((size_t)b * N + key) * RS + h * 64;
-#pragma unroll
-    for (int dhf = 0; dhf < 2; ++dhf)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float fk[4] = {dk[dhf][4 * g] * scale, dk[dhf][4 * g + 1] * scale, dk[dhf][4 * g + 2] * scale, dk[dhf][4 * g + 3] * scale};
-            const float fv[4] = {dv[dhf][4 * g], dv[dhf][4 * g + 1], dv[dhf][4 * g + 2], dv[dhf][4 * g + 3]};
-            store4_split(dqkv_hi, nullptr, orow + (size_t)H * 64 + 32 * dhf + 8 * g + 4 * lh, fk);
-            store4_split(dqkv_hi, nullptr, orow + 2 * (size_t)H * 64 + 32 * dhf + 8 * g + 4 * lh, fv);
-        }
-}
-
 }  // namespace
 IG_DET_TU(attention2)  // constant-memory descriptor of the deterministic-reduction mode (common.h)
 
-// IG_ERR_UNSUPPORTED (no error string): the caller runs the first-generation kernel.  IG_ATTN2=0 disables (A/B runs).
 int ig_attention2_fwd(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, float* lse, int B, int N, int H, void* stream) {
-    const char* e = getenv("IG_ATTN2");
-    if (e && atoi(e) == 0) return IG_ERR_UNSUPPORTED;
-    if (N < 1 || H > 65535 || B > 65535) return IG_ERR_UNSUPPORTED;
-    if ((((uintptr_t)qkv_hi | (uintptr_t)qkv_lo) & 15) != 0) return IG_ERR_UNSUPPORTED;
+    IG_REQUIRE(N >= 1 && H <= 65535 && B <= 65535, "ig_attention_fwd: B and H must be <= 65535 (grid dimensions), got B = %d, H = %d", B, H);
+    IG_REQUIRE((((uintptr_t)qkv_hi | (uintptr_t)qkv_lo) & 15) == 0, "ig_attention_fwd: qkv must be 16-byte aligned%s", "");
     const bool split = qkv_lo != nullptr;
     const dim3 grid((N + A2_QB - 1) / A2_QB, H, B);
     const int lds = (split ? 4 : 2) * A2_TILE;
@@ -1084,47 +878,33 @@ int ig_attention2_fwd(const void* qkv_hi, const void* qkv_lo, void* out_hi, void
 }
 
 // dbias (optional): the qkv bias gradient, dbias[3][H][64] += column sums of dqkv over the B * N tokens -- fused into the single-pass
-// kernel and into the dQ kernel of the two-pass form (the K third is identically zero; IG_ATTN2_DQ_BIAS=0: one ig_colsum pass over dqkv)
+// kernel and into the dQ kernel of the two-pass form (the K third is identically zero; the K third is identically zero)
 int ig_attention2_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi, const void* out_lo, const void* dout_hi,
                       const void* dout_lo, const float* lse, float* delta, void* dqkv_hi, void* dqkv_lo, float* dbias, int B, int N, int H,
                       void* stream) {
-    const char* e = getenv("IG_ATTN2");
-    if (e && (atoi(e) == 0 || atoi(e) == 2)) return IG_ERR_UNSUPPORTED;  // 2 = second generation for the forward only
-    if (N < 1 || H > 65535 || B > 65535) return IG_ERR_UNSUPPORTED;
-    if ((((uintptr_t)qkv_hi | (uintptr_t)qkv_lo | (uintptr_t)dout_hi | (uintptr_t)dout_lo | (uintptr_t)out_hi | (uintptr_t)out_lo) & 15) != 0) return IG_ERR_UNSUPPORTED;
+    IG_REQUIRE(N >= 1 && H <= 65535 && B <= 65535, "ig_attention_bwd: B and H must be <= 65535 (grid dimensions), got B = %d, H = %d", B, H);
+    IG_REQUIRE((((uintptr_t)qkv_hi | (uintptr_t)qkv_lo | (uintptr_t)dout_hi | (uintptr_t)dout_lo | (uintptr_t)out_hi | (uintptr_t)out_lo) & 15) == 0,
+               "ig_attention_bwd: the tensors must be 16-byte aligned%s", "");
     const bool split = qkv_lo != nullptr;
     const dim3 grid((N + A2_QB - 1) / A2_QB, H, B);
     const int lds_q = (split ? 4 : 2) * A2_TILE, lds_kv = lds_q + 2 * A2_CH * (int)sizeof(float);
     const float scale = 0.125f;
     hipStream_t st = (hipStream_t)stream;
-    const char* fe = getenv("IG_ATTN2_FUSED");  // 0: always the two-pass kernels (A/B runs)
-    if (!split && N <= A2_CH && !(fe && atoi(fe) == 0)) {
+    if (!split && N <= A2_CH) {  // one chunk of keys, plain bf16: the single-pass kernel
         static bool attr = false;
         if (!attr) {
             (void)hipFuncSetAttribute((const void*)attn2_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, A2F_SMEM);
             attr = true;
-        }
-        if (fe && atoi(fe) == 2) {  // IG_ATTN2_FUSED=2: the dS-exchange form (measured equal: 136.5 / 135.4 against 139.2 / 133.6 us at B = 108; step 45.32 against 45.40 ms)
-            static bool attr2 = false;
-            if (!attr2) {
-                (void)hipFuncSetAttribute((const void*)attn2_bwd_fused2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, A2G_SMEM);
-                attr2 = true;
-            }
-            ig_note_kernel("attn2_bwd_fused2_kernel");
-            hipLaunchKernelGGL(attn2_bwd_fused2_kernel, dim3(1, H, B), dim3(A2_THREADS), A2G_SMEM, st, (const bf16_t*)qkv_hi, (const bf16_t*)dout_hi,
-                               (const bf16_t*)out_hi, lse, delta, (bf16_t*)dqkv_hi, N, H, scale, dbias);
-            return ig_check_launch("ig_attention_bwd(attn2 fused2)");
         }
         ig_note_kernel("attn2_bwd_fused_kernel");
         hipLaunchKernelGGL(attn2_bwd_fused_kernel, dim3(1, H, B), dim3(A2_THREADS), A2F_SMEM, st, (const bf16_t*)qkv_hi, (const bf16_t*)dout_hi,
                            (const bf16_t*)out_hi, lse, delta, (bf16_t*)dqkv_hi, N, H, scale, dbias);
         return ig_check_launch("ig_attention_bwd(attn2 fused)");
     }
-    const char* lb = getenv("IG_ATTN2_DQLB");  // 4 (default): two dQ workgroups per CU at 128 registers (56 B of scratch); 2: one at 143 -- measured 75 vs 85 us
-    const int dqlb = lb ? atoi(lb) : 4;
-    const char* be = getenv("IG_ATTN2_DQ_BIAS");  // 0: the qkv bias gradient by a column-sum pass over dqkv (A/B runs)
-    const bool kbias = dbias && !(be && atoi(be) == 0);
-    float* dbias_k = kbias ? dbias : nullptr;
+    // plain bf16: two dQ workgroups per CU at 128 registers (56 B of scratch; measured 75 against 85 us for one at 143); the qkv bias
+    // gradient comes out of the dQ kernel (a column-sum pass over dqkv was 41.9 us at T = 3 / B = 36)
+    constexpr int dqlb = 4;
+    float* dbias_k = dbias;
 #define IG_A2_BWD(SPLIT_)                                                                                                          \
     {                                                                                                                              \
         static bool attr = false;                                                                                                  \
@@ -1149,12 +929,5 @@ int ig_attention2_bwd(const void* qkv_hi, const void* qkv_lo, const void* out_hi
     }
     if (split) IG_A2_BWD(true) else IG_A2_BWD(false)
 #undef IG_A2_BWD
-    if (dbias && !kbias) {
-        // (round 4, measured and not kept: Q part = column sums of the dQ third, K part = 0, V part = column sums of dO -- two passes over
-        // M x D instead of one over M x 3D -- is SLOWER at T = 3 / B = 36: 2 x 30.8 us against 41.9 us, the pass is bound by its launch and
-        // its final atomics at this size, not by the bytes; kept: the same sums from INSIDE the dQ kernel, above)
-        const int rc = ig_colsum(dqkv_hi, dqkv_lo, dbias, (long)B * N, 3 * H * 64, stream);
-        if (rc != IG_OK) return rc;
-    }
     return ig_check_launch("ig_attention_bwd(attn2)");
 }

@@ -496,31 +496,6 @@ def test_attention_fwd_bwd(split, N):
     assert kpart <= (1e-4 if split else 2e-2) * bref.abs().max().item(), f"K third of the qkv bias gradient should vanish, got {kpart}"
 
 
-@pytest.mark.parametrize("N", [197, 33, 224, 1])
-def test_attention_bwd_exchange_variant(N, monkeypatch):
-    """IG_ATTN2_FUSED=2: the single-pass backward that exchanges bf16 dS tiles between the waves (dQ in registers) instead of folding fp32
-    dQ partials through an LDS image -- same results as the default form up to summation order, and against float64."""
-    B, H = 2, 3
-    qkv, qr = bt(rnd(B, N, 3 * H * 64, seed=23), False)
-    out = BT.empty((B, N, H * 64), False, DEV)
-    lse = torch.empty(B, H, N, device=DEV)
-    ops.attention_fwd(qkv, out, lse, B, N, H)
-    dout, dor = bt(rnd(B, N, H * 64, seed=24), False)
-    qd = qr.clone().requires_grad_(True)
-    (gref,) = torch.autograd.grad((attn_ref(qd, B, N, H) * dor).sum(), qd)
-    res = []
-    for mode in ("1", "2"):
-        monkeypatch.setenv("IG_ATTN2_FUSED", mode)
-        dqkv = BT.empty((B, N, 3 * H * 64), False, DEV)
-        delta = torch.empty(B * H * N, device=DEV)
-        dbias = torch.zeros(3 * H * 64, device=DEV)
-        ops.attention_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, dbias=dbias)
-        close(dqkv.float(), gref, 2e-2, what=f"attn bwd (IG_ATTN2_FUSED={mode})")
-        close(dbias, gref.reshape(B * N, 3 * H * 64).sum(0), 6e-3, what="qkv bias gradient")
-        res.append((dqkv.float().clone(), dbias.clone()))
-    close(res[1][0], res[0][0].double().cpu(), 8e-3, what="exchange form vs image form")
-
-
 @pytest.mark.parametrize("split", SPLITS)
 @pytest.mark.parametrize("N,hd", [(257, 80), (769, 80), (1, 80), (16, 80), (33, 80), (197, 64)])
 def test_attention_generic_head_dim(split, N, hd, monkeypatch):
