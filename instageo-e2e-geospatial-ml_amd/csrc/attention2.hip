@@ -231,13 +231,35 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_fwd_kernel(const bf16_t* __r
     if (q < N) {
         const float inv = 1.f / l_run;
         const size_t orow = ((size_t)b * N + q) * ((size_t)H * 64) + h * 64;
+        if constexpr (!SPLIT) {
+            // 16-byte stores: lane half lh holds columns 32 dh + 8 g + 4 lh .. + 3; per pair of groups (g = 2 gp, 2 gp + 1) the halves
+            // exchange one 4-column piece -- v_permlane32_swap(x, y): the lower lanes receive x of lane + 32 in result[1], the upper
+            // lanes y of lane - 32 in result[0] -- then half 0 owns the 8 columns of the even group and half 1 those of the odd one
+            // (4 store instructions of 32 rows x 32 contiguous bytes instead of 8 of 32 rows x 16)
 #pragma unroll
-        for (int dh = 0; dh < 2; ++dh)
+            for (int dh = 0; dh < 2; ++dh)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float f[4] = {o[dh][4 * g] * inv, o[dh][4 * g + 1] * inv, o[dh][4 * g + 2] * inv, o[dh][4 * g + 3] * inv};
-                store4_split(out_hi, out_lo, orow + 32 * dh + 8 * g + 4 * lh, f);
-            }
+                for (int gp = 0; gp < 2; ++gp) {
+                    uint32_t a[2], c[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        a[e] = pack_bf2(o[dh][8 * gp + 2 * e] * inv, o[dh][8 * gp + 2 * e + 1] * inv);
+                        c[e] = pack_bf2(o[dh][8 * gp + 4 + 2 * e] * inv, o[dh][8 * gp + 4 + 2 * e + 1] * inv);
+                    }
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(a[0], c[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(a[1], c[1], false, false);
+                    const uint4 u = lh == 0 ? make_uint4(a[0], a[1], s0[1], s1[1]) : make_uint4(s0[0], s1[0], c[0], c[1]);
+                    *reinterpret_cast<uint4*>(out_hi + orow + 32 * dh + 16 * gp + 8 * lh) = u;
+                }
+        } else {
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float f[4] = {o[dh][4 * g] * inv, o[dh][4 * g + 1] * inv, o[dh][4 * g + 2] * inv, o[dh][4 * g + 3] * inv};
+                    store4_split(out_hi, out_lo, orow + 32 * dh + 8 * g + 4 * lh, f);
+                }
+        }
         if (lse && lh == 0) lse[((long)b * H + h) * N + q] = (m_run + __log2f(l_run)) * 0.69314718055994530942f;
     }
 }
