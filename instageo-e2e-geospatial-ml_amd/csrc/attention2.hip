@@ -63,6 +63,38 @@ __device__ __forceinline__ f32x16 mma3(bf16x8_t ah, bf16x8_t al, bf16x8_t bh, bf
     return c;
 }
 
+// One token row of 64 head-dim columns from two 32x32 accumulator tiles (lane half lh holds columns 32 dh + 8 g + 4 lh .. + 3 in
+// registers 4 g .. 4 g + 3) as 16-byte stores: per pair of groups (g = 2 gp, 2 gp + 1) the lane halves exchange one 4-column piece --
+// v_permlane32_swap(x, y): the lower lanes receive x of lane + 32 in result[1], the upper lanes y of lane - 32 in result[0] -- then
+// half 0 owns the 8 columns of the even group and half 1 those of the odd one: 4 store instructions of 32 rows x 32 contiguous bytes
+// instead of 8 of 32 rows x 16 (forward 70.5 -> 65.7 us at B = 216).  Both lanes of a pair must be active (same token row).
+template <bool SPLIT>
+__device__ __forceinline__ void a2_store_row64(bf16_t* hi, bf16_t* lo, size_t orow, const f32x16 (&acc)[2], float scale, int lh) {
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+            float va[4], vc[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) va[e] = acc[dh][8 * gp + e] * scale, vc[e] = acc[dh][8 * gp + 4 + e] * scale;
+            const uint32_t a0 = pack_bf2(va[0], va[1]), a1 = pack_bf2(va[2], va[3]), c0 = pack_bf2(vc[0], vc[1]), c1 = pack_bf2(vc[2], vc[3]);
+            {
+                const auto s0 = __builtin_amdgcn_permlane32_swap(a0, c0, false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(a1, c1, false, false);
+                *reinterpret_cast<uint4*>(hi + orow + 32 * dh + 16 * gp + 8 * lh) = lh == 0 ? make_uint4(a0, a1, s0[1], s1[1]) : make_uint4(s0[0], s1[0], c0, c1);
+            }
+            if constexpr (SPLIT) {
+                const uint32_t la0 = pack_bf2(va[0] - __uint_as_float(a0 << 16), va[1] - __uint_as_float(a0 & 0xffff0000u));
+                const uint32_t la1 = pack_bf2(va[2] - __uint_as_float(a1 << 16), va[3] - __uint_as_float(a1 & 0xffff0000u));
+                const uint32_t lc0 = pack_bf2(vc[0] - __uint_as_float(c0 << 16), vc[1] - __uint_as_float(c0 & 0xffff0000u));
+                const uint32_t lc1 = pack_bf2(vc[2] - __uint_as_float(c1 << 16), vc[3] - __uint_as_float(c1 & 0xffff0000u));
+                const auto s0 = __builtin_amdgcn_permlane32_swap(la0, lc0, false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(la1, lc1, false, false);
+                *reinterpret_cast<uint4*>(lo + orow + 32 * dh + 16 * gp + 8 * lh) = lh == 0 ? make_uint4(la0, la1, s0[1], s1[1]) : make_uint4(s0[0], s1[0], lc0, lc1);
+            }
+        }
+}
+
 template <bool SPLIT>
 __global__ __launch_bounds__(A2_THREADS) void attn2_fwd_kernel(const bf16_t* __restrict__ qkv_hi, const bf16_t* __restrict__ qkv_lo,
                                                                bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo,
@@ -231,35 +263,7 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_fwd_kernel(const bf16_t* __r
     if (q < N) {
         const float inv = 1.f / l_run;
         const size_t orow = ((size_t)b * N + q) * ((size_t)H * 64) + h * 64;
-        if constexpr (!SPLIT) {
-            // 16-byte stores: lane half lh holds columns 32 dh + 8 g + 4 lh .. + 3; per pair of groups (g = 2 gp, 2 gp + 1) the halves
-            // exchange one 4-column piece -- v_permlane32_swap(x, y): the lower lanes receive x of lane + 32 in result[1], the upper
-            // lanes y of lane - 32 in result[0] -- then half 0 owns the 8 columns of the even group and half 1 those of the odd one
-            // (4 store instructions of 32 rows x 32 contiguous bytes instead of 8 of 32 rows x 16)
-#pragma unroll
-            for (int dh = 0; dh < 2; ++dh)
-#pragma unroll
-                for (int gp = 0; gp < 2; ++gp) {
-                    uint32_t a[2], c[2];
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        a[e] = pack_bf2(o[dh][8 * gp + 2 * e] * inv, o[dh][8 * gp + 2 * e + 1] * inv);
-                        c[e] = pack_bf2(o[dh][8 * gp + 4 + 2 * e] * inv, o[dh][8 * gp + 4 + 2 * e + 1] * inv);
-                    }
-                    const auto s0 = __builtin_amdgcn_permlane32_swap(a[0], c[0], false, false);
-                    const auto s1 = __builtin_amdgcn_permlane32_swap(a[1], c[1], false, false);
-                    const uint4 u = lh == 0 ? make_uint4(a[0], a[1], s0[1], s1[1]) : make_uint4(s0[0], s1[0], c[0], c[1]);
-                    *reinterpret_cast<uint4*>(out_hi + orow + 32 * dh + 16 * gp + 8 * lh) = u;
-                }
-        } else {
-#pragma unroll
-            for (int dh = 0; dh < 2; ++dh)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float f[4] = {o[dh][4 * g] * inv, o[dh][4 * g + 1] * inv, o[dh][4 * g + 2] * inv, o[dh][4 * g + 3] * inv};
-                    store4_split(out_hi, out_lo, orow + 32 * dh + 8 * g + 4 * lh, f);
-                }
-        }
+        a2_store_row64<SPLIT>(out_hi, out_lo, orow, o, inv, lh);
         if (lse && lh == 0) lse[((long)b * H + h) * N + q] = (m_run + __log2f(l_run)) * 0.69314718055994530942f;
     }
 }
@@ -434,13 +438,7 @@ __global__ __launch_bounds__(A2_THREADS, LB) void attn2_bwd_dq_kernel(const bf16
     const bool valid = active && q < N;
     if (valid) {
         const size_t orow = ((size_t)b * N + q) * RS + h * 64;
-#pragma unroll
-        for (int dhf = 0; dhf < 2; ++dhf)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float f[4] = {dq[dhf][4 * g] * scale, dq[dhf][4 * g + 1] * scale, dq[dhf][4 * g + 2] * scale, dq[dhf][4 * g + 3] * scale};
-                store4_split(dqkv_hi, dqkv_lo, orow + 32 * dhf + 8 * g + 4 * lh, f);
-            }
+        a2_store_row64<SPLIT>(dqkv_hi, dqkv_lo, orow, dq, scale, lh);
     }
     if (!dbias) return;  // wave-uniform
     // Bias gradient of the fused qkv Linear (column sums of dqkv over the tokens) from what this workgroup already holds, as in the
@@ -604,15 +602,8 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_dkv_kernel(const bf16_t*
     }
     if (!active || key >= N) return;
     const size_t orow = ((size_t)b * N + key) * RS + h * 64;
-#pragma unroll
-    for (int dhf = 0; dhf < 2; ++dhf)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float fk[4] = {dk[dhf][4 * g] * scale, dk[dhf][4 * g + 1] * scale, dk[dhf][4 * g + 2] * scale, dk[dhf][4 * g + 3] * scale};
-            const float fv[4] = {dv[dhf][4 * g], dv[dhf][4 * g + 1], dv[dhf][4 * g + 2], dv[dhf][4 * g + 3]};
-            store4_split(dqkv_hi, dqkv_lo, orow + (size_t)H * 64 + 32 * dhf + 8 * g + 4 * lh, fk);
-            store4_split(dqkv_hi, dqkv_lo, orow + 2 * (size_t)H * 64 + 32 * dhf + 8 * g + 4 * lh, fv);
-        }
+    a2_store_row64<SPLIT>(dqkv_hi, dqkv_lo, orow + (size_t)H * 64, dk, scale, lh);
+    a2_store_row64<SPLIT>(dqkv_hi, dqkv_lo, orow + 2 * (size_t)H * 64, dv, 1.f, lh);
 }
 
 
@@ -854,15 +845,8 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_fused_kernel(const bf16_
     A2P_MARK(47)
     if (active && key < N) {
         const size_t orow = ((size_t)b * N + key) * RS + h * 64;
-#pragma unroll
-        for (int dhf = 0; dhf < 2; ++dhf)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float fk[4] = {dk[dhf][4 * g] * scale, dk[dhf][4 * g + 1] * scale, dk[dhf][4 * g + 2] * scale, dk[dhf][4 * g + 3] * scale};
-                const float fv[4] = {dv[dhf][4 * g], dv[dhf][4 * g + 1], dv[dhf][4 * g + 2], dv[dhf][4 * g + 3]};
-                store4_split(dqkv_hi, nullptr, orow + (size_t)H * 64 + 32 * dhf + 8 * g + 4 * lh, fk);
-                store4_split(dqkv_hi, nullptr, orow + 2 * (size_t)H * 64 + 32 * dhf + 8 * g + 4 * lh, fv);
-            }
+        a2_store_row64<false>(dqkv_hi, nullptr, orow + (size_t)H * 64, dk, scale, lh);
+        a2_store_row64<false>(dqkv_hi, nullptr, orow + 2 * (size_t)H * 64, dv, 1.f, lh);
     }
 }
 
