@@ -557,10 +557,7 @@ __global__ __launch_bounds__(AGL_WPB * 64) void attng_bwd_dq_lds_kernel(const bf
     }
 }
 
-inline bool agl_enabled() {  // IG_ATTNG_LDS=0: the register / L2 kernels above for the plain mode too (A/B runs, tests)
-    const char* e = getenv("IG_ATTNG_LDS");
-    return !(e && atoi(e) == 0);
-}
+constexpr bool agl_enabled() { return true; }  // plain bf16: the LDS-staged kernels (round 4: backward 587 -> 252 us); split mode: the register / L2 kernels above
 template <class K>
 inline bool agl_attr(K kern, int bytes) {
     return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;

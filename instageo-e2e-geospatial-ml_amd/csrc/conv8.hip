@@ -656,8 +656,6 @@ int ig_conv8(int kind, int sign, const void* x_hi, const void* x_lo, const void*
     const int slots = ig_cu_count();
     int best = -1;
     double best_cost = 0;
-    const char* ge = getenv("IG_CONV8_BN");
-    const int force_bn = ge ? atoi(ge) : 0;
     for (int i = 0; i < (int)(sizeof(kShapes) / sizeof(kShapes[0])); ++i) {
         const C8Shape& s = kShapes[i];
         const int tn = (N + s.bn - 1) / s.bn;
@@ -665,7 +663,6 @@ int ig_conv8(int kind, int sign, const void* x_hi, const void* x_lo, const void*
         // ragged last column tile: N = 144 on one 192-wide tile pays (measured); 288 on two does not; the 128-wide instance never does
         // (N = 96 on it: 3360 vs 2192 us in the split mode, 797 vs 610 us plain)
         if (util < (env == 2 ? 0.5 : s.bn == 128 ? 1.0 : tn == 1 ? 0.74 : 0.80)) continue;
-        if (force_bn && s.bn != force_bn) continue;
         if ((w_lo ? s.lds3 : s.lds) + (tent + 32) * 4 > 160 * 1024) continue;
         const long tiles = (M + s.bm - 1) / s.bm * tn * pl.nphase;
         const long rounds = (tiles + slots - 1) / slots;
@@ -681,12 +678,10 @@ int ig_conv8(int kind, int sign, const void* x_hi, const void* x_lo, const void*
     // ConvTranspose forward: the statically dealt 1- / 2- / 4-tap phase tiles leave the workgroups 10-25 % out of balance (the
     // round-1 engine's phases are dispatched heaviest-first by the hardware).  Measured per stage (tools/head_bench.py): it pays with
     // long reductions and many tiles (768 -> 384 at B = 216, 1152 -> 576, 576 -> 288) and at the widths the round-1 tiles fit badly
-    // (N = 144); IG_CONV8_CONVT_FWD = 1 / 0 forces it on / off.
+    // (N = 144).
     if (kind == 1 && env != 2) {
-        const char* e = getenv("IG_CONV8_CONVT_FWD");
-        const int f = e ? atoi(e) : -1;
         const bool pays = ntiles >= 4L * slots && sh.bn >= 192 && (C >= 512 || (N % 64) != 0);
-        if (f == 0 || (f < 0 && !pays)) return IG_ERR_UNSUPPORTED;
+        if (!pays) return IG_ERR_UNSUPPORTED;
     }
     if (ntiles >= (1L << 30)) return IG_ERR_UNSUPPORTED;
     for (int ph = 0; ph < pl.nphase; ++ph)

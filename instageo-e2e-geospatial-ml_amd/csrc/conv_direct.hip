@@ -371,8 +371,7 @@ int launch_direct(CDParams p, hipStream_t st, const char* what, double* stat_sum
         (void)hipFuncSetAttribute((const void*)conv3x3_direct_kernel<C, NCLS>, hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
         attr_done = true;
     }
-    static const int nwg_env = getenv("IG_CONV_DIRECT_WGS") ? atoi(getenv("IG_CONV_DIRECT_WGS")) : 0;
-    long nwg = nwg_env > 0 ? nwg_env : 512;  // two persistent workgroups per CU
+    long nwg = 512;  // two persistent workgroups per CU
     if (nwg > p.ntiles) nwg = p.ntiles;
     if (stat_sums) {
         p.stats_part = (float*)ig_scratch(0, (size_t)nwg * 2 * C * sizeof(float));
@@ -408,152 +407,6 @@ struct CWParams {
     long ntiles;
 };
 
-template <int CIN, int NWAVES>
-__global__ __launch_bounds__(64 * NWAVES, NWAVES == 4 ? 2 : 1) void conv3x3_wgrad_direct_kernel(CWParams p) {
-    constexpr int TPB_ = 64 * NWAVES;
-    constexpr int COB = 48;                                    // output channels per workgroup
-    constexpr int PPX = 2 * CIN + ((CIN / 2) % 16 == 8 ? 0 : 32 - (CIN % 16) * 2);  // x pixel pitch: = 8 (mod 16) dwords
-    constexpr int PPD = 2 * COB;                               // dy pixel pitch (24 dwords)
-    static_assert((PPX / 4) % 16 == 8 && (PPD / 4) % 16 == 8, "pixel pitches must be = 8 (mod 16) dwords");
-    constexpr int XU = CIN / 8, DU = COB / 8;
-    constexpr int XH_BYTES = HH * HW_ * PPX;
-    constexpr int XUNITS = HH * HW_ * XU, XROUNDS = (XUNITS + TPB_ - 1) / TPB_;
-    constexpr int DUNITS = TH * TW * DU, DROUNDS = DUNITS / TPB_;
-    static_assert(DUNITS % TPB_ == 0, "dy tile units must divide evenly");
-    constexpr int CB = COB / 16;                // output-channel blocks (rows of dWc)
-    constexpr int CIB = CIN / 16;               // input-channel blocks per tap
-    constexpr int NBLK = 9 * CIB;               // (tap, ci) column blocks
-    constexpr int NBW = (NBLK + NWAVES - 1) / NWAVES;  // column blocks per wave
-    constexpr int KS = TH * TW / 32;            // K-steps per tile (two tile rows each)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* xh = smem;
-    char* dyt = smem + XH_BYTES;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pq = i16 & 3;
-    const int co0 = blockIdx.y * COB;
-
-    // global offsets of this thread's 16-byte units; the pixel coordinates for the bounds tests are recomputed per fetch
-    // (registers are the scarce resource here)
-    int h_goff[XROUNDS], d_goff[DROUNDS];
-#pragma unroll
-    for (int r = 0; r < XROUNDS; ++r) {
-        const int u = r * TPB_ + tid;
-        const int hp = u / XU, c8 = u - hp * XU;
-        const int hy = hp / HW_, hx = hp - hy * HW_;
-        h_goff[r] = ((hy - 1) * p.W + (hx - 1)) * CIN + c8 * 8;
-    }
-#pragma unroll
-    for (int r = 0; r < DROUNDS; ++r) {
-        const int u = r * TPB_ + tid;
-        const int px = u / DU, c8 = u - px * DU;
-        const int ty = px / TW, tx = px - ty * TW;
-        d_goff[r] = (ty * p.W + tx) * p.Cout + co0 + c8 * 8;
-    }
-    // operand addresses: k-row of lane (g, q) in read h of K-step s is pixel (row 2s + (g>>1), column 8h + 4(g&1) + q)
-    const int a_base = (((g >> 1) * TW + 4 * (g & 1) + q) * PPD) + pq * 8;
-    const int b_lane = (((g >> 1) * HW_ + 4 * (g & 1) + q) * PPX) + pq * 8;
-    int b_base[NBW];
-#pragma unroll
-    for (int b = 0; b < NBW; ++b) {
-        const int nb = min(wave * NBW + b, NBLK - 1);
-        const int tap = nb / CIB, cib = nb - tap * CIB;
-        const int dy = tap / 3, dx = tap - dy * 3;
-        b_base[b] = b_lane + (dy * HW_ + dx) * PPX + cib * 32;
-    }
-
-    auto tile_coords = [&](long t, int& b, int& ty0, int& tx0) {
-        const int per_img = p.tiles_x * p.tiles_y;
-        b = (int)(t / per_img);
-        const int r = (int)(t - (long)b * per_img);
-        const int ty = r / p.tiles_x;
-        ty0 = ty * TH, tx0 = (r - ty * p.tiles_x) * TW;
-    };
-    uint4 prex[XROUNDS], pred[DROUNDS];
-    auto fetch = [&](long t) {
-        int b, ty0, tx0;
-        tile_coords(t, b, ty0, tx0);
-        const size_t origin = ((size_t)b * p.H + ty0) * p.W + tx0;
-#pragma unroll
-        for (int r = 0; r < XROUNDS; ++r) {
-            const int u = r * TPB_ + tid, hp = u / XU, hy = hp / HW_, hx = hp - hy * HW_;
-            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
-            prex[r] = make_uint4(0, 0, 0, 0);
-            if ((u < XUNITS) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W))
-                prex[r] = *reinterpret_cast<const uint4*>(p.x + origin * CIN + h_goff[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < DROUNDS; ++r) {
-            const int px = (r * TPB_ + tid) / DU;
-            const int gy = ty0 + px / TW, gx = tx0 + px % TW;
-            pred[r] = make_uint4(0, 0, 0, 0);  // pixels of a ragged tile outside the image contribute nothing
-            if ((gy < p.H) & (gx < p.W)) pred[r] = *reinterpret_cast<const uint4*>(p.dy + origin * p.Cout + d_goff[r]);
-        }
-    };
-    auto to_lds = [&]() {
-#pragma unroll
-        for (int r = 0; r < XROUNDS; ++r) {
-            const int u = r * TPB_ + tid, hp = u / XU;
-            const int off = PPX == XU * 16 ? u * 16 : hp * PPX + (u - hp * XU) * 16;  // unpadded pitch: units are contiguous
-            if (u < XUNITS) *reinterpret_cast<uint4*>(xh + off) = prex[r];
-        }
-#pragma unroll
-        for (int r = 0; r < DROUNDS; ++r) *reinterpret_cast<uint4*>(dyt + (r * TPB_ + tid) * 16) = pred[r];  // pitch = DU * 16
-    };
-    typedef __attribute__((address_space(3))) s16x4* lds_ptr;
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
-    auto tr_frag = [&](const char* base, int off, int pitch) {  // 8 k-values: reads h = 0 and h = 1 (8 pixels further along the row)
-        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(base + off));
-        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(base + off + 8 * pitch));
-        const s16x8 r = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        return __builtin_bit_cast(bf16x8_t, r);
-    };
-
-    f32x4 acc[CB][NBW];
-#pragma unroll
-    for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-        for (int b = 0; b < NBW; ++b) acc[cb][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    long t = xcd_first_tile();
-    if (t < p.ntiles) {
-        fetch(t);
-        to_lds();
-        if (t + gridDim.x < p.ntiles) fetch(t + gridDim.x);
-    }
-    __syncthreads();
-    for (; t < p.ntiles; t += gridDim.x) {
-        const long tn = t + gridDim.x, tnn = tn + gridDim.x;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            bf16x8_t af[CB];
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb) af[cb] = tr_frag(dyt, a_base + s * 2 * TW * PPD + cb * 32, PPD);
-#pragma unroll
-            for (int b = 0; b < NBW; ++b) {
-                const bf16x8_t bf = tr_frag(xh, b_base[b] + s * 2 * HW_ * PPX, PPX);
-#pragma unroll
-                for (int cb = 0; cb < CB; ++cb) acc[cb][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cb], bf, acc[cb][b], 0, 0, 0);
-            }
-        }
-        __syncthreads();
-        if (tn < p.ntiles) to_lds();
-        __syncthreads();
-        if (tnn < p.ntiles) fetch(tnn);
-    }
-
-    // ---- one atomic pass per workgroup: lane holds rows co = co0 + 16 cb + 4g + r of column n = 16 nb + (lane & 15)
-#pragma unroll
-    for (int b = 0; b < NBW; ++b) {
-        const int nb = wave * NBW + b;
-        if (nb < NBLK) {
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ig_red_add(p.dw + (size_t)(co0 + cb * 16 + 4 * g + r) * (9 * CIN) + nb * 16 + i16, acc[cb][b][r]);
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------- ConvTranspose2d forward
 // nn.ConvTranspose2d(k=3, s=2, p=1, op=1) of the last stage (112 x 112 x 96 -> 224 x 224 x 48; model.py:361-368), weights
 // Wc[Cout][9][Cin].  Output (2iy+py, 2ix+px) reads tap rows ky = 1 (py = 0, input row iy) or ky = 0 / 2 (py = 1, input rows
@@ -579,151 +432,6 @@ struct CTParams {
     float drop_inv;
 };
 
-template <int CIN, int COUT>
-__global__ __launch_bounds__(CT_TPB, 1) void convT_direct_kernel(CTParams p) {
-    constexpr int KSUB = CIN / 32;                   // K-steps per tap
-    constexpr int WP = 9 * KSUB * 64 + 32;           // weight row pitch (bytes): 440 dwords for CIN = 96, conflict-free
-    constexpr int PP = 2 * CIN + 32;                 // patch pixel pitch (bytes): 56 dwords for CIN = 96, conflict-free
-    static_assert((WP / 4) % 16 == 8 && (PP / 4) % 16 == 8, "pitches must be = 8 (mod 16) dwords for ds_read_b128");
-    constexpr int NB = COUT / 16, NPAIR = NB / 2;
-    constexpr int W_BYTES = COUT * WP, X_BYTES = CT_P * CT_P * PP;
-    constexpr int UNITS = CIN / 8, XUNITS = CT_P * CT_P * UNITS, ROUNDS = (XUNITS + CT_TPB - 1) / CT_TPB;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* wl = smem;
-    char* xp = smem + W_BYTES;
-    float* par = reinterpret_cast<float*>(smem + W_BYTES + X_BYTES);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane >> 4, j = lane & 15;
-    uint32_t drop_seed = p.drop_seed;
-    if (p.drop_seed_dev) drop_seed += *p.drop_seed_dev;
-
-    // ---- weights -> LDS once (channel rows interleaved as in the 3x3 kernel: a lane owns 8 consecutive output channels)
-    auto pos_of = [](int c) { return c < NPAIR * 32 ? (c / 32) * 32 + ((c % 8) / 4) * 16 + ((c % 32) / 8) * 4 + c % 4 : c; };
-    constexpr int WUNITS = 9 * CIN / 8;
-    for (int u = tid; u < COUT * WUNITS; u += CT_TPB) {
-        const int co = u / WUNITS, k8 = u - co * WUNITS;
-        *reinterpret_cast<uint4*>(wl + pos_of(co) * WP + k8 * 16) = *reinterpret_cast<const uint4*>(p.w + ((size_t)co * WUNITS + k8) * 8);
-    }
-    for (int c = tid; c < COUT; c += CT_TPB) par[c] = p.bias ? p.bias[c] : 0.f;
-
-    int h_goff[ROUNDS], h_lds[ROUNDS];
-#pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-        const int u = r * CT_TPB + tid;
-        const int hp = u / UNITS, c8 = u - hp * UNITS;
-        const int hy = hp / CT_P, hx = hp - hy * CT_P;
-        h_goff[r] = (hy * p.W + hx) * CIN + c8 * 8;
-        h_lds[r] = hp * PP + c8 * 16;
-    }
-    auto tile_coords = [&](long t, int& b, int& ty0, int& tx0) {
-        const int per_img = p.tiles_x * p.tiles_y;
-        b = (int)(t / per_img);
-        const int r = (int)(t - (long)b * per_img);
-        const int ty = r / p.tiles_x;
-        ty0 = ty * CT_T, tx0 = (r - ty * p.tiles_x) * CT_T;
-    };
-    uint4 pre[ROUNDS];
-    auto fetch = [&](long t) {
-        int b, ty0, tx0;
-        tile_coords(t, b, ty0, tx0);
-        const bf16_t* base = p.x + (((size_t)b * p.H + ty0) * p.W + tx0) * CIN;
-#pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
-            const int u = r * CT_TPB + tid, hp = u / UNITS, hy = hp / CT_P, hx = hp - hy * CT_P;
-            pre[r] = make_uint4(0, 0, 0, 0);
-            if ((u < XUNITS) & (ty0 + hy < p.H) & (tx0 + hx < p.W)) pre[r] = *reinterpret_cast<const uint4*>(base + h_goff[r]);
-        }
-    };
-    auto to_lds = [&]() {
-#pragma unroll
-        for (int r = 0; r < ROUNDS; ++r)
-            if (r * CT_TPB + tid < XUNITS) *reinterpret_cast<uint4*>(xp + h_lds[r]) = pre[r];
-    };
-    const char* x_lane = xp + ((wave * 2) * CT_P + j) * PP + g * 16;  // px-block 0 of this wave (input row 2*wave), pixel j
-    const char* w_lane = wl + j * WP + g * 16;
-
-    long t = xcd_first_tile();
-    if (t < p.ntiles) {
-        fetch(t);
-        to_lds();
-        if (t + gridDim.x < p.ntiles) fetch(t + gridDim.x);
-    }
-    __syncthreads();
-    for (; t < p.ntiles; t += gridDim.x) {
-        int b, ty0, tx0;
-        tile_coords(t, b, ty0, tx0);
-        const long tn = t + gridDim.x, tnn = tn + gridDim.x;
-        f32x4 acc[2][4][NB];  // [input row of the wave][phase py*2+px][channel block]
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int ph = 0; ph < 4; ++ph)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[mb][ph][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap % 3;
-            const int ph = (ky != 1) * 2 + (kx != 1);
-            const int xoff = ((ky == 0) * CT_P + (kx == 0)) * PP;  // tap row/column 0 reads the next input row/column
-#pragma unroll
-            for (int ks = 0; ks < KSUB; ++ks) {
-                bf16x8_t wf[NB], pf[2];
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) wf[nb] = *reinterpret_cast<const bf16x8_t*>(w_lane + nb * 16 * WP + (tap * KSUB + ks) * 64);
-#pragma unroll
-                for (int mb = 0; mb < 2; ++mb) pf[mb] = *reinterpret_cast<const bf16x8_t*>(x_lane + mb * CT_P * PP + xoff + ks * 64);
-#pragma unroll
-                for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) acc[mb][ph][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], pf[mb], acc[mb][ph][nb], 0, 0, 0);
-            }
-        }
-        __syncthreads();
-        if (tn < p.ntiles) to_lds();
-        __syncthreads();
-        if (tnn < p.ntiles) fetch(tnn);
-
-        // ---- epilogue: bias, dropout, bf16; lane = input pixel (ty0 + 2*wave + mb, tx0 + j), channels 8g..8g+7 | 32+4g..+3
-        auto finish4 = [&](f32x4 a, int n, size_t idx, float* v) {
-            const float4 bb = *reinterpret_cast<const float4*>(par + n);
-            v[0] = a[0] + bb.x, v[1] = a[1] + bb.y, v[2] = a[2] + bb.z, v[3] = a[3] + bb.w;
-            if (p.drop_thresh) {
-                float mk[4];
-                dropout_scale4(drop_seed, (uint32_t)idx, p.drop_thresh, p.drop_inv, mk);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] *= mk[i];
-            }
-        };
-        const int ix = tx0 + j;
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-            const int iy = ty0 + wave * 2 + mb;
-            if (iy < p.H && ix < p.W) {
-#pragma unroll
-                for (int ph = 0; ph < 4; ++ph) {
-                    const size_t pix = ((size_t)b * 2 * p.H + 2 * iy + (ph >> 1)) * (2 * p.W) + 2 * ix + (ph & 1);
-#pragma unroll
-                    for (int pr = 0; pr < NPAIR; ++pr) {
-                        const int n = pr * 32 + 8 * g;
-                        const size_t idx = pix * COUT + n;
-                        float v[8];
-                        finish4(acc[mb][ph][2 * pr], n, idx, v);
-                        finish4(acc[mb][ph][2 * pr + 1], n + 4, idx + 4, v + 4);
-                        *reinterpret_cast<uint4*>(p.y + idx) = pack8(v);
-                    }
-                    if (NB & 1) {
-                        const int n = (NB - 1) * 16 + 4 * g;
-                        const size_t idx = pix * COUT + n;
-                        float v[4];
-                        finish4(acc[mb][ph][NB - 1], n, idx, v);
-                        store4_split(p.y, nullptr, idx, v);
-                    }
-                }
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------- ConvTranspose2d weight gradient
 // dWc[co][tap][ci] += sum over base pixels (iy, ix) of dy[2iy + py(tap)][2ix + px(tap)][co] * x[iy + (ky==0)][ix + (kx==0)][ci]
 // for the 96 -> 48 stage (the implicit GEMM ran one split-K GEMM per tap: 440 us).  Same scheme as the 3x3 weight gradient:
@@ -745,138 +453,8 @@ struct CTWParams {
     long ntiles;
 };
 
-template <int CIN, int COUT>
-__global__ __launch_bounds__(TW_TPB, 1) void convT_wgrad_direct_kernel(CTWParams p) {
-    static_assert(CIN == 16 * (TW_TPB / 64), "one 16-channel input block per wave");
-    constexpr int PPX = 2 * CIN + 32;   // 56 dwords
-    constexpr int PPD = 2 * COUT;       // 24 dwords
-    static_assert((PPX / 4) % 16 == 8 && (PPD / 4) % 16 == 8, "pixel pitches must be = 8 (mod 16) dwords");
-    constexpr int PH = TWH + 1, PW = TWW + 1;
-    constexpr int X_BYTES = PH * PW * PPX, PLANE = TWH * TWW * PPD;
-    constexpr int XU = CIN / 8, DU = COUT / 8;
-    constexpr int XUNITS = PH * PW * XU, XROUNDS = (XUNITS + TW_TPB - 1) / TW_TPB;
-    constexpr int DUNITS = 4 * TWH * TWW * DU, DROUNDS = DUNITS / TW_TPB;
-    static_assert(DUNITS % TW_TPB == 0, "dy tile units must divide evenly");
-    constexpr int CB = COUT / 16;
-    constexpr int KS = TWH * TWW / 32;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* xp = smem;
-    char* dyp = smem + X_BYTES;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pq = i16 & 3;
-
-    int h_goff[XROUNDS], d_goff[DROUNDS], d_lds[DROUNDS];
-#pragma unroll
-    for (int r = 0; r < XROUNDS; ++r) {
-        const int u = r * TW_TPB + tid;
-        const int hp = u / XU, c8 = u - hp * XU;
-        const int hy = hp / PW, hx = hp - hy * PW;
-        h_goff[r] = (hy * p.W + hx) * CIN + c8 * 8;
-    }
-#pragma unroll
-    for (int r = 0; r < DROUNDS; ++r) {
-        const int u = r * TW_TPB + tid;
-        const int px = u / DU, c8 = u - px * DU;
-        const int oy = px / (2 * TWW), ox = px - oy * (2 * TWW);
-        d_goff[r] = (oy * 2 * p.W + ox) * COUT + c8 * 8;
-        d_lds[r] = ((oy & 1) * 2 + (ox & 1)) * PLANE + ((oy >> 1) * TWW + (ox >> 1)) * PPD + c8 * 16;
-    }
-    // k-row of lane (g, q) in read h of K-step s: base pixel (row 2s + (g>>1), column 8h + 4(g&1) + q)
-    const int a_base = (((g >> 1) * TWW + 4 * (g & 1) + q) * PPD) + pq * 8;
-    const int b_base = (((g >> 1) * PW + 4 * (g & 1) + q) * PPX) + pq * 8 + wave * 32;
-
-    auto tile_coords = [&](long t, int& b, int& ty0, int& tx0) {
-        const int per_img = p.tiles_x * p.tiles_y;
-        b = (int)(t / per_img);
-        const int r = (int)(t - (long)b * per_img);
-        const int ty = r / p.tiles_x;
-        ty0 = ty * TWH, tx0 = (r - ty * p.tiles_x) * TWW;
-    };
-    uint4 prex[XROUNDS], pred[DROUNDS];
-    auto fetch = [&](long t) {
-        int b, ty0, tx0;
-        tile_coords(t, b, ty0, tx0);
-        const bf16_t* xb = p.x + (((size_t)b * p.H + ty0) * p.W + tx0) * CIN;
-        const bf16_t* db = p.dy + (((size_t)b * 2 * p.H + 2 * ty0) * (2 * p.W) + 2 * tx0) * COUT;
-#pragma unroll
-        for (int r = 0; r < XROUNDS; ++r) {
-            const int u = r * TW_TPB + tid, hp = u / XU, hy = hp / PW, hx = hp - hy * PW;
-            prex[r] = make_uint4(0, 0, 0, 0);
-            if ((u < XUNITS) & (ty0 + hy < p.H) & (tx0 + hx < p.W)) prex[r] = *reinterpret_cast<const uint4*>(xb + h_goff[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < DROUNDS; ++r) {
-            const int px = (r * TW_TPB + tid) / DU, oy = px / (2 * TWW), ox = px - oy * (2 * TWW);
-            pred[r] = make_uint4(0, 0, 0, 0);
-            if ((2 * ty0 + oy < 2 * p.H) & (2 * tx0 + ox < 2 * p.W)) pred[r] = *reinterpret_cast<const uint4*>(db + d_goff[r]);
-        }
-    };
-    auto to_lds = [&]() {
-#pragma unroll
-        for (int r = 0; r < XROUNDS; ++r) {
-            const int u = r * TW_TPB + tid, hp = u / XU;
-            if (u < XUNITS) *reinterpret_cast<uint4*>(xp + hp * PPX + (u - hp * XU) * 16) = prex[r];
-        }
-#pragma unroll
-        for (int r = 0; r < DROUNDS; ++r) *reinterpret_cast<uint4*>(dyp + d_lds[r]) = pred[r];
-    };
-    typedef __attribute__((address_space(3))) s16x4* lds_ptr;
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
-    auto tr_frag = [&](const char* base, int off, int pitch) {
-        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(base + off));
-        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(base + off + 8 * pitch));
-        const s16x8 r = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        return __builtin_bit_cast(bf16x8_t, r);
-    };
-
-    f32x4 acc[9][CB];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb) acc[tap][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    long t = xcd_first_tile();
-    if (t < p.ntiles) {
-        fetch(t);
-        to_lds();
-        if (t + gridDim.x < p.ntiles) fetch(t + gridDim.x);
-    }
-    __syncthreads();
-    for (; t < p.ntiles; t += gridDim.x) {
-        const long tn = t + gridDim.x, tnn = tn + gridDim.x;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-#pragma unroll
-            for (int ph = 0; ph < 4; ++ph) {  // phase (py, px) = (ph >> 1, ph & 1): taps with (ky != 1) == py and (kx != 1) == px
-                bf16x8_t af[CB];
-#pragma unroll
-                for (int cb = 0; cb < CB; ++cb) af[cb] = tr_frag(dyp, ph * PLANE + a_base + s * 2 * TWW * PPD + cb * 32, PPD);
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const int ky = tap / 3, kx = tap % 3;
-                    if ((ky != 1) * 2 + (kx != 1) != ph) continue;
-                    const bf16x8_t bf = tr_frag(xp, b_base + (s * 2 * PW + (ky == 0) * PW + (kx == 0)) * PPX, PPX);
-#pragma unroll
-                    for (int cb = 0; cb < CB; ++cb) acc[tap][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cb], bf, acc[tap][cb], 0, 0, 0);
-                }
-            }
-        }
-        __syncthreads();
-        if (tn < p.ntiles) to_lds();
-        __syncthreads();
-        if (tnn < p.ntiles) fetch(tnn);
-    }
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                ig_red_add(p.dw + (size_t)(cb * 16 + 4 * g + r) * (9 * CIN) + tap * CIN + wave * 16 + i16, acc[tap][cb][r]);
-}
-
 // ---- LDS-DMA variant of the ConvTranspose weight gradient ------------------------------------------------------
-// The register-prefetch kernel above keeps one tile (83 KB) of loads in flight per CU and nothing while it computes: one
+// The register-prefetch kernel of round 2 (removed in round 5) kept one tile (83 KB) of loads in flight per CU and nothing while it computed: one
 // workgroup per CU reached 2 TB/s (the two-workgroup 3x3 kernels reach 4).  Here the tile is 4 x 16 base pixels (48 KiB
 // stage, both images lane-linear so that global_load_lds_dwordx4 can fill them: x patch 5 x 17 pixels x 224 B, dy as four
 // phase planes of 4 x 16 pixels x 96 B) and a 3-stage ring keeps two tiles in flight while a third is consumed -- the
@@ -1719,8 +1297,7 @@ static const bf16_t* cd_zero_page() {
 // (no error string) when the shape is not covered (C != 48, more than 2 classes): the caller runs the two kernels.
 int ig_conv3x3_cls_direct(const void* x, const void* w, const float* bias, const float* bn_scale, const float* bn_shift, void* y,
                           const float* cls_w, const float* cls_b, float* logits, int B, int H, int W, int C, int ncls, void* stream) {
-    static const int enabled = getenv("IG_CONV_CLS") ? atoi(getenv("IG_CONV_CLS")) : 1;
-    if (!enabled || C != 48 || ncls < 1 || ncls > 2 || (long)B * H * W * C >= (1L << 31)) return IG_ERR_UNSUPPORTED;
+    if (C != 48 || ncls < 1 || ncls > 2 || (long)B * H * W * C >= (1L << 31)) return IG_ERR_UNSUPPORTED;
     CDParams p{};
     p.x = (const bf16_t*)x, p.w = (const bf16_t*)w, p.y = (bf16_t*)y;
     p.bias = bias, p.col_scale = bn_scale, p.col_shift = bn_shift;
@@ -1739,8 +1316,7 @@ int ig_conv3x3_direct(const void* x, const void* w, const float* bias, const flo
                       float drop_p, void* stream, double* stat_sums, int* stats_fused) {
     if (stats_fused) *stats_fused = 0;
     static const int enabled = getenv("IG_CONV_DIRECT") ? atoi(getenv("IG_CONV_DIRECT")) : 1;
-    static const int use96 = getenv("IG_CD_96") ? atoi(getenv("IG_CD_96")) : 1;
-    if (!enabled || Cin != Cout || (Cin != 48 && !(Cin == 96 && use96))) return IG_ERR_UNSUPPORTED;
+    if (!enabled || Cin != Cout || (Cin != 48 && Cin != 96)) return IG_ERR_UNSUPPORTED;
     if ((long)B * H * W * Cin >= (1L << 31)) return IG_ERR_UNSUPPORTED;  // 32-bit halo offsets
     CDParams p{};
     p.x = (const bf16_t*)x, p.w = (const bf16_t*)w, p.y = (bf16_t*)y;
@@ -1768,7 +1344,7 @@ int ig_conv3x3_direct(const void* x, const void* w, const float* bias, const flo
             attr96 = true;
         }
         const long nwg = p.ntiles < 128 ? p.ntiles : 128;
-        const bool st96 = stat_sums && stats_fused && !dgrad && (!getenv("IG_CONV_STATS") || atoi(getenv("IG_CONV_STATS")));
+        const bool st96 = stat_sums && stats_fused && !dgrad;
         if (st96) {
             p.stats_part = (float*)ig_scratch(0, (size_t)nwg * 2 * 96 * sizeof(float));
             if (!p.stats_part) {
@@ -1783,37 +1359,17 @@ int ig_conv3x3_direct(const void* x, const void* w, const float* bias, const flo
             hipLaunchKernelGGL(bn_part_fold_kernel, dim3(ig_cdiv(2 * 96, 64)), dim3(1024), 0, (hipStream_t)stream, p.stats_part, stat_sums, (int)nwg, 2 * 96);
         return ig_check_launch(dgrad ? "ig_conv3x3_dgrad(direct, slices)" : "ig_conv3x3_fwd(direct, slices)");
     }
-    static const int fuse_stats = getenv("IG_CONV_STATS") ? atoi(getenv("IG_CONV_STATS")) : 1;
-    const bool st = stat_sums && stats_fused && fuse_stats && !dgrad;
+    const bool st = stat_sums && stats_fused && !dgrad;
     if (st) *stats_fused = 1;
     return launch_direct<48>(p, (hipStream_t)stream, dgrad ? "ig_conv3x3_dgrad(direct)" : "ig_conv3x3_fwd(direct)", st ? stat_sums : nullptr);
 }
 
 // Called by ig_conv3x3_wgrad (gemm.hip); IG_ERR_UNSUPPORTED when the shape is not covered.
-template <int CIN, int NWAVES>
-static int launch_wgrad_direct(const CWParams& p, int nslices, hipStream_t st) {
-    constexpr int ppx = 2 * CIN + ((CIN / 2) % 16 == 8 ? 0 : 32 - (CIN % 16) * 2);
-    constexpr int smem = HH * HW_ * ppx + TH * TW * 96;
-    static const int nwg_env = getenv("IG_CONV_DIRECT_WGS") ? atoi(getenv("IG_CONV_DIRECT_WGS")) : 0;
-    long nwg = (nwg_env > 0 ? nwg_env : (NWAVES == 4 ? 512 : 256)) / nslices;  // all workgroups co-resident
-    if (nwg > p.ntiles) nwg = p.ntiles;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_direct_kernel<CIN, NWAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_done = true;
-    }
-    ig_note_kernel("conv3x3_wgrad_direct_kernel<%d,%d>", CIN, NWAVES);
-    hipLaunchKernelGGL((conv3x3_wgrad_direct_kernel<CIN, NWAVES>), dim3((unsigned)nwg, nslices), dim3(64 * NWAVES), smem, st, p);
-    return ig_check_launch("ig_conv3x3_wgrad(direct)");
-}
-
 int ig_conv3x3_wgrad_direct(const void* dy, const void* x, float* dw, float* dbias, int* bias_fused, int B, int H, int W, int Cin,
                             int Cout, void* stream) {
     static const int enabled = getenv("IG_CONV_DIRECT") ? atoi(getenv("IG_CONV_DIRECT")) : 1;
-    static const int use192 = getenv("IG_CW_192") ? atoi(getenv("IG_CW_192")) : 1;
-    static const int use_dma = getenv("IG_CW_DMA") ? atoi(getenv("IG_CW_DMA")) : 1;  // 0: register-prefetch kernels for 48 / 96 channels
     *bias_fused = 0;
-    if (!enabled || Cout % 48 != 0 || (Cin != 48 && Cin != 96 && !(Cin == 192 && use192))) return IG_ERR_UNSUPPORTED;
+    if (!enabled || Cout % 48 != 0 || (Cin != 48 && Cin != 96 && Cin != 192)) return IG_ERR_UNSUPPORTED;
     if ((long)B * H * W * (Cin > Cout ? Cin : Cout) >= (1L << 31)) return IG_ERR_UNSUPPORTED;
     CWParams p{};
     p.x = (const bf16_t*)x, p.dy = (const bf16_t*)dy, p.dw = dw, p.dbias = nullptr;
@@ -1821,10 +1377,7 @@ int ig_conv3x3_wgrad_direct(const void* dy, const void* x, float* dw, float* dbi
     p.tiles_x = (W + TW - 1) / TW, p.tiles_y = (H + TH - 1) / TH;
     p.ntiles = (long)B * p.tiles_x * p.tiles_y;
     if (p.ntiles == 0) return IG_OK;
-    if (!use_dma && Cin == 48) return launch_wgrad_direct<48, 4>(p, Cout / 48, (hipStream_t)stream);
-    if (!use_dma && Cin == 96) return launch_wgrad_direct<96, 8>(p, Cout / 48, (hipStream_t)stream);
-    static const int r48 = getenv("IG_CW_R48") ? atoi(getenv("IG_CW_R48")) : 12;
-    const int rows = Cin == 192 ? 4 : Cin == 48 ? r48 : 8;  // tile rows of the DMA kernels (x 16 columns)
+    const int rows = Cin == 192 ? 4 : Cin == 48 ? 12 : 8;  // tile rows of the DMA kernels (x 16 columns)
     p.tiles_y = (H + rows - 1) / rows;
     p.ntiles = (long)B * p.tiles_x * p.tiles_y;
     p.dbias = dbias;
@@ -1834,10 +1387,9 @@ int ig_conv3x3_wgrad_direct(const void* dy, const void* x, float* dw, float* dbi
         ig_set_error("ig_conv3x3_wgrad: could not allocate the zero page");
         return IG_ERR_HIP;
     }
-    constexpr int smem48 = 3 * 29 * 1024, smem48b = 3 * 42 * 1024, smem96 = 3 * 52 * 1024, smem192 = 3 * 50 * 1024;
+    constexpr int smem48b = 3 * 42 * 1024, smem96 = 3 * 52 * 1024, smem192 = 3 * 50 * 1024;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_dma_kernel<48, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, smem48);
         (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_dma_kernel<48, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, smem48b);
         (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_dma_kernel<96, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, smem96);
         (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_dma_kernel<192, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem192);
@@ -1848,8 +1400,7 @@ int ig_conv3x3_wgrad_direct(const void* dy, const void* x, float* dw, float* dbi
     if (nwg > p.ntiles) nwg = p.ntiles;
     const dim3 grid((unsigned)nwg, nslices);
     ig_note_kernel("conv3x3_wgrad_dma_kernel<%d,%d>", Cin, Cin == 48 ? rows : Cin == 96 ? 8 : 4);
-    if (Cin == 48 && rows == 12) hipLaunchKernelGGL((conv3x3_wgrad_dma_kernel<48, 12>), grid, dim3(512), smem48b, (hipStream_t)stream, p, zp);
-    else if (Cin == 48) hipLaunchKernelGGL((conv3x3_wgrad_dma_kernel<48, 8>), grid, dim3(512), smem48, (hipStream_t)stream, p, zp);
+    if (Cin == 48) hipLaunchKernelGGL((conv3x3_wgrad_dma_kernel<48, 12>), grid, dim3(512), smem48b, (hipStream_t)stream, p, zp);
     else if (Cin == 96) hipLaunchKernelGGL((conv3x3_wgrad_dma_kernel<96, 8>), grid, dim3(512), smem96, (hipStream_t)stream, p, zp);
     else hipLaunchKernelGGL((conv3x3_wgrad_dma_kernel<192, 4>), grid, dim3(512), smem192, (hipStream_t)stream, p, zp);
     return ig_check_launch("ig_conv3x3_wgrad(direct, dma)");
@@ -1870,36 +1421,23 @@ int ig_convT_fwd_direct(const void* x, const void* w, const float* bias, void* y
     p.drop_thresh = ig_drop_thresh16(drop_p);
     p.drop_inv = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     if (p.ntiles == 0) return IG_OK;
-    static const int use_dma = getenv("IG_CT_DMA") ? atoi(getenv("IG_CT_DMA")) : 1;
-    if (use_dma) {
-        p.tiles_y = (H + 7) / 8;  // 8 x 16 input tiles
-        p.ntiles = (long)B * p.tiles_x * p.tiles_y;
-        constexpr int smem_d = 48 * (27 * 64 + 32) + 2 * 34 * 1024 + 48 * 4;
-        const bf16_t* zp = cd_zero_page();
-        if (!zp) {
-            ig_set_error("ig_convT_fwd: could not allocate the zero page");
-            return IG_ERR_HIP;
-        }
-        static bool attr_d = false;
-        if (!attr_d) {
-            (void)hipFuncSetAttribute((const void*)convT_direct_dma_kernel<96, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_d);
-            attr_d = true;
-        }
-        const long nwg_d = p.ntiles < 256 ? p.ntiles : 256;
-        ig_note_kernel("convT_direct_dma_kernel<96,48>");
-        hipLaunchKernelGGL((convT_direct_dma_kernel<96, 48>), dim3((unsigned)nwg_d), dim3(576), smem_d, (hipStream_t)stream, p, zp);
-        return ig_check_launch("ig_convT_fwd(direct, dma)");
+    p.tiles_y = (H + 7) / 8;  // 8 x 16 input tiles
+    p.ntiles = (long)B * p.tiles_x * p.tiles_y;
+    constexpr int smem_d = 48 * (27 * 64 + 32) + 2 * 34 * 1024 + 48 * 4;
+    const bf16_t* zp = cd_zero_page();
+    if (!zp) {
+        ig_set_error("ig_convT_fwd: could not allocate the zero page");
+        return IG_ERR_HIP;
     }
-    constexpr int smem = 48 * (27 * 64 + 32) + CT_P * CT_P * (2 * 96 + 32) + 48 * 4;
-    long nwg = p.ntiles < 256 ? p.ntiles : 256;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)convT_direct_kernel<96, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_done = true;
+    static bool attr_d = false;
+    if (!attr_d) {
+        (void)hipFuncSetAttribute((const void*)convT_direct_dma_kernel<96, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_d);
+        attr_d = true;
     }
-    ig_note_kernel("convT_direct_kernel<96,48>");
-    hipLaunchKernelGGL((convT_direct_kernel<96, 48>), dim3((unsigned)nwg), dim3(CT_TPB), smem, (hipStream_t)stream, p);
-    return ig_check_launch("ig_convT_fwd(direct)");
+    const long nwg_d = p.ntiles < 256 ? p.ntiles : 256;
+    ig_note_kernel("convT_direct_dma_kernel<96,48>");
+    hipLaunchKernelGGL((convT_direct_dma_kernel<96, 48>), dim3((unsigned)nwg_d), dim3(576), smem_d, (hipStream_t)stream, p, zp);
+    return ig_check_launch("ig_convT_fwd(direct, dma)");
 }
 
 // Called by ig_convT_wgrad (gemm.hip); IG_ERR_UNSUPPORTED when the shape is not covered.
@@ -1907,51 +1445,38 @@ int ig_convT_wgrad_direct(const void* dy, const void* x, float* dw, float* dbias
                           int Cout, void* stream) {
     *bias_fused = 0;
     static const int enabled = getenv("IG_CONV_DIRECT") ? atoi(getenv("IG_CONV_DIRECT")) : 1;
-    static const int use_dma = getenv("IG_CTW_DMA") ? atoi(getenv("IG_CTW_DMA")) : 1;
     if (!enabled || Cin != 96 || Cout != 48) return IG_ERR_UNSUPPORTED;
     if ((long)B * H * W * 4 * Cout >= (1L << 31)) return IG_ERR_UNSUPPORTED;
     CTWParams p{};
     p.x = (const bf16_t*)x, p.dy = (const bf16_t*)dy, p.dw = dw;
-    p.dbias = use_dma ? dbias : nullptr;
+    p.dbias = dbias;
     *bias_fused = p.dbias != nullptr;
     p.B = B, p.H = H, p.W = W;
-    const int th = use_dma ? 4 : TWH;
+    const int th = 4;
     p.tiles_x = (W + TWW - 1) / TWW, p.tiles_y = (H + th - 1) / th;
     p.ntiles = (long)B * p.tiles_x * p.tiles_y;
     if (p.ntiles == 0) return IG_OK;
     long nwg = p.ntiles < 256 ? p.ntiles : 256;
-    if (use_dma) {
-        constexpr int smem = 3 * 48 * 1024;
-        const bf16_t* zp = cd_zero_page();
-        if (!zp) {
-            ig_set_error("ig_convT_wgrad: could not allocate the zero page");
-            return IG_ERR_HIP;
-        }
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)convT_wgrad_dma_kernel<96, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-            attr_done = true;
-        }
-        ig_note_kernel("convT_wgrad_dma_kernel<96,48>");
-        hipLaunchKernelGGL((convT_wgrad_dma_kernel<96, 48>), dim3((unsigned)nwg), dim3(TW_TPB), smem, (hipStream_t)stream, p, zp);
-        return ig_check_launch("ig_convT_wgrad(direct, dma)");
+    constexpr int smem = 3 * 48 * 1024;
+    const bf16_t* zp = cd_zero_page();
+    if (!zp) {
+        ig_set_error("ig_convT_wgrad: could not allocate the zero page");
+        return IG_ERR_HIP;
     }
-    constexpr int smem = (TWH + 1) * (TWW + 1) * (2 * 96 + 32) + 4 * TWH * TWW * 96;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)convT_wgrad_direct_kernel<96, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)convT_wgrad_dma_kernel<96, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_done = true;
     }
-    ig_note_kernel("convT_wgrad_direct_kernel<96,48>");
-    hipLaunchKernelGGL((convT_wgrad_direct_kernel<96, 48>), dim3((unsigned)nwg), dim3(TW_TPB), smem, (hipStream_t)stream, p);
-    return ig_check_launch("ig_convT_wgrad(direct)");
+    ig_note_kernel("convT_wgrad_dma_kernel<96,48>");
+    hipLaunchKernelGGL((convT_wgrad_dma_kernel<96, 48>), dim3((unsigned)nwg), dim3(TW_TPB), smem, (hipStream_t)stream, p, zp);
+    return ig_check_launch("ig_convT_wgrad(direct, dma)");
 }
 
 // Called by ig_convT_dgrad (gemm.hip); IG_ERR_UNSUPPORTED when the shape is not covered.
 int ig_convT_dgrad_direct(const void* dy, const void* w, void* dx, int B, int H, int W, int Cin, int Cout, void* stream) {
     static const int enabled = getenv("IG_CONV_DIRECT") ? atoi(getenv("IG_CONV_DIRECT")) : 1;
-    static const int use_it = getenv("IG_CTD") ? atoi(getenv("IG_CTD")) : 1;
-    if (!enabled || !use_it || Cin != 96 || Cout != 48) return IG_ERR_UNSUPPORTED;
+    if (!enabled || Cin != 96 || Cout != 48) return IG_ERR_UNSUPPORTED;
     if ((long)B * H * W * 4 * Cout >= (1L << 31)) return IG_ERR_UNSUPPORTED;
     CTDParams p{};
     p.dy = (const bf16_t*)dy, p.w = (const bf16_t*)w, p.dx = (bf16_t*)dx;

@@ -1170,7 +1170,6 @@ int ig_layernorm_bwd(const void* dy_hi, const void* dy_lo, const float* x, const
     IG_REQUIRE(dy_hi && x && mean && rstd && gamma && dx, "ig_layernorm_bwd: null pointer");
     IG_REQUIRE(D % 4 == 0 && D <= 2048, "ig_layernorm_bwd: D must be a multiple of 4 and <= 2048 (got %d)", D);
     if (M == 0) return IG_OK;
-    static const int rpb_env = getenv("IG_LNB_RPB") ? atoi(getenv("IG_LNB_RPB")) : 0;
     // 48 rows per workgroup (measured best of 16..128 at M = 21168, tools/ln_bench.py).  For small M keep ~200 workgroups
     // (every workgroup ends in 3 D atomics, so more is not better): M = 3152 (the YAML's batch 16) 16 rows -> 21 us against
     // 38 us at 48 and 24 us at 8; M = 10638 stays at 48 (60 us; 32 rows: 75 us)
@@ -1179,7 +1178,6 @@ int ig_layernorm_bwd(const void* dy_hi, const void* dy_lo, const float* x, const
     int rpb = (int)((((long)M + 209) / 210 + 7) / 8 * 8);
     if (rpb < 8) rpb = 8;
     if (rpb > 48) rpb = std::max(48, (int)(((long)M / 444 + 4) / 8 * 8));  // nearest multiple of 8 to M / 444
-    if (rpb_env > 0) rpb = rpb_env;
     dim3 grid(ig_cdiv(M, rpb));
     size_t sm = 3 * (size_t)D * sizeof(float);
     const size_t sm_exact = (LNB_TPB / 64) * sm;  // one slab per wave (plain-store reduction)
@@ -1221,8 +1219,6 @@ int ig_colsum_ld(const void* hi, const void* lo, float* out, long M, int C, long
     // ~768 workgroups in total: fewer leave HBM idle, more are bound by the final global atomics (measured, tools/colsum_bench.py)
     const long cchunks = ig_cdiv(C, 1024);
     int rpb = (int)(((M * cchunks + 767) / 768 + 31) / 32 * 32);
-    static const int blocks_env = getenv("IG_COLSUM_BLOCKS") ? atoi(getenv("IG_COLSUM_BLOCKS")) : 0;  // tuning knob (tools/colsum_bench.py)
-    if (blocks_env > 0) rpb = (int)(((M * cchunks + blocks_env - 1) / blocks_env + 31) / 32 * 32);
     hipLaunchKernelGGL(colsum_kernel, dim3(ig_cdiv(M, rpb), ig_cdiv(C, 1024)), dim3(TPB), 0, ST(stream), (const bf16_t*)hi, (const bf16_t*)lo, out, M,
                        C, rpb, ld);
     return ig_check_launch("ig_colsum");

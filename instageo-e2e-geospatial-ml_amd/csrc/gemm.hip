@@ -1401,10 +1401,7 @@ inline float* splitk_workspace(size_t bytes, hipStream_t st) {
     }
     return (float*)ws[dev];
 }
-inline bool splitk_partial_enabled() {
-    static const int v = getenv("IG_WGRAD_PARTIAL") ? atoi(getenv("IG_WGRAD_PARTIAL")) : 1;
-    return v != 0;
-}
+constexpr bool splitk_partial_enabled() { return true; }  // split-K partials + ordered fold (the float-atomic form was an A/B arm)
 
 // ------------------------------------------------------------------------------------ launch
 // Engine choice for the plain-matrix GEMMs.  IG_GEMM=1|2|5 forces one engine (A/B runs); unset: v2 everywhere except
@@ -1421,14 +1418,8 @@ inline int gemm_env() {
 inline int gemm_version() { return gemm_env() ? gemm_env() : 2; }
 inline int gemm_version_prefer5(bool prefer) { return gemm_env() ? gemm_env() : (prefer ? 5 : 2); }
 inline int conv_version(int n_out) {
-    static int mode = -1;  // IG_CONV_V2: 0 = always v1 (default), 1 = v2 when n_out % 128 == 0, 2 = v2 when n_out >= 128
-    if (mode < 0) {
-        const char* e = getenv("IG_CONV_V2");
-        mode = e ? atoi(e) : 0;  // measured: v1 is faster for every conv stage (gather address math per LDS-DMA issue)
-    }
-    if (mode == 1 && n_out % 128 == 0) return 2;
-    if (mode == 2 && n_out >= 128) return 2;
-    return 1;
+    (void)n_out;
+    return 1;  // measured: v1 is faster for every conv stage (gather address math per LDS-DMA issue)
 }
 inline const bf16_t* zero_page() {
     static void* z = nullptr;
@@ -1542,20 +1533,18 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep_in, int M, int N, int K
         // 48-row ~280.  So 576 channels take 5 x 128 (11 % padding) rather than 6 x 96, and 144 take 2 x 96 rather than 3 x 48.
         static const int eff_n[4] = {100, 76, 60, 55}, eff_m[4] = {100, 80, 60, 50};
         const int* eff = EP::kStagedAtomic ? eff_m : eff_n;
-        static const int cost_env = getenv("IG_V1_TILE_COST") ? atoi(getenv("IG_V1_TILE_COST")) : 1;
         for (int c = 0; c < 4; ++c) {
             if (EP::kStagedAtomic && cand[c] == 64) continue;
             long padded = (long)ig_cdiv(dim, cand[c]) * cand[c];
-            if (cost_env) padded = padded * 100 / eff[c];
+            padded = padded * 100 / eff[c];
             if (best < 0 || padded < best) best = padded, pick = c;
         }
         if (EP::kStagedAtomic) mt = code[pick], bm_rows = cand[pick], bn_cols = 128;
         else nt = code[pick], bn_cols = cand[pick], bm_rows = nt == 1 ? 256 : 128;
     }
     int tm = ig_cdiv(M, bm_rows), tn = ig_cdiv(N, bn_cols);
-    // K-step 32 for the narrow (<= 96 columns) non-atomic v1 tiles: IG_V1_BK32=0 disables
-    static const int bk32_env = getenv("IG_V1_BK32") ? atoi(getenv("IG_V1_BK32")) : 1;
-    const bool bk32 = ver == 1 && !EP::kStagedAtomic && nt <= 3 && bk32_env;
+    // K-step 32 for the narrow (<= 96 columns) non-atomic v1 tiles
+    const bool bk32 = ver == 1 && !EP::kStagedAtomic && nt <= 3;
     int nk_all = ig_cdiv(K, bk32 ? 32 : BK);
     int ksplit = 1;
     if (allow_ksplit) {  // atomic epilogues only: fill the chip once; every extra split is one more atomic pass
@@ -1590,8 +1579,7 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep_in, int M, int N, int K
         if constexpr (EP::kStagedAtomic) {
             // one tile per workgroup (split-K over blockIdx.y); the fp32 tile is staged through the ring in two halves
             const int nk32 = ig_cdiv(K, 32);
-            static const int dual_env = getenv("IG_WGRAD_DUAL") ? atoi(getenv("IG_WGRAD_DUAL")) : 1;
-            const bool dual = dual_env && !split && AL::kLinearK && BL::kLinearK && nk32 >= 64;
+            const bool dual = !split && AL::kLinearK && BL::kLinearK && nk32 >= 64;
             int ks = (dual ? 256 : 512) / (tm * tn * Z);  // two 8-wave workgroups per CU, or one 16-wave workgroup (two K halves)
             if (ks > nk32 / (dual ? 32 : 16)) ks = nk32 / (dual ? 32 : 16);
             if (ks < 1) ks = 1;
@@ -1607,8 +1595,7 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep_in, int M, int N, int K
                     }
                     ig_note_kernel("gemm2_kernel<%s,%s,%s,%s,%s,1,32,2>", AL::kName, BL::kName, EP::kName, A_TR ? "true" : "false", B_TR ? "true" : "false");
                     if (prep_partial((int)grid.y) != IG_OK) return IG_ERR_HIP;
-                    static const int pairmap = getenv("IG_WGRAD_PAIRMAP") ? atoi(getenv("IG_WGRAD_PAIRMAP")) : 1;
-                    if (pairmap) {  // 1-D grid, (split, tile) pairs dealt split-major to the XCDs (see gemm2_kernel)
+                    {  // 1-D grid, (split, tile) pairs dealt split-major to the XCDs (see gemm2_kernel)
                         ep.pairs = (int)grid.y;
                         grid.x = grid.x * grid.y, grid.y = 1;
                     }
@@ -1619,8 +1606,7 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep_in, int M, int N, int K
             }
             if (prep_partial((int)grid.y) != IG_OK) return IG_ERR_HIP;
             {
-                static const int pairmap2 = getenv("IG_WGRAD_PAIRMAP") ? atoi(getenv("IG_WGRAD_PAIRMAP")) : 1;
-                if (pairmap2 && grid.y > 1) {
+                if (grid.y > 1) {
                     ep.pairs = (int)grid.y;
                     grid.x = grid.x * grid.y, grid.y = 1;
                 }
@@ -1656,8 +1642,7 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep_in, int M, int N, int K
 #define IG_LAUNCH_V1(NSEG_, MT_, NT_, WM_) IG_LAUNCH_V1K(NSEG_, MT_, NT_, WM_, 64)
     if constexpr (EP::kStagedAtomic) {
         if (prep_partial((int)grid.y) != IG_OK) return IG_ERR_HIP;
-        static const int pairmap1 = getenv("IG_WGRAD_PAIRMAP") ? atoi(getenv("IG_WGRAD_PAIRMAP")) : 1;
-        if (pairmap1 && grid.y > 1) {  // 1-D grid of (split, tile) pairs, split-major per XCD (see gemm_kernel)
+        if (grid.y > 1) {  // 1-D grid of (split, tile) pairs, split-major per XCD (see gemm_kernel)
             ep.pairs = (int)grid.y, ep.ntiles = (int)grid.x;
             grid.x = grid.x * grid.y, grid.y = 1;
         }
@@ -1976,11 +1961,8 @@ int ig_conv3x3_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, con
         al, bl, ep, al.Mtot, Cin, 9 * Cout, 1, dy_lo != nullptr, (hipStream_t)stream, "ig_conv3x3_dgrad", false, conv_version(Cin));
 }
 
-// IG_DIRECT_X3=0: split-operand weight gradients of the narrow stages back on the gather GEMM (A/B switch; read per call)
-static inline bool direct_x3_env() {
-    const char* e = getenv("IG_DIRECT_X3");
-    return !e || atoi(e) != 0;
-}
+// split-operand weight gradients of the narrow stages: three launches of the bf16 direct kernels (round 4: +6.6 % on the bf16x3 step)
+static constexpr bool direct_x3_env() { return true; }
 
 // dWc[Cout][9][Cin] += sum_pixels dy[p][co] * x[shift_tap(p)][ci]
 int ig_conv3x3_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, const void* x_lo, float* dw, float* dbias, int B,

@@ -633,17 +633,12 @@ int ig_gemm8_nt(const G8Params& p, void* stream) {
     if ((p.K & 127) || (p.N & 127)) return IG_ERR_UNSUPPORTED;
     if (p.lda * 2 * 256 >= (1L << 24) || p.ldb * 2 * 256 >= (1L << 24)) return IG_ERR_UNSUPPORTED;  // 24-bit offset multiply
     const int ntiles256 = (p.N & 255) ? 0 : ((p.M + 255) >> 8) * (p.N >> 8);
-    const int min_tiles = getenv("IG_GEMM8_MIN_TILES") ? atoi(getenv("IG_GEMM8_MIN_TILES")) : 128;
+    constexpr int min_tiles = 128;
     // The 256 x 256 instance needs enough tiles for one workgroup per CU.  Threshold swept on the whole step: 128 beats 192 at the
     // YAML's batch 16 (117-156 tiles: 1707 -> 1770 chips/s) and for the 300M model at B = 54 (168 tiles: 1200 -> 1279), neutral at
     // B = 32 / 48 / 108; 96 starts to lose at B = 48.  Below it (and for N = 128 mod 256) the 128 x 128 instance takes over: four
-    // times the tiles, two workgroups per CU (IG_GEMM8_SMALL=0: back to the round-1 engines for those shapes).
-    bool small = false;
-    if (ntiles256 < min_tiles && g8_env() != 2) {
-        const char* e = getenv("IG_GEMM8_SMALL");
-        if (e && atoi(e) == 0) return IG_ERR_UNSUPPORTED;
-        small = true;
-    }
+    // times the tiles, two workgroups per CU.
+    const bool small = ntiles256 < min_tiles && g8_env() != 2;
     // (Round 4, measured and not kept: taking the 128 x 128 instance whenever its round count beats the big one's by a cost model --
     // 261 tiles of 256 x 256 on 256 CUs are two rounds for 1.02 rounds of work at B = 112, 1044 quarter-tiles are three rounds of 512 --
     // made the cliff WORSE: 4142 -> 4005 chips/s at B = 112, 4599 -> 4343 at B = 221; a small-instance round costs more than half a big one.)

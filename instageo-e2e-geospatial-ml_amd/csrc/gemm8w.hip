@@ -3,10 +3,9 @@
 //   mode 0  dW_g[n][k] += sum_m dy_g[m][n] * x_g[m][k]       the linears of a timm Block (pritvhi.py:446-456: qkv / proj / fc1 / fc2;
 //                                                            autograd's grad_weight of F.linear), g = 0 .. ng-1 share the token count
 //   mode 1  dWc[co][tap][ci] += sum_p dy[p][co] * x[p + shift(tap)][ci]        nn.Conv2d(k=3, padding=1)      (model.py:370-375)
-//   mode 2  dWc[co][tap][ci] += sum_p dy[up(p) + shift(tap)][co] * x[p][ci]    nn.ConvTranspose2d(k3,s2,p1,op1) (model.py:361-368)
-//           round 4b: run as mode 1 with the ROLES SWAPPED -- rows = ci (x, plain: 256-row tiles), columns = (tap, co) (dy, gathered
-//           at the stride-2 positions, the lane's tap from its column), the fold stores the tile transposed into dWc[co][tap][ci];
-//           the per-tap form (A gathered, 192-row tiles) stays for A/B runs (IG_WGRAD8_CONVT_SWAP=0)
+//           dWc[co][tap][ci] += sum_p dy[up(p) + shift(tap)][co] * x[p][ci]    nn.ConvTranspose2d(k3,s2,p1,op1) (model.py:361-368)
+//           runs as mode 1 with the ROLES SWAPPED -- rows = ci (x, plain: 256-row tiles), columns = (tap, co) (dy, gathered at the
+//           stride-2 positions, the lane's tap from its column), the fold stores the tile transposed into dWc[co][tap][ci]
 //
 // * The reduction runs over tokens / pixels, so BOTH operands are reduce-strided ("TR"): an operand half-tile in LDS is
 //   [64 tokens][128 columns] (256-byte rows, 16 KiB), filled by LDS-DMA in full 256-byte source rows (two cache lines per
@@ -19,7 +18,7 @@
 // * Convolutions: the shifted operand is GATHERED by the LDS-DMA through a buffer descriptor (`buffer_load_dwordx4 ... offen lds`:
 //   border taps get an out-of-range offset and the hardware writes zeros, see conv8.hip): per lane a 32-bit byte offset = pixel row
 //   (kept incrementally per K-tile: p, y, x advance by 64 tokens) + the tap's displacement and the lane's channel chunk (per segment).
-//   mode 1 gathers x (the lane's tap follows from its output column), mode 2 gathers dy (one tap per tile).
+//   mode 1 gathers x (the lane's tap follows from its output column); the ConvTranspose runs in mode 1 with the roles swapped.
 // * Work = (output tile, token range) SEGMENTS from a host-built table: the tiles of all GEMMs of the group form one list, so
 //   a group of four GEMMs (108 tiles at D = 768) runs with 2 token splits on 216 CUs where four separate launches needed
 //   7-28 splits each -- the split-K fold (slab stores + ordered reduce) shrinks from 4 x 32 MB to 54 MB per block and every
@@ -167,12 +166,10 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
     const unsigned ldsw = lds_base + wave * 2048;
 
     WCur cA0, cA1, cB;  // the two B halves of a K-tile are always issued together: one cursor
-    WRows rA0, rA1, rB;  // MODE 2: rA0 / rA1; MODE 1: rB
+    WRows rA0, rA1, rB;  // row state of the gathered operand (MODE 1: rB)
     // per-segment lane constants of the gathered operand
     bool okA[2] = {true, true}, okB[2] = {true, true};  // this lane's column exists in half 0 / 1 of the tile
     int shB[2] = {0, 0}, dyB[2] = {0, 0}, dxB[2] = {0, 0};  // MODE 1: byte displacement (tap shift + channel), tap displacement per B half
-    int shA[2] = {0, 0}, kyA[2] = {1, 1}, kxA[2] = {1, 1};  // MODE 2: byte displacement of the tile's tap, the tap (per A cursor = half)
-    int colA[2] = {0, 0};                                   // MODE 2: byte offset of this lane's column chunk in half 0 / 1
     i32x4 rs_hi = {0, 0, 0, 0}, rs_lo = {0, 0, 0, 0};
     if constexpr (MODE != 0) {  // one gathered tensor per launch (the group holds ONE convolution)
         rs_hi = w_rsrc(MODE == 1 ? args.b[0][0] : args.a[0][0], cv.g_bytes);
@@ -204,18 +201,8 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
         const int pa_ = NSEG == 1 ? 0 : (C.pseg == 2 ? 1 : 0);
         C.ld2 = s_->lda2, C.kt = s_->nkt, C.rows = s_->rows;
         pseg = pa_;
-        if constexpr (MODE == 2) {
-            C.base = nullptr;
-            W_DECODE_ROWS(R, s_->tok0)
-            const int tap = s_->tap;
-            kyA[hg] = (tap * 11) >> 5, kxA[hg] = tap - kyA[hg] * 3;
-            shA[hg] = ((kyA[hg] - 1) * 2 * cv.W + (kxA[hg] - 1)) * C2g;
-            colA[hg] = (int)s_->aoff + hg * (ACOLS * 2) + lch16;
-            okA[hg] = lch * 8 < ACOLS && hg * ACOLS + lch * 8 < s_->acols;
-        } else {
-            C.base = args.a[g_][pa_] + s_->aoff;
-            if constexpr (MASKED) okA[hg] = lch * 8 < ACOLS && hg * ACOLS + lch * 8 < s_->acols;
-        }
+        C.base = args.a[g_][pa_] + s_->aoff;
+        if constexpr (MASKED) okA[hg] = lch * 8 < ACOLS && hg * ACOLS + lch * 8 < s_->acols;
     };
     auto rebaseB = [&](WCur& C, WRows& R, int& pseg) {
         const WSeg* s_ = my + C.seg;
@@ -274,19 +261,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
     auto issueA = [&](WCur& C, WRows& R, int hg, int buf, int& pseg) {
         if (C.left <= 0) return;
         const unsigned dst = ldsw + buf * W_BUF + hg * W_HALF;
-        if constexpr (MODE == 2) {
-            const i32x4 rs = (NSEG == 3 && pseg) ? rs_lo : rs_hi;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const bool v = okA[hg] & (R.p[i] < cv.M) & ((R.y[i] > 0) | (kyA[hg] > 0)) & ((R.x[i] > 0) | (kxA[hg] > 0));
-                const int pix = (R.b[i] * 2 * cv.H + 2 * R.y[i]) * (2 * cv.W) + 2 * R.x[i];
-                const unsigned voff = v ? (unsigned)(pix * C2g + shA[hg] + colA[hg]) : 0x80000000u;
-                w_blds(voff, rs, dst + i * 1024);
-            }
-            W_ADVANCE_ROWS(R)
-        } else {
-            issue_plain(C, dst, hg * (ACOLS * 2), okA[hg]);
-        }
+        issue_plain(C, dst, hg * (ACOLS * 2), okA[hg]);
         if (advance(C)) rebaseA(C, R, hg, pseg);
     };
     // B half g of the cursor's K-tile into buffer buf; the cursor advances behind half 1 (the halves of a K-tile are issued in two
@@ -526,10 +501,7 @@ inline int wg8_env() {  // IG_WGRAD8: 0 = off (the BK = 32 ring engine of gemm.h
     const char* e = getenv("IG_WGRAD8");
     return e ? atoi(e) : 1;
 }
-inline int wg8_rem_env() {  // IG_WGRAD8_REM=0: uniform token splits only (A/B runs)
-    const char* e = getenv("IG_WGRAD8_REM");
-    return e ? atoi(e) : 1;
-}
+constexpr int wg8_rem_env() { return 1; }  // ragged token splits (uniform-only splits were an A/B arm)
 
 struct TileRef {  // one output tile of the launch
     int g;         // GEMM (pointer set)
@@ -652,7 +624,7 @@ int w_run(const WKey& key, const std::vector<TileRef>& tl, int M, int lda2_of_g[
                     const long tok0 = (long)v[si].p0 * 128;
                     WSeg& d = hs[(size_t)b * W_MAXSEG + si];
                     d.lda2 = lda2_of_g[tr.g], d.ldb2 = ldb2_of_g[tr.g];
-                    d.aoff = tr.aoff + (MODE == 2 ? 0 : tok0 * d.lda2);
+                    d.aoff = tr.aoff + tok0 * d.lda2;
                     d.boff = tr.boff + (MODE == 1 ? 0 : tok0 * d.ldb2);
                     d.slab = (long)v[si].t * spt + tcount[v[si].t]++;
                     d.nkt = v[si].np * 2;
@@ -779,10 +751,10 @@ int ig_wgrad8_conv(int kind, const void* dy_hi, const void* dy_lo, const void* x
     const double g_bytes = kind == 0 ? (double)M * Cin * 2.0 : (double)M * 4.0 * Cout * 2.0;
     if (M >= (1L << 30) || g_bytes >= 2147483648.0) return IG_ERR_UNSUPPORTED;
     if ((long)Cout * 2 * 64 >= (1L << 24) || (long)Cin * 2 * 64 >= (1L << 24)) return IG_ERR_UNSUPPORTED;
-    // ConvTranspose: roles swapped by default (rows = ci from x, columns = (tap, co) from dy gathered at the stride-2 positions, transposed
-    // fold): one GEMM with 256- or 192-row tiles instead of nine with 192-row tiles of a gathered A.  IG_WGRAD8_CONVT_SWAP=0: the per-tap form.
-    const char* se = getenv("IG_WGRAD8_CONVT_SWAP");
-    const bool swap = kind == 1 && !(se && atoi(se) == 0);
+    // ConvTranspose: roles swapped (rows = ci from x, columns = (tap, co) from dy gathered at the stride-2 positions, transposed fold):
+    // one GEMM with 256- or 192-row tiles.  (The per-tap form of round 4 -- nine GEMMs with 192-row tiles of a gathered A, 455 against
+    // 325 us at 768 -> 384 -- was an A/B arm and is gone.)
+    const bool swap = kind == 1;
     const int nrows = swap ? Cin : Cout;                                  // rows of the GEMM's output
     const int ncols = kind == 0 ? 9 * Cin : (swap ? 9 * Cout : Cin);      // its columns
     auto waste = [](int n, int b) { return (double)((n + b - 1) / b * b) / n; };
@@ -790,7 +762,6 @@ int ig_wgrad8_conv(int kind, const void* dy_hi, const void* dy_lo, const void* x
     // tile wins unless it leaves more than ~12 % of itself empty
     const int BMt = (swap || kind == 0) && waste(nrows, 256) <= waste(nrows, 192) + 1e-9 ? 256 : (waste(nrows, 256) < waste(nrows, 192) - 0.12 ? 256 : 192);
     const int BNt = waste(ncols, 256) <= waste(ncols, 192) + 0.12 ? 256 : 192;
-    if (!swap && kind == 1 && BMt != 192) return IG_ERR_UNSUPPORTED;  // (the per-tap form is instantiated for 192-row tiles only)
     const int tiles_m = (nrows + BMt - 1) / BMt, tiles_n = (ncols + BNt - 1) / BNt;
     const double util = (double)nrows * ncols / ((double)tiles_m * BMt * tiles_n * BNt);
     int ncu = ig_cu_count() - ig_reserved_cus();
@@ -841,8 +812,6 @@ int ig_wgrad8_conv(int kind, const void* dy_hi, const void* dy_lo, const void* x
         return w_run<MODE, 3, 1, TRANS>(key, tl, M_, lda2, ldb2, split, args, cv, dws, 0, st, WHAT);                                \
     }
     if (kind == 0) IG_W8C(1, false, "ig_conv3x3_wgrad")
-    if (swap) IG_W8C(1, true, "ig_convT_wgrad")
+    IG_W8C(1, true, "ig_convT_wgrad")
 #undef IG_W8C
-    if (BNt == 256) return w_run<2, 3, 2>(key, tl, M_, lda2, ldb2, split, args, cv, dws, 0, st, "ig_convT_wgrad");
-    return w_run<2, 3, 1>(key, tl, M_, lda2, ldb2, split, args, cv, dws, 0, st, "ig_convT_wgrad");
 }

@@ -934,8 +934,8 @@ static int classifier_bwd_impl(int mode, ClsBn bn, int* nwg_out, const float* dl
     const unsigned gx = (unsigned)((M + ppb - 1) / ppb);
     const unsigned gy_split = wide ? (unsigned)((ncls + 7) / 8) : 1u;  // class groups of the dW passes
     // > 8 classes: the dW passes take all 16 class slots in one group (default: 13 classes, S form: 722 against 1040 us for two groups of 8, each of
-    // which repeats the loads, the dropout hash and the mask; IG_CLS_ONE_GROUP=0 for A/B runs)
-    static const bool one_group = !getenv("IG_CLS_ONE_GROUP") || atoi(getenv("IG_CLS_ONE_GROUP"));
+    // which repeats the loads, the dropout hash and the mask)
+    constexpr bool one_group = true;
     if (nwg_out) {  // geometry query of the reduce pass (the caller sizes the partial-sum scratch before the launch)
         *nwg_out = (int)(gx * (nc == 16 && one_group ? 1u : gy_split));
         return IG_OK;
@@ -945,7 +945,7 @@ static int classifier_bwd_impl(int mode, ClsBn bn, int* nwg_out, const float* dl
     ig = ig < 8 ? 8 : ig > ig_max ? ig_max : ig & ~7L;  // whole trips of the prefetching loop (4 pixels)
     const size_t sm = (32 + (size_t)CLS_SLAB + (size_t)nc * ig * nsl) * sizeof(float);
     const float inv = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    static const bool sform = !getenv("IG_CLS_SFORM") || atoi(getenv("IG_CLS_SFORM"));  // reduce pass in S form also at <= 4 classes (A/B switch)
+    constexpr bool sform = true;  // the reduce pass runs in S form at every class count (round 4: 111 -> 83 us at 2 classes)
     // narrow heads (C = 16 with > 8 classes, C = 8 with > 4) stage more than the default 64 KiB limit of dynamic LDS: 32 KiB slab + ig >= 8
     // groups of nc x nsl floats; every instantiation raises its limit once (as classifier_fwd_kernel does)
 #define IG_CLS_BWD(NC, VEC, MD, GY)                                                                                                      \

@@ -341,8 +341,8 @@ class SegEngine:
         # multi-contributor reductions go through the fixed-point shadow of the gradient buffer (ops.set_deterministic).  On by
         # default (0.15-0.2 ms per step); IG_DETERMINISTIC=0 or ``engine.deterministic = False`` selects the float atomics.
         self.deterministic = os.environ.get("IG_DETERMINISTIC", "1") != "0"
-        # training: the last stage's BatchNorm + ReLU run inside the classifier kernels (IG_FUSE_TAIL=0: the separate passes, for A/B runs)
-        self.fuse_tail = os.environ.get("IG_FUSE_TAIL", "1") != "0"
+        # training: the last stage's BatchNorm + ReLU run inside the classifier kernels (``fuse_tail = False``: the separate passes)
+        self.fuse_tail = True
         self._det_pending: List[Tuple[int, int]] = []
         self._pos_cache: Dict[int, Any] = {}
         self._last: Optional[Dict[str, Any]] = None

@@ -34,8 +34,8 @@ except Exception:  # pragma: no cover - Lightning is absent in this image
 # --------------------------------------------------------------------------------------------------
 # AdamW on the flat parameter buffer (base.py:124-126: torch.optim.AdamW defaults)
 # --------------------------------------------------------------------------------------------------
-_FRESH_STEP = os.environ.get("IG_FRESH_STEP", "1") != "0"  # A/B switch: 0 = zero every gradient and accumulate (rounds 1-2)
-_ADAMW_OVERLAP = os.environ.get("IG_ADAMW_OVERLAP", "1") != "0"  # A/B switch: 0 = one AdamW launch after the backward pass (rounds 1-3)
+_FRESH_STEP = True     # the Blocks' weight gradients are written, not accumulated: the step neither zeroes nor reads them (round 3)
+_ADAMW_OVERLAP = True  # AdamW per gradient range on a side stream during backward (round 4: +0.1-0.7 % at B = 216; off below ~50 chips)
 
 class FusedAdamW(torch.optim.Optimizer):
     """``torch.optim.AdamW`` semantics, one HIP launch over the flat buffer of a :class:`PrithviSeg`.
@@ -455,7 +455,7 @@ class PrithviSegmentationModule(_Base):
             eng.zero_grads_for_step(opt.lo, opt.hi)
         else:
             g[opt.lo : opt.hi].zero_()
-        # single process, not under a stream capture: the optimizer work rides on the backward pass (IG_ADAMW_OVERLAP=0: afterwards)
+        # single process, not under a stream capture: the optimizer work rides on the backward pass
         # (measured, tools/ab_step.sh: +0.5-0.7 % at B = 216; at the YAML's batch 16 the extra fold launches and stream events cost
         # more than the 0.5 ms they hide -- the step there is bound by the host's launch rate -- so small batches keep the single launch)
         early = (self.grad_sync is None and opt.sharded is None and eng.on_grad_ready is None and _ADAMW_OVERLAP and self._early_ok

@@ -259,7 +259,7 @@ def test_transpose_bf16_batched():
 @pytest.mark.parametrize("M,N,K", [(21276, 2304, 768), (21276, 768, 768), (4100, 768, 3072), (3152, 768, 768)])
 def test_linear_wgrad_is_deterministic(split, M, N, K):
     """The reference trains with deterministic=True: split-K weight gradients go through workspace slabs + one ordered reduce
-    (no float atomics), so repeated launches are bit-identical; IG_WGRAD_PARTIAL=0 would restore the atomic form."""
+    (no float atomics), so repeated launches are bit-identical."""
     dy, dyr = bt(rnd(M, N, seed=5), split)
     x, xr = bt(rnd(M, K, seed=7), split)
     dw = torch.zeros(N, K, device=DEV)
