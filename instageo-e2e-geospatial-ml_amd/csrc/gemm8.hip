@@ -100,7 +100,9 @@ struct Cur {  // issue cursor of one half-tile type (all wave-uniform)
 // long read phase go.  WAR: the slot was last read two intervals earlier, by both groups.  The DMA stream of a wave in program order:
 // [R1: A1(t+1)] [R2: A0 B0 (t+2)] [M2: B1(t+2)]; R1's wait retires A1(t) with 6 younger operations in flight, R2's retires
 // A0 B0 B1 (t+1) with 2 (last iteration: 6 2 0 0).  qkv 142.0 -> 135.4 us, fc2 193.8 -> 190.4 at M = 42552 (same box, tools/gemm8_bench.py
-// --sched); also measured, not kept: A1 behind the MFMAs of big phase 1 as well (140.1), the waits moved alone (141.9).
+// --sched); also measured, not kept: A1 behind the MFMAs of big phase 1 as well (140.1), the waits moved alone (141.9), the issues in front
+// of their phase's fragment reads (134.0 against 135.1: noise).  In shader cycles the K-loop runs the matrix pipe at ~65 % and the clock sits
+// at ~1.9 GHz under it (32 MFMAs issue in 620-660 s_memtime ticks = 512 cycles): schedule gains come back only in part (DVFS give-back).
 // DBG (timing ablations, built with -DIG_G8_ABLATE only; results are garbage): 1 = no LDS-DMA inside the loop, 2 = + no fragment
 // reads, 3 = + no barriers, 4 = everything but the epilogue stores.  profiles/r02_v8_ablation_qkv.log: of 71 us (qkv, B = 108)
 // the epilogue is 13.7 (its 33 MB store burst per round sits in front of the next loads in the in-order vmcnt), LDS-DMA 10.2,

@@ -2,7 +2,7 @@
 # The other BASELINE configs / batch sizes on one box: short bench.py runs (train + inference + encoder legs), one JSON line each.
 # usage: tools/bench_configs.sh OUTDIR
 OUT=${1:-gpurun_out/configs}; mkdir -p $OUT
-run() { name=$1; shift; python bench.py --steps 30 --warmup 6 --no-tile --no-cpu-baseline --no-parity-leg --detail-file $OUT/detail_$name.json "$@" 2>&1 | grep '^{' > $OUT/bench_$name.json; python - <<PY
+run() { name=$1; shift; python bench.py --steps 30 --warmup 6 --no-tile --no-yaml-legs --no-cpu-baseline --no-parity-leg --detail-file $OUT/detail_$name.json "$@" 2>&1 | grep '^{' > $OUT/bench_$name.json; python - <<PY
 import json; d=json.load(open("$OUT/bench_$name.json")); c=d["config"]
 print(f"$name: train {d['value']:.0f} chips/s ({d['ms_per_step']:.2f} ms, whole-step frac {c['whole_step_mfma_frac']:.3f}), inference {c['inference_chips_per_s']:.0f}, encoder fwd {c['encoder_fwd_ms']:.2f} ms ({c['encoder_fwd_mfma_frac']:.3f}); roofline {d.get('roofline',{}).get('kernel')} {d.get('roofline',{}).get('frac')}")
 PY

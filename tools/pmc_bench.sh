@@ -8,5 +8,5 @@ case $OUT in /*) ;; *) OUT=$R/$OUT;; esac
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for P in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/pmc_$P -o pmc -- python3 $R/bench.py --steps 3 --warmup 1 --no-profile --no-cpu-baseline --no-parity-leg --no-tile "$@" > $OUT/pmc_$P.log 2>&1
+  timeout 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/pmc_$P -o pmc -- python3 $R/bench.py --steps 3 --warmup 1 --no-profile --no-cpu-baseline --no-parity-leg --no-tile --no-yaml-legs "$@" > $OUT/pmc_$P.log 2>&1
 done

@@ -2,7 +2,7 @@
 # tools/prof_step.sh BATCH TAG [bench args]: rocprofv3 kernel trace of a short training bench -> per-step busy / idle split and the
 # per-kernel time of ONE training step (inference legs excluded) under gpurun_out/step_TAG/
 R=${GRAFT_REPO_ROOT:-/root/repo}; B=$1; TAG=$2; shift 2; OUT=$R/gpurun_out/step_$TAG; mkdir -p $OUT
-(cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof -o b -- python3 $R/bench.py --batch $B --steps 20 --warmup 5 --no-cpu-baseline --no-parity-leg --no-tile --no-profile --detail-file /tmp/d.json "$@" > $OUT/prof.log 2>&1)
+(cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof -o b -- python3 $R/bench.py --batch $B --steps 20 --warmup 5 --no-cpu-baseline --no-parity-leg --no-tile --no-yaml-legs --no-profile --detail-file /tmp/d.json "$@" > $OUT/prof.log 2>&1)
 python3 $R/tools/step_timeline.py $OUT/prof/b_kernel_trace.csv 4 > $OUT/timeline.txt 2>&1; head -1 $OUT/timeline.txt
 python3 - <<PY > $OUT/train_step_kernels.txt
 import csv, collections
