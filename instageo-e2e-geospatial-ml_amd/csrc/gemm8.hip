@@ -33,9 +33,11 @@
 // behind the epilogue (how long until they are acknowledged), 2 leaves the kernel's own waits alone.
 __device__ unsigned long long g_g8prof[8 * 64];
 #define G8P_MARK(I) { if (g8p_on) g_g8prof[wave * 64 + (I)] = __builtin_readcyclecounter(); }
+#define G8P_REAL(I) { if (g8p_on) g_g8prof[wave * 64 + (I)] = __builtin_amdgcn_s_memrealtime(); }  // 100 MHz: the clock = d(memtime) / d(memrealtime) x 100 MHz
 extern "C" int ig_debug_g8prof(unsigned long long* dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_g8prof), sizeof(g_g8prof)) == hipSuccess ? 0 : -1; }
 #else
 #define G8P_MARK(I)
+#define G8P_REAL(I)
 #endif
 namespace {
 
@@ -101,8 +103,9 @@ struct Cur {  // issue cursor of one half-tile type (all wave-uniform)
 // [R1: A1(t+1)] [R2: A0 B0 (t+2)] [M2: B1(t+2)]; R1's wait retires A1(t) with 6 younger operations in flight, R2's retires
 // A0 B0 B1 (t+1) with 2 (last iteration: 6 2 0 0).  qkv 142.0 -> 135.4 us, fc2 193.8 -> 190.4 at M = 42552 (same box, tools/gemm8_bench.py
 // --sched); also measured, not kept: A1 behind the MFMAs of big phase 1 as well (140.1), the waits moved alone (141.9), the issues in front
-// of their phase's fragment reads (134.0 against 135.1: noise).  In shader cycles the K-loop runs the matrix pipe at ~65 % and the clock sits
-// at ~1.9 GHz under it (32 MFMAs issue in 620-660 s_memtime ticks = 512 cycles): schedule gains come back only in part (DVFS give-back).
+// of their phase's fragment reads (134.0 against 135.1: noise).  In-kernel clock under the loop: 2.12-2.15 GHz (s_memtime / s_memrealtime);
+// a 2-K-tile iteration takes ~7950 cycles against the 4096 of its MFMAs: the matrix pipe is ~50 % busy; inside an MFMA phase the 32 MFMAs
+// issue in 620-660 cycles (512 back to back).
 // DBG (timing ablations, built with -DIG_G8_ABLATE only; results are garbage): 1 = no LDS-DMA inside the loop, 2 = + no fragment
 // reads, 3 = + no barriers, 4 = everything but the epilogue stores.  profiles/r02_v8_ablation_qkv.log: of 71 us (qkv, B = 108)
 // the epilogue is 13.7 (its 33 MB store burst per round sits in front of the next loads in the in-order vmcnt), LDS-DMA 10.2,
@@ -276,6 +279,7 @@ __global__ __launch_bounds__(128 * WC, 2) void gemm8_kernel(G8Params p) {
         g8p_on = blockIdx.x == 0 && g8p_tiles == 2 && it_c <= 1;
         g8p_base = it_c == 0 ? 0 : 16;
         G8P_MARK(g8p_base + 2)
+        if (g8p_base) G8P_REAL(56)
 #endif
         if (!staggered) {  // (re-)establish the stagger: group 1 runs one barrier behind group 0
             if (wr == 1) asm volatile("s_barrier" ::: "memory");
@@ -344,6 +348,9 @@ __global__ __launch_bounds__(128 * WC, 2) void gemm8_kernel(G8Params p) {
             G8P_MARK(g8p_base + 13)
             G8_MFMA2T(1, (g8p_base ? 52 : 60), G8_ISSUE(cB1, false, 1, 1))
             G8P_MARK(g8p_base + 14)
+#ifdef IG_G8_PROF
+            if (g8p_base) G8P_REAL(57)
+#endif
         }
         if (++it_c < per_tile2) continue;
         // ================= tile finished: epilogue (the next tile's first K-tiles are in flight) =================

@@ -72,3 +72,8 @@ print("-- inside the four MFMA phases of the plain iteration: [lgkmcnt done -> b
 for nm, b in (("M1e", 40), ("M2e", 44), ("M1o", 48), ("M2o", 52)):
     row(f"  {nm} wait at opening barrier", b, b + 1)
     row(f"  {nm} 32 MFMAs issued", b + 1, b + 2)
+if t[0, 57] > t[0, 56] > 0:
+    ticks = [int(t[w_, 30] - t[w_, 18]) for w_ in range(8)]
+    real = [int(t[w_, 57] - t[w_, 56]) for w_ in range(8)]
+    print("-- plain iteration: s_memtime ticks / s_memrealtime ticks (100 MHz) -> clock of the s_memtime counter")
+    print("  " + "  ".join(f"{a}/{b} = {a / max(b, 1) / 10:.2f} GHz" for a, b in zip(ticks, real)))
