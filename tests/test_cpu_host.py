@@ -316,3 +316,28 @@ def test_whole_network_custom_op_is_registered_with_a_fake_implementation():
         from instageo_amd.model import network_of
 
         network_of(handle)
+
+
+def test_m0_is_only_written_by_the_lds_dma_helpers():
+    """gemm8.hip / gemm8w.hip / conv8.hip set M0 (the LDS destination of an LDS-DMA) without saving or restoring it.  That is sound only while
+    hipcc keeps nothing of its own in M0 in those kernels: compile each file to gfx950 assembly (no GPU needed) and check that every M0
+    reference is one of the helpers' `s_mov_b32 m0, sN` -- no read of M0, no other writer."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "instageo-e2e-geospatial-ml_amd", "csrc")
+    with tempfile.TemporaryDirectory() as tmp:
+        for name in ("gemm8", "gemm8w", "conv8"):
+            out = os.path.join(tmp, name + ".s")
+            subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(root, "include"), "-DIG_HEADER_STAMP=0", "-S",
+                            "--cuda-device-only", os.path.join(csrc, name + ".hip"), "-o", out], check=True, capture_output=True)
+            refs = [ln.strip() for ln in open(out) if re.search(r"\bm0\b", ln) and not ln.lstrip().startswith(";")]
+            assert refs, name
+            bad = [ln for ln in refs if not re.fullmatch(r"s_mov_b32 m0, s\d+", ln)]
+            assert not bad, (name, bad[:5])
