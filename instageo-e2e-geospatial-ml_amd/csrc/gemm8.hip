@@ -22,7 +22,14 @@
 // * Epilogue: the groups are re-aligned first (both epilogues run concurrently on the SIMD's two waves), the bias is the
 //   accumulator INIT (no epilogue loads), results go through a wave-private 4 KiB LDS staging slab and leave as
 //   row-contiguous 16-byte stores (8 full 128-byte lines per wave-instruction instead of 16 x 32-byte pieces).
-// * NSEG = 3 runs the split-bf16 (hi*hi + hi*lo + lo*hi) precision mode through the same loop.
+// * NSEG = 3 runs the split-bf16 (hi*hi + hi*lo + lo*hi) precision mode through the same loop, one operand pair after the other: three
+//   times the LDS-DMA traffic and fragment reads for three times the MFMAs.
+// * NSEG = 2 ("paired", round 5) is the same precision mode for operands whose lo tensor lies within 4 GiB ABOVE its hi tensor (ops.BT
+//   allocates them as one block): a K-tile covers 32 reduction elements and its 128-byte LDS row is [hi k..k+31 | lo k..k+31] -- the
+//   lanes of one LDS-DMA instruction fetch their 16-byte chunk from hi or lo (the lo lanes carry the tensors' distance in their 32-bit
+//   offset).  The fragment reads are unchanged (k-substep 0 = hi, 1 = lo) and a big phase issues 48 MFMAs (hi hi, hi lo, lo hi) on the
+//   fragments that the plain kernel feeds to 32: twice the traffic and reads of the plain kernel for three times its MFMAs, and an MFMA
+//   phase (768 cycles) that is as long as the other group's read phase (760-970, see SCHED 4) instead of shorter.
 #include <stdlib.h>
 
 #include "common.h"
@@ -125,8 +132,9 @@ __global__ __launch_bounds__(128 * WC, 2) void gemm8_kernel(G8Params p) {
     const int tlo = xcd * qT + min(xcd, rT), tcnt = qT + (xcd < rT ? 1 : 0);
     const int my_tiles = tcnt > jx ? (tcnt - jx + nbx - 1) / nbx : 0;
     if (my_tiles <= 0) return;
-    const int nk = p.K >> 6;         // K-tiles per segment (even: K % 128 == 0)
-    const int per_tile = nk * NSEG;  // K-tiles per output tile
+    constexpr bool PAIR = NSEG == 2;
+    const int nk = PAIR ? p.K >> 5 : p.K >> 6;     // K-tiles per segment (even: K % 128 == 0)
+    const int per_tile = nk * (NSEG == 3 ? 3 : 1);  // K-tiles per output tile
     const int Gtot = my_tiles * per_tile;
     const int lda2 = (int)(p.lda * 2), ldb2 = (int)(p.ldb * 2);
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_char_ptr)smem;
@@ -138,7 +146,10 @@ __global__ __launch_bounds__(128 * WC, 2) void gemm8_kernel(G8Params p) {
     // LDS-DMA lane constants: LDS row of instruction i of this wave = wave*16 + i*8 + (lane >> 3)
     const int rbaseA = ((16 * wave) / (MT * 16)) * (2 * MT * 16) + (16 * wave) % (MT * 16) + (lane >> 3);  // + h*MT*16 + i*8  -> tile row
     const int rbaseB = (wave >> 1) * 64 + (wave & 1) * 16 + (lane >> 3);   // + g*32 + i*8  -> tile column
-    const int c16 = ((lane & 7) ^ (lane >> 3)) << 4;
+    // source chunk of this lane's LDS chunk; paired: chunks 0-3 = hi, 4-7 = lo of the same 32 reduction elements
+    const int sc = (lane & 7) ^ (lane >> 3);
+    const unsigned c16a = PAIR ? (unsigned)((sc & 3) << 4) + (sc >= 4 ? (unsigned)((const char*)p.a[2] - (const char*)p.a[0]) : 0u) : (unsigned)(sc << 4);
+    const unsigned c16b = PAIR ? (unsigned)((sc & 3) << 4) + (sc >= 4 ? (unsigned)((const char*)p.b[1] - (const char*)p.b[0]) : 0u) : (unsigned)(sc << 4);
     const unsigned ldsw = lds_base + wave * 2048;
 
     Cur cA0, cA1, cB0, cB1;
@@ -146,7 +157,7 @@ __global__ __launch_bounds__(128 * WC, 2) void gemm8_kernel(G8Params p) {
 #define G8_REBASE(C, ISA)                                                                   \
     {                                                                                       \
         const int bm_ = (C).tile / tiles_n, bn_ = (C).tile - bm_ * tiles_n;                 \
-        const int s_ = NSEG == 1 ? 0 : (C).seg;                                             \
+        const int s_ = NSEG != 3 ? 0 : (C).seg;                                             \
         if (ISA) {                                                                          \
             const bf16_t* b_ = s_ == 0 ? p.a[0] : s_ == 1 ? p.a[1] : p.a[2];                \
             (C).base = (const char*)b_ + (long)bm_ * BM * lda2;                             \
@@ -168,14 +179,14 @@ __global__ __launch_bounds__(128 * WC, 2) void gemm8_kernel(G8Params p) {
         _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                     \
             int row_ = ((ISA) ? rbaseA + (HG)*(MT * 16) : rbaseB + (HG)*32) + i_ * 8;                          \
             row_ = min(row_, (C).vr - 1);                                                                      \
-            const unsigned voff_ = (unsigned)(__mul24(row_, (ISA) ? lda2 : ldb2) + c16);                       \
+            const unsigned voff_ = (unsigned)__mul24(row_, (ISA) ? lda2 : ldb2) + ((ISA) ? c16a : c16b);       \
             glds16_s(voff_, (C).base, ldsw + (BUF)*G8_BUF + ((ISA) ? 0 : 2 * G8_HALF) + (HG)*G8_HALF + i_ * 1024); \
         }                                                                                                      \
         (C).left--;                                                                                            \
-        (C).base += 128;                                                                                       \
+        (C).base += PAIR ? 64 : 128;                                                                           \
         if (++(C).kt == nk) {                                                                                  \
             (C).kt = 0;                                                                                        \
-            if (NSEG == 1 || ++(C).seg == NSEG) {                                                              \
+            if (NSEG != 3 || ++(C).seg == NSEG) {                                                              \
                 (C).seg = 0;                                                                                   \
                 (C).tile += nbx;                                                                               \
             }                                                                                                  \
@@ -231,6 +242,10 @@ __global__ __launch_bounds__(128 * WC, 2) void gemm8_kernel(G8Params p) {
     // (lgkmcnt(0)), so a half-tile may be refilled in the very next phase
 #define G8_MFMA2(H) G8_MFMA2T(H, 60, )
     // PM: first of three stamp slots of the diagnostic build; TAIL: LDS-DMA issues of this wave placed behind its MFMAs (SCHED 4)
+#define G8_MFMA_TERM(H, T)                                                                                         \
+    _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_) _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_)           \
+        _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_)                                                       \
+            acc[H][g_][nt_][mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g_ ? bf1[nt_][(T) == 1] : bf0[nt_][(T) == 1], af[mt_][(T) == 2], acc[H][g_][nt_][mt_], 0, 0, 0);
 #define G8_MFMA2T(H, PM, TAIL)                                                                                     \
     {                                                                                                              \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
@@ -238,9 +253,17 @@ __global__ __launch_bounds__(128 * WC, 2) void gemm8_kernel(G8Params p) {
         if (DBG != 3) asm volatile("s_barrier" ::: "memory");                                                      \
         G8P_MARK(PM + 1)                                                                                           \
         __builtin_amdgcn_s_setprio(1);                                                                             \
+        if constexpr (PAIR) { /* fragments [0] = hi, [1] = lo: hi hi, lo(B) hi(A), hi(B) lo(A), each term over all 16 accumulators.  (Issuing  \
+            the first term in FRONT of the opening barrier -- behind a sched_barrier, hipcc moves MFMAs across an asm barrier -- to fill   \
+            the pipe behind the other group's last MFMAs: qkv 362 -> 366 us, fc2 443 -> 442: nothing.) */                              \
+            G8_MFMA_TERM(H, 0)                                                                                     \
+            G8_MFMA_TERM(H, 1)                                                                                     \
+            G8_MFMA_TERM(H, 2)                                                                                     \
+        } else {                                                                                                   \
         _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_) _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_)       \
             _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)  \
                 acc[H][g_][nt_][mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g_ ? bf1[nt_][s_] : bf0[nt_][s_], af[mt_][s_], acc[H][g_][nt_][mt_], 0, 0, 0); \
+        }                                                                                                          \
         __builtin_amdgcn_s_setprio(0);                                                                             \
         G8P_MARK(PM + 2)                                                                                           \
         TAIL                                                                                                       \
@@ -573,6 +596,7 @@ __global__ __launch_bounds__(128 * WC, 2) void gemm8_kernel(G8Params p) {
 #undef G8_WAIT
 #undef G8_MFMA2
 #undef G8_MFMA2T
+#undef G8_MFMA_TERM
 #undef G8_WAITN
 #undef G8_READ_A
 #undef G8_READ_B
@@ -654,6 +678,14 @@ int ig_gemm8_nt(const G8Params& p, void* stream) {
     const int grid = ig_tile_grid(ntiles, small ? 2 : 1);
     hipStream_t st = (hipStream_t)stream;
     const bool split_in = p.nseg == 3;
+    // paired form of the split mode (NSEG = 2 in the kernel): both lo tensors must lie above their hi tensors, 16-byte aligned, near enough
+    // for the 32-bit lane offsets (largest: 255 rows + one row + the distance).  IG_G8_PAIR=0: the three-pass form (A/B runs)
+    bool pair = false;
+    if (split_in) {
+        const char* e = getenv("IG_G8_PAIR");
+        const long dA = (const char*)p.a[2] - (const char*)p.a[0], dB = (const char*)p.b[1] - (const char*)p.b[0];
+        pair = (!e || atoi(e) != 0) && dA > 0 && dB > 0 && !(dA & 15) && !(dB & 15) && dA + 257L * p.lda * 2 < (1L << 32) && dB + 257L * p.ldb * 2 < (1L << 32);
+    }
     if (p.kind == 0) {
         const bool split_out = p.out_lo != nullptr;
         const bool dact = p.dact_hi != nullptr;
@@ -664,17 +696,24 @@ int ig_gemm8_nt(const G8Params& p, void* stream) {
             if (!dact) return g8_launch<0, 1, 1, false, false>(p, grid, st, small);
             return g8_launch<0, 1, 1, true, false>(p, grid, st, small);
         }
+        if (pair) {
+            if (p.act == 0) return g8_launch<0, 2, 0, false, true>(p, grid, st, small);
+            if (!dact) return g8_launch<0, 2, 1, false, true>(p, grid, st, small);
+            return g8_launch<0, 2, 1, true, true>(p, grid, st, small);
+        }
         if (p.act == 0) return g8_launch<0, 3, 0, false, true>(p, grid, st, small);
         if (!dact) return g8_launch<0, 3, 1, false, true>(p, grid, st, small);
         return g8_launch<0, 3, 1, true, true>(p, grid, st, small);
     }
     if (p.kind == 1) {
         if (!split_in) return g8_launch<1, 1, 0, false, false>(p, grid, st, small);
+        if (pair) return g8_launch<1, 2, 0, false, false>(p, grid, st, small);
         return g8_launch<1, 3, 0, false, false>(p, grid, st, small);
     }
     if (p.kind == 2) {
         if (!p.dact_hi || (split_in != (p.out_lo != nullptr)) || (split_in != (p.dact_lo != nullptr))) return IG_ERR_UNSUPPORTED;
         if (!split_in) return g8_launch<2, 1, 0, false, false>(p, grid, st, small);
+        if (pair) return g8_launch<2, 2, 0, false, true>(p, grid, st, small);
         return g8_launch<2, 3, 0, false, true>(p, grid, st, small);
     }
     return IG_ERR_UNSUPPORTED;

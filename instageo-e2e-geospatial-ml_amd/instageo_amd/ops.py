@@ -25,14 +25,28 @@ class BT:
         self.hi, self.lo = hi, lo
 
     @staticmethod
+    def _alloc(shape, split: bool, device, zero: bool) -> "BT":
+        """hi [, lo] of one allocation, lo a fixed distance (a multiple of 256 bytes) ABOVE hi: the paired split-mode kernels (gemm8.hip
+        NSEG = 2) fetch a K-tile's hi and lo chunks with ONE LDS-DMA instruction and carry that distance in the lo lanes' 32-bit offsets.
+        Slices of both halves at the same position keep the distance."""
+        make = torch.zeros if zero else torch.empty
+        if not split:
+            return BT(make(shape, dtype=BF16, device=device))
+        shape = tuple(shape) if isinstance(shape, (tuple, list, torch.Size)) else (int(shape),)
+        n = 1
+        for d in shape:
+            n *= int(d)
+        pitch = (n + 127) // 128 * 128
+        buf = make((2 * pitch,), dtype=BF16, device=device)
+        return BT(buf[:n].view(shape), buf[pitch : pitch + n].view(shape))
+
+    @staticmethod
     def empty(shape, split: bool, device) -> "BT":
-        hi = torch.empty(shape, dtype=BF16, device=device)
-        return BT(hi, torch.empty(shape, dtype=BF16, device=device) if split else None)
+        return BT._alloc(shape, split, device, False)
 
     @staticmethod
     def zeros(shape, split: bool, device) -> "BT":
-        hi = torch.zeros(shape, dtype=BF16, device=device)
-        return BT(hi, torch.zeros(shape, dtype=BF16, device=device) if split else None)
+        return BT._alloc(shape, split, device, True)
 
     @staticmethod
     def from_float(x: torch.Tensor, split: bool) -> "BT":

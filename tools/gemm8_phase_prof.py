@@ -3,7 +3,7 @@
 
     IG_HIP_LIB=instageo-e2e-geospatial-ml_amd/instageo_amd/libinstageo_hip_g8prof2.so python tools/gemm8_phase_prof.py [M] [case]
 
-case: qkv (default) | fc1 | proj | fc2.  Prints, per wave of workgroup 0, s_memtime deltas (shader cycles) of: the tile's epilogue,
+case: qkv (default) | fc1 | proj | fc2; --x3: the split precision mode.  Prints, per wave of workgroup 0, s_memtime deltas (shader cycles) of: the tile's epilogue,
 the first iteration (two K-tiles) of the next tile, and a plain mid-tile iteration for comparison.
 """
 import ctypes
@@ -17,21 +17,23 @@ import torch  # noqa: E402
 from instageo_amd import _lib, ops  # noqa: E402
 from instageo_amd.ops import BT  # noqa: E402
 
-M = int(sys.argv[1]) if len(sys.argv) > 1 else 42552
-case = sys.argv[2] if len(sys.argv) > 2 else "qkv"
+split = "--x3" in sys.argv  # the split precision mode (IG_G8_PAIR=0: its three-pass form)
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+M = int(argv[0]) if argv else 42552
+case = argv[1] if len(argv) > 1 else "qkv"
 D = 768
 dev = "cuda"
 N, K, kind = {"qkv": (3 * D, D, "plain"), "fc1": (4 * D, D, "gelu_train"), "proj": (D, D, "resid"), "fc2": (D, 4 * D, "resid")}[case]
-x = BT.from_float(torch.randn(M, K, device=dev), False)
-w = BT.from_float(torch.randn(N, K, device=dev) * K**-0.5, False)
+x = BT.from_float(torch.randn(M, K, device=dev), split)
+w = BT.from_float(torch.randn(N, K, device=dev) * K**-0.5, split)
 bias = torch.randn(N, device=dev)
 if kind == "resid":
     res = torch.randn(M, N, device=dev)
     out = torch.empty_like(res)
     fn = lambda: ops.linear_residual_fwd(x, w, bias, res, out, M, N, K)  # noqa: E731
 else:
-    y = BT.empty((M, N), False, dev)
-    pre = BT.empty((M, N), False, dev) if kind == "gelu_train" else None
+    y = BT.empty((M, N), split, dev)
+    pre = BT.empty((M, N), split, dev) if kind == "gelu_train" else None
     fn = lambda: ops.linear_fwd(x, w, bias, y, M, N, K, act=0 if kind == "plain" else 1, pre=pre)  # noqa: E731
 for _ in range(200):  # clocks settle under load
     fn()
