@@ -26,6 +26,11 @@
 //   arguments, so a plan depends on shapes only (bounded cache, no device allocation per pointer set).
 // * Deterministic: every segment stores its fp32 partial tile to its own slab in the accumulator's own (lane-linear) layout
 //   -- 16-byte coalesced stores, no LDS staging -- and wgrad8_reduce_kernel adds a tile's slabs in slab order.
+// * NSEG = 2 is the split precision mode (bf16x3: hi hi + hi lo + lo hi) in its "paired" form (round 5; the three-pass form it replaces
+//   ran the loop once per operand pair): a K-tile covers 32 tokens and its 64 LDS rows are [hi tokens 0-31 | lo tokens 0-31] -- waves 0-3
+//   fetch from the hi tensors, waves 4-7 the same token rows from the lo tensors (wave-uniform: no address arithmetic per lane), k-substep
+//   0 of the fragment reads is hi, 1 is lo, and a big phase issues its MFMAs three times (hi hi, lo(B) hi(A), hi(B) lo(A)): twice the
+//   LDS-DMA traffic and fragment reads of the plain kernel for three times its MFMAs.
 // * Same barrier / vmcnt protocol as gemm8_kernel (SCHED 4): two big phases per K-tile, the two row groups one
 //   barrier apart, counted vmcnt(6) / vmcnt(2) in front of the issues, the second B half issued behind the MFMAs of big phase 2.
 #include <stdlib.h>
@@ -116,7 +121,7 @@ __device__ __forceinline__ i32x4 w_rsrc(const void* base, unsigned bytes) {
 
 struct WCur {  // issue cursor of one operand (wave-uniform part)
     const char* base;
-    int kt, rows, ld2, seg, pseg, left;
+    int kt, rows, ld2, seg, left;
 };
 struct WRows {  // gathered operand: the two token rows this lane fetches per K-tile (rows krow, krow + 4 of the K-tile)
     int p[2], y[2], x[2], b[2];
@@ -131,6 +136,9 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
     constexpr int ACOLS = 2 * MT * 16;  // columns of an A half actually used (of the 128 in the image)
     constexpr int B1COLS = NT1 * 64;    // columns of the second B half actually used
     constexpr bool MASKED = MODE != 0 || MT != 4 || NT1 != 2;
+    static_assert(NSEG == 1 || NSEG == 2, "gemm8w: plain (1) or paired split (2)");
+    constexpr bool PAIR = NSEG == 2;
+    constexpr int KT = PAIR ? 32 : 64;  // tokens per K-tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -153,7 +161,8 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
 #define W_AOFF(mt_) (k0off + (((((wr * MT) + (mt_)) ^ rkey) << 5) | rlow))
 #define W_BOFF(nt_) (2 * W_HALF + ((nt_) < 2 ? 0 : W_HALF) + k0off + (((((nt_) < 2 ? wc * 2 + (nt_) : wc * NT1 + (nt_)-2) ^ rkey) << 5) | rlow))
     // ---- LDS-DMA lane constants: instruction i of this wave fills token rows wave*8 + i*4 + (lane >> 4) ----
-    const int krow = wave * 8 + (lane >> 4);
+    const int lo_wave = PAIR && wave >= 4 ? 1 : 0;                  // paired: this wave fills the lo rows (32-63) of every half-tile
+    const int krow = (PAIR ? (wave & 3) : wave) * 8 + (lane >> 4);  // token of the K-tile behind LDS row wave*8 + i*4 + (lane >> 4)
     const int dkey = (lane >> 4) | ((wave & 1) << 2);
     const int lch = (lane & 15) ^ (dkey << 1);  // logical source chunk (8 columns) of this lane's physical chunk
     const int lch16 = lch << 4;
@@ -180,30 +189,24 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
     }
 #define W_ADVANCE_ROWS(R)                                                                    \
     _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                       \
-        (R).p[i_] += 64;                                                                     \
-        const int xs_ = (R).x[i_] + 64, q_ = cv.f_w.div(xs_);                                \
+        (R).p[i_] += KT;                                                                     \
+        const int xs_ = (R).x[i_] + KT, q_ = cv.f_w.div(xs_);                                \
         (R).x[i_] = xs_ - __mul24(q_, cv.W);                                                 \
         int y_ = (R).y[i_] + q_;                                                             \
         while (y_ >= cv.H) y_ -= cv.H, (R).b[i_]++;                                          \
         (R).y[i_] = y_;                                                                      \
     }
-    int psegA0 = 0, psegA1 = 0, psegB = 0;  // split-precision pass of each cursor's current segment: 0 hi*hi, 1 hi*lo, 2 lo*hi
-
-    auto rebaseA = [&](WCur& C, WRows& R, int hg, int& pseg) {
+    auto rebaseA = [&](WCur& C, WRows& R, int hg) {
         const WSeg* s_ = my + C.seg;
         const int g_ = s_->g;
-        const int pa_ = NSEG == 1 ? 0 : (C.pseg == 2 ? 1 : 0);
-        C.ld2 = s_->lda2, C.kt = s_->nkt, C.rows = s_->rows;
-        pseg = pa_;
-        C.base = args.a[g_][pa_] + s_->aoff;
+        C.ld2 = s_->lda2, C.kt = s_->nkt * NSEG, C.rows = s_->rows;
+        C.base = args.a[g_][lo_wave] + s_->aoff;
         if constexpr (MASKED) okA[hg] = lch * 8 < ACOLS && hg * ACOLS + lch * 8 < s_->acols;
     };
-    auto rebaseB = [&](WCur& C, WRows& R, int& pseg) {
+    auto rebaseB = [&](WCur& C, WRows& R) {
         const WSeg* s_ = my + C.seg;
         const int g_ = s_->g;
-        const int pb_ = NSEG == 1 ? 0 : (C.pseg == 1 ? 1 : 0);
-        C.ld2 = s_->ldb2, C.kt = s_->nkt, C.rows = s_->rows;
-        pseg = pb_;
+        C.ld2 = s_->ldb2, C.kt = s_->nkt * NSEG, C.rows = s_->rows;
         if constexpr (MODE == 1) {
             C.base = nullptr;
             W_DECODE_ROWS(R, s_->tok0)
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
                 okB[g] = lch * 8 < (g ? B1COLS : 128) && g * 128 + lch * 8 < s_->bcols && tap < 9;
             }
         } else {
-            C.base = args.b[g_][pb_] + s_->boff;
+            C.base = args.b[g_][lo_wave] + s_->boff;
             if constexpr (MASKED) {
 #pragma unroll
                 for (int g = 0; g < 2; ++g) okB[g] = lch * 8 < (g ? B1COLS : 128) && g * 128 + lch * 8 < s_->bcols;
@@ -226,10 +229,10 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
     };
     auto advance = [&](WCur& C) -> bool {  // one K-tile issued; true: the cursor moved to its next segment (rebase)
         C.left--;
-        if (C.base) C.base += (long)C.ld2 << 6;
-        C.rows -= 64;
+        if (C.base) C.base += (long)C.ld2 * KT;
+        C.rows -= KT;
         if (--C.kt == 0) {
-            if (NSEG == 1 || ++C.pseg == NSEG) C.pseg = 0, C.seg++;
+            C.seg++;
             return C.left > 0;
         }
         return false;
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
         // a masked lane (column outside the tile / the half) re-reads the first chunk of the tile's block: every wave must issue both
         // instructions (the counted vmcnt waits rely on it), the address stays inside the tensor, the LDS columns it fills are never used
         const int cb = (!MASKED || ok) ? colbyte + lch16 : 0;
-        if (C.rows >= 64) {
+        if (C.rows >= KT) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) w_glds_s((unsigned)(__mul24(krow + i * 4, C.ld2) + cb), C.base, dst + i * 1024);
         } else {  // ragged tail of the token range: rows past the end come from the zero page
@@ -252,19 +255,19 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
         }
     };
     // A half hg of the cursor's K-tile into buffer buf
-    auto issueA = [&](WCur& C, WRows& R, int hg, int buf, int& pseg) {
+    auto issueA = [&](WCur& C, WRows& R, int hg, int buf) {
         if (C.left <= 0) return;
         const unsigned dst = ldsw + buf * W_BUF + hg * W_HALF;
         issue_plain(C, dst, hg * (ACOLS * 2), okA[hg]);
-        if (advance(C)) rebaseA(C, R, hg, pseg);
+        if (advance(C)) rebaseA(C, R, hg);
     };
     // B half g of the cursor's K-tile into buffer buf; the cursor advances behind half 1 (the halves of a K-tile are issued in two
     // different phases: half 0 in the read phase of big phase 2, half 1 behind that phase's MFMAs -- see the main loop)
-    auto issueB = [&](WCur& C, WRows& R, int buf, int& pseg, int g) {
+    auto issueB = [&](WCur& C, WRows& R, int buf, int g) {
         if (C.left <= 0) return;
         const unsigned dst = ldsw + buf * W_BUF + 2 * W_HALF + g * W_HALF;
         if constexpr (MODE == 1) {
-            const i32x4 rs = (NSEG == 3 && pseg) ? rs_lo : rs_hi;
+            const i32x4 rs = lo_wave ? rs_lo : rs_hi;
             // source pixel of token p = (b, y, x): p itself (sm = 1), or (b, 2y, 2x) of the (2H, 2W) image = 4 p - 2 x (ConvTranspose, sm = 2):
             // shifts and one 32-bit multiply per row (the per-half work is two adds, two compares, a select)
             const int sh = cv.sm - 1, Hs = cv.H << sh, Ws = cv.W << sh;
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
         } else {
             issue_plain(C, dst, g * 256, okB[g]);
         }
-        if (g == 1 && advance(C)) rebaseB(C, R, pseg);
+        if (g == 1 && advance(C)) rebaseB(C, R);
     };
 
     f32x4 acc[2][NTW][MT];  // [h][nt][mt]
@@ -291,18 +294,17 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
 
     // prologue: K-tile 0 complete + A0, B0, B1 of K-tile 1 (the state the steady-state schedule leaves behind)
     cA0.seg = cA1.seg = cB.seg = 0;
-    cA0.pseg = cA1.pseg = cB.pseg = 0;
     cA0.left = cA1.left = cB.left = Gtot;
-    rebaseA(cA0, rA0, 0, psegA0);
-    rebaseA(cA1, rA1, 1, psegA1);
-    rebaseB(cB, rB, psegB);
-    issueA(cA0, rA0, 0, 0, psegA0);
-    issueB(cB, rB, 0, psegB, 0);
-    issueB(cB, rB, 0, psegB, 1);
-    issueA(cA1, rA1, 1, 0, psegA1);
-    issueA(cA0, rA0, 0, 1, psegA0);
-    issueB(cB, rB, 1, psegB, 0);
-    issueB(cB, rB, 1, psegB, 1);
+    rebaseA(cA0, rA0, 0);
+    rebaseA(cA1, rA1, 1);
+    rebaseB(cB, rB);
+    issueA(cA0, rA0, 0, 0);
+    issueB(cB, rB, 0, 0);
+    issueB(cB, rB, 0, 1);
+    issueA(cA1, rA1, 1, 0);
+    issueA(cA0, rA0, 0, 1);
+    issueB(cB, rB, 1, 0);
+    issueB(cB, rB, 1, 1);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
 
@@ -328,9 +330,15 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
         asm volatile("s_barrier" ::: "memory");                                                                   \
         __builtin_amdgcn_s_setprio(1);                                                                            \
+        if constexpr (PAIR) { /* fragments [0] = hi, [1] = lo */                                                   \
+            _Pragma("unroll") for (int t_ = 0; t_ < 3; ++t_) _Pragma("unroll") for (int nt_ = 0; nt_ < NTW; ++nt_)   \
+                _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_)                                              \
+                    acc[H][nt_][mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt_][t_ == 1], af[mt_][t_ == 2], acc[H][nt_][mt_], 0, 0, 0); \
+        } else {                                                                                                  \
         _Pragma("unroll") for (int nt_ = 0; nt_ < NTW; ++nt_) _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_) \
             _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                      \
                 acc[H][nt_][mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt_][s_], af[mt_][s_], acc[H][nt_][mt_], 0, 0, 0); \
+        }                                                                                                         \
         __builtin_amdgcn_s_setprio(0);                                                                            \
         TAIL                                                                                                      \
         asm volatile("s_barrier" ::: "memory");                                                                   \
@@ -356,23 +364,23 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
         W_READ_B(0)
         W_READ_A(0, 0)
         W_WAIT(6, 6)
-        issueA(cA1, rA1, 1, 1, psegA1);
+        issueA(cA1, rA1, 1, 1);
         W_MFMA2(0, )
         W_READ_A(0, 1)
         W_WAIT(2, 2)
-        issueA(cA0, rA0, 0, 0, psegA0);
-        issueB(cB, rB, 0, psegB, 0);
-        W_MFMA2(1, issueB(cB, rB, 0, psegB, 1);)
+        issueA(cA0, rA0, 0, 0);
+        issueB(cB, rB, 0, 0);
+        W_MFMA2(1, issueB(cB, rB, 0, 1);)
         W_READ_B(1)
         W_READ_A(1, 0)
         W_WAIT(6, 0)
-        issueA(cA1, rA1, 1, 0, psegA1);
+        issueA(cA1, rA1, 1, 0);
         W_MFMA2(0, )
         W_READ_A(1, 1)
         W_WAIT(2, 0)
-        issueA(cA0, rA0, 0, 1, psegA0);
-        issueB(cB, rB, 1, psegB, 0);
-        W_MFMA2(1, issueB(cB, rB, 1, psegB, 1);)
+        issueA(cA0, rA0, 0, 1);
+        issueB(cB, rB, 1, 0);
+        W_MFMA2(1, issueB(cB, rB, 1, 1);)
         if (++it_c < seg_iters) continue;
         // ===== segment finished: store the partial tile (the next segment's first K-tiles are in flight) =====
         it_c = 0;
@@ -673,7 +681,7 @@ int w_run(const WKey& key, const std::vector<TileRef>& tl, int M, int lda2_of_g[
         ig_set_error("%s: could not allocate the slab workspace (%ld slabs)", what, pl.nslab);
         return IG_ERR_HIP;
     }
-    if (split) return w_launch<3, MODE, MT, NT1, TRANS>(pl, ws, zp, args, cv, dws, overwrite, st);
+    if (split) return w_launch<2, MODE, MT, NT1, TRANS>(pl, ws, zp, args, cv, dws, overwrite, st);
     return w_launch<1, MODE, MT, NT1, TRANS>(pl, ws, zp, args, cv, dws, overwrite, st);
 }
 
