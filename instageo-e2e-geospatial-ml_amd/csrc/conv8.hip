@@ -138,10 +138,16 @@ __global__ __launch_bounds__(128 * WC, 2) void conv8_kernel(C8Params p) {
     for (int i = 0; i < my_tiles; ++i) {
         int bm_, ph_, bn_;
         C8_DECODE(tlo + jx + i * nbx, bm_, ph_, bn_)
-        Gtot += p.ktab[ph_ * 8] * NSEG;
+        Gtot += p.ktab[ph_ * 8] * NSEG;  // (paired: two K-tiles of 32 per table K-tile of 64)
     }
-    const i32x4 rs_hi = c8_rsrc(p.a[0], p.a_bytes);
+    // NSEG = 2: the split precision mode with PAIRED K-tiles (gemm8.hip): a K-tile covers 32 reduction elements, its 128-byte LDS row is
+    // [hi | lo]; the lo lanes of a DMA instruction add the distance of the lo tensor to their offset.  For the gathered operand that needs
+    // ONE buffer descriptor over both tensors (lo above hi, the host checks the distance), and the "off the image" offset moves above it.
+    constexpr bool PAIR = NSEG == 2;
+    const unsigned dA = PAIR ? (unsigned)((const char*)p.a[1] - (const char*)p.a[0]) : 0u;
+    const i32x4 rs_hi = c8_rsrc(p.a[0], PAIR ? dA + p.a_bytes : p.a_bytes);
     const i32x4 rs_lo = c8_rsrc(NSEG == 3 ? p.a[1] : p.a[0], p.a_bytes);
+    constexpr unsigned OOB = PAIR ? 0xfffffff0u : 0x80000000u;
 
     // fragment read offsets inside a half-tile (k-substep 1: ^ 64)
     const int sw = ((lane >> 4) ^ (lane & 7)) << 4;
@@ -150,7 +156,10 @@ __global__ __launch_bounds__(128 * WC, 2) void conv8_kernel(C8Params p) {
     const int boff1 = OFF_B1 + (wc * NT1 * 16 + (lane & 15)) * 128 + sw;
     // LDS-DMA lane constants
     const int sc = (lane & 7) ^ ((lane >> 3) & 7);  // source chunk of this lane's LDS slot (bank swizzle on the source side)
-    const int c16 = sc << 4;
+    const unsigned c16 = PAIR ? (unsigned)((sc & 3) << 4) + (sc >= 4 ? (unsigned)((const char*)p.b[1] - (const char*)p.b[0]) : 0u) : (unsigned)(sc << 4);
+    const unsigned a_lo_add = PAIR && sc >= 4 ? dA : 0u;
+    const int tsc = PAIR ? (sc & 3) : sc;  // table entry of this lane inside a K-tile's group of TPK entries
+    constexpr int TPK = PAIR ? 4 : 8;
     const unsigned ldsw_a = lds_base + wave * (AI * 1024);
     const unsigned ldsw_b0 = lds_base + OFF_B0 + wave * (NT0 * 1024);
     const unsigned ldsw_b1 = lds_base + OFF_B1 + wave * (NT1 * 1024);
@@ -179,7 +188,7 @@ __global__ __launch_bounds__(128 * WC, 2) void conv8_kernel(C8Params p) {
     {                                                                                                          \
         int bm_, ph_, bn_;                                                                                     \
         C8_DECODE(tlo + jx + (CUR).i * nbx, bm_, ph_, bn_)                                                       \
-        (CUR).nk = phase_nk(ph_), (CUR).toff = __builtin_amdgcn_readfirstlane(phc[ph_ * 8 + 1]);                                        \
+        (CUR).nk = phase_nk(ph_) * (PAIR ? 2 : 1), (CUR).toff = __builtin_amdgcn_readfirstlane(phc[ph_ * 8 + 1]);                     \
         _Pragma("unroll") for (int i_ = 0; i_ < AI; ++i_) {                                                    \
             const int m_ = bm_ * BM + arow[i_] + (HF)*MH;                                                       \
             const int b_ = p.f_hw.div(m_), rem_ = m_ - b_ * (p.H * p.W);                                       \
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(128 * WC, 2) void conv8_kernel(C8Params p) {
     {                                                                                                          \
         int bm_, ph_, bn_;                                                                                     \
         C8_DECODE(tlo + jx + (CUR).i * nbx, bm_, ph_, bn_)                                                       \
-        (CUR).nk = phase_nk(ph_);                                                                                \
+        (CUR).nk = phase_nk(ph_) * (PAIR ? 2 : 1);                                                               \
         (CUR).ldb2 = __builtin_amdgcn_readfirstlane(phc[ph_ * 8 + 2]) * 2;                                       \
         const long bo_ = (long)(unsigned)__builtin_amdgcn_readfirstlane(phc[ph_ * 8 + 3]) |                      \
                          ((long)__builtin_amdgcn_readfirstlane(phc[ph_ * 8 + 4]) << 32);                         \
@@ -212,7 +221,7 @@ __global__ __launch_bounds__(128 * WC, 2) void conv8_kernel(C8Params p) {
 #define C8_ADVANCE(CUR, REBASE)                                       \
     if (++(CUR).kt == (CUR).nk) {                                       \
         (CUR).kt = 0;                                                 \
-        if (NSEG == 1 || ++(CUR).seg == NSEG) (CUR).seg = 0, (CUR).i++;   \
+        if (NSEG != 3 || ++(CUR).seg == NSEG) (CUR).seg = 0, (CUR).i++;   \
         REBASE                                                      \
     }
     // the two LDS-DMA instructions of this wave for A half H of the cursor's K-tile into buffer BUFI
@@ -224,11 +233,11 @@ __global__ __launch_bounds__(128 * WC, 2) void conv8_kernel(C8Params p) {
         const i32x4 rs_ = (NSEG == 3 && (CUR).seg == 2) ? rs_lo : rs_hi;                                         \
         _Pragma("unroll") for (int i_ = 0; i_ < AI; ++i_) {                                                    \
             const bool ok_ = ((CUR).mask[i_] >> bit_) & 1u;                                                      \
-            const unsigned voff_ = ok_ ? (CUR).rowoff[i_] + (unsigned)delta_ : 0x80000000u;                      \
+            const unsigned voff_ = ok_ ? (CUR).rowoff[i_] + (unsigned)delta_ + a_lo_add : OOB;                   \
             c8_blds16(voff_, rs_, ldsw_a + (BUFI)*BUF + (HF)*HALF_A + i_ * 1024);                               \
         }                                                                                                      \
         C8_ADVANCE(CUR, C8_REBASE_A(CUR, HF))                                                                       \
-        (CUR).e = tab[(CUR).toff + (CUR).kt * 8 + sc];                                                               \
+        (CUR).e = tab[(CUR).toff + (CUR).kt * TPK + tsc];                                                            \
     }
     // B pieces of the cursor's K-tile into buffer BUFI in two parts (as gemm8.hip, schedule 4): part 0 in the read phase of big phase 2,
     // part 1 behind that phase's MFMAs.  Only the 256-wide instances (two column halves of two pieces each) move their second half
@@ -239,12 +248,12 @@ __global__ __launch_bounds__(128 * WC, 2) void conv8_kernel(C8Params p) {
     if ((CUR).i < my_tiles) {                                                                                  \
         if ((PART) == 0) {                                                                                     \
             _Pragma("unroll") for (int i_ = 0; i_ < NT0; ++i_)                                                 \
-                c8_glds16_s((unsigned)(__mul24(min(bcol0[i_], (CUR).vr - 1), (CUR).ldb2) + c16), (CUR).base, ldsw_b0 + (BUFI)*BUF + i_ * 1024); \
+                c8_glds16_s((unsigned)__mul24(min(bcol0[i_], (CUR).vr - 1), (CUR).ldb2) + c16, (CUR).base, ldsw_b0 + (BUFI)*BUF + i_ * 1024); \
         }                                                                                                      \
         if ((PART) == (B_TAIL ? 1 : 0)) {                                                                      \
             _Pragma("unroll") for (int i_ = 0; i_ < NT1; ++i_)                                                 \
-                c8_glds16_s((unsigned)(__mul24(min(bcol1[i_], (CUR).vr - 1), (CUR).ldb2) + c16), (CUR).base, ldsw_b1 + (BUFI)*BUF + i_ * 1024); \
-            (CUR).base += 128;                                                                                 \
+                c8_glds16_s((unsigned)__mul24(min(bcol1[i_], (CUR).vr - 1), (CUR).ldb2) + c16, (CUR).base, ldsw_b1 + (BUFI)*BUF + i_ * 1024); \
+            (CUR).base += PAIR ? 64 : 128;                                                                     \
             C8_ADVANCE(CUR, C8_REBASE_B(CUR))                                                                  \
         }                                                                                                      \
     }
@@ -267,7 +276,7 @@ __global__ __launch_bounds__(128 * WC, 2) void conv8_kernel(C8Params p) {
     C8_REBASE_A(cA0, 0)
     C8_REBASE_A(cA1, 1)
     C8_REBASE_B(cB)
-    cA0.e = tab[cA0.toff + sc];
+    cA0.e = tab[cA0.toff + tsc];
     cA1.e = cA0.e;
     C8_ISSUE_A(cA0, 0, 0)
     C8_ISSUE_B(cB, 0, 0)
@@ -294,9 +303,15 @@ __global__ __launch_bounds__(128 * WC, 2) void conv8_kernel(C8Params p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
         asm volatile("s_barrier" ::: "memory");                                                                 \
         __builtin_amdgcn_s_setprio(1);                                                                          \
+        if constexpr (PAIR) { /* fragments [0] = hi, [1] = lo: hi hi, lo(B) hi(A), hi(B) lo(A) */                 \
+            _Pragma("unroll") for (int t_ = 0; t_ < 3; ++t_) _Pragma("unroll") for (int nt_ = 0; nt_ < NTW; ++nt_) \
+                _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_)                                            \
+                    acc[HF][nt_][mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt_][t_ == 1], af[mt_][t_ == 2], acc[HF][nt_][mt_], 0, 0, 0); \
+        } else {                                                                                                \
         _Pragma("unroll") for (int nt_ = 0; nt_ < NTW; ++nt_) _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_) \
             _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                    \
                 acc[HF][nt_][mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt_][s_], af[mt_][s_], acc[HF][nt_][mt_], 0, 0, 0); \
+        }                                                                                                       \
         __builtin_amdgcn_s_setprio(0);                                                                          \
         TAIL                                                                                                    \
         asm volatile("s_barrier" ::: "memory");                                                                 \
@@ -577,7 +592,15 @@ int c8_launch(const C8Params& p, int grid, hipStream_t st) {
 
 template <int WC, int MT, int NT0, int NT1>
 int c8_launch_seg(const C8Params& p, int grid, hipStream_t st) {
-    if (p.a[1]) return c8_launch<WC, MT, NT0, NT1, 3, true>(p, grid, st);
+    if (p.a[1]) {
+        // paired K-tiles when one buffer descriptor can span hi and lo of the gathered tensor (ops.BT allocates them as one block; the packed
+        // weights always are); IG_G8_PAIR=0: the three-pass form (A/B runs)
+        const char* e = getenv("IG_G8_PAIR");
+        const long dA = (const char*)p.a[1] - (const char*)p.a[0], dB = (const char*)p.b[1] - (const char*)p.b[0];
+        const bool pair = (!e || atoi(e) != 0) && dA > 0 && dB > 0 && !(dA & 15) && !(dB & 15) && dA + (long)p.a_bytes < 0xfffffff0L && dB + (1L << 24) < (1L << 32);
+        if (pair) return c8_launch<WC, MT, NT0, NT1, 2, true>(p, grid, st);
+        return c8_launch<WC, MT, NT0, NT1, 3, true>(p, grid, st);
+    }
     return c8_launch<WC, MT, NT0, NT1, 1, false>(p, grid, st);
 }
 
