@@ -25,6 +25,9 @@ int ig_check_launch(const char* what);
 int ig_conv3x3_direct(const void* x, const void* w, const float* bias, const float* bn_scale, const float* bn_shift, void* y,
                       int B, int H, int W, int Cin, int Cout, int dgrad, unsigned drop_seed, const unsigned* drop_seed_dev,
                       float drop_p, void* stream, double* stat_sums = nullptr, int* stats_fused = nullptr);
+int ig_conv3x3_direct_split(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias, const float* bn_scale,
+                            const float* bn_shift, void* y_hi, void* y_lo, int B, int H, int W, int Cin, int Cout, int dgrad, unsigned drop_seed,
+                            const unsigned* drop_seed_dev, float drop_p, void* stream, double* stat_sums = nullptr, int* stats_fused = nullptr);
 int ig_conv3x3_cls_direct(const void* x, const void* w, const float* bias, const float* bn_scale, const float* bn_shift, void* y,
                           const float* cls_w, const float* cls_b, float* logits, int B, int H, int W, int C, int ncls, void* stream);
 int ig_convT_fwd_direct(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,

@@ -386,6 +386,281 @@ int launch_direct(CDParams p, hipStream_t st, const char* what, double* stat_sum
     return ig_check_launch(what);
 }
 
+// ---- split precision (bf16x3) form of conv3x3_direct_kernel, C = 48 -----------------------------------------------------------------
+// The split mode ran this stage on the implicit GEMM (2.4-2.7 ms per launch at 216 x 224 x 224 x 48: a 48-wide output fills 37 % of its
+// 128-wide tiles, and the three operand pairs were three passes).  Here the hi AND lo images of the weights (2 x 43.5 KiB) and of the
+// halo (2 x 30.4 KiB) sit in LDS -- 148 KiB, one 8-wave workgroup per CU, a wave owns 2 rows of the 16 x 16 tile -- and every fragment
+// pair feeds three MFMAs (hi hi, lo(w) hi(x), hi(w) lo(x); lo lo is dropped as in every split GEMM here); the epilogue stores hi and lo.
+// Everything else (halo prefetch through registers two tiles ahead, channel interleave for 16-byte stores, fused BatchNorm statistics of
+// the STORED value hi + lo, the data-gradient form with the weights gathered transposed and flipped) follows the plain kernel.
+struct CDSplit {
+    const bf16_t *x_lo, *w_lo;
+    bf16_t* y_lo;
+};
+
+template <int C>
+__global__ __launch_bounds__(512, 1) void conv3x3_direct_split_kernel(CDParams p, CDSplit q) {
+    using G = CDCfg<C>;
+    constexpr int TPB = 512, NWV = 8, RPW = TH / NWV;
+    constexpr int ROUNDS = (G::HUNITS + TPB - 1) / TPB;
+    constexpr int HSTR = G::H_BYTES + 16;  // halo image + its zero slot
+    constexpr int PAR_OFF = 2 * G::W_BYTES + 2 * HSTR;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* wl0 = smem;
+    char* wl1 = smem + G::W_BYTES;
+    char* hal0 = smem + 2 * G::W_BYTES;
+    char* hal1 = hal0 + HSTR;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t drop_seed = p.drop_seed;
+    if (p.drop_seed_dev) drop_seed += *p.drop_seed_dev;
+
+    for (int i = tid; i < PAR_OFF / 16; i += TPB) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const bf16_t* wsrc = half ? q.w_lo : p.w;
+        char* wl = half ? wl1 : wl0;
+        if (!p.dgrad) {
+            for (int u = tid; u < C * G::KG; u += TPB) {
+                const int co = u / G::KG, g = u - co * G::KG;
+                *reinterpret_cast<uint4*>(wl + G::pos_of(co) * G::WP + g * 16) = *reinterpret_cast<const uint4*>(wsrc + ((size_t)co * G::KG + g) * 8);
+            }
+        } else {  // W'[ci][tap'][co] = Wc[co][8 - tap'][ci]
+            for (int u = tid; u < C * G::KG; u += TPB) {
+                const int co = u / G::KG, gk = u - co * G::KG;
+                const int tap = gk / G::UNITS, ci0 = (gk - tap * G::UNITS) * 8;
+                const uint4 v = *reinterpret_cast<const uint4*>(wsrc + ((size_t)co * G::KG + gk) * 8);
+                const uint32_t qv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    reinterpret_cast<bf16_t*>(wl + G::pos_of(ci0 + i) * G::WP)[(8 - tap) * C + co] = (bf16_t)(qv[i >> 1] >> ((i & 1) * 16));
+            }
+        }
+    }
+    float* par = reinterpret_cast<float*>(smem + PAR_OFF);
+    for (int c = tid; c < C; c += TPB) {
+        par[c] = p.bias ? p.bias[c] : 0.f;
+        par[C + c] = p.col_scale ? p.col_scale[c] : 1.f;
+        par[2 * C + c] = p.col_scale ? p.col_shift[c] : 0.f;
+    }
+    const bool has_bn = p.col_scale != nullptr;
+
+    int h_goff[ROUNDS], h_yx[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int u = r * TPB + tid;
+        const int hp = u / G::UNITS, c8 = u - hp * G::UNITS;
+        const int hy = hp / HW_, hx = hp - hy * HW_;
+        h_goff[r] = (hy * p.W + hx) * C + c8 * 8;
+        h_yx[r] = u < G::HUNITS ? ((hy - 1) << 16) | ((hx - 1) & 0xffff) : 0x7fff0000;
+    }
+    const int g = lane >> 4, j = lane & 15;
+    int offk[G::KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < G::KSTEPS; ++ks) {
+        const int kg = ks * 4 + g;
+        const int tap = kg / G::UNITS, cg = kg - tap * G::UNITS;
+        const int dy = tap / 3, dx = tap - dy * 3;
+        offk[ks] = (dy * HW_ + dx) * G::PP + cg * 16;
+    }
+    const int pix_lane = ((wave * RPW) * HW_ + j) * G::PP;
+    const int zero_slot = G::H_BYTES;
+    const int w_lane = j * G::WP + g * 16;
+
+    auto tile_coords = [&](int t, int& b, int& ty0, int& tx0) {
+        const int per_img = p.tiles_x * p.tiles_y;
+        b = t / per_img;
+        const int r = t - b * per_img;
+        const int ty = r / p.tiles_x;
+        ty0 = ty * TH, tx0 = (r - ty * p.tiles_x) * TW;
+    };
+    uint4 pre0[ROUNDS], pre1[ROUNDS];
+    auto fetch = [&](int t) {
+        int b, ty0, tx0;
+        tile_coords(t, b, ty0, tx0);
+        const long org = (((long)b * p.H + ty0 - 1) * p.W + tx0 - 1) * C;  // halo origin (may lie outside: masked)
+        const bf16_t *b0 = p.x + org, *b1 = q.x_lo + org;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int gy = ty0 + (h_yx[r] >> 16), gx = tx0 + (int)(short)(h_yx[r] & 0xffff);
+            const bool ok = ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
+            pre0[r] = pre1[r] = make_uint4(0, 0, 0, 0);
+            if (ok) pre0[r] = *reinterpret_cast<const uint4*>(b0 + h_goff[r]), pre1[r] = *reinterpret_cast<const uint4*>(b1 + h_goff[r]);
+        }
+    };
+    auto halo_to_lds = [&]() {
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r)
+            if (r * TPB + tid < G::HUNITS) {
+                *reinterpret_cast<uint4*>(hal0 + (r * TPB + tid) * 16) = pre0[r];
+                *reinterpret_cast<uint4*>(hal1 + (r * TPB + tid) * 16) = pre1[r];
+            }
+    };
+    auto finish4 = [&](f32x4 a, int n, size_t idx, float* v) {
+        const float4 bb = *reinterpret_cast<const float4*>(par + n);
+        v[0] = a[0] + bb.x, v[1] = a[1] + bb.y, v[2] = a[2] + bb.z, v[3] = a[3] + bb.w;
+        if (has_bn) {
+            const float4 sc = *reinterpret_cast<const float4*>(par + C + n);
+            const float4 sh = *reinterpret_cast<const float4*>(par + 2 * C + n);
+            v[0] = fmaxf(v[0] * sc.x + sh.x, 0.f), v[1] = fmaxf(v[1] * sc.y + sh.y, 0.f);
+            v[2] = fmaxf(v[2] * sc.z + sh.z, 0.f), v[3] = fmaxf(v[3] * sc.w + sh.w, 0.f);
+        }
+        if (p.drop_thresh) {
+            float mk[4];
+            dropout_scale4(drop_seed, (uint32_t)idx, p.drop_thresh, p.drop_inv, mk);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] *= mk[i];
+        }
+    };
+    constexpr int NS = G::NPAIR * 8 + (G::NB & 1) * 4;
+    float st_s[NS], st_q[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) st_s[k] = 0.f, st_q[k] = 0.f;
+    const bool want_stats = p.stats_part != nullptr;
+    const int e_lane = ((wave * RPW) * p.W + j) * C;
+    const int nt = (int)p.ntiles, gstep = (int)gridDim.x;
+    int t = xcd_first_tile();
+    if (t < nt) {
+        fetch(t);
+        halo_to_lds();
+        if (t + gstep < nt) fetch(t + gstep);
+    }
+    __syncthreads();
+    for (; t < nt; t += gstep) {
+        int b, ty0, tx0;
+        tile_coords(t, b, ty0, tx0);
+        const int tn = t + gstep, tnn = tn + gstep;
+        f32x4 acc[G::NB][RPW];
+#pragma unroll
+        for (int nb = 0; nb < G::NB; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < RPW; ++mb) acc[nb][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < G::KSTEPS; ++ks) {
+            bf16x8_t wf0[G::NB], wf1[G::NB], pf0[RPW], pf1[RPW];
+            const bool padded = G::KG % 4 != 0 && ks == G::KSTEPS - 1 && g >= G::KG % 4;  // these k-groups read zeros
+            const int po = padded ? zero_slot : pix_lane + offk[ks];
+#pragma unroll
+            for (int nb = 0; nb < G::NB; ++nb) {
+                wf0[nb] = *reinterpret_cast<const bf16x8_t*>(wl0 + w_lane + nb * 16 * G::WP + ks * 64);
+                wf1[nb] = *reinterpret_cast<const bf16x8_t*>(wl1 + w_lane + nb * 16 * G::WP + ks * 64);
+            }
+#pragma unroll
+            for (int mb = 0; mb < RPW; ++mb) {
+                pf0[mb] = *reinterpret_cast<const bf16x8_t*>(hal0 + (padded ? po : po + mb * HW_ * G::PP));
+                pf1[mb] = *reinterpret_cast<const bf16x8_t*>(hal1 + (padded ? po : po + mb * HW_ * G::PP));
+            }
+#pragma unroll
+            for (int nb = 0; nb < G::NB; ++nb)
+#pragma unroll
+                for (int mb = 0; mb < RPW; ++mb) {
+                    acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[nb], pf0[mb], acc[nb][mb], 0, 0, 0);
+                    acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[nb], pf0[mb], acc[nb][mb], 0, 0, 0);
+                    acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[nb], pf1[mb], acc[nb][mb], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        if (tn < nt) halo_to_lds();
+        __syncthreads();
+        if (tnn < nt) fetch(tnn);
+
+        const int ox = tx0 + j;
+        const size_t origin = (((size_t)b * p.H + ty0) * p.W + tx0) * C;
+#pragma unroll
+        for (int mb = 0; mb < RPW; ++mb) {
+            const int oy = ty0 + wave * RPW + mb;
+            if (oy < p.H && ox < p.W) {
+                const size_t pixc = origin + (unsigned)(e_lane + mb * p.W * C);
+#pragma unroll
+                for (int pr = 0; pr < G::NPAIR; ++pr) {
+                    const int n = pr * 32 + 8 * g;
+                    const size_t idx = pixc + n;
+                    float v[8], r[8], d[8];
+                    finish4(acc[2 * pr][mb], n, idx, v);
+                    finish4(acc[2 * pr + 1][mb], n + 4, idx + 4, v + 4);
+                    const uint4 pk = pack8(v);
+                    unpack8(pk, r);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) d[i] = v[i] - r[i];
+                    const uint4 pl = pack8(d);
+                    *reinterpret_cast<uint4*>(p.y + idx) = pk;
+                    *reinterpret_cast<uint4*>(q.y_lo + idx) = pl;
+                    if (want_stats) {
+                        unpack8(pl, d);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const float sv = r[i] + d[i];
+                            st_s[pr * 8 + i] += sv, st_q[pr * 8 + i] = fmaf(sv, sv, st_q[pr * 8 + i]);
+                        }
+                    }
+                }
+                if (G::NB & 1) {
+                    const int n = (G::NB - 1) * 16 + 4 * g;
+                    const size_t idx = pixc + n;
+                    float v[4];
+                    finish4(acc[G::NB - 1][mb], n, idx, v);
+                    store4_split(p.y, q.y_lo, idx, v);
+                    if (want_stats) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float hi = bf2f(f2bf(v[i])), sv = hi + bf2f(f2bf(v[i] - hi));
+                            st_s[G::NPAIR * 8 + i] += sv, st_q[G::NPAIR * 8 + i] = fmaf(sv, sv, st_q[G::NPAIR * 8 + i]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (want_stats) {  // lanes j of a k-group -> wave -> workgroup, all in a fixed order (the tile schedule is static too)
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) st_s[k] += __shfl_xor(st_s[k], o, 64), st_q[k] += __shfl_xor(st_q[k], o, 64);
+        }
+        __syncthreads();  // the halo buffers are dead
+        float* red = reinterpret_cast<float*>(hal0);  // [wave][g][NS][2]
+        if (j == 0) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) red[((wave * 4 + g) * NS + k) * 2] = st_s[k], red[((wave * 4 + g) * NS + k) * 2 + 1] = st_q[k];
+        }
+        __syncthreads();
+        for (int c = tid; c < C; c += TPB) {
+            int gg, k;
+            if (c < G::NPAIR * 32) gg = (c % 32) / 8, k = (c / 32) * 8 + c % 8;
+            else gg = (c - (G::NB - 1) * 16) / 4, k = G::NPAIR * 8 + (c - (G::NB - 1) * 16) % 4;
+            float ss = 0.f, qq = 0.f;
+            for (int w = 0; w < NWV; ++w) ss += red[((w * 4 + gg) * NS + k) * 2], qq += red[((w * 4 + gg) * NS + k) * 2 + 1];
+            p.stats_part[(size_t)blockIdx.x * 2 * C + c] = ss;
+            p.stats_part[(size_t)blockIdx.x * 2 * C + C + c] = qq;
+        }
+    }
+}
+
+template <int C>
+int launch_direct_split(CDParams p, CDSplit q, hipStream_t st, const char* what, double* stat_sums) {
+    using G = CDCfg<C>;
+    constexpr int smem = 2 * G::W_BYTES + 2 * (G::H_BYTES + 16) + 3 * C * 4;
+    static_assert(smem <= 160 * 1024, "hi + lo images must fit the LDS");
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_direct_split_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    long nwg = ig_cu_count();  // one persistent workgroup per CU
+    if (nwg > p.ntiles) nwg = p.ntiles;
+    if (stat_sums) {
+        p.stats_part = (float*)ig_scratch(0, (size_t)nwg * 2 * C * sizeof(float));
+        if (!p.stats_part) {
+            ig_set_error("%s: scratch allocation failed", what);
+            return IG_ERR_HIP;
+        }
+    }
+    ig_note_kernel("conv3x3_direct_split_kernel<%d>", C);
+    hipLaunchKernelGGL((conv3x3_direct_split_kernel<C>), dim3((unsigned)nwg), dim3(512), smem, st, p, q);
+    if (stat_sums) hipLaunchKernelGGL(bn_part_fold_kernel, dim3(ig_cdiv(2 * C, 64)), dim3(1024), 0, st, p.stats_part, stat_sums, (int)nwg, 2 * C);
+    return ig_check_launch(what);
+}
+
 // ---------------------------------------------------------------------------------------------- weight gradient
 
 // dWc[co][tap][ci] += sum_pixels dy[p][co] * x[p + off(tap)][ci] for the 48- and 96-channel stages.  The implicit GEMM needs
@@ -1362,6 +1637,32 @@ int ig_conv3x3_direct(const void* x, const void* w, const float* bias, const flo
     const bool st = stat_sums && stats_fused && !dgrad;
     if (st) *stats_fused = 1;
     return launch_direct<48>(p, (hipStream_t)stream, dgrad ? "ig_conv3x3_dgrad(direct)" : "ig_conv3x3_fwd(direct)", st ? stat_sums : nullptr);
+}
+
+// Split precision form (all of x, w, y as hi + lo pairs) of ig_conv3x3_direct: the 48-channel stage only (the hi + lo images of the
+// 96-channel stage do not fit the LDS); IG_ERR_UNSUPPORTED (no error string) otherwise.
+int ig_conv3x3_direct_split(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias, const float* bn_scale,
+                            const float* bn_shift, void* y_hi, void* y_lo, int B, int H, int W, int Cin, int Cout, int dgrad, unsigned drop_seed,
+                            const unsigned* drop_seed_dev, float drop_p, void* stream, double* stat_sums, int* stats_fused) {
+    if (stats_fused) *stats_fused = 0;
+    static const int enabled = getenv("IG_CONV_DIRECT") ? atoi(getenv("IG_CONV_DIRECT")) : 1;
+    if (!enabled || Cin != Cout || Cin != 48 || !x_lo || !w_lo || !y_lo) return IG_ERR_UNSUPPORTED;
+    if ((long)B * H * W * Cin >= (1L << 31)) return IG_ERR_UNSUPPORTED;  // 32-bit halo offsets
+    CDParams p{};
+    p.x = (const bf16_t*)x_hi, p.w = (const bf16_t*)w_hi, p.y = (bf16_t*)y_hi;
+    p.bias = bias, p.col_scale = bn_scale, p.col_shift = bn_shift;
+    p.B = B, p.H = H, p.W = W;
+    p.tiles_x = (W + TW - 1) / TW, p.tiles_y = (H + TH - 1) / TH;
+    p.ntiles = (long)B * p.tiles_x * p.tiles_y;
+    p.dgrad = dgrad;
+    p.drop_seed = drop_seed, p.drop_seed_dev = drop_seed_dev;
+    p.drop_thresh = ig_drop_thresh16(drop_p);
+    p.drop_inv = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    if (p.ntiles == 0) return IG_OK;
+    const CDSplit q{(const bf16_t*)x_lo, (const bf16_t*)w_lo, (bf16_t*)y_lo};
+    const bool st = stat_sums && stats_fused && !dgrad;
+    if (st) *stats_fused = 1;
+    return launch_direct_split<48>(p, q, (hipStream_t)stream, dgrad ? "ig_conv3x3_dgrad(direct, split)" : "ig_conv3x3_fwd(direct, split)", st ? stat_sums : nullptr);
 }
 
 // Called by ig_conv3x3_wgrad (gemm.hip); IG_ERR_UNSUPPORTED when the shape is not covered.

@@ -1876,6 +1876,9 @@ int ig_conv3x3_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const v
     if (!x_lo && !y_lo) {  // narrow last stage: halo-tile direct convolution (conv_direct.hip)
         const int rc = ig_conv3x3_direct(x_hi, w_hi, bias, bn_scale, bn_shift, y_hi, B, H, W, Cin, Cout, 0, 0, nullptr, 0.f, stream);
         if (rc != IG_ERR_UNSUPPORTED) return rc;
+    } else if (x_lo && y_lo) {  // the same stage with split operands
+        const int rc = ig_conv3x3_direct_split(x_hi, x_lo, w_hi, w_lo, bias, bn_scale, bn_shift, y_hi, y_lo, B, H, W, Cin, Cout, 0, 0, nullptr, 0.f, stream);
+        if (rc != IG_ERR_UNSUPPORTED) return rc;
     }
     {  // wide stages: implicit GEMM on the 8-phase schedule with gathering LDS-DMA (conv8.hip)
         const int rc = ig_conv8(0, 1, x_hi, x_lo, w_hi, w_lo, bias, bn_scale, bn_shift, y_hi, y_lo, B, H, W, Cin, Cout, 0, nullptr, 0.f, stream);
@@ -1903,6 +1906,9 @@ int ig_conv3x3_fwd_stats(const void* x_hi, const void* x_lo, const void* w_hi, c
     *fused = 0;
     if (!x_lo && !y_lo && Cin % 8 == 0 && Cout % 8 == 0 && (x_lo == nullptr) == (w_lo == nullptr)) {
         const int rc = ig_conv3x3_direct(x_hi, w_hi, bias, nullptr, nullptr, y_hi, B, H, W, Cin, Cout, 0, 0, nullptr, 0.f, stream, sums, fused);
+        if (rc != IG_ERR_UNSUPPORTED) return rc;
+    } else if (x_lo && w_lo && y_lo && Cin % 8 == 0 && Cout % 8 == 0) {
+        const int rc = ig_conv3x3_direct_split(x_hi, x_lo, w_hi, w_lo, bias, nullptr, nullptr, y_hi, y_lo, B, H, W, Cin, Cout, 0, 0, nullptr, 0.f, stream, sums, fused);
         if (rc != IG_ERR_UNSUPPORTED) return rc;
     }
     *fused = 0;
@@ -1936,6 +1942,10 @@ int ig_conv3x3_dgrad(const void* dy_hi, const void* dy_lo, const void* w_hi, con
     if (!dy_lo && !dx_lo) {
         const int rc = ig_conv3x3_direct(dy_hi, w_hi, nullptr, nullptr, nullptr, dx_hi, B, H, W, Cin, Cout, 1, drop_seed, drop_seed_dev,
                                          drop_p, stream);
+        if (rc != IG_ERR_UNSUPPORTED) return rc;
+    } else if (dy_lo && dx_lo) {
+        const int rc = ig_conv3x3_direct_split(dy_hi, dy_lo, w_hi, w_lo, nullptr, nullptr, nullptr, dx_hi, dx_lo, B, H, W, Cin, Cout, 1, drop_seed,
+                                               drop_seed_dev, drop_p, stream);
         if (rc != IG_ERR_UNSUPPORTED) return rc;
     }
     {
