@@ -683,7 +683,9 @@ int ig_conv8(int kind, int sign, const void* x_hi, const void* x_lo, const void*
         const double util = (double)N / ((double)tn * s.bn);  // ragged last column tile: dead MFMA columns
         // ragged last column tile: N = 144 on one 192-wide tile pays (measured); 288 on two does not; the 128-wide instance never does
         // (N = 96 on it: 3360 vs 2192 us in the split mode, 797 vs 610 us plain)
-        if (util < (env == 2 ? 0.5 : s.bn == 128 ? 1.0 : tn == 1 ? 0.74 : 0.80)) continue;
+        // (split mode, paired K-tiles: N = 96 on the 128-wide instance now beats the round-1 engine -- bf16x3 step + 0.7 % together with the
+        // ConvTranspose rule below)
+        if (util < (env == 2 ? 0.5 : s.bn == 128 ? (w_lo ? 0.74 : 1.0) : tn == 1 ? 0.74 : 0.80)) continue;
         if ((w_lo ? s.lds3 : s.lds) + (tent + 32) * 4 > 160 * 1024) continue;
         const long tiles = (M + s.bm - 1) / s.bm * tn * pl.nphase;
         const long rounds = (tiles + slots - 1) / slots;
@@ -701,7 +703,7 @@ int ig_conv8(int kind, int sign, const void* x_hi, const void* x_lo, const void*
     // long reductions and many tiles (768 -> 384 at B = 216, 1152 -> 576, 576 -> 288) and at the widths the round-1 tiles fit badly
     // (N = 144).
     if (kind == 1 && env != 2) {
-        const bool pays = ntiles >= 4L * slots && sh.bn >= 192 && (C >= 512 || (N % 64) != 0);
+        const bool pays = ntiles >= 4L * slots && (sh.bn >= 192 || w_lo) && (C >= 512 || (N % 64) != 0);
         if (!pays) return IG_ERR_UNSUPPORTED;
     }
     if (ntiles >= (1L << 30)) return IG_ERR_UNSUPPORTED;
