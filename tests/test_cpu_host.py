@@ -341,3 +341,25 @@ def test_m0_is_only_written_by_the_lds_dma_helpers():
             assert refs, name
             bad = [ln for ln in refs if not re.fullmatch(r"s_mov_b32 m0, s\d+", ln)]
             assert not bad, (name, bad[:5])
+
+
+def test_split_tensors_are_one_allocation_with_lo_above_hi():
+    """ops.BT allocates hi and lo of a split tensor as ONE block, lo a fixed multiple of 256 bytes above hi, and slices taken at the same
+    position keep that distance: the paired split-mode kernels (gemm8.hip / conv8.hip NSEG = 2) carry it in the lo lanes' 32-bit offsets."""
+    import torch
+    from instageo_amd.ops import BT
+
+    for shape in [(7,), (5, 3), (1000, 768), (2, 3, 5, 48)]:
+        for make in (BT.empty, BT.zeros):
+            t = make(shape, True, "cpu")
+            assert t.hi.shape == torch.Size(shape) and t.lo.shape == t.hi.shape and t.hi.is_contiguous() and t.lo.is_contiguous()
+            d = t.lo.data_ptr() - t.hi.data_ptr()
+            assert d >= t.hi.numel() * 2 and d % 256 == 0
+            assert t.hi.untyped_storage().data_ptr() == t.lo.untyped_storage().data_ptr()
+            flat = BT(t.hi.reshape(-1), t.lo.reshape(-1))
+            assert flat.lo[3:].data_ptr() - flat.hi[3:].data_ptr() == d
+        z = BT.zeros(shape, True, "cpu")
+        assert not z.hi.any() and not z.lo.any()
+        z.hi.fill_(1)
+        assert not z.lo.any()  # the halves do not overlap
+    assert BT.empty((4, 4), False, "cpu").lo is None

@@ -835,6 +835,99 @@ def test_direct_head_kernels_at_model_size_vs_float64(kind, C, H):
     close(db, dyr.sum((0, 1, 2)), 3e-5, what=f"{kind} bias gradient")
 
 
+def test_split_direct_conv48_and_its_fused_statistics():
+    """The split-precision (bf16x3) form of the 48-channel stage (conv_direct.hip conv3x3_direct_split_kernel: hi + lo images of weights and
+    halo in LDS): forward with eval-mode BatchNorm + ReLU folded in, data gradient with the dropout mask, and the training-mode form whose
+    epilogue leaves the BatchNorm sums of the STORED hi + lo values; ragged tile edges; float64 references at the split tolerance."""
+    C, B, H, W = 48, 3, 21, 37
+    x, xr = bt(nhwc(rnd(B, C, H, W, seed=70)), True)
+    w, wr = bt(rnd(C, C, 3, 3, seed=71, scale=(9 * C) ** -0.5).permute(0, 2, 3, 1).reshape(C, 9, C).contiguous(), True)
+    bias, sc, sh = rnd(C, seed=72), 1 + 0.2 * rnd(C, seed=73), 0.3 * rnd(C, seed=74)
+    wt = wr.reshape(C, 3, 3, C).permute(0, 3, 1, 2)
+    conv = F.conv2d(xr.permute(0, 3, 1, 2), wt, bias.double(), padding=1)
+    y = BT.empty((B, H, W, C), True, DEV)
+    ops.conv3x3_fwd(x, w, bias.to(DEV), y, B, H, W, C, C, bn_scale=sc.float().to(DEV), bn_shift=sh.float().to(DEV))
+    assert ops.last_kernel().startswith("conv3x3_direct_split_kernel"), ops.last_kernel()
+    ref = torch.relu(conv * sc.double().view(1, C, 1, 1) + sh.double().view(1, C, 1, 1))
+    close(y.float(), nhwc(ref), tol_out(True), what="split direct conv + bn fold")
+    # training form: plain convolution + the statistics of what was stored
+    sums = torch.full((2 * C,), -1.0, dtype=torch.float64, device=DEV)
+    assert ops.conv3x3_fwd_stats(x, w, bias.to(DEV), y, sums, B, H, W, C, C)
+    assert ops.last_kernel().startswith("conv3x3_direct_split_kernel"), ops.last_kernel()
+    close(y.float(), nhwc(conv), tol_out(True), what="split direct conv (statistics form)")
+    yd = y.float().double().cpu().reshape(-1, C)
+    close(sums[:C], yd.sum(0), 2e-6, what="sum")
+    close(sums[C:], (yd * yd).sum(0), 2e-6, what="sum of squares")
+    sums2 = torch.empty_like(sums)
+    ops.conv3x3_fwd_stats(x, w, bias.to(DEV), y, sums2, B, H, W, C, C)
+    assert torch.equal(sums, sums2)  # ordered partial sums
+    # data gradient, with and without the dropout mask of the convolution's input (the mask is the plain kernels' mask)
+    dy, dyr = bt(nhwc(rnd(B, C, H, W, seed=75)), True)
+    gx = F.conv_transpose2d(dyr.permute(0, 3, 1, 2), wt, padding=1)
+    dx = BT.empty((B, H, W, C), True, DEV)
+    ops.conv3x3_dgrad(dy, w, dx, B, H, W, C, C)
+    assert ops.last_kernel().startswith("conv3x3_direct_split_kernel"), ops.last_kernel()
+    close(dx.float(), nhwc(gx), tol_out(True), what="split direct dgrad")
+    dxm, dxp = BT.empty((B, H, W, C), True, DEV), BT.empty((B, H, W, C), False, DEV)
+    ops.conv3x3_dgrad(dy, w, dxm, B, H, W, C, C, seed=99, p=0.1)
+    ops.conv3x3_dgrad(BT(dy.hi), BT(w.hi), dxp, B, H, W, C, C, seed=99, p=0.1)
+    assert ((dxm.float() == 0) != (dxp.float() == 0)).float().mean().item() < 1e-4  # same counter-based mask as the plain kernel
+    close(dxm.float(), nhwc(gx) * (dxm.float() != 0).double().cpu() / 0.9, tol_out(True), what="split direct dgrad x dropout mask")
+
+
+@pytest.mark.parametrize("lo_first", [False, True])
+def test_split_three_pass_fallback(lo_first, monkeypatch):
+    """C-ABI callers may hand over hi and lo buffers that are NOT one block (lo below hi, or far away): gemm8 / conv8 then run the
+    three-pass form of the split mode (NSEG = 3) instead of the paired K-tiles (NSEG = 2, what ops.BT's allocations get).  Both forms
+    against float64, and against each other."""
+    monkeypatch.setenv("IG_GEMM8", "2")
+    monkeypatch.setenv("IG_CONV8", "2")
+    M, N, K = 1300, 512, 256
+
+    def separate(t: BT) -> BT:  # the same values in two separate allocations, lo below hi when asked
+        a, b = torch.empty_like(t.hi), torch.empty_like(t.hi)
+        if (b.data_ptr() < a.data_ptr()) != lo_first:
+            a, b = b, a
+        a.copy_(t.hi), b.copy_(t.lo)
+        return BT(a, b)
+
+    x, xr = bt(rnd(M, K, seed=1), True)
+    w, wr = bt(rnd(N, K, seed=2, scale=K**-0.5), True)
+    b = rnd(N, seed=3).to(DEV)
+    ref = xr @ wr.t() + b.double().cpu()
+    y2, y3 = BT.zeros((M, N), True, DEV), BT.zeros((M, N), True, DEV)
+    ops.linear_fwd(x, w, b, y2, M, N, K, act=0)
+    assert ops.last_kernel().startswith("gemm8_kernel<0,2,"), ops.last_kernel()
+    xs, ws = separate(x), separate(w)
+    ops.linear_fwd(xs, ws, b, y3, M, N, K, act=0)
+    if lo_first:
+        assert ops.last_kernel().startswith("gemm8_kernel<0,3,"), ops.last_kernel()
+    close(y2.float(), ref, tol_out(True), what="paired")
+    close(y3.float(), ref, tol_out(True), what="three-pass (or paired across two allocations)")
+    monkeypatch.setenv("IG_G8_PAIR", "0")
+    ops.linear_fwd(x, w, b, y3, M, N, K, act=0)
+    assert ops.last_kernel().startswith("gemm8_kernel<0,3,"), ops.last_kernel()
+    close(y3.float(), ref, tol_out(True), what="three-pass")
+    close(y3.float(), y2.float().double().cpu(), tol_out(True), what="three-pass vs paired")
+    # conv8, gathered operand
+    B, H, C = 2, 16, 256
+    xi, xir = bt(nhwc(rnd(B, C, H, H, seed=5)), True)
+    wc, wcr = bt(rnd(C, C, 3, 3, seed=6, scale=(9 * C) ** -0.5).permute(0, 2, 3, 1).reshape(C, 9, C).contiguous(), True)
+    cref = nhwc(F.conv2d(xir.permute(0, 3, 1, 2), wcr.reshape(C, 3, 3, C).permute(0, 3, 1, 2), None, padding=1))
+    yc3, yc2 = BT.empty((B, H, H, C), True, DEV), BT.empty((B, H, H, C), True, DEV)
+    ops.conv3x3_fwd(xi, wc, None, yc3, B, H, H, C, C)
+    assert ops.last_kernel().startswith("conv8_kernel") and ",3,true>" in ops.last_kernel(), ops.last_kernel()
+    monkeypatch.delenv("IG_G8_PAIR")
+    ops.conv3x3_fwd(xi, wc, None, yc2, B, H, H, C, C)
+    assert ops.last_kernel().startswith("conv8_kernel") and ",2,true>" in ops.last_kernel(), ops.last_kernel()
+    close(yc2.float(), cref, tol_out(True), what="conv8 paired")
+    close(yc3.float(), cref, tol_out(True), what="conv8 three-pass")
+    ops.conv3x3_fwd(separate(xi), wc, None, yc3, B, H, H, C, C)  # (lo below hi: no common buffer descriptor -> three passes)
+    if lo_first:
+        assert ",3,true>" in ops.last_kernel(), ops.last_kernel()
+    close(yc3.float(), cref, tol_out(True), what="conv8 with separate hi / lo allocations")
+
+
 @pytest.mark.parametrize("C", [48, 96])
 def test_conv3x3_direct_bn_fold(C):
     """C -> C forward with the eval-mode BatchNorm + ReLU folded into the epilogue (direct kernels), ragged tile edges."""
