@@ -10,6 +10,10 @@
  * bf16 tensors: raw uint16 storage.  Every bf16 tensor argument is a pair (x_hi, x_lo): x_lo == NULL selects
  * plain bf16; non-NULL selects the split "bf16x3" precision mode (value = hi + lo, products hi*hi+hi*lo+lo*hi).
  * Either all bf16 operands of a call are split or none.  Activations in the decode head are NHWC.
+ * Placement of a split pair (performance only, results are the same up to fp32 summation order): when x_lo lies ABOVE x_hi, 16-byte aligned
+ * and less than 4 GiB minus the tensor away -- e.g. both halves of one allocation, which is how the Python host allocates them -- the
+ * linear and wide-convolution engines fetch hi and lo with ONE LDS-DMA stream ("paired" K-tiles, 5-35 % faster); any other placement runs
+ * the three-pass form of the same products.
  * Conv weights (3x3 and transposed) are stored Wc[Cout][9][Cin], tap = ky*3+kx.
  * Dropout is a counter-based hash of (drop_seed + *drop_seed_dev, element index): backward regenerates the mask;
  * drop_seed_dev (device uint32, may be NULL) lets a captured graph advance the seed without new host arguments.
