@@ -13,6 +13,7 @@ from instageo_amd.segmentation import PrithviSegmentationModule  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 108
+precision = sys.argv[3] if len(sys.argv) > 3 else "bf16"  # or bf16x3 (the split mode: paired K-tiles, split direct convolution)
 dev = "cuda"
 
 
@@ -23,7 +24,7 @@ def digest(t: torch.Tensor) -> str:
 def run():
     torch.manual_seed(1042)
     mod = PrithviSegmentationModule(freeze_backbone=False, load_pretrained_weights=False, num_classes=2, class_weights=[1, 3], ignore_index=-1,
-                                    learning_rate=1e-4, precision="bf16", device=dev)
+                                    learning_rate=1e-4, precision=precision, device=dev)
     g = torch.Generator().manual_seed(7)
     xs = [torch.randn(B, 6, 1, 224, 224, generator=g).to(dev) for _ in range(3)]
     ys = [torch.randint(-1, 2, (B, 224, 224), generator=g).to(dev) for _ in range(3)]
