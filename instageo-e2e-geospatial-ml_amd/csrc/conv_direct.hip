@@ -1200,8 +1200,11 @@ __global__ __launch_bounds__(576, 1) void convT_direct_dma_kernel(CTParams p, co
 // All of Wc[96][864] (166 KiB) does not fit the LDS next to a halo, so a workgroup owns a 48-wide slice of the output channels
 // (blockIdx.y; 84.5 KiB of weights) and the input halo is staged by both slices' workgroups (the second read is an L2 / MALL
 // hit).  Tile = 8 x 16 pixels, one row per MFMA wave; the halo (10 x 18 pixels x 192 B, lane-linear, 34 wave-DMAs) goes
-// through a 2-stage ring filled by the loader wave (see convT_direct_dma_kernel).  The unpadded 192-byte pixel pitch makes
-// the pixel-side ds_read_b128 2-way conflicted -- the conflict-free 224 bytes would not leave room for the second stage.
+// through a 2-stage ring filled by the loader wave (see convT_direct_dma_kernel).  The 224-byte pixel pitch that is conflict-free
+// by itself would not leave room for the second stage; at the unpadded 192 bytes the pixel-side ds_read_b128 is 2-way conflicted
+// unless the 16-byte chunks of a pixel are swizzled: chunk ^= 2 for halo columns with (hx >> 2) & 1 -- applied on the SOURCE chunk by
+// the loader wave and by the same involution on the fragment reads -- is conflict-free for all three tap columns and K-substeps
+// (tools/lds_bank_model.py; round 5: the kernel is bound by its LDS reads, 3 weight + 1 pixel fragment per 3 MFMAs).
 template <int C>
 __global__ __launch_bounds__(576, 1) void conv3x3_direct_slice_kernel(CDParams p, const bf16_t* zero_page) {
     static_assert(C == 96, "written for 96 channels (48-wide output slices)");
@@ -1276,7 +1279,7 @@ __global__ __launch_bounds__(576, 1) void conv3x3_direct_slice_kernel(CDParams p
             const int u = i * 64 + lane;
             const int hp = u / UNITS, c8 = u - hp * UNITS;
             const int hy = hp / HW_, hx = hp - hy * HW_;
-            u_off[i] = (hy * p.W + hx) * C + c8 * 8;
+            u_off[i] = (hy * p.W + hx) * C + (c8 ^ (((hx >> 2) & 1) << 1)) * 8;  // bank swizzle on the source chunk
             u_yx[i] = u < HUNITS ? (hy << 8) | hx : 0xffff;
         }
         auto issue = [&](int t, int st) {
@@ -1302,7 +1305,9 @@ __global__ __launch_bounds__(576, 1) void conv3x3_direct_slice_kernel(CDParams p
 
     // ================================= MFMA waves: row `wave` of the tile =================================
     const int g = lane >> 4, j = lane & 15;
-    const int x_lane = (wave * HW_ + j) * PP + g * 16;
+    int x_lane[3];  // per tap column dx: this lane's pixel + its swizzled chunk (halo column j + dx)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) x_lane[dx] = (wave * HW_ + j + dx) * PP + ((g ^ ((((j + dx) >> 2) & 1) << 1)) << 4);
     const char* w_lane = wl + j * WP + g * 16;
     auto finish4 = [&](f32x4 a, int n, size_t idx, float* v) {
         const float4 bb = *reinterpret_cast<const float4*>(par + n);
@@ -1330,7 +1335,7 @@ __global__ __launch_bounds__(576, 1) void conv3x3_direct_slice_kernel(CDParams p
         asm volatile("s_barrier" ::: "memory");
         int b, ty0, tx0;
         tile_coords(t0 + n * gstep, b, ty0, tx0);
-        const char* xs = smem + W_BYTES + (n & 1) * STAGE + x_lane;
+        const char* xs = smem + W_BYTES + (n & 1) * STAGE;
         f32x4 acc[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1340,7 +1345,7 @@ __global__ __launch_bounds__(576, 1) void conv3x3_direct_slice_kernel(CDParams p
             bf16x8_t wf[NB];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) wf[nb] = *reinterpret_cast<const bf16x8_t*>(w_lane + nb * 16 * WP + ks * 64);
-            const bf16x8_t pf = *reinterpret_cast<const bf16x8_t*>(xs + (dy * HW_ + dx) * PP + (ks % 3) * 64);
+            const bf16x8_t pf = *reinterpret_cast<const bf16x8_t*>(xs + x_lane[dx] + dy * HW_ * PP + (ks % 3) * 64);
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], pf, acc[nb], 0, 0, 0);
         }

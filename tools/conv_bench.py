@@ -12,7 +12,7 @@ def timeit(fn,n=10):
     for _ in range(n): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b)/n*1e3
-B=108
+B=int(sys.argv[1]) if len(sys.argv) > 1 else 108
 for H,C in [(224,48),(112,96),(56,192),(28,384)]:
     x=BT(torch.randn(B,H,H,C,device=dev).bfloat16()); w=BT(torch.randn(C,9,C,device=dev).bfloat16()*0.05); bias=torch.zeros(C,device=dev)
     y=BT.empty((B,H,H,C),False,dev)
