@@ -1204,7 +1204,9 @@ __global__ __launch_bounds__(576, 1) void convT_direct_dma_kernel(CTParams p, co
 // by itself would not leave room for the second stage; at the unpadded 192 bytes the pixel-side ds_read_b128 is 2-way conflicted
 // unless the 16-byte chunks of a pixel are swizzled: chunk ^= 2 for halo columns with (hx >> 2) & 1 -- applied on the SOURCE chunk by
 // the loader wave and by the same involution on the fragment reads -- is conflict-free for all three tap columns and K-substeps
-// (tools/lds_bank_model.py; round 5: the kernel is bound by its LDS reads, 3 weight + 1 pixel fragment per 3 MFMAs).
+// (tools/lds_bank_model.py): forward 524 -> 496 us, data gradient 541 -> 510 at B = 216.  Two rows per MFMA wave (4 MFMA waves + the
+// loader: every weight fragment feeds two pixel rows, 5 fragment reads per 6 MFMAs instead of 4 per 3) was measured SLOWER (530-540 us):
+// it is the eight waves' latency hiding that the kernel needs, not LDS bandwidth.
 template <int C>
 __global__ __launch_bounds__(576, 1) void conv3x3_direct_slice_kernel(CDParams p, const bf16_t* zero_page) {
     static_assert(C == 96, "written for 96 channels (48-wide output slices)");
