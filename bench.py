@@ -11,13 +11,14 @@ The line is kept COMPACT (< 2000 characters: the driver's record keeps only a ta
   config             workload + the other legs' headline numbers: encoder_fwd_mfma_frac / encoder_fwd_ms (the encoder forward
                      alone: patch embed + L blocks + final LayerNorm -- the north-star target is stated on it),
                      inference_chips_per_s (K0 + forward + argmax int8), parity_mode_chips_per_s / _inference (the SAME workload
-                     in bf16x3, the mode that meets the 1e-3 logits bar), tile_windows_per_s (BASELINE.json configs[3]: sliding
+                     in bf16x3, the mode that meets the 1e-3 logits bar), yaml_b16 / yaml_t3_b8 / t3_b72 _chips_per_s (N = 1: short
+                     legs at the reference YAMLs' batches and at configs[2]'s shape), tile_windows_per_s (BASELINE.json configs[3]: sliding
                      window over a resident 10980^2 int16 tile, window gather included; N > 1: windows sharded by rank, final
                      RCCL gather of the int8 maps included, plus the per-GPU rate without the gather), whole_step_mfma_frac
   roofline           the dominant KERNEL of the timed region (per-step time = launches/step x average launch): algorithmic FLOPs
                      of its launches / HIP-event time, against the dense bf16 MFMA peak; `traffic` from the committed PMC passes
-  cpu_baseline       N=1: the CPU oracle (kind "port") on the host cores: the train step (32 threads and all cores) and the
-                     configs[0] forward (B=4)
+  cpu_baseline       N=1: the CPU oracle (kind "port") on the host cores: the train step (16 threads: the best count of the
+                     sweep on the 256-core boxes, stated in `cores`) and the configs[0] forward (B=4)
   dist               N>1: ranks, backend, reserved CUs, all-reduce milliseconds per step (instrumented extra step)
   detail             path of the JSON file with everything else (written by rank 0, default profiles/bench_detail_*.json):
                      roofline_timed_region / roofline_kernels (every MFMA kernel keyed by the name rocprofv3 prints), hbm_ops (HBM-bound
