@@ -64,6 +64,9 @@ struct G8Params {
     float* colsum;
 };
 int ig_gemm8_nt(const G8Params& p, void* stream);  // IG_ERR_UNSUPPORTED (no error string) when the shape is not covered
+// gemm4.hip: the same contract on the 4-wave (one wave per SIMD, 128 x 128 per wave) kernel with a generated K-loop: plain bf16 operands,
+// N % 256 == 0, K % 128 == 0, >= 128 tiles; ig_gemm8_nt tries it first
+int ig_gemm4_nt(const G8Params& p, void* stream);
 // gemm8w.hip: grouped linear weight gradients dW_g += dy_g^T x_g (shared token count M) on the 8-phase schedule with transposed
 // fragment reads; IG_ERR_UNSUPPORTED (no error string) when a shape is not covered (N, K multiples of 256)
 int ig_wgrad8_group(int n, const void* const* dy_hi, const void* const* dy_lo, const void* const* x_hi, const void* const* x_lo,
@@ -141,8 +144,8 @@ static __constant__ IgDet g_igdet;
 bool ig_deterministic();  // host-side view of the mode (runtime.hip)
 // per-device grow-only scratch buffers (slot 0: BatchNorm partial sums); never freed, a superseded buffer stays allocated because
 // launches in flight may still use it; NULL on allocation failure.  Not to be grown during a graph capture (first calls are warm-ups).
-void* ig_scratch(int slot, size_t bytes);
-void* ig_scratch2(int slot, size_t bytes, bool may_grow);  // may_grow = false: NULL instead of an allocation (stream captures)
+void* ig_scratch(int slot, size_t bytes, hipStream_t st);                   // per (device, stream, slot): see runtime.hip
+void* ig_scratch2(int slot, size_t bytes, bool may_grow, hipStream_t st);  // may_grow = false: NULL instead of an allocation (stream captures)
 
 // device side ----------------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }

@@ -54,14 +54,14 @@ __device__ __forceinline__ void c8_glds16_s(unsigned voff, const void* sbase, un
     // M0 = LDS destination of the DMA.  It is neither saved nor restored (2 SALU fewer per issue; round 5: the s_nop 4 -> 0 and this together
     // are worth 3 % on the grouped weight gradients): hipcc keeps nothing in M0 in these kernels -- gfx9 LDS instructions do not read it -- and
     // tests/test_cpu_host.py::test_m0_is_only_written_by_the_lds_dma_helpers checks the ISA for any other M0 reference
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
 }
 // LDS-DMA through a buffer descriptor: lanes whose offset lies beyond num_records write zeros
 __device__ __forceinline__ void c8_blds16(unsigned voff, i32x4 rsrc, unsigned lds_dst) {
     // M0 = LDS destination of the DMA.  It is neither saved nor restored (2 SALU fewer per issue; round 5: the s_nop 4 -> 0 and this together
     // are worth 3 % on the grouped weight gradients): hipcc keeps nothing in M0 in these kernels -- gfx9 LDS instructions do not read it -- and
     // tests/test_cpu_host.py::test_m0_is_only_written_by_the_lds_dma_helpers checks the ISA for any other M0 reference
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_dst) : "memory", "m0");
 }
 __device__ __forceinline__ i32x4 c8_rsrc(const void* base, unsigned bytes) {
     const uint64_t a = (uint64_t)base;
@@ -715,7 +715,7 @@ int ig_conv8(int kind, int sign, const void* x_hi, const void* x_lo, const void*
     const size_t need = wbytes * (w_lo ? 2 : 1) + (size_t)(tent + 32) * 4;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
-    char* scratch = (char*)ig_scratch2(1, need, !capturing);
+    char* scratch = (char*)ig_scratch2(1, need, !capturing, st);
     if (!scratch) return IG_ERR_UNSUPPORTED;
     bf16_t* p_hi = (bf16_t*)scratch;
     bf16_t* p_lo = w_lo ? (bf16_t*)(scratch + wbytes) : nullptr;

@@ -374,7 +374,7 @@ int launch_direct(CDParams p, hipStream_t st, const char* what, double* stat_sum
     long nwg = 512;  // two persistent workgroups per CU
     if (nwg > p.ntiles) nwg = p.ntiles;
     if (stat_sums) {
-        p.stats_part = (float*)ig_scratch(0, (size_t)nwg * 2 * C * sizeof(float));
+        p.stats_part = (float*)ig_scratch(0, (size_t)nwg * 2 * C * sizeof(float), st);
         if (!p.stats_part) {
             ig_set_error("%s: scratch allocation failed", what);
             return IG_ERR_HIP;
@@ -649,7 +649,7 @@ int launch_direct_split(CDParams p, CDSplit q, hipStream_t st, const char* what,
     long nwg = ig_cu_count();  // one persistent workgroup per CU
     if (nwg > p.ntiles) nwg = p.ntiles;
     if (stat_sums) {
-        p.stats_part = (float*)ig_scratch(0, (size_t)nwg * 2 * C * sizeof(float));
+        p.stats_part = (float*)ig_scratch(0, (size_t)nwg * 2 * C * sizeof(float), st);
         if (!p.stats_part) {
             ig_set_error("%s: scratch allocation failed", what);
             return IG_ERR_HIP;
@@ -1628,7 +1628,7 @@ int ig_conv3x3_direct(const void* x, const void* w, const float* bias, const flo
         const long nwg = p.ntiles < 128 ? p.ntiles : 128;
         const bool st96 = stat_sums && stats_fused && !dgrad;
         if (st96) {
-            p.stats_part = (float*)ig_scratch(0, (size_t)nwg * 2 * 96 * sizeof(float));
+            p.stats_part = (float*)ig_scratch(0, (size_t)nwg * 2 * 96 * sizeof(float), (hipStream_t)stream);
             if (!p.stats_part) {
                 ig_set_error("ig_conv3x3_fwd: scratch allocation failed");
                 return IG_ERR_HIP;

@@ -1292,7 +1292,7 @@ int ig_bn_relu_fwd(const void* x_hi, const void* x_lo, const float* gamma, const
         const int rpb = bn_reduce_rows(M), nwg = ig_cdiv(M, rpb);
         float* part = nullptr;
         if (ig_deterministic()) {
-            part = (float*)ig_scratch(0, (size_t)nwg * 2 * C * sizeof(float));
+            part = (float*)ig_scratch(0, (size_t)nwg * 2 * C * sizeof(float), ST(stream));
             IG_REQUIRE(part, "ig_bn_relu_fwd: scratch allocation failed");
         } else {
             (void)hipMemsetAsync(sums, 0, 2 * (size_t)C * sizeof(double), ST(stream));
@@ -1331,7 +1331,7 @@ int ig_bn_relu_bwd(const void* x_hi, const void* x_lo, const void* dy_hi, const 
     const int rpb = bn_reduce_rows(M), nwg = ig_cdiv(M, rpb);
     float* part = nullptr;
     if (ig_deterministic()) {
-        part = (float*)ig_scratch(0, (size_t)nwg * 2 * C * sizeof(float));
+        part = (float*)ig_scratch(0, (size_t)nwg * 2 * C * sizeof(float), ST(stream));
         IG_REQUIRE(part, "ig_bn_relu_bwd: scratch allocation failed");
     } else {
         (void)hipMemsetAsync(sums, 0, 2 * (size_t)C * sizeof(double), ST(stream));

@@ -91,7 +91,7 @@ __device__ __forceinline__ void glds16_s(unsigned voff, const void* sbase, unsig
     // M0 = LDS destination of the DMA.  It is neither saved nor restored (2 SALU fewer per issue; round 5: the s_nop 4 -> 0 and this together
     // are worth 3 % on the grouped weight gradients): hipcc keeps nothing in M0 in these kernels -- gfx9 LDS instructions do not read it -- and
     // tests/test_cpu_host.py::test_m0_is_only_written_by_the_lds_dma_helpers checks the ISA for any other M0 reference
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
 }
 
 struct Cur {  // issue cursor of one half-tile type (all wave-uniform)
@@ -662,6 +662,10 @@ IG_DET_TU(gemm8)  // constant-memory descriptor of the deterministic-reduction m
 int ig_gemm8_nt(const G8Params& p, void* stream) {
     if (!g8_env()) return IG_ERR_UNSUPPORTED;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return IG_ERR_UNSUPPORTED;
+    {  // the 4-wave kernel (gemm4.hip) takes the plain bf16 shapes it is routed for
+        const int rc4 = ig_gemm4_nt(p, stream);
+        if (rc4 != IG_ERR_UNSUPPORTED) return rc4;
+    }
     if ((p.K & 127) || (p.N & 127)) return IG_ERR_UNSUPPORTED;
     if (p.lda * 2 * 256 >= (1L << 24) || p.ldb * 2 * 256 >= (1L << 24)) return IG_ERR_UNSUPPORTED;  // 24-bit offset multiply
     const int ntiles256 = (p.N & 255) ? 0 : ((p.M + 255) >> 8) * (p.N >> 8);

@@ -98,16 +98,16 @@ __device__ __forceinline__ void w_glds_s(unsigned voff, const void* sbase, unsig
     // M0 = LDS destination of the DMA.  It is neither saved nor restored (2 SALU fewer per issue; round 5: the s_nop 4 -> 0 and this together
     // are worth 3 % on the grouped weight gradients): hipcc keeps nothing in M0 in these kernels -- gfx9 LDS instructions do not read it -- and
     // tests/test_cpu_host.py::test_m0_is_only_written_by_the_lds_dma_helpers checks the ISA for any other M0 reference
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
 }
 __device__ __forceinline__ void w_glds_v(const void* gsrc, unsigned lds_dst) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory", "m0");
 }
 __device__ __forceinline__ void w_blds(unsigned voff, i32x4 rsrc, unsigned lds_dst) {
     // M0 = LDS destination of the DMA.  It is neither saved nor restored (2 SALU fewer per issue; round 5: the s_nop 4 -> 0 and this together
     // are worth 3 % on the grouped weight gradients): hipcc keeps nothing in M0 in these kernels -- gfx9 LDS instructions do not read it -- and
     // tests/test_cpu_host.py::test_m0_is_only_written_by_the_lds_dma_helpers checks the ISA for any other M0 reference
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_dst) : "memory", "m0");
 }
 __device__ __forceinline__ i32x4 w_rsrc(const void* base, unsigned bytes) {
     const uint64_t a = (uint64_t)base;

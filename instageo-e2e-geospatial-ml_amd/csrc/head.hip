@@ -1015,7 +1015,7 @@ int ig_classifier_bn_bwd(const float* dlogits, const void* x_hi, const void* x_l
     if (rc != IG_OK) return rc;
     ClsBn bn{scale, shift, mean, rstd, sums, nullptr, dgamma, dbeta, 1.0 / (double)M};
     if (ig_deterministic()) {
-        bn.part = (float*)ig_scratch(0, (size_t)nwg * 2 * C * sizeof(float));
+        bn.part = (float*)ig_scratch(0, (size_t)nwg * 2 * C * sizeof(float), (hipStream_t)stream);
         IG_REQUIRE(bn.part, "ig_classifier_bn_bwd: scratch allocation failed");
     } else {
         (void)hipMemsetAsync(sums, 0, 2 * (size_t)C * sizeof(double), (hipStream_t)stream);

@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 
 #include "common.h"
 
@@ -82,24 +83,52 @@ int ig_det_sync_head(const IgDet*, hipStream_t);
 int ig_det_sync_conv_direct(const IgDet*, hipStream_t);
 int ig_det_sync_gemm(const IgDet*, hipStream_t);
 int ig_det_sync_gemm8(const IgDet*, hipStream_t);
+int ig_det_sync_gemm4(const IgDet*, hipStream_t);
 int ig_det_sync_attention2(const IgDet*, hipStream_t);
 IG_DET_TU(runtime)
 static IgDet g_det_host = {nullptr, nullptr, 0};
 bool ig_deterministic() { return g_det_host.shadow != nullptr; }
-void* ig_scratch(int slot, size_t bytes) { return ig_scratch2(slot, bytes, true); }
-void* ig_scratch2(int slot, size_t bytes, bool may_grow) {
-    static void* buf[16][4] = {};
-    static size_t cap[16][4] = {};
+// Scratch buffers are keyed by (device, STREAM, slot): two streams of one device -- a distillation teacher's forward beside the student's
+// step (segmentation.py:216-451), a graph replay beside eager inference -- never share a buffer, so a kernel on one stream cannot read
+// partial sums or packed weights that a launch on another stream is overwriting.  A stream gets its entry on first
+// use (up to IG_SCRATCH_STREAMS per device, then NULL: the callers report it).  Growing frees the old buffer: hipFree synchronises the
+// device, so no kernel still reads it (the grow path is outside stream captures: may_grow = false there).
+void* ig_scratch(int slot, size_t bytes, hipStream_t st) { return ig_scratch2(slot, bytes, true, st); }
+void* ig_scratch2(int slot, size_t bytes, bool may_grow, hipStream_t st) {
+    constexpr int IG_SCRATCH_STREAMS = 16;
+    struct Entry {
+        hipStream_t stream;
+        bool used;
+        void* buf[4];
+        size_t cap[4];
+    };
+    static Entry tab[16][IG_SCRATCH_STREAMS] = {};
+    static std::mutex mu;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || slot < 0 || slot >= 4) return nullptr;
-    if (cap[dev][slot] < bytes) {
+    std::lock_guard<std::mutex> lock(mu);
+    Entry* e = nullptr;
+    for (int i = 0; i < IG_SCRATCH_STREAMS && !e; ++i) {
+        if (tab[dev][i].used && tab[dev][i].stream == st) e = &tab[dev][i];
+        else if (!tab[dev][i].used) {
+            e = &tab[dev][i];
+            e->used = true, e->stream = st;
+        }
+    }
+    if (!e) {
+        ig_set_error("scratch: more than %d streams use the library on device %d", IG_SCRATCH_STREAMS, dev);
+        return nullptr;
+    }
+    if (e->cap[slot] < bytes) {
         if (!may_grow) return nullptr;  // e.g. during a stream capture: nothing may be allocated
         void* p = nullptr;
         const size_t want = bytes + bytes / 2;
+        if (e->buf[slot]) (void)hipFree(e->buf[slot]);  // synchronises the device: nothing in flight still reads the old buffer
+        e->buf[slot] = nullptr, e->cap[slot] = 0;
         if (hipMalloc(&p, want) != hipSuccess) return nullptr;
-        buf[dev][slot] = p, cap[dev][slot] = want;
+        e->buf[slot] = p, e->cap[slot] = want;
     }
-    return buf[dev][slot];
+    return e->buf[slot];
 }
 
 namespace {
@@ -152,6 +181,7 @@ int ig_set_deterministic(void* shadow, const void* grad_base, long n, void* stre
     rc |= ig_det_sync_conv_direct(&g_det_host, st);
     rc |= ig_det_sync_gemm(&g_det_host, st);
     rc |= ig_det_sync_gemm8(&g_det_host, st);
+    rc |= ig_det_sync_gemm4(&g_det_host, st);
     rc |= ig_det_sync_attention2(&g_det_host, st);
     if (rc != IG_OK) {
         ig_set_error("ig_set_deterministic: hipMemcpyToSymbol failed: %s", hipGetErrorString(hipGetLastError()));

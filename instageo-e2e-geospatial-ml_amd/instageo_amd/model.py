@@ -1057,7 +1057,7 @@ class PrithviSeg(nn.Module):
         torch_ops.register()
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         params = [p for _, p in self._flat_params()]
-        logits, feats = torch.ops.instageo_mi355x.prithvi_seg(img, params, self._handle, self.training, needs_grad, return_features)
+        logits, feats, _gen = torch.ops.instageo_mi355x.prithvi_seg(img, params, self._handle, self.training, needs_grad, return_features)
         if return_features:
             return logits, feats
         return logits

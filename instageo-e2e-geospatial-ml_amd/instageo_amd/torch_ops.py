@@ -232,7 +232,10 @@ def _register_network(lib: torch.library.Library) -> None:
     # (nn.Module.train()); save: keep the activations for prithvi_seg_backward; features: also return reshaped_features (B, D*T, 14, 14)
     # (an empty tensor otherwise).  Hidden state behind the handle: workspaces, the saved activations of the latest save=True call,
     # the BatchNorm running statistics (updated when training), the dropout counter.
-    lib.define("prithvi_seg(Tensor img, Tensor[] params, int handle, bool training, bool save, bool features) -> (Tensor, Tensor)")
+    # Third output: the engine's forward GENERATION as a 1-element int64 CPU tensor.  It is a real op output -- not Python state read in
+    # setup_context -- so that a traced graph (torch.compile / AOTAutograd, where setup_context runs once on fake tensors) hands the
+    # backward the generation of the forward that actually ran, not a constant baked in at trace time.
+    lib.define("prithvi_seg(Tensor img, Tensor[] params, int handle, bool training, bool save, bool features) -> (Tensor, Tensor, Tensor)")
 
     def seg_impl(img, params, handle, training, save, features):
         net = M.network_of(handle)
@@ -240,7 +243,7 @@ def _register_network(lib: torch.library.Library) -> None:
         eng.mark_params_changed()  # foreign optimizers write into the fp32 views directly: always refresh the bf16 operands
         logits = eng.forward(img, training, save=save or features, update_running=True)
         feats = eng.features_nchw() if features else logits.new_empty((0,))
-        return logits, feats
+        return logits, feats, torch.tensor([eng._generation], dtype=torch.int64)
 
     lib.impl("prithvi_seg", seg_impl, "CUDA")
 
@@ -250,20 +253,20 @@ def _register_network(lib: torch.library.Library) -> None:
         B = img.shape[0]
         logits = img.new_empty((B, cfg.num_classes, cfg.out_size, cfg.out_size), dtype=torch.float32)
         shape = (B, cfg.embed_dim * cfg.num_frames, cfg.grid, cfg.grid) if features else (0,)
-        return logits, img.new_empty(shape, dtype=torch.float32)
+        return logits, img.new_empty(shape, dtype=torch.float32), torch.empty((1,), dtype=torch.int64, device="cpu")
 
     torch.library.register_fake(f"{NAMESPACE}::prithvi_seg", seg_fake, lib=lib)
 
     # gradients of the parameters for an upstream dlogits, from the activations the forward call of ``generation`` saved; an empty
     # tensor for a parameter that does not require a gradient
-    lib.define("prithvi_seg_backward(Tensor dlogits, Tensor[] params, int handle, int generation) -> Tensor[]")
+    lib.define("prithvi_seg_backward(Tensor dlogits, Tensor[] params, int handle, Tensor generation) -> Tensor[]")
 
     def seg_bwd_impl(dlogits, params, handle, generation):
         net = M.network_of(handle)
         eng, store = net.engine, net.store
         g = store.ensure_grad()
         g.zero_()
-        eng.backward(dlogits.contiguous().float(), generation=generation)
+        eng.backward(dlogits.contiguous().float(), generation=int(generation.item()))  # a CPU tensor: no device synchronisation
         return [store.entries[name].api_view(g).clone() if p.requires_grad else p.new_empty((0,)) for name, p in net._flat_params()]
 
     lib.impl("prithvi_seg_backward", seg_bwd_impl, "CUDA")
@@ -273,12 +276,21 @@ def _register_network(lib: torch.library.Library) -> None:
 
     def seg_setup(ctx, inputs, output):
         img, params, handle, training, save, features = inputs
-        ctx.handle, ctx.generation = handle, M.network_of(handle).engine._generation
+        ctx.handle = handle
         ctx.req = [p.requires_grad for p in params]
-        ctx.save_for_backward(*params)
+        ctx.set_materialize_grads(False)  # an unused output arrives as None, so a gradient INTO the features can be told from no gradient
+        ctx.save_for_backward(*params, output[2])
 
-    def seg_bwd(ctx, dlogits, _dfeats):
-        grads = ns.prithvi_seg_backward(dlogits, list(ctx.saved_tensors), ctx.handle, ctx.generation)
+    def seg_bwd(ctx, dlogits, dfeats, _dgen):
+        # The engine propagates a gradient from the logits only.  A loss built on the features output (return_features=True) used to
+        # train nothing through it, silently: refuse instead.
+        if dfeats is not None:
+            raise RuntimeError("instageo_mi355x::prithvi_seg: the features output is not differentiable (the engine back-propagates from "
+                               "the logits only); detach() it, or build the loss on the logits")
+        if dlogits is None:
+            raise RuntimeError("instageo_mi355x::prithvi_seg: backward without a gradient for the logits")
+        *params, gen = ctx.saved_tensors
+        grads = ns.prithvi_seg_backward(dlogits, list(params), ctx.handle, gen)
         return None, [g if r else None for g, r in zip(grads, ctx.req)], None, None, None, None
 
     torch.library.register_autograd(f"{NAMESPACE}::prithvi_seg", seg_bwd, setup_context=seg_setup, lib=lib)

@@ -110,8 +110,105 @@ def install_shims() -> None:
 from oracle.cases import CASES, EVAL_ONLY, GRAD_KEYS, class_weights_for, make_inputs, sub  # noqa: E402
 
 
+def task_losses(out_dir: str) -> None:
+    """6. the f4 task losses from the reference's OWN step arithmetic (VERDICT r5 "missing" 2): the unbound methods
+    ``PrithviDistillationSegmentationModule._compute_loss`` (segmentation.py:352-378), ``PrithviRegressionModule._shared_step``
+    (regression.py:141-168) and ``PrithviDistillationRegressionModule._shared_step`` + ``_compute_loss`` (regression.py:477-534) are
+    called on a stand-in ``self`` that carries exactly the attributes their constructors set (criterion, distillation_loss, ignore_index,
+    log_scaler, the reference's RunningRegressionMetrics); network outputs are seeded tensors.  Stored: inputs, the loss parts in fp64 and
+    fp32, and the reference autograd gradient w.r.t. the student output -- what ig_kd_loss / ig_mse_loss / ig_kd_mse_loss must reproduce."""
+    for name in ["hydra", "omegaconf", "rasterio", "rasterio.crs", "xarray", "absl", "absl.logging", "rioxarray", "matplotlib", "matplotlib.pyplot", "seaborn"]:
+        sys.modules.setdefault(name, MagicMock())
+    if "instageo.model.neptune_logger" not in sys.modules:
+        nl = types.ModuleType("instageo.model.neptune_logger")
+        nl.AIchorNeptuneLogger = type("AIchorNeptuneLogger", (), {})
+        nl.set_neptune_api_token = lambda *a, **k: None
+        sys.modules["instageo.model.neptune_logger"] = nl
+    from instageo.model import metrics as ref_metrics  # noqa
+    from instageo.model import regression as ref_reg  # noqa
+    from instageo.model import segmentation as ref_seg  # noqa
+
+    fix = {}
+    # --- segmentation distillation -------------------------------------------------------------
+    B, ncls, H, W, ign = 2, 3, 32, 40, -1
+    g = torch.Generator().manual_seed(23)
+    s_log = torch.randn(B, ncls, H, W, generator=g)
+    t_log = torch.randn(B, ncls, H, W, generator=g) * 1.5
+    lab = torch.randint(-1, ncls, (B, H, W), generator=g)
+    cw = torch.tensor([1.0, 2.0, 0.5])
+    fix.update(seg_student=s_log.numpy(), seg_teacher=t_log.numpy(), seg_labels=lab.numpy(), seg_class_weights=cw.numpy(), seg_ignore=np.int64(ign))
+    for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+        me = types.SimpleNamespace(criterion=nn.CrossEntropyLoss(weight=cw.to(dt), ignore_index=ign, reduction="none"),  # segmentation.py:274-276
+                                   distillation_loss=nn.KLDivLoss(reduction="batchmean"), ignore_index=ign, _num_classes=ncls)  # :268
+        s = s_log.to(dt).clone().requires_grad_(True)
+        total, parts = ref_seg.PrithviDistillationSegmentationModule._compute_loss(me, s, t_log.to(dt), lab)
+        total.backward()
+        fix[f"seg_parts_{tag}"] = np.array([parts["loss"], parts["ce_loss"], parts["distill_loss"]], dtype=np.float64)
+        if dt == torch.float64:  # the fp32 run only contributes its loss parts (the reference's production precision)
+            fix["seg_grad_f64"] = s.grad.numpy()
+        if dt == torch.float64:
+            s2 = s_log.double().clone().requires_grad_(True)
+            mt, mce, mkd = O.distillation_loss(s2, t_log.double(), lab, ign, cw.double())
+            mt.backward()
+            assert abs(mt.item() - parts["loss"]) < 1e-12 and abs(mce.item() - parts["ce_loss"]) < 1e-12 and abs(mkd.item() - parts["distill_loss"]) < 1e-12
+            assert (s2.grad - s.grad).abs().max().item() < 1e-14, "distillation gradient: oracle != reference"
+    # --- regression, regression distillation ---------------------------------------------------
+    B, H, W, ignf = 2, 32, 40, -1.0
+    g = torch.Generator().manual_seed(29)
+    s_out = torch.rand(B, 1, H, W, generator=g) * 2.0
+    t_out = torch.rand(B, 1, H, W, generator=g) * 2.0
+    labf = torch.rand(B, H, W, generator=g) * 3.0
+    labf[torch.rand(B, H, W, generator=g) < 0.2] = ignf
+    fix.update(reg_student=s_out.numpy(), reg_teacher=t_out.numpy(), reg_labels=labf.numpy(), reg_ignore=np.float64(ignf))
+    for use_log in (False, True):
+        for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+            key = f"{'log' if use_log else 'lin'}_{tag}"
+            # plain regression step
+            s = s_out.to(dt).clone().requires_grad_(True)
+            logged = {}
+            me = types.SimpleNamespace(forward=lambda x, s=s: s, ignore_index=ignf, use_log_scale=use_log, log_scaler=ref_reg.LogScaler(),
+                                       criterion=nn.MSELoss(reduction="none"), train_metrics=ref_metrics.RunningRegressionMetrics(include_ee=True),
+                                       plot_reg_results=False, log=lambda k, v, **kw: logged.__setitem__(k, v))
+            loss = ref_reg.PrithviRegressionModule._shared_step(me, (torch.zeros(1), labf.to(dt)), "train")
+            loss.backward()
+            fix[f"reg_loss_{key}"] = np.float64(loss.item())
+            if dt == torch.float64:
+                fix[f"reg_grad_{key}"] = s.grad.numpy()
+            rm = me.train_metrics.compute()
+            fix[f"reg_metrics_{key}"] = np.array([rm[k] for k in ("mae", "rmse", "r2_score", "pearson_corrcoef", "ee_percentage")], dtype=np.float64)
+            # distillation step
+            s = s_out.to(dt).clone().requires_grad_(True)
+            logged = {}
+            me = types.SimpleNamespace(net=lambda x, s=s: s, teacher=types.SimpleNamespace(net=lambda x: t_out.to(dt)), ignore_index=ignf,
+                                       use_log_scale=use_log, log_scaler=ref_reg.LogScaler(), criterion=nn.MSELoss(reduction="none"),
+                                       distillation_loss=nn.MSELoss(reduction="none"),  # regression.py:398-400
+                                       train_metrics=ref_metrics.RunningRegressionMetrics(include_ee=True), plot_reg_results=False,
+                                       log=lambda k, v, **kw: logged.__setitem__(k, v))
+            me._compute_loss = types.MethodType(ref_reg.PrithviDistillationRegressionModule._compute_loss, me)
+            total = ref_reg.PrithviDistillationRegressionModule._shared_step(me, (torch.zeros(1), labf.to(dt)), "train")
+            total.backward()
+            fix[f"regkd_parts_{key}"] = np.array([logged["train_loss"], logged["train_mse_loss"], logged["train_distill_loss"]], dtype=np.float64)
+            if dt == torch.float64:
+                fix[f"regkd_grad_{key}"] = s.grad.numpy()
+            if dt == torch.float64:
+                s2 = s_out.double().clone().requires_grad_(True)
+                l2, _, _ = O.regression_loss(s2, labf.double(), ignf, use_log)
+                l2.backward()
+                assert abs(l2.item() - fix[f"reg_loss_{key}"]) < 1e-12 and (s2.grad.numpy() - fix[f"reg_grad_{key}"]).__abs__().max() < 1e-14
+                s3 = s_out.double().clone().requires_grad_(True)
+                tt, mm, kk = O.regression_distillation_loss(s3, t_out.double(), labf.double(), ignf, use_log)
+                tt.backward()
+                assert np.allclose([tt.item(), mm.item(), kk.item()], fix[f"regkd_parts_{key}"], rtol=0, atol=1e-12)
+                assert (s3.grad.numpy() - fix[f"regkd_grad_{key}"]).__abs__().max() < 1e-14, "regression distillation gradient: oracle != reference"
+    np.savez_compressed(os.path.join(out_dir, "task_losses.npz"), **fix)
+    print("task_losses fixture written (reference _compute_loss / _shared_step == oracle, fp64 to 1e-12)")
+
+
 def main() -> None:
     install_shims()
+    if "--losses-only" in sys.argv:
+        task_losses(os.path.join(ROOT, "tests", "golden"))
+        return
     from instageo.model import metrics as ref_metrics  # noqa
     from instageo.model import pritvhi as ref_vit  # noqa
     from instageo.model.model import PrithviSeg as RefSeg  # noqa
@@ -318,6 +415,9 @@ def main() -> None:
         st[f"{case}_mean"], st[f"{case}_std"], st[f"{case}_class_weights"] = np.array(mean), np.array(std), np.array(cw, dtype=np.float64)
     np.savez_compressed(os.path.join(out_dir, "stats.npz"), **st)
     print("stats fixtures written (reference compute_stats == oracle)")
+
+    # 6. task losses (distillation, regression, regression distillation) from the reference's own step methods
+    task_losses(out_dir)
 
 
 if __name__ == "__main__":

@@ -225,6 +225,36 @@ def test_distillation_loss_restatement():
     assert abs(kd.item() - kl_pix1 / 2) < 1e-12 and abs(total.item() - (ce + kd).item()) < 1e-15
 
 
+def test_task_losses_oracle_matches_reference_generated_fixture():
+    """tests/golden/task_losses.npz holds the loss parts and autograd gradients of the reference's own
+    PrithviDistillationSegmentationModule._compute_loss (segmentation.py:352-378), PrithviRegressionModule._shared_step
+    (regression.py:141-168) and PrithviDistillationRegressionModule._shared_step / _compute_loss (regression.py:477-534), written by
+    oracle/gen_golden.py from an import of /root/reference.  The oracle restatements must reproduce them in fp64."""
+    z = np.load(os.path.join(GOLD, "task_losses.npz"))
+    s = torch.from_numpy(z["seg_student"]).double().requires_grad_(True)
+    total, ce, kd = O.distillation_loss(s, torch.from_numpy(z["seg_teacher"]).double(), torch.from_numpy(z["seg_labels"]), int(z["seg_ignore"]),
+                                        torch.from_numpy(z["seg_class_weights"]).double())
+    total.backward()
+    assert np.allclose([total.item(), ce.item(), kd.item()], z["seg_parts_f64"], rtol=0, atol=1e-12)
+    assert np.abs(s.grad.numpy() - z["seg_grad_f64"]).max() < 1e-14
+    assert np.abs(z["seg_parts_f32"] - z["seg_parts_f64"]).max() < 1e-5  # the reference's own fp32 run of the same method
+    lab = torch.from_numpy(z["reg_labels"]).double()
+    ign = float(z["reg_ignore"])
+    for use_log, key in ((False, "lin"), (True, "log")):
+        s = torch.from_numpy(z["reg_student"]).double().requires_grad_(True)
+        loss, preds, l2 = O.regression_loss(s, lab, ign, use_log)
+        loss.backward()
+        assert abs(loss.item() - float(z[f"reg_loss_{key}_f64"])) < 1e-12 and np.abs(s.grad.numpy() - z[f"reg_grad_{key}_f64"]).max() < 1e-14
+        m = O.regression_metrics(O.regression_sums(l2.numpy(), preds.numpy()), include_ee=True)
+        got = np.array([m[k] for k in ("mae", "rmse", "r2_score", "pearson_corrcoef", "ee_percentage")])
+        assert np.allclose(got, z[f"reg_metrics_{key}_f64"], rtol=1e-12, atol=1e-12)  # the step's metrics.update(labels, preds) operands
+        s = torch.from_numpy(z["reg_student"]).double().requires_grad_(True)
+        tot, mse, kdl = O.regression_distillation_loss(s, torch.from_numpy(z["reg_teacher"]).double(), lab, ign, use_log)
+        tot.backward()
+        assert np.allclose([tot.item(), mse.item(), kdl.item()], z[f"regkd_parts_{key}_f64"], rtol=0, atol=1e-12)
+        assert np.abs(s.grad.numpy() - z[f"regkd_grad_{key}_f64"]).max() < 1e-14
+
+
 def test_interpolated_pos_embed_matches_reference_fixture():
     """interpolate_pos_encoding (pritvhi.py:149-203; inputs off the configured 224 grid): the oracle restatement against the rows
     gen_golden.py stored from the imported reference function (bicubic, align_corners=True, cls row kept)."""

@@ -344,6 +344,22 @@ def test_whole_network_custom_op_opcheck_and_torch_compile():
         err = np.linalg.norm(sub(g.contiguous(), 1024).astype(np.float64) - gold["grad_sub__" + k]) / np.linalg.norm(gold["grad_sub__" + k])
         print(f"   grad through the op {k}: rel-L2 {err:.3e}")
         assert err <= 1e-2, k
+    eager_grads = {k: p.grad.clone() for k, p in net.named_parameters()}
+    # a loss on the features output must not train nothing silently: the op refuses a gradient into it
+    out, feats = net(x, return_features=True)
+    with pytest.raises(RuntimeError, match="not differentiable"):
+        (out.mean() + feats.mean()).backward()
+    # COMPILED training steps: the forward generation is an op output, so the backward graph traced once stays valid for every later
+    # step (read from Python state in setup_context it was baked in at trace time and the first real step raised)
+    dynamo.reset()
+    comp = torch.compile(net, fullgraph=True, backend="aot_eager")
+    for step in range(3):
+        for p in net.parameters():
+            p.grad = None
+        loss = segmentation_loss(comp(x), lab.to(DEV), cw, -1)
+        loss.backward()
+        for k, p in net.named_parameters():
+            assert torch.equal(p.grad, eager_grads[k]), f"compiled step {step}: gradient of {k} differs from eager"
 
 
 def test_frozen_backbone_and_state_dict_roundtrip(tmp_path):

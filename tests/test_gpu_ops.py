@@ -137,6 +137,77 @@ def test_linear_v8_engine(split, M, N, K, monkeypatch):
     close(res, rref, 2e-5 if split else 1e-5, what="v8 residual in-place")
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 512, 256), (2300, 768, 768), (21276, 2304, 768), (5000, 768, 3072), (700, 1024, 1024), (600, 1024, 4096),
+                                   (900, 1280, 1280), (257, 256, 384)])
+def test_linear_v4_engine(M, N, K, monkeypatch):
+    """The 4-wave / one-wave-per-SIMD engine with the generated K-loop (gemm4.hip + gen_gemm4.py), forced for every covered shape
+    (IG_GEMM4=2): qkv / fc1 (+GELU, +saved gelu') / proj / fc2 forms and the data gradient with the gelu' factor + fused column sums,
+    against float64 on the same rounded operands; K = 256 (no middle loop trip) .. 4096, the 300M / 600M widths (K = 1024 / 4096 / 1280),
+    a ragged last row block and a one-row last block; repeated launches bit-identical (LDS-DMA / barrier / AGPR read-out race screen);
+    equal to the 8-phase engine's result to the output rounding."""
+    monkeypatch.setenv("IG_GEMM8", "2")
+    monkeypatch.setenv("IG_GEMM4", "2")
+    x, xr = bt(rnd(M, K, seed=1), False)
+    w, wr = bt(rnd(N, K, seed=2, scale=K**-0.5), False)
+    b = rnd(N, seed=3).to(DEV)
+    y = BT.zeros((M, N), False, DEV)
+    pre = BT.zeros((M, N), False, DEV)
+    ref = xr @ wr.t() + b.double().cpu()
+    ops.linear_fwd(x, w, b, y, M, N, K, act=0)
+    assert ops.last_kernel().startswith("gemm4_kernel<0,0"), ops.last_kernel()
+    close(y.float(), ref, tol_out(False), what="v4 linear")
+    first = y.hi.clone()
+    for _ in range(6):
+        y.hi.zero_()
+        ops.linear_fwd(x, w, b, y, M, N, K, act=0)
+        assert torch.equal(y.hi, first), "v4 linear differs between identical launches"
+    monkeypatch.setenv("IG_GEMM4", "0")
+    y8 = BT.zeros((M, N), False, DEV)
+    ops.linear_fwd(x, w, b, y8, M, N, K, act=0)
+    assert ops.last_kernel().startswith("gemm8_kernel"), ops.last_kernel()
+    close(y.float(), y8.float().double().cpu(), tol_out(False), what="v4 vs v8")
+    monkeypatch.setenv("IG_GEMM4", "2")
+    ops.linear_fwd(x, w, None, y, M, N, K, act=0)
+    close(y.float(), xr @ wr.t(), tol_out(False), what="v4 linear, no bias")
+    ops.linear_fwd(x, w, b, y, M, N, K, act=1, pre=pre)
+    assert ops.last_kernel().startswith("gemm4_kernel<0,1,true"), ops.last_kernel()
+    rr = ref.clone().requires_grad_(True)
+    (dref,) = torch.autograd.grad(F.gelu(rr).sum(), rr)
+    close(y.float(), F.gelu(ref), tol_out(False), what="v4 gelu")
+    close(pre.float(), dref, tol_out(False), what="v4 saved gelu'")
+    ops.linear_fwd(x, w, b, y, M, N, K, act=1)
+    assert ops.last_kernel().startswith("gemm4_kernel<0,1,false"), ops.last_kernel()
+    close(y.float(), F.gelu(ref), tol_out(False), what="v4 gelu (no save)")
+    res = rnd(M, N, seed=4).to(DEV)
+    out = torch.zeros_like(res)
+    ops.linear_residual_fwd(x, w, b, res, out, M, N, K)
+    assert ops.last_kernel().startswith("gemm4_kernel<1"), ops.last_kernel()
+    rref = res.double().cpu() + ref
+    close(out, rref, 1e-5, what="v4 residual")
+    first = out.clone()
+    for _ in range(4):
+        out.zero_()
+        ops.linear_residual_fwd(x, w, b, res, out, M, N, K)
+        assert torch.equal(out, first), "v4 residual differs between identical launches"
+    ops.linear_residual_fwd(x, w, b, res, res, M, N, K)  # in place, as the engine uses it
+    close(res, rref, 1e-5, what="v4 residual in-place")
+    # data gradient through the transposed weight copy: dx = (dy @ w) * dact, fused column sums
+    dy, dyr = bt(rnd(M, N, seed=5), False)
+    wt = BT(w.hi.t().contiguous(), None)          # (K, N): the K-contiguous operand of the dgrad GEMM  (here: dx is (M, K))
+    dx = BT.zeros((M, K), False, DEV)
+    fac, facr = bt(rnd(M, K, seed=8), False)
+    cs = torch.zeros(K, device=DEV)
+    if K % 256 == 0 and N >= 256:
+        ops.linear_dgrad(dy, None, dx, M, N, K, pre=fac, colsum=cs, wt=wt)
+        assert ops.last_kernel().startswith("gemm4_kernel<2"), ops.last_kernel()
+        want = (dyr @ wr) * facr
+        close(dx.float(), want, tol_out(False), what="v4 dgrad*dact")
+        close(cs, want.sum(0), 3e-5, what="v4 fused column sums")
+        ops.linear_dgrad(dy, None, dx, M, N, K, wt=wt)
+        assert ops.last_kernel().startswith("gemm4_kernel<0,0"), ops.last_kernel()
+        close(dx.float(), dyr @ wr, tol_out(False), what="v4 plain dgrad")
+
+
 @pytest.mark.parametrize("split", SPLITS)
 def test_linear_residual(split):
     M, N, K = 333, 256, 1024
@@ -627,6 +698,40 @@ def test_convT(split, B, H, Cin, Cout):  # 96 -> 48 unsplit runs the direct sub-
     ops.convT_wgrad(dy, x, dw, B, H, W, Cin, Cout, dbias=db)
     close(dw, gw.permute(1, 2, 3, 0).reshape(Cout, 9, Cin), 3e-5, what="convT wgrad")
     close(db - 0.25, dyr.sum((0, 1, 2)), 3e-5, what="convT bias gradient")
+
+
+def test_two_streams_do_not_share_scratch(monkeypatch):
+    """The library's scratch buffers are keyed by (device, stream, slot) (runtime.hip): conv8 re-packs its weights into slot 1 on every call
+    and the GEMM behind it reads them, and the BatchNorm statistics kernels keep their workgroup partials in slot 0.  Two streams of one
+    device -- a distillation teacher's forward beside the student's step (segmentation.py:216-451) -- used to share ONE buffer per slot and
+    could overwrite each other silently.  Here two streams run the same convolution with DIFFERENT weights, interleaved
+    launch by launch: every result must equal its single-stream result bit for bit (the model-level form -- a teacher forward beside a
+    student step -- is tests/test_gpu_pipeline.py::test_teacher_forward_on_a_side_stream_beside_a_student_step)."""
+    monkeypatch.setenv("IG_CONV8", "2")
+    monkeypatch.setenv("IG_CONV_DIRECT", "0")
+    B, H, Cin, Cout = 2, 24, 128, 256
+    W = H + 3
+    x, _ = bt(nhwc(rnd(B, Cin, H, W, seed=71)), False)
+    ws = [bt((rnd(Cout, Cin, 3, 3, seed=72 + i, scale=(9 * Cin) ** -0.5)).permute(0, 2, 3, 1).reshape(Cout, 9, Cin).contiguous(), False)[0] for i in range(2)]
+    bias = rnd(Cout, seed=75).to(DEV)
+    want = []
+    for w in ws:
+        y = BT.zeros((B, H, W, Cout), False, DEV)
+        ops.conv3x3_fwd(x, w, bias, y, B, H, W, Cin, Cout)
+        assert ops.last_kernel().startswith("conv8_kernel"), ops.last_kernel()
+        want.append(y.hi.clone())
+    assert not torch.equal(want[0], want[1])
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[BT.zeros((B, H, W, Cout), False, DEV) for _ in range(12)] for _ in range(2)]
+    for it in range(12):
+        for si in range(2):
+            with torch.cuda.stream(streams[si]):
+                ops.conv3x3_fwd(x, ws[si], bias, outs[si][it], B, H, W, Cin, Cout)
+    torch.cuda.synchronize()
+    for si in range(2):
+        for it in range(12):
+            assert torch.equal(outs[si][it].hi, want[si]), f"stream {si}, launch {it}: conv8 read the other stream's packed weights"
 
 
 @pytest.mark.parametrize("split", SPLITS)

@@ -566,6 +566,95 @@ def test_distillation_module_loss_gradient_and_run(tmp_path, capsys):
     assert not any(k.startswith("teacher.") for k in s_sd)
 
 
+def test_teacher_forward_on_a_side_stream_beside_a_student_step():
+    """Distillation flow (segmentation.py:216-451) with the teacher on its OWN stream: a frozen teacher's inference forward runs on a side
+    stream while the student's fused training steps run on the main stream.  Both engines use the library's scratch (BatchNorm partial
+    sums, packed conv8 weights), which is per (device, stream): the teacher's logits must equal its single-stream logits bit for bit on
+    every repetition, and the student's three steps must equal the same three steps run alone."""
+    from instageo_amd.segmentation import PrithviSegmentationModule
+    from oracle import prithvi_oracle as O
+    from oracle.cases import case_config, make_inputs
+
+    name = "tiny_t1_c2"
+    cfg = case_config(name)
+    sd = O.make_state_dict(cfg, seed=1042)
+    img, lab = make_inputs(name, cfg, 4)
+    img, lab = img.to(DEV), lab.to(DEV)
+
+    def student():
+        m = PrithviSegmentationModule(freeze_backbone=False, load_pretrained_weights=False, num_classes=2, model_name="prithvi_eo_tiny",
+                                      class_weights=[1, 3], ignore_index=-1, precision="bf16", device=DEV)
+        m.net.load_state_dict(sd)
+        return m
+
+    teacher = student().net
+    teacher.eval()
+    with torch.no_grad():
+        t_ref = teacher(img).clone()
+    alone = student()
+    ref_losses = []
+    for _ in range(3):
+        st = alone.fused_train_step(img, lab)
+        ref_losses.append((st[0] / st[1]).item())
+    ref_flat = alone.net.store.flat.clone()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    stu = student()
+    losses, t_outs = [], []
+    for _ in range(3):
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(2):
+                t_outs.append(teacher(img).clone())
+        st = stu.fused_train_step(img, lab)
+        losses.append((st[0] / st[1]).item())
+    torch.cuda.synchronize()
+    assert all(torch.equal(t, t_ref) for t in t_outs), "teacher logits changed beside the student's step"
+    assert losses == ref_losses and torch.equal(stu.net.store.flat, ref_flat), "student steps changed beside the teacher's forward"
+
+
+def test_task_loss_kernels_match_the_reference_generated_fixture():
+    """ig_ce_loss + ig_kd_loss, ig_mse_loss and ig_mse_loss + ig_kd_mse_loss against tests/golden/task_losses.npz, i.e. against the
+    reference's own PrithviDistillationSegmentationModule._compute_loss (segmentation.py:352-378), PrithviRegressionModule._shared_step
+    (regression.py:141-168) and PrithviDistillationRegressionModule._shared_step (regression.py:477-534) run by oracle/gen_golden.py:
+    loss parts to 2e-6 relative (fp32 per-element arithmetic, fp64 sums), gradients w.r.t. the student output to 2e-6 absolute."""
+    from instageo_amd.metrics import RunningRegressionMetrics
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "task_losses.npz"))
+    s_log, t_log, lab = (torch.from_numpy(z[k]) for k in ("seg_student", "seg_teacher", "seg_labels"))
+    stats = torch.zeros(2, dtype=torch.float64, device=DEV)
+    kl = torch.zeros(1, dtype=torch.float64, device=DEV)
+    dl = torch.empty(s_log.shape, device=DEV)
+    ops.ce_loss(s_log.to(DEV), lab.to(DEV), torch.from_numpy(z["seg_class_weights"]).to(DEV), int(z["seg_ignore"]), stats, dl)
+    ops.kd_loss(s_log.to(DEV), t_log.to(DEV), lab.to(DEV), int(z["seg_ignore"]), kl, dl)
+    n = stats[1].item()
+    tot, ce, kd = z["seg_parts_f64"]
+    assert n == int((lab != int(z["seg_ignore"])).sum())
+    assert abs(stats[0].item() / n - ce) < 2e-6 * max(1.0, ce) and abs(kl.item() / n - kd) < 2e-6 * max(1.0, kd)
+    assert abs((stats[0].item() + kl.item()) / n - tot) < 4e-6 * max(1.0, tot)
+    assert np.abs((dl / n).cpu().double().numpy() - z["seg_grad_f64"]).max() < 2e-6, "CE + KL gradient vs the reference's autograd"
+    s_out, t_out, labf = (torch.from_numpy(z[k]) for k in ("reg_student", "reg_teacher", "reg_labels"))
+    ign = float(z["reg_ignore"])
+    for use_log, key in ((False, "lin"), (True, "log")):
+        stats.zero_()
+        dl = torch.empty(s_out.shape, device=DEV)
+        met = RunningRegressionMetrics(include_ee=True, device=DEV)
+        ops.mse_loss(s_out.to(DEV), labf.to(DEV), ign, use_log, stats, dl, met.device_sums(DEV), met.ee_bias, met.ee_coef, True)
+        n = stats[1].item()
+        ref = float(z[f"reg_loss_{key}_f64"])
+        assert abs(stats[0].item() / n - ref) < 2e-6 * max(1.0, ref)
+        assert np.abs((dl / n).cpu().double().numpy() - z[f"reg_grad_{key}_f64"]).max() < 2e-6
+        got = met.compute()
+        want = dict(zip(("mae", "rmse", "r2_score", "pearson_corrcoef", "ee_percentage"), z[f"reg_metrics_{key}_f64"]))
+        for k in ("mae", "rmse", "r2_score", "pearson_corrcoef"):
+            assert abs(got[k] - want[k]) <= 2e-5 * max(1.0, abs(want[k])), k
+        assert abs(got["ee_percentage"] - want["ee_percentage"]) <= 0.1
+        kdsum = torch.zeros(1, dtype=torch.float64, device=DEV)
+        ops.kd_mse_loss(s_out.to(DEV), t_out.to(DEV), labf.to(DEV), ign, use_log, kdsum, dl)  # adds the teacher term onto dl
+        tot, mse, kdl = z[f"regkd_parts_{key}_f64"]
+        assert abs(kdsum.item() / n - kdl) < 2e-6 * max(1.0, kdl) and abs(stats[0].item() / n - mse) < 2e-6 * max(1.0, mse)
+        assert np.abs((dl / n).cpu().double().numpy() - z[f"regkd_grad_{key}_f64"]).max() < 2e-6
+
+
 @pytest.mark.parametrize("use_log", [False, True])
 def test_regression_distillation_loss_gradient_and_run(tmp_path, capsys, use_log):
     """is_reg_task + train.distillation (regression.py:345-534): ig_mse_loss + ig_kd_mse_loss against the oracle restatement
