@@ -261,8 +261,11 @@ def main() -> None:
 
     rank, local_rank, world = D.init_from_env()
     dp = D.dp_active()  # more than one rank -- or ONE rank under IG_DIST_FORCE=1 (pre-flight of the RCCL path on a one-GPU box)
-    if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if world != args.gpus:  # every rank: a bench line whose n_gpus differs from the ranks that ran is not a measurement
+        print(f"bench.py: --gpus {args.gpus} but {world} rank(s) joined the rendezvous (rank {rank})", file=sys.stderr)
+        if world > 1:
+            dist.destroy_process_group()
+        sys.exit(2)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     torch.manual_seed(1042 + rank)
@@ -334,8 +337,15 @@ def main() -> None:
         for i in range(args.steps):
             train_step(i)
         barrier()
-        dt = max_over_ranks(time.perf_counter() - t0)
-        res = {"mod": mod, "dt": dt, "prof": ops.profile_end() if profile else None, "prof_all": None, "graphed": graphed is not None,
+        dt_own = time.perf_counter() - t0
+        dt = max_over_ranks(dt_own)
+        per_rank = None
+        if dp and dist.is_initialized():  # every rank's own clock around the same K steps (the barrier makes them nearly equal: a straggler shows)
+            mine = torch.tensor([dt_own], dtype=torch.float64, device=dev)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            per_rank = [round(B * args.steps / a.item(), 1) for a in allr]
+        res = {"mod": mod, "dt": dt, "per_rank_chips_per_s": per_rank, "prof": ops.profile_end() if profile else None, "prof_all": None, "graphed": graphed is not None,
                "loss": (stats[0] / stats[1]).item(), "buckets": None}
         res["dp_mode"] = None if sync is None else ("zero1" if isinstance(sync, D.ShardedGradSync) else "allreduce")
         if isinstance(sync, D.GradSync):  # per-bucket all-reduce time of one extra, instrumented step (outside the timed region)
@@ -394,6 +404,51 @@ def main() -> None:
             res["enc_ms"] = e0.elapsed_time(e1) / args.steps
         return res
 
+    def dp_preflight() -> dict:
+        """Before anything is timed on a data-parallel run: every rank agrees on the world size, and the DEFERRED all-gather of the bf16 operand
+        copy (IG_DP_DEFER=1, the default: waited for Block by Block by the next forward) leaves exactly the operand copy and fp32 masters that
+        the blocking form leaves -- two modules from the same seed take two steps on the same batch, one per form, and a checksum of
+        ``store.shadow`` / ``store.flat`` is compared on every rank.  A difference switches this process to the blocking form (the variable is
+        read per step; no re-exec) and is reported on the JSON line."""
+        t = torch.tensor([world, dist.get_world_size(), 1], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        ranks_seen = int(t[2].item())
+        if ranks_seen != world or int(t[0].item()) != world * world or int(t[1].item()) != world * world:
+            raise SystemExit(f"bench.py pre-flight: {ranks_seen} ranks answered, WORLD_SIZE={world}, get_world_size()={dist.get_world_size()}")
+        info = {"ranks_seen": ranks_seen, "defer": os.environ.get("IG_DP_DEFER", "1") != "0", "defer_fallback": False}
+        if os.environ.get("IG_DP_MODE", "zero1") != "zero1" or not info["defer"]:
+            return info
+        sums = []
+        for form in ("1", "0"):
+            os.environ["IG_DP_DEFER"] = form
+            torch.manual_seed(4242)
+            m = PrithviSegmentationModule(image_size=224, learning_rate=1e-4, freeze_backbone=False, load_pretrained_weights=False, num_classes=NCLS,
+                                          temporal_step=T, class_weights=main_wl["cw"], ignore_index=-1, weight_decay=0.01, scheduler=False,
+                                          model_name=args.model, precision=args.precision, device=dev)  # fmt: skip
+            sy = D.attach_data_parallel(m)
+            pb = min(B, 8)
+            ops.normalize_chips(raws[0][:pb], mean, std, T, 1e-4, out=xbuf[:pb])
+            for _ in range(2):
+                m.fused_train_step(xbuf[:pb], labels[0][:pb])
+            if hasattr(sy, "wait_params"):
+                sy.wait_params()
+            torch.cuda.synchronize()
+            st = m.net.store
+            sums.append((st.shadow.hi.view(torch.int16).to(torch.int64).sum().item(),))  # the bf16 operand copy every kernel of the next forward reads
+            del m, sy
+        os.environ["IG_DP_DEFER"] = "1"
+        bad = torch.tensor([int(sums[0][0] != sums[1][0])], dtype=torch.int64, device=dev)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        info["shadow_checksum"] = sums[0][0]
+        if bad.item():
+            os.environ["IG_DP_DEFER"] = "0"  # every rank takes the same decision (the MAX above)
+            info["defer"], info["defer_fallback"] = False, True
+            if rank == 0:
+                print("bench.py pre-flight: deferred all-gather != blocking all-gather on the operand copy; falling back to IG_DP_DEFER=0", file=sys.stderr)
+        torch.cuda.empty_cache()
+        return info
+
+    preflight = dp_preflight() if dp and dist.is_initialized() else None
     main_res = run_mode(args.precision, not args.no_profile and not args.graph, args.graph)
     mod = main_res["mod"]
     cfgm = mod.net.cfg
@@ -643,6 +698,7 @@ def main() -> None:
     if dp:
         bk = main_res["buckets"] or []
         out["dist"] = {"ranks": world, "backend": dist.get_backend(), "mode": main_res.get("dp_mode"), "reserved_cus": ops.reserved_cus(), "buckets": len(bk),
+                       "per_rank_chips_per_s": main_res.get("per_rank_chips_per_s"), "preflight": preflight,
                        "allreduce_mbytes": round(sum(b["mbytes"] for b in bk), 1), "allreduce_ms_serial": round(sum(b["ms"] for b in bk), 3)}
         ex = main_res.get("exposed")
         if ex is not None:  # zero1: time the compute stream stood still for the reduce-scatters / all-gathers of one instrumented step

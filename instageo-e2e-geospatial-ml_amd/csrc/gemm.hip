@@ -1382,24 +1382,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __rest
         out[i] = o;
     }
 }
-// workspace of the split-K partial tiles, per device: grown on demand and never freed -- a superseded buffer stays allocated,
-// because a captured hipGraph (make_graphed_train_step) may have baked its address into kernel nodes that are replayed after an
-// eager launch with more splits has grown the workspace.  All launches are ordered on the caller's stream.  While a
-// stream capture is active nothing may be allocated: the caller then falls back to atomics unless the workspace already fits.
+// workspace of the split-K partial tiles: per (device, stream), grown on demand (runtime.hip: ig_scratch slot 5; a buffer a captured
+// hipGraph may hold is never freed there).  While a stream capture is active nothing may be allocated: the caller then falls back to
+// atomics unless the workspace already fits.
 inline float* splitk_workspace(size_t bytes, hipStream_t st) {
-    constexpr int kMaxDev = 16;
-    static void* ws[kMaxDev] = {};
-    static size_t cap[kMaxDev] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
-    if (bytes > cap[dev]) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;
-        void* p = nullptr;
-        if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
-        ws[dev] = p, cap[dev] = bytes;  // the previous buffer is deliberately leaked (bounded: sizes only grow)
-    }
-    return (float*)ws[dev];
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+    return (float*)ig_scratch2(5, bytes, !capturing, st);
 }
 constexpr bool splitk_partial_enabled() { return true; }  // split-K partials + ordered fold (the float-atomic form was an A/B arm)
 

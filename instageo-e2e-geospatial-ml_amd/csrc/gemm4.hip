@@ -9,11 +9,9 @@
 //   written by gen_gemm4.py (the Makefile runs it): accumulators in a0..a255, two fragment sets in v128..v255, the LDS-DMA issues woven in
 //   behind every 4th MFMA of the loop's second half, fragment reads behind every 3rd.  This file holds the C++ around it: the persistent tile
 //   loop, the operand addressing and the epilogues, which read the accumulators back with v_accvgpr_read_b32 (g4_acc_row).
-// * LDS: 2 stages x {A 256 x 128 B, B 256 x 128 B} = 128 KiB, 16-byte chunks swizzled by row & 7 on the DMA source address and on the
-//   fragment reads (as gemm8.hip), + 4 x 8 KiB wave-private epilogue staging = 160 KiB.
-// * L2 prefetch: the LDS ring holds one K-tile of DMA in flight; activation rows that no other tile of the XCD has pulled in yet come from HBM
-//   and do not return inside that window.  One `global_load_dword` per wave and K-tile touches the 64 lines of the wave's rows one K-tile
-//   ahead of the DMA stream (gen_gemm4.py, pf): qkv 130 -> 122 us, fc2-shaped 159 -> 145 us at M = 42552 (profiles/r06_gemm4_*.txt).
+// * LDS (all 160 KiB): a ring of three A slots + two B stages of 256 rows x 128 B, 16-byte chunks swizzled by row & 7 on the DMA source address
+//   and on the fragment reads (as gemm8.hip).  The A slot whose K-tile was consumed last is free until the next tile's first iteration: it is
+//   the epilogue's staging buffer (4 x 8 KiB, wave-private).  The ring state (three slot offsets) lives in registers across tiles.
 // * Epilogues (same contracts as gemm8.hip's kinds; the bias is added here, not in the accumulator init):
 //     kind 0: bf16 store of act(acc + bias) [+ the gelu' copy for the backward pass]
 //     kind 1: fp32 out = resid + acc + bias
@@ -27,7 +25,7 @@
 namespace {
 
 typedef __attribute__((address_space(3))) char* lds_char_ptr;
-constexpr int G4_STAGES = 2 * 65536, G4_SMEM = G4_STAGES + 4 * 8192;
+constexpr int G4_SMEM = 5 * 32768;  // A slots at 0 / 32 / 64 KiB, B stages at 96 / 128 KiB (gen_gemm4.py)
 
 template <bool NT = false, typename T>
 __device__ __forceinline__ void g4_store(T* ptr, const T& v) {
@@ -66,6 +64,7 @@ __global__ __launch_bounds__(256) void gemm4_kernel(G8Params p) {
     const unsigned fb = lds_base + (wc * 128 + (lane & 15)) * 128 + swz;
     const unsigned ldsw = lds_base + wave * 8192;
 
+    unsigned a0 = 0, a1 = 32768, a2 = 65536;  // A ring: slot offsets of K-tiles kt, kt + 1, kt + 2 (rotated by the asm blocks)
     int tile = tlo + jx;
     {
         const int bm = tile / tiles_n, bn = tile - bm * tiles_n;
@@ -73,7 +72,7 @@ __global__ __launch_bounds__(256) void gemm4_kernel(G8Params p) {
         const char* bptr = (const char*)p.b[0] + (long)bn * 256 * ldb2;
         const int vrc = min(256, p.M - bm * 256) - 1;
         asm volatile(G4_ASM_PROLOGUE ::[aptr] "s"(aptr), [bptr] "s"(bptr), [lda2] "s"(lda2), [ldb2] "s"(ldb2), [vrc] "s"(vrc), [vrn] "s"(vrc), [ldsw] "s"(ldsw),
-                     [rowv] "v"(rowv), [c16] "v"(c16), [fa] "v"(fa), [fb] "v"(fb)
+                     [a0] "s"(a0), [a1] "s"(a1), [a2] "s"(a2), [rowv] "v"(rowv), [c16] "v"(c16), [fa] "v"(fa), [fb] "v"(fb)
                      : G4_CLOBBERS);
     }
     for (int t = 0; t < my_tiles; ++t, tile += nbx) {
@@ -85,7 +84,7 @@ __global__ __launch_bounds__(256) void gemm4_kernel(G8Params p) {
         const char* anext = (const char*)p.a[0] + (long)bm2 * 256 * lda2;
         const char* bnext = (const char*)p.b[0] + (long)bn2 * 256 * ldb2;
         const int vrc = min(256, p.M - bm * 256) - 1, vrn = min(256, p.M - bm2 * 256) - 1;
-        asm volatile(G4_ASM_TILE ::[aptr] "s"(aptr), [bptr] "s"(bptr), [anext] "s"(anext), [bnext] "s"(bnext), [lda2] "s"(lda2), [ldb2] "s"(ldb2), [vrc] "s"(vrc),
+        asm volatile(G4_ASM_TILE : [a0] "+s"(a0), [a1] "+s"(a1), [a2] "+s"(a2) : [aptr] "s"(aptr), [bptr] "s"(bptr), [anext] "s"(anext), [bnext] "s"(bnext), [lda2] "s"(lda2), [ldb2] "s"(ldb2), [vrc] "s"(vrc),
                      [vrn] "s"(vrn), [npair] "s"(npair), [ldsw] "s"(ldsw), [wave] "s"(wave), [rowv] "v"(rowv), [c16] "v"(c16), [fa] "v"(fa), [fb] "v"(fb)
                      : G4_CLOBBERS);
         // ================= epilogue (the next tile's K-tiles 0 and 1 are in flight) =================
@@ -95,7 +94,7 @@ __global__ __launch_bounds__(256) void gemm4_kernel(G8Params p) {
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
 #define lane lane_e
-        char* st = smem + G4_STAGES + wave * 8192;
+        char* st = smem + a2 + wave * 8192;  // the A slot this tile's last K-tile has left
         const int n0 = bn * 256 + wc * 128, mw = bm * 256 + wr * 128;
         const int erow = lane & 15, eq = lane >> 4;
         if constexpr (KIND == 0) {
@@ -154,11 +153,16 @@ __global__ __launch_bounds__(256) void gemm4_kernel(G8Params p) {
             // (32 lanes = one 512-byte row); the residual rows of row block mi + 1 are loaded before row block mi is stored
             const int rc = lane & 31, rr = lane >> 5;
             const float4 b4 = p.bias ? *reinterpret_cast<const float4*>(p.bias + n0 + rc * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            // wave-uniform bases + 32-bit lane offsets (scalar-base addressing: half the address registers of per-lane 64-bit pointers)
+            const float* rbase = p.resid + (size_t)mw * p.ldo + n0;
+            float* obase = p.outf + (size_t)mw * p.ldo + n0;
+            const int mlast = p.M - 1 - mw;  // last valid row of the wave's 128 (>= 0: a tile has at least one row; may be < 0 for wr = 1 -> clamp)
+            const unsigned ldo4 = (unsigned)p.ldo;
             float4 rs[2][8];
 #define G4_RESID_LOAD(MI, DST)                                                                     \
     _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                             \
-        const int m_ = min(mw + (MI)*16 + i_ * 2 + rr, p.M - 1);                                   \
-        DST[i_] = *reinterpret_cast<const float4*>(p.resid + (size_t)m_ * p.ldo + n0 + rc * 4);    \
+        const int r_ = max(min((MI)*16 + i_ * 2 + rr, mlast), -mw);                                \
+        DST[i_] = *reinterpret_cast<const float4*>(rbase + (long)r_ * ldo4 + rc * 4);              \
     }
             G4_RESID_LOAD(0, rs[0])
 #pragma unroll
@@ -175,10 +179,10 @@ __global__ __launch_bounds__(256) void gemm4_kernel(G8Params p) {
                 for (int i = 0; i < 8; ++i) {
                     const int r = i * 2 + rr;
                     const f32x4 a = *reinterpret_cast<const f32x4*>(st + r * 512 + ((rc ^ (r & 7)) << 4));
-                    const int m = mw + mi * 16 + r;
-                    if (m < p.M) {
+                    const int rl = mi * 16 + r;
+                    if (rl <= mlast) {
                         const float4 rv = rs[mi & 1][i];
-                        g4_store(reinterpret_cast<float4*>(p.outf + (size_t)m * p.ldo + n0 + rc * 4),
+                        g4_store(reinterpret_cast<float4*>(obase + (unsigned)rl * ldo4 + rc * 4),
                                  make_float4(rv.x + a[0] + b4.x, rv.y + a[1] + b4.y, rv.z + a[2] + b4.z, rv.w + a[3] + b4.w));
                     }
                 }
@@ -190,16 +194,20 @@ __global__ __launch_bounds__(256) void gemm4_kernel(G8Params p) {
             // the four factor loads of a row block go out before its staging round trip
             const int rcol = (lane & 15) * 8;
             float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+            uint4 fh[2][4];
+            // gelu' was saved by the forward pass and is read exactly once: streaming (non-temporal) loads; the four loads of row block mi + 1 go
+            // out before row block mi is staged and stored (one wave per SIMD: nothing else hides their latency)
+#define G4_FACTOR_LOAD(MI, DST)                                                                                                    \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                                             \
+        const int m_ = min(mw + (MI)*16 + j_ * 4 + eq, p.M - 1);                                                                   \
+        DST[j_] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p.dact_hi + (size_t)m_ * p.ldo + n0 + rcol))); \
+    }
+            G4_FACTOR_LOAD(0, fh[0])
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) {
                 const int m0 = mw + mi * 16;
-                typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-                uint4 fh[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int m = min(m0 + j * 4 + eq, p.M - 1);
-                    fh[j] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p.dact_hi + (size_t)m * p.ldo + n0 + rcol)));
-                }
+                if (mi + 1 < 8) G4_FACTOR_LOAD(mi + 1, fh[(mi + 1) & 1])
                 f32x4 tt[8];
                 g4_acc_row(mi, tt);
 #pragma unroll
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(256) void gemm4_kernel(G8Params p) {
                     const f32x4 a1 = *reinterpret_cast<const f32x4*>(st + r * 512 + (((cc + 1) ^ (r & 7)) << 4));
                     float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
                     float f[8];
-                    unpack8(fh[j], f);
+                    unpack8(fh[mi & 1][j], f);
                     if (m0 + r < p.M) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] *= f[e], cs[e] += v[e];
@@ -222,6 +230,7 @@ __global__ __launch_bounds__(256) void gemm4_kernel(G8Params p) {
                     }
                 }
             }
+#undef G4_FACTOR_LOAD
             if (p.colsum) {  // lanes with equal (lane & 15) own the same 8 columns: fold over lane >> 4, one atomic per column
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -271,6 +280,11 @@ int ig_gemm4_nt(const G8Params& p, void* stream) {
     if ((p.lda & 7) || (p.ldb & 7) || (p.ldo & 7) || ((uintptr_t)p.a[0] & 15) || ((uintptr_t)p.b[0] & 15)) return IG_ERR_UNSUPPORTED;
     const int ntiles = ((p.M + 255) >> 8) * (p.N >> 8);
     if (ntiles < 128 && g4_env() != 2) return IG_ERR_UNSUPPORTED;  // below one tile per CU the 128 x 128 instance of gemm8.hip takes over (as there)
+    // Routing by measurement (same-process A/B at M = 42552, profiles/r06_gemm4_vs_gemm8.txt): the plain bf16 store (qkv -4 %, the N = 768 /
+    // K = 3072 data gradient -9 %), the fp32 residual kind (fc2 -8 %, proj -4 %) and dx * gelu' (-6 %) win; the GELU epilogues are bound by VALU
+    // issue -- one wave per SIMD issues a vector instruction every 4 cycles where the two co-resident waves of gemm8.hip issue one every 2 --
+    // and come out equal (+0.5 %): they stay on the 8-phase engine.  IG_GEMM4=2 forces every kind (tests).
+    if (g4_env() != 2 && p.act != 0) return IG_ERR_UNSUPPORTED;
     const int grid = ig_tile_grid(ntiles, 1);
     hipStream_t st = (hipStream_t)stream;
     if (p.kind == 0) {

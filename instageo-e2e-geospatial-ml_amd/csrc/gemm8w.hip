@@ -469,24 +469,10 @@ PlanCache& plan_cache() {
     static PlanCache c;
     return c;
 }
-// slab workspace, per device: grown on demand; superseded buffers are kept (a captured graph may still hold their address) and
-// nothing is allocated while a stream capture is active (the first eager step has sized it by then)
-float* slab_workspace(long nslab, bool capturing) {
-    constexpr int kMaxDev = 16;
-    static float* ws[kMaxDev] = {};
-    static long cap[kMaxDev] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
-    if (nslab > cap[dev]) {
-        if (capturing) return nullptr;
-        // geometric growth: superseded buffers are never freed, so the sizes must not creep up slab by slab (a sweep over 110 token
-        // counts left 520 MB of them behind); with a factor of 1.5 the total stays below three times the largest request
-        const long want = nslab > cap[dev] + cap[dev] / 2 ? nslab : cap[dev] + cap[dev] / 2;
-        void* p = nullptr;
-        if (hipMalloc(&p, (size_t)want * W_SLAB * sizeof(float)) != hipSuccess) return nullptr;
-        ws[dev] = (float*)p, cap[dev] = want;
-    }
-    return ws[dev];
+// slab workspace: per (device, stream), grown on demand (runtime.hip: ig_scratch slot 4); nothing is allocated while a stream capture is
+// active (the first eager step on that stream has sized it by then)
+float* slab_workspace(long nslab, bool capturing, hipStream_t st) {
+    return (float*)ig_scratch2(4, (size_t)nslab * W_SLAB * sizeof(float), !capturing, st);
 }
 const bf16_t* w_zero_page() {
     constexpr int kMaxDev = 16;
@@ -674,7 +660,7 @@ int w_run(const WKey& key, const std::vector<TileRef>& tl, int M, int lda2_of_g[
             cache.map.emplace(key, std::make_pair(pl, cache.lru.begin()));
         }
     }
-    float* ws = slab_workspace(pl.nslab, capturing);
+    float* ws = slab_workspace(pl.nslab, capturing, st);
     const bf16_t* zp = w_zero_page();
     if (!ws || !zp) {
         if (capturing) return IG_ERR_UNSUPPORTED;

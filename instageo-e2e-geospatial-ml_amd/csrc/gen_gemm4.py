@@ -6,32 +6,47 @@ tile is ONE inline-asm block with hand-assigned registers; this script writes it
 loop + the accumulator read-out helpers of the C++ epilogues).  Run by the Makefile; the output is not committed.
 
 Structure of a tile (256 x 256 x K, BK = 64, 4 waves, wave (wr, wc) owns C[wr 128 ..][wc 128 ..] as 8 x 8 MFMA 16x16x32 accumulators = a0..a255):
-  LDS: 2 stages x {A 256 rows x 128 B, B 256 rows x 128 B} = 128 KiB (+ epilogue staging behind it), rows swizzled (16-byte chunk ^= row & 7).
+  LDS (160 KiB): a ring of THREE A slots (256 rows x 128 B = 32 KiB each, at 0 / 32 / 64 KiB) and TWO B stages (96 / 128 KiB); rows swizzled
+  (16-byte chunk ^= row & 7).  The slot of A K-tile g (counted over the workgroup's whole tile sequence) is g mod 3: three scalar registers
+  hold the slot offsets of K-tiles kt, kt + 1, kt + 2 and rotate once per iteration (they travel through the asm block's in/out operands from
+  tile to tile); B's stage is kt & 1 (K-tiles per tile are even), so the loop body is unrolled by two.  The slot whose K-tile has just been
+  consumed is free until the next tile's first iteration: it is the epilogue's staging buffer.
   Fragments: two register sets of 16 x 4 VGPRs (8 A row blocks + 8 B column blocks of ONE 32-deep k-substep); while the 64 MFMAs of a
-  substep run on one set the other set is read from LDS.  Iteration kt (stage p = kt & 1):
-      H1: 64 MFMAs on set 0 (K-tile kt, substep 0)      | 16 ds_read_b128 -> set 1 (stage p, substep 1)
-      sync: lgkmcnt(0), vmcnt(0), s_barrier             (stage p is dead for every wave, K-tile kt+1 has landed for every wave)
-      H2: 64 MFMAs on set 1                             | 16 ds_read_b128 -> set 0 (stage p^1 = K-tile kt+1, substep 0)
-                                                        | 16 LDS-DMA issues of K-tile kt+2 -> stage p
-  One barrier per K-tile; the DMA stream runs two K-tiles ahead and crosses the tile boundary (the last two iterations fetch K-tiles 0 and 1 of
-  the workgroup's next tile, whose row clamp has its own offset registers).
+  substep run on one set the other set is read from LDS.  Iteration kt (B stage p = kt & 1):
+      H1: 64 MFMAs on set 0 (K-tile kt, substep 0)      | 16 ds_read_b128 -> set 1 (K-tile kt, substep 1)
+                                                        | 8 LDS-DMA issues: A of K-tile kt + 2 -> the slot K-tile kt - 1 left
+      sync: lgkmcnt(0), vmcnt(8), s_barrier             (everything but the 8 A pieces just issued has landed, for every wave;
+                                                         B stage p and A slot kt are dead for every wave)
+      H2: 64 MFMAs on set 1                             | 16 ds_read_b128 -> set 0 (K-tile kt + 1, substep 0)
+                                                        | 8 LDS-DMA issues: B of K-tile kt + 2 -> stage p
+  One barrier per K-tile.  The 16 LDS-DMA issues of a wave are spread over the WHOLE iteration (one per 8 MFMAs = 128 cycles; four waves: one
+  per 32 cycles on the CU's texture-address path, which takes ~16 cycles per 1-KiB piece) -- with two 64-KiB stages all 16 had to go out in
+  H2 (one per 16 cycles CU-wide: saturated) -- and A, whose rows come from HBM when no other tile of the XCD has touched them yet, has 1.5
+  iterations to land instead of 0.5-1.  The DMA stream crosses the tile boundary (the last two iterations fetch K-tiles 0 and 1 of the
+  workgroup's next tile, whose row clamp has its own offset registers).
+  History (profiles/r06_gemm4_*.txt): the first form had two 64-KiB stages, all 16 issues in H2 and an L2 prefetch of the activation rows one
+  K-tile ahead (a global_load_dword per wave and K-tile: qkv 130 -> 122 us on that form); with the ring the prefetch LOSES (d_fc1 143 -> 161 us:
+  vmcnt retires in order, the HBM-latency prefetch holds back the L2-hit pieces behind it) and is gone.
 """
 import sys
 
 # ---- register map (explicit; everything here is in the asm blocks' clobber lists) ----
-V_PF = 90            # v90: L2-prefetch offset of A (one row per lane), v92: its dummy destination
 V_TMP = 94           # v94, v95: scratch
-V_FB = 96            # v96..v103: fragment base addresses  [stage][A_s0, A_s1, B_s0, B_s1]
+V_FA = 96            # v96, v97: A fragment base of k-substep 0 / 1 (without the slot offset)
+V_FB = 98            # v98..v101: B fragment bases [stage][substep]
+V_AC = 102           # v102: A fragment base of the half being read (V_FA[s] + slot offset)
 V_OFFA_N = 104       # v104..v111: DMA offsets of A, NEXT tile's row clamp
 V_OFFA = 112         # v112..v119: DMA offsets of A, this tile
 V_OFFB = 120         # v120..v127: DMA offsets of B
 V_SET = 128          # v128..v255: set q at 128 + 64 q: A blocks [0..7] x 4, then B blocks [0..7] x 4
-V_LO, V_HI = 90, 255
-S_APTR, S_BPTR, S_CNT, S_LDSW, S_PFP = 70, 72, 74, 75, 76   # s[70:71], s[72:73], s74, s75, s[76:77]
-S_LO, S_HI = 70, 77
+V_LO, V_HI = 94, 255
+S_APTR, S_BPTR, S_CNT, S_LDSW = 70, 72, 74, 75   # s[70:71], s[72:73], s74, s75
+S_A0, S_A1, S_A2, S_ADST, S_T = 78, 79, 80, 81, 82          # slot offsets of A K-tiles kt, kt + 1, kt + 2; DMA destination base; scratch
+S_LO, S_HI = 70, 82
 
-STAGE = 65536
-B_OFF = 32768
+A_SLOT = 32768       # three A slots at 0, 32 KiB, 64 KiB
+B_BASE = 98304       # two B stages at 96 KiB, 128 KiB
+B_STAGE = 32768
 
 
 def afrag(q, mi):
@@ -49,8 +64,8 @@ def acc(mi, ni):
     return f"a[{b}:{b + 3}]"
 
 
-def fbase(stage, is_b, s):
-    return f"v{V_FB + 4 * stage + 2 * is_b + s}"
+def fbase_b(stage, s):
+    return f"v{V_FB + 2 * stage + s}"
 
 
 class Stream:
@@ -64,33 +79,32 @@ class Stream:
         return "\n".join(f'    "{l}\\n\\t"' for l in self.lines)
 
 
-def reads(stage, s, q):
-    """the 16 fragment reads of k-substep s of `stage` into set q (A blocks first)"""
+def reads(bstage, s, q):
+    """the 16 fragment reads of k-substep s into set q: A from the slot V_AC points into (set by the half's preamble), B from `bstage`"""
     out = []
     for i in range(8):
-        out.append(f"ds_read_b128 {afrag(q, i)}, {fbase(stage, 0, s)} offset:{i * 2048}")
+        out.append(f"ds_read_b128 {afrag(q, i)}, v{V_AC} offset:{i * 2048}")
     for i in range(8):
-        out.append(f"ds_read_b128 {bfrag(q, i)}, {fbase(stage, 1, s)} offset:{B_OFF + i * 2048}")
+        out.append(f"ds_read_b128 {bfrag(q, i)}, {fbase_b(bstage, s)} offset:{i * 2048}")
     return out
 
 
-def dmas(stage, next_tile):
-    """16 x (M0 write, LDS-DMA issue) of one K-tile into `stage`: 8 pieces of A (8 rows x 128 B each), 8 of B"""
-    out = []
+def dmas_a(next_tile):
+    """8 x (M0 write, LDS-DMA issue): the wave's 64 rows of an A K-tile (8 rows x 128 B per piece) into the slot S_ADST points at"""
     offa = V_OFFA_N if next_tile else V_OFFA
-    for i in range(8):
-        out.append((f"s_add_u32 m0, s{S_LDSW}, {stage * STAGE + i * 1024}", f"global_load_lds_dwordx4 v{offa + i}, s[{S_APTR}:{S_APTR + 1}]"))
-    for i in range(8):
-        out.append((f"s_add_u32 m0, s{S_LDSW}, {stage * STAGE + B_OFF + i * 1024}", f"global_load_lds_dwordx4 v{V_OFFB + i}, s[{S_BPTR}:{S_BPTR + 1}]"))
-    return out
+    return [(f"s_add_u32 m0, s{S_ADST}, {i * 1024}", f"global_load_lds_dwordx4 v{offa + i}, s[{S_APTR}:{S_APTR + 1}]") for i in range(8)]
 
 
-def advance():
-    return [f"s_add_u32 s{S_APTR}, s{S_APTR}, 128", f"s_addc_u32 s{S_APTR + 1}, s{S_APTR + 1}, 0",
-            f"s_add_u32 s{S_BPTR}, s{S_BPTR}, 128", f"s_addc_u32 s{S_BPTR + 1}, s{S_BPTR + 1}, 0"]
+def dmas_b(bstage):
+    return [(f"s_add_u32 m0, s{S_LDSW}, {B_BASE + bstage * B_STAGE + i * 1024}", f"global_load_lds_dwordx4 v{V_OFFB + i}, s[{S_BPTR}:{S_BPTR + 1}]")
+            for i in range(8)]
 
 
-def half(st, q, first, rd, dm, cfg, tail=()):
+def advance(ptr):
+    return [f"s_add_u32 s{ptr}, s{ptr}, 128", f"s_addc_u32 s{ptr + 1}, s{ptr + 1}, 0"]
+
+
+def half(st, q, first, rd, dm, cfg):
     """64 MFMAs on set q with the reads `rd` (16) and DMA pairs `dm` (0 or 16) woven in behind them"""
     rd_every, rd_at0 = cfg["rd_every"], cfg["rd_at"]
     dm_every, dm_at0 = cfg["dm_every"], cfg["dm_at"]
@@ -101,8 +115,6 @@ def half(st, q, first, rd, dm, cfg, tail=()):
         j = min(62, dm_at0 + k * dm_every)
         extra[j].append(m0w)       # M0 write behind MFMA j, the DMA behind MFMA j + 1 (one instruction between them: the wait state M0 needs)
         extra[j + 1].insert(0, ld)
-    for x in tail:   # behind the last DMA issue
-        extra[min(63, dm_at0 + len(dm) * dm_every)].append(x)
     j = 0
     order = [(mi, ni) for ni in range(8) for mi in range(8)] if cfg["order"] == "ni" else [(mi, ni) for mi in range(8) for ni in range(8)]
     for mi, ni in order:
@@ -126,37 +138,31 @@ def skew(st, cfg, tag):
         st.e(f"L_skew_{tag}_{k}_%=:")
 
 
-def iteration(st, p, first, next_tile, cfg, tag, prev_pf=True, pf_guard=None):
+def iteration(st, p, first, next_tile, cfg, tag):
     # timing ablations (garbage results): abl_rd = no fragment reads, abl_dma = no LDS-DMA issues, abl_vmw = no vmcnt wait, abl_bar = no barrier
-    rd1 = [] if cfg.get("abl_rd") else reads(p, 1, 1)
-    rd0 = [] if cfg.get("abl_rd") else reads(p ^ 1, 0, 0)
-    dm = [] if cfg.get("abl_dma") else dmas(p, next_tile)
-    if cfg.get("dma_half"):   # timing experiment: every other piece only
-        dm = dm[::2]
-    half(st, 0, first, rd1, [], cfg)
+    no_rd, no_dm = cfg.get("abl_rd"), cfg.get("abl_dma")
+    # ---- H1: K-tile kt substep 0 | reads of substep 1 | A pieces of K-tile kt + 2 -> slot S_A2
+    st.e(f"v_add_u32 v{V_AC}, s{S_A0}, v{V_FA + 1}")
+    st.e(f"s_add_u32 s{S_ADST}, s{S_LDSW}, s{S_A2}")
+    half(st, 0, first, [] if no_rd else reads(p, 1, 1), [] if no_dm else dmas_a(next_tile), cfg)
+    for a in advance(S_APTR):
+        st.e(a)
     st.e("s_waitcnt lgkmcnt(0)")
     if not cfg.get("abl_vmw"):
-        npf = 1 if (cfg.get("pf", 0) and prev_pf) else 0   # the previous iteration's prefetch may stay in flight
-        st.e(f"s_waitcnt vmcnt({npf})")
+        st.e(f"s_waitcnt vmcnt({0 if no_dm else 8})")   # this half's 8 A pieces may stay in flight
     if not cfg.get("abl_bar"):
         st.e("s_barrier")
     skew(st, cfg, tag)
-    pf = []
-    if cfg.get("pf", 0) and not next_tile:
-        # L2 prefetch: one dword of every row of A's K-tile kt + pf (64 lanes = 64 lines = 8 KiB per instruction; B is L2-resident: prefetching
-        # it cost more than it bought).  Younger than this iteration's LDS-DMA issues, so the next sync may leave it outstanding (vmcnt(1)).
-        # In the last trip before the tile's final pair the target K-tile kt + pf would lie behind the row's K extent (behind the tensor for
-        # its last row): pf_guard = the trip count value at which this iteration is that one -> the prefetch re-touches K-tile pf of the tile.
-        d = (cfg["pf"] - 2) * 128
-        base = f"s[{S_APTR}:{S_APTR + 1}]"
-        if pf_guard is not None:
-            pf.append(f"s_cmp_eq_u32 s{S_CNT}, {pf_guard}")
-            pf.append(f"s_cselect_b64 s[{S_PFP}:{S_PFP + 1}], %[aptr], s[{S_APTR}:{S_APTR + 1}]")
-            base = f"s[{S_PFP}:{S_PFP + 1}]"
-        pf.append(f"global_load_dword v{V_PF + 2}, v{V_PF}, {base} offset:{d}")
-    half(st, 1, False, rd0, dm, cfg, pf)   # only H1 of a tile's first K-tile starts from the constant 0
-    for a in advance():
+    # ---- H2: substep 1 | reads of K-tile kt + 1 substep 0 (slot S_A1, B stage p ^ 1) | B pieces of K-tile kt + 2 -> stage p | prefetch
+    st.e(f"v_add_u32 v{V_AC}, s{S_A1}, v{V_FA}")
+    half(st, 1, False, [] if no_rd else reads(p ^ 1, 0, 0), [] if no_dm else dmas_b(p), cfg)   # only H1 of a tile's first K-tile starts from 0
+    for a in advance(S_BPTR):
         st.e(a)
+    # rotate the A ring: (kt, kt + 1, kt + 2) <- (kt + 1, kt + 2, the slot kt has just left)
+    st.e(f"s_mov_b32 s{S_T}, s{S_A0}")
+    st.e(f"s_mov_b32 s{S_A0}, s{S_A1}")
+    st.e(f"s_mov_b32 s{S_A1}, s{S_A2}")
+    st.e(f"s_mov_b32 s{S_A2}, s{S_T}")
     st.e("s_waitcnt lgkmcnt(0)")
 
 
@@ -169,34 +175,31 @@ def setup(st):
         st.e(f"v_min_u32 v{V_TMP + 1}, %[vrn], v{V_TMP}")
         st.e(f"v_mad_u32_u24 v{V_OFFA_N + i}, v{V_TMP + 1}, %[lda2], %[c16]")
         st.e(f"v_mad_u32_u24 v{V_OFFB + i}, v{V_TMP}, %[ldb2], %[c16]")
-    for is_b, nm in ((0, "%[fa]"), (1, "%[fb]")):
-        st.e(f"v_mov_b32 {fbase(0, is_b, 0)}, {nm}")
-        st.e(f"v_xor_b32 {fbase(0, is_b, 1)}, 64, {nm}")
-        st.e(f"v_add_u32 {fbase(1, is_b, 0)}, {STAGE}, {nm}")
-        st.e(f"v_xor_b32 {fbase(1, is_b, 1)}, 64, {fbase(1, is_b, 0)}")
+    st.e(f"v_mov_b32 v{V_FA}, %[fa]")
+    st.e(f"v_xor_b32 v{V_FA + 1}, 64, %[fa]")
+    for b in (0, 1):
+        st.e(f"v_add_u32 {fbase_b(b, 0)}, {B_BASE + b * B_STAGE}, %[fb]")
+        st.e(f"v_xor_b32 {fbase_b(b, 1)}, 64, {fbase_b(b, 0)}")
     st.e(f"s_mov_b32 s{S_LDSW}, %[ldsw]")
-    # prefetch rows: lane l of wave w -> row 64 w + l of the tile
-    st.e(f"v_lshrrev_b32 v{V_TMP}, 3, %[rowv]")             # rowv = 64 w + (l >> 3)  ->  8 w
-    st.e(f"v_lshlrev_b32 v{V_TMP}, 3, v{V_TMP}")            # 64 w
-    st.e(f"v_mbcnt_lo_u32_b32 v{V_TMP + 1}, -1, 0")
-    st.e(f"v_mbcnt_hi_u32_b32 v{V_TMP + 1}, -1, v{V_TMP + 1}")   # lane id
-    st.e(f"v_add_u32 v{V_TMP}, v{V_TMP}, v{V_TMP + 1}")
-    st.e(f"v_min_u32 v{V_TMP}, %[vrc], v{V_TMP}")
-    st.e(f"v_mul_u32_u24 v{V_PF}, v{V_TMP}, %[lda2]")
+    st.e(f"s_mov_b32 s{S_A0}, %[a0]")
+    st.e(f"s_mov_b32 s{S_A1}, %[a1]")
+    st.e(f"s_mov_b32 s{S_A2}, %[a2]")
 
 
 def gen_prologue():
-    """first tile of a workgroup: K-tiles 0 and 1 -> stages 0 and 1 (inputs: aptr / bptr = the tile's operand bases, vrc = its row clamp)"""
+    """first tile of a workgroup: A K-tiles 0 and 1 -> slots a0, a1; B K-tiles 0 and 1 -> stages 0 and 1 (inputs: aptr / bptr = the tile's
+    operand bases, vrc = its row clamp)"""
     st = Stream()
     setup(st)
     st.e(f"s_mov_b64 s[{S_APTR}:{S_APTR + 1}], %[aptr]")
     st.e(f"s_mov_b64 s[{S_BPTR}:{S_BPTR + 1}], %[bptr]")
-    for stage in (0, 1):
-        for m0w, ld in dmas(stage, False):
+    for k, slot in enumerate((S_A0, S_A1)):
+        st.e(f"s_add_u32 s{S_ADST}, s{S_LDSW}, s{slot}")
+        for m0w, ld in dmas_a(False) + dmas_b(k):
             st.e(m0w)
             st.e("s_nop 0")
             st.e(ld)
-        for a in advance():
+        for a in advance(S_APTR) + advance(S_BPTR):
             st.e(a)
     return st.text()
 
@@ -207,22 +210,20 @@ def gen_tile(cfg):
     st.e(f"s_mov_b64 s[{S_APTR}:{S_APTR + 1}], %[aptr]")   # K-tile 2 of this tile
     st.e(f"s_mov_b64 s[{S_BPTR}:{S_BPTR + 1}], %[bptr]")
     st.e(f"s_mov_b32 s{S_CNT}, %[npair]")                  # middle pairs: nk / 2 - 2
-    st.e("s_waitcnt vmcnt(0)")
-    st.e("s_barrier")
+    st.e("s_waitcnt vmcnt(0)")                             # K-tiles 0, 1 (and the previous epilogue's stores)
+    st.e("s_barrier")                                      # ... for every wave; every wave has left the staging slot (= S_A2)
+    st.e(f"v_add_u32 v{V_AC}, s{S_A0}, v{V_FA}")
     for r in reads(0, 0, 0):
         st.e(r)
     st.e("s_waitcnt lgkmcnt(0)")
     # first pair: the accumulators start from the inline constant 0
-    pf_ = cfg.get("pf", 0)
-    assert pf_ in (0, 3, 4), "prefetch distance: 3 or 4 K-tiles ahead of the compute (1 or 2 ahead of the LDS-DMA stream)"
-    g0, g1 = (pf_ >= 4), (pf_ >= 3)   # which iteration of the trip before the final pair runs past K
-    iteration(st, 0, True, False, cfg, "f0", prev_pf=False, pf_guard=0 if g0 else None)   # first pair: that trip iff npair == 0
-    iteration(st, 1, False, False, cfg, "f1", pf_guard=0 if g1 else None)
+    iteration(st, 0, True, False, cfg, "f0")
+    iteration(st, 1, False, False, cfg, "f1")
     st.e(f"s_cmp_eq_u32 s{S_CNT}, 0")
     st.e("s_cbranch_scc1 L_last_%=")
     st.e("L_loop_%=:")
-    iteration(st, 0, False, False, cfg, "m0", pf_guard=1 if g0 else None)   # middle pairs: the trip with the count at 1
-    iteration(st, 1, False, False, cfg, "m1", pf_guard=1 if g1 else None)
+    iteration(st, 0, False, False, cfg, "m0")
+    iteration(st, 1, False, False, cfg, "m1")
     st.e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
     st.e(f"s_cmp_lg_u32 s{S_CNT}, 0")
     st.e("s_cbranch_scc1 L_loop_%=")
@@ -231,7 +232,10 @@ def gen_tile(cfg):
     st.e(f"s_mov_b64 s[{S_APTR}:{S_APTR + 1}], %[anext]")
     st.e(f"s_mov_b64 s[{S_BPTR}:{S_BPTR + 1}], %[bnext]")
     iteration(st, 0, False, True, cfg, "l0")
-    iteration(st, 1, False, True, cfg, "l1", prev_pf=False)
+    iteration(st, 1, False, True, cfg, "l1")
+    st.e(f"s_mov_b32 %[a0], s{S_A0}")   # ring state for the next tile; a2 = the slot this tile's last K-tile has left = the epilogue's staging
+    st.e(f"s_mov_b32 %[a1], s{S_A1}")
+    st.e(f"s_mov_b32 %[a2], s{S_A2}")
     st.e("s_nop 15")   # the last MFMAs retire before the epilogue's v_accvgpr_read (the compiler's hazard recognizer does not see into this block)
     st.e("s_nop 15")
     return st.text()
@@ -265,7 +269,7 @@ def gen_readout():
 
 
 def main():
-    cfg = {"rd_every": 3, "rd_at": 0, "dm_every": 3, "dm_at": 1, "order": "ni", "skew": 0}
+    cfg = {"rd_every": 3, "rd_at": 0, "dm_every": 8, "dm_at": 1, "order": "ni", "skew": 0}
     out_path = "gemm4_gen.inc"
     for a in sys.argv[1:]:
         if "=" in a:

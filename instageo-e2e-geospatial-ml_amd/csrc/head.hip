@@ -1029,19 +1029,14 @@ int ig_classifier_bn_bwd(const float* dlogits, const void* x_hi, const void* x_l
                                drop_seed_dev, drop_p, stream);
 }
 
-// per-device scratch of ordered_grid_totals: 1024 workgroups x 16 partials + the ticket; allocated (zeroed) once, never freed,
-// never during a graph capture (the first call of a process is a warm-up call)
-static double* loss_scratch(unsigned** ticket) {
-    static double* buf[16] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    if (!buf[dev]) {
-        const size_t bytes = (1024 * 16 + 2) * sizeof(double);
-        if (hipMalloc((void**)&buf[dev], bytes) != hipSuccess) return nullptr;
-        if (hipMemset(buf[dev], 0, bytes) != hipSuccess) return nullptr;
-    }
-    *ticket = reinterpret_cast<unsigned*>(buf[dev] + 1024 * 16);
-    return buf[dev];
+// scratch of ordered_grid_totals: 1024 workgroups x 16 partials + the ticket, per (device, stream) (runtime.hip: ig_scratch slot 2, zero-filled
+// when it is made; its kernels re-arm the ticket).  Launches that share it are ordered on their stream; two streams never share it.  Not to be
+// made during a graph capture (the first call on a stream is a warm-up call).
+static double* loss_scratch(unsigned** ticket, hipStream_t st) {
+    double* buf = (double*)ig_scratch(2, (1024 * 16 + 2) * sizeof(double), st);
+    if (!buf) return nullptr;
+    *ticket = reinterpret_cast<unsigned*>(buf + 1024 * 16);
+    return buf;
 }
 
 // label_dtype: 0 = int64, 1 = int32, 2 = float32 (reference labels are float tensors cast with .long())
@@ -1053,21 +1048,17 @@ int ig_ce_loss(const float* logits, const void* labels, int label_dtype, const f
     long M = (long)B * HW;
     if (M == 0) return IG_OK;
     size_t sm = (size_t)ncls * ncls * sizeof(unsigned);
-    // per-device scratch of the order-independent (loss, count) sums: two 64-bit accumulators + the arrival counter; allocated once,
-    // never freed, never during a graph capture (the first call of a process is a warm-up call)
-    static unsigned long long* acc_dev[16] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    IG_REQUIRE(dev >= 0 && dev < 16, "ig_ce_loss: device index %d", dev);
-    if (stats && !acc_dev[dev]) {
-        if (hipMalloc((void**)&acc_dev[dev], 4 * sizeof(unsigned long long)) != hipSuccess ||
-            hipMemset(acc_dev[dev], 0, 4 * sizeof(unsigned long long)) != hipSuccess) {
+    // scratch of the order-independent (loss, count) sums: two 64-bit accumulators + the arrival counter, per (device, stream) (ig_scratch
+    // slot 3, zero-filled when it is made; the kernel re-arms it); never made during a graph capture (the first call on a stream is a warm-up)
+    unsigned long long* acc_stream = nullptr;
+    if (stats) {
+        acc_stream = (unsigned long long*)ig_scratch(3, 4 * sizeof(unsigned long long), (hipStream_t)stream);
+        if (!acc_stream) {
             ig_set_error("ig_ce_loss: scratch allocation failed");
-            acc_dev[dev] = nullptr;
             return IG_ERR_HIP;
         }
     }
-    unsigned long long* acc = acc_dev[dev];
+    unsigned long long* acc = acc_stream;
     unsigned* arrived = acc ? reinterpret_cast<unsigned*>(acc + 2) : nullptr;
     const bool vec4 = HW % 4 == 0 && (reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits) |
                                       reinterpret_cast<uintptr_t>(preds) | reinterpret_cast<uintptr_t>(preds_i8)) % 16 == 0;
@@ -1113,7 +1104,7 @@ int ig_kd_loss(const float* student_logits, const float* teacher_logits, const v
     if (nblk > 1024) nblk = 1024;
     hipStream_t st = (hipStream_t)stream;
     unsigned* ticket = nullptr;
-    double* scratch = loss_scratch(&ticket);
+    double* scratch = loss_scratch(&ticket, (hipStream_t)stream);
     IG_REQUIRE(scratch, "ig_kd_loss: scratch allocation failed");
     if (label_dtype == 0)
         hipLaunchKernelGGL(kd_loss_kernel<long long>, dim3((unsigned)nblk), dim3(TPB), 0, st, student_logits, teacher_logits,
@@ -1182,7 +1173,7 @@ int ig_mse_loss(const float* pred, const float* labels, float ignore_value, int 
     long nblk = (n + TPB - 1) / TPB;
     if (nblk > 1024) nblk = 1024;
     unsigned* ticket = nullptr;
-    double* scratch = loss_scratch(&ticket);
+    double* scratch = loss_scratch(&ticket, (hipStream_t)stream);
     IG_REQUIRE(scratch, "ig_mse_loss: scratch allocation failed");
     hipLaunchKernelGGL(mse_loss_kernel, dim3((unsigned)nblk), dim3(TPB), 0, (hipStream_t)stream, pred, labels, ignore_value, use_log_scale,
                        stats, dpred, msums, ee_bias, ee_coef, include_ee, n, scratch, ticket);
@@ -1196,7 +1187,7 @@ int ig_kd_mse_loss(const float* pred, const float* teacher, const float* labels,
     long nblk = (n + TPB - 1) / TPB;
     if (nblk > 1024) nblk = 1024;
     unsigned* ticket = nullptr;
-    double* scratch = loss_scratch(&ticket);
+    double* scratch = loss_scratch(&ticket, (hipStream_t)stream);
     IG_REQUIRE(scratch, "ig_kd_mse_loss: scratch allocation failed");
     hipLaunchKernelGGL(kd_mse_loss_kernel, dim3((unsigned)nblk), dim3(TPB), 0, (hipStream_t)stream, pred, teacher, labels, ignore_value,
                        use_log_scale, sum, dpred, n, scratch, ticket);

@@ -90,22 +90,25 @@ static IgDet g_det_host = {nullptr, nullptr, 0};
 bool ig_deterministic() { return g_det_host.shadow != nullptr; }
 // Scratch buffers are keyed by (device, STREAM, slot): two streams of one device -- a distillation teacher's forward beside the student's
 // step (segmentation.py:216-451), a graph replay beside eager inference -- never share a buffer, so a kernel on one stream cannot read
-// partial sums or packed weights that a launch on another stream is overwriting.  A stream gets its entry on first
-// use (up to IG_SCRATCH_STREAMS per device, then NULL: the callers report it).  Growing frees the old buffer: hipFree synchronises the
-// device, so no kernel still reads it (the grow path is outside stream captures: may_grow = false there).
+// partial sums, packed weights, tickets or split-K slabs that a launch on another stream is overwriting.  Slots: 0 BatchNorm
+// partial sums, 1 packed conv8 weights, 2 / 3 loss tickets and accumulators, 4 weight-gradient slabs (gemm8w.hip), 5 split-K partials (gemm.hip).
+// A stream gets its entry on first use (up to IG_SCRATCH_STREAMS per device, then NULL: the callers report it).  A fresh buffer is zero-filled.
+// Nothing is allocated while the stream is capturing (NULL + an error text: warm up on the capture stream first).  Growing frees the old buffer
+// (hipFree synchronises the device, so no kernel in flight still reads it) -- unless a capture has ever been served from this entry: a
+// captured graph may have baked the address into its kernel nodes, so that buffer is kept for the life of the process.
 void* ig_scratch(int slot, size_t bytes, hipStream_t st) { return ig_scratch2(slot, bytes, true, st); }
 void* ig_scratch2(int slot, size_t bytes, bool may_grow, hipStream_t st) {
-    constexpr int IG_SCRATCH_STREAMS = 16;
+    constexpr int IG_SCRATCH_STREAMS = 16, IG_SCRATCH_SLOTS = 6;
     struct Entry {
         hipStream_t stream;
-        bool used;
-        void* buf[4];
-        size_t cap[4];
+        bool used, captured;
+        void* buf[IG_SCRATCH_SLOTS];
+        size_t cap[IG_SCRATCH_SLOTS];
     };
     static Entry tab[16][IG_SCRATCH_STREAMS] = {};
     static std::mutex mu;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || slot < 0 || slot >= 4) return nullptr;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || slot < 0 || slot >= IG_SCRATCH_SLOTS) return nullptr;
     std::lock_guard<std::mutex> lock(mu);
     Entry* e = nullptr;
     for (int i = 0; i < IG_SCRATCH_STREAMS && !e; ++i) {
@@ -119,13 +122,25 @@ void* ig_scratch2(int slot, size_t bytes, bool may_grow, hipStream_t st) {
         ig_set_error("scratch: more than %d streams use the library on device %d", IG_SCRATCH_STREAMS, dev);
         return nullptr;
     }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+    if (capturing) e->captured = true;
     if (e->cap[slot] < bytes) {
-        if (!may_grow) return nullptr;  // e.g. during a stream capture: nothing may be allocated
+        if (!may_grow) return nullptr;
+        if (capturing) {
+            ig_set_error("scratch: stream %p is capturing and has no %zu-byte buffer in slot %d yet: scratch is per (device, stream) -- run one warm-up "
+                         "call on the capture stream first (torch.cuda.graph(g, stream=warmup_stream))", (void*)st, bytes, slot);
+            return nullptr;
+        }
         void* p = nullptr;
-        const size_t want = bytes + bytes / 2;
-        if (e->buf[slot]) (void)hipFree(e->buf[slot]);  // synchronises the device: nothing in flight still reads the old buffer
+        const size_t want = bytes + bytes / 2;  // geometric growth: the kept buffers of a capturing entry stay below three times the largest request
+        if (e->buf[slot] && !e->captured) (void)hipFree(e->buf[slot]);
         e->buf[slot] = nullptr, e->cap[slot] = 0;
         if (hipMalloc(&p, want) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, want) != hipSuccess) {
+            (void)hipFree(p);
+            return nullptr;
+        }
         e->buf[slot] = p, e->cap[slot] = want;
     }
     return e->buf[slot];

@@ -507,6 +507,7 @@ def attach_data_parallel(module, bucket_bytes: int = 32 << 20):
         net.engine.master_sync = sync.gather_master
         net.engine.master_complete = lambda: sync.master_complete  # state_dict() refuses to read sharded masters (see PrithviSeg.state_dict)
         net.engine.param_wait = sync.wait_params                   # deferred all-gather waits, in front of each Block of the next forward
+        net.store.pending_from = lambda: (sync._pending[0][0] if sync._pending else None)  # ParamStore.w() refuses to read under an in-flight gather
         module.grad_sync = None  # the exchange is finished inside the optimizer step
         return sync
     sync = GradSync(lambda: net.store.ensure_grad(), bucket_bytes, scale_in_optimizer=True)

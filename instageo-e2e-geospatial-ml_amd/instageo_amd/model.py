@@ -308,9 +308,18 @@ class ParamStore:
         o = block * self.t_block + toff
         return BT(self.shadow_t.hi[o : o + R * C], None if self.shadow_t.lo is None else self.shadow_t.lo[o : o + R * C])
 
+    # data parallel: lowest flat offset whose deferred all-gather is still in flight (distributed.ShardedGradSync), None = none pending.
+    # Reading an operand at or above it would race the gather: w() refuses (the engine's readers call SegEngine._need first, which waits).
+    pending_from: Optional[Callable[[], Optional[int]]] = None
+
     def w(self, name: str) -> BT:
         """bf16 operand view of a parameter (storage layout)."""
         e = self.entries[name]
+        if self.pending_from is not None:
+            lo = self.pending_from()
+            if lo is not None and e.offset + e.numel > lo:
+                raise RuntimeError(f"ParamStore.w({name!r}): the all-gather of the operand copy from flat offset {lo} is still in flight; "
+                                   "call the engine's param_wait / ShardedGradSync.wait_params() before reading it")
         sh = self.shadow
         return BT(sh.hi[e.offset : e.offset + e.numel], None if sh.lo is None else sh.lo[e.offset : e.offset + e.numel])
 

@@ -517,7 +517,10 @@ class PrithviSegmentationModule(_Base):
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # Captured on the warm-up's OWN stream: the library's scratch buffers are per (device, stream) and nothing can be allocated during
+            # a capture, so the capture must meet the buffers the warm-up made.  The graph's kernels keep using that stream's buffers wherever
+            # it is replayed, so a replay never shares scratch with eager work on the replaying stream either.
+            with torch.cuda.graph(graph, stream=side):
                 self.fused_train_step(static_x, static_y, stats)
         finally:
             self._early_ok = True

@@ -336,7 +336,7 @@ def test_m0_is_only_written_by_the_lds_dma_helpers():
     csrc = os.path.join(root, "instageo-e2e-geospatial-ml_amd", "csrc")
     with tempfile.TemporaryDirectory() as tmp:
         if not os.path.exists(os.path.join(csrc, "gemm4_gen.inc")):  # normally written by the Makefile
-            subprocess.run([sys.executable, os.path.join(csrc, "gen_gemm4.py"), os.path.join(csrc, "gemm4_gen.inc"), "dm_every=4", "pf=3"], check=True)
+            subprocess.run([sys.executable, os.path.join(csrc, "gen_gemm4.py"), os.path.join(csrc, "gemm4_gen.inc")], check=True)
         for name in ("gemm8", "gemm8w", "conv8", "gemm4"):
             out = os.path.join(tmp, name + ".s")
             subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(root, "include"), "-DIG_HEADER_STAMP=0", "-S",
@@ -367,3 +367,23 @@ def test_split_tensors_are_one_allocation_with_lo_above_hi():
         z.hi.fill_(1)
         assert not z.lo.any()  # the halves do not overlap
     assert BT.empty((4, 4), False, "cpu").lo is None
+
+
+def test_operand_copy_reads_refuse_an_in_flight_all_gather():
+    """Data parallel, deferred all-gather (distributed.ShardedGradSync, IG_DP_DEFER=1): the bf16 operand copy above the lowest pending bucket
+    is being written by RCCL.  ``ParamStore.w`` -- the only accessor of operand views -- raises for a parameter at or above that offset
+    (the ordering used to rest on every reader remembering to call ``wait_params``); below it, and with nothing pending, it does not."""
+    from instageo_amd.model import PrithviSeg
+
+    net = PrithviSeg(variant="prithvi_eo_tiny", temporal_step=1, num_classes=2, load_pretrained_weights=False, device="cpu")
+    st = net.store
+    names = list(st.entries)
+    first, last = names[0], names[-1]
+    boundary = st.entries[last].offset
+    st.pending_from = lambda: boundary
+    with pytest.raises(RuntimeError, match="still in flight"):
+        st.w(last)
+    st.shadow = type("S", (), {"hi": st.flat.to(torch.bfloat16), "lo": None})()  # a stand-in operand copy (the real one is made by a HIP kernel)
+    assert st.w(first).hi.numel() == st.entries[first].numel  # below the pending bucket: readable
+    st.pending_from = lambda: None
+    assert st.w(last).hi.numel() == st.entries[last].numel

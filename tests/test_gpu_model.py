@@ -143,6 +143,46 @@ def test_benchmark_batch_ties_to_the_golden_fixture_and_is_permutation_equivaria
         assert gmx <= 8e-2 and d <= 8e-2
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_300m_benchmark_batch_ties_to_the_golden_fixture(precision):
+    """BASELINE configs[4] (Prithvi-V2-300M: D = 1024, 24 blocks, K = 1024 / 4096 linears) at bench.py's per-GPU batch of 32 chips
+    (6304 tokens: 300 / 400 / 100 tiles of 256 x 256).  The B = 1 fixture runs the 128 x 128 instances only; here the fixture's chip sits at
+    scattered positions of a random batch (eval mode has no cross-sample coupling):
+    (i) its logits equal the reference-generated golden vector (tests/golden/v2_300_t1_c2.npz) within 1e-3 in bf16x3 (the bf16 bound otherwise),
+    (ii) a batch permutation permutes the logits bit for bit, and
+    (iii) the launch log shows the 256-wide GEMM instances (gemm8.hip's 256 x 256 kernel -- 7 template fields in its name -- or gemm4.hip) and
+          the 8-phase convolution engine at D = 1024 / K = 4096."""
+    B = 32
+    name = "v2_300_t1_c2"
+    cfg, sd, net, img1, _ = build(name, precision)
+    net.eval()
+    g = torch.Generator().manual_seed(17)
+    img = torch.randn((B, *img1.shape[1:]), generator=g)
+    pos = [0, 13, B - 1]
+    for q in pos:
+        img[q] = img1[0]
+    ops.profile_begin(["ig_conv3x3_fwd", "ig_convT_fwd", "ig_linear_fwd", "ig_linear_residual_fwd", "ig_attention_fwd"])
+    with torch.no_grad():
+        logits = net(img.to(DEV))
+    names = sorted(ops.profile_end()["kernels"])
+    print("   kernels:", names)
+    wide = [k for k in names if k.startswith("gemm4_kernel") or (k.startswith("gemm8_kernel") and k.count(",") == 6)]
+    assert wide, f"no 256-wide GEMM instance ran at B = {B}: {names}"
+    if precision == "bf16":
+        assert any(k.startswith("gemm4_kernel") for k in names), names  # plain bf16 store / residual kinds with >= 128 tiles
+    assert any(k.startswith("conv8_kernel") for k in names), f"the wide-convolution engine did not run at B = {B}: {names}"
+    with torch.no_grad():
+        perm = torch.randperm(B, generator=g)
+        logits_p = net(img[perm].to(DEV))
+    assert torch.equal(logits_p.cpu(), logits.cpu()[perm]), "eval logits depend on the batch position of a chip"
+    gold = np.load(os.path.join(GOLD, f"{name}.npz"))
+    for q in pos:
+        gmx = np.abs(sub(logits[q:q + 1].cpu()) - gold["eval_logits_sub"]).max()
+        print(f"   [{precision}] B={B} chip at {q}: vs golden {gmx:.3e}")
+        assert gmx <= (1e-3 if precision == "bf16x3" else 8e-2)
+    assert torch.equal(logits[pos[0]].cpu(), logits[pos[1]].cpu()) and torch.equal(logits[pos[0]].cpu(), logits[pos[2]].cpu())
+
+
 @pytest.mark.parametrize("B", [36, 72])
 def test_multitemporal_benchmark_batch_ties_to_the_golden_fixture(B):
     """BASELINE configs[2] (T = 3, 13 classes: configs/multitemporal_crop_classification.yaml:14-30) at the batches bench.py times it
