@@ -703,7 +703,7 @@ def main() -> None:
         ex = main_res.get("exposed")
         if ex is not None:  # zero1: time the compute stream stood still for the reduce-scatters / all-gathers of one instrumented step
             out["dist"].update({"rs_exposed_ms": round(ex["rs"], 3), "ag_exposed_ms": round(ex["ag"], 3), "tail_exposed_ms": round(ex["tail"], 3),
-                                "gather": os.environ.get("IG_DP_GATHER", "shadow")})
+                                "gather": "shadow"})
         if t3_leg is not None:
             out["dist"]["t3_c13_chips_per_s"] = t3_leg["value"]
             out["dist"]["t3_c13_ms_per_step"] = t3_leg["ms_per_step"]

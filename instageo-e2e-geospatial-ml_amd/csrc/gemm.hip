@@ -1393,19 +1393,11 @@ inline float* splitk_workspace(size_t bytes, hipStream_t st) {
 constexpr bool splitk_partial_enabled() { return true; }  // split-K partials + ordered fold (the float-atomic form was an A/B arm)
 
 // ------------------------------------------------------------------------------------ launch
-// Engine choice for the plain-matrix GEMMs.  IG_GEMM=1|2|5 forces one engine (A/B runs); unset: v2 everywhere except
-// the shapes where the ping-pong v5 measured faster on the same box (tools/gemm_bench.py): dgrad without an
-// elementwise factor (+8-9 %) and the residual GEMM with a long reduction (fc2, K = 4D: +9 %).
-inline int gemm_env() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("IG_GEMM");
-        v = (e && e[0] == '1') ? 1 : (e && e[0] == '2') ? 2 : (e && e[0] == '5') ? 5 : 0;
-    }
-    return v;
-}
-inline int gemm_version() { return gemm_env() ? gemm_env() : 2; }
-inline int gemm_version_prefer5(bool prefer) { return gemm_env() ? gemm_env() : (prefer ? 5 : 2); }
+// Engine choice for the plain-matrix GEMMs that the 8-phase / 4-wave engines do not cover: v2 everywhere except the shapes where the
+// ping-pong v5 measured faster on the same box (tools/gemm_bench.py): dgrad without an elementwise factor (+8-9 %) and the residual
+// GEMM with a long reduction (fc2, K = 4D: +9 %).  (The IG_GEMM switch that forced one engine was an A/B arm and is gone.)
+inline int gemm_version() { return 2; }
+inline int gemm_version_prefer5(bool prefer) { return prefer ? 5 : 2; }
 inline int conv_version(int n_out) {
     (void)n_out;
     return 1;  // measured: v1 is faster for every conv stage (gather address math per LDS-DMA issue)
@@ -1458,7 +1450,7 @@ int launch_gemm(const AL& al, const BL& bl, const EP& ep_in, int M, int N, int K
     // v2 (256x128, LDS-DMA ring) wins on the encoder linears; the head convolutions (Cout 48..384, huge M) are
     // better served by the 128x128 register-staged tile at 2 workgroups/CU until a narrow-N tile exists
     int ver = force_ver ? force_ver : gemm_version();
-    if (!gemm_env() && !EP::kStagedAtomic && AL::kLinearK && BL::kLinearK) {
+    if (!EP::kStagedAtomic && AL::kLinearK && BL::kLinearK) {
         // small problems (e.g. the YAML's batch 16: M = 3152 rows): the big tiles leave most CUs idle -- a 256x256 tile
         // needs >= 192 tiles to be worth one workgroup per CU, a 256x128 tile >= 256; below that the 128x128 engine's
         // 2-4x larger tile count wins (measured at B = 16: fc2 94.9 us on v5)
@@ -1705,7 +1697,7 @@ int ig_linear_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const vo
     IG_REQUIRE(aligned16(x_hi) && aligned16(w_hi) && aligned16(y_hi), "ig_linear_fwd: pointers must be 16-byte aligned");
     IG_SPLIT_CONSISTENT(x_lo, w_lo);
     IG_REQUIRE((x_lo == nullptr) == (y_lo == nullptr), "ig_linear_fwd: input and output must both be split or both plain");
-    if (!gemm_env()) {  // 256 x 256 x 64 8-phase engine (gemm8.hip) for the shapes it covers
+    {  // 256 x 256 x 64 8-phase engine (gemm8.hip) for the shapes it covers
         G8Params g{};
         seg_a(g.a, x_hi, x_lo), seg_b(g.b, w_hi, w_lo);
         g.nseg = x_lo ? 3 : 1, g.M = M, g.N = N, g.K = K, g.lda = K, g.ldb = K, g.ldo = N, g.kind = 0, g.act = act, g.bias = bias;
@@ -1727,7 +1719,7 @@ int ig_linear_residual_fwd(const void* x_hi, const void* x_lo, const void* w_hi,
     IG_REQUIRE(x_hi && w_hi && resid && out, "ig_linear_residual_fwd: null pointer");
     IG_REQUIRE(N % 8 == 0 && K % 8 == 0, "ig_linear_residual_fwd: N and K must be multiples of 8");
     IG_SPLIT_CONSISTENT(x_lo, w_lo);
-    if (!gemm_env() && aligned16(x_hi) && aligned16(w_hi) && aligned16(resid) && aligned16(out)) {
+    if (aligned16(x_hi) && aligned16(w_hi) && aligned16(resid) && aligned16(out)) {
         G8Params g{};
         seg_a(g.a, x_hi, x_lo), seg_b(g.b, w_hi, w_lo);
         g.nseg = x_lo ? 3 : 1, g.M = M, g.N = N, g.K = K, g.lda = K, g.ldb = K, g.ldo = N, g.kind = 1, g.bias = bias;
@@ -1768,7 +1760,7 @@ int ig_linear_dgrad_wt(const void* dy_hi, const void* dy_lo, const void* wt_hi, 
     IG_REQUIRE(aligned16(dy_hi) && aligned16(wt_hi) && aligned16(dx_hi), "ig_linear_dgrad_wt: pointers must be 16-byte aligned");
     IG_SPLIT_CONSISTENT(dy_lo, wt_lo);
     IG_REQUIRE((dy_lo == nullptr) == (dx_lo == nullptr), "ig_linear_dgrad_wt: input and output must both be split or both plain");
-    if (!gemm_env() && (mode == 1 || dx_colsum == nullptr)) {
+    if (mode == 1 || dx_colsum == nullptr) {
         G8Params g{};
         seg_a(g.a, dy_hi, dy_lo), seg_b(g.b, wt_hi, wt_lo);
         g.nseg = dy_lo ? 3 : 1, g.M = M, g.N = K, g.K = N, g.lda = N, g.ldb = N, g.ldo = K;
@@ -1793,7 +1785,7 @@ int ig_linear_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, cons
     IG_REQUIRE(dy_hi && x_hi && dw, "ig_linear_wgrad: null pointer");
     IG_REQUIRE(N % 8 == 0 && K % 8 == 0, "ig_linear_wgrad: N and K must be multiples of 8");
     IG_SPLIT_CONSISTENT(dy_lo, x_lo);
-    if (!gemm_env()) {  // 8-phase engine with transposed fragment reads (gemm8w.hip) for the shapes it covers
+    {  // 8-phase engine with transposed fragment reads (gemm8w.hip) for the shapes it covers
         const int rc = ig_wgrad8_group(1, &dy_hi, &dy_lo, &x_hi, &x_lo, &dw, &N, &K, M, 0, stream);
         if (rc != IG_ERR_UNSUPPORTED) return rc;
     }
@@ -1811,9 +1803,7 @@ int ig_linear_wgrad(const void* dy_hi, const void* dy_lo, const void* x_hi, cons
         // on every shape measured (M = 3152 .. 21168: +6 .. +20 % over the 128 x 128 engine, proj 768 x 768 included from
         // M = 6304) except the smallest output at the YAML's batch (M = 3152, 768 x 768: 151 vs 175 TFLOP/s); below M = 2048
         // the dual form does not apply and the old rule stands (128 x 128 unless a 256 x 128 workgroup gets >= 50 K-steps)
-        gemm_env() ? gemm_env()
-                   : (nk32 >= 64 ? (((long)N * K <= (1L << 20) && M < 6000) ? 1 : 2)
-                                 : (((long)N * K <= (1L << 20) || v2_steps < 50) ? 1 : 2)));
+        nk32 >= 64 ? (((long)N * K <= (1L << 20) && M < 6000) ? 1 : 2) : (((long)N * K <= (1L << 20) || v2_steps < 50) ? 1 : 2));
 }
 
 // n weight gradients that share the token count M in ONE launch: dw[g][N[g]][K[g]] += dy[g][M][N[g]]^T @ x[g][M][K[g]].  The pointer
@@ -1823,7 +1813,7 @@ int ig_linear_wgrad_group(int n, const void* const* dy_hi, const void* const* dy
     IG_REQUIRE(n > 0 && n <= 16 && dy_hi && x_hi && dw && N && K, "ig_linear_wgrad_group: 1..16 GEMMs and non-null arrays");
     for (int g = 0; g < n; ++g) IG_REQUIRE(dy_hi[g] && x_hi[g] && dw[g], "ig_linear_wgrad_group: null pointer in GEMM %d", g);
     if (M <= 0 && !overwrite) return IG_OK;
-    if (!gemm_env() && M > 0) {
+    if (M > 0) {
         const int rc = ig_wgrad8_group(n, dy_hi, dy_lo, x_hi, x_lo, dw, N, K, M, overwrite, stream);
         if (rc != IG_ERR_UNSUPPORTED) return rc;
     }

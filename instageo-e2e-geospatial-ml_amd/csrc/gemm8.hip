@@ -112,11 +112,10 @@ struct Cur {  // issue cursor of one half-tile type (all wave-uniform)
 // of their phase's fragment reads (134.0 against 135.1: noise).  In-kernel clock under the loop: 2.12-2.15 GHz (s_memtime / s_memrealtime);
 // a 2-K-tile iteration takes ~7950 cycles against the 4096 of its MFMAs: the matrix pipe is ~50 % busy; inside an MFMA phase the 32 MFMAs
 // issue in 620-660 cycles (512 back to back).
-// DBG (timing ablations, built with -DIG_G8_ABLATE only; results are garbage): 1 = no LDS-DMA inside the loop, 2 = + no fragment
-// reads, 3 = + no barriers, 4 = everything but the epilogue stores.  profiles/r02_v8_ablation_qkv.log: of 71 us (qkv, B = 108)
-// the epilogue is 13.7 (its 33 MB store burst per round sits in front of the next loads in the in-order vmcnt), LDS-DMA 10.2,
-// fragment reads 2.5, barriers 1.7 and the MFMAs themselves 43 us.
-template <int KIND, int NSEG, int ACT, bool DACT, bool SPLIT_OUT, int SCHED = 4, int DBG = 0, int MT = 4, int WC = 4>
+// (Timing ablations of round 2 -- no LDS-DMA / no fragment reads / no barriers / no epilogue stores: of 71 us (qkv, B = 108) the epilogue was
+// 13.7, LDS-DMA 10.2, fragment reads 2.5, barriers 1.7 and the MFMAs themselves 43 us -- are in profiles/r02_v8_ablation_qkv.log; the build
+// switch that produced them is gone.)
+template <int KIND, int NSEG, int ACT, bool DACT, bool SPLIT_OUT, int SCHED = 4, int MT = 4, int WC = 4>
 __global__ __launch_bounds__(128 * WC, 2) void gemm8_kernel(G8Params p) {
     using Geo = G8Geo<MT, WC>;
     constexpr int G8_HALF = Geo::HALF, G8_BUF = Geo::BUF, G8_STAGE = Geo::STAGE, BM = Geo::BM, BN = Geo::BN;
@@ -153,7 +152,6 @@ __global__ __launch_bounds__(128 * WC, 2) void gemm8_kernel(G8Params p) {
     const unsigned ldsw = lds_base + wave * 2048;
 
     Cur cA0, cA1, cB0, cB1;
-    bool in_loop = false;
 #define G8_REBASE(C, ISA)                                                                   \
     {                                                                                       \
         const int bm_ = (C).tile / tiles_n, bn_ = (C).tile - bm_ * tiles_n;                 \
@@ -175,7 +173,7 @@ __global__ __launch_bounds__(128 * WC, 2) void gemm8_kernel(G8Params p) {
     }
     // issue the two wave-instructions of this wave for half-tile (ISA ? A : B, HG) of the cursor's K-tile into buffer BUF
 #define G8_ISSUE(C, ISA, HG, BUF)                                                                              \
-    if ((DBG == 0 || DBG == 4 || !in_loop) && (C).left > 0) {                                                                                        \
+    if ((C).left > 0) {                                                                                        \
         _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                     \
             int row_ = ((ISA) ? rbaseA + (HG)*(MT * 16) : rbaseB + (HG)*32) + i_ * 8;                          \
             row_ = min(row_, (C).vr - 1);                                                                      \
@@ -233,10 +231,10 @@ __global__ __launch_bounds__(128 * WC, 2) void gemm8_kernel(G8Params p) {
 
     bf16x8_t af[MT][2], bf0[2][2], bf1[2][2];
 #define G8_READ_A(BUF, H)                                                                                          \
-    if (DBG < 2 || DBG == 4 || !in_loop) _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) \
+    _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) \
         af[mt_][s_] = *reinterpret_cast<const bf16x8_t*>(smem + (BUF)*G8_BUF + (H)*G8_HALF + mt_ * 2048 + (aoff ^ (s_ * 64)));
 #define G8_READ_B(BUF, G, DST)                                                                                     \
-    if (DBG < 2 || DBG == 4 || !in_loop) _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) \
+    _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) \
         DST[nt_][s_] = *reinterpret_cast<const bf16x8_t*>(smem + (BUF)*G8_BUF + (G)*G8_HALF + nt_ * 2048 + (boff ^ (s_ * 64)));
 // SCHED 2 "big phase": 32 MFMAs (two quadrants) between one barrier pair; reads are retired BEFORE the first barrier
     // (lgkmcnt(0)), so a half-tile may be refilled in the very next phase
@@ -250,7 +248,7 @@ __global__ __launch_bounds__(128 * WC, 2) void gemm8_kernel(G8Params p) {
     {                                                                                                              \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
         G8P_MARK(PM)                                                                                               \
-        if (DBG != 3) asm volatile("s_barrier" ::: "memory");                                                      \
+        asm volatile("s_barrier" ::: "memory");                                                      \
         G8P_MARK(PM + 1)                                                                                           \
         __builtin_amdgcn_s_setprio(1);                                                                             \
         if constexpr (PAIR) { /* fragments [0] = hi, [1] = lo: hi hi, lo(B) hi(A), hi(B) lo(A), each term over all 16 accumulators.  (Issuing  \
@@ -267,7 +265,7 @@ __global__ __launch_bounds__(128 * WC, 2) void gemm8_kernel(G8Params p) {
         __builtin_amdgcn_s_setprio(0);                                                                             \
         G8P_MARK(PM + 2)                                                                                           \
         TAIL                                                                                                       \
-        if (DBG != 3) asm volatile("s_barrier" ::: "memory");                                                      \
+        asm volatile("s_barrier" ::: "memory");                                                      \
     }
 #define G8_WAITN(CNT, LASTCNT)                                                               \
     {                                                                                        \
@@ -288,12 +286,6 @@ __global__ __launch_bounds__(128 * WC, 2) void gemm8_kernel(G8Params p) {
     int it_c = 0;  // iterations (K-tile pairs) done of the current tile
     const int iters = Gtot >> 1, per_tile2 = per_tile >> 1;
     bool staggered = false;
-    if constexpr (DBG >= 2) {
-        G8_READ_A(0, 0)
-        G8_READ_B(0, 0, bf0)
-        G8_READ_B(0, 1, bf1)
-    }
-    in_loop = true;
     for (int it = 0; it < iters; ++it) {
         const bool last = it == iters - 1;
 #ifdef IG_G8_PROF
@@ -390,16 +382,7 @@ __global__ __launch_bounds__(128 * WC, 2) void gemm8_kernel(G8Params p) {
         char* st = smem + G8_STAGE + wave * 4096;
         const int erow = lane & 15, eq = lane >> 4;
         const int n0 = bn * BN + wc * 64;
-        if constexpr (DBG == 4) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int g = 0; g < 2; ++g)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(acc[h][g][nt][mt]));
-        } else if constexpr (KIND == 0) {
+        if constexpr (KIND == 0) {
             // bf16 (split) store of act(acc): two 2 KiB staging slots (16 rows x 64 bf16, chunk ^= row & 7)
             const int rrow = lane >> 3, rch = ((lane & 7) ^ (lane >> 3)) << 4, rcol = (lane & 7) * 8;
 #pragma unroll
@@ -613,10 +596,10 @@ inline int g8_env() {
     return e ? atoi(e) : 1;
 }
 
-template <int KIND, int NSEG, int ACT, bool DACT, bool SPLIT_OUT, int SCHED = 1, int DBG = 0, int MT = 4, int WC = 4>
+template <int KIND, int NSEG, int ACT, bool DACT, bool SPLIT_OUT, int SCHED = 1, int MT = 4, int WC = 4>
 int g8_launch_v(const G8Params& p, int grid, hipStream_t st) {
     using Geo = G8Geo<MT, WC>;
-    auto kern = gemm8_kernel<KIND, NSEG, ACT, DACT, SPLIT_OUT, SCHED, DBG, MT, WC>;
+    auto kern = gemm8_kernel<KIND, NSEG, ACT, DACT, SPLIT_OUT, SCHED, MT, WC>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Geo::SMEM) != hipSuccess) {
@@ -625,34 +608,20 @@ int g8_launch_v(const G8Params& p, int grid, hipStream_t st) {
         }
         attr_done = true;
     }
-    if (MT == 4) ig_note_kernel("gemm8_kernel<%d,%d,%d,%s,%s,%d,%d>", KIND, NSEG, ACT, DACT ? "true" : "false", SPLIT_OUT ? "true" : "false", SCHED, DBG);
-    else ig_note_kernel("gemm8_kernel<%d,%d,%d,%s,%s,%d,%d,%d,%d>", KIND, NSEG, ACT, DACT ? "true" : "false", SPLIT_OUT ? "true" : "false", SCHED, DBG, MT, WC);
+    if (MT == 4) ig_note_kernel("gemm8_kernel<%d,%d,%d,%s,%s,%d>", KIND, NSEG, ACT, DACT ? "true" : "false", SPLIT_OUT ? "true" : "false", SCHED);
+    else ig_note_kernel("gemm8_kernel<%d,%d,%d,%s,%s,%d,%d,%d>", KIND, NSEG, ACT, DACT ? "true" : "false", SPLIT_OUT ? "true" : "false", SCHED, MT, WC);
     ig_note_grid(grid);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(Geo::NTHR), Geo::SMEM, st, p);
     return ig_check_launch("gemm8");
 }
 
-// small = the 128 x 128 instance (two workgroups per CU).  IG_G8_SCHED = 2 selects the round-2 placement of the LDS-DMA issues (A/B
-// runs); with -DIG_G8_ABLATE, IG_G8_DBG = 1..4 the timing ablations
+// small = the 128 x 128 instance (two workgroups per CU): it keeps the round-2 placement of the LDS-DMA issues (SCHED 2: with schedule 4 its
+// launches were 9-10 % slower in the B = 16 step, profiles/r05_configs/step_b16_sched4_small_instance.txt: 24.8 -> 27.2 us); the 256 x 256
+// instance runs schedule 4 (same-box A/B of the two: profiles/r05_gemm8_sched_ab_*.log).
 template <int KIND, int NSEG, int ACT, bool DACT, bool SPLIT_OUT>
 int g8_launch(const G8Params& p, int grid, hipStream_t st, bool small) {
-    const char* e = getenv("IG_G8_SCHED");
-    const int sched = e ? atoi(e) : 4;
-    // the 128 x 128 instance (16 MFMAs per big phase, two workgroups per CU) keeps the round-2 placement: with schedule 4 its launches
-    // were 9-10 % slower in the B = 16 step (profiles/r05_configs/step_b16_sched4_small_instance.txt: 24.8 -> 27.2 us)
-    if (small) return g8_launch_v<KIND, NSEG, ACT, DACT, SPLIT_OUT, 2, 0, 2, 2>(p, grid, st);
-#ifdef IG_G8_ABLATE
-    if constexpr (KIND == 0 && NSEG == 1 && ACT == 0) {
-        const char* d = getenv("IG_G8_DBG");
-        const int dbg = d ? atoi(d) : 0;
-        if (dbg == 1) return g8_launch_v<KIND, NSEG, ACT, DACT, SPLIT_OUT, 2, 1>(p, grid, st);
-        if (dbg == 2) return g8_launch_v<KIND, NSEG, ACT, DACT, SPLIT_OUT, 2, 2>(p, grid, st);
-        if (dbg == 3) return g8_launch_v<KIND, NSEG, ACT, DACT, SPLIT_OUT, 2, 3>(p, grid, st);
-        if (dbg == 4) return g8_launch_v<KIND, NSEG, ACT, DACT, SPLIT_OUT, 2, 4>(p, grid, st);
-    }
-#endif
-    if (sched == 2) return g8_launch_v<KIND, NSEG, ACT, DACT, SPLIT_OUT, 2, 0>(p, grid, st);
-    return g8_launch_v<KIND, NSEG, ACT, DACT, SPLIT_OUT, 4, 0>(p, grid, st);
+    if (small) return g8_launch_v<KIND, NSEG, ACT, DACT, SPLIT_OUT, 2, 2, 2>(p, grid, st);
+    return g8_launch_v<KIND, NSEG, ACT, DACT, SPLIT_OUT, 4>(p, grid, st);
 }
 
 }  // namespace
@@ -662,6 +631,10 @@ IG_DET_TU(gemm8)  // constant-memory descriptor of the deterministic-reduction m
 int ig_gemm8_nt(const G8Params& p, void* stream) {
     if (!g8_env()) return IG_ERR_UNSUPPORTED;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return IG_ERR_UNSUPPORTED;
+    // (Round 6, measured and removed -- profiles/r06_tail_round_split.txt: sending the row tiles of a nearly empty last round to a second launch
+    // on the 128 x 128 instance.  At M = 22064 (B = 112: 783 tiles = 3.06 rounds) qkv 86.4 -> 80.6 us, fc2 127.8 -> 123.1, but proj 47.1 -> 50.1 and
+    // the whole B = 112 step 4287 -> 4267 chips/s: a lone 128 x 128 tile still walks its 12 serialized K-tiles in ~25 us, as long as a round
+    // of big tiles.  The batch-size cliff needs shorter tails, not smaller tiles.)
     {  // the 4-wave kernel (gemm4.hip) takes the plain bf16 shapes it is routed for
         const int rc4 = ig_gemm4_nt(p, stream);
         if (rc4 != IG_ERR_UNSUPPORTED) return rc4;

@@ -269,7 +269,7 @@ def gen_readout():
 
 
 def main():
-    cfg = {"rd_every": 3, "rd_at": 0, "dm_every": 8, "dm_at": 1, "order": "ni", "skew": 0}
+    cfg = {"rd_every": 3, "rd_at": 0, "dm_every": 8, "dm_at": 3, "order": "ni", "skew": 0}
     out_path = "gemm4_gen.inc"
     for a in sys.argv[1:]:
         if "=" in a:

@@ -38,10 +38,8 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # functional testing of the multi-rank path on a one-GPU box: IG_DIST_BACKEND=gloo IG_SINGLE_DEVICE=1
+    # functional testing of the multi-rank path on a one-GPU box: IG_DIST_BACKEND=gloo with LOCAL_RANK=0 on every rank
     backend = backend or os.environ.get("IG_DIST_BACKEND") or None
-    if os.environ.get("IG_SINGLE_DEVICE") == "1":
-        local_rank = 0
     # IG_DIST_FORCE=1: initialise the process group (and run every collective of the data-parallel path) with ONE rank too -- the
     # pre-flight of the RCCL code path on a one-GPU box, where every collective degenerates to a copy (tests/test_gpu_data_parallel.py,
     # `IG_DIST_FORCE=1 python bench.py`)

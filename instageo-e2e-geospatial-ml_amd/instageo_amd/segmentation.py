@@ -123,24 +123,20 @@ class FusedAdamW(torch.optim.Optimizer):
         if self.sharded is not None:
             # data parallel, "zero1": the gradient buckets were reduce-scattered during backward; AdamW runs on this rank's slice
             # of every bucket (moments live in the ShardedGradSync) and writes the fp32 masters AND the bf16 operand copy of the
-            # slice.  IG_DP_GATHER=shadow (default): the other ranks only compute with the bf16 copy, so THAT is all-gathered
-            # (2 bytes per parameter on the wire instead of 4, and no refresh pass over the slices other ranks updated); the fp32
-            # masters stay sharded until gather_master() (checkpoints), the fp32-read vectors travel in one small all-reduce.
-            # IG_DP_GATHER=fp32: all-gather the fp32 parameters and refresh the whole operand copy (round 3).
+            # slice.  The other ranks only compute with the bf16 copy, so THAT is all-gathered (2 bytes per parameter on the wire
+            # instead of 4, and no refresh pass over the slices other ranks updated); the fp32 masters stay sharded until
+            # gather_master() (checkpoints), the fp32-read vectors travel in one small all-reduce.  (Round 3's form -- all-gather of the
+            # fp32 parameters + a refresh of the whole operand copy -- was an A/B arm and is gone.)
             def adam(param, grad, m, v, index0):
                 shw = ops.BT(sh.hi[index0 : index0 + param.numel()], None if sh.lo is None else sh.lo[index0 : index0 + param.numel()])
                 ops.adamw_step(param, grad, m, v, shw, self.hyper, param.numel())
 
-            if os.environ.get("IG_DP_GATHER", "shadow") == "fp32":
-                self.sharded.step(adam)
-                store.refresh_shadow(eng.split)
-            else:
-                if self._small_ranges is None:
-                    self._small_ranges = [(e.offset, e.offset + e.numel) for e in store.entries.values()
-                                          if e.numel <= 65536 and e.offset + e.numel > self.lo and e.offset < self.hi]
-                # the waits for the all-gathers are left to the next forward pass (engine.param_wait, one per Block): IG_DP_DEFER=0 waits here
-                self.sharded.step(adam, gather=[sh.hi] + ([] if sh.lo is None else [sh.lo]), small_ranges=self._small_ranges,
-                                  defer=os.environ.get("IG_DP_DEFER", "1") != "0" and eng.param_wait is not None)
+            if self._small_ranges is None:
+                self._small_ranges = [(e.offset, e.offset + e.numel) for e in store.entries.values()
+                                      if e.numel <= 65536 and e.offset + e.numel > self.lo and e.offset < self.hi]
+            # the waits for the all-gathers are left to the next forward pass (engine.param_wait, one per Block): IG_DP_DEFER=0 waits here
+            self.sharded.step(adam, gather=[sh.hi] + ([] if sh.lo is None else [sh.lo]), small_ranges=self._small_ranges,
+                              defer=os.environ.get("IG_DP_DEFER", "1") != "0" and eng.param_wait is not None)
             eng.shadow_dirty = False
             eng.shadow_t_dirty = True
             return loss

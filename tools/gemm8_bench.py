@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B of the forward linear GEMM engines in ONE process (interleaved rounds, random data, HIP events):
-the two placements of the LDS-DMA issues in gemm8.hip (IG_G8_SCHED=2 / 4; --old adds the round-1 engines).  Usage: python tools/gemm8_bench.py [M] [--x3]"""
+the 8-phase engine (gemm8.hip) against the 4-wave engine (gemm4.hip; default) or, with --old, the round-1 engines; --x3: the split mode's
+three-pass against its paired form.  Usage: python tools/gemm8_bench.py [M] [D] [--v4 | --old | --x3]"""
 import os
 import statistics
 import sys
@@ -88,18 +89,14 @@ if "--v8-only" in sys.argv:  # profiling passes: a few launches of each case on 
             fn()
     torch.cuda.synchronize()
     sys.exit(0)
-VARIANTS = [("sched 2", {"IG_GEMM8": "1", "IG_G8_SCHED": "2"}), ("sched 4", {"IG_GEMM8": "1", "IG_G8_SCHED": "4"})]
-if "--v4" in sys.argv:  # the 4-wave engine (gemm4.hip) against the 8-phase engine, same process
-    VARIANTS = [("gemm8", {"IG_GEMM8": "1", "IG_GEMM4": "0"}), ("gemm4", {"IG_GEMM8": "1", "IG_GEMM4": "2"})]
+VARIANTS = [("gemm8", {"IG_GEMM8": "1", "IG_GEMM4": "0"}), ("gemm4", {"IG_GEMM8": "1", "IG_GEMM4": "2"})]
 if "--old" in sys.argv:
-    VARIANTS = [("old", {"IG_GEMM8": "0"})] + VARIANTS
+    VARIANTS = [("old", {"IG_GEMM8": "0"})] + VARIANTS[:1]
 if split:  # the split mode: three passes over the operand pairs against the paired K-tiles (hi | lo in one LDS row)
     VARIANTS = [("3-pass", {"IG_GEMM8": "1", "IG_G8_PAIR": "0"}), ("paired", {"IG_GEMM8": "1", "IG_G8_PAIR": "1"})]
-KEYS = ("IG_GEMM8", "IG_G8_SCHED", "IG_G8_DBG", "IG_G8_PAIR", "IG_GEMM4")
-ABL = [("s2 noDMA", {"IG_GEMM8": "1", "IG_G8_SCHED": "2", "IG_G8_DBG": "1"}), ("s2 noDMA noLDS", {"IG_GEMM8": "1", "IG_G8_SCHED": "2", "IG_G8_DBG": "2"}),
-       ("s2 noDMA noLDS noBAR", {"IG_GEMM8": "1", "IG_G8_SCHED": "2", "IG_G8_DBG": "3"}), ("s2 noEPI", {"IG_GEMM8": "1", "IG_G8_SCHED": "2", "IG_G8_DBG": "4"})]
+KEYS = ("IG_GEMM8", "IG_G8_PAIR", "IG_GEMM4")
 for ci, (name, N, K, fn) in enumerate(cases):
-    variants = VARIANTS + (ABL if (ci == 0 and not split and "--ablate" in sys.argv) else [])
+    variants = VARIANTS
     res = {v: [] for v, _ in variants}
     for rnd_i in range(5):
         for v, env in variants:

@@ -34,7 +34,7 @@ shapes = [(12608, 2304, 768), (12608, 3072, 768), (12608, 768, 768), (12608, 768
           (10752, 2304, 768), (10752, 768, 3072)]
 if len(sys.argv) > 1:
     shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
-print(f"IG_GEMM={os.environ.get('IG_GEMM', '2')}")
+
 for M, N, K in shapes:
     x, w, y = rnd(M, K), rnd(N, K), BT(torch.empty(M, N, device=dev, dtype=torch.bfloat16))
     bias = torch.zeros(N, device=dev)
