@@ -92,13 +92,13 @@ bool ig_deterministic() { return g_det_host.shadow != nullptr; }
 // step (segmentation.py:216-451), a graph replay beside eager inference -- never share a buffer, so a kernel on one stream cannot read
 // partial sums, packed weights, tickets or split-K slabs that a launch on another stream is overwriting.  Slots: 0 BatchNorm
 // partial sums, 1 packed conv8 weights, 2 / 3 loss tickets and accumulators, 4 weight-gradient slabs (gemm8w.hip), 5 split-K partials (gemm.hip).
-// A stream gets its entry on first use (up to IG_SCRATCH_STREAMS per device, then NULL: the callers report it).  A fresh buffer is zero-filled.
+// A stream gets its entry on first use (up to IG_SCRATCH_STREAMS = 96 per device, then NULL: the callers report it).  A fresh buffer is zero-filled.
 // Nothing is allocated while the stream is capturing (NULL + an error text: warm up on the capture stream first).  Growing frees the old buffer
 // (hipFree synchronises the device, so no kernel in flight still reads it) -- unless a capture has ever been served from this entry: a
 // captured graph may have baked the address into its kernel nodes, so that buffer is kept for the life of the process.
 void* ig_scratch(int slot, size_t bytes, hipStream_t st) { return ig_scratch2(slot, bytes, true, st); }
 void* ig_scratch2(int slot, size_t bytes, bool may_grow, hipStream_t st) {
-    constexpr int IG_SCRATCH_STREAMS = 16, IG_SCRATCH_SLOTS = 6;
+    constexpr int IG_SCRATCH_STREAMS = 96, IG_SCRATCH_SLOTS = 6;  // (PyTorch's stream pools hold 2 x 32 streams + the default one)
     struct Entry {
         hipStream_t stream;
         bool used, captured;
