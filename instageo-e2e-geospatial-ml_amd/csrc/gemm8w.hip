@@ -490,6 +490,10 @@ inline int wg8_env() {  // IG_WGRAD8: 0 = off (the BK = 32 ring engine of gemm.h
     return e ? atoi(e) : 1;
 }
 constexpr int wg8_rem_env() { return 1; }  // ragged token splits (uniform-only splits were an A/B arm)
+inline int IG_W_DEAL_ENV() {  // IG_G8W_DEAL=0: the round-3 dealing (A/B runs)
+    const char* e = getenv("IG_G8W_DEAL");
+    return e ? atoi(e) : 1;
+}
 
 struct TileRef {  // one output tile of the launch
     int g;         // GEMM (pointer set)
@@ -595,6 +599,18 @@ int w_run(const WKey& key, const std::vector<TileRef>& tl, int M, int lda2_of_g[
                     wl.push_back(v);
                 }
             }
+            // XCD x owns a contiguous eighth of the logical workgroup list.  With the remainder workgroups at the END of the list the eighths
+            // straddle the token splits (XCD 3: the last 12 tiles of split 0 + the first 20 of split 1 -- nothing shared between them); when the
+            // counts divide, every XCD gets an equal run of main segments of ONE split and an equal share of the remainder workgroups instead.
+            if (rem && ((long)T * ks) % 8 == 0 && (wl.size() - (size_t)T * ks) % 8 == 0 && IG_W_DEAL_ENV()) {
+                const size_t nm = (size_t)T * ks / 8, nr = (wl.size() - (size_t)T * ks) / 8;
+                std::vector<std::vector<SegRef>> w2;
+                for (int x = 0; x < 8; ++x) {
+                    for (size_t i = 0; i < nm; ++i) w2.push_back(wl[x * nm + i]);
+                    for (size_t i = 0; i < nr; ++i) w2.push_back(wl[(size_t)T * ks + x * nr + i]);
+                }
+                wl.swap(w2);
+            }
             const long nq = (long)wl.size();
             const int nwg = 8 * (int)((nq + 7) / 8);
             std::vector<WSeg> hs((size_t)nwg * W_MAXSEG);
@@ -693,15 +709,22 @@ int ig_wgrad8_group(int n, const void* const* dy_hi, const void* const* dy_lo, c
         args.b[g][0] = (const char*)x_hi[g], args.b[g][1] = split ? (const char*)x_lo[g] : (const char*)x_hi[g];
         dws.dw[g] = dw[g];
         lda2[g] = N[g] * 2, ldb2[g] = K[g] * 2;
-        for (int tm = 0; tm < (N[g] >> 8); ++tm)
-            for (int tn = 0; tn < (K[g] >> 8); ++tn)
+        // Tile order: the LONGER dimension of the tile grid is the outer loop, so that a run of consecutive tiles (what one XCD gets) is a
+        // compact rectangle: 27 tiles of fc1's 12 x 3 grid = 9 rows x 3 columns share 9 + 3 operand slabs, 27 of fc2's 3 x 12 grid in
+        // row-major order 3 + 12 (round 6; a model of the plan, DESIGN 9: 1.32 -> 1.20 x the algorithmic bytes under ideal L2 sharing)
+        const int tR = N[g] >> 8, tC = K[g] >> 8;
+        const bool rows_outer = tR >= tC || !IG_W_DEAL_ENV();
+        for (int o = 0; o < (rows_outer ? tR : tC); ++o)
+            for (int i = 0; i < (rows_outer ? tC : tR); ++i) {
+                const int tm = rows_outer ? o : i, tn = rows_outer ? i : o;
                 tl.push_back(TileRef{g, (long)tm * 512, (long)tn * 512, 256, 256, (long)tm * 256 * K[g] + (long)tn * 256, K[g], 0, 0});
+            }
     }
     int ncu = ig_cu_count() - ig_reserved_cus();
     if (ncu < 8) ncu = 8;
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
-    WKey key = {0, n, M, ncu, split, wg8_rem_env(), dev_};
+    WKey key = {0, n, M, ncu, split, wg8_rem_env() + 2 * IG_W_DEAL_ENV(), dev_};
     for (int g = 0; g < n; ++g) key.push_back(N[g]), key.push_back(K[g]);
     WConv cv{};
     return w_run<0, 4, 2>(key, tl, M, lda2, ldb2, split, args, cv, dws, overwrite, (hipStream_t)stream, "ig_linear_wgrad_group");

@@ -209,7 +209,12 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def early_abort(self) -> None:
         """The backward pass raised in the middle of an overlapped step: join the side stream (its launches read the gradient
-        buffer) and take back the step counter the preamble advanced, so that the failed step leaves no half-applied bookkeeping."""
+        buffer) and take back the step counter the preamble advanced.  The BOOKKEEPING is rolled back; the PARAMETERS are not: the AdamW
+        launches that were already issued (head and late blocks) have updated their fp32 masters and moments, so a failed overlapped step
+        leaves the model partially updated and must not be retried as if it had not happened (a retry would apply those ranges twice with
+        the same bias-correction step) -- restore a checkpoint instead, as after any exception inside ``optimizer.step()``.  Step pre / post
+        hooks registered on this optimizer are called with empty ``(args, kwargs)`` and their return values are ignored; the global hooks of
+        ``torch.optim.Optimizer.step``'s wrapper do not run on the overlapped path."""
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
         self._early_cur, self._early_done = None, []
