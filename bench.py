@@ -713,7 +713,8 @@ def main() -> None:
         cb = cpu_baseline()
         detail["cpu_baseline"] = cb
         out["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
-                               "sample": f"oracle train steps (fwd+CE+bwd+AdamW), batch 4, Prithvi-100M T=1 fp32, {cb['cores']} of {cb['host_cores']} host cores",
+                               "sample": f"oracle train steps (fwd+CE+bwd+AdamW), batch 4, Prithvi-100M T=1 fp32, {cb['cores']} of {cb['host_cores']} host cores "
+                                         "= the BEST of a thread sweep (8 / 16 / 32 / 64 / all: more threads are slower at batch 4; the sweep is in the detail file)",
                                "host_cores": cb["host_cores"], "forward_configs0_chips_per_s": cb["forward_configs0"]["value"],
                                "forward_configs0_all_cores": (cb.get("all_cores") or {}).get("forward_configs0_chips_per_s"),
                                "all_cores_upper_bound": (cb.get("all_cores") or {}).get("upper_bound_chips_per_s")}  # (thread sweep: detail file)

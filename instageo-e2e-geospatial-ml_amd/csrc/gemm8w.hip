@@ -490,10 +490,7 @@ inline int wg8_env() {  // IG_WGRAD8: 0 = off (the BK = 32 ring engine of gemm.h
     return e ? atoi(e) : 1;
 }
 constexpr int wg8_rem_env() { return 1; }  // ragged token splits (uniform-only splits were an A/B arm)
-inline int IG_W_DEAL_ENV() {  // IG_G8W_DEAL=0: the round-3 dealing (A/B runs)
-    const char* e = getenv("IG_G8W_DEAL");
-    return e ? atoi(e) : 1;
-}
+constexpr int IG_W_DEAL_ENV() { return 1; }  // per-XCD rectangles (the round-3 dealing was the A/B arm: profiles/r06_gemm8w_xcd_rectangles.txt)
 
 struct TileRef {  // one output tile of the launch
     int g;         // GEMM (pointer set)

@@ -387,3 +387,71 @@ def test_operand_copy_reads_refuse_an_in_flight_all_gather():
     assert st.w(first).hi.numel() == st.entries[first].numel  # below the pending bucket: readable
     st.pending_from = lambda: None
     assert st.w(last).hi.numel() == st.entries[last].numel
+
+
+def test_gemm4_generator_emits_a_consistent_instruction_stream(tmp_path):
+    """csrc/gen_gemm4.py writes the hand-scheduled K-loop of gemm4.hip (one inline-asm block per tile, registers assigned by hand).  Structural
+    invariants of what it emits, checked on the generated text (no GPU, no compiler):
+    * the tile block holds 6 iterations (first / middle / last pair) of 128 MFMAs, every accumulator block a[4i : 4i+3] is the destination of
+      exactly two MFMAs per iteration, and only the 64 MFMAs of the very first half start from the inline constant 0;
+    * per iteration 32 fragment reads (+ 16 at the tile's entry), 16 LDS-DMA issues each preceded by its own M0 write with one other instruction
+      between them, one `vmcnt(8)` + one `s_barrier` (+ the entry's `vmcnt(0)` + barrier);
+    * every explicitly named VGPR / SGPR / AGPR lies inside the clobber list, M0 and SCC are declared, and a fragment register is never the
+      destination of a read in the half whose MFMAs consume it."""
+    import re
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "g4.inc"
+    subprocess.run([sys.executable, os.path.join(root, "instageo-e2e-geospatial-ml_amd", "csrc", "gen_gemm4.py"), str(out)], check=True)
+    text = out.read_text()
+    tile = text[text.index("#define G4_ASM_TILE"):text.index("#define G4_CLOBBERS")]
+    pro = text[text.index("#define G4_ASM_PROLOGUE"):text.index("#define G4_ASM_TILE")]
+    clob = text[text.index("#define G4_CLOBBERS"):].split("\n", 1)[0]
+    ins = re.findall(r'"([^"]*?)\\n\\t"', tile)
+    mf = [i for i in ins if i.startswith("v_mfma_f32_16x16x32_bf16")]
+    assert len(mf) == 6 * 128
+    assert sum(1 for i in mf if i.endswith(", 0")) == 64 and all(i.endswith(", 0") for i in mf[:64])
+    for it in range(6):
+        dst = [re.match(r"v_mfma_f32_16x16x32_bf16 a\[(\d+):(\d+)\]", i).group(1) for i in mf[it * 128:(it + 1) * 128]]
+        assert sorted(map(int, dst)) == sorted([4 * b for b in range(64)] * 2)
+    assert sum(1 for i in ins if i.startswith("ds_read_b128")) == 16 + 6 * 32
+    dma = [k for k, i in enumerate(ins) if i.startswith("global_load_lds_dwordx4")]
+    assert len(dma) == 6 * 16
+    for k in dma:  # M0 write two instructions earlier, something else in between (the wait state M0 needs)
+        assert ins[k - 2].startswith("s_add_u32 m0, ") and not ins[k - 1].startswith(("s_add_u32 m0", "global_load_lds")), ins[k - 2:k + 1]
+    assert sum(1 for i in ins if i == "s_waitcnt vmcnt(8)") == 6 and sum(1 for i in ins if i == "s_waitcnt vmcnt(0)") == 1
+    assert sum(1 for i in ins if i == "s_barrier") == 7
+    pins = re.findall(r'"([^"]*?)\\n\\t"', pro)
+    assert sum(1 for i in pins if i.startswith("global_load_lds_dwordx4")) == 32  # K-tiles 0 and 1 of the workgroup's first tile
+    cv = {int(x) for x in re.findall(r'"v(\d+)"', clob)}
+    cs = {int(x) for x in re.findall(r'"s(\d+)"', clob)}
+    ca = {int(x) for x in re.findall(r'"a(\d+)"', clob)}
+    assert ca == set(range(256)) and '"m0"' in clob and '"scc"' in clob and '"memory"' in clob
+    for i in ins + pins:
+        body = re.sub(r"%\[[a-z0-9_]+\]", "", i)
+        for lo, hi in re.findall(r"\bv\[(\d+):(\d+)\]", body):
+            assert set(range(int(lo), int(hi) + 1)) <= cv, i
+        for r in re.findall(r"\bv(\d+)\b", body):
+            assert int(r) in cv, i
+        for lo, hi in re.findall(r"\bs\[(\d+):(\d+)\]", body):
+            assert set(range(int(lo), int(hi) + 1)) <= cs, i
+        for r in re.findall(r"\bs(\d+)\b", body):
+            assert int(r) in cs, i
+    # a half's reads never write the fragment set its MFMAs consume: split the stream at the waits that end a half
+    half, halves = [], []
+    for i in ins:
+        half.append(i)
+        if i == "s_waitcnt lgkmcnt(0)":
+            halves.append(half)
+            half = []
+    for h in halves:
+        used = set()
+        for i in h:
+            m = re.match(r"v_mfma_f32_16x16x32_bf16 a\[\d+:\d+\], v\[(\d+):\d+\], v\[(\d+):\d+\]", i)
+            if m:
+                used |= {int(m.group(1)), int(m.group(2))}
+        for i in h:
+            m = re.match(r"ds_read_b128 v\[(\d+):\d+\]", i)
+            if m and used:
+                assert int(m.group(1)) not in used, (i, sorted(used)[:4])
