@@ -490,6 +490,7 @@ inline int wg8_env() {  // IG_WGRAD8: 0 = off (the BK = 32 ring engine of gemm.h
     return e ? atoi(e) : 1;
 }
 constexpr int wg8_rem_env() { return 1; }  // ragged token splits (uniform-only splits were an A/B arm)
+constexpr int w_rem_aligned_env() { return 1; }  // remainder workgroups in step (the walking remainder was the A/B arm: profiles/r06_gemm8w_xcd_rectangles.txt)
 constexpr int IG_W_DEAL_ENV() { return 1; }  // per-XCD rectangles (the round-3 dealing was the A/B arm: profiles/r06_gemm8w_xcd_rectangles.txt)
 
 struct TileRef {  // one output tile of the launch
@@ -567,7 +568,37 @@ int w_run(const WKey& key, const std::vector<TileRef>& tl, int M, int lda2_of_g[
                     rem = (q + r - 1) / r + 1 <= W_MAXSEG;
                 }
             }
-            if (rem) {
+            // Remainder workgroups that run IN STEP (round 6).  The walk below gives every remainder workgroup q token pairs of the
+            // concatenated tile remainders: it enters its first tile at an offset of its own, so no two of them are ever at the same token of
+            // a shared operand slab at the same time -- their fetches (T r 2 slab pairs against the 48 r a Block needs) were most of the
+            // kernel's excess traffic.  When the counts divide over the 8 XCDs the remainder is cut differently: every XCD's nr remainder
+            // workgroups take WHOLE tile remainders of that XCD's share of the tiles, d = ceil(share / nr) tiles each, one after the other and
+            // all starting at the same token -- tiles that are neighbours in the (rectangle-ordered) list, so each time step's nr tiles share
+            // their operand slabs in step.  r is chosen so that d remainders weigh about one main segment: P = ks c + r with d r ~ c.
+            bool aligned = false;
+            if (rem && ((long)T * ks) % 8 == 0 && R % 8 == 0 && w_rem_aligned_env()) {
+                const int nr = R / 8, share = (T + 7) / 8, d = (share + nr - 1) / nr;
+                if (d >= 1 && d <= W_MAXSEG && (long)nr * d * 8 >= T) {
+                    int r2 = (int)((P + (ks * d + 1) / 2) / (ks * d + 1));
+                    while (r2 > 1 && (P - r2) % ks) --r2;
+                    const int c2 = (P - r2) / ks;
+                    if (r2 >= 1 && (P - r2) % ks == 0 && c2 >= 1 && c2 <= c + c / 16) {  // at most ~6 % more than the balanced main segment
+                        c = c2, r = r2, aligned = true;
+                        for (int sp = 0; sp < ks; ++sp)
+                            for (int t = 0; t < T; ++t) wl.push_back({SegRef{t, sp * c, c}});
+                        for (int x = 0; x < 8; ++x) {
+                            const int t0 = (int)((long)T * x / 8), t1 = (int)((long)T * (x + 1) / 8);  // this XCD's share of the tile remainders
+                            for (int j = 0; j < nr; ++j) {
+                                std::vector<SegRef> v;
+                                for (int t = t0 + j; t < t1; t += nr) v.push_back(SegRef{t, ks * c, r});
+                                wl.push_back(v);  // (an empty list is a workgroup without work: it returns at once)
+                            }
+                        }
+                    }
+                }
+            }
+            if (aligned) {
+            } else if (rem) {
                 for (int sp = 0; sp < ks; ++sp)
                     for (int t = 0; t < T; ++t) wl.push_back({SegRef{t, sp * c, c}});
                 for (int j = 0; j < R; ++j) {
@@ -721,7 +752,7 @@ int ig_wgrad8_group(int n, const void* const* dy_hi, const void* const* dy_lo, c
     if (ncu < 8) ncu = 8;
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
-    WKey key = {0, n, M, ncu, split, wg8_rem_env() + 2 * IG_W_DEAL_ENV(), dev_};
+    WKey key = {0, n, M, ncu, split, wg8_rem_env() + 2 * IG_W_DEAL_ENV() + 4 * w_rem_aligned_env(), dev_};
     for (int g = 0; g < n; ++g) key.push_back(N[g]), key.push_back(K[g]);
     WConv cv{};
     return w_run<0, 4, 2>(key, tl, M, lda2, ldb2, split, args, cv, dws, overwrite, (hipStream_t)stream, "ig_linear_wgrad_group");
