@@ -241,6 +241,179 @@ def gen_tile(cfg):
     return st.text()
 
 
+# =====================================================================================================================================
+# PAIRED form (the split precision mode bf16x3: value = hi + lo, products hi hi + hi lo + lo hi).  A K-tile covers 32 reduction elements; its
+# 128-byte LDS row is [hi k..k+31 | lo k..k+31] (the lo lanes of an LDS-DMA piece carry the hi -> lo tensor distance in their 32-bit offset, as
+# gemm8.hip's NSEG = 2), so k-substep 0 of the fragment reads is hi and substep 1 is lo, and a K-tile is THREE products of 64 MFMAs:
+#     P1  acc += Bhi x Ahi      | 8 reads: Blo of this K-tile                         | 8 LDS-DMA issues: A of K-tile kt + 2
+#     sync lgkmcnt(0), vmcnt(8), s_barrier
+#     P2  acc += Bhi x Alo      | 8 reads: Ahi of K-tile kt + 1 -> the OTHER Ahi buffer | 4 LDS-DMA issues: B of K-tile kt + 2 (first half)
+#     P3  acc += Blo x Ahi      | 16 reads: Bhi, Alo of K-tile kt + 1                   | 4 LDS-DMA issues (second half)
+# Five quarter sets of 8 x 4 VGPRs (Ahi twice -- it is live from P1 to P3, so the next K-tile's copy needs a buffer of its own; the two
+# alternate with the K-tile parity, which the loop is unrolled by anyway), 192 MFMAs for the 64 KiB a K-tile moves: 21 B/clk/CU at full MFMA
+# rate instead of the plain form's 32 -- the paired form is NOT bound by the L2 -> LDS feed.
+PV_TMP, PV_FA, PV_FB, PV_AC = 54, 56, 58, 62
+PV_OFFA_N, PV_OFFA, PV_OFFB = 64, 72, 80
+PQ_AHI, PQ_ALO, PQ_BHI, PQ_BLO = (96, 128), 160, 192, 224
+PV_LO = 54
+
+
+def pq(base, i):
+    return f"v[{base + 4 * i}:{base + 4 * i + 3}]"
+
+
+def p_fbase_b(stage, s):
+    return f"v{PV_FB + 2 * stage + s}"
+
+
+def p_reads_a(base):
+    return [f"ds_read_b128 {pq(base, i)}, v{PV_AC} offset:{i * 2048}" for i in range(8)]
+
+
+def p_reads_b(base, bstage, s):
+    return [f"ds_read_b128 {pq(base, i)}, {p_fbase_b(bstage, s)} offset:{i * 2048}" for i in range(8)]
+
+
+def p_dmas_a(next_tile):
+    offa = PV_OFFA_N if next_tile else PV_OFFA
+    return [(f"s_add_u32 m0, s{S_ADST}, {i * 1024}", f"global_load_lds_dwordx4 v{offa + i}, s[{S_APTR}:{S_APTR + 1}]") for i in range(8)]
+
+
+def p_dmas_b(bstage):
+    return [(f"s_add_u32 m0, s{S_LDSW}, {B_BASE + bstage * B_STAGE + i * 1024}", f"global_load_lds_dwordx4 v{PV_OFFB + i}, s[{S_BPTR}:{S_BPTR + 1}]")
+            for i in range(8)]
+
+
+def p_advance(ptr):
+    return [f"s_add_u32 s{ptr}, s{ptr}, 64", f"s_addc_u32 s{ptr + 1}, s{ptr + 1}, 0"]
+
+
+def product(st, bbase, abase, first, rd, dm, cfg, dm_every, dm_at0):
+    """64 MFMAs acc += B[bbase] x A[abase] with reads and DMA pairs woven in"""
+    rd_every, rd_at0 = cfg["rd_every"], cfg["rd_at"]
+    extra = {j: [] for j in range(64)}
+    for k, r in enumerate(rd):
+        extra[min(63, rd_at0 + k * rd_every)].append(r)
+    for k, (m0w, ld) in enumerate(dm):
+        j = min(62, dm_at0 + k * dm_every)
+        extra[j].append(m0w)
+        extra[j + 1].insert(0, ld)
+    j = 0
+    for ni in range(8):
+        for mi in range(8):
+            c = "0" if first else acc(mi, ni)
+            st.e(f"v_mfma_f32_16x16x32_bf16 {acc(mi, ni)}, {pq(bbase, ni)}, {pq(abase, mi)}, {c}")
+            for x in extra[j]:
+                st.e(x)
+            j += 1
+
+
+def p_iteration(st, p, first, next_tile, cfg):
+    ahi_cur, ahi_nxt = PQ_AHI[p], PQ_AHI[p ^ 1]
+    st.e(f"s_add_u32 s{S_ADST}, s{S_LDSW}, s{S_A2}")
+    product(st, PQ_BHI, ahi_cur, first, p_reads_b(PQ_BLO, p, 1), p_dmas_a(next_tile), cfg, 8, cfg["dm_at"])
+    for a in p_advance(S_APTR):
+        st.e(a)
+    st.e("s_waitcnt lgkmcnt(0)")
+    st.e("s_waitcnt vmcnt(8)")
+    st.e("s_barrier")
+    st.e(f"v_add_u32 v{PV_AC}, s{S_A1}, v{PV_FA}")        # A of K-tile kt + 1, hi half
+    bd = p_dmas_b(p)
+    product(st, PQ_BHI, PQ_ALO, False, p_reads_a(ahi_nxt), bd[:4], cfg, 16, cfg["dm_at"])
+    st.e(f"v_add_u32 v{PV_AC}, s{S_A1}, v{PV_FA + 1}")    # ... lo half (the reads above have been issued: the address is consumed at issue)
+    product(st, PQ_BLO, ahi_cur, False, p_reads_b(PQ_BHI, p ^ 1, 0) + p_reads_a(PQ_ALO), bd[4:], cfg, 16, cfg["dm_at"])
+    for a in p_advance(S_BPTR):
+        st.e(a)
+    st.e(f"s_mov_b32 s{S_T}, s{S_A0}")
+    st.e(f"s_mov_b32 s{S_A0}, s{S_A1}")
+    st.e(f"s_mov_b32 s{S_A1}, s{S_A2}")
+    st.e(f"s_mov_b32 s{S_A2}, s{S_T}")
+    st.e("s_waitcnt lgkmcnt(0)")
+
+
+def p_setup(st):
+    for i in range(8):
+        st.e(f"v_add_u32 v{PV_TMP}, {8 * i}, %[rowv]")
+        st.e(f"v_min_u32 v{PV_TMP + 1}, %[vrc], v{PV_TMP}")
+        st.e(f"v_mad_u32_u24 v{PV_OFFA + i}, v{PV_TMP + 1}, %[lda2], %[c16a]")
+        st.e(f"v_min_u32 v{PV_TMP + 1}, %[vrn], v{PV_TMP}")
+        st.e(f"v_mad_u32_u24 v{PV_OFFA_N + i}, v{PV_TMP + 1}, %[lda2], %[c16a]")
+        st.e(f"v_mad_u32_u24 v{PV_OFFB + i}, v{PV_TMP}, %[ldb2], %[c16b]")
+    st.e(f"v_mov_b32 v{PV_FA}, %[fa]")
+    st.e(f"v_xor_b32 v{PV_FA + 1}, 64, %[fa]")
+    for b in (0, 1):
+        st.e(f"v_add_u32 {p_fbase_b(b, 0)}, {B_BASE + b * B_STAGE}, %[fb]")
+        st.e(f"v_xor_b32 {p_fbase_b(b, 1)}, 64, {p_fbase_b(b, 0)}")
+    st.e(f"s_mov_b32 s{S_LDSW}, %[ldsw]")
+    st.e(f"s_mov_b32 s{S_A0}, %[a0]")
+    st.e(f"s_mov_b32 s{S_A1}, %[a1]")
+    st.e(f"s_mov_b32 s{S_A2}, %[a2]")
+
+
+def gen_p_prologue():
+    st = Stream()
+    p_setup(st)
+    st.e(f"s_mov_b64 s[{S_APTR}:{S_APTR + 1}], %[aptr]")
+    st.e(f"s_mov_b64 s[{S_BPTR}:{S_BPTR + 1}], %[bptr]")
+    for k, slot in enumerate((S_A0, S_A1)):
+        st.e(f"s_add_u32 s{S_ADST}, s{S_LDSW}, s{slot}")
+        for m0w, ld in p_dmas_a(False) + p_dmas_b(k):
+            st.e(m0w)
+            st.e("s_nop 0")
+            st.e(ld)
+        for a in p_advance(S_APTR) + p_advance(S_BPTR):
+            st.e(a)
+    return st.text()
+
+
+def gen_p_tile(cfg):
+    st = Stream()
+    p_setup(st)
+    st.e(f"s_mov_b64 s[{S_APTR}:{S_APTR + 1}], %[aptr]")   # K-tile 2 of this tile
+    st.e(f"s_mov_b64 s[{S_BPTR}:{S_BPTR + 1}], %[bptr]")
+    st.e(f"s_mov_b32 s{S_CNT}, %[npair]")
+    st.e("s_waitcnt vmcnt(0)")
+    st.e("s_barrier")
+    st.e(f"v_add_u32 v{PV_AC}, s{S_A0}, v{PV_FA}")
+    for r in p_reads_a(PQ_AHI[0]):
+        st.e(r)
+    st.e(f"v_add_u32 v{PV_AC}, s{S_A0}, v{PV_FA + 1}")
+    for r in p_reads_a(PQ_ALO) + p_reads_b(PQ_BHI, 0, 0):
+        st.e(r)
+    st.e("s_waitcnt lgkmcnt(0)")
+    p_iteration(st, 0, True, False, cfg)
+    p_iteration(st, 1, False, False, cfg)
+    st.e(f"s_cmp_eq_u32 s{S_CNT}, 0")
+    st.e("s_cbranch_scc1 L_last_%=")
+    st.e("L_loop_%=:")
+    p_iteration(st, 0, False, False, cfg)
+    p_iteration(st, 1, False, False, cfg)
+    st.e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
+    st.e(f"s_cmp_lg_u32 s{S_CNT}, 0")
+    st.e("s_cbranch_scc1 L_loop_%=")
+    st.e("L_last_%=:")
+    st.e(f"s_mov_b64 s[{S_APTR}:{S_APTR + 1}], %[anext]")
+    st.e(f"s_mov_b64 s[{S_BPTR}:{S_BPTR + 1}], %[bnext]")
+    p_iteration(st, 0, False, True, cfg)
+    p_iteration(st, 1, False, True, cfg)
+    st.e(f"s_mov_b32 %[a0], s{S_A0}")
+    st.e(f"s_mov_b32 %[a1], s{S_A1}")
+    st.e(f"s_mov_b32 %[a2], s{S_A2}")
+    st.e("s_nop 15")
+    st.e("s_nop 15")
+    return st.text()
+
+
+def p_clobbers():
+    c = ['"memory"', '"scc"', '"m0"']
+    c += [f'"a{i}"' for i in range(256)]
+    used = set(range(PV_TMP, PV_TMP + 2)) | set(range(PV_FA, PV_FA + 2)) | set(range(PV_FB, PV_FB + 4)) | {PV_AC}
+    used |= set(range(PV_OFFA_N, PV_OFFA_N + 8)) | set(range(PV_OFFA, PV_OFFA + 8)) | set(range(PV_OFFB, PV_OFFB + 8)) | set(range(96, 256))
+    c += [f'"v{i}"' for i in sorted(used)]   # exactly the registers the block names: the compiler keeps the rest (v63, v88..v95 among them)
+    c += [f'"s{i}"' for i in range(S_LO, S_HI + 1)]
+    return ", ".join(c)
+
+
 def clobbers():
     c = ['"memory"', '"scc"', '"m0"']
     c += [f'"a{i}"' for i in range(256)]
@@ -282,6 +455,9 @@ def main():
         f.write("#define G4_ASM_PROLOGUE \\\n" + gen_prologue().replace("\n", " \\\n") + "\n\n")
         f.write("#define G4_ASM_TILE \\\n" + gen_tile(cfg).replace("\n", " \\\n") + "\n\n")
         f.write("#define G4_CLOBBERS " + clobbers() + "\n\n")
+        f.write("#define G4P_ASM_PROLOGUE \\\n" + gen_p_prologue().replace("\n", " \\\n") + "\n\n")
+        f.write("#define G4P_ASM_TILE \\\n" + gen_p_tile(cfg).replace("\n", " \\\n") + "\n\n")
+        f.write("#define G4P_CLOBBERS " + p_clobbers() + "\n\n")
         f.write(gen_readout() + "\n")
 
 

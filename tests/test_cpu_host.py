@@ -438,6 +438,31 @@ def test_gemm4_generator_emits_a_consistent_instruction_stream(tmp_path):
             assert set(range(int(lo), int(hi) + 1)) <= cs, i
         for r in re.findall(r"\bs(\d+)\b", body):
             assert int(r) in cs, i
+    # ---- the paired form (split precision mode): three products per K-tile, five quarter sets
+    ptile = text[text.index("#define G4P_ASM_TILE"):text.index("#define G4P_CLOBBERS")]
+    pclob = text[text.index("#define G4P_CLOBBERS"):].split("\n", 1)[0]
+    pin = re.findall(r'"([^"]*?)\\n\\t"', ptile)
+    pmf = [k for k, i in enumerate(pin) if i.startswith("v_mfma_f32_16x16x32_bf16")]
+    assert len(pmf) == 6 * 192 and all(pin[k].endswith(", 0") for k in pmf[:64]) and sum(1 for k in pmf if pin[k].endswith(", 0")) == 64
+    assert sum(1 for i in pin if i.startswith("ds_read_b128")) == 24 + 6 * 32 and sum(1 for i in pin if i.startswith("global_load_lds_dwordx4")) == 6 * 16
+    assert sum(1 for i in pin if i == "s_waitcnt vmcnt(8)") == 6 and sum(1 for i in pin if i == "s_barrier") == 7
+    pcv = {int(x) for x in re.findall(r'"v(\d+)"', pclob)}
+    for i in pin:
+        body = re.sub(r"%\[[a-z0-9_]+\]", "", i)
+        for lo, hi in re.findall(r"\bv\[(\d+):(\d+)\]", body):
+            assert set(range(int(lo), int(hi) + 1)) <= pcv, i
+        for r in re.findall(r"\bv(\d+)\b", body):
+            assert int(r) in pcv, i
+    for b in range(0, len(pmf), 64):  # a product's reads never write a quarter set its own MFMAs consume
+        lo_k, hi_k = pmf[b], pmf[b + 63]
+        used = set()
+        for k in pmf[b:b + 64]:
+            m = re.match(r"v_mfma_f32_16x16x32_bf16 a\[\d+:\d+\], v\[(\d+):\d+\], v\[(\d+):\d+\]", pin[k])
+            used |= {int(m.group(1)), int(m.group(2))}
+        for i in pin[lo_k:hi_k + 1]:
+            m = re.match(r"ds_read_b128 v\[(\d+):\d+\]", i)
+            if m:
+                assert int(m.group(1)) not in used, (i, b // 64)
     # a half's reads never write the fragment set its MFMAs consume: split the stream at the waits that end a half
     half, halves = [], []
     for i in ins:

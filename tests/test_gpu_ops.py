@@ -137,75 +137,81 @@ def test_linear_v8_engine(split, M, N, K, monkeypatch):
     close(res, rref, 2e-5 if split else 1e-5, what="v8 residual in-place")
 
 
+@pytest.mark.parametrize("split", SPLITS)
 @pytest.mark.parametrize("M,N,K", [(1000, 512, 256), (2300, 768, 768), (21276, 2304, 768), (5000, 768, 3072), (700, 1024, 1024), (600, 1024, 4096),
                                    (900, 1280, 1280), (257, 256, 384)])
-def test_linear_v4_engine(M, N, K, monkeypatch):
+def test_linear_v4_engine(split, M, N, K, monkeypatch):
     """The 4-wave / one-wave-per-SIMD engine with the generated K-loop (gemm4.hip + gen_gemm4.py), forced for every covered shape
-    (IG_GEMM4=2): qkv / fc1 (+GELU, +saved gelu') / proj / fc2 forms and the data gradient with the gelu' factor + fused column sums,
-    against float64 on the same rounded operands; K = 256 (no middle loop trip) .. 4096, the 300M / 600M widths (K = 1024 / 4096 / 1280),
-    a ragged last row block and a one-row last block; repeated launches bit-identical (LDS-DMA / barrier / AGPR read-out race screen);
-    equal to the 8-phase engine's result to the output rounding."""
+    (IG_GEMM4=2), plain bf16 operands and the split precision mode on paired K-tiles: qkv / fc1 (+GELU, +saved gelu') / proj / fc2 forms and
+    the data gradient with the gelu' factor + fused column sums, against float64 on the same rounded operands; K = 256 (no middle loop trip)
+    .. 4096, the 300M / 600M widths (K = 1024 / 4096 / 1280), a ragged last row block and a one-row last block; repeated launches
+    bit-identical (LDS-DMA / barrier / AGPR read-out race screen); equal to the 8-phase engine's result to the output rounding."""
     monkeypatch.setenv("IG_GEMM8", "2")
     monkeypatch.setenv("IG_GEMM4", "2")
-    x, xr = bt(rnd(M, K, seed=1), False)
-    w, wr = bt(rnd(N, K, seed=2, scale=K**-0.5), False)
+    tag = ",2>" if split else ">"  # the paired instances carry NSEG = 2 as a fourth template field
+    x, xr = bt(rnd(M, K, seed=1), split)
+    w, wr = bt(rnd(N, K, seed=2, scale=K**-0.5), split)
     b = rnd(N, seed=3).to(DEV)
-    y = BT.zeros((M, N), False, DEV)
-    pre = BT.zeros((M, N), False, DEV)
+    y = BT.zeros((M, N), split, DEV)
+    pre = BT.zeros((M, N), split, DEV)
     ref = xr @ wr.t() + b.double().cpu()
     ops.linear_fwd(x, w, b, y, M, N, K, act=0)
-    assert ops.last_kernel().startswith("gemm4_kernel<0,0"), ops.last_kernel()
-    close(y.float(), ref, tol_out(False), what="v4 linear")
-    first = y.hi.clone()
+    assert ops.last_kernel().startswith("gemm4_kernel<0,0,false") and ops.last_kernel().endswith(tag), ops.last_kernel()
+    close(y.float(), ref, tol_out(split), what="v4 linear")
+    first = (y.hi.clone(), None if not split else y.lo.clone())
     for _ in range(6):
         y.hi.zero_()
         ops.linear_fwd(x, w, b, y, M, N, K, act=0)
-        assert torch.equal(y.hi, first), "v4 linear differs between identical launches"
+        assert torch.equal(y.hi, first[0]) and (not split or torch.equal(y.lo, first[1])), "v4 linear differs between identical launches"
     monkeypatch.setenv("IG_GEMM4", "0")
-    y8 = BT.zeros((M, N), False, DEV)
+    y8 = BT.zeros((M, N), split, DEV)
     ops.linear_fwd(x, w, b, y8, M, N, K, act=0)
     assert ops.last_kernel().startswith("gemm8_kernel"), ops.last_kernel()
-    close(y.float(), y8.float().double().cpu(), tol_out(False), what="v4 vs v8")
+    close(y.float(), y8.float().double().cpu(), tol_out(split), what="v4 vs v8")
     monkeypatch.setenv("IG_GEMM4", "2")
     ops.linear_fwd(x, w, None, y, M, N, K, act=0)
-    close(y.float(), xr @ wr.t(), tol_out(False), what="v4 linear, no bias")
+    close(y.float(), xr @ wr.t(), tol_out(split), what="v4 linear, no bias")
     ops.linear_fwd(x, w, b, y, M, N, K, act=1, pre=pre)
-    assert ops.last_kernel().startswith("gemm4_kernel<0,1,true"), ops.last_kernel()
+    # the split mode saves gelu' in two halves (four staging slabs): that kind stays on the 8-phase engine
+    assert ops.last_kernel().startswith("gemm8_kernel" if split else "gemm4_kernel<0,1,true"), ops.last_kernel()
     rr = ref.clone().requires_grad_(True)
     (dref,) = torch.autograd.grad(F.gelu(rr).sum(), rr)
-    close(y.float(), F.gelu(ref), tol_out(False), what="v4 gelu")
-    close(pre.float(), dref, tol_out(False), what="v4 saved gelu'")
+    close(y.float(), F.gelu(ref), tol_out(split), what="v4 gelu")
+    close(pre.float(), dref, tol_out(split), what="v4 saved gelu'")
     ops.linear_fwd(x, w, b, y, M, N, K, act=1)
-    assert ops.last_kernel().startswith("gemm4_kernel<0,1,false"), ops.last_kernel()
-    close(y.float(), F.gelu(ref), tol_out(False), what="v4 gelu (no save)")
+    assert ops.last_kernel().startswith("gemm4_kernel<0,1,false") and ops.last_kernel().endswith(tag), ops.last_kernel()
+    close(y.float(), F.gelu(ref), tol_out(split), what="v4 gelu (no save)")
     res = rnd(M, N, seed=4).to(DEV)
     out = torch.zeros_like(res)
     ops.linear_residual_fwd(x, w, b, res, out, M, N, K)
-    assert ops.last_kernel().startswith("gemm4_kernel<1"), ops.last_kernel()
+    assert ops.last_kernel().startswith("gemm4_kernel<1") and ops.last_kernel().endswith(tag), ops.last_kernel()
     rref = res.double().cpu() + ref
-    close(out, rref, 1e-5, what="v4 residual")
+    close(out, rref, 2e-5 if split else 1e-5, what="v4 residual")
     first = out.clone()
     for _ in range(4):
         out.zero_()
         ops.linear_residual_fwd(x, w, b, res, out, M, N, K)
         assert torch.equal(out, first), "v4 residual differs between identical launches"
     ops.linear_residual_fwd(x, w, b, res, res, M, N, K)  # in place, as the engine uses it
-    close(res, rref, 1e-5, what="v4 residual in-place")
+    close(res, rref, 2e-5 if split else 1e-5, what="v4 residual in-place")
     # data gradient through the transposed weight copy: dx = (dy @ w) * dact, fused column sums
-    dy, dyr = bt(rnd(M, N, seed=5), False)
-    wt = BT(w.hi.t().contiguous(), None)          # (K, N): the K-contiguous operand of the dgrad GEMM  (here: dx is (M, K))
-    dx = BT.zeros((M, K), False, DEV)
-    fac, facr = bt(rnd(M, K, seed=8), False)
+    dy, dyr = bt(rnd(M, N, seed=5), split)
+    wt = BT.empty((K, N), split, DEV)          # (K, N): the K-contiguous operand of the dgrad GEMM  (here: dx is (M, K))
+    wt.hi.copy_(w.hi.t())
+    if split:
+        wt.lo.copy_(w.lo.t())
+    dx = BT.zeros((M, K), split, DEV)
+    fac, facr = bt(rnd(M, K, seed=8), split)
     cs = torch.zeros(K, device=DEV)
     if K % 256 == 0 and N >= 256:
         ops.linear_dgrad(dy, None, dx, M, N, K, pre=fac, colsum=cs, wt=wt)
-        assert ops.last_kernel().startswith("gemm4_kernel<2"), ops.last_kernel()
+        assert ops.last_kernel().startswith("gemm4_kernel<2") and ops.last_kernel().endswith(tag), ops.last_kernel()
         want = (dyr @ wr) * facr
-        close(dx.float(), want, tol_out(False), what="v4 dgrad*dact")
+        close(dx.float(), want, tol_out(split), what="v4 dgrad*dact")
         close(cs, want.sum(0), 3e-5, what="v4 fused column sums")
         ops.linear_dgrad(dy, None, dx, M, N, K, wt=wt)
-        assert ops.last_kernel().startswith("gemm4_kernel<0,0"), ops.last_kernel()
-        close(dx.float(), dyr @ wr, tol_out(False), what="v4 plain dgrad")
+        assert ops.last_kernel().startswith("gemm4_kernel<0,0") and ops.last_kernel().endswith(tag), ops.last_kernel()
+        close(dx.float(), dyr @ wr, tol_out(split), what="v4 plain dgrad")
 
 
 @pytest.mark.parametrize("split", SPLITS)

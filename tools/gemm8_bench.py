@@ -93,7 +93,8 @@ VARIANTS = [("gemm8", {"IG_GEMM8": "1", "IG_GEMM4": "0"}), ("gemm4", {"IG_GEMM8"
 if "--old" in sys.argv:
     VARIANTS = [("old", {"IG_GEMM8": "0"})] + VARIANTS[:1]
 if split:  # the split mode: three passes over the operand pairs against the paired K-tiles (hi | lo in one LDS row)
-    VARIANTS = [("3-pass", {"IG_GEMM8": "1", "IG_G8_PAIR": "0"}), ("paired", {"IG_GEMM8": "1", "IG_G8_PAIR": "1"})]
+    VARIANTS = [("gemm8 3-pass", {"IG_GEMM8": "1", "IG_G8_PAIR": "0"}), ("gemm8 paired", {"IG_GEMM8": "1", "IG_G8_PAIR": "1", "IG_GEMM4": "0"}),
+                ("gemm4 paired", {"IG_GEMM8": "1", "IG_G8_PAIR": "1", "IG_GEMM4": "2"})]
 KEYS = ("IG_GEMM8", "IG_G8_PAIR", "IG_GEMM4")
 for ci, (name, N, K, fn) in enumerate(cases):
     variants = VARIANTS
