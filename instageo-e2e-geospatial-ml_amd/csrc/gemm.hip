@@ -658,7 +658,7 @@ __global__ __launch_bounds__(NTHR2 * DUALK, (BKT == 32 ? 4 : 2)) void gemm2_kern
 }
 
 // ==============================================================================================
-// v5 (IG_GEMM=5): "ping-pong" 256x256 tile.  8 waves = 2 row groups (wr) x 4 column waves (wc); a wave owns 128 x 64
+// v5: "ping-pong" 256x256 tile.  8 waves = 2 row groups (wr) x 4 column waves (wc); a wave owns 128 x 64
 // (acc[4][8], 128 accumulator registers, one workgroup per CU => 256 registers per wave).  BK = 32, LDS-DMA into a
 // 4-stage ring (4 x 32 KiB), two K-steps in flight.  Every K-step is two PHASES (the two 64-row halves of the wave's
 // rows); a phase = [fragment ds_reads + 2 DMA pieces] s_barrier [16 MFMAs under s_setprio 1] s_barrier.  The two row

@@ -10,6 +10,8 @@ import ctypes
 import os
 import sys
 
+os.environ["IG_GEMM4"] = "0"  # the stamps live in gemm8.hip: keep the 4-wave engine (which takes the plain / residual kinds by default) out of the way
+
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "instageo-e2e-geospatial-ml_amd"))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
