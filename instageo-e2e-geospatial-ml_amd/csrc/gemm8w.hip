@@ -410,19 +410,105 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
 #undef W_ADVANCE_ROWS
 }
 
+// ===================================================================================================================================
+// gemm4w: the plain 256 x 256 linears on FOUR waves, one per SIMD, each owning a 128 x 128 quadrant of the tile in 256 accumulator
+// registers (round 6; the forward-side twin is gemm4.hip).  The K-loop of a segment is one generated assembly block (gen_gemm4.py, the
+// "w" form: three A slots + two B stages of the same [64 tokens][128 columns] TR image, 32 fragment reads and 8 LDS-DMA wave-instructions
+// per half-iteration between 64 MFMAs); ragged token tails are zero-filled by the buffer descriptor's bound instead of a zero page.
+// Same segment tables, same slab workspace, same ordered fold (the slab holds the accumulators in this kernel's lane-linear order:
+// wgrad8_reduce_kernel<.., W4 = true>).
+#include "gemm4_gen.inc"
+constexpr int W4_SMEM = 5 * 32768;
+
+__global__ __launch_bounds__(256) void gemm4w_kernel(const WSeg* __restrict__ segs, float* __restrict__ slabs, WArgs args) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const WSeg* __restrict__ my = segs + (size_t)blockIdx.x * W_MAXSEG;
+    if (my[0].nkt <= 0) return;
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_char_ptr)smem;
+    // lane constants of the asm blocks (gen_gemm4.py: w_setup): fragment reads as in gemm8w_kernel (16 lanes read 4 tokens x 16 columns)
+    const unsigned g4 = lane >> 4, li = lane & 15, qq = li >> 2, pp = li & 3;
+    const unsigned rkey5 = (qq | ((g4 & 1) << 2)) << 5;
+    const unsigned tbase = lds_base + (8 * g4 + qq) * 256 + pp * 8;
+    const unsigned fah = wr * W_HALF, fbh = wc * W_HALF;
+    // LDS-DMA: instruction i of this wave fills token rows wave*16 + i*4 + (lane >> 4) of a half-tile
+    const unsigned rowv = wave * 16 + (lane >> 4);
+    const unsigned lch0 = ((lane & 15) ^ ((lane >> 4) << 1)) << 4;
+    const unsigned ldsw = lds_base + wave * 4096;
+    unsigned a0 = 0, a1 = 32768, a2 = 65536;  // A ring (rotated by the asm blocks)
+
+    // descriptor of a segment's operand stream from K-tile `skip` on: base, valid bytes (rows x pitch, clamped)
+#define W4_DESC(S, OPER, OFF, LD, SKIP, PTR, NB)                                                  \
+    const char* PTR = args.OPER[(S)->g][0] + (S)->OFF + (long)(SKIP) * 64 * (S)->LD;             \
+    const unsigned NB = (unsigned)max((S)->rows - (SKIP) * 64, 0) * (unsigned)(S)->LD;
+    {
+        const WSeg* s0 = my;
+        W4_DESC(s0, a, aoff, lda2, 0, ra, na)
+        W4_DESC(s0, b, boff, ldb2, 0, rb, nb)
+        const int lda2 = s0->lda2, ldb2 = s0->ldb2;
+        asm volatile(G4W_ASM_PROLOGUE ::[ra] "s"(ra), [na] "s"(na), [rb] "s"(rb), [nb] "s"(nb), [lda2] "s"(lda2), [ldb2] "s"(ldb2), [ldsw] "s"(ldsw),
+                     [a0] "s"(a0), [a1] "s"(a1), [a2] "s"(a2), [rowv] "v"(rowv), [lch0] "v"(lch0), [rkey5] "v"(rkey5), [tbase] "v"(tbase),
+                     [fah] "v"(fah), [fbh] "v"(fbh)
+                     : G4W_CLOBBERS);
+    }
+    for (int sg = 0; sg < W_MAXSEG; ++sg) {
+        const WSeg* s = my + sg;
+        const int nkt = s->nkt;
+        if (nkt <= 0) break;
+        const bool more = sg + 1 < W_MAXSEG && my[sg + 1].nkt > 0;
+        const WSeg* sn = more ? s + 1 : s;
+        W4_DESC(s, a, aoff, lda2, 2, ra, na)
+        W4_DESC(s, b, boff, ldb2, 2, rb, nb)
+        W4_DESC(sn, a, aoff, lda2, 0, ran, nan0)
+        W4_DESC(sn, b, boff, ldb2, 0, rbn, nbn0)
+        const unsigned nan = more ? nan0 : 0u, nbn = more ? nbn0 : 0u;  // no next segment: the last two DMA rounds fill zeros (bound 0)
+        const int lda2 = s->lda2, ldb2 = s->ldb2, lda2n = sn->lda2, ldb2n = sn->ldb2, npair = (nkt >> 1) - 2;
+        asm volatile(G4W_ASM_SEG
+                     : [a0] "+s"(a0), [a1] "+s"(a1), [a2] "+s"(a2)
+                     : [ra] "s"(ra), [na] "s"(na), [rb] "s"(rb), [nb] "s"(nb), [ran] "s"(ran), [nan] "s"(nan), [rbn] "s"(rbn), [nbn] "s"(nbn),
+                       [lda2] "s"(lda2), [ldb2] "s"(ldb2), [lda2n] "s"(lda2n), [ldb2n] "s"(ldb2n), [npair] "s"(npair), [ldsw] "s"(ldsw),
+                       [rowv] "v"(rowv), [lch0] "v"(lch0), [rkey5] "v"(rkey5), [tbase] "v"(tbase), [fah] "v"(fah), [fbh] "v"(fbh)
+                     : G4W_CLOBBERS);
+        // the partial tile leaves in the accumulators' own order: slab element (mi 8 + ni) 256 + tid (16-byte coalesced stores); the next
+        // segment's K-tiles 0 and 1 are in flight.  (The thread index is re-materialised behind an empty asm: see gemm4.hip.)
+        int tid_e = tid;
+        asm volatile("" : "+v"(tid_e));
+        f32x4* sl = reinterpret_cast<f32x4*>(slabs + s->slab * W_SLAB) + tid_e;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            f32x4 tt[8];
+            g4_acc_row(mi, tt);
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni) sl[(mi * 8 + ni) * 256] = tt[ni];
+        }
+    }
+#undef W4_DESC
+}
+
 // dW tile (+)= sum of its slabs, in slab (= token) order.  Slab element e = a * 512 + tid holds accumulator a = (h NTW + nt) MT + mt
 // of thread tid: dW rows h*2MT16 + wr*MT16 + mt*16 + (lane & 15), columns (nt < 2: wc*32 + nt*16 | 128 + wc*NT1*16 + (nt-2)*16) + 4 (lane >> 4) .. +3.
-template <int MT, int NT1, bool TRANS>
+// W4: the slab was written by gemm4w_kernel -- element e = a * 256 + tid, a = mi 8 + ni: rows (wave >> 1) 128 + mi 16 + (lane & 15), columns
+// (wave & 1) 128 + ni 16 + 4 (lane >> 4) .. +3.
+template <int MT, int NT1, bool TRANS, bool W4 = false>
 __global__ __launch_bounds__(256) void wgrad8_reduce_kernel(const WTile* __restrict__ tiles, const float4* __restrict__ slabs, WDw dws,
                                                             int overwrite, int cout_t, int cin_t) {
     constexpr int NTW = 2 + NT1, NA = 2 * NTW * MT;
     const WTile T = tiles[blockIdx.y];
     const int e = blockIdx.x * 256 + threadIdx.x;  // 0 .. NA * 512 - 1
     if (e >= NA * 512) return;
-    const int a = e >> 9, tid = e & 511, wave = tid >> 6, lane = tid & 63;
-    const int h = a / (NTW * MT), nt = (a / MT) % NTW, mt = a % MT;
-    const int row = h * (2 * MT * 16) + (wave >> 2) * (MT * 16) + mt * 16 + (lane & 15);
-    const int col = (nt < 2 ? (wave & 3) * 32 + nt * 16 : 128 + (wave & 3) * (NT1 * 16) + (nt - 2) * 16) + 4 * (lane >> 4);
+    int row, col;
+    if constexpr (W4) {
+        const int a = e >> 8, tid = e & 255, wave = tid >> 6, lane = tid & 63;
+        row = (wave >> 1) * 128 + (a >> 3) * 16 + (lane & 15);
+        col = (wave & 1) * 128 + (a & 7) * 16 + 4 * (lane >> 4);
+    } else {
+        const int a = e >> 9, tid = e & 511, wave = tid >> 6, lane = tid & 63;
+        const int h = a / (NTW * MT), nt = (a / MT) % NTW, mt = a % MT;
+        row = h * (2 * MT * 16) + (wave >> 2) * (MT * 16) + mt * 16 + (lane & 15);
+        col = (nt < 2 ? (wave & 3) * 32 + nt * 16 : 128 + (wave & 3) * (NT1 * 16) + (nt - 2) * 16) + 4 * (lane >> 4);
+    }
     if (row >= T.rows || col >= T.cols) return;
     const float4* p = slabs + T.first * (W_SLAB / 4) + e;
     float4 s = p[0];
@@ -456,6 +542,7 @@ struct WPlan {
     WTile* tiles = nullptr;  // device
     int nwg = 0, ntiles = 0;
     long nslab = 0;
+    int min_nkt = 0;  // shortest segment in K-tiles (gemm4w_kernel needs 4)
 };
 typedef std::vector<long> WKey;
 // Plans depend on shapes only (the tables hold offsets), so the cache is small: bounded, least-recently-used eviction, one lock.
@@ -502,8 +589,31 @@ struct TileRef {  // one output tile of the launch
     int tap, jcol0;
 };
 
+inline int wg4_env() {  // IG_GEMM4W: 0 = the 8-wave kernel for the plain linears too (A/B runs), 1 = default
+    const char* e = getenv("IG_GEMM4W");
+    return e ? atoi(e) : 1;
+}
+
 template <int NSEG, int MODE, int MT, int NT1, bool TRANS>
 int w_launch(const WPlan& pl, float* ws, const bf16_t* zp, const WArgs& args, const WConv& cv, const WDw& dws, int overwrite, hipStream_t st) {
+    if constexpr (NSEG == 1 && MODE == 0 && MT == 4 && NT1 == 2 && !TRANS) {
+        if (pl.min_nkt >= 4 && wg4_env()) {
+            static bool attr4_done = false;
+            if (!attr4_done) {
+                if (hipFuncSetAttribute((const void*)gemm4w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W4_SMEM) != hipSuccess) {
+                    ig_set_error("gemm4w: could not reserve %d bytes of LDS", W4_SMEM);
+                    return IG_ERR_HIP;
+                }
+                attr4_done = true;
+            }
+            ig_note_kernel("gemm4w_kernel");
+            ig_note_grid(pl.nwg);
+            hipLaunchKernelGGL(gemm4w_kernel, dim3(pl.nwg), dim3(256), W4_SMEM, st, (const WSeg*)pl.segs, ws, args);
+            hipLaunchKernelGGL((wgrad8_reduce_kernel<4, 2, false, true>), dim3(64, pl.ntiles), dim3(256), 0, st, (const WTile*)pl.tiles,
+                               (const float4*)ws, dws, overwrite, 0, 0);
+            return ig_check_launch("gemm4w");
+        }
+    }
     auto kern = gemm8w_kernel<NSEG, MODE, MT, NT1>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -645,6 +755,7 @@ int w_run(const WKey& key, const std::vector<TileRef>& tl, int M, int lda2_of_g[
             memset(hs.data(), 0, hs.size() * sizeof(WSeg));
             const int spt = ks + 2;  // slab slots per tile (a tile's remainder may be cut once by a workgroup boundary)
             std::vector<int> tcount(T, 0);
+            int min_nkt = 1 << 30;
             const long qx = nq >> 3, rx = nq & 7;
             for (int b = 0; b < nwg; ++b) {
                 const int xcd = b & 7, j = b >> 3;
@@ -660,6 +771,7 @@ int w_run(const WKey& key, const std::vector<TileRef>& tl, int M, int lda2_of_g[
                     d.boff = tr.boff + (MODE == 1 ? 0 : tok0 * d.ldb2);
                     d.slab = (long)v[si].t * spt + tcount[v[si].t]++;
                     d.nkt = v[si].np * 2;
+                    if (d.nkt < min_nkt) min_nkt = d.nkt;
                     const long left = (long)M - tok0;
                     d.rows = (int)(left < (long)d.nkt * 64 ? left : (long)d.nkt * 64);
                     d.tok0 = (int)tok0;
@@ -679,7 +791,9 @@ int w_run(const WKey& key, const std::vector<TileRef>& tl, int M, int lda2_of_g[
                     return IG_ERR_ARG;
                 }
             }
-            pl.nwg = nwg, pl.ntiles = (int)ntiles, pl.nslab = ntiles * spt;
+            for (int g = 0; g < W_MAXG; ++g)  // gemm4w_kernel's descriptor bound (valid rows x pitch) is 32 bits
+                if ((long)M * lda2_of_g[g] >= (1L << 32) || (long)M * ldb2_of_g[g] >= (1L << 32)) min_nkt = 0;
+            pl.nwg = nwg, pl.ntiles = (int)ntiles, pl.nslab = ntiles * spt, pl.min_nkt = min_nkt;
             if (hipMalloc((void**)&pl.segs, hs.size() * sizeof(WSeg)) != hipSuccess ||
                 hipMalloc((void**)&pl.tiles, ht.size() * sizeof(WTile)) != hipSuccess) {
                 ig_set_error("%s: could not allocate the segment tables", what);

@@ -414,6 +414,200 @@ def p_clobbers():
     return ", ".join(c)
 
 
+# =====================================================================================================================================
+# WEIGHT-GRADIENT form (gemm4w, used by gemm8w.hip for the plain 256 x 256 linears): dW[n][k] += sum_t dy[t][n] x[t][k].  The reduction runs over
+# tokens, so both operands are reduce-strided: an operand tile in LDS is two halves of [64 tokens][128 columns] (256-byte rows), filled by
+# LDS-DMA in full 256-byte source rows through a buffer descriptor (tokens past the segment's end read as zeros), and the MFMA fragments come
+# from ds_read_b64_tr_b16 (hardware transpose; the image, its chunk-pair swizzle and the fragment addressing are gemm8w.hip's).  Wave (wr, wc)
+# reads A half wr (the n side: dy) and B half wc (the k side: x).  Same ring (three A slots, two B stages), same iteration shape as the
+# forward form; a fragment is two 8-byte reads, so a half-iteration carries 32 reads.  The unit of work is a SEGMENT (output tile x token
+# range) of the host-built plan; the DMA stream crosses segment boundaries the way the forward form crosses tiles.
+WV_TMP = 62                     # v62, v63
+WV_ABASE, WV_ACUR = 64, 72      # v64..v71: A fragment address of block mi without the slot; v72..v79: with the slot of the half being read
+WV_B = 80                       # v80..v95: B fragment addresses [stage][ni]
+WV_OFFA, WV_OFFA_N, WV_OFFB, WV_OFFB_N = 96, 104, 112, 120   # DMA offsets (h, i) of A / B, this and the next segment
+WV_LO = 62
+WS_RA, WS_RB = 84, 88           # s[84:87], s[88:91]: buffer descriptors of the A / B stream
+WS_STEPA, WS_STEPB = 92, 93     # bytes per K-tile (64 tokens x row pitch)
+WS_LO, WS_HI = 70, 93
+
+
+def w_frag(q, is_b, i):
+    b = V_SET + 64 * q + 32 * is_b + 4 * i
+    return b
+
+
+def w_reads(q, s, bstage):
+    out = []
+    for i in range(8):
+        d = w_frag(q, 0, i)
+        out.append(f"ds_read_b64_tr_b16 v[{d}:{d + 1}], v{WV_ACUR + i} offset:{s * 8192}")
+        out.append(f"ds_read_b64_tr_b16 v[{d + 2}:{d + 3}], v{WV_ACUR + i} offset:{s * 8192 + 1024}")
+    for i in range(8):
+        d = w_frag(q, 1, i)
+        out.append(f"ds_read_b64_tr_b16 v[{d}:{d + 1}], v{WV_B + 8 * bstage + i} offset:{s * 8192}")
+        out.append(f"ds_read_b64_tr_b16 v[{d + 2}:{d + 3}], v{WV_B + 8 * bstage + i} offset:{s * 8192 + 1024}")
+    return out
+
+
+def w_dmas_a(next_seg):
+    off = WV_OFFA_N if next_seg else WV_OFFA
+    return [(f"s_add_u32 m0, s{S_ADST}, {h * 16384 + i * 1024}", f"buffer_load_dwordx4 v{off + h * 4 + i}, s[{WS_RA}:{WS_RA + 3}], 0 offen lds")
+            for h in range(2) for i in range(4)]
+
+
+def w_dmas_b(bstage, next_seg):
+    off = WV_OFFB_N if next_seg else WV_OFFB
+    return [(f"s_add_u32 m0, s{S_LDSW}, {B_BASE + bstage * B_STAGE + h * 16384 + i * 1024}",
+             f"buffer_load_dwordx4 v{off + h * 4 + i}, s[{WS_RB}:{WS_RB + 3}], 0 offen lds") for h in range(2) for i in range(4)]
+
+
+def w_advance(rs, step):
+    """next K-tile: base += step, num_records -= step (clamped at 0: the tokens past the segment's end read as zeros)"""
+    return [f"s_add_u32 s{rs}, s{rs}, s{step}", f"s_addc_u32 s{rs + 1}, s{rs + 1}, 0",
+            f"s_sub_u32 s{rs + 2}, s{rs + 2}, s{step}", f"s_cselect_b32 s{rs + 2}, 0, s{rs + 2}"]
+
+
+def w_half(st, q, first, rd, dm, cfg):
+    extra = {j: [] for j in range(64)}
+    for k, r in enumerate(rd):
+        extra[min(63, k * 2)].append(r)
+    for k, (m0w, ld) in enumerate(dm):
+        j = min(62, cfg["dm_at"] + k * 8)
+        extra[j].append(m0w)
+        extra[j + 1].insert(0, ld)
+    j = 0
+    for ni in range(8):
+        for mi in range(8):
+            a = w_frag(q, 0, mi)
+            b = w_frag(q, 1, ni)
+            c = "0" if first else acc(mi, ni)
+            st.e(f"v_mfma_f32_16x16x32_bf16 {acc(mi, ni)}, v[{b}:{b + 3}], v[{a}:{a + 3}], {c}")
+            for x in extra[j]:
+                st.e(x)
+            j += 1
+
+
+def w_iteration(st, p, first, next_seg, cfg):
+    for i in range(8):
+        st.e(f"v_add_u32 v{WV_ACUR + i}, s{S_A0}, v{WV_ABASE + i}")
+    st.e(f"s_add_u32 s{S_ADST}, s{S_LDSW}, s{S_A2}")
+    w_half(st, 0, first, w_reads(1, 1, p), w_dmas_a(next_seg), cfg)
+    for a in w_advance(WS_RA, WS_STEPA):
+        st.e(a)
+    st.e("s_waitcnt lgkmcnt(0)")
+    st.e("s_waitcnt vmcnt(8)")
+    st.e("s_barrier")
+    for i in range(8):
+        st.e(f"v_add_u32 v{WV_ACUR + i}, s{S_A1}, v{WV_ABASE + i}")
+    w_half(st, 1, False, w_reads(0, 0, p ^ 1), w_dmas_b(p, next_seg), cfg)
+    for a in w_advance(WS_RB, WS_STEPB):
+        st.e(a)
+    st.e(f"s_mov_b32 s{S_T}, s{S_A0}")
+    st.e(f"s_mov_b32 s{S_A0}, s{S_A1}")
+    st.e(f"s_mov_b32 s{S_A1}, s{S_A2}")
+    st.e(f"s_mov_b32 s{S_A2}, s{S_T}")
+    st.e("s_waitcnt lgkmcnt(0)")
+
+
+def w_setup(st, with_next):
+    # fragment addresses: toff[i] = tbase + ((i << 5) ^ rkey5); A: + the wave's half (fah); B: + the wave's half + stage base (fbh)
+    for i in range(8):
+        st.e(f"v_xor_b32 v{WV_TMP}, {i << 5}, %[rkey5]")
+        st.e(f"v_add_u32 v{WV_TMP}, v{WV_TMP}, %[tbase]")
+        st.e(f"v_add_u32 v{WV_ABASE + i}, v{WV_TMP}, %[fah]")
+        st.e(f"v_add_u32 v{WV_TMP}, v{WV_TMP}, %[fbh]")
+        st.e(f"v_add_u32 v{WV_B + i}, {B_BASE}, v{WV_TMP}")
+        st.e(f"v_add_u32 v{WV_B + 8 + i}, {B_BASE + B_STAGE}, v{WV_TMP}")
+    # DMA offsets: piece (h, i) of this wave = token rows 16 w + 4 i + (lane >> 4), half h: row x pitch + 256 h + 16 x source chunk
+    # (the chunk-pair key of LDS rows 8 .. 15 of a 16-row group has bit 2 set: source chunk ^ 8, byte offset ^ 128)
+    st.e(f"v_xor_b32 v{WV_TMP + 1}, 128, %[lch0]")
+    sets = [(WV_OFFA, "%[lda2]"), (WV_OFFB, "%[ldb2]")]
+    if with_next:
+        sets += [(WV_OFFA_N, "%[lda2n]"), (WV_OFFB_N, "%[ldb2n]")]
+    for base, ld in sets:
+        for h in range(2):
+            for i in range(4):
+                st.e(f"v_add_u32 v{WV_TMP}, {4 * i}, %[rowv]")
+                st.e(f"v_mad_u32_u24 v{base + h * 4 + i}, v{WV_TMP}, {ld}, {f'v{WV_TMP + 1}' if i >= 2 else '%[lch0]'}")
+                if h:
+                    st.e(f"v_add_u32 v{base + h * 4 + i}, 256, v{base + h * 4 + i}")
+    st.e(f"s_mov_b32 s{S_LDSW}, %[ldsw]")
+    st.e(f"s_mov_b32 s{S_A0}, %[a0]")
+    st.e(f"s_mov_b32 s{S_A1}, %[a1]")
+    st.e(f"s_mov_b32 s{S_A2}, %[a2]")
+    w_desc(st, "")
+
+
+def w_desc(st, sfx):
+    """descriptors of the two streams: 64-bit base (stride 0), bytes, raw-buffer flags; bytes per K-tile = 64 x row pitch"""
+    st.e(f"s_mov_b64 s[{WS_RA}:{WS_RA + 1}], %[ra{sfx}]")
+    st.e(f"s_mov_b32 s{WS_RA + 2}, %[na{sfx}]")
+    st.e(f"s_mov_b32 s{WS_RA + 3}, 0x00020000")
+    st.e(f"s_mov_b64 s[{WS_RB}:{WS_RB + 1}], %[rb{sfx}]")
+    st.e(f"s_mov_b32 s{WS_RB + 2}, %[nb{sfx}]")
+    st.e(f"s_mov_b32 s{WS_RB + 3}, 0x00020000")
+    st.e(f"s_lshl_b32 s{WS_STEPA}, %[lda2{sfx}], 6")
+    st.e(f"s_lshl_b32 s{WS_STEPB}, %[ldb2{sfx}], 6")
+
+
+def gen_w_prologue():
+    """first segment of a workgroup: K-tiles 0 and 1 (ra / rb: descriptors at the segment's first token)"""
+    st = Stream()
+    w_setup(st, False)
+    for k, slot in enumerate((S_A0, S_A1)):
+        st.e(f"s_add_u32 s{S_ADST}, s{S_LDSW}, s{slot}")
+        for m0w, ld in w_dmas_a(False) + w_dmas_b(k, False):
+            st.e(m0w)
+            st.e("s_nop 0")
+            st.e(ld)
+        for a in w_advance(WS_RA, WS_STEPA) + w_advance(WS_RB, WS_STEPB):
+            st.e(a)
+    return st.text()
+
+
+def gen_w_seg(cfg):
+    """one segment: ra / rb stand on its K-tile 2, ran / rbn on the next segment's first token"""
+    st = Stream()
+    w_setup(st, True)
+    st.e(f"s_mov_b32 s{S_CNT}, %[npair]")
+    st.e("s_waitcnt vmcnt(0)")
+    st.e("s_barrier")
+    for i in range(8):
+        st.e(f"v_add_u32 v{WV_ACUR + i}, s{S_A0}, v{WV_ABASE + i}")
+    for r in w_reads(0, 0, 0):
+        st.e(r)
+    st.e("s_waitcnt lgkmcnt(0)")
+    w_iteration(st, 0, True, False, cfg)
+    w_iteration(st, 1, False, False, cfg)
+    st.e(f"s_cmp_eq_u32 s{S_CNT}, 0")
+    st.e("s_cbranch_scc1 L_last_%=")
+    st.e("L_loop_%=:")
+    w_iteration(st, 0, False, False, cfg)
+    w_iteration(st, 1, False, False, cfg)
+    st.e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
+    st.e(f"s_cmp_lg_u32 s{S_CNT}, 0")
+    st.e("s_cbranch_scc1 L_loop_%=")
+    st.e("L_last_%=:")
+    w_desc(st, "n")   # the DMA stream moves on to the next segment
+    w_iteration(st, 0, False, True, cfg)
+    w_iteration(st, 1, False, True, cfg)
+    st.e(f"s_mov_b32 %[a0], s{S_A0}")
+    st.e(f"s_mov_b32 %[a1], s{S_A1}")
+    st.e(f"s_mov_b32 %[a2], s{S_A2}")
+    st.e("s_nop 15")
+    st.e("s_nop 15")
+    return st.text()
+
+
+def w_clobbers():
+    c = ['"memory"', '"scc"', '"m0"']
+    c += [f'"a{i}"' for i in range(256)]
+    c += [f'"v{i}"' for i in range(WV_LO, V_HI + 1)]
+    c += [f'"s{i}"' for i in range(WS_LO, WS_HI + 1)]
+    return ", ".join(c)
+
+
 def clobbers():
     c = ['"memory"', '"scc"', '"m0"']
     c += [f'"a{i}"' for i in range(256)]
@@ -458,6 +652,9 @@ def main():
         f.write("#define G4P_ASM_PROLOGUE \\\n" + gen_p_prologue().replace("\n", " \\\n") + "\n\n")
         f.write("#define G4P_ASM_TILE \\\n" + gen_p_tile(cfg).replace("\n", " \\\n") + "\n\n")
         f.write("#define G4P_CLOBBERS " + p_clobbers() + "\n\n")
+        f.write("#define G4W_ASM_PROLOGUE \\\n" + gen_w_prologue().replace("\n", " \\\n") + "\n\n")
+        f.write("#define G4W_ASM_SEG \\\n" + gen_w_seg(cfg).replace("\n", " \\\n") + "\n\n")
+        f.write("#define G4W_CLOBBERS " + w_clobbers() + "\n\n")
         f.write(gen_readout() + "\n")
 
 

@@ -746,7 +746,7 @@ class SegEngine:
             # Did the grouped 8-phase kernel take it (ordered fold straight into dW), or the per-GEMM engines (whose split-K adds go
             # through the fixed-point shadow)?  The library decides on EVERY call (IG_WGRAD8, reserved CUs, a stream capture meeting an
             # unplanned shape ...), so the answer is read back every time: a change re-plans this block's fold and the zeroing table.
-            took8 = ops.last_kernel().startswith("gemm8w_kernel")
+            took8 = ops.last_kernel().startswith(("gemm8w_kernel", "gemm4w_kernel"))
             if ws["wgrad8"].get(i) is not took8:
                 ws["wgrad8"][i] = took8
                 ws["det_folds"].pop(i, None)

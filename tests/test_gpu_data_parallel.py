@@ -6,6 +6,7 @@ import os
 import socket
 
 import pytest
+import numpy as np
 import torch
 import torch.multiprocessing as mp
 
@@ -159,6 +160,32 @@ def test_two_rank_fused_training_equals_manual_gradient_mean(backend, mode):
     diff = (flat0 - ref).abs()
     print(f"update cosine {cos:.6f}; max diff {diff.max().item():.2e}; mean diff {diff.mean().item():.2e}")
     assert cos >= 0.999 and diff.max().item() <= 4.5e-3 and diff.mean().item() <= 2e-5
+
+
+def test_deferred_all_gather_equals_the_blocking_form_bit_for_bit(monkeypatch):
+    """``IG_DP_DEFER=1`` (default: the all-gathers of the bf16 operand copy are left in flight and waited for by the next forward pass, Block
+    by Block) against ``IG_DP_DEFER=0`` (waited for inside ``optimizer.step()``): two ranks (gloo, sharing cuda:0 -- the transport this pool
+    offers; on RCCL ``bench.py --gpus N`` makes the same comparison in its pre-flight) run the real fused training step twice under each
+    setting.  The completed fp32 parameters and the operand copy must be identical between the two forms, on both ranks."""
+    ctx = mp.get_context("spawn")
+    out = {}
+    for defer in ("1", "0"):
+        monkeypatch.setenv("IG_DP_DEFER", defer)  # inherited by the spawned workers
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, q, "gloo", "zero1")) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=60)
+        for r in res:
+            assert not isinstance(r[1], str), r[1]
+        out[defer] = res
+    for rank in (0, 1):
+        a, b = out["1"][rank], out["0"][rank]
+        assert np.array_equal(a[1], b[1]), f"rank {rank}: fp32 parameters differ between the deferred and the blocking all-gather"
+        assert a[5] == b[5], f"rank {rank}: bf16 operand copies differ between the deferred and the blocking all-gather"
 
 
 @pytest.mark.parametrize("mode", ["zero1", "allreduce"])

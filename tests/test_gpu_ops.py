@@ -391,6 +391,35 @@ def test_linear_wgrad_group(split, M, shapes):
         assert torch.equal(it[2], a), "overwrite form differs from accumulate-into-zero"
 
 
+@pytest.mark.parametrize("M,shapes", [
+    (42336, [(768, 3072), (3072, 768), (768, 768), (2304, 768)]),  # the benchmark batch (B = 216): 2 token splits + aligned remainders
+    (21276, [(768, 3072), (3072, 768), (768, 768), (2304, 768)]),
+    (42336 + 37, [(1280, 1280), (256, 5120)]),                     # ragged last K-tile, other pitches
+    (6304, [(1024, 4096), (4096, 1024), (1024, 1024), (3072, 1024)]),
+])
+def test_linear_wgrad_group_four_wave_kernel(M, shapes, monkeypatch):
+    """gemm4w_kernel (4 waves, generated-assembly K-loop, descriptor-bounded ragged tails) takes the plain grouped launches whose segments
+    hold at least four K-tiles, and equals the 8-wave kernel BIT FOR BIT: same segments, same MFMA instruction in the same token order,
+    same ordered fold."""
+    items, refs = [], []
+    for gi, (N, K) in enumerate(shapes):
+        dy, dyr = bt(rnd(M, N, seed=51 + gi), False)
+        x, xr = bt(rnd(M, K, seed=71 + gi), False)
+        items.append((dy, x, torch.zeros(N, K, device=DEV), N, K))
+        refs.append(dyr.t() @ xr)
+    out = {}
+    for arm in ("0", "1"):
+        monkeypatch.setenv("IG_GEMM4W", arm)
+        for it in items:
+            it[2].fill_(float("nan"))
+        ops.linear_wgrad_group(items, M, overwrite=True)
+        assert ops.last_kernel().startswith("gemm4w_kernel" if arm == "1" else "gemm8w_kernel<1,0,4,2>"), ops.last_kernel()
+        out[arm] = [it[2].clone() for it in items]
+    for a, b, ref, (N, K) in zip(out["0"], out["1"], refs, shapes):
+        assert torch.equal(a, b), f"gemm4w differs from gemm8w on dW {N}x{K}"
+        close(b, ref, 2e-5, atol=None, what=f"gemm4w {N}x{K}")
+
+
 def test_linear_wgrad_group_fallback_shapes():
     """Shapes the 8-phase engine does not cover (N or K not a multiple of 256) run one ig_linear_wgrad per GEMM."""
     M = 500
@@ -1522,7 +1551,7 @@ def test_wgrad8_plan_cache_is_pointer_free_and_capture_safe():
             dwe.zero_()
             ops.linear_wgrad(BT(dye.hi[:Me], None), BT(xe.hi[:Me], None), dwe, Me, 256, 256)
             if j % 27 == 0:
-                assert ops.last_kernel().startswith("gemm8w_kernel"), ops.last_kernel()
+                assert ops.last_kernel().startswith(("gemm8w_kernel", "gemm4w_kernel")), ops.last_kernel()
                 close(dwe, dyer[:Me].t() @ xer[:Me], 3e-5, what=f"linear wgrad M={Me} (plan cache eviction)")
     torch.cuda.synchronize()
     assert torch.cuda.mem_get_info()[0] > free1 - (96 << 20)  # (the slab workspace of the widest token split: grown geometrically, kept)
