@@ -29,7 +29,7 @@
 // * NSEG = 2 is the split precision mode (bf16x3: hi hi + hi lo + lo hi) in its "paired" form (round 5; the three-pass form it replaces
 //   ran the loop once per operand pair): a K-tile covers 32 tokens and its 64 LDS rows are [hi tokens 0-31 | lo tokens 0-31] -- waves 0-3
 //   fetch from the hi tensors, waves 4-7 the same token rows from the lo tensors (wave-uniform: no address arithmetic per lane), k-substep
-//   0 of the fragment reads is hi, 1 is lo, and a big phase issues its MFMAs three times (hi hi, lo(B) hi(A), hi(B) lo(A)): twice the
+//   0 of the fragment reads is hi, 1 is lo, and a big phase issues its MFMAs three times (hi hi, hi(B) lo(A), lo(B) hi(A) -- gemm4w's order): twice the
 //   LDS-DMA traffic and fragment reads of the plain kernel for three times its MFMAs.
 // * Same barrier / vmcnt protocol as gemm8_kernel (SCHED 4): two big phases per K-tile, the two row groups one
 //   barrier apart, counted vmcnt(6) / vmcnt(2) in front of the issues, the second B half issued behind the MFMAs of big phase 2.
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
         if constexpr (PAIR) { /* fragments [0] = hi, [1] = lo */                                                   \
             _Pragma("unroll") for (int t_ = 0; t_ < 3; ++t_) _Pragma("unroll") for (int nt_ = 0; nt_ < NTW; ++nt_)   \
                 _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_)                                              \
-                    acc[H][nt_][mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt_][t_ == 1], af[mt_][t_ == 2], acc[H][nt_][mt_], 0, 0, 0); \
+                    acc[H][nt_][mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt_][t_ == 2], af[mt_][t_ == 1], acc[H][nt_][mt_], 0, 0, 0); \
         } else {                                                                                                  \
         _Pragma("unroll") for (int nt_ = 0; nt_ < NTW; ++nt_) _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_) \
             _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                      \
@@ -420,7 +420,11 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const WSeg* __restrict__
 #include "gemm4_gen.inc"
 constexpr int W4_SMEM = 5 * 32768;
 
+// PAIR: the split precision mode in its paired form (K-tiles of 32 tokens, LDS rows [hi | lo]: waves 0, 1 fetch hi, waves 2, 3 lo; three
+// products per K-tile -- gen_gemm4.py, "wp" form).
+template <bool PAIR>
 __global__ __launch_bounds__(256) void gemm4w_kernel(const WSeg* __restrict__ segs, float* __restrict__ slabs, WArgs args) {
+    constexpr int KT = PAIR ? 32 : 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -433,25 +437,29 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const WSeg* __restrict__ se
     const unsigned rkey5 = (qq | ((g4 & 1) << 2)) << 5;
     const unsigned tbase = lds_base + (8 * g4 + qq) * 256 + pp * 8;
     const unsigned fah = wr * W_HALF, fbh = wc * W_HALF;
-    // LDS-DMA: instruction i of this wave fills token rows wave*16 + i*4 + (lane >> 4) of a half-tile
-    const unsigned rowv = wave * 16 + (lane >> 4);
+    // LDS-DMA: instruction i of this wave fills LDS rows wave*16 + i*4 + (lane >> 4) of a half-tile (paired: token (wave & 1)*16 + ..., hi / lo)
+    const int lo_wave = PAIR ? wave >> 1 : 0;
+    const unsigned rowv = (PAIR ? (wave & 1) : wave) * 16 + (lane >> 4);
     const unsigned lch0 = ((lane & 15) ^ ((lane >> 4) << 1)) << 4;
     const unsigned ldsw = lds_base + wave * 4096;
     unsigned a0 = 0, a1 = 32768, a2 = 65536;  // A ring (rotated by the asm blocks)
 
     // descriptor of a segment's operand stream from K-tile `skip` on: base, valid bytes (rows x pitch, clamped)
 #define W4_DESC(S, OPER, OFF, LD, SKIP, PTR, NB)                                                  \
-    const char* PTR = args.OPER[(S)->g][0] + (S)->OFF + (long)(SKIP) * 64 * (S)->LD;             \
-    const unsigned NB = (unsigned)max((S)->rows - (SKIP) * 64, 0) * (unsigned)(S)->LD;
+    const char* PTR = args.OPER[(S)->g][lo_wave] + (S)->OFF + (long)(SKIP) * KT * (S)->LD;       \
+    const unsigned NB = (unsigned)max((S)->rows - (SKIP) * KT, 0) * (unsigned)(S)->LD;
+#define W4_LANE_OPERANDS [rowv] "v"(rowv), [lch0] "v"(lch0), [rkey5] "v"(rkey5), [tbase] "v"(tbase), [fah] "v"(fah), [fbh] "v"(fbh)
     {
         const WSeg* s0 = my;
         W4_DESC(s0, a, aoff, lda2, 0, ra, na)
         W4_DESC(s0, b, boff, ldb2, 0, rb, nb)
         const int lda2 = s0->lda2, ldb2 = s0->ldb2;
-        asm volatile(G4W_ASM_PROLOGUE ::[ra] "s"(ra), [na] "s"(na), [rb] "s"(rb), [nb] "s"(nb), [lda2] "s"(lda2), [ldb2] "s"(ldb2), [ldsw] "s"(ldsw),
-                     [a0] "s"(a0), [a1] "s"(a1), [a2] "s"(a2), [rowv] "v"(rowv), [lch0] "v"(lch0), [rkey5] "v"(rkey5), [tbase] "v"(tbase),
-                     [fah] "v"(fah), [fbh] "v"(fbh)
-                     : G4W_CLOBBERS);
+#define W4_PRO_OPERANDS                                                                                                                 \
+    ::[ra] "s"(ra), [na] "s"(na), [rb] "s"(rb), [nb] "s"(nb), [lda2] "s"(lda2), [ldb2] "s"(ldb2), [ldsw] "s"(ldsw), [a0] "s"(a0), [a1] "s"(a1), \
+        [a2] "s"(a2), W4_LANE_OPERANDS
+        if constexpr (PAIR) asm volatile(G4WP_ASM_PROLOGUE W4_PRO_OPERANDS : G4WP_CLOBBERS);
+        else asm volatile(G4W_ASM_PROLOGUE W4_PRO_OPERANDS : G4W_CLOBBERS);
+#undef W4_PRO_OPERANDS
     }
     for (int sg = 0; sg < W_MAXSEG; ++sg) {
         const WSeg* s = my + sg;
@@ -464,13 +472,16 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const WSeg* __restrict__ se
         W4_DESC(sn, a, aoff, lda2, 0, ran, nan0)
         W4_DESC(sn, b, boff, ldb2, 0, rbn, nbn0)
         const unsigned nan = more ? nan0 : 0u, nbn = more ? nbn0 : 0u;  // no next segment: the last two DMA rounds fill zeros (bound 0)
-        const int lda2 = s->lda2, ldb2 = s->ldb2, lda2n = sn->lda2, ldb2n = sn->ldb2, npair = (nkt >> 1) - 2;
-        asm volatile(G4W_ASM_SEG
-                     : [a0] "+s"(a0), [a1] "+s"(a1), [a2] "+s"(a2)
-                     : [ra] "s"(ra), [na] "s"(na), [rb] "s"(rb), [nb] "s"(nb), [ran] "s"(ran), [nan] "s"(nan), [rbn] "s"(rbn), [nbn] "s"(nbn),
-                       [lda2] "s"(lda2), [ldb2] "s"(ldb2), [lda2n] "s"(lda2n), [ldb2n] "s"(ldb2n), [npair] "s"(npair), [ldsw] "s"(ldsw),
-                       [rowv] "v"(rowv), [lch0] "v"(lch0), [rkey5] "v"(rkey5), [tbase] "v"(tbase), [fah] "v"(fah), [fbh] "v"(fbh)
-                     : G4W_CLOBBERS);
+        const int lda2 = s->lda2, ldb2 = s->ldb2, lda2n = sn->lda2, ldb2n = sn->ldb2;
+        const int npair = PAIR ? nkt - 2 : (nkt >> 1) - 2;  // K-tile pairs between the peeled first and last pair
+#define W4_SEG_OPERANDS                                                                                                                   \
+    : [a0] "+s"(a0), [a1] "+s"(a1), [a2] "+s"(a2)                                                                                         \
+    : [ra] "s"(ra), [na] "s"(na), [rb] "s"(rb), [nb] "s"(nb), [ran] "s"(ran), [nan] "s"(nan), [rbn] "s"(rbn), [nbn] "s"(nbn),             \
+      [lda2] "s"(lda2), [ldb2] "s"(ldb2), [lda2n] "s"(lda2n), [ldb2n] "s"(ldb2n), [npair] "s"(npair), [ldsw] "s"(ldsw), W4_LANE_OPERANDS
+        if constexpr (PAIR) asm volatile(G4WP_ASM_SEG W4_SEG_OPERANDS : G4WP_CLOBBERS);
+        else if (nkt == 2) asm volatile(G4W_ASM_SEG_SHORT W4_SEG_OPERANDS : G4W_CLOBBERS);
+        else asm volatile(G4W_ASM_SEG W4_SEG_OPERANDS : G4W_CLOBBERS);
+#undef W4_SEG_OPERANDS
         // the partial tile leaves in the accumulators' own order: slab element (mi 8 + ni) 256 + tid (16-byte coalesced stores); the next
         // segment's K-tiles 0 and 1 are in flight.  (The thread index is re-materialised behind an empty asm: see gemm4.hip.)
         int tid_e = tid;
@@ -484,6 +495,7 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const WSeg* __restrict__ se
             for (int ni = 0; ni < 8; ++ni) sl[(mi * 8 + ni) * 256] = tt[ni];
         }
     }
+#undef W4_LANE_OPERANDS
 #undef W4_DESC
 }
 
@@ -542,7 +554,7 @@ struct WPlan {
     WTile* tiles = nullptr;  // device
     int nwg = 0, ntiles = 0;
     long nslab = 0;
-    int min_nkt = 0;  // shortest segment in K-tiles (gemm4w_kernel needs 4)
+    int min_nkt = 0;  // shortest segment in K-tiles; 0: gemm4w_kernel cannot take the plan (32-bit descriptor bounds)
 };
 typedef std::vector<long> WKey;
 // Plans depend on shapes only (the tables hold offsets), so the cache is small: bounded, least-recently-used eviction, one lock.
@@ -596,19 +608,19 @@ inline int wg4_env() {  // IG_GEMM4W: 0 = the 8-wave kernel for the plain linear
 
 template <int NSEG, int MODE, int MT, int NT1, bool TRANS>
 int w_launch(const WPlan& pl, float* ws, const bf16_t* zp, const WArgs& args, const WConv& cv, const WDw& dws, int overwrite, hipStream_t st) {
-    if constexpr (NSEG == 1 && MODE == 0 && MT == 4 && NT1 == 2 && !TRANS) {
-        if (pl.min_nkt >= 4 && wg4_env()) {
+    if constexpr (MODE == 0 && MT == 4 && NT1 == 2 && !TRANS) {
+        if (pl.min_nkt >= 2 && wg4_env()) {
             static bool attr4_done = false;
             if (!attr4_done) {
-                if (hipFuncSetAttribute((const void*)gemm4w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W4_SMEM) != hipSuccess) {
+                if (hipFuncSetAttribute((const void*)gemm4w_kernel<NSEG == 2>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_SMEM) != hipSuccess) {
                     ig_set_error("gemm4w: could not reserve %d bytes of LDS", W4_SMEM);
                     return IG_ERR_HIP;
                 }
                 attr4_done = true;
             }
-            ig_note_kernel("gemm4w_kernel");
+            ig_note_kernel("gemm4w_kernel<%s>", NSEG == 2 ? "true" : "false");
             ig_note_grid(pl.nwg);
-            hipLaunchKernelGGL(gemm4w_kernel, dim3(pl.nwg), dim3(256), W4_SMEM, st, (const WSeg*)pl.segs, ws, args);
+            hipLaunchKernelGGL(gemm4w_kernel<NSEG == 2>, dim3(pl.nwg), dim3(256), W4_SMEM, st, (const WSeg*)pl.segs, ws, args);
             hipLaunchKernelGGL((wgrad8_reduce_kernel<4, 2, false, true>), dim3(64, pl.ntiles), dim3(256), 0, st, (const WTile*)pl.tiles,
                                (const float4*)ws, dws, overwrite, 0, 0);
             return ig_check_launch("gemm4w");

@@ -470,10 +470,14 @@ def w_advance(rs, step):
 
 def w_half(st, q, first, rd, dm, cfg):
     extra = {j: [] for j in range(64)}
+    if cfg.get("abl_rd"):   # timing ablations (garbage results), as in the forward form
+        rd = []
+    if cfg.get("abl_dma"):
+        dm = []
     for k, r in enumerate(rd):
-        extra[min(63, k * 2)].append(r)
+        extra[min(63, cfg["w_rd_at"] + k * cfg["w_rd_num"] // cfg["w_rd_den"])].append(r)
     for k, (m0w, ld) in enumerate(dm):
-        j = min(62, cfg["dm_at"] + k * 8)
+        j = min(62, cfg["w_dm_at"] + k * cfg["w_dm_every"])
         extra[j].append(m0w)
         extra[j + 1].insert(0, ld)
     j = 0
@@ -496,8 +500,10 @@ def w_iteration(st, p, first, next_seg, cfg):
     for a in w_advance(WS_RA, WS_STEPA):
         st.e(a)
     st.e("s_waitcnt lgkmcnt(0)")
-    st.e("s_waitcnt vmcnt(8)")
-    st.e("s_barrier")
+    if not cfg.get("abl_vmw"):
+        st.e("s_waitcnt vmcnt(8)")
+    if not cfg.get("abl_bar"):
+        st.e("s_barrier")
     for i in range(8):
         st.e(f"v_add_u32 v{WV_ACUR + i}, s{S_A1}, v{WV_ABASE + i}")
     w_half(st, 1, False, w_reads(0, 0, p ^ 1), w_dmas_b(p, next_seg), cfg)
@@ -539,16 +545,16 @@ def w_setup(st, with_next):
     w_desc(st, "")
 
 
-def w_desc(st, sfx):
-    """descriptors of the two streams: 64-bit base (stride 0), bytes, raw-buffer flags; bytes per K-tile = 64 x row pitch"""
+def w_desc(st, sfx, shift=6):
+    """descriptors of the two streams: 64-bit base (stride 0), bytes, raw-buffer flags; bytes per K-tile = 64 (paired: 32) x row pitch"""
     st.e(f"s_mov_b64 s[{WS_RA}:{WS_RA + 1}], %[ra{sfx}]")
     st.e(f"s_mov_b32 s{WS_RA + 2}, %[na{sfx}]")
     st.e(f"s_mov_b32 s{WS_RA + 3}, 0x00020000")
     st.e(f"s_mov_b64 s[{WS_RB}:{WS_RB + 1}], %[rb{sfx}]")
     st.e(f"s_mov_b32 s{WS_RB + 2}, %[nb{sfx}]")
     st.e(f"s_mov_b32 s{WS_RB + 3}, 0x00020000")
-    st.e(f"s_lshl_b32 s{WS_STEPA}, %[lda2{sfx}], 6")
-    st.e(f"s_lshl_b32 s{WS_STEPB}, %[ldb2{sfx}], 6")
+    st.e(f"s_lshl_b32 s{WS_STEPA}, %[lda2{sfx}], {shift}")
+    st.e(f"s_lshl_b32 s{WS_STEPB}, %[ldb2{sfx}], {shift}")
 
 
 def gen_w_prologue():
@@ -566,11 +572,13 @@ def gen_w_prologue():
     return st.text()
 
 
-def gen_w_seg(cfg):
-    """one segment: ra / rb stand on its K-tile 2, ran / rbn on the next segment's first token"""
+def gen_w_seg(cfg, short=False):
+    """one segment: ra / rb stand on its K-tile 2, ran / rbn on the next segment's first token.  short: a segment of ONE K-tile pair (the
+    walking remainder of a plan cuts such pieces): its only pair is the first and the last one"""
     st = Stream()
     w_setup(st, True)
-    st.e(f"s_mov_b32 s{S_CNT}, %[npair]")
+    if not short:
+        st.e(f"s_mov_b32 s{S_CNT}, %[npair]")
     st.e("s_waitcnt vmcnt(0)")
     st.e("s_barrier")
     for i in range(8):
@@ -578,19 +586,20 @@ def gen_w_seg(cfg):
     for r in w_reads(0, 0, 0):
         st.e(r)
     st.e("s_waitcnt lgkmcnt(0)")
-    w_iteration(st, 0, True, False, cfg)
-    w_iteration(st, 1, False, False, cfg)
-    st.e(f"s_cmp_eq_u32 s{S_CNT}, 0")
-    st.e("s_cbranch_scc1 L_last_%=")
-    st.e("L_loop_%=:")
-    w_iteration(st, 0, False, False, cfg)
-    w_iteration(st, 1, False, False, cfg)
-    st.e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
-    st.e(f"s_cmp_lg_u32 s{S_CNT}, 0")
-    st.e("s_cbranch_scc1 L_loop_%=")
-    st.e("L_last_%=:")
+    if not short:
+        w_iteration(st, 0, True, False, cfg)
+        w_iteration(st, 1, False, False, cfg)
+        st.e(f"s_cmp_eq_u32 s{S_CNT}, 0")
+        st.e("s_cbranch_scc1 L_last_%=")
+        st.e("L_loop_%=:")
+        w_iteration(st, 0, False, False, cfg)
+        w_iteration(st, 1, False, False, cfg)
+        st.e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
+        st.e(f"s_cmp_lg_u32 s{S_CNT}, 0")
+        st.e("s_cbranch_scc1 L_loop_%=")
+        st.e("L_last_%=:")
     w_desc(st, "n")   # the DMA stream moves on to the next segment
-    w_iteration(st, 0, False, True, cfg)
+    w_iteration(st, 0, short, True, cfg)
     w_iteration(st, 1, False, True, cfg)
     st.e(f"s_mov_b32 %[a0], s{S_A0}")
     st.e(f"s_mov_b32 %[a1], s{S_A1}")
@@ -604,6 +613,175 @@ def w_clobbers():
     c = ['"memory"', '"scc"', '"m0"']
     c += [f'"a{i}"' for i in range(256)]
     c += [f'"v{i}"' for i in range(WV_LO, V_HI + 1)]
+    c += [f'"s{i}"' for i in range(WS_LO, WS_HI + 1)]
+    return ", ".join(c)
+
+
+# ---- paired weight-gradient form (bf16x3): a K-tile covers 32 tokens, the 64 LDS rows of a half-tile are [hi tokens 0-31 | lo tokens 0-31]
+# (waves 0, 1 fetch from the hi tensors, waves 2, 3 the same token rows from the lo tensors: wave-uniform, the descriptor base selects), so
+# k-substep 0 of the fragment reads is hi and substep 1 is lo, and a K-tile is the three products of the forward paired form:
+#     P1  acc += Bhi x Ahi      | 16 reads: Blo of this K-tile                              | 8 LDS-DMA issues: A of K-tile kt + 2
+#     sync lgkmcnt(0), vmcnt(8), s_barrier
+#     P2  acc += Bhi x Alo      | 16 reads: Ahi of K-tile kt + 1 -> the other Ahi buffer    | 4 LDS-DMA issues: B of K-tile kt + 2
+#     P3  acc += Blo x Ahi      | 32 reads: Bhi, Alo of K-tile kt + 1                       | 4 LDS-DMA issues
+# The next segment's DMA offsets are computed in place before the last pair (no second offset set: the five quarter sets take v96..v255).
+WPV_TMP, WPV_ABASE, WPV_ACUR, WPV_B, WPV_OFFA, WPV_OFFB = 46, 48, 56, 64, 80, 88
+WPV_LO = 46
+
+
+def wp_reads_a(base, s):
+    out = []
+    for i in range(8):
+        out.append(f"ds_read_b64_tr_b16 v[{base + 4 * i}:{base + 4 * i + 1}], v{WPV_ACUR + i} offset:{s * 8192}")
+        out.append(f"ds_read_b64_tr_b16 v[{base + 4 * i + 2}:{base + 4 * i + 3}], v{WPV_ACUR + i} offset:{s * 8192 + 1024}")
+    return out
+
+
+def wp_reads_b(base, bstage, s):
+    out = []
+    for i in range(8):
+        out.append(f"ds_read_b64_tr_b16 v[{base + 4 * i}:{base + 4 * i + 1}], v{WPV_B + 8 * bstage + i} offset:{s * 8192}")
+        out.append(f"ds_read_b64_tr_b16 v[{base + 4 * i + 2}:{base + 4 * i + 3}], v{WPV_B + 8 * bstage + i} offset:{s * 8192 + 1024}")
+    return out
+
+
+def wp_dmas_a():
+    return [(f"s_add_u32 m0, s{S_ADST}, {h * 16384 + i * 1024}", f"buffer_load_dwordx4 v{WPV_OFFA + h * 4 + i}, s[{WS_RA}:{WS_RA + 3}], 0 offen lds")
+            for h in range(2) for i in range(4)]
+
+
+def wp_dmas_b(bstage):
+    return [(f"s_add_u32 m0, s{S_LDSW}, {B_BASE + bstage * B_STAGE + h * 16384 + i * 1024}",
+             f"buffer_load_dwordx4 v{WPV_OFFB + h * 4 + i}, s[{WS_RB}:{WS_RB + 3}], 0 offen lds") for h in range(2) for i in range(4)]
+
+
+def wp_product(st, bbase, abase, first, rd, dm, cfg, dm_every):
+    extra = {j: [] for j in range(64)}
+    if cfg.get("abl_rd"):
+        rd = []
+    if cfg.get("abl_dma"):
+        dm = []
+    for k, r in enumerate(rd):
+        extra[min(63, k * 64 // max(len(rd), 1) * cfg["wp_rd_num"] // cfg["wp_rd_den"])].append(r)
+    for k, (m0w, ld) in enumerate(dm):
+        j = min(62, cfg["w_dm_at"] + k * dm_every)
+        extra[j].append(m0w)
+        extra[j + 1].insert(0, ld)
+    j = 0
+    for ni in range(8):
+        for mi in range(8):
+            c = "0" if first else acc(mi, ni)
+            st.e(f"v_mfma_f32_16x16x32_bf16 {acc(mi, ni)}, {pq(bbase, ni)}, {pq(abase, mi)}, {c}")
+            for x in extra[j]:
+                st.e(x)
+            j += 1
+
+
+def wp_iteration(st, p, first, cfg):
+    ahi_cur, ahi_nxt = PQ_AHI[p], PQ_AHI[p ^ 1]
+    st.e(f"s_add_u32 s{S_ADST}, s{S_LDSW}, s{S_A2}")
+    for i in range(8):
+        st.e(f"v_add_u32 v{WPV_ACUR + i}, s{S_A1}, v{WPV_ABASE + i}")   # A of K-tile kt + 1
+    wp_product(st, PQ_BHI, ahi_cur, first, wp_reads_b(PQ_BLO, p, 1), wp_dmas_a(), cfg, 8)
+    for a in w_advance(WS_RA, WS_STEPA):
+        st.e(a)
+    st.e("s_waitcnt lgkmcnt(0)")
+    if not cfg.get("abl_vmw"):
+        st.e("s_waitcnt vmcnt(8)")
+    if not cfg.get("abl_bar"):
+        st.e("s_barrier")
+    bd = wp_dmas_b(p)
+    wp_product(st, PQ_BHI, PQ_ALO, False, wp_reads_a(ahi_nxt, 0), bd[:4], cfg, 16)
+    wp_product(st, PQ_BLO, ahi_cur, False, wp_reads_b(PQ_BHI, p ^ 1, 0) + wp_reads_a(PQ_ALO, 1), bd[4:], cfg, 16)
+    for a in w_advance(WS_RB, WS_STEPB):
+        st.e(a)
+    st.e(f"s_mov_b32 s{S_T}, s{S_A0}")
+    st.e(f"s_mov_b32 s{S_A0}, s{S_A1}")
+    st.e(f"s_mov_b32 s{S_A1}, s{S_A2}")
+    st.e(f"s_mov_b32 s{S_A2}, s{S_T}")
+    st.e("s_waitcnt lgkmcnt(0)")
+
+
+def wp_offsets(st, sfx):
+    st.e(f"v_xor_b32 v{WPV_TMP + 1}, 128, %[lch0]")
+    for base, ld in ((WPV_OFFA, f"%[lda2{sfx}]"), (WPV_OFFB, f"%[ldb2{sfx}]")):
+        for h in range(2):
+            for i in range(4):
+                st.e(f"v_add_u32 v{WPV_TMP}, {4 * i}, %[rowv]")
+                st.e(f"v_mad_u32_u24 v{base + h * 4 + i}, v{WPV_TMP}, {ld}, {f'v{WPV_TMP + 1}' if i >= 2 else '%[lch0]'}")
+                if h:
+                    st.e(f"v_add_u32 v{base + h * 4 + i}, 256, v{base + h * 4 + i}")
+
+
+def wp_setup(st):
+    for i in range(8):
+        st.e(f"v_xor_b32 v{WPV_TMP}, {i << 5}, %[rkey5]")
+        st.e(f"v_add_u32 v{WPV_TMP}, v{WPV_TMP}, %[tbase]")
+        st.e(f"v_add_u32 v{WPV_ABASE + i}, v{WPV_TMP}, %[fah]")
+        st.e(f"v_add_u32 v{WPV_TMP}, v{WPV_TMP}, %[fbh]")
+        st.e(f"v_add_u32 v{WPV_B + i}, {B_BASE}, v{WPV_TMP}")
+        st.e(f"v_add_u32 v{WPV_B + 8 + i}, {B_BASE + B_STAGE}, v{WPV_TMP}")
+    wp_offsets(st, "")
+    st.e(f"s_mov_b32 s{S_LDSW}, %[ldsw]")
+    st.e(f"s_mov_b32 s{S_A0}, %[a0]")
+    st.e(f"s_mov_b32 s{S_A1}, %[a1]")
+    st.e(f"s_mov_b32 s{S_A2}, %[a2]")
+    w_desc(st, "", 5)
+
+
+def gen_wp_prologue():
+    st = Stream()
+    wp_setup(st)
+    for k, slot in enumerate((S_A0, S_A1)):
+        st.e(f"s_add_u32 s{S_ADST}, s{S_LDSW}, s{slot}")
+        for m0w, ld in wp_dmas_a() + wp_dmas_b(k):
+            st.e(m0w)
+            st.e("s_nop 0")
+            st.e(ld)
+        for a in w_advance(WS_RA, WS_STEPA) + w_advance(WS_RB, WS_STEPB):
+            st.e(a)
+    return st.text()
+
+
+def gen_wp_seg(cfg):
+    """one segment of the paired form (at least four 32-token K-tiles: a plan's shortest segment is one 128-token pair)"""
+    st = Stream()
+    wp_setup(st)
+    st.e(f"s_mov_b32 s{S_CNT}, %[npair]")
+    st.e("s_waitcnt vmcnt(0)")
+    st.e("s_barrier")
+    for i in range(8):
+        st.e(f"v_add_u32 v{WPV_ACUR + i}, s{S_A0}, v{WPV_ABASE + i}")
+    for r in wp_reads_a(PQ_AHI[0], 0) + wp_reads_a(PQ_ALO, 1) + wp_reads_b(PQ_BHI, 0, 0):
+        st.e(r)
+    st.e("s_waitcnt lgkmcnt(0)")
+    wp_iteration(st, 0, True, cfg)
+    wp_iteration(st, 1, False, cfg)
+    st.e(f"s_cmp_eq_u32 s{S_CNT}, 0")
+    st.e("s_cbranch_scc1 L_last_%=")
+    st.e("L_loop_%=:")
+    wp_iteration(st, 0, False, cfg)
+    wp_iteration(st, 1, False, cfg)
+    st.e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
+    st.e(f"s_cmp_lg_u32 s{S_CNT}, 0")
+    st.e("s_cbranch_scc1 L_loop_%=")
+    st.e("L_last_%=:")
+    w_desc(st, "n", 5)   # the DMA stream moves on to the next segment
+    wp_offsets(st, "n")
+    wp_iteration(st, 0, False, cfg)
+    wp_iteration(st, 1, False, cfg)
+    st.e(f"s_mov_b32 %[a0], s{S_A0}")
+    st.e(f"s_mov_b32 %[a1], s{S_A1}")
+    st.e(f"s_mov_b32 %[a2], s{S_A2}")
+    st.e("s_nop 15")
+    st.e("s_nop 15")
+    return st.text()
+
+
+def wp_clobbers():
+    c = ['"memory"', '"scc"', '"m0"']
+    c += [f'"a{i}"' for i in range(256)]
+    c += [f'"v{i}"' for i in range(WPV_LO, V_HI + 1)]
     c += [f'"s{i}"' for i in range(WS_LO, WS_HI + 1)]
     return ", ".join(c)
 
@@ -636,7 +814,8 @@ def gen_readout():
 
 
 def main():
-    cfg = {"rd_every": 3, "rd_at": 0, "dm_every": 8, "dm_at": 3, "order": "ni", "skew": 0}
+    cfg = {"rd_every": 3, "rd_at": 0, "dm_every": 8, "dm_at": 3, "order": "ni", "skew": 0,
+           "w_rd_at": 0, "w_rd_num": 2, "w_rd_den": 1, "w_dm_at": 3, "w_dm_every": 8, "wp_rd_num": 1, "wp_rd_den": 1}
     out_path = "gemm4_gen.inc"
     for a in sys.argv[1:]:
         if "=" in a:
@@ -654,7 +833,11 @@ def main():
         f.write("#define G4P_CLOBBERS " + p_clobbers() + "\n\n")
         f.write("#define G4W_ASM_PROLOGUE \\\n" + gen_w_prologue().replace("\n", " \\\n") + "\n\n")
         f.write("#define G4W_ASM_SEG \\\n" + gen_w_seg(cfg).replace("\n", " \\\n") + "\n\n")
+        f.write("#define G4W_ASM_SEG_SHORT \\\n" + gen_w_seg(cfg, True).replace("\n", " \\\n") + "\n\n")
         f.write("#define G4W_CLOBBERS " + w_clobbers() + "\n\n")
+        f.write("#define G4WP_ASM_PROLOGUE \\\n" + gen_wp_prologue().replace("\n", " \\\n") + "\n\n")
+        f.write("#define G4WP_ASM_SEG \\\n" + gen_wp_seg(cfg).replace("\n", " \\\n") + "\n\n")
+        f.write("#define G4WP_CLOBBERS " + wp_clobbers() + "\n\n")
         f.write(gen_readout() + "\n")
 
 
