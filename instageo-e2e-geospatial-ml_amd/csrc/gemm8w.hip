@@ -601,8 +601,8 @@ struct TileRef {  // one output tile of the launch
     int tap, jcol0;
 };
 
-inline int wg4_env() {  // IG_GEMM4W: 0 = the 8-wave kernel for the plain linears too (A/B runs), 1 = default
-    const char* e = getenv("IG_GEMM4W");
+inline int wg4_env() {  // IG_GEMM4 (shared with gemm4.hip): 0 = the 8-wave kernel for the linears too (tests, A/B runs), otherwise gemm4w_kernel
+    const char* e = getenv("IG_GEMM4");
     return e ? atoi(e) : 1;
 }
 

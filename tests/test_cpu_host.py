@@ -322,8 +322,8 @@ def test_whole_network_custom_op_is_registered_with_a_fake_implementation():
 def test_m0_is_only_written_by_the_lds_dma_helpers():
     """gemm8.hip / gemm8w.hip / conv8.hip / gemm4.hip set M0 (the LDS destination of an LDS-DMA) without saving or restoring it (the asm statements
     declare the clobber).  That is sound and free only while hipcc keeps nothing of its own in M0 in those kernels: compile each file to gfx950
-    assembly (no GPU needed) and check that every M0 reference is one of the helpers' `s_mov_b32 m0, sN` -- or, in the generated K-loop of
-    gemm4.hip, `s_add_u32 m0, sN, imm` -- no read of M0, no other writer."""
+    assembly (no GPU needed) and check that every M0 reference is one of the helpers' `s_mov_b32 m0, sN` -- or, in the generated K-loops of
+    gemm4.hip and of gemm8w.hip's gemm4w_kernel, `s_add_u32 m0, sN, imm` -- no read of M0, no other writer."""
     import re
     import shutil
     import subprocess
@@ -343,8 +343,109 @@ def test_m0_is_only_written_by_the_lds_dma_helpers():
                             "--cuda-device-only", os.path.join(csrc, name + ".hip"), "-o", out], check=True, capture_output=True)
             refs = [ln.strip() for ln in open(out) if re.search(r"\bm0\b", ln) and not ln.lstrip().startswith(";")]
             assert refs, name
-            bad = [ln for ln in refs if not re.fullmatch(r"s_mov_b32 m0, s\d+", ln) and not (name == "gemm4" and re.fullmatch(r"s_add_u32 m0, s\d+, (0x)?[0-9a-f]+", ln))]
+            bad = [ln for ln in refs if not re.fullmatch(r"s_mov_b32 m0, s\d+", ln) and not (name in ("gemm4", "gemm8w") and re.fullmatch(r"s_add_u32 m0, s\d+, (0x)?[0-9a-f]+", ln))]
             assert not bad, (name, bad[:5])
+
+
+def test_gemm4w_generator_emits_a_consistent_instruction_stream(tmp_path):
+    """The weight-gradient forms of csrc/gen_gemm4.py (gemm4w_kernel in gemm8w.hip: plain, short-segment and paired blocks).  Structural
+    invariants of the generated text:
+    * plain segment block: 6 iterations of 128 MFMAs (first / middle / last pair), only the first 64 start from 0; 64 transposed fragment reads
+      per iteration (+ 32 at entry); 16 buffer LDS-DMA issues per iteration, each two instructions behind its own M0 write; one vmcnt(8) + one
+      barrier per iteration; the descriptors are re-pointed at the next segment exactly once, in front of the last pair; the short block is the
+      first-and-last pair alone;
+    * paired block: 6 iterations of 192 MFMAs in three products, 64 reads per iteration (+ 48 at entry), 16 DMA issues, and no product's reads
+      write a quarter set its own MFMAs consume;
+    * every named register lies inside the clobber list; the clobbered VGPR range leaves the low registers to the compiler."""
+    import re
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "g4.inc"
+    subprocess.run([sys.executable, os.path.join(root, "instageo-e2e-geospatial-ml_amd", "csrc", "gen_gemm4.py"), str(out)], check=True)
+    text = out.read_text()
+
+    def block(name, end):
+        return re.findall(r'"([^"]*?)\\n\\t"', text[text.index("#define " + name):text.index("#define " + end)])
+
+    def check_regs(ins, clob):
+        cv = {int(x) for x in re.findall(r'"v(\d+)"', clob)}
+        cs = {int(x) for x in re.findall(r'"s(\d+)"', clob)}
+        assert {int(x) for x in re.findall(r'"a(\d+)"', clob)} == set(range(256)) and '"m0"' in clob and '"scc"' in clob and '"memory"' in clob
+        for i in ins:
+            body = re.sub(r"%\[[a-z0-9_]+\]", "", i)
+            for lo, hi in re.findall(r"\bv\[(\d+):(\d+)\]", body):
+                assert set(range(int(lo), int(hi) + 1)) <= cv, i
+            for r in re.findall(r"\bv(\d+)\b", body):
+                assert int(r) in cv, i
+            for lo, hi in re.findall(r"\bs\[(\d+):(\d+)\]", body):
+                assert set(range(int(lo), int(hi) + 1)) <= cs, i
+            for r in re.findall(r"\bs(\d+)\b", body):
+                assert int(r) in cs, i
+        return cv
+
+    def check_dma(ins, n):
+        dma = [k for k, i in enumerate(ins) if i.startswith("buffer_load_dwordx4")]
+        assert len(dma) == n
+        for k in dma:
+            assert ins[k].endswith("offen lds") and ins[k - 2].startswith("s_add_u32 m0, ") and not ins[k - 1].startswith(("s_add_u32 m0", "buffer_load")), ins[k - 2:k + 1]
+
+    MF, RD = "v_mfma_f32_16x16x32_bf16", "ds_read_b64_tr_b16"
+    wclob = text[text.index("#define G4W_CLOBBERS"):].split("\n", 1)[0]
+    seg, short, pro = block("G4W_ASM_SEG", "G4W_ASM_SEG_SHORT"), block("G4W_ASM_SEG_SHORT", "G4W_CLOBBERS"), block("G4W_ASM_PROLOGUE", "G4W_ASM_SEG")
+    for ins, iters in ((seg, 6), (short, 2)):
+        mf = [i for i in ins if i.startswith(MF)]
+        assert len(mf) == iters * 128 and all(i.endswith(", 0") for i in mf[:64]) and sum(1 for i in mf if i.endswith(", 0")) == 64
+        for it in range(iters):
+            dst = [int(re.match(MF + r" a\[(\d+):", i).group(1)) for i in mf[it * 128:(it + 1) * 128]]
+            assert sorted(dst) == sorted([4 * b for b in range(64)] * 2)
+        assert sum(1 for i in ins if i.startswith(RD)) == 32 + iters * 64
+        check_dma(ins, iters * 16)
+        assert sum(1 for i in ins if i == "s_waitcnt vmcnt(8)") == iters and sum(1 for i in ins if i == "s_barrier") == iters + 1
+        assert sum(1 for i in ins if i == "s_waitcnt vmcnt(0)") == 1
+        # descriptors: set up once at entry, re-pointed once (the next segment) in front of the last pair
+        flags = [k for k, i in enumerate(ins) if i.endswith("0x00020000")]
+        assert len(flags) == 4
+        mfk = [k for k, i in enumerate(ins) if i.startswith(MF)]
+        assert flags[1] < mfk[0] and mfk[(iters - 2) * 128 - 1] < flags[2] < flags[3] < mfk[(iters - 2) * 128] if iters > 2 else flags[3] < mfk[0]
+    check_dma(pro, 32)
+    cv = check_regs(seg + short + pro, wclob)
+    assert min(cv) >= 48  # the compiler keeps v0 .. v47 at least
+    # a half's reads never write the fragment set its own MFMAs consume
+    half = []
+    for i in seg:
+        half.append(i)
+        if i == "s_waitcnt lgkmcnt(0)":
+            used = set()
+            for j in half:
+                m = re.match(MF + r" a\[\d+:\d+\], v\[(\d+):\d+\], v\[(\d+):\d+\]", j)
+                if m:
+                    used |= {int(m.group(1)), int(m.group(2))}
+            for j in half:
+                m = re.match(RD + r" v\[(\d+):(\d+)\]", j)
+                if m and used:
+                    assert int(m.group(1)) // 4 * 4 not in used, j
+            half = []
+    # ---- paired form
+    pclob = text[text.index("#define G4WP_CLOBBERS"):].split("\n", 1)[0]
+    pseg, ppro = block("G4WP_ASM_SEG", "G4WP_CLOBBERS"), block("G4WP_ASM_PROLOGUE", "G4WP_ASM_SEG")
+    pmf = [k for k, i in enumerate(pseg) if i.startswith(MF)]
+    assert len(pmf) == 6 * 192 and all(pseg[k].endswith(", 0") for k in pmf[:64]) and sum(1 for k in pmf if pseg[k].endswith(", 0")) == 64
+    assert sum(1 for i in pseg if i.startswith(RD)) == 48 + 6 * 64
+    check_dma(pseg, 6 * 16)
+    check_dma(ppro, 32)
+    assert sum(1 for i in pseg if i == "s_waitcnt vmcnt(8)") == 6 and sum(1 for i in pseg if i == "s_barrier") == 7
+    pcv = check_regs(pseg + ppro, pclob)
+    assert min(pcv) >= 32
+    for b in range(0, len(pmf), 64):
+        used = set()
+        for k in pmf[b:b + 64]:
+            m = re.match(MF + r" a\[\d+:\d+\], v\[(\d+):\d+\], v\[(\d+):\d+\]", pseg[k])
+            used |= {int(m.group(1)), int(m.group(2))}
+        for i in pseg[pmf[b]:pmf[b + 63] + 1]:
+            m = re.match(RD + r" v\[(\d+):", i)
+            if m:
+                assert int(m.group(1)) // 4 * 4 not in used, (i, b // 64)
 
 
 def test_split_tensors_are_one_allocation_with_lo_above_hi():

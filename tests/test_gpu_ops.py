@@ -410,7 +410,7 @@ def test_linear_wgrad_group_four_wave_kernel(split, M, shapes, monkeypatch):
         refs.append(dyr.t() @ xr)
     out = {}
     for arm in ("0", "1"):
-        monkeypatch.setenv("IG_GEMM4W", arm)
+        monkeypatch.setenv("IG_GEMM4", arm)
         for it in items:
             it[2].fill_(float("nan"))
         ops.linear_wgrad_group(items, M, overwrite=True)

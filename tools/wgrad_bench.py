@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Weight gradients of one Block: four ig_linear_wgrad launches on the 8-phase engine vs ONE grouped launch (ig_linear_wgrad_group)
-on the 8-wave kernel (IG_GEMM4W=0) and on the 4-wave generated-assembly kernel (gemm4w).  Interleaved rounds, random data, HIP events.
+on the 8-wave kernel (IG_GEMM4=0) and on the 4-wave generated-assembly kernel (gemm4w).  Interleaved rounds, random data, HIP events.
 Usage: python tools/wgrad_bench.py [M] [D] [--x3]"""
 import os
 import statistics
@@ -59,8 +59,8 @@ if "--group-only" in sys.argv:  # profiling passes: a few grouped launches only
         grouped()
     torch.cuda.synchronize()
     sys.exit(0)
-variants = [("v8w x4", {"IG_WGRAD8": "1", "IG_GEMM4W": "0"}, separate), ("v8w grouped", {"IG_WGRAD8": "1", "IG_GEMM4W": "0"}, grouped),
-            ("v4w grouped", {"IG_WGRAD8": "1", "IG_GEMM4W": "1"}, grouped)]
+variants = [("v8w x4", {"IG_WGRAD8": "1", "IG_GEMM4": "0"}, separate), ("v8w grouped", {"IG_WGRAD8": "1", "IG_GEMM4": "0"}, grouped),
+            ("v4w grouped", {"IG_WGRAD8": "1", "IG_GEMM4": "1"}, grouped)]
 res = {v: [] for v, _, _ in variants}
 for r in range(5):
     for v, env, fn in variants:
@@ -72,7 +72,7 @@ for r in range(5):
 print(f"M={M} D={D} mode={'bf16x3' if split else 'bf16'}: " + "   ".join(
     f"{v} {statistics.median(t):7.1f} us ({fl / statistics.median(t) / 1e6:5.0f} TF/s)" for v, t in res.items()))
 os.environ.pop("IG_WGRAD8", None)
-os.environ.pop("IG_GEMM4W", None)
+os.environ.pop("IG_GEMM4", None)
 for (name, N, K), it in zip(shapes, items):
     t = statistics.median(timeit(lambda it=it: ops.linear_wgrad(it[0], it[1], it[2], M, it[3], it[4])) for _ in range(3))
     print(f"  v8w {name:5s} N={N:5d} K={K:5d}: {t:7.1f} us ({2.0 * M * N * K * (3 if split else 1) / t / 1e6:5.0f} TF/s)")
