@@ -109,10 +109,10 @@ def test_custom_head_widths_embed_dims():
         PrithviSeg(variant="prithvi_eo_tiny", load_pretrained_weights=False, embed_dims=[128, 96, 64, 40, 24], device=DEV)  # dims[0] != D * T
 
 
-@pytest.mark.parametrize("B", [108, 216])
+@pytest.mark.parametrize("B", [108, 216, 432])
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
 def test_benchmark_batch_ties_to_the_golden_fixture_and_is_permutation_equivariant(precision, B):
-    """BASELINE configs[1] at its benchmark batches (216 chips = bench.py's default, 108 = the default of rounds 1-3: the sizes at
+    """BASELINE configs[1] at its benchmark batches (432 chips = bench.py's default, 216 / 108 = the defaults of earlier rounds: the sizes at
     which the 8-phase GEMM engine, the persistent tile walks -- one and two rounds of 256 CUs -- and the full-occupancy attention
     grids run).  Eval mode has no cross-sample coupling, so
     (i) the logits of the fixture's four chips, placed at scattered batch positions, must equal the reference-generated golden

@@ -12,6 +12,7 @@ run b32 --batch 32
 run b108 --batch 108
 run b112 --batch 112
 run b216 --batch 216
+run b432 --batch 432
 run t3_c13_b36 --temporal 3 --classes 13 --batch 36
 run t3_c13_b72 --temporal 3 --classes 13 --batch 72
 run t3_c13_b8 --temporal 3 --classes 13 --batch 8
