@@ -459,6 +459,171 @@ __global__ __launch_bounds__(128 * WC, 2) void conv8_kernel(C8Params p) {
 #undef C8_DECODE
 }
 
+// =====================================================================================================================================
+// conv4: the same implicit GEMM on FOUR waves, one per SIMD, 256 x 192 tile, wave (wr, wc) owns 128 rows x 96 columns in 192 accumulator
+// registers; the K-loop of a tile is one generated assembly block (gen_gemm4.py, the "c" form: gemm4.hip's ring of three A slots + two
+// B stages, the A pieces gathered through the buffer descriptor with three vector instructions of address arithmetic each).  Single-phase
+// launches (Conv2d forward / data gradient, ConvTranspose data gradient) of plain bf16 operands whose width tiles by 192.  Same packed
+// weights, chunk table and epilogue features as conv8_kernel, and the same results bit for bit (same MFMA, same K order).
+#include "gemm4_gen.inc"
+constexpr int C4_OFF_TAB = 147456;  // 144 KiB: 3 x 32 KiB A slots, 2 x 24 KiB B stages, then the chunk table (32-word header + entries)
+constexpr int C4_TAB_MAX = 4096 - 32;
+
+__global__ __launch_bounds__(256) void conv4_kernel(C8Params p) {
+    constexpr int BM = 256, BN = 192, PITCH = 96 * 2 + 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM, ntiles = tiles_m * tiles_n;
+    // persistent, XCD-aware (as conv8_kernel): XCD x owns a contiguous tile range; the column tiles of a row tile are neighbours
+    const int nb = gridDim.x, xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int nbx = (nb >> 3) + (xcd < (nb & 7) ? 1 : 0);
+    const int qT = ntiles >> 3, rT = ntiles & 7;
+    const int tlo = xcd * qT + min(xcd, rT), tcnt = qT + (xcd < rT ? 1 : 0);
+    const int my_tiles = tcnt > jx ? (tcnt - jx + nbx - 1) / nbx : 0;
+    if (my_tiles <= 0) return;
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_char_ptr)smem;
+    int* phc = reinterpret_cast<int*>(smem + C4_OFF_TAB);
+    for (int i = tid; i < p.ktab_n + 32; i += 256) phc[i] = p.ktab[i];
+    const int nk = __builtin_amdgcn_readfirstlane(p.ktab[0]);        // K-tiles of 64 per tile (even, >= 4)
+    const int ldb2 = __builtin_amdgcn_readfirstlane(p.ktab[2]) * 2;  // packed row pitch in bytes
+    const long boff = (long)(unsigned)__builtin_amdgcn_readfirstlane(p.ktab[3]) | ((long)__builtin_amdgcn_readfirstlane(p.ktab[4]) << 32);
+    const char* bbase = (const char*)(p.b[0] + boff);
+    const int npair = (nk >> 1) - 2;
+    const unsigned abytes = p.a_bytes;
+    const char* abase = (const char*)p.a[0];
+    // lane constants of the asm blocks (gen_gemm4.py: c_setup)
+    const unsigned sc = (lane & 7) ^ ((lane >> 3) & 7);  // source chunk of this lane's LDS chunk
+    const unsigned c16 = sc << 4;
+    const unsigned swz = ((lane >> 4) ^ (lane & 7)) << 4;
+    const unsigned fa = lds_base + (wr * 128 + (lane & 15)) * 128 + swz;
+    const unsigned fb = lds_base + (wc * 96 + (lane & 15)) * 128 + swz;
+    const unsigned ldsw = lds_base + wave * 8192, ldswb = lds_base + wave * 6144;
+    const unsigned browv = wave * 48 + (lane >> 3);
+    const unsigned vtl = lds_base + C4_OFF_TAB + 128 + sc * 4;  // this lane's entry of K-tile 0
+    const int Hs = p.H * p.sm, Ws = p.W * p.sm;
+    uint32_t drop_seed = p.drop_seed;
+    if (p.drop_seed_dev) drop_seed += *p.drop_seed_dev;
+
+    // rows of A piece i of this wave: tile row wave*64 + i*8 + (lane >> 3): byte offset of its source pixel, INVERTED tap mask (bit t set:
+    // tap t falls off the image; bit 31 always set: padding chunks; all ones for rows past M)
+    auto decode_rows = [&](int bm, unsigned (&ro)[8], unsigned (&im)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = bm * BM + wave * 64 + i * 8 + (lane >> 3);
+            const int b_ = p.f_hw.div(m), rem = m - b_ * (p.H * p.W);
+            const int y = p.f_w.div(rem), x = rem - y * p.W;
+            const int sy = y * p.sm, sx = x * p.sm;
+            unsigned mk = 0;
+            if (m < p.M) {
+                for (int t = 0; t < p.nbits; ++t) {
+                    const int dy = (int)((p.ddy_code >> (2 * t)) & 3u) - 1, dx = (int)((p.ddx_code >> (2 * t)) & 3u) - 1;
+                    const bool v = ((unsigned)(sy + dy) < (unsigned)Hs) & ((unsigned)(sx + dx) < (unsigned)Ws);
+                    mk |= (v ? 1u : 0u) << t;
+                }
+            }
+            im[i] = ~mk;
+            ro[i] = m < p.M ? (unsigned)((b_ * Hs + sy) * Ws + sx) * (unsigned)(p.C * 2) : 0u;
+        }
+    };
+    __syncthreads();  // the chunk table is in LDS
+
+    unsigned a0 = 0, a1 = 32768, a2 = 65536;  // A ring (rotated by the asm blocks)
+    unsigned ro[8], im[8], ron[8], imn[8];
+    int tile = tlo + jx;
+    decode_rows(tile / tiles_n, ro, im);
+#define C4_ROWS(A, S) [ro##S##0] "v"(A##ro[0]), [ro##S##1] "v"(A##ro[1]), [ro##S##2] "v"(A##ro[2]), [ro##S##3] "v"(A##ro[3]), [ro##S##4] "v"(A##ro[4]), \
+                      [ro##S##5] "v"(A##ro[5]), [ro##S##6] "v"(A##ro[6]), [ro##S##7] "v"(A##ro[7])
+    {
+        const int bn = tile % tiles_n;
+        const char* bptr = bbase + (long)bn * BN * ldb2;
+        asm volatile(G4C_ASM_PROLOGUE ::[abase] "s"(abase), [abytes] "s"(abytes), [bptr] "s"(bptr), [ldb2] "s"(ldb2), [ldsw] "s"(ldsw),
+                     [ldswb] "s"(ldswb), [nk] "s"(nk), [a0] "s"(a0), [a1] "s"(a1), [a2] "s"(a2), [browv] "v"(browv), [c16] "v"(c16), [fa] "v"(fa),
+                     [fb] "v"(fb), [vtl] "v"(vtl), [ro0] "v"(ro[0]), [ro1] "v"(ro[1]), [ro2] "v"(ro[2]), [ro3] "v"(ro[3]), [ro4] "v"(ro[4]),
+                     [ro5] "v"(ro[5]), [ro6] "v"(ro[6]), [ro7] "v"(ro[7]), [im0] "v"(im[0]), [im1] "v"(im[1]), [im2] "v"(im[2]), [im3] "v"(im[3]),
+                     [im4] "v"(im[4]), [im5] "v"(im[5]), [im6] "v"(im[6]), [im7] "v"(im[7])
+                     : G4C_CLOBBERS);
+    }
+    for (int t = 0; t < my_tiles; ++t) {
+        const int bm = tile / tiles_n, bn = tile - bm * tiles_n;
+        const bool more = t + 1 < my_tiles;
+        const int tn = more ? tile + nbx : tile;
+        const int bm2 = tn / tiles_n, bn2 = tn - bm2 * tiles_n;
+        decode_rows(bm2, ron, imn);
+        if (!more) {  // no next tile: the last two DMA rounds fill zeros
+#pragma unroll
+            for (int i = 0; i < 8; ++i) imn[i] = 0xffffffffu;
+        }
+        const char* bptr = bbase + (long)bn * BN * ldb2 + 256;  // K-tile 2 (0 and 1 are in flight)
+        const char* bnext = bbase + (long)bn2 * BN * ldb2;
+        asm volatile(G4C_ASM_TILE
+                     : [a0] "+s"(a0), [a1] "+s"(a1), [a2] "+s"(a2)
+                     : [abase] "s"(abase), [abytes] "s"(abytes), [bptr] "s"(bptr), [bnext] "s"(bnext), [ldb2] "s"(ldb2), [ldsw] "s"(ldsw),
+                       [ldswb] "s"(ldswb), [nk] "s"(nk), [npair] "s"(npair), [browv] "v"(browv), [c16] "v"(c16), [fa] "v"(fa), [fb] "v"(fb),
+                       [vtl] "v"(vtl), [ro0] "v"(ro[0]), [ro1] "v"(ro[1]), [ro2] "v"(ro[2]), [ro3] "v"(ro[3]), [ro4] "v"(ro[4]), [ro5] "v"(ro[5]),
+                       [ro6] "v"(ro[6]), [ro7] "v"(ro[7]), [im0] "v"(im[0]), [im1] "v"(im[1]), [im2] "v"(im[2]), [im3] "v"(im[3]), [im4] "v"(im[4]),
+                       [im5] "v"(im[5]), [im6] "v"(im[6]), [im7] "v"(im[7]), [ron0] "v"(ron[0]), [ron1] "v"(ron[1]), [ron2] "v"(ron[2]),
+                       [ron3] "v"(ron[3]), [ron4] "v"(ron[4]), [ron5] "v"(ron[5]), [ron6] "v"(ron[6]), [ron7] "v"(ron[7]), [imn0] "v"(imn[0]),
+                       [imn1] "v"(imn[1]), [imn2] "v"(imn[2]), [imn3] "v"(imn[3]), [imn4] "v"(imn[4]), [imn5] "v"(imn[5]), [imn6] "v"(imn[6]),
+                       [imn7] "v"(imn[7])
+                     : G4C_CLOBBERS);
+        // ================= epilogue (the next tile's K-tiles 0 and 1 are in flight) =================
+        // accumulator block (mi, ni) of this lane: out[m = mi 16 + (lane & 15)][n = ni 16 + 4 (lane >> 4) .. + 3] of the wave's 128 x 96
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        char* st = smem + a2 + wave * 8192;  // the A slot this tile's last K-tile has left
+        const int erow = lane_e & 15, eq = lane_e >> 4;
+        const int n0 = bn * BN + wc * 96, mw = bm * BM + wr * 128;
+        f32x4 bias4[6];
+#pragma unroll
+        for (int ni = 0; ni < 6; ++ni) {
+            bias4[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+                const float4 b_ = *reinterpret_cast<const float4*>(p.bias + n0 + ni * 16 + 4 * eq);
+                bias4[ni] = f32x4{b_.x, b_.y, b_.z, b_.w};
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            f32x4 tt[8];
+            g4_acc_row(mi, tt);
+            const int m0 = mw + mi * 16;
+#pragma unroll
+            for (int ni = 0; ni < 6; ++ni) {
+                const f32x4 a = tt[ni] + bias4[ni];
+                float v[4] = {a[0], a[1], a[2], a[3]};
+                if (p.scale) {  // eval-mode BatchNorm + ReLU (inference only)
+                    const float4 s4 = *reinterpret_cast<const float4*>(p.scale + n0 + ni * 16 + 4 * eq);
+                    const float4 t4 = *reinterpret_cast<const float4*>(p.shift + n0 + ni * 16 + 4 * eq);
+                    v[0] = fmaxf(v[0] * s4.x + t4.x, 0.f), v[1] = fmaxf(v[1] * s4.y + t4.y, 0.f);
+                    v[2] = fmaxf(v[2] * s4.z + t4.z, 0.f), v[3] = fmaxf(v[3] * s4.w + t4.w, 0.f);
+                }
+                if (p.drop_thresh) {
+                    float mk[4];
+                    dropout_scale4(drop_seed, (uint32_t)((long)(m0 + erow) * p.ldo + n0 + ni * 16 + 4 * eq), p.drop_thresh, p.drop_inv, mk);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] *= mk[j];
+                }
+                uint2 po;
+                po.x = pack_bf2(v[0], v[1]), po.y = pack_bf2(v[2], v[3]);
+                *reinterpret_cast<uint2*>(st + erow * PITCH + ni * 32 + eq * 8) = po;
+            }
+#pragma unroll
+            for (int itu = 0; itu < 3; ++itu) {  // 16 rows x 12 sixteen-byte units
+                const int u = itu * 64 + lane_e;
+                const int r = u / 12, ch = u - r * 12;
+                const uint4 ux = *reinterpret_cast<const uint4*>(st + r * PITCH + ch * 16);
+                const int m = m0 + r;
+                if (m < p.M) *reinterpret_cast<uint4*>(p.out_hi + (size_t)m * p.ldo + n0 + ch * 8) = ux;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ro[i] = ron[i], im[i] = imn[i];
+        tile = tn;
+    }
+}
+
 // ---- weight packing + chunk table (one launch per convolution call) -------------------------------------------------------------
 struct C8Plan {
     int nphase;
@@ -743,6 +908,29 @@ int ig_conv8(int kind, int sign, const void* x_hi, const void* x_lo, const void*
     p.drop_seed = drop_seed, p.drop_seed_dev = drop_seed_dev;
     p.drop_thresh = ig_drop_thresh16(drop_p);
     p.drop_inv = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    {   // conv4_kernel (4 waves, generated K-loop): single-phase plain-bf16 launches whose width tiles by 192.  IG_GEMM4 = 0: off, 2: every
+        // covered shape (tests); default: where conv8 would have taken its own 256 x 192 instance
+        const char* e4 = getenv("IG_GEMM4");
+        const int g4 = e4 ? atoi(e4) : 1;
+        const long nt4 = (M + 255) / 256 * (N / 192);
+        const bool ok4 = g4 && !w_lo && pl.nphase == 1 && N % 192 == 0 && tent <= C4_TAB_MAX && a_bytes < 2147483648.0 - 16777216.0 &&
+                         pl.kpad[0] / 64 >= 4 && nt4 < (1L << 30);
+        if (ok4 && (g4 == 2 || (best == 1 && nt4 >= slots - slots / 8))) {
+            static bool attr4_done = false;
+            if (!attr4_done) {
+                if (hipFuncSetAttribute((const void*)conv4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                    ig_set_error("conv4: could not reserve 160 KiB of LDS");
+                    return IG_ERR_HIP;
+                }
+                attr4_done = true;
+            }
+            const int grid4 = ig_tile_grid((int)nt4, 1);
+            ig_note_kernel("conv4_kernel");
+            ig_note_grid(grid4);
+            hipLaunchKernelGGL(conv4_kernel, dim3(grid4), dim3(256), C4_OFF_TAB + (tent + 32) * 4, st, p);
+            return ig_check_launch("conv4");
+        }
+    }
     const int grid = ig_tile_grid((int)ntiles, 1);
     switch (best) {
         case 0: return c8_launch_seg<4, 4, 2, 2>(p, grid, st);

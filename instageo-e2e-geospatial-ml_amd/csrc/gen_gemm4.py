@@ -786,6 +786,203 @@ def wp_clobbers():
     return ", ".join(c)
 
 
+# =====================================================================================================================================
+# CONVOLUTION form (conv4_kernel in conv8.hip: the decode head's 3 x 3 convolutions as implicit GEMMs on a 256 x 192 tile, wave (wr, wc) owns
+# 128 rows x 96 columns = 8 x 6 accumulator blocks).  The loop is the forward form's with two changes:
+#   * A is GATHERED (conv8.hip): piece i of a wave is `buffer_load_dwordx4 v_off, s[desc], 0 offen lds` with
+#         v_off = rowoff_i + delta(K chunk) + (invalid ? 2^31 : 0)
+#     where (delta, mask bit) of the lane's 16-byte K chunk come from ONE table entry per lane and K-tile (read from LDS one iteration ahead),
+#     invalid = bit `mask bit` of the row's INVERTED tap mask, and an offset beyond the descriptor's bound makes the hardware write zeros:
+#     three vector instructions per piece (v_bfe_u32, v_lshl_add_u32, v_add_u32) woven in front of its issue.  The table index runs
+#     cyclically over the nk K-tiles of a tile (every tile of a launch has the same K), so it simply continues across tile boundaries; the
+#     row offsets / masks of the NEXT tile take over for the last pair.
+#   * B (packed weights [N][Kpad]) has 192 rows: 6 pieces per wave and K-tile, stages of 24 KiB at 96 / 120 KiB; the chunk table sits behind
+#     them at 144 KiB.
+CV_E = 103            # table entry of the K-tile whose A pieces are issued next
+CV_O = 104            # v104..v111: gathered offsets of the 8 A pieces
+CV_OFFB = 112         # v112..v117: DMA offsets of the 6 B pieces
+CV_TA = 118           # table read address
+CS_RSRC = 84          # s[84:87]: buffer descriptor of the gathered tensor
+CS_TOFF, CS_LEFT, CS_NK = 88, 89, 90   # table byte offset of the next entry to read, entries left before it wraps, K-tiles per tile
+CS_LDSWB = 91         # LDS-DMA destination base of this wave's B pieces (48 rows per wave: wave * 6 KiB)
+CS_LO, CS_HI = 70, 91
+C_NI = 6
+CB_BASE, CB_STAGE = 98304, 24576
+
+
+def c_fbase_b(stage, s):
+    return f"v{V_FB + 2 * stage + s}"
+
+
+def c_reads(bstage, s, q):
+    out = [f"ds_read_b128 {afrag(q, i)}, v{V_AC} offset:{i * 2048}" for i in range(8)]
+    out += [f"ds_read_b128 {bfrag(q, i)}, {c_fbase_b(bstage, s)} offset:{i * 2048}" for i in range(C_NI)]
+    return out
+
+
+def c_dmas_a(next_tile):
+    """8 x (3 VALU, M0 write, issue): v94 = delta bytes, v95 = mask bit of this K-tile's entry (set at the top of the half)"""
+    sfx = "n" if next_tile else ""
+    out = []
+    for i in range(8):
+        pre = [f"v_bfe_u32 v{CV_O + i}, %[im{sfx}{i}], v{V_TMP + 1}, 1",
+               f"v_lshl_add_u32 v{CV_O + i}, v{CV_O + i}, 31, v{V_TMP}",
+               f"v_add_u32 v{CV_O + i}, v{CV_O + i}, %[ro{sfx}{i}]"]
+        out.append((pre, f"s_add_u32 m0, s{S_ADST}, {i * 1024}", f"buffer_load_dwordx4 v{CV_O + i}, s[{CS_RSRC}:{CS_RSRC + 3}], 0 offen lds"))
+    return out
+
+
+def c_dmas_b(bstage):
+    return [([], f"s_add_u32 m0, s{CS_LDSWB}, {CB_BASE + bstage * CB_STAGE + i * 1024}", f"global_load_lds_dwordx4 v{CV_OFFB + i}, s[{S_BPTR}:{S_BPTR + 1}]")
+            for i in range(C_NI)]
+
+
+def c_half(st, q, first, rd, dm, tail, cfg):
+    """48 MFMAs on set q; reads every 3rd MFMA; DMA pieces (with their address arithmetic in front) every 5th from MFMA 3; `tail` behind MFMA 40"""
+    n = 8 * C_NI
+    extra = {j: [] for j in range(n)}
+    if cfg.get("abl_rd"):
+        rd = []
+    if cfg.get("abl_dma"):
+        dm = []
+    for k, r in enumerate(rd):
+        extra[min(n - 1, cfg["c_rd_at"] + k * cfg["c_rd_every"])].append(r)
+    for k, (pre, m0w, ld) in enumerate(dm):
+        j = min(n - 2, cfg["c_dm_at"] + k * cfg["c_dm_every"])
+        extra[j - 1].extend(pre)
+        extra[j].append(m0w)
+        extra[j + 1].insert(0, ld)
+    extra[min(n - 1, 40)].extend(tail)
+    j = 0
+    for ni in range(C_NI):
+        for mi in range(8):
+            c = "0" if first else acc(mi, ni)
+            st.e(f"v_mfma_f32_16x16x32_bf16 {acc(mi, ni)}, {bfrag(q, ni)}, {afrag(q, mi)}, {c}")
+            for x in extra[j]:
+                st.e(x)
+            j += 1
+
+
+def c_entry_decode(st):
+    st.e(f"v_ashrrev_i32 v{V_TMP}, 8, v{CV_E}")          # displacement in 16-byte units (signed)
+    st.e(f"v_lshlrev_b32 v{V_TMP}, 4, v{V_TMP}")
+    st.e(f"v_and_b32 v{V_TMP + 1}, 31, v{CV_E}")          # bit of the row's inverted tap mask (31: padding chunk, always invalid)
+
+
+def c_table_next():
+    """advance the cyclic table offset and read the entry of the K-tile whose A pieces the NEXT iteration issues"""
+    return [f"s_add_u32 s{CS_TOFF}, s{CS_TOFF}, 32", f"s_sub_u32 s{CS_LEFT}, s{CS_LEFT}, 1", f"s_cmp_eq_u32 s{CS_LEFT}, 0",
+            f"s_cselect_b32 s{CS_TOFF}, 0, s{CS_TOFF}", f"s_cselect_b32 s{CS_LEFT}, s{CS_NK}, s{CS_LEFT}",
+            f"v_add_u32 v{CV_TA}, s{CS_TOFF}, %[vtl]", f"ds_read_b32 v{CV_E}, v{CV_TA}"]
+
+
+def c_iteration(st, p, first, next_tile, cfg):
+    st.e(f"v_add_u32 v{V_AC}, s{S_A0}, v{V_FA + 1}")
+    st.e(f"s_add_u32 s{S_ADST}, s{S_LDSW}, s{S_A2}")
+    c_entry_decode(st)
+    c_half(st, 0, first, c_reads(p, 1, 1), c_dmas_a(next_tile), [], cfg)
+    st.e("s_waitcnt lgkmcnt(0)")
+    if not cfg.get("abl_vmw"):
+        st.e("s_waitcnt vmcnt(8)")
+    if not cfg.get("abl_bar"):
+        st.e("s_barrier")
+    st.e(f"v_add_u32 v{V_AC}, s{S_A1}, v{V_FA}")
+    c_half(st, 1, False, c_reads(p ^ 1, 0, 0), c_dmas_b(p), c_table_next(), cfg)
+    for a in advance(S_BPTR):
+        st.e(a)
+    st.e(f"s_mov_b32 s{S_T}, s{S_A0}")
+    st.e(f"s_mov_b32 s{S_A0}, s{S_A1}")
+    st.e(f"s_mov_b32 s{S_A1}, s{S_A2}")
+    st.e(f"s_mov_b32 s{S_A2}, s{S_T}")
+    st.e("s_waitcnt lgkmcnt(0)")
+
+
+def c_setup(st):
+    for i in range(C_NI):
+        st.e(f"v_add_u32 v{V_TMP}, {8 * i}, %[browv]")
+        st.e(f"v_mad_u32_u24 v{CV_OFFB + i}, v{V_TMP}, %[ldb2], %[c16]")
+    st.e(f"v_mov_b32 v{V_FA}, %[fa]")
+    st.e(f"v_xor_b32 v{V_FA + 1}, 64, %[fa]")
+    for b in (0, 1):
+        st.e(f"v_add_u32 {c_fbase_b(b, 0)}, {CB_BASE + b * CB_STAGE}, %[fb]")
+        st.e(f"v_xor_b32 {c_fbase_b(b, 1)}, 64, {c_fbase_b(b, 0)}")
+    st.e(f"s_mov_b32 s{S_LDSW}, %[ldsw]")
+    st.e(f"s_mov_b32 s{S_A0}, %[a0]")
+    st.e(f"s_mov_b32 s{S_A1}, %[a1]")
+    st.e(f"s_mov_b32 s{S_A2}, %[a2]")
+    st.e(f"s_mov_b64 s[{CS_RSRC}:{CS_RSRC + 1}], %[abase]")
+    st.e(f"s_mov_b32 s{CS_RSRC + 2}, %[abytes]")
+    st.e(f"s_mov_b32 s{CS_RSRC + 3}, 0x00020000")
+    st.e(f"s_mov_b32 s{CS_NK}, %[nk]")
+    st.e(f"s_mov_b32 s{CS_LDSWB}, %[ldswb]")
+
+
+def gen_c_prologue():
+    """first tile of a workgroup: K-tiles 0 and 1 (table entries 0 and 1)"""
+    st = Stream()
+    c_setup(st)
+    st.e(f"s_mov_b64 s[{S_BPTR}:{S_BPTR + 1}], %[bptr]")
+    for k, slot in enumerate((S_A0, S_A1)):
+        st.e(f"ds_read_b32 v{CV_E}, %[vtl] offset:{32 * k}")
+        st.e("s_waitcnt lgkmcnt(0)")
+        c_entry_decode(st)
+        st.e(f"s_add_u32 s{S_ADST}, s{S_LDSW}, s{slot}")
+        for pre, m0w, ld in c_dmas_a(False) + c_dmas_b(k):
+            for x in pre:
+                st.e(x)
+            st.e(m0w)
+            st.e("s_nop 0")
+            st.e(ld)
+        for a in advance(S_BPTR):
+            st.e(a)
+    return st.text()
+
+
+def gen_c_tile(cfg):
+    """one tile: bptr on its K-tile 2, bnext on the next tile's K-tile 0; ro / im = this tile's rows, ron / imn = the next tile's"""
+    st = Stream()
+    c_setup(st)
+    st.e(f"s_mov_b64 s[{S_BPTR}:{S_BPTR + 1}], %[bptr]")
+    st.e(f"s_mov_b32 s{S_CNT}, %[npair]")
+    st.e(f"s_mov_b32 s{CS_TOFF}, 64")                 # the first iteration issues K-tile 2
+    st.e(f"s_sub_u32 s{CS_LEFT}, s{CS_NK}, 2")
+    st.e(f"ds_read_b32 v{CV_E}, %[vtl] offset:64")
+    st.e("s_waitcnt vmcnt(0)")
+    st.e("s_barrier")
+    st.e(f"v_add_u32 v{V_AC}, s{S_A0}, v{V_FA}")
+    for r in c_reads(0, 0, 0):
+        st.e(r)
+    st.e("s_waitcnt lgkmcnt(0)")
+    c_iteration(st, 0, True, False, cfg)
+    c_iteration(st, 1, False, False, cfg)
+    st.e(f"s_cmp_eq_u32 s{S_CNT}, 0")
+    st.e("s_cbranch_scc1 L_last_%=")
+    st.e("L_loop_%=:")
+    c_iteration(st, 0, False, False, cfg)
+    c_iteration(st, 1, False, False, cfg)
+    st.e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
+    st.e(f"s_cmp_lg_u32 s{S_CNT}, 0")
+    st.e("s_cbranch_scc1 L_loop_%=")
+    st.e("L_last_%=:")
+    st.e(f"s_mov_b64 s[{S_BPTR}:{S_BPTR + 1}], %[bnext]")
+    c_iteration(st, 0, False, True, cfg)
+    c_iteration(st, 1, False, True, cfg)
+    st.e(f"s_mov_b32 %[a0], s{S_A0}")
+    st.e(f"s_mov_b32 %[a1], s{S_A1}")
+    st.e(f"s_mov_b32 %[a2], s{S_A2}")
+    st.e("s_nop 15")
+    st.e("s_nop 15")
+    return st.text()
+
+
+def c_clobbers():
+    c = ['"memory"', '"scc"', '"m0"']
+    c += [f'"a{i}"' for i in range(256)]
+    c += [f'"v{i}"' for i in range(V_LO, V_HI + 1)]
+    c += [f'"s{i}"' for i in range(CS_LO, CS_HI + 1)]
+    return ", ".join(c)
+
+
 def clobbers():
     c = ['"memory"', '"scc"', '"m0"']
     c += [f'"a{i}"' for i in range(256)]
@@ -815,7 +1012,8 @@ def gen_readout():
 
 def main():
     cfg = {"rd_every": 3, "rd_at": 0, "dm_every": 8, "dm_at": 3, "order": "ni", "skew": 0,
-           "w_rd_at": 0, "w_rd_num": 2, "w_rd_den": 1, "w_dm_at": 3, "w_dm_every": 8, "wp_rd_num": 1, "wp_rd_den": 1}
+           "w_rd_at": 0, "w_rd_num": 2, "w_rd_den": 1, "w_dm_at": 3, "w_dm_every": 8, "wp_rd_num": 1, "wp_rd_den": 1,
+           "c_rd_at": 0, "c_rd_every": 3, "c_dm_at": 3, "c_dm_every": 5}
     out_path = "gemm4_gen.inc"
     for a in sys.argv[1:]:
         if "=" in a:
@@ -838,6 +1036,9 @@ def main():
         f.write("#define G4WP_ASM_PROLOGUE \\\n" + gen_wp_prologue().replace("\n", " \\\n") + "\n\n")
         f.write("#define G4WP_ASM_SEG \\\n" + gen_wp_seg(cfg).replace("\n", " \\\n") + "\n\n")
         f.write("#define G4WP_CLOBBERS " + wp_clobbers() + "\n\n")
+        f.write("#define G4C_ASM_PROLOGUE \\\n" + gen_c_prologue().replace("\n", " \\\n") + "\n\n")
+        f.write("#define G4C_ASM_TILE \\\n" + gen_c_tile(cfg).replace("\n", " \\\n") + "\n\n")
+        f.write("#define G4C_CLOBBERS " + c_clobbers() + "\n\n")
         f.write(gen_readout() + "\n")
 
 
