@@ -462,8 +462,8 @@ __global__ __launch_bounds__(128 * WC, 2) void conv8_kernel(C8Params p) {
 // =====================================================================================================================================
 // conv4: the same implicit GEMM on FOUR waves, one per SIMD, 256 x 192 tile, wave (wr, wc) owns 128 rows x 96 columns in 192 accumulator
 // registers; the K-loop of a tile is one generated assembly block (gen_gemm4.py, the "c" form: gemm4.hip's ring of three A slots + two
-// B stages, the A pieces gathered through the buffer descriptor with three vector instructions of address arithmetic each).  Single-phase
-// launches (Conv2d forward / data gradient, ConvTranspose data gradient) of plain bf16 operands whose width tiles by 192.  Same packed
+// B stages, the A pieces gathered through the buffer descriptor with three vector instructions of address arithmetic each).  Conv2d forward /
+// data gradient, ConvTranspose forward (four phases) / data gradient, plain bf16 operands, widths that tile by 192.  Same packed
 // weights, chunk table and epilogue features as conv8_kernel, and the same results bit for bit (same MFMA, same K order).
 #include "gemm4_gen.inc"
 constexpr int C4_OFF_TAB = 147456;  // 144 KiB: 3 x 32 KiB A slots, 2 x 24 KiB B stages, then the chunk table (32-word header + entries)
@@ -475,22 +475,17 @@ __global__ __launch_bounds__(256) void conv4_kernel(C8Params p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
-    const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM, ntiles = tiles_m * tiles_n;
-    // persistent, XCD-aware (as conv8_kernel): XCD x owns a contiguous tile range; the column tiles of a row tile are neighbours
+    const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM, tpb = tiles_n * p.nphase, ntiles = tiles_m * tpb;
+    // persistent, XCD-aware (as conv8_kernel): XCD x owns a contiguous tile range; the column tiles and phases of a row tile are neighbours
     const int nb = gridDim.x, xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-    const int nbx = (nb >> 3) + (xcd < (nb & 7) ? 1 : 0);
+    const int nbx = (nb >> 3) + (xcd < (nb & 7) ? 1 : 0), nbx_nom = max(nb >> 3, 1);
     const int qT = ntiles >> 3, rT = ntiles & 7;
     const int tlo = xcd * qT + min(xcd, rT), tcnt = qT + (xcd < rT ? 1 : 0);
     const int my_tiles = tcnt > jx ? (tcnt - jx + nbx - 1) / nbx : 0;
     if (my_tiles <= 0) return;
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_char_ptr)smem;
-    int* phc = reinterpret_cast<int*>(smem + C4_OFF_TAB);
+    int* phc = reinterpret_cast<int*>(smem + C4_OFF_TAB);  // 32-word header of per-phase constants, then the chunk table
     for (int i = tid; i < p.ktab_n + 32; i += 256) phc[i] = p.ktab[i];
-    const int nk = __builtin_amdgcn_readfirstlane(p.ktab[0]);        // K-tiles of 64 per tile (even, >= 4)
-    const int ldb2 = __builtin_amdgcn_readfirstlane(p.ktab[2]) * 2;  // packed row pitch in bytes
-    const long boff = (long)(unsigned)__builtin_amdgcn_readfirstlane(p.ktab[3]) | ((long)__builtin_amdgcn_readfirstlane(p.ktab[4]) << 32);
-    const char* bbase = (const char*)(p.b[0] + boff);
-    const int npair = (nk >> 1) - 2;
     const unsigned abytes = p.a_bytes;
     const char* abase = (const char*)p.a[0];
     // lane constants of the asm blocks (gen_gemm4.py: c_setup)
@@ -501,11 +496,34 @@ __global__ __launch_bounds__(256) void conv4_kernel(C8Params p) {
     const unsigned fb = lds_base + (wc * 96 + (lane & 15)) * 128 + swz;
     const unsigned ldsw = lds_base + wave * 8192, ldswb = lds_base + wave * 6144;
     const unsigned browv = wave * 48 + (lane >> 3);
-    const unsigned vtl = lds_base + C4_OFF_TAB + 128 + sc * 4;  // this lane's entry of K-tile 0
+    const unsigned vtl = lds_base + C4_OFF_TAB + 128 + sc * 4;  // this lane's entry of table position 0
     const int Hs = p.H * p.sm, Ws = p.W * p.sm;
     uint32_t drop_seed = p.drop_seed;
     if (p.drop_seed_dev) drop_seed += *p.drop_seed_dev;
 
+    // tile t of the list -> (row tile, phase, column tile); the phase of slot s rotates with the row tile (conv8_kernel's order)
+    auto decode_tile = [&](int t, int& bm, int& ph, int& bn) {
+        bm = t / tpb;
+        const int r = t - bm * tpb, s_ = r / tiles_n;
+        bn = r - s_ * tiles_n;
+        ph = p.nphase == 1 ? 0 : ((s_ + (bm * tpb) / nbx_nom) & 3);
+    };
+    // per-phase constants: K-tiles, byte offset of the phase's table, packed row pitch in bytes, the phase's packed block
+    struct PhaseK { int nk, toff4, ldb2; const char* b; };
+    auto phase_k = [&](int ph) {
+        PhaseK k;
+        k.nk = __builtin_amdgcn_readfirstlane(phc[ph * 8]);
+        k.toff4 = __builtin_amdgcn_readfirstlane(phc[ph * 8 + 1]) * 4;
+        k.ldb2 = __builtin_amdgcn_readfirstlane(phc[ph * 8 + 2]) * 2;
+        const long bo = (long)(unsigned)__builtin_amdgcn_readfirstlane(phc[ph * 8 + 3]) | ((long)__builtin_amdgcn_readfirstlane(phc[ph * 8 + 4]) << 32);
+        k.b = (const char*)(p.b[0] + bo);
+        return k;
+    };
+    auto uni = [](const char* q) {  // a wave-uniform pointer the compiler can keep in scalar registers (the asm blocks take it as "s")
+        const uint64_t v = (uint64_t)q;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+        return (const char*)(((uint64_t)hi << 32) | lo);
+    };
     // rows of A piece i of this wave: tile row wave*64 + i*8 + (lane >> 3): byte offset of its source pixel, INVERTED tap mask (bit t set:
     // tap t falls off the image; bit 31 always set: padding chunks; all ones for rows past M)
     auto decode_rows = [&](int bm, unsigned (&ro)[8], unsigned (&im)[8]) {
@@ -532,41 +550,43 @@ __global__ __launch_bounds__(256) void conv4_kernel(C8Params p) {
     unsigned a0 = 0, a1 = 32768, a2 = 65536;  // A ring (rotated by the asm blocks)
     unsigned ro[8], im[8], ron[8], imn[8];
     int tile = tlo + jx;
-    decode_rows(tile / tiles_n, ro, im);
-#define C4_ROWS(A, S) [ro##S##0] "v"(A##ro[0]), [ro##S##1] "v"(A##ro[1]), [ro##S##2] "v"(A##ro[2]), [ro##S##3] "v"(A##ro[3]), [ro##S##4] "v"(A##ro[4]), \
-                      [ro##S##5] "v"(A##ro[5]), [ro##S##6] "v"(A##ro[6]), [ro##S##7] "v"(A##ro[7])
+    int c_bm, c_ph, c_bn;
+    decode_tile(tile, c_bm, c_ph, c_bn);
+    decode_rows(c_bm, ro, im);
     {
-        const int bn = tile % tiles_n;
-        const char* bptr = bbase + (long)bn * BN * ldb2;
-        asm volatile(G4C_ASM_PROLOGUE ::[abase] "s"(abase), [abytes] "s"(abytes), [bptr] "s"(bptr), [ldb2] "s"(ldb2), [ldsw] "s"(ldsw),
-                     [ldswb] "s"(ldswb), [nk] "s"(nk), [a0] "s"(a0), [a1] "s"(a1), [a2] "s"(a2), [browv] "v"(browv), [c16] "v"(c16), [fa] "v"(fa),
-                     [fb] "v"(fb), [vtl] "v"(vtl), [ro0] "v"(ro[0]), [ro1] "v"(ro[1]), [ro2] "v"(ro[2]), [ro3] "v"(ro[3]), [ro4] "v"(ro[4]),
-                     [ro5] "v"(ro[5]), [ro6] "v"(ro[6]), [ro7] "v"(ro[7]), [im0] "v"(im[0]), [im1] "v"(im[1]), [im2] "v"(im[2]), [im3] "v"(im[3]),
-                     [im4] "v"(im[4]), [im5] "v"(im[5]), [im6] "v"(im[6]), [im7] "v"(im[7])
+        const PhaseK k = phase_k(c_ph);
+        const char* bptr = uni(k.b + (long)c_bn * BN * k.ldb2);
+        asm volatile(G4C_ASM_PROLOGUE ::[abase] "s"(abase), [abytes] "s"(abytes), [bptr] "s"(bptr), [ldb2] "s"(k.ldb2), [ldsw] "s"(ldsw),
+                     [ldswb] "s"(ldswb), [nk] "s"(k.nk), [toff4] "s"(k.toff4), [a0] "s"(a0), [a1] "s"(a1), [a2] "s"(a2), [browv] "v"(browv),
+                     [c16] "v"(c16), [fa] "v"(fa), [fb] "v"(fb), [vtl] "v"(vtl), [ro0] "v"(ro[0]), [ro1] "v"(ro[1]), [ro2] "v"(ro[2]), [ro3] "v"(ro[3]),
+                     [ro4] "v"(ro[4]), [ro5] "v"(ro[5]), [ro6] "v"(ro[6]), [ro7] "v"(ro[7]), [im0] "v"(im[0]), [im1] "v"(im[1]), [im2] "v"(im[2]),
+                     [im3] "v"(im[3]), [im4] "v"(im[4]), [im5] "v"(im[5]), [im6] "v"(im[6]), [im7] "v"(im[7])
                      : G4C_CLOBBERS);
     }
     for (int t = 0; t < my_tiles; ++t) {
-        const int bm = tile / tiles_n, bn = tile - bm * tiles_n;
+        const int bm = c_bm, ph = c_ph, bn = c_bn;
         const bool more = t + 1 < my_tiles;
         const int tn = more ? tile + nbx : tile;
-        const int bm2 = tn / tiles_n, bn2 = tn - bm2 * tiles_n;
-        decode_rows(bm2, ron, imn);
+        decode_tile(tn, c_bm, c_ph, c_bn);
+        decode_rows(c_bm, ron, imn);
         if (!more) {  // no next tile: the last two DMA rounds fill zeros
 #pragma unroll
             for (int i = 0; i < 8; ++i) imn[i] = 0xffffffffu;
         }
-        const char* bptr = bbase + (long)bn * BN * ldb2 + 256;  // K-tile 2 (0 and 1 are in flight)
-        const char* bnext = bbase + (long)bn2 * BN * ldb2;
+        const PhaseK k = phase_k(ph), kn = phase_k(c_ph);
+        const char* bptr = uni(k.b + (long)bn * BN * k.ldb2 + 256);  // K-tile 2 (0 and 1 are in flight)
+        const char* bnext = uni(kn.b + (long)c_bn * BN * kn.ldb2);
+        const int npair = (k.nk >> 1) - 2;
         asm volatile(G4C_ASM_TILE
                      : [a0] "+s"(a0), [a1] "+s"(a1), [a2] "+s"(a2)
-                     : [abase] "s"(abase), [abytes] "s"(abytes), [bptr] "s"(bptr), [bnext] "s"(bnext), [ldb2] "s"(ldb2), [ldsw] "s"(ldsw),
-                       [ldswb] "s"(ldswb), [nk] "s"(nk), [npair] "s"(npair), [browv] "v"(browv), [c16] "v"(c16), [fa] "v"(fa), [fb] "v"(fb),
-                       [vtl] "v"(vtl), [ro0] "v"(ro[0]), [ro1] "v"(ro[1]), [ro2] "v"(ro[2]), [ro3] "v"(ro[3]), [ro4] "v"(ro[4]), [ro5] "v"(ro[5]),
-                       [ro6] "v"(ro[6]), [ro7] "v"(ro[7]), [im0] "v"(im[0]), [im1] "v"(im[1]), [im2] "v"(im[2]), [im3] "v"(im[3]), [im4] "v"(im[4]),
-                       [im5] "v"(im[5]), [im6] "v"(im[6]), [im7] "v"(im[7]), [ron0] "v"(ron[0]), [ron1] "v"(ron[1]), [ron2] "v"(ron[2]),
-                       [ron3] "v"(ron[3]), [ron4] "v"(ron[4]), [ron5] "v"(ron[5]), [ron6] "v"(ron[6]), [ron7] "v"(ron[7]), [imn0] "v"(imn[0]),
-                       [imn1] "v"(imn[1]), [imn2] "v"(imn[2]), [imn3] "v"(imn[3]), [imn4] "v"(imn[4]), [imn5] "v"(imn[5]), [imn6] "v"(imn[6]),
-                       [imn7] "v"(imn[7])
+                     : [abase] "s"(abase), [abytes] "s"(abytes), [bptr] "s"(bptr), [bnext] "s"(bnext), [ldb2] "s"(k.ldb2), [ldb2n] "s"(kn.ldb2),
+                       [ldsw] "s"(ldsw), [ldswb] "s"(ldswb), [nk] "s"(k.nk), [toff4] "s"(k.toff4), [toffn4] "s"(kn.toff4), [npair] "s"(npair),
+                       [browv] "v"(browv), [c16] "v"(c16), [fa] "v"(fa), [fb] "v"(fb), [vtl] "v"(vtl), [ro0] "v"(ro[0]), [ro1] "v"(ro[1]),
+                       [ro2] "v"(ro[2]), [ro3] "v"(ro[3]), [ro4] "v"(ro[4]), [ro5] "v"(ro[5]), [ro6] "v"(ro[6]), [ro7] "v"(ro[7]), [im0] "v"(im[0]),
+                       [im1] "v"(im[1]), [im2] "v"(im[2]), [im3] "v"(im[3]), [im4] "v"(im[4]), [im5] "v"(im[5]), [im6] "v"(im[6]), [im7] "v"(im[7]),
+                       [ron0] "v"(ron[0]), [ron1] "v"(ron[1]), [ron2] "v"(ron[2]), [ron3] "v"(ron[3]), [ron4] "v"(ron[4]), [ron5] "v"(ron[5]),
+                       [ron6] "v"(ron[6]), [ron7] "v"(ron[7]), [imn0] "v"(imn[0]), [imn1] "v"(imn[1]), [imn2] "v"(imn[2]), [imn3] "v"(imn[3]),
+                       [imn4] "v"(imn[4]), [imn5] "v"(imn[5]), [imn6] "v"(imn[6]), [imn7] "v"(imn[7])
                      : G4C_CLOBBERS);
         // ================= epilogue (the next tile's K-tiles 0 and 1 are in flight) =================
         // accumulator block (mi, ni) of this lane: out[m = mi 16 + (lane & 15)][n = ni 16 + 4 (lane >> 4) .. + 3] of the wave's 128 x 96
@@ -575,6 +595,14 @@ __global__ __launch_bounds__(256) void conv4_kernel(C8Params p) {
         char* st = smem + a2 + wave * 8192;  // the A slot this tile's last K-tile has left
         const int erow = lane_e & 15, eq = lane_e >> 4;
         const int n0 = bn * BN + wc * 96, mw = bm * BM + wr * 128;
+        const int py = ph >> 1, px = ph & 1;
+        // output row of tile row m: identity, or the sub-pixel phase map of the ConvTranspose forward
+        auto out_row = [&](int m) -> long {
+            if (!p.phase_map) return (long)m;
+            const int b_ = p.f_hw.div(m), rem_ = m - b_ * (p.H * p.W);
+            const int y_ = p.f_w.div(rem_), x_ = rem_ - y_ * p.W;
+            return ((long)(b_ * 2 * p.H + 2 * y_ + py)) * (2 * p.W) + 2 * x_ + px;
+        };
         f32x4 bias4[6];
 #pragma unroll
         for (int ni = 0; ni < 6; ++ni) {
@@ -589,6 +617,7 @@ __global__ __launch_bounds__(256) void conv4_kernel(C8Params p) {
             f32x4 tt[8];
             g4_acc_row(mi, tt);
             const int m0 = mw + mi * 16;
+            const long orow_e = p.drop_thresh ? out_row(m0 + erow) : 0L;
 #pragma unroll
             for (int ni = 0; ni < 6; ++ni) {
                 const f32x4 a = tt[ni] + bias4[ni];
@@ -601,7 +630,7 @@ __global__ __launch_bounds__(256) void conv4_kernel(C8Params p) {
                 }
                 if (p.drop_thresh) {
                     float mk[4];
-                    dropout_scale4(drop_seed, (uint32_t)((long)(m0 + erow) * p.ldo + n0 + ni * 16 + 4 * eq), p.drop_thresh, p.drop_inv, mk);
+                    dropout_scale4(drop_seed, (uint32_t)(orow_e * p.ldo + n0 + ni * 16 + 4 * eq), p.drop_thresh, p.drop_inv, mk);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] *= mk[j];
                 }
@@ -615,7 +644,7 @@ __global__ __launch_bounds__(256) void conv4_kernel(C8Params p) {
                 const int r = u / 12, ch = u - r * 12;
                 const uint4 ux = *reinterpret_cast<const uint4*>(st + r * PITCH + ch * 16);
                 const int m = m0 + r;
-                if (m < p.M) *reinterpret_cast<uint4*>(p.out_hi + (size_t)m * p.ldo + n0 + ch * 8) = ux;
+                if (m < p.M) *reinterpret_cast<uint4*>(p.out_hi + (size_t)out_row(m) * p.ldo + n0 + ch * 8) = ux;
             }
         }
 #pragma unroll
@@ -860,14 +889,27 @@ int ig_conv8(int kind, int sign, const void* x_hi, const void* x_lo, const void*
     if (best < 0) return IG_ERR_UNSUPPORTED;
     const C8Shape& sh = kShapes[best];
     const long ntiles = (M + sh.bm - 1) / sh.bm * ((N + sh.bn - 1) / sh.bn) * pl.nphase;
+    // conv4_kernel (4 waves, generated K-loop): plain-bf16 launches whose width tiles by 192.  IG_GEMM4 = 0: off, 2: every covered shape
+    // (tests); default: where conv8 would have taken its 256 x 192 or 256 x 256 instance (tools/head_bench.py, B = 216: Conv2d 384 forward
+    // 481 -> 375 us, data gradient 473 -> 394; Conv2d 192: 530 -> 415, 567 -> 451; ConvTranspose data gradients 288 -> 235, 347 -> 309,
+    // 768 -> 384: 206 -> 194; ConvTranspose forward 768 -> 384: 367 -> 280 (conv8), 384 -> 192: 417 -> 376 (the round-1 engine))
+    bool use4 = false;
+    const long nt4 = (M + 255) / 256 * (N / 192) * pl.nphase;
+    {
+        const char* e4 = getenv("IG_GEMM4");
+        const int g4 = e4 ? atoi(e4) : 1;
+        bool ok4 = g4 && !w_lo && N % 192 == 0 && tent <= C4_TAB_MAX && a_bytes < 2147483648.0 - 16777216.0 && nt4 < (1L << 30);
+        for (int ph = 0; ph < pl.nphase; ++ph) ok4 = ok4 && pl.kpad[ph] / 64 >= 4;
+        use4 = ok4 && (g4 == 2 || (best <= 1 && nt4 >= slots - slots / 8));
+    }
     // (nearly) one tile per CU or more: 252 tiles pay (ConvTranspose dgrad 2304 -> 1152 at B = 36: 477 -> 319 us), 196 do not (B = 16: -0.9 %
     // of the step): below that the round-1 engine's finer tiles
-    if (env != 2 && ntiles < slots - slots / 8) return IG_ERR_UNSUPPORTED;
+    if (env != 2 && ntiles < slots - slots / 8 && !use4) return IG_ERR_UNSUPPORTED;
     // ConvTranspose forward: the statically dealt 1- / 2- / 4-tap phase tiles leave the workgroups 10-25 % out of balance (the
     // round-1 engine's phases are dispatched heaviest-first by the hardware).  Measured per stage (tools/head_bench.py): it pays with
     // long reductions and many tiles (768 -> 384 at B = 216, 1152 -> 576, 576 -> 288) and at the widths the round-1 tiles fit badly
     // (N = 144).
-    if (kind == 1 && env != 2) {
+    if (kind == 1 && env != 2 && !use4) {
         const bool pays = ntiles >= 4L * slots && (sh.bn >= 192 || w_lo) && (C >= 512 || (N % 64) != 0);
         if (!pays) return IG_ERR_UNSUPPORTED;
     }
@@ -908,14 +950,8 @@ int ig_conv8(int kind, int sign, const void* x_hi, const void* x_lo, const void*
     p.drop_seed = drop_seed, p.drop_seed_dev = drop_seed_dev;
     p.drop_thresh = ig_drop_thresh16(drop_p);
     p.drop_inv = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
-    {   // conv4_kernel (4 waves, generated K-loop): single-phase plain-bf16 launches whose width tiles by 192.  IG_GEMM4 = 0: off, 2: every
-        // covered shape (tests); default: where conv8 would have taken its own 256 x 192 instance
-        const char* e4 = getenv("IG_GEMM4");
-        const int g4 = e4 ? atoi(e4) : 1;
-        const long nt4 = (M + 255) / 256 * (N / 192);
-        const bool ok4 = g4 && !w_lo && pl.nphase == 1 && N % 192 == 0 && tent <= C4_TAB_MAX && a_bytes < 2147483648.0 - 16777216.0 &&
-                         pl.kpad[0] / 64 >= 4 && nt4 < (1L << 30);
-        if (ok4 && (g4 == 2 || (best == 1 && nt4 >= slots - slots / 8))) {
+    {
+        if (use4) {  // (also where conv8 would take 256 x 256: 768 -> 384 data gradient 206 -> 194 us)
             static bool attr4_done = false;
             if (!attr4_done) {
                 if (hipFuncSetAttribute((const void*)conv4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {

@@ -794,14 +794,15 @@ def wp_clobbers():
 #     where (delta, mask bit) of the lane's 16-byte K chunk come from ONE table entry per lane and K-tile (read from LDS one iteration ahead),
 #     invalid = bit `mask bit` of the row's INVERTED tap mask, and an offset beyond the descriptor's bound makes the hardware write zeros:
 #     three vector instructions per piece (v_bfe_u32, v_lshl_add_u32, v_add_u32) woven in front of its issue.  The table index runs
-#     cyclically over the nk K-tiles of a tile (every tile of a launch has the same K), so it simply continues across tile boundaries; the
-#     row offsets / masks of the NEXT tile take over for the last pair.
+#     cyclically over the nk K-tiles of a tile and wraps to the NEXT tile's table (the four sub-pixel phases of a ConvTranspose forward have
+#     their own tables, K lengths and packed row pitches); the row offsets / masks and B offsets of the next tile take over for the last pair.
 #   * B (packed weights [N][Kpad]) has 192 rows: 6 pieces per wave and K-tile, stages of 24 KiB at 96 / 120 KiB; the chunk table sits behind
 #     them at 144 KiB.
 CV_E = 103            # table entry of the K-tile whose A pieces are issued next
 CV_O = 104            # v104..v111: gathered offsets of the 8 A pieces
 CV_OFFB = 112         # v112..v117: DMA offsets of the 6 B pieces
 CV_TA = 118           # table read address
+CV_OFFB_N = 119       # v119..v124: DMA offsets of the 6 B pieces of the NEXT tile (another phase of a ConvTranspose forward has another row pitch)
 CS_RSRC = 84          # s[84:87]: buffer descriptor of the gathered tensor
 CS_TOFF, CS_LEFT, CS_NK = 88, 89, 90   # table byte offset of the next entry to read, entries left before it wraps, K-tiles per tile
 CS_LDSWB = 91         # LDS-DMA destination base of this wave's B pieces (48 rows per wave: wave * 6 KiB)
@@ -832,8 +833,9 @@ def c_dmas_a(next_tile):
     return out
 
 
-def c_dmas_b(bstage):
-    return [([], f"s_add_u32 m0, s{CS_LDSWB}, {CB_BASE + bstage * CB_STAGE + i * 1024}", f"global_load_lds_dwordx4 v{CV_OFFB + i}, s[{S_BPTR}:{S_BPTR + 1}]")
+def c_dmas_b(bstage, next_tile):
+    offb = CV_OFFB_N if next_tile else CV_OFFB
+    return [([], f"s_add_u32 m0, s{CS_LDSWB}, {CB_BASE + bstage * CB_STAGE + i * 1024}", f"global_load_lds_dwordx4 v{offb + i}, s[{S_BPTR}:{S_BPTR + 1}]")
             for i in range(C_NI)]
 
 
@@ -872,7 +874,7 @@ def c_entry_decode(st):
 def c_table_next():
     """advance the cyclic table offset and read the entry of the K-tile whose A pieces the NEXT iteration issues"""
     return [f"s_add_u32 s{CS_TOFF}, s{CS_TOFF}, 32", f"s_sub_u32 s{CS_LEFT}, s{CS_LEFT}, 1", f"s_cmp_eq_u32 s{CS_LEFT}, 0",
-            f"s_cselect_b32 s{CS_TOFF}, 0, s{CS_TOFF}", f"s_cselect_b32 s{CS_LEFT}, s{CS_NK}, s{CS_LEFT}",
+            f"s_cselect_b32 s{CS_TOFF}, %[toffn4], s{CS_TOFF}", f"s_cselect_b32 s{CS_LEFT}, s{CS_NK}, s{CS_LEFT}",
             f"v_add_u32 v{CV_TA}, s{CS_TOFF}, %[vtl]", f"ds_read_b32 v{CV_E}, v{CV_TA}"]
 
 
@@ -887,7 +889,7 @@ def c_iteration(st, p, first, next_tile, cfg):
     if not cfg.get("abl_bar"):
         st.e("s_barrier")
     st.e(f"v_add_u32 v{V_AC}, s{S_A1}, v{V_FA}")
-    c_half(st, 1, False, c_reads(p ^ 1, 0, 0), c_dmas_b(p), c_table_next(), cfg)
+    c_half(st, 1, False, c_reads(p ^ 1, 0, 0), c_dmas_b(p, next_tile), c_table_next(), cfg)
     for a in advance(S_BPTR):
         st.e(a)
     st.e(f"s_mov_b32 s{S_T}, s{S_A0}")
@@ -897,10 +899,12 @@ def c_iteration(st, p, first, next_tile, cfg):
     st.e("s_waitcnt lgkmcnt(0)")
 
 
-def c_setup(st):
+def c_setup(st, with_next):
     for i in range(C_NI):
         st.e(f"v_add_u32 v{V_TMP}, {8 * i}, %[browv]")
         st.e(f"v_mad_u32_u24 v{CV_OFFB + i}, v{V_TMP}, %[ldb2], %[c16]")
+        if with_next:
+            st.e(f"v_mad_u32_u24 v{CV_OFFB_N + i}, v{V_TMP}, %[ldb2n], %[c16]")
     st.e(f"v_mov_b32 v{V_FA}, %[fa]")
     st.e(f"v_xor_b32 v{V_FA + 1}, 64, %[fa]")
     for b in (0, 1):
@@ -920,14 +924,15 @@ def c_setup(st):
 def gen_c_prologue():
     """first tile of a workgroup: K-tiles 0 and 1 (table entries 0 and 1)"""
     st = Stream()
-    c_setup(st)
+    c_setup(st, False)
     st.e(f"s_mov_b64 s[{S_BPTR}:{S_BPTR + 1}], %[bptr]")
+    st.e(f"v_add_u32 v{CV_TA}, %[toff4], %[vtl]")
     for k, slot in enumerate((S_A0, S_A1)):
-        st.e(f"ds_read_b32 v{CV_E}, %[vtl] offset:{32 * k}")
+        st.e(f"ds_read_b32 v{CV_E}, v{CV_TA} offset:{32 * k}")
         st.e("s_waitcnt lgkmcnt(0)")
         c_entry_decode(st)
         st.e(f"s_add_u32 s{S_ADST}, s{S_LDSW}, s{slot}")
-        for pre, m0w, ld in c_dmas_a(False) + c_dmas_b(k):
+        for pre, m0w, ld in c_dmas_a(False) + c_dmas_b(k, False):
             for x in pre:
                 st.e(x)
             st.e(m0w)
@@ -941,12 +946,13 @@ def gen_c_prologue():
 def gen_c_tile(cfg):
     """one tile: bptr on its K-tile 2, bnext on the next tile's K-tile 0; ro / im = this tile's rows, ron / imn = the next tile's"""
     st = Stream()
-    c_setup(st)
+    c_setup(st, True)
     st.e(f"s_mov_b64 s[{S_BPTR}:{S_BPTR + 1}], %[bptr]")
     st.e(f"s_mov_b32 s{S_CNT}, %[npair]")
-    st.e(f"s_mov_b32 s{CS_TOFF}, 64")                 # the first iteration issues K-tile 2
+    st.e(f"s_add_u32 s{CS_TOFF}, %[toff4], 64")        # the first iteration issues K-tile 2 of this tile's table (toff4: its byte offset)
     st.e(f"s_sub_u32 s{CS_LEFT}, s{CS_NK}, 2")
-    st.e(f"ds_read_b32 v{CV_E}, %[vtl] offset:64")
+    st.e(f"v_add_u32 v{CV_TA}, s{CS_TOFF}, %[vtl]")
+    st.e(f"ds_read_b32 v{CV_E}, v{CV_TA}")
     st.e("s_waitcnt vmcnt(0)")
     st.e("s_barrier")
     st.e(f"v_add_u32 v{V_AC}, s{S_A0}, v{V_FA}")
@@ -978,7 +984,10 @@ def gen_c_tile(cfg):
 def c_clobbers():
     c = ['"memory"', '"scc"', '"m0"']
     c += [f'"a{i}"' for i in range(256)]
-    c += [f'"v{i}"' for i in range(V_LO, V_HI + 1)]
+    used = set(range(V_TMP, CV_OFFB_N + C_NI))   # v94 .. v124
+    for q in (0, 1):                              # fragment sets: 8 A blocks + 6 B blocks of 4 registers
+        used |= set(range(V_SET + 64 * q, V_SET + 64 * q + 32)) | set(range(V_SET + 64 * q + 32, V_SET + 64 * q + 32 + 4 * C_NI))
+    c += [f'"v{i}"' for i in sorted(used)]       # exactly the registers the block names: the compiler keeps the rest
     c += [f'"s{i}"' for i in range(CS_LO, CS_HI + 1)]
     return ", ".join(c)
 

@@ -323,7 +323,7 @@ def test_m0_is_only_written_by_the_lds_dma_helpers():
     """gemm8.hip / gemm8w.hip / conv8.hip / gemm4.hip set M0 (the LDS destination of an LDS-DMA) without saving or restoring it (the asm statements
     declare the clobber).  That is sound and free only while hipcc keeps nothing of its own in M0 in those kernels: compile each file to gfx950
     assembly (no GPU needed) and check that every M0 reference is one of the helpers' `s_mov_b32 m0, sN` -- or, in the generated K-loops of
-    gemm4.hip and of gemm8w.hip's gemm4w_kernel, `s_add_u32 m0, sN, imm` -- no read of M0, no other writer."""
+    gemm4.hip, gemm8w.hip's gemm4w_kernel and conv8.hip's conv4_kernel, `s_add_u32 m0, sN, imm` -- no read of M0, no other writer."""
     import re
     import shutil
     import subprocess
@@ -343,7 +343,7 @@ def test_m0_is_only_written_by_the_lds_dma_helpers():
                             "--cuda-device-only", os.path.join(csrc, name + ".hip"), "-o", out], check=True, capture_output=True)
             refs = [ln.strip() for ln in open(out) if re.search(r"\bm0\b", ln) and not ln.lstrip().startswith(";")]
             assert refs, name
-            bad = [ln for ln in refs if not re.fullmatch(r"s_mov_b32 m0, s\d+", ln) and not (name in ("gemm4", "gemm8w") and re.fullmatch(r"s_add_u32 m0, s\d+, (0x)?[0-9a-f]+", ln))]
+            bad = [ln for ln in refs if not re.fullmatch(r"s_mov_b32 m0, s\d+", ln) and not (name in ("gemm4", "gemm8w", "conv8") and re.fullmatch(r"s_add_u32 m0, s\d+, (0x)?[0-9a-f]+", ln))]
             assert not bad, (name, bad[:5])
 
 
@@ -446,6 +446,57 @@ def test_gemm4w_generator_emits_a_consistent_instruction_stream(tmp_path):
             m = re.match(RD + r" v\[(\d+):", i)
             if m:
                 assert int(m.group(1)) // 4 * 4 not in used, (i, b // 64)
+
+
+def test_conv4_generator_emits_a_consistent_instruction_stream(tmp_path):
+    """The convolution form of csrc/gen_gemm4.py (conv4_kernel in conv8.hip: 256 x 192 tile, gathered A pieces).  Per iteration: 96 MFMAs on
+    8 x 6 accumulator blocks, 28 fragment reads, 8 gathered A pieces -- each `buffer_load ... offen lds` preceded by its own M0 write and by the
+    three instructions that build its offset from the row offset, the row's inverted tap mask and this K-tile's table entry -- and 6 plain B
+    pieces; one table read per iteration, behind the decode of the previous entry; the last pair takes the NEXT tile's rows; every named
+    register lies inside the clobber list."""
+    import re
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "g4.inc"
+    subprocess.run([sys.executable, os.path.join(root, "instageo-e2e-geospatial-ml_amd", "csrc", "gen_gemm4.py"), str(out)], check=True)
+    text = out.read_text()
+    tile = re.findall(r'"([^"]*?)\\n\\t"', text[text.index("#define G4C_ASM_TILE"):text.index("#define G4C_CLOBBERS")])
+    pro = re.findall(r'"([^"]*?)\\n\\t"', text[text.index("#define G4C_ASM_PROLOGUE"):text.index("#define G4C_ASM_TILE")])
+    clob = text[text.index("#define G4C_CLOBBERS"):].split("\n", 1)[0]
+    MF = "v_mfma_f32_16x16x32_bf16"
+    mf = [i for i in tile if i.startswith(MF)]
+    assert len(mf) == 6 * 96 and all(i.endswith(", 0") for i in mf[:48]) and sum(1 for i in mf if i.endswith(", 0")) == 48
+    for it in range(6):
+        dst = sorted(int(re.match(MF + r" a\[(\d+):", i).group(1)) for i in mf[it * 96:(it + 1) * 96])
+        assert dst == sorted([(mi * 8 + ni) * 4 for mi in range(8) for ni in range(6)] * 2)
+    assert sum(1 for i in tile if i.startswith("ds_read_b128")) == 14 + 6 * 28
+    assert sum(1 for i in tile if i.startswith("ds_read_b32")) == 1 + 6 and sum(1 for i in pro if i.startswith("ds_read_b32")) == 2
+    ga = [k for k, i in enumerate(tile) if i.startswith("buffer_load_dwordx4")]
+    gb = [k for k, i in enumerate(tile) if i.startswith("global_load_lds_dwordx4")]
+    assert len(ga) == 6 * 8 and len(gb) == 6 * 6
+    for k in ga + gb:
+        assert tile[k - 2].startswith("s_add_u32 m0, ") and not tile[k - 1].startswith(("s_add_u32 m0", "buffer_load", "global_load")), tile[k - 2:k + 1]
+    for n, k in enumerate(ga):  # the piece's offset register is written by bfe -> lshl_add -> add, in that order, before the issue
+        reg = re.match(r"buffer_load_dwordx4 (v\d+),", tile[k]).group(1)
+        ops3 = [i for i in tile[:k] if re.match(r"v_(bfe_u32|lshl_add_u32|add_u32) " + reg + ",", i)][-3:]
+        assert [o.split()[0] for o in ops3] == ["v_bfe_u32", "v_lshl_add_u32", "v_add_u32"], (reg, ops3)
+        nxt = n >= 4 * 8  # the last pair gathers the next tile's rows
+        assert ("%[imn" in ops3[0]) == nxt and ("%[ron" in ops3[2]) == nxt, ops3
+    assert sum(1 for i in tile if i == "s_waitcnt vmcnt(8)") == 6 and sum(1 for i in tile if i == "s_barrier") == 7
+    cv = {int(x) for x in re.findall(r'"v(\d+)"', clob)}
+    cs = {int(x) for x in re.findall(r'"s(\d+)"', clob)}
+    assert {int(x) for x in re.findall(r'"a(\d+)"', clob)} == set(range(256)) and '"m0"' in clob and '"scc"' in clob
+    for i in tile + pro:
+        body = re.sub(r"%\[[a-z0-9_]+\]", "", i)
+        for lo, hi in re.findall(r"\bv\[(\d+):(\d+)\]", body):
+            assert set(range(int(lo), int(hi) + 1)) <= cv, i
+        for r in re.findall(r"\bv(\d+)\b", body):
+            assert int(r) in cv, i
+        for lo, hi in re.findall(r"\bs\[(\d+):(\d+)\]", body):
+            assert set(range(int(lo), int(hi) + 1)) <= cs, i
+        for r in re.findall(r"\bs(\d+)\b", body):
+            assert int(r) in cs, i
 
 
 def test_split_tensors_are_one_allocation_with_lo_above_hi():

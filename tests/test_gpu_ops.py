@@ -836,12 +836,12 @@ def test_conv8_engine_conv3x3(split, B, H, Cin, Cout, monkeypatch):
 @pytest.mark.parametrize("kind,B,H,Cin,Cout", [
     ("conv", 3, 14, 384, 384), ("conv", 2, 9, 192, 192), ("conv", 1, 7, 576, 576), ("conv", 1, 5, 1152, 1152), ("conv", 1, 1, 192, 192),
     ("conv", 1, 2, 384, 192), ("conv", 2, 28, 384, 384),
-    ("convT", 3, 14, 768, 384), ("convT", 2, 9, 384, 192), ("convT", 1, 13, 192, 96), ("convT", 1, 6, 2304, 1152), ("convT", 1, 1, 384, 192),
+    ("convT", 3, 14, 768, 384), ("convT", 2, 9, 384, 192), ("convT", 1, 13, 192, 96), ("convT", 1, 6, 2304, 1152), ("convT", 1, 1, 384, 192), ("convT", 2, 28, 384, 192),
 ])
 def test_conv4_equals_conv8_bit_for_bit(kind, B, H, Cin, Cout, monkeypatch):
     """conv4_kernel (conv8.hip: the 4-wave 256 x 192 form with a generated K-loop, A pieces gathered with three vector instructions of address
     arithmetic each) against conv8_kernel on the same packed weights and chunk table: Conv2d forward (+ bias, + eval BatchNorm / ReLU fold),
-    its data gradient (+ dropout mask) and the ConvTranspose data gradient, widths that tile by 192.  Same MFMA instruction in the same K
+    its data gradient (+ dropout mask), the ConvTranspose data gradient and forward (+ bias, + dropout), widths that tile by 192.  Same MFMA instruction in the same K
     order, so the results must be IDENTICAL; the float64 comparison of conv8 itself is test_conv8_engine_*."""
     monkeypatch.setenv("IG_CONV8", "2")
     monkeypatch.setenv("IG_CONV_DIRECT", "0")
@@ -880,6 +880,17 @@ def test_conv4_equals_conv8_bit_for_bit(kind, B, H, Cin, Cout, monkeypatch):
             ops.convT_dgrad(dy, w, dx, B, H, W, Cin, Cout)
             assert ops.last_kernel().startswith(want), ops.last_kernel()
             got.append(dx.hi.clone())
+            if Cout % 192 == 0:  # forward: four sub-pixel phases (own tables, K lengths and row pitches) as tiles of one launch
+                x, _ = bt(nhwc(rnd(B, Cin, H, W, seed=30)), False)
+                bias = rnd(Cout, seed=32).to(DEV)
+                y = BT.zeros((B, 2 * H, 2 * W, Cout), False, DEV)
+                ops.convT_fwd(x, w, bias, y, B, H, W, Cin, Cout)
+                assert ops.last_kernel().startswith(want), ops.last_kernel()
+                got.append(y.hi.clone())
+                y.hi.zero_()
+                ops.convT_fwd(x, w, bias, y, B, H, W, Cin, Cout, seed=77, p=0.1)
+                assert ops.last_kernel().startswith(want), ops.last_kernel()
+                got.append(y.hi.clone())
         assert got
         outs[arm] = got
     for i, (a, b) in enumerate(zip(outs["0"], outs["2"])):
