@@ -469,8 +469,10 @@ __global__ __launch_bounds__(128 * WC, 2) void conv8_kernel(C8Params p) {
 constexpr int C4_OFF_TAB = 147456;  // 144 KiB: 3 x 32 KiB A slots, 2 x 24 KiB B stages, then the chunk table (32-word header + entries)
 constexpr int C4_TAB_MAX = 4096 - 32;
 
+template <int NI>  // 16-column blocks per wave: 6 = the 256 x 192 tile, 3 = 256 x 96 (N = 96, 288)
 __global__ __launch_bounds__(256) void conv4_kernel(C8Params p) {
-    constexpr int BM = 256, BN = 192, PITCH = 96 * 2 + 16;
+    static_assert(NI == 6 || NI == 3, "conv4: 256 x 192 or 256 x 96 tiles");
+    constexpr int BM = 256, BN = 32 * NI, WNC = 16 * NI, PITCH = WNC * 2 + 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -493,9 +495,9 @@ __global__ __launch_bounds__(256) void conv4_kernel(C8Params p) {
     const unsigned c16 = sc << 4;
     const unsigned swz = ((lane >> 4) ^ (lane & 7)) << 4;
     const unsigned fa = lds_base + (wr * 128 + (lane & 15)) * 128 + swz;
-    const unsigned fb = lds_base + (wc * 96 + (lane & 15)) * 128 + swz;
-    const unsigned ldsw = lds_base + wave * 8192, ldswb = lds_base + wave * 6144;
-    const unsigned browv = wave * 48 + (lane >> 3);
+    const unsigned fb = lds_base + (wc * WNC + (lane & 15)) * 128 + swz;
+    const unsigned ldsw = lds_base + wave * 8192, ldswb = lds_base + wave * (NI * 1024);
+    const unsigned browv = wave * (NI * 8) + (lane >> 3);
     const unsigned vtl = lds_base + C4_OFF_TAB + 128 + sc * 4;  // this lane's entry of table position 0
     const int Hs = p.H * p.sm, Ws = p.W * p.sm;
     uint32_t drop_seed = p.drop_seed;
@@ -556,12 +558,14 @@ __global__ __launch_bounds__(256) void conv4_kernel(C8Params p) {
     {
         const PhaseK k = phase_k(c_ph);
         const char* bptr = uni(k.b + (long)c_bn * BN * k.ldb2);
-        asm volatile(G4C_ASM_PROLOGUE ::[abase] "s"(abase), [abytes] "s"(abytes), [bptr] "s"(bptr), [ldb2] "s"(k.ldb2), [ldsw] "s"(ldsw),
-                     [ldswb] "s"(ldswb), [nk] "s"(k.nk), [toff4] "s"(k.toff4), [a0] "s"(a0), [a1] "s"(a1), [a2] "s"(a2), [browv] "v"(browv),
-                     [c16] "v"(c16), [fa] "v"(fa), [fb] "v"(fb), [vtl] "v"(vtl), [ro0] "v"(ro[0]), [ro1] "v"(ro[1]), [ro2] "v"(ro[2]), [ro3] "v"(ro[3]),
-                     [ro4] "v"(ro[4]), [ro5] "v"(ro[5]), [ro6] "v"(ro[6]), [ro7] "v"(ro[7]), [im0] "v"(im[0]), [im1] "v"(im[1]), [im2] "v"(im[2]),
+#define C4_PRO_OPERANDS ::[abase] "s"(abase), [abytes] "s"(abytes), [bptr] "s"(bptr), [ldb2] "s"(k.ldb2), [ldsw] "s"(ldsw), \
+                     [ldswb] "s"(ldswb), [nk] "s"(k.nk), [toff4] "s"(k.toff4), [a0] "s"(a0), [a1] "s"(a1), [a2] "s"(a2), [browv] "v"(browv), \
+                     [c16] "v"(c16), [fa] "v"(fa), [fb] "v"(fb), [vtl] "v"(vtl), [ro0] "v"(ro[0]), [ro1] "v"(ro[1]), [ro2] "v"(ro[2]), [ro3] "v"(ro[3]), \
+                     [ro4] "v"(ro[4]), [ro5] "v"(ro[5]), [ro6] "v"(ro[6]), [ro7] "v"(ro[7]), [im0] "v"(im[0]), [im1] "v"(im[1]), [im2] "v"(im[2]), \
                      [im3] "v"(im[3]), [im4] "v"(im[4]), [im5] "v"(im[5]), [im6] "v"(im[6]), [im7] "v"(im[7])
-                     : G4C_CLOBBERS);
+        if constexpr (NI == 6) asm volatile(G4C6_ASM_PROLOGUE C4_PRO_OPERANDS : G4C6_CLOBBERS);
+        else asm volatile(G4C3_ASM_PROLOGUE C4_PRO_OPERANDS : G4C3_CLOBBERS);
+#undef C4_PRO_OPERANDS
     }
     for (int t = 0; t < my_tiles; ++t) {
         const int bm = c_bm, ph = c_ph, bn = c_bn;
@@ -577,24 +581,26 @@ __global__ __launch_bounds__(256) void conv4_kernel(C8Params p) {
         const char* bptr = uni(k.b + (long)bn * BN * k.ldb2 + 256);  // K-tile 2 (0 and 1 are in flight)
         const char* bnext = uni(kn.b + (long)c_bn * BN * kn.ldb2);
         const int npair = (k.nk >> 1) - 2;
-        asm volatile(G4C_ASM_TILE
-                     : [a0] "+s"(a0), [a1] "+s"(a1), [a2] "+s"(a2)
-                     : [abase] "s"(abase), [abytes] "s"(abytes), [bptr] "s"(bptr), [bnext] "s"(bnext), [ldb2] "s"(k.ldb2), [ldb2n] "s"(kn.ldb2),
-                       [ldsw] "s"(ldsw), [ldswb] "s"(ldswb), [nk] "s"(k.nk), [toff4] "s"(k.toff4), [toffn4] "s"(kn.toff4), [npair] "s"(npair),
-                       [browv] "v"(browv), [c16] "v"(c16), [fa] "v"(fa), [fb] "v"(fb), [vtl] "v"(vtl), [ro0] "v"(ro[0]), [ro1] "v"(ro[1]),
-                       [ro2] "v"(ro[2]), [ro3] "v"(ro[3]), [ro4] "v"(ro[4]), [ro5] "v"(ro[5]), [ro6] "v"(ro[6]), [ro7] "v"(ro[7]), [im0] "v"(im[0]),
-                       [im1] "v"(im[1]), [im2] "v"(im[2]), [im3] "v"(im[3]), [im4] "v"(im[4]), [im5] "v"(im[5]), [im6] "v"(im[6]), [im7] "v"(im[7]),
-                       [ron0] "v"(ron[0]), [ron1] "v"(ron[1]), [ron2] "v"(ron[2]), [ron3] "v"(ron[3]), [ron4] "v"(ron[4]), [ron5] "v"(ron[5]),
-                       [ron6] "v"(ron[6]), [ron7] "v"(ron[7]), [imn0] "v"(imn[0]), [imn1] "v"(imn[1]), [imn2] "v"(imn[2]), [imn3] "v"(imn[3]),
+#define C4_TILE_OPERANDS \
+                     : [a0] "+s"(a0), [a1] "+s"(a1), [a2] "+s"(a2) \
+                     : [abase] "s"(abase), [abytes] "s"(abytes), [bptr] "s"(bptr), [bnext] "s"(bnext), [ldb2] "s"(k.ldb2), [ldb2n] "s"(kn.ldb2), \
+                       [ldsw] "s"(ldsw), [ldswb] "s"(ldswb), [nk] "s"(k.nk), [toff4] "s"(k.toff4), [toffn4] "s"(kn.toff4), [npair] "s"(npair), \
+                       [browv] "v"(browv), [c16] "v"(c16), [fa] "v"(fa), [fb] "v"(fb), [vtl] "v"(vtl), [ro0] "v"(ro[0]), [ro1] "v"(ro[1]), \
+                       [ro2] "v"(ro[2]), [ro3] "v"(ro[3]), [ro4] "v"(ro[4]), [ro5] "v"(ro[5]), [ro6] "v"(ro[6]), [ro7] "v"(ro[7]), [im0] "v"(im[0]), \
+                       [im1] "v"(im[1]), [im2] "v"(im[2]), [im3] "v"(im[3]), [im4] "v"(im[4]), [im5] "v"(im[5]), [im6] "v"(im[6]), [im7] "v"(im[7]), \
+                       [ron0] "v"(ron[0]), [ron1] "v"(ron[1]), [ron2] "v"(ron[2]), [ron3] "v"(ron[3]), [ron4] "v"(ron[4]), [ron5] "v"(ron[5]), \
+                       [ron6] "v"(ron[6]), [ron7] "v"(ron[7]), [imn0] "v"(imn[0]), [imn1] "v"(imn[1]), [imn2] "v"(imn[2]), [imn3] "v"(imn[3]), \
                        [imn4] "v"(imn[4]), [imn5] "v"(imn[5]), [imn6] "v"(imn[6]), [imn7] "v"(imn[7])
-                     : G4C_CLOBBERS);
+        if constexpr (NI == 6) asm volatile(G4C6_ASM_TILE C4_TILE_OPERANDS : G4C6_CLOBBERS);
+        else asm volatile(G4C3_ASM_TILE C4_TILE_OPERANDS : G4C3_CLOBBERS);
+#undef C4_TILE_OPERANDS
         // ================= epilogue (the next tile's K-tiles 0 and 1 are in flight) =================
-        // accumulator block (mi, ni) of this lane: out[m = mi 16 + (lane & 15)][n = ni 16 + 4 (lane >> 4) .. + 3] of the wave's 128 x 96
+        // accumulator block (mi, ni) of this lane: out[m = mi 16 + (lane & 15)][n = ni 16 + 4 (lane >> 4) .. + 3] of the wave's 128 x 16 NI
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         char* st = smem + a2 + wave * 8192;  // the A slot this tile's last K-tile has left
         const int erow = lane_e & 15, eq = lane_e >> 4;
-        const int n0 = bn * BN + wc * 96, mw = bm * BM + wr * 128;
+        const int n0 = bn * BN + wc * WNC, mw = bm * BM + wr * 128;
         const int py = ph >> 1, px = ph & 1;
         // output row of tile row m: identity, or the sub-pixel phase map of the ConvTranspose forward
         auto out_row = [&](int m) -> long {
@@ -603,9 +609,9 @@ __global__ __launch_bounds__(256) void conv4_kernel(C8Params p) {
             const int y_ = p.f_w.div(rem_), x_ = rem_ - y_ * p.W;
             return ((long)(b_ * 2 * p.H + 2 * y_ + py)) * (2 * p.W) + 2 * x_ + px;
         };
-        f32x4 bias4[6];
+        f32x4 bias4[NI];
 #pragma unroll
-        for (int ni = 0; ni < 6; ++ni) {
+        for (int ni = 0; ni < NI; ++ni) {
             bias4[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (p.bias) {
                 const float4 b_ = *reinterpret_cast<const float4*>(p.bias + n0 + ni * 16 + 4 * eq);
@@ -619,7 +625,7 @@ __global__ __launch_bounds__(256) void conv4_kernel(C8Params p) {
             const int m0 = mw + mi * 16;
             const long orow_e = p.drop_thresh ? out_row(m0 + erow) : 0L;
 #pragma unroll
-            for (int ni = 0; ni < 6; ++ni) {
+            for (int ni = 0; ni < NI; ++ni) {
                 const f32x4 a = tt[ni] + bias4[ni];
                 float v[4] = {a[0], a[1], a[2], a[3]};
                 if (p.scale) {  // eval-mode BatchNorm + ReLU (inference only)
@@ -638,13 +644,16 @@ __global__ __launch_bounds__(256) void conv4_kernel(C8Params p) {
                 po.x = pack_bf2(v[0], v[1]), po.y = pack_bf2(v[2], v[3]);
                 *reinterpret_cast<uint2*>(st + erow * PITCH + ni * 32 + eq * 8) = po;
             }
+            constexpr int UPR = NI * 2, NU = 16 * UPR;  // sixteen-byte units per staged row, per row block
 #pragma unroll
-            for (int itu = 0; itu < 3; ++itu) {  // 16 rows x 12 sixteen-byte units
+            for (int itu = 0; itu < (NU + 63) / 64; ++itu) {
                 const int u = itu * 64 + lane_e;
-                const int r = u / 12, ch = u - r * 12;
-                const uint4 ux = *reinterpret_cast<const uint4*>(st + r * PITCH + ch * 16);
-                const int m = m0 + r;
-                if (m < p.M) *reinterpret_cast<uint4*>(p.out_hi + (size_t)out_row(m) * p.ldo + n0 + ch * 8) = ux;
+                if (NU % 64 == 0 || u < NU) {
+                    const int r = u / UPR, ch = u - r * UPR;
+                    const uint4 ux = *reinterpret_cast<const uint4*>(st + r * PITCH + ch * 16);
+                    const int m = m0 + r;
+                    if (m < p.M) *reinterpret_cast<uint4*>(p.out_hi + (size_t)out_row(m) * p.ldo + n0 + ch * 8) = ux;
+                }
             }
         }
 #pragma unroll
@@ -867,8 +876,23 @@ int ig_conv8(int kind, int sign, const void* x_hi, const void* x_lo, const void*
     }
     pl.rows_total = pl.nphase * N, pl.ktab_n = tent;
 
-    // instance: the one with the least (rounds x tile area / efficiency) among those whose width divides N
     const int slots = ig_cu_count();
+    // conv4_kernel<NI> (4 waves, generated K-loop): plain-bf16 launches whose width tiles by 192 (NI = 6) or by 96 (NI = 3).  IG_GEMM4 = 0: off,
+    // 2: every covered shape (tests); default: (nearly) one tile per CU or more (tools/head_bench.py, B = 216: Conv2d 384 forward
+    // 481 -> 375 us, data gradient 473 -> 394; Conv2d 192: 530 -> 415, 567 -> 451; ConvTranspose data gradients 288 -> 235, 347 -> 309,
+    // 768 -> 384: 206 -> 194; ConvTranspose forward 768 -> 384: 367 -> 280 (conv8), 384 -> 192: 417 -> 376, 192 -> 96: 642 -> 578 (the round-1
+    // engine); T = 3, B = 72, 256 x 96 tiles: Conv2d 288 forward 1887 -> 1345, data gradient 1920 -> 1517, ConvTranspose forward 576 -> 288: 1203 -> 854)
+    bool use4 = false;
+    const int ni4 = N % 192 == 0 ? 6 : 3;  // 256 x 192 tiles, or 256 x 96 (N = 96: the 192 -> 96 ConvTranspose forward; 288 = 3 x 96)
+    const long nt4 = (M + 255) / 256 * (N / (32 * ni4)) * pl.nphase;
+    {
+        const char* e4 = getenv("IG_GEMM4");
+        const int g4 = e4 ? atoi(e4) : 1;
+        bool ok4 = g4 && !w_lo && N % 96 == 0 && tent <= C4_TAB_MAX && a_bytes < 2147483648.0 - 16777216.0 && nt4 < (1L << 30);
+        for (int ph = 0; ph < pl.nphase; ++ph) ok4 = ok4 && pl.kpad[ph] / 64 >= 4;
+        use4 = ok4 && (g4 == 2 || nt4 >= slots - slots / 8);
+    }
+    // instance: the one with the least (rounds x tile area / efficiency) among those whose width divides N
     int best = -1;
     double best_cost = 0;
     for (int i = 0; i < (int)(sizeof(kShapes) / sizeof(kShapes[0])); ++i) {
@@ -886,22 +910,9 @@ int ig_conv8(int kind, int sign, const void* x_hi, const void* x_lo, const void*
         const double cost = (double)rounds * s.bm * s.bn / s.eff;
         if (best < 0 || cost < best_cost) best = i, best_cost = cost;
     }
-    if (best < 0) return IG_ERR_UNSUPPORTED;
-    const C8Shape& sh = kShapes[best];
+    if (best < 0 && !use4) return IG_ERR_UNSUPPORTED;
+    const C8Shape& sh = kShapes[best < 0 ? 0 : best];
     const long ntiles = (M + sh.bm - 1) / sh.bm * ((N + sh.bn - 1) / sh.bn) * pl.nphase;
-    // conv4_kernel (4 waves, generated K-loop): plain-bf16 launches whose width tiles by 192.  IG_GEMM4 = 0: off, 2: every covered shape
-    // (tests); default: where conv8 would have taken its 256 x 192 or 256 x 256 instance (tools/head_bench.py, B = 216: Conv2d 384 forward
-    // 481 -> 375 us, data gradient 473 -> 394; Conv2d 192: 530 -> 415, 567 -> 451; ConvTranspose data gradients 288 -> 235, 347 -> 309,
-    // 768 -> 384: 206 -> 194; ConvTranspose forward 768 -> 384: 367 -> 280 (conv8), 384 -> 192: 417 -> 376 (the round-1 engine))
-    bool use4 = false;
-    const long nt4 = (M + 255) / 256 * (N / 192) * pl.nphase;
-    {
-        const char* e4 = getenv("IG_GEMM4");
-        const int g4 = e4 ? atoi(e4) : 1;
-        bool ok4 = g4 && !w_lo && N % 192 == 0 && tent <= C4_TAB_MAX && a_bytes < 2147483648.0 - 16777216.0 && nt4 < (1L << 30);
-        for (int ph = 0; ph < pl.nphase; ++ph) ok4 = ok4 && pl.kpad[ph] / 64 >= 4;
-        use4 = ok4 && (g4 == 2 || (best <= 1 && nt4 >= slots - slots / 8));
-    }
     // (nearly) one tile per CU or more: 252 tiles pay (ConvTranspose dgrad 2304 -> 1152 at B = 36: 477 -> 319 us), 196 do not (B = 16: -0.9 %
     // of the step): below that the round-1 engine's finer tiles
     if (env != 2 && ntiles < slots - slots / 8 && !use4) return IG_ERR_UNSUPPORTED;
@@ -954,16 +965,18 @@ int ig_conv8(int kind, int sign, const void* x_hi, const void* x_lo, const void*
         if (use4) {  // (also where conv8 would take 256 x 256: 768 -> 384 data gradient 206 -> 194 us)
             static bool attr4_done = false;
             if (!attr4_done) {
-                if (hipFuncSetAttribute((const void*)conv4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                if (hipFuncSetAttribute((const void*)conv4_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                    hipFuncSetAttribute((const void*)conv4_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                     ig_set_error("conv4: could not reserve 160 KiB of LDS");
                     return IG_ERR_HIP;
                 }
                 attr4_done = true;
             }
             const int grid4 = ig_tile_grid((int)nt4, 1);
-            ig_note_kernel("conv4_kernel");
+            ig_note_kernel("conv4_kernel<%d>", ni4);
             ig_note_grid(grid4);
-            hipLaunchKernelGGL(conv4_kernel, dim3(grid4), dim3(256), C4_OFF_TAB + (tent + 32) * 4, st, p);
+            if (ni4 == 6) hipLaunchKernelGGL(conv4_kernel<6>, dim3(grid4), dim3(256), C4_OFF_TAB + (tent + 32) * 4, st, p);
+            else hipLaunchKernelGGL(conv4_kernel<3>, dim3(grid4), dim3(256), C4_OFF_TAB + (tent + 32) * 4, st, p);
             return ig_check_launch("conv4");
         }
     }

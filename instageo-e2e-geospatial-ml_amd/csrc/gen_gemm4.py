@@ -787,8 +787,8 @@ def wp_clobbers():
 
 
 # =====================================================================================================================================
-# CONVOLUTION form (conv4_kernel in conv8.hip: the decode head's 3 x 3 convolutions as implicit GEMMs on a 256 x 192 tile, wave (wr, wc) owns
-# 128 rows x 96 columns = 8 x 6 accumulator blocks).  The loop is the forward form's with two changes:
+# CONVOLUTION form (conv4_kernel<NI> in conv8.hip: the decode head's 3 x 3 convolutions as implicit GEMMs on a 256 x 32 NI tile, wave (wr, wc)
+# owns 128 rows x 16 NI columns = 8 x NI accumulator blocks; NI = 6 or 3).  The loop is the forward form's with two changes:
 #   * A is GATHERED (conv8.hip): piece i of a wave is `buffer_load_dwordx4 v_off, s[desc], 0 offen lds` with
 #         v_off = rowoff_i + delta(K chunk) + (invalid ? 2^31 : 0)
 #     where (delta, mask bit) of the lane's 16-byte K chunk come from ONE table entry per lane and K-tile (read from LDS one iteration ahead),
@@ -796,28 +796,23 @@ def wp_clobbers():
 #     three vector instructions per piece (v_bfe_u32, v_lshl_add_u32, v_add_u32) woven in front of its issue.  The table index runs
 #     cyclically over the nk K-tiles of a tile and wraps to the NEXT tile's table (the four sub-pixel phases of a ConvTranspose forward have
 #     their own tables, K lengths and packed row pitches); the row offsets / masks and B offsets of the next tile take over for the last pair.
-#   * B (packed weights [N][Kpad]) has 192 rows: 6 pieces per wave and K-tile, stages of 24 KiB at 96 / 120 KiB; the chunk table sits behind
-#     them at 144 KiB.
+#   * B (packed weights [N][Kpad]) has 32 ni rows (ni = 6: the 256 x 192 tile, 3: 256 x 96): ni pieces per wave and K-tile, two stages of
+#     4 ni KiB behind the A slots; the chunk table sits at 144 KiB.
 CV_E = 103            # table entry of the K-tile whose A pieces are issued next
 CV_O = 104            # v104..v111: gathered offsets of the 8 A pieces
-CV_OFFB = 112         # v112..v117: DMA offsets of the 6 B pieces
+CV_OFFB = 112         # v112..v117: DMA offsets of the (up to 6) B pieces
 CV_TA = 118           # table read address
-CV_OFFB_N = 119       # v119..v124: DMA offsets of the 6 B pieces of the NEXT tile (another phase of a ConvTranspose forward has another row pitch)
+CV_OFFB_N = 119       # v119..v124: DMA offsets of the B pieces of the NEXT tile (another phase of a ConvTranspose forward has another row pitch)
 CS_RSRC = 84          # s[84:87]: buffer descriptor of the gathered tensor
 CS_TOFF, CS_LEFT, CS_NK = 88, 89, 90   # table byte offset of the next entry to read, entries left before it wraps, K-tiles per tile
-CS_LDSWB = 91         # LDS-DMA destination base of this wave's B pieces (48 rows per wave: wave * 6 KiB)
+CS_LDSWB = 91         # LDS-DMA destination base of this wave's B pieces (8 ni rows per wave: wave * ni KiB)
 CS_LO, CS_HI = 70, 91
-C_NI = 6
-CB_BASE, CB_STAGE = 98304, 24576
+CB_BASE = 98304       # B stages of ni * 4 KiB behind the three A slots
 
 
-def c_fbase_b(stage, s):
-    return f"v{V_FB + 2 * stage + s}"
-
-
-def c_reads(bstage, s, q):
+def c_reads(ni, bstage, s, q):
     out = [f"ds_read_b128 {afrag(q, i)}, v{V_AC} offset:{i * 2048}" for i in range(8)]
-    out += [f"ds_read_b128 {bfrag(q, i)}, {c_fbase_b(bstage, s)} offset:{i * 2048}" for i in range(C_NI)]
+    out += [f"ds_read_b128 {bfrag(q, i)}, {fbase_b(bstage, s)} offset:{i * 2048}" for i in range(ni)]
     return out
 
 
@@ -833,33 +828,33 @@ def c_dmas_a(next_tile):
     return out
 
 
-def c_dmas_b(bstage, next_tile):
+def c_dmas_b(ni, bstage, next_tile):
     offb = CV_OFFB_N if next_tile else CV_OFFB
-    return [([], f"s_add_u32 m0, s{CS_LDSWB}, {CB_BASE + bstage * CB_STAGE + i * 1024}", f"global_load_lds_dwordx4 v{offb + i}, s[{S_BPTR}:{S_BPTR + 1}]")
-            for i in range(C_NI)]
+    return [([], f"s_add_u32 m0, s{CS_LDSWB}, {CB_BASE + bstage * ni * 4096 + i * 1024}", f"global_load_lds_dwordx4 v{offb + i}, s[{S_BPTR}:{S_BPTR + 1}]")
+            for i in range(ni)]
 
 
-def c_half(st, q, first, rd, dm, tail, cfg):
-    """48 MFMAs on set q; reads every 3rd MFMA; DMA pieces (with their address arithmetic in front) every 5th from MFMA 3; `tail` behind MFMA 40"""
-    n = 8 * C_NI
+def c_half(st, ni, q, first, rd, dm, tail, cfg):
+    """8 ni MFMAs on set q with the reads, the DMA pieces (each with its address arithmetic in front) and `tail` spread over them"""
+    n = 8 * ni
     extra = {j: [] for j in range(n)}
     if cfg.get("abl_rd"):
         rd = []
     if cfg.get("abl_dma"):
         dm = []
     for k, r in enumerate(rd):
-        extra[min(n - 1, cfg["c_rd_at"] + k * cfg["c_rd_every"])].append(r)
+        extra[k * (n - 4) // len(rd)].append(r)
     for k, (pre, m0w, ld) in enumerate(dm):
-        j = min(n - 2, cfg["c_dm_at"] + k * cfg["c_dm_every"])
+        j = 2 + k * (n - 4) // len(dm)
         extra[j - 1].extend(pre)
         extra[j].append(m0w)
         extra[j + 1].insert(0, ld)
-    extra[min(n - 1, 40)].extend(tail)
+    extra[n * 5 // 6].extend(tail)
     j = 0
-    for ni in range(C_NI):
+    for b in range(ni):
         for mi in range(8):
-            c = "0" if first else acc(mi, ni)
-            st.e(f"v_mfma_f32_16x16x32_bf16 {acc(mi, ni)}, {bfrag(q, ni)}, {afrag(q, mi)}, {c}")
+            c = "0" if first else acc(mi, b)
+            st.e(f"v_mfma_f32_16x16x32_bf16 {acc(mi, b)}, {bfrag(q, b)}, {afrag(q, mi)}, {c}")
             for x in extra[j]:
                 st.e(x)
             j += 1
@@ -878,18 +873,18 @@ def c_table_next():
             f"v_add_u32 v{CV_TA}, s{CS_TOFF}, %[vtl]", f"ds_read_b32 v{CV_E}, v{CV_TA}"]
 
 
-def c_iteration(st, p, first, next_tile, cfg):
+def c_iteration(st, ni, p, first, next_tile, cfg):
     st.e(f"v_add_u32 v{V_AC}, s{S_A0}, v{V_FA + 1}")
     st.e(f"s_add_u32 s{S_ADST}, s{S_LDSW}, s{S_A2}")
     c_entry_decode(st)
-    c_half(st, 0, first, c_reads(p, 1, 1), c_dmas_a(next_tile), [], cfg)
+    c_half(st, ni, 0, first, c_reads(ni, p, 1, 1), c_dmas_a(next_tile), [], cfg)
     st.e("s_waitcnt lgkmcnt(0)")
     if not cfg.get("abl_vmw"):
         st.e("s_waitcnt vmcnt(8)")
     if not cfg.get("abl_bar"):
         st.e("s_barrier")
     st.e(f"v_add_u32 v{V_AC}, s{S_A1}, v{V_FA}")
-    c_half(st, 1, False, c_reads(p ^ 1, 0, 0), c_dmas_b(p, next_tile), c_table_next(), cfg)
+    c_half(st, ni, 1, False, c_reads(ni, p ^ 1, 0, 0), c_dmas_b(ni, p, next_tile), c_table_next(), cfg)
     for a in advance(S_BPTR):
         st.e(a)
     st.e(f"s_mov_b32 s{S_T}, s{S_A0}")
@@ -899,8 +894,8 @@ def c_iteration(st, p, first, next_tile, cfg):
     st.e("s_waitcnt lgkmcnt(0)")
 
 
-def c_setup(st, with_next):
-    for i in range(C_NI):
+def c_setup(st, ni, with_next):
+    for i in range(ni):
         st.e(f"v_add_u32 v{V_TMP}, {8 * i}, %[browv]")
         st.e(f"v_mad_u32_u24 v{CV_OFFB + i}, v{V_TMP}, %[ldb2], %[c16]")
         if with_next:
@@ -908,8 +903,8 @@ def c_setup(st, with_next):
     st.e(f"v_mov_b32 v{V_FA}, %[fa]")
     st.e(f"v_xor_b32 v{V_FA + 1}, 64, %[fa]")
     for b in (0, 1):
-        st.e(f"v_add_u32 {c_fbase_b(b, 0)}, {CB_BASE + b * CB_STAGE}, %[fb]")
-        st.e(f"v_xor_b32 {c_fbase_b(b, 1)}, 64, {c_fbase_b(b, 0)}")
+        st.e(f"v_add_u32 {fbase_b(b, 0)}, {CB_BASE + b * ni * 4096}, %[fb]")
+        st.e(f"v_xor_b32 {fbase_b(b, 1)}, 64, {fbase_b(b, 0)}")
     st.e(f"s_mov_b32 s{S_LDSW}, %[ldsw]")
     st.e(f"s_mov_b32 s{S_A0}, %[a0]")
     st.e(f"s_mov_b32 s{S_A1}, %[a1]")
@@ -921,10 +916,10 @@ def c_setup(st, with_next):
     st.e(f"s_mov_b32 s{CS_LDSWB}, %[ldswb]")
 
 
-def gen_c_prologue():
-    """first tile of a workgroup: K-tiles 0 and 1 (table entries 0 and 1)"""
+def gen_c_prologue(ni):
+    """first tile of a workgroup: K-tiles 0 and 1 (table entries 0 and 1 of its phase)"""
     st = Stream()
-    c_setup(st, False)
+    c_setup(st, ni, False)
     st.e(f"s_mov_b64 s[{S_BPTR}:{S_BPTR + 1}], %[bptr]")
     st.e(f"v_add_u32 v{CV_TA}, %[toff4], %[vtl]")
     for k, slot in enumerate((S_A0, S_A1)):
@@ -932,7 +927,7 @@ def gen_c_prologue():
         st.e("s_waitcnt lgkmcnt(0)")
         c_entry_decode(st)
         st.e(f"s_add_u32 s{S_ADST}, s{S_LDSW}, s{slot}")
-        for pre, m0w, ld in c_dmas_a(False) + c_dmas_b(k, False):
+        for pre, m0w, ld in c_dmas_a(False) + c_dmas_b(ni, k, False):
             for x in pre:
                 st.e(x)
             st.e(m0w)
@@ -943,10 +938,10 @@ def gen_c_prologue():
     return st.text()
 
 
-def gen_c_tile(cfg):
+def gen_c_tile(ni, cfg):
     """one tile: bptr on its K-tile 2, bnext on the next tile's K-tile 0; ro / im = this tile's rows, ron / imn = the next tile's"""
     st = Stream()
-    c_setup(st, True)
+    c_setup(st, ni, True)
     st.e(f"s_mov_b64 s[{S_BPTR}:{S_BPTR + 1}], %[bptr]")
     st.e(f"s_mov_b32 s{S_CNT}, %[npair]")
     st.e(f"s_add_u32 s{CS_TOFF}, %[toff4], 64")        # the first iteration issues K-tile 2 of this tile's table (toff4: its byte offset)
@@ -956,23 +951,23 @@ def gen_c_tile(cfg):
     st.e("s_waitcnt vmcnt(0)")
     st.e("s_barrier")
     st.e(f"v_add_u32 v{V_AC}, s{S_A0}, v{V_FA}")
-    for r in c_reads(0, 0, 0):
+    for r in c_reads(ni, 0, 0, 0):
         st.e(r)
     st.e("s_waitcnt lgkmcnt(0)")
-    c_iteration(st, 0, True, False, cfg)
-    c_iteration(st, 1, False, False, cfg)
+    c_iteration(st, ni, 0, True, False, cfg)
+    c_iteration(st, ni, 1, False, False, cfg)
     st.e(f"s_cmp_eq_u32 s{S_CNT}, 0")
     st.e("s_cbranch_scc1 L_last_%=")
     st.e("L_loop_%=:")
-    c_iteration(st, 0, False, False, cfg)
-    c_iteration(st, 1, False, False, cfg)
+    c_iteration(st, ni, 0, False, False, cfg)
+    c_iteration(st, ni, 1, False, False, cfg)
     st.e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
     st.e(f"s_cmp_lg_u32 s{S_CNT}, 0")
     st.e("s_cbranch_scc1 L_loop_%=")
     st.e("L_last_%=:")
     st.e(f"s_mov_b64 s[{S_BPTR}:{S_BPTR + 1}], %[bnext]")
-    c_iteration(st, 0, False, True, cfg)
-    c_iteration(st, 1, False, True, cfg)
+    c_iteration(st, ni, 0, False, True, cfg)
+    c_iteration(st, ni, 1, False, True, cfg)
     st.e(f"s_mov_b32 %[a0], s{S_A0}")
     st.e(f"s_mov_b32 %[a1], s{S_A1}")
     st.e(f"s_mov_b32 %[a2], s{S_A2}")
@@ -981,12 +976,12 @@ def gen_c_tile(cfg):
     return st.text()
 
 
-def c_clobbers():
+def c_clobbers(ni):
     c = ['"memory"', '"scc"', '"m0"']
     c += [f'"a{i}"' for i in range(256)]
-    used = set(range(V_TMP, CV_OFFB_N + C_NI))   # v94 .. v124
-    for q in (0, 1):                              # fragment sets: 8 A blocks + 6 B blocks of 4 registers
-        used |= set(range(V_SET + 64 * q, V_SET + 64 * q + 32)) | set(range(V_SET + 64 * q + 32, V_SET + 64 * q + 32 + 4 * C_NI))
+    used = set(range(V_TMP, CV_OFFB + ni)) | {CV_TA} | set(range(CV_OFFB_N, CV_OFFB_N + ni))
+    for q in (0, 1):                              # fragment sets: 8 A blocks + ni B blocks of 4 registers
+        used |= set(range(V_SET + 64 * q, V_SET + 64 * q + 32)) | set(range(V_SET + 64 * q + 32, V_SET + 64 * q + 32 + 4 * ni))
     c += [f'"v{i}"' for i in sorted(used)]       # exactly the registers the block names: the compiler keeps the rest
     c += [f'"s{i}"' for i in range(CS_LO, CS_HI + 1)]
     return ", ".join(c)
@@ -1021,8 +1016,7 @@ def gen_readout():
 
 def main():
     cfg = {"rd_every": 3, "rd_at": 0, "dm_every": 8, "dm_at": 3, "order": "ni", "skew": 0,
-           "w_rd_at": 0, "w_rd_num": 2, "w_rd_den": 1, "w_dm_at": 3, "w_dm_every": 8, "wp_rd_num": 1, "wp_rd_den": 1,
-           "c_rd_at": 0, "c_rd_every": 3, "c_dm_at": 3, "c_dm_every": 5}
+           "w_rd_at": 0, "w_rd_num": 2, "w_rd_den": 1, "w_dm_at": 3, "w_dm_every": 8, "wp_rd_num": 1, "wp_rd_den": 1}
     out_path = "gemm4_gen.inc"
     for a in sys.argv[1:]:
         if "=" in a:
@@ -1045,9 +1039,10 @@ def main():
         f.write("#define G4WP_ASM_PROLOGUE \\\n" + gen_wp_prologue().replace("\n", " \\\n") + "\n\n")
         f.write("#define G4WP_ASM_SEG \\\n" + gen_wp_seg(cfg).replace("\n", " \\\n") + "\n\n")
         f.write("#define G4WP_CLOBBERS " + wp_clobbers() + "\n\n")
-        f.write("#define G4C_ASM_PROLOGUE \\\n" + gen_c_prologue().replace("\n", " \\\n") + "\n\n")
-        f.write("#define G4C_ASM_TILE \\\n" + gen_c_tile(cfg).replace("\n", " \\\n") + "\n\n")
-        f.write("#define G4C_CLOBBERS " + c_clobbers() + "\n\n")
+        for ni in (6, 3):   # conv4_kernel<NI>: 256 x 192 and 256 x 96 tiles
+            f.write(f"#define G4C{ni}_ASM_PROLOGUE \\\n" + gen_c_prologue(ni).replace("\n", " \\\n") + "\n\n")
+            f.write(f"#define G4C{ni}_ASM_TILE \\\n" + gen_c_tile(ni, cfg).replace("\n", " \\\n") + "\n\n")
+            f.write(f"#define G4C{ni}_CLOBBERS " + c_clobbers(ni) + "\n\n")
         f.write(gen_readout() + "\n")
 
 

@@ -449,9 +449,9 @@ def test_gemm4w_generator_emits_a_consistent_instruction_stream(tmp_path):
 
 
 def test_conv4_generator_emits_a_consistent_instruction_stream(tmp_path):
-    """The convolution form of csrc/gen_gemm4.py (conv4_kernel in conv8.hip: 256 x 192 tile, gathered A pieces).  Per iteration: 96 MFMAs on
-    8 x 6 accumulator blocks, 28 fragment reads, 8 gathered A pieces -- each `buffer_load ... offen lds` preceded by its own M0 write and by the
-    three instructions that build its offset from the row offset, the row's inverted tap mask and this K-tile's table entry -- and 6 plain B
+    """The convolution form of csrc/gen_gemm4.py (conv4_kernel in conv8.hip: 256 x 192 tile, gathered A pieces).  Per iteration: 16 NI MFMAs on
+    8 x NI accumulator blocks (NI = 6: 256 x 192 tile, 3: 256 x 96), 2 (8 + NI) fragment reads, 8 gathered A pieces -- each `buffer_load ... offen lds` preceded by its own M0 write and by the
+    three instructions that build its offset from the row offset, the row's inverted tap mask and this K-tile's table entry -- and NI plain B
     pieces; one table read per iteration, behind the decode of the previous entry; the last pair takes the NEXT tile's rows; every named
     register lies inside the clobber list."""
     import re
@@ -461,20 +461,28 @@ def test_conv4_generator_emits_a_consistent_instruction_stream(tmp_path):
     out = tmp_path / "g4.inc"
     subprocess.run([sys.executable, os.path.join(root, "instageo-e2e-geospatial-ml_amd", "csrc", "gen_gemm4.py"), str(out)], check=True)
     text = out.read_text()
-    tile = re.findall(r'"([^"]*?)\\n\\t"', text[text.index("#define G4C_ASM_TILE"):text.index("#define G4C_CLOBBERS")])
-    pro = re.findall(r'"([^"]*?)\\n\\t"', text[text.index("#define G4C_ASM_PROLOGUE"):text.index("#define G4C_ASM_TILE")])
-    clob = text[text.index("#define G4C_CLOBBERS"):].split("\n", 1)[0]
+    for NI in (6, 3):
+        _check_conv4_blocks(text, NI)
+
+
+def _check_conv4_blocks(text, NI):
+    import re
+
+    tile = re.findall(r'"([^"]*?)\\n\\t"', text[text.index("#define G4C%d_ASM_TILE" % NI):text.index("#define G4C%d_CLOBBERS" % NI)])
+    pro = re.findall(r'"([^"]*?)\\n\\t"', text[text.index("#define G4C%d_ASM_PROLOGUE" % NI):text.index("#define G4C%d_ASM_TILE" % NI)])
+    clob = text[text.index("#define G4C%d_CLOBBERS" % NI):].split("\n", 1)[0]
     MF = "v_mfma_f32_16x16x32_bf16"
     mf = [i for i in tile if i.startswith(MF)]
-    assert len(mf) == 6 * 96 and all(i.endswith(", 0") for i in mf[:48]) and sum(1 for i in mf if i.endswith(", 0")) == 48
+    H = 8 * NI
+    assert len(mf) == 6 * 2 * H and all(i.endswith(", 0") for i in mf[:H]) and sum(1 for i in mf if i.endswith(", 0")) == H
     for it in range(6):
-        dst = sorted(int(re.match(MF + r" a\[(\d+):", i).group(1)) for i in mf[it * 96:(it + 1) * 96])
-        assert dst == sorted([(mi * 8 + ni) * 4 for mi in range(8) for ni in range(6)] * 2)
-    assert sum(1 for i in tile if i.startswith("ds_read_b128")) == 14 + 6 * 28
+        dst = sorted(int(re.match(MF + r" a\[(\d+):", i).group(1)) for i in mf[it * 2 * H:(it + 1) * 2 * H])
+        assert dst == sorted([(mi * 8 + ni) * 4 for mi in range(8) for ni in range(NI)] * 2)
+    assert sum(1 for i in tile if i.startswith("ds_read_b128")) == (8 + NI) + 6 * 2 * (8 + NI)
     assert sum(1 for i in tile if i.startswith("ds_read_b32")) == 1 + 6 and sum(1 for i in pro if i.startswith("ds_read_b32")) == 2
     ga = [k for k, i in enumerate(tile) if i.startswith("buffer_load_dwordx4")]
     gb = [k for k, i in enumerate(tile) if i.startswith("global_load_lds_dwordx4")]
-    assert len(ga) == 6 * 8 and len(gb) == 6 * 6
+    assert len(ga) == 6 * 8 and len(gb) == 6 * NI
     for k in ga + gb:
         assert tile[k - 2].startswith("s_add_u32 m0, ") and not tile[k - 1].startswith(("s_add_u32 m0", "buffer_load", "global_load")), tile[k - 2:k + 1]
     for n, k in enumerate(ga):  # the piece's offset register is written by bfe -> lshl_add -> add, in that order, before the issue

@@ -837,11 +837,13 @@ def test_conv8_engine_conv3x3(split, B, H, Cin, Cout, monkeypatch):
     ("conv", 3, 14, 384, 384), ("conv", 2, 9, 192, 192), ("conv", 1, 7, 576, 576), ("conv", 1, 5, 1152, 1152), ("conv", 1, 1, 192, 192),
     ("conv", 1, 2, 384, 192), ("conv", 2, 28, 384, 384),
     ("convT", 3, 14, 768, 384), ("convT", 2, 9, 384, 192), ("convT", 1, 13, 192, 96), ("convT", 1, 6, 2304, 1152), ("convT", 1, 1, 384, 192), ("convT", 2, 28, 384, 192),
+    ("conv", 2, 11, 96, 288), ("conv", 1, 14, 288, 288), ("conv", 1, 9, 96, 96), ("convT", 1, 13, 192, 96), ("convT", 1, 7, 576, 288),  # 256 x 96 tiles
 ])
 def test_conv4_equals_conv8_bit_for_bit(kind, B, H, Cin, Cout, monkeypatch):
     """conv4_kernel (conv8.hip: the 4-wave 256 x 192 form with a generated K-loop, A pieces gathered with three vector instructions of address
     arithmetic each) against conv8_kernel on the same packed weights and chunk table: Conv2d forward (+ bias, + eval BatchNorm / ReLU fold),
-    its data gradient (+ dropout mask), the ConvTranspose data gradient and forward (+ bias, + dropout), widths that tile by 192.  Same MFMA instruction in the same K
+    its data gradient (+ dropout mask), the ConvTranspose data gradient and forward (+ bias, + dropout), widths that tile by 192 (256 x 192
+    tiles) or by 96 (256 x 96).  Same MFMA instruction in the same K
     order, so the results must be IDENTICAL; the float64 comparison of conv8 itself is test_conv8_engine_*."""
     monkeypatch.setenv("IG_CONV8", "2")
     monkeypatch.setenv("IG_CONV_DIRECT", "0")
@@ -856,7 +858,7 @@ def test_conv4_equals_conv8_bit_for_bit(kind, B, H, Cin, Cout, monkeypatch):
             w, _ = bt(rnd(Cout, Cin, 3, 3, seed=27, scale=(9 * Cin) ** -0.5).permute(0, 2, 3, 1).reshape(Cout, 9, Cin).contiguous(), False)
             bias = rnd(Cout, seed=28).to(DEV)
             y = BT.zeros((B, H, W, Cout), False, DEV)
-            if Cout % 192 == 0:
+            if Cout % 96 == 0:
                 ops.conv3x3_fwd(x, w, bias, y, B, H, W, Cin, Cout)
                 assert ops.last_kernel().startswith(want), ops.last_kernel()
                 got.append(y.hi.clone())
@@ -864,7 +866,7 @@ def test_conv4_equals_conv8_bit_for_bit(kind, B, H, Cin, Cout, monkeypatch):
                 ops.conv3x3_fwd(x, w, bias, y, B, H, W, Cin, Cout, bn_scale=sc, bn_shift=sh)
                 assert ops.last_kernel().startswith(want), ops.last_kernel()
                 got.append(y.hi.clone())
-            if Cin % 192 == 0:
+            if Cin % 96 == 0:
                 dy, _ = bt(nhwc(rnd(B, Cout, H, W, seed=29)), False)
                 dx = BT.zeros((B, H, W, Cin), False, DEV)
                 ops.conv3x3_dgrad(dy, w, dx, B, H, W, Cin, Cout)
@@ -880,7 +882,7 @@ def test_conv4_equals_conv8_bit_for_bit(kind, B, H, Cin, Cout, monkeypatch):
             ops.convT_dgrad(dy, w, dx, B, H, W, Cin, Cout)
             assert ops.last_kernel().startswith(want), ops.last_kernel()
             got.append(dx.hi.clone())
-            if Cout % 192 == 0:  # forward: four sub-pixel phases (own tables, K lengths and row pitches) as tiles of one launch
+            if Cout % 96 == 0:  # forward: four sub-pixel phases (own tables, K lengths and row pitches) as tiles of one launch
                 x, _ = bt(nhwc(rnd(B, Cin, H, W, seed=30)), False)
                 bias = rnd(Cout, seed=32).to(DEV)
                 y = BT.zeros((B, 2 * H, 2 * W, Cout), False, DEV)
