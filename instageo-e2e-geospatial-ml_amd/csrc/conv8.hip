@@ -303,10 +303,10 @@ __global__ __launch_bounds__(128 * WC, 2) void conv8_kernel(C8Params p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
         asm volatile("s_barrier" ::: "memory");                                                                 \
         __builtin_amdgcn_s_setprio(1);                                                                          \
-        if constexpr (PAIR) { /* fragments [0] = hi, [1] = lo: hi hi, lo(B) hi(A), hi(B) lo(A) */                 \
+        if constexpr (PAIR) { /* fragments [0] = hi, [1] = lo: hi hi, hi(B) lo(A), lo(B) hi(A) -- conv4's order */                 \
             _Pragma("unroll") for (int t_ = 0; t_ < 3; ++t_) _Pragma("unroll") for (int nt_ = 0; nt_ < NTW; ++nt_) \
                 _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_)                                            \
-                    acc[HF][nt_][mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt_][t_ == 1], af[mt_][t_ == 2], acc[HF][nt_][mt_], 0, 0, 0); \
+                    acc[HF][nt_][mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt_][t_ == 2], af[mt_][t_ == 1], acc[HF][nt_][mt_], 0, 0, 0); \
         } else {                                                                                                \
         _Pragma("unroll") for (int nt_ = 0; nt_ < NTW; ++nt_) _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_) \
             _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                    \
@@ -469,9 +469,12 @@ __global__ __launch_bounds__(128 * WC, 2) void conv8_kernel(C8Params p) {
 constexpr int C4_OFF_TAB = 147456;  // 144 KiB: 3 x 32 KiB A slots, 2 x 24 KiB B stages, then the chunk table (32-word header + entries)
 constexpr int C4_TAB_MAX = 4096 - 32;
 
-template <int NI>  // 16-column blocks per wave: 6 = the 256 x 192 tile, 3 = 256 x 96 (N = 96, 288)
+// NI: 16-column blocks per wave: 6 = the 256 x 192 tile, 3 = 256 x 96 (N = 96, 288).  PAIR: the split precision mode (bf16x3) on paired K-tiles
+// (32 reduction elements, LDS row = [hi | lo], three products per K-tile: gen_gemm4.py "cp" form; operands and outputs are (hi, lo) pairs with
+// lo a 32-bit distance above hi, as conv8_kernel's NSEG = 2).
+template <int NI, bool PAIR = false>
 __global__ __launch_bounds__(256) void conv4_kernel(C8Params p) {
-    static_assert(NI == 6 || NI == 3, "conv4: 256 x 192 or 256 x 96 tiles");
+    static_assert(NI == 6 || (NI == 3 && !PAIR), "conv4: 256 x 192 or 256 x 96 tiles; the paired form has the 192-wide tile only");
     constexpr int BM = 256, BN = 32 * NI, WNC = 16 * NI, PITCH = WNC * 2 + 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -488,17 +491,19 @@ __global__ __launch_bounds__(256) void conv4_kernel(C8Params p) {
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_char_ptr)smem;
     int* phc = reinterpret_cast<int*>(smem + C4_OFF_TAB);  // 32-word header of per-phase constants, then the chunk table
     for (int i = tid; i < p.ktab_n + 32; i += 256) phc[i] = p.ktab[i];
-    const unsigned abytes = p.a_bytes;
+    const unsigned dA = PAIR ? (unsigned)((const char*)p.a[1] - (const char*)p.a[0]) : 0u;  // one descriptor spans hi and lo (the host checks)
+    const unsigned abytes = p.a_bytes + dA;
     const char* abase = (const char*)p.a[0];
-    // lane constants of the asm blocks (gen_gemm4.py: c_setup)
-    const unsigned sc = (lane & 7) ^ ((lane >> 3) & 7);  // source chunk of this lane's LDS chunk
-    const unsigned c16 = sc << 4;
+    // lane constants of the asm blocks (gen_gemm4.py: c_setup / cp_setup)
+    const unsigned sc = (lane & 7) ^ ((lane >> 3) & 7);  // source chunk of this lane's LDS chunk; paired: chunks 0-3 = hi, 4-7 = lo of the same 32 elements
+    const unsigned c16 = PAIR ? ((sc & 3) << 4) + (sc >= 4 ? (unsigned)((const char*)p.b[1] - (const char*)p.b[0]) : 0u) : sc << 4;
+    const unsigned aloadd = PAIR && sc >= 4 ? dA : 0u;
     const unsigned swz = ((lane >> 4) ^ (lane & 7)) << 4;
     const unsigned fa = lds_base + (wr * 128 + (lane & 15)) * 128 + swz;
     const unsigned fb = lds_base + (wc * WNC + (lane & 15)) * 128 + swz;
     const unsigned ldsw = lds_base + wave * 8192, ldswb = lds_base + wave * (NI * 1024);
     const unsigned browv = wave * (NI * 8) + (lane >> 3);
-    const unsigned vtl = lds_base + C4_OFF_TAB + 128 + sc * 4;  // this lane's entry of table position 0
+    const unsigned vtl = lds_base + C4_OFF_TAB + 128 + (PAIR ? sc & 3 : sc) * 4;  // this lane's entry of table position 0
     const int Hs = p.H * p.sm, Ws = p.W * p.sm;
     uint32_t drop_seed = p.drop_seed;
     if (p.drop_seed_dev) drop_seed += *p.drop_seed_dev;
@@ -514,7 +519,7 @@ __global__ __launch_bounds__(256) void conv4_kernel(C8Params p) {
     struct PhaseK { int nk, toff4, ldb2; const char* b; };
     auto phase_k = [&](int ph) {
         PhaseK k;
-        k.nk = __builtin_amdgcn_readfirstlane(phc[ph * 8]);
+        k.nk = __builtin_amdgcn_readfirstlane(phc[ph * 8]) * (PAIR ? 2 : 1);  // (paired: two 32-element K-tiles per table K-tile)
         k.toff4 = __builtin_amdgcn_readfirstlane(phc[ph * 8 + 1]) * 4;
         k.ldb2 = __builtin_amdgcn_readfirstlane(phc[ph * 8 + 2]) * 2;
         const long bo = (long)(unsigned)__builtin_amdgcn_readfirstlane(phc[ph * 8 + 3]) | ((long)__builtin_amdgcn_readfirstlane(phc[ph * 8 + 4]) << 32);
@@ -560,10 +565,11 @@ __global__ __launch_bounds__(256) void conv4_kernel(C8Params p) {
         const char* bptr = uni(k.b + (long)c_bn * BN * k.ldb2);
 #define C4_PRO_OPERANDS ::[abase] "s"(abase), [abytes] "s"(abytes), [bptr] "s"(bptr), [ldb2] "s"(k.ldb2), [ldsw] "s"(ldsw), \
                      [ldswb] "s"(ldswb), [nk] "s"(k.nk), [toff4] "s"(k.toff4), [a0] "s"(a0), [a1] "s"(a1), [a2] "s"(a2), [browv] "v"(browv), \
-                     [c16] "v"(c16), [fa] "v"(fa), [fb] "v"(fb), [vtl] "v"(vtl), [ro0] "v"(ro[0]), [ro1] "v"(ro[1]), [ro2] "v"(ro[2]), [ro3] "v"(ro[3]), \
+                     [c16] "v"(c16), [c16b] "v"(c16), [aloadd] "v"(aloadd), [fa] "v"(fa), [fb] "v"(fb), [vtl] "v"(vtl), [ro0] "v"(ro[0]), [ro1] "v"(ro[1]), [ro2] "v"(ro[2]), [ro3] "v"(ro[3]), \
                      [ro4] "v"(ro[4]), [ro5] "v"(ro[5]), [ro6] "v"(ro[6]), [ro7] "v"(ro[7]), [im0] "v"(im[0]), [im1] "v"(im[1]), [im2] "v"(im[2]), \
                      [im3] "v"(im[3]), [im4] "v"(im[4]), [im5] "v"(im[5]), [im6] "v"(im[6]), [im7] "v"(im[7])
-        if constexpr (NI == 6) asm volatile(G4C6_ASM_PROLOGUE C4_PRO_OPERANDS : G4C6_CLOBBERS);
+        if constexpr (PAIR) asm volatile(G4CP6_ASM_PROLOGUE C4_PRO_OPERANDS : G4CP6_CLOBBERS);
+        else if constexpr (NI == 6) asm volatile(G4C6_ASM_PROLOGUE C4_PRO_OPERANDS : G4C6_CLOBBERS);
         else asm volatile(G4C3_ASM_PROLOGUE C4_PRO_OPERANDS : G4C3_CLOBBERS);
 #undef C4_PRO_OPERANDS
     }
@@ -578,20 +584,21 @@ __global__ __launch_bounds__(256) void conv4_kernel(C8Params p) {
             for (int i = 0; i < 8; ++i) imn[i] = 0xffffffffu;
         }
         const PhaseK k = phase_k(ph), kn = phase_k(c_ph);
-        const char* bptr = uni(k.b + (long)bn * BN * k.ldb2 + 256);  // K-tile 2 (0 and 1 are in flight)
+        const char* bptr = uni(k.b + (long)bn * BN * k.ldb2 + (PAIR ? 128 : 256));  // K-tile 2 (0 and 1 are in flight)
         const char* bnext = uni(kn.b + (long)c_bn * BN * kn.ldb2);
         const int npair = (k.nk >> 1) - 2;
 #define C4_TILE_OPERANDS \
                      : [a0] "+s"(a0), [a1] "+s"(a1), [a2] "+s"(a2) \
                      : [abase] "s"(abase), [abytes] "s"(abytes), [bptr] "s"(bptr), [bnext] "s"(bnext), [ldb2] "s"(k.ldb2), [ldb2n] "s"(kn.ldb2), \
                        [ldsw] "s"(ldsw), [ldswb] "s"(ldswb), [nk] "s"(k.nk), [toff4] "s"(k.toff4), [toffn4] "s"(kn.toff4), [npair] "s"(npair), \
-                       [browv] "v"(browv), [c16] "v"(c16), [fa] "v"(fa), [fb] "v"(fb), [vtl] "v"(vtl), [ro0] "v"(ro[0]), [ro1] "v"(ro[1]), \
+                       [browv] "v"(browv), [c16] "v"(c16), [c16b] "v"(c16), [aloadd] "v"(aloadd), [fa] "v"(fa), [fb] "v"(fb), [vtl] "v"(vtl), [ro0] "v"(ro[0]), [ro1] "v"(ro[1]), \
                        [ro2] "v"(ro[2]), [ro3] "v"(ro[3]), [ro4] "v"(ro[4]), [ro5] "v"(ro[5]), [ro6] "v"(ro[6]), [ro7] "v"(ro[7]), [im0] "v"(im[0]), \
                        [im1] "v"(im[1]), [im2] "v"(im[2]), [im3] "v"(im[3]), [im4] "v"(im[4]), [im5] "v"(im[5]), [im6] "v"(im[6]), [im7] "v"(im[7]), \
                        [ron0] "v"(ron[0]), [ron1] "v"(ron[1]), [ron2] "v"(ron[2]), [ron3] "v"(ron[3]), [ron4] "v"(ron[4]), [ron5] "v"(ron[5]), \
                        [ron6] "v"(ron[6]), [ron7] "v"(ron[7]), [imn0] "v"(imn[0]), [imn1] "v"(imn[1]), [imn2] "v"(imn[2]), [imn3] "v"(imn[3]), \
                        [imn4] "v"(imn[4]), [imn5] "v"(imn[5]), [imn6] "v"(imn[6]), [imn7] "v"(imn[7])
-        if constexpr (NI == 6) asm volatile(G4C6_ASM_TILE C4_TILE_OPERANDS : G4C6_CLOBBERS);
+        if constexpr (PAIR) asm volatile(G4CP6_ASM_TILE C4_TILE_OPERANDS : G4CP6_CLOBBERS);
+        else if constexpr (NI == 6) asm volatile(G4C6_ASM_TILE C4_TILE_OPERANDS : G4C6_CLOBBERS);
         else asm volatile(G4C3_ASM_TILE C4_TILE_OPERANDS : G4C3_CLOBBERS);
 #undef C4_TILE_OPERANDS
         // ================= epilogue (the next tile's K-tiles 0 and 1 are in flight) =================
@@ -643,6 +650,12 @@ __global__ __launch_bounds__(256) void conv4_kernel(C8Params p) {
                 uint2 po;
                 po.x = pack_bf2(v[0], v[1]), po.y = pack_bf2(v[2], v[3]);
                 *reinterpret_cast<uint2*>(st + erow * PITCH + ni * 32 + eq * 8) = po;
+                if constexpr (PAIR) {  // split output: lo = bf16(v - hi) in the second slab
+                    uint2 pl;
+                    pl.x = pack_bf2(v[0] - __uint_as_float(po.x << 16), v[1] - __uint_as_float(po.x & 0xffff0000u));
+                    pl.y = pack_bf2(v[2] - __uint_as_float(po.y << 16), v[3] - __uint_as_float(po.y & 0xffff0000u));
+                    *reinterpret_cast<uint2*>(st + 16 * PITCH + erow * PITCH + ni * 32 + eq * 8) = pl;
+                }
             }
             constexpr int UPR = NI * 2, NU = 16 * UPR;  // sixteen-byte units per staged row, per row block
 #pragma unroll
@@ -651,8 +664,14 @@ __global__ __launch_bounds__(256) void conv4_kernel(C8Params p) {
                 if (NU % 64 == 0 || u < NU) {
                     const int r = u / UPR, ch = u - r * UPR;
                     const uint4 ux = *reinterpret_cast<const uint4*>(st + r * PITCH + ch * 16);
+                    uint4 ul = ux;
+                    if constexpr (PAIR) ul = *reinterpret_cast<const uint4*>(st + 16 * PITCH + r * PITCH + ch * 16);
                     const int m = m0 + r;
-                    if (m < p.M) *reinterpret_cast<uint4*>(p.out_hi + (size_t)out_row(m) * p.ldo + n0 + ch * 8) = ux;
+                    if (m < p.M) {
+                        const size_t o = (size_t)out_row(m) * p.ldo + n0 + ch * 8;
+                        *reinterpret_cast<uint4*>(p.out_hi + o) = ux;
+                        if constexpr (PAIR) *reinterpret_cast<uint4*>(p.out_lo + o) = ul;
+                    }
                 }
             }
         }
@@ -888,7 +907,13 @@ int ig_conv8(int kind, int sign, const void* x_hi, const void* x_lo, const void*
     {
         const char* e4 = getenv("IG_GEMM4");
         const int g4 = e4 ? atoi(e4) : 1;
-        bool ok4 = g4 && !w_lo && N % 96 == 0 && tent <= C4_TAB_MAX && a_bytes < 2147483648.0 - 16777216.0 && nt4 < (1L << 30);
+        bool ok4 = g4 && N % 96 == 0 && tent <= C4_TAB_MAX && a_bytes < 2147483648.0 - 16777216.0 && nt4 < (1L << 30);
+        if (w_lo) {  // the split mode: paired K-tiles on the 192-wide tile, hi and lo of the gathered tensor under ONE descriptor below 2 GiB
+            const char* ep = getenv("IG_G8_PAIR");
+            const long dA = (const char*)x_lo - (const char*)x_hi, dB = (long)(((size_t)elems * 2 + 255) / 256 * 256);
+            ok4 = ok4 && ni4 == 6 && (!ep || atoi(ep) != 0) && dA > 0 && !(dA & 15) && (double)dA + a_bytes < 2147483648.0 - 16777216.0 &&
+                  dB + (1L << 24) < (1L << 32);
+        }
         for (int ph = 0; ph < pl.nphase; ++ph) ok4 = ok4 && pl.kpad[ph] / 64 >= 4;
         use4 = ok4 && (g4 == 2 || nt4 >= slots - slots / 8);
     }
@@ -966,16 +991,18 @@ int ig_conv8(int kind, int sign, const void* x_hi, const void* x_lo, const void*
             static bool attr4_done = false;
             if (!attr4_done) {
                 if (hipFuncSetAttribute((const void*)conv4_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-                    hipFuncSetAttribute((const void*)conv4_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                    hipFuncSetAttribute((const void*)conv4_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                    hipFuncSetAttribute((const void*)conv4_kernel<6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                     ig_set_error("conv4: could not reserve 160 KiB of LDS");
                     return IG_ERR_HIP;
                 }
                 attr4_done = true;
             }
             const int grid4 = ig_tile_grid((int)nt4, 1);
-            ig_note_kernel("conv4_kernel<%d>", ni4);
+            ig_note_kernel(w_lo ? "conv4_kernel<%d,true>" : "conv4_kernel<%d>", ni4);
             ig_note_grid(grid4);
-            if (ni4 == 6) hipLaunchKernelGGL(conv4_kernel<6>, dim3(grid4), dim3(256), C4_OFF_TAB + (tent + 32) * 4, st, p);
+            if (w_lo) hipLaunchKernelGGL((conv4_kernel<6, true>), dim3(grid4), dim3(256), C4_OFF_TAB + (tent + 32) * 4, st, p);
+            else if (ni4 == 6) hipLaunchKernelGGL(conv4_kernel<6>, dim3(grid4), dim3(256), C4_OFF_TAB + (tent + 32) * 4, st, p);
             else hipLaunchKernelGGL(conv4_kernel<3>, dim3(grid4), dim3(256), C4_OFF_TAB + (tent + 32) * 4, st, p);
             return ig_check_launch("conv4");
         }

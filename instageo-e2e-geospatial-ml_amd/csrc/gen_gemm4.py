@@ -987,6 +987,202 @@ def c_clobbers(ni):
     return ", ".join(c)
 
 
+# ---- paired convolution form (conv4_kernel<6, PAIR>: the split precision mode bf16x3 of the wide head stages).  The forward paired form's
+# K-tile (32 reduction elements, LDS row = [hi | lo], three products on five quarter fragment sets) with the convolution form's gathered A
+# pieces: the lo lanes of a piece (source chunk >= 4) carry the hi -> lo tensor distance in `aloadd` / in their B offset, the table has four
+# entries per K-tile (16 bytes), the descriptor spans both tensors.
+CPV_TMP, CPV_FA, CPV_FB, CPV_AC, CPV_E = 54, 56, 58, 62, 63
+CPV_O, CPV_OFFB, CPV_TA, CPV_OFFB_N = 64, 72, 78, 80
+
+
+def cp_fbase_b(stage, s):
+    return f"v{CPV_FB + 2 * stage + s}"
+
+
+def cp_reads_a(base):
+    return [f"ds_read_b128 {pq(base, i)}, v{CPV_AC} offset:{i * 2048}" for i in range(8)]
+
+
+def cp_reads_b(ni, base, bstage, s):
+    return [f"ds_read_b128 {pq(base, i)}, {cp_fbase_b(bstage, s)} offset:{i * 2048}" for i in range(ni)]
+
+
+def cp_dmas_a(next_tile):
+    sfx = "n" if next_tile else ""
+    out = []
+    for i in range(8):
+        pre = [f"v_bfe_u32 v{CPV_O + i}, %[im{sfx}{i}], v{CPV_TMP + 1}, 1",
+               f"v_lshl_add_u32 v{CPV_O + i}, v{CPV_O + i}, 31, v{CPV_TMP}",
+               f"v_add_u32 v{CPV_O + i}, v{CPV_O + i}, %[ro{sfx}{i}]"]
+        out.append((pre, f"s_add_u32 m0, s{S_ADST}, {i * 1024}", f"buffer_load_dwordx4 v{CPV_O + i}, s[{CS_RSRC}:{CS_RSRC + 3}], 0 offen lds"))
+    return out
+
+
+def cp_dmas_b(ni, bstage, next_tile):
+    offb = CPV_OFFB_N if next_tile else CPV_OFFB
+    return [([], f"s_add_u32 m0, s{CS_LDSWB}, {CB_BASE + bstage * ni * 4096 + i * 1024}", f"global_load_lds_dwordx4 v{offb + i}, s[{S_BPTR}:{S_BPTR + 1}]")
+            for i in range(ni)]
+
+
+def cp_product(st, ni, bbase, abase, first, rd, dm, tail, cfg):
+    n = 8 * ni
+    extra = {j: [] for j in range(n)}
+    if cfg.get("abl_rd"):
+        rd = []
+    if cfg.get("abl_dma"):
+        dm = []
+    for k, r in enumerate(rd):
+        extra[k * (n - 4) // len(rd)].append(r)
+    for k, (pre, m0w, ld) in enumerate(dm):
+        j = 2 + k * (n - 4) // len(dm)
+        extra[j - 1].extend(pre)
+        extra[j].append(m0w)
+        extra[j + 1].insert(0, ld)
+    extra[n * 5 // 6].extend(tail)
+    j = 0
+    for b in range(ni):
+        for mi in range(8):
+            c = "0" if first else acc(mi, b)
+            st.e(f"v_mfma_f32_16x16x32_bf16 {acc(mi, b)}, {pq(bbase, b)}, {pq(abase, mi)}, {c}")
+            for x in extra[j]:
+                st.e(x)
+            j += 1
+
+
+def cp_entry_decode(st):
+    st.e(f"v_ashrrev_i32 v{CPV_TMP}, 8, v{CPV_E}")
+    st.e(f"v_lshlrev_b32 v{CPV_TMP}, 4, v{CPV_TMP}")
+    st.e(f"v_add_u32 v{CPV_TMP}, v{CPV_TMP}, %[aloadd]")   # lanes that fetch lo: + the distance of the lo tensor
+    st.e(f"v_and_b32 v{CPV_TMP + 1}, 31, v{CPV_E}")
+
+
+def cp_table_next():
+    return [f"s_add_u32 s{CS_TOFF}, s{CS_TOFF}, 16", f"s_sub_u32 s{CS_LEFT}, s{CS_LEFT}, 1", f"s_cmp_eq_u32 s{CS_LEFT}, 0",
+            f"s_cselect_b32 s{CS_TOFF}, %[toffn4], s{CS_TOFF}", f"s_cselect_b32 s{CS_LEFT}, s{CS_NK}, s{CS_LEFT}",
+            f"v_add_u32 v{CPV_TA}, s{CS_TOFF}, %[vtl]", f"ds_read_b32 v{CPV_E}, v{CPV_TA}"]
+
+
+def cp_iteration(st, ni, p, first, next_tile, cfg):
+    ahi_cur, ahi_nxt = PQ_AHI[p], PQ_AHI[p ^ 1]
+    st.e(f"s_add_u32 s{S_ADST}, s{S_LDSW}, s{S_A2}")
+    cp_entry_decode(st)
+    cp_product(st, ni, PQ_BHI, ahi_cur, first, cp_reads_b(ni, PQ_BLO, p, 1), cp_dmas_a(next_tile), [], cfg)
+    st.e("s_waitcnt lgkmcnt(0)")
+    if not cfg.get("abl_vmw"):
+        st.e("s_waitcnt vmcnt(8)")
+    if not cfg.get("abl_bar"):
+        st.e("s_barrier")
+    st.e(f"v_add_u32 v{CPV_AC}, s{S_A1}, v{CPV_FA}")        # A of K-tile kt + 1, hi half
+    bd = cp_dmas_b(ni, p, next_tile)
+    cp_product(st, ni, PQ_BHI, PQ_ALO, False, cp_reads_a(ahi_nxt), bd[:ni // 2], [], cfg)
+    st.e(f"v_add_u32 v{CPV_AC}, s{S_A1}, v{CPV_FA + 1}")    # ... lo half (the reads above have been issued)
+    cp_product(st, ni, PQ_BLO, ahi_cur, False, cp_reads_b(ni, PQ_BHI, p ^ 1, 0) + cp_reads_a(PQ_ALO), bd[ni // 2:], cp_table_next(), cfg)
+    for a in p_advance(S_BPTR):
+        st.e(a)
+    st.e(f"s_mov_b32 s{S_T}, s{S_A0}")
+    st.e(f"s_mov_b32 s{S_A0}, s{S_A1}")
+    st.e(f"s_mov_b32 s{S_A1}, s{S_A2}")
+    st.e(f"s_mov_b32 s{S_A2}, s{S_T}")
+    st.e("s_waitcnt lgkmcnt(0)")
+
+
+def cp_setup(st, ni, with_next):
+    for i in range(ni):
+        st.e(f"v_add_u32 v{CPV_TMP}, {8 * i}, %[browv]")
+        st.e(f"v_mad_u32_u24 v{CPV_OFFB + i}, v{CPV_TMP}, %[ldb2], %[c16b]")
+        if with_next:
+            st.e(f"v_mad_u32_u24 v{CPV_OFFB_N + i}, v{CPV_TMP}, %[ldb2n], %[c16b]")
+    st.e(f"v_mov_b32 v{CPV_FA}, %[fa]")
+    st.e(f"v_xor_b32 v{CPV_FA + 1}, 64, %[fa]")
+    for b in (0, 1):
+        st.e(f"v_add_u32 {cp_fbase_b(b, 0)}, {CB_BASE + b * ni * 4096}, %[fb]")
+        st.e(f"v_xor_b32 {cp_fbase_b(b, 1)}, 64, {cp_fbase_b(b, 0)}")
+    st.e(f"s_mov_b32 s{S_LDSW}, %[ldsw]")
+    st.e(f"s_mov_b32 s{S_A0}, %[a0]")
+    st.e(f"s_mov_b32 s{S_A1}, %[a1]")
+    st.e(f"s_mov_b32 s{S_A2}, %[a2]")
+    st.e(f"s_mov_b64 s[{CS_RSRC}:{CS_RSRC + 1}], %[abase]")
+    st.e(f"s_mov_b32 s{CS_RSRC + 2}, %[abytes]")
+    st.e(f"s_mov_b32 s{CS_RSRC + 3}, 0x00020000")
+    st.e(f"s_mov_b32 s{CS_NK}, %[nk]")
+    st.e(f"s_mov_b32 s{CS_LDSWB}, %[ldswb]")
+
+
+def gen_cp_prologue(ni):
+    st = Stream()
+    cp_setup(st, ni, False)
+    st.e(f"s_mov_b64 s[{S_BPTR}:{S_BPTR + 1}], %[bptr]")
+    st.e(f"v_add_u32 v{CPV_TA}, %[toff4], %[vtl]")
+    for k, slot in enumerate((S_A0, S_A1)):
+        st.e(f"ds_read_b32 v{CPV_E}, v{CPV_TA} offset:{16 * k}")
+        st.e("s_waitcnt lgkmcnt(0)")
+        cp_entry_decode(st)
+        st.e(f"s_add_u32 s{S_ADST}, s{S_LDSW}, s{slot}")
+        for pre, m0w, ld in cp_dmas_a(False) + cp_dmas_b(ni, k, False):
+            for x in pre:
+                st.e(x)
+            st.e(m0w)
+            st.e("s_nop 0")
+            st.e(ld)
+        for a in p_advance(S_BPTR):
+            st.e(a)
+    return st.text()
+
+
+def gen_cp_tile(ni, cfg):
+    """one tile of the paired form: nk = its 32-element K-tiles (a multiple of 4), bptr on K-tile 2, toff4 = byte offset of its table"""
+    st = Stream()
+    cp_setup(st, ni, True)
+    st.e(f"s_mov_b64 s[{S_BPTR}:{S_BPTR + 1}], %[bptr]")
+    st.e(f"s_mov_b32 s{S_CNT}, %[npair]")
+    st.e(f"s_add_u32 s{CS_TOFF}, %[toff4], 32")        # the first iteration issues K-tile 2 (16 bytes of table per K-tile)
+    st.e(f"s_sub_u32 s{CS_LEFT}, s{CS_NK}, 2")
+    st.e(f"v_add_u32 v{CPV_TA}, s{CS_TOFF}, %[vtl]")
+    st.e(f"ds_read_b32 v{CPV_E}, v{CPV_TA}")
+    st.e("s_waitcnt vmcnt(0)")
+    st.e("s_barrier")
+    st.e(f"v_add_u32 v{CPV_AC}, s{S_A0}, v{CPV_FA}")
+    for r in cp_reads_a(PQ_AHI[0]):
+        st.e(r)
+    st.e(f"v_add_u32 v{CPV_AC}, s{S_A0}, v{CPV_FA + 1}")
+    for r in cp_reads_a(PQ_ALO) + cp_reads_b(ni, PQ_BHI, 0, 0):
+        st.e(r)
+    st.e("s_waitcnt lgkmcnt(0)")
+    cp_iteration(st, ni, 0, True, False, cfg)
+    cp_iteration(st, ni, 1, False, False, cfg)
+    st.e(f"s_cmp_eq_u32 s{S_CNT}, 0")
+    st.e("s_cbranch_scc1 L_last_%=")
+    st.e("L_loop_%=:")
+    cp_iteration(st, ni, 0, False, False, cfg)
+    cp_iteration(st, ni, 1, False, False, cfg)
+    st.e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
+    st.e(f"s_cmp_lg_u32 s{S_CNT}, 0")
+    st.e("s_cbranch_scc1 L_loop_%=")
+    st.e("L_last_%=:")
+    st.e(f"s_mov_b64 s[{S_BPTR}:{S_BPTR + 1}], %[bnext]")
+    cp_iteration(st, ni, 0, False, True, cfg)
+    cp_iteration(st, ni, 1, False, True, cfg)
+    st.e(f"s_mov_b32 %[a0], s{S_A0}")
+    st.e(f"s_mov_b32 %[a1], s{S_A1}")
+    st.e(f"s_mov_b32 %[a2], s{S_A2}")
+    st.e("s_nop 15")
+    st.e("s_nop 15")
+    return st.text()
+
+
+def cp_clobbers(ni):
+    c = ['"memory"', '"scc"', '"m0"']
+    c += [f'"a{i}"' for i in range(256)]
+    used = set(range(CPV_TMP, CPV_OFFB + ni)) | {CPV_TA} | set(range(CPV_OFFB_N, CPV_OFFB_N + ni))
+    for base in (PQ_AHI[0], PQ_AHI[1], PQ_ALO):
+        used |= set(range(base, base + 32))
+    for base in (PQ_BHI, PQ_BLO):
+        used |= set(range(base, base + 4 * ni))
+    c += [f'"v{i}"' for i in sorted(used)]
+    c += [f'"s{i}"' for i in range(CS_LO, CS_HI + 1)]
+    return ", ".join(c)
+
+
 def clobbers():
     c = ['"memory"', '"scc"', '"m0"']
     c += [f'"a{i}"' for i in range(256)]
@@ -1043,6 +1239,9 @@ def main():
             f.write(f"#define G4C{ni}_ASM_PROLOGUE \\\n" + gen_c_prologue(ni).replace("\n", " \\\n") + "\n\n")
             f.write(f"#define G4C{ni}_ASM_TILE \\\n" + gen_c_tile(ni, cfg).replace("\n", " \\\n") + "\n\n")
             f.write(f"#define G4C{ni}_CLOBBERS " + c_clobbers(ni) + "\n\n")
+        f.write("#define G4CP6_ASM_PROLOGUE \\\n" + gen_cp_prologue(6).replace("\n", " \\\n") + "\n\n")
+        f.write("#define G4CP6_ASM_TILE \\\n" + gen_cp_tile(6, cfg).replace("\n", " \\\n") + "\n\n")
+        f.write("#define G4CP6_CLOBBERS " + cp_clobbers(6) + "\n\n")
         f.write(gen_readout() + "\n")
 
 

@@ -833,20 +833,23 @@ def test_conv8_engine_conv3x3(split, B, H, Cin, Cout, monkeypatch):
     close(dxd.float(), dxo.float().double().cpu(), tol_out(split), what="conv8 dgrad with dropout vs the gather GEMM")
 
 
+@pytest.mark.parametrize("split", SPLITS)
 @pytest.mark.parametrize("kind,B,H,Cin,Cout", [
     ("conv", 3, 14, 384, 384), ("conv", 2, 9, 192, 192), ("conv", 1, 7, 576, 576), ("conv", 1, 5, 1152, 1152), ("conv", 1, 1, 192, 192),
     ("conv", 1, 2, 384, 192), ("conv", 2, 28, 384, 384),
     ("convT", 3, 14, 768, 384), ("convT", 2, 9, 384, 192), ("convT", 1, 13, 192, 96), ("convT", 1, 6, 2304, 1152), ("convT", 1, 1, 384, 192), ("convT", 2, 28, 384, 192),
     ("conv", 2, 11, 96, 288), ("conv", 1, 14, 288, 288), ("convT", 1, 13, 192, 96), ("convT", 1, 7, 576, 288),  # 256 x 96 tiles
 ])
-def test_conv4_equals_conv8_bit_for_bit(kind, B, H, Cin, Cout, monkeypatch):
+def test_conv4_equals_conv8_bit_for_bit(split, kind, B, H, Cin, Cout, monkeypatch):
     """conv4_kernel (conv8.hip: the 4-wave 256 x 192 form with a generated K-loop, A pieces gathered with three vector instructions of address
     arithmetic each) against conv8_kernel on the same packed weights and chunk table: Conv2d forward (+ bias, + eval BatchNorm / ReLU fold),
     its data gradient (+ dropout mask), the ConvTranspose data gradient and forward (+ bias, + dropout), widths that tile by 192 (256 x 192
-    tiles) or by 96 (256 x 96).  Same MFMA instruction in the same K
+    tiles) or by 96 (256 x 96), plain and -- 192-wide -- the paired split form.  Same MFMA instruction in the same K (and hi / lo product)
     order, so the results must be IDENTICAL; the float64 comparison of conv8 itself is test_conv8_engine_*."""
     monkeypatch.setenv("IG_CONV8", "2")
     monkeypatch.setenv("IG_CONV_DIRECT", "0")
+    if split and (Cin % 192 or Cout % 192):
+        pytest.skip("the paired form has the 192-wide tile only")
     W = H + 3
     outs = {}
     for arm in ("0", "2"):
@@ -854,45 +857,59 @@ def test_conv4_equals_conv8_bit_for_bit(kind, B, H, Cin, Cout, monkeypatch):
         want = "conv4_kernel" if arm == "2" else "conv8_kernel"
         got = []
         if kind == "conv":
-            x, _ = bt(nhwc(rnd(B, Cin, H, W, seed=26)), False)
-            w, _ = bt(rnd(Cout, Cin, 3, 3, seed=27, scale=(9 * Cin) ** -0.5).permute(0, 2, 3, 1).reshape(Cout, 9, Cin).contiguous(), False)
+            x, _ = bt(nhwc(rnd(B, Cin, H, W, seed=26)), split)
+            w, _ = bt(rnd(Cout, Cin, 3, 3, seed=27, scale=(9 * Cin) ** -0.5).permute(0, 2, 3, 1).reshape(Cout, 9, Cin).contiguous(), split)
             bias = rnd(Cout, seed=28).to(DEV)
-            y = BT.zeros((B, H, W, Cout), False, DEV)
+            y = BT.zeros((B, H, W, Cout), split, DEV)
             if Cout % 96 == 0:
                 ops.conv3x3_fwd(x, w, bias, y, B, H, W, Cin, Cout)
                 assert ops.last_kernel().startswith(want), ops.last_kernel()
                 got.append(y.hi.clone())
+                if split:
+                    got.append(y.lo.clone())
                 sc, sh = (rnd(Cout, seed=61).abs() + 0.5).to(DEV), rnd(Cout, seed=62).to(DEV)
                 ops.conv3x3_fwd(x, w, bias, y, B, H, W, Cin, Cout, bn_scale=sc, bn_shift=sh)
                 assert ops.last_kernel().startswith(want), ops.last_kernel()
                 got.append(y.hi.clone())
+                if split:
+                    got.append(y.lo.clone())
             if Cin % 96 == 0:
-                dy, _ = bt(nhwc(rnd(B, Cout, H, W, seed=29)), False)
-                dx = BT.zeros((B, H, W, Cin), False, DEV)
+                dy, _ = bt(nhwc(rnd(B, Cout, H, W, seed=29)), split)
+                dx = BT.zeros((B, H, W, Cin), split, DEV)
                 ops.conv3x3_dgrad(dy, w, dx, B, H, W, Cin, Cout)
                 assert ops.last_kernel().startswith(want), ops.last_kernel()
                 got.append(dx.hi.clone())
+                if split:
+                    got.append(dx.lo.clone())
                 ops.conv3x3_dgrad(dy, w, dx, B, H, W, Cin, Cout, seed=1234, p=0.1)
                 assert ops.last_kernel().startswith(want), ops.last_kernel()
                 got.append(dx.hi.clone())
+                if split:
+                    got.append(dx.lo.clone())
         else:
-            w, _ = bt(rnd(Cin, Cout, 3, 3, seed=31, scale=(2.25 * Cin) ** -0.5).permute(1, 2, 3, 0).reshape(Cout, 9, Cin).contiguous(), False)
-            dy, _ = bt(nhwc(rnd(B, Cout, 2 * H, 2 * W, seed=33)), False)
-            dx = BT.zeros((B, H, W, Cin), False, DEV)
+            w, _ = bt(rnd(Cin, Cout, 3, 3, seed=31, scale=(2.25 * Cin) ** -0.5).permute(1, 2, 3, 0).reshape(Cout, 9, Cin).contiguous(), split)
+            dy, _ = bt(nhwc(rnd(B, Cout, 2 * H, 2 * W, seed=33)), split)
+            dx = BT.zeros((B, H, W, Cin), split, DEV)
             ops.convT_dgrad(dy, w, dx, B, H, W, Cin, Cout)
             assert ops.last_kernel().startswith(want), ops.last_kernel()
             got.append(dx.hi.clone())
+            if split:
+                got.append(dx.lo.clone())
             if Cout % 96 == 0:  # forward: four sub-pixel phases (own tables, K lengths and row pitches) as tiles of one launch
-                x, _ = bt(nhwc(rnd(B, Cin, H, W, seed=30)), False)
+                x, _ = bt(nhwc(rnd(B, Cin, H, W, seed=30)), split)
                 bias = rnd(Cout, seed=32).to(DEV)
-                y = BT.zeros((B, 2 * H, 2 * W, Cout), False, DEV)
+                y = BT.zeros((B, 2 * H, 2 * W, Cout), split, DEV)
                 ops.convT_fwd(x, w, bias, y, B, H, W, Cin, Cout)
                 assert ops.last_kernel().startswith(want), ops.last_kernel()
                 got.append(y.hi.clone())
+                if split:
+                    got.append(y.lo.clone())
                 y.hi.zero_()
                 ops.convT_fwd(x, w, bias, y, B, H, W, Cin, Cout, seed=77, p=0.1)
                 assert ops.last_kernel().startswith(want), ops.last_kernel()
                 got.append(y.hi.clone())
+                if split:
+                    got.append(y.lo.clone())
         assert got
         outs[arm] = got
     for i, (a, b) in enumerate(zip(outs["0"], outs["2"])):
