@@ -463,6 +463,32 @@ def test_conv4_generator_emits_a_consistent_instruction_stream(tmp_path):
     text = out.read_text()
     for NI in (6, 3):
         _check_conv4_blocks(text, NI)
+    # ---- the paired split form (256 x 192 tile): three products of 48 MFMAs per 32-element K-tile on five quarter sets
+    import re as _re
+    pt = _re.findall(r'"([^"]*?)\\n\\t"', text[text.index("#define G4CP6_ASM_TILE"):text.index("#define G4CP6_CLOBBERS")])
+    pclob = text[text.index("#define G4CP6_CLOBBERS"):].split("\n", 1)[0]
+    MF = "v_mfma_f32_16x16x32_bf16"
+    pmf = [k for k, i in enumerate(pt) if i.startswith(MF)]
+    assert len(pmf) == 6 * 3 * 48 and all(pt[k].endswith(", 0") for k in pmf[:48]) and sum(1 for k in pmf if pt[k].endswith(", 0")) == 48
+    assert sum(1 for i in pt if i.startswith("ds_read_b128")) == (8 + 8 + 6) + 6 * (6 + 8 + 6 + 8)
+    assert sum(1 for i in pt if i.startswith("buffer_load_dwordx4")) == 6 * 8 and sum(1 for i in pt if i.startswith("global_load_lds_dwordx4")) == 6 * 6
+    assert sum(1 for i in pt if i.startswith("ds_read_b32")) == 7 and sum(1 for i in pt if i == "s_barrier") == 7
+    pcv = {int(x) for x in _re.findall(r'"v(\d+)"', pclob)}
+    for i in pt:
+        body = _re.sub(r"%\[[a-z0-9_]+\]", "", i)
+        for lo, hi in _re.findall(r"\bv\[(\d+):(\d+)\]", body):
+            assert set(range(int(lo), int(hi) + 1)) <= pcv, i
+        for r in _re.findall(r"\bv(\d+)\b", body):
+            assert int(r) in pcv, i
+    for b in range(0, len(pmf), 48):  # a product's reads never write a quarter set its own MFMAs consume
+        used = set()
+        for k in pmf[b:b + 48]:
+            m = _re.match(MF + r" a\[\d+:\d+\], v\[(\d+):\d+\], v\[(\d+):\d+\]", pt[k])
+            used |= {int(m.group(1)), int(m.group(2))}
+        for i in pt[pmf[b]:pmf[b + 47] + 1]:
+            m = _re.match(r"ds_read_b128 v\[(\d+):", i)
+            if m:
+                assert int(m.group(1)) not in used, (i, b // 48)
 
 
 def _check_conv4_blocks(text, NI):
