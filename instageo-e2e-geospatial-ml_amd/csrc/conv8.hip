@@ -19,6 +19,8 @@
 // * The four sub-pixel phases of a ConvTranspose forward are tiles of ONE persistent launch with their own K length; a row
 //   tile's phases and column tiles are neighbours in the tile list, so the XCD that owns them reads x once; the phase a
 //   workgroup gets rotates with the row tile, so every workgroup sees the 1-, 2- and 4-tap tiles equally often.
+// * conv4_kernel<NI, PAIR> (round 6, further down): the same implicit GEMM on FOUR waves (256 x 192 / 256 x 96 tiles) with a generated
+//   assembly K-loop; it takes the launches whose width tiles by 192 or 96, conv8_kernel the rest (144 / 128 / 256-wide, small launches).
 #include <stdlib.h>
 
 #include "common.h"

@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Generator of the hand-scheduled K-loop of gemm4.hip (the 4-wave, one-wave-per-SIMD form of the forward linear GEMM, pritvhi.py:446-456).
+"""Generator of the hand-scheduled K-loops of the 4-wave, one-wave-per-SIMD kernels: gemm4.hip (forward linears and data gradients,
+pritvhi.py:446-456; plain and paired-split forms), gemm4w_kernel in gemm8w.hip (grouped weight gradients: the "w" / "wp" forms below) and
+conv4_kernel in conv8.hip (the decode head's 3 x 3 convolutions, model.py:349-390: the "c" / "cp" forms).  The first section documents the
+forward form; every other form is described where its functions start.
 
 hipcc cannot hold 256 accumulators + 128 fragment registers of a 128 x 128-per-wave tile without spilling (rounds 2 and 5), so the K-loop of a
 tile is ONE inline-asm block with hand-assigned registers; this script writes it (`gemm4_gen.inc`: string macros for the prologue and the tile
