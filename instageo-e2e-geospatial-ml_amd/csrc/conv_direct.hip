@@ -1597,7 +1597,8 @@ int ig_conv3x3_direct(const void* x, const void* w, const float* bias, const flo
                       int B, int H, int W, int Cin, int Cout, int dgrad, unsigned drop_seed, const unsigned* drop_seed_dev,
                       float drop_p, void* stream, double* stat_sums, int* stats_fused) {
     if (stats_fused) *stats_fused = 0;
-    static const int enabled = getenv("IG_CONV_DIRECT") ? atoi(getenv("IG_CONV_DIRECT")) : 1;
+    const char* e_dir = getenv("IG_CONV_DIRECT");  // read per call, like every engine switch (tests set it for single calls)
+    const int enabled = e_dir ? atoi(e_dir) : 1;
     if (!enabled || Cin != Cout || (Cin != 48 && Cin != 96)) return IG_ERR_UNSUPPORTED;
     if ((long)B * H * W * Cin >= (1L << 31)) return IG_ERR_UNSUPPORTED;  // 32-bit halo offsets
     CDParams p{};
@@ -1652,7 +1653,8 @@ int ig_conv3x3_direct_split(const void* x_hi, const void* x_lo, const void* w_hi
                             const float* bn_shift, void* y_hi, void* y_lo, int B, int H, int W, int Cin, int Cout, int dgrad, unsigned drop_seed,
                             const unsigned* drop_seed_dev, float drop_p, void* stream, double* stat_sums, int* stats_fused) {
     if (stats_fused) *stats_fused = 0;
-    static const int enabled = getenv("IG_CONV_DIRECT") ? atoi(getenv("IG_CONV_DIRECT")) : 1;
+    const char* e_dir = getenv("IG_CONV_DIRECT");  // read per call, like every engine switch (tests set it for single calls)
+    const int enabled = e_dir ? atoi(e_dir) : 1;
     if (!enabled || Cin != Cout || Cin != 48 || !x_lo || !w_lo || !y_lo) return IG_ERR_UNSUPPORTED;
     if ((long)B * H * W * Cin >= (1L << 31)) return IG_ERR_UNSUPPORTED;  // 32-bit halo offsets
     CDParams p{};
@@ -1675,7 +1677,8 @@ int ig_conv3x3_direct_split(const void* x_hi, const void* x_lo, const void* w_hi
 // Called by ig_conv3x3_wgrad (gemm.hip); IG_ERR_UNSUPPORTED when the shape is not covered.
 int ig_conv3x3_wgrad_direct(const void* dy, const void* x, float* dw, float* dbias, int* bias_fused, int B, int H, int W, int Cin,
                             int Cout, void* stream) {
-    static const int enabled = getenv("IG_CONV_DIRECT") ? atoi(getenv("IG_CONV_DIRECT")) : 1;
+    const char* e_dir = getenv("IG_CONV_DIRECT");  // read per call, like every engine switch (tests set it for single calls)
+    const int enabled = e_dir ? atoi(e_dir) : 1;
     *bias_fused = 0;
     if (!enabled || Cout % 48 != 0 || (Cin != 48 && Cin != 96 && Cin != 192)) return IG_ERR_UNSUPPORTED;
     if ((long)B * H * W * (Cin > Cout ? Cin : Cout) >= (1L << 31)) return IG_ERR_UNSUPPORTED;
@@ -1717,7 +1720,8 @@ int ig_conv3x3_wgrad_direct(const void* dy, const void* x, float* dw, float* dbi
 // Called by ig_convT_fwd (gemm.hip); IG_ERR_UNSUPPORTED when the shape is not covered.
 int ig_convT_fwd_direct(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,
                         unsigned drop_seed, const unsigned* drop_seed_dev, float drop_p, void* stream) {
-    static const int enabled = getenv("IG_CONV_DIRECT") ? atoi(getenv("IG_CONV_DIRECT")) : 1;
+    const char* e_dir = getenv("IG_CONV_DIRECT");  // read per call, like every engine switch (tests set it for single calls)
+    const int enabled = e_dir ? atoi(e_dir) : 1;
     if (!enabled || Cin != 96 || Cout != 48) return IG_ERR_UNSUPPORTED;
     if ((long)B * H * W * Cin >= (1L << 31)) return IG_ERR_UNSUPPORTED;
     CTParams p{};
@@ -1752,7 +1756,8 @@ int ig_convT_fwd_direct(const void* x, const void* w, const float* bias, void* y
 int ig_convT_wgrad_direct(const void* dy, const void* x, float* dw, float* dbias, int* bias_fused, int B, int H, int W, int Cin,
                           int Cout, void* stream) {
     *bias_fused = 0;
-    static const int enabled = getenv("IG_CONV_DIRECT") ? atoi(getenv("IG_CONV_DIRECT")) : 1;
+    const char* e_dir = getenv("IG_CONV_DIRECT");  // read per call, like every engine switch (tests set it for single calls)
+    const int enabled = e_dir ? atoi(e_dir) : 1;
     if (!enabled || Cin != 96 || Cout != 48) return IG_ERR_UNSUPPORTED;
     if ((long)B * H * W * 4 * Cout >= (1L << 31)) return IG_ERR_UNSUPPORTED;
     CTWParams p{};
@@ -1783,7 +1788,8 @@ int ig_convT_wgrad_direct(const void* dy, const void* x, float* dw, float* dbias
 
 // Called by ig_convT_dgrad (gemm.hip); IG_ERR_UNSUPPORTED when the shape is not covered.
 int ig_convT_dgrad_direct(const void* dy, const void* w, void* dx, int B, int H, int W, int Cin, int Cout, void* stream) {
-    static const int enabled = getenv("IG_CONV_DIRECT") ? atoi(getenv("IG_CONV_DIRECT")) : 1;
+    const char* e_dir = getenv("IG_CONV_DIRECT");  // read per call, like every engine switch (tests set it for single calls)
+    const int enabled = e_dir ? atoi(e_dir) : 1;
     if (!enabled || Cin != 96 || Cout != 48) return IG_ERR_UNSUPPORTED;
     if ((long)B * H * W * 4 * Cout >= (1L << 31)) return IG_ERR_UNSUPPORTED;
     CTDParams p{};

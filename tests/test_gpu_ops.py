@@ -838,7 +838,7 @@ def test_conv8_engine_conv3x3(split, B, H, Cin, Cout, monkeypatch):
     ("conv", 3, 14, 384, 384), ("conv", 2, 9, 192, 192), ("conv", 1, 7, 576, 576), ("conv", 1, 5, 1152, 1152), ("conv", 1, 1, 192, 192),
     ("conv", 1, 2, 384, 192), ("conv", 2, 28, 384, 384),
     ("convT", 3, 14, 768, 384), ("convT", 2, 9, 384, 192), ("convT", 1, 13, 192, 96), ("convT", 1, 6, 2304, 1152), ("convT", 1, 1, 384, 192), ("convT", 2, 28, 384, 192),
-    ("conv", 2, 11, 96, 288), ("conv", 1, 14, 288, 288), ("convT", 1, 13, 192, 96), ("convT", 1, 7, 576, 288),  # 256 x 96 tiles
+    ("conv", 2, 11, 96, 288), ("conv", 1, 14, 288, 288), ("conv", 1, 9, 96, 96), ("convT", 1, 13, 192, 96), ("convT", 1, 7, 576, 288),  # 256 x 96 tiles
 ])
 def test_conv4_equals_conv8_bit_for_bit(split, kind, B, H, Cin, Cout, monkeypatch):
     """conv4_kernel (conv8.hip: the 4-wave 256 x 192 form with a generated K-loop, A pieces gathered with three vector instructions of address
