@@ -476,7 +476,7 @@ constexpr int C4_TAB_MAX = 4096 - 32;
 // lo a 32-bit distance above hi, as conv8_kernel's NSEG = 2).
 template <int NI, bool PAIR = false>
 __global__ __launch_bounds__(256) void conv4_kernel(C8Params p) {
-    static_assert(NI == 6 || (NI == 3 && !PAIR), "conv4: 256 x 192 or 256 x 96 tiles; the paired form has the 192-wide tile only");
+    static_assert(NI == 6 || NI == 3, "conv4: 256 x 192 or 256 x 96 tiles");
     constexpr int BM = 256, BN = 32 * NI, WNC = 16 * NI, PITCH = WNC * 2 + 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -570,7 +570,8 @@ __global__ __launch_bounds__(256) void conv4_kernel(C8Params p) {
                      [c16] "v"(c16), [c16b] "v"(c16), [aloadd] "v"(aloadd), [fa] "v"(fa), [fb] "v"(fb), [vtl] "v"(vtl), [ro0] "v"(ro[0]), [ro1] "v"(ro[1]), [ro2] "v"(ro[2]), [ro3] "v"(ro[3]), \
                      [ro4] "v"(ro[4]), [ro5] "v"(ro[5]), [ro6] "v"(ro[6]), [ro7] "v"(ro[7]), [im0] "v"(im[0]), [im1] "v"(im[1]), [im2] "v"(im[2]), \
                      [im3] "v"(im[3]), [im4] "v"(im[4]), [im5] "v"(im[5]), [im6] "v"(im[6]), [im7] "v"(im[7])
-        if constexpr (PAIR) asm volatile(G4CP6_ASM_PROLOGUE C4_PRO_OPERANDS : G4CP6_CLOBBERS);
+        if constexpr (PAIR && NI == 6) asm volatile(G4CP6_ASM_PROLOGUE C4_PRO_OPERANDS : G4CP6_CLOBBERS);
+        else if constexpr (PAIR) asm volatile(G4CP3_ASM_PROLOGUE C4_PRO_OPERANDS : G4CP3_CLOBBERS);
         else if constexpr (NI == 6) asm volatile(G4C6_ASM_PROLOGUE C4_PRO_OPERANDS : G4C6_CLOBBERS);
         else asm volatile(G4C3_ASM_PROLOGUE C4_PRO_OPERANDS : G4C3_CLOBBERS);
 #undef C4_PRO_OPERANDS
@@ -599,7 +600,8 @@ __global__ __launch_bounds__(256) void conv4_kernel(C8Params p) {
                        [ron0] "v"(ron[0]), [ron1] "v"(ron[1]), [ron2] "v"(ron[2]), [ron3] "v"(ron[3]), [ron4] "v"(ron[4]), [ron5] "v"(ron[5]), \
                        [ron6] "v"(ron[6]), [ron7] "v"(ron[7]), [imn0] "v"(imn[0]), [imn1] "v"(imn[1]), [imn2] "v"(imn[2]), [imn3] "v"(imn[3]), \
                        [imn4] "v"(imn[4]), [imn5] "v"(imn[5]), [imn6] "v"(imn[6]), [imn7] "v"(imn[7])
-        if constexpr (PAIR) asm volatile(G4CP6_ASM_TILE C4_TILE_OPERANDS : G4CP6_CLOBBERS);
+        if constexpr (PAIR && NI == 6) asm volatile(G4CP6_ASM_TILE C4_TILE_OPERANDS : G4CP6_CLOBBERS);
+        else if constexpr (PAIR) asm volatile(G4CP3_ASM_TILE C4_TILE_OPERANDS : G4CP3_CLOBBERS);
         else if constexpr (NI == 6) asm volatile(G4C6_ASM_TILE C4_TILE_OPERANDS : G4C6_CLOBBERS);
         else asm volatile(G4C3_ASM_TILE C4_TILE_OPERANDS : G4C3_CLOBBERS);
 #undef C4_TILE_OPERANDS
@@ -910,10 +912,10 @@ int ig_conv8(int kind, int sign, const void* x_hi, const void* x_lo, const void*
         const char* e4 = getenv("IG_GEMM4");
         const int g4 = e4 ? atoi(e4) : 1;
         bool ok4 = g4 && N % 96 == 0 && tent <= C4_TAB_MAX && a_bytes < 2147483648.0 - 16777216.0 && nt4 < (1L << 30);
-        if (w_lo) {  // the split mode: paired K-tiles on the 192-wide tile, hi and lo of the gathered tensor under ONE descriptor below 2 GiB
+        if (w_lo) {  // the split mode: paired K-tiles, hi and lo of the gathered tensor under ONE descriptor below 2 GiB
             const char* ep = getenv("IG_G8_PAIR");
             const long dA = (const char*)x_lo - (const char*)x_hi, dB = (long)(((size_t)elems * 2 + 255) / 256 * 256);
-            ok4 = ok4 && ni4 == 6 && (!ep || atoi(ep) != 0) && dA > 0 && !(dA & 15) && (double)dA + a_bytes < 2147483648.0 - 16777216.0 &&
+            ok4 = ok4 && (!ep || atoi(ep) != 0) && dA > 0 && !(dA & 15) && (double)dA + a_bytes < 2147483648.0 - 16777216.0 &&
                   dB + (1L << 24) < (1L << 32);
         }
         for (int ph = 0; ph < pl.nphase; ++ph) ok4 = ok4 && pl.kpad[ph] / 64 >= 4;
@@ -994,7 +996,8 @@ int ig_conv8(int kind, int sign, const void* x_hi, const void* x_lo, const void*
             if (!attr4_done) {
                 if (hipFuncSetAttribute((const void*)conv4_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
                     hipFuncSetAttribute((const void*)conv4_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-                    hipFuncSetAttribute((const void*)conv4_kernel<6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                    hipFuncSetAttribute((const void*)conv4_kernel<6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                    hipFuncSetAttribute((const void*)conv4_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                     ig_set_error("conv4: could not reserve 160 KiB of LDS");
                     return IG_ERR_HIP;
                 }
@@ -1003,7 +1006,8 @@ int ig_conv8(int kind, int sign, const void* x_hi, const void* x_lo, const void*
             const int grid4 = ig_tile_grid((int)nt4, 1);
             ig_note_kernel(w_lo ? "conv4_kernel<%d,true>" : "conv4_kernel<%d>", ni4);
             ig_note_grid(grid4);
-            if (w_lo) hipLaunchKernelGGL((conv4_kernel<6, true>), dim3(grid4), dim3(256), C4_OFF_TAB + (tent + 32) * 4, st, p);
+            if (w_lo && ni4 == 6) hipLaunchKernelGGL((conv4_kernel<6, true>), dim3(grid4), dim3(256), C4_OFF_TAB + (tent + 32) * 4, st, p);
+            else if (w_lo) hipLaunchKernelGGL((conv4_kernel<3, true>), dim3(grid4), dim3(256), C4_OFF_TAB + (tent + 32) * 4, st, p);
             else if (ni4 == 6) hipLaunchKernelGGL(conv4_kernel<6>, dim3(grid4), dim3(256), C4_OFF_TAB + (tent + 32) * 4, st, p);
             else hipLaunchKernelGGL(conv4_kernel<3>, dim3(grid4), dim3(256), C4_OFF_TAB + (tent + 32) * 4, st, p);
             return ig_check_launch("conv4");

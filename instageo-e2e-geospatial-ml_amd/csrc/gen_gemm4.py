@@ -1242,9 +1242,10 @@ def main():
             f.write(f"#define G4C{ni}_ASM_PROLOGUE \\\n" + gen_c_prologue(ni).replace("\n", " \\\n") + "\n\n")
             f.write(f"#define G4C{ni}_ASM_TILE \\\n" + gen_c_tile(ni, cfg).replace("\n", " \\\n") + "\n\n")
             f.write(f"#define G4C{ni}_CLOBBERS " + c_clobbers(ni) + "\n\n")
-        f.write("#define G4CP6_ASM_PROLOGUE \\\n" + gen_cp_prologue(6).replace("\n", " \\\n") + "\n\n")
-        f.write("#define G4CP6_ASM_TILE \\\n" + gen_cp_tile(6, cfg).replace("\n", " \\\n") + "\n\n")
-        f.write("#define G4CP6_CLOBBERS " + cp_clobbers(6) + "\n\n")
+        for ni in (6, 3):   # conv4_kernel<NI, true>
+            f.write(f"#define G4CP{ni}_ASM_PROLOGUE \\\n" + gen_cp_prologue(ni).replace("\n", " \\\n") + "\n\n")
+            f.write(f"#define G4CP{ni}_ASM_TILE \\\n" + gen_cp_tile(ni, cfg).replace("\n", " \\\n") + "\n\n")
+            f.write(f"#define G4CP{ni}_CLOBBERS " + cp_clobbers(ni) + "\n\n")
         f.write(gen_readout() + "\n")
 
 

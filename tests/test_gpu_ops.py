@@ -844,12 +844,10 @@ def test_conv4_equals_conv8_bit_for_bit(split, kind, B, H, Cin, Cout, monkeypatc
     """conv4_kernel (conv8.hip: the 4-wave 256 x 192 form with a generated K-loop, A pieces gathered with three vector instructions of address
     arithmetic each) against conv8_kernel on the same packed weights and chunk table: Conv2d forward (+ bias, + eval BatchNorm / ReLU fold),
     its data gradient (+ dropout mask), the ConvTranspose data gradient and forward (+ bias, + dropout), widths that tile by 192 (256 x 192
-    tiles) or by 96 (256 x 96), plain and -- 192-wide -- the paired split form.  Same MFMA instruction in the same K (and hi / lo product)
+    tiles) or by 96 (256 x 96), plain and the paired split form.  Same MFMA instruction in the same K (and hi / lo product)
     order, so the results must be IDENTICAL; the float64 comparison of conv8 itself is test_conv8_engine_*."""
     monkeypatch.setenv("IG_CONV8", "2")
     monkeypatch.setenv("IG_CONV_DIRECT", "0")
-    if split and (Cin % 192 or Cout % 192):
-        pytest.skip("the paired form has the 192-wide tile only")
     W = H + 3
     outs = {}
     for arm in ("0", "2"):
