@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void conv4_kernel(C8Params p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
-    const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM, tpb = tiles_n * p.nphase, ntiles = tiles_m * tpb;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM, tpb = tiles_n * p.nphase, ntiles = tiles_m * tpb;  // (a ragged last column tile: N = 144)
     // persistent, XCD-aware (as conv8_kernel): XCD x owns a contiguous tile range; the column tiles and phases of a row tile are neighbours
     const int nb = gridDim.x, xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
     const int nbx = (nb >> 3) + (xcd < (nb & 7) ? 1 : 0), nbx_nom = max(nb >> 3, 1);
@@ -564,8 +564,9 @@ __global__ __launch_bounds__(256) void conv4_kernel(C8Params p) {
     decode_rows(c_bm, ro, im);
     {
         const PhaseK k = phase_k(c_ph);
+        const int vrb = min(BN, p.N - c_bn * BN) - 1;
         const char* bptr = uni(k.b + (long)c_bn * BN * k.ldb2);
-#define C4_PRO_OPERANDS ::[abase] "s"(abase), [abytes] "s"(abytes), [bptr] "s"(bptr), [ldb2] "s"(k.ldb2), [ldsw] "s"(ldsw), \
+#define C4_PRO_OPERANDS ::[abase] "s"(abase), [abytes] "s"(abytes), [bptr] "s"(bptr), [ldb2] "s"(k.ldb2), [vrb] "s"(vrb), [ldsw] "s"(ldsw), \
                      [ldswb] "s"(ldswb), [nk] "s"(k.nk), [toff4] "s"(k.toff4), [a0] "s"(a0), [a1] "s"(a1), [a2] "s"(a2), [browv] "v"(browv), \
                      [c16] "v"(c16), [c16b] "v"(c16), [aloadd] "v"(aloadd), [fa] "v"(fa), [fb] "v"(fb), [vtl] "v"(vtl), [ro0] "v"(ro[0]), [ro1] "v"(ro[1]), [ro2] "v"(ro[2]), [ro3] "v"(ro[3]), \
                      [ro4] "v"(ro[4]), [ro5] "v"(ro[5]), [ro6] "v"(ro[6]), [ro7] "v"(ro[7]), [im0] "v"(im[0]), [im1] "v"(im[1]), [im2] "v"(im[2]), \
@@ -590,9 +591,10 @@ __global__ __launch_bounds__(256) void conv4_kernel(C8Params p) {
         const char* bptr = uni(k.b + (long)bn * BN * k.ldb2 + (PAIR ? 128 : 256));  // K-tile 2 (0 and 1 are in flight)
         const char* bnext = uni(kn.b + (long)c_bn * BN * kn.ldb2);
         const int npair = (k.nk >> 1) - 2;
+        const int vrb = min(BN, p.N - bn * BN) - 1, vrbn = min(BN, p.N - c_bn * BN) - 1;
 #define C4_TILE_OPERANDS \
                      : [a0] "+s"(a0), [a1] "+s"(a1), [a2] "+s"(a2) \
-                     : [abase] "s"(abase), [abytes] "s"(abytes), [bptr] "s"(bptr), [bnext] "s"(bnext), [ldb2] "s"(k.ldb2), [ldb2n] "s"(kn.ldb2), \
+                     : [abase] "s"(abase), [abytes] "s"(abytes), [bptr] "s"(bptr), [bnext] "s"(bnext), [ldb2] "s"(k.ldb2), [ldb2n] "s"(kn.ldb2), [vrb] "s"(vrb), [vrbn] "s"(vrbn), \
                        [ldsw] "s"(ldsw), [ldswb] "s"(ldswb), [nk] "s"(k.nk), [toff4] "s"(k.toff4), [toffn4] "s"(kn.toff4), [npair] "s"(npair), \
                        [browv] "v"(browv), [c16] "v"(c16), [c16b] "v"(c16), [aloadd] "v"(aloadd), [fa] "v"(fa), [fb] "v"(fb), [vtl] "v"(vtl), [ro0] "v"(ro[0]), [ro1] "v"(ro[1]), \
                        [ro2] "v"(ro[2]), [ro3] "v"(ro[3]), [ro4] "v"(ro[4]), [ro5] "v"(ro[5]), [ro6] "v"(ro[6]), [ro7] "v"(ro[7]), [im0] "v"(im[0]), \
@@ -624,7 +626,7 @@ __global__ __launch_bounds__(256) void conv4_kernel(C8Params p) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             bias4[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (p.bias) {
+            if (p.bias && n0 + ni * 16 + 4 * eq < p.N) {
                 const float4 b_ = *reinterpret_cast<const float4*>(p.bias + n0 + ni * 16 + 4 * eq);
                 bias4[ni] = f32x4{b_.x, b_.y, b_.z, b_.w};
             }
@@ -639,7 +641,7 @@ __global__ __launch_bounds__(256) void conv4_kernel(C8Params p) {
             for (int ni = 0; ni < NI; ++ni) {
                 const f32x4 a = tt[ni] + bias4[ni];
                 float v[4] = {a[0], a[1], a[2], a[3]};
-                if (p.scale) {  // eval-mode BatchNorm + ReLU (inference only)
+                if (p.scale && n0 + ni * 16 + 4 * eq < p.N) {  // eval-mode BatchNorm + ReLU (inference only)
                     const float4 s4 = *reinterpret_cast<const float4*>(p.scale + n0 + ni * 16 + 4 * eq);
                     const float4 t4 = *reinterpret_cast<const float4*>(p.shift + n0 + ni * 16 + 4 * eq);
                     v[0] = fmaxf(v[0] * s4.x + t4.x, 0.f), v[1] = fmaxf(v[1] * s4.y + t4.y, 0.f);
@@ -671,7 +673,7 @@ __global__ __launch_bounds__(256) void conv4_kernel(C8Params p) {
                     uint4 ul = ux;
                     if constexpr (PAIR) ul = *reinterpret_cast<const uint4*>(st + 16 * PITCH + r * PITCH + ch * 16);
                     const int m = m0 + r;
-                    if (m < p.M) {
+                    if (m < p.M && n0 + ch * 8 < p.N) {
                         const size_t o = (size_t)out_row(m) * p.ldo + n0 + ch * 8;
                         *reinterpret_cast<uint4*>(p.out_hi + o) = ux;
                         if constexpr (PAIR) *reinterpret_cast<uint4*>(p.out_lo + o) = ul;
@@ -906,12 +908,13 @@ int ig_conv8(int kind, int sign, const void* x_hi, const void* x_lo, const void*
     // 768 -> 384: 206 -> 194; ConvTranspose forward 768 -> 384: 367 -> 280 (conv8), 384 -> 192: 417 -> 376, 192 -> 96: 642 -> 578 (the round-1
     // engine); T = 3, B = 72, 256 x 96 tiles: Conv2d 288 forward 1887 -> 1345, data gradient 1920 -> 1517, ConvTranspose forward 576 -> 288: 1203 -> 854)
     bool use4 = false;
-    const int ni4 = N % 192 == 0 ? 6 : 3;  // 256 x 192 tiles, or 256 x 96 (N = 96: the 192 -> 96 ConvTranspose forward; 288 = 3 x 96)
-    const long nt4 = (M + 255) / 256 * (N / (32 * ni4)) * pl.nphase;
+    // 256 x 192 tiles, 256 x 96 (N = 96: the 192 -> 96 ConvTranspose forward; 288 = 3 x 96), or ONE ragged 192-wide tile (N = 144: T = 3's last stage)
+    const int ni4 = N % 192 == 0 ? 6 : N % 96 == 0 ? 3 : 6;
+    const long nt4 = (M + 255) / 256 * ((N + 32 * ni4 - 1) / (32 * ni4)) * pl.nphase;
     {
         const char* e4 = getenv("IG_GEMM4");
         const int g4 = e4 ? atoi(e4) : 1;
-        bool ok4 = g4 && N % 96 == 0 && tent <= C4_TAB_MAX && a_bytes < 2147483648.0 - 16777216.0 && nt4 < (1L << 30);
+        bool ok4 = g4 && (N % 96 == 0 || N == 144) && tent <= C4_TAB_MAX && a_bytes < 2147483648.0 - 16777216.0 && nt4 < (1L << 30);
         if (w_lo) {  // the split mode: paired K-tiles, hi and lo of the gathered tensor under ONE descriptor below 2 GiB
             const char* ep = getenv("IG_G8_PAIR");
             const long dA = (const char*)x_lo - (const char*)x_hi, dB = (long)(((size_t)elems * 2 + 255) / 256 * 256);

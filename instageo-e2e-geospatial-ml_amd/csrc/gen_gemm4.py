@@ -898,11 +898,13 @@ def c_iteration(st, ni, p, first, next_tile, cfg):
 
 
 def c_setup(st, ni, with_next):
-    for i in range(ni):
+    for i in range(ni):   # B rows past the tile's valid width (a ragged last column tile) re-read its last valid row: vrb = valid rows - 1
         st.e(f"v_add_u32 v{V_TMP}, {8 * i}, %[browv]")
-        st.e(f"v_mad_u32_u24 v{CV_OFFB + i}, v{V_TMP}, %[ldb2], %[c16]")
+        st.e(f"v_min_u32 v{V_TMP + 1}, %[vrb], v{V_TMP}")
+        st.e(f"v_mad_u32_u24 v{CV_OFFB + i}, v{V_TMP + 1}, %[ldb2], %[c16]")
         if with_next:
-            st.e(f"v_mad_u32_u24 v{CV_OFFB_N + i}, v{V_TMP}, %[ldb2n], %[c16]")
+            st.e(f"v_min_u32 v{V_TMP + 1}, %[vrbn], v{V_TMP}")
+            st.e(f"v_mad_u32_u24 v{CV_OFFB_N + i}, v{V_TMP + 1}, %[ldb2n], %[c16]")
     st.e(f"v_mov_b32 v{V_FA}, %[fa]")
     st.e(f"v_xor_b32 v{V_FA + 1}, 64, %[fa]")
     for b in (0, 1):
@@ -1092,9 +1094,11 @@ def cp_iteration(st, ni, p, first, next_tile, cfg):
 def cp_setup(st, ni, with_next):
     for i in range(ni):
         st.e(f"v_add_u32 v{CPV_TMP}, {8 * i}, %[browv]")
-        st.e(f"v_mad_u32_u24 v{CPV_OFFB + i}, v{CPV_TMP}, %[ldb2], %[c16b]")
+        st.e(f"v_min_u32 v{CPV_TMP + 1}, %[vrb], v{CPV_TMP}")
+        st.e(f"v_mad_u32_u24 v{CPV_OFFB + i}, v{CPV_TMP + 1}, %[ldb2], %[c16b]")
         if with_next:
-            st.e(f"v_mad_u32_u24 v{CPV_OFFB_N + i}, v{CPV_TMP}, %[ldb2n], %[c16b]")
+            st.e(f"v_min_u32 v{CPV_TMP + 1}, %[vrbn], v{CPV_TMP}")
+            st.e(f"v_mad_u32_u24 v{CPV_OFFB_N + i}, v{CPV_TMP + 1}, %[ldb2n], %[c16b]")
     st.e(f"v_mov_b32 v{CPV_FA}, %[fa]")
     st.e(f"v_xor_b32 v{CPV_FA + 1}, 64, %[fa]")
     for b in (0, 1):

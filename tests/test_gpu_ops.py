@@ -839,6 +839,7 @@ def test_conv8_engine_conv3x3(split, B, H, Cin, Cout, monkeypatch):
     ("conv", 1, 2, 384, 192), ("conv", 2, 28, 384, 384),
     ("convT", 3, 14, 768, 384), ("convT", 2, 9, 384, 192), ("convT", 1, 13, 192, 96), ("convT", 1, 6, 2304, 1152), ("convT", 1, 1, 384, 192), ("convT", 2, 28, 384, 192),
     ("conv", 2, 11, 96, 288), ("conv", 1, 14, 288, 288), ("conv", 1, 9, 96, 96), ("convT", 1, 13, 192, 96), ("convT", 1, 7, 576, 288),  # 256 x 96 tiles
+    ("conv", 1, 20, 144, 144), ("convT", 1, 7, 288, 144), ("conv", 2, 13, 288, 144),  # N = 144: one ragged 192-wide tile
 ])
 def test_conv4_equals_conv8_bit_for_bit(split, kind, B, H, Cin, Cout, monkeypatch):
     """conv4_kernel (conv8.hip: the 4-wave 256 x 192 form with a generated K-loop, A pieces gathered with three vector instructions of address
@@ -859,7 +860,7 @@ def test_conv4_equals_conv8_bit_for_bit(split, kind, B, H, Cin, Cout, monkeypatc
             w, _ = bt(rnd(Cout, Cin, 3, 3, seed=27, scale=(9 * Cin) ** -0.5).permute(0, 2, 3, 1).reshape(Cout, 9, Cin).contiguous(), split)
             bias = rnd(Cout, seed=28).to(DEV)
             y = BT.zeros((B, H, W, Cout), split, DEV)
-            if Cout % 96 == 0:
+            if Cout % 96 == 0 or Cout == 144:
                 ops.conv3x3_fwd(x, w, bias, y, B, H, W, Cin, Cout)
                 assert ops.last_kernel().startswith(want), ops.last_kernel()
                 got.append(y.hi.clone())
@@ -871,7 +872,7 @@ def test_conv4_equals_conv8_bit_for_bit(split, kind, B, H, Cin, Cout, monkeypatc
                 got.append(y.hi.clone())
                 if split:
                     got.append(y.lo.clone())
-            if Cin % 96 == 0:
+            if Cin % 96 == 0 or Cin == 144:
                 dy, _ = bt(nhwc(rnd(B, Cout, H, W, seed=29)), split)
                 dx = BT.zeros((B, H, W, Cin), split, DEV)
                 ops.conv3x3_dgrad(dy, w, dx, B, H, W, Cin, Cout)
@@ -893,7 +894,7 @@ def test_conv4_equals_conv8_bit_for_bit(split, kind, B, H, Cin, Cout, monkeypatc
             got.append(dx.hi.clone())
             if split:
                 got.append(dx.lo.clone())
-            if Cout % 96 == 0:  # forward: four sub-pixel phases (own tables, K lengths and row pitches) as tiles of one launch
+            if Cout % 96 == 0 or Cout == 144:  # forward: four sub-pixel phases (own tables, K lengths and row pitches) as tiles of one launch
                 x, _ = bt(nhwc(rnd(B, Cin, H, W, seed=30)), split)
                 bias = rnd(Cout, seed=32).to(DEV)
                 y = BT.zeros((B, 2 * H, 2 * W, Cout), split, DEV)
